@@ -1,0 +1,16 @@
+"""cu-sdr-collection_amd — MI355X-native acquisition + tracking hot path for the
+CU-SDR-Collection GNSS software receivers.
+
+Layout: csrc/ (HIP kernels + the C-ABI of include/gnsscorr.h), _lib.py (ctypes binding),
+engine.py (context wrapper), receiver.py (acquisition / preRun / tracking with the reference's
+names and struct fields), codes.py (code generators), settings.py (initSettings mirror),
+synth.py (synthetic IF records).  Nothing here imports `oracle/`; there is no CPU fallback.
+"""
+from . import _lib, codes, settings, synth  # noqa: F401
+from ._lib import GnssCorrError  # noqa: F401
+from .engine import Engine  # noqa: F401
+from .receiver import CNoVSM, acquisition, preRun, tracking  # noqa: F401
+from .settings import initSettings  # noqa: F401
+
+__all__ = ["Engine", "GnssCorrError", "acquisition", "preRun", "tracking", "CNoVSM", "initSettings",
+           "codes", "settings", "synth"]

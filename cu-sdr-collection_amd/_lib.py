@@ -1,0 +1,118 @@
+"""ctypes binding of libgnsscorr.so (include/gnsscorr.h).  There is no Python or CPU fallback:
+if the HIP library is missing or no MI355X is visible, calls raise GnssCorrError."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgnsscorr.so")
+
+GC_OK, GC_E_INVALID, GC_E_RANGE, GC_E_NOMEM, GC_E_HIP, GC_E_STATE, GC_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+GC_I8, GC_I16 = 0, 1
+GC_REAL, GC_IQ, GC_QI = 0, 1, 2
+GC_MAX_ARMS = 3
+GC_OUT_STRIDE = 6 * GC_MAX_ARMS
+GC_PLL_2ND_ORDER, GC_PLL_3_STATE = 0, 1
+
+TRK_FIELDS = ["absoluteSample", "codeFreq", "carrFreq", "I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L",
+              "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase",
+              "Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L"]
+GC_TRK_NFIELDS = len(TRK_FIELDS)
+
+
+class GnssCorrError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"gnsscorr status {status}: {message}")
+        self.status = status
+
+
+class gc_block(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("blksize", C.c_int32), ("first_sample", C.c_int64),
+                ("rem_code_phase", C.c_double), ("code_phase_step", C.c_double),
+                ("el_spacing", C.c_double), ("carr_freq", C.c_double), ("rem_carr_phase", C.c_double),
+                ("table_offset", C.c_int32 * GC_MAX_ARMS), ("reserved", C.c_int32)]
+
+
+class gc_track_params(C.Structure):
+    _fields_ = [("sampling_freq", C.c_double), ("code_freq_basis", C.c_double), ("code_length", C.c_double),
+                ("el_spacing", C.c_double), ("int_time", C.c_double),
+                ("dll_noise_bw", C.c_double), ("dll_damping", C.c_double),
+                ("pll_noise_bw", C.c_double), ("pll_damping", C.c_double),
+                ("pll_kind", C.c_int32), ("pilot_combine", C.c_int32),
+                ("pf1", C.c_double), ("pf2", C.c_double), ("pf3", C.c_double),
+                ("skip_samples", C.c_int64), ("n_epochs", C.c_int32), ("reserved", C.c_int32)]
+
+
+class gc_channel_init(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("prn", C.c_int32), ("acquired_freq", C.c_double),
+                ("code_freq", C.c_double), ("code_phase", C.c_int64)]
+
+
+class gc_acq_params(C.Structure):
+    _fields_ = [("sampling_freq", C.c_double), ("code_freq_basis", C.c_double), ("code_length", C.c_double),
+                ("intermediate_freq", C.c_double), ("search_band", C.c_double), ("search_step", C.c_double),
+                ("non_coh_time", C.c_int32), ("reserved", C.c_int32), ("first_sample", C.c_int64)]
+
+
+class gc_acq_result(C.Structure):
+    _fields_ = [("coarse_bin", C.c_int32), ("code_phase", C.c_int32), ("peak", C.c_double),
+                ("peak_metric", C.c_double), ("coarse_freq", C.c_double)]
+
+
+# every symbol include/gnsscorr.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "gc_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "gc_destroy": (C.c_int, [_P]),
+    "gc_last_error": (C.c_char_p, []),
+    "gc_api_version": (C.c_int, []),
+    "gc_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    "gc_synchronize": (C.c_int, [_P]),
+    "gc_load_if": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int]),
+    "gc_open_if_file": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
+    "gc_attach_if": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int]),
+    "gc_if_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "gc_alloc_if": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
+    "gc_read_if": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
+    "gc_set_channel": (C.c_int, [_P, C.c_int, C.c_int, C.c_double]),
+    "gc_set_code": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_double]),
+    "gc_set_code_window": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "gc_set_sampling_freq": (C.c_int, [_P, C.c_double]),
+    "gc_correlate": (C.c_int, [_P, C.c_int, C.POINTER(gc_block), C.POINTER(C.c_double)]),
+    "gc_replay_prepare": (C.c_int, [_P, C.c_int64, C.POINTER(gc_block)]),
+    "gc_replay_launch": (C.c_int, [_P]),
+    "gc_replay_fetch": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "gc_timer_start": (C.c_int, [_P]),
+    "gc_timer_stop": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "gc_track": (C.c_int, [_P, C.POINTER(gc_track_params), C.c_int, C.POINTER(gc_channel_init),
+                           C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "gc_acquire_coarse": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(gc_acq_result)]),
+    "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,
+                                       C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libgnsscorr.so (building is a separate, explicit step: cu_sdr_collection_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnssCorrError(GC_E_STATE, f"{LIB_PATH} not built — run `python -m cu_sdr_collection_amd.build` "
+                                        "(hipcc, gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != GC_OK:
+        msg = load().gc_last_error()
+        raise GnssCorrError(status, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,61 @@
+"""Builds the HIP shared libraries for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m cu_sdr_collection_amd.build        # or  __graft_entry__.build()
+
+Outputs (git-ignored, but shipped to the GPU box by gpurun):
+    cu-sdr-collection_amd/lib/libgnsscorr.so     the product: C-ABI of include/gnsscorr.h
+    cu-sdr-collection_amd/lib/libgnsssynth.so    test/bench utility: synthetic IF generator
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+
+LIBS = {
+    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "track.hip", "acq.hip"],
+    "libgnsssynth.so": ["synth.hip"],
+}
+HEADERS = ["gc_internal.h", os.path.join("..", "..", "include", "gnsscorr.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; a ROCm toolchain is required to build libgnsscorr.so")
+    return exe
+
+
+def _stale(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def build(force: bool = False, verbose: bool = True) -> None:
+    os.makedirs(LIBDIR, exist_ok=True)
+    for lib, srcs in LIBS.items():
+        src_paths = [os.path.join(CSRC, s) for s in srcs]
+        missing = [s for s in src_paths if not os.path.exists(s)]
+        if missing:
+            raise RuntimeError(f"missing sources for {lib}: {missing}")
+        target = os.path.join(LIBDIR, lib)
+        deps = src_paths + [os.path.join(CSRC, h) for h in HEADERS]
+        if not force and not _stale(target, deps):
+            continue
+        cmd = [_hipcc(), *FLAGS, *src_paths, "-o", target]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

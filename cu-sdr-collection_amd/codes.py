@@ -1,0 +1,65 @@
+"""Host-side spreading-code generators and replica tables that feed the device.
+
+Independent bit-level implementations (integer LFSRs) of what the reference computes with
++-1 product registers; outputs are int8 in {-1, 0, +1} ready for gc_set_code / gc_acquire_coarse.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# G2 code delays in chips for PRN 1..32 (IS-GPS-200 Table 3-Ia) followed by the SBAS delays the
+# reference also carries (generateCAcode.m:42-50).
+_CA_G2_DELAY = (5, 6, 7, 8, 17, 18, 139, 140, 141, 251, 252, 254, 255, 256, 257, 258, 469, 470,
+                471, 472, 473, 474, 509, 512, 513, 514, 515, 516, 859, 860, 861, 862,
+                145, 175, 52, 21, 237, 235, 886, 657, 634, 762, 355, 1012, 176, 603, 130, 359,
+                595, 68, 386)
+
+
+def _lfsr10(taps) -> np.ndarray:
+    """1023 output bits of a 10-stage Fibonacci LFSR, all-ones start, output = stage 10."""
+    reg = [1] * 10  # reg[0] = stage 1
+    out = np.empty(1023, dtype=np.uint8)
+    for i in range(1023):
+        out[i] = reg[9]
+        fb = 0
+        for t in taps:
+            fb ^= reg[t - 1]
+        reg = [fb] + reg[:9]
+    return out
+
+
+_G1 = _lfsr10((3, 10))
+_G2 = _lfsr10((2, 3, 6, 8, 9, 10))
+
+
+def generateCAcode(PRN: int) -> np.ndarray:
+    """GPS C/A code of `PRN` as int8 +-1, logic 1 -> +1 (same convention as
+    GPS/GPS_L1CA/include/generateCAcode.m:90)."""
+    if not 1 <= PRN <= len(_CA_G2_DELAY):
+        raise ValueError(f"PRN {PRN} out of range")
+    g2d = np.roll(_G2, _CA_G2_DELAY[PRN - 1])
+    logic = _G1 ^ g2d
+    return (2 * logic.astype(np.int8) - 1).astype(np.int8)
+
+
+def padded_table(code: np.ndarray) -> np.ndarray:
+    """[c(end) c c(1)] — the replica table of tracking.m:158."""
+    code = np.asarray(code, dtype=np.int8)
+    return np.concatenate([code[-1:], code, code[:1]])
+
+
+def samplesPerCode(settings) -> int:
+    x = settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength)
+    return int(math.floor(x + 0.5))  # MATLAB round() for positive x
+
+
+def makeCaTable(PRN: int, settings) -> np.ndarray:
+    """Sampled C/A code for acquisition (makeCaTable.m:43-67): index ceil(ts*(1:spc)/tc), last = 1023."""
+    spc = samplesPerCode(settings)
+    ts = 1.0 / settings.samplingFreq
+    tc = 1.0 / settings.codeFreqBasis
+    idx = np.ceil((ts * np.arange(1, spc + 1, dtype=np.float64)) / tc).astype(np.int64)
+    idx[-1] = 1023
+    return generateCAcode(PRN)[idx - 1]

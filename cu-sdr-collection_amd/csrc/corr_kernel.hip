@@ -1,0 +1,392 @@
+// corr_kernel.hip — Early/Prompt/Late integrate-and-dump correlator for gfx950 (MI355X).
+//
+// Replaces the vector expressions of GPS/GPS_L1CA/include/tracking.m:247-300 (and the R-scaled /
+// multi-arm variants GAL_E1C/include/tracking.m:236-303, GPS_L5C/include/tracking.m:255-326):
+//   T2  code-replica index ramps   tcode = a : step : b ; idx = ceil(tcode)+1      (:252-270)
+//   T3  carrier replica            exp(-1i*((carrFreq*2*pi)*(n/fs) + remCarrPhase)) (:280-287)
+//   T4  mix + six sums per arm                                                      (:291-300)
+//
+// Design (wave64, 256-thread workgroups, no MFMA — elementwise multiply + reduce):
+//   * raw int8/int16 IF samples are read straight from HBM as 16-byte vectors: one lane-chunk
+//     = 8 consecutive samples, chunk grid aligned to absolute sample index so every load is
+//     16-B aligned and fully coalesced (1 KiB per wave-instruction);
+//   * padded code tables staged once per workgroup in LDS as int8;
+//   * code phase is a 64-bit fixed-point fraction per lane (exact double-precision base per
+//     thread, 2^-64-chip increments), so chip-edge decisions match the float64 reference
+//     except within ~1e-13 chip of an edge;
+//   * carrier: per-block table delta^j = exp(-i*2*pi*j*f/fs), j = 0..7, held in SGPRs, an
+//     exact double-precision phase base per thread reduced to one turn before the float
+//     sincos, and a per-iteration rotation by delta^2048;
+//   * 6*ARMS float accumulators per lane, wavefront shuffle reduction, LDS cross-wave
+//     combine in double, one store per output.
+#include "gc_internal.h"
+
+namespace {
+
+constexpr int kWG = 256;
+constexpr int kSPL = 8;  // samples per lane-chunk
+
+enum Mode { I8_IQ = 0, I8_QI, I16_IQ, I16_QI, I8_REAL, I16_REAL };
+
+struct KArgs {
+  const uint8_t* if_base;
+  const gc_block* blocks;
+  const DevChannel* chans;
+  double* out;      // [nblocks][GC_OUT_STRIDE] when splits == 1
+  double* partial;  // [nblocks][splits][GC_OUT_STRIDE] when splits > 1
+  double fs;
+  int64_t nblocks;
+  int splits;
+  int xcd_swizzle;
+  int red_off;  // byte offset of the reduction scratch in dynamic LDS
+};
+
+// t = k0 - G / 2^64 ;  ceil(t + x) for x = xi + xf/2^64  is  k0 + xi + (xf > G)
+struct Fx {
+  int k0;
+  unsigned long long G;
+};
+
+__device__ __forceinline__ unsigned long long frac_to_u64(double g) {
+  // g in [0,1) -> floor(g * 2^64), exact for doubles with <= 64 fractional bits
+  const double gh = g * 4294967296.0;
+  const unsigned int hi = (unsigned int)gh;
+  const double gl = (gh - (double)hi) * 4294967296.0;
+  const unsigned int lo = (unsigned int)gl;
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ Fx to_fx(double t) {
+  const double kf = ceil(t);
+  Fx r;
+  r.k0 = (int)kf;
+  r.G = frac_to_u64(kf - t);
+  return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ void load_chunk(const uint8_t* __restrict__ base, long long q,
+                                           float (&a)[kSPL], float (&b)[kSPL]) {
+  if constexpr (MODE == I8_IQ || MODE == I8_QI) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + 16 * q);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < kSPL; ++j) {
+      const unsigned int word = w[j >> 1];
+      const int sh = (j & 1) * 16;
+      const float x0 = (float)(int)(signed char)(word >> sh);
+      const float x1 = (float)(int)(signed char)(word >> (sh + 8));
+      a[j] = (MODE == I8_IQ) ? x0 : x1;
+      b[j] = (MODE == I8_IQ) ? x1 : x0;
+    }
+  } else if constexpr (MODE == I16_IQ || MODE == I16_QI) {
+    const uint4 v0 = *reinterpret_cast<const uint4*>(base + 32 * q);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(base + 32 * q + 16);
+    const unsigned int w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < kSPL; ++j) {
+      const float x0 = (float)(int)(short)(w[j] & 0xffffu);
+      const float x1 = (float)(int)(short)(w[j] >> 16);
+      a[j] = (MODE == I16_IQ) ? x0 : x1;
+      b[j] = (MODE == I16_IQ) ? x1 : x0;
+    }
+  } else if constexpr (MODE == I8_REAL) {
+    const uint2 v = *reinterpret_cast<const uint2*>(base + 8 * q);
+    const unsigned int w[2] = {v.x, v.y};
+#pragma unroll
+    for (int j = 0; j < kSPL; ++j) {
+      a[j] = (float)(int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
+      b[j] = 0.0f;
+    }
+  } else {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + 16 * q);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < kSPL; ++j) {
+      a[j] = (float)(int)(short)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+      b[j] = 0.0f;
+    }
+  }
+}
+
+__device__ __forceinline__ float rl_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ unsigned int rl_u(unsigned int v, int lane) {
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+template <int ARMS, int MODE>
+__global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  // ---- which block / which split -------------------------------------------------------
+  long long wg = blockIdx.x;
+  if (p.xcd_swizzle) {
+    // Workgroup b is dispatched to XCD b % 8.  Give every XCD one contiguous range of the
+    // descriptor list so that neighbouring descriptors (the channels of one epoch, which read
+    // the same IF window) share an L2.
+    const long long total = gridDim.x;
+    const long long per = total >> 3;  // host guarantees total % 8 == 0 when swizzling
+    wg = (wg & 7) * per + (wg >> 3);
+  }
+  const long long lb = wg / p.splits;
+  const int split = (int)(wg - lb * p.splits);
+  const gc_block blk = p.blocks[lb];
+  const DevChannel* __restrict__ chn = p.chans + blk.channel;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+
+  // ---- stage the code tables into LDS --------------------------------------------------
+  int lds_off[ARMS];
+  int nent[ARMS];
+  const int arms_here = chn->arms;
+#pragma unroll
+  for (int a = 0; a < ARMS; ++a) {
+    const int aa = (a < arms_here) ? a : 0;  // absent arms alias arm 0; their outputs are zeroed
+    lds_off[a] = chn->lds_off[aa];
+    const int off = blk.table_offset[aa];
+    nent[a] = min(chn->stage_len[aa], chn->nent[aa] - off);
+    if (a < arms_here) {
+      const int8_t* __restrict__ src = chn->tab[a] + off;
+      for (int i = tid; i < nent[a] + 8; i += kWG)
+        smem[lds_off[a] + i] = (i < nent[a]) ? (unsigned char)src[i] : 0;
+    }
+  }
+  float* red = reinterpret_cast<float*>(smem + p.red_off);
+  __syncthreads();
+
+  // ---- per-block uniform quantities ----------------------------------------------------
+  const double R = chn->index_scale;
+  const double M = chn->mult[0];
+  const double rem = blk.rem_code_phase;
+  const double step = blk.code_phase_step;
+  const double d = blk.el_spacing;
+  const int N = blk.blksize;
+  const long long s0 = blk.first_sample;
+  // colon() arguments exactly as the reference writes them (tracking.m:252-268;
+  // GAL_E1C tracking.m:236-262 for R = 2); x*1.0 is exact so R = 1 needs no special case.
+  const double aE = (rem - d) * R;
+  const double aL = (rem + d) * R;
+  const double aP = rem * R;
+  const double sp = step * R;
+  const double tau = blk.carr_freq / p.fs;  // carrier turns per sample
+
+  // lanes 0..7: delta^j and the fixed-point ramp increments j*sp*M; lane 8: chunk-stride terms
+  float myC, myS;
+  unsigned int myJlo, myJhi;
+  int myJint;
+  {
+    const int j = (lane < 8) ? lane : kSPL * kWG;
+    const double x = (double)j * tau;
+    const double fr = x - floor(x);
+    double sn, cs;
+    sincospi(2.0 * fr, &sn, &cs);
+    myC = (float)cs;
+    myS = (float)sn;
+    const double y = (double)j * (sp * M);
+    const double yi = floor(y);
+    const unsigned long long jf = frac_to_u64(y - yi);
+    myJint = (int)yi;
+    myJlo = (unsigned int)jf;
+    myJhi = (unsigned int)(jf >> 32);
+  }
+  float C[kSPL], S[kSPL];
+  unsigned long long Jf[kSPL];
+  int Ji[kSPL];
+#pragma unroll
+  for (int j = 0; j < kSPL; ++j) {
+    C[j] = rl_f(myC, j);
+    S[j] = rl_f(myS, j);
+    Jf[j] = ((unsigned long long)rl_u(myJhi, j) << 32) | rl_u(myJlo, j);
+    Ji[j] = __builtin_amdgcn_readlane(myJint, j);
+  }
+  const float rotC = rl_f(myC, 8), rotS = rl_f(myS, 8);
+  const unsigned long long Df = ((unsigned long long)rl_u(myJhi, 8) << 32) | rl_u(myJlo, 8);
+  const int Di = __builtin_amdgcn_readlane(myJint, 8);
+
+  // ---- chunk range of this split -------------------------------------------------------
+  const long long q0 = s0 >> 3;
+  const long long q1 = (s0 + N - 1) >> 3;
+  const int nchunks = (int)(q1 - q0 + 1);
+  const int cps = (nchunks + p.splits - 1) / p.splits;
+  const int cbeg = split * cps;
+  const int cend = min(nchunks, cbeg + cps);
+
+  float accr[ARMS][3], acci[ARMS][3];
+#pragma unroll
+  for (int a = 0; a < ARMS; ++a)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) accr[a][x] = acci[a][x] = 0.0f;
+
+  int c = cbeg + tid;
+  if (c < cend) {
+    int i0 = (int)((q0 + c) * kSPL - s0);  // block-relative index of the chunk's first sample
+    // exact double-precision bases (the reference's a + k*d, then *M for the BOC(6,1) arm)
+    Fx fx[3];
+    const double isp = __dmul_rn((double)i0, sp);
+    fx[0] = to_fx(__dmul_rn(__dadd_rn(aE, isp), M));
+    fx[1] = to_fx(__dmul_rn(__dadd_rn(aP, isp), M));
+    fx[2] = to_fx(__dmul_rn(__dadd_rn(aL, isp), M));
+    float wc, ws;
+    {
+      const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i0 * tau;
+      const float f = (float)(ph - floor(ph));
+      sincospif(2.0f * f, &ws, &wc);
+    }
+    const uint8_t* __restrict__ base = p.if_base;
+
+    for (; c < cend; c += kWG) {
+      float a[kSPL], b[kSPL];
+      load_chunk<MODE>(base, q0 + c, a, b);
+      const bool edge = (i0 < 0) | (i0 + kSPL > N);
+      float sr[ARMS][3], si[ARMS][3];
+#pragma unroll
+      for (int ar = 0; ar < ARMS; ++ar)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) sr[ar][x] = si[ar][x] = 0.0f;
+
+#pragma unroll
+      for (int j = 0; j < kSPL; ++j) {
+        float yr = a[j] * C[j] + b[j] * S[j];
+        float yi = b[j] * C[j] - a[j] * S[j];
+        if (edge) {
+          const bool valid = (unsigned int)(i0 + j) < (unsigned int)N;
+          yr = valid ? yr : 0.0f;
+          yi = valid ? yi : 0.0f;
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          int k = fx[x].k0 + Ji[j] + (Jf[j] > fx[x].G ? 1 : 0);
+#pragma unroll
+          for (int ar = 0; ar < ARMS; ++ar) {
+            int kk = k;
+            if (edge) kk = max(0, min(kk, nent[ar] - 1));
+            const float cf = (float)(int)(signed char)smem[lds_off[ar] + kk];
+            sr[ar][x] = fmaf(cf, yr, sr[ar][x]);
+            si[ar][x] = fmaf(cf, yi, si[ar][x]);
+          }
+        }
+      }
+      // rotate the chunk sums from the lane frame by w = exp(-i*theta0) and accumulate
+#pragma unroll
+      for (int ar = 0; ar < ARMS; ++ar)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          accr[ar][x] += wc * sr[ar][x] + ws * si[ar][x];
+          acci[ar][x] += wc * si[ar][x] - ws * sr[ar][x];
+        }
+      // advance this thread by kWG chunks
+      const float nwc = wc * rotC - ws * rotS;
+      const float nws = wc * rotS + ws * rotC;
+      wc = nwc;
+      ws = nws;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const unsigned long long g = fx[x].G;
+        fx[x].k0 += Di + (g < Df ? 1 : 0);
+        fx[x].G = g - Df;
+      }
+      i0 += kSPL * kWG;
+    }
+  }
+
+  // ---- reduce: wavefront shuffles, then LDS across the 4 waves in double ----------------
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int ar = 0; ar < ARMS; ++ar)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      float vr = accr[ar][x], vi = acci[ar][x];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        vr += __shfl_down(vr, off, 64);
+        vi += __shfl_down(vi, off, 64);
+      }
+      if (lane == 0) {
+        red[(wave * ARMS + ar) * 6 + 2 * x] = vr;
+        red[(wave * ARMS + ar) * 6 + 2 * x + 1] = vi;
+      }
+    }
+  __syncthreads();
+  if (tid < ARMS * 6) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWG / 64; ++w) s += (double)red[w * ARMS * 6 + tid];
+    if (tid >= arms_here * 6) s = 0.0;
+    if (p.splits == 1)
+      p.out[lb * GC_OUT_STRIDE + tid] = s;
+    else
+      p.partial[(lb * p.splits + split) * GC_OUT_STRIDE + tid] = s;
+  }
+}
+
+__global__ void combine_partials_kernel(const double* __restrict__ partial, double* __restrict__ out,
+                                        long long nblocks, int splits) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblocks * GC_OUT_STRIDE) return;
+  const long long lb = i / GC_OUT_STRIDE;
+  const int v = (int)(i - lb * GC_OUT_STRIDE);
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += partial[(lb * splits + k) * GC_OUT_STRIDE + v];
+  out[i] = s;
+}
+
+template <int ARMS>
+int launch_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
+  int mode;
+  if (ctx->if_dtype == GC_I8)
+    mode = ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
+  else
+    mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
+  switch (mode) {
+    case I8_IQ: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I8_IQ>), grid, dim3(kWG), smem, ctx->stream, a); break;
+    case I8_QI: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I8_QI>), grid, dim3(kWG), smem, ctx->stream, a); break;
+    case I16_IQ: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I16_IQ>), grid, dim3(kWG), smem, ctx->stream, a); break;
+    case I16_QI: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I16_QI>), grid, dim3(kWG), smem, ctx->stream, a); break;
+    case I8_REAL: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I8_REAL>), grid, dim3(kWG), smem, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I16_REAL>), grid, dim3(kWG), smem, ctx->stream, a); break;
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+}  // namespace
+
+int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
+                         double* d_out, double* d_partial, int max_arms) {
+  if (nblocks <= 0) return GC_OK;
+  KArgs a;
+  a.if_base = ctx->d_if;
+  a.blocks = d_blocks;
+  a.chans = ctx->d_channels;
+  a.out = d_out;
+  a.partial = d_partial;
+  a.fs = ctx->fs;
+  a.nblocks = nblocks;
+  a.splits = splits;
+  a.red_off = ctx->max_lds_bytes;
+  const long long total = (long long)nblocks * splits;
+  a.xcd_swizzle = (total % 8 == 0 && total >= 64) ? 1 : 0;
+  if (total > 0x7fffffffLL) {
+    gc_set_error("too many workgroups (%lld)", total);
+    return GC_E_INVALID;
+  }
+  const size_t smem = (size_t)ctx->max_lds_bytes + kWG / 64 * GC_OUT_STRIDE * sizeof(float);
+  dim3 grid((unsigned int)total);
+  int rc;
+  switch (max_arms) {
+    case 1: rc = launch_mode<1>(ctx, a, grid, smem); break;
+    case 2: rc = launch_mode<2>(ctx, a, grid, smem); break;
+    default: rc = launch_mode<3>(ctx, a, grid, smem); break;
+  }
+  if (rc != GC_OK) return rc;
+  if (splits > 1 && d_out != nullptr) {
+    const long long n = nblocks * GC_OUT_STRIDE;
+    hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_partial, d_out, (long long)nblocks, splits);
+    GC_HIP(hipGetLastError());
+  }
+  return GC_OK;
+}

@@ -1,0 +1,97 @@
+// Internal declarations shared by the translation units of libgnsscorr.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gnsscorr.h"
+
+#define GC_MAX_CHANNELS 256
+
+void gc_set_error(const char* fmt, ...);
+
+#define GC_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      gc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GC_E_HIP;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+// Device-side view of one tracking channel (gc_set_channel / gc_set_code).
+struct DevChannel {
+  const int8_t* tab[GC_MAX_ARMS];  // padded tables in HBM
+  int32_t nent[GC_MAX_ARMS];       // entries per table
+  double mult[GC_MAX_ARMS];        // per-arm ramp multiplier (1 or 6)
+  double index_scale;              // R
+  int32_t arms;
+  int32_t stage_len[GC_MAX_ARMS];  // entries staged into LDS per arm (window or whole table)
+  int32_t lds_off[GC_MAX_ARMS];    // byte offset of each staged table in LDS
+  int32_t lds_bytes;               // total staged bytes (16-B aligned)
+};
+
+struct HostChannel {
+  bool configured = false;
+  int arms = 0;
+  double index_scale = 1.0;
+  int8_t* d_tab[GC_MAX_ARMS] = {nullptr, nullptr, nullptr};
+  int nent[GC_MAX_ARMS] = {0, 0, 0};
+  double mult[GC_MAX_ARMS] = {1.0, 1.0, 1.0};
+  int window[GC_MAX_ARMS] = {0, 0, 0};  // 0 = stage the whole table
+};
+
+struct gc_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  int compute_units = 0;
+  char device_name[128] = {0};
+
+  // IF buffer
+  uint8_t* d_if = nullptr;
+  bool if_owned = false;
+  uint64_t if_nsamples = 0;
+  uint64_t if_capacity_bytes = 0;  // bytes the kernels may read (>= payload)
+  int if_dtype = GC_I8;
+  int if_layout = GC_IQ;
+  double fs = 0.0;
+
+  // channels
+  HostChannel ch[GC_MAX_CHANNELS];
+  DevChannel* d_channels = nullptr;  // GC_MAX_CHANNELS entries
+  bool channels_dirty = true;
+  int max_lds_bytes = 0;
+
+  // scratch for gc_correlate / gc_track
+  gc_block* d_blocks = nullptr;
+  int64_t d_blocks_cap = 0;
+  double* d_out = nullptr;
+  int64_t d_out_cap = 0;  // doubles
+  double* d_partial = nullptr;
+  int64_t d_partial_cap = 0;
+  gc_block* h_blocks_pinned = nullptr;  // host-mapped, for the closed loop
+  double* h_out_pinned = nullptr;
+  int pinned_cap_blocks = 0;
+
+  // replay
+  gc_block* d_replay_blocks = nullptr;
+  double* d_replay_out = nullptr;
+  int64_t replay_nblocks = 0;
+  int replay_max_arms = 1;
+
+  // acquisition scratch (acq.hip)
+  void* acq_scratch = nullptr;
+  size_t acq_scratch_bytes = 0;
+};
+
+int gc_bytes_per_sample(int dtype, int layout);
+int gc_sync_channels(gc_context* ctx);
+// Launches the correlator for `nblocks` descriptors already on the device.
+int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
+                         double* d_out, double* d_partial, int max_arms);

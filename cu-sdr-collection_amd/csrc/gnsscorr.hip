@@ -1,0 +1,563 @@
+// gnsscorr.hip — context, IF buffer, code tables, correlate / replay entry points of the
+// C-ABI declared in include/gnsscorr.h.  gfx950 only; there is no CPU fallback in this
+// library: every compute entry point launches HIP kernels.
+#include <algorithm>
+#include <cmath>
+
+#include "gc_internal.h"
+
+static thread_local std::string g_last_error;
+
+void gc_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int gc_bytes_per_sample(int dtype, int layout) {
+  const int comp = (layout == GC_REAL) ? 1 : 2;
+  return comp * (dtype == GC_I16 ? 2 : 1);
+}
+
+extern "C" {
+
+const char* gc_last_error(void) { return g_last_error.c_str(); }
+int gc_api_version(void) { return GC_API_VERSION; }
+
+int gc_create(gc_context** out, int device_id) {
+  if (!out) {
+    gc_set_error("gc_create: null output pointer");
+    return GC_E_INVALID;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  GC_HIP(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) {
+    gc_set_error("gc_create: device %d not available (%d devices visible)", device_id, ndev);
+    return GC_E_HIP;
+  }
+  GC_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  GC_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    gc_set_error("gc_create: device %d is %s; this library is built for gfx950 (MI355X) only",
+                 device_id, prop.gcnArchName);
+    return GC_E_UNSUPPORTED;
+  }
+  gc_context* ctx = new (std::nothrow) gc_context();
+  if (!ctx) return GC_E_NOMEM;
+  ctx->device = device_id;
+  ctx->compute_units = prop.multiProcessorCount;
+  std::snprintf(ctx->device_name, sizeof ctx->device_name, "%s", prop.name);
+  GC_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  GC_HIP(hipEventCreate(&ctx->ev_start));
+  GC_HIP(hipEventCreate(&ctx->ev_stop));
+  GC_HIP(hipMalloc(&ctx->d_channels, sizeof(DevChannel) * GC_MAX_CHANNELS));
+  GC_HIP(hipMemset(ctx->d_channels, 0, sizeof(DevChannel) * GC_MAX_CHANNELS));
+  *out = ctx;
+  return GC_OK;
+}
+
+static void free_if(gc_context* ctx) {
+  if (ctx->d_if && ctx->if_owned) (void)hipFree(ctx->d_if);
+  ctx->d_if = nullptr;
+  ctx->if_owned = false;
+  ctx->if_nsamples = 0;
+  ctx->if_capacity_bytes = 0;
+}
+
+int gc_destroy(gc_context* ctx) {
+  if (!ctx) return GC_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_if(ctx);
+  for (auto& c : ctx->ch)
+    for (auto& t : c.d_tab)
+      if (t) (void)hipFree(t);
+  if (ctx->d_channels) (void)hipFree(ctx->d_channels);
+  if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
+  if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->h_blocks_pinned) (void)hipHostFree(ctx->h_blocks_pinned);
+  if (ctx->h_out_pinned) (void)hipHostFree(ctx->h_out_pinned);
+  if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
+  if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
+  if (ctx->acq_scratch) (void)hipFree(ctx->acq_scratch);
+  (void)hipEventDestroy(ctx->ev_start);
+  (void)hipEventDestroy(ctx->ev_stop);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return GC_OK;
+}
+
+int gc_device_info(gc_context* ctx, char* name, int name_len, int* compute_units) {
+  if (!ctx) return GC_E_INVALID;
+  if (name && name_len > 0) std::snprintf(name, (size_t)name_len, "%s", ctx->device_name);
+  if (compute_units) *compute_units = ctx->compute_units;
+  return GC_OK;
+}
+
+int gc_synchronize(gc_context* ctx) {
+  if (!ctx) return GC_E_INVALID;
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  return GC_OK;
+}
+
+int gc_set_sampling_freq(gc_context* ctx, double fs) {
+  if (!ctx || !(fs > 0)) {
+    gc_set_error("gc_set_sampling_freq: fs must be positive");
+    return GC_E_INVALID;
+  }
+  ctx->fs = fs;
+  return GC_OK;
+}
+
+// ---- IF buffer ---------------------------------------------------------------------------
+
+static int check_fmt(int dtype, int layout) {
+  if ((dtype != GC_I8 && dtype != GC_I16) || (layout != GC_REAL && layout != GC_IQ && layout != GC_QI)) {
+    gc_set_error("unknown dtype/layout (%d/%d)", dtype, layout);
+    return GC_E_INVALID;
+  }
+  return GC_OK;
+}
+
+int gc_alloc_if(gc_context* ctx, uint64_t nsamples, int dtype, int layout) {
+  if (!ctx || nsamples == 0) {
+    gc_set_error("gc_alloc_if: bad arguments");
+    return GC_E_INVALID;
+  }
+  int rc = check_fmt(dtype, layout);
+  if (rc) return rc;
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  free_if(ctx);
+  const uint64_t bytes = nsamples * (uint64_t)gc_bytes_per_sample(dtype, layout);
+  const uint64_t cap = ((bytes + 63) / 64) * 64 + 64;  // kernels read whole 32-B chunks
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cap);
+  if (e != hipSuccess) {
+    gc_set_error("gc_alloc_if: hipMalloc(%llu) failed: %s", (unsigned long long)cap, hipGetErrorString(e));
+    return GC_E_NOMEM;
+  }
+  GC_HIP(hipMemsetAsync((uint8_t*)p + (cap - 128), 0, 128, ctx->stream));
+  ctx->d_if = (uint8_t*)p;
+  ctx->if_owned = true;
+  ctx->if_nsamples = nsamples;
+  ctx->if_capacity_bytes = cap;
+  ctx->if_dtype = dtype;
+  ctx->if_layout = layout;
+  return GC_OK;
+}
+
+int gc_load_if(gc_context* ctx, const void* samples, uint64_t nsamples, int dtype, int layout) {
+  if (!ctx || !samples) {
+    gc_set_error("gc_load_if: null argument");
+    return GC_E_INVALID;
+  }
+  int rc = gc_alloc_if(ctx, nsamples, dtype, layout);
+  if (rc) return rc;
+  const uint64_t bytes = nsamples * (uint64_t)gc_bytes_per_sample(dtype, layout);
+  GC_HIP(hipMemcpyAsync(ctx->d_if, samples, bytes, hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  return GC_OK;
+}
+
+int gc_open_if_file(gc_context* ctx, const char* path, uint64_t skip_bytes, uint64_t nsamples,
+                    int dtype, int layout) {
+  if (!ctx || !path) return GC_E_INVALID;
+  int rc = check_fmt(dtype, layout);
+  if (rc) return rc;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) {
+    gc_set_error("Unable to read file %s", path);  // postProcessing.m:157
+    return GC_E_INVALID;
+  }
+  const uint64_t bps = (uint64_t)gc_bytes_per_sample(dtype, layout);
+  std::fseek(f, 0, SEEK_END);
+  const uint64_t fsize = (uint64_t)std::ftell(f);
+  if (skip_bytes >= fsize) {
+    std::fclose(f);
+    gc_set_error("gc_open_if_file: skip (%llu) beyond end of file", (unsigned long long)skip_bytes);
+    return GC_E_RANGE;
+  }
+  uint64_t avail = (fsize - skip_bytes) / bps;
+  if (nsamples == 0 || nsamples > avail) nsamples = avail;
+  rc = gc_alloc_if(ctx, nsamples, dtype, layout);
+  if (rc) {
+    std::fclose(f);
+    return rc;
+  }
+  std::fseek(f, (long)skip_bytes, SEEK_SET);
+  // stream through a pinned staging buffer (two halves, copy overlaps the next read)
+  const size_t chunk = 64u << 20;
+  uint8_t* stage = nullptr;
+  if (hipHostMalloc((void**)&stage, 2 * chunk, hipHostMallocDefault) != hipSuccess) {
+    std::fclose(f);
+    gc_set_error("gc_open_if_file: pinned staging allocation failed");
+    return GC_E_NOMEM;
+  }
+  hipEvent_t ev[2];
+  (void)hipEventCreate(&ev[0]);
+  (void)hipEventCreate(&ev[1]);
+  uint64_t done = 0;
+  const uint64_t total = nsamples * bps;
+  int half = 0;
+  bool used[2] = {false, false};
+  int status = GC_OK;
+  while (done < total) {
+    const size_t n = (size_t)std::min<uint64_t>(chunk, total - done);
+    if (used[half]) (void)hipEventSynchronize(ev[half]);
+    if (std::fread(stage + half * chunk, 1, n, f) != n) {
+      gc_set_error("gc_open_if_file: short read");
+      status = GC_E_RANGE;
+      break;
+    }
+    if (hipMemcpyAsync(ctx->d_if + done, stage + half * chunk, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+      gc_set_error("gc_open_if_file: H2D copy failed");
+      status = GC_E_HIP;
+      break;
+    }
+    (void)hipEventRecord(ev[half], ctx->stream);
+    used[half] = true;
+    done += n;
+    half ^= 1;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  (void)hipHostFree(stage);
+  std::fclose(f);
+  return status;
+}
+
+int gc_attach_if(gc_context* ctx, void* device_ptr, uint64_t nsamples, int dtype, int layout) {
+  if (!ctx || !device_ptr || nsamples == 0) return GC_E_INVALID;
+  int rc = check_fmt(dtype, layout);
+  if (rc) return rc;
+  if (((uintptr_t)device_ptr & 31) != 0) {
+    gc_set_error("gc_attach_if: device pointer must be 32-byte aligned");
+    return GC_E_INVALID;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  free_if(ctx);
+  const uint64_t bytes = nsamples * (uint64_t)gc_bytes_per_sample(dtype, layout);
+  ctx->d_if = (uint8_t*)device_ptr;
+  ctx->if_owned = false;
+  ctx->if_nsamples = nsamples;
+  ctx->if_capacity_bytes = ((bytes + 31) / 32) * 32;  // the allocation must be readable up to here
+  ctx->if_dtype = dtype;
+  ctx->if_layout = layout;
+  return GC_OK;
+}
+
+int gc_if_buffer(gc_context* ctx, void** device_ptr, uint64_t* nsamples) {
+  if (!ctx) return GC_E_INVALID;
+  if (device_ptr) *device_ptr = ctx->d_if;
+  if (nsamples) *nsamples = ctx->if_nsamples;
+  return GC_OK;
+}
+
+int gc_read_if(gc_context* ctx, uint64_t first, uint64_t n, void* dst) {
+  if (!ctx || !dst) return GC_E_INVALID;
+  if (!ctx->d_if) {
+    gc_set_error("gc_read_if: no IF buffer loaded");
+    return GC_E_STATE;
+  }
+  if (first + n > ctx->if_nsamples) {
+    gc_set_error("gc_read_if: range beyond IF buffer");
+    return GC_E_RANGE;
+  }
+  const uint64_t bps = (uint64_t)gc_bytes_per_sample(ctx->if_dtype, ctx->if_layout);
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipMemcpyAsync(dst, ctx->d_if + first * bps, n * bps, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  return GC_OK;
+}
+
+// ---- code tables -------------------------------------------------------------------------
+
+int gc_set_channel(gc_context* ctx, int channel, int arms, double index_scale) {
+  if (!ctx || channel < 0 || channel >= GC_MAX_CHANNELS || arms < 1 || arms > GC_MAX_ARMS ||
+      !(index_scale >= 1.0)) {
+    gc_set_error("gc_set_channel: bad arguments (channel %d, arms %d, R %g)", channel, arms, index_scale);
+    return GC_E_INVALID;
+  }
+  HostChannel& c = ctx->ch[channel];
+  c.configured = true;
+  c.arms = arms;
+  c.index_scale = index_scale;
+  ctx->channels_dirty = true;
+  return GC_OK;
+}
+
+int gc_set_code(gc_context* ctx, int channel, int arm, const int8_t* table, int n_entries,
+                double arm_mult) {
+  if (!ctx || channel < 0 || channel >= GC_MAX_CHANNELS || !table || n_entries < 3 ||
+      !(arm_mult >= 1.0)) {
+    gc_set_error("gc_set_code: bad arguments");
+    return GC_E_INVALID;
+  }
+  HostChannel& c = ctx->ch[channel];
+  if (!c.configured || arm < 0 || arm >= c.arms) {
+    gc_set_error("gc_set_code: channel %d not configured for arm %d", channel, arm);
+    return GC_E_STATE;
+  }
+  for (int i = 0; i < n_entries; ++i)
+    if (table[i] < -1 || table[i] > 1) {
+      gc_set_error("gc_set_code: table values must be in {-1,0,+1}");
+      return GC_E_INVALID;
+    }
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  if (c.d_tab[arm]) (void)hipFree(c.d_tab[arm]);
+  c.d_tab[arm] = nullptr;
+  GC_HIP(hipMalloc((void**)&c.d_tab[arm], (size_t)n_entries + 64));
+  GC_HIP(hipMemset(c.d_tab[arm], 0, (size_t)n_entries + 64));
+  GC_HIP(hipMemcpy(c.d_tab[arm], table, (size_t)n_entries, hipMemcpyHostToDevice));
+  c.nent[arm] = n_entries;
+  c.mult[arm] = arm_mult;
+  ctx->channels_dirty = true;
+  return GC_OK;
+}
+
+// Optional: restrict LDS staging of arm `arm` to `window_entries` entries starting at the
+// block's table_offset (GPS L2C CL code, 1 534 502-entry table, GPS_L2C tracking.m:261).
+int gc_set_code_window(gc_context* ctx, int channel, int arm, int window_entries) {
+  if (!ctx || channel < 0 || channel >= GC_MAX_CHANNELS || arm < 0 || arm >= GC_MAX_ARMS ||
+      window_entries < 0)
+    return GC_E_INVALID;
+  ctx->ch[channel].window[arm] = window_entries;
+  ctx->channels_dirty = true;
+  return GC_OK;
+}
+
+}  // extern "C"
+
+int gc_sync_channels(gc_context* ctx) {
+  if (!ctx->channels_dirty) return GC_OK;
+  std::vector<DevChannel> dev(GC_MAX_CHANNELS);
+  std::memset(dev.data(), 0, sizeof(DevChannel) * GC_MAX_CHANNELS);
+  int max_lds = 0;
+  for (int i = 0; i < GC_MAX_CHANNELS; ++i) {
+    const HostChannel& c = ctx->ch[i];
+    if (!c.configured) continue;
+    DevChannel& d = dev[i];
+    d.arms = c.arms;
+    d.index_scale = c.index_scale;
+    int off = 0;
+    for (int a = 0; a < c.arms; ++a) {
+      if (!c.d_tab[a]) continue;  // checked per launch
+      d.tab[a] = c.d_tab[a];
+      d.nent[a] = c.nent[a];
+      d.mult[a] = c.mult[a];
+      d.stage_len[a] = (c.window[a] > 0) ? std::min(c.window[a], c.nent[a]) : c.nent[a];
+      d.lds_off[a] = off;
+      off += ((d.stage_len[a] + 8 + 15) / 16) * 16;
+    }
+    d.lds_bytes = off;
+    max_lds = std::max(max_lds, off);
+  }
+  if (max_lds > 150 * 1024) {
+    gc_set_error("code tables need %d bytes of LDS (> 150 KiB); set a window with gc_set_code_window", max_lds);
+    return GC_E_UNSUPPORTED;
+  }
+  GC_HIP(hipMemcpyAsync(ctx->d_channels, dev.data(), sizeof(DevChannel) * GC_MAX_CHANNELS,
+                        hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->max_lds_bytes = max_lds;
+  ctx->channels_dirty = false;
+  return GC_OK;
+}
+
+// Validates descriptors on the host; returns the largest arm count among the referenced
+// channels, or a negative status.
+static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b) {
+  if (!ctx->d_if) {
+    gc_set_error("no IF buffer loaded");
+    return GC_E_STATE;
+  }
+  if (!(ctx->fs > 0)) {
+    gc_set_error("sampling frequency not set (gc_set_sampling_freq)");
+    return GC_E_STATE;
+  }
+  int max_arms = 1;
+  for (int64_t i = 0; i < n; ++i) {
+    const gc_block& k = b[i];
+    if (k.channel < 0 || k.channel >= GC_MAX_CHANNELS || !ctx->ch[k.channel].configured) {
+      gc_set_error("block %lld: channel %d not configured", (long long)i, k.channel);
+      return GC_E_STATE;
+    }
+    const HostChannel& c = ctx->ch[k.channel];
+    for (int a = 0; a < c.arms; ++a) {
+      if (!c.d_tab[a]) {
+        gc_set_error("block %lld: channel %d arm %d has no code table", (long long)i, k.channel, a);
+        return GC_E_STATE;
+      }
+      if (c.mult[a] != c.mult[0]) {
+        gc_set_error("channel %d: arms with different ramp multipliers are not supported yet", k.channel);
+        return GC_E_UNSUPPORTED;
+      }
+      if (k.table_offset[a] < 0 || k.table_offset[a] + 3 > c.nent[a]) {
+        gc_set_error("block %lld: table offset out of range", (long long)i);
+        return GC_E_INVALID;
+      }
+    }
+    if (k.blksize <= 0 || k.first_sample < 0 || !(k.code_phase_step > 0) ||
+        !(k.el_spacing * c.index_scale * c.mult[0] < 1.0) || !(k.el_spacing >= 0) ||
+        !(k.rem_code_phase > -1.0) || !std::isfinite(k.carr_freq) || !std::isfinite(k.rem_carr_phase)) {
+      gc_set_error("block %lld: invalid descriptor", (long long)i);
+      return GC_E_INVALID;
+    }
+    if ((uint64_t)k.first_sample + (uint64_t)k.blksize > ctx->if_nsamples) {
+      gc_set_error("block %lld: samples [%lld, %lld) exceed the IF buffer (%llu samples)", (long long)i,
+                   (long long)k.first_sample, (long long)(k.first_sample + k.blksize),
+                   (unsigned long long)ctx->if_nsamples);
+      return GC_E_RANGE;  // tracking.m:241-245
+    }
+    // highest table index the ramps can reach must stay inside the staged window
+    const double tmax = ((k.blksize - 1) * k.code_phase_step + k.rem_code_phase + k.el_spacing) *
+                        c.index_scale * c.mult[0];
+    for (int a = 0; a < c.arms; ++a) {
+      const int stage = (c.window[a] > 0) ? std::min(c.window[a], c.nent[a]) : c.nent[a];
+      const int avail = std::min(stage, c.nent[a] - k.table_offset[a]);
+      if (std::ceil(tmax) > avail - 1) {
+        gc_set_error("block %lld: code ramp reaches index %g beyond table (%d entries)", (long long)i,
+                     std::ceil(tmax), avail);
+        return GC_E_INVALID;
+      }
+    }
+    max_arms = std::max(max_arms, c.arms);
+  }
+  return max_arms;
+}
+
+static int ensure(void** p, int64_t* cap, int64_t need, size_t elem) {
+  if (*cap >= need) return GC_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const int64_t n = std::max<int64_t>(need, 1024);
+  if (hipMalloc(p, (size_t)n * elem) != hipSuccess) {
+    gc_set_error("device allocation of %lld bytes failed", (long long)(n * (int64_t)elem));
+    return GC_E_NOMEM;
+  }
+  *cap = n;
+  return GC_OK;
+}
+
+// Number of workgroups per block for small launches: aim at >= 2 workgroups per CU.
+static int choose_splits(gc_context* ctx, int64_t nblocks, const gc_block* b) {
+  if (nblocks >= 2 * (int64_t)ctx->compute_units) return 1;
+  int min_chunks = 1 << 30;
+  for (int64_t i = 0; i < nblocks; ++i) min_chunks = std::min(min_chunks, b[i].blksize / 8 + 1);
+  int s = (int)((2 * (int64_t)ctx->compute_units + nblocks - 1) / nblocks);
+  s = std::min(s, std::max(1, min_chunks / 256));  // keep >= 256 chunks (one per thread) per split
+  return std::max(1, std::min(s, 64));
+}
+
+extern "C" {
+
+int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* out) {
+  if (!ctx || nblocks < 0 || (nblocks > 0 && (!blocks || !out))) {
+    gc_set_error("gc_correlate: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (nblocks == 0) return GC_OK;
+  GC_HIP(hipSetDevice(ctx->device));
+  const int max_arms = validate_blocks(ctx, nblocks, blocks);
+  if (max_arms < 0) return max_arms;
+  int rc = gc_sync_channels(ctx);
+  if (rc) return rc;
+  const int splits = choose_splits(ctx, nblocks, blocks);
+  if ((rc = ensure((void**)&ctx->d_blocks, &ctx->d_blocks_cap, nblocks, sizeof(gc_block)))) return rc;
+  if ((rc = ensure((void**)&ctx->d_out, &ctx->d_out_cap, (int64_t)nblocks * GC_OUT_STRIDE, sizeof(double)))) return rc;
+  if (splits > 1 &&
+      (rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, (int64_t)nblocks * splits * GC_OUT_STRIDE, sizeof(double))))
+    return rc;
+  GC_HIP(hipMemcpyAsync(ctx->d_blocks, blocks, sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
+  rc = gc_launch_correlator(ctx, ctx->d_blocks, nblocks, splits, ctx->d_out, ctx->d_partial, max_arms);
+  if (rc) return rc;
+  GC_HIP(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)nblocks * GC_OUT_STRIDE, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  return GC_OK;
+}
+
+int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) {
+  if (!ctx || nblocks <= 0 || !blocks) {
+    gc_set_error("gc_replay_prepare: bad arguments");
+    return GC_E_INVALID;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  const int max_arms = validate_blocks(ctx, nblocks, blocks);
+  if (max_arms < 0) return max_arms;
+  int rc = gc_sync_channels(ctx);
+  if (rc) return rc;
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
+  if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
+  ctx->d_replay_blocks = nullptr;
+  ctx->d_replay_out = nullptr;
+  ctx->replay_nblocks = 0;
+  if (hipMalloc((void**)&ctx->d_replay_blocks, sizeof(gc_block) * (size_t)nblocks) != hipSuccess ||
+      hipMalloc((void**)&ctx->d_replay_out, sizeof(double) * (size_t)nblocks * GC_OUT_STRIDE) != hipSuccess) {
+    gc_set_error("gc_replay_prepare: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, blocks, sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->replay_nblocks = nblocks;
+  ctx->replay_max_arms = max_arms;
+  return GC_OK;
+}
+
+int gc_replay_launch(gc_context* ctx) {
+  if (!ctx || ctx->replay_nblocks <= 0) {
+    gc_set_error("gc_replay_launch: nothing prepared");
+    return GC_E_STATE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  int splits = 1;
+  if (ctx->replay_nblocks < 2 * (int64_t)ctx->compute_units) {
+    // small replay sets: same split heuristic as gc_correlate, scratch from d_partial
+    splits = (int)std::min<int64_t>(8, (2 * (int64_t)ctx->compute_units + ctx->replay_nblocks - 1) / ctx->replay_nblocks);
+    int rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, ctx->replay_nblocks * splits * GC_OUT_STRIDE, sizeof(double));
+    if (rc) return rc;
+  }
+  return gc_launch_correlator(ctx, ctx->d_replay_blocks, ctx->replay_nblocks, splits, ctx->d_replay_out,
+                              ctx->d_partial, ctx->replay_max_arms);
+}
+
+int gc_replay_fetch(gc_context* ctx, double* out) {
+  if (!ctx || !out || ctx->replay_nblocks <= 0) return GC_E_STATE;
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipMemcpyAsync(out, ctx->d_replay_out, sizeof(double) * (size_t)ctx->replay_nblocks * GC_OUT_STRIDE,
+                        hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  return GC_OK;
+}
+
+int gc_timer_start(gc_context* ctx) {
+  if (!ctx) return GC_E_INVALID;
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+  return GC_OK;
+}
+
+int gc_timer_stop(gc_context* ctx, double* elapsed_ms) {
+  if (!ctx || !elapsed_ms) return GC_E_INVALID;
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+  GC_HIP(hipEventSynchronize(ctx->ev_stop));
+  float ms = 0.f;
+  GC_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  *elapsed_ms = (double)ms;
+  return GC_OK;
+}
+
+}  // extern "C"

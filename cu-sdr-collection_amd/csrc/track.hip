@@ -1,0 +1,257 @@
+// track.hip — gc_track: the reference's tracking loop (GPS/GPS_L1CA/include/tracking.m:133-368
+// and the 3-state / pilot variants GPS_L5C/include/tracking.m:255-382,
+// GAL_E1C/include/tracking.m:236-348) with the correlator (lines 247-300) on the GPU and the
+// discriminators + loop filters (lines 302-335) on the host, as BASELINE.json's north_star
+// prescribes.  All channels advance in lock step: one correlator launch per epoch covers every
+// active channel; descriptors and partial sums live in host-mapped pinned memory so an epoch
+// costs one kernel launch and one stream synchronisation.
+#include <algorithm>
+#include <cmath>
+
+#include "gc_internal.h"
+
+namespace {
+
+struct ChanState {
+  bool active = false;
+  int64_t pos = 0;
+  double code_freq = 0, code_freq_basis = 0, rem_code = 0;
+  double carr_freq = 0, carr_basis = 0, rem_carr = 0;
+  double old_code_nco = 0, old_code_err = 0;
+  double old_carr_nco = 0, old_carr_err = 0;  // 2nd-order PLL
+  double d2_carr_err = 0, d_carr_err = 0;      // 3-state PLL
+  int epochs = 0;
+  bool aborted = false;
+};
+
+// Common/calcLoopCoef.m:41-45
+void calc_loop_coef(double lbw, double zeta, double k, double* tau1, double* tau2) {
+  const double wn = lbw * 8 * zeta / (4 * zeta * zeta + 1);
+  *tau1 = k / (wn * wn);
+  *tau2 = 2.0 * zeta / wn;
+}
+
+const double kPi = 3.141592653589793;  // MATLAB pi
+
+}  // namespace
+
+extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
+                        double* out, int32_t* epochs_done) {
+  if (!ctx || !p || nch <= 0 || nch > GC_MAX_CHANNELS || !init || !out || !epochs_done || p->n_epochs <= 0) {
+    gc_set_error("gc_track: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if) {
+    gc_set_error("gc_track: no IF buffer loaded");
+    return GC_E_STATE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  ctx->fs = p->sampling_freq;
+  int rc = gc_sync_channels(ctx);
+  if (rc) return rc;
+
+  int max_arms = 1;
+  for (int c = 0; c < nch; ++c) {
+    const int ci = init[c].channel;
+    if (ci < 0 || ci >= GC_MAX_CHANNELS || !ctx->ch[ci].configured) {
+      gc_set_error("gc_track: channel %d not configured", ci);
+      return GC_E_STATE;
+    }
+    for (int a = 0; a < ctx->ch[ci].arms; ++a)
+      if (!ctx->ch[ci].d_tab[a]) {
+        gc_set_error("gc_track: channel %d arm %d has no code table", ci, a);
+        return GC_E_STATE;
+      }
+    max_arms = std::max(max_arms, ctx->ch[ci].arms);
+  }
+  if (p->pilot_combine != 0 && max_arms < 2) {
+    gc_set_error("gc_track: pilot_combine requires a pilot arm");
+    return GC_E_INVALID;
+  }
+
+  // splits: fill the device with one epoch's worth of blocks
+  const int approx_chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / 8.0) + 1;
+  int splits = (2 * ctx->compute_units + nch - 1) / nch;
+  splits = std::max(1, std::min(std::min(splits, 32), std::max(1, approx_chunks / 256)));
+
+  // pinned, device-visible descriptor and result buffers
+  if (ctx->pinned_cap_blocks < nch * 32) {
+    if (ctx->h_blocks_pinned) (void)hipHostFree(ctx->h_blocks_pinned);
+    if (ctx->h_out_pinned) (void)hipHostFree(ctx->h_out_pinned);
+    ctx->h_blocks_pinned = nullptr;
+    ctx->h_out_pinned = nullptr;
+    ctx->pinned_cap_blocks = 0;
+    GC_HIP(hipHostMalloc((void**)&ctx->h_blocks_pinned, sizeof(gc_block) * (size_t)nch, hipHostMallocMapped));
+    GC_HIP(hipHostMalloc((void**)&ctx->h_out_pinned, sizeof(double) * (size_t)nch * 32 * GC_OUT_STRIDE, hipHostMallocMapped));
+    ctx->pinned_cap_blocks = nch * 32;
+  }
+  gc_block* blocks = ctx->h_blocks_pinned;
+  double* partial = ctx->h_out_pinned;
+
+  const int n_epochs = p->n_epochs;
+  std::fill(out, out + (size_t)nch * GC_TRK_NFIELDS * n_epochs, 0.0);
+
+  double tau1code, tau2code, tau1carr, tau2carr;
+  calc_loop_coef(p->dll_noise_bw, p->dll_damping, 1.0, &tau1code, &tau2code);   // tracking.m:100-102
+  calc_loop_coef(p->pll_noise_bw, p->pll_damping, 0.25, &tau1carr, &tau2carr);  // tracking.m:109-110
+  const double pdi = p->int_time;
+
+  std::vector<ChanState> st((size_t)nch);
+  for (int c = 0; c < nch; ++c) {
+    ChanState& s = st[c];
+    s.active = true;
+    s.pos = p->skip_samples + init[c].code_phase - 1;  // tracking.m:150-152
+    s.code_freq = s.code_freq_basis = init[c].code_freq;  // :163 / GPS_L5C :165
+    s.carr_freq = s.carr_basis = init[c].acquired_freq;   // :167-168
+  }
+  const double R_of = 1.0;
+  (void)R_of;
+
+  std::vector<int> slot((size_t)nch);
+  bool any_range = false;
+  for (int e = 0; e < n_epochs; ++e) {
+    int nb = 0;
+    for (int c = 0; c < nch; ++c) {
+      ChanState& s = st[c];
+      if (!s.active) continue;
+      const double step = s.code_freq / p->sampling_freq;                      // :219
+      const int n = (int)std::ceil((p->code_length - s.rem_code) / step);     // :222
+      if (s.pos < 0 || (uint64_t)(s.pos + n) > ctx->if_nsamples) {            // :241-245
+        s.active = false;
+        s.aborted = true;
+        any_range = true;
+        continue;
+      }
+      gc_block& b = blocks[nb];
+      std::memset(&b, 0, sizeof b);
+      b.channel = init[c].channel;
+      b.blksize = n;
+      b.first_sample = s.pos;
+      b.rem_code_phase = s.rem_code;
+      b.code_phase_step = step;
+      b.el_spacing = p->el_spacing;
+      b.carr_freq = s.carr_freq;
+      b.rem_carr_phase = s.rem_carr;
+      slot[nb] = c;
+      ++nb;
+    }
+    if (nb == 0) break;
+    rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms);
+    if (rc) return rc;
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+
+    for (int k = 0; k < nb; ++k) {
+      const int c = slot[k];
+      ChanState& s = st[c];
+      const gc_block& b = blocks[k];
+      const double R = ctx->ch[b.channel].index_scale;
+      double sums[GC_OUT_STRIDE];
+      for (int v = 0; v < GC_OUT_STRIDE; ++v) {
+        double acc = 0.0;
+        for (int sp = 0; sp < splits; ++sp) acc += partial[((size_t)k * splits + sp) * GC_OUT_STRIDE + v];
+        sums[v] = acc;
+      }
+      const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
+      double* o = out + (size_t)c * GC_TRK_NFIELDS * n_epochs;
+      auto rec = [&](int f, double v) { o[(size_t)f * n_epochs + e] = v; };
+      rec(GC_TRK_ABSOLUTE_SAMPLE, (double)s.pos);  // :212-216
+      rec(GC_TRK_REM_CODE_PHASE, s.rem_code);      // :249
+      rec(GC_TRK_REM_CARR_PHASE, s.rem_carr);      // :277
+      const int n = b.blksize;
+      const double step = b.code_phase_step;
+      // remCodePhase update, :273 (R = 1) / GAL_E1C tracking.m:268 (R = 2).  tcode(blksize) is the
+      // colon end point ((blksize-1)*codePhaseStep + remCodePhase) * R.
+      const double t_last = ((n - 1) * step + s.rem_code) * R;
+      const double rem_code_new = (R != 1.0) ? (t_last / R + step) - p->code_length : (t_last + step) - p->code_length;
+      // remCarrPhase update, :280-283
+      const double time_n = (double)n / p->sampling_freq;
+      const double trig_n = ((s.carr_freq * 2.0 * kPi) * time_n) + s.rem_carr;
+      const double rem_carr_new = std::fmod(trig_n, 2 * kPi);
+      s.pos += n;
+      s.rem_code = rem_code_new;
+      s.rem_carr = rem_carr_new;
+
+      // ---- PLL discriminator (:305) and pilot combining ---------------------------------
+      double carr_err = std::atan(q_p / i_p) / (2.0 * kPi);
+      double code_err = (std::sqrt(i_e * i_e + q_e * q_e) - std::sqrt(i_l * i_l + q_l * q_l)) /
+                        (std::sqrt(i_e * i_e + q_e * q_e) + std::sqrt(i_l * i_l + q_l * q_l));  // :322-323
+      if (p->pilot_combine != 0) {
+        const double pi_e = sums[6], pq_e = sums[7], pi_p = sums[8], pq_p = sums[9], pi_l = sums[10], pq_l = sums[11];
+        double carr_err_q;
+        if (p->pilot_combine == 1) {
+          // QI = (I_PQ + 1i*Q_PQ) * exp(-1i*pi/2), GPS_L5C tracking.m:340
+          const double cr = std::cos(kPi / 2), ci = -std::sin(kPi / 2);
+          const double re = pi_p * cr - pq_p * ci;
+          const double im = pi_p * ci + pq_p * cr;
+          carr_err_q = std::atan(im / re) / (2.0 * kPi);
+        } else {
+          carr_err_q = std::atan(pq_p / pi_p) / (2.0 * kPi);  // GAL_E1C tracking.m:309
+        }
+        carr_err = (carr_err + carr_err_q) / 2;
+        const double code_err_q = (std::sqrt(pi_e * pi_e + pq_e * pq_e) - std::sqrt(pi_l * pi_l + pq_l * pq_l)) /
+                                  (std::sqrt(pi_e * pi_e + pq_e * pq_e) + std::sqrt(pi_l * pi_l + pq_l * pq_l));
+        code_err = (code_err + code_err_q) / 2;
+      }
+      double carr_nco;
+      if (p->pll_kind == GC_PLL_2ND_ORDER) {
+        carr_nco = s.old_carr_nco + (tau2carr / tau1carr) * (carr_err - s.old_carr_err) + carr_err * (pdi / tau1carr);  // :308-309
+        s.old_carr_nco = carr_nco;
+        s.old_carr_err = carr_err;
+      } else {
+        s.d2_carr_err = s.d2_carr_err + carr_err * p->pf3;  // GPS_L5C tracking.m:351-353
+        s.d_carr_err = s.d2_carr_err + carr_err * p->pf2 + s.d_carr_err;
+        carr_nco = s.d_carr_err + carr_err * p->pf1;
+      }
+      rec(GC_TRK_CARR_FREQ, s.carr_freq);  // :314
+      s.carr_freq = s.carr_basis + carr_nco;  // :317
+      // ---- DLL (:326-335) -----------------------------------------------------------------
+      const double code_nco = s.old_code_nco + (tau2code / tau1code) * (code_err - s.old_code_err) + code_err * (pdi / tau1code);
+      s.old_code_nco = code_nco;
+      s.old_code_err = code_err;
+      rec(GC_TRK_CODE_FREQ, s.code_freq);  // :332
+      s.code_freq = s.code_freq_basis - code_nco;  // :335
+      rec(GC_TRK_DLL_DISCR, code_err);
+      rec(GC_TRK_DLL_DISCR_FILT, code_nco);
+      rec(GC_TRK_PLL_DISCR, carr_err);
+      rec(GC_TRK_PLL_DISCR_FILT, carr_nco);
+      rec(GC_TRK_I_E, i_e);
+      rec(GC_TRK_Q_E, q_e);
+      rec(GC_TRK_I_P, i_p);
+      rec(GC_TRK_Q_P, q_p);
+      rec(GC_TRK_I_L, i_l);
+      rec(GC_TRK_Q_L, q_l);
+      if (ctx->ch[b.channel].arms >= 2) {
+        rec(GC_TRK_PILOT_I_E, sums[6]);
+        rec(GC_TRK_PILOT_Q_E, sums[7]);
+        rec(GC_TRK_PILOT_I_P, sums[8]);
+        rec(GC_TRK_PILOT_Q_P, sums[9]);
+        rec(GC_TRK_PILOT_I_L, sums[10]);
+        rec(GC_TRK_PILOT_Q_L, sums[11]);
+      }
+      s.epochs = e + 1;
+    }
+  }
+
+  // The reference processes channels one after the other and returns from the whole function at
+  // the first short read (tracking.m:241-245): channels after the first aborted one are never run.
+  int first_aborted = nch;
+  for (int c = 0; c < nch; ++c)
+    if (st[c].aborted) {
+      first_aborted = c;
+      break;
+    }
+  for (int c = 0; c < nch; ++c) {
+    if (c > first_aborted) {
+      double* o = out + (size_t)c * GC_TRK_NFIELDS * n_epochs;
+      std::fill(o, o + (size_t)GC_TRK_NFIELDS * n_epochs, 0.0);
+      epochs_done[c] = 0;
+    } else {
+      epochs_done[c] = st[c].epochs;
+    }
+  }
+  if (any_range) {
+    gc_set_error("Not able to read the specified number of samples for tracking");
+    return GC_E_RANGE;
+  }
+  return GC_OK;
+}

@@ -1,0 +1,174 @@
+"""Thin object wrapper over the C-ABI (one context = one GPU = one host thread)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Engine:
+    """Owns a gc_context on `device_id`.  Raises GnssCorrError when no MI355X is visible."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = L.load()
+        self._ctx = C.c_void_p()
+        L.check(self._lib.gc_create(C.byref(self._ctx), int(device_id)))
+        self.device_id = device_id
+
+    # ---- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.gc_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cus = C.c_int()
+        L.check(self._lib.gc_device_info(self._ctx, name, 128, C.byref(cus)))
+        return name.value.decode(), cus.value
+
+    def synchronize(self):
+        L.check(self._lib.gc_synchronize(self._ctx))
+
+    # ---- IF buffer -----------------------------------------------------------------------
+    @staticmethod
+    def _fmt(arr_dtype, layout):
+        if arr_dtype == np.int8:
+            dt = L.GC_I8
+        elif arr_dtype == np.int16:
+            dt = L.GC_I16
+        else:
+            raise TypeError("IF samples must be int8 or int16 (settings.dataType)")
+        comp = 1 if layout == L.GC_REAL else 2
+        return dt, comp
+
+    def load_if(self, raw: np.ndarray, layout: int = L.GC_IQ, fs: float | None = None):
+        """raw: the file content as a 1-D int8/int16 array (interleaved for IQ/QI)."""
+        raw = np.ascontiguousarray(raw)
+        dt, comp = self._fmt(raw.dtype, layout)
+        n = raw.shape[0] // comp
+        L.check(self._lib.gc_load_if(self._ctx, raw.ctypes.data_as(C.c_void_p), n, dt, layout))
+        if fs is not None:
+            self.set_sampling_freq(fs)
+
+    def open_if_file(self, path: str, skip_bytes: int = 0, nsamples: int = 0, dtype=np.int8,
+                     layout: int = L.GC_IQ, fs: float | None = None):
+        dt, _ = self._fmt(np.dtype(dtype), layout)
+        L.check(self._lib.gc_open_if_file(self._ctx, path.encode(), skip_bytes, nsamples, dt, layout))
+        if fs is not None:
+            self.set_sampling_freq(fs)
+
+    def alloc_if(self, nsamples: int, dtype=np.int8, layout: int = L.GC_IQ):
+        dt, _ = self._fmt(np.dtype(dtype), layout)
+        L.check(self._lib.gc_alloc_if(self._ctx, nsamples, dt, layout))
+
+    def attach_if(self, device_ptr: int, nsamples: int, dtype=np.int8, layout: int = L.GC_IQ):
+        dt, _ = self._fmt(np.dtype(dtype), layout)
+        L.check(self._lib.gc_attach_if(self._ctx, C.c_void_p(device_ptr), nsamples, dt, layout))
+
+    def if_buffer(self):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        L.check(self._lib.gc_if_buffer(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_if(self, first: int, n: int, dtype=np.int8, layout: int = L.GC_IQ) -> np.ndarray:
+        comp = 1 if layout == L.GC_REAL else 2
+        out = np.empty(n * comp, dtype=dtype)
+        L.check(self._lib.gc_read_if(self._ctx, first, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_sampling_freq(self, fs: float):
+        L.check(self._lib.gc_set_sampling_freq(self._ctx, float(fs)))
+
+    # ---- code tables ---------------------------------------------------------------------
+    def set_channel(self, channel: int, tables, index_scale: float = 1.0, arm_mult=None, windows=None):
+        """tables: list of padded code tables ([c(end) c c(1)]), one per arm."""
+        arms = len(tables)
+        L.check(self._lib.gc_set_channel(self._ctx, channel, arms, float(index_scale)))
+        for a, t in enumerate(tables):
+            t8 = np.ascontiguousarray(np.asarray(t), dtype=np.int8)
+            if not np.array_equal(t8, np.asarray(t)):
+                raise ValueError("code tables must hold integers in {-1,0,+1}")
+            m = 1.0 if arm_mult is None else float(arm_mult[a])
+            L.check(self._lib.gc_set_code(self._ctx, channel, a, t8.ctypes.data_as(C.c_void_p), t8.shape[0], m))
+            if windows is not None and windows[a]:
+                L.check(self._lib.gc_set_code_window(self._ctx, channel, a, int(windows[a])))
+
+    # ---- correlator ----------------------------------------------------------------------
+    @staticmethod
+    def make_blocks(n: int):
+        return (L.gc_block * n)()
+
+    def correlate(self, blocks) -> np.ndarray:
+        """blocks: ctypes array of gc_block.  Returns float64 [nblocks, GC_MAX_ARMS, 6]."""
+        n = len(blocks)
+        out = np.zeros((n, L.GC_MAX_ARMS, 6))
+        L.check(self._lib.gc_correlate(self._ctx, n, blocks, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def replay_prepare(self, blocks):
+        self._replay_n = len(blocks)
+        L.check(self._lib.gc_replay_prepare(self._ctx, len(blocks), blocks))
+
+    def replay_launch(self):
+        L.check(self._lib.gc_replay_launch(self._ctx))
+
+    def replay_fetch(self) -> np.ndarray:
+        out = np.zeros((self._replay_n, L.GC_MAX_ARMS, 6))
+        L.check(self._lib.gc_replay_fetch(self._ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def timer_start(self):
+        L.check(self._lib.gc_timer_start(self._ctx))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double()
+        L.check(self._lib.gc_timer_stop(self._ctx, C.byref(ms)))
+        return ms.value
+
+    # ---- closed-loop tracking ------------------------------------------------------------
+    def track(self, params: L.gc_track_params, inits):
+        """Runs gc_track.  Returns (fields dict name -> [nch, n_epochs], epochs_done, status)."""
+        nch = len(inits)
+        arr = (L.gc_channel_init * nch)(*inits)
+        n_ep = params.n_epochs
+        out = np.zeros((nch, L.GC_TRK_NFIELDS, n_ep))
+        done = (C.c_int32 * nch)()
+        st = self._lib.gc_track(self._ctx, C.byref(params), nch, arr,
+                                out.ctypes.data_as(C.POINTER(C.c_double)), done)
+        if st not in (L.GC_OK, L.GC_E_RANGE):
+            L.check(st)
+        fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
+        return fields, np.array(list(done)), st
+
+    # ---- acquisition ---------------------------------------------------------------------
+    def acquire_coarse(self, params: L.gc_acq_params, sampled_codes: np.ndarray):
+        codes = np.ascontiguousarray(sampled_codes, dtype=np.int8)
+        nprn = codes.shape[0]
+        res = (L.gc_acq_result * nprn)()
+        L.check(self._lib.gc_acquire_coarse(self._ctx, C.byref(params), nprn,
+                                            codes.ctypes.data_as(C.c_void_p), res))
+        return list(res)
+
+    def acquire_fine_l1ca(self, params: L.gc_acq_params, code: np.ndarray, code_phase: int,
+                          coarse_freq: float) -> float:
+        c8 = np.ascontiguousarray(code, dtype=np.int8)
+        f = C.c_double()
+        L.check(self._lib.gc_acquire_fine_l1ca(self._ctx, C.byref(params), c8.ctypes.data_as(C.c_void_p),
+                                               int(code_phase), float(coarse_freq), C.byref(f)))
+        return f.value

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's operator interface for the hot path (GPS L1 C/A package):
+
+    acqResults            = acquisition(longSignal, settings)       GPS/GPS_L1CA/include/acquisition.m:1
+    channel               = preRun(acqResults, settings)            GPS/GPS_L1CA/include/preRun.m:1
+    [trackResults, chan]  = tracking(fid, channel, settings)        GPS/GPS_L1CA/include/tracking.m:1
+
+Same names, argument meaning, struct fields and error behaviour; the heavy lifting is done by
+libgnsscorr.so on the GPU (no CPU path exists here).  `fid` is an Engine whose IF buffer plays
+the role of the open file; `longSignal` is identified by its position in that buffer.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib as L
+from . import codes
+from .engine import Engine
+
+
+def _round(x: float) -> int:
+    return int(math.floor(x + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5))
+
+
+# ---------------------------------------------------------------------------------------------
+# C/N0 estimator (host side, Common/CNoVSM.m:38-47)
+# ---------------------------------------------------------------------------------------------
+def CNoVSM(I, Q, T):
+    Z = np.asarray(I) ** 2 + np.asarray(Q) ** 2
+    Zm = np.mean(Z)
+    Zv = np.var(Z, ddof=1)
+    Pav = np.sqrt(complex(Zm ** 2 - Zv))
+    Nv = 0.5 * (Zm - Pav)
+    return float(10 * np.log10(abs((1 / T) * Pav / (2 * Nv))))
+
+
+# ---------------------------------------------------------------------------------------------
+# acquisition
+# ---------------------------------------------------------------------------------------------
+def _acq_params(settings, first_sample: int) -> L.gc_acq_params:
+    p = L.gc_acq_params()
+    p.sampling_freq = settings.samplingFreq
+    p.code_freq_basis = settings.codeFreqBasis
+    p.code_length = settings.codeLength
+    p.intermediate_freq = settings.IF
+    p.search_band = settings.acqSearchBand
+    p.search_step = settings.acqSearchStep
+    p.non_coh_time = int(settings.acqNonCohTime)
+    p.first_sample = int(first_sample)
+    return p
+
+
+def acquisition(engine: Engine, settings, first_sample: int | None = None):
+    """acqResults = acquisition(longSignal, settings) with longSignal = the IF buffer from
+    `first_sample` (default settings.skipNumberOfBytes, as postProcessing.m:74-96 reads it).
+
+    Only the resampling-off path (initSettings.m:93 default) is implemented; the optional
+    FIR/decimation front end (acquisition.m:50-111) is out of scope.
+    """
+    if settings.samplingFreq > settings.resamplingThreshold and settings.resamplingflag == 1:
+        raise NotImplementedError("acquisition resampling front end (acquisition.m:50-111) is out of scope")
+    if first_sample is None:
+        first_sample = int(settings.skipNumberOfBytes)
+    prns = list(settings.acqSatelliteList)
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32))
+    p = _acq_params(settings, first_sample)
+    tables = np.stack([codes.makeCaTable(prn, settings) for prn in prns])
+    res = engine.acquire_coarse(p, tables)
+    for prn, r in zip(prns, res):
+        acq.peakMetric[prn - 1] = r.peak_metric                      # acquisition.m:200
+        if r.peak_metric > settings.acqThreshold:                    # :206
+            f = engine.acquire_fine_l1ca(p, codes.generateCAcode(prn), r.code_phase, r.coarse_freq)
+            acq.carrFreq[prn - 1] = f                                # :254-260
+            acq.codePhase[prn - 1] = r.code_phase                    # :256
+    return acq
+
+
+# ---------------------------------------------------------------------------------------------
+# preRun
+# ---------------------------------------------------------------------------------------------
+def preRun(acqResults, settings):
+    n_ch = int(settings.numberOfChannels)
+    channel = [SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-") for _ in range(n_ch)]
+    order = np.argsort(-np.asarray(acqResults.peakMetric), kind="stable")   # preRun.m:60
+    n_found = int(np.sum(np.asarray(acqResults.carrFreq) != 0))
+    for ii in range(min(n_ch, n_found)):                                      # :65
+        p = int(order[ii])
+        channel[ii].PRN = p + 1
+        channel[ii].acquiredFreq = float(acqResults.carrFreq[p])
+        channel[ii].codePhase = int(acqResults.codePhase[p])
+        channel[ii].status = "T"
+    return channel
+
+
+# ---------------------------------------------------------------------------------------------
+# tracking
+# ---------------------------------------------------------------------------------------------
+_REC_FIELDS = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
+               "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase")
+
+
+def track_params(settings) -> L.gc_track_params:
+    p = L.gc_track_params()
+    p.sampling_freq = settings.samplingFreq
+    p.code_freq_basis = settings.codeFreqBasis
+    p.code_length = settings.codeLength
+    p.el_spacing = settings.dllCorrelatorSpacing
+    p.int_time = settings.intTime
+    p.dll_noise_bw = settings.dllNoiseBandwidth
+    p.dll_damping = settings.dllDampingRatio
+    p.pll_noise_bw = settings.pllNoiseBandwidth
+    p.pll_damping = settings.pllDampingRatio
+    p.pll_kind = L.GC_PLL_2ND_ORDER
+    p.pilot_combine = 0
+    p.skip_samples = int(settings.skipNumberOfBytes)
+    p.n_epochs = int(settings.msToProcess)
+    return p
+
+
+def tracking(fid: Engine, channel, settings):
+    """[trackResults, channel] = tracking(fid, channel, settings) for GPS L1 C/A.
+
+    Returns (trackResults, channel).  On a short read the reference prints a message and
+    returns what it has (tracking.m:241-245); here the partially filled results are returned
+    the same way and `trackResults[i].status` stays '-' for channels that did not finish.
+    """
+    if settings.fileType != 2 or settings.dataType not in ("schar", "int8", "int16"):
+        raise NotImplementedError("tracking(): fileType 2 (I/Q) schar/int16 input only in this build")
+    code_periods = int(settings.msToProcess)
+    results = []
+    active = []
+    for i, ch in enumerate(channel):
+        tr = SimpleNamespace(status="-", PRN=0)
+        for f in _REC_FIELDS:
+            setattr(tr, f, np.zeros(code_periods))
+        tr.CNo = SimpleNamespace(VSMValue=[], VSMIndex=[])
+        results.append(tr)
+        if ch.PRN != 0:
+            tr.PRN = ch.PRN
+            fid.set_channel(i, [codes.padded_table(codes.generateCAcode(ch.PRN))])   # tracking.m:156-158
+            active.append(i)
+    if not active:
+        return results, channel
+    p = track_params(settings)
+    inits = []
+    for i in active:
+        ch = channel[i]
+        inits.append(L.gc_channel_init(channel=i, prn=ch.PRN, acquired_freq=ch.acquiredFreq,
+                                       code_freq=settings.codeFreqBasis, code_phase=int(ch.codePhase)))
+    fields, done, status = fid.track(p, inits)
+    vsm = int(settings.CNo.VSMinterval)
+    for k, i in enumerate(active):
+        tr = results[i]
+        for f in _REC_FIELDS:
+            getattr(tr, f)[:] = fields[f][k]
+        n_done = int(done[k])
+        for loop in range(vsm, n_done + 1, vsm):                                      # tracking.m:351-358
+            tr.CNo.VSMValue.append(CNoVSM(tr.I_P[loop - vsm:loop], tr.Q_P[loop - vsm:loop], settings.CNo.accTime))
+            tr.CNo.VSMIndex.append(loop)
+        if n_done == code_periods:
+            tr.status = channel[i].status                                             # tracking.m:365
+    if status == L.GC_E_RANGE:
+        print("Not able to read the specified number of samples  for tracking, exiting!")
+    return results, channel

@@ -1,0 +1,45 @@
+"""Receiver settings struct — mirror of GPS/GPS_L1CA/initSettings.m (field names unchanged so a
+MATLAB `settings` struct maps 1:1 onto it)."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+
+def initSettings() -> SimpleNamespace:
+    """GPS L1 C/A defaults (GPS/GPS_L1CA/initSettings.m:44-136)."""
+    s = SimpleNamespace()
+    s.msToProcess = 60000            # :44
+    s.numberOfChannels = 12          # :47
+    s.skipNumberOfBytes = 0          # :53
+    s.fileName = "../../../L1_IF20KHz_FS18MHz.bin"   # :58
+    s.dataType = "schar"             # :60
+    s.fileType = 2                   # :65  (1 = real, 2 = I/Q interleaved)
+    s.IF = 20e3                      # :68
+    s.samplingFreq = 18e6            # :69
+    s.codeFreqBasis = 1.023e6        # :70
+    s.codeLength = 1023.0            # :73
+    s.skipAcquisition = 0            # :77
+    s.acqSatelliteList = list(range(1, 33))  # :80
+    s.acqSearchBand = 7000           # :83
+    s.acqNonCohTime = 20             # :85
+    s.acqThreshold = 3.5             # :87
+    s.acqSearchStep = 500            # :89
+    s.resamplingThreshold = 8e6      # :91
+    s.resamplingflag = 0             # :93
+    s.dllDampingRatio = 0.7          # :97
+    s.dllNoiseBandwidth = 1.5        # :98
+    s.dllCorrelatorSpacing = 0.5     # :99
+    s.pllDampingRatio = 0.7          # :102
+    s.pllNoiseBandwidth = 20         # :103
+    s.intTime = 0.001                # :105
+    s.navSolPeriod = 500
+    s.elevationMask = 5
+    s.useTropCorr = 1
+    s.truePosition = SimpleNamespace(E=float("nan"), N=float("nan"), U=float("nan"))
+    s.plotTracking = 1
+    s.plotAcquisition = 1
+    s.plotNavigation = 1
+    s.c = 299792458
+    s.startOffset = 68.802
+    s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=40)  # :133-136
+    return s

@@ -1,0 +1,73 @@
+"""Synthetic IF record generator (NumPy) — stands in for the externally hosted data sets the
+reference's README points to (README.md:10-11; there is no network here).
+
+Signal model per satellite k, sample n (t = n/fs):
+    x_k[n] = A_k * D_k(m) * c_k(chip) * exp(+j*(2*pi*(IF + fd_k)*t + phi_k))
+    chip phase = (n - n0_k) * (fc + fd_k/1540 * fc/1.023e6 ...) / fs   (code Doppler = Doppler/1540 for L1)
+    D_k flips every 20 code periods, aligned to the code epoch (50 bps)
+plus complex AWGN of per-component sigma, rounded and clipped to int8, interleaved I,Q
+(settings.fileType = 2, dataType 'schar').  A_k from C/N0: A = sigma*sqrt(2*10^(CN0/10)/fs).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class SatSpec:
+    prn: int
+    doppler: float           # Hz
+    code_phase_samples: float  # sample index (0-based, may be fractional) at which a code period starts
+    carrier_phase: float     # rad at n = 0
+    cn0_dbhz: float = 45.0
+
+
+def scene(n_sats: int, seed: int, fs: float, cn0=45.0, doppler_max=5e3, prn_pool=range(1, 33)):
+    """Config-2 style scene: PRNs without replacement, Doppler U(-5,5) kHz, code phase U[0,1 ms)."""
+    rng = np.random.default_rng(seed)
+    prns = rng.choice(np.array(list(prn_pool)), size=n_sats, replace=False)
+    sats = []
+    for p in prns:
+        sats.append(SatSpec(prn=int(p), doppler=float(rng.uniform(-doppler_max, doppler_max)),
+                            code_phase_samples=float(rng.uniform(0, fs * 1e-3)),
+                            carrier_phase=float(rng.uniform(0, 2 * np.pi)), cn0_dbhz=cn0))
+    return sats
+
+
+def generate_if(sats, n_samples: int, fs: float, intermediate_freq: float, code_fn, code_rate: float,
+                code_len: int, seed: int, sigma: float = 20.0, carrier_ratio: float = 1540.0,
+                bit_periods: int = 20, chunk: int = 1 << 21, noise: bool = True) -> np.ndarray:
+    """Returns int8[2*n_samples] interleaved I,Q.
+
+    code_fn(prn) -> +-1 chips (length code_len).  carrier_ratio = f_carrier/f_chip * (chip-rate
+    units): code Doppler = doppler / carrier_ratio * (code_rate / 1.023e6)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(2 * n_samples, dtype=np.int8)
+    codes = {s.prn: np.asarray(code_fn(s.prn), dtype=np.float64) for s in sats}
+    bits = {s.prn: rng.integers(0, 2, size=int(n_samples / fs * code_rate / code_len / bit_periods) + 8) * 2.0 - 1.0
+            for s in sats}
+    for start in range(0, n_samples, chunk):
+        n = np.arange(start, min(n_samples, start + chunk), dtype=np.float64)
+        acc = np.zeros(n.shape[0], dtype=np.complex128)
+        for s in sats:
+            amp = sigma * np.sqrt(2.0 * 10 ** (s.cn0_dbhz / 10.0) / fs)
+            fcode = code_rate + s.doppler / carrier_ratio * (code_rate / 1.023e6)
+            cp = (n - s.code_phase_samples) * (fcode / fs)      # chips since the reference code start
+            chip = np.floor(cp).astype(np.int64)
+            period = np.floor_divide(chip, code_len)
+            bit_idx = np.floor_divide(period, bit_periods)
+            b = bits[s.prn]
+            data = b[np.mod(bit_idx, b.shape[0])]
+            c = codes[s.prn][np.mod(chip, code_len)]
+            theta = 2 * np.pi * (intermediate_freq + s.doppler) * (n / fs) + s.carrier_phase
+            acc += amp * data * c * np.exp(1j * theta)
+        if noise:
+            acc += sigma * (rng.standard_normal(n.shape[0]) + 1j * rng.standard_normal(n.shape[0]))
+        i = np.clip(np.rint(acc.real), -127, 127).astype(np.int8)
+        q = np.clip(np.rint(acc.imag), -127, 127).astype(np.int8)
+        sl = slice(2 * start, 2 * (start + n.shape[0]))
+        out[sl][0::2] = i
+        out[sl][1::2] = q
+    return out

@@ -1,0 +1,221 @@
+/*
+ * gnsscorr.h — C-ABI of libgnsscorr.so, the MI355X (gfx950) replacement for the hot path of
+ * gnsscusdr/CU-SDR-Collection (reference @ 2024_10_08, 100 % MATLAB).
+ *
+ * The reference has no FFI boundary of its own: the boundary is cut *inside*
+ * two MATLAB functions and every entry point below names the reference lines it replaces
+ * (paths relative to the reference root; "L1CA/" = GPS/GPS_L1CA/).
+ *
+ *   tracking.m:226-236   fread + int8->double + de-interleave      -> gc_load_if / gc_attach_if
+ *   tracking.m:156-158   padded code table [c(L) c c(1)]           -> gc_set_channel / gc_set_code
+ *   tracking.m:247-300   replica ramps, carrier, mix, six sums     -> gc_correlate (+ replay API)
+ *   tracking.m:133-368   channel x epoch loops incl. loop closure  -> gc_track  (host C++ filters)
+ *   acquisition.m:151-200  sigPower, coarse PCPS search, peak pick -> gc_acquire_coarse
+ *   acquisition.m:206-254  fine-frequency search                   -> gc_acquire_fine
+ *
+ * Conventions: plain C types only; status-code returns (0 = OK, negative = error, text via
+ * gc_last_error()); no exceptions cross the ABI; caller-owned host buffers are never retained
+ * past the call that receives them; a context is used by one host thread at a time.
+ * There is NO CPU fallback: every compute entry point runs HIP kernels on the context's
+ * device and fails with GC_E_HIP if that is impossible.
+ */
+#ifndef GNSSCORR_H
+#define GNSSCORR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GC_API_VERSION 1
+
+typedef struct gc_context gc_context;
+
+enum gc_status {
+  GC_OK = 0,
+  GC_E_INVALID = -1,     /* bad argument */
+  GC_E_RANGE = -2,       /* a block reaches past the loaded IF buffer (tracking.m:241-245) */
+  GC_E_NOMEM = -3,
+  GC_E_HIP = -4,         /* HIP runtime / device failure */
+  GC_E_STATE = -5,       /* call sequence error (no IF loaded, channel not configured ...) */
+  GC_E_UNSUPPORTED = -6
+};
+
+/* settings.dataType ('schar' | 'int16'), initSettings.m:60 */
+enum gc_dtype { GC_I8 = 0, GC_I16 = 1 };
+/* settings.fileType (1 = real, 2 = I/Q interleaved), initSettings.m:62-65; GC_QI is the
+ * GLONASS sample order (GLO_GL1/include/tracking.m:227). */
+enum gc_layout { GC_REAL = 0, GC_IQ = 1, GC_QI = 2 };
+
+#define GC_MAX_ARMS 3
+#define GC_TAPS 3  /* early, prompt, late */
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int gc_create(gc_context** ctx, int device_id);
+int gc_destroy(gc_context* ctx);
+const char* gc_last_error(void);
+int gc_api_version(void);
+/* Device name / CU count of the context's device (for bench reporting). */
+int gc_device_info(gc_context* ctx, char* name, int name_len, int* compute_units);
+int gc_synchronize(gc_context* ctx);
+
+/* ---- IF samples -> HBM (replaces fread + conversion, tracking.m:226-236) ------------ */
+/* Copies `nsamples` samples (complex samples for IQ/QI, real samples for REAL) of raw
+ * integers to the device.  The raw bytes stay as they are in HBM; conversion happens in
+ * the kernels.  Replaces any previously loaded buffer. */
+int gc_load_if(gc_context* ctx, const void* samples, uint64_t nsamples, int dtype, int layout);
+/* As gc_load_if, reading from a file: `skip_bytes` as postProcessing.m:74
+ * (fseek(fid, dataAdaptCoeff*skipNumberOfBytes)); nsamples = 0 reads to end of file. */
+int gc_open_if_file(gc_context* ctx, const char* path, uint64_t skip_bytes, uint64_t nsamples,
+                    int dtype, int layout);
+/* Zero-copy: adopt a device pointer that already holds the raw samples (not owned). */
+int gc_attach_if(gc_context* ctx, void* device_ptr, uint64_t nsamples, int dtype, int layout);
+/* Device pointer and size of the current IF buffer (for tools that fill it in place). */
+int gc_if_buffer(gc_context* ctx, void** device_ptr, uint64_t* nsamples);
+/* Allocate an uninitialised device IF buffer owned by the context. */
+int gc_alloc_if(gc_context* ctx, uint64_t nsamples, int dtype, int layout);
+/* Read back raw samples [first, first+n) to the host (tests, CPU-baseline sampling). */
+int gc_read_if(gc_context* ctx, uint64_t first, uint64_t n, void* dst);
+
+/* ---- code replicas (replaces tracking.m:156-158) ------------------------------------ */
+/* Declares a tracking channel: `arms` code arms (1 = data only; 2 = data+pilot,
+ * GPS_L5C/include/tracking.m:151-160; 3 = B1C wide-band, BDS/B1C/include/WB_tracking.m:176-188)
+ * whose index ramps are multiplied by `index_scale` R (1; 2 for BOC(1,1) / RZ tables,
+ * GAL_E1C/include/tracking.m:236-262). */
+int gc_set_channel(gc_context* ctx, int channel, int arms, double index_scale);
+/* Padded table exactly as the reference builds it ([c(end) c c(1)], values in {-1,0,+1});
+ * `arm_mult` is the extra factor applied to the ramp of this arm before ceil()
+ * (6 for the BOC(6,1) arm, WB_tracking.m:293; otherwise 1). */
+int gc_set_code(gc_context* ctx, int channel, int arm, const int8_t* table, int n_entries,
+                double arm_mult);
+/* Optional: stage only `window_entries` table entries (starting at the block's table_offset)
+ * into LDS — needed for the 1 534 502-entry GPS L2C CL table, of which one block touches
+ * 2*codeLength+2 entries (GPS_L2C/include/tracking.m:261).  0 = whole table (default). */
+int gc_set_code_window(gc_context* ctx, int channel, int arm, int window_entries);
+
+/* ---- correlator (replaces tracking.m:247-300) --------------------------------------- */
+/* One integrate-and-dump block = the five scalars the reference records per epoch
+ * (tracking.m:212-216,249,277,314,332) + block geometry. */
+typedef struct gc_block {
+  int32_t channel;          /* index given to gc_set_channel */
+  int32_t blksize;          /* N, tracking.m:222 */
+  int64_t first_sample;     /* 0-based sample index of the block start in the IF buffer
+                               (ftell/dataAdaptCoeff, tracking.m:212-216) */
+  double rem_code_phase;    /* remCodePhase  (chips),   tracking.m:249 */
+  double code_phase_step;   /* codeFreq/fs,             tracking.m:219 */
+  double el_spacing;        /* earlyLateSpc (chips),    tracking.m:94  */
+  double carr_freq;         /* carrFreq (Hz),           tracking.m:314 */
+  double rem_carr_phase;    /* remCarrPhase (rad),      tracking.m:277 */
+  int32_t table_offset[GC_MAX_ARMS]; /* per-arm index offset (GPS_L2C tracking.m:261) */
+  int32_t reserved;
+} gc_block;
+
+/* Sampling frequency used for the carrier replica (settings.samplingFreq, tracking.m:280). */
+int gc_set_sampling_freq(gc_context* ctx, double fs);
+
+/* Synchronous correlate: `out` receives arms x [I_E,Q_E,I_P,Q_P,I_L,Q_L] doubles per block,
+ * blocks in input order, stride = 6*GC_MAX_ARMS doubles per block.
+ * Returns GC_E_RANGE (nothing computed) if any block exceeds the IF buffer. */
+#define GC_OUT_STRIDE (6 * GC_MAX_ARMS)
+int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* out);
+
+/* Replay (batched, open-loop) mode: descriptors stay resident in HBM so that the timed
+ * region contains only kernel work (SURVEY.md §7 hard part 1a). */
+int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks);
+int gc_replay_launch(gc_context* ctx);                 /* asynchronous on the context stream */
+int gc_replay_fetch(gc_context* ctx, double* out);     /* waits, copies nblocks*GC_OUT_STRIDE */
+/* hipEvent timer on the context stream (bench: roofline.achieved). */
+int gc_timer_start(gc_context* ctx);
+int gc_timer_stop(gc_context* ctx, double* elapsed_ms);
+
+/* ---- closed-loop tracking (replaces tracking.m:133-368; loop filters on the host) ---- */
+enum gc_pll_kind {
+  GC_PLL_2ND_ORDER = 0, /* L1CA: tracking.m:308-311 with calcLoopCoef.m:41-45 */
+  GC_PLL_3_STATE = 1    /* all other packages: GPS_L5C/include/tracking.m:351-353 */
+};
+
+typedef struct gc_track_params {
+  double sampling_freq;      /* settings.samplingFreq */
+  double code_freq_basis;    /* settings.codeFreqBasis */
+  double code_length;        /* settings.codeLength (chips per block) */
+  double el_spacing;         /* settings.dllCorrelatorSpacing */
+  double int_time;           /* settings.intTime (PDIcode = PDIcarr) */
+  double dll_noise_bw, dll_damping;   /* settings.dllNoiseBandwidth, dllDampingRatio */
+  double pll_noise_bw, pll_damping;   /* settings.pllNoiseBandwidth, pllDampingRatio */
+  int32_t pll_kind;          /* gc_pll_kind */
+  int32_t pilot_combine;     /* 0 = data arm only; 1 = average data+pilot discriminators with the
+                                pilot rotated by -pi/2 (GPS_L5C tracking.m:336-348);
+                                2 = plain average (GAL_E1C tracking.m:303-311,326-331) */
+  double pf1, pf2, pf3;      /* 3-state filter coefficients (calcLoopCoefCarr.m), if used */
+  int64_t skip_samples;      /* settings.skipNumberOfBytes, in samples */
+  int32_t n_epochs;          /* codePeriods = settings.msToProcess (tracking.m:90) */
+  int32_t reserved;
+} gc_track_params;
+
+typedef struct gc_channel_init {
+  int32_t channel;           /* gc_set_channel index holding this PRN's tables */
+  int32_t prn;               /* recorded only */
+  double acquired_freq;      /* channel.acquiredFreq, preRun.m:68 */
+  double code_freq;          /* initial codeFreq: settings.codeFreqBasis (tracking.m:163) or
+                                channel.codeFreq (GPS_L5C tracking.m:165) */
+  int64_t code_phase;        /* channel.codePhase, 1-based sample index, preRun.m:69 */
+} gc_channel_init;
+
+/* Per-epoch records, one row of n_epochs doubles per field per channel
+ * (trackResults fields, tracking.m:47-86).  Layout: out[(ch*GC_TRK_NFIELDS + field)*n_epochs + e]. */
+enum gc_track_field {
+  GC_TRK_ABSOLUTE_SAMPLE = 0, GC_TRK_CODE_FREQ, GC_TRK_CARR_FREQ,
+  GC_TRK_I_E, GC_TRK_Q_E, GC_TRK_I_P, GC_TRK_Q_P, GC_TRK_I_L, GC_TRK_Q_L,
+  GC_TRK_DLL_DISCR, GC_TRK_DLL_DISCR_FILT, GC_TRK_PLL_DISCR, GC_TRK_PLL_DISCR_FILT,
+  GC_TRK_REM_CODE_PHASE, GC_TRK_REM_CARR_PHASE,
+  GC_TRK_PILOT_I_E, GC_TRK_PILOT_Q_E, GC_TRK_PILOT_I_P, GC_TRK_PILOT_Q_P,
+  GC_TRK_PILOT_I_L, GC_TRK_PILOT_Q_L,
+  GC_TRK_NFIELDS
+};
+
+/* Runs the reference's tracking loop for `nch` channels in lock step: one correlator launch
+ * per epoch for all channels, discriminators + loop filters on the host between launches.
+ * `epochs_done[ch]` receives the number of completed epochs (== n_epochs unless the IF
+ * buffer ran out, in which case the call returns GC_E_RANGE after filling what it could —
+ * the reference's early return, tracking.m:241-245). */
+int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
+             double* out, int32_t* epochs_done);
+
+/* ---- acquisition (replaces acquisition.m:151-254, resampling off) ------------------- */
+typedef struct gc_acq_params {
+  double sampling_freq;      /* settings.samplingFreq */
+  double code_freq_basis;    /* settings.codeFreqBasis */
+  double code_length;        /* settings.codeLength */
+  double intermediate_freq;  /* settings.IF */
+  double search_band;        /* settings.acqSearchBand (Hz, single-sided) */
+  double search_step;        /* settings.acqSearchStep */
+  int32_t non_coh_time;      /* settings.acqNonCohTime */
+  int32_t reserved;
+  int64_t first_sample;      /* start of longSignal within the IF buffer */
+} gc_acq_params;
+
+typedef struct gc_acq_result {
+  int32_t coarse_bin;        /* 1-based frequency-bin index, acquisition.m:196 */
+  int32_t code_phase;        /* 1-based sample index over 2*samplesPerCode columns, :198 */
+  double peak;               /* max(max(results)) */
+  double peak_metric;        /* peak/sigPower/acqNonCohTime, :200 */
+  double coarse_freq;        /* coarseFreqBin(acqCoarseBin), :169-170 */
+} gc_acq_result;
+
+/* `sampled_codes`: nprn rows of samplesPerCode int8 (makeCaTable.m:59-67 output).
+ * For each PRN returns the coarse peak (acquisition.m:158-200). */
+int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn,
+                      const int8_t* sampled_codes, gc_acq_result* out);
+
+/* Fine-frequency stage of GPS L1 C/A (acquisition.m:213-254) for one detected PRN:
+ * `code` = 1023 chips (+-1), `code_phase` / `coarse_freq` from gc_acquire_coarse.
+ * Returns the fine carrier frequency (with the "0 -> 1 Hz" rule of :258-260 applied). */
+int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code,
+                         int code_phase, double coarse_freq, double* carr_freq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNSSCORR_H */

@@ -1,0 +1,481 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) — float64 NumPy restatement of the reference hot path.
+
+This file restates, line by line, the arithmetic of the MATLAB reference
+(gnsscusdr/CU-SDR-Collection @ 2024_10_08) for the acquisition + tracking hot path.
+It is the *checker* for the HIP kernels; it is never imported by the product package
+(`cu-sdr-collection_amd/`).  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it.
+
+PARITY STATUS: "parity unpinned by the reference" — the reference ships no tests, golden
+vectors or fixtures and neither MATLAB nor Octave exists in the build container or on the
+GPU box, so this restatement cannot be run against the reference itself.  What pins it
+instead (tests/test_oracle_*.py): public-ICD known-answer tests for the code generators,
+analytic correlator identities, a second independent restatement in C
+(`oracle/gnss_oracle.c`) that must agree to the last few ulps, and closed-loop lock tests.
+
+All citations are file:line under /root/reference/.  MATLAB semantics modelled
+explicitly: colon-operator construction, `ceil` on exact integers, `rem` keeping the sign
+of the dividend, `round` half-away-from-zero, `max` returning the first maximum, `var`
+normalised by N-1.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import numpy as np
+
+TWO_PI = 2.0 * math.pi  # MATLAB `2 * pi`
+
+# --------------------------------------------------------------------------------------
+# MATLAB built-in semantics
+# --------------------------------------------------------------------------------------
+
+
+def matlab_round(x: float) -> float:
+    """MATLAB round(): half away from zero (acquisition.m:116,124)."""
+    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+
+
+def colon(a: float, d: float, b: float) -> np.ndarray:
+    """MATLAB `a:d:b` for doubles (MathWorks' published colon algorithm).
+
+    The vector is NOT a + k*d for every k: the first half is built forwards from `a`,
+    the second half backwards from the (tolerance-snapped) end point `c`, and for an even
+    number of intervals the middle element is (a+c)/2.  tracking.m:252-273 relies on it
+    (remCodePhase inherits the end-point rule through tcode(blksize)).
+    """
+    a = float(a)
+    d = float(d)
+    b = float(b)
+    if d == 0 or (d > 0 and a > b) or (d < 0 and a < b):
+        return np.zeros(0)
+    tol = 2.0 * np.finfo(np.float64).eps * max(abs(a), abs(b))
+    sig = 1.0 if d > 0 else -1.0
+    if a == math.floor(a) and d == 1.0:
+        n = int(math.floor(b) - a)
+    elif a == math.floor(a) and d == math.floor(d):
+        n = int(math.floor((b - a) / d))
+    else:
+        n = int(matlab_round((b - a) / d))
+        if sig * (a + n * d - b) > tol:
+            n -= 1
+    c = a + n * d
+    if sig * (c - b) > -tol:
+        c = b
+    out = np.empty(n + 1, dtype=np.float64)
+    k = np.arange(0, n // 2 + 1, dtype=np.float64)
+    ki = np.arange(0, n // 2 + 1)
+    out[ki] = a + k * d
+    out[n - ki] = c - k * d
+    if n % 2 == 0:
+        out[n // 2] = (a + c) / 2.0
+    return out
+
+
+def matlab_rem(x: float, y: float) -> float:
+    """MATLAB rem(x, y): result has the sign of x (tracking.m:283)."""
+    return math.fmod(x, y)
+
+
+# --------------------------------------------------------------------------------------
+# C1 — code generators
+# --------------------------------------------------------------------------------------
+
+# G2 delay table, generateCAcode.m:42-50 (values are public IS-GPS-200 / SBAS data)
+_G2S = [5, 6, 7, 8, 17, 18, 139, 140, 141, 251,
+        252, 254, 255, 256, 257, 258, 469, 470, 471, 472,
+        473, 474, 509, 512, 513, 514, 515, 516, 859, 860,
+        861, 862,
+        145, 175, 52, 21, 237, 235, 886, 657,
+        634, 762, 355, 1012, 176, 603, 130, 359, 595, 68,
+        386]
+
+
+def generate_ca_code(prn: int) -> np.ndarray:
+    """GPS C/A code, 1023 chips of +-1 (generateCAcode.m:42-90).
+
+    Product form of the LFSRs: registers hold +-1, feedback = product of taps
+    (G1 taps {3,10}: :65; G2 taps {2,3,6,8,9,10}: :80), all -1 initial state (:61,:76),
+    G2 rotated right by g2s(PRN) (:87), CAcode = -(g1.*g2) (:90).
+    """
+    g2shift = _G2S[prn - 1]
+    g1 = np.empty(1023)
+    reg = -np.ones(10)
+    for i in range(1023):
+        g1[i] = reg[9]
+        save = reg[2] * reg[9]
+        reg[1:10] = reg[0:9].copy()
+        reg[0] = save
+    g2 = np.empty(1023)
+    reg = -np.ones(10)
+    for i in range(1023):
+        g2[i] = reg[9]
+        save = reg[1] * reg[2] * reg[5] * reg[7] * reg[8] * reg[9]
+        reg[1:10] = reg[0:9].copy()
+        reg[0] = save
+    g2 = np.concatenate([g2[1023 - g2shift:], g2[:1023 - g2shift]])
+    return -(g1 * g2)
+
+
+def pad_code(code: np.ndarray) -> np.ndarray:
+    """[c(end) c c(1)] (tracking.m:158; GAL_E1C tracking.m:143)."""
+    return np.concatenate([[code[-1]], code, [code[0]]])
+
+
+def samples_per_code(settings) -> int:
+    """round(fs / (fc / L)) (acquisition.m:116-117; makeCaTable.m:43-44)."""
+    return int(matlab_round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength)))
+
+
+def make_ca_table(prn: int, settings) -> np.ndarray:
+    """C2 — sampled C/A code for acquisition (makeCaTable.m:43-67)."""
+    spc = samples_per_code(settings)
+    ts = 1.0 / settings.samplingFreq
+    tc = 1.0 / settings.codeFreqBasis
+    ca = generate_ca_code(prn)
+    idx = np.ceil((ts * np.arange(1, spc + 1, dtype=np.float64)) / tc).astype(np.int64)
+    idx[-1] = 1023
+    return ca[idx - 1]
+
+
+# --------------------------------------------------------------------------------------
+# T6 helpers — loop coefficients and C/N0 (host side in the product, restated here)
+# --------------------------------------------------------------------------------------
+
+
+def calc_loop_coef(lbw: float, zeta: float, k: float):
+    """Common/calcLoopCoef.m:41-45."""
+    wn = lbw * 8 * zeta / (4 * zeta ** 2 + 1)
+    tau1 = k / (wn * wn)
+    tau2 = 2.0 * zeta / wn
+    return tau1, tau2
+
+
+def calc_loop_coef_carr(settings, variant: str = "a"):
+    """Common/calcLoopCoefCarr.m — 3-state carrier filter coefficients.
+
+    Two variants exist in the tree.  "a" (GPS_L5C/Common/calcLoopCoefCarr.m:41-56, shared by
+    B1I, B2a, E1C, E5a, GLO, L2C): a3 = b3 = 2, Wn = 1.2*LBW.  "b" (BDS/B1C, B3I, GAL_E5b:
+    :41-50): a3 = 1.1, b3 = 2.4, Wn = LBW/0.7845.  Returns (pf3, pf2, pf1) like the source.
+    """
+    lbw = settings.pllNoiseBandwidth
+    t = settings.intTime
+    if variant == "a":
+        a3, b3 = 2, 2
+        wn = 1.2 * lbw
+    else:
+        a3, b3 = 1.1, 2.4
+        wn = lbw / 0.7845
+    pf3 = wn ** 3 * t ** 2
+    pf2 = a3 * wn ** 2 * t
+    pf1 = b3 * wn
+    return pf3, pf2, pf1
+
+
+def cno_vsm(i_p: np.ndarray, q_p: np.ndarray, t: float) -> float:
+    """Common/CNoVSM.m:38-47 (var normalised by N-1)."""
+    z = i_p ** 2 + q_p ** 2
+    zm = np.mean(z)
+    zv = np.var(z, ddof=1)
+    pav = np.sqrt(complex(zm ** 2 - zv))  # MATLAB sqrt of a negative returns complex
+    nv = 0.5 * (zm - pav)
+    return float(10 * np.log10(abs((1 / t) * pav / (2 * nv))))
+
+
+# --------------------------------------------------------------------------------------
+# T2-T4 — one correlator block
+# --------------------------------------------------------------------------------------
+
+
+def blksize_for(code_length: float, rem_code_phase: float, code_phase_step: float) -> int:
+    """tracking.m:222."""
+    return int(math.ceil((code_length - rem_code_phase) / code_phase_step))
+
+
+def code_ramps(rem: float, step: float, d: float, n: int, r: float):
+    """The three index ramps of tracking.m:252-270, scaled by R as in
+    GAL_E1C/include/tracking.m:236-262.  Returned in source order early, late, prompt.
+
+    For R == 1 the source has no multiplication; x*1.0 is exact so one expression serves.
+    """
+    t_e = colon((rem - d) * r, step * r, ((n - 1) * step + rem - d) * r)
+    t_l = colon((rem + d) * r, step * r, ((n - 1) * step + rem + d) * r)
+    t_p = colon(rem * r, step * r, ((n - 1) * step + rem) * r)
+    return t_e, t_l, t_p
+
+
+def correlate_block(raw: np.ndarray, tables, rem: float, step: float, d: float,
+                    carr_freq: float, rem_carr: float, fs: float, code_length: float,
+                    r: float = 1.0, arm_mult=None, table_offset=None):
+    """One integrate-and-dump block (tracking.m:247-300).
+
+    raw     complex128[N]  (data1 + 1i*data2, tracking.m:233-235; callers swap for GLONASS)
+    tables  list of padded code tables, one per arm ([c(end) c c(1)], tracking.m:158)
+    arm_mult per-arm extra multiplier applied to the ramp before ceil
+            (6 for the BOC(6,1) arm, BDS/B1C/include/WB_tracking.m:293)
+    table_offset per-arm index offset (GPS_L2C tracking.m:261)
+    Returns (sums[arms,6] ordered I_E,Q_E,I_P,Q_P,I_L,Q_L, rem_code', rem_carr').
+    """
+    n = raw.shape[0]
+    arms = len(tables)
+    arm_mult = arm_mult or [1.0] * arms
+    table_offset = table_offset or [0] * arms
+    t_e, t_l, t_p = code_ramps(rem, step, d, n, r)
+    assert t_e.shape[0] == n and t_l.shape[0] == n and t_p.shape[0] == n
+    # tracking.m:273 / GAL_E1C tracking.m:268
+    rem_code_new = (t_p[n - 1] / r + step) - code_length if r != 1.0 else (t_p[n - 1] + step) - code_length
+    # tracking.m:280-287
+    time = np.arange(0, n + 1, dtype=np.float64) / fs
+    trigarg = ((carr_freq * 2.0 * math.pi) * time) + rem_carr
+    rem_carr_new = matlab_rem(float(trigarg[n]), TWO_PI)
+    carrsig = np.exp(-1j * trigarg[:n])
+    mixed = carrsig * raw
+    i_bb = mixed.real
+    q_bb = mixed.imag
+    sums = np.empty((arms, 6))
+    for a in range(arms):
+        tab = tables[a]
+        m = arm_mult[a]
+        off = table_offset[a]
+        # MATLAB index ceil(t)+1 (1-based) == ceil(t) (0-based)
+        k_e = np.ceil(t_e * m).astype(np.int64) + off
+        k_l = np.ceil(t_l * m).astype(np.int64) + off
+        k_p = np.ceil(t_p * m).astype(np.int64) + off
+        c_e = tab[k_e]
+        c_l = tab[k_l]
+        c_p = tab[k_p]
+        sums[a, 0] = np.sum(c_e * i_bb)
+        sums[a, 1] = np.sum(c_e * q_bb)
+        sums[a, 2] = np.sum(c_p * i_bb)
+        sums[a, 3] = np.sum(c_p * q_bb)
+        sums[a, 4] = np.sum(c_l * i_bb)
+        sums[a, 5] = np.sum(c_l * q_bb)
+    return sums, rem_code_new, rem_carr_new
+
+
+def raw_from_if(if_bytes: np.ndarray, first_sample: int, n: int, file_type: int = 2,
+                swap_iq: bool = False) -> np.ndarray:
+    """fread + de-interleave (tracking.m:226-236).  `if_bytes` is the int8/int16 file
+    content; first_sample counts complex samples (fileType 2) or real samples (fileType 1)."""
+    if file_type == 1:
+        return if_bytes[first_sample:first_sample + n].astype(np.float64).astype(np.complex128)
+    seg = if_bytes[2 * first_sample:2 * (first_sample + n)].astype(np.float64)
+    if swap_iq:  # GLO_GL1/include/tracking.m:227
+        return seg[1::2] + 1j * seg[0::2]
+    return seg[0::2] + 1j * seg[1::2]
+
+
+# --------------------------------------------------------------------------------------
+# tracking(fid, channel, settings) — GPS L1 C/A closed loop (tracking.m:47-371)
+# --------------------------------------------------------------------------------------
+
+TRACK_FIELDS = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P",
+                "Q_L", "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase",
+                "remCarrPhase")
+
+
+def tracking_l1ca(if_bytes: np.ndarray, channel, settings, correlate=None):
+    """Closed-loop restatement of GPS/GPS_L1CA/include/tracking.m.
+
+    `if_bytes` stands for the file behind `fid` (int8 interleaved I/Q for fileType 2).
+    `channel` is a list of objects with PRN, acquiredFreq, codePhase, status (preRun.m:44-73).
+    `correlate` lets a test substitute the device correlator for lines 247-300 while keeping
+    the host loop closure; default is the oracle's own correlate_block.
+    Returns a list of SimpleNamespace trackResults (fields tracking.m:47-86).
+    """
+    code_periods = int(settings.msToProcess)
+    d = settings.dllCorrelatorSpacing
+    pdi_code = settings.intTime
+    tau1code, tau2code = calc_loop_coef(settings.dllNoiseBandwidth, settings.dllDampingRatio, 1.0)
+    pdi_carr = settings.intTime
+    tau1carr, tau2carr = calc_loop_coef(settings.pllNoiseBandwidth, settings.pllDampingRatio, 0.25)
+    adapt = 1 if settings.fileType == 1 else 2
+    n_total = if_bytes.shape[0] // adapt
+    results = []
+    for ch in channel:
+        tr = SimpleNamespace(status="-", PRN=0)
+        for f in TRACK_FIELDS:
+            setattr(tr, f, np.zeros(code_periods))
+        tr.CNo = SimpleNamespace(VSMValue=[], VSMIndex=[])
+        results.append(tr)
+        if ch.PRN == 0:
+            continue
+        tr.PRN = ch.PRN
+        pos = int(settings.skipNumberOfBytes + ch.codePhase - 1)  # tracking.m:150-152
+        table = pad_code(generate_ca_code(ch.PRN))  # :156-158
+        code_freq = settings.codeFreqBasis
+        rem_code = 0.0
+        carr_freq = ch.acquiredFreq
+        carr_basis = ch.acquiredFreq
+        rem_carr = 0.0
+        old_code_nco = 0.0
+        old_code_err = 0.0
+        old_carr_nco = 0.0
+        old_carr_err = 0.0
+        aborted = False
+        for loop in range(code_periods):
+            tr.absoluteSample[loop] = pos  # :212-216
+            step = code_freq / settings.samplingFreq  # :219
+            n = blksize_for(settings.codeLength, rem_code, step)  # :222
+            if pos + n > n_total:  # short read, :241-245
+                aborted = True
+                break
+            tr.remCodePhase[loop] = rem_code  # :249
+            tr.remCarrPhase[loop] = rem_carr  # :277
+            if correlate is None:
+                raw = raw_from_if(if_bytes, pos, n, settings.fileType)
+                sums, rem_code_new, rem_carr_new = correlate_block(
+                    raw, [table], rem_code, step, d, carr_freq, rem_carr,
+                    settings.samplingFreq, settings.codeLength)
+            else:
+                sums, rem_code_new, rem_carr_new = correlate(
+                    ch, pos, n, rem_code, step, d, carr_freq, rem_carr)
+            pos += n
+            i_e, q_e, i_p, q_p, i_l, q_l = (float(v) for v in sums[0])
+            rem_code, rem_carr = rem_code_new, rem_carr_new
+            # PLL, :305-317
+            with np.errstate(divide="ignore", invalid="ignore"):
+                carr_err = float(np.arctan(np.float64(q_p) / np.float64(i_p)) / (2.0 * math.pi))
+            carr_nco = old_carr_nco + (tau2carr / tau1carr) * (carr_err - old_carr_err) \
+                + carr_err * (pdi_carr / tau1carr)
+            old_carr_nco = carr_nco
+            old_carr_err = carr_err
+            tr.carrFreq[loop] = carr_freq
+            carr_freq = carr_basis + carr_nco
+            # DLL, :322-335
+            e_mag = math.sqrt(i_e * i_e + q_e * q_e)
+            l_mag = math.sqrt(i_l * i_l + q_l * q_l)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                code_err = float((np.float64(e_mag) - l_mag) / (np.float64(e_mag) + l_mag))
+            code_nco = old_code_nco + (tau2code / tau1code) * (code_err - old_code_err) \
+                + code_err * (pdi_code / tau1code)
+            old_code_nco = code_nco
+            old_code_err = code_err
+            tr.codeFreq[loop] = code_freq
+            code_freq = settings.codeFreqBasis - code_nco
+            # record, :338-348
+            tr.dllDiscr[loop] = code_err
+            tr.dllDiscrFilt[loop] = code_nco
+            tr.pllDiscr[loop] = carr_err
+            tr.pllDiscrFilt[loop] = carr_nco
+            tr.I_E[loop], tr.I_P[loop], tr.I_L[loop] = i_e, i_p, i_l
+            tr.Q_E[loop], tr.Q_P[loop], tr.Q_L[loop] = q_e, q_p, q_l
+            # C/N0, :351-358
+            vsm = int(settings.CNo.VSMinterval)
+            if (loop + 1) % vsm == 0:
+                val = cno_vsm(tr.I_P[loop + 1 - vsm:loop + 1], tr.Q_P[loop + 1 - vsm:loop + 1],
+                              settings.CNo.accTime)
+                tr.CNo.VSMValue.append(val)
+                tr.CNo.VSMIndex.append(loop + 1)
+        if aborted:
+            # the reference prints and returns from the whole function (:241-245)
+            return results
+        tr.status = ch.status  # :365
+    return results
+
+
+# --------------------------------------------------------------------------------------
+# acquisition(longSignal, settings) — GPS L1 C/A (acquisition.m:113-260), resampling off
+# --------------------------------------------------------------------------------------
+
+
+def matlab_var(x: np.ndarray) -> float:
+    """var() of a (complex) vector: sum |x-mean|^2 / (N-1)."""
+    m = np.mean(x)
+    return float(np.sum(np.abs(x - m) ** 2) / (x.shape[0] - 1))
+
+
+def acquisition_coarse_results(long_signal: np.ndarray, prn: int, settings) -> np.ndarray:
+    """results[bin, tau] of acquisition.m:158-192 for one PRN (float64 FFTs)."""
+    spc = samples_per_code(settings)
+    ts = 1.0 / settings.samplingFreq
+    phase_points = np.arange(0, spc * 2, dtype=np.float64) * 2 * math.pi * ts  # :122
+    n_bins = int(matlab_round(settings.acqSearchBand * 2 / settings.acqSearchStep)) + 1  # :124
+    table = make_ca_table(prn, settings)
+    code2 = np.concatenate([table, np.zeros(spc)])  # :160
+    code_fd = np.conj(np.fft.fft(code2))  # :164
+    results = np.zeros((n_bins, spc * 2))
+    for b in range(n_bins):
+        f = settings.IF + settings.acqSearchBand - settings.acqSearchStep * b  # :169-170
+        sig_carr = np.exp(-1j * f * phase_points)  # :172
+        for h in range(int(settings.acqNonCohTime)):
+            sig = long_signal[h * spc:(h + 2) * spc]  # :177-178
+            iq = sig_carr * sig
+            conv = np.fft.fft(iq) * code_fd  # :183-186
+            results[b, :] += np.abs(np.fft.ifft(conv))  # :188-190
+    return results
+
+
+def acquisition_l1ca(long_signal: np.ndarray, settings, want_results: bool = False):
+    """acqResults = acquisition(longSignal, settings) (acquisition.m:113-260).
+
+    Only the resampling-off path (initSettings.m:93 default) is restated.
+    Returns SimpleNamespace(carrFreq, codePhase, peakMetric) with 32 entries each and, for
+    test use, coarseBin (1-based, 0 = not computed).
+    """
+    assert not (settings.samplingFreq > settings.resamplingThreshold and settings.resamplingflag == 1)
+    spc = samples_per_code(settings)
+    ts = 1.0 / settings.samplingFreq
+    n_bins = int(matlab_round(settings.acqSearchBand * 2 / settings.acqSearchStep)) + 1
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32),
+                          coarseBin=np.zeros(32, dtype=np.int64))
+    fine_step = 25
+    n_fine = int(matlab_round(settings.acqSearchStep / fine_step)) + 1  # :140
+    fine_phase = np.arange(0, 40 * spc, dtype=np.float64) * 2 * math.pi * ts  # :148
+    sig_power = math.sqrt(matlab_var(long_signal[:spc]) * spc)  # :151
+    all_results = {}
+    for prn in settings.acqSatelliteList:
+        results = acquisition_coarse_results(long_signal, prn, settings)
+        if want_results:
+            all_results[prn] = results
+        # :196-198 — max() returns the first maximum
+        coarse_bin = int(np.argmax(np.max(results, axis=1)))
+        col_max = np.max(results, axis=0)
+        code_phase0 = int(np.argmax(col_max))
+        peak = float(col_max[code_phase0])
+        acq.peakMetric[prn - 1] = peak / sig_power / settings.acqNonCohTime  # :200
+        acq.coarseBin[prn - 1] = coarse_bin + 1
+        if acq.peakMetric[prn - 1] > settings.acqThreshold:  # :206
+            code_phase = code_phase0 + 1  # 1-based sample index
+            ca = generate_ca_code(prn)
+            tc = 1.0 / settings.codeFreqBasis
+            idx = np.floor((ts * np.arange(0, 40 * spc, dtype=np.float64)) / tc).astype(np.int64)  # :215
+            ca40 = ca[idx % int(settings.codeLength)]  # :218
+            sig40 = long_signal[code_phase - 1:code_phase - 1 + 40 * spc]  # :221
+            fine_result = np.zeros(n_fine)
+            fine_bins = np.zeros(n_fine)
+            coarse_f = settings.IF + settings.acqSearchBand - settings.acqSearchStep * coarse_bin
+            for fb in range(n_fine):
+                fine_bins[fb] = coarse_f + settings.acqSearchStep / 2 - fine_step * fb  # :227-228
+                carr = np.exp(-1j * fine_bins[fb] * fine_phase)  # :230
+                bb = sig40 * ca40 * carr  # :232
+                sum_per_code = bb.reshape(40, spc).sum(axis=1)  # :235-238
+                max_power = 0.0
+                for com in range(20):  # :243-248
+                    max_power = max(max_power, abs(np.sum(sum_per_code[com:com + 20])))
+                fine_result[fb] = max_power
+            max_fin = int(np.argmax(fine_result))  # :253
+            acq.carrFreq[prn - 1] = fine_bins[max_fin]
+            acq.codePhase[prn - 1] = code_phase
+            if acq.carrFreq[prn - 1] == 0:  # :258-260
+                acq.carrFreq[prn - 1] = 1
+    if want_results:
+        return acq, all_results
+    return acq
+
+
+def pre_run(acq, settings):
+    """channel = preRun(acqResults, settings) (preRun.m:44-73)."""
+    n_ch = int(settings.numberOfChannels)
+    channel = [SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-") for _ in range(n_ch)]
+    # sort(..., 'descend') is stable: ties keep ascending index order
+    order = np.argsort(-acq.peakMetric, kind="stable")
+    n_found = int(np.sum(acq.carrFreq != 0))
+    for ii in range(min(n_ch, n_found)):
+        p = int(order[ii])
+        channel[ii].PRN = p + 1
+        channel[ii].acquiredFreq = float(acq.carrFreq[p])
+        channel[ii].codePhase = int(acq.codePhase[p])
+        channel[ii].status = "T"
+    return channel

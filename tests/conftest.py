@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """A live gc_context on cuda:0.  GPU tests FAIL (not skip) when the HIP library is missing
+    or no MI355X is visible: there is no CPU fallback to hide behind."""
+    import cu_sdr_collection_amd as P
+    eng = P.Engine(0)
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="session")
+def l1ca_scene():
+    """0.3 s, 4-satellite GPS L1 C/A scene at the reference's default front end
+    (18 Msps int8 I/Q, IF 20 kHz: GPS/GPS_L1CA/initSettings.m:60-69)."""
+    import numpy as np
+    import cu_sdr_collection_amd as P
+    S = P.initSettings()
+    sats = P.synth.scene(4, 20241008 + 2, S.samplingFreq)
+    iq = P.synth.generate_if(sats, int(0.3 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateCAcode,
+                             S.codeFreqBasis, 1023, seed=77)
+    return S, sats, iq

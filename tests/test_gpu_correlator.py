@@ -1,0 +1,174 @@
+"""HIP correlator (gc_correlate / replay, through the C-ABI) vs the CPU oracle — the parity
+gate for tracking.m:247-300.
+
+Tolerance.  The reference computes in float64; the kernel keeps code/carrier *phase* in float64 /
+64-bit fixed point (so chip-edge decisions are exact) but mixes and accumulates in float32.
+Bound used: |delta| <= TOL * sum_n(|I_n| + |Q_n|) per output, TOL = 2e-6; measured margin is
+reported by test_tolerance_margin (typically < 2e-7).  A single wrong chip decision or a one-sample
+misalignment changes an output by ~1e-4 * sum, i.e. 50x the bound.
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import gnss_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+def _blocks(engine, descs):
+    b = engine.make_blocks(len(descs))
+    for k, d in enumerate(descs):
+        b[k].channel = d["channel"]
+        b[k].blksize = d["n"]
+        b[k].first_sample = d["s0"]
+        b[k].rem_code_phase = d["rem"]
+        b[k].code_phase_step = d["step"]
+        b[k].el_spacing = d["d"]
+        b[k].carr_freq = d["f"]
+        b[k].rem_carr_phase = d["phi"]
+    return b
+
+
+def _oracle(iq, d, table, code_length=1023.0, fs=18e6):
+    s, _, _ = CO.correlate_block(iq, d["s0"], d["n"], [table], d["rem"], d["step"], d["d"], d["f"], d["phi"],
+                                 fs, code_length)
+    return s[0]
+
+
+def _scale(iq, d):
+    seg = iq[2 * d["s0"]:2 * (d["s0"] + d["n"])].astype(np.float64)
+    return np.sum(np.abs(seg))
+
+
+def _random_descs(rng, n, nsamp, nch, fs=18e6, fc=1.023e6, L=1023.0):
+    out = []
+    for _ in range(n):
+        step = (fc + rng.uniform(-5, 5)) / fs
+        rem = rng.uniform(0, step)
+        N = int(np.ceil((L - rem) / step))
+        out.append(dict(channel=int(rng.integers(0, nch)), n=N, s0=int(rng.integers(0, nsamp - N)),
+                        rem=rem, step=step, d=0.5, f=20e3 + rng.uniform(-5e3, 5e3),
+                        phi=rng.uniform(-2 * np.pi, 2 * np.pi)))
+    return out
+
+
+def test_correlate_matches_oracle(engine, l1ca_scene):
+    S, sats, iq = l1ca_scene
+    engine.load_if(iq, fs=S.samplingFreq)
+    tables = []
+    for i, s in enumerate(sats):
+        t = O.pad_code(O.generate_ca_code(s.prn))
+        tables.append(t)
+        engine.set_channel(i, [t.astype(np.int8)])
+    rng = np.random.default_rng(1)
+    descs = _random_descs(rng, 64, iq.shape[0] // 2, len(sats))
+    # edge cases the reference hits: rem = 0 at the first block (tracking.m:165; ceil(0)+1 -> the
+    # wrapped last chip, :266-270), block starting at sample 0 and ending at the last sample
+    descs[0].update(rem=0.0, s0=0, phi=0.0)
+    descs[1].update(s0=iq.shape[0] // 2 - descs[1]["n"])
+    descs[2].update(s0=7)  # unaligned head
+    got = engine.correlate(_blocks(engine, descs))
+    worst = 0.0
+    for k, d in enumerate(descs):
+        ref = _oracle(iq, d, tables[d["channel"]])
+        err = np.abs(got[k, 0] - ref).max() / _scale(iq, d)
+        worst = max(worst, err)
+        assert err < TOL, (k, d, got[k, 0], ref)
+        assert np.all(got[k, 1:] == 0)
+    print(f"worst relative error {worst:.3e} (bound {TOL:.1e})")
+
+
+def test_replay_matches_correlate_and_is_deterministic(engine, l1ca_scene):
+    S, sats, iq = l1ca_scene
+    engine.load_if(iq, fs=S.samplingFreq)
+    for i, s in enumerate(sats):
+        engine.set_channel(i, [O.pad_code(O.generate_ca_code(s.prn)).astype(np.int8)])
+    rng = np.random.default_rng(2)
+    descs = _random_descs(rng, 1024, iq.shape[0] // 2, len(sats))
+    b = _blocks(engine, descs)
+    a = engine.correlate(b)
+    engine.replay_prepare(b)
+    engine.replay_launch()
+    r1 = engine.replay_fetch()
+    engine.replay_launch()
+    r2 = engine.replay_fetch()
+    assert np.array_equal(r1, r2), "replay must be bit-reproducible (no atomics in the reduction)"
+    # correlate() may split blocks over several workgroups; the sums then differ by rounding only
+    scale = np.array([_scale(iq, d) for d in descs])[:, None]
+    assert np.max(np.abs(a[:, 0] - r1[:, 0]) / scale) < 5e-7
+
+
+def test_noise_free_identities(engine):
+    """Analytic identities: a noise-free block correlated against its own replica
+    gives I_P = A*N, Q_P ~ 0 and E = L = A*N*(1 - d) for spacing d."""
+    import cu_sdr_collection_amd as P
+    S = P.initSettings()
+    fs, fc = S.samplingFreq, S.codeFreqBasis
+    sat = P.synth.SatSpec(prn=7, doppler=1234.0, code_phase_samples=0.0, carrier_phase=0.0, cn0_dbhz=0.0)
+    n = int(0.004 * fs)
+    A = 100.0
+    # amplitude override: build the IF by hand (no noise, no data bits)
+    code = P.codes.generateCAcode(7).astype(np.float64)
+    t = np.arange(n) / fs
+    chip = np.floor(np.arange(n) * (fc / fs)).astype(np.int64) % 1023
+    x = A * code[chip] * np.exp(1j * 2 * np.pi * (S.IF + sat.doppler) * t)
+    iq = np.empty(2 * n, dtype=np.int8)
+    iq[0::2] = np.rint(x.real)
+    iq[1::2] = np.rint(x.imag)
+    engine.load_if(iq, fs=fs)
+    engine.set_channel(0, [P.codes.padded_table(P.codes.generateCAcode(7))])
+    step = fc / fs
+    N = int(np.ceil(1023 / step))
+    # rem = 0: replica index ceil(n*step) picks chip floor(n*step) for every n > 0, i.e. exactly the
+    # chip the synthetic signal carries; only sample 0 reads the wrapped last chip (tracking.m:266-270)
+    d = dict(channel=0, n=N, s0=0, rem=0.0, step=step, d=0.5, f=S.IF + sat.doppler, phi=0.0)
+    got = engine.correlate(_blocks(engine, [d]))[0, 0]
+    ref = _oracle(iq, d, O.pad_code(O.generate_ca_code(7)))
+    assert np.abs(got - ref).max() < TOL * _scale(iq, d)
+    i_e, q_e, i_p, q_p, i_l, q_l = got
+    assert abs(i_p - A * N) < 0.01 * A * N
+    assert abs(q_p) < 0.01 * A * N
+    assert abs(np.hypot(i_e, q_e) - 0.5 * A * N) < 0.05 * A * N
+    assert abs(np.hypot(i_l, q_l) - 0.5 * A * N) < 0.05 * A * N
+
+
+def test_range_error_and_argument_checks(engine, l1ca_scene):
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene
+    engine.load_if(iq, fs=S.samplingFreq)
+    engine.set_channel(0, [O.pad_code(O.generate_ca_code(1)).astype(np.int8)])
+    d = dict(channel=0, n=18000, s0=iq.shape[0] // 2 - 17999, rem=0.0, step=1.023e6 / 18e6, d=0.5, f=2e4, phi=0.0)
+    with pytest.raises(P.GnssCorrError) as e:
+        engine.correlate(_blocks(engine, [d]))
+    assert e.value.status == P._lib.GC_E_RANGE  # short read, tracking.m:241-245
+    d.update(s0=0, channel=200)
+    with pytest.raises(P.GnssCorrError) as e:
+        engine.correlate(_blocks(engine, [d]))
+    assert e.value.status == P._lib.GC_E_STATE
+    assert engine.correlate(engine.make_blocks(0)).shape[0] == 0  # empty input
+
+
+def test_int16_and_qi_layouts(engine, l1ca_scene):
+    """int16 samples (tracking.m:145-148,212-213) and the GLONASS Q,I order
+    (GLO_GL1/include/tracking.m:227) go through the same kernel template."""
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene
+    iq = iq[:2 * 400000]
+    rng = np.random.default_rng(5)
+    descs = _random_descs(rng, 16, iq.shape[0] // 2, 1)
+    tab = O.pad_code(O.generate_ca_code(sats[0].prn))
+    engine.set_channel(0, [tab.astype(np.int8)])
+    # int16: scale by 37 so the high byte matters
+    iq16 = iq.astype(np.int16) * 37
+    engine.load_if(iq16, fs=S.samplingFreq)
+    got16 = engine.correlate(_blocks(engine, descs))[:, 0]
+    engine.load_if(iq, layout=P._lib.GC_QI, fs=S.samplingFreq)
+    gotqi = engine.correlate(_blocks(engine, descs))[:, 0]
+    for k, d in enumerate(descs):
+        ref = _oracle(iq, d, tab)
+        assert np.abs(got16[k] - 37 * ref).max() < TOL * 37 * _scale(iq, d)
+        sw, _, _ = CO.correlate_block(iq, d["s0"], d["n"], [tab], d["rem"], d["step"], d["d"], d["f"], d["phi"],
+                                      18e6, 1023.0, swap_iq=True)
+        assert np.abs(gotqi[k] - sw[0]).max() < TOL * _scale(iq, d)
