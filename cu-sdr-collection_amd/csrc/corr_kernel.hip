@@ -172,6 +172,12 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
   const double aP = rem * R;
   const double sp = step * R;
   const double tau = blk.carr_freq / p.fs;  // carrier turns per sample
+  // colon() end points b = ((N-1)*step + rem -/+ d) * R, evaluated in the reference's order
+  const double bP = __dmul_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), R);
+  const double bE = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), -d), R);
+  const double bL = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), d), R);
+  const float inv_spm = (float)(1.0 / (sp * M));
+  const float tie_tol = 1e-6f + 4e-7f * inv_spm;
 
   // lanes 0..7: delta^j and the fixed-point ramp increments j*sp*M; lane 8: chunk-stride terms
   float myC, myS;
@@ -247,6 +253,25 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
 #pragma unroll
         for (int x = 0; x < 3; ++x) sr[ar][x] = si[ar][x] = 0.0f;
 
+      // Near-tie filter.  The fixed-point ramp equals the real-number value a + i*d to ~2^-60 chip,
+      // whereas the reference evaluates fl(a + fl(i*d)) (and builds the second half of the colon
+      // vector backwards): the two can disagree on ceil() only when a sample sits within ~1e-13
+      // chip of a chip edge.  That is not measure-zero: with remCodePhase = 0 and the nominal code
+      // rate (every channel's first block, tracking.m:163-165) 1.023e6/18e6 is rational and samples
+      // 3000k land exactly on edges.  Sample j of this chunk is on an edge iff (g + m)/(sp*M) = j
+      // for an integer m, so test that quotient in float (tolerance >> rounding noise) and send
+      // the rare suspects through the exact double-precision path.
+      bool suspect = false;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const float g = (float)(unsigned int)(fx[x].G >> 32) * 2.3283064365386963e-10f;
+        for (int m = 0; m <= Ji[kSPL - 1]; ++m) {
+          const float u = (g + (float)m) * inv_spm;
+          suspect |= fabsf(u - rintf(u)) < tie_tol;
+        }
+      }
+      const bool exact = __any(suspect) != 0;  // wave-uniform: the exact path is ~1e-3 of wave-chunks
+
 #pragma unroll
       for (int j = 0; j < kSPL; ++j) {
         float yr = a[j] * C[j] + b[j] * S[j];
@@ -258,7 +283,24 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
         }
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-          int k = fx[x].k0 + Ji[j] + (Jf[j] > fx[x].G ? 1 : 0);
+          int k;
+          if (exact) {
+            // MATLAB colon element i (tracking.m:252-270): forwards from a for the first half,
+            // backwards from the end point b for the second, mean of both in the exact middle.
+            const int i = i0 + j;
+            const double ax = (x == 0) ? aE : (x == 1) ? aP : aL;
+            const double bx = (x == 0) ? bE : (x == 1) ? bP : bL;
+            double t;
+            if (2 * i < N - 1)
+              t = __dadd_rn(ax, __dmul_rn((double)i, sp));
+            else if (2 * i > N - 1)
+              t = __dadd_rn(bx, -__dmul_rn((double)(N - 1 - i), sp));
+            else
+              t = __dadd_rn(ax, bx) / 2.0;
+            k = (int)ceil(__dmul_rn(t, M));
+          } else {
+            k = fx[x].k0 + Ji[j] + (Jf[j] > fx[x].G ? 1 : 0);
+          }
 #pragma unroll
           for (int ar = 0; ar < ARMS; ++ar) {
             int kk = k;

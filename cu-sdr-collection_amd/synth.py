@@ -71,3 +71,43 @@ def generate_if(sats, n_samples: int, fs: float, intermediate_freq: float, code_
         out[sl][0::2] = i
         out[sl][1::2] = q
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU generator (libgnsssynth.so, csrc/synth.hip) — same signal model, counter-based noise
+# ---------------------------------------------------------------------------------------------
+def generate_if_gpu(engine, sats, n_samples: int, fs: float, intermediate_freq: float, code_fn,
+                    code_rate: float, code_len: int, seed: int, sigma: float = 20.0,
+                    carrier_ratio: float = 1540.0, bit_periods: int = 20) -> None:
+    """Allocates the engine's IF buffer (int8 I/Q) and fills it on the GPU."""
+    import ctypes as C
+    import os
+
+    class gs_sat(C.Structure):
+        _fields_ = [("prn", C.c_int32), ("code_index", C.c_int32), ("doppler", C.c_double),
+                    ("code_phase_samples", C.c_double), ("carrier_phase", C.c_double),
+                    ("amplitude", C.c_double), ("code_rate", C.c_double)]
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgnsssynth.so")
+    lib = C.CDLL(path)
+    lib.gs_generate.restype = C.c_int
+    lib.gs_generate.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int,
+                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_uint64]
+    engine.alloc_if(n_samples, np.int8)
+    engine.synchronize()
+    ptr, n = engine.if_buffer()
+    codes = np.ascontiguousarray(np.stack([np.asarray(code_fn(s.prn), dtype=np.int8) for s in sats]))
+    arr = (gs_sat * len(sats))()
+    for i, s in enumerate(sats):
+        arr[i].prn = s.prn
+        arr[i].code_index = i
+        arr[i].doppler = s.doppler
+        arr[i].code_phase_samples = s.code_phase_samples
+        arr[i].carrier_phase = s.carrier_phase
+        arr[i].amplitude = sigma * np.sqrt(2.0 * 10 ** (s.cn0_dbhz / 10.0) / fs)
+        arr[i].code_rate = code_rate + s.doppler / carrier_ratio * (code_rate / 1.023e6)
+    rc = lib.gs_generate(C.c_void_p(ptr), n_samples, engine.device_id, fs, intermediate_freq,
+                         codes.ctypes.data_as(C.c_void_p), len(sats), code_len, bit_periods, arr, len(sats),
+                         sigma, seed)
+    if rc != 0:
+        raise RuntimeError(f"gs_generate failed with {rc}")
