@@ -79,6 +79,7 @@ SYMBOLS = {
     "gc_set_code": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_double]),
     "gc_set_code_window": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "gc_set_sampling_freq": (C.c_int, [_P, C.c_double]),
+    "gc_force_generic_kernel": (C.c_int, [_P, C.c_int]),
     "gc_correlate": (C.c_int, [_P, C.c_int, C.POINTER(gc_block), C.POINTER(C.c_double)]),
     "gc_replay_prepare": (C.c_int, [_P, C.c_int64, C.POINTER(gc_block)]),
     "gc_replay_launch": (C.c_int, [_P]),

@@ -18,10 +18,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
 LIBS = {
-    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "track.hip", "acq.hip"],
+    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "track.hip", "acq.hip"],
     "libgnsssynth.so": ["synth.hip"],
 }
-HEADERS = ["gc_internal.h", os.path.join("..", "..", "include", "gnsscorr.h")]
+HEADERS = ["gc_internal.h", "corr_common.h", os.path.join("..", "..", "include", "gnsscorr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
          "-Wno-unused-function"]
 

@@ -84,6 +84,8 @@ struct gc_context {
   double* d_replay_out = nullptr;
   int64_t replay_nblocks = 0;
   int replay_max_arms = 1;
+  bool replay_fast = false;
+  bool force_generic = false;
 
   // acquisition scratch (acq.hip)
   void* acq_scratch = nullptr;
@@ -94,4 +96,7 @@ int gc_bytes_per_sample(int dtype, int layout);
 int gc_sync_channels(gc_context* ctx);
 // Launches the correlator for `nblocks` descriptors already on the device.
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
-                         double* d_out, double* d_partial, int max_arms);
+                         double* d_out, double* d_partial, int max_arms, bool fast);
+// True when every block may take the fast (single-transition-per-chunk) kernel.
+bool gc_block_is_lowrate(const gc_context* ctx, const gc_block& b);
+bool gc_fast_lds_ok(const gc_context* ctx);

@@ -107,6 +107,13 @@ int gc_synchronize(gc_context* ctx) {
   return GC_OK;
 }
 
+// Test hook: 1 forces the generic (per-sample table lookup) kernel even where the fast kernel applies.
+int gc_force_generic_kernel(gc_context* ctx, int on) {
+  if (!ctx) return GC_E_INVALID;
+  ctx->force_generic = on != 0;
+  return GC_OK;
+}
+
 int gc_set_sampling_freq(gc_context* ctx, double fs) {
   if (!ctx || !(fs > 0)) {
     gc_set_error("gc_set_sampling_freq: fs must be positive");
@@ -375,9 +382,18 @@ int gc_sync_channels(gc_context* ctx) {
   return GC_OK;
 }
 
+bool gc_block_is_lowrate(const gc_context* ctx, const gc_block& b) {
+  const HostChannel& c = ctx->ch[b.channel];
+  // at most one table transition per 8-sample lane-chunk, with a safety margin
+  return 7.0 * b.code_phase_step * c.index_scale * c.mult[0] < 0.995;
+}
+
+bool gc_fast_lds_ok(const gc_context* ctx) { return 8 * ctx->max_lds_bytes + 512 <= 64 * 1024; }
+
 // Validates descriptors on the host; returns the largest arm count among the referenced
-// channels, or a negative status.
-static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b) {
+// channels, or a negative status.  *all_lowrate is cleared if any block needs the generic kernel.
+static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, bool* all_lowrate) {
+  *all_lowrate = true;
   if (!ctx->d_if) {
     gc_set_error("no IF buffer loaded");
     return GC_E_STATE;
@@ -433,6 +449,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b) {
       }
     }
     max_arms = std::max(max_arms, c.arms);
+    if (!gc_block_is_lowrate(ctx, k)) *all_lowrate = false;
   }
   return max_arms;
 }
@@ -470,10 +487,12 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
   }
   if (nblocks == 0) return GC_OK;
   GC_HIP(hipSetDevice(ctx->device));
-  const int max_arms = validate_blocks(ctx, nblocks, blocks);
+  bool lowrate;
+  const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate);
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
+  const bool fast = lowrate && gc_fast_lds_ok(ctx) && !ctx->force_generic;
   const int splits = choose_splits(ctx, nblocks, blocks);
   if ((rc = ensure((void**)&ctx->d_blocks, &ctx->d_blocks_cap, nblocks, sizeof(gc_block)))) return rc;
   if ((rc = ensure((void**)&ctx->d_out, &ctx->d_out_cap, (int64_t)nblocks * GC_OUT_STRIDE, sizeof(double)))) return rc;
@@ -481,7 +500,7 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
       (rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, (int64_t)nblocks * splits * GC_OUT_STRIDE, sizeof(double))))
     return rc;
   GC_HIP(hipMemcpyAsync(ctx->d_blocks, blocks, sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
-  rc = gc_launch_correlator(ctx, ctx->d_blocks, nblocks, splits, ctx->d_out, ctx->d_partial, max_arms);
+  rc = gc_launch_correlator(ctx, ctx->d_blocks, nblocks, splits, ctx->d_out, ctx->d_partial, max_arms, fast);
   if (rc) return rc;
   GC_HIP(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)nblocks * GC_OUT_STRIDE, hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
@@ -494,10 +513,12 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
     return GC_E_INVALID;
   }
   GC_HIP(hipSetDevice(ctx->device));
-  const int max_arms = validate_blocks(ctx, nblocks, blocks);
+  bool lowrate;
+  const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate);
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
+  ctx->replay_fast = lowrate && gc_fast_lds_ok(ctx) && !ctx->force_generic;
   GC_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
   if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
@@ -530,7 +551,7 @@ int gc_replay_launch(gc_context* ctx) {
     if (rc) return rc;
   }
   return gc_launch_correlator(ctx, ctx->d_replay_blocks, ctx->replay_nblocks, splits, ctx->d_replay_out,
-                              ctx->d_partial, ctx->replay_max_arms);
+                              ctx->d_partial, ctx->replay_max_arms, ctx->replay_fast);
 }
 
 int gc_replay_fetch(gc_context* ctx, double* out) {

@@ -136,7 +136,9 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       ++nb;
     }
     if (nb == 0) break;
-    rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms);
+    bool fast = gc_fast_lds_ok(ctx) && !ctx->force_generic;
+    for (int k = 0; k < nb && fast; ++k) fast = gc_block_is_lowrate(ctx, blocks[k]);
+    rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast);
     if (rc) return rc;
     GC_HIP(hipStreamSynchronize(ctx->stream));
 

@@ -92,6 +92,9 @@ class Engine:
         L.check(self._lib.gc_read_if(self._ctx, first, n, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def force_generic_kernel(self, on: bool):
+        L.check(self._lib.gc_force_generic_kernel(self._ctx, int(bool(on))))
+
     def set_sampling_freq(self, fs: float):
         L.check(self._lib.gc_set_sampling_freq(self._ctx, float(fs)))
 

@@ -112,6 +112,10 @@ typedef struct gc_block {
   int32_t reserved;
 } gc_block;
 
+/* Test hook: non-zero forces the generic correlator kernel (per-sample table lookup) even where the
+ * fast single-transition kernel applies, so both can be checked against the oracle. */
+int gc_force_generic_kernel(gc_context* ctx, int on);
+
 /* Sampling frequency used for the carrier replica (settings.samplingFreq, tracking.m:280). */
 int gc_set_sampling_freq(gc_context* ctx, double fs);
 

@@ -172,3 +172,32 @@ def test_int16_and_qi_layouts(engine, l1ca_scene):
         sw, _, _ = CO.correlate_block(iq, d["s0"], d["n"], [tab], d["rem"], d["step"], d["d"], d["f"], d["phi"],
                                       18e6, 1023.0, swap_iq=True)
         assert np.abs(gotqi[k] - sw[0]).max() < TOL * _scale(iq, d)
+
+
+def test_fast_and_generic_kernels_agree_with_oracle(engine, l1ca_scene):
+    """GPS L1 C/A qualifies for the fast single-transition kernel (corr_fast.hip); the generic
+    per-sample-lookup kernel (corr_kernel.hip) must give the same sums.  Both vs the oracle,
+    including first-block ties (rem = 0 with the rational nominal step: samples 3000k sit exactly
+    on chip edges) at every head alignment."""
+    S, sats, iq = l1ca_scene
+    engine.load_if(iq, fs=S.samplingFreq)
+    tab = O.pad_code(O.generate_ca_code(sats[0].prn))
+    engine.set_channel(0, [tab.astype(np.int8)])
+    rng = np.random.default_rng(11)
+    descs = _random_descs(rng, 40, iq.shape[0] // 2, 1)
+    step0 = 1.023e6 / 18e6
+    for k in range(16):  # tie blocks
+        descs[k].update(rem=0.0, step=step0, n=18000, s0=1000 + k, phi=0.0)
+    b = _blocks(engine, descs)
+    try:
+        engine.force_generic_kernel(False)
+        fast = engine.correlate(b)[:, 0]
+        engine.force_generic_kernel(True)
+        gen = engine.correlate(b)[:, 0]
+    finally:
+        engine.force_generic_kernel(False)
+    for k, d in enumerate(descs):
+        ref = _oracle(iq, d, tab)
+        sc = _scale(iq, d)
+        assert np.abs(fast[k] - ref).max() < TOL * sc, ("fast", k, d)
+        assert np.abs(gen[k] - ref).max() < TOL * sc, ("generic", k, d)
