@@ -23,7 +23,7 @@ LIBS = {
 }
 HEADERS = ["gc_internal.h", "corr_common.h", os.path.join("..", "..", "include", "gnsscorr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-fno-slp-vectorize"]
 
 
 def _hipcc() -> str:

@@ -20,6 +20,8 @@ struct KArgs {
   int splits;
   int xcd_swizzle;
   int red_off;  // byte offset of the reduction scratch in dynamic LDS
+  int bpw;      // blocks per workgroup (fast kernel)
+  int stride;   // descriptor stride between consecutive blocks of one workgroup
 };
 
 // t = k0 - G / 2^64 ;  ceil(t + x) for x = xi + xf/2^64  is  k0 + xi + (xf > G)
@@ -101,4 +103,4 @@ __device__ __forceinline__ unsigned int rl_u(unsigned int v, int lane) {
 }  // namespace gcorr
 
 // corr_fast.hip
-int gc_launch_correlator_fast(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int max_arms);
+int gc_launch_correlator_fast(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int max_arms, bool spl16);

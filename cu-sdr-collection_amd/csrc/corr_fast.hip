@@ -1,15 +1,18 @@
 // corr_fast.hip — fast path of the E/P/L correlator for "low-rate" replicas: the table index
-// advances by less than one entry over a lane-chunk of 8 samples (7*step*R*M < 1: GPS L1 C/A 17.6
-// samples/chip, GLONASS 23.5, B1I / E1 BOC(1,1) / B1C BOC(1,1) 8.8, L2C 7.8).  Same arithmetic
-// contract as corr_kernel.hip (tracking.m:247-300), ~3x fewer VALU instructions per sample:
+// advances by less than one entry over a lane-chunk of SPL samples ((SPL-1)*step*R*M < 1).
+//   SPL = 16: GPS L1 C/A (17.6 samples/chip at 18 Msps), GLONASS (23.5)
+//   SPL =  8: B1I / E1 BOC(1,1) / B1C BOC(1,1) (8.8), L2C (7.8), and L1 C/A at lower rates
+// Same arithmetic contract as corr_kernel.hip (tracking.m:247-300), ~3-4x fewer VALU instructions
+// per sample:
 //
 //   * a lane-chunk sees at most ONE table transition per tap, so the replica over the chunk is
 //     c1 + dc*step(j - u): the six sums become c1*T + dc*S_x with T = sum_j y_j shared by all taps
 //     and arms and S_x = sum_j step(j - u_x)*y_j; step() is ONE full-rate VALU op
-//     (v_sub_f32 ... clamp), no compare / select / LDS gather per sample;
+//     (v_fma_f32 ... clamp), no compare / select / LDS gather per sample;
 //   * LDS holds {c[k], c[k+1]-c[k]} as float2, one ds_read_b64 per tap and arm per chunk;
-//   * int8 samples are converted with v_cvt_f32_ubyteN after xor 0x80 and the +128 offset is
-//     folded into the addend of the carrier FMAs (no extra instruction);
+//   * int8/int16 samples are converted by SDWA sign-extending v_cvt_f32_i32 (one op per component);
+//   * one wavefront per workgroup: no barrier and no cross-wave reduction; the next chunk's 16-byte
+//     loads are issued before the current chunk is processed;
 //   * the carrier base rotation is applied Horner-style to the accumulators (acc = acc*conj(rho) + U)
 //     and once more at the end with the exact per-thread phase;
 //   * the transition position u = g/(step*R*M) is a float quotient; chunks where any u is within
@@ -23,96 +26,163 @@ namespace {
 
 constexpr float kBig = 8388608.0f;  // 2^23: clamp(kBig*(j-u)) is exactly 0 or 1 outside the tie band
 constexpr float kTieTol = 4e-6f;
+constexpr int kFW = 64;  // one wavefront per workgroup
 
 template <int MODE>
-__device__ __forceinline__ void load_words(const uint8_t* __restrict__ base, long long q, unsigned int (&w)[8]) {
-  if constexpr (MODE == I8_IQ || MODE == I8_QI || MODE == I16_REAL) {
-    const uint4 v = *reinterpret_cast<const uint4*>(base + 16 * q);
-    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-  } else if constexpr (MODE == I16_IQ || MODE == I16_QI) {
-    const uint4 v0 = *reinterpret_cast<const uint4*>(base + 32 * q);
-    const uint4 v1 = *reinterpret_cast<const uint4*>(base + 32 * q + 16);
-    w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
-  } else {
-    const uint2 v = *reinterpret_cast<const uint2*>(base + 8 * q);
+struct Fmt {
+  static constexpr int bps = (MODE == I8_IQ || MODE == I8_QI || MODE == I16_REAL) ? 2 : (MODE == I8_REAL) ? 1 : 4;
+  static constexpr bool swap = (MODE == I8_QI || MODE == I16_QI);
+};
+
+template <int MODE, int SPL>
+__device__ __forceinline__ void load_words(const uint8_t* __restrict__ base, long long q,
+                                           unsigned int (&w)[SPL * Fmt<MODE>::bps / 4]) {
+  constexpr int NW = SPL * Fmt<MODE>::bps / 4;
+  const uint8_t* p = base + (long long)(SPL * Fmt<MODE>::bps) * q;
+  if constexpr (NW == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
     w[0] = v.x; w[1] = v.y;
+  } else {
+#pragma unroll
+    for (int k = 0; k < NW / 4; ++k) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * k);
+      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
   }
 }
 
 // Zero the samples of an edge chunk that lie outside [0, N): sample j is valid iff 0 <= i0+j < N.
-template <int MODE>
-__device__ __forceinline__ void mask_words(unsigned int (&w)[8], int i0, int N) {
-  constexpr int bits = (MODE == I8_IQ || MODE == I8_QI || MODE == I16_REAL) ? 16 : (MODE == I8_REAL) ? 8 : 32;
+template <int MODE, int SPL>
+__device__ __forceinline__ void mask_words(unsigned int (&w)[SPL * Fmt<MODE>::bps / 4], int i0, int N) {
+  constexpr int bits = 8 * Fmt<MODE>::bps;
   constexpr int per_word = 32 / bits;
 #pragma unroll
-  for (int j = 0; j < kSPL; ++j) {
+  for (int j = 0; j < SPL; ++j) {
     const bool valid = (unsigned int)(i0 + j) < (unsigned int)N;
     const unsigned int m = (bits == 32) ? 0xffffffffu : (((1u << bits) - 1u) << ((j % per_word) * bits));
     if (!valid) w[j / per_word] &= ~m;
   }
 }
 
-// Sample j of the chunk as floats (a, b) = (first, second) component in file order, offset by
-// OFS (128 for the xor-0x80 int8 path, 0 otherwise).
-template <int MODE>
-__device__ __forceinline__ void sample_ab(const unsigned int (&w)[8], int j, float& a, float& b) {
+#define GC_CVT_SDWA(sel)                                                                                  \
+  {                                                                                                       \
+    float r;                                                                                              \
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel : "=v"(r) : "v"(word)); \
+    return r;                                                                                             \
+  }
+template <int B>
+__device__ __forceinline__ float cvt_byte(unsigned int word) {
+  if constexpr (B == 0) GC_CVT_SDWA("BYTE_0")
+  else if constexpr (B == 1) GC_CVT_SDWA("BYTE_1")
+  else if constexpr (B == 2) GC_CVT_SDWA("BYTE_2")
+  else GC_CVT_SDWA("BYTE_3")
+}
+template <int H>
+__device__ __forceinline__ float cvt_half(unsigned int word) {
+  if constexpr (H == 0) GC_CVT_SDWA("WORD_0")
+  else GC_CVT_SDWA("WORD_1")
+}
+
+// Sample J of the chunk as floats (a, b) = (I, Q) after the layout's swap; b = 0 for real data.
+template <int MODE, int J, int NW>
+__device__ __forceinline__ void sample_ab(const unsigned int (&w)[NW], float& a, float& b) {
+  float x0, x1;
   if constexpr (MODE == I8_IQ || MODE == I8_QI) {
-    const unsigned int word = w[j >> 1] ^ 0x80808080u;
-    const int sh = (j & 1) * 16;
-    a = (float)((word >> sh) & 0xffu);        // v_cvt_f32_ubyteN
-    b = (float)((word >> (sh + 8)) & 0xffu);
+    x0 = cvt_byte<(J & 1) * 2>(w[J >> 1]);
+    x1 = cvt_byte<(J & 1) * 2 + 1>(w[J >> 1]);
   } else if constexpr (MODE == I16_IQ || MODE == I16_QI) {
-    a = (float)(int)(short)(w[j] & 0xffffu);
-    b = (float)(int)(short)(w[j] >> 16);
+    x0 = cvt_half<0>(w[J]);
+    x1 = cvt_half<1>(w[J]);
   } else if constexpr (MODE == I8_REAL) {
-    const unsigned int word = w[j >> 2] ^ 0x80808080u;
-    a = (float)((word >> ((j & 3) * 8)) & 0xffu);
-    b = 128.0f;
+    x0 = cvt_byte<J & 3>(w[J >> 2]);
+    x1 = 0.0f;
   } else {
-    a = (float)(int)(short)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-    b = 0.0f;
+    x0 = cvt_half<J & 1>(w[J >> 1]);
+    x1 = 0.0f;
+  }
+  a = Fmt<MODE>::swap ? x1 : x0;
+  b = Fmt<MODE>::swap ? x0 : x1;
+}
+
+// Wavefront sum with DPP row shifts / broadcasts (no LDS traffic); the total lands in lane 63.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value,
+                                                      decltype(row_mask)::value, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31
+  return v;
+}
+
+template <int J, int SPL, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (J < SPL) {
+    f(std::integral_constant<int, J>{});
+    static_for<J + 1, SPL>(f);
   }
 }
 
-template <int ARMS, int MODE>
-__global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
+template <int ARMS, int MODE, int SPL>
+__global__ __launch_bounds__(256) void corr_epl_fast_kernel(const KArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool kSwap = (MODE == I8_QI || MODE == I16_QI);
-  constexpr float kOfs = (MODE == I8_IQ || MODE == I8_QI || MODE == I8_REAL) ? 128.0f : 0.0f;
+  constexpr int NW = SPL * Fmt<MODE>::bps / 4;
+  constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
+  constexpr int kShift = (SPL == 16) ? 4 : 3;
 
   long long wg = blockIdx.x;
   if (p.xcd_swizzle) {
     const long long per = (long long)gridDim.x >> 3;
     wg = (wg & 7) * per + (wg >> 3);
   }
-  const long long lb = wg / p.splits;
-  const int split = (int)(wg - lb * p.splits);
-  const gc_block blk = p.blocks[lb];
-  const DevChannel* __restrict__ chn = p.chans + blk.channel;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int arms_here = chn->arms;
+  // Workgroup -> blocks.  With bpw > 1 (replay lists that interleave `stride` channels epoch by
+  // epoch) one workgroup walks bpw consecutive epochs of ONE channel, so the code table is staged
+  // into LDS once per bpw blocks; neighbouring workgroups hold the other channels of the same
+  // epochs and read the same IF window through the same L2.
+  const long long wq = wg / p.splits;
+  const int split = (int)(wg - wq * p.splits);
+  const long long grp = wq / p.stride;
+  const int cslot = (int)(wq - grp * p.stride);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
 
-  // ---- stage {c[k], c[k+1]-c[k]} for k = -1 .. nent (c[-1] := c[0], c[>=nent] := 0) ---------------
+  // ---- stage {c[k], c[k+1]-c[k]} for k = -1 .. nent (c[-1] := c[0], c[>=nent] := 0), once per
+  //      workgroup: the host guarantees that all blocks of a workgroup share channel and offsets
   float2* tab2[ARMS];
+  {
+    const long long lb0 = grp * p.bpw * p.stride + cslot;
+    const gc_block blk0 = p.blocks[lb0];
+    const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
 #pragma unroll
-  for (int a = 0; a < ARMS; ++a) {
-    const int aa = (a < arms_here) ? a : 0;
-    tab2[a] = reinterpret_cast<float2*>(smem + 8 * (size_t)chn->lds_off[aa]);
-    if (a < arms_here) {
-      const int off = blk.table_offset[a];
-      const int n = min(chn->stage_len[a], chn->nent[a] - off);
-      const int8_t* __restrict__ src = chn->tab[a] + off;
-      for (int i = tid; i < n + 3; i += kWG) {
-        const int k = i - 1;  // table index of .x
-        const float c0 = (k < 0) ? (float)src[0] : (k < n) ? (float)src[k] : 0.0f;
-        const float c1 = (k + 1 < n) ? (float)src[k + 1] : 0.0f;
-        tab2[a][i] = make_float2(c0, c1 - c0);
+    for (int a = 0; a < ARMS; ++a) {
+      const int aa = (a < chn0->arms) ? a : 0;
+      tab2[a] = reinterpret_cast<float2*>(smem + 8 * (size_t)chn0->lds_off[aa]);
+      if (a < chn0->arms) {
+        const int off = blk0.table_offset[a];
+        const int n = min(chn0->stage_len[a], chn0->nent[a] - off);
+        const int8_t* __restrict__ src = chn0->tab[a] + off;
+        for (int i = threadIdx.x; i < n + 3; i += blockDim.x) {
+          const int k = i - 1;  // table index of .x
+          const float c0 = (k < 0) ? (float)src[0] : (k < n) ? (float)src[k] : 0.0f;
+          const float c1 = (k + 1 < n) ? (float)src[k + 1] : 0.0f;
+          tab2[a][i] = make_float2(c0, c1 - c0);
+        }
       }
     }
+    __syncthreads();
   }
-  float* red = reinterpret_cast<float*>(smem + p.red_off);
-  __syncthreads();
+
+  for (int bi = wave; bi < p.bpw; bi += nwaves) {
+  const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
+  if (lb >= p.nblocks) break;
+  const gc_block blk = p.blocks[lb];
+  const DevChannel* __restrict__ chn = p.chans + blk.channel;
+  const int arms_here = chn->arms;
 
   // ---- per-block uniform quantities (see corr_kernel.hip for the reference line citations) --------
   const double R = chn->index_scale;
@@ -133,17 +203,15 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
   const float uk = (float)(1.0 / (sp * M) * 2.3283064365386963e-10);  // g_hi (2^-32 units) -> u
   const float ukB = uk * kBig;
 
-  // lanes 0..7: delta^j = exp(-i*2*pi*j*tau) with the +128 offset terms; lane 8: chunk stride
+  // lanes 0..SPL-1: delta^j = exp(-i*2*pi*j*tau); lane SPL: the chunk stride SPL*kFW samples
   float myC, myS;
   unsigned int myJlo, myJhi;
   int myJint;
   {
-    const int j = (lane < 8) ? lane : kSPL * kWG;
+    const int j = (lane < SPL) ? lane : SPL * kFW;
     const double x = (double)j * tau;
-    double sn, cs;
-    sincospi(2.0 * (x - floor(x)), &sn, &cs);
-    myC = (float)cs;
-    myS = (float)sn;
+    // range reduction in double, sincos in float
+    sincospif(2.0f * (float)(x - floor(x)), &myS, &myC);
     const double y = (double)j * (sp * M);
     const double yi = floor(y);
     const unsigned long long jf = frac_to_u64(y - yi);
@@ -151,22 +219,19 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
     myJlo = (unsigned int)jf;
     myJhi = (unsigned int)(jf >> 32);
   }
-  float C[kSPL], S[kSPL], KR[kSPL], KI[kSPL], KJ[kSPL];
+  float C[SPL], S[SPL], KJ[SPL];
 #pragma unroll
-  for (int j = 0; j < kSPL; ++j) {
+  for (int j = 0; j < SPL; ++j) {
     C[j] = rl_f(myC, j);
     S[j] = rl_f(myS, j);
-    // y = (a + i b)(C - i S) with (a, b) = (ua - 128, ub - 128):  constants of the folded offset
-    KR[j] = -kOfs * (C[j] + S[j]);
-    KI[j] = -kOfs * (C[j] - S[j]);
     KJ[j] = (float)j * kBig;
   }
-  const float rotC = rl_f(myC, 8), rotS = rl_f(myS, 8);
-  const unsigned long long Df = ((unsigned long long)rl_u(myJhi, 8) << 32) | rl_u(myJlo, 8);
-  const int Di = __builtin_amdgcn_readlane(myJint, 8);
+  const float rotC = rl_f(myC, SPL), rotS = rl_f(myS, SPL);
+  const unsigned long long Df = ((unsigned long long)rl_u(myJhi, SPL) << 32) | rl_u(myJlo, SPL);
+  const int Di = __builtin_amdgcn_readlane(myJint, SPL);
 
-  const long long q0 = s0 >> 3;
-  const long long q1 = (s0 + N - 1) >> 3;
+  const long long q0 = s0 >> kShift;
+  const long long q1 = (s0 + N - 1) >> kShift;
   const int nchunks = (int)(q1 - q0 + 1);
   const int cps = (nchunks + p.splits - 1) / p.splits;
   const int cbeg = split * cps;
@@ -178,10 +243,10 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
 #pragma unroll
     for (int x = 0; x < 3; ++x) accr[a][x] = acci[a][x] = 0.0f;
 
-  int c = cbeg + tid;
+  int c = cbeg + lane;
   float wc = 1.0f, ws = 0.0f;
   if (c < cend) {
-    int i0 = (int)((q0 + c) * kSPL - s0);
+    int i0 = (int)((q0 + c) * SPL - s0);
     Fx fx[3];
     const double isp = __dmul_rn((double)i0, sp);
     fx[0] = to_fx(__dmul_rn(__dadd_rn(aE, isp), M));
@@ -189,20 +254,24 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
     fx[2] = to_fx(__dmul_rn(__dadd_rn(aL, isp), M));
     const uint8_t* __restrict__ base = p.if_base;
 
-    for (; c < cend; c += kWG) {
-      unsigned int w[8];
-      load_words<MODE>(base, q0 + c, w);
-      if ((i0 < 0) | (i0 + kSPL > N)) mask_words<MODE>(w, i0, N);
+    unsigned int w[NW];
+    load_words<MODE, SPL>(base, q0 + c, w);
+    while (true) {
+      // issue the next chunk's loads before touching this one
+      const int cn = c + kFW;
+      unsigned int wn[NW];
+      if (cn < cend) load_words<MODE, SPL>(base, q0 + cn, wn);
+
+      if (__builtin_expect((i0 < 0) | (i0 + SPL > N), 0)) mask_words<MODE, SPL>(w, i0, N);
 
       // transition positions and the near-tie filter
-      float u[3], uB[3];
+      float gh[3];
       bool suspect = false;
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
-        const float gh = (float)(unsigned int)(fx[x].G >> 32);
-        u[x] = gh * uk;
-        uB[x] = gh * ukB;
-        suspect |= fabsf(u[x] - rintf(u[x])) < kTieTol;
+        gh[x] = (float)(unsigned int)(fx[x].G >> 32);
+        const float u = gh[x] * uk;
+        suspect |= fabsf(u - rintf(u)) < kTieTol;
       }
 
       float Ur[ARMS][3], Ui[ARMS][3];
@@ -212,13 +281,12 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
         for (int ar = 0; ar < ARMS; ++ar)
 #pragma unroll
           for (int x = 0; x < 3; ++x) Ur[ar][x] = Ui[ar][x] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kSPL; ++j) {
+        static_for<0, SPL>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
           float a, b;
-          sample_ab<MODE>(w, j, a, b);
-          if (kSwap) { const float t = a; a = b; b = t; }
-          const float yr = fmaf(a, C[j], fmaf(b, S[j], KR[j]));
-          const float yi = fmaf(b, C[j], fmaf(a, -S[j], KI[j]));
+          sample_ab<MODE, j, NW>(w, a, b);
+          const float yr = kReal ? a * C[j] : fmaf(a, C[j], b * S[j]);
+          const float yi = kReal ? -a * S[j] : fmaf(b, C[j], -a * S[j]);
           const int i = i0 + j;
 #pragma unroll
           for (int x = 0; x < 3; ++x) {
@@ -241,26 +309,26 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
               Ui[ar][x] = fmaf(cf, yi, Ui[ar][x]);
             }
           }
-        }
+        });
       } else {
         // ---- fast path ------------------------------------------------------------------------------
         float Tr = 0.f, Ti = 0.f, Sr[3] = {0.f, 0.f, 0.f}, Si[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < kSPL; ++j) {
+        static_for<0, SPL>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
           float a, b;
-          sample_ab<MODE>(w, j, a, b);
-          if (kSwap) { const float t = a; a = b; b = t; }
-          const float yr = fmaf(a, C[j], fmaf(b, S[j], KR[j]));
-          const float yi = fmaf(b, C[j], fmaf(a, -S[j], KI[j]));
+          sample_ab<MODE, j, NW>(w, a, b);
+          const float yr = kReal ? a * C[j] : fmaf(a, C[j], b * S[j]);
+          const float yi = kReal ? -a * S[j] : fmaf(b, C[j], -a * S[j]);
           Tr += yr;
           Ti += yi;
 #pragma unroll
           for (int x = 0; x < 3; ++x) {
-            const float s = __builtin_amdgcn_fmed3f(KJ[j] - uB[x], 0.0f, 1.0f);  // clamp: 1 iff j > u
+            // 1 iff j > u  (v_fma_f32 ... clamp)
+            const float s = __builtin_amdgcn_fmed3f(fmaf(-gh[x], ukB, KJ[j]), 0.0f, 1.0f);
             Sr[x] = fmaf(s, yr, Sr[x]);
             Si[x] = fmaf(s, yi, Si[x]);
           }
-        }
+        });
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
 #pragma unroll
@@ -271,7 +339,7 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
           }
         }
       }
-      // Horner step: acc = acc * conj(rho) + U, rho = delta^2048 = rotC - i rotS
+      // Horner step: acc = acc * conj(rho) + U, rho = delta^(SPL*kFW) = rotC - i rotS
 #pragma unroll
       for (int ar = 0; ar < ARMS; ++ar)
 #pragma unroll
@@ -281,52 +349,42 @@ __global__ __launch_bounds__(kWG) void corr_epl_fast_kernel(const KArgs p) {
           accr[ar][x] = nr;
           acci[ar][x] = ni;
         }
+      if (cn >= cend) break;
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
         const unsigned long long g = fx[x].G;
         fx[x].k0 += Di + (g < Df ? 1 : 0);
         fx[x].G = g - Df;
       }
-      i0 += kSPL * kWG;
+      i0 += SPL * kFW;
+      c = cn;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) w[k] = wn[k];
     }
     // exact carrier phase at the first sample of this thread's LAST chunk
-    const int i_last = i0 - kSPL * kWG;
-    const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i_last * tau;
+    const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i0 * tau;
     sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
   }
 
-  // ---- rotate into the absolute frame, reduce across the wave and the 4 waves -------------------------
-  const int wave = tid >> 6;
+  // ---- rotate into the absolute frame and reduce across the wavefront (DPP) ------------------------
+  double* o = (p.splits == 1) ? p.out + lb * GC_OUT_STRIDE : p.partial + (lb * p.splits + split) * GC_OUT_STRIDE;
+  float tot[ARMS * 6];
 #pragma unroll
   for (int ar = 0; ar < ARMS; ++ar)
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
-      float vr = wc * accr[ar][x] + ws * acci[ar][x];
-      float vi = wc * acci[ar][x] - ws * accr[ar][x];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        vr += __shfl_down(vr, off, 64);
-        vi += __shfl_down(vi, off, 64);
-      }
-      if (lane == 0) {
-        red[(wave * ARMS + ar) * 6 + 2 * x] = vr;
-        red[(wave * ARMS + ar) * 6 + 2 * x + 1] = vi;
-      }
+      tot[ar * 6 + 2 * x] = wave_sum_lane63(wc * accr[ar][x] + ws * acci[ar][x]);
+      tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(wc * acci[ar][x] - ws * accr[ar][x]);
     }
-  __syncthreads();
-  if (tid < ARMS * 6) {
-    double s = 0.0;
+  if (lane == 63) {
 #pragma unroll
-    for (int wv = 0; wv < kWG / 64; ++wv) s += (double)red[wv * ARMS * 6 + tid];
-    if (tid >= arms_here * 6) s = 0.0;
-    if (p.splits == 1)
-      p.out[lb * GC_OUT_STRIDE + tid] = s;
-    else
-      p.partial[(lb * p.splits + split) * GC_OUT_STRIDE + tid] = s;
+    for (int v = 0; v < ARMS * 6; ++v) o[v] = (v < arms_here * 6) ? (double)tot[v] : 0.0;
+    for (int v = ARMS * 6; v < GC_OUT_STRIDE; ++v) o[v] = 0.0;
   }
+  }  // bpw loop
 }
 
-template <int ARMS>
+template <int ARMS, int SPL>
 int launch_fast_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
   int mode;
   if (ctx->if_dtype == GC_I8)
@@ -334,12 +392,12 @@ int launch_fast_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
   else
     mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
   switch (mode) {
-    case I8_IQ: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_IQ>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I8_QI: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_QI>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I16_IQ: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_IQ>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I16_QI: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_QI>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I8_REAL: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_REAL>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    default: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_REAL>), grid, dim3(kWG), smem, ctx->stream, a); break;
+    case I8_IQ: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_IQ, SPL>), grid, dim3(kFW), smem, ctx->stream, a); break;
+    case I8_QI: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_QI, SPL>), grid, dim3(kFW), smem, ctx->stream, a); break;
+    case I16_IQ: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_IQ, 8>), grid, dim3(kFW), smem, ctx->stream, a); break;
+    case I16_QI: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_QI, 8>), grid, dim3(kFW), smem, ctx->stream, a); break;
+    case I8_REAL: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_REAL, 8>), grid, dim3(kFW), smem, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_REAL, 8>), grid, dim3(kFW), smem, ctx->stream, a); break;
   }
   GC_HIP(hipGetLastError());
   return GC_OK;
@@ -347,12 +405,21 @@ int launch_fast_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
 
 }  // namespace
 
-int gc_launch_correlator_fast(gc_context* ctx, const KArgs& a, unsigned int grid, int max_arms) {
-  // float2 tables: 8 bytes per staged entry (+3 pad entries per arm) — lds_off is in entries here
-  const size_t smem = (size_t)a.red_off + kWG / 64 * GC_OUT_STRIDE * sizeof(float);
+// spl16: every block satisfies 15*step*R*M < 1 and the samples are int8 I/Q
+int gc_launch_correlator_fast(gc_context* ctx, const KArgs& a, unsigned int grid, int max_arms, bool spl16) {
+  // float2 tables: 8 bytes per staged entry (lds_off counts entries here)
+  const size_t smem = (size_t)a.red_off + 64;
+  const bool wide = spl16 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
+  if (wide) {
+    switch (max_arms) {
+      case 1: return launch_fast_mode<1, 16>(ctx, a, dim3(grid), smem);
+      case 2: return launch_fast_mode<2, 16>(ctx, a, dim3(grid), smem);
+      default: return launch_fast_mode<3, 16>(ctx, a, dim3(grid), smem);
+    }
+  }
   switch (max_arms) {
-    case 1: return launch_fast_mode<1>(ctx, a, dim3(grid), smem);
-    case 2: return launch_fast_mode<2>(ctx, a, dim3(grid), smem);
-    default: return launch_fast_mode<3>(ctx, a, dim3(grid), smem);
+    case 1: return launch_fast_mode<1, 8>(ctx, a, dim3(grid), smem);
+    case 2: return launch_fast_mode<2, 8>(ctx, a, dim3(grid), smem);
+    default: return launch_fast_mode<3, 8>(ctx, a, dim3(grid), smem);
   }
 }

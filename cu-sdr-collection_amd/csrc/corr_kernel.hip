@@ -306,7 +306,7 @@ int launch_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
 }  // namespace
 
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
-                         double* d_out, double* d_partial, int max_arms, bool fast) {
+                         double* d_out, double* d_partial, int max_arms, int fast, int period) {
   if (nblocks <= 0) return GC_OK;
   KArgs a;
   a.if_base = ctx->d_if;
@@ -318,7 +318,16 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   a.nblocks = nblocks;
   a.splits = splits;
   a.red_off = ctx->max_lds_bytes;
-  const long long total = (long long)nblocks * splits;
+  a.bpw = 1;
+  a.stride = 1;
+  long long total = (long long)nblocks * splits;
+  if (fast && splits == 1 && period > 0 && nblocks >= 64 * (long long)period * ctx->compute_units) {
+    // big periodic list (all table offsets zero): one single-wave workgroup stages the channel's
+    // table once and walks 8 consecutive epochs (a 4-wave workgroup sharing the table measured 10 % slower)
+    a.bpw = 8;
+    a.stride = period;
+    total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
+  }
   a.xcd_swizzle = (total % 8 == 0 && total >= 64) ? 1 : 0;
   if (total > 0x7fffffffLL) {
     gc_set_error("too many workgroups (%lld)", total);
@@ -329,7 +338,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   int rc;
   if (fast) {
     a.red_off = 8 * ctx->max_lds_bytes;  // float2 {c, dc} tables: 8 bytes per staged entry
-    rc = gc_launch_correlator_fast(ctx, a, (unsigned int)total, max_arms);
+    rc = gc_launch_correlator_fast(ctx, a, (unsigned int)total, max_arms, fast == 2);
   } else {
     switch (max_arms) {
       case 1: rc = launch_mode<1>(ctx, a, grid, smem); break;

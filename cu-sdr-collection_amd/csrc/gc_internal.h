@@ -84,7 +84,8 @@ struct gc_context {
   double* d_replay_out = nullptr;
   int64_t replay_nblocks = 0;
   int replay_max_arms = 1;
-  bool replay_fast = false;
+  int replay_fast = 0;
+  int replay_period = 0;  // channel pattern period of the replay list (0 = not periodic)
   bool force_generic = false;
 
   // acquisition scratch (acq.hip)
@@ -96,7 +97,8 @@ int gc_bytes_per_sample(int dtype, int layout);
 int gc_sync_channels(gc_context* ctx);
 // Launches the correlator for `nblocks` descriptors already on the device.
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
-                         double* d_out, double* d_partial, int max_arms, bool fast);
-// True when every block may take the fast (single-transition-per-chunk) kernel.
-bool gc_block_is_lowrate(const gc_context* ctx, const gc_block& b);
+                         double* d_out, double* d_partial, int max_arms, int fast, int period = 0);
+// Kernel class a block qualifies for: 0 = generic only, 1 = fast kernel with 8-sample lane-chunks,
+// 2 = fast kernel with 16-sample lane-chunks (at most one table transition per chunk and tap).
+int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b);
 bool gc_fast_lds_ok(const gc_context* ctx);

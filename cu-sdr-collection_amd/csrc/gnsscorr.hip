@@ -382,18 +382,19 @@ int gc_sync_channels(gc_context* ctx) {
   return GC_OK;
 }
 
-bool gc_block_is_lowrate(const gc_context* ctx, const gc_block& b) {
+int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b) {
   const HostChannel& c = ctx->ch[b.channel];
-  // at most one table transition per 8-sample lane-chunk, with a safety margin
-  return 7.0 * b.code_phase_step * c.index_scale * c.mult[0] < 0.995;
+  // at most one table transition per lane-chunk (8 or 16 samples), with a safety margin
+  const double s = b.code_phase_step * c.index_scale * c.mult[0];
+  return (15.0 * s < 0.995) ? 2 : (7.0 * s < 0.995) ? 1 : 0;
 }
 
 bool gc_fast_lds_ok(const gc_context* ctx) { return 8 * ctx->max_lds_bytes + 512 <= 64 * 1024; }
 
 // Validates descriptors on the host; returns the largest arm count among the referenced
 // channels, or a negative status.  *all_lowrate is cleared if any block needs the generic kernel.
-static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, bool* all_lowrate) {
-  *all_lowrate = true;
+static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* all_lowrate) {
+  *all_lowrate = 2;
   if (!ctx->d_if) {
     gc_set_error("no IF buffer loaded");
     return GC_E_STATE;
@@ -449,7 +450,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, bool* 
       }
     }
     max_arms = std::max(max_arms, c.arms);
-    if (!gc_block_is_lowrate(ctx, k)) *all_lowrate = false;
+    *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
   }
   return max_arms;
 }
@@ -469,12 +470,13 @@ static int ensure(void** p, int64_t* cap, int64_t need, size_t elem) {
 }
 
 // Number of workgroups per block for small launches: aim at >= 2 workgroups per CU.
-static int choose_splits(gc_context* ctx, int64_t nblocks, const gc_block* b) {
-  if (nblocks >= 2 * (int64_t)ctx->compute_units) return 1;
+static int choose_splits(gc_context* ctx, int64_t nblocks, const gc_block* b, int wg_threads, int spl) {
+  if (nblocks * (wg_threads / 64) >= 8 * (int64_t)ctx->compute_units) return 1;
   int min_chunks = 1 << 30;
-  for (int64_t i = 0; i < nblocks; ++i) min_chunks = std::min(min_chunks, b[i].blksize / 8 + 1);
-  int s = (int)((2 * (int64_t)ctx->compute_units + nblocks - 1) / nblocks);
-  s = std::min(s, std::max(1, min_chunks / 256));  // keep >= 256 chunks (one per thread) per split
+  for (int64_t i = 0; i < nblocks; ++i) min_chunks = std::min(min_chunks, b[i].blksize / spl + 1);
+  // aim at ~8 wavefronts per CU, but keep at least two chunks per thread in every split
+  int s = (int)((8 * (int64_t)ctx->compute_units * 64 / wg_threads + nblocks - 1) / nblocks);
+  s = std::min(s, std::max(1, min_chunks / (2 * wg_threads)));
   return std::max(1, std::min(s, 64));
 }
 
@@ -487,13 +489,13 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
   }
   if (nblocks == 0) return GC_OK;
   GC_HIP(hipSetDevice(ctx->device));
-  bool lowrate;
+  int lowrate;
   const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate);
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
-  const bool fast = lowrate && gc_fast_lds_ok(ctx) && !ctx->force_generic;
-  const int splits = choose_splits(ctx, nblocks, blocks);
+  const int fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
+  const int splits = choose_splits(ctx, nblocks, blocks, fast ? 64 : 256, fast == 2 ? 16 : 8);
   if ((rc = ensure((void**)&ctx->d_blocks, &ctx->d_blocks_cap, nblocks, sizeof(gc_block)))) return rc;
   if ((rc = ensure((void**)&ctx->d_out, &ctx->d_out_cap, (int64_t)nblocks * GC_OUT_STRIDE, sizeof(double)))) return rc;
   if (splits > 1 &&
@@ -513,12 +515,12 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
     return GC_E_INVALID;
   }
   GC_HIP(hipSetDevice(ctx->device));
-  bool lowrate;
+  int lowrate;
   const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate);
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
-  ctx->replay_fast = lowrate && gc_fast_lds_ok(ctx) && !ctx->force_generic;
+  ctx->replay_fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
   if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
@@ -534,6 +536,21 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   GC_HIP(hipStreamSynchronize(ctx->stream));
   ctx->replay_nblocks = nblocks;
   ctx->replay_max_arms = max_arms;
+  // channel pattern period: blocks[i].channel == blocks[i % P].channel (epoch-major replay lists)
+  int period = 0;
+  for (int64_t i = 1; i < nblocks && i <= GC_MAX_CHANNELS; ++i)
+    if (blocks[i].channel == blocks[0].channel) {
+      period = (int)i;
+      break;
+    }
+  if (period > 0)
+    for (int64_t i = 0; i < nblocks; ++i)
+      if ((i >= period && blocks[i].channel != blocks[i - period].channel) || blocks[i].table_offset[0] != 0 ||
+          blocks[i].table_offset[1] != 0 || blocks[i].table_offset[2] != 0) {
+        period = 0;
+        break;
+      }
+  ctx->replay_period = period;
   return GC_OK;
 }
 
@@ -544,14 +561,15 @@ int gc_replay_launch(gc_context* ctx) {
   }
   GC_HIP(hipSetDevice(ctx->device));
   int splits = 1;
-  if (ctx->replay_nblocks < 2 * (int64_t)ctx->compute_units) {
-    // small replay sets: same split heuristic as gc_correlate, scratch from d_partial
-    splits = (int)std::min<int64_t>(8, (2 * (int64_t)ctx->compute_units + ctx->replay_nblocks - 1) / ctx->replay_nblocks);
+  const int wg_waves = ctx->replay_fast ? 1 : 4;
+  if (ctx->replay_nblocks * wg_waves < 8 * (int64_t)ctx->compute_units) {
+    // small replay sets: split blocks over several workgroups, scratch from d_partial
+    splits = (int)std::min<int64_t>(8, (8 * (int64_t)ctx->compute_units / wg_waves + ctx->replay_nblocks - 1) / ctx->replay_nblocks);
     int rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, ctx->replay_nblocks * splits * GC_OUT_STRIDE, sizeof(double));
     if (rc) return rc;
   }
   return gc_launch_correlator(ctx, ctx->d_replay_blocks, ctx->replay_nblocks, splits, ctx->d_replay_out,
-                              ctx->d_partial, ctx->replay_max_arms, ctx->replay_fast);
+                              ctx->d_partial, ctx->replay_max_arms, ctx->replay_fast, ctx->replay_period);
 }
 
 int gc_replay_fetch(gc_context* ctx, double* out) {

@@ -7,6 +7,7 @@
 // costs one kernel launch and one stream synchronisation.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "gc_internal.h"
 
@@ -71,8 +72,21 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
 
   // splits: fill the device with one epoch's worth of blocks
   const int approx_chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / 8.0) + 1;
-  int splits = (2 * ctx->compute_units + nch - 1) / nch;
-  splits = std::max(1, std::min(std::min(splits, 32), std::max(1, approx_chunks / 256)));
+  // nominal kernel choice (per-epoch blocks are re-checked below): the fast kernel runs one
+  // wavefront per workgroup, the generic one four
+  int fast_nominal = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
+  for (int c = 0; c < nch && fast_nominal; ++c) {
+    gc_block probe;
+    std::memset(&probe, 0, sizeof probe);
+    probe.channel = init[c].channel;
+    probe.code_phase_step = init[c].code_freq * 1.001 / p->sampling_freq;
+    fast_nominal = std::min(fast_nominal, gc_block_lowrate_level(ctx, probe));
+  }
+  const int wg_threads = fast_nominal ? 64 : 256;
+  const int chunks_nominal = approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8);
+  int splits = (8 * ctx->compute_units * 64 / wg_threads + nch - 1) / nch;
+  splits = std::max(1, std::min(std::min(splits, 32), std::max(1, chunks_nominal / (2 * wg_threads))));
+  if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));
 
   // pinned, device-visible descriptor and result buffers
   if (ctx->pinned_cap_blocks < nch * 32) {
@@ -136,8 +150,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       ++nb;
     }
     if (nb == 0) break;
-    bool fast = gc_fast_lds_ok(ctx) && !ctx->force_generic;
-    for (int k = 0; k < nb && fast; ++k) fast = gc_block_is_lowrate(ctx, blocks[k]);
+    int fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
+    for (int k = 0; k < nb && fast; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
     rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast);
     if (rc) return rc;
     GC_HIP(hipStreamSynchronize(ctx->stream));
