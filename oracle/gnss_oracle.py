@@ -293,12 +293,13 @@ def tracking_l1ca(if_bytes: np.ndarray, channel, settings, correlate=None):
     adapt = 1 if settings.fileType == 1 else 2
     n_total = if_bytes.shape[0] // adapt
     results = []
-    for ch in channel:
+    for _ in channel:  # trackResults = repmat(trackResults, 1, numberOfChannels), tracking.m:47-86
         tr = SimpleNamespace(status="-", PRN=0)
         for f in TRACK_FIELDS:
             setattr(tr, f, np.zeros(code_periods))
         tr.CNo = SimpleNamespace(VSMValue=[], VSMIndex=[])
         results.append(tr)
+    for tr, ch in zip(results, channel):
         if ch.PRN == 0:
             continue
         tr.PRN = ch.PRN

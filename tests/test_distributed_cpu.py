@@ -1,0 +1,50 @@
+"""The N > 1 control plane of bench.py on CPU: world_size-2 gloo — channel sharding is disjoint and
+complete, the barrier + MAX-over-ranks timing reduction works, and rank 0 alone reports."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from cu_sdr_collection_amd.sharding import shard_channels
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    mine = shard_channels(13, world, rank)
+    # every rank times its own (fake) work; the job time is the MAX over ranks
+    elapsed = 0.5 + rank
+    dist.barrier()
+    t = torch.tensor([elapsed, float(len(mine))], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, float(t[0]), gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world_size_two_control_plane():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, tmax, gathered in res:
+        assert tmax == 1.5  # MAX over ranks
+        assert sorted(gathered[0] + gathered[1]) == list(range(13))
+        assert not set(gathered[0]) & set(gathered[1])

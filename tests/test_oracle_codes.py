@@ -1,0 +1,52 @@
+"""Known-answer tests that pin the code generators: the reference ships no
+vectors, so the pins are the public ICD values."""
+import numpy as np
+
+from oracle import c_oracle as CO
+from oracle import gnss_oracle as O
+
+# IS-GPS-200 Table 3-Ia, "first 10 chips, octal" for PRN 1..32
+ICD_FIRST10_OCTAL = [0o1440, 0o1620, 0o1710, 0o1744, 0o1133, 0o1455, 0o1131, 0o1454, 0o1626, 0o1504,
+                     0o1642, 0o1750, 0o1764, 0o1772, 0o1775, 0o1776, 0o1156, 0o1467, 0o1633, 0o1715,
+                     0o1746, 0o1763, 0o1063, 0o1706, 0o1743, 0o1761, 0o1770, 0o1774, 0o1127, 0o1453,
+                     0o1625, 0o1712]
+
+
+def _first10(code):
+    return int("".join("1" if v > 0 else "0" for v in code[:10]), 2)
+
+
+def test_ca_code_first_ten_chips_match_icd():
+    for prn, want in enumerate(ICD_FIRST10_OCTAL, start=1):
+        assert _first10(O.generate_ca_code(prn)) == want, prn  # logic 1 -> +1 (generateCAcode.m:90)
+
+
+def test_ca_code_three_implementations_agree():
+    import cu_sdr_collection_amd as P
+    for prn in range(1, 52):  # incl. the SBAS shifts of generateCAcode.m:47-50
+        a = O.generate_ca_code(prn)
+        assert np.array_equal(a, CO.generate_ca(prn))
+        assert np.array_equal(a, P.codes.generateCAcode(prn).astype(np.float64))
+
+
+def test_ca_code_gold_properties():
+    for prn in (1, 7, 19, 32):
+        c = O.generate_ca_code(prn)
+        assert set(np.unique(c)) == {-1.0, 1.0} and c.shape == (1023,)
+        assert c.sum() == 1.0  # balance: 512 ones, 511 zeros with logic 1 -> +1
+        ac = np.array([np.dot(c, np.roll(c, k)) for k in range(1, 1023)])
+        assert set(np.unique(ac)) <= {-1.0, 63.0, -65.0}
+    x = np.dot(O.generate_ca_code(3), np.roll(O.generate_ca_code(11), 77))
+    assert x in (-1.0, 63.0, -65.0)
+
+
+def test_sampled_table_matches_product_side():
+    import cu_sdr_collection_amd as P
+    S = P.initSettings()
+    for prn in (1, 17, 32):
+        t = O.make_ca_table(prn, S)
+        assert t.shape == (18000,)
+        assert np.array_equal(t, P.codes.makeCaTable(prn, S).astype(np.float64))
+        assert t[-1] == O.generate_ca_code(prn)[1022]  # makeCaTable.m:62 forces the last index
+    assert np.array_equal(O.pad_code(O.generate_ca_code(5)),
+                          P.codes.padded_table(P.codes.generateCAcode(5)).astype(np.float64))

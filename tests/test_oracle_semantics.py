@@ -1,0 +1,112 @@
+"""MATLAB semantics the oracle models explicitly and agreement of its two
+independent restatements (NumPy and C)."""
+import math
+
+import numpy as np
+
+from oracle import c_oracle as CO
+from oracle import gnss_oracle as O
+
+
+def test_colon_matches_documented_algorithm():
+    # integer special cases
+    assert np.array_equal(O.colon(0, 1, 5), np.arange(6.0))
+    assert np.array_equal(O.colon(2, 3, 11), np.array([2.0, 5.0, 8.0, 11.0]))
+    assert O.colon(1, 1, 0).shape == (0,)
+    # general case: first half forwards from a, second half backwards from b, exact middle averaged
+    a, d, n = 0.3 - 0.5, 1.023e6 / 18e6, 17999
+    b = (n * d + 0.3) - 0.5
+    v = O.colon(a, d, b)
+    assert v.shape == (n + 1,)
+    assert v[0] == a and v[-1] == b
+    k = 5000
+    assert v[k] == a + k * d
+    assert v[n - k] == b - k * d
+    v2 = O.colon(a, d, a + 18000 * d)  # even number of intervals -> averaged middle
+    assert v2.shape == (18001,) and v2[9000] == (a + (a + 18000 * d)) / 2.0
+    # tolerance snap: an end point one ulp short still yields the full count
+    assert O.colon(0.0, 0.1, 0.30000000000000004).shape == (4,)
+    assert O.colon(0.0, 0.1, 0.3).shape == (4,)
+
+
+def test_matlab_builtins():
+    assert O.matlab_round(2.5) == 3 and O.matlab_round(-2.5) == -3 and O.matlab_round(2.4) == 2
+    assert O.matlab_rem(-7.5, 2 * math.pi) == math.fmod(-7.5, 2 * math.pi) < 0
+    assert abs(O.matlab_var(np.array([1 + 1j, 3 - 1j, 5 + 3j])) - np.var([1 + 1j, 3 - 1j, 5 + 3j], ddof=1)) < 1e-12
+    assert O.blksize_for(1023.0, 0.0, 1.023e6 / 18e6) == 18000
+
+
+def test_loop_coefficients():
+    t1, t2 = O.calc_loop_coef(20, 0.7, 0.25)  # calcLoopCoef.m:41-45
+    wn = 20 * 8 * 0.7 / (4 * 0.49 + 1)
+    assert t1 == 0.25 / (wn * wn) and t2 == 1.4 / wn
+    from types import SimpleNamespace
+    s = SimpleNamespace(pllNoiseBandwidth=15.0, intTime=0.001)
+    pf3, pf2, pf1 = O.calc_loop_coef_carr(s, "a")
+    assert (pf3, pf2, pf1) == ((18.0) ** 3 * 1e-6, 2 * 18.0 ** 2 * 1e-3, 36.0)
+    pf3b, pf2b, pf1b = O.calc_loop_coef_carr(s, "b")
+    wnb = 15.0 / 0.7845
+    assert (pf3b, pf2b, pf1b) == (wnb ** 3 * 1e-6, 1.1 * wnb ** 2 * 1e-3, 2.4 * wnb)
+
+
+def test_numpy_and_c_oracles_agree_on_blocks(l1ca_scene):
+    S, sats, iq = l1ca_scene
+    rng = np.random.default_rng(3)
+    tab = O.pad_code(O.generate_ca_code(sats[1].prn))
+    for _ in range(6):
+        step = (1.023e6 + rng.uniform(-5, 5)) / 18e6
+        rem = float(rng.uniform(0, step)) if rng.random() < 0.7 else 0.0
+        n = O.blksize_for(1023.0, rem, step)
+        s0 = int(rng.integers(0, iq.shape[0] // 2 - n))
+        f, phi = 20e3 + rng.uniform(-5e3, 5e3), rng.uniform(-6, 6)
+        a, rc_a, rp_a = O.correlate_block(O.raw_from_if(iq, s0, n), [tab], rem, step, 0.5, f, phi, 18e6, 1023.0)
+        b, rc_b, rp_b = CO.correlate_block(iq, s0, n, [tab], rem, step, 0.5, f, phi, 18e6, 1023.0)
+        assert rc_a == rc_b and rp_a == rp_b  # state updates: identical expressions, identical doubles
+        assert np.max(np.abs(a - b)) < 1e-9 * np.sum(np.abs(iq[2 * s0:2 * (s0 + n)].astype(float)))
+    # R = 2 (BOC(1,1)-style table of 2L+2 entries, GAL_E1C tracking.m:236-268) and two arms
+    code2 = np.repeat(O.generate_ca_code(3), 2) * np.tile([1.0, -1.0], 1023)
+    t2 = O.pad_code(code2)
+    t3 = O.pad_code(np.repeat(O.generate_ca_code(9), 2))
+    step, rem, n = 1.023e6 / 18e6, 0.01, 17999
+    a, rc_a, _ = O.correlate_block(O.raw_from_if(iq, 500, n), [t2, t3], rem, step, 0.3, 2.1e4, 0.4, 18e6, 1023.0, r=2.0)
+    b, rc_b, _ = CO.correlate_block(iq, 500, n, [t2, t3], rem, step, 0.3, 2.1e4, 0.4, 18e6, 1023.0, r=2.0)
+    assert rc_a == rc_b and a.shape == (2, 6) and np.max(np.abs(a - b)) < 1e-6
+
+
+def test_closed_loop_oracles_agree_and_lock(l1ca_scene):
+    from types import SimpleNamespace
+    S, sats, iq = l1ca_scene
+    S.msToProcess = 150
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 4.0, status="T",
+                          codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in sats[:2]]
+    ch.append(SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-"))
+    py = O.tracking_l1ca(iq, ch, S)
+    c, done, aborted = CO.track_l1ca(iq, ch, S)
+    assert not aborted and list(done) == [150, 150, 0]
+    for k in range(2):
+        assert py[k].status == "T" and py[k].PRN == sats[k].prn
+        assert np.array_equal(py[k].absoluteSample, c["absoluteSample"][k])
+        for f in ("carrFreq", "codeFreq", "remCodePhase", "I_P", "Q_P", "I_E", "Q_L", "dllDiscr", "pllDiscr"):
+            scale = max(1.0, np.max(np.abs(c[f][k])))
+            assert np.max(np.abs(getattr(py[k], f) - c[f][k])) < 1e-8 * scale, f
+        # lock: prompt power in I, Doppler recovered, ~18000 samples per code period
+        assert np.mean(np.abs(py[k].I_P[50:])) > 5 * np.mean(np.abs(py[k].Q_P[50:]))
+        assert abs(py[k].carrFreq[-1] - (S.IF + sats[k].doppler)) < 20
+        assert set(np.diff(py[k].absoluteSample)) <= {17999.0, 18000.0, 18001.0}
+        assert len(py[k].CNo.VSMValue) == 3 and 38 < py[k].CNo.VSMValue[-1] < 50
+    assert py[2].status == "-" and not py[2].I_P.any()
+
+
+def test_short_read_returns_from_the_function(l1ca_scene):
+    """tracking.m:241-245: a short read exits tracking() altogether, later channels never run."""
+    from types import SimpleNamespace
+    S, sats, iq = l1ca_scene
+    S.msToProcess = 50
+    short = iq[:2 * 18000 * 30]
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler, status="T",
+                          codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in sats[:2]]
+    py = O.tracking_l1ca(short, ch, S)
+    c, done, aborted = CO.track_l1ca(short, ch, S)
+    assert aborted and 27 <= done[0] < 30 and done[1] == 0
+    assert py[0].status == "-" and not py[0].I_P[int(done[0]):].any() and py[0].I_P[:int(done[0])].all()
+    assert len(py) == 2 and not py[1].I_P.any()
