@@ -91,6 +91,7 @@ SYMBOLS = {
     "gc_acquire_coarse": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,
                                        C.POINTER(C.c_double)]),
+    "gc_debug_fft": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int]),
 }
 
 _lib = None

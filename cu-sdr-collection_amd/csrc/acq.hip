@@ -1,10 +1,671 @@
-// acq.hip — placeholder until the acquisition kernels land (replaced in the next commit).
+// acq.hip — FFT-based parallel code-phase search (acquisition.m:151-200) and the GPS L1 C/A
+// fine-frequency stage (acquisition.m:213-254) on gfx950.
+//
+// Reference per PRN, bin b, hop h (acquisition.m:167-191):
+//     results(b,:) += abs(ifft( fft( exp(-1i*f_b*phasePoints) .* x[h*spc : (h+2)*spc) ) .* conj(fft([code zeros]))))
+// What is done differently (same arithmetic contract, float32 transforms):
+//   * the signal spectra depend on (b, h) only, so they are computed ONCE (nbins*H transforms) and
+//     reused by every PRN — the reference recomputes them for each of the 32 PRNs;
+//   * N = 2*spc (36 000 at the default front end) is not a power of two: a four-step
+//     (N = N1 x N2) mixed-radix {5,4,3,2} Stockham FFT, each pass a tile of short vectors
+//     transformed in LDS by one workgroup, twiddles from a float64-computed table;
+//   * int8 -> float conversion, carrier mixing, the product with the conjugated code spectrum,
+//     the twiddles, abs() and the non-coherent sum over hops are fused into the passes;
+//   * the peak pick reproduces max(max(.)) first-occurrence semantics with exact float compares.
+#include <algorithm>
+#include <cmath>
+
 #include "gc_internal.h"
-extern "C" int gc_acquire_coarse(gc_context*, const gc_acq_params*, int, const int8_t*, gc_acq_result*) {
-  gc_set_error("gc_acquire_coarse: not implemented yet");
-  return GC_E_UNSUPPORTED;
+
+namespace {
+
+constexpr int kMaxRadices = 12;
+constexpr int kFftThreads = 256;
+
+struct SubPlan {
+  int len;
+  int nrad;
+  int rad[kMaxRadices];
+};
+
+struct Plan {
+  int n, n1, n2;  // n = n1 * n2; n1 = column length (stride n2), n2 = row length (contiguous)
+  SubPlan p1, p2;
+};
+
+bool factor(int len, SubPlan* sp) {
+  sp->len = len;
+  sp->nrad = 0;
+  int r = len;
+  const int cand[4] = {5, 4, 3, 2};
+  for (int c : cand)
+    while (r % c == 0) {
+      if (sp->nrad >= kMaxRadices) return false;
+      sp->rad[sp->nrad++] = c;
+      r /= c;
+    }
+  return r == 1;
 }
-extern "C" int gc_acquire_fine_l1ca(gc_context*, const gc_acq_params*, const int8_t*, int, double, double*) {
-  gc_set_error("gc_acquire_fine_l1ca: not implemented yet");
-  return GC_E_UNSUPPORTED;
+
+bool make_plan(int n, Plan* pl) {
+  int best = 1;
+  for (int d = 1; (long long)d * d <= n; ++d)
+    if (n % d == 0) best = d;
+  pl->n = n;
+  pl->n1 = best;
+  pl->n2 = n / best;
+  return factor(pl->n1, &pl->p1) && factor(pl->n2, &pl->p2) && pl->n2 <= 1024;
+}
+
+enum PreOp { PRE_NONE = 0, PRE_IF_CARRIER, PRE_CODE, PRE_MUL_CONJ };
+enum PostOp { POST_STORE = 0, POST_TWIDDLE, POST_ABS_ACC };
+
+struct PassArgs {
+  // geometry of this pass
+  int len;           // vector length L
+  int nvec;          // vectors per transform
+  int estride;       // element stride (in complex elements)
+  int vstride;       // vector stride
+  int cols;          // vectors per workgroup tile
+  int nrad;
+  int rad[kMaxRadices];
+  int n;             // full transform size (twiddle table period)
+  int inverse;       // 0: exp(-i..), 1: exp(+i..)
+  int pre, post;
+  long long in_batch_stride;   // elements between transforms of the batch
+  long long out_batch_stride;
+  const float2* in;
+  float2* out;
+  const float2* tw;   // exp(-2*pi*i*k/n), k = 0..n-1
+  // PRE_IF_CARRIER
+  const int8_t* if_base;
+  long long first_sample;
+  int spc, nhops;
+  double f0, fstep, fs;  // bin frequency f_b = f0 - fstep*b (Hz)
+  // PRE_CODE
+  const int8_t* codes;  // [batch][spc]
+  // PRE_MUL_CONJ
+  const float2* other;  // code spectrum (same layout)
+  // POST_ABS_ACC: batch index = bin; loops over nhops transforms in*, accumulates |.|/n
+  float* acc_out;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// One workgroup: `cols` vectors of length L, Stockham autosort in LDS (ping-pong), one output
+// element group (j, column) per thread per stage.
+__global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int L = a.len, C = a.cols;
+  float2* buf0 = lds;
+  float2* buf1 = lds + (size_t)L * C;
+  const int tiles = (a.nvec + C - 1) / C;
+  const int tile = blockIdx.x % tiles;
+  const long long batch = blockIdx.x / tiles;
+  const int v0 = tile * C;
+  const int tid = threadIdx.x;
+  const int nel = L * C;
+  const float sign = a.inverse ? -1.0f : 1.0f;  // table holds exp(-i..): conjugate for the inverse
+
+  const int reps = (a.post == POST_ABS_ACC) ? a.nhops : 1;
+  // POST_ABS_ACC keeps its accumulators in registers across the hop loop
+  float accv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) accv[k] = 0.f;
+
+  for (int rep = 0; rep < reps; ++rep) {
+    const long long tb = (a.post == POST_ABS_ACC) ? batch * a.nhops + rep : batch;
+    // ---- load tile (coalesced along whichever index is contiguous in memory) ------------------------
+    for (int idx = tid; idx < nel; idx += kFftThreads) {
+      int e, c;
+      if (a.estride == 1) {
+        e = idx % L;
+        c = idx / L;
+      } else {
+        c = idx % C;
+        e = idx / C;
+      }
+      const int v = v0 + c;
+      float2 val = make_float2(0.f, 0.f);
+      if (v < a.nvec) {
+        const long long pos = (long long)e * a.estride + (long long)v * a.vstride;  // index within transform
+        if (a.pre == PRE_IF_CARRIER) {
+          // x[n] = (I + iQ) * exp(-1i * f_b * n*2*pi/fs)  (acquisition.m:169-181), batch = b*nhops + h
+          const int b = (int)(tb / a.nhops), h = (int)(tb % a.nhops);
+          const long long s = a.first_sample + (long long)h * a.spc + pos;
+          const float xi = (float)a.if_base[2 * s], xq = (float)a.if_base[2 * s + 1];
+          const double fb = a.f0 - a.fstep * b;
+          const double ph = (fb / a.fs) * (double)pos;
+          float sn, cs;
+          sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
+          val = make_float2(xi * cs + xq * sn, xq * cs - xi * sn);
+        } else if (a.pre == PRE_CODE) {
+          val = (pos < a.spc) ? make_float2((float)a.codes[tb * a.spc + pos], 0.f) : make_float2(0.f, 0.f);
+        } else {
+          val = a.in[tb * a.in_batch_stride + pos];
+          if (a.pre == PRE_MUL_CONJ) {
+            const float2 o = a.other[pos];
+            val = cmul(val, make_float2(o.x, -o.y));
+          }
+        }
+      }
+      buf0[c * L + e] = val;
+    }
+    __syncthreads();
+
+    // ---- Stockham stages ---------------------------------------------------------------------------
+    float2* src = buf0;
+    float2* dst = buf1;
+    int ns = 1;
+    for (int s = 0; s < a.nrad; ++s) {
+      const int r = a.rad[s];
+      const int lr = L / r;
+      const int tws = a.n / (ns * r);  // table stride for W_{ns*r}
+      for (int idx = tid; idx < lr * C; idx += kFftThreads) {
+        const int j = idx % lr, c = idx / lr;
+        const int k = j % ns;
+        float2 vq[5];
+        for (int q = 0; q < r; ++q) {
+          float2 x = src[c * L + j + q * lr];
+          if (k != 0 && q != 0) {
+            float2 w = a.tw[((long long)k * q * tws) % a.n];
+            w.y *= sign;
+            x = cmul(x, w);
+          }
+          vq[q] = x;
+        }
+        const int obase = c * L + (j - k) * r + k;
+        const int wr = a.n / r;  // W_r = tw[wr]
+        for (int q = 0; q < r; ++q) {
+          float2 acc = vq[0];
+          for (int pp = 1; pp < r; ++pp) {
+            float2 w = a.tw[((long long)pp * q % r) * wr];
+            w.y *= sign;
+            const float2 t = cmul(vq[pp], w);
+            acc.x += t.x;
+            acc.y += t.y;
+          }
+          dst[obase + q * ns] = acc;
+        }
+      }
+      __syncthreads();
+      float2* t = src;
+      src = dst;
+      dst = t;
+      ns *= r;
+    }
+
+    // ---- store -------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int slot = 0; slot < 8; ++slot) {
+      const int idx = tid + slot * kFftThreads;
+      if (idx >= nel) continue;
+      int e, c;
+      if (a.estride == 1) {
+        e = idx % L;
+        c = idx / L;
+      } else {
+        c = idx % C;
+        e = idx / C;
+      }
+      const int v = v0 + c;
+      if (v >= a.nvec) continue;
+      float2 val = src[c * L + e];
+      const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
+      if (a.post == POST_TWIDDLE) {
+        float2 w = a.tw[((long long)v * e) % a.n];
+        w.y *= sign;
+        val = cmul(val, w);
+      }
+      if (a.post == POST_ABS_ACC) {
+        accv[slot] += sqrtf(val.x * val.x + val.y * val.y);
+      } else {
+        a.out[tb * a.out_batch_stride + pos] = val;
+      }
+    }
+    __syncthreads();
+  }
+  if (a.post == POST_ABS_ACC) {
+    const float inv_n = 1.0f / (float)a.n;
+#pragma unroll
+    for (int slot = 0; slot < 8; ++slot) {
+      const int idx = tid + slot * kFftThreads;
+      if (idx >= nel) continue;
+      int e, c;
+      if (a.estride == 1) {
+        e = idx % L;
+        c = idx / L;
+      } else {
+        c = idx % C;
+        e = idx / C;
+      }
+      const int v = v0 + c;
+      if (v >= a.nvec) continue;
+      const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
+      a.acc_out[batch * a.n + pos] = accv[slot] * inv_n;
+    }
+  }
+}
+
+// ---- sigPower inputs: exact integer sums of the first spc samples (acquisition.m:151) -------------------
+__global__ void sigpower_kernel(const int8_t* __restrict__ x, long long first, int n, long long* out3) {
+  long long si = 0, sq = 0, s2 = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int a = x[2 * (first + i)], b = x[2 * (first + i) + 1];
+    si += a;
+    sq += b;
+    s2 += a * a + b * b;
+  }
+  atomicAdd((unsigned long long*)&out3[0], (unsigned long long)si);
+  atomicAdd((unsigned long long*)&out3[1], (unsigned long long)sq);
+  atomicAdd((unsigned long long*)&out3[2], (unsigned long long)s2);
+}
+
+// ---- peak pick with MATLAB first-occurrence semantics (acquisition.m:196-198) ---------------------------
+// pass 1: global max (positive floats order like their bit patterns)
+__global__ void max_kernel(const float* __restrict__ r, long long n, unsigned int* gmax) {
+  unsigned int m = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(r[i]));
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_down((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(gmax, m);
+}
+// pass 2: smallest bin and smallest column holding that value
+__global__ void argmax_kernel(const float* __restrict__ r, int nbins, int ncols, const unsigned int* gmax, int* out2) {
+  const unsigned int m = *gmax;
+  const long long n = (long long)nbins * ncols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (__float_as_uint(r[i]) == m) {
+      atomicMin(&out2[0], (int)(i / ncols));
+      atomicMin(&out2[1], (int)(i % ncols));
+    }
+}
+
+// ---- fine frequency, GPS L1 C/A (acquisition.m:213-238): 40 per-code sums for each fine bin ---------------
+__global__ __launch_bounds__(256) void fine_kernel(const int8_t* __restrict__ x, long long first, int spc, int ncodes,
+                                                    const int8_t* __restrict__ code, int code_len, double ts, double tc,
+                                                    double f0, double fstep, double fs, double* __restrict__ out) {
+  const int bin = blockIdx.x / ncodes, ci = blockIdx.x % ncodes;
+  const double f = f0 - fstep * bin;
+  double sr = 0.0, si = 0.0;
+  for (int i = threadIdx.x; i < spc; i += blockDim.x) {
+    const long long n = (long long)ci * spc + i;
+    // codeValueIndex = floor((ts * n) / tc), exactly as acquisition.m:215-216 (float64)
+    const double cvi = floor(__ddiv_rn(__dmul_rn(ts, (double)n), tc));
+    const int k = (int)fmod(cvi, (double)code_len);
+    const float c = (float)code[k];
+    const float xi = (float)x[2 * (first + n)], xq = (float)x[2 * (first + n) + 1];
+    const double ph = (f / fs) * (double)n;
+    float sn, cs;
+    sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
+    sr += (double)(c * (xi * cs + xq * sn));
+    si += (double)(c * (xq * cs - xi * sn));
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = sr;
+  red[1][threadIdx.x] = si;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = red[0][0];
+    out[2 * blockIdx.x + 1] = red[1][0];
+  }
+}
+
+int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
+  const int tiles = (a.nvec + a.cols - 1) / a.cols;
+  const size_t smem = (size_t)2 * a.len * a.cols * sizeof(float2);
+  hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned int)(tiles * nbatch_groups)), dim3(kFftThreads), smem, ctx->stream, a);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+void fill_sub(PassArgs& a, const SubPlan& sp) {
+  a.len = sp.len;
+  a.nrad = sp.nrad;
+  for (int i = 0; i < sp.nrad; ++i) a.rad[i] = sp.rad[i];
+}
+
+// columns per tile: keep 2*L*C*8 bytes <= 64 KiB and L*C <= 8*256 (POST_ABS_ACC register slots)
+int choose_cols(int L) { return std::max(1, std::min(16, 2048 / L)); }
+
+struct AcqScratch {
+  int n = 0;
+  Plan plan;
+  float2* tw = nullptr;       // n
+  float2* sig = nullptr;      // nbh * n   signal spectra, layout [k1][k2]
+  float2* tmp = nullptr;      // nbh * n   scratch between passes
+  float2* codespec = nullptr; // nprn * n
+  float* results = nullptr;   // nbins * n
+  int8_t* codes = nullptr;    // nprn * spc
+  long long* sums = nullptr;  // 3 + scratch for argmax
+  double* fine = nullptr;     // fine sums
+  long long nbh = 0;
+  int nprn = 0, nbins = 0;
+};
+
+void free_scratch(AcqScratch* s) {
+  if (!s) return;
+  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->codes, s->sums, s->fine};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete s;
+}
+
+}  // namespace
+
+void gc_acq_free(gc_context* ctx) {
+  free_scratch((AcqScratch*)ctx->acq_scratch);
+  ctx->acq_scratch = nullptr;
+}
+
+static int ensure_scratch(gc_context* ctx, int n, long long nbh, int nprn, int nbins, int spc, AcqScratch** out) {
+  AcqScratch* s = (AcqScratch*)ctx->acq_scratch;
+  if (s && s->n == n && s->nbh >= nbh && s->nprn >= nprn && s->nbins >= nbins) {
+    *out = s;
+    return GC_OK;
+  }
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  free_scratch(s);
+  ctx->acq_scratch = nullptr;
+  s = new AcqScratch();
+  if (!make_plan(n, &s->plan)) {
+    delete s;
+    gc_set_error("acquisition: FFT size %d is not of the form 2^a 3^b 5^c (or its factors are too large)", n);
+    return GC_E_UNSUPPORTED;
+  }
+  s->n = n;
+  s->nbh = nbh;
+  s->nprn = nprn;
+  s->nbins = nbins;
+  const size_t ne = (size_t)n;
+  if (hipMalloc((void**)&s->tw, ne * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void**)&s->sig, (size_t)nbh * ne * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void**)&s->tmp, (size_t)nbh * ne * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void**)&s->codespec, (size_t)nprn * ne * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void**)&s->results, (size_t)nbins * ne * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&s->codes, (size_t)nprn * spc) != hipSuccess ||
+      hipMalloc((void**)&s->sums, 16 * sizeof(long long)) != hipSuccess ||
+      hipMalloc((void**)&s->fine, 4096 * 2 * sizeof(double)) != hipSuccess) {
+    free_scratch(s);
+    gc_set_error("acquisition: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  std::vector<float2> tw(ne);
+  for (size_t k = 0; k < ne; ++k) {
+    const double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
+    tw[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  GC_HIP(hipMemcpy(s->tw, tw.data(), ne * sizeof(float2), hipMemcpyHostToDevice));
+  ctx->acq_scratch = s;
+  *out = s;
+  return GC_OK;
+}
+
+// Forward transform of `nbatch` sequences produced by `pre` into `dst` (layout [k1][k2]).
+static int forward(gc_context* ctx, AcqScratch* s, PassArgs base, int pre, long long nbatch, float2* dst) {
+  const Plan& pl = s->plan;
+  PassArgs a = base;
+  a.n = pl.n;
+  a.tw = s->tw;
+  a.inverse = 0;
+  // F1: columns (length n1, element stride n2), twiddle, store [k1][n2]
+  fill_sub(a, pl.p1);
+  a.nvec = pl.n2;
+  a.estride = pl.n2;
+  a.vstride = 1;
+  a.cols = choose_cols(a.len);
+  a.pre = pre;
+  a.post = POST_TWIDDLE;
+  a.out = s->tmp;
+  a.out_batch_stride = pl.n;
+  int rc = launch_pass(ctx, a, nbatch);
+  if (rc) return rc;
+  // F2: rows (length n2, contiguous)
+  fill_sub(a, pl.p2);
+  a.nvec = pl.n1;
+  a.estride = 1;
+  a.vstride = pl.n2;
+  a.cols = choose_cols(a.len);
+  a.pre = PRE_NONE;
+  a.post = POST_STORE;
+  a.in = s->tmp;
+  a.in_batch_stride = pl.n;
+  a.out = dst;
+  a.out_batch_stride = pl.n;
+  return launch_pass(ctx, a, nbatch);
+}
+
+extern "C" int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn, const int8_t* sampled_codes,
+                                 gc_acq_result* out) {
+  if (!ctx || !p || nprn <= 0 || !sampled_codes || !out) {
+    gc_set_error("gc_acquire_coarse: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
+    gc_set_error("gc_acquire_coarse: needs an int8 I/Q IF buffer");
+    return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  const double x = p->sampling_freq / (p->code_freq_basis / p->code_length);
+  const int spc = (int)std::floor(x + 0.5);                                     // acquisition.m:116
+  const int nbins = (int)std::floor(p->search_band * 2 / p->search_step + 0.5) + 1;  // :124
+  const int H = p->non_coh_time;
+  const int n = 2 * spc;
+  if (spc <= 0 || nbins <= 0 || H <= 0 || p->first_sample < 0) return GC_E_INVALID;
+  if ((uint64_t)p->first_sample + (uint64_t)(H + 1) * spc > ctx->if_nsamples) {
+    gc_set_error("gc_acquire_coarse: needs %lld samples from %lld, buffer holds %llu", (long long)(H + 1) * spc,
+                 (long long)p->first_sample, (unsigned long long)ctx->if_nsamples);
+    return GC_E_RANGE;
+  }
+  AcqScratch* s = nullptr;
+  int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn, nbins, spc, &s);
+  if (rc) return rc;
+  const Plan& pl = s->plan;
+
+  // sigPower = sqrt(var(x(1:spc)) * spc), var normalised by N-1 (acquisition.m:151)
+  GC_HIP(hipMemsetAsync(s->sums, 0, 16 * sizeof(long long), ctx->stream));
+  hipLaunchKernelGGL(sigpower_kernel, dim3(64), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (long long)p->first_sample,
+                     spc, s->sums);
+  long long hs[3];
+  GC_HIP(hipMemcpyAsync(hs, s->sums, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipMemcpyAsync(s->codes, sampled_codes, (size_t)nprn * spc, hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  const double mr = (double)hs[0] / spc, mi = (double)hs[1] / spc;
+  const double var = ((double)hs[2] - spc * (mr * mr + mi * mi)) / (spc - 1);
+  const double sig_power = std::sqrt(var * spc);
+
+  // signal spectra for every (bin, hop)
+  PassArgs base;
+  std::memset(&base, 0, sizeof base);
+  base.if_base = (const int8_t*)ctx->d_if;
+  base.first_sample = p->first_sample;
+  base.spc = spc;
+  base.nhops = H;
+  base.f0 = p->intermediate_freq + p->search_band;  // coarseFreqBin(1), :169
+  base.fstep = p->search_step;
+  base.fs = p->sampling_freq;
+  rc = forward(ctx, s, base, PRE_IF_CARRIER, (long long)nbins * H, s->sig);
+  if (rc) return rc;
+  // code spectra (conj applied at the product)
+  base.codes = s->codes;
+  rc = forward(ctx, s, base, PRE_CODE, nprn, s->codespec);
+  if (rc) return rc;
+
+  for (int ip = 0; ip < nprn; ++ip) {
+    // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
+    PassArgs a = base;
+    a.n = pl.n;
+    a.tw = s->tw;
+    a.inverse = 1;
+    fill_sub(a, pl.p2);
+    a.nvec = pl.n1;
+    a.estride = 1;
+    a.vstride = pl.n2;
+    a.cols = choose_cols(a.len);
+    a.pre = PRE_MUL_CONJ;
+    a.post = POST_TWIDDLE;
+    a.in = s->sig;
+    a.in_batch_stride = pl.n;
+    a.other = s->codespec + (size_t)ip * pl.n;
+    a.out = s->tmp;
+    a.out_batch_stride = pl.n;
+    rc = launch_pass(ctx, a, (long long)nbins * H);
+    if (rc) return rc;
+    // I2: columns (length n1, stride n2), inverse, |.|/n accumulated over the hops of each bin
+    fill_sub(a, pl.p1);
+    a.nvec = pl.n2;
+    a.estride = pl.n2;
+    a.vstride = 1;
+    a.cols = choose_cols(a.len);
+    a.pre = PRE_NONE;
+    a.post = POST_ABS_ACC;
+    a.in = s->tmp;
+    a.acc_out = s->results;
+    rc = launch_pass(ctx, a, nbins);
+    if (rc) return rc;
+    // peak pick
+    unsigned int* gmax = (unsigned int*)(s->sums + 4);
+    int* arg = (int*)(s->sums + 6);
+    const int init[2] = {0x7fffffff, 0x7fffffff};
+    GC_HIP(hipMemsetAsync(gmax, 0, sizeof(unsigned int), ctx->stream));
+    GC_HIP(hipMemcpyAsync(arg, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    const long long total = (long long)nbins * n;
+    hipLaunchKernelGGL(max_kernel, dim3(512), dim3(256), 0, ctx->stream, s->results, total, gmax);
+    hipLaunchKernelGGL(argmax_kernel, dim3(512), dim3(256), 0, ctx->stream, s->results, nbins, n, gmax, arg);
+    GC_HIP(hipGetLastError());
+    unsigned int hmax;
+    int harg[2];
+    GC_HIP(hipMemcpyAsync(&hmax, gmax, sizeof hmax, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipMemcpyAsync(harg, arg, sizeof harg, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    float peak;
+    std::memcpy(&peak, &hmax, sizeof peak);
+    out[ip].coarse_bin = harg[0] + 1;   // 1-based like MATLAB
+    out[ip].code_phase = harg[1] + 1;
+    out[ip].peak = (double)peak;
+    out[ip].peak_metric = (double)peak / sig_power / H;  // :200
+    out[ip].coarse_freq = p->intermediate_freq + p->search_band - p->search_step * harg[0];
+  }
+  return GC_OK;
+}
+
+// Test hook: forward FFT of `nbatch` host sequences of length n (complex64) with the library's
+// transform; output in natural frequency order.
+extern "C" int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in, float* out_natural, int inverse) {
+  if (!ctx || n <= 1 || nbatch <= 0 || !in || !out_natural) return GC_E_INVALID;
+  GC_HIP(hipSetDevice(ctx->device));
+  AcqScratch* s = nullptr;
+  int rc = ensure_scratch(ctx, n, nbatch, 1, 1, n / 2, &s);
+  if (rc) return rc;
+  const Plan& pl = s->plan;
+  GC_HIP(hipMemcpy(s->sig, in, (size_t)nbatch * n * sizeof(float2), hipMemcpyHostToDevice));
+  PassArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.n = pl.n;
+  a.tw = s->tw;
+  a.inverse = inverse;
+  fill_sub(a, pl.p1);
+  a.nvec = pl.n2;
+  a.estride = pl.n2;
+  a.vstride = 1;
+  a.cols = choose_cols(a.len);
+  a.pre = PRE_NONE;
+  a.post = POST_TWIDDLE;
+  a.in = s->sig;
+  a.in_batch_stride = pl.n;
+  a.out = s->tmp;
+  a.out_batch_stride = pl.n;
+  rc = launch_pass(ctx, a, nbatch);
+  if (rc) return rc;
+  fill_sub(a, pl.p2);
+  a.nvec = pl.n1;
+  a.estride = 1;
+  a.vstride = pl.n2;
+  a.cols = choose_cols(a.len);
+  a.post = POST_STORE;
+  a.in = s->tmp;
+  a.out = s->sig;
+  rc = launch_pass(ctx, a, nbatch);
+  if (rc) return rc;
+  std::vector<float2> h((size_t)nbatch * n);
+  GC_HIP(hipMemcpyAsync(h.data(), s->sig, h.size() * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  float2* o = (float2*)out_natural;
+  for (int b = 0; b < nbatch; ++b)
+    for (int k1 = 0; k1 < pl.n1; ++k1)
+      for (int k2 = 0; k2 < pl.n2; ++k2) o[(size_t)b * n + k1 + (size_t)pl.n1 * k2] = h[(size_t)b * n + (size_t)k1 * pl.n2 + k2];
+  return GC_OK;
+}
+
+extern "C" int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code, int code_phase,
+                                    double coarse_freq, double* carr_freq) {
+  if (!ctx || !p || !code || !carr_freq || code_phase < 1) {
+    gc_set_error("gc_acquire_fine_l1ca: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  GC_HIP(hipSetDevice(ctx->device));
+  const double x = p->sampling_freq / (p->code_freq_basis / p->code_length);
+  const int spc = (int)std::floor(x + 0.5);
+  const int ncodes = 40;
+  const double fine_step = 25;                                                   // acquisition.m:138
+  const int nfine = (int)std::floor(p->search_step / fine_step + 0.5) + 1;      // :140
+  const long long first = p->first_sample + code_phase - 1;                      // sig40cm, :221
+  if ((uint64_t)first + (uint64_t)ncodes * spc > ctx->if_nsamples) {
+    gc_set_error("gc_acquire_fine_l1ca: 40 code periods from sample %lld exceed the IF buffer", first);
+    return GC_E_RANGE;
+  }
+  AcqScratch* s = (AcqScratch*)ctx->acq_scratch;
+  if (!s) {
+    gc_set_error("gc_acquire_fine_l1ca: call gc_acquire_coarse first");
+    return GC_E_STATE;
+  }
+  if (nfine * ncodes > 4096) return GC_E_UNSUPPORTED;
+  const int code_len = (int)p->code_length;
+  int8_t* dcode = nullptr;
+  GC_HIP(hipMalloc((void**)&dcode, (size_t)code_len));
+  GC_HIP(hipMemcpy(dcode, code, (size_t)code_len, hipMemcpyHostToDevice));
+  const double ts = 1.0 / p->sampling_freq, tc = 1.0 / p->code_freq_basis;
+  const double f0 = coarse_freq + p->search_step / 2;                            // fineFreqBins(1), :227-228
+  hipLaunchKernelGGL(fine_kernel, dim3(nfine * ncodes), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, first, spc,
+                     ncodes, (const int8_t*)dcode, code_len, ts, tc, f0, fine_step, p->sampling_freq, s->fine);
+  std::vector<double> h((size_t)nfine * ncodes * 2);
+  hipError_t e = hipMemcpyAsync(h.data(), s->fine, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dcode);
+  if (e != hipSuccess) {
+    gc_set_error("gc_acquire_fine_l1ca: %s", hipGetErrorString(e));
+    return GC_E_HIP;
+  }
+  // 20 navigation-bit-edge hypotheses, max |sum of 20 consecutive per-code sums| (:242-249); first max (:253)
+  double best = -1.0;
+  int best_bin = 0;
+  for (int b = 0; b < nfine; ++b) {
+    double max_power = 0.0;
+    for (int c0 = 0; c0 < 20; ++c0) {
+      double sr = 0.0, si = 0.0;
+      for (int c = c0; c < c0 + 20; ++c) {
+        sr += h[2 * ((size_t)b * ncodes + c)];
+        si += h[2 * ((size_t)b * ncodes + c) + 1];
+      }
+      max_power = std::max(max_power, std::sqrt(sr * sr + si * si));
+    }
+    if (max_power > best) {
+      best = max_power;
+      best_bin = b;
+    }
+  }
+  double f = f0 - fine_step * best_bin;
+  if (f == 0) f = 1;  // :258-260
+  *carr_freq = f;
+  return GC_OK;
 }

@@ -90,10 +90,10 @@ struct gc_context {
 
   // acquisition scratch (acq.hip)
   void* acq_scratch = nullptr;
-  size_t acq_scratch_bytes = 0;
 };
 
 int gc_bytes_per_sample(int dtype, int layout);
+void gc_acq_free(gc_context* ctx);  // acq.hip
 int gc_sync_channels(gc_context* ctx);
 // Launches the correlator for `nblocks` descriptors already on the device.
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,

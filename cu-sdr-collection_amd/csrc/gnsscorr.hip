@@ -85,7 +85,7 @@ int gc_destroy(gc_context* ctx) {
   if (ctx->h_out_pinned) (void)hipHostFree(ctx->h_out_pinned);
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
   if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
-  if (ctx->acq_scratch) (void)hipFree(ctx->acq_scratch);
+  gc_acq_free(ctx);
   (void)hipEventDestroy(ctx->ev_start);
   (void)hipEventDestroy(ctx->ev_stop);
   (void)hipStreamDestroy(ctx->stream);

@@ -168,6 +168,14 @@ class Engine:
                                             codes.ctypes.data_as(C.c_void_p), res))
         return list(res)
 
+    def debug_fft(self, x: np.ndarray, inverse: bool = False) -> np.ndarray:
+        """x: complex64 [nbatch, n].  The library's FFT (test hook)."""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.empty_like(x)
+        L.check(self._lib.gc_debug_fft(self._ctx, x.shape[1], x.shape[0], x.ctypes.data_as(C.c_void_p),
+                                       out.ctypes.data_as(C.c_void_p), int(inverse)))
+        return out
+
     def acquire_fine_l1ca(self, params: L.gc_acq_params, code: np.ndarray, code_phase: int,
                           coarse_freq: float) -> float:
         c8 = np.ascontiguousarray(code, dtype=np.int8)

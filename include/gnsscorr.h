@@ -219,6 +219,10 @@ int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn,
 int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code,
                          int code_phase, double coarse_freq, double* carr_freq);
 
+/* Test hook: the library's four-step mixed-radix FFT on `nbatch` host sequences of n complex64
+ * values (n of the form 2^a 3^b 5^c); output in natural order, unnormalised. */
+int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in, float* out, int inverse);
+
 #ifdef __cplusplus
 }
 #endif
