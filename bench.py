@@ -148,6 +148,16 @@ def main() -> None:
     algo_bytes = 2.0 * chan_samples  # int8 I/Q: 2 bytes per channel-sample
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch of the replay kernel, measured offline with rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE on this exact command (profiles/r01/traffic.json, gfx950 x2 read correction applied)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+        if tj.get("blocks_per_launch") == nb:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     result = {
         "metric": "IF Msamples/s through tracking correlators; x real-time @ 12-ch GPS L1 C/A",
         "value": round(value, 1),
@@ -170,12 +180,24 @@ def main() -> None:
         "closed_loop": {"corr_msps": round(closed_msps, 1), "x_realtime": round(closed_msps / nch / (fs / 1e6), 2),
                         "us_per_epoch": round(t_closed / n_epochs * 1e6, 2), "channels_locked": int(locked.sum())},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "corr_epl_kernel<1, I8_IQ>", "kernel_ms": round(kernel_ms, 4),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "kernel": "corr_epl_fast_kernel<ARMS=1, I8_IQ, SPL=16>", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": algo_bytes},
         "replay_vs_closed_loop_max_dev": replay_dev,
         "device": dev_name, "compute_units": cus, "synth_s": round(t_synth, 2),
     }
+
+    # ---- acquisition (the other half of the hot path), reference defaults: 32 PRNs x 29 bins x 20 ms ----
+    from cu_sdr_collection_amd.receiver import acquisition as gpu_acquisition
+    Sa = P.initSettings()
+    gpu_acquisition(eng, Sa)  # warm-up (plans, twiddles, scratch)
+    t0 = time.perf_counter()
+    acq = gpu_acquisition(eng, Sa)
+    t_acq = time.perf_counter() - t0
+    found = sorted(int(i) + 1 for i in np.nonzero(acq.carrFreq)[0])
+    result["acquisition"] = {"seconds": round(t_acq, 4), "prns_searched": 32, "bins": 29, "non_coh_ms": 20,
+                             "fft_size": 36000, "acquired": found,
+                             "all_scene_prns_found": sorted(s.prn for s in sats) == found}
 
     # ---- CPU baseline: the oracle's C restatement of tracking.m, closed loop, 1 core ------------
     if rank == 0 and world == 1 and not args.no_cpu:

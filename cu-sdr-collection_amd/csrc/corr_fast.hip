@@ -128,7 +128,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int ARMS, int MODE, int SPL>
-__global__ __launch_bounds__(256) void corr_epl_fast_kernel(const KArgs p) {
+__global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = SPL * Fmt<MODE>::bps / 4;
   constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
@@ -147,9 +147,7 @@ __global__ __launch_bounds__(256) void corr_epl_fast_kernel(const KArgs p) {
   const int split = (int)(wg - wq * p.splits);
   const long long grp = wq / p.stride;
   const int cslot = (int)(wq - grp * p.stride);
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x;  // one wavefront per workgroup
 
   // ---- stage {c[k], c[k+1]-c[k]} for k = -1 .. nent (c[-1] := c[0], c[>=nent] := 0), once per
   //      workgroup: the host guarantees that all blocks of a workgroup share channel and offsets
@@ -166,7 +164,7 @@ __global__ __launch_bounds__(256) void corr_epl_fast_kernel(const KArgs p) {
         const int off = blk0.table_offset[a];
         const int n = min(chn0->stage_len[a], chn0->nent[a] - off);
         const int8_t* __restrict__ src = chn0->tab[a] + off;
-        for (int i = threadIdx.x; i < n + 3; i += blockDim.x) {
+        for (int i = lane; i < n + 3; i += kFW) {
           const int k = i - 1;  // table index of .x
           const float c0 = (k < 0) ? (float)src[0] : (k < n) ? (float)src[k] : 0.0f;
           const float c1 = (k + 1 < n) ? (float)src[k + 1] : 0.0f;
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256) void corr_epl_fast_kernel(const KArgs p) {
     __syncthreads();
   }
 
-  for (int bi = wave; bi < p.bpw; bi += nwaves) {
+  for (int bi = 0; bi < p.bpw; ++bi) {
   const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
   const gc_block blk = p.blocks[lb];

@@ -19,6 +19,8 @@
 //     sincos, and a per-iteration rotation by delta^2048;
 //   * 6*ARMS float accumulators per lane, wavefront shuffle reduction, LDS cross-wave
 //     combine in double, one store per output.
+#include <cstdlib>
+
 #include "corr_common.h"
 
 using namespace gcorr;
@@ -321,10 +323,12 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   a.bpw = 1;
   a.stride = 1;
   long long total = (long long)nblocks * splits;
-  if (fast && splits == 1 && period > 0 && nblocks >= 64 * (long long)period * ctx->compute_units) {
+  int want_bpw = 8;
+  if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
+  if (want_bpw > 1 && fast && splits == 1 && period > 0 && nblocks >= 64 * (long long)period * ctx->compute_units) {
     // big periodic list (all table offsets zero): one single-wave workgroup stages the channel's
     // table once and walks 8 consecutive epochs (a 4-wave workgroup sharing the table measured 10 % slower)
-    a.bpw = 8;
+    a.bpw = want_bpw;
     a.stride = period;
     total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
   }

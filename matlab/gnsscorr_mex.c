@@ -1,0 +1,209 @@
+/*
+ * gnsscorr_mex.c — MEX gateway: MATLAB <-> libgnsscorr.so (include/gnsscorr.h).
+ *
+ * This is the reference-side binding a maintainer of CU-SDR-Collection adds so that
+ * include/tracking.m and include/acquisition.m can hand their inner loops to the GPU
+ * (INTEGRATION.md).  It is a pure translation layer (mxArray <-> C structs); every computation
+ * lives behind the C-ABI.  MATLAB/mex.h do not exist in the build container, so this file is not
+ * compiled by __graft_entry__.build(); build it on a MATLAB host with
+ *
+ *     mex -R2018a -I<repo>/include gnsscorr_mex.c -L<repo>/cu-sdr-collection_amd/lib -lgnsscorr
+ *
+ * Usage:  out = gnsscorr_mex(cmd, args...)
+ *   h    = gnsscorr_mex('create', device_id)
+ *          gnsscorr_mex('destroy', h)
+ *          gnsscorr_mex('open_if_file', h, fileName, skipBytes, nSamples, dataType, fileType, samplingFreq)
+ *          gnsscorr_mex('load_if', h, int8_or_int16_vector, fileType, samplingFreq)
+ *          gnsscorr_mex('set_channel', h, channelIdx0, {paddedCode1, ...}, indexScale)
+ *   sums = gnsscorr_mex('correlate', h, blocks)      % blocks: 8 x nblocks double, see below
+ *   [trk, epochs, status] = gnsscorr_mex('track', h, params_struct, channels)   % channels: 5 x nch
+ *   res  = gnsscorr_mex('acquire_coarse', h, acq_struct, sampledCodes)          % int8 spc x nprn
+ *   f    = gnsscorr_mex('acquire_fine_l1ca', h, acq_struct, caCode, codePhase, coarseFreq)
+ */
+#include <string.h>
+
+#include "gnsscorr.h"
+#include "mex.h"
+
+static gc_context* g_ctx[16];
+
+static void fail(const char* where) { mexErrMsgIdAndTxt("gnsscorr:error", "%s: %s", where, gc_last_error()); }
+
+static void at_exit(void) {
+  for (int i = 0; i < 16; ++i)
+    if (g_ctx[i]) {
+      gc_destroy(g_ctx[i]);
+      g_ctx[i] = NULL;
+    }
+}
+
+static gc_context* handle(const mxArray* a) {
+  int i = (int)mxGetScalar(a);
+  if (i < 0 || i >= 16 || !g_ctx[i]) mexErrMsgIdAndTxt("gnsscorr:handle", "invalid context handle");
+  return g_ctx[i];
+}
+
+static double field(const mxArray* s, const char* name) {
+  const mxArray* f = mxGetField(s, 0, name);
+  if (!f) mexErrMsgIdAndTxt("gnsscorr:field", "missing field %s", name);
+  return mxGetScalar(f);
+}
+
+static void fill_acq(const mxArray* s, gc_acq_params* p) {
+  memset(p, 0, sizeof *p);
+  p->sampling_freq = field(s, "samplingFreq");
+  p->code_freq_basis = field(s, "codeFreqBasis");
+  p->code_length = field(s, "codeLength");
+  p->intermediate_freq = field(s, "IF");
+  p->search_band = field(s, "acqSearchBand");
+  p->search_step = field(s, "acqSearchStep");
+  p->non_coh_time = (int32_t)field(s, "acqNonCohTime");
+  p->first_sample = (int64_t)field(s, "firstSample");
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  char cmd[32];
+  if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("gnsscorr:usage", "first argument: command string");
+  mexAtExit(at_exit);
+
+  if (!strcmp(cmd, "create")) {
+    int slot = -1;
+    for (int i = 0; i < 16 && slot < 0; ++i)
+      if (!g_ctx[i]) slot = i;
+    if (slot < 0) mexErrMsgIdAndTxt("gnsscorr:handle", "too many contexts");
+    if (gc_create(&g_ctx[slot], nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0)) fail("gc_create");
+    mexLock();
+    plhs[0] = mxCreateDoubleScalar(slot);
+  } else if (!strcmp(cmd, "destroy")) {
+    int i = (int)mxGetScalar(prhs[1]);
+    handle(prhs[1]);
+    gc_destroy(g_ctx[i]);
+    g_ctx[i] = NULL;
+    mexUnlock();
+  } else if (!strcmp(cmd, "open_if_file")) {
+    /* settings.fileName, skipNumberOfBytes*dataAdaptCoeff, dataType 'schar'|'int16', fileType 1|2 */
+    char path[4096], dtype[16];
+    mxGetString(prhs[2], path, sizeof path);
+    mxGetString(prhs[5], dtype, sizeof dtype);
+    int layout = (int)mxGetScalar(prhs[6]) == 1 ? GC_REAL : GC_IQ;
+    if (gc_open_if_file(handle(prhs[1]), path, (uint64_t)mxGetScalar(prhs[3]), (uint64_t)mxGetScalar(prhs[4]),
+                        !strcmp(dtype, "int16") ? GC_I16 : GC_I8, layout))
+      fail("gc_open_if_file");
+    if (gc_set_sampling_freq(handle(prhs[1]), mxGetScalar(prhs[7]))) fail("gc_set_sampling_freq");
+  } else if (!strcmp(cmd, "load_if")) {
+    int dt = mxIsInt16(prhs[2]) ? GC_I16 : GC_I8;
+    if (!mxIsInt8(prhs[2]) && !mxIsInt16(prhs[2])) mexErrMsgIdAndTxt("gnsscorr:type", "IF samples must be int8 or int16");
+    int layout = (int)mxGetScalar(prhs[3]) == 1 ? GC_REAL : GC_IQ;
+    uint64_t n = (uint64_t)mxGetNumberOfElements(prhs[2]) / (layout == GC_REAL ? 1 : 2);
+    if (gc_load_if(handle(prhs[1]), mxGetData(prhs[2]), n, dt, layout)) fail("gc_load_if");
+    if (gc_set_sampling_freq(handle(prhs[1]), mxGetScalar(prhs[4]))) fail("gc_set_sampling_freq");
+  } else if (!strcmp(cmd, "set_channel")) {
+    /* cell array of padded code tables [c(end) c c(1)] as built at tracking.m:158 (double or int8) */
+    gc_context* c = handle(prhs[1]);
+    int ch = (int)mxGetScalar(prhs[2]);
+    int arms = (int)mxGetNumberOfElements(prhs[3]);
+    if (gc_set_channel(c, ch, arms, nrhs > 4 ? mxGetScalar(prhs[4]) : 1.0)) fail("gc_set_channel");
+    for (int a = 0; a < arms; ++a) {
+      const mxArray* t = mxGetCell(prhs[3], a);
+      int n = (int)mxGetNumberOfElements(t);
+      int8_t* tmp = (int8_t*)mxMalloc((size_t)n);
+      if (mxIsDouble(t)) {
+        const double* d = mxGetDoubles(t);
+        for (int i = 0; i < n; ++i) tmp[i] = (int8_t)d[i];
+      } else {
+        memcpy(tmp, mxGetData(t), (size_t)n);
+      }
+      int rc = gc_set_code(c, ch, a, tmp, n, 1.0);
+      mxFree(tmp);
+      if (rc) fail("gc_set_code");
+    }
+  } else if (!strcmp(cmd, "correlate")) {
+    /* blocks rows: channel, first_sample (0-based), blksize, remCodePhase, codePhaseStep,
+     * earlyLateSpc, carrFreq, remCarrPhase — the quantities of tracking.m:212-222,249,277 */
+    const double* b = mxGetDoubles(prhs[2]);
+    int n = (int)mxGetN(prhs[2]);
+    if (mxGetM(prhs[2]) != 8) mexErrMsgIdAndTxt("gnsscorr:usage", "blocks must be 8 x nblocks");
+    gc_block* blk = (gc_block*)mxCalloc((size_t)n, sizeof(gc_block));
+    for (int i = 0; i < n; ++i) {
+      const double* r = b + 8 * i;
+      blk[i].channel = (int32_t)r[0];
+      blk[i].first_sample = (int64_t)r[1];
+      blk[i].blksize = (int32_t)r[2];
+      blk[i].rem_code_phase = r[3];
+      blk[i].code_phase_step = r[4];
+      blk[i].el_spacing = r[5];
+      blk[i].carr_freq = r[6];
+      blk[i].rem_carr_phase = r[7];
+    }
+    plhs[0] = mxCreateDoubleMatrix(GC_OUT_STRIDE, (mwSize)n, mxREAL); /* rows: I_E Q_E I_P Q_P I_L Q_L per arm */
+    int rc = gc_correlate(handle(prhs[1]), n, blk, mxGetDoubles(plhs[0]));
+    mxFree(blk);
+    if (rc == GC_E_RANGE) mexErrMsgIdAndTxt("gnsscorr:range", "%s", gc_last_error()); /* tracking.m:241-245 */
+    if (rc) fail("gc_correlate");
+  } else if (!strcmp(cmd, "track")) {
+    const mxArray* s = prhs[2];
+    gc_track_params p;
+    memset(&p, 0, sizeof p);
+    p.sampling_freq = field(s, "samplingFreq");
+    p.code_freq_basis = field(s, "codeFreqBasis");
+    p.code_length = field(s, "codeLength");
+    p.el_spacing = field(s, "dllCorrelatorSpacing");
+    p.int_time = field(s, "intTime");
+    p.dll_noise_bw = field(s, "dllNoiseBandwidth");
+    p.dll_damping = field(s, "dllDampingRatio");
+    p.pll_noise_bw = field(s, "pllNoiseBandwidth");
+    p.pll_damping = field(s, "pllDampingRatio");
+    p.pll_kind = mxGetField(s, 0, "pllKind") ? (int32_t)field(s, "pllKind") : GC_PLL_2ND_ORDER;
+    p.skip_samples = (int64_t)field(s, "skipNumberOfBytes");
+    p.n_epochs = (int32_t)field(s, "msToProcess");
+    /* channels: 5 x nch rows = channel index, PRN, acquiredFreq, codeFreq, codePhase (preRun.m:65-73) */
+    int nch = (int)mxGetN(prhs[3]);
+    const double* c = mxGetDoubles(prhs[3]);
+    gc_channel_init* init = (gc_channel_init*)mxCalloc((size_t)nch, sizeof *init);
+    for (int i = 0; i < nch; ++i) {
+      init[i].channel = (int32_t)c[5 * i];
+      init[i].prn = (int32_t)c[5 * i + 1];
+      init[i].acquired_freq = c[5 * i + 2];
+      init[i].code_freq = c[5 * i + 3];
+      init[i].code_phase = (int64_t)c[5 * i + 4];
+    }
+    const mwSize dims[3] = {(mwSize)p.n_epochs, GC_TRK_NFIELDS, (mwSize)nch};
+    plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); /* trk(epoch, field, channel) */
+    int32_t* done = (int32_t*)mxCalloc((size_t)nch, sizeof *done);
+    int rc = gc_track(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done);
+    if (nlhs > 1) {
+      plhs[1] = mxCreateDoubleMatrix(1, (mwSize)nch, mxREAL);
+      for (int i = 0; i < nch; ++i) mxGetDoubles(plhs[1])[i] = done[i];
+    }
+    if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(rc);
+    mxFree(init);
+    mxFree(done);
+    if (rc && rc != GC_E_RANGE) fail("gc_track"); /* GC_E_RANGE = the reference's short-read return */
+  } else if (!strcmp(cmd, "acquire_coarse")) {
+    gc_acq_params p;
+    fill_acq(prhs[2], &p);
+    int nprn = (int)mxGetN(prhs[3]);
+    gc_acq_result* r = (gc_acq_result*)mxCalloc((size_t)nprn, sizeof *r);
+    if (gc_acquire_coarse(handle(prhs[1]), &p, nprn, (const int8_t*)mxGetData(prhs[3]), r)) fail("gc_acquire_coarse");
+    plhs[0] = mxCreateDoubleMatrix(5, (mwSize)nprn, mxREAL); /* rows: bin, codePhase, peak, peakMetric, coarseFreq */
+    for (int i = 0; i < nprn; ++i) {
+      double* o = mxGetDoubles(plhs[0]) + 5 * i;
+      o[0] = r[i].coarse_bin;
+      o[1] = r[i].code_phase;
+      o[2] = r[i].peak;
+      o[3] = r[i].peak_metric;
+      o[4] = r[i].coarse_freq;
+    }
+    mxFree(r);
+  } else if (!strcmp(cmd, "acquire_fine_l1ca")) {
+    gc_acq_params p;
+    fill_acq(prhs[2], &p);
+    double f = 0;
+    if (gc_acquire_fine_l1ca(handle(prhs[1]), &p, (const int8_t*)mxGetData(prhs[3]), (int)mxGetScalar(prhs[4]),
+                             mxGetScalar(prhs[5]), &f))
+      fail("gc_acquire_fine_l1ca");
+    plhs[0] = mxCreateDoubleScalar(f);
+  } else {
+    mexErrMsgIdAndTxt("gnsscorr:usage", "unknown command %s", cmd);
+  }
+}
