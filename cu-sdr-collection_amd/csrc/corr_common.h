@@ -9,6 +9,20 @@ constexpr int kSPL = 8;  // samples per lane-chunk
 
 enum Mode { I8_IQ = 0, I8_QI, I16_IQ, I16_QI, I8_REAL, I16_REAL };
 
+constexpr int kInlineBlocks = 16;
+
+struct TaggedSlot {
+  double value;
+  unsigned int tag;
+  unsigned int zero;
+};
+
+// Second kernel argument of the fast kernel: never named in device code (it is read through the
+// kernel-argument segment pointer with scalar loads), only copied there by the launch.
+struct InlineBlocks {
+  gc_block b[kInlineBlocks];
+};
+
 struct KArgs {
   const uint8_t* if_base;
   const gc_block* blocks;
@@ -22,6 +36,15 @@ struct KArgs {
   int red_off;  // byte offset of the reduction scratch in dynamic LDS
   int bpw;      // blocks per workgroup (fast kernel)
   int stride;   // descriptor stride between consecutive blocks of one workgroup
+  // Closed loop (fast kernel only): results go to host-mapped TAGGED slots — one 16-byte record
+  // {double value, uint32 tag, uint32 0} per output, written by ONE store instruction per workgroup — so
+  // the host polls the tags instead of paying a stream-synchronise wake-up, and no fence / atomic /
+  // counter is needed on the device.  nullptr = off.
+  TaggedSlot* tagged;       // [nblocks][splits][GC_OUT_STRIDE]
+  unsigned int notify_tag;
+  // Up to kInlineBlocks descriptors travel in the kernel-argument segment (no PCIe read of the
+  // host-mapped descriptor buffer at the start of every workgroup).
+  int use_inline;
 };
 
 // t = k0 - G / 2^64 ;  ceil(t + x) for x = xi + xf/2^64  is  k0 + xi + (xf > G)
@@ -103,4 +126,5 @@ __device__ __forceinline__ unsigned int rl_u(unsigned int v, int lane) {
 }  // namespace gcorr
 
 // corr_fast.hip
-int gc_launch_correlator_fast(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int max_arms, bool spl16);
+int gc_launch_correlator_fast(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
+                              int max_arms, bool spl16);

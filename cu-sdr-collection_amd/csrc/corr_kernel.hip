@@ -308,7 +308,7 @@ int launch_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
 }  // namespace
 
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
-                         double* d_out, double* d_partial, int max_arms, int fast, int period) {
+                         double* d_out, double* d_partial, int max_arms, int fast, int period, unsigned int notify_tag) {
   if (nblocks <= 0) return GC_OK;
   KArgs a;
   a.if_base = ctx->d_if;
@@ -322,6 +322,19 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   a.red_off = ctx->max_lds_bytes;
   a.bpw = 1;
   a.stride = 1;
+  InlineBlocks ib;
+  a.tagged = nullptr;
+  a.notify_tag = 0;
+  a.use_inline = 0;
+  if (fast && notify_tag != 0 && ctx->h_tagged_pinned) {
+    // closed loop: d_blocks is the host-mapped descriptor buffer (readable by the host right here)
+    a.tagged = reinterpret_cast<TaggedSlot*>(ctx->h_tagged_pinned);
+    a.notify_tag = notify_tag;
+    if (nblocks <= kInlineBlocks) {
+      a.use_inline = 1;
+      for (int64_t i = 0; i < nblocks; ++i) ib.b[i] = d_blocks[i];
+    }
+  }
   long long total = (long long)nblocks * splits;
   int want_bpw = 8;
   if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
@@ -342,7 +355,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   int rc;
   if (fast) {
     a.red_off = 8 * ctx->max_lds_bytes;  // float2 {c, dc} tables: 8 bytes per staged entry
-    rc = gc_launch_correlator_fast(ctx, a, (unsigned int)total, max_arms, fast == 2);
+    rc = gc_launch_correlator_fast(ctx, a, ib, (unsigned int)total, max_arms, fast == 2);
   } else {
     switch (max_arms) {
       case 1: rc = launch_mode<1>(ctx, a, grid, smem); break;

@@ -27,6 +27,7 @@ void gc_set_error(const char* fmt, ...);
 // Device-side view of one tracking channel (gc_set_channel / gc_set_code).
 struct DevChannel {
   const int8_t* tab[GC_MAX_ARMS];  // padded tables in HBM
+  const float2* tab2[GC_MAX_ARMS];  // {c[k], c[k+1]-c[k]} for k = -1 .. nent+1 (nent+3 entries), fast kernel
   int32_t nent[GC_MAX_ARMS];       // entries per table
   double mult[GC_MAX_ARMS];        // per-arm ramp multiplier (1 or 6)
   double index_scale;              // R
@@ -41,6 +42,7 @@ struct HostChannel {
   int arms = 0;
   double index_scale = 1.0;
   int8_t* d_tab[GC_MAX_ARMS] = {nullptr, nullptr, nullptr};
+  float2* d_tab2[GC_MAX_ARMS] = {nullptr, nullptr, nullptr};
   int nent[GC_MAX_ARMS] = {0, 0, 0};
   double mult[GC_MAX_ARMS] = {1.0, 1.0, 1.0};
   int window[GC_MAX_ARMS] = {0, 0, 0};  // 0 = stage the whole table
@@ -77,6 +79,8 @@ struct gc_context {
   int64_t d_partial_cap = 0;
   gc_block* h_blocks_pinned = nullptr;  // host-mapped, for the closed loop
   double* h_out_pinned = nullptr;
+  void* h_tagged_pinned = nullptr;  // host-mapped tagged result slots (closed loop, fast kernel)
+  int64_t tagged_cap = 0;            // slots
   int pinned_cap_blocks = 0;
 
   // replay
@@ -97,7 +101,8 @@ void gc_acq_free(gc_context* ctx);  // acq.hip
 int gc_sync_channels(gc_context* ctx);
 // Launches the correlator for `nblocks` descriptors already on the device.
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
-                         double* d_out, double* d_partial, int max_arms, int fast, int period = 0);
+                         double* d_out, double* d_partial, int max_arms, int fast, int period = 0,
+                         unsigned int notify_tag = 0);
 // Kernel class a block qualifies for: 0 = generic only, 1 = fast kernel with 8-sample lane-chunks,
 // 2 = fast kernel with 16-sample lane-chunks (at most one table transition per chunk and tap).
 int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b);

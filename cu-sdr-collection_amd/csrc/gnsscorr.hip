@@ -74,15 +74,19 @@ int gc_destroy(gc_context* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   free_if(ctx);
-  for (auto& c : ctx->ch)
+  for (auto& c : ctx->ch) {
     for (auto& t : c.d_tab)
       if (t) (void)hipFree(t);
+    for (auto& t : c.d_tab2)
+      if (t) (void)hipFree(t);
+  }
   if (ctx->d_channels) (void)hipFree(ctx->d_channels);
   if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->h_blocks_pinned) (void)hipHostFree(ctx->h_blocks_pinned);
   if (ctx->h_out_pinned) (void)hipHostFree(ctx->h_out_pinned);
+  if (ctx->h_tagged_pinned) (void)hipHostFree(ctx->h_tagged_pinned);
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
   if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
   gc_acq_free(ctx);
@@ -327,6 +331,20 @@ int gc_set_code(gc_context* ctx, int channel, int arm, const int8_t* table, int 
   GC_HIP(hipMalloc((void**)&c.d_tab[arm], (size_t)n_entries + 64));
   GC_HIP(hipMemset(c.d_tab[arm], 0, (size_t)n_entries + 64));
   GC_HIP(hipMemcpy(c.d_tab[arm], table, (size_t)n_entries, hipMemcpyHostToDevice));
+  // pre-differenced float2 form for the fast kernel: entry m <-> k = m - 1, c[-1] := c[0], c[>=n] := 0
+  {
+    std::vector<float2> t2((size_t)n_entries + 3);
+    for (int m = 0; m < n_entries + 3; ++m) {
+      const int k = m - 1;
+      const float c0 = (k < 0) ? (float)table[0] : (k < n_entries) ? (float)table[k] : 0.0f;
+      const float c1 = (k + 1 < n_entries) ? (float)table[k + 1] : 0.0f;
+      t2[m] = make_float2(c0, c1 - c0);
+    }
+    if (c.d_tab2[arm]) (void)hipFree(c.d_tab2[arm]);
+    c.d_tab2[arm] = nullptr;
+    GC_HIP(hipMalloc((void**)&c.d_tab2[arm], t2.size() * sizeof(float2)));
+    GC_HIP(hipMemcpy(c.d_tab2[arm], t2.data(), t2.size() * sizeof(float2), hipMemcpyHostToDevice));
+  }
   c.nent[arm] = n_entries;
   c.mult[arm] = arm_mult;
   ctx->channels_dirty = true;
@@ -361,6 +379,7 @@ int gc_sync_channels(gc_context* ctx) {
     for (int a = 0; a < c.arms; ++a) {
       if (!c.d_tab[a]) continue;  // checked per launch
       d.tab[a] = c.d_tab[a];
+      d.tab2[a] = c.d_tab2[a];
       d.nent[a] = c.nent[a];
       d.mult[a] = c.mult[a];
       d.stage_len[a] = (c.window[a] > 0) ? std::min(c.window[a], c.nent[a]) : c.nent[a];

@@ -6,10 +6,12 @@
 // active channel; descriptors and partial sums live in host-mapped pinned memory so an epoch
 // costs one kernel launch and one stream synchronisation.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
-#include "gc_internal.h"
+#include "corr_common.h"
 
 namespace {
 
@@ -99,6 +101,21 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     GC_HIP(hipHostMalloc((void**)&ctx->h_out_pinned, sizeof(double) * (size_t)nch * 32 * GC_OUT_STRIDE, hipHostMallocMapped));
     ctx->pinned_cap_blocks = nch * 32;
   }
+  // Results of the fast kernel arrive as host-mapped tagged 16-byte records (corr_common.h TaggedSlot): a
+  // stream synchronise costs ~15-20 us of wake-up latency per epoch, polling the tags does not.
+  const bool poll = std::getenv("GC_TRACK_NO_POLL") == nullptr;
+  const int64_t need_slots = (int64_t)nch * 32 * GC_OUT_STRIDE;
+  if (ctx->tagged_cap < need_slots) {
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_tagged_pinned) (void)hipHostFree(ctx->h_tagged_pinned);
+    ctx->h_tagged_pinned = nullptr;
+    ctx->tagged_cap = 0;
+    GC_HIP(hipHostMalloc(&ctx->h_tagged_pinned, sizeof(gcorr::TaggedSlot) * (size_t)need_slots, hipHostMallocMapped));
+    ctx->tagged_cap = need_slots;
+  }
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  std::memset(ctx->h_tagged_pinned, 0, sizeof(gcorr::TaggedSlot) * (size_t)ctx->tagged_cap);
+  volatile gcorr::TaggedSlot* tagged = (volatile gcorr::TaggedSlot*)ctx->h_tagged_pinned;
   gc_block* blocks = ctx->h_blocks_pinned;
   double* partial = ctx->h_out_pinned;
 
@@ -152,9 +169,38 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     if (nb == 0) break;
     int fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
     for (int k = 0; k < nb && fast; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
-    rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast);
+    const unsigned int tag = (unsigned int)(e + 1);
+    const bool polled = poll && fast != 0;
+    rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast, 0,
+                              polled ? tag : 0u);
     if (rc) return rc;
-    GC_HIP(hipStreamSynchronize(ctx->stream));
+    bool signalled = false;
+    if (polled) {
+      // wait until every record of this launch carries the epoch tag (bounded: never hang here)
+      const auto t0 = std::chrono::steady_clock::now();
+      const int arms6 = max_arms * 6;
+      signalled = true;
+      for (int k = 0; k < nb * splits && signalled; ++k)
+        for (int v = 0; v < arms6; ++v) {
+          volatile gcorr::TaggedSlot* s = tagged + (size_t)k * GC_OUT_STRIDE + v;
+          unsigned int spins = 0;
+          while (s->tag != tag) {
+            if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+              signalled = false;
+              break;
+            }
+          }
+          if (!signalled) break;
+        }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!signalled) {
+      GC_HIP(hipStreamSynchronize(ctx->stream));
+      if (polled) {
+        gc_set_error("gc_track: result records of epoch %d did not arrive", e);
+        return GC_E_HIP;
+      }
+    }
 
     for (int k = 0; k < nb; ++k) {
       const int c = slot[k];
@@ -164,7 +210,9 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       double sums[GC_OUT_STRIDE];
       for (int v = 0; v < GC_OUT_STRIDE; ++v) {
         double acc = 0.0;
-        for (int sp = 0; sp < splits; ++sp) acc += partial[((size_t)k * splits + sp) * GC_OUT_STRIDE + v];
+        for (int sp = 0; sp < splits; ++sp)
+          acc += polled ? ((v < max_arms * 6) ? tagged[((size_t)k * splits + sp) * GC_OUT_STRIDE + v].value : 0.0)
+                        : partial[((size_t)k * splits + sp) * GC_OUT_STRIDE + v];
         sums[v] = acc;
       }
       const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
