@@ -63,3 +63,36 @@ def makeCaTable(PRN: int, settings) -> np.ndarray:
     idx = np.ceil((ts * np.arange(1, spc + 1, dtype=np.float64)) / tc).astype(np.int64)
     idx[-1] = 1023
     return generateCAcode(PRN)[idx - 1]
+
+
+# ---------------------------------------------------------------------------------------------
+# Galileo E1-B / E1-C (GAL/GAL_E1C/include/generateE1Bcode.m, generateE1Ccode.m)
+# ---------------------------------------------------------------------------------------------
+_E1 = None
+
+
+def _e1_primary(which: str, PRN: int) -> np.ndarray:
+    """4092-chip memory code of Galileo OS SIS ICD Annex C as 0/1 bits (data/gal_e1_memory_codes.npz:
+    the packed form of the tables the reference reads from E1b.dat / E1c.dat)."""
+    global _E1
+    if not 1 <= PRN <= 50:
+        raise ValueError(f"Galileo PRN {PRN} out of range")
+    if _E1 is None:
+        import os
+        _E1 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "gal_e1_memory_codes.npz"))
+    return np.unpackbits(_E1[which][PRN - 1])[:4092]
+
+
+def _boc11(bits: np.ndarray) -> np.ndarray:
+    chips = (1 - 2 * bits.astype(np.int8)).astype(np.int8)      # logic 1 -> -1 (generateE1Bcode.m:56)
+    return np.stack([chips, -chips], axis=1).reshape(-1)         # sub-carrier [+1, -1] (:59-65)
+
+
+def generateE1Bcode(PRN: int) -> np.ndarray:
+    """E1-B data code with BOC(1,1): 8184 half-chips, int8 +-1."""
+    return _boc11(_e1_primary("E1b", PRN))
+
+
+def generateE1Ccode(PRN: int) -> np.ndarray:
+    """E1-C pilot primary code with BOC(1,1): 8184 half-chips, int8 +-1."""
+    return _boc11(_e1_primary("E1c", PRN))

@@ -99,9 +99,12 @@ def preRun(acqResults, settings):
 # ---------------------------------------------------------------------------------------------
 _REC_FIELDS = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
                "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase")
+_PILOT_FIELDS = ("Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L")
 
 
-def track_params(settings) -> L.gc_track_params:
+def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
+    from . import signals
+    spec = signals.SIGNALS[signal]
     p = L.gc_track_params()
     p.sampling_freq = settings.samplingFreq
     p.code_freq_basis = settings.codeFreqBasis
@@ -112,54 +115,63 @@ def track_params(settings) -> L.gc_track_params:
     p.dll_damping = settings.dllDampingRatio
     p.pll_noise_bw = settings.pllNoiseBandwidth
     p.pll_damping = settings.pllDampingRatio
-    p.pll_kind = L.GC_PLL_2ND_ORDER
-    p.pilot_combine = 0
+    p.pll_kind = spec.pll_kind
+    pilot = spec.pilot_combine if getattr(settings, "pilotTRKflag", 0) == 1 else 0
+    p.pilot_combine = pilot
+    if spec.pll_kind == L.GC_PLL_3_STATE:
+        p.pf3, p.pf2, p.pf1 = signals.calcLoopCoefCarr(settings, spec.coef_variant)
     p.skip_samples = int(settings.skipNumberOfBytes)
-    p.n_epochs = int(settings.msToProcess)
+    p.n_epochs = signals.epochs_to_process(settings)
     return p
 
 
-def tracking(fid: Engine, channel, settings):
-    """[trackResults, channel] = tracking(fid, channel, settings) for GPS L1 C/A.
+def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
+    """[trackResults, channel] = tracking(fid, channel, settings) — `signal` selects the reference
+    package whose tracking.m is mirrored ("GPS_L1CA": GPS/GPS_L1CA/include/tracking.m;
+    "GAL_E1C": GAL/GAL_E1C/include/tracking.m, data + pilot arms, BOC(1,1) half-chip tables).
 
     Returns (trackResults, channel).  On a short read the reference prints a message and
     returns what it has (tracking.m:241-245); here the partially filled results are returned
     the same way and `trackResults[i].status` stays '-' for channels that did not finish.
     """
+    from . import signals
+    spec = signals.SIGNALS[signal]
     if settings.fileType != 2 or settings.dataType not in ("schar", "int8", "int16"):
         raise NotImplementedError("tracking(): fileType 2 (I/Q) schar/int16 input only in this build")
-    code_periods = int(settings.msToProcess)
+    n_ep = signals.epochs_to_process(settings)
+    p = track_params(settings, signal)
+    pilot = p.pilot_combine != 0
     results = []
     active = []
     for i, ch in enumerate(channel):
         tr = SimpleNamespace(status="-", PRN=0)
-        for f in _REC_FIELDS:
-            setattr(tr, f, np.zeros(code_periods))
+        for f in _REC_FIELDS + (_PILOT_FIELDS if pilot else ()):
+            setattr(tr, f, np.zeros(n_ep))
         tr.CNo = SimpleNamespace(VSMValue=[], VSMIndex=[])
         results.append(tr)
         if ch.PRN != 0:
             tr.PRN = ch.PRN
-            fid.set_channel(i, [codes.padded_table(codes.generateCAcode(ch.PRN))])   # tracking.m:156-158
+            fid.set_channel(i, spec.tables(ch.PRN, settings), index_scale=spec.index_scale)
             active.append(i)
     if not active:
         return results, channel
-    p = track_params(settings)
     inits = []
     for i in active:
         ch = channel[i]
+        cf = ch.codeFreq if spec.code_freq_from_channel else settings.codeFreqBasis
         inits.append(L.gc_channel_init(channel=i, prn=ch.PRN, acquired_freq=ch.acquiredFreq,
-                                       code_freq=settings.codeFreqBasis, code_phase=int(ch.codePhase)))
+                                       code_freq=cf, code_phase=int(ch.codePhase)))
     fields, done, status = fid.track(p, inits)
     vsm = int(settings.CNo.VSMinterval)
     for k, i in enumerate(active):
         tr = results[i]
-        for f in _REC_FIELDS:
+        for f in _REC_FIELDS + (_PILOT_FIELDS if pilot else ()):
             getattr(tr, f)[:] = fields[f][k]
         n_done = int(done[k])
         for loop in range(vsm, n_done + 1, vsm):                                      # tracking.m:351-358
             tr.CNo.VSMValue.append(CNoVSM(tr.I_P[loop - vsm:loop], tr.Q_P[loop - vsm:loop], settings.CNo.accTime))
             tr.CNo.VSMIndex.append(loop)
-        if n_done == code_periods:
+        if n_done == n_ep:
             tr.status = channel[i].status                                             # tracking.m:365
     if status == L.GC_E_RANGE:
         print("Not able to read the specified number of samples  for tracking, exiting!")

@@ -43,3 +43,26 @@ def initSettings() -> SimpleNamespace:
     s.startOffset = 68.802
     s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=40)  # :133-136
     return s
+
+
+def initSettings_GAL_E1C() -> SimpleNamespace:
+    """Galileo E1 B/C defaults (GAL/GAL_E1C/initSettings.m): only the fields the hot path reads."""
+    s = initSettings()
+    s.codeLength = 4092              # :74  (8184 half-chips after BOC(1,1))
+    s.codeFreqBasis = 1.023e6        # :71
+    s.samplingFreq = 18e6            # :70
+    s.IF = 20e3                      # :69
+    s.acqSatelliteList = list(range(1, 51))
+    s.acqSearchBand = 7000           # :83
+    s.acqNonCohTime = 1              # :85
+    s.acqSearchStep = 150            # :87
+    s.acqThreshold = 10              # :89
+    s.dllDampingRatio = 0.7          # :96
+    s.dllNoiseBandwidth = 1.5        # :97
+    s.dllCorrelatorSpacing = 0.3     # :98
+    s.pllDampingRatio = 0.7          # :101
+    s.pllNoiseBandwidth = 15         # :102
+    s.intTime = 0.004                # :104
+    s.pilotTRKflag = 1               # :106
+    s.CNo = SimpleNamespace(accTime=0.004, VSMinterval=400)  # :138-140
+    return s

@@ -1,0 +1,54 @@
+"""Per-signal parameters of the tracking hot path (SURVEY.md §8a signal-variant matrix): which replica
+tables a channel carries, the index scale R of the ramps, the carrier loop filter and how the pilot
+arm enters the discriminators.  One entry per reference package that is wired up so far."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable
+
+import numpy as np
+
+from . import _lib as L
+from . import codes
+
+
+@dataclass(frozen=True)
+class SignalSpec:
+    name: str
+    tables: Callable            # (PRN, settings) -> list of padded int8 tables [c(end) c c(1)], arm 0 = data
+    index_scale: float          # R: 1, or 2 for BOC(1,1) half-chip tables (GAL_E1C/include/tracking.m:236)
+    pll_kind: int               # L.GC_PLL_2ND_ORDER | L.GC_PLL_3_STATE
+    coef_variant: str           # calcLoopCoefCarr.m variant "a" (a3=b3=2, Wn=1.2*LBW) | "b" (1.1, 2.4, LBW/0.7845)
+    pilot_combine: int          # 0 none | 1 rotate pilot by -pi/2 then average | 2 plain average
+    code_freq_from_channel: bool  # initial codeFreq = channel.codeFreq (GPS_L5C tracking.m:165) or codeFreqBasis
+
+
+def calcLoopCoefCarr(settings, variant: str = "a"):
+    """(pf3, pf2, pf1) of Common/calcLoopCoefCarr.m (two variants in the tree, see SignalSpec)."""
+    lbw, t = settings.pllNoiseBandwidth, settings.intTime
+    a3, b3, wn = (2, 2, 1.2 * lbw) if variant == "a" else (1.1, 2.4, lbw / 0.7845)
+    return wn ** 3 * t ** 2, a3 * wn ** 2 * t, b3 * wn
+
+
+def _l1ca_tables(prn, settings):
+    return [codes.padded_table(codes.generateCAcode(prn))]                   # GPS_L1CA tracking.m:156-158
+
+
+def _e1_tables(prn, settings):
+    t = [codes.padded_table(codes.generateE1Bcode(prn))]                      # GAL_E1C tracking.m:139-143
+    if getattr(settings, "pilotTRKflag", 0) == 1:
+        t.append(codes.padded_table(codes.generateE1Ccode(prn)))              # :145-150
+    return t
+
+
+SIGNALS = {
+    "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False),
+    # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
+    "GAL_E1C": SignalSpec("GAL_E1C", _e1_tables, 2.0, L.GC_PLL_3_STATE, "a", 2, False),
+}
+
+
+def epochs_to_process(settings) -> int:
+    """NumToProcess = round(msToProcess/1000/intTime) (GAL_E1C tracking.m:51); = msToProcess for 1-ms codes."""
+    x = settings.msToProcess / 1000 / settings.intTime
+    return int(np.floor(x + 0.5))

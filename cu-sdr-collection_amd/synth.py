@@ -38,7 +38,8 @@ def scene(n_sats: int, seed: int, fs: float, cn0=45.0, doppler_max=5e3, prn_pool
 
 def generate_if(sats, n_samples: int, fs: float, intermediate_freq: float, code_fn, code_rate: float,
                 code_len: int, seed: int, sigma: float = 20.0, carrier_ratio: float = 1540.0,
-                bit_periods: int = 20, chunk: int = 1 << 21, noise: bool = True) -> np.ndarray:
+                bit_periods: int = 20, chunk: int = 1 << 21, noise: bool = True, pilot_fn=None,
+                pilot_phase: float = 0.0) -> np.ndarray:
     """Returns int8[2*n_samples] interleaved I,Q.
 
     code_fn(prn) -> +-1 chips (length code_len).  carrier_ratio = f_carrier/f_chip * (chip-rate
@@ -46,6 +47,9 @@ def generate_if(sats, n_samples: int, fs: float, intermediate_freq: float, code_
     rng = np.random.default_rng(seed)
     out = np.empty(2 * n_samples, dtype=np.int8)
     codes = {s.prn: np.asarray(code_fn(s.prn), dtype=np.float64) for s in sats}
+    # optional pilot component (no data bits) at carrier phase offset `pilot_phase` (rad):
+    # 0 for Galileo E1-C next to E1-B, +pi/2 for GPS L5-Q next to L5-I
+    pilots = {s.prn: np.asarray(pilot_fn(s.prn), dtype=np.float64) for s in sats} if pilot_fn else None
     bits = {s.prn: rng.integers(0, 2, size=int(n_samples / fs * code_rate / code_len / bit_periods) + 8) * 2.0 - 1.0
             for s in sats}
     for start in range(0, n_samples, chunk):
@@ -62,7 +66,10 @@ def generate_if(sats, n_samples: int, fs: float, intermediate_freq: float, code_
             data = b[np.mod(bit_idx, b.shape[0])]
             c = codes[s.prn][np.mod(chip, code_len)]
             theta = 2 * np.pi * (intermediate_freq + s.doppler) * (n / fs) + s.carrier_phase
-            acc += amp * data * c * np.exp(1j * theta)
+            comp = data * c
+            if pilots is not None:
+                comp = comp + pilots[s.prn][np.mod(chip, code_len)] * np.exp(1j * pilot_phase)
+            acc += amp * comp * np.exp(1j * theta)
         if noise:
             acc += sigma * (rng.standard_normal(n.shape[0]) + 1j * rng.standard_normal(n.shape[0]))
         i = np.clip(np.rint(acc.real), -127, 127).astype(np.int8)

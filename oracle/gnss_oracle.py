@@ -480,3 +480,133 @@ def pre_run(acq, settings):
         channel[ii].codePhase = int(acq.codePhase[p])
         channel[ii].status = "T"
     return channel
+
+
+# --------------------------------------------------------------------------------------
+# Galileo E1-B / E1-C codes (GAL/GAL_E1C/include/generateE1Bcode.m:40-67, generateE1Ccode.m)
+# --------------------------------------------------------------------------------------
+_E1_DATA = None
+
+
+def _e1_bits(which: str, prn: int) -> np.ndarray:
+    """Memory codes (no generator exists): packed copy of the reference's E1b.dat / E1c.dat,
+    tests/golden/gal_e1_memory_codes.npz (made by tests/golden/make_e1_codes.py)."""
+    global _E1_DATA
+    if _E1_DATA is None:
+        import os
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        _E1_DATA = np.load(os.path.join(here, "tests", "golden", "gal_e1_memory_codes.npz"))
+    return np.unpackbits(_E1_DATA[which][prn - 1])[:4092].astype(np.float64)
+
+
+def generate_e1_code(prn: int, component: str) -> np.ndarray:
+    """8184 half-chips: primary code 1-2*bit (logic 1 -> -1, generateE1Bcode.m:56) times the
+    BOC(1,1) sub-carrier [+1, -1] (:59-65).  component 'B' (data) or 'C' (pilot)."""
+    raw = 1.0 - 2.0 * _e1_bits("E1b" if component == "B" else "E1c", prn)
+    out = np.empty(2 * raw.shape[0])
+    out[0::2] = raw
+    out[1::2] = -raw
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Generic closed loop: 3-state PLL, data + pilot arms, R-scaled tables
+# (GAL/GAL_E1C/include/tracking.m:45-383; GPS/GPS_L5C/include/tracking.m:47-424)
+# --------------------------------------------------------------------------------------
+
+
+def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=None):
+    """spec: SimpleNamespace(
+         tables(prn) -> list of padded tables (arm 0 = data, arm 1 = pilot),
+         r            index scale (2 for the BOC(1,1) half-chip tables, GAL_E1C tracking.m:236),
+         pll          '2nd' (L1CA) | '3state' (calcLoopCoefCarr variant spec.coef_variant),
+         pilot_combine 0 none | 1 rotate pilot by exp(-1i*pi/2) then average (GPS_L5C tracking.m:336-348)
+                       | 2 plain average (GAL_E1C tracking.m:303-311,326-331),
+         code_freq_from_channel  True: channel.codeFreq (GPS_L5C tracking.m:165), False: codeFreqBasis)
+    Epoch count NumToProcess = round(msToProcess/1000/intTime) (GAL_E1C tracking.m:51)."""
+    n_ep = int(matlab_round(settings.msToProcess / 1000 / settings.intTime))
+    d = settings.dllCorrelatorSpacing
+    pdi = settings.intTime
+    tau1code, tau2code = calc_loop_coef(settings.dllNoiseBandwidth, settings.dllDampingRatio, 1.0)
+    if spec.pll == "2nd":
+        tau1carr, tau2carr = calc_loop_coef(settings.pllNoiseBandwidth, settings.pllDampingRatio, 0.25)
+    else:
+        pf3, pf2, pf1 = calc_loop_coef_carr(settings, spec.coef_variant)
+    n_total = if_bytes.shape[0] // 2
+    fields = TRACK_FIELDS + ("Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L")
+    results = []
+    for _ in channel:
+        tr = SimpleNamespace(status="-", PRN=0)
+        for f in fields:
+            setattr(tr, f, np.zeros(n_ep))
+        results.append(tr)
+    for tr, ch in zip(results, channel):
+        if ch.PRN == 0:
+            continue
+        tr.PRN = ch.PRN
+        pos = int(settings.skipNumberOfBytes + ch.codePhase - 1)
+        tables = spec.tables(ch.PRN)
+        basis = ch.codeFreq if spec.code_freq_from_channel else settings.codeFreqBasis
+        code_freq = basis
+        rem_code = 0.0
+        carr_freq = carr_basis = ch.acquiredFreq
+        rem_carr = 0.0
+        old_code_nco = old_code_err = 0.0
+        old_carr_nco = old_carr_err = 0.0
+        d2_carr = d_carr = 0.0
+        for e in range(n_ep):
+            tr.absoluteSample[e] = pos
+            step = code_freq / settings.samplingFreq
+            n = blksize_for(settings.codeLength, rem_code, step)
+            if pos + n > n_total:
+                return results
+            tr.remCodePhase[e] = rem_code
+            tr.remCarrPhase[e] = rem_carr
+            if correlate is None:
+                sums, rem_code_new, rem_carr_new = correlate_block(
+                    raw_from_if(if_bytes, pos, n), tables, rem_code, step, d, carr_freq, rem_carr,
+                    settings.samplingFreq, settings.codeLength, r=spec.r)
+            else:
+                sums, rem_code_new, rem_carr_new = correlate(ch, pos, n, rem_code, step, d, carr_freq, rem_carr)
+            pos += n
+            rem_code, rem_carr = rem_code_new, rem_carr_new
+            i_e, q_e, i_p, q_p, i_l, q_l = (float(v) for v in sums[0])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                carr_err = float(np.arctan(np.float64(q_p) / np.float64(i_p)) / (2.0 * math.pi))
+                code_err = float((np.float64(math.hypot(i_e, q_e)) - math.hypot(i_l, q_l)) /
+                                 (np.float64(math.hypot(i_e, q_e)) + math.hypot(i_l, q_l)))
+            # note: the reference writes sqrt(I*I + Q*Q); hypot differs by <= 1 ulp, far below any tolerance
+            code_err = float((math.sqrt(i_e * i_e + q_e * q_e) - math.sqrt(i_l * i_l + q_l * q_l)) /
+                             (math.sqrt(i_e * i_e + q_e * q_e) + math.sqrt(i_l * i_l + q_l * q_l)))
+            if spec.pilot_combine:
+                pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = (float(v) for v in sums[1])
+                if spec.pilot_combine == 1:
+                    qi = (pi_p + 1j * pq_p) * np.exp(-1j * math.pi / 2)
+                    carr_err_q = float(np.arctan(np.float64(qi.imag) / np.float64(qi.real)) / (2.0 * math.pi))
+                else:
+                    carr_err_q = float(np.arctan(np.float64(pq_p) / np.float64(pi_p)) / (2.0 * math.pi))
+                carr_err = (carr_err + carr_err_q) / 2
+                code_err_q = (math.sqrt(pi_e ** 2 + pq_e ** 2) - math.sqrt(pi_l ** 2 + pq_l ** 2)) / \
+                             (math.sqrt(pi_e ** 2 + pq_e ** 2) + math.sqrt(pi_l ** 2 + pq_l ** 2))
+                code_err = (code_err + code_err_q) / 2
+                tr.Pilot_I_E[e], tr.Pilot_Q_E[e], tr.Pilot_I_P[e] = pi_e, pq_e, pi_p
+                tr.Pilot_Q_P[e], tr.Pilot_I_L[e], tr.Pilot_Q_L[e] = pq_p, pi_l, pq_l
+            if spec.pll == "2nd":
+                carr_nco = old_carr_nco + (tau2carr / tau1carr) * (carr_err - old_carr_err) + carr_err * (pdi / tau1carr)
+                old_carr_nco, old_carr_err = carr_nco, carr_err
+            else:
+                d2_carr = d2_carr + carr_err * pf3
+                d_carr = d2_carr + carr_err * pf2 + d_carr
+                carr_nco = d_carr + carr_err * pf1
+            tr.carrFreq[e] = carr_freq
+            carr_freq = carr_basis + carr_nco
+            code_nco = old_code_nco + (tau2code / tau1code) * (code_err - old_code_err) + code_err * (pdi / tau1code)
+            old_code_nco, old_code_err = code_nco, code_err
+            tr.codeFreq[e] = code_freq
+            code_freq = basis - code_nco
+            tr.dllDiscr[e], tr.dllDiscrFilt[e] = code_err, code_nco
+            tr.pllDiscr[e], tr.pllDiscrFilt[e] = carr_err, carr_nco
+            tr.I_E[e], tr.I_P[e], tr.I_L[e] = i_e, i_p, i_l
+            tr.Q_E[e], tr.Q_P[e], tr.Q_L[e] = q_e, q_p, q_l
+        tr.status = ch.status
+    return results

@@ -103,3 +103,45 @@ def test_short_read_returns_partial_results(engine, l1ca_scene, capsys):
     assert np.array_equal(tr[0].absoluteSample[:n0], ref["absoluteSample"][0][:n0])
     assert not tr[0].I_P[n0:].any()
     assert not tr[1].I_P.any()  # the reference never reaches channel 2 (returns from the function)
+
+
+def test_galileo_e1_two_arm_tracking_matches_oracle(engine):
+    """BASELINE config 3 shape: E1-B + E1-C BOC(1,1) tables from the ICD memory codes, R = 2, 12 sums,
+    4-ms blocks (72 000 samples), 3-state PLL with pilot averaging — GAL/GAL_E1C/include/tracking.m."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E1C
+    S = initSettings_GAL_E1C()
+    fs = S.samplingFreq
+    S.msToProcess = 120  # 30 epochs of 4 ms
+    S.numberOfChannels = 3
+    rng = np.random.default_rng(8)
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 72000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=48.0) for p in (4, 19)]
+    n = int(0.130 * fs)
+    iq = P.synth.generate_if(sats, n, fs, S.IF, P.codes.generateE1Bcode, 2 * S.codeFreqBasis, 8184, seed=21,
+                             bit_periods=1, pilot_fn=P.codes.generateE1Ccode)
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 2.0, status="T",
+                          codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in sats]
+    ch.append(SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-"))
+    engine.load_if(iq, fs=fs)
+    tr, _ = P.tracking(engine, ch, S, signal="GAL_E1C")
+    spec = SimpleNamespace(tables=lambda prn: [O.pad_code(O.generate_e1_code(prn, "B")), O.pad_code(O.generate_e1_code(prn, "C"))],
+                           r=2.0, pll="3state", coef_variant="a", pilot_combine=2, code_freq_from_channel=False)
+    ref = O.tracking_generic(iq, ch, S, spec)
+    for k in range(2):
+        assert tr[k].status == "T" and ref[k].status == "T"
+        assert np.array_equal(tr[k].absoluteSample, ref[k].absoluteSample)
+        scale = 2.0 * 72000 * 28.0
+        for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L", "Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P",
+                  "Pilot_I_L", "Pilot_Q_L"):
+            assert np.max(np.abs(getattr(tr[k], f) - getattr(ref[k], f))) < 1e-5 * scale, f
+        assert np.max(np.abs(tr[k].carrFreq - ref[k].carrFreq)) < 1e-3
+        assert np.max(np.abs(tr[k].remCodePhase - ref[k].remCodePhase)) < 1e-7
+        # both arms carry signal (prompt power well above the early/late arms' difference) and the
+        # carrier loop stays within its pull-in range over these 120 ms
+        for pre in ("", "Pilot_"):
+            pm = np.hypot(getattr(tr[k], pre + "I_P"), getattr(tr[k], pre + "Q_P"))[5:]
+            em = np.hypot(getattr(tr[k], pre + "I_E"), getattr(tr[k], pre + "Q_E"))[5:]
+            assert np.mean(pm) > 5e4 and np.mean(pm) > 1.2 * np.mean(em)
+        assert abs(tr[k].carrFreq[-1] - (S.IF + sats[k].doppler)) < 15
+    assert tr[2].status == "-" and not tr[2].I_P.any()
