@@ -96,3 +96,59 @@ def generateE1Bcode(PRN: int) -> np.ndarray:
 def generateE1Ccode(PRN: int) -> np.ndarray:
     """E1-C pilot primary code with BOC(1,1): 8184 half-chips, int8 +-1."""
     return _boc11(_e1_primary("E1c", PRN))
+
+
+# ---------------------------------------------------------------------------------------------
+# GPS L5 I5 / Q5 (GPS/GPS_L5C/include/generateL5Icode.m, generateL5Qcode.m)
+# ---------------------------------------------------------------------------------------------
+# XB code advance in chips for PRN 1..37, IS-GPS-705 Table 3-I
+_L5I_ADVANCE = (266, 365, 804, 1138, 1509, 1559, 1756, 2084, 2170, 2303, 2527, 2687, 2930, 3471, 3940, 4132, 4332,
+                4924, 5343, 5443, 5641, 5816, 5898, 5918, 5955, 6243, 6345, 6477, 6518, 6875, 7168, 7187, 7329, 7577,
+                7720, 7777, 8057)
+_L5Q_ADVANCE = (1701, 323, 5292, 2020, 5429, 7136, 1041, 5947, 4315, 148, 535, 1939, 5206, 5910, 3595, 5135, 6082,
+                6990, 3546, 1523, 4548, 4484, 1893, 3961, 7106, 5299, 4660, 276, 4389, 3783, 1591, 1601, 749, 1387,
+                1661, 3210, 708)
+
+
+def _lfsr13(taps, n_out: int, skip: int = 0, short_cycle_at: int | None = None) -> np.ndarray:
+    """13-stage Fibonacci LFSR in integer form (bit i = stage i+1), all-ones start, output = stage 13.
+    `short_cycle_at`: reload all ones after emitting from this state (XA: 0b1111111111101 -> 8190 period)."""
+    mask = sum(1 << (t - 1) for t in taps)
+    reg = 0x1FFF
+    for _ in range(skip):
+        fb = bin(reg & mask).count("1") & 1
+        reg = ((reg << 1) & 0x1FFF) | fb
+    out = np.empty(n_out, dtype=np.uint8)
+    for i in range(n_out):
+        out[i] = (reg >> 12) & 1
+        if short_cycle_at is not None and reg == short_cycle_at:
+            reg = 0x1FFF
+        else:
+            fb = bin(reg & mask).count("1") & 1
+            reg = ((reg << 1) & 0x1FFF) | fb
+    return out
+
+
+_XA = None
+
+
+def _l5(PRN: int, adv) -> np.ndarray:
+    global _XA
+    if not 1 <= PRN <= len(adv):
+        raise ValueError(f"GPS L5 PRN {PRN} out of range")
+    if _XA is None:
+        # stage 12 = logic 0, all others 1  <->  the reference's reset_state [-1 x11, +1, -1]
+        _XA = _lfsr13((9, 10, 12, 13), 10230, short_cycle_at=0x1FFF & ~(1 << 11))
+    xb = _lfsr13((1, 3, 4, 6, 7, 8, 12, 13), 10230, skip=adv[PRN - 1])
+    # product of +-1 registers with logic 1 -> -1:  XOR = 1 -> -1  (generateL5Icode.m:123)
+    return (1 - 2 * (_XA ^ xb).astype(np.int8)).astype(np.int8)
+
+
+def generateL5Icode(PRN: int) -> np.ndarray:
+    """GPS L5 I5 (data) code, 10230 chips int8 +-1."""
+    return _l5(PRN, _L5I_ADVANCE)
+
+
+def generateL5Qcode(PRN: int) -> np.ndarray:
+    """GPS L5 Q5 (pilot) code, 10230 chips int8 +-1."""
+    return _l5(PRN, _L5Q_ADVANCE)

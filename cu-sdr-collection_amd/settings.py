@@ -66,3 +66,26 @@ def initSettings_GAL_E1C() -> SimpleNamespace:
     s.pilotTRKflag = 1               # :106
     s.CNo = SimpleNamespace(accTime=0.004, VSMinterval=400)  # :138-140
     return s
+
+
+def initSettings_GPS_L5C() -> SimpleNamespace:
+    """GPS L5 defaults (GPS/GPS_L5C/initSettings.m): only the fields the hot path reads."""
+    s = initSettings()
+    s.IF = 20e3                      # :63
+    s.samplingFreq = 18e6            # :64
+    s.codeLength = 10230             # :67
+    s.codeFreqBasis = 10.23e6        # :68
+    s.acqSearchBand = 5000           # :77
+    s.acqNonCohTime = 25             # :79
+    s.acqThreshold = 4.5             # :81
+    s.acqSearchStep = 500            # :83
+    s.dllDampingRatio = 0.7          # :90
+    s.dllNoiseBandwidth = 2          # :91
+    s.dllCorrelatorSpacing = 0.5     # :92
+    s.pllDampingRatio = 0.7          # :94
+    s.pllNoiseBandwidth = 15         # :95
+    s.intTime = 0.001                # :97
+    s.pilotTRKflag = 0               # :99
+    s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=400)  # :128-130
+    s.carrFreqBasis = 1176.45e6      # :132
+    return s

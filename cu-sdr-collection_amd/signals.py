@@ -41,10 +41,18 @@ def _e1_tables(prn, settings):
     return t
 
 
+def _l5_tables(prn, settings):
+    t = [codes.padded_table(codes.generateL5Icode(prn))]                      # GPS_L5C tracking.m:150-152
+    if getattr(settings, "pilotTRKflag", 0) == 1:
+        t.append(codes.padded_table(codes.generateL5Qcode(prn)))              # :154-159
+    return t
+
+
 SIGNALS = {
     "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False),
     # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
     "GAL_E1C": SignalSpec("GAL_E1C", _e1_tables, 2.0, L.GC_PLL_3_STATE, "a", 2, False),
+    "GPS_L5C": SignalSpec("GPS_L5C", _l5_tables, 1.0, L.GC_PLL_3_STATE, "a", 1, True),
 }
 
 

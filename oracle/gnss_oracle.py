@@ -610,3 +610,43 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
             tr.Q_E[e], tr.Q_P[e], tr.Q_L[e] = q_e, q_p, q_l
         tr.status = ch.status
     return results
+
+
+# --------------------------------------------------------------------------------------
+# GPS L5 I5 / Q5 codes (GPS/GPS_L5C/include/generateL5Icode.m:44-133, generateL5Qcode.m)
+# --------------------------------------------------------------------------------------
+# XB code advances, IS-GPS-705 Table 3-I, PRN 1..37 (the reference carries more SBAS/extended PRNs)
+_L5I_ADV = [266, 365, 804, 1138, 1509, 1559, 1756, 2084, 2170, 2303, 2527, 2687, 2930, 3471, 3940, 4132,
+            4332, 4924, 5343, 5443, 5641, 5816, 5898, 5918, 5955, 6243, 6345, 6477, 6518, 6875, 7168, 7187,
+            7329, 7577, 7720, 7777, 8057]
+_L5Q_ADV = [1701, 323, 5292, 2020, 5429, 7136, 1041, 5947, 4315, 148, 535, 1939, 5206, 5910, 3595, 5135,
+            6082, 6990, 3546, 1523, 4548, 4484, 1893, 3961, 7106, 5299, 4660, 276, 4389, 3783, 1591, 1601,
+            749, 1387, 1661, 3210, 708]
+
+
+def generate_l5_code(prn: int, component: str, code_length: int = 10230) -> np.ndarray:
+    """Product-form LFSRs exactly as the reference: XA taps {9,10,12,13}, short-cycled when the register
+    equals [-1 x11, +1, -1] (:54-67); XB taps {1,3,4,6,7,8,12,13} pre-advanced by the PRN's table entry
+    (:103-121); code = XB .* XA (:123)."""
+    xa_reg = -np.ones(13)
+    reset_state = np.array([-1.0] * 11 + [1.0, -1.0])
+    xa = np.empty(code_length)
+    for i in range(code_length):
+        xa[i] = xa_reg[-1]
+        if np.array_equal(xa_reg, reset_state):
+            xa_reg = -np.ones(13)
+        else:
+            fb = xa_reg[8] * xa_reg[9] * xa_reg[11] * xa_reg[12]
+            xa_reg = np.concatenate([[fb], xa_reg[:-1]])
+    adv = (_L5I_ADV if component == "I" else _L5Q_ADV)[prn - 1]
+    xb_reg = -np.ones(13)
+    taps = [0, 2, 3, 5, 6, 7, 11, 12]
+    for _ in range(adv):
+        fb = np.prod(xb_reg[taps])
+        xb_reg = np.concatenate([[fb], xb_reg[:-1]])
+    xb = np.empty(code_length)
+    for i in range(code_length):
+        xb[i] = xb_reg[-1]
+        fb = np.prod(xb_reg[taps])
+        xb_reg = np.concatenate([[fb], xb_reg[:-1]])
+    return xb * xa

@@ -145,3 +145,45 @@ def test_galileo_e1_two_arm_tracking_matches_oracle(engine):
             assert np.mean(pm) > 5e4 and np.mean(pm) > 1.2 * np.mean(em)
         assert abs(tr[k].carrFreq[-1] - (S.IF + sats[k].doppler)) < 15
     assert tr[2].status == "-" and not tr[2].I_P.any()
+
+
+def test_gps_l5_pilot_data_tracking_matches_oracle(engine):
+    """BASELINE config 4 shape (L5 half): 10 230-chip codes at 10.23 Mcps (1.76 samples/chip -> the
+    generic multi-transition kernel), I5 + Q5 arms, pilot rotated by -pi/2 in the discriminators,
+    channel.codeFreq from preRun — GPS/GPS_L5C/include/tracking.m."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GPS_L5C
+    S = initSettings_GPS_L5C()
+    S.pilotTRKflag = 1
+    fs = S.samplingFreq
+    S.msToProcess = 60
+    S.numberOfChannels = 2
+    rng = np.random.default_rng(9)
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 18000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0) for p in (6, 30)]
+    n = int(0.064 * fs)
+    iq = P.synth.generate_if(sats, n, fs, S.IF, P.codes.generateL5Icode, S.codeFreqBasis, 10230, seed=33,
+                             carrier_ratio=1150.0, bit_periods=10, pilot_fn=P.codes.generateL5Qcode,
+                             pilot_phase=np.pi / 2)
+    ch = []
+    for s in sats:
+        f = S.IF + s.doppler + 2.0
+        ch.append(SimpleNamespace(PRN=s.prn, acquiredFreq=f, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1,
+                                  codeFreq=S.codeFreqBasis + (f - S.IF) / S.carrFreqBasis * S.codeFreqBasis))  # preRun.m:69-71
+    engine.load_if(iq, fs=fs)
+    tr, _ = P.tracking(engine, ch, S, signal="GPS_L5C")
+    spec = SimpleNamespace(tables=lambda prn: [O.pad_code(O.generate_l5_code(prn, "I")), O.pad_code(O.generate_l5_code(prn, "Q"))],
+                           r=1.0, pll="3state", coef_variant="a", pilot_combine=1, code_freq_from_channel=True)
+    ref = O.tracking_generic(iq, ch, S, spec)
+    for k in range(2):
+        assert tr[k].status == "T" and ref[k].status == "T"
+        assert np.array_equal(tr[k].absoluteSample, ref[k].absoluteSample)
+        scale = 2.0 * 18000 * 28.0
+        for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L", "Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P",
+                  "Pilot_I_L", "Pilot_Q_L"):
+            assert np.max(np.abs(getattr(tr[k], f) - getattr(ref[k], f))) < 1e-5 * scale, f
+        assert np.max(np.abs(tr[k].carrFreq - ref[k].carrFreq)) < 1e-3
+        assert np.max(np.abs(tr[k].codeFreq - ref[k].codeFreq)) < 1e-3
+        # pilot arm in quadrature: its energy sits in Q while the data arm's sits in I
+        assert np.mean(np.abs(tr[k].I_P[20:])) > 2 * np.mean(np.abs(tr[k].Q_P[20:]))
+        assert np.mean(np.abs(tr[k].Pilot_Q_P[20:])) > 2 * np.mean(np.abs(tr[k].Pilot_I_P[20:]))
