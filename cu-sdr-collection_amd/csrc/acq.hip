@@ -88,6 +88,7 @@ struct PassArgs {
   const float2* other;  // code spectrum (same layout)
   // POST_ABS_ACC: batch index = bin; loops over nhops transforms in*, accumulates |.|/n
   float* acc_out;
+  int acc_add;  // POST_ABS_ACC: add to what acc_out already holds (second code arm of the same PRN)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       const int v = v0 + c;
       if (v >= a.nvec) continue;
       const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
-      a.acc_out[batch * a.n + pos] = accv[slot] * inv_n;
+      float* dstp = a.acc_out + batch * a.n + pos;
+      *dstp = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n;
     }
   }
 }
@@ -444,9 +446,19 @@ static int forward(gc_context* ctx, AcqScratch* s, PassArgs base, int pre, long 
   return launch_pass(ctx, a, nbatch);
 }
 
+extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
+                                       const int8_t* sampled_codes, gc_acq_result* out);
+
 extern "C" int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn, const int8_t* sampled_codes,
                                  gc_acq_result* out) {
-  if (!ctx || !p || nprn <= 0 || !sampled_codes || !out) {
+  return gc_acquire_coarse_multi(ctx, p, nprn, 1, sampled_codes, out);
+}
+
+// `narms` sampled codes per PRN (rows prn*narms + arm): results = sum over arms of |ifft(S .* conj(C_arm))|,
+// the data+pilot search of GPS_L5C/include/acquisition.m:175-216 (narms = 1: acquisition.m:158-192).
+extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
+                                       const int8_t* sampled_codes, gc_acq_result* out) {
+  if (!ctx || !p || nprn <= 0 || narms < 1 || narms > 4 || !sampled_codes || !out) {
     gc_set_error("gc_acquire_coarse: bad arguments");
     return GC_E_INVALID;
   }
@@ -467,7 +479,7 @@ extern "C" int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int np
     return GC_E_RANGE;
   }
   AcqScratch* s = nullptr;
-  int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn, nbins, spc, &s);
+  int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn * narms, nbins, spc, &s);
   if (rc) return rc;
   const Plan& pl = s->plan;
 
@@ -477,7 +489,7 @@ extern "C" int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int np
                      spc, s->sums);
   long long hs[3];
   GC_HIP(hipMemcpyAsync(hs, s->sums, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
-  GC_HIP(hipMemcpyAsync(s->codes, sampled_codes, (size_t)nprn * spc, hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipMemcpyAsync(s->codes, sampled_codes, (size_t)nprn * narms * spc, hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
   const double mr = (double)hs[0] / spc, mi = (double)hs[1] / spc;
   const double var = ((double)hs[2] - spc * (mr * mr + mi * mi)) / (spc - 1);
@@ -497,41 +509,44 @@ extern "C" int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int np
   if (rc) return rc;
   // code spectra (conj applied at the product)
   base.codes = s->codes;
-  rc = forward(ctx, s, base, PRE_CODE, nprn, s->codespec);
+  rc = forward(ctx, s, base, PRE_CODE, (long long)nprn * narms, s->codespec);
   if (rc) return rc;
 
   for (int ip = 0; ip < nprn; ++ip) {
-    // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
-    PassArgs a = base;
-    a.n = pl.n;
-    a.tw = s->tw;
-    a.inverse = 1;
-    fill_sub(a, pl.p2);
-    a.nvec = pl.n1;
-    a.estride = 1;
-    a.vstride = pl.n2;
-    a.cols = choose_cols(a.len);
-    a.pre = PRE_MUL_CONJ;
-    a.post = POST_TWIDDLE;
-    a.in = s->sig;
-    a.in_batch_stride = pl.n;
-    a.other = s->codespec + (size_t)ip * pl.n;
-    a.out = s->tmp;
-    a.out_batch_stride = pl.n;
-    rc = launch_pass(ctx, a, (long long)nbins * H);
-    if (rc) return rc;
-    // I2: columns (length n1, stride n2), inverse, |.|/n accumulated over the hops of each bin
-    fill_sub(a, pl.p1);
-    a.nvec = pl.n2;
-    a.estride = pl.n2;
-    a.vstride = 1;
-    a.cols = choose_cols(a.len);
-    a.pre = PRE_NONE;
-    a.post = POST_ABS_ACC;
-    a.in = s->tmp;
-    a.acc_out = s->results;
-    rc = launch_pass(ctx, a, nbins);
-    if (rc) return rc;
+    for (int arm = 0; arm < narms; ++arm) {
+      // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
+      PassArgs a = base;
+      a.n = pl.n;
+      a.tw = s->tw;
+      a.inverse = 1;
+      fill_sub(a, pl.p2);
+      a.nvec = pl.n1;
+      a.estride = 1;
+      a.vstride = pl.n2;
+      a.cols = choose_cols(a.len);
+      a.pre = PRE_MUL_CONJ;
+      a.post = POST_TWIDDLE;
+      a.in = s->sig;
+      a.in_batch_stride = pl.n;
+      a.other = s->codespec + ((size_t)ip * narms + arm) * pl.n;
+      a.out = s->tmp;
+      a.out_batch_stride = pl.n;
+      rc = launch_pass(ctx, a, (long long)nbins * H);
+      if (rc) return rc;
+      // I2: columns (length n1, stride n2), inverse, |.|/n accumulated over the hops of each bin
+      fill_sub(a, pl.p1);
+      a.nvec = pl.n2;
+      a.estride = pl.n2;
+      a.vstride = 1;
+      a.cols = choose_cols(a.len);
+      a.pre = PRE_NONE;
+      a.post = POST_ABS_ACC;
+      a.in = s->tmp;
+      a.acc_out = s->results;
+      a.acc_add = arm > 0;
+      rc = launch_pass(ctx, a, nbins);
+      if (rc) return rc;
+    }
     // peak pick
     unsigned int* gmax = (unsigned int*)(s->sums + 4);
     int* arg = (int*)(s->sums + 6);

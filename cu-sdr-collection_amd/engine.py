@@ -161,11 +161,13 @@ class Engine:
 
     # ---- acquisition ---------------------------------------------------------------------
     def acquire_coarse(self, params: L.gc_acq_params, sampled_codes: np.ndarray):
+        """sampled_codes: int8 [nprn, spc], or [nprn, narms, spc] for a data+pilot search."""
         codes = np.ascontiguousarray(sampled_codes, dtype=np.int8)
         nprn = codes.shape[0]
+        narms = codes.shape[1] if codes.ndim == 3 else 1
         res = (L.gc_acq_result * nprn)()
-        L.check(self._lib.gc_acquire_coarse(self._ctx, C.byref(params), nprn,
-                                            codes.ctypes.data_as(C.c_void_p), res))
+        L.check(self._lib.gc_acquire_coarse_multi(self._ctx, C.byref(params), nprn, narms,
+                                                  codes.ctypes.data_as(C.c_void_p), res))
         return list(res)
 
     def debug_fft(self, x: np.ndarray, inverse: bool = False) -> np.ndarray:

@@ -213,6 +213,11 @@ typedef struct gc_acq_result {
 int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn,
                       const int8_t* sampled_codes, gc_acq_result* out);
 
+/* Data + pilot search: `narms` sampled codes per PRN (row prn*narms + arm); the per-arm correlation
+ * magnitudes are added before the non-coherent sum (GPS_L5C/include/acquisition.m:175-216). */
+int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
+                            const int8_t* sampled_codes, gc_acq_result* out);
+
 /* Fine-frequency stage of GPS L1 C/A (acquisition.m:213-254) for one detected PRN:
  * `code` = 1023 chips (+-1), `code_phase` / `coarse_freq` from gc_acquire_coarse.
  * Returns the fine carrier frequency (with the "0 -> 1 Hz" rule of :258-260 applied). */

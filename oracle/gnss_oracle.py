@@ -387,15 +387,16 @@ def matlab_var(x: np.ndarray) -> float:
     return float(np.sum(np.abs(x - m) ** 2) / (x.shape[0] - 1))
 
 
-def acquisition_coarse_results(long_signal: np.ndarray, prn: int, settings) -> np.ndarray:
-    """results[bin, tau] of acquisition.m:158-192 for one PRN (float64 FFTs)."""
+def acquisition_coarse_results(long_signal: np.ndarray, prn: int, settings, tables=None) -> np.ndarray:
+    """results[bin, tau] of acquisition.m:158-192 for one PRN (float64 FFTs).  `tables`: explicit list of
+    sampled codes; more than one = the data+pilot sum of GPS_L5C/include/acquisition.m:210-216."""
     spc = samples_per_code(settings)
     ts = 1.0 / settings.samplingFreq
     phase_points = np.arange(0, spc * 2, dtype=np.float64) * 2 * math.pi * ts  # :122
     n_bins = int(matlab_round(settings.acqSearchBand * 2 / settings.acqSearchStep)) + 1  # :124
-    table = make_ca_table(prn, settings)
-    code2 = np.concatenate([table, np.zeros(spc)])  # :160
-    code_fd = np.conj(np.fft.fft(code2))  # :164
+    if tables is None:
+        tables = [make_ca_table(prn, settings)]
+    code_fds = [np.conj(np.fft.fft(np.concatenate([t, np.zeros(spc)]))) for t in tables]  # :160-164
     results = np.zeros((n_bins, spc * 2))
     for b in range(n_bins):
         f = settings.IF + settings.acqSearchBand - settings.acqSearchStep * b  # :169-170
@@ -403,8 +404,9 @@ def acquisition_coarse_results(long_signal: np.ndarray, prn: int, settings) -> n
         for h in range(int(settings.acqNonCohTime)):
             sig = long_signal[h * spc:(h + 2) * spc]  # :177-178
             iq = sig_carr * sig
-            conv = np.fft.fft(iq) * code_fd  # :183-186
-            results[b, :] += np.abs(np.fft.ifft(conv))  # :188-190
+            iq_fd = np.fft.fft(iq)  # :183
+            for code_fd in code_fds:
+                results[b, :] += np.abs(np.fft.ifft(iq_fd * code_fd))  # :186-190
     return results
 
 

@@ -106,3 +106,44 @@ def test_acquisition_range_error(engine, acq_scene):
     with pytest.raises(P.GnssCorrError) as e:
         P.acquisition(engine, S)
     assert e.value.status == P._lib.GC_E_RANGE
+
+
+def test_data_plus_pilot_coarse_search_matches_oracle(engine):
+    """GPS_L5C/include/acquisition.m:175-216: two code spectra per PRN, |ifft| summed over the arms."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.receiver import _acq_params
+    from cu_sdr_collection_amd.settings import initSettings_GPS_L5C
+    S = initSettings_GPS_L5C()
+    S.acqNonCohTime = 3
+    fs = S.samplingFreq
+    sat = P.synth.SatSpec(prn=9, doppler=2100.0, code_phase_samples=4321.3, carrier_phase=1.0, cn0_dbhz=50.0)
+    n = 6 * 18000
+    iq = P.synth.generate_if([sat], n, fs, S.IF, P.codes.generateL5Icode, S.codeFreqBasis, 10230, seed=3,
+                             carrier_ratio=1150.0, bit_periods=10, pilot_fn=P.codes.generateL5Qcode, pilot_phase=np.pi / 2)
+    engine.load_if(iq, fs=fs)
+    spc = 18000
+    idx = np.ceil((1 / fs) * np.arange(1, spc + 1) / (1 / S.codeFreqBasis)).astype(np.int64)
+    idx[-1] = 10230  # makeL5ITable.m: last index forced to the code length
+    tabs = {p: [O.generate_l5_code(p, "I")[idx - 1], O.generate_l5_code(p, "Q")[idx - 1]] for p in (9, 17)}
+    codes = np.stack([np.stack(tabs[p]) for p in (9, 17)]).astype(np.int8)
+    res = engine.acquire_coarse(_acq_params(S, 0), codes)
+    long_signal = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    for p, r in zip((9, 17), res):
+        results = O.acquisition_coarse_results(long_signal, p, S, tables=tabs[p])
+        assert abs(r.peak - results.max()) < 1e-4 * results.max()
+        if p == 9:
+            assert r.coarse_bin == int(np.argmax(np.max(results, axis=1))) + 1
+            assert r.code_phase == int(np.argmax(np.max(results, axis=0))) + 1
+            assert abs(((r.code_phase - 1) % spc) - 4322) <= 1 and r.peak_metric > S.acqThreshold
+        else:
+            assert r.peak_metric < S.acqThreshold
+
+
+def test_long_fft_sizes(engine):
+    """E1C (4-ms codes: N = 144 000) and B1C-size (360 000) transforms used by the other packages."""
+    rng = np.random.default_rng(2)
+    for n in (144000, 360000, 320000):
+        x = (rng.standard_normal((1, n)) + 1j * rng.standard_normal((1, n))).astype(np.complex64)
+        got = engine.debug_fft(x)
+        ref = np.fft.fft(x.astype(np.complex128), axis=1)
+        assert np.max(np.abs(got - ref)) < 3e-6 * np.max(np.abs(ref)) * np.log2(n), n
