@@ -1,0 +1,147 @@
+"""Kernel features behind the reference's signal-variant matrix that the L1 C/A, E1 and L5
+tests do not reach: ternary RZ tables and table windows/offsets (GPS L2C CM/CL), very long blocks, three
+arms, Q/I sample order in the closed loop (GLONASS), int16 records in the closed loop."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import gnss_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+def _noise_iq(n, seed, scale=20):
+    rng = np.random.default_rng(seed)
+    return np.clip(np.rint(scale * rng.standard_normal(2 * n)), -127, 127).astype(np.int8)
+
+
+def _block(b, k, **kw):
+    b[k].channel = kw["channel"]
+    b[k].blksize = kw["n"]
+    b[k].first_sample = kw["s0"]
+    b[k].rem_code_phase = kw["rem"]
+    b[k].code_phase_step = kw["step"]
+    b[k].el_spacing = kw["d"]
+    b[k].carr_freq = kw["f"]
+    b[k].rem_carr_phase = kw["phi"]
+    for a, off in enumerate(kw.get("off", ())):
+        b[k].table_offset[a] = off
+
+
+def test_l2c_style_ternary_tables_windows_and_long_blocks(engine):
+    """GPS_L2C/include/tracking.m: RZ-interleaved CM code ({+-1, 0}, 20 460 entries, 20-ms blocks of
+    160 000 samples at 8 Msps) and the CL arm read through a window of a much longer table
+    (index + 2L*(CLCodePhase-1), :261)."""
+    fs, L = 8e6, 20460.0
+    n_if = 340000
+    iq = _noise_iq(n_if, 1)
+    rng = np.random.default_rng(2)
+    cm = rng.choice([-1.0, 1.0], size=10230)
+    cm_rz = np.zeros(20460)
+    cm_rz[0::2] = cm                       # generateCMcode.m:110-111: chip, 0, chip, 0, ...
+    cl_long = np.zeros(20460 * 6)
+    cl_long[1::2] = rng.choice([-1.0, 1.0], size=10230 * 6)
+    tab_cm = O.pad_code(cm_rz)
+    tab_cl = O.pad_code(cl_long)           # long table; one block touches a 20 462-entry window
+    engine.load_if(iq, fs=fs)
+    engine.set_channel(0, [tab_cm.astype(np.int8), tab_cl.astype(np.int8)], windows=[0, 20462])
+    step = 2 * 0.5115e6 / fs * (1 + 1e-6)
+    b = engine.make_blocks(3)
+    descs = []
+    for k, clphase in enumerate((1, 3, 6)):
+        rem = float(rng.uniform(0, step))
+        n = O.blksize_for(L, rem, step)
+        d = dict(channel=0, n=n, s0=int(rng.integers(0, n_if - n)), rem=rem, step=step, d=0.25,
+                 f=float(rng.uniform(-4e3, 4e3)), phi=float(rng.uniform(-3, 3)), off=(0, int(L) * (clphase - 1)))
+        descs.append(d)
+        _block(b, k, **d)
+    got = engine.correlate(b)
+    for k, d in enumerate(descs):
+        raw = O.raw_from_if(iq, d["s0"], d["n"])
+        ref, _, _ = O.correlate_block(raw, [tab_cm, tab_cl], d["rem"], d["step"], d["d"], d["f"], d["phi"], fs, L,
+                                      table_offset=list(d["off"]))
+        sc = np.sum(np.abs(iq[2 * d["s0"]:2 * (d["s0"] + d["n"])].astype(np.float64)))
+        assert d["n"] > 159000
+        assert np.max(np.abs(got[k, :2] - ref)) < TOL * sc, k
+        assert not got[k, 2].any()
+
+
+def test_three_arms_same_ramp(engine):
+    iq = _noise_iq(60000, 3)
+    rng = np.random.default_rng(4)
+    tabs = [O.pad_code(rng.choice([-1.0, 1.0], size=2046)) for _ in range(3)]
+    engine.load_if(iq, fs=18e6)
+    engine.set_channel(5, [t.astype(np.int8) for t in tabs], index_scale=2.0)
+    step = 1.023e6 / 18e6
+    b = engine.make_blocks(4)
+    descs = []
+    for k in range(4):
+        rem = float(rng.uniform(0, step))
+        d = dict(channel=5, n=O.blksize_for(1023.0, rem, step), s0=int(rng.integers(0, 40000)), rem=rem, step=step,
+                 d=0.3, f=2.2e4, phi=0.1 * k)
+        descs.append(d)
+        _block(b, k, **d)
+    for generic in (False, True):
+        engine.force_generic_kernel(generic)
+        try:
+            got = engine.correlate(b)
+        finally:
+            engine.force_generic_kernel(False)
+        for k, d in enumerate(descs):
+            ref, _, _ = O.correlate_block(O.raw_from_if(iq, d["s0"], d["n"]), tabs, d["rem"], d["step"], d["d"], d["f"],
+                                          d["phi"], 18e6, 1023.0, r=2.0)
+            sc = np.sum(np.abs(iq[2 * d["s0"]:2 * (d["s0"] + d["n"])].astype(np.float64)))
+            assert np.max(np.abs(got[k] - ref)) < TOL * sc, (generic, k)
+
+
+def test_mixed_ramp_multipliers_are_rejected_not_miscomputed(engine):
+    """B1C wide-band needs ceil(6*t) for its BOC(6,1) arm (WB_tracking.m:293): not implemented yet ->
+    a loud GC_E_UNSUPPORTED, never a silently wrong sum."""
+    import cu_sdr_collection_amd as P
+    iq = _noise_iq(40000, 5)
+    engine.load_if(iq, fs=18e6)
+    t1 = np.ones(2048, dtype=np.int8)
+    t6 = np.ones(12278, dtype=np.int8)
+    engine.set_channel(7, [t1, t1, t6], index_scale=2.0, arm_mult=[1, 1, 6])
+    b = engine.make_blocks(1)
+    _block(b, 0, channel=7, n=18000, s0=0, rem=0.0, step=1.023e6 / 18e6, d=0.06, f=2e4, phi=0.0)
+    with pytest.raises(P.GnssCorrError) as e:
+        engine.correlate(b)
+    assert e.value.status == P._lib.GC_E_UNSUPPORTED
+
+
+def test_closed_loop_with_int16_and_qi_records(engine, l1ca_scene):
+    """tracking.m:145-148,212-213 (int16) and GLO_GL1/include/tracking.m:227 (Q,I order): the closed loop on
+    a 16-bit copy and on a component-swapped copy of the record reproduces the int8 I/Q run."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    from cu_sdr_collection_amd.receiver import track_params
+    S, sats, iq = l1ca_scene
+    S.msToProcess = 60
+    inits = []
+    for i, s in enumerate(sats[:2]):
+        inits.append(L.gc_channel_init(channel=i, prn=s.prn, acquired_freq=S.IF + s.doppler + 4.0,
+                                       code_freq=S.codeFreqBasis, code_phase=int(np.ceil(s.code_phase_samples)) + 1))
+
+    def run(load):
+        load()
+        for i, s in enumerate(sats[:2]):
+            engine.set_channel(i, [P.codes.padded_table(P.codes.generateCAcode(s.prn))])
+        f, done, st = engine.track(track_params(S), inits)
+        assert st == 0 and list(done) == [60, 60]
+        return f
+
+    base = run(lambda: engine.load_if(iq, fs=S.samplingFreq))
+    i16 = run(lambda: engine.load_if(iq.astype(np.int16), fs=S.samplingFreq))
+    swapped = np.empty_like(iq)
+    swapped[0::2], swapped[1::2] = iq[1::2], iq[0::2]
+    qi = run(lambda: engine.load_if(swapped, layout=L.GC_QI, fs=S.samplingFreq))
+    scale = 2.0 * 18000 * 28.0
+    for other in (i16, qi):
+        assert np.array_equal(other["absoluteSample"], base["absoluteSample"])
+        for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L"):
+            assert np.max(np.abs(other[f] - base[f])) < 1e-6 * scale, f
+        assert np.max(np.abs(other["carrFreq"] - base["carrFreq"])) < 1e-4
