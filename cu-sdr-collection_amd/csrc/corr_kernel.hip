@@ -275,6 +275,94 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
   }
 }
 
+// ---- exact reference kernel for channels whose arms use DIFFERENT ramp multipliers ---------------------
+// (BDS B1C wide-band: data BOC(1,1), pilot BOC(1,1) and pilot BOC(6,1) read through ceil(6*t),
+// BDS/B1C/include/WB_tracking.m:285-317; the 122 762-entry BOC(6,1) table does not fit LDS next to the
+// other two).  One thread per sample (grid-stride), every index from the reference's float64 colon element
+// rule, tables read through L2: simple and exact rather than fast — this is one signal of twelve.
+template <int MODE>
+__global__ __launch_bounds__(kWG) void corr_epl_mixed_kernel(const KArgs p) {
+  __shared__ double red[kWG / 64][GC_OUT_STRIDE];
+  const long long lb = blockIdx.x / p.splits;
+  const int split = (int)(blockIdx.x - lb * p.splits);
+  const gc_block blk = p.blocks[lb];
+  const DevChannel* __restrict__ chn = p.chans + blk.channel;
+  const int arms = chn->arms;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double R = chn->index_scale, rem = blk.rem_code_phase, step = blk.code_phase_step, d = blk.el_spacing;
+  const int N = blk.blksize;
+  const double sp = step * R;
+  const double a3[3] = {(rem - d) * R, rem * R, (rem + d) * R};
+  const double nm1s = __dmul_rn((double)(N - 1), step);
+  const double b3[3] = {__dmul_rn(__dadd_rn(__dadd_rn(nm1s, rem), -d), R), __dmul_rn(__dadd_rn(nm1s, rem), R),
+                        __dmul_rn(__dadd_rn(__dadd_rn(nm1s, rem), d), R)};
+  const double tau = blk.carr_freq / p.fs;
+  const double ph0 = blk.rem_carr_phase * 0.15915494309189535;
+  const int per = (N + p.splits - 1) / p.splits;
+  const int i_beg = split * per, i_end = min(N, i_beg + per);
+  float acc[GC_OUT_STRIDE];
+#pragma unroll
+  for (int v = 0; v < GC_OUT_STRIDE; ++v) acc[v] = 0.f;
+  constexpr int bps = (MODE == I8_IQ || MODE == I8_QI || MODE == I16_REAL) ? 2 : (MODE == I8_REAL) ? 1 : 4;
+  for (int i = i_beg + tid; i < i_end; i += kWG) {
+    const uint8_t* s = p.if_base + (size_t)(blk.first_sample + i) * bps;
+    float a, b;
+    if (MODE == I8_IQ || MODE == I8_QI) {
+      a = (float)(signed char)s[0];
+      b = (float)(signed char)s[1];
+    } else if (MODE == I16_IQ || MODE == I16_QI) {
+      a = (float)((const short*)s)[0];
+      b = (float)((const short*)s)[1];
+    } else if (MODE == I8_REAL) {
+      a = (float)(signed char)s[0];
+      b = 0.f;
+    } else {
+      a = (float)((const short*)s)[0];
+      b = 0.f;
+    }
+    if (MODE == I8_QI || MODE == I16_QI) {
+      const float t = a;
+      a = b;
+      b = t;
+    }
+    const double ph = ph0 + (double)i * tau;
+    float sn, cs;
+    sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
+    const float xr = a * cs + b * sn, xi = b * cs - a * sn;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      double t;
+      if (2 * i < N - 1)
+        t = __dadd_rn(a3[x], __dmul_rn((double)i, sp));
+      else if (2 * i > N - 1)
+        t = __dadd_rn(b3[x], -__dmul_rn((double)(N - 1 - i), sp));
+      else
+        t = __dadd_rn(a3[x], b3[x]) / 2.0;
+      for (int ar = 0; ar < arms; ++ar) {
+        const int k = (int)ceil(__dmul_rn(t, chn->mult[ar])) + blk.table_offset[ar];
+        const float c = (float)chn->tab[ar][min(max(k, 0), chn->nent[ar] - 1)];
+        acc[ar * 6 + 2 * x] = fmaf(c, xr, acc[ar * 6 + 2 * x]);
+        acc[ar * 6 + 2 * x + 1] = fmaf(c, xi, acc[ar * 6 + 2 * x + 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < GC_OUT_STRIDE; ++v) {
+    float x = acc[v];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane == 0) red[wave][v] = (double)x;
+  }
+  __syncthreads();
+  if (tid < GC_OUT_STRIDE) {
+    double sum = 0.0;
+    for (int w = 0; w < kWG / 64; ++w) sum += red[w][tid];
+    if (p.splits == 1)
+      p.out[lb * GC_OUT_STRIDE + tid] = sum;
+    else
+      p.partial[(lb * p.splits + split) * GC_OUT_STRIDE + tid] = sum;
+  }
+}
+
 __global__ void combine_partials_kernel(const double* __restrict__ partial, double* __restrict__ out,
                                         long long nblocks, int splits) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,7 +433,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     a.stride = period;
     total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
   }
-  a.xcd_swizzle = (total % 8 == 0 && total >= 64) ? 1 : 0;
+  a.xcd_swizzle = (fast >= 0 && total % 8 == 0 && total >= 64) ? 1 : 0;
   if (total > 0x7fffffffLL) {
     gc_set_error("too many workgroups (%lld)", total);
     return GC_E_INVALID;
@@ -353,7 +441,23 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   const size_t smem = (size_t)ctx->max_lds_bytes + kWG / 64 * GC_OUT_STRIDE * sizeof(float);
   dim3 grid((unsigned int)total);
   int rc;
-  if (fast) {
+  if (fast < 0) {
+    // mixed ramp multipliers: exact per-sample kernel
+    int mode;
+    if (ctx->if_dtype == GC_I8)
+      mode = ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
+    else
+      mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
+    switch (mode) {
+      case I8_IQ: hipLaunchKernelGGL((corr_epl_mixed_kernel<I8_IQ>), grid, dim3(kWG), 0, ctx->stream, a); break;
+      case I8_QI: hipLaunchKernelGGL((corr_epl_mixed_kernel<I8_QI>), grid, dim3(kWG), 0, ctx->stream, a); break;
+      case I16_IQ: hipLaunchKernelGGL((corr_epl_mixed_kernel<I16_IQ>), grid, dim3(kWG), 0, ctx->stream, a); break;
+      case I16_QI: hipLaunchKernelGGL((corr_epl_mixed_kernel<I16_QI>), grid, dim3(kWG), 0, ctx->stream, a); break;
+      case I8_REAL: hipLaunchKernelGGL((corr_epl_mixed_kernel<I8_REAL>), grid, dim3(kWG), 0, ctx->stream, a); break;
+      default: hipLaunchKernelGGL((corr_epl_mixed_kernel<I16_REAL>), grid, dim3(kWG), 0, ctx->stream, a); break;
+    }
+    rc = (hipGetLastError() == hipSuccess) ? GC_OK : GC_E_HIP;
+  } else if (fast) {
     a.red_off = 8 * ctx->max_lds_bytes;  // float2 {c, dc} tables: 8 bytes per staged entry
     rc = gc_launch_correlator_fast(ctx, a, ib, (unsigned int)total, max_arms, fast == 2);
   } else {

@@ -386,8 +386,10 @@ int gc_sync_channels(gc_context* ctx) {
       d.lds_off[a] = off;
       off += ((d.stage_len[a] + 8 + 15) / 16) * 16;
     }
+    bool mixed = false;
+    for (int a = 1; a < c.arms; ++a) mixed |= c.mult[a] != c.mult[0];
     d.lds_bytes = off;
-    max_lds = std::max(max_lds, off);
+    if (!mixed) max_lds = std::max(max_lds, off);  // mixed-multiplier channels use the LDS-free exact kernel
   }
   if (max_lds > 150 * 1024) {
     gc_set_error("code tables need %d bytes of LDS (> 150 KiB); set a window with gc_set_code_window", max_lds);
@@ -435,17 +437,16 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
         gc_set_error("block %lld: channel %d arm %d has no code table", (long long)i, k.channel, a);
         return GC_E_STATE;
       }
-      if (c.mult[a] != c.mult[0]) {
-        gc_set_error("channel %d: arms with different ramp multipliers are not supported yet", k.channel);
-        return GC_E_UNSUPPORTED;
-      }
+      if (c.mult[a] != c.mult[0]) *all_lowrate = -1;  // mixed multipliers: exact per-sample kernel
       if (k.table_offset[a] < 0 || k.table_offset[a] + 3 > c.nent[a]) {
         gc_set_error("block %lld: table offset out of range", (long long)i);
         return GC_E_INVALID;
       }
     }
+    double max_mult = c.mult[0];
+    for (int a = 1; a < c.arms; ++a) max_mult = std::max(max_mult, c.mult[a]);
     if (k.blksize <= 0 || k.first_sample < 0 || !(k.code_phase_step > 0) ||
-        !(k.el_spacing * c.index_scale * c.mult[0] < 1.0) || !(k.el_spacing >= 0) ||
+        !(k.el_spacing * c.index_scale * max_mult < 1.0) || !(k.el_spacing >= 0) ||
         !(k.rem_code_phase > -1.0) || !std::isfinite(k.carr_freq) || !std::isfinite(k.rem_carr_phase)) {
       gc_set_error("block %lld: invalid descriptor", (long long)i);
       return GC_E_INVALID;
@@ -457,9 +458,9 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
       return GC_E_RANGE;  // tracking.m:241-245
     }
     // highest table index the ramps can reach must stay inside the staged window
-    const double tmax = ((k.blksize - 1) * k.code_phase_step + k.rem_code_phase + k.el_spacing) *
-                        c.index_scale * c.mult[0];
     for (int a = 0; a < c.arms; ++a) {
+      const double tmax = ((k.blksize - 1) * k.code_phase_step + k.rem_code_phase + k.el_spacing) *
+                          c.index_scale * c.mult[a];
       const int stage = (c.window[a] > 0) ? std::min(c.window[a], c.nent[a]) : c.nent[a];
       const int avail = std::min(stage, c.nent[a] - k.table_offset[a]);
       if (std::ceil(tmax) > avail - 1) {
@@ -469,7 +470,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
       }
     }
     max_arms = std::max(max_arms, c.arms);
-    *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
+    if (*all_lowrate >= 0) *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
   }
   return max_arms;
 }
@@ -513,8 +514,8 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
-  const int fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
-  const int splits = choose_splits(ctx, nblocks, blocks, fast ? 64 : 256, fast == 2 ? 16 : 8);
+  const int fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
+  const int splits = choose_splits(ctx, nblocks, blocks, fast > 0 ? 64 : 256, fast == 2 ? 16 : 8);
   if ((rc = ensure((void**)&ctx->d_blocks, &ctx->d_blocks_cap, nblocks, sizeof(gc_block)))) return rc;
   if ((rc = ensure((void**)&ctx->d_out, &ctx->d_out_cap, (int64_t)nblocks * GC_OUT_STRIDE, sizeof(double)))) return rc;
   if (splits > 1 &&
@@ -539,7 +540,7 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
-  ctx->replay_fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
+  ctx->replay_fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
   if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
@@ -580,7 +581,7 @@ int gc_replay_launch(gc_context* ctx) {
   }
   GC_HIP(hipSetDevice(ctx->device));
   int splits = 1;
-  const int wg_waves = ctx->replay_fast ? 1 : 4;
+  const int wg_waves = ctx->replay_fast > 0 ? 1 : 4;
   if (ctx->replay_nblocks * wg_waves < 8 * (int64_t)ctx->compute_units) {
     // small replay sets: split blocks over several workgroups, scratch from d_partial
     splits = (int)std::min<int64_t>(8, (8 * (int64_t)ctx->compute_units / wg_waves + ctx->replay_nblocks - 1) / ctx->replay_nblocks);

@@ -66,6 +66,11 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
         return GC_E_STATE;
       }
     max_arms = std::max(max_arms, ctx->ch[ci].arms);
+    for (int a = 1; a < ctx->ch[ci].arms; ++a)
+      if (ctx->ch[ci].mult[a] != ctx->ch[ci].mult[0]) {
+        gc_set_error("gc_track: channel %d mixes ramp multipliers (B1C wide-band): closed loop not wired up, use gc_correlate", ci);
+        return GC_E_UNSUPPORTED;
+      }
   }
   if (p->pilot_combine != 0 && max_arms < 2) {
     gc_set_error("gc_track: pilot_combine requires a pilot arm");

@@ -97,20 +97,36 @@ def test_three_arms_same_ramp(engine):
             assert np.max(np.abs(got[k] - ref)) < TOL * sc, (generic, k)
 
 
-def test_mixed_ramp_multipliers_are_rejected_not_miscomputed(engine):
-    """B1C wide-band needs ceil(6*t) for its BOC(6,1) arm (WB_tracking.m:293): not implemented yet ->
-    a loud GC_E_UNSUPPORTED, never a silently wrong sum."""
-    import cu_sdr_collection_amd as P
-    iq = _noise_iq(40000, 5)
-    engine.load_if(iq, fs=18e6)
-    t1 = np.ones(2048, dtype=np.int8)
-    t6 = np.ones(12278, dtype=np.int8)
-    engine.set_channel(7, [t1, t1, t6], index_scale=2.0, arm_mult=[1, 1, 6])
-    b = engine.make_blocks(1)
-    _block(b, 0, channel=7, n=18000, s0=0, rem=0.0, step=1.023e6 / 18e6, d=0.06, f=2e4, phi=0.0)
-    with pytest.raises(P.GnssCorrError) as e:
-        engine.correlate(b)
-    assert e.value.status == P._lib.GC_E_UNSUPPORTED
+def test_b1c_wideband_mixed_ramp_multipliers(engine):
+    """BDS/B1C/include/WB_tracking.m:176-188,285-369: data BOC(1,1), pilot BOC(1,1) (index ceil(t), t the
+    R = 2 ramp) and pilot BOC(6,1) (index ceil(6*t) into a 12*L+2 table), 10-ms blocks, d = 0.06 chip."""
+    fs, L = 18e6, 10230.0
+    n_if = 200000
+    iq = _noise_iq(n_if, 5)
+    rng = np.random.default_rng(6)
+    chips_d, chips_p = rng.choice([-1.0, 1.0], size=10230), rng.choice([-1.0, 1.0], size=10230)
+    boc11 = lambda c: (np.repeat(c, 2) * np.tile([-1.0, 1.0], c.size))          # generateDataBOC11.m: chip x [-1,+1]
+    boc61 = lambda c: (np.repeat(c, 12) * np.tile([-1.0, 1.0], 6 * c.size))     # generatePilotBOC61.m:89-96
+    tabs = [O.pad_code(boc11(chips_d)), O.pad_code(boc11(chips_p)), O.pad_code(boc61(chips_p))]
+    assert tabs[2].shape == (122762,)
+    engine.load_if(iq, fs=fs)
+    engine.set_channel(7, [t.astype(np.int8) for t in tabs], index_scale=2.0, arm_mult=[1, 1, 6])
+    step = 1.023e6 / fs * (1 - 2e-6)
+    b = engine.make_blocks(2)
+    descs = []
+    for k in range(2):
+        rem = 0.0 if k == 0 else float(rng.uniform(0, step))
+        n = O.blksize_for(L, rem, step)
+        d = dict(channel=7, n=n, s0=int(rng.integers(0, n_if - n)), rem=rem, step=step, d=0.06,
+                 f=float(rng.uniform(1.5e4, 2.5e4)), phi=float(rng.uniform(-3, 3)))
+        descs.append(d)
+        _block(b, k, **d)
+    got = engine.correlate(b)
+    for k, d in enumerate(descs):
+        ref, _, _ = O.correlate_block(O.raw_from_if(iq, d["s0"], d["n"]), tabs, d["rem"], d["step"], d["d"], d["f"],
+                                      d["phi"], fs, L, r=2.0, arm_mult=[1.0, 1.0, 6.0])
+        sc = np.sum(np.abs(iq[2 * d["s0"]:2 * (d["s0"] + d["n"])].astype(np.float64)))
+        assert d["n"] > 179000 and np.max(np.abs(got[k] - ref)) < TOL * sc, k
 
 
 def test_closed_loop_with_int16_and_qi_records(engine, l1ca_scene):
