@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgnsscorr.so")
+LIB_PATH = os.environ.get("GC_LIB_PATH") or os.path.join(HERE, "lib", "libgnsscorr.so")  # env override: tuning builds
 
 GC_OK, GC_E_INVALID, GC_E_RANGE, GC_E_NOMEM, GC_E_HIP, GC_E_STATE, GC_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 GC_I8, GC_I16 = 0, 1

@@ -27,6 +27,9 @@ namespace {
 constexpr float kBig = 8388608.0f;  // 2^23: clamp(kBig*(j-u)) is exactly 0 or 1 outside the tie band
 constexpr float kTieTol = 4e-6f;
 constexpr int kFW = 64;  // one wavefront per workgroup
+#ifndef GC_SCHED_GROUP
+#define GC_SCHED_GROUP 4
+#endif
 
 template <int MODE>
 struct Fmt {
@@ -154,7 +157,9 @@ __device__ __forceinline__ gc_block load_block(const KArgs& p, long long lb) {
 
 // CL = closed-loop variant: descriptors from the kernel-argument segment, results as host-mapped tagged
 // records.  The replay instantiation (CL = false) carries none of that code.
-template <int ARMS, int MODE, int SPL, bool CL>
+// SHARE = every block of the launch has earlyLateSpc*R*M == 1/2 (host-checked): early and late share one
+// step mask.  A separate instantiation per value — both variants inside one kernel measured 25 % slower.
+template <int ARMS, int MODE, int SPL, bool CL, bool SHARE_EL>
 __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = SPL * Fmt<MODE>::bps / 4;
@@ -278,6 +283,14 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
     fx[2] = to_fx(__dmul_rn(__dadd_rn(aL, isp), M));
     const uint8_t* __restrict__ base = p.if_base;
 
+    // With earlyLateSpc*R*M = 1/2 (the reference's default 0.5-chip spacing) the early and late ramps differ by
+    // exactly one table entry: same fraction, same transition position in every chunk, so they share one
+    // step mask and one S sum (3 of 17 VALU instructions per sample less).  Decided once per block.
+    const bool share_lane = ((fx[0].G - fx[2].G + (1ull << 23)) >> 24) == 0;
+    const bool share_broken = SHARE_EL && __all(share_lane) == 0;  // never expected: then every chunk goes exact
+    auto chunk_loop = [&](auto share_tag) {
+    constexpr bool SHARE = decltype(share_tag)::value;
+    constexpr int NS = SHARE ? 2 : 3;
     unsigned int w[NW];
     load_words<MODE, SPL>(base, q0 + c, w);
     while (true) {
@@ -289,12 +302,12 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
       if (__builtin_expect((i0 < 0) | (i0 + SPL > N), 0)) mask_words<MODE, SPL>(w, i0, N);
 
       // transition positions and the near-tie filter
-      float gh[3];
-      bool suspect = false;
+      float gh[NS];
+      bool suspect = share_broken;
 #pragma unroll
-      for (int x = 0; x < 3; ++x) {
-        gh[x] = (float)(unsigned int)(fx[x].G >> 32);
-        const float u = gh[x] * uk;
+      for (int sx = 0; sx < NS; ++sx) {
+        gh[sx] = (float)(unsigned int)(fx[sx].G >> 32);  // sets: 0 = early (and late when shared), 1 = prompt, 2 = late
+        const float u = gh[sx] * uk;
         suspect |= fabsf(u - rintf(u)) < kTieTol;
       }
 
@@ -305,40 +318,66 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
         for (int ar = 0; ar < ARMS; ++ar)
 #pragma unroll
           for (int x = 0; x < 3; ++x) Ur[ar][x] = Ui[ar][x] = 0.0f;
-        static_for<0, SPL>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          float a, b;
-          sample_ab<MODE, j, NW>(w, a, b);
-          const float yr = kReal ? a * C[j] : fmaf(a, C[j], b * S[j]);
-          const float yi = kReal ? -a * S[j] : fmaf(b, C[j], -a * S[j]);
-          const int i = i0 + j;
+        // A rolled loop that re-reads the chunk's samples from memory (L1-resident) and carries delta^j by
+        // recurrence: the rare path must not set the kernel's register budget (unrolled it cost 200 VGPRs).
+        {
+          const uint8_t* sp8 = base + (long long)(SPL * Fmt<MODE>::bps) * (q0 + c);
+          float cr = 1.0f, ci = 0.0f;  // delta^j = cr - i*ci
+#pragma unroll 1
+          for (int j = 0; j < SPL; ++j) {
+            const int i = i0 + j;
+            float x0, x1 = 0.0f;
+            if constexpr (Fmt<MODE>::bps == 2 && !kReal) {
+              x0 = (float)(signed char)sp8[2 * j];
+              x1 = (float)(signed char)sp8[2 * j + 1];
+            } else if constexpr (Fmt<MODE>::bps == 4) {
+              x0 = (float)reinterpret_cast<const short*>(sp8)[2 * j];
+              x1 = (float)reinterpret_cast<const short*>(sp8)[2 * j + 1];
+            } else if constexpr (Fmt<MODE>::bps == 1) {
+              x0 = (float)(signed char)sp8[j];
+            } else {
+              x0 = (float)reinterpret_cast<const short*>(sp8)[j];
+            }
+            float a = Fmt<MODE>::swap ? x1 : x0, b = Fmt<MODE>::swap ? x0 : x1;
+            if ((unsigned int)i >= (unsigned int)N) a = b = 0.0f;  // edge chunk
+            const float yr = a * cr + b * ci;
+            const float yi = b * cr - a * ci;
+            const float ncr = cr * C[1] - ci * S[1], nci = cr * S[1] + ci * C[1];
+            cr = ncr;
+            ci = nci;
 #pragma unroll
-          for (int x = 0; x < 3; ++x) {
-            const double ax = (x == 0) ? aE : (x == 1) ? aP : aL;
-            const double bx = (x == 0) ? bE : (x == 1) ? bP : bL;
-            double t;
-            if (2 * i < N - 1)
-              t = __dadd_rn(ax, __dmul_rn((double)i, sp));
-            else if (2 * i > N - 1)
-              t = __dadd_rn(bx, -__dmul_rn((double)(N - 1 - i), sp));
-            else
-              t = __dadd_rn(ax, bx) / 2.0;
-            int k = (int)ceil(__dmul_rn(t, M));
-            k = max(-1, min(k, 0x3fffffff));
+            for (int x = 0; x < 3; ++x) {
+              const double ax = (x == 0) ? aE : (x == 1) ? aP : aL;
+              const double bx = (x == 0) ? bE : (x == 1) ? bP : bL;
+              double t;
+              if (2 * i < N - 1)
+                t = __dadd_rn(ax, __dmul_rn((double)i, sp));
+              else if (2 * i > N - 1)
+                t = __dadd_rn(bx, -__dmul_rn((double)(N - 1 - i), sp));
+              else
+                t = __dadd_rn(ax, bx) / 2.0;
+              int k = (int)ceil(__dmul_rn(t, M));
+              k = max(-1, min(k, 0x3fffffff));
 #pragma unroll
-            for (int ar = 0; ar < ARMS; ++ar) {
-              const int kk = min(k, chn->stage_len[(ar < arms_here) ? ar : 0] + 1);
-              const float cf = tab2[ar][kk + 1].x;
-              Ur[ar][x] = fmaf(cf, yr, Ur[ar][x]);
-              Ui[ar][x] = fmaf(cf, yi, Ui[ar][x]);
+              for (int ar = 0; ar < ARMS; ++ar) {
+                const int kk = min(k, chn->stage_len[(ar < arms_here) ? ar : 0] + 1);
+                const float cf = tab2[ar][kk + 1].x;
+                Ur[ar][x] = fmaf(cf, yr, Ur[ar][x]);
+                Ui[ar][x] = fmaf(cf, yi, Ui[ar][x]);
+              }
             }
           }
-        });
+        }
       } else {
         // ---- fast path ------------------------------------------------------------------------------
-        float Tr = 0.f, Ti = 0.f, Sr[3] = {0.f, 0.f, 0.f}, Si[3] = {0.f, 0.f, 0.f};
+        float Tr = 0.f, Ti = 0.f, Sr[NS], Si[NS];
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) Sr[sx] = Si[sx] = 0.f;
         static_for<0, SPL>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
+          // keep the scheduler from hoisting all 32 conversions / 64 carrier products to the top of the
+          // chunk (200+ VGPRs, 2 waves per SIMD): fence the instruction stream every GC_SCHED_GROUP samples
+          if constexpr (j % GC_SCHED_GROUP == 0 && j != 0) __builtin_amdgcn_sched_barrier(0);
           float a, b;
           sample_ab<MODE, j, NW>(w, a, b);
           const float yr = kReal ? a * C[j] : fmaf(a, C[j], b * S[j]);
@@ -346,20 +385,21 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
           Tr += yr;
           Ti += yi;
 #pragma unroll
-          for (int x = 0; x < 3; ++x) {
+          for (int sx = 0; sx < NS; ++sx) {
             // 1 iff j > u  (v_fma_f32 ... clamp)
-            const float s = __builtin_amdgcn_fmed3f(fmaf(-gh[x], ukB, KJ[j]), 0.0f, 1.0f);
-            Sr[x] = fmaf(s, yr, Sr[x]);
-            Si[x] = fmaf(s, yi, Si[x]);
+            const float s = __builtin_amdgcn_fmed3f(fmaf(-gh[sx], ukB, KJ[j]), 0.0f, 1.0f);
+            Sr[sx] = fmaf(s, yr, Sr[sx]);
+            Si[sx] = fmaf(s, yi, Si[sx]);
           }
         });
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
 #pragma unroll
           for (int ar = 0; ar < ARMS; ++ar) {
+            const int sx = (SHARE && x == 2) ? 0 : x;
             const float2 cd = tab2[ar][fx[x].k0 + 1];
-            Ur[ar][x] = fmaf(cd.x, Tr, cd.y * Sr[x]);
-            Ui[ar][x] = fmaf(cd.x, Ti, cd.y * Si[x]);
+            Ur[ar][x] = fmaf(cd.x, Tr, cd.y * Sr[sx]);
+            Ui[ar][x] = fmaf(cd.x, Ti, cd.y * Si[sx]);
           }
         }
       }
@@ -385,6 +425,8 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
 #pragma unroll
       for (int k = 0; k < NW; ++k) w[k] = wn[k];
     }
+    };
+    chunk_loop(std::integral_constant<bool, SHARE_EL>{});
     // exact carrier phase at the first sample of this thread's LAST chunk
     const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i0 * tau;
     sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
@@ -424,6 +466,23 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
   }  // bpw loop
 
 }
+template <int ARMS, int MODE, int SPL>
+void launch_variant(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem) {
+  const bool cl = a.tagged != nullptr;
+  // the shared-early/late instantiation exists for single-arm channels (GPS L1 C/A, B1I, GLONASS)
+  const bool share = (ARMS == 1) && a.share_el != 0;
+  if constexpr (ARMS == 1) {
+    if (cl && share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, true>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, true>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+  } else {
+    (void)share;
+    if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+  }
+}
+
 template <int ARMS, int SPL>
 int launch_fast_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem) {
   int mode;
@@ -432,12 +491,12 @@ int launch_fast_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, di
   else
     mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
   switch (mode) {
-    case I8_IQ: if (a.tagged) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_IQ, SPL, true>), grid, dim3(kFW), smem, ctx->stream, a, ib); else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_IQ, SPL, false>), grid, dim3(kFW), smem, ctx->stream, a, ib); break;
-    case I8_QI: if (a.tagged) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_QI, SPL, true>), grid, dim3(kFW), smem, ctx->stream, a, ib); else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_QI, SPL, false>), grid, dim3(kFW), smem, ctx->stream, a, ib); break;
-    case I16_IQ: if (a.tagged) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_IQ, 8, true>), grid, dim3(kFW), smem, ctx->stream, a, ib); else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_IQ, 8, false>), grid, dim3(kFW), smem, ctx->stream, a, ib); break;
-    case I16_QI: if (a.tagged) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_QI, 8, true>), grid, dim3(kFW), smem, ctx->stream, a, ib); else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_QI, 8, false>), grid, dim3(kFW), smem, ctx->stream, a, ib); break;
-    case I8_REAL: if (a.tagged) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_REAL, 8, true>), grid, dim3(kFW), smem, ctx->stream, a, ib); else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I8_REAL, 8, false>), grid, dim3(kFW), smem, ctx->stream, a, ib); break;
-    default: if (a.tagged) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_REAL, 8, true>), grid, dim3(kFW), smem, ctx->stream, a, ib); else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, I16_REAL, 8, false>), grid, dim3(kFW), smem, ctx->stream, a, ib); break;
+    case I8_IQ: launch_variant<ARMS, I8_IQ, SPL>(ctx, a, ib, grid, smem); break;
+    case I8_QI: launch_variant<ARMS, I8_QI, SPL>(ctx, a, ib, grid, smem); break;
+    case I16_IQ: launch_variant<ARMS, I16_IQ, 8>(ctx, a, ib, grid, smem); break;
+    case I16_QI: launch_variant<ARMS, I16_QI, 8>(ctx, a, ib, grid, smem); break;
+    case I8_REAL: launch_variant<ARMS, I8_REAL, 8>(ctx, a, ib, grid, smem); break;
+    default: launch_variant<ARMS, I16_REAL, 8>(ctx, a, ib, grid, smem); break;
   }
   GC_HIP(hipGetLastError());
   return GC_OK;

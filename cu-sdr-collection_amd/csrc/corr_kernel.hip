@@ -396,7 +396,8 @@ int launch_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
 }  // namespace
 
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
-                         double* d_out, double* d_partial, int max_arms, int fast, int period, unsigned int notify_tag) {
+                         double* d_out, double* d_partial, int max_arms, int fast, int period, unsigned int notify_tag,
+                         bool share_el) {
   if (nblocks <= 0) return GC_OK;
   KArgs a;
   a.if_base = ctx->d_if;
@@ -414,6 +415,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   a.tagged = nullptr;
   a.notify_tag = 0;
   a.use_inline = 0;
+  a.share_el = share_el ? 1 : 0;
   if (fast && notify_tag != 0 && ctx->h_tagged_pinned) {
     // closed loop: d_blocks is the host-mapped descriptor buffer (readable by the host right here)
     a.tagged = reinterpret_cast<TaggedSlot*>(ctx->h_tagged_pinned);

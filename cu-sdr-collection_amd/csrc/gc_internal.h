@@ -89,7 +89,8 @@ struct gc_context {
   int64_t replay_nblocks = 0;
   int replay_max_arms = 1;
   int replay_fast = 0;
-  int replay_period = 0;  // channel pattern period of the replay list (0 = not periodic)
+  int replay_period = 0;
+  bool replay_share_el = false;  // channel pattern period of the replay list (0 = not periodic)
   bool force_generic = false;
 
   // acquisition scratch (acq.hip)
@@ -102,7 +103,9 @@ int gc_sync_channels(gc_context* ctx);
 // Launches the correlator for `nblocks` descriptors already on the device.
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
                          double* d_out, double* d_partial, int max_arms, int fast, int period = 0,
-                         unsigned int notify_tag = 0);
+                         unsigned int notify_tag = 0, bool share_el = false);
+// el_spacing * R * M == 1/2 exactly: early and late ramps differ by one whole table entry
+bool gc_block_shares_el(const gc_context* ctx, const gc_block& b);
 // Kernel class a block qualifies for: 0 = generic only, 1 = fast kernel with 8-sample lane-chunks,
 // 2 = fast kernel with 16-sample lane-chunks (at most one table transition per chunk and tap).
 int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b);

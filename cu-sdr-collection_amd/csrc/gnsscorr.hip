@@ -410,12 +410,18 @@ int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b) {
   return (15.0 * s < 0.995) ? 2 : (7.0 * s < 0.995) ? 1 : 0;
 }
 
+bool gc_block_shares_el(const gc_context* ctx, const gc_block& b) {
+  const HostChannel& c = ctx->ch[b.channel];
+  return c.arms == 1 && b.el_spacing * c.index_scale * c.mult[0] == 0.5;
+}
+
 bool gc_fast_lds_ok(const gc_context* ctx) { return 8 * ctx->max_lds_bytes + 512 <= 64 * 1024; }
 
 // Validates descriptors on the host; returns the largest arm count among the referenced
 // channels, or a negative status.  *all_lowrate is cleared if any block needs the generic kernel.
-static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* all_lowrate) {
+static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* all_lowrate, bool* all_share = nullptr) {
   *all_lowrate = 2;
+  if (all_share) *all_share = true;
   if (!ctx->d_if) {
     gc_set_error("no IF buffer loaded");
     return GC_E_STATE;
@@ -471,6 +477,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
     }
     max_arms = std::max(max_arms, c.arms);
     if (*all_lowrate >= 0) *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
+    if (all_share && !gc_block_shares_el(ctx, k)) *all_share = false;
   }
   return max_arms;
 }
@@ -510,7 +517,8 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
   if (nblocks == 0) return GC_OK;
   GC_HIP(hipSetDevice(ctx->device));
   int lowrate;
-  const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate);
+  bool share;
+  const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate, &share);
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
@@ -522,7 +530,7 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
       (rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, (int64_t)nblocks * splits * GC_OUT_STRIDE, sizeof(double))))
     return rc;
   GC_HIP(hipMemcpyAsync(ctx->d_blocks, blocks, sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
-  rc = gc_launch_correlator(ctx, ctx->d_blocks, nblocks, splits, ctx->d_out, ctx->d_partial, max_arms, fast);
+  rc = gc_launch_correlator(ctx, ctx->d_blocks, nblocks, splits, ctx->d_out, ctx->d_partial, max_arms, fast, 0, 0u, share);
   if (rc) return rc;
   GC_HIP(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)nblocks * GC_OUT_STRIDE, hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
@@ -536,10 +544,12 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   }
   GC_HIP(hipSetDevice(ctx->device));
   int lowrate;
-  const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate);
+  bool share;
+  const int max_arms = validate_blocks(ctx, nblocks, blocks, &lowrate, &share);
   if (max_arms < 0) return max_arms;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
+  ctx->replay_share_el = share;
   ctx->replay_fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
@@ -589,7 +599,8 @@ int gc_replay_launch(gc_context* ctx) {
     if (rc) return rc;
   }
   return gc_launch_correlator(ctx, ctx->d_replay_blocks, ctx->replay_nblocks, splits, ctx->d_replay_out,
-                              ctx->d_partial, ctx->replay_max_arms, ctx->replay_fast, ctx->replay_period);
+                              ctx->d_partial, ctx->replay_max_arms, ctx->replay_fast, ctx->replay_period, 0u,
+                              ctx->replay_share_el);
 }
 
 int gc_replay_fetch(gc_context* ctx, double* out) {

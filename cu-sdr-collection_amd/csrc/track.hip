@@ -174,10 +174,12 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     if (nb == 0) break;
     int fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
     for (int k = 0; k < nb && fast; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
+    bool share = true;
+    for (int k = 0; k < nb && share; ++k) share = gc_block_shares_el(ctx, blocks[k]);
     const unsigned int tag = (unsigned int)(e + 1);
     const bool polled = poll && fast != 0;
     rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast, 0,
-                              polled ? tag : 0u);
+                              polled ? tag : 0u, share);
     if (rc) return rc;
     bool signalled = false;
     if (polled) {
