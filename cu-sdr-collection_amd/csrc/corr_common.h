@@ -45,6 +45,7 @@ struct KArgs {
   // Up to kInlineBlocks descriptors travel in the kernel-argument segment (no PCIe read of the
   // host-mapped descriptor buffer at the start of every workgroup).
   int use_inline;
+  int wide;      // fast kernel variant with 4 waves per workgroup and int8-pair LDS tables
   int share_el;  // every block has el_spacing*R*M == 1/2: early and late taps share their step mask
 };
 

@@ -159,8 +159,12 @@ __device__ __forceinline__ gc_block load_block(const KArgs& p, long long lb) {
 // records.  The replay instantiation (CL = false) carries none of that code.
 // SHARE = every block of the launch has earlyLateSpc*R*M == 1/2 (host-checked): early and late share one
 // step mask.  A separate instantiation per value — both variants inside one kernel measured 25 % slower.
-template <int ARMS, int MODE, int SPL, bool CL, bool SHARE_EL>
-__global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
+// WIDE = four wavefronts per workgroup sharing ONE staged table kept as int8 pairs {c, dc} (2 bytes per
+// entry instead of 8): for tables that would otherwise leave one wave per SIMD (Galileo E1 B+C: 2 x 8186
+// entries = 131 KB as float2, 33 KB as int8 pairs).  Every wave owns its own blocks / splits; the only
+// barrier is the one after staging.
+template <int ARMS, int MODE, int SPL, bool CL, bool SHARE_EL, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = SPL * Fmt<MODE>::bps / 4;
   constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
@@ -175,38 +179,68 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
   // epoch) one workgroup walks bpw consecutive epochs of ONE channel, so the code table is staged
   // into LDS once per bpw blocks; neighbouring workgroups hold the other channels of the same
   // epochs and read the same IF window through the same L2.
-  const long long wq = wg / p.splits;
-  const int split = (int)(wg - wq * p.splits);
+  const int lane = threadIdx.x & 63;
+  const int wave = WIDE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // wave-uniform (SGPR)
+  // WIDE, single block per item (closed loop / small lists): the four waves take four consecutive
+  // (block, split) items — the host keeps splits a multiple of 4 so they share block and table;
+  // WIDE, periodic replay: the waves interleave over the workgroup's bpw blocks.
+  const bool wave_items = WIDE && p.bpw == 1;
+  const long long item = wave_items ? wg * 4 + wave : wg;
+  const long long wq = item / p.splits;
+  const int split = (int)(item - wq * p.splits);
   const long long grp = wq / p.stride;
   const int cslot = (int)(wq - grp * p.stride);
-  const int lane = threadIdx.x;  // one wavefront per workgroup
+  if (wave_items && wq >= p.nblocks) {
+    // tail of the last workgroup: still has to reach the staging barrier below
+  }
 
   // ---- stage {c[k], c[k+1]-c[k]} for k = -1 .. nent (c[-1] := c[0], c[>=nent] := 0), once per
   //      workgroup: the host guarantees that all blocks of a workgroup share channel and offsets
   float2* tab2[ARMS];
+  unsigned short* tab16[ARMS];
   {
-    const long long lb0 = grp * p.bpw * p.stride + cslot;
+    const long long lb0 = min(grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
     const gc_block blk0 = CL ? load_block(p, lb0) : p.blocks[lb0];
     const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
 #pragma unroll
     for (int a = 0; a < ARMS; ++a) {
       const int aa = (a < chn0->arms) ? a : 0;
       tab2[a] = reinterpret_cast<float2*>(smem + 8 * (size_t)chn0->lds_off[aa]);
+      tab16[a] = reinterpret_cast<unsigned short*>(smem + 2 * (size_t)chn0->lds_off[aa]);
       if (a < chn0->arms) {
         const int off = blk0.table_offset[a];
         const int n = min(chn0->stage_len[a], chn0->nent[a] - off);
         // window-relative entry i <-> absolute entry off + i of the pre-differenced table; all loads
-        // are independent 8-byte coalesced reads (one wait), which matters for the closed loop where a
+        // are independent coalesced reads (one wait), which matters for the closed loop where a
         // launch is only a few microseconds long
-        const float2* __restrict__ src = chn0->tab2[a] + off;
+        if constexpr (WIDE) {
+          const unsigned short* __restrict__ src = chn0->tab2b[a] + off;
 #pragma unroll 4
-        for (int i = lane; i < n + 3; i += kFW) tab2[a][i] = src[i];
+          for (int i = threadIdx.x; i < n + 3; i += 256) tab16[a][i] = src[i];
+        } else {
+          const float2* __restrict__ src = chn0->tab2[a] + off;
+#pragma unroll 4
+          for (int i = lane; i < n + 3; i += kFW) tab2[a][i] = src[i];
+        }
       }
     }
     __syncthreads();
   }
+  // table entry k (k = -1 .. n+1) as {c[k], c[k+1] - c[k]}
+  auto table_entry = [&](int ar, int k) -> float2 {
+    if constexpr (WIDE) {
+      const unsigned int e = tab16[ar][k + 1];
+      float c, dc;
+      asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(c) : "v"(e));
+      asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(dc) : "v"(e));
+      return make_float2(c, dc);
+    } else {
+      return tab2[ar][k + 1];
+    }
+  };
+  if (wave_items && wq >= p.nblocks) return;
 
-  for (int bi = 0; bi < p.bpw; ++bi) {
+  for (int bi = (WIDE && !wave_items) ? wave : 0; bi < p.bpw; bi += (WIDE && !wave_items) ? 4 : 1) {
   const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
   const gc_block blk = CL ? load_block(p, lb) : p.blocks[lb];
@@ -361,7 +395,7 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
 #pragma unroll
               for (int ar = 0; ar < ARMS; ++ar) {
                 const int kk = min(k, chn->stage_len[(ar < arms_here) ? ar : 0] + 1);
-                const float cf = tab2[ar][kk + 1].x;
+                const float cf = table_entry(ar, kk).x;
                 Ur[ar][x] = fmaf(cf, yr, Ur[ar][x]);
                 Ui[ar][x] = fmaf(cf, yi, Ui[ar][x]);
               }
@@ -397,7 +431,7 @@ __global__ __launch_bounds__(kFW) void corr_epl_fast_kernel(const KArgs p, const
 #pragma unroll
           for (int ar = 0; ar < ARMS; ++ar) {
             const int sx = (SHARE && x == 2) ? 0 : x;
-            const float2 cd = tab2[ar][fx[x].k0 + 1];
+            const float2 cd = table_entry(ar, fx[x].k0);
             Ur[ar][x] = fmaf(cd.x, Tr, cd.y * Sr[sx]);
             Ui[ar][x] = fmaf(cd.x, Ti, cd.y * Si[sx]);
           }
@@ -471,15 +505,24 @@ void launch_variant(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim
   const bool cl = a.tagged != nullptr;
   // the shared-early/late instantiation exists for single-arm channels (GPS L1 C/A, B1I, GLONASS)
   const bool share = (ARMS == 1) && a.share_el != 0;
+  if (a.wide) {
+    // four-wave workgroups + int8-pair tables: instantiated for the 8-sample chunk, int8 I/Q records,
+    // one or two arms (Galileo E1 B / B+C and similar 8000-20000-entry tables)
+    if constexpr (SPL == 8 && ARMS <= 2 && (MODE == I8_IQ || MODE == I8_QI)) {
+      if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+      else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+    }
+    return;
+  }
   if constexpr (ARMS == 1) {
-    if (cl && share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, true>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, true>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    if (cl && share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
   } else {
     (void)share;
-    if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
   }
 }
 
@@ -509,7 +552,7 @@ int gc_launch_correlator_fast(gc_context* ctx, const KArgs& a, const InlineBlock
                               bool spl16) {
   // float2 tables: 8 bytes per staged entry (lds_off counts entries here)
   const size_t smem = (size_t)a.red_off + 64;
-  const bool wide = spl16 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
+  const bool wide = !a.wide && spl16 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
   if (wide) {
     switch (max_arms) {
       case 1: return launch_fast_mode<1, 16>(ctx, a, ib, dim3(grid), smem);

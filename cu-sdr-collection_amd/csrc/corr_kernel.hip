@@ -416,6 +416,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   a.notify_tag = 0;
   a.use_inline = 0;
   a.share_el = share_el ? 1 : 0;
+  a.wide = 0;
   if (fast && notify_tag != 0 && ctx->h_tagged_pinned) {
     // closed loop: d_blocks is the host-mapped descriptor buffer (readable by the host right here)
     a.tagged = reinterpret_cast<TaggedSlot*>(ctx->h_tagged_pinned);
@@ -428,10 +429,13 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   long long total = (long long)nblocks * splits;
   int want_bpw = 8;
   if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
-  if (want_bpw > 1 && fast && splits == 1 && period > 0 && nblocks >= 64 * (long long)period * ctx->compute_units) {
-    // big periodic list (all table offsets zero): one single-wave workgroup stages the channel's
-    // table once and walks 8 consecutive epochs (a 4-wave workgroup sharing the table measured 10 % slower)
-    a.bpw = want_bpw;
+  const bool wide_tables = fast > 0 && gc_fast_table_mode(ctx) == 1;
+  const bool big_list = nblocks >= 64 * (long long)period * ctx->compute_units;
+  if (want_bpw > 1 && fast > 0 && splits == 1 && period > 0 && (big_list || wide_tables)) {
+    // periodic list (all table offsets zero): a workgroup stages its channel's table once and walks
+    // several consecutive epochs of that channel — 8 for big lists; the WIDE variant needs at least one
+    // block per wave, so 4 even for short lists
+    a.bpw = big_list ? std::max(want_bpw, wide_tables ? 4 : 1) : 4;
     a.stride = period;
     total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
   }
@@ -443,6 +447,28 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   const size_t smem = (size_t)ctx->max_lds_bytes + kWG / 64 * GC_OUT_STRIDE * sizeof(float);
   dim3 grid((unsigned int)total);
   int rc;
+  if (fast > 0 && gc_fast_table_mode(ctx) == 1) {
+    // WIDE fast kernel: 8-sample chunks, four waves per workgroup
+    a.wide = 1;
+    fast = 1;
+    a.share_el = 0;
+    if (a.bpw == 1) {
+      if (splits % 4 != 0 && splits != 1) {
+        gc_set_error("internal: WIDE correlator launch needs splits %% 4 == 0 (got %d)", splits);
+        return GC_E_INVALID;
+      }
+      if (splits == 1) {
+        // unrelated blocks cannot share a staged table: one block per workgroup, split four ways in-kernel
+        // is not supported -> take the generic kernel for such lists
+        a.wide = 0;
+        fast = 0;
+      } else {
+        total = (total + 3) / 4;
+        grid = dim3((unsigned int)total);
+      }
+    }
+    a.xcd_swizzle = (a.wide && total % 8 == 0 && total >= 64) ? 1 : 0;
+  }
   if (fast < 0) {
     // mixed ramp multipliers: exact per-sample kernel
     int mode;
@@ -460,7 +486,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     }
     rc = (hipGetLastError() == hipSuccess) ? GC_OK : GC_E_HIP;
   } else if (fast) {
-    a.red_off = 8 * ctx->max_lds_bytes;  // float2 {c, dc} tables: 8 bytes per staged entry
+    a.red_off = (a.wide ? 2 : 8) * ctx->max_lds_bytes;  // float2 {c, dc} tables: 8 bytes per staged entry (int8 pairs: 2)
     rc = gc_launch_correlator_fast(ctx, a, ib, (unsigned int)total, max_arms, fast == 2);
   } else {
     switch (max_arms) {

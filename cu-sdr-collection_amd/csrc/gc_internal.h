@@ -27,6 +27,7 @@ void gc_set_error(const char* fmt, ...);
 // Device-side view of one tracking channel (gc_set_channel / gc_set_code).
 struct DevChannel {
   const int8_t* tab[GC_MAX_ARMS];  // padded tables in HBM
+  const unsigned short* tab2b[GC_MAX_ARMS];  // the same as int8 pairs (low byte c, high byte dc), WIDE fast kernel
   const float2* tab2[GC_MAX_ARMS];  // {c[k], c[k+1]-c[k]} for k = -1 .. nent+1 (nent+3 entries), fast kernel
   int32_t nent[GC_MAX_ARMS];       // entries per table
   double mult[GC_MAX_ARMS];        // per-arm ramp multiplier (1 or 6)
@@ -43,6 +44,7 @@ struct HostChannel {
   double index_scale = 1.0;
   int8_t* d_tab[GC_MAX_ARMS] = {nullptr, nullptr, nullptr};
   float2* d_tab2[GC_MAX_ARMS] = {nullptr, nullptr, nullptr};
+  unsigned short* d_tab2b[GC_MAX_ARMS] = {nullptr, nullptr, nullptr};
   int nent[GC_MAX_ARMS] = {0, 0, 0};
   double mult[GC_MAX_ARMS] = {1.0, 1.0, 1.0};
   int window[GC_MAX_ARMS] = {0, 0, 0};  // 0 = stage the whole table
@@ -69,6 +71,7 @@ struct gc_context {
   DevChannel* d_channels = nullptr;  // GC_MAX_CHANNELS entries
   bool channels_dirty = true;
   int max_lds_bytes = 0;
+  int max_arms_configured = 0;
 
   // scratch for gc_correlate / gc_track
   gc_block* d_blocks = nullptr;
@@ -110,3 +113,5 @@ bool gc_block_shares_el(const gc_context* ctx, const gc_block& b);
 // 2 = fast kernel with 16-sample lane-chunks (at most one table transition per chunk and tap).
 int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b);
 bool gc_fast_lds_ok(const gc_context* ctx);
+// 0 = float2 tables / single-wave workgroups, 1 = WIDE (int8 pairs, four waves), -1 = tables too large for the fast kernel
+int gc_fast_table_mode(const gc_context* ctx);

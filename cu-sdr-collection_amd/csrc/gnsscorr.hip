@@ -79,6 +79,8 @@ int gc_destroy(gc_context* ctx) {
       if (t) (void)hipFree(t);
     for (auto& t : c.d_tab2)
       if (t) (void)hipFree(t);
+    for (auto& t : c.d_tab2b)
+      if (t) (void)hipFree(t);
   }
   if (ctx->d_channels) (void)hipFree(ctx->d_channels);
   if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
@@ -344,6 +346,14 @@ int gc_set_code(gc_context* ctx, int channel, int arm, const int8_t* table, int 
     c.d_tab2[arm] = nullptr;
     GC_HIP(hipMalloc((void**)&c.d_tab2[arm], t2.size() * sizeof(float2)));
     GC_HIP(hipMemcpy(c.d_tab2[arm], t2.data(), t2.size() * sizeof(float2), hipMemcpyHostToDevice));
+    std::vector<unsigned short> t2b(t2.size());
+    for (size_t m = 0; m < t2.size(); ++m)
+      t2b[m] = (unsigned short)(((unsigned int)(unsigned char)(signed char)t2[m].x) |
+                                ((unsigned int)(unsigned char)(signed char)t2[m].y << 8));
+    if (c.d_tab2b[arm]) (void)hipFree(c.d_tab2b[arm]);
+    c.d_tab2b[arm] = nullptr;
+    GC_HIP(hipMalloc((void**)&c.d_tab2b[arm], t2b.size() * sizeof(unsigned short)));
+    GC_HIP(hipMemcpy(c.d_tab2b[arm], t2b.data(), t2b.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   }
   c.nent[arm] = n_entries;
   c.mult[arm] = arm_mult;
@@ -380,6 +390,7 @@ int gc_sync_channels(gc_context* ctx) {
       if (!c.d_tab[a]) continue;  // checked per launch
       d.tab[a] = c.d_tab[a];
       d.tab2[a] = c.d_tab2[a];
+      d.tab2b[a] = c.d_tab2b[a];
       d.nent[a] = c.nent[a];
       d.mult[a] = c.mult[a];
       d.stage_len[a] = (c.window[a] > 0) ? std::min(c.window[a], c.nent[a]) : c.nent[a];
@@ -399,6 +410,9 @@ int gc_sync_channels(gc_context* ctx) {
                         hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
   ctx->max_lds_bytes = max_lds;
+  ctx->max_arms_configured = 0;
+  for (int i = 0; i < GC_MAX_CHANNELS; ++i)
+    if (ctx->ch[i].configured) ctx->max_arms_configured = std::max(ctx->max_arms_configured, ctx->ch[i].arms);
   ctx->channels_dirty = false;
   return GC_OK;
 }
@@ -415,7 +429,18 @@ bool gc_block_shares_el(const gc_context* ctx, const gc_block& b) {
   return c.arms == 1 && b.el_spacing * c.index_scale * c.mult[0] == 0.5;
 }
 
-bool gc_fast_lds_ok(const gc_context* ctx) { return 8 * ctx->max_lds_bytes + 512 <= 64 * 1024; }
+int gc_fast_table_mode(const gc_context* ctx) {
+  if (8 * ctx->max_lds_bytes + 512 <= 64 * 1024) return 0;   // float2 tables, one wave per workgroup
+  if (2 * ctx->max_lds_bytes + 512 <= 40 * 1024 && ctx->max_arms_configured <= 2) return 1;  // int8 pairs, 4 waves share them
+  return -1;
+}
+
+bool gc_fast_lds_ok(const gc_context* ctx) {
+  const int m = gc_fast_table_mode(ctx);
+  if (m == 0) return true;
+  // WIDE is instantiated for int8 I/Q (Q/I) records and 8-sample chunks only
+  return m == 1 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
+}
 
 // Validates descriptors on the host; returns the largest arm count among the referenced
 // channels, or a negative status.  *all_lowrate is cleared if any block needs the generic kernel.
@@ -523,7 +548,8 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
   const int fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
-  const int splits = choose_splits(ctx, nblocks, blocks, fast > 0 ? 64 : 256, fast == 2 ? 16 : 8);
+  int splits = choose_splits(ctx, nblocks, blocks, fast > 0 ? 64 : 256, fast == 2 ? 16 : 8);
+  if (fast > 0 && gc_fast_table_mode(ctx) == 1 && splits > 1) splits = std::max(4, (splits / 4) * 4);  // WIDE kernel
   if ((rc = ensure((void**)&ctx->d_blocks, &ctx->d_blocks_cap, nblocks, sizeof(gc_block)))) return rc;
   if ((rc = ensure((void**)&ctx->d_out, &ctx->d_out_cap, (int64_t)nblocks * GC_OUT_STRIDE, sizeof(double)))) return rc;
   if (splits > 1 &&
@@ -595,6 +621,7 @@ int gc_replay_launch(gc_context* ctx) {
   if (ctx->replay_nblocks * wg_waves < 8 * (int64_t)ctx->compute_units) {
     // small replay sets: split blocks over several workgroups, scratch from d_partial
     splits = (int)std::min<int64_t>(8, (8 * (int64_t)ctx->compute_units / wg_waves + ctx->replay_nblocks - 1) / ctx->replay_nblocks);
+    if (ctx->replay_fast > 0 && gc_fast_table_mode(ctx) == 1 && splits > 1) splits = std::max(4, (splits / 4) * 4);
     int rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, ctx->replay_nblocks * splits * GC_OUT_STRIDE, sizeof(double));
     if (rc) return rc;
   }

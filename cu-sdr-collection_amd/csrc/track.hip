@@ -93,6 +93,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   const int chunks_nominal = approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8);
   int splits = (8 * ctx->compute_units * 64 / wg_threads + nch - 1) / nch;
   splits = std::max(1, std::min(std::min(splits, 32), std::max(1, chunks_nominal / (2 * wg_threads))));
+  if (fast_nominal && gc_fast_table_mode(ctx) == 1) splits = std::max(4, std::min(32, (splits / 4) * 4));  // WIDE: 4 waves per workgroup
   if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));
 
   // pinned, device-visible descriptor and result buffers

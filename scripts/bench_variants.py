@@ -1,0 +1,64 @@
+"""Throughput of the other BASELINE.json configs' shapes (parity is covered by tests/; this is timing only):
+config 3 shape — Galileo E1 B+C, R = 2, 2 arms, 4-ms blocks, 8 channels;
+config 4 shape — GPS L5 I5+Q5, 10.23 Mcps, 2 arms, 1-ms blocks, 8 channels (18 Msps record)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cu_sdr_collection_amd as P
+from cu_sdr_collection_amd import _lib as L
+from cu_sdr_collection_amd.receiver import track_params
+from cu_sdr_collection_amd.settings import initSettings_GAL_E1C, initSettings_GPS_L5C
+
+def run(name, S, signal, code_fn, code_rate, code_len, carrier_ratio, bit_periods, nch, seconds, prns):
+    fs = S.samplingFreq
+    eng = P.Engine(0)
+    rng = np.random.default_rng(1)
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, fs * S.intTime)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=48.0) for p in prns[:nch]]
+    n = int(seconds * fs)
+    P.synth.generate_if_gpu(eng, sats, n, fs, S.IF, code_fn, code_rate, code_len, seed=5, carrier_ratio=carrier_ratio, bit_periods=bit_periods)
+    eng.set_sampling_freq(fs)
+    S.msToProcess = int(seconds * 1000) - int(2 * S.intTime * 1000) - 2
+    spec = P.signals.SIGNALS[signal]
+    p = track_params(S, signal)
+    inits = []
+    for i, s in enumerate(sats):
+        eng.set_channel(i, spec.tables(s.prn, S), index_scale=spec.index_scale)
+        f = S.IF + s.doppler + 2.0
+        cf = S.codeFreqBasis + (f - S.IF) / getattr(S, "carrFreqBasis", 1575.42e6) * S.codeFreqBasis if spec.code_freq_from_channel else S.codeFreqBasis
+        inits.append(L.gc_channel_init(channel=i, prn=s.prn, acquired_freq=f, code_freq=cf, code_phase=int(np.ceil(s.code_phase_samples)) + 1))
+    t0 = time.time(); fields, done, st = eng.track(p, inits); t_cl = time.time() - t0
+    n_ep = p.n_epochs
+    assert st == 0 and done.min() == n_ep, (st, done)
+    blks = np.ceil((S.codeLength - fields["remCodePhase"]) / (fields["codeFreq"] / fs)).astype(np.int64)
+    nb = nch * n_ep
+    blocks = eng.make_blocks(nb)
+    dt = np.dtype([("channel", "<i4"), ("blksize", "<i4"), ("first_sample", "<i8"), ("rem_code_phase", "<f8"), ("code_phase_step", "<f8"),
+                   ("el_spacing", "<f8"), ("carr_freq", "<f8"), ("rem_carr_phase", "<f8"), ("table_offset", "<i4", (3,)), ("reserved", "<i4")])
+    v = np.frombuffer(blocks, dtype=dt)
+    for k in range(nch):
+        sl = slice(k, nb, nch)
+        v["channel"][sl] = k; v["blksize"][sl] = blks[k]; v["first_sample"][sl] = fields["absoluteSample"][k].astype(np.int64)
+        v["rem_code_phase"][sl] = fields["remCodePhase"][k]; v["code_phase_step"][sl] = fields["codeFreq"][k] / fs
+        v["el_spacing"][sl] = S.dllCorrelatorSpacing; v["carr_freq"][sl] = fields["carrFreq"][k]; v["rem_carr_phase"][sl] = fields["remCarrPhase"][k]
+    eng.replay_prepare(blocks)
+    for _ in range(2): eng.replay_launch()
+    eng.synchronize(); eng.timer_start()
+    K = 5
+    for _ in range(K): eng.replay_launch()
+    ms = eng.timer_stop() / K
+    out = eng.replay_fetch()
+    rec = np.stack([fields[f].T.reshape(-1) for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")], axis=1)
+    dev = float(np.max(np.abs(out[:, 0, :] - rec)) / (2.0 * blks.mean() * 28.0))
+    cs = float(blks.sum())
+    print(json.dumps({"shape": name, "channels": nch, "arms": len(spec.tables(sats[0].prn, S)), "epochs": n_ep, "record_s": seconds,
+                      "replay_ms": round(ms, 3), "corr_msps": round(cs / ms / 1e3, 1), "algorithmic_GBps": round(2 * cs / ms / 1e6, 1),
+                      "x_realtime_replay": round(cs / nch / ms / 1e3 / (fs / 1e6), 1),
+                      "closed_loop_us_per_epoch": round(t_cl / n_ep * 1e6, 1), "closed_loop_x_realtime": round(cs / nch / t_cl / fs, 1),
+                      "replay_vs_closed_loop_max_dev": dev}))
+    eng.close()
+
+S = initSettings_GAL_E1C()
+run("config3: GAL E1 B+C, BOC(1,1), 8 ch", S, "GAL_E1C", P.codes.generateE1Bcode, 2 * 1.023e6, 8184, 1540.0, 1, 8, 20.0, list(range(1, 51)))
+S = initSettings_GPS_L5C(); S.pilotTRKflag = 1
+run("config4 (L5 half): GPS L5 I5+Q5, 8 ch", S, "GPS_L5C", P.codes.generateL5Icode, 10.23e6, 10230, 1150.0, 10, 8, 10.0, list(range(1, 38)))
