@@ -89,3 +89,36 @@ def initSettings_GPS_L5C() -> SimpleNamespace:
     s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=400)  # :128-130
     s.carrFreqBasis = 1176.45e6      # :132
     return s
+
+
+def initSettings_GLO_GL1() -> SimpleNamespace:
+    """GLONASS L1OF defaults (GLO/GLO_GL1/initSettings.m): only the fields the hot path reads."""
+    s = initSettings()
+    s.freqSpacing = 562.5e3          # :73
+    s.IF = 0.0                       # :77  nominal IF of channel K = 0
+    s.samplingFreq = 12e6            # :79
+    s.codeFreqBasis = 0.511e6        # :80
+    s.codeLength = 511               # :83
+    s.dllNoiseBandwidth = 2          # :107
+    s.dllCorrelatorSpacing = 0.5     # :108
+    s.pllNoiseBandwidth = 25         # :112
+    s.intTime = 0.001                # :114
+    s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=40)  # :144-146
+    return s
+
+
+def initSettings_BDS_B1I() -> SimpleNamespace:
+    """BDS B1I defaults (BDS/B1I/initSettings.m): only the fields the hot path reads."""
+    s = initSettings()
+    s.IF = 20e3                      # :71
+    s.samplingFreq = 18e6            # :72
+    s.codeFreqBasis = 2.046e6        # :73
+    s.codeLength = 2046              # :76
+    s.dllDampingRatio = 0.7          # :99
+    s.dllNoiseBandwidth = 4          # :100
+    s.dllCorrelatorSpacing = 0.5     # :101
+    s.pllDampingRatio = 0.7          # :104
+    s.pllNoiseBandwidth = 35         # :105
+    s.intTime = 0.001                # :107
+    s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=400)  # :141-143
+    return s

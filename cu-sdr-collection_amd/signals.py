@@ -48,10 +48,22 @@ def _l5_tables(prn, settings):
     return t
 
 
+def _glo_tables(prn, settings):
+    return [codes.padded_table(codes.generateGLOcode())]                      # GLO_GL1 tracking.m:88-89 (one code for all)
+
+
+def _b1i_tables(prn, settings):
+    return [codes.padded_table(codes.generateCAcode53(prn))]                  # BDS/B1I tracking.m:144-145
+
+
 SIGNALS = {
     "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False),
     # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
     "GAL_E1C": SignalSpec("GAL_E1C", _e1_tables, 2.0, L.GC_PLL_3_STATE, "a", 2, False),
+    # GLONASS: the record must be loaded with layout GC_QI (GLO_GL1 tracking.m:227 swaps the components);
+    # channel.PRN carries the frequency number K (GLO_GL1 preRun.m:66), the FDMA offset lives in acquiredFreq
+    "GLO_GL1": SignalSpec("GLO_GL1", _glo_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False),
+    "BDS_B1I": SignalSpec("BDS_B1I", _b1i_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False),
     "GPS_L5C": SignalSpec("GPS_L5C", _l5_tables, 1.0, L.GC_PLL_3_STATE, "a", 1, True),
 }
 

@@ -547,7 +547,7 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
             continue
         tr.PRN = ch.PRN
         pos = int(settings.skipNumberOfBytes + ch.codePhase - 1)
-        tables = spec.tables(ch.PRN)
+        tables = spec.tables(ch.PRN)  # GLONASS: one code for every channel, PRN carries K (GLO tracking.m:88-89,136)
         basis = ch.codeFreq if spec.code_freq_from_channel else settings.codeFreqBasis
         code_freq = basis
         rem_code = 0.0
@@ -566,8 +566,8 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
             tr.remCarrPhase[e] = rem_carr
             if correlate is None:
                 sums, rem_code_new, rem_carr_new = correlate_block(
-                    raw_from_if(if_bytes, pos, n), tables, rem_code, step, d, carr_freq, rem_carr,
-                    settings.samplingFreq, settings.codeLength, r=spec.r)
+                    raw_from_if(if_bytes, pos, n, swap_iq=getattr(spec, "swap_iq", False)), tables, rem_code, step, d,
+                    carr_freq, rem_carr, settings.samplingFreq, settings.codeLength, r=spec.r)
             else:
                 sums, rem_code_new, rem_carr_new = correlate(ch, pos, n, rem_code, step, d, carr_freq, rem_carr)
             pos += n
@@ -652,3 +652,49 @@ def generate_l5_code(prn: int, component: str, code_length: int = 10230) -> np.n
         fb = np.prod(xb_reg[taps])
         xb_reg = np.concatenate([[fb], xb_reg[:-1]])
     return xb * xa
+
+
+# --------------------------------------------------------------------------------------
+# GLONASS L1OF ranging code (GLO/GLO_GL1/include/generateCAcode.m:93-104) and BDS B1I
+# (BDS/B1I/include/generateCAcode53.m:42-103)
+# --------------------------------------------------------------------------------------
+
+
+def generate_glo_code() -> np.ndarray:
+    """511-chip m-sequence: 9-stage register of -1s, feedback reg(5)*reg(9), output stage 7."""
+    reg = -np.ones(9)
+    code = np.empty(511)
+    for i in range(511):
+        code[i] = reg[6]
+        save1 = reg[4] * reg[8]
+        reg[1:9] = reg[0:8].copy()
+        reg[0] = save1
+    return code
+
+
+# G2 phase-selector taps for PRN 1..37 (BDS-SIS-ICD-B1I; generateCAcode53.m:58-70)
+_B1I_S1 = [1, 1, 1, 1, 1, 1, 1, 1, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 6, 6, 6, 6, 8, 8, 8, 9, 9, 10]
+_B1I_S2 = [3, 4, 5, 6, 8, 9, 10, 11, 7, 4, 5, 6, 8, 9, 10, 11, 5, 6, 8, 9, 10, 11, 6, 8, 9, 10, 11, 8, 9, 10, 11, 9, 10, 11, 10, 11, 11]
+
+
+def generate_b1i_code(prn: int) -> np.ndarray:
+    """2046 chips; G1 taps {1,7,8,9,10,11}, G2 taps {1,2,3,4,5,8,9,11}, both registers start at
+    -1*[-1 1 -1 1 ...] (:43,:55), G2 output = product of the PRN's two selector stages (:94),
+    CAcode = -(g1.*g2) (:103).  PRN 1..37."""
+    init = -1.0 * np.array([-1, 1, -1, 1, -1, 1, -1, 1, -1, 1, -1], dtype=np.float64)
+    reg = init.copy()
+    g1 = np.empty(2046)
+    for i in range(2046):
+        g1[i] = reg[10]
+        save = reg[0] * reg[6] * reg[7] * reg[8] * reg[9] * reg[10]
+        reg[1:11] = reg[0:10].copy()
+        reg[0] = save
+    reg = init.copy()
+    g2 = np.empty(2046)
+    s1, s2 = _B1I_S1[prn - 1] - 1, _B1I_S2[prn - 1] - 1
+    for i in range(2046):
+        g2[i] = reg[s1] * reg[s2]
+        save = reg[0] * reg[1] * reg[2] * reg[3] * reg[4] * reg[7] * reg[8] * reg[10]
+        reg[1:11] = reg[0:10].copy()
+        reg[0] = save
+    return -(g1 * g2)

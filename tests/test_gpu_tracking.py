@@ -187,3 +187,64 @@ def test_gps_l5_pilot_data_tracking_matches_oracle(engine):
         # pilot arm in quadrature: its energy sits in Q while the data arm's sits in I
         assert np.mean(np.abs(tr[k].I_P[20:])) > 2 * np.mean(np.abs(tr[k].Q_P[20:]))
         assert np.mean(np.abs(tr[k].Pilot_Q_P[20:])) > 2 * np.mean(np.abs(tr[k].Pilot_I_P[20:]))
+
+
+def _single_arm_case(engine, S, signal, code_fn, code_rate, code_len, carrier_ratio, oracle_code, prns, ifreqs, layout, ms=80):
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    fs = S.samplingFreq
+    S.msToProcess = ms
+    S.numberOfChannels = len(prns)
+    rng = np.random.default_rng(17)
+    iq = np.zeros(2 * int((ms + 4) * 1e-3 * fs), dtype=np.float64)
+    sats = []
+    for p, f_if in zip(prns, ifreqs):
+        s = P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-2e3, 2e3)), code_phase_samples=float(rng.uniform(0, fs * 1e-3)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0)
+        sats.append(s)
+        part = P.synth.generate_if([s], iq.shape[0] // 2, fs, f_if, code_fn, code_rate, code_len, seed=100 + p,
+                                   carrier_ratio=carrier_ratio, noise=False, sigma=20.0)
+        iq += part
+    iq = np.clip(np.rint(iq + 20.0 * rng.standard_normal(iq.shape[0])), -127, 127).astype(np.int8)
+    if layout == L.GC_QI:  # GLONASS front end delivers Q first (GLO_GL1 tracking.m:227)
+        rec = np.empty_like(iq)
+        rec[0::2], rec[1::2] = iq[1::2], iq[0::2]
+    else:
+        rec = iq
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=f_if + s.doppler + 2.0, status="T",
+                          codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s, f_if in zip(sats, ifreqs)]
+    engine.load_if(rec, layout=layout, fs=fs)
+    tr, _ = P.tracking(engine, ch, S, signal=signal)
+    spec = SimpleNamespace(tables=lambda prn: [O.pad_code(oracle_code(prn))], r=1.0, pll="3state", coef_variant="a",
+                           pilot_combine=0, code_freq_from_channel=False, swap_iq=(layout == L.GC_QI))
+    ref = O.tracking_generic(rec, ch, S, spec)
+    for k in range(len(prns)):
+        assert tr[k].status == "T" and ref[k].status == "T"
+        assert np.array_equal(tr[k].absoluteSample, ref[k].absoluteSample)
+        scale = 2.0 * fs * 1e-3 * 28.0
+        for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L"):
+            assert np.max(np.abs(getattr(tr[k], f) - getattr(ref[k], f))) < 1e-5 * scale, (k, f)
+        assert np.max(np.abs(tr[k].carrFreq - ref[k].carrFreq)) < 1e-3
+        assert np.mean(np.hypot(tr[k].I_P, tr[k].Q_P)[10:]) > 1.3 * np.mean(np.hypot(tr[k].I_E, tr[k].Q_E)[10:])
+
+
+def test_glonass_l1of_fdma_qi_record(engine):
+    """GLO/GLO_GL1/include/tracking.m: one 511-chip code for every satellite, FDMA offsets K*562.5 kHz in
+    acquiredFreq (carrier up to MHz: thousands of cycles per block), Q,I sample order, 12 Msps."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    from cu_sdr_collection_amd.settings import initSettings_GLO_GL1
+    S = initSettings_GLO_GL1()
+    ks = [-3, 5]
+    _single_arm_case(engine, S, "GLO_GL1", lambda prn: P.codes.generateGLOcode(), S.codeFreqBasis, 511, 3135.0,
+                     lambda prn: O.generate_glo_code(), ks, [S.IF + k * S.freqSpacing for k in ks], L.GC_QI)
+
+
+def test_beidou_b1i(engine):
+    """BDS/B1I/include/tracking.m: 2046-chip code at 2.046 Mcps (8.8 samples/chip: the 8-sample fast kernel)."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B1I
+    S = initSettings_BDS_B1I()
+    _single_arm_case(engine, S, "BDS_B1I", P.codes.generateCAcode53, S.codeFreqBasis, 2046, 763.0 * 2,
+                     O.generate_b1i_code, [7, 23], [S.IF, S.IF], L.GC_IQ)

@@ -83,3 +83,15 @@ def test_gps_l5_codes_two_implementations_agree():
     # so their product is a pure XB x XB sequence with the 8191-chip m-sequence period structure
     a, b = O.generate_l5_code(1, "I"), O.generate_l5_code(2, "I")
     assert not np.array_equal(a, b)
+
+
+def test_glonass_and_b1i_codes_two_implementations_agree():
+    import cu_sdr_collection_amd as P
+    g = O.generate_glo_code()
+    assert g.shape == (511,) and np.array_equal(g, P.codes.generateGLOcode().astype(np.float64))
+    ac = np.array([np.dot(g, np.roll(g, k)) for k in range(1, 511)])
+    assert np.all(ac == -1.0)  # maximal-length sequence
+    for prn in (1, 8, 9, 22, 37):
+        b = O.generate_b1i_code(prn)
+        assert b.shape == (2046,) and np.array_equal(b, P.codes.generateCAcode53(prn).astype(np.float64))
+        assert abs(b.sum()) <= 2
