@@ -190,9 +190,6 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   const int split = (int)(item - wq * p.splits);
   const long long grp = wq / p.stride;
   const int cslot = (int)(wq - grp * p.stride);
-  if (wave_items && wq >= p.nblocks) {
-    // tail of the last workgroup: still has to reach the staging barrier below
-  }
 
   // ---- stage {c[k], c[k+1]-c[k]} for k = -1 .. nent (c[-1] := c[0], c[>=nent] := 0), once per
   //      workgroup: the host guarantees that all blocks of a workgroup share channel and offsets

@@ -51,7 +51,8 @@ int gc_create(gc_context** out, int device_id) {
   if (!ctx) return GC_E_NOMEM;
   ctx->device = device_id;
   ctx->compute_units = prop.multiProcessorCount;
-  std::snprintf(ctx->device_name, sizeof ctx->device_name, "%s", prop.name);
+  // prop.name is empty on some ROCm 7.2 boxes: fall back to the architecture string
+  std::snprintf(ctx->device_name, sizeof ctx->device_name, "%s", prop.name[0] ? prop.name : prop.gcnArchName);
   GC_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   GC_HIP(hipEventCreate(&ctx->ev_start));
   GC_HIP(hipEventCreate(&ctx->ev_stop));

@@ -141,8 +141,6 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     s.code_freq = s.code_freq_basis = init[c].code_freq;  // :163 / GPS_L5C :165
     s.carr_freq = s.carr_basis = init[c].acquired_freq;   // :167-168
   }
-  const double R_of = 1.0;
-  (void)R_of;
 
   std::vector<int> slot((size_t)nch);
   bool any_range = false;

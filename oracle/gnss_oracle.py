@@ -575,9 +575,6 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
             i_e, q_e, i_p, q_p, i_l, q_l = (float(v) for v in sums[0])
             with np.errstate(divide="ignore", invalid="ignore"):
                 carr_err = float(np.arctan(np.float64(q_p) / np.float64(i_p)) / (2.0 * math.pi))
-                code_err = float((np.float64(math.hypot(i_e, q_e)) - math.hypot(i_l, q_l)) /
-                                 (np.float64(math.hypot(i_e, q_e)) + math.hypot(i_l, q_l)))
-            # note: the reference writes sqrt(I*I + Q*Q); hypot differs by <= 1 ulp, far below any tolerance
             code_err = float((math.sqrt(i_e * i_e + q_e * q_e) - math.sqrt(i_l * i_l + q_l * q_l)) /
                              (math.sqrt(i_e * i_e + q_e * q_e) + math.sqrt(i_l * i_l + q_l * q_l)))
             if spec.pilot_combine:
