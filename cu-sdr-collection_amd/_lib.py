@@ -92,6 +92,7 @@ SYMBOLS = {
     "gc_acquire_coarse_multi": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,
                                        C.POINTER(C.c_double)]),
+    "gc_debug_first_sample_near_edge": (C.c_longlong, [C.c_double, C.c_double, C.c_longlong, C.c_double]),
     "gc_debug_fft": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int]),
 }
 

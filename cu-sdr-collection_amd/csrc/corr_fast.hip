@@ -262,6 +262,7 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   const double bL = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), d), R);
   const float uk = (float)(1.0 / (sp * M) * 2.3283064365386963e-10);  // g_hi (2^-32 units) -> u
   const float ukB = uk * kBig;
+  const bool tie_free = (blk.reserved & 1) != 0;
 
   // lanes 0..SPL-1: delta^j = exp(-i*2*pi*j*tau); lane SPL: the chunk stride SPL*kFW samples
   float myC, myS;
@@ -336,10 +337,14 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
       float gh[NS];
       bool suspect = share_broken;
 #pragma unroll
-      for (int sx = 0; sx < NS; ++sx) {
+      for (int sx = 0; sx < NS; ++sx)
         gh[sx] = (float)(unsigned int)(fx[sx].G >> 32);  // sets: 0 = early (and late when shared), 1 = prompt, 2 = late
-        const float u = gh[sx] * uk;
-        suspect |= fabsf(u - rintf(u)) < kTieTol;
+      if (!tie_free) {  // blocks the host proved tie-free (gc_mark_tie_free) skip the filter
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) {
+          const float u = gh[sx] * uk;
+          suspect |= fabsf(u - rintf(u)) < kTieTol;
+        }
       }
 
       float Ur[ARMS][3], Ui[ARMS][3];

@@ -41,30 +41,49 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
     const long long per = total >> 3;  // host guarantees total % 8 == 0 when swizzling
     wg = (wg & 7) * per + (wg >> 3);
   }
-  const long long lb = wg / p.splits;
-  const int split = (int)(wg - lb * p.splits);
-  const gc_block blk = p.blocks[lb];
-  const DevChannel* __restrict__ chn = p.chans + blk.channel;
-
+  // With bpw > 1 (periodic replay lists) a workgroup walks bpw consecutive epochs of ONE channel and
+  // re-stages the tables only when channel or table offsets change: for 10 230-chip codes the two
+  // staged tables (41 KB) are more bytes than one block's IF samples (36 KB).
+  const long long wq = wg / p.splits;
+  const int split = (int)(wg - wq * p.splits);
+  const long long grp = wq / p.stride;
+  const int cslot = (int)(wq - grp * p.stride);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  int staged_channel = -1;
+  int staged_off[ARMS];
+#pragma unroll
+  for (int a = 0; a < ARMS; ++a) staged_off[a] = -1;
+
+  for (int bi = 0; bi < p.bpw; ++bi) {
+  const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
+  if (lb >= p.nblocks) break;
+  const gc_block blk = p.blocks[lb];
+  const DevChannel* __restrict__ chn = p.chans + blk.channel;
 
   // ---- stage the code tables into LDS --------------------------------------------------
   int lds_off[ARMS];
   int nent[ARMS];
   const int arms_here = chn->arms;
+  bool restage = blk.channel != staged_channel;
+#pragma unroll
+  for (int a = 0; a < ARMS; ++a)
+    if (a < arms_here && blk.table_offset[a] != staged_off[a]) restage = true;
+  __syncthreads();  // the previous block's table reads and reduction scratch are done
 #pragma unroll
   for (int a = 0; a < ARMS; ++a) {
     const int aa = (a < arms_here) ? a : 0;  // absent arms alias arm 0; their outputs are zeroed
     lds_off[a] = chn->lds_off[aa];
     const int off = blk.table_offset[aa];
     nent[a] = min(chn->stage_len[aa], chn->nent[aa] - off);
-    if (a < arms_here) {
+    if (restage && a < arms_here) {
+      staged_off[a] = off;
       const int8_t* __restrict__ src = chn->tab[a] + off;
       for (int i = tid; i < nent[a] + 8; i += kWG)
         smem[lds_off[a] + i] = (i < nent[a]) ? (unsigned char)src[i] : 0;
     }
   }
+  staged_channel = blk.channel;
   float* red = reinterpret_cast<float*>(smem + p.red_off);
   __syncthreads();
 
@@ -87,8 +106,11 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
   const double bP = __dmul_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), R);
   const double bE = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), -d), R);
   const double bL = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), d), R);
-  const float inv_spm = (float)(1.0 / (sp * M));
-  const float tie_tol = 1e-6f + 4e-7f * inv_spm;
+  // near-tie window in 2^-32 chip units: 16 ulp of the largest ramp value, at least 2 units
+  const bool tie_free = (blk.reserved & 1) != 0;
+  const unsigned int tie_e =
+      2u + (unsigned int)((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fabs(M) * (16.0 * 2.220446049250313e-16 * 4294967296.0));
+  const unsigned int tie_w = 2u * tie_e;
 
   // lanes 0..7: delta^j and the fixed-point ramp increments j*sp*M; lane 8: chunk-stride terms
   float myC, myS;
@@ -98,10 +120,7 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
     const int j = (lane < 8) ? lane : kSPL * kWG;
     const double x = (double)j * tau;
     const double fr = x - floor(x);
-    double sn, cs;
-    sincospi(2.0 * fr, &sn, &cs);
-    myC = (float)cs;
-    myS = (float)sn;
+    sincospif(2.0f * (float)fr, &myS, &myC);  // range reduction in double above, sincos in float
     const double y = (double)j * (sp * M);
     const double yi = floor(y);
     const unsigned long long jf = frac_to_u64(y - yi);
@@ -166,19 +185,21 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
 
       // Near-tie filter.  The fixed-point ramp equals the real-number value a + i*d to ~2^-60 chip,
       // whereas the reference evaluates fl(a + fl(i*d)) (and builds the second half of the colon
-      // vector backwards): the two can disagree on ceil() only when a sample sits within ~1e-13
-      // chip of a chip edge.  That is not measure-zero: with remCodePhase = 0 and the nominal code
+      // vector backwards): the two can disagree on ceil() only when a sample sits within a few ulp
+      // of a chip edge.  That is not measure-zero: with remCodePhase = 0 and the nominal code
       // rate (every channel's first block, tracking.m:163-165) 1.023e6/18e6 is rational and samples
-      // 3000k land exactly on edges.  Sample j of this chunk is on an edge iff (g + m)/(sp*M) = j
-      // for an integer m, so test that quotient in float (tolerance >> rounding noise) and send
-      // the rare suspects through the exact double-precision path.
+      // 3000k land exactly on edges.  Sample j of tap x is within e chips of an edge iff
+      // (Jf[j] - G_x) mod 2^64 is within e*2^64 of zero; the test below does that on the high words
+      // (resolution 2.3e-10 chip, window tie_w >> the rounding noise) and sends the rare suspects
+      // through the exact double-precision path.  Blocks the host proved tie-free (gc_mark_tie_free:
+      // an exact number-theoretic search over the block's three ramps) skip the test.
       bool suspect = false;
+      if (!tie_free) {
 #pragma unroll
-      for (int x = 0; x < 3; ++x) {
-        const float g = (float)(unsigned int)(fx[x].G >> 32) * 2.3283064365386963e-10f;
-        for (int m = 0; m <= Ji[kSPL - 1]; ++m) {
-          const float u = (g + (float)m) * inv_spm;
-          suspect |= fabsf(u - rintf(u)) < tie_tol;
+        for (int x = 0; x < 3; ++x) {
+          const unsigned int gq = (unsigned int)(fx[x].G >> 32) - tie_e;
+#pragma unroll
+          for (int j = 0; j < kSPL; ++j) suspect |= ((unsigned int)(Jf[j] >> 32) - gq) <= tie_w;
         }
       }
       const bool exact = __any(suspect) != 0;  // wave-uniform: the exact path is ~1e-3 of wave-chunks
@@ -273,6 +294,7 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
     else
       p.partial[(lb * p.splits + split) * GC_OUT_STRIDE + tid] = s;
   }
+  }  // bpw loop
 }
 
 // ---- exact reference kernel for channels whose arms use DIFFERENT ramp multipliers ---------------------
@@ -431,11 +453,11 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
   const bool wide_tables = fast > 0 && gc_fast_table_mode(ctx) == 1;
   const bool big_list = nblocks >= 64 * (long long)period * ctx->compute_units;
-  if (want_bpw > 1 && fast > 0 && splits == 1 && period > 0 && (big_list || wide_tables)) {
+  if (want_bpw > 1 && fast >= 0 && splits == 1 && period > 0 && (big_list || wide_tables || fast == 0)) {
     // periodic list (all table offsets zero): a workgroup stages its channel's table once and walks
     // several consecutive epochs of that channel — 8 for big lists; the WIDE variant needs at least one
     // block per wave, so 4 even for short lists
-    a.bpw = big_list ? std::max(want_bpw, wide_tables ? 4 : 1) : 4;
+    a.bpw = big_list ? std::max(want_bpw, wide_tables ? 4 : 1) : (fast == 0 ? std::min(want_bpw, 8) : 4);
     a.stride = period;
     total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
   }

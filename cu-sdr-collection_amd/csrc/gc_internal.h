@@ -113,5 +113,7 @@ bool gc_block_shares_el(const gc_context* ctx, const gc_block& b);
 // 2 = fast kernel with 16-sample lane-chunks (at most one table transition per chunk and tap).
 int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b);
 bool gc_fast_lds_ok(const gc_context* ctx);
+int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps);
+void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps);
 // 0 = float2 tables / single-wave workgroups, 1 = WIDE (int8 pairs, four waves), -1 = tables too large for the fast kernel
 int gc_fast_table_mode(const gc_context* ctx);

@@ -418,6 +418,99 @@ int gc_sync_channels(gc_context* ctx) {
   return GC_OK;
 }
 
+// ---- host-side near-tie analysis --------------------------------------------------------------------
+// The kernels evaluate the replica ramps in exact real arithmetic; the reference evaluates
+// fl(a + fl(i*d)).  The two can disagree on ceil() only if some sample of the block lies within ~1e-13
+// chip of a table edge.  Whether a block contains such a sample is an exact number-theoretic question:
+// is there 0 <= i < N with (A + i*D) mod 2^64 inside a small window around 0, where A, D are the 64-bit
+// fractions of the ramp start and step?  It is answered in O(log) by a Euclid-style descent, so that
+// almost all blocks can be marked tie-free and skip the per-chunk filter in the kernels.
+namespace {
+typedef unsigned __int128 u128;
+const uint64_t kNone = ~0ull;
+
+// smallest x >= 0, x < limit, with l <= (a*x mod m) <= r;  0 <= a < m <= 2^63 here (the 2^64 level is peeled
+// off by the caller), 0 <= l <= r < m.
+uint64_t first_in_range_u64(uint64_t a, uint64_t m, uint64_t l, uint64_t r, uint64_t limit) {
+  if (l == 0) return limit > 0 ? 0 : kNone;
+  if (a == 0 || limit == 0) return kNone;
+  const uint64_t c = l / a + (l % a != 0);
+  if ((u128)a * c <= r) return c < limit ? c : kNone;
+  const uint64_t mm = m % a;
+  if (mm == 0) return kNone;
+  const uint64_t lp = l % a, rp = r % a;  // same quotient: no multiple of a in [l, r]
+  const u128 ylim = ((u128)limit * a) / m + 2;
+  const uint64_t y = first_in_range_u64(mm, a, a - rp, a - lp, ylim > kNone ? kNone : (uint64_t)ylim);
+  if (y == kNone) return kNone;
+  const u128 x = ((u128)m * y + l + a - 1) / a;
+  return x < limit ? (uint64_t)x : kNone;
+}
+
+// same with modulus 2^64 (A, D, l, r given as uint64)
+uint64_t first_in_range_2p64(uint64_t a, uint64_t l, uint64_t r, uint64_t limit) {
+  if (l == 0) return limit > 0 ? 0 : kNone;
+  if (a == 0 || limit == 0) return kNone;
+  const u128 m = (u128)1 << 64;
+  const uint64_t c = l / a + (l % a != 0);
+  if ((u128)a * c <= r) return c < limit ? c : kNone;
+  const uint64_t mm = (uint64_t)(m % a);
+  if (mm == 0) return kNone;
+  const uint64_t lp = l % a, rp = r % a;
+  const u128 ylim = ((u128)limit * a) / m + 2;
+  const uint64_t y = first_in_range_u64(mm, a, a - rp, a - lp, (uint64_t)ylim);
+  if (y == kNone) return kNone;
+  const u128 x = (m * y + l + a - 1) / a;
+  return x < limit ? (uint64_t)x : kNone;
+}
+
+uint64_t frac64(double v) {
+  const double f = v - std::floor(v);  // [0,1)
+  const double hi = std::floor(f * 4294967296.0);
+  const double lo = std::floor((f * 4294967296.0 - hi) * 4294967296.0);
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+}  // namespace
+
+// First sample index i in [0, n) whose ramp value a + i*step lies within eps (chips, < 0.25) of an integer,
+// or -1.  Exact in 2^-64 chip arithmetic.
+int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps) {
+  if (n <= 0) return -1;
+  const uint64_t e = (uint64_t)(eps * 18446744073709551616.0);
+  const uint64_t A = frac64(a), D = frac64(step);
+  const uint64_t W = 2 * e;
+  const uint64_t B = A + e;  // mod 2^64: the window [-e, +e] around an integer becomes [0, W] after this shift
+  if (B <= W) return 0;      // sample 0 itself sits in the window
+  // (B + i*D) mod 2^64 in [0, W]  <=>  (i*D) mod 2^64 in [L, L + W] with L = 2^64 - B  (no wrap: B > W)
+  const uint64_t L = 0 - B;
+  const uint64_t r = L + W;
+  const uint64_t x = first_in_range_2p64(D, L, r, (uint64_t)n);
+  return x == kNone ? -1 : (int64_t)x;
+}
+
+// Marks tie-free blocks (bit 0 of `reserved`) for a launch whose kernel needs the band `eps_chips`.
+void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps) {
+  for (int64_t i = 0; i < n; ++i) {
+    gc_block& k = b[i];
+    k.reserved &= ~1;
+    const HostChannel& c = ctx->ch[k.channel];
+    if (c.mult[0] != 1.0) continue;
+    const double R = c.index_scale, sp = k.code_phase_step * R;
+    // band: the reference's rounding noise (a few ulp of the ramp) for the exact-compare kernel, or the float
+    // step quotient's resolution (eps_unit_steps samples of ramp) for the fast kernel
+    const double maxv = std::fabs(k.rem_code_phase) * R + std::fabs(k.el_spacing) * R + (double)k.blksize * std::fabs(sp) + 1.0;
+    const double eps = std::max(std::max(4e-12, 16.0 * 2.220446049250313e-16 * maxv), eps_unit_steps * sp);
+    const double starts[3] = {(k.rem_code_phase - k.el_spacing) * R, k.rem_code_phase * R,
+                              (k.rem_code_phase + k.el_spacing) * R};
+    bool clean = true;
+    for (int t = 0; t < 3 && clean; ++t) clean = gc_first_sample_near_edge(starts[t], sp, k.blksize, eps) < 0;
+    if (clean) k.reserved |= 1;
+  }
+}
+
+extern "C" long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps) {
+  return gc_first_sample_near_edge(a, step, n, eps);
+}
+
 int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b) {
   const HostChannel& c = ctx->ch[b.channel];
   // at most one table transition per lane-chunk (8 or 16 samples), with a safety margin
@@ -556,7 +649,9 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
   if (splits > 1 &&
       (rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, (int64_t)nblocks * splits * GC_OUT_STRIDE, sizeof(double))))
     return rc;
-  GC_HIP(hipMemcpyAsync(ctx->d_blocks, blocks, sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<gc_block> marked(blocks, blocks + nblocks);
+  gc_mark_tie_free(ctx, marked.data(), nblocks, fast > 0 ? 8e-6 : 0.0);
+  GC_HIP(hipMemcpyAsync(ctx->d_blocks, marked.data(), sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
   rc = gc_launch_correlator(ctx, ctx->d_blocks, nblocks, splits, ctx->d_out, ctx->d_partial, max_arms, fast, 0, 0u, share);
   if (rc) return rc;
   GC_HIP(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)nblocks * GC_OUT_STRIDE, hipMemcpyDeviceToHost, ctx->stream));
@@ -589,8 +684,12 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
     gc_set_error("gc_replay_prepare: device allocation failed");
     return GC_E_NOMEM;
   }
-  GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, blocks, sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
-  GC_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    std::vector<gc_block> marked(blocks, blocks + nblocks);
+    gc_mark_tie_free(ctx, marked.data(), nblocks, ctx->replay_fast > 0 ? 8e-6 : 0.0);
+    GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, marked.data(), sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+  }
   ctx->replay_nblocks = nblocks;
   ctx->replay_max_arms = max_arms;
   // channel pattern period: blocks[i].channel == blocks[i % P].channel (epoch-major replay lists)

@@ -224,6 +224,10 @@ int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, i
 int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code,
                          int code_phase, double coarse_freq, double* carr_freq);
 
+/* Test hook (host only, no GPU): first sample i in [0, n) whose ramp value a + i*step is within eps chips of
+ * an integer, or -1 — the exact near-tie analysis that lets the kernels skip their per-chunk filters. */
+long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps);
+
 /* Test hook: the library's four-step mixed-radix FFT on `nbatch` host sequences of n complex64
  * values (n of the form 2^a 3^b 5^c); output in natural order, unnormalised. */
 int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in, float* out, int inverse);

@@ -63,3 +63,40 @@ def test_synth_scene_is_reproducible_and_well_formed():
     assert all(-5e3 <= s.doppler <= 5e3 and 0 <= s.code_phase_samples < 18000 for s in a)
     iq = P.synth.generate_if(a[:2], 4000, 18e6, 20e3, P.codes.generateCAcode, 1.023e6, 1023, seed=1)
     assert iq.dtype == np.int8 and iq.shape == (8000,) and 10 < iq.std() < 30
+
+
+def test_first_sample_near_edge_matches_brute_force():
+    """gc_debug_first_sample_near_edge (host-only exact near-tie search behind the tie-free block flag) against
+    a rational-arithmetic brute force, including the reference's exact-tie case rem = 0, step = 1.023e6/18e6."""
+    from fractions import Fraction
+
+    from cu_sdr_collection_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(7)
+
+    def brute(a, step, n, eps):
+        A, D, e = Fraction(a), Fraction(step), Fraction(eps)
+        for i in range(n):
+            v = A + i * D
+            fr = v - (v.numerator // v.denominator)
+            if fr <= e or fr >= 1 - e:
+                return i
+        return -1
+
+    step0 = 1.023e6 / 18e6
+    assert lib.gc_debug_first_sample_near_edge(0.0, step0, 18000, 1e-12) == 0
+    assert lib.gc_debug_first_sample_near_edge(step0, step0, 18000, 1e-9) == brute(step0, step0, 18000, 1e-9)
+    hits = 0
+    for t in range(120):
+        kind = t % 3
+        if kind == 0:
+            a, st, n, eps = rng.uniform(-1, 1), rng.uniform(0.01, 0.9), int(rng.integers(1, 2000)), 10 ** rng.uniform(-6, -2)
+        elif kind == 1:
+            a, st, n, eps = -0.5, step0 * (1 + rng.uniform(-1e-6, 1e-6)), 6000, 10 ** rng.uniform(-8, -5)
+        else:
+            a, st, n, eps = rng.uniform(0, 2046), rng.uniform(0.05, 0.6), 3000, 10 ** rng.uniform(-7, -3)
+        got = lib.gc_debug_first_sample_near_edge(float(a), float(st), n, float(eps))
+        ref = brute(float(a), float(st), n, float(eps))
+        hits += ref >= 0
+        assert got == ref, (a, st, n, eps, got, ref)
+    assert 10 < hits < 110
