@@ -31,82 +31,6 @@ constexpr int kFW = 64;  // one wavefront per workgroup
 #define GC_SCHED_GROUP 4
 #endif
 
-template <int MODE>
-struct Fmt {
-  static constexpr int bps = (MODE == I8_IQ || MODE == I8_QI || MODE == I16_REAL) ? 2 : (MODE == I8_REAL) ? 1 : 4;
-  static constexpr bool swap = (MODE == I8_QI || MODE == I16_QI);
-};
-
-template <int MODE, int SPL>
-__device__ __forceinline__ void load_words(const uint8_t* __restrict__ base, long long q,
-                                           unsigned int (&w)[SPL * Fmt<MODE>::bps / 4]) {
-  constexpr int NW = SPL * Fmt<MODE>::bps / 4;
-  const uint8_t* p = base + (long long)(SPL * Fmt<MODE>::bps) * q;
-  if constexpr (NW == 2) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    w[0] = v.x; w[1] = v.y;
-  } else {
-#pragma unroll
-    for (int k = 0; k < NW / 4; ++k) {
-      const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * k);
-      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-    }
-  }
-}
-
-// Zero the samples of an edge chunk that lie outside [0, N): sample j is valid iff 0 <= i0+j < N.
-template <int MODE, int SPL>
-__device__ __forceinline__ void mask_words(unsigned int (&w)[SPL * Fmt<MODE>::bps / 4], int i0, int N) {
-  constexpr int bits = 8 * Fmt<MODE>::bps;
-  constexpr int per_word = 32 / bits;
-#pragma unroll
-  for (int j = 0; j < SPL; ++j) {
-    const bool valid = (unsigned int)(i0 + j) < (unsigned int)N;
-    const unsigned int m = (bits == 32) ? 0xffffffffu : (((1u << bits) - 1u) << ((j % per_word) * bits));
-    if (!valid) w[j / per_word] &= ~m;
-  }
-}
-
-#define GC_CVT_SDWA(sel)                                                                                  \
-  {                                                                                                       \
-    float r;                                                                                              \
-    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel : "=v"(r) : "v"(word)); \
-    return r;                                                                                             \
-  }
-template <int B>
-__device__ __forceinline__ float cvt_byte(unsigned int word) {
-  if constexpr (B == 0) GC_CVT_SDWA("BYTE_0")
-  else if constexpr (B == 1) GC_CVT_SDWA("BYTE_1")
-  else if constexpr (B == 2) GC_CVT_SDWA("BYTE_2")
-  else GC_CVT_SDWA("BYTE_3")
-}
-template <int H>
-__device__ __forceinline__ float cvt_half(unsigned int word) {
-  if constexpr (H == 0) GC_CVT_SDWA("WORD_0")
-  else GC_CVT_SDWA("WORD_1")
-}
-
-// Sample J of the chunk as floats (a, b) = (I, Q) after the layout's swap; b = 0 for real data.
-template <int MODE, int J, int NW>
-__device__ __forceinline__ void sample_ab(const unsigned int (&w)[NW], float& a, float& b) {
-  float x0, x1;
-  if constexpr (MODE == I8_IQ || MODE == I8_QI) {
-    x0 = cvt_byte<(J & 1) * 2>(w[J >> 1]);
-    x1 = cvt_byte<(J & 1) * 2 + 1>(w[J >> 1]);
-  } else if constexpr (MODE == I16_IQ || MODE == I16_QI) {
-    x0 = cvt_half<0>(w[J]);
-    x1 = cvt_half<1>(w[J]);
-  } else if constexpr (MODE == I8_REAL) {
-    x0 = cvt_byte<J & 3>(w[J >> 2]);
-    x1 = 0.0f;
-  } else {
-    x0 = cvt_half<J & 1>(w[J >> 1]);
-    x1 = 0.0f;
-  }
-  a = Fmt<MODE>::swap ? x1 : x0;
-  b = Fmt<MODE>::swap ? x0 : x1;
-}
-
 // Wavefront sum with DPP row shifts / broadcasts (no LDS traffic); the total lands in lane 63.
 __device__ __forceinline__ float wave_sum_lane63(float v) {
   auto dpp = [](float x, auto ctrl, auto row_mask) {
@@ -120,14 +44,6 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15
   v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31
   return v;
-}
-
-template <int J, int SPL, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (J < SPL) {
-    f(std::integral_constant<int, J>{});
-    static_for<J + 1, SPL>(f);
-  }
 }
 
 // Descriptor fetch: the device/host-mapped list, or (closed loop, <= kInlineBlocks blocks) the copy that

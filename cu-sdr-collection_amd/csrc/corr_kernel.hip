@@ -1,4 +1,6 @@
-// corr_kernel.hip — Early/Prompt/Late integrate-and-dump correlator for gfx950 (MI355X).
+// corr_kernel.hip — Early/Prompt/Late integrate-and-dump correlator for gfx950 (MI355X), generic variant:
+// any chipping rate (GPS L5, BDS B2a/B3I, Galileo E5 at 10.23 Mcps take several table transitions per
+// 8-sample lane-chunk, which rules out the transition-mask kernel of corr_fast.hip).
 //
 // Replaces the vector expressions of GPS/GPS_L1CA/include/tracking.m:247-300 (and the R-scaled /
 // multi-arm variants GAL_E1C/include/tracking.m:236-303, GPS_L5C/include/tracking.m:255-326):
@@ -6,19 +8,25 @@
 //   T3  carrier replica            exp(-1i*((carrFreq*2*pi)*(n/fs) + remCarrPhase)) (:280-287)
 //   T4  mix + six sums per arm                                                      (:291-300)
 //
-// Design (wave64, 256-thread workgroups, no MFMA — elementwise multiply + reduce):
+// Design (wave64, 256-thread workgroups, no MFMA — elementwise multiply + reduce, VALU-issue bound):
 //   * raw int8/int16 IF samples are read straight from HBM as 16-byte vectors: one lane-chunk
 //     = 8 consecutive samples, chunk grid aligned to absolute sample index so every load is
-//     16-B aligned and fully coalesced (1 KiB per wave-instruction);
-//   * padded code tables staged once per workgroup in LDS as int8;
-//   * code phase is a 64-bit fixed-point fraction per lane (exact double-precision base per
-//     thread, 2^-64-chip increments), so chip-edge decisions match the float64 reference
-//     except within ~1e-13 chip of an edge;
-//   * carrier: per-block table delta^j = exp(-i*2*pi*j*f/fs), j = 0..7, held in SGPRs, an
-//     exact double-precision phase base per thread reduced to one turn before the float
-//     sincos, and a per-iteration rotation by delta^2048;
-//   * 6*ARMS float accumulators per lane, wavefront shuffle reduction, LDS cross-wave
-//     combine in double, one store per output.
+//     16-B aligned and fully coalesced (1 KiB per wave-instruction), next chunk prefetched;
+//   * the padded code tables of all arms are staged once per workgroup in LDS as INTERLEAVED f16
+//     ({arm0, arm1} per entry): one ds_read per tap and sample serves every arm, and the f16 value
+//     feeds v_fma_mix_f32 directly — no int->float conversion in the loop.  16 zero guard entries on
+//     both sides let the masked samples of a block's first/last chunk index without clamps;
+//   * code phase is a 64-bit fixed-point fraction per lane (exact double-precision base per thread,
+//     2^-64-chip increments).  The per-sample edge decision is ONE v_sub_co_u32 on the high words
+//     (borrow -> table index via v_subb), and the same difference feeds a running unsigned min/max:
+//     only if some difference lies within a few 2^-32 chip of zero can the high-word decision (or
+//     the reference's float64 rounding, fl(a + fl(i*d)) and MATLAB's two-sided colon) disagree, and
+//     then the whole wave-chunk is redone by the exact float64 per-sample path;
+//   * carrier: per-block table delta^j = exp(-i*2*pi*j*f/fs), j = 0..7, held in SGPRs, an exact
+//     double-precision phase base per thread reduced to one turn before the float sincos, and a
+//     per-iteration rotation by delta^2048;
+//   * 6*ARMS float accumulators per lane, wavefront shuffle reduction, LDS cross-wave combine in
+//     double, one store per output.
 #include <cstdlib>
 
 #include "corr_common.h"
@@ -30,6 +38,10 @@ namespace {
 template <int ARMS, int MODE>
 __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int AP = ArmPitch<ARMS>::v;  // f16 values per staged entry
+  constexpr int NW = kSPL * Fmt<MODE>::bps / 4;
+  constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
+  _Float16* tabh = reinterpret_cast<_Float16*>(smem);  // [kGuard + maxn + kGuard][AP]
 
   // ---- which block / which split -------------------------------------------------------
   long long wg = blockIdx.x;
@@ -62,26 +74,45 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
   const DevChannel* __restrict__ chn = p.chans + blk.channel;
 
   // ---- stage the code tables into LDS --------------------------------------------------
-  int lds_off[ARMS];
   int nent[ARMS];
+  int maxn = 0;
   const int arms_here = chn->arms;
   bool restage = blk.channel != staged_channel;
-#pragma unroll
-  for (int a = 0; a < ARMS; ++a)
-    if (a < arms_here && blk.table_offset[a] != staged_off[a]) restage = true;
-  __syncthreads();  // the previous block's table reads and reduction scratch are done
+  bool plain = chn->tabh != nullptr && chn->tabh_ap == AP;  // pre-interleaved copy usable as is
 #pragma unroll
   for (int a = 0; a < ARMS; ++a) {
-    const int aa = (a < arms_here) ? a : 0;  // absent arms alias arm 0; their outputs are zeroed
-    lds_off[a] = chn->lds_off[aa];
-    const int off = blk.table_offset[aa];
-    nent[a] = min(chn->stage_len[aa], chn->nent[aa] - off);
-    if (restage && a < arms_here) {
-      staged_off[a] = off;
-      const int8_t* __restrict__ src = chn->tab[a] + off;
-      for (int i = tid; i < nent[a] + 8; i += kWG)
-        smem[lds_off[a] + i] = (i < nent[a]) ? (unsigned char)src[i] : 0;
+    nent[a] = 0;
+    if (a < arms_here) {
+      const int off = blk.table_offset[a];
+      nent[a] = min(chn->stage_len[a], chn->nent[a] - off);
+      maxn = max(maxn, nent[a]);
+      restage |= off != staged_off[a];
+      plain &= off == 0 && chn->stage_len[a] == chn->nent[a];
     }
+  }
+  __syncthreads();  // the previous block's table reads and reduction scratch are done
+  if (restage) {
+    if (plain) {
+      const uint4* __restrict__ src = reinterpret_cast<const uint4*>(chn->tabh);
+      uint4* dst = reinterpret_cast<uint4*>(smem);
+      const int n16 = chn->tabh_bytes >> 4;
+#pragma unroll 4
+      for (int i = tid; i < n16; i += kWG) dst[i] = src[i];
+    } else {
+      const int total = maxn + 2 * kGuard;
+      for (int i = tid; i < total; i += kWG) {
+        const int e = i - kGuard;
+#pragma unroll
+        for (int a = 0; a < AP; ++a) {
+          float v = 0.0f;
+          if (a < ARMS && a < arms_here && e >= 0 && e < nent[a < ARMS ? a : 0])
+            v = (float)chn->tab[a < ARMS ? a : 0][blk.table_offset[a < ARMS ? a : 0] + e];
+          tabh[i * AP + a] = (_Float16)v;
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < ARMS; ++a) staged_off[a] = (a < arms_here) ? blk.table_offset[a] : -1;
   }
   staged_channel = blk.channel;
   float* red = reinterpret_cast<float*>(smem + p.red_off);
@@ -107,10 +138,10 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
   const double bE = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), -d), R);
   const double bL = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)(N - 1), step), rem), d), R);
   // near-tie window in 2^-32 chip units: 16 ulp of the largest ramp value, at least 2 units
-  const bool tie_free = (blk.reserved & 1) != 0;
   const unsigned int tie_e =
       2u + (unsigned int)((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fabs(M) * (16.0 * 2.220446049250313e-16 * 4294967296.0));
-  const unsigned int tie_w = 2u * tie_e;
+  // the masked samples of an edge chunk index at most 7 ramp steps outside the table: inside the guard?
+  const bool guard_ok = 7.0 * fabs(sp * M) + 2.0 < (double)kGuard;
 
   // lanes 0..7: delta^j and the fixed-point ramp increments j*sp*M; lane 8: chunk-stride terms
   float myC, myS;
@@ -129,13 +160,13 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
     myJhi = (unsigned int)(jf >> 32);
   }
   float C[kSPL], S[kSPL];
-  unsigned long long Jf[kSPL];
+  unsigned int Jfh[kSPL];
   int Ji[kSPL];
 #pragma unroll
   for (int j = 0; j < kSPL; ++j) {
     C[j] = rl_f(myC, j);
     S[j] = rl_f(myS, j);
-    Jf[j] = ((unsigned long long)rl_u(myJhi, j) << 32) | rl_u(myJlo, j);
+    Jfh[j] = rl_u(myJhi, j);
     Ji[j] = __builtin_amdgcn_readlane(myJint, j);
   }
   const float rotC = rl_f(myC, 8), rotS = rl_f(myS, 8);
@@ -159,7 +190,7 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
   int c = cbeg + tid;
   if (c < cend) {
     int i0 = (int)((q0 + c) * kSPL - s0);  // block-relative index of the chunk's first sample
-    // exact double-precision bases (the reference's a + k*d, then *M for the BOC(6,1) arm)
+    // exact double-precision bases (the reference's a + k*d, then *M for a BOC(6,1)-only channel)
     Fx fx[3];
     const double isp = __dmul_rn((double)i0, sp);
     fx[0] = to_fx(__dmul_rn(__dadd_rn(aE, isp), M));
@@ -172,10 +203,14 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
       sincospif(2.0f * f, &ws, &wc);
     }
     const uint8_t* __restrict__ base = p.if_base;
+    unsigned int w[NW];
+    load_words<MODE, kSPL>(base, q0 + c, w);
 
-    for (; c < cend; c += kWG) {
-      float a[kSPL], b[kSPL];
-      load_chunk<MODE>(base, q0 + c, a, b);
+    while (true) {
+      const int cn = c + kWG;
+      unsigned int wn[NW];
+      if (cn < cend) load_words<MODE, kSPL>(base, q0 + cn, wn);
+
       const bool edge = (i0 < 0) | (i0 + kSPL > N);
       float sr[ARMS][3], si[ARMS][3];
 #pragma unroll
@@ -183,43 +218,103 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
 #pragma unroll
         for (int x = 0; x < 3; ++x) sr[ar][x] = si[ar][x] = 0.0f;
 
-      // Near-tie filter.  The fixed-point ramp equals the real-number value a + i*d to ~2^-60 chip,
-      // whereas the reference evaluates fl(a + fl(i*d)) (and builds the second half of the colon
-      // vector backwards): the two can disagree on ceil() only when a sample sits within a few ulp
-      // of a chip edge.  That is not measure-zero: with remCodePhase = 0 and the nominal code
-      // rate (every channel's first block, tracking.m:163-165) 1.023e6/18e6 is rational and samples
-      // 3000k land exactly on edges.  Sample j of tap x is within e chips of an edge iff
-      // (Jf[j] - G_x) mod 2^64 is within e*2^64 of zero; the test below does that on the high words
-      // (resolution 2.3e-10 chip, window tie_w >> the rounding noise) and sends the rare suspects
-      // through the exact double-precision path.  Blocks the host proved tie-free (gc_mark_tie_free:
-      // an exact number-theoretic search over the block's three ramps) skip the test.
-      bool suspect = false;
-      if (!tie_free) {
+      bool slow = !guard_ok && __any(edge) != 0;
+      if (!slow) {
+        // ---- lean path ---------------------------------------------------------------------
+        if (__builtin_expect(edge, 0)) mask_words<MODE, kSPL>(w, i0, N);
+        unsigned int gh[3], kb[3];
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-          const unsigned int gq = (unsigned int)(fx[x].G >> 32) - tie_e;
-#pragma unroll
-          for (int j = 0; j < kSPL; ++j) suspect |= ((unsigned int)(Jf[j] >> 32) - gq) <= tie_w;
+          gh[x] = (unsigned int)(fx[x].G >> 32);
+          kb[x] = (unsigned int)fx[x].k0;
         }
+        unsigned int dmin = 0xffffffffu, dmax = 0u;
+        static_for<0, kSPL>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          float a, b;
+          sample_ab<MODE, j, NW>(w, a, b);
+          const float yr = kReal ? a * C[j] : fmaf(a, C[j], b * S[j]);
+          const float yi = kReal ? -a * S[j] : fmaf(b, C[j], -a * S[j]);
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
+            // ceil(t + j*sp*M) = k0 + Ji[j] + (Jf[j] > G), decided on the high words (which differ unless the
+            // chunk is flagged below): the borrow of G_hi - Jf_hi[j] IS that bit, added to k0 by v_addc.
+            // (The C form compiles to cndmask + shifts + add3: 7 instructions instead of 2.)
+            unsigned int df, t;
+            asm("v_subrev_co_u32_e32 %0, vcc, %2, %3\n\tv_addc_co_u32_e32 %1, vcc, 0, %4, vcc"
+                : "=&v"(df), "=v"(t)
+                : "s"(Jfh[j]), "v"(gh[x]), "v"(kb[x])
+                : "vcc");
+            const unsigned int k = t + (unsigned int)Ji[j];
+            dmin = min(dmin, df);
+            dmax = max(dmax, df);
+            if constexpr (AP == 1) {
+              const float cf = (float)tabh[kGuard + (int)k];
+              sr[0][x] = fmaf(cf, yr, sr[0][x]);
+              si[0][x] = fmaf(cf, yi, si[0][x]);
+            } else if constexpr (AP == 2) {
+              typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+              const h2 e = reinterpret_cast<const h2*>(tabh)[kGuard + (int)k];
+#pragma unroll
+              for (int ar = 0; ar < ARMS; ++ar) {
+                const float cf = (float)e[ar];
+                sr[ar][x] = fmaf(cf, yr, sr[ar][x]);
+                si[ar][x] = fmaf(cf, yi, si[ar][x]);
+              }
+            } else {
+              typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+              const h4 e = reinterpret_cast<const h4*>(tabh)[kGuard + (int)k];
+#pragma unroll
+              for (int ar = 0; ar < ARMS; ++ar) {
+                const float cf = (float)e[ar];
+                sr[ar][x] = fmaf(cf, yr, sr[ar][x]);
+                si[ar][x] = fmaf(cf, yi, si[ar][x]);
+              }
+            }
+          }
+        });
+        // Near-tie test.  Sample j of tap x lies within e chips of a table edge iff (Jf[j] - G_x) mod 2^64 is
+        // within e*2^64 of zero.  That is not measure-zero: with remCodePhase = 0 and the nominal code rate
+        // (every channel's first block, tracking.m:163-165) 1.023e6/18e6 is rational and samples 3000k land
+        // exactly on edges.
+        const bool suspect = (dmin <= tie_e) | (dmax >= 0u - tie_e);
+        slow = __any(suspect) != 0;
       }
-      const bool exact = __any(suspect) != 0;  // wave-uniform: the exact path is ~1e-3 of wave-chunks
-
+      if (slow) {
+        // ---- exact path: MATLAB colon element i (tracking.m:252-270) in float64 for every sample of the
+        // chunk — forwards from a for the first half, backwards from the end point b for the second, mean
+        // of both in the exact middle.  A rolled loop that re-reads the samples from memory (L1-resident)
+        // so that the rare path does not set the kernel's register budget.
 #pragma unroll
-      for (int j = 0; j < kSPL; ++j) {
-        float yr = a[j] * C[j] + b[j] * S[j];
-        float yi = b[j] * C[j] - a[j] * S[j];
-        if (edge) {
-          const bool valid = (unsigned int)(i0 + j) < (unsigned int)N;
-          yr = valid ? yr : 0.0f;
-          yi = valid ? yi : 0.0f;
-        }
+        for (int ar = 0; ar < ARMS; ++ar)
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-          int k;
-          if (exact) {
-            // MATLAB colon element i (tracking.m:252-270): forwards from a for the first half,
-            // backwards from the end point b for the second, mean of both in the exact middle.
-            const int i = i0 + j;
+          for (int x = 0; x < 3; ++x) sr[ar][x] = si[ar][x] = 0.0f;
+        const uint8_t* sp8 = base + (long long)(kSPL * Fmt<MODE>::bps) * (q0 + c);
+        float cr = 1.0f, ci = 0.0f;  // delta^j = cr - i*ci
+#pragma unroll 1
+        for (int j = 0; j < kSPL; ++j) {
+          const int i = i0 + j;
+          float x0, x1 = 0.0f;
+          if constexpr (Fmt<MODE>::bps == 2 && !kReal) {
+            x0 = (float)(signed char)sp8[2 * j];
+            x1 = (float)(signed char)sp8[2 * j + 1];
+          } else if constexpr (Fmt<MODE>::bps == 4) {
+            x0 = (float)reinterpret_cast<const short*>(sp8)[2 * j];
+            x1 = (float)reinterpret_cast<const short*>(sp8)[2 * j + 1];
+          } else if constexpr (Fmt<MODE>::bps == 1) {
+            x0 = (float)(signed char)sp8[j];
+          } else {
+            x0 = (float)reinterpret_cast<const short*>(sp8)[j];
+          }
+          float a = Fmt<MODE>::swap ? x1 : x0, b = Fmt<MODE>::swap ? x0 : x1;
+          if ((unsigned int)i >= (unsigned int)N) a = b = 0.0f;  // edge chunk
+          const float yr = a * cr + b * ci;
+          const float yi = b * cr - a * ci;
+          const float ncr = cr * C[1] - ci * S[1], nci = cr * S[1] + ci * C[1];
+          cr = ncr;
+          ci = nci;
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
             const double ax = (x == 0) ? aE : (x == 1) ? aP : aL;
             const double bx = (x == 0) ? bE : (x == 1) ? bP : bL;
             double t;
@@ -229,17 +324,14 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
               t = __dadd_rn(bx, -__dmul_rn((double)(N - 1 - i), sp));
             else
               t = __dadd_rn(ax, bx) / 2.0;
-            k = (int)ceil(__dmul_rn(t, M));
-          } else {
-            k = fx[x].k0 + Ji[j] + (Jf[j] > fx[x].G ? 1 : 0);
-          }
+            const double kc = fmin(fmax(ceil(__dmul_rn(t, M)), (double)-kGuard), (double)(maxn + kGuard - 1));
+            const int kk = (int)kc;  // out-of-table indices belong to masked samples only
 #pragma unroll
-          for (int ar = 0; ar < ARMS; ++ar) {
-            int kk = k;
-            if (edge) kk = max(0, min(kk, nent[ar] - 1));
-            const float cf = (float)(int)(signed char)smem[lds_off[ar] + kk];
-            sr[ar][x] = fmaf(cf, yr, sr[ar][x]);
-            si[ar][x] = fmaf(cf, yi, si[ar][x]);
+            for (int ar = 0; ar < ARMS; ++ar) {
+              const float cf = (float)tabh[(kGuard + kk) * AP + ar];
+              sr[ar][x] = fmaf(cf, yr, sr[ar][x]);
+              si[ar][x] = fmaf(cf, yi, si[ar][x]);
+            }
           }
         }
       }
@@ -251,6 +343,7 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
           accr[ar][x] += wc * sr[ar][x] + ws * si[ar][x];
           acci[ar][x] += wc * si[ar][x] - ws * sr[ar][x];
         }
+      if (cn >= cend) break;
       // advance this thread by kWG chunks
       const float nwc = wc * rotC - ws * rotS;
       const float nws = wc * rotS + ws * rotC;
@@ -263,6 +356,9 @@ __global__ __launch_bounds__(kWG) void corr_epl_kernel(const KArgs p) {
         fx[x].G = g - Df;
       }
       i0 += kSPL * kWG;
+      c = cn;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) w[k] = wn[k];
     }
   }
 
@@ -396,20 +492,35 @@ __global__ void combine_partials_kernel(const double* __restrict__ partial, doub
   out[i] = s;
 }
 
+template <typename K>
+void launch_generic(gc_context* ctx, K kernel, const KArgs& a, dim3 grid, size_t smem) {
+  if (smem > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kernel, grid, dim3(kWG), smem, ctx->stream, a);
+}
+
 template <int ARMS>
-int launch_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
+int launch_mode(gc_context* ctx, KArgs a, dim3 grid) {
+  // interleaved f16 tables with guards, then the cross-wave reduction scratch
+  const size_t tab_bytes = ((size_t)(ctx->max_stage_len + 2 * kGuard) * ArmPitch<ARMS>::v * 2 + 15) / 16 * 16;
+  const size_t smem = tab_bytes + kWG / 64 * GC_OUT_STRIDE * sizeof(float);
+  if (smem > 160 * 1024) {
+    gc_set_error("code tables need %zu bytes of LDS (> 160 KiB); set a window with gc_set_code_window", smem);
+    return GC_E_UNSUPPORTED;
+  }
+  a.red_off = (int)tab_bytes;
   int mode;
   if (ctx->if_dtype == GC_I8)
     mode = ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
   else
     mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
   switch (mode) {
-    case I8_IQ: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I8_IQ>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I8_QI: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I8_QI>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I16_IQ: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I16_IQ>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I16_QI: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I16_QI>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    case I8_REAL: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I8_REAL>), grid, dim3(kWG), smem, ctx->stream, a); break;
-    default: hipLaunchKernelGGL((corr_epl_kernel<ARMS, I16_REAL>), grid, dim3(kWG), smem, ctx->stream, a); break;
+    case I8_IQ: launch_generic(ctx, corr_epl_kernel<ARMS, I8_IQ>, a, grid, smem); break;
+    case I8_QI: launch_generic(ctx, corr_epl_kernel<ARMS, I8_QI>, a, grid, smem); break;
+    case I16_IQ: launch_generic(ctx, corr_epl_kernel<ARMS, I16_IQ>, a, grid, smem); break;
+    case I16_QI: launch_generic(ctx, corr_epl_kernel<ARMS, I16_QI>, a, grid, smem); break;
+    case I8_REAL: launch_generic(ctx, corr_epl_kernel<ARMS, I8_REAL>, a, grid, smem); break;
+    default: launch_generic(ctx, corr_epl_kernel<ARMS, I16_REAL>, a, grid, smem); break;
   }
   GC_HIP(hipGetLastError());
   return GC_OK;
@@ -466,7 +577,6 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     gc_set_error("too many workgroups (%lld)", total);
     return GC_E_INVALID;
   }
-  const size_t smem = (size_t)ctx->max_lds_bytes + kWG / 64 * GC_OUT_STRIDE * sizeof(float);
   dim3 grid((unsigned int)total);
   int rc;
   if (fast > 0 && gc_fast_table_mode(ctx) == 1) {
@@ -512,9 +622,9 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     rc = gc_launch_correlator_fast(ctx, a, ib, (unsigned int)total, max_arms, fast == 2);
   } else {
     switch (max_arms) {
-      case 1: rc = launch_mode<1>(ctx, a, grid, smem); break;
-      case 2: rc = launch_mode<2>(ctx, a, grid, smem); break;
-      default: rc = launch_mode<3>(ctx, a, grid, smem); break;
+      case 1: rc = launch_mode<1>(ctx, a, grid); break;
+      case 2: rc = launch_mode<2>(ctx, a, grid); break;
+      default: rc = launch_mode<3>(ctx, a, grid); break;
     }
   }
   if (rc != GC_OK) return rc;

@@ -36,6 +36,11 @@ struct DevChannel {
   int32_t stage_len[GC_MAX_ARMS];  // entries staged into LDS per arm (window or whole table)
   int32_t lds_off[GC_MAX_ARMS];    // byte offset of each staged table in LDS
   int32_t lds_bytes;               // total staged bytes (16-B aligned)
+  // generic kernel: all arms interleaved as f16 with kGuard zero entries on both sides, ready to be copied
+  // into LDS 16 bytes at a time (whole tables, no window); nullptr = stage from tab[] entry by entry
+  const uint16_t* tabh;
+  int32_t tabh_ap;     // f16 values per entry (1, 2 or 4)
+  int32_t tabh_bytes;  // multiple of 16
 };
 
 struct HostChannel {
@@ -48,6 +53,8 @@ struct HostChannel {
   int nent[GC_MAX_ARMS] = {0, 0, 0};
   double mult[GC_MAX_ARMS] = {1.0, 1.0, 1.0};
   int window[GC_MAX_ARMS] = {0, 0, 0};  // 0 = stage the whole table
+  std::vector<int8_t> h_tab[GC_MAX_ARMS];  // host copies (interleaved f16 form is built at sync time)
+  uint16_t* d_tabh = nullptr;
 };
 
 struct gc_context {
@@ -70,8 +77,11 @@ struct gc_context {
   HostChannel ch[GC_MAX_CHANNELS];
   DevChannel* d_channels = nullptr;  // GC_MAX_CHANNELS entries
   bool channels_dirty = true;
-  int max_lds_bytes = 0;
+  // scope of the launch being prepared (gc_scope_reset / gc_scope_add): LDS needs of the channels it references
+  int max_lds_bytes = 0;  // int8 bytes of the largest channel (fast kernels scale it by 8 or 2)
+  int max_stage_len = 0;  // longest staged table (entries), generic kernel
   int max_arms_configured = 0;
+  int replay_scope[3] = {0, 0, 0};
 
   // scratch for gc_correlate / gc_track
   gc_block* d_blocks = nullptr;
@@ -103,6 +113,8 @@ struct gc_context {
 int gc_bytes_per_sample(int dtype, int layout);
 void gc_acq_free(gc_context* ctx);  // acq.hip
 int gc_sync_channels(gc_context* ctx);
+void gc_scope_reset(gc_context* ctx);
+void gc_scope_add(gc_context* ctx, int channel);
 // Launches the correlator for `nblocks` descriptors already on the device.
 int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblocks, int splits,
                          double* d_out, double* d_partial, int max_arms, int fast, int period = 0,

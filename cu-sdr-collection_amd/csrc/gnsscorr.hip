@@ -4,7 +4,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "gc_internal.h"
+#include "corr_common.h"
 
 static thread_local std::string g_last_error;
 
@@ -82,6 +82,7 @@ int gc_destroy(gc_context* ctx) {
       if (t) (void)hipFree(t);
     for (auto& t : c.d_tab2b)
       if (t) (void)hipFree(t);
+    if (c.d_tabh) (void)hipFree(c.d_tabh);
   }
   if (ctx->d_channels) (void)hipFree(ctx->d_channels);
   if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
@@ -356,6 +357,7 @@ int gc_set_code(gc_context* ctx, int channel, int arm, const int8_t* table, int 
     GC_HIP(hipMalloc((void**)&c.d_tab2b[arm], t2b.size() * sizeof(unsigned short)));
     GC_HIP(hipMemcpy(c.d_tab2b[arm], t2b.data(), t2b.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   }
+  c.h_tab[arm].assign(table, table + n_entries);
   c.nent[arm] = n_entries;
   c.mult[arm] = arm_mult;
   ctx->channels_dirty = true;
@@ -379,7 +381,6 @@ int gc_sync_channels(gc_context* ctx) {
   if (!ctx->channels_dirty) return GC_OK;
   std::vector<DevChannel> dev(GC_MAX_CHANNELS);
   std::memset(dev.data(), 0, sizeof(DevChannel) * GC_MAX_CHANNELS);
-  int max_lds = 0;
   for (int i = 0; i < GC_MAX_CHANNELS; ++i) {
     const HostChannel& c = ctx->ch[i];
     if (!c.configured) continue;
@@ -401,19 +402,36 @@ int gc_sync_channels(gc_context* ctx) {
     bool mixed = false;
     for (int a = 1; a < c.arms; ++a) mixed |= c.mult[a] != c.mult[0];
     d.lds_bytes = off;
-    if (!mixed) max_lds = std::max(max_lds, off);  // mixed-multiplier channels use the LDS-free exact kernel
-  }
-  if (max_lds > 150 * 1024) {
-    gc_set_error("code tables need %d bytes of LDS (> 150 KiB); set a window with gc_set_code_window", max_lds);
-    return GC_E_UNSUPPORTED;
+    // generic kernel: interleaved f16 copy of the whole tables (when no arm is windowed)
+    HostChannel& hc = ctx->ch[i];
+    if (hc.d_tabh) (void)hipFree(hc.d_tabh);
+    hc.d_tabh = nullptr;
+    bool whole = !mixed;
+    int maxn = 0;
+    for (int a = 0; a < c.arms; ++a) {
+      whole &= c.d_tab[a] != nullptr && c.window[a] == 0 && (int)c.h_tab[a].size() == c.nent[a];
+      maxn = std::max(maxn, d.stage_len[a]);
+    }
+    if (whole && maxn <= 65536) {
+      const int ap = gcorr::gc_arm_pitch(c.arms);
+      const size_t entries = (size_t)maxn + 2 * gcorr::kGuard;
+      const size_t bytes = (entries * ap * 2 + 15) / 16 * 16;
+      std::vector<uint16_t> t(bytes / 2, 0);
+      for (int a = 0; a < c.arms; ++a)
+        for (int e = 0; e < c.nent[a]; ++e) {
+          const int8_t v = c.h_tab[a][e];
+          t[((size_t)e + gcorr::kGuard) * ap + a] = v > 0 ? 0x3C00 : v < 0 ? 0xBC00 : 0;  // f16 +1 / -1 / 0
+        }
+      GC_HIP(hipMalloc((void**)&hc.d_tabh, bytes));
+      GC_HIP(hipMemcpy(hc.d_tabh, t.data(), bytes, hipMemcpyHostToDevice));
+      d.tabh = hc.d_tabh;
+      d.tabh_ap = ap;
+      d.tabh_bytes = (int32_t)bytes;
+    }
   }
   GC_HIP(hipMemcpyAsync(ctx->d_channels, dev.data(), sizeof(DevChannel) * GC_MAX_CHANNELS,
                         hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
-  ctx->max_lds_bytes = max_lds;
-  ctx->max_arms_configured = 0;
-  for (int i = 0; i < GC_MAX_CHANNELS; ++i)
-    if (ctx->ch[i].configured) ctx->max_arms_configured = std::max(ctx->max_arms_configured, ctx->ch[i].arms);
   ctx->channels_dirty = false;
   return GC_OK;
 }
@@ -523,6 +541,30 @@ bool gc_block_shares_el(const gc_context* ctx, const gc_block& b) {
   return c.arms == 1 && b.el_spacing * c.index_scale * c.mult[0] == 0.5;
 }
 
+// LDS needs of the launch being prepared ("scope" = the channels its descriptors reference): the kernels
+// size their staging areas for the largest table among THOSE channels, not among everything configured.
+void gc_scope_reset(gc_context* ctx) {
+  ctx->max_lds_bytes = 0;
+  ctx->max_stage_len = 0;
+  ctx->max_arms_configured = 0;
+}
+
+void gc_scope_add(gc_context* ctx, int channel) {
+  const HostChannel& c = ctx->ch[channel];
+  int off = 0, maxn = 0;
+  bool mixed = false;
+  for (int a = 0; a < c.arms; ++a) {
+    const int stage = (c.window[a] > 0) ? std::min(c.window[a], c.nent[a]) : c.nent[a];
+    off += ((stage + 8 + 15) / 16) * 16;  // as DevChannel::lds_off in gc_sync_channels
+    maxn = std::max(maxn, stage);
+    mixed |= c.mult[a] != c.mult[0];
+  }
+  ctx->max_arms_configured = std::max(ctx->max_arms_configured, c.arms);
+  if (mixed) return;  // mixed-multiplier channels use the LDS-free exact kernel
+  ctx->max_lds_bytes = std::max(ctx->max_lds_bytes, off);
+  ctx->max_stage_len = std::max(ctx->max_stage_len, maxn);
+}
+
 int gc_fast_table_mode(const gc_context* ctx) {
   if (8 * ctx->max_lds_bytes + 512 <= 64 * 1024) return 0;   // float2 tables, one wave per workgroup
   if (2 * ctx->max_lds_bytes + 512 <= 40 * 1024 && ctx->max_arms_configured <= 2) return 1;  // int8 pairs, 4 waves share them
@@ -550,6 +592,8 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
     return GC_E_STATE;
   }
   int max_arms = 1;
+  bool seen[GC_MAX_CHANNELS] = {false};
+  gc_scope_reset(ctx);
   for (int64_t i = 0; i < n; ++i) {
     const gc_block& k = b[i];
     if (k.channel < 0 || k.channel >= GC_MAX_CHANNELS || !ctx->ch[k.channel].configured) {
@@ -557,6 +601,10 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
       return GC_E_STATE;
     }
     const HostChannel& c = ctx->ch[k.channel];
+    if (!seen[k.channel]) {
+      seen[k.channel] = true;
+      gc_scope_add(ctx, k.channel);
+    }
     for (int a = 0; a < c.arms; ++a) {
       if (!c.d_tab[a]) {
         gc_set_error("block %lld: channel %d arm %d has no code table", (long long)i, k.channel, a);
@@ -672,6 +720,9 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
   ctx->replay_share_el = share;
+  ctx->replay_scope[0] = ctx->max_lds_bytes;
+  ctx->replay_scope[1] = ctx->max_stage_len;
+  ctx->replay_scope[2] = ctx->max_arms_configured;
   ctx->replay_fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
@@ -716,6 +767,9 @@ int gc_replay_launch(gc_context* ctx) {
     return GC_E_STATE;
   }
   GC_HIP(hipSetDevice(ctx->device));
+  ctx->max_lds_bytes = ctx->replay_scope[0];
+  ctx->max_stage_len = ctx->replay_scope[1];
+  ctx->max_arms_configured = ctx->replay_scope[2];
   int splits = 1;
   const int wg_waves = ctx->replay_fast > 0 ? 1 : 4;
   if (ctx->replay_nblocks * wg_waves < 8 * (int64_t)ctx->compute_units) {

@@ -54,6 +54,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   if (rc) return rc;
 
   int max_arms = 1;
+  gc_scope_reset(ctx);
   for (int c = 0; c < nch; ++c) {
     const int ci = init[c].channel;
     if (ci < 0 || ci >= GC_MAX_CHANNELS || !ctx->ch[ci].configured) {
@@ -66,6 +67,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
         return GC_E_STATE;
       }
     max_arms = std::max(max_arms, ctx->ch[ci].arms);
+    gc_scope_add(ctx, ci);
     for (int a = 1; a < ctx->ch[ci].arms; ++a)
       if (ctx->ch[ci].mult[a] != ctx->ch[ci].mult[0]) {
         gc_set_error("gc_track: channel %d mixes ramp multipliers (B1C wide-band): closed loop not wired up, use gc_correlate", ci);
