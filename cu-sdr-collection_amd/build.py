@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
 LIBS = {
-    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "track.hip", "acq.hip"],
+    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_lane.hip", "track.hip", "acq.hip"],
     "libgnsssynth.so": ["synth.hip"],
 }
 HEADERS = ["gc_internal.h", "corr_common.h", os.path.join("..", "..", "include", "gnsscorr.h")]
@@ -51,7 +51,24 @@ def build(force: bool = False, verbose: bool = True) -> None:
         deps = src_paths + [os.path.join(CSRC, h) for h in HEADERS]
         if not force and not _stale(target, deps):
             continue
-        cmd = [_hipcc(), *FLAGS, *src_paths, "-o", target]
+        # one object per translation unit, compiled in parallel (the kernels are heavily templated), then linked
+        objdir = os.path.join(HERE, "build")
+        os.makedirs(objdir, exist_ok=True)
+        cflags = [f for f in FLAGS if f != "-shared"]
+        jobs = []
+        for s in src_paths:
+            obj = os.path.join(objdir, os.path.splitext(os.path.basename(s))[0] + ".o")
+            if not force and not _stale(obj, [s] + [os.path.join(CSRC, h) for h in HEADERS]):
+                jobs.append((obj, None, None))
+                continue
+            cmd = [_hipcc(), *cflags, "-c", s, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            jobs.append((obj, cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        for obj, cmd, proc in jobs:
+            if proc is not None and proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+        cmd = [_hipcc(), *FLAGS, *[j[0] for j in jobs], "-o", target]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)

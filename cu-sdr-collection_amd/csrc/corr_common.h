@@ -20,6 +20,15 @@ struct ArmPitch {  // f16 values per interleaved table entry
 };
 inline int gc_arm_pitch(int arms) { return arms <= 1 ? 1 : arms == 2 ? 2 : 4; }
 
+constexpr int kLaneWaves = 16;  // wavefronts per workgroup of the lane kernel (corr_lane.hip)
+
+// Near-tie window of the lane kernel in 2^-32-chip units: 16 ulp of the largest ramp value (the reference's
+// float64 rounding of a + i*d and its two-sided colon), one unit per ramp step of a lane (the 32.32 increment
+// is rounded to 2^-33 chip), and 2 units of slack.  Host (gc_mark_tie_free) and device use the same formula.
+__host__ __device__ inline unsigned int gc_tie_window_units(double max_ramp, int lane_steps) {
+  return 2u + (unsigned int)lane_steps + (unsigned int)(max_ramp * (16.0 * 2.220446049250313e-16 * 4294967296.0));
+}
+
 struct TaggedSlot {
   double value;
   unsigned int tag;
@@ -210,6 +219,21 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// Wavefront sum with DPP row shifts / broadcasts (no LDS traffic); the total lands in lane 63.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value,
+                                                      decltype(row_mask)::value, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31
+  return v;
+}
+
 __device__ __forceinline__ float rl_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -218,8 +242,37 @@ __device__ __forceinline__ unsigned int rl_u(unsigned int v, int lane) {
 }
 
 
+// Descriptor fetch: the device/host-mapped list, or (closed loop, <= kInlineBlocks blocks) the copy that
+// travels in the kernel-argument segment.  The segment is read through its constant-address-space
+// pointer so the loads stay scalar (s_load) and the per-block quantities stay in SGPRs; indexing p.inl as
+// a by-value array, or going through a generic pointer, drags everything into VGPRs (measured: 179 VGPRs,
+// -20 % throughput).
+constexpr size_t kInlineOffset = (sizeof(KArgs) + 7) / 8 * 8;  // second explicit kernel argument
+
+__device__ __forceinline__ gc_block load_block(const KArgs& p, long long lb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (p.use_inline) {
+    typedef const __attribute__((address_space(4))) char* cptr4;
+    typedef const __attribute__((address_space(4))) unsigned long long* qptr4;
+    qptr4 src = (qptr4)((cptr4)__builtin_amdgcn_kernarg_segment_ptr() + kInlineOffset + lb * sizeof(gc_block));
+    union {
+      gc_block b;
+      unsigned long long q[sizeof(gc_block) / 8];
+    } u;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) u.q[i] = src[i];
+    return u.b;
+  }
+#endif
+  return p.blocks[lb];
+}
+
+
 }  // namespace gcorr
 
+// corr_lane.hip
+int gc_launch_correlator_lane(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
+                              int max_arms, bool share_el);
 // corr_fast.hip
 int gc_launch_correlator_fast(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
                               int max_arms, bool spl16);

@@ -31,46 +31,6 @@ constexpr int kFW = 64;  // one wavefront per workgroup
 #define GC_SCHED_GROUP 4
 #endif
 
-// Wavefront sum with DPP row shifts / broadcasts (no LDS traffic); the total lands in lane 63.
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-  auto dpp = [](float x, auto ctrl, auto row_mask) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value,
-                                                      decltype(row_mask)::value, 0xf, true));
-  };
-  v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
-  v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
-  v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
-  v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
-  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15
-  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31
-  return v;
-}
-
-// Descriptor fetch: the device/host-mapped list, or (closed loop, <= kInlineBlocks blocks) the copy that
-// travels in the kernel-argument segment.  The segment is read through its constant-address-space
-// pointer so the loads stay scalar (s_load) and the per-block quantities stay in SGPRs; indexing p.inl as
-// a by-value array, or going through a generic pointer, drags everything into VGPRs (measured: 179 VGPRs,
-// -20 % throughput).
-constexpr size_t kInlineOffset = (sizeof(KArgs) + 7) / 8 * 8;  // second explicit kernel argument
-
-__device__ __forceinline__ gc_block load_block(const KArgs& p, long long lb) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (p.use_inline) {
-    typedef const __attribute__((address_space(4))) char* cptr4;
-    typedef const __attribute__((address_space(4))) unsigned long long* qptr4;
-    qptr4 src = (qptr4)((cptr4)__builtin_amdgcn_kernarg_segment_ptr() + kInlineOffset + lb * sizeof(gc_block));
-    union {
-      gc_block b;
-      unsigned long long q[sizeof(gc_block) / 8];
-    } u;
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) u.q[i] = src[i];
-    return u.b;
-  }
-#endif
-  return p.blocks[lb];
-}
-
 // CL = closed-loop variant: descriptors from the kernel-argument segment, results as host-mapped tagged
 // records.  The replay instantiation (CL = false) carries none of that code.
 // SHARE = every block of the launch has earlyLateSpc*R*M == 1/2 (host-checked): early and late share one

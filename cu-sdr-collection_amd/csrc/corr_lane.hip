@@ -1,0 +1,493 @@
+// corr_lane.hip — Early/Prompt/Late integrate-and-dump correlator for gfx950 (MI355X), any chipping rate.
+//
+// The kernel for signals whose replica crosses several table entries per 8-sample chunk (GPS L5, BDS
+// B2a/B3I, Galileo E5 at 10.23 Mcps: 0.57 chip per sample at 18 Msps), where the transition-mask trick of
+// corr_fast.hip does not apply and every sample needs its own table lookup.
+//
+// Replaces the vector expressions of GPS/GPS_L1CA/include/tracking.m:247-300 (and the R-scaled / multi-arm
+// variants GAL_E1C/include/tracking.m:236-303, GPS_L5C/include/tracking.m:255-326):
+//   T2  code-replica index ramps   tcode = a : step : b ; idx = ceil(tcode)+1      (:252-270)
+//   T3  carrier replica            exp(-1i*((carrFreq*2*pi)*(n/fs) + remCarrPhase)) (:280-287)
+//   T4  mix + six sums per arm                                                      (:291-300)
+//
+// Design (wave64; measured instruction costs in profiles/r01/ubench_valu_rates.txt — only f32 fma/mul/add
+// and 32-bit integer add issue at full rate on gfx950, every other VALU instruction costs ~1.7x):
+//   * lane = sample: a wavefront walks its block 64 consecutive samples at a time, so the 64 table lookups
+//     of one ds_read fall into <= 40 consecutive LDS words — no bank conflicts (lane = 8-sample chunk put
+//     the lanes 4.5 entries apart: 5.4 conflict cycles per read, measured);
+//   * wave = work item: every wavefront owns whole (block, split) items, no barrier or LDS reduction after
+//     the table staging; 16 wavefronts per workgroup share ONE staged copy of the channel's tables;
+//   * tables of all arms interleaved per entry, as f32 when that fits half of LDS ({arm0, arm1} = one
+//     ds_read_b64 per tap and sample, values feed v_fma_f32 directly), else as f16 (v_fma_mix_f32);
+//   * ramp state per tap = ONE 64-bit integer Q (32.32 fixed point, biased so that its high word IS the
+//     table index ceil(t)), advanced by one v_lshl_add_u64 per sample — no carry chains.  The 2^-33-chip
+//     rounding of the per-step increment accumulates to < 1e-7 chip per block, which the near-tie window
+//     absorbs: a wave-group containing a sample whose fraction lies inside the window (or any sample, in
+//     blocks the host could not prove tie-free) is redone in float64 exactly as the reference computes it;
+//   * with earlyLateSpc*R*M a multiple of 1/2 the late tap reads the early tap's entry + 2*spacing (SHARE);
+//   * carrier: per-lane phasor from an exact float64 phase, rotated by exp(-i*2*pi*64*f/fs) per step;
+//   * 6*ARMS float accumulators per lane, DPP wavefront reduction, results as doubles or (closed loop) as
+//     host-mapped tagged 16-byte records.
+#include "corr_common.h"
+
+using namespace gcorr;
+
+namespace {
+
+constexpr int kLW = kLaneWaves;  // wavefronts per workgroup
+constexpr int kGRP = 4;          // samples per lane and group: the loads of the next group fly under this one
+
+// TAB: 0 = f32 tables, 1 = f32 tables + shared early/late ramp, 2 = f16 tables
+template <int ARMS, int MODE, bool CL, int TAB>
+__global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int AP = ArmPitch<ARMS>::v;  // values per staged entry
+  constexpr bool kF16 = (TAB == 2);
+  constexpr bool kShare = (TAB == 1);
+  constexpr int NT = kShare ? 2 : 3;  // ramps carried per sample
+  constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
+  constexpr int bps = Fmt<MODE>::bps;
+  typedef typename std::conditional<kF16, _Float16, float>::type tab_t;
+  const tab_t* tab = reinterpret_cast<const tab_t*>(smem);  // [kGuard + maxn + kGuard][AP]
+
+  long long wg = blockIdx.x;
+  if (p.xcd_swizzle) {
+    // Workgroup b is dispatched to XCD b % 8.  Give every XCD one contiguous range of the descriptor list so
+    // that neighbouring descriptors (the channels of one epoch, which read the same IF window) share an L2.
+    const long long per = (long long)gridDim.x >> 3;  // host guarantees gridDim.x % 8 == 0 when swizzling
+    wg = (wg & 7) * per + (wg >> 3);
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform (SGPR)
+  // bpw == 1: the workgroup's 16 waves take 16 consecutive (block, split) items — the host keeps splits a
+  // multiple of 16, so they share block and table.  bpw > 1 (periodic replay lists that interleave `stride`
+  // channels epoch by epoch): the workgroup walks bpw consecutive epochs of ONE channel, wave w taking
+  // epochs w, w + 16, ...
+  // bpw == 1 and p.wide: ONE block per workgroup, split 16 ways over its waves, combined through LDS (big
+  // lists of unrelated blocks: no partial buffer, no second kernel).
+  const bool wave_items = p.bpw == 1;
+  const bool wg_block = wave_items && p.wide != 0;
+  const int nsplit = wg_block ? kLW : p.splits;
+  const long long item = wg_block ? wg * kLW + wave : wave_items ? wg * kLW + wave : wg;
+  const long long wq = item / nsplit;
+  const int split = (int)(item - wq * nsplit);
+  const long long grp = wq / p.stride;
+  const int cslot = (int)(wq - grp * p.stride);
+
+  // ---- stage the tables once per workgroup (all its blocks share channel and table offsets) ----------
+  int maxn = 0;
+  {
+    const long long lb0 = min(wave_items ? (wg * kLW) / nsplit : grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
+    const gc_block blk0 = CL ? load_block(p, lb0) : p.blocks[lb0];
+    const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
+    const int arms0 = chn0->arms;
+    int nent[ARMS];
+    const void* pre = kF16 ? (const void*)chn0->tabh : (const void*)chn0->tabf;
+    bool plain = pre != nullptr && chn0->tabh_ap == AP;  // pre-interleaved copy usable as is
+#pragma unroll
+    for (int a = 0; a < ARMS; ++a) {
+      nent[a] = 0;
+      if (a < arms0) {
+        const int off = blk0.table_offset[a];
+        nent[a] = min(chn0->stage_len[a], chn0->nent[a] - off);
+        maxn = max(maxn, nent[a]);
+        plain &= off == 0 && chn0->stage_len[a] == chn0->nent[a];
+      }
+    }
+    if (plain) {
+      const uint4* __restrict__ src = reinterpret_cast<const uint4*>(pre);
+      uint4* dst = reinterpret_cast<uint4*>(smem);
+      const int n16 = (kF16 ? chn0->tabh_bytes : 2 * chn0->tabh_bytes) >> 4;
+#pragma unroll 4
+      for (int i = threadIdx.x; i < n16; i += kLW * 64) dst[i] = src[i];
+    } else {
+      tab_t* wtab = reinterpret_cast<tab_t*>(smem);
+      const int total = maxn + 2 * kGuard;
+      for (int i = threadIdx.x; i < total; i += kLW * 64) {
+        const int e = i - kGuard;
+#pragma unroll
+        for (int a = 0; a < AP; ++a) {
+          float v = 0.0f;
+          if (a < ARMS) {
+            const int aa = a < ARMS ? a : 0;
+            if (a < arms0 && e >= 0 && e < nent[aa]) v = (float)chn0->tab[aa][blk0.table_offset[aa] + e];
+          }
+          wtab[i * AP + a] = (tab_t)v;
+        }
+      }
+    }
+    __syncthreads();  // the only barrier
+  }
+  if (wave_items && wq >= p.nblocks) return;
+
+  for (int bi = wave_items ? 0 : wave; bi < p.bpw; bi += wave_items ? 1 : kLW) {
+  const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
+  if (lb >= p.nblocks) break;
+  const gc_block blk = CL ? load_block(p, lb) : p.blocks[lb];
+  const DevChannel* __restrict__ chn = p.chans + blk.channel;
+  const int arms_here = chn->arms;
+
+  // ---- per-block uniform quantities ----------------------------------------------------------------
+  const double R = chn->index_scale;
+  const double M = chn->mult[0];
+  const double rem = blk.rem_code_phase;
+  const double step = blk.code_phase_step;
+  const double d = blk.el_spacing;
+  const int N = blk.blksize;
+  const long long s0 = blk.first_sample;
+  // colon() arguments exactly as the reference writes them (tracking.m:252-268; GAL_E1C tracking.m:236-262
+  // for R = 2); x*1.0 is exact so R = 1 needs no special case.
+  const double aE = (rem - d) * R;
+  const double aL = (rem + d) * R;
+  const double aP = rem * R;
+  const double sp = step * R;
+  const double tau = blk.carr_freq / p.fs;  // carrier turns per sample
+  const bool tie_free = (blk.reserved & 1) != 0;  // host-proved: no sample within the window of a table edge
+
+  // sample range of this split: a multiple of 64 samples per split
+  const int per = (((N + nsplit - 1) / nsplit) + 63) / 64 * 64;
+  const int ibeg = split * per;
+  const int iend = min(N, ibeg + per);
+  const unsigned int tie_e = gc_tie_window_units((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fabs(M), (per >> 6) + 1);
+
+  // Per-sample ramp step sp*M as a 64.64 fixed-point number (exact: a double has at most 64 fractional bits
+  // here); one step of a lane = 64 samples = that number << 6, rounded to 32 fractional bits for Q.
+  unsigned long long Sf, dQ;
+  int Si;
+  float rotC, rotS;
+  int el_off = 0;
+  {
+    const double y = sp * M;
+    const double yi = floor(y);
+    Sf = frac_to_u64(y - yi);
+    Sf = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(Sf >> 32)) << 32) |
+         (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)Sf);
+    Si = __builtin_amdgcn_readfirstlane((int)yi);
+    const unsigned long long df = Sf << 6;  // fraction of the 64-sample step, 64 fractional bits
+    const long long di = (long long)Si * 64 + (long long)(Sf >> 58);
+    dQ = ((unsigned long long)di << 32) + (df >> 32) + ((df >> 31) & 1ull);
+    const double x = 64.0 * tau;
+    float s_, c_;
+    sincospif(2.0f * (float)(x - floor(x)), &s_, &c_);  // range reduction in double, sincos in float
+    rotC = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c_)));
+    rotS = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_)));
+    if (kShare) el_off = __builtin_amdgcn_readfirstlane((int)(2.0 * d * R * M));  // host-checked: exact integer
+  }
+
+  float accr[ARMS][3], acci[ARMS][3];
+#pragma unroll
+  for (int a = 0; a < ARMS; ++a)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) accr[a][x] = acci[a][x] = 0.0f;
+
+  int i = ibeg + lane;  // this lane's samples: i, i + 64, i + 128, ...
+  if (i < iend) {
+    // Ramp state of this lane's first sample: the block-uniform value at sample ibeg from the reference's
+    // doubles ((a + ibeg*d) * M), advanced by `lane` steps in exact fixed-point arithmetic, then narrowed to
+    // Q = floor(t * 2^32) + 2^32 - 1, whose high word is ceil(t) unless t is within 2^-32 of an integer.
+    unsigned long long Q[NT];
+    {
+      const double isp = __dmul_rn((double)ibeg, sp);
+      const double base3[3] = {__dmul_rn(__dadd_rn(aE, isp), M), __dmul_rn(__dadd_rn(aP, isp), M),
+                               __dmul_rn(__dadd_rn(aL, isp), M)};
+      const unsigned __int128 prod = (unsigned __int128)Sf * (unsigned int)lane;
+      const unsigned long long F = (unsigned long long)prod;
+      const int I = lane * Si + (int)(unsigned long long)(prod >> 64);
+#pragma unroll
+      for (int x = 0; x < NT; ++x) {
+        const Fx f0 = to_fx(base3[x]);
+        const unsigned long long g = f0.G - F;  // t = k - g / 2^64
+        const int k = f0.k0 + I + (f0.G < F ? 1 : 0);
+        const unsigned long long gc = (g >> 32) + (((unsigned int)g != 0u) ? 1ull : 0ull);  // ceil(g / 2^32) <= 2^32
+        const unsigned long long q = ((unsigned long long)(unsigned int)k << 32) + 0xffffffffull - gc;
+        Q[x] = q;
+      }
+    }
+    float wc, ws;  // exp(-i*theta_i) = wc - i*ws
+    {
+      const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
+      sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+    }
+    const uint8_t* ptr = p.if_base + (long long)bps * (s0 + i);
+    auto load_sample = [](const uint8_t* q) -> unsigned int {
+      if constexpr (bps == 2) return *reinterpret_cast<const unsigned short*>(q);
+      else if constexpr (bps == 4) return *reinterpret_cast<const unsigned int*>(q);
+      else return *q;
+    };
+    auto sample_of = [](unsigned int word, float& a, float& b) {
+      float x0, x1 = 0.0f;
+      if constexpr (MODE == I8_IQ || MODE == I8_QI) {
+        x0 = cvt_byte<0>(word);
+        x1 = cvt_byte<1>(word);
+      } else if constexpr (MODE == I16_IQ || MODE == I16_QI) {
+        x0 = cvt_half<0>(word);
+        x1 = cvt_half<1>(word);
+      } else if constexpr (MODE == I8_REAL) {
+        x0 = cvt_byte<0>(word);
+      } else {
+        x0 = cvt_half<0>(word);
+      }
+      a = Fmt<MODE>::swap ? x1 : x0;
+      b = Fmt<MODE>::swap ? x0 : x1;
+    };
+    auto rotate_w = [&]() {
+      const float nwc = wc * rotC - ws * rotS;
+      const float nws = wc * rotS + ws * rotC;
+      wc = nwc;
+      ws = nws;
+    };
+    auto mix = [&](unsigned int word, float& yr, float& yi) {
+      float a, b;
+      sample_of(word, a, b);
+      yr = kReal ? a * wc : fmaf(a, wc, b * ws);
+      yi = kReal ? -a * ws : fmaf(b, wc, -a * ws);
+    };
+    auto accumulate = [&](int x, int k, float yr, float yi) {
+      if constexpr (AP == 1) {
+        const float cf = (float)tab[kGuard + k];
+        accr[0][x] = fmaf(cf, yr, accr[0][x]);
+        acci[0][x] = fmaf(cf, yi, acci[0][x]);
+      } else {
+        typedef tab_t vec_t __attribute__((ext_vector_type(AP)));
+        const vec_t e = reinterpret_cast<const vec_t*>(tab)[kGuard + k];
+#pragma unroll
+        for (int ar = 0; ar < ARMS; ++ar) {
+          const float cf = (float)e[ar];
+          accr[ar][x] = fmaf(cf, yr, accr[ar][x]);
+          acci[ar][x] = fmaf(cf, yi, acci[ar][x]);
+        }
+      }
+    };
+    // lean accumulate of one sample: y = x*exp(-i theta), one LDS read per tap serves every arm
+    auto lean_sample = [&](unsigned int word, const int (&k)[NT]) {
+      float yr, yi;
+      mix(word, yr, yi);
+      accumulate(0, k[0], yr, yi);
+      accumulate(1, k[1], yr, yi);
+      accumulate(2, kShare ? k[0] + el_off : k[NT - 1], yr, yi);
+    };
+    // exact accumulate of one sample: MATLAB colon element i (tracking.m:252-270) in float64 — forwards from
+    // a for the first half, backwards from the end point b for the second, mean of both in the exact middle
+    auto exact_sample = [&](unsigned int word, int is) {
+      float yr, yi;
+      mix(word, yr, yi);
+      // colon() end points b = ((N-1)*step + rem -/+ d) * R, evaluated in the reference's order
+      const double nm1s = __dmul_rn((double)(N - 1), step);
+      const double bP = __dmul_rn(__dadd_rn(nm1s, rem), R);
+      const double bE = __dmul_rn(__dadd_rn(__dadd_rn(nm1s, rem), -d), R);
+      const double bL = __dmul_rn(__dadd_rn(__dadd_rn(nm1s, rem), d), R);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const double ax = (x == 0) ? aE : (x == 1) ? aP : aL;
+        const double bx = (x == 0) ? bE : (x == 1) ? bP : bL;
+        double t;
+        if (2 * is < N - 1)
+          t = __dadd_rn(ax, __dmul_rn((double)is, sp));
+        else if (2 * is > N - 1)
+          t = __dadd_rn(bx, -__dmul_rn((double)(N - 1 - is), sp));
+        else
+          t = __dadd_rn(ax, bx) / 2.0;
+        const int kx = (int)fmin(fmax(ceil(__dmul_rn(t, M)), (double)-kGuard), (double)(maxn + kGuard - 1));
+        accumulate(x, kx, yr, yi);
+      }
+    };
+    // ramp step of one tap: table index of the CURRENT sample (high word), the low word into the running
+    // min / max of the near-tie test, then Q += dQ
+    auto ramp_step = [&](int x, bool test, unsigned int& dmin, unsigned int& dmax) -> int {
+      const int k = (int)(unsigned int)(Q[x] >> 32);
+      if (test) {
+        dmin = min(dmin, (unsigned int)Q[x]);
+        dmax = max(dmax, (unsigned int)Q[x]);
+      }
+      Q[x] += dQ;
+      return k;
+    };
+
+    // one group: the loads of the NEXT group go out first, into the other buffer
+    auto group = [&](unsigned int (&cur)[kGRP], unsigned int (&nxt)[kGRP]) -> bool {
+      const bool more = i + (2 * kGRP - 1) * 64 < iend;
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < kGRP; ++j) nxt[j] = load_sample(ptr + (long long)(kGRP + j) * bps * 64);
+      }
+      // Ramp stage for the whole group, with the near-tie test: a sample lies within e chips of a table edge
+      // iff the low word of its Q is within e*2^32 of 0 (mod 2^32).  Not measure-zero: with remCodePhase = 0
+      // and the nominal code rate (every channel's first block, tracking.m:163-165) 1.023e6/18e6 is rational
+      // and samples 3000k land exactly on edges.  Any suspect lane sends the wave's group through the exact
+      // path.  Blocks the host proved tie-free (gc_mark_tie_free, an exact search) skip the test.
+      int kg[kGRP][NT];
+      unsigned int dmin = 0xffffffffu, dmax = 0u;
+      if (tie_free) {
+#pragma unroll
+        for (int j = 0; j < kGRP; ++j)
+#pragma unroll
+          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, false, dmin, dmax);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kGRP; ++j)
+#pragma unroll
+          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, true, dmin, dmax);
+      }
+      const bool suspect = !tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u));
+      if (__builtin_expect(__any(suspect) != 0, 0)) {
+#pragma unroll 1
+        for (int j = 0; j < kGRP; ++j) {
+          exact_sample(load_sample(ptr + (long long)j * bps * 64), i + j * 64);
+          rotate_w();
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kGRP; ++j) {
+          lean_sample(cur[j], kg[j]);
+          rotate_w();
+        }
+      }
+      i += kGRP * 64;
+      ptr += (long long)kGRP * bps * 64;
+      return more;
+    };
+    unsigned int xa[kGRP], xb[kGRP];
+    bool have = i + (kGRP - 1) * 64 < iend;
+    if (have) {
+#pragma unroll
+      for (int j = 0; j < kGRP; ++j) xa[j] = load_sample(ptr + (long long)j * bps * 64);
+    }
+    while (have) {
+      have = group(xa, xb);
+      if (!have) break;
+      have = group(xb, xa);
+    }
+    // tail: fewer than kGRP samples left for this lane
+    for (; i < iend; i += 64, ptr += (long long)bps * 64) {
+      const unsigned int word = load_sample(ptr);
+      int k1[NT];
+      unsigned int dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+      for (int x = 0; x < NT; ++x) k1[x] = ramp_step(x, true, dmin, dmax);
+      if (!tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)))
+        exact_sample(word, i);
+      else
+        lean_sample(word, k1);
+      rotate_w();
+    }
+  }
+
+  // ---- reduce across the wavefront (DPP) and store --------------------------------------------------
+  float tot[ARMS * 6];
+#pragma unroll
+  for (int ar = 0; ar < ARMS; ++ar)
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      tot[ar * 6 + 2 * x] = wave_sum_lane63(accr[ar][x]);
+      tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(acci[ar][x]);
+    }
+  if (wg_block) {
+    // one block per workgroup: lane 63 of every wave parks its sums in LDS, wave 0 adds them in double
+    float* red = reinterpret_cast<float*>(smem + p.red_off);
+    if (lane == 63) {
+#pragma unroll
+      for (int v = 0; v < ARMS * 6; ++v) red[wave * GC_OUT_STRIDE + v] = tot[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < GC_OUT_STRIDE) {
+      double s = 0.0;
+      if ((int)threadIdx.x < arms_here * 6 && (int)threadIdx.x < ARMS * 6)
+        for (int w = 0; w < kLW; ++w) s += (double)red[w * GC_OUT_STRIDE + threadIdx.x];
+      p.out[lb * GC_OUT_STRIDE + threadIdx.x] = s;
+    }
+  } else if (CL) {
+    // lane v takes total v (broadcast from lane 63) and stores its 16-byte tagged record
+    TaggedSlot* ts = p.tagged + (lb * p.splits + split) * GC_OUT_STRIDE;
+    float mine = 0.0f;
+#pragma unroll
+    for (int v = 0; v < ARMS * 6; ++v) {
+      const float t = rl_f(tot[v], 63);
+      mine = (lane == v) ? t : mine;
+    }
+    if (lane < ARMS * 6) {
+      TaggedSlot rec;
+      rec.value = (lane < arms_here * 6) ? (double)mine : 0.0;
+      rec.tag = p.notify_tag;
+      rec.zero = 0u;
+      *reinterpret_cast<uint4*>(ts + lane) = *reinterpret_cast<const uint4*>(&rec);
+    }
+  } else if (lane == 63) {
+    double* o = (p.splits == 1) ? p.out + lb * GC_OUT_STRIDE : p.partial + (lb * p.splits + split) * GC_OUT_STRIDE;
+#pragma unroll
+    for (int v = 0; v < ARMS * 6; ++v) o[v] = (v < arms_here * 6) ? (double)tot[v] : 0.0;
+    for (int v = ARMS * 6; v < GC_OUT_STRIDE; ++v) o[v] = 0.0;
+  }
+  }  // bpw loop
+}
+
+template <typename K>
+void launch_one(gc_context* ctx, K kernel, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem) {
+  if (smem > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kernel, grid, dim3(kLW * 64), smem, ctx->stream, a, ib);
+}
+
+template <int ARMS, int MODE>
+void launch_tab(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, int tabkind) {
+  const bool cl = a.tagged != nullptr;
+  if (cl) {
+    if (tabkind == 0) launch_one(ctx, corr_epl_lane_kernel<ARMS, MODE, true, 0>, a, ib, grid, smem);
+    else if (tabkind == 1) launch_one(ctx, corr_epl_lane_kernel<ARMS, MODE, true, 1>, a, ib, grid, smem);
+    else launch_one(ctx, corr_epl_lane_kernel<ARMS, MODE, true, 2>, a, ib, grid, smem);
+  } else {
+    if (tabkind == 0) launch_one(ctx, corr_epl_lane_kernel<ARMS, MODE, false, 0>, a, ib, grid, smem);
+    else if (tabkind == 1) launch_one(ctx, corr_epl_lane_kernel<ARMS, MODE, false, 1>, a, ib, grid, smem);
+    else launch_one(ctx, corr_epl_lane_kernel<ARMS, MODE, false, 2>, a, ib, grid, smem);
+  }
+}
+
+template <int ARMS>
+int launch_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, int tabkind) {
+  int mode;
+  if (ctx->if_dtype == GC_I8)
+    mode = ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
+  else
+    mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
+  switch (mode) {
+    case I8_IQ: launch_tab<ARMS, I8_IQ>(ctx, a, ib, grid, smem, tabkind); break;
+    case I8_QI: launch_tab<ARMS, I8_QI>(ctx, a, ib, grid, smem, tabkind); break;
+    case I16_IQ: launch_tab<ARMS, I16_IQ>(ctx, a, ib, grid, smem, tabkind); break;
+    case I16_QI: launch_tab<ARMS, I16_QI>(ctx, a, ib, grid, smem, tabkind); break;
+    case I8_REAL: launch_tab<ARMS, I8_REAL>(ctx, a, ib, grid, smem, tabkind); break;
+    default: launch_tab<ARMS, I16_REAL>(ctx, a, ib, grid, smem, tabkind); break;
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+
+}  // namespace
+
+// share_el: every block of the launch has 2*el_spacing*R*M an exact positive integer
+int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBlocks& ib, unsigned int grid, int max_arms,
+                              bool share_el) {
+  KArgs a = a_in;
+  const int ap = gc_arm_pitch(max_arms);
+  const size_t entries = (size_t)ctx->max_stage_len + 2 * kGuard;
+  const size_t f32_bytes = (entries * ap * 4 + 15) / 16 * 16;
+  const size_t f16_bytes = (entries * ap * 2 + 15) / 16 * 16;
+  int tabkind;
+  size_t smem;
+  if (f32_bytes <= 96 * 1024) {  // f32 tables: one 16-wave workgroup per CU still fits next to a second one up to 80 KiB
+    tabkind = share_el ? 1 : 0;
+    smem = f32_bytes;
+    a.red_off = (int)f32_bytes;
+  } else if (f16_bytes + 2048 <= 160 * 1024) {
+    tabkind = 2;
+    smem = f16_bytes;
+    a.red_off = (int)f16_bytes;
+  } else {
+    gc_set_error("code tables need %zu bytes of LDS (> 160 KiB); set a window with gc_set_code_window", f16_bytes);
+    return GC_E_UNSUPPORTED;
+  }
+  smem += kLW * GC_OUT_STRIDE * sizeof(float);  // cross-wave scratch of the one-block-per-workgroup mode
+  switch (max_arms) {
+    case 1: return launch_mode<1>(ctx, a, ib, dim3(grid), smem, tabkind);
+    case 2: return launch_mode<2>(ctx, a, ib, dim3(grid), smem, tabkind);
+    default: return launch_mode<3>(ctx, a, ib, dim3(grid), smem, tabkind);
+  }
+}

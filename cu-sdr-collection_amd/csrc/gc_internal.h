@@ -39,6 +39,7 @@ struct DevChannel {
   // generic kernel: all arms interleaved as f16 with kGuard zero entries on both sides, ready to be copied
   // into LDS 16 bytes at a time (whole tables, no window); nullptr = stage from tab[] entry by entry
   const uint16_t* tabh;
+  const float* tabf;   // the same as f32 (2 * tabh_bytes bytes)
   int32_t tabh_ap;     // f16 values per entry (1, 2 or 4)
   int32_t tabh_bytes;  // multiple of 16
 };
@@ -55,6 +56,7 @@ struct HostChannel {
   int window[GC_MAX_ARMS] = {0, 0, 0};  // 0 = stage the whole table
   std::vector<int8_t> h_tab[GC_MAX_ARMS];  // host copies (interleaved f16 form is built at sync time)
   uint16_t* d_tabh = nullptr;
+  float* d_tabf = nullptr;
 };
 
 struct gc_context {
@@ -82,6 +84,9 @@ struct gc_context {
   int max_stage_len = 0;  // longest staged table (entries), generic kernel
   int max_arms_configured = 0;
   int replay_scope[3] = {0, 0, 0};
+  bool scope_share_lane = false;  // every block of the scope has 2*el_spacing*R*M an exact positive integer
+  bool replay_share_lane = false;
+  int replay_min_blksize = 0;
 
   // scratch for gc_correlate / gc_track
   gc_block* d_blocks = nullptr;
@@ -121,10 +126,13 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
                          unsigned int notify_tag = 0, bool share_el = false);
 // el_spacing * R * M == 1/2 exactly: early and late ramps differ by one whole table entry
 bool gc_block_shares_el(const gc_context* ctx, const gc_block& b);
+// 2 * el_spacing * R * M is an exact positive integer: the late tap reads the early tap's entry + that integer
+bool gc_block_shares_el_lane(const gc_context* ctx, const gc_block& b);
 // Kernel class a block qualifies for: 0 = generic only, 1 = fast kernel with 8-sample lane-chunks,
 // 2 = fast kernel with 16-sample lane-chunks (at most one table transition per chunk and tap).
 int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b);
 bool gc_fast_lds_ok(const gc_context* ctx);
+int gc_lane_splits(const gc_context* ctx, int64_t nblocks, int min_blksize, int cap);
 int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps);
 void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps);
 // 0 = float2 tables / single-wave workgroups, 1 = WIDE (int8 pairs, four waves), -1 = tables too large for the fast kernel

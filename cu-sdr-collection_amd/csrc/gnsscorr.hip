@@ -83,6 +83,7 @@ int gc_destroy(gc_context* ctx) {
     for (auto& t : c.d_tab2b)
       if (t) (void)hipFree(t);
     if (c.d_tabh) (void)hipFree(c.d_tabh);
+    if (c.d_tabf) (void)hipFree(c.d_tabf);
   }
   if (ctx->d_channels) (void)hipFree(ctx->d_channels);
   if (ctx->d_blocks) (void)hipFree(ctx->d_blocks);
@@ -405,7 +406,9 @@ int gc_sync_channels(gc_context* ctx) {
     // generic kernel: interleaved f16 copy of the whole tables (when no arm is windowed)
     HostChannel& hc = ctx->ch[i];
     if (hc.d_tabh) (void)hipFree(hc.d_tabh);
+    if (hc.d_tabf) (void)hipFree(hc.d_tabf);
     hc.d_tabh = nullptr;
+    hc.d_tabf = nullptr;
     bool whole = !mixed;
     int maxn = 0;
     for (int a = 0; a < c.arms; ++a) {
@@ -417,13 +420,18 @@ int gc_sync_channels(gc_context* ctx) {
       const size_t entries = (size_t)maxn + 2 * gcorr::kGuard;
       const size_t bytes = (entries * ap * 2 + 15) / 16 * 16;
       std::vector<uint16_t> t(bytes / 2, 0);
+      std::vector<float> tf(bytes / 2, 0.0f);
       for (int a = 0; a < c.arms; ++a)
         for (int e = 0; e < c.nent[a]; ++e) {
           const int8_t v = c.h_tab[a][e];
           t[((size_t)e + gcorr::kGuard) * ap + a] = v > 0 ? 0x3C00 : v < 0 ? 0xBC00 : 0;  // f16 +1 / -1 / 0
+          tf[((size_t)e + gcorr::kGuard) * ap + a] = (float)v;
         }
       GC_HIP(hipMalloc((void**)&hc.d_tabh, bytes));
       GC_HIP(hipMemcpy(hc.d_tabh, t.data(), bytes, hipMemcpyHostToDevice));
+      GC_HIP(hipMalloc((void**)&hc.d_tabf, 2 * bytes));
+      GC_HIP(hipMemcpy(hc.d_tabf, tf.data(), 2 * bytes, hipMemcpyHostToDevice));
+      d.tabf = hc.d_tabf;
       d.tabh = hc.d_tabh;
       d.tabh_ap = ap;
       d.tabh_bytes = (int32_t)bytes;
@@ -513,10 +521,11 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
     const HostChannel& c = ctx->ch[k.channel];
     if (c.mult[0] != 1.0) continue;
     const double R = c.index_scale, sp = k.code_phase_step * R;
-    // band: the reference's rounding noise (a few ulp of the ramp) for the exact-compare kernel, or the float
+    const double maxv = std::fabs(k.rem_code_phase - k.el_spacing) * R + std::fabs(k.rem_code_phase + k.el_spacing) * R +
+                        (double)k.blksize * std::fabs(sp) + 1.0;
+    // band: the lane kernel's own window (corr_common.h, splits = 1 is the widest) plus 3 units, or the float
     // step quotient's resolution (eps_unit_steps samples of ramp) for the fast kernel
-    const double maxv = std::fabs(k.rem_code_phase) * R + std::fabs(k.el_spacing) * R + (double)k.blksize * std::fabs(sp) + 1.0;
-    const double eps = std::max(std::max(4e-12, 16.0 * 2.220446049250313e-16 * maxv), eps_unit_steps * sp);
+    const double eps = std::max((gcorr::gc_tie_window_units(maxv, k.blksize / 64 + 2) + 3.0) / 4294967296.0, eps_unit_steps * sp);
     const double starts[3] = {(k.rem_code_phase - k.el_spacing) * R, k.rem_code_phase * R,
                               (k.rem_code_phase + k.el_spacing) * R};
     bool clean = true;
@@ -534,6 +543,12 @@ int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b) {
   // at most one table transition per lane-chunk (8 or 16 samples), with a safety margin
   const double s = b.code_phase_step * c.index_scale * c.mult[0];
   return (15.0 * s < 0.995) ? 2 : (7.0 * s < 0.995) ? 1 : 0;
+}
+
+bool gc_block_shares_el_lane(const gc_context* ctx, const gc_block& b) {
+  const HostChannel& c = ctx->ch[b.channel];
+  const double v = 2.0 * b.el_spacing * c.index_scale * c.mult[0];
+  return v >= 1.0 && v <= 64.0 && v == std::floor(v);
 }
 
 bool gc_block_shares_el(const gc_context* ctx, const gc_block& b) {
@@ -594,6 +609,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
   int max_arms = 1;
   bool seen[GC_MAX_CHANNELS] = {false};
   gc_scope_reset(ctx);
+  ctx->scope_share_lane = true;
   for (int64_t i = 0; i < n; ++i) {
     const gc_block& k = b[i];
     if (k.channel < 0 || k.channel >= GC_MAX_CHANNELS || !ctx->ch[k.channel].configured) {
@@ -645,6 +661,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
     max_arms = std::max(max_arms, c.arms);
     if (*all_lowrate >= 0) *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
     if (all_share && !gc_block_shares_el(ctx, k)) *all_share = false;
+    if (ctx->scope_share_lane && !gc_block_shares_el_lane(ctx, k)) ctx->scope_share_lane = false;
   }
   return max_arms;
 }
@@ -674,6 +691,16 @@ static int choose_splits(gc_context* ctx, int64_t nblocks, const gc_block* b, in
   return std::max(1, std::min(s, 64));
 }
 
+// Lane kernel (corr_lane.hip): one wavefront per (block, split) item, 16 items per workgroup sharing a block
+// -> splits is a multiple of 16; aim at 16 wavefronts per CU, keep >= 8 samples per lane in every split.
+int gc_lane_splits(const gc_context* ctx, int64_t nblocks, int min_blksize, int cap) {
+  if (nblocks >= 2 * (int64_t)ctx->compute_units) return 1;  // one block per 16-wave workgroup, combined in LDS
+  int64_t s = (16 * (int64_t)ctx->compute_units + nblocks - 1) / nblocks;
+  s = std::min<int64_t>(s, std::max(1, min_blksize / 512));
+  s = (s + 15) / 16 * 16;
+  return (int)std::max<int64_t>(16, std::min<int64_t>(s, cap / 16 * 16));
+}
+
 extern "C" {
 
 int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* out) {
@@ -692,6 +719,11 @@ int gc_correlate(gc_context* ctx, int nblocks, const gc_block* blocks, double* o
   const int fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   int splits = choose_splits(ctx, nblocks, blocks, fast > 0 ? 64 : 256, fast == 2 ? 16 : 8);
   if (fast > 0 && gc_fast_table_mode(ctx) == 1 && splits > 1) splits = std::max(4, (splits / 4) * 4);  // WIDE kernel
+  if (fast == 0) {
+    int min_blk = 1 << 30;
+    for (int i = 0; i < nblocks; ++i) min_blk = std::min(min_blk, blocks[i].blksize);
+    splits = gc_lane_splits(ctx, nblocks, min_blk, 256);
+  }
   if ((rc = ensure((void**)&ctx->d_blocks, &ctx->d_blocks_cap, nblocks, sizeof(gc_block)))) return rc;
   if ((rc = ensure((void**)&ctx->d_out, &ctx->d_out_cap, (int64_t)nblocks * GC_OUT_STRIDE, sizeof(double)))) return rc;
   if (splits > 1 &&
@@ -723,6 +755,7 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   ctx->replay_scope[0] = ctx->max_lds_bytes;
   ctx->replay_scope[1] = ctx->max_stage_len;
   ctx->replay_scope[2] = ctx->max_arms_configured;
+  ctx->replay_share_lane = ctx->scope_share_lane;
   ctx->replay_fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
@@ -743,6 +776,8 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   }
   ctx->replay_nblocks = nblocks;
   ctx->replay_max_arms = max_arms;
+  ctx->replay_min_blksize = 1 << 30;
+  for (int64_t i = 0; i < nblocks; ++i) ctx->replay_min_blksize = std::min(ctx->replay_min_blksize, blocks[i].blksize);
   // channel pattern period: blocks[i].channel == blocks[i % P].channel (epoch-major replay lists)
   int period = 0;
   for (int64_t i = 1; i < nblocks && i <= GC_MAX_CHANNELS; ++i)
@@ -770,10 +805,20 @@ int gc_replay_launch(gc_context* ctx) {
   ctx->max_lds_bytes = ctx->replay_scope[0];
   ctx->max_stage_len = ctx->replay_scope[1];
   ctx->max_arms_configured = ctx->replay_scope[2];
+  ctx->scope_share_lane = ctx->replay_share_lane;
   int splits = 1;
-  const int wg_waves = ctx->replay_fast > 0 ? 1 : 4;
-  if (ctx->replay_nblocks * wg_waves < 8 * (int64_t)ctx->compute_units) {
+  if (ctx->replay_fast == 0) {
+    // lane kernel: periodic lists with enough blocks run one block per wavefront (bpw path of the launcher),
+    // everything else is split 16-fold or more
+    const bool periodic = ctx->replay_period > 0 && ctx->replay_nblocks >= 8 * (int64_t)ctx->compute_units;
+    if (!periodic) splits = gc_lane_splits(ctx, ctx->replay_nblocks, ctx->replay_min_blksize, 256);
+    if (splits > 1) {
+      int rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, ctx->replay_nblocks * splits * GC_OUT_STRIDE, sizeof(double));
+      if (rc) return rc;
+    }
+  } else if (ctx->replay_nblocks * (ctx->replay_fast > 0 ? 1 : 4) < 8 * (int64_t)ctx->compute_units) {
     // small replay sets: split blocks over several workgroups, scratch from d_partial
+    const int wg_waves = ctx->replay_fast > 0 ? 1 : 4;
     splits = (int)std::min<int64_t>(8, (8 * (int64_t)ctx->compute_units / wg_waves + ctx->replay_nblocks - 1) / ctx->replay_nblocks);
     if (ctx->replay_fast > 0 && gc_fast_table_mode(ctx) == 1 && splits > 1) splits = std::max(4, (splits / 4) * 4);
     int rc = ensure((void**)&ctx->d_partial, &ctx->d_partial_cap, ctx->replay_nblocks * splits * GC_OUT_STRIDE, sizeof(double));

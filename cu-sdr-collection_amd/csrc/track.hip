@@ -91,11 +91,16 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     probe.code_phase_step = init[c].code_freq * 1.001 / p->sampling_freq;
     fast_nominal = std::min(fast_nominal, gc_block_lowrate_level(ctx, probe));
   }
-  const int wg_threads = fast_nominal ? 64 : 256;
-  const int chunks_nominal = approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8);
-  int splits = (8 * ctx->compute_units * 64 / wg_threads + nch - 1) / nch;
-  splits = std::max(1, std::min(std::min(splits, 32), std::max(1, chunks_nominal / (2 * wg_threads))));
-  if (fast_nominal && gc_fast_table_mode(ctx) == 1) splits = std::max(4, std::min(32, (splits / 4) * 4));  // WIDE: 4 waves per workgroup
+  int splits;
+  if (fast_nominal) {
+    const int chunks_nominal = approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8);
+    splits = (8 * ctx->compute_units + nch - 1) / nch;
+    splits = std::max(1, std::min(std::min(splits, 32), std::max(1, chunks_nominal / (2 * 64))));
+    if (gc_fast_table_mode(ctx) == 1) splits = std::max(4, std::min(32, (splits / 4) * 4));  // WIDE: 4 waves per workgroup
+  } else {
+    splits = gc_lane_splits(ctx, nch, approx_chunks * 8, 32);  // lane kernel: one wave per item, 16 items per workgroup
+    if (splits == 1) splits = 16;  // the closed loop always goes through per-item records
+  }
   if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));
 
   // pinned, device-visible descriptor and result buffers
@@ -177,8 +182,10 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     for (int k = 0; k < nb && fast; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
     bool share = true;
     for (int k = 0; k < nb && share; ++k) share = gc_block_shares_el(ctx, blocks[k]);
+    ctx->scope_share_lane = true;
+    for (int k = 0; k < nb && ctx->scope_share_lane; ++k) ctx->scope_share_lane = gc_block_shares_el_lane(ctx, blocks[k]);
     const unsigned int tag = (unsigned int)(e + 1);
-    const bool polled = poll && fast != 0;
+    const bool polled = poll && fast >= 0;
     rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast, 0,
                               polled ? tag : 0u, share);
     if (rc) return rc;

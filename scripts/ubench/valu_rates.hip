@@ -23,6 +23,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     if (OP == 9) { REP16(asm volatile("v_sub_f32 %0, %8, %9 clamp\n v_sub_f32 %1, %8, %9 clamp\n v_sub_f32 %2, %8, %9 clamp\n v_sub_f32 %3, %8, %9 clamp\n v_sub_f32 %4, %8, %9 clamp\n v_sub_f32 %5, %8, %9 clamp\n v_sub_f32 %6, %8, %9 clamp\n v_sub_f32 %7, %8, %9 clamp" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(b), "v"(c));) }
     if (OP == 10) { REP16(asm volatile("v_cmp_gt_u32 vcc, %1, %2\n v_cndmask_b32 %0, %3, %4, vcc\n v_cmp_gt_u32 vcc, %2, %1\n v_cndmask_b32 %0, %4, %3, vcc\n v_cmp_gt_u32 vcc, %1, %2\n v_cndmask_b32 %0, %3, %4, vcc\n v_cmp_gt_u32 vcc, %2, %1\n v_cndmask_b32 %0, %4, %3, vcc" : "+v"(a0) : "v"(a1), "v"(a2), "v"(b), "v"(c) : "vcc");) }
     if (OP == 11) { REP16(asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));) }
+    if (OP == 12) { REP16(asm volatile("v_fma_mix_f32 %0, %8, %9, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %8, %9, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %9, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %8, %9, %4 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, %8, %9, %6 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+    if (OP == 13) { unsigned int* u = (unsigned int*)&a0; (void)u; REP16(asm volatile("v_add_co_u32_e32 %0, vcc, %4, %0\n v_addc_co_u32_e32 %1, vcc, %5, %1, vcc\n v_add_co_u32_e32 %2, vcc, %4, %2\n v_addc_co_u32_e32 %3, vcc, %5, %3, vcc\n v_add_co_u32_e32 %0, vcc, %4, %0\n v_addc_co_u32_e32 %1, vcc, %5, %1, vcc\n v_add_co_u32_e32 %2, vcc, %4, %2\n v_addc_co_u32_e32 %3, vcc, %5, %3, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");) }
+    if (OP == 14) { REP16(asm volatile("v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2" : "+v"(d0), "+v"(d1) : "v"(g));) }
+    if (OP == 15) { REP16(asm volatile("v_min3_u32 %0, %0, %8, %9\n v_max3_u32 %1, %1, %8, %9\n v_min3_u32 %2, %2, %8, %9\n v_max3_u32 %3, %3, %8, %9\n v_min3_u32 %4, %4, %8, %9\n v_max3_u32 %5, %5, %8, %9\n v_min3_u32 %6, %6, %8, %9\n v_max3_u32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+    if (OP == 16) { REP16(asm volatile("v_lshl_add_u32 %0, %8, 2, %9\n v_lshl_add_u32 %1, %8, 2, %9\n v_lshl_add_u32 %2, %8, 2, %9\n v_lshl_add_u32 %3, %8, 2, %9\n v_lshl_add_u32 %4, %8, 2, %9\n v_lshl_add_u32 %5, %8, 2, %9\n v_lshl_add_u32 %6, %8, 2, %9\n v_lshl_add_u32 %7, %8, 2, %9" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(b), "v"(c));) }
+    if (OP == 17) { REP16(asm volatile("v_add_u32 %0, %8, %0\n v_add_u32 %1, %8, %1\n v_add_u32 %2, %8, %2\n v_add_u32 %3, %8, %3\n v_add_u32 %4, %8, %4\n v_add_u32 %5, %8, %5\n v_add_u32 %6, %8, %6\n v_add_u32 %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));) }
+    if (OP == 18) { REP16(asm volatile("v_min_u32 %0, %8, %0\n v_max_u32 %1, %8, %1\n v_min_u32 %2, %8, %2\n v_max_u32 %3, %8, %3\n v_min_u32 %4, %8, %4\n v_max_u32 %5, %8, %5\n v_min_u32 %6, %8, %6\n v_max_u32 %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));) }
+    if (OP == 19) { REP16(asm volatile("v_alignbit_b32 %0, %8, %0, 7\n v_alignbit_b32 %1, %8, %1, 7\n v_alignbit_b32 %2, %8, %2, 7\n v_alignbit_b32 %3, %8, %3, 7\n v_bfe_u32 %4, %8, 3, 9\n v_bfe_u32 %5, %8, 3, 9\n v_and_or_b32 %6, %8, %9, %6\n v_and_or_b32 %7, %8, %9, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)d0 + (float)d1 + (float)g;
 }
@@ -55,5 +63,13 @@ int main() {
   run<5>("v_cvt_f32_i32_sdwa sext", d, 128);
   run<9>("v_sub_f32 clamp", d, 128);
   run<7>("v_fma_f64", d, 128);
+  run<12>("v_fma_mix_f32", d, 128);
+  run<13>("v_add_co+v_addc_co", d, 128);
+  run<14>("v_lshl_add_u64", d, 128);
+  run<15>("v_min3/max3_u32", d, 128);
+  run<16>("v_lshl_add_u32", d, 128);
+  run<17>("v_add_u32", d, 128);
+  run<18>("v_min/max_u32", d, 128);
+  run<19>("alignbit/bfe/and_or", d, 128);
   return 0;
 }
