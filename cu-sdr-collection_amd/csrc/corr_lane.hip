@@ -35,7 +35,10 @@ using namespace gcorr;
 namespace {
 
 constexpr int kLW = kLaneWaves;  // wavefronts per workgroup
-constexpr int kGRP = 4;          // samples per lane and group: the loads of the next group fly under this one
+#ifndef GC_LANE_GRP
+#define GC_LANE_GRP 4
+#endif
+constexpr int kGRP = GC_LANE_GRP;  // samples per lane and group: the loads of the next group fly under this one
 
 // TAB: 0 = f32 tables, 1 = f32 tables + shared early/late ramp, 2 = f16 tables
 template <int ARMS, int MODE, bool CL, int TAB>
@@ -352,10 +355,17 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
 #pragma unroll
       for (int j = 0; j < kGRP; ++j) xa[j] = load_sample(ptr + (long long)j * bps * 64);
     }
+    int pairs = 0;
     while (have) {
       have = group(xa, xb);
       if (!have) break;
       have = group(xb, xa);
+      // the phasor recurrence drifts by ~1 ulp per step: re-seed it from the exact float64 phase every
+      // 256 steps (matters for the 10-20 ms blocks of B1C / L2C, thousands of steps per lane)
+      if ((++pairs & 31) == 0) {
+        const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
+        sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+      }
     }
     // tail: fewer than kGRP samples left for this lane
     for (; i < iend; i += 64, ptr += (long long)bps * 64) {

@@ -3,6 +3,7 @@
 // library: every compute entry point launches HIP kernels.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "corr_common.h"
 
@@ -58,6 +59,7 @@ int gc_create(gc_context** out, int device_id) {
   GC_HIP(hipEventCreate(&ctx->ev_stop));
   GC_HIP(hipMalloc(&ctx->d_channels, sizeof(DevChannel) * GC_MAX_CHANNELS));
   GC_HIP(hipMemset(ctx->d_channels, 0, sizeof(DevChannel) * GC_MAX_CHANNELS));
+  if (const char* e = std::getenv("GC_FORCE_GENERIC")) ctx->force_generic = std::atoi(e) != 0;  // tuning: lane kernel everywhere
   *out = ctx;
   return GC_OK;
 }

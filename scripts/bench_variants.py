@@ -12,6 +12,8 @@ from cu_sdr_collection_amd.settings import initSettings_GAL_E1C, initSettings_GP
 def run(name, S, signal, code_fn, code_rate, code_len, carrier_ratio, bit_periods, nch, seconds, prns):
     fs = S.samplingFreq
     eng = P.Engine(0)
+    if "--generic" in sys.argv:
+        eng.force_generic_kernel(True)  # lane kernel (corr_lane.hip) even where the fast kernels apply
     rng = np.random.default_rng(1)
     sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, fs * S.intTime)),
                             carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=48.0) for p in prns[:nch]]
@@ -59,6 +61,7 @@ def run(name, S, signal, code_fn, code_rate, code_len, carrier_ratio, bit_period
     eng.close()
 
 S = initSettings_GAL_E1C()
-run("config3: GAL E1 B+C, BOC(1,1), 8 ch", S, "GAL_E1C", P.codes.generateE1Bcode, 2 * 1.023e6, 8184, 1540.0, 1, 8, 20.0, list(range(1, 51)))
+if "--l5only" not in sys.argv:
+  run("config3: GAL E1 B+C, BOC(1,1), 8 ch", S, "GAL_E1C", P.codes.generateE1Bcode, 2 * 1.023e6, 8184, 1540.0, 1, 8, 20.0, list(range(1, 51)))
 S = initSettings_GPS_L5C(); S.pilotTRKflag = 1
 run("config4 (L5 half): GPS L5 I5+Q5, 8 ch", S, "GPS_L5C", P.codes.generateL5Icode, 10.23e6, 10230, 1150.0, 10, 8, 10.0, list(range(1, 38)))
