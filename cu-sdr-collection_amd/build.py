@@ -24,6 +24,12 @@ LIBS = {
 HEADERS = ["gc_internal.h", "corr_common.h", os.path.join("..", "..", "include", "gnsscorr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
          "-Wno-unused-function", "-fno-slp-vectorize"]
+# The correlator's exact paths restate the reference's float64 arithmetic operation by operation
+# (fl(a + fl(i*d)), MATLAB's two-sided colon).  HIP's __dadd_rn / __dmul_rn are plain operators defined in a
+# header compiled under the default -ffp-contract=fast, so the backend fuses them into v_fma_f64 (one rounding
+# instead of two: wrong table index at exact ties).  These translation units therefore forbid contraction;
+# wanted FMAs are written as fmaf() / fma().
+NO_CONTRACT = {"gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_lane.hip", "track.hip"}
 
 
 def _hipcc() -> str:
@@ -61,7 +67,8 @@ def build(force: bool = False, verbose: bool = True) -> None:
             if not force and not _stale(obj, [s] + [os.path.join(CSRC, h) for h in HEADERS]):
                 jobs.append((obj, None, None))
                 continue
-            cmd = [_hipcc(), *cflags, "-c", s, "-o", obj]
+            extra = ["-ffp-contract=off"] if os.path.basename(s) in NO_CONTRACT else []
+            cmd = [_hipcc(), *cflags, *extra, "-c", s, "-o", obj]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             jobs.append((obj, cmd, subprocess.Popen(cmd, cwd=CSRC)))

@@ -4,6 +4,9 @@
 
 #include "gc_internal.h"
 
+// NOTE: the correlator translation units are compiled with -ffp-contract=off (build.py explains why): write
+// wanted FMAs as fmaf() / fma().
+
 namespace gcorr {
 
 constexpr int kWG = 256;

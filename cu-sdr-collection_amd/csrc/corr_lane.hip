@@ -151,7 +151,12 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
   const int per = (((N + nsplit - 1) / nsplit) + 63) / 64 * 64;
   const int ibeg = split * per;
   const int iend = min(N, ibeg + per);
+#ifdef GC_LANE_FORCE_EXACT
+  const unsigned int tie_e = 0x7fffffffu;
+  (void)gc_tie_window_units(0.0, 0);
+#else
   const unsigned int tie_e = gc_tie_window_units((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fabs(M), (per >> 6) + 1);
+#endif
 
   // Per-sample ramp step sp*M as a 64.64 fixed-point number (exact: a double has at most 64 fractional bits
   // here); one step of a lane = 64 samples = that number << 6, rounded to 32 fractional bits for Q.
@@ -234,8 +239,8 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
       b = Fmt<MODE>::swap ? x0 : x1;
     };
     auto rotate_w = [&]() {
-      const float nwc = wc * rotC - ws * rotS;
-      const float nws = wc * rotS + ws * rotC;
+      const float nwc = fmaf(wc, rotC, -(ws * rotS));
+      const float nws = fmaf(wc, rotS, ws * rotC);
       wc = nwc;
       ws = nws;
     };

@@ -517,9 +517,11 @@ int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps) 
 
 // Marks tie-free blocks (bit 0 of `reserved`) for a launch whose kernel needs the band `eps_chips`.
 void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps) {
+  static const bool off = std::getenv("GC_NO_TIE_MARK") != nullptr;  // debugging aid: every block takes the in-kernel test
   for (int64_t i = 0; i < n; ++i) {
     gc_block& k = b[i];
     k.reserved &= ~1;
+    if (off) continue;
     const HostChannel& c = ctx->ch[k.channel];
     if (c.mult[0] != 1.0) continue;
     const double R = c.index_scale, sp = k.code_phase_step * R;

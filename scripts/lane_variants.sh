@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../cu-sdr-collection_amd"
 python -m cu_sdr_collection_amd.build >/dev/null 2>&1 || (cd .. && python -m cu_sdr_collection_amd.build >/dev/null)
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $flags -c csrc/corr_lane.hip -o build/corr_lane_$name.o &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize -ffp-contract=off $flags -c csrc/corr_lane.hip -o build/corr_lane_$name.o &
 done
 wait
 for spec in "$@"; do

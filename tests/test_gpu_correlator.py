@@ -201,3 +201,30 @@ def test_fast_and_generic_kernels_agree_with_oracle(engine, l1ca_scene):
         sc = _scale(iq, d)
         assert np.abs(fast[k] - ref).max() < TOL * sc, ("fast", k, d)
         assert np.abs(gen[k] - ref).max() < TOL * sc, ("generic", k, d)
+
+
+def test_tie_dense_blocks_use_the_references_two_roundings(engine, l1ca_scene):
+    """Rational code steps (0.05, 0.1, 0.2 chip per sample) with rem = 0.1 and early-late spacing 0.3 put a
+    sample of the early or late ramp within 1e-16 chip of a table edge every few samples.  There the reference's
+    fl(a + fl(i*d)) (and the backwards half of MATLAB's colon, tracking.m:252-270) decides the index, and a fused
+    multiply-add gives a DIFFERENT answer (one rounding instead of two) — the regression this test pins: the
+    exact paths must not be compiled with floating-point contraction.  All three kernels: 16- and 8-sample
+    transition-mask kernels and the lane kernel."""
+    S, sats, iq = l1ca_scene
+    engine.load_if(iq, fs=S.samplingFreq)
+    tab = O.pad_code(O.generate_ca_code(sats[0].prn))
+    engine.set_channel(0, [tab.astype(np.int8)])
+    descs = []
+    for step in (0.05, 0.1, 0.2):
+        for d in (0.3, 0.5, 0.25):
+            for n in (64, 1000, 5000):
+                descs.append(dict(channel=0, n=n, s0=777 + 13 * len(descs), rem=0.1, step=step, d=d, f=2.2e4, phi=0.4))
+    for generic in (False, True):
+        engine.force_generic_kernel(generic)
+        try:
+            for d in descs:      # one launch per block: the step decides which kernel a launch takes
+                got = engine.correlate(_blocks(engine, [d]))[0, 0]
+                ref = _oracle(iq, d, tab)
+                assert np.abs(got - ref).max() < TOL * _scale(iq, d), (generic, d, got, ref)
+        finally:
+            engine.force_generic_kernel(False)

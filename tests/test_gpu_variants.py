@@ -161,3 +161,62 @@ def test_closed_loop_with_int16_and_qi_records(engine, l1ca_scene):
         for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L"):
             assert np.max(np.abs(other[f] - base[f])) < 1e-6 * scale, f
         assert np.max(np.abs(other["carrFreq"] - base["carrFreq"])) < 1e-4
+
+
+def test_lane_kernel_work_decompositions(engine):
+    """corr_lane.hip's three work decompositions against the oracle at a 10.23-Mcps rate (0.57 chip per
+    sample: several table entries per 8 samples, so the lane kernel is the one that runs): (A) periodic replay
+    list, one block per wavefront; (B) few blocks, split 16-fold and more with partial sums; (C) a long list of
+    unrelated blocks, one per workgroup, combined in LDS.  Two channels with different two-arm tables; one of
+    them long enough (2 x 16 384 entries) that the tables are staged as f16 instead of f32."""
+    fs = 18e6
+    n_if = 400000
+    iq = _noise_iq(n_if, 11)
+    rng = np.random.default_rng(12)
+    engine.load_if(iq, fs=fs)
+    L = {6: 10230.0, 7: 16382.0}
+    tabs = {}
+    for ch in (6, 7):
+        tabs[ch] = [O.pad_code(rng.choice([-1.0, 1.0], size=int(L[ch]))) for _ in range(2)]
+        engine.set_channel(ch, [t.astype(np.int8) for t in tabs[ch]])
+    step = 10.23e6 / fs
+
+    def make(nb, chan_of, nmax=None):
+        b = engine.make_blocks(nb)
+        descs = []
+        for k in range(nb):
+            ch = chan_of(k)
+            rem = float(rng.uniform(0, step)) if k % 5 else 0.0   # rem = 0: samples exactly on table edges
+            st = step * (1 + float(rng.uniform(-2e-6, 2e-6))) if k % 5 else step
+            n = O.blksize_for(L[ch], rem, st)
+            if nmax:
+                n = min(n, nmax)
+            d = dict(channel=ch, n=n, s0=int(rng.integers(0, n_if - n)), rem=rem, step=st, d=0.5 if k % 3 else 0.3,
+                     f=float(rng.uniform(-5e3, 5e3)) + 2.0e6 * (k % 2), phi=float(rng.uniform(-3, 3)))
+            descs.append(d)
+            _block(b, k, **d)
+        return b, descs
+
+    def check(got, descs, idx):
+        for k in idx:
+            d = descs[k]
+            ref, _, _ = O.correlate_block(O.raw_from_if(iq, d["s0"], d["n"]), tabs[d["channel"]], d["rem"], d["step"],
+                                          d["d"], d["f"], d["phi"], fs, L[d["channel"]])
+            sc = np.sum(np.abs(iq[2 * d["s0"]:2 * (d["s0"] + d["n"])].astype(np.float64)))
+            assert np.max(np.abs(got[k, :2] - ref)) < TOL * sc, (k, d)
+            assert not got[k, 2].any()
+
+    # (B) three blocks: split over many wavefronts
+    b, descs = make(3, lambda k: 6 + (k & 1))
+    check(engine.correlate(b), descs, range(3))
+    # (C) 700 unrelated blocks (short ones, to keep the oracle quick): one workgroup each
+    b, descs = make(700, lambda k: 6 + ((k * 7919) >> 3 & 1), nmax=3000)
+    got = engine.correlate(b)
+    check(got, descs, list(range(0, 700, 37)) + [699])
+    # (A) periodic replay list: channels 6, 7, 6, 7, ... over 1100 epochs
+    b, descs = make(2200, lambda k: 6 + (k & 1), nmax=2500)
+    engine.replay_prepare(b)
+    engine.replay_launch()
+    got = engine.replay_fetch()
+    check(got, descs, list(range(0, 2200, 97)) + [2198, 2199])
+    assert np.max(np.abs(got - engine.correlate(b))) < 0.2   # decomposition (C) of the same list: float sums only reorder
