@@ -196,3 +196,259 @@ def generateCAcode53(PRN: int) -> np.ndarray:
         r1 = [f1] + r1[:10]
         r2 = [f2] + r2[:10]
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# ICD constant tables (register initial states, advances, Weil parameters): data/icd_tables.npz,
+# extracted once by tests/golden/make_icd_tables.py
+# ---------------------------------------------------------------------------------------------
+_ICD = None
+
+
+def _icd(name: str) -> np.ndarray:
+    global _ICD
+    if _ICD is None:
+        import os
+        _ICD = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "icd_tables.npz")))
+    return _ICD[name]
+
+
+def _prn_row(table: np.ndarray, PRN: int, what: str):
+    if not 1 <= PRN <= table.shape[0]:
+        raise ValueError(f"{what} PRN {PRN} out of range 1..{table.shape[0]}")
+    return table[PRN - 1]
+
+
+def _fib_lfsr(nbits: int, taps, state: int, n_out: int, reset_after: int | None = None, reset_state: int | None = None,
+              skip: int = 0) -> np.ndarray:
+    """Fibonacci LFSR in integer form, bit i = stage i+1, feedback = XOR of `taps` (1-based stages) shifted into
+    stage 1, output = stage nbits.  reset_after: reload all ones after that many output chips (BDS B2a register 1);
+    reset_state: reload all ones instead of shifting when the register equals it (BDS B3I G1)."""
+    full = (1 << nbits) - 1
+    mask = sum(1 << (t - 1) for t in taps)
+    reg = state
+    for _ in range(skip):
+        reg = ((reg << 1) & full) | (bin(reg & mask).count("1") & 1)
+    out = np.empty(n_out, dtype=np.uint8)
+    for i in range(n_out):
+        out[i] = reg >> (nbits - 1)
+        if reset_state is not None and reg == reset_state:
+            reg = full
+        else:
+            reg = ((reg << 1) & full) | (bin(reg & mask).count("1") & 1)
+        if reset_after is not None and i + 1 == reset_after:
+            reg = full
+    return out
+
+
+def _stages_to_int(bits) -> int:
+    """bits[j] = logic value of stage j+1  ->  integer with bit j = stage j+1."""
+    return int(sum(int(b) << j for j, b in enumerate(bits)))
+
+
+# ---------------------------------------------------------------------------------------------
+# BDS B2a data / pilot (BDS/B2a/include/generateB2aDataCode.m:109-138, generateB2aPilotCode.m:104-138)
+# ---------------------------------------------------------------------------------------------
+def _b2a(PRN: int, taps1, taps2, g2_table: str) -> np.ndarray:
+    g2 = _stages_to_int(_prn_row(_icd(g2_table), PRN, "BDS B2a"))
+    r1 = _fib_lfsr(13, taps1, 0x1FFF, 10230, reset_after=8190)   # register 1 restarts from all ones after chip 8190
+    r2 = _fib_lfsr(13, taps2, g2, 10230)
+    return (1 - 2 * (r1 ^ r2).astype(np.int8)).astype(np.int8)
+
+
+def generateB2aDataCode(PRN: int) -> np.ndarray:
+    """BDS B2a data-channel code, 10230 chips int8 +-1 (logic 1 -> -1)."""
+    return _b2a(PRN, (1, 5, 11, 13), (3, 5, 9, 11, 12, 13), "b2a_data_g2")
+
+
+def generateB2aPilotCode(PRN: int) -> np.ndarray:
+    """BDS B2a pilot-channel code, 10230 chips int8 +-1."""
+    return _b2a(PRN, (3, 6, 7, 13), (1, 5, 7, 8, 12, 13), "b2a_pilot_g2")
+
+
+# ---------------------------------------------------------------------------------------------
+# BDS B3I (BDS/B3I/include/generateB3Icode.m:39-110)
+# ---------------------------------------------------------------------------------------------
+_B3I_G1 = None
+
+
+def generateB3Icode(PRN: int) -> np.ndarray:
+    """BDS B3I ranging code, 10230 chips int8 +-1: G1 (taps 1,3,4,13; restarts when it reaches 1111111111100,
+    period 8190) times G2 (taps 1,5,6,7,9,10,12,13) pre-advanced by the PRN's table entry."""
+    global _B3I_G1
+    adv = int(_prn_row(_icd("b3i_advance"), PRN, "BDS B3I"))
+    if _B3I_G1 is None:
+        # reset_state [-1 x11, +1, +1] in the reference's +-1 form = stages 1..11 logic 1, stages 12, 13 logic 0
+        _B3I_G1 = _fib_lfsr(13, (1, 3, 4, 13), 0x1FFF, 10230, reset_state=0x07FF)
+    g2 = _fib_lfsr(13, (1, 5, 6, 7, 9, 10, 12, 13), 0x1FFF, 10230, skip=adv)
+    return (1 - 2 * (_B3I_G1 ^ g2).astype(np.int8)).astype(np.int8)
+
+
+# ---------------------------------------------------------------------------------------------
+# Galileo E5a-I/Q, E5b-I/Q primary codes and the tiered E5-I codes
+# (GAL/GAL_E5a/include/generateE5aIcode.m:36-124, generateE5aQcode.m, generateE5aQ_secondary.m; GAL_E5b twins)
+# ---------------------------------------------------------------------------------------------
+def _e5_primary(sig: str, PRN: int) -> np.ndarray:
+    """Two 14-stage registers written MSB-first: output = first element, feedback = XOR of the elements selected
+    by the first 14 bits of the octal polynomial, shifted in at the last element.  Register 1 starts at all ones,
+    register 2 at the PRN's start value (Galileo OS SIS ICD tables 15 / 17)."""
+    start = int(_prn_row(_icd(sig + "_start_octal"), PRN, "Galileo " + sig))
+    polys = _icd(sig + "_poly_octal")
+    out = []
+    for poly, reg in ((int(polys[0]), 0x3FFF), (int(polys[1]), start)):
+        nb = poly.bit_length()                       # dec2bin drops leading zeros
+        sel = (poly >> (nb - 14)) & 0x3FFF           # first 14 binary digits, digit 1 = element 1 = bit 13 here
+        bits = np.empty(10230, dtype=np.uint8)
+        for i in range(10230):
+            bits[i] = (reg >> 13) & (sel >> 13)      # RegOut(1) = Register(1) * taps(1)
+            fb = bin(reg & sel).count("1") & 1
+            reg = ((reg << 1) & 0x3FFF) | fb
+        out.append(bits)
+    return (1 - 2 * (out[0] ^ out[1]).astype(np.int8)).astype(np.int8)
+
+
+_E5I_SECONDARY = {"e5ai": (20, 0x842E9), "e5bi": (4, 0xE)}   # CS20_1 / CS4_1, Galileo OS SIS ICD table 18
+
+
+def _e5_i(sig: str, PRN: int, flag: int) -> np.ndarray:
+    prim = _e5_primary(sig, PRN)
+    if flag == 1:
+        return prim
+    n, word = _E5I_SECONDARY[sig]
+    sec = np.array([1 - 2 * ((word >> (n - 1 - k)) & 1) for k in range(n)], dtype=np.int8)
+    return (sec[:, None] * prim[None, :]).reshape(-1)
+
+
+def generateE5aIcode(PRN: int, flag: int = 1) -> np.ndarray:
+    """flag 1: 10230-chip primary code; flag 2: the 20-ms tiered code (primary x CS20_1 = 842E9)."""
+    return _e5_i("e5ai", PRN, flag)
+
+
+def generateE5bIcode(PRN: int, flag: int = 1) -> np.ndarray:
+    """flag 1: primary; flag 2: the 4-ms tiered code (primary x CS4_1 = E)."""
+    return _e5_i("e5bi", PRN, flag)
+
+
+def _e5_secondary100(sig: str, PRN: int) -> np.ndarray:
+    hexstr = str(_prn_row(_icd(sig + "_secondary_hex"), PRN, "Galileo " + sig))
+    bits = [(int(hexstr[:13], 16) >> (51 - k)) & 1 for k in range(52)] + [(int(hexstr[13:], 16) >> (47 - k)) & 1 for k in range(48)]
+    return (1 - 2 * np.array(bits, dtype=np.int8)).astype(np.int8)
+
+
+def _e5_q(sig: str, PRN: int, flag: int) -> np.ndarray:
+    prim = _e5_primary(sig, PRN)
+    if flag == 1:
+        return prim
+    return (_e5_secondary100(sig, PRN)[:, None] * prim[None, :]).reshape(-1)
+
+
+def generateE5aQcode(PRN: int, flag: int = 1) -> np.ndarray:
+    return _e5_q("e5aq", PRN, flag)
+
+
+def generateE5bQcode(PRN: int, flag: int = 1) -> np.ndarray:
+    return _e5_q("e5bq", PRN, flag)
+
+
+def generateE5aQ_secondary(PRN: int) -> np.ndarray:
+    """100-chip secondary code CS100 of E5a-Q as +-1."""
+    return _e5_secondary100("e5aq", PRN)
+
+
+def generateE5bQ_secondary(PRN: int) -> np.ndarray:
+    return _e5_secondary100("e5bq", PRN)
+
+
+# ---------------------------------------------------------------------------------------------
+# GPS L2C CM / CL (GPS/GPS_L2C/include/generateCMcode.m:39-111, generateCLcode.m): 27-stage modular register,
+# returned RZ-interleaved with zeros (CM in the even, CL in the odd positions of the doubled-rate code)
+# ---------------------------------------------------------------------------------------------
+_L2C_XOR = (4, 7, 9, 12, 15, 17, 19, 22, 23, 24, 25)
+
+
+def _l2c_index(PRN: int) -> int:
+    if 1 <= PRN <= 63:
+        return PRN - 1
+    if 159 <= PRN <= 210:
+        return PRN - 96
+    raise ValueError(f"GPS L2C PRN {PRN} does not exist")
+
+
+def _l2c_chips(state: int, n: int) -> np.ndarray:
+    """state: the octal initial state read as a 27-digit binary number, digit 1 = stage 1 ... digit 27 = output."""
+    xor_mask = sum(1 << (27 - p) for p in _L2C_XOR)   # digit p <-> bit 27 - p
+    out = np.empty(n, dtype=np.uint8)
+    reg = state
+    for i in range(n):
+        o = reg & 1                                   # digit 27
+        out[i] = o
+        reg = (reg >> 1) | (o << 26)                  # rotate: the output re-enters at digit 1
+        if o:
+            reg ^= xor_mask
+    return out
+
+
+def generateCMcode(PRN: int, codeLength: int = 10230) -> np.ndarray:
+    """L2 CM code as the reference returns it: 2*codeLength entries [chip, 0, chip, 0, ...], chips +-1."""
+    chips = 1 - 2 * _l2c_chips(int(_icd("l2cm_init_octal")[_l2c_index(PRN)]), codeLength).astype(np.int8)
+    out = np.zeros(2 * codeLength, dtype=np.int8)
+    out[0::2] = chips
+    return out
+
+
+def generateCLcode(PRN: int, CLCodeLength: int = 767250) -> np.ndarray:
+    """L2 CL code: 2*CLCodeLength entries [0, chip, 0, chip, ...]."""
+    chips = 1 - 2 * _l2c_chips(int(_icd("l2cl_init_octal")[_l2c_index(PRN)]), CLCodeLength).astype(np.int8)
+    out = np.zeros(2 * CLCodeLength, dtype=np.int8)
+    out[1::2] = chips
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# BDS B1C Weil codes (BDS/B1C/include/generateDataBOC11.m:43-91, generatePilotBOC11.m, generatePilotBOC61.m:44-96,
+# generate2ndCode.m, JacobiSymbol.m)
+# ---------------------------------------------------------------------------------------------
+_LEGENDRE = {}
+
+
+def _legendre_bits(N: int) -> np.ndarray:
+    """L[0] = 0, L[i] = 1 if i is a quadratic residue mod the prime N else 0 (Jacobi symbol -1 -> 0)."""
+    if N not in _LEGENDRE:
+        L = np.zeros(N, dtype=np.uint8)
+        L[(np.arange(1, N, dtype=np.int64) ** 2) % N] = 1
+        _LEGENDRE[N] = L
+    return _LEGENDRE[N]
+
+
+def _weil(N: int, w: int, p: int, n: int) -> np.ndarray:
+    L = _legendre_bits(N)
+    k = (np.arange(n, dtype=np.int64) + p - 1) % N
+    return (1 - 2 * (L[k] ^ L[(k + w) % N]).astype(np.int8)).astype(np.int8)
+
+
+def generateB1Cprimary(PRN: int, component: str) -> np.ndarray:
+    w, p = _prn_row(_icd("b1c_data_wp" if component == "data" else "b1c_pilot_wp"), PRN, "BDS B1C")
+    return _weil(10243, int(w), int(p), 10230)
+
+
+def generateDataBOC11(PRN: int) -> np.ndarray:
+    """B1C data component with the BOC(1,1) sub-carrier baked in: 20460 half-chips, chip x [-1, +1]."""
+    c = generateB1Cprimary(PRN, "data")
+    return (c[:, None] * np.array([-1, 1], dtype=np.int8)[None, :]).reshape(-1)
+
+
+def generatePilotBOC11(PRN: int) -> np.ndarray:
+    c = generateB1Cprimary(PRN, "pilot")
+    return (c[:, None] * np.array([-1, 1], dtype=np.int8)[None, :]).reshape(-1)
+
+
+def generatePilotBOC61(PRN: int) -> np.ndarray:
+    """B1C pilot BOC(6,1) component: 122760 entries, chip x (-1)^ii, ii = 1..12."""
+    c = generateB1Cprimary(PRN, "pilot")
+    return (c[:, None] * np.tile(np.array([-1, 1], dtype=np.int8), 6)[None, :]).reshape(-1)
+
+
+def generatePilot2ndCodes(PRN: int) -> np.ndarray:
+    """1800-chip B1C pilot secondary (overlay) code: Weil code of length 3607."""
+    w, p = _prn_row(_icd("b1c_secondary_wp"), PRN, "BDS B1C")
+    return _weil(3607, int(w), int(p), 1800)

@@ -162,13 +162,14 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
         inits.append(L.gc_channel_init(channel=i, prn=ch.PRN, acquired_freq=ch.acquiredFreq,
                                        code_freq=cf, code_phase=int(ch.codePhase)))
     fields, done, status = fid.track(p, inits)
-    vsm = int(settings.CNo.VSMinterval)
+    cno = getattr(settings, "CNo", None)   # B2a / B1C estimate C/N0 with Calc_CNo_PLD instead (not on the hot path)
+    vsm = int(cno.VSMinterval) if cno is not None else 0
     for k, i in enumerate(active):
         tr = results[i]
         for f in _REC_FIELDS + (_PILOT_FIELDS if pilot else ()):
             getattr(tr, f)[:] = fields[f][k]
         n_done = int(done[k])
-        for loop in range(vsm, n_done + 1, vsm):                                      # tracking.m:351-358
+        for loop in (range(vsm, n_done + 1, vsm) if vsm else ()):                     # tracking.m:351-358
             tr.CNo.VSMValue.append(CNoVSM(tr.I_P[loop - vsm:loop], tr.Q_P[loop - vsm:loop], settings.CNo.accTime))
             tr.CNo.VSMIndex.append(loop)
         if n_done == n_ep:

@@ -122,3 +122,51 @@ def initSettings_BDS_B1I() -> SimpleNamespace:
     s.intTime = 0.001                # :107
     s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=400)  # :141-143
     return s
+
+
+def _ten23(s, **kw):
+    """Common part of the 10.23-Mcps, 10230-chip, 1-ms packages (B2a, B3I, E5a, E5b)."""
+    s.IF = 20e3
+    s.samplingFreq = 18e6
+    s.codeLength = 10230
+    s.codeFreqBasis = 10.23e6
+    s.acqSearchBand = 5000
+    s.dllDampingRatio = 0.7
+    s.dllCorrelatorSpacing = 0.5
+    s.pllDampingRatio = 0.7
+    s.intTime = 0.001
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def initSettings_BDS_B2a() -> SimpleNamespace:
+    """BDS B2a defaults (BDS/B2a/initSettings.m:43-127)."""
+    return _ten23(initSettings(), numberOfChannels=12, acqSatelliteList=list(range(19, 31)) + list(range(32, 47)) + [59, 60],  # :45,73
+                  acqNonCohTime=15, acqThreshold=5, acqSearchStep=500,          # :78-82
+                  dllNoiseBandwidth=2, pllNoiseBandwidth=15, pilotTRKflag=0,    # :90,94,98
+                  CNoInterval=200, carrFreqBasis=1176.45e6)  # :125 (B2a estimates C/N0 with Calc_CNo_PLD), :127
+
+
+def initSettings_BDS_B3I() -> SimpleNamespace:
+    """BDS B3I defaults (BDS/B3I/initSettings.m:43-132)."""
+    return _ten23(initSettings(), numberOfChannels=15, acqSatelliteList=list(range(1, 64)),      # :45,76
+                  acqNonCohTime=10, acqThreshold=3, acqSearchStep=500,          # :80-84
+                  dllNoiseBandwidth=2, pllNoiseBandwidth=15,                    # :92,96
+                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=40), carrFreqBasis=1268.520e6)  # :127-132
+
+
+def initSettings_GAL_E5a() -> SimpleNamespace:
+    """Galileo E5a defaults (GAL/GAL_E5a/initSettings.m:6-104)."""
+    return _ten23(initSettings(), numberOfChannels=12, acqSatelliteList=list(range(1, 37)),      # :9,44
+                  acqNonCohTime=15, acqThreshold=4.5, acqSearchStep=500,        # :49-53
+                  dllNoiseBandwidth=1.5, pllNoiseBandwidth=15, pilotTRKflag=1,  # :61,66,70
+                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=100), carrFreqBasis=1176.45e6)  # :100-104
+
+
+def initSettings_GAL_E5b() -> SimpleNamespace:
+    """Galileo E5b defaults (GAL/GAL_E5b/initSettings.m:44-144; the second dll block :103-105 wins)."""
+    return _ten23(initSettings(), numberOfChannels=12, acqSatelliteList=list(range(1, 37)),      # :47,83
+                  acqNonCohTime=15, acqThreshold=4.5, acqSearchStep=60,         # :88-92
+                  dllNoiseBandwidth=1.5, pllNoiseBandwidth=25, pilotTRKflag=1,  # :104,108,112
+                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=100), carrFreqBasis=1207.14e6)  # :140-144

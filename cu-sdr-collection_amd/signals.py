@@ -56,6 +56,32 @@ def _b1i_tables(prn, settings):
     return [codes.padded_table(codes.generateCAcode53(prn))]                  # BDS/B1I tracking.m:144-145
 
 
+def _b2a_tables(prn, settings):
+    t = [codes.padded_table(codes.generateB2aDataCode(prn))]                 # BDS/B2a tracking.m:156-158
+    if getattr(settings, "pilotTRKflag", 0) == 1:
+        t.append(codes.padded_table(codes.generateB2aPilotCode(prn)))         # :160-165
+    return t
+
+
+def _b3i_tables(prn, settings):
+    return [codes.padded_table(codes.generateB3Icode(prn))]                  # BDS/B3I tracking.m:150-152
+
+
+def _e5_tables(i_fn, q_fn):
+    def tables(prn, settings):
+        L = int(settings.codeLength)
+        tiered = i_fn(prn, 2)
+        # GAL_E5a tracking.m:148-150: [E5aICode(codeLength) E5aICode E5aICode(1)] of the TIERED code, of which the
+        # ramps only ever reach the first codeLength + 2 entries (entry L+1 is tiered chip L+1 = primary chip 1 times
+        # the SECOND secondary chip: not the periodic wrap of the first period)
+        data = np.concatenate([tiered[L - 1:L], tiered[:L + 1]]).astype(np.int8)
+        t = [data]
+        if getattr(settings, "pilotTRKflag", 0) == 1:
+            t.append(codes.padded_table(q_fn(prn, 1)))                        # :152-156, primary code only
+        return t
+    return tables
+
+
 SIGNALS = {
     "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False),
     # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
@@ -65,6 +91,12 @@ SIGNALS = {
     "GLO_GL1": SignalSpec("GLO_GL1", _glo_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False),
     "BDS_B1I": SignalSpec("BDS_B1I", _b1i_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False),
     "GPS_L5C": SignalSpec("GPS_L5C", _l5_tables, 1.0, L.GC_PLL_3_STATE, "a", 1, True),
+    # the 10.23-Mcps family shares GPS L5's loop closure (pilot rotated by -pi/2, discriminators averaged) and
+    # differs in codes, loop-coefficient variant (Common/calcLoopCoefCarr.m of each package) and bandwidths
+    "BDS_B2a": SignalSpec("BDS_B2a", _b2a_tables, 1.0, L.GC_PLL_3_STATE, "a", 1, True),
+    "BDS_B3I": SignalSpec("BDS_B3I", _b3i_tables, 1.0, L.GC_PLL_3_STATE, "b", 0, True),
+    "GAL_E5a": SignalSpec("GAL_E5a", _e5_tables(codes.generateE5aIcode, codes.generateE5aQcode), 1.0, L.GC_PLL_3_STATE, "a", 1, True),
+    "GAL_E5b": SignalSpec("GAL_E5b", _e5_tables(codes.generateE5bIcode, codes.generateE5bQcode), 1.0, L.GC_PLL_3_STATE, "b", 1, True),
 }
 
 

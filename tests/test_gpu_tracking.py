@@ -248,3 +248,90 @@ def test_beidou_b1i(engine):
     S = initSettings_BDS_B1I()
     _single_arm_case(engine, S, "BDS_B1I", P.codes.generateCAcode53, S.codeFreqBasis, 2046, 763.0 * 2,
                      O.generate_b1i_code, [7, 23], [S.IF, S.IF], L.GC_IQ)
+
+
+def _ten23_case(engine, S, signal, data_fn, pilot_fn, oracle_tables, coef_variant, carrier_ratio, prns, seed):
+    """Closed loop of a 10.23-Mcps package (lane kernel) against the oracle's generic tracking restatement."""
+    import cu_sdr_collection_amd as P
+    fs = S.samplingFreq
+    S.msToProcess = 50
+    S.numberOfChannels = len(prns)
+    pilot = getattr(S, "pilotTRKflag", 0) == 1
+    rng = np.random.default_rng(seed)
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 18000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0) for p in prns]
+    n = int(0.054 * fs)
+    iq = P.synth.generate_if(sats, n, fs, S.IF, data_fn, S.codeFreqBasis, 10230, seed=seed + 1, carrier_ratio=carrier_ratio,
+                             bit_periods=10, pilot_fn=pilot_fn if pilot else None, pilot_phase=np.pi / 2)
+    ch = []
+    for s in sats:
+        f = S.IF + s.doppler + 2.0
+        ch.append(SimpleNamespace(PRN=s.prn, acquiredFreq=f, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1,
+                                  codeFreq=S.codeFreqBasis + (f - S.IF) / S.carrFreqBasis * S.codeFreqBasis))  # preRun.m:69-71
+    engine.load_if(iq, fs=fs)
+    tr, _ = P.tracking(engine, ch, S, signal=signal)
+    spec = SimpleNamespace(tables=oracle_tables, r=1.0, pll="3state", coef_variant=coef_variant,
+                           pilot_combine=1 if pilot else 0, code_freq_from_channel=True)
+    ref = O.tracking_generic(iq, ch, S, spec)
+    fields = ["I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L"] + (["Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L"] if pilot else [])
+    for k in range(len(prns)):
+        assert tr[k].status == "T" and ref[k].status == "T"
+        assert np.array_equal(tr[k].absoluteSample, ref[k].absoluteSample)
+        scale = 2.0 * 18000 * 28.0
+        for f in fields:
+            assert np.max(np.abs(getattr(tr[k], f) - getattr(ref[k], f))) < 1e-5 * scale, (k, f)
+        assert np.max(np.abs(tr[k].carrFreq - ref[k].carrFreq)) < 1e-3
+        assert np.max(np.abs(tr[k].codeFreq - ref[k].codeFreq)) < 1e-3
+        assert np.mean(np.hypot(tr[k].I_P, tr[k].Q_P)[10:]) > 1.3 * np.mean(np.hypot(tr[k].I_E, tr[k].Q_E)[10:])   # locked
+        assert abs(tr[k].carrFreq[-1] - (S.IF + sats[k].doppler)) < 20
+    return tr
+
+
+def test_beidou_b2a_data_pilot(engine):
+    """BDS/B2a/include/tracking.m with pilotTRKflag = 1: truncated Gold codes of BDS-SIS-ICD-B2a, pilot in quadrature."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B2a
+    S = initSettings_BDS_B2a()
+    S.pilotTRKflag = 1
+    _ten23_case(engine, S, "BDS_B2a", P.codes.generateB2aDataCode, P.codes.generateB2aPilotCode,
+                lambda prn: [O.pad_code(O.generate_b2a_code(prn, "data")), O.pad_code(O.generate_b2a_code(prn, "pilot"))],
+                "a", 1150.0, (20, 44), 41)
+
+
+def test_beidou_b3i(engine):
+    """BDS/B3I/include/tracking.m: single arm, loop coefficients of the package's own calcLoopCoefCarr.m
+    (a3 = 1.1, b3 = 2.4, Wn = LBW/0.7845), codeFreq from channel.codeFreq (:156,324)."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B3I
+    S = initSettings_BDS_B3I()
+    _ten23_case(engine, S, "BDS_B3I", P.codes.generateB3Icode, None, lambda prn: [O.pad_code(O.generate_b3i_code(prn))],
+                "b", 1240.0, (3, 37), 43)
+
+
+def _e5_oracle_tables(i_sig, q_sig):
+    def tables(prn):
+        tiered = O.generate_e5_code(i_sig, prn, 2)
+        # GAL_E5a/include/tracking.m:148-150: [code(codeLength) code code(1)] of the tiered code; only the first
+        # codeLength + 2 entries can be indexed
+        data = np.concatenate([[tiered[10229]], tiered, [tiered[0]]])[:10232]
+        q = O.generate_e5_primary(q_sig, prn)
+        return [data, O.pad_code(q)]
+    return tables
+
+
+def test_galileo_e5a(engine):
+    """GAL/GAL_E5a/include/tracking.m: data arm = first period of the tiered E5a-I code, pilot arm = E5a-Q primary."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E5a
+    S = initSettings_GAL_E5a()
+    _ten23_case(engine, S, "GAL_E5a", lambda prn: P.codes.generateE5aIcode(prn, 1), lambda prn: P.codes.generateE5aQcode(prn, 1),
+                _e5_oracle_tables("e5ai", "e5aq"), "a", 1150.0, (2, 33), 47)
+
+
+def test_galileo_e5b(engine):
+    """GAL/GAL_E5b/include/tracking.m: 25-Hz PLL, 1.5-Hz DLL, loop coefficients variant b."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E5b
+    S = initSettings_GAL_E5b()
+    _ten23_case(engine, S, "GAL_E5b", lambda prn: P.codes.generateE5bIcode(prn, 1), lambda prn: P.codes.generateE5bQcode(prn, 1),
+                _e5_oracle_tables("e5bi", "e5bq"), "b", 1180.0, (11, 36), 53)

@@ -1,7 +1,9 @@
 """Known-answer tests that pin the code generators: the reference ships no
 vectors, so the pins are the public ICD values."""
 import numpy as np
+import pytest
 
+from cu_sdr_collection_amd import codes as C
 from oracle import c_oracle as CO
 from oracle import gnss_oracle as O
 
@@ -95,3 +97,64 @@ def test_glonass_and_b1i_codes_two_implementations_agree():
         b = O.generate_b1i_code(prn)
         assert b.shape == (2046,) and np.array_equal(b, P.codes.generateCAcode53(prn).astype(np.float64))
         assert abs(b.sum()) <= 2
+
+
+# ---- 10.23-Mcps family, L2C, B1C: product generators against the per-chip oracle restatement and ICD KATs -------
+def _first24(code, base):
+    v = int("".join(str(int(b)) for b in ((1 - np.asarray(code[:24])) // 2).astype(int)), 2)
+    return ("%06X" if base == 16 else "%08o") % v
+
+
+def test_e5_codes_match_icd_initial_sequences_and_oracle():
+    """Galileo OS SIS ICD tables 15/17 list the first 24 chips of every primary code in hex (logic 1 <-> chip -1):
+    E5a-I code 1 = 3CEA9D, E5a-Q code 1 = 515537."""
+    assert _first24(C.generateE5aIcode(1), 16) == "3CEA9D"
+    assert _first24(C.generateE5aQcode(1), 16) == "515537"
+    for sig, fn in (("e5ai", C.generateE5aIcode), ("e5aq", C.generateE5aQcode), ("e5bi", C.generateE5bIcode), ("e5bq", C.generateE5bQcode)):
+        for prn in (1, 17, 50):
+            assert np.array_equal(fn(prn), O.generate_e5_primary(sig, prn)), (sig, prn)
+        assert abs(int(fn(3).sum())) < 400
+    assert np.array_equal(C.generateE5aIcode(2, 2), O.generate_e5_code("e5ai", 2, 2))
+    assert C.generateE5aIcode(2, 2).shape == (204600,)
+    assert np.array_equal(C.generateE5bIcode(5, 2), O.generate_e5_code("e5bi", 5, 2))
+    assert np.array_equal(C.generateE5aQ_secondary(7), O.generate_e5_secondary100("e5aq", 7))
+    assert np.array_equal(C.generateE5bQcode(9, 2)[:30690], O.generate_e5_code("e5bq", 9, 2)[:30690])
+
+
+def test_b2a_b3i_codes():
+    """BDS-SIS-ICD-B2a table 5-2: data code of PRN 1 starts 26771056 (octal, first 24 chips)."""
+    assert _first24(C.generateB2aDataCode(1), 8) == "26771056"
+    for prn in (1, 30, 63):
+        assert np.array_equal(C.generateB2aDataCode(prn), O.generate_b2a_code(prn, "data"))
+        assert np.array_equal(C.generateB2aPilotCode(prn), O.generate_b2a_code(prn, "pilot"))
+        assert np.array_equal(C.generateB3Icode(prn), O.generate_b3i_code(prn))
+    # register 1 has period 8190 in both B2a components and in B3I's G1: the code is NOT 8190-periodic, but the
+    # product of two PRNs' codes is (register 1 cancels, register 2 runs free with period 8191) -- structure check
+    a, b = C.generateB2aDataCode(1).astype(int), C.generateB2aDataCode(2).astype(int)
+    assert not np.array_equal(a[:2040], a[8190:])
+    assert abs(int((a * b).sum())) < 600
+
+
+def test_l2c_codes():
+    cm = C.generateCMcode(1)
+    assert cm.shape == (20460,) and not cm[1::2].any() and set(np.unique(cm[0::2])) == {-1, 1}
+    assert np.array_equal(cm, O.generate_l2c_code(1, "CM", 10230))
+    assert np.array_equal(C.generateCMcode(63), O.generate_l2c_code(63, "CM", 10230))
+    assert np.array_equal(C.generateCMcode(159), O.generate_l2c_code(159, "CM", 10230))
+    cl = C.generateCLcode(5, 4000)
+    assert not cl[0::2].any() and np.array_equal(cl, O.generate_l2c_code(5, "CL", 4000))
+    with pytest.raises(ValueError):
+        C.generateCMcode(100)
+
+
+def test_b1c_weil_codes():
+    assert O.jacobi_symbol(2, 10243) == (1 if pow(2, 5121, 10243) == 1 else -1)
+    for prn in (1, 40, 63):
+        for which, fn in (("data", C.generateDataBOC11), ("pilot11", C.generatePilotBOC11)):
+            assert np.array_equal(fn(prn), O.generate_b1c_code(prn, which)), (prn, which)
+    assert np.array_equal(C.generatePilotBOC61(2), O.generate_b1c_code(2, "pilot61"))
+    assert C.generatePilotBOC61(2).shape == (122760,)
+    assert np.array_equal(C.generatePilot2ndCodes(3), O.generate_b1c_code(3, "secondary"))
+    d = C.generateDataBOC11(1).astype(int)
+    assert np.array_equal(d[0::2], -d[1::2])              # BOC(1,1): chip x [-1, +1]
+    assert abs(int(d[1::2].sum())) < 300                  # Weil codes are balanced
