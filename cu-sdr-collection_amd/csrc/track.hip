@@ -54,6 +54,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   if (rc) return rc;
 
   int max_arms = 1;
+  bool any_mixed = false;
   gc_scope_reset(ctx);
   for (int c = 0; c < nch; ++c) {
     const int ci = init[c].channel;
@@ -69,10 +70,11 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     max_arms = std::max(max_arms, ctx->ch[ci].arms);
     gc_scope_add(ctx, ci);
     for (int a = 1; a < ctx->ch[ci].arms; ++a)
-      if (ctx->ch[ci].mult[a] != ctx->ch[ci].mult[0]) {
-        gc_set_error("gc_track: channel %d mixes ramp multipliers (B1C wide-band): closed loop not wired up, use gc_correlate", ci);
-        return GC_E_UNSUPPORTED;
-      }
+      if (ctx->ch[ci].mult[a] != ctx->ch[ci].mult[0]) any_mixed = true;  // B1C wide-band: exact per-sample kernel
+  }
+  if (p->pilot_combine == 4 && max_arms < 3) {
+    gc_set_error("gc_track: pilot_combine 4 needs three arms {data, pilot BOC(1,1), pilot BOC(6,1)}");
+    return GC_E_INVALID;
   }
   if (p->pilot_combine != 0 && max_arms < 2) {
     gc_set_error("gc_track: pilot_combine requires a pilot arm");
@@ -178,8 +180,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       ++nb;
     }
     if (nb == 0) break;
-    int fast = (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
-    for (int k = 0; k < nb && fast; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
+    int fast = any_mixed ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
+    for (int k = 0; k < nb && fast > 0; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
     bool share = true;
     for (int k = 0; k < nb && share; ++k) share = gc_block_shares_el(ctx, blocks[k]);
     ctx->scope_share_lane = true;
@@ -254,8 +256,18 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       double carr_err = std::atan(q_p / i_p) / (2.0 * kPi);
       double code_err = (std::sqrt(i_e * i_e + q_e * q_e) - std::sqrt(i_l * i_l + q_l * q_l)) /
                         (std::sqrt(i_e * i_e + q_e * q_e) + std::sqrt(i_l * i_l + q_l * q_l));  // :322-323
+      double pilot6[6] = {sums[6], sums[7], sums[8], sums[9], sums[10], sums[11]};  // arm 1 as correlated
       if (p->pilot_combine != 0) {
-        const double pi_e = sums[6], pq_e = sums[7], pi_p = sums[8], pq_p = sums[9], pi_l = sums[10], pq_l = sums[11];
+        if (p->pilot_combine == 4) {
+          // BDS B1C wide-band: arms {data, pilot BOC(1,1), pilot BOC(6,1)} -> one pilot (WB_tracking.m:364-369)
+          const double a61 = -std::sqrt(4.0 / 33.0), a11 = std::sqrt(29.0 / 33.0);
+          for (int x = 0; x < 3; ++x) {
+            const double i11 = sums[6 + 2 * x], q11 = sums[7 + 2 * x], i61 = sums[12 + 2 * x], q61 = sums[13 + 2 * x];
+            pilot6[2 * x] = a61 * i61 + a11 * q11;
+            pilot6[2 * x + 1] = a61 * q61 - a11 * i11;
+          }
+        }
+        const double pi_e = pilot6[0], pq_e = pilot6[1], pi_p = pilot6[2], pq_p = pilot6[3], pi_l = pilot6[4], pq_l = pilot6[5];
         double carr_err_q;
         if (p->pilot_combine == 1) {
           // QI = (I_PQ + 1i*Q_PQ) * exp(-1i*pi/2), GPS_L5C tracking.m:340
@@ -263,13 +275,29 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
           const double re = pi_p * cr - pq_p * ci;
           const double im = pi_p * ci + pq_p * cr;
           carr_err_q = std::atan(im / re) / (2.0 * kPi);
+        } else if (p->pilot_combine == 3) {
+          carr_err_q = std::atan(-pi_p / pq_p) / (2.0 * kPi);  // BDS/B1C NB_tracking.m:341
         } else {
-          carr_err_q = std::atan(pq_p / pi_p) / (2.0 * kPi);  // GAL_E1C tracking.m:309
+          carr_err_q = std::atan(pq_p / pi_p) / (2.0 * kPi);  // GAL_E1C tracking.m:309; WB_tracking.m:381
         }
-        carr_err = (carr_err + carr_err_q) / 2;
-        const double code_err_q = (std::sqrt(pi_e * pi_e + pq_e * pq_e) - std::sqrt(pi_l * pi_l + pq_l * pq_l)) /
-                                  (std::sqrt(pi_e * pi_e + pq_e * pq_e) + std::sqrt(pi_l * pi_l + pq_l * pq_l));
-        code_err = (code_err + code_err_q) / 2;
+        double code_err_q = (std::sqrt(pi_e * pi_e + pq_e * pq_e) - std::sqrt(pi_l * pi_l + pq_l * pq_l)) /
+                            (std::sqrt(pi_e * pi_e + pq_e * pq_e) + std::sqrt(pi_l * pi_l + pq_l * pq_l));
+        const bool pll_w = p->pll_weight[0] != 0.0 || p->pll_weight[1] != 0.0;
+        const bool dll_w = p->dll_weight[0] != 0.0 || p->dll_weight[1] != 0.0;
+        if (p->dll_scale != 0.0) {  // NB_tracking.m:346-348
+          code_err = code_err * p->dll_scale;
+          code_err_q = code_err_q * p->dll_scale;
+        }
+        if (pll_w)  // (carrError*11 + p11_carrError*29)/40, NB_tracking.m:342; (carrError*1 + p_carrError*3)/4, WB :382
+          carr_err = (carr_err * p->pll_weight[0] + carr_err_q * p->pll_weight[1]) / (p->pll_weight[0] + p->pll_weight[1]);
+        else
+          carr_err = (carr_err + carr_err_q) / 2;
+        if (dll_w && p->pilot_combine == 4)  // codeError*factor + p_codeError*(1-factor), WB_tracking.m:403
+          code_err = code_err * p->dll_weight[0] + code_err_q * p->dll_weight[1];
+        else if (dll_w)  // (codeError*11 + p11_codeError*29)/40, NB_tracking.m:349
+          code_err = (code_err * p->dll_weight[0] + code_err_q * p->dll_weight[1]) / (p->dll_weight[0] + p->dll_weight[1]);
+        else
+          code_err = (code_err + code_err_q) / 2;
       }
       double carr_nco;
       if (p->pll_kind == GC_PLL_2ND_ORDER) {
@@ -300,12 +328,12 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       rec(GC_TRK_I_L, i_l);
       rec(GC_TRK_Q_L, q_l);
       if (ctx->ch[b.channel].arms >= 2) {
-        rec(GC_TRK_PILOT_I_E, sums[6]);
-        rec(GC_TRK_PILOT_Q_E, sums[7]);
-        rec(GC_TRK_PILOT_I_P, sums[8]);
-        rec(GC_TRK_PILOT_Q_P, sums[9]);
-        rec(GC_TRK_PILOT_I_L, sums[10]);
-        rec(GC_TRK_PILOT_Q_L, sums[11]);
+        rec(GC_TRK_PILOT_I_E, pilot6[0]);
+        rec(GC_TRK_PILOT_Q_E, pilot6[1]);
+        rec(GC_TRK_PILOT_I_P, pilot6[2]);
+        rec(GC_TRK_PILOT_Q_P, pilot6[3]);
+        rec(GC_TRK_PILOT_I_L, pilot6[4]);
+        rec(GC_TRK_PILOT_Q_L, pilot6[5]);
       }
       s.epochs = e + 1;
     }

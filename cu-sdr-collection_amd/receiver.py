@@ -120,6 +120,15 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
     p.pilot_combine = pilot
     if spec.pll_kind == L.GC_PLL_3_STATE:
         p.pf3, p.pf2, p.pf1 = signals.calcLoopCoefCarr(settings, spec.coef_variant)
+    if pilot:
+        for name in ("pll_weight", "dll_weight"):
+            w = getattr(spec, name)
+            if callable(w):
+                w = w(settings)
+            if w is not None:
+                getattr(p, name)[0], getattr(p, name)[1] = float(w[0]), float(w[1])
+        if spec.dll_scale_spacing:
+            p.dll_scale = 1.0 - settings.dllCorrelatorSpacing
     p.skip_samples = int(settings.skipNumberOfBytes)
     p.n_epochs = signals.epochs_to_process(settings)
     return p
@@ -151,7 +160,7 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
         results.append(tr)
         if ch.PRN != 0:
             tr.PRN = ch.PRN
-            fid.set_channel(i, spec.tables(ch.PRN, settings), index_scale=spec.index_scale)
+            fid.set_channel(i, spec.tables(ch.PRN, settings), index_scale=spec.index_scale, arm_mult=spec.arm_mult)
             active.append(i)
     if not active:
         return results, channel

@@ -170,3 +170,31 @@ def initSettings_GAL_E5b() -> SimpleNamespace:
                   acqNonCohTime=15, acqThreshold=4.5, acqSearchStep=60,         # :88-92
                   dllNoiseBandwidth=1.5, pllNoiseBandwidth=25, pilotTRKflag=1,  # :104,108,112
                   CNo=SimpleNamespace(accTime=0.001, VSMinterval=100), carrFreqBasis=1207.14e6)  # :140-144
+
+
+def initSettings_BDS_B1C() -> SimpleNamespace:
+    """BDS B1C defaults (BDS/B1C/initSettings.m:55-143): 10-ms integration, 0.06-chip correlator spacing."""
+    s = initSettings()
+    s.IF = 20e3                      # :55
+    s.samplingFreq = 18e6            # :56
+    s.FEBW = 27e6                    # :59 front-end bandwidth (CalcWeighingFactor.m)
+    s.acqSatelliteList = list(range(1, 63))  # :67
+    s.pilotTRKflag = 1               # :71
+    s.numberOfChannels = 15          # :73
+    s.codeLength = 10230             # :82
+    s.codeFreqBasis = 1.023e6        # :84
+    s.carrFreqBasis = 1575.42e6      # :86
+    s.acqSearchBand = 5000           # :92
+    s.acqCohT = 10                   # :95
+    s.acqStep = 1000 / s.acqCohT / 2  # :97
+    s.acqThreshold = 10              # :99
+    s.dllDampingRatio = 0.7          # :107
+    s.dllNoiseBandwidth = 1          # :108
+    s.dllCorrelatorSpacing = 0.06    # :111
+    s.pllDampingRatio = 0.7          # :113
+    s.pllNoiseBandwidth = 18         # :114
+    s.intTime = 0.01                 # :116
+    s.CNoInterval = 50               # :143
+    if hasattr(s, "CNo"):
+        del s.CNo                    # B1C estimates C/N0 with Calc_CNo_PLD (not on the hot path)
+    return s

@@ -3,6 +3,7 @@ tables a channel carries, the index scale R of the ramps, the carrier loop filte
 arm enters the discriminators.  One entry per reference package that is wired up so far."""
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import Callable
 
@@ -21,6 +22,10 @@ class SignalSpec:
     coef_variant: str           # calcLoopCoefCarr.m variant "a" (a3=b3=2, Wn=1.2*LBW) | "b" (1.1, 2.4, LBW/0.7845)
     pilot_combine: int          # 0 none | 1 rotate pilot by -pi/2 then average | 2 plain average
     code_freq_from_channel: bool  # initial codeFreq = channel.codeFreq (GPS_L5C tracking.m:165) or codeFreqBasis
+    arm_mult: tuple | None = None          # per-arm ramp multipliers (B1C wide-band: (1, 1, 6), WB_tracking.m:293)
+    pll_weight: tuple | Callable | None = None   # (data, pilot) discriminator weights; None = plain average
+    dll_weight: tuple | Callable | None = None   # tuple or settings -> tuple (B1C WB: CalcWeighingFactor)
+    dll_scale_spacing: bool = False        # DLL discriminators times (1 - earlyLateSpc), NB_tracking.m:346-348
 
 
 def calcLoopCoefCarr(settings, variant: str = "a"):
@@ -82,6 +87,50 @@ def _e5_tables(i_fn, q_fn):
     return tables
 
 
+def _b1c_nb_tables(prn, settings):
+    return [codes.padded_table(codes.generateDataBOC11(prn)),                # BDS/B1C NB_tracking.m:161-164
+            codes.padded_table(codes.generatePilotBOC11(prn))]
+
+
+def _b1c_wb_tables(prn, settings):
+    return _b1c_nb_tables(prn, settings) + [codes.padded_table(codes.generatePilotBOC61(prn))]   # WB_tracking.m:176-188
+
+
+def CalcWeighingFactor(settings) -> float:
+    """BDS/B1C/include/CalcWeighingFactor.m: weight of the data-component DLL discriminator in the wide-band
+    tracker, from the RMS bandwidths of BOC(1,1) and of the 29/33 BOC(1,1) + 4/33 BOC(6,1) pilot inside the
+    front-end bandwidth settings.FEBW.  MATLAB's integral() -> scipy.integrate.quad (host-side, once per run)."""
+    from scipy.integrate import quad
+    fc = settings.codeFreqBasis
+    tc = 1.0 / fc
+    br = settings.FEBW
+
+    def g11(f):
+        f = f if f != 0.0 else 1e-9
+        return tc * (math.sin(math.pi / 2 * f / fc) * math.sin(math.pi * f / fc) / math.cos(math.pi / 2 * f / fc) * fc / f / math.pi) ** 2
+
+    def g61(f):
+        f = f if f != 0.0 else 1e-9
+        return tc * (math.sin(math.pi / 12 * f / fc) * math.sin(math.pi * f / fc) / math.cos(math.pi / 12 * f / fc) * fc / f / math.pi) ** 2
+
+    def integ(fn):
+        return quad(fn, -br / 2, br / 2, limit=400, epsabs=0, epsrel=1e-10)[0]
+
+    p11_2, p11 = integ(lambda f: g11(f) * f * f), integ(g11)
+    pil_2 = integ(lambda f: (29 / 33 * g11(f) + 4 / 33 * g61(f)) * f * f)
+    pil = integ(lambda f: 29 / 33 * g11(f) + 4 / 33 * g61(f))
+    t1 = 11 * p11 * (p11_2 / p11)      # 11 * Power * RMS_BW^2
+    t2 = 33 * pil * (pil_2 / pil)
+    return t1 / (t1 + t2)
+
+
+def _b1c_wb_dll_weight(settings):
+    f = getattr(settings, "dllWeighingFactor", None)
+    if f is None:
+        f = CalcWeighingFactor(settings)
+    return (f, 1.0 - f)
+
+
 SIGNALS = {
     "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False),
     # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
@@ -96,6 +145,12 @@ SIGNALS = {
     "BDS_B2a": SignalSpec("BDS_B2a", _b2a_tables, 1.0, L.GC_PLL_3_STATE, "a", 1, True),
     "BDS_B3I": SignalSpec("BDS_B3I", _b3i_tables, 1.0, L.GC_PLL_3_STATE, "b", 0, True),
     "GAL_E5a": SignalSpec("GAL_E5a", _e5_tables(codes.generateE5aIcode, codes.generateE5aQcode), 1.0, L.GC_PLL_3_STATE, "a", 1, True),
+    # BDS B1C: 10-ms blocks, BOC(1,1) half-chip tables (R = 2).  Narrow-band: data + pilot BOC(1,1), pilot in
+    # quadrature, 11:29 weights; wide-band: + the pilot's BOC(6,1) arm read through ceil(6*t), folded 1:3 / factor
+    "BDS_B1C_NB": SignalSpec("BDS_B1C_NB", _b1c_nb_tables, 2.0, L.GC_PLL_3_STATE, "b", 3, True,
+                             pll_weight=(11.0, 29.0), dll_weight=(11.0, 29.0), dll_scale_spacing=True),
+    "BDS_B1C_WB": SignalSpec("BDS_B1C_WB", _b1c_wb_tables, 2.0, L.GC_PLL_3_STATE, "b", 4, True, arm_mult=(1.0, 1.0, 6.0),
+                             pll_weight=(1.0, 3.0), dll_weight=_b1c_wb_dll_weight, dll_scale_spacing=True),
     "GAL_E5b": SignalSpec("GAL_E5b", _e5_tables(codes.generateE5bIcode, codes.generateE5bQcode), 1.0, L.GC_PLL_3_STATE, "b", 1, True),
 }
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GC_API_VERSION 1
+#define GC_API_VERSION 2
 
 typedef struct gc_context gc_context;
 
@@ -149,13 +149,24 @@ typedef struct gc_track_params {
   double dll_noise_bw, dll_damping;   /* settings.dllNoiseBandwidth, dllDampingRatio */
   double pll_noise_bw, pll_damping;   /* settings.pllNoiseBandwidth, pllDampingRatio */
   int32_t pll_kind;          /* gc_pll_kind */
-  int32_t pilot_combine;     /* 0 = data arm only; 1 = average data+pilot discriminators with the
+  int32_t pilot_combine;     /* 0 = data arm only; 1 = combine data+pilot discriminators with the
                                 pilot rotated by -pi/2 (GPS_L5C tracking.m:336-348);
-                                2 = plain average (GAL_E1C tracking.m:303-311,326-331) */
+                                2 = pilot as is (GAL_E1C tracking.m:303-311,326-331);
+                                3 = pilot in quadrature, atan(-I/Q) (BDS/B1C NB_tracking.m:340-342);
+                                4 = three arms {data, pilot BOC(1,1), pilot BOC(6,1)} folded into one pilot
+                                    p = -sqrt(4/33)*p61 + sqrt(29/33)*(Q11, -I11) (WB_tracking.m:364-369),
+                                    which is also what the Pilot_* records then hold (:420-425) */
   double pf1, pf2, pf3;      /* 3-state filter coefficients (calcLoopCoefCarr.m), if used */
   int64_t skip_samples;      /* settings.skipNumberOfBytes, in samples */
   int32_t n_epochs;          /* codePeriods = settings.msToProcess (tracking.m:90) */
   int32_t reserved;
+  /* API version 2: discriminator weights {data, pilot}; all-zero pairs mean 1:1 (the plain averages of L5 / E1).
+   * B1C NB: pll 11:29, dll 11:29 (NB_tracking.m:342,349); B1C WB: pll 1:3, dll factor:(1-factor) with
+   * factor = CalcWeighingFactor(settings) (WB_tracking.m:382,403). */
+  double pll_weight[2];
+  double dll_weight[2];
+  double dll_scale;          /* both DLL discriminators are multiplied by it: 1 - earlyLateSpc for B1C
+                                (NB_tracking.m:346-348); 0 means 1 */
 } gc_track_params;
 
 typedef struct gc_channel_init {

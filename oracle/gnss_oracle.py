@@ -524,7 +524,9 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
          r            index scale (2 for the BOC(1,1) half-chip tables, GAL_E1C tracking.m:236),
          pll          '2nd' (L1CA) | '3state' (calcLoopCoefCarr variant spec.coef_variant),
          pilot_combine 0 none | 1 rotate pilot by exp(-1i*pi/2) then average (GPS_L5C tracking.m:336-348)
-                       | 2 plain average (GAL_E1C tracking.m:303-311,326-331),
+                       | 2 plain average (GAL_E1C tracking.m:303-311,326-331)
+                       | 3 pilot in quadrature atan(-I/Q) (B1C NB_tracking.m:341) | 4 B1C wide-band three-arm fold,
+         optional pll_weight / dll_weight (data, pilot), dll_scale_spacing, arm_mult (per-arm ramp multipliers),
          code_freq_from_channel  True: channel.codeFreq (GPS_L5C tracking.m:165), False: codeFreqBasis)
     Epoch count NumToProcess = round(msToProcess/1000/intTime) (GAL_E1C tracking.m:51)."""
     n_ep = int(matlab_round(settings.msToProcess / 1000 / settings.intTime))
@@ -568,7 +570,8 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
             if correlate is None:
                 sums, rem_code_new, rem_carr_new = correlate_block(
                     raw_from_if(if_bytes, pos, n, swap_iq=getattr(spec, "swap_iq", False)), tables, rem_code, step, d,
-                    carr_freq, rem_carr, settings.samplingFreq, settings.codeLength, r=spec.r)
+                    carr_freq, rem_carr, settings.samplingFreq, settings.codeLength, r=spec.r,
+                    arm_mult=getattr(spec, "arm_mult", None))
             else:
                 sums, rem_code_new, rem_carr_new = correlate(ch, pos, n, rem_code, step, d, carr_freq, rem_carr)
             pos += n
@@ -579,16 +582,41 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
             code_err = float((math.sqrt(i_e * i_e + q_e * q_e) - math.sqrt(i_l * i_l + q_l * q_l)) /
                              (math.sqrt(i_e * i_e + q_e * q_e) + math.sqrt(i_l * i_l + q_l * q_l)))
             if spec.pilot_combine:
-                pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = (float(v) for v in sums[1])
-                if spec.pilot_combine == 1:
-                    qi = (pi_p + 1j * pq_p) * np.exp(-1j * math.pi / 2)
-                    carr_err_q = float(np.arctan(np.float64(qi.imag) / np.float64(qi.real)) / (2.0 * math.pi))
+                if spec.pilot_combine == 4:
+                    # BDS/B1C/include/WB_tracking.m:364-369: arms {data, pilot BOC(1,1), pilot BOC(6,1)}
+                    a61, a11 = -math.sqrt(4 / 33), math.sqrt(29 / 33)
+                    p11, p61 = [float(v) for v in sums[1]], [float(v) for v in sums[2]]
+                    pil = []
+                    for x in range(3):
+                        pil += [a61 * p61[2 * x] + a11 * p11[2 * x + 1], a61 * p61[2 * x + 1] - a11 * p11[2 * x]]
+                    pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = pil
                 else:
-                    carr_err_q = float(np.arctan(np.float64(pq_p) / np.float64(pi_p)) / (2.0 * math.pi))
-                carr_err = (carr_err + carr_err_q) / 2
+                    pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = (float(v) for v in sums[1])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    if spec.pilot_combine == 1:
+                        qi = (pi_p + 1j * pq_p) * np.exp(-1j * math.pi / 2)
+                        carr_err_q = float(np.arctan(np.float64(qi.imag) / np.float64(qi.real)) / (2.0 * math.pi))
+                    elif spec.pilot_combine == 3:
+                        carr_err_q = float(np.arctan(np.float64(-pi_p) / np.float64(pq_p)) / (2.0 * math.pi))   # NB_tracking.m:341
+                    else:
+                        carr_err_q = float(np.arctan(np.float64(pq_p) / np.float64(pi_p)) / (2.0 * math.pi))
                 code_err_q = (math.sqrt(pi_e ** 2 + pq_e ** 2) - math.sqrt(pi_l ** 2 + pq_l ** 2)) / \
                              (math.sqrt(pi_e ** 2 + pq_e ** 2) + math.sqrt(pi_l ** 2 + pq_l ** 2))
-                code_err = (code_err + code_err_q) / 2
+                if getattr(spec, "dll_scale_spacing", False):      # * (1-earlyLateSpc), NB_tracking.m:346-348
+                    code_err = code_err * (1 - d)
+                    code_err_q = code_err_q * (1 - d)
+                pw = getattr(spec, "pll_weight", None)
+                dw = getattr(spec, "dll_weight", None)
+                if pw:    # (carrError*11 + p11_carrError*29)/40 (NB :342); (carrError*1 + p_carrError*3)/4 (WB :382)
+                    carr_err = (carr_err * pw[0] + carr_err_q * pw[1]) / (pw[0] + pw[1])
+                else:
+                    carr_err = (carr_err + carr_err_q) / 2
+                if dw and spec.pilot_combine == 4:    # codeError*factor + p_codeError*(1-factor), WB_tracking.m:403
+                    code_err = code_err * dw[0] + code_err_q * dw[1]
+                elif dw:                               # (codeError*11 + p11_codeError*29)/40, NB_tracking.m:349
+                    code_err = (code_err * dw[0] + code_err_q * dw[1]) / (dw[0] + dw[1])
+                else:
+                    code_err = (code_err + code_err_q) / 2
                 tr.Pilot_I_E[e], tr.Pilot_Q_E[e], tr.Pilot_I_P[e] = pi_e, pq_e, pi_p
                 tr.Pilot_Q_P[e], tr.Pilot_I_L[e], tr.Pilot_Q_L[e] = pq_p, pi_l, pq_l
             if spec.pll == "2nd":
