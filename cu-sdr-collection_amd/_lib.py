@@ -41,13 +41,13 @@ class gc_track_params(C.Structure):
                 ("pll_noise_bw", C.c_double), ("pll_damping", C.c_double),
                 ("pll_kind", C.c_int32), ("pilot_combine", C.c_int32),
                 ("pf1", C.c_double), ("pf2", C.c_double), ("pf3", C.c_double),
-                ("skip_samples", C.c_int64), ("n_epochs", C.c_int32), ("reserved", C.c_int32),
+                ("skip_samples", C.c_int64), ("n_epochs", C.c_int32), ("table_phase_count", C.c_int32),
                 ("pll_weight", C.c_double * 2), ("dll_weight", C.c_double * 2), ("dll_scale", C.c_double)]
 
 
 class gc_channel_init(C.Structure):
     _fields_ = [("channel", C.c_int32), ("prn", C.c_int32), ("acquired_freq", C.c_double),
-                ("code_freq", C.c_double), ("code_phase", C.c_int64)]
+                ("code_freq", C.c_double), ("code_phase", C.c_int64), ("table_phase", C.c_int32), ("reserved", C.c_int32)]
 
 
 class gc_acq_params(C.Structure):

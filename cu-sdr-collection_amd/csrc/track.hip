@@ -25,6 +25,7 @@ struct ChanState {
   double d2_carr_err = 0, d_carr_err = 0;      // 3-state PLL
   int epochs = 0;
   bool aborted = false;
+  int table_phase = 0;  // GPS L2C CLCodePhase
 };
 
 // Common/calcLoopCoef.m:41-45
@@ -147,6 +148,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     ChanState& s = st[c];
     s.active = true;
     s.pos = p->skip_samples + init[c].code_phase - 1;  // tracking.m:150-152
+    s.table_phase = init[c].table_phase;
     s.code_freq = s.code_freq_basis = init[c].code_freq;  // :163 / GPS_L5C :165
     s.carr_freq = s.carr_basis = init[c].acquired_freq;   // :167-168
   }
@@ -172,6 +174,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       b.blksize = n;
       b.first_sample = s.pos;
       b.rem_code_phase = s.rem_code;
+      if (p->table_phase_count > 0 && s.table_phase > 0)  // GPS_L2C tracking.m:261: index + codeLength*(CLCodePhase-1)
+        b.table_offset[1] = (int32_t)p->code_length * (s.table_phase - 1);
       b.code_phase_step = step;
       b.el_spacing = p->el_spacing;
       b.carr_freq = s.carr_freq;
@@ -334,6 +338,10 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
         rec(GC_TRK_PILOT_Q_P, pilot6[3]);
         rec(GC_TRK_PILOT_I_L, pilot6[4]);
         rec(GC_TRK_PILOT_Q_L, pilot6[5]);
+      }
+      if (p->table_phase_count > 0 && s.table_phase > 0 && p->pilot_combine != 0) {  // GPS_L2C tracking.m:357-360
+        s.table_phase += 1;
+        if (s.table_phase >= p->table_phase_count + 1) s.table_phase = 1;
       }
       s.epochs = e + 1;
     }

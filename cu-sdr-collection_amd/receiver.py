@@ -131,6 +131,14 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
             p.dll_scale = 1.0 - settings.dllCorrelatorSpacing
     p.skip_samples = int(settings.skipNumberOfBytes)
     p.n_epochs = signals.epochs_to_process(settings)
+    if spec.doubled_code:
+        # GPS_L2C/include/tracking.m:107-109: spacing and code length in units of the RZ-doubled code; :153 seeks to
+        # skipNumberOfBytes + codePhase WITHOUT the usual -1; :261,357-360 CL window bookkeeping
+        p.el_spacing = settings.dllCorrelatorSpacing * 2
+        p.code_length = settings.codeLength * 2
+        p.code_freq_basis = settings.codeFreqBasis * 2
+        p.skip_samples = int(settings.skipNumberOfBytes) + 1
+        p.table_phase_count = 75 if pilot else 0
     return p
 
 
@@ -160,7 +168,8 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
         results.append(tr)
         if ch.PRN != 0:
             tr.PRN = ch.PRN
-            fid.set_channel(i, spec.tables(ch.PRN, settings), index_scale=spec.index_scale, arm_mult=spec.arm_mult)
+            fid.set_channel(i, spec.tables(ch.PRN, settings), index_scale=spec.index_scale, arm_mult=spec.arm_mult,
+                            windows=spec.windows)
             active.append(i)
     if not active:
         return results, channel
@@ -168,8 +177,11 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
     for i in active:
         ch = channel[i]
         cf = ch.codeFreq if spec.code_freq_from_channel else settings.codeFreqBasis
+        if spec.doubled_code:
+            cf = settings.codeFreqBasis * 2                                           # GPS_L2C tracking.m:171
         inits.append(L.gc_channel_init(channel=i, prn=ch.PRN, acquired_freq=ch.acquiredFreq,
-                                       code_freq=cf, code_phase=int(ch.codePhase)))
+                                       code_freq=cf, code_phase=int(ch.codePhase),
+                                       table_phase=int(getattr(ch, "CLCodePhase", 0)) if (spec.doubled_code and pilot) else 0))
     fields, done, status = fid.track(p, inits)
     cno = getattr(settings, "CNo", None)   # B2a / B1C estimate C/N0 with Calc_CNo_PLD instead (not on the hot path)
     vsm = int(cno.VSMinterval) if cno is not None else 0
@@ -178,6 +190,13 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
         for f in _REC_FIELDS + (_PILOT_FIELDS if pilot else ()):
             getattr(tr, f)[:] = fields[f][k]
         n_done = int(done[k])
+        if spec.doubled_code:
+            # GPS_L2C tracking.m:226,250,376,382-383: what the reference RECORDS is in single-code units, and
+            # absoluteSample is pushed back by the code-phase remainder expressed in samples
+            step = tr.codeFreq[:n_done] / settings.samplingFreq
+            tr.absoluteSample[:n_done] = tr.absoluteSample[:n_done] + 1 - tr.remCodePhase[:n_done] / step
+            for f in ("remCodePhase", "codeFreq", "dllDiscr", "dllDiscrFilt"):
+                getattr(tr, f)[:n_done] /= 2
         for loop in (range(vsm, n_done + 1, vsm) if vsm else ()):                     # tracking.m:351-358
             tr.CNo.VSMValue.append(CNoVSM(tr.I_P[loop - vsm:loop], tr.Q_P[loop - vsm:loop], settings.CNo.accTime))
             tr.CNo.VSMIndex.append(loop)

@@ -198,3 +198,29 @@ def initSettings_BDS_B1C() -> SimpleNamespace:
     if hasattr(s, "CNo"):
         del s.CNo                    # B1C estimates C/N0 with Calc_CNo_PLD (not on the hot path)
     return s
+
+
+def initSettings_GPS_L2C() -> SimpleNamespace:
+    """GPS L2C defaults (GPS/GPS_L2C/initSettings.m:44-143): 8 Msps, 20-ms blocks of the RZ-multiplexed CM / CL codes."""
+    s = initSettings()
+    s.numberOfChannels = 12          # :47
+    s.IF = 20e3                      # :69
+    s.samplingFreq = 8e6             # :70
+    s.codeLength = 10230             # :74
+    s.codeFreqBasis = 0.5115e6       # :75
+    s.CLCodeLength = 10230 * 75      # :76
+    s.acqSatelliteList = list(range(1, 33))  # :84
+    s.acqSearchBand = 10             # :87 (kHz in this package's acquisition.m)
+    s.acqThreshold = 1.5             # :89
+    s.acqCohT = 20                   # :91
+    s.acqStep = (1000 / 2) / 20 / 2  # :94
+    s.dllDampingRatio = 0.7          # :102
+    s.dllNoiseBandwidth = 4          # :103
+    s.dllCorrelatorSpacing = 0.25    # :104
+    s.pllDampingRatio = 0.7          # :106
+    s.pllNoiseBandwidth = 10         # :107
+    s.intTime = 0.02                 # :109
+    s.pilotTRKflag = 0               # :111
+    s.CNo = SimpleNamespace(accTime=0.02, VSMinterval=40)  # :141-143
+    s.carrFreqBasis = 1227.60e6
+    return s

@@ -26,6 +26,8 @@ class SignalSpec:
     pll_weight: tuple | Callable | None = None   # (data, pilot) discriminator weights; None = plain average
     dll_weight: tuple | Callable | None = None   # tuple or settings -> tuple (B1C WB: CalcWeighingFactor)
     dll_scale_spacing: bool = False        # DLL discriminators times (1 - earlyLateSpc), NB_tracking.m:346-348
+    windows: tuple | None = None           # per-arm LDS staging window in entries (L2C CL: one block's worth)
+    doubled_code: bool = False             # GPS L2C: the loop runs on the RZ-doubled code (tracking.m:107-109,171)
 
 
 def calcLoopCoefCarr(settings, variant: str = "a"):
@@ -85,6 +87,14 @@ def _e5_tables(i_fn, q_fn):
             t.append(codes.padded_table(q_fn(prn, 1)))                        # :152-156, primary code only
         return t
     return tables
+
+
+def _l2c_tables(prn, settings):
+    cm = codes.generateCMcode(prn, int(settings.codeLength))                  # GPS_L2C tracking.m:155-156
+    t = [codes.padded_table(cm)]
+    if getattr(settings, "pilotTRKflag", 0):
+        t.append(codes.padded_table(codes.generateCLcode(prn, int(settings.CLCodeLength))))   # :158-162
+    return t
 
 
 def _b1c_nb_tables(prn, settings):
@@ -151,6 +161,8 @@ SIGNALS = {
                              pll_weight=(11.0, 29.0), dll_weight=(11.0, 29.0), dll_scale_spacing=True),
     "BDS_B1C_WB": SignalSpec("BDS_B1C_WB", _b1c_wb_tables, 2.0, L.GC_PLL_3_STATE, "b", 4, True, arm_mult=(1.0, 1.0, 6.0),
                              pll_weight=(1.0, 3.0), dll_weight=_b1c_wb_dll_weight, dll_scale_spacing=True),
+    # GPS L2C: RZ-interleaved CM (+ CL through a moving window of its 1.5-s table), everything in doubled-code units
+    "GPS_L2C": SignalSpec("GPS_L2C", _l2c_tables, 1.0, L.GC_PLL_3_STATE, "a", 2, False, windows=(0, 20464), doubled_code=True),
     "GAL_E5b": SignalSpec("GAL_E5b", _e5_tables(codes.generateE5bIcode, codes.generateE5bQcode), 1.0, L.GC_PLL_3_STATE, "b", 1, True),
 }
 

@@ -159,7 +159,10 @@ typedef struct gc_track_params {
   double pf1, pf2, pf3;      /* 3-state filter coefficients (calcLoopCoefCarr.m), if used */
   int64_t skip_samples;      /* settings.skipNumberOfBytes, in samples */
   int32_t n_epochs;          /* codePeriods = settings.msToProcess (tracking.m:90) */
-  int32_t reserved;
+  int32_t table_phase_count; /* API version 2.  0 = off.  GPS L2C: 75 — the pilot arm's table is read through a window
+                                that advances by code_length entries per epoch, table_offset[1] = code_length *
+                                (phase - 1), phase = channel.CLCodePhase, +1 per epoch, back to 1 after
+                                table_phase_count (GPS_L2C/include/tracking.m:261,357-360) */
   /* API version 2: discriminator weights {data, pilot}; all-zero pairs mean 1:1 (the plain averages of L5 / E1).
    * B1C NB: pll 11:29, dll 11:29 (NB_tracking.m:342,349); B1C WB: pll 1:3, dll factor:(1-factor) with
    * factor = CalcWeighingFactor(settings) (WB_tracking.m:382,403). */
@@ -176,6 +179,8 @@ typedef struct gc_channel_init {
   double code_freq;          /* initial codeFreq: settings.codeFreqBasis (tracking.m:163) or
                                 channel.codeFreq (GPS_L5C tracking.m:165) */
   int64_t code_phase;        /* channel.codePhase, 1-based sample index, preRun.m:69 */
+  int32_t table_phase;       /* API version 2: channel.CLCodePhase (1-based; GPS_L2C preRun.m:71), else 0 */
+  int32_t reserved;
 } gc_channel_init;
 
 /* Per-epoch records, one row of n_epochs doubles per field per channel

@@ -915,3 +915,86 @@ def generate_b1c_code(prn: int, which: str) -> np.ndarray:
     else:
         sub = np.array([-1.0, 1.0])
     return (prim[:, None] * sub[None, :]).reshape(-1)
+
+
+def tracking_l2c(if_bytes: np.ndarray, channel, settings):
+    """GPS/GPS_L2C/include/tracking.m:40-420 restated: the loop runs on the RZ-doubled code (earlyLateSpc*2,
+    codeLength*2, codeFreqBasis*2, :107-109,171), seeks to skipNumberOfBytes + codePhase without -1 (:153), reads the
+    CL arm at index + codeLength*(CLCodePhase-1) with CLCodePhase cycling 1..75 (:261,357-360), averages data and
+    pilot discriminators when pilotTRKflag (:336-339,352-356), records remCodePhase, codeFreq, dllDiscr and
+    dllDiscrFilt halved and absoluteSample = position + 1 - remCodePhase/codePhaseStep (:226,250,376,382-383)."""
+    n_ep = int(matlab_round(settings.msToProcess / 1000 / settings.intTime))
+    d = settings.dllCorrelatorSpacing * 2
+    code_length = settings.codeLength * 2
+    pdi = settings.intTime
+    pilot = bool(getattr(settings, "pilotTRKflag", 0))
+    tau1code, tau2code = calc_loop_coef(settings.dllNoiseBandwidth, settings.dllDampingRatio, 1.0)
+    pf3, pf2, pf1 = calc_loop_coef_carr(settings, "a")
+    n_total = if_bytes.shape[0] // 2
+    fields = TRACK_FIELDS + ("Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L")
+    results = []
+    for _ in channel:
+        tr = SimpleNamespace(status="-", PRN=0)
+        for f in fields:
+            setattr(tr, f, np.zeros(n_ep))
+        results.append(tr)
+    for tr, ch in zip(results, channel):
+        if ch.PRN == 0:
+            continue
+        tr.PRN = ch.PRN
+        pos = int(settings.skipNumberOfBytes + ch.codePhase)
+        tables = [pad_code(generate_l2c_code(ch.PRN, "CM", int(settings.codeLength)))]
+        cl_phase = 0
+        if pilot:
+            cl_phase = int(ch.CLCodePhase)
+            tables.append(pad_code(generate_l2c_code(ch.PRN, "CL", int(settings.CLCodeLength))))
+        code_freq = settings.codeFreqBasis * 2
+        rem_code = 0.0
+        carr_freq = carr_basis = ch.acquiredFreq
+        rem_carr = 0.0
+        old_code_nco = old_code_err = 0.0
+        d2_carr = d_carr = 0.0
+        for e in range(n_ep):
+            step = code_freq / settings.samplingFreq
+            tr.absoluteSample[e] = pos + 1 - rem_code / step
+            n = blksize_for(code_length, rem_code, step)
+            if pos + n > n_total:
+                return results
+            tr.remCodePhase[e] = rem_code / 2
+            tr.remCarrPhase[e] = rem_carr
+            off = [0, int(code_length) * (cl_phase - 1)] if pilot else None
+            sums, rem_code, rem_carr = correlate_block(raw_from_if(if_bytes, pos, n), tables, rem_code, step, d, carr_freq,
+                                                       rem_carr, settings.samplingFreq, code_length, table_offset=off)
+            pos += n
+            i_e, q_e, i_p, q_p, i_l, q_l = (float(v) for v in sums[0])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                carr_err = float(np.arctan(np.float64(q_p) / np.float64(i_p)) / (2.0 * math.pi))
+            code_err = (math.sqrt(i_e ** 2 + q_e ** 2) - math.sqrt(i_l ** 2 + q_l ** 2)) / \
+                       (math.sqrt(i_e ** 2 + q_e ** 2) + math.sqrt(i_l ** 2 + q_l ** 2))
+            if pilot:
+                pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = (float(v) for v in sums[1])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    carr_err = (carr_err + float(np.arctan(np.float64(pq_p) / np.float64(pi_p)) / (2.0 * math.pi))) / 2
+                code_err_cl = (math.sqrt(pi_e ** 2 + pq_e ** 2) - math.sqrt(pi_l ** 2 + pq_l ** 2)) / \
+                              (math.sqrt(pi_e ** 2 + pq_e ** 2) + math.sqrt(pi_l ** 2 + pq_l ** 2))
+                code_err = (code_err + code_err_cl) / 2
+                cl_phase += 1
+                if cl_phase >= 76:
+                    cl_phase = 1
+                tr.Pilot_I_E[e], tr.Pilot_Q_E[e], tr.Pilot_I_P[e] = pi_e, pq_e, pi_p
+                tr.Pilot_Q_P[e], tr.Pilot_I_L[e], tr.Pilot_Q_L[e] = pq_p, pi_l, pq_l
+            d2_carr = d2_carr + carr_err * pf3
+            d_carr = d2_carr + carr_err * pf2 + d_carr
+            carr_nco = d_carr + carr_err * pf1
+            tr.carrFreq[e] = carr_freq
+            carr_freq = carr_basis + carr_nco
+            code_nco = old_code_nco + (tau2code / tau1code) * (code_err - old_code_err) + code_err * (pdi / tau1code)
+            old_code_nco, old_code_err = code_nco, code_err
+            tr.codeFreq[e] = code_freq / 2
+            code_freq = settings.codeFreqBasis * 2 - code_nco
+            tr.dllDiscr[e], tr.dllDiscrFilt[e] = code_err / 2, code_nco / 2
+            tr.pllDiscr[e], tr.pllDiscrFilt[e] = carr_err, carr_nco
+            tr.I_E[e], tr.I_P[e], tr.I_L[e] = i_e, i_p, i_l
+            tr.Q_E[e], tr.Q_P[e], tr.Q_L[e] = q_e, q_p, q_l
+        tr.status = ch.status
+    return results
