@@ -156,16 +156,26 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.pll_kind = mxGetField(s, 0, "pllKind") ? (int32_t)field(s, "pllKind") : GC_PLL_2ND_ORDER;
     p.skip_samples = (int64_t)field(s, "skipNumberOfBytes");
     p.n_epochs = (int32_t)field(s, "msToProcess");
-    /* channels: 5 x nch rows = channel index, PRN, acquiredFreq, codeFreq, codePhase (preRun.m:65-73) */
+    /* optional (API v2): pilot handling of the multi-component packages, see gc_track_params in gnsscorr.h */
+    if (mxGetField(s, 0, "pilotCombine")) p.pilot_combine = (int32_t)field(s, "pilotCombine");
+    if (mxGetField(s, 0, "pf1")) { p.pf1 = field(s, "pf1"); p.pf2 = field(s, "pf2"); p.pf3 = field(s, "pf3"); }
+    if (mxGetField(s, 0, "numEpochs")) p.n_epochs = (int32_t)field(s, "numEpochs"); /* NumToProcess of the 4/10/20-ms packages */
+    if (mxGetField(s, 0, "pllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "pllWeight")); p.pll_weight[0] = w[0]; p.pll_weight[1] = w[1]; }
+    if (mxGetField(s, 0, "dllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "dllWeight")); p.dll_weight[0] = w[0]; p.dll_weight[1] = w[1]; }
+    if (mxGetField(s, 0, "dllScale")) p.dll_scale = field(s, "dllScale");
+    if (mxGetField(s, 0, "tablePhaseCount")) p.table_phase_count = (int32_t)field(s, "tablePhaseCount");
+    /* channels: 5 (or 6) x nch rows = channel index, PRN, acquiredFreq, codeFreq, codePhase[, CLCodePhase] (preRun.m:65-73) */
+    const int crow = (int)mxGetM(prhs[3]);
     int nch = (int)mxGetN(prhs[3]);
     const double* c = mxGetDoubles(prhs[3]);
     gc_channel_init* init = (gc_channel_init*)mxCalloc((size_t)nch, sizeof *init);
     for (int i = 0; i < nch; ++i) {
-      init[i].channel = (int32_t)c[5 * i];
-      init[i].prn = (int32_t)c[5 * i + 1];
-      init[i].acquired_freq = c[5 * i + 2];
-      init[i].code_freq = c[5 * i + 3];
-      init[i].code_phase = (int64_t)c[5 * i + 4];
+      init[i].channel = (int32_t)c[crow * i];
+      init[i].prn = (int32_t)c[crow * i + 1];
+      init[i].acquired_freq = c[crow * i + 2];
+      init[i].code_freq = c[crow * i + 3];
+      init[i].code_phase = (int64_t)c[crow * i + 4];
+      if (crow >= 6) init[i].table_phase = (int32_t)c[crow * i + 5];
     }
     const mwSize dims[3] = {(mwSize)p.n_epochs, GC_TRK_NFIELDS, (mwSize)nch};
     plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); /* trk(epoch, field, channel) */
