@@ -89,6 +89,10 @@ struct PassArgs {
   // POST_ABS_ACC: batch index = bin; loops over nhops transforms in*, accumulates |.|/n
   float* acc_out;
   int acc_add;  // POST_ABS_ACC: add to what acc_out already holds (second code arm of the same PRN)
+  float acc_scale;  // POST_ABS_ACC: weight of this arm (B1C: sqrt(11/40), sqrt(29/40)); 0 means 1
+  // PRE_MUL_CONJ with circular spectrum shifts (the circshift search family): batch tb reads input transform
+  // tb / shift_bins shifted by tb % shift_bins natural-frequency bins; n1, n2 give the [k1][k2] storage order
+  int shift_bins, n1, n2;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -145,7 +149,18 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
         } else if (a.pre == PRE_CODE) {
           val = (pos < a.spc) ? make_float2((float)a.codes[tb * a.spc + pos], 0.f) : make_float2(0.f, 0.f);
         } else {
-          val = a.in[tb * a.in_batch_stride + pos];
+          if (a.pre == PRE_MUL_CONJ && a.shift_bins > 0) {
+            // circshift(X, s): Y[k] = X[(k - s) mod n] in natural frequency order; storage position of frequency
+            // k = k1 + n1*k2 is k1*n2 + k2
+            const long long src = tb / a.shift_bins;
+            const int sft = (int)(tb % a.shift_bins);
+            const int k1 = (int)(pos / a.n2), k2 = (int)(pos % a.n2);
+            int k = k1 + a.n1 * k2 - sft;
+            if (k < 0) k += a.n;
+            val = a.in[src * a.in_batch_stride + (long long)(k % a.n1) * a.n2 + k / a.n1];
+          } else {
+            val = a.in[tb * a.in_batch_stride + pos];
+          }
           if (a.pre == PRE_MUL_CONJ) {
             const float2 o = a.other[pos];
             val = cmul(val, make_float2(o.x, -o.y));
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       if (v >= a.nvec) continue;
       const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
       float* dstp = a.acc_out + batch * a.n + pos;
-      *dstp = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n;
+      *dstp = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * (a.acc_scale != 0.0f ? a.acc_scale : 1.0f);
     }
   }
 }
@@ -322,6 +337,40 @@ __global__ __launch_bounds__(256) void fine_kernel(const int8_t* __restrict__ x,
   }
 }
 
+// One workgroup per row: maximum and its first position (MATLAB's max returns the first maximum).
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r, int ncols, float* vmax, int* amax) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const float* row = r + (long long)blockIdx.x * ncols;
+  float best = -1.0f;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < ncols; i += 256) {
+    const float v = row[i];
+    if (v > best) {
+      best = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const float v = sv[threadIdx.x + off];
+      const int i = si[threadIdx.x + off];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
+        sv[threadIdx.x] = v;
+        si[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    vmax[blockIdx.x] = sv[0];
+    amax[blockIdx.x] = si[0];
+  }
+}
+
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   const size_t smem = (size_t)2 * a.len * a.cols * sizeof(float2);
@@ -352,11 +401,16 @@ struct AcqScratch {
   double* fine = nullptr;     // fine sums
   long long nbh = 0;
   int nprn = 0, nbins = 0;
+  // circshift search family (gc_acq_shift_*)
+  gc_acq_shift_params shift;  // what `sig` currently holds (n == 0: nothing)
+  float* rowmax = nullptr;
+  int* rowarg = nullptr;
+  int shift_rows = 0;
 };
 
 void free_scratch(AcqScratch* s) {
   if (!s) return;
-  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->codes, s->sums, s->fine};
+  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->codes, s->sums, s->fine, s->rowmax, s->rowarg};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -379,6 +433,7 @@ static int ensure_scratch(gc_context* ctx, int n, long long nbh, int nprn, int n
   free_scratch(s);
   ctx->acq_scratch = nullptr;
   s = new AcqScratch();
+  std::memset(&s->shift, 0, sizeof s->shift);
   if (!make_plan(n, &s->plan)) {
     delete s;
     gc_set_error("acquisition: FFT size %d is not of the form 2^a 3^b 5^c (or its factors are too large)", n);
@@ -481,6 +536,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   AcqScratch* s = nullptr;
   int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn * narms, nbins, spc, &s);
   if (rc) return rc;
+  s->shift.n = 0;  // the signal spectra of a circshift search, if any, are overwritten below
   const Plan& pl = s->plan;
 
   // sigPower = sqrt(var(x(1:spc)) * spc), var normalised by N-1 (acquisition.m:151)
@@ -570,6 +626,138 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     out[ip].peak_metric = (double)peak / sig_power / H;  // :200
     out[ip].coarse_freq = p->intermediate_freq + p->search_band - p->search_step * harg[0];
   }
+  return GC_OK;
+}
+
+
+// ---- circshift search family ------------------------------------------------------------------------------
+// GPS_L2C/include/acquisition.m:40-75, BDS/B1I/include/acquisition.m:76-123, BDS/B1C/include/acquisition.m:137-170:
+// the signal block is mixed with a handful of carriers and transformed ONCE; Doppler bins are circular shifts of
+// that spectrum before the product with the code spectrum and the inverse transform.
+extern "C" int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* p) {
+  if (!ctx || !p || p->n <= 0 || p->n_signals <= 0 || p->n_carriers <= 0 || p->n_bins <= 0 || p->first_sample < 0 ||
+      p->n_arms_max < 1 || p->n_arms_max > 4) {
+    gc_set_error("gc_acq_shift_prepare: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
+    gc_set_error("gc_acq_shift_prepare: needs an int8 I/Q IF buffer");
+    return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  }
+  if ((uint64_t)p->first_sample + (uint64_t)p->n_signals * p->n > ctx->if_nsamples) {
+    gc_set_error("gc_acq_shift_prepare: needs %lld samples from %lld, buffer holds %llu", (long long)p->n_signals * p->n,
+                 (long long)p->first_sample, (unsigned long long)ctx->if_nsamples);
+    return GC_E_RANGE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  const int rows = p->n_carriers * p->n_signals * p->n_bins;
+  AcqScratch* s = nullptr;
+  int rc = ensure_scratch(ctx, p->n, rows, p->n_arms_max, rows, p->n, &s);
+  if (rc) return rc;
+  if (s->shift_rows < rows) {
+    if (s->rowmax) (void)hipFree(s->rowmax);
+    if (s->rowarg) (void)hipFree(s->rowarg);
+    s->rowmax = nullptr;
+    s->rowarg = nullptr;
+    s->shift_rows = 0;
+    if (hipMalloc((void**)&s->rowmax, sizeof(float) * rows) != hipSuccess || hipMalloc((void**)&s->rowarg, sizeof(int) * rows) != hipSuccess) {
+      gc_set_error("gc_acq_shift_prepare: device allocation failed");
+      return GC_E_NOMEM;
+    }
+    s->shift_rows = rows;
+  }
+  PassArgs base;
+  std::memset(&base, 0, sizeof base);
+  base.if_base = (const int8_t*)ctx->d_if;
+  base.first_sample = p->first_sample;
+  base.spc = p->n;              // signal k starts k*n samples later; the carrier phase restarts with every block
+  base.nhops = p->n_signals;
+  base.f0 = p->carrier_f0;
+  base.fstep = -p->carrier_step;  // kernel: f_b = f0 - fstep*b
+  base.fs = p->sampling_freq;
+  rc = forward(ctx, s, base, PRE_IF_CARRIER, (long long)p->n_carriers * p->n_signals, s->sig);
+  if (rc) return rc;
+  s->shift = *p;
+  return GC_OK;
+}
+
+extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
+                                   float* row_max, int32_t* row_argmax) {
+  AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
+  if (!s || s->shift.n <= 0 || s->shift.n != s->n) {
+    gc_set_error("gc_acq_shift_search: call gc_acq_shift_prepare first");
+    return GC_E_STATE;
+  }
+  const gc_acq_shift_params& p = s->shift;
+  if (narms < 1 || narms > p.n_arms_max || !codes || !row_max || !row_argmax) {
+    gc_set_error("gc_acq_shift_search: bad arguments");
+    return GC_E_INVALID;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  const Plan& pl = s->plan;
+  const int rows = p.n_carriers * p.n_signals * p.n_bins;
+  GC_HIP(hipMemcpyAsync(s->codes, codes, (size_t)narms * p.n, hipMemcpyHostToDevice, ctx->stream));
+  PassArgs base;
+  std::memset(&base, 0, sizeof base);
+  base.spc = p.n;
+  base.nhops = 1;
+  base.codes = s->codes;
+  int rc = forward(ctx, s, base, PRE_CODE, narms, s->codespec);
+  if (rc) return rc;
+  for (int arm = 0; arm < narms; ++arm) {
+    PassArgs a = base;
+    a.n = pl.n;
+    a.tw = s->tw;
+    a.inverse = 1;
+    fill_sub(a, pl.p2);
+    a.nvec = pl.n1;
+    a.estride = 1;
+    a.vstride = pl.n2;
+    a.cols = choose_cols(a.len);
+    a.pre = PRE_MUL_CONJ;
+    a.post = POST_TWIDDLE;
+    a.in = s->sig;
+    a.in_batch_stride = pl.n;
+    a.other = s->codespec + (size_t)arm * pl.n;
+    a.out = s->tmp;
+    a.out_batch_stride = pl.n;
+    a.shift_bins = p.n_bins;
+    a.n1 = pl.n1;
+    a.n2 = pl.n2;
+    rc = launch_pass(ctx, a, rows);
+    if (rc) return rc;
+    fill_sub(a, pl.p1);
+    a.nvec = pl.n2;
+    a.estride = pl.n2;
+    a.vstride = 1;
+    a.cols = choose_cols(a.len);
+    a.pre = PRE_NONE;
+    a.shift_bins = 0;
+    a.post = POST_ABS_ACC;
+    a.in = s->tmp;
+    a.acc_out = s->results;
+    a.acc_add = arm > 0;
+    a.acc_scale = arm_weight ? (float)arm_weight[arm] : 1.0f;
+    rc = launch_pass(ctx, a, rows);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(rowmax_kernel, dim3(rows), dim3(256), 0, ctx->stream, s->results, p.n, s->rowmax, s->rowarg);
+  GC_HIP(hipGetLastError());
+  GC_HIP(hipMemcpyAsync(row_max, s->rowmax, sizeof(float) * rows, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipMemcpyAsync(row_argmax, s->rowarg, sizeof(int) * rows, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  return GC_OK;
+}
+
+extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
+  AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
+  if (!s || s->shift.n <= 0 || !out || row < 0 || row >= s->shift.n_carriers * s->shift.n_signals * s->shift.n_bins) {
+    gc_set_error("gc_acq_shift_row: bad arguments or nothing searched yet");
+    return GC_E_INVALID;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipMemcpyAsync(out, s->results + (size_t)row * s->shift.n, sizeof(float) * s->shift.n, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
   return GC_OK;
 }
 

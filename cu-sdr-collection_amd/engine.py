@@ -170,6 +170,29 @@ class Engine:
                                                   codes.ctypes.data_as(C.c_void_p), res))
         return list(res)
 
+    def acq_shift_prepare(self, params: L.gc_acq_shift_params):
+        self._shift = params
+        L.check(self._lib.gc_acq_shift_prepare(self._ctx, C.byref(params)))
+
+    def acq_shift_search(self, codes: np.ndarray, arm_weight=None):
+        """codes: int8 [narms, n].  Returns (row_max float32[rows], row_argmax int32[rows])."""
+        p = self._shift
+        c8 = np.ascontiguousarray(codes, dtype=np.int8).reshape(-1, p.n)
+        rows = p.n_carriers * p.n_signals * p.n_bins
+        rmax = np.empty(rows, dtype=np.float32)
+        rarg = np.empty(rows, dtype=np.int32)
+        w = None
+        if arm_weight is not None:
+            w = (C.c_double * c8.shape[0])(*[float(v) for v in arm_weight])
+        L.check(self._lib.gc_acq_shift_search(self._ctx, c8.shape[0], c8.ctypes.data_as(C.c_void_p), w,
+                                              rmax.ctypes.data_as(C.POINTER(C.c_float)), rarg.ctypes.data_as(C.POINTER(C.c_int32))))
+        return rmax, rarg
+
+    def acq_shift_row(self, row: int) -> np.ndarray:
+        out = np.empty(self._shift.n, dtype=np.float32)
+        L.check(self._lib.gc_acq_shift_row(self._ctx, int(row), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def debug_fft(self, x: np.ndarray, inverse: bool = False) -> np.ndarray:
         """x: complex64 [nbatch, n].  The library's FFT (test hook)."""
         x = np.ascontiguousarray(x, dtype=np.complex64)

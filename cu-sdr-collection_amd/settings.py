@@ -114,6 +114,10 @@ def initSettings_BDS_B1I() -> SimpleNamespace:
     s.samplingFreq = 18e6            # :72
     s.codeFreqBasis = 2.046e6        # :73
     s.codeLength = 2046              # :76
+    s.acqSatelliteList = list(range(6, 59))  # :83
+    s.acqSearchBand = 10             # :85 (kHz in this package's acquisition.m)
+    s.acqThreshold = 2               # :87
+    s.stepSize = 125                 # :94
     s.dllDampingRatio = 0.7          # :99
     s.dllNoiseBandwidth = 4          # :100
     s.dllCorrelatorSpacing = 0.5     # :101

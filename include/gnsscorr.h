@@ -240,6 +240,33 @@ int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, i
 int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code,
                          int code_phase, double coarse_freq, double* carr_freq);
 
+/* ---- acquisition, circshift search family (replaces GPS_L2C/include/acquisition.m:40-75,
+ * BDS/B1I/include/acquisition.m:76-123, BDS/B1C/include/acquisition.m:137-170): the signal block(s) are mixed with
+ * n_carriers carriers and transformed once (gc_acq_shift_prepare); per PRN every Doppler bin is a circular shift of
+ * that spectrum by 0 .. n_bins-1 positions before the product with the code spectrum and the inverse transform
+ * (gc_acq_shift_search).  Rows are ordered ((carrier * n_signals + signal) * n_bins + bin). */
+typedef struct gc_acq_shift_params {
+  double sampling_freq;      /* settings.samplingFreq */
+  double carrier_f0;         /* first wipe-off carrier in Hz: initFreq */
+  double carrier_step;       /* carrier i = carrier_f0 + i*carrier_step (B1I: +freqResolution/Nshifts, L2C: minus) */
+  int64_t first_sample;      /* signal block k starts at first_sample + k*n */
+  int32_t n;                 /* samplesPerBlock = transform length (2^a 3^b 5^c) */
+  int32_t n_signals;         /* consecutive signal blocks (B1I: signal1, signal2) */
+  int32_t n_carriers;        /* Nshifts */
+  int32_t n_bins;            /* numberOfFrqBins: circshift(IQfreqDom, bin), bin = 0 .. n_bins-1 */
+  int32_t n_arms_max;        /* code components per PRN that gc_acq_shift_search will be given (1..4) */
+  int32_t reserved;
+} gc_acq_shift_params;
+
+int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* p);
+/* codes: int8 [narms][n], the local replica already sampled and zero-padded to n by the caller
+ * ([cmCodesTable(1:spc) zeros], acquisition.m:44-45).  results(row, :) = sum_arm weight_arm * abs(ifft(shifted
+ * spectrum .* conj(fft(code_arm)))) (weights: NULL = 1; B1C sqrt(11/40), sqrt(29/40), acquisition.m:186-187).
+ * Returns each row's maximum and its 0-based first position; the rows stay on the device for gc_acq_shift_row. */
+int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
+                        float* row_max, int32_t* row_argmax);
+int gc_acq_shift_row(gc_context* ctx, int row, float* out /* n floats */);
+
 /* Test hook (host only, no GPU): first sample i in [0, n) whose ramp value a + i*step is within eps chips of
  * an integer, or -1 — the exact near-tie analysis that lets the kernels skip their per-chunk filters. */
 long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps);

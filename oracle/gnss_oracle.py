@@ -998,3 +998,82 @@ def tracking_l2c(if_bytes: np.ndarray, channel, settings):
             tr.Q_E[e], tr.Q_P[e], tr.Q_L[e] = q_e, q_p, q_l
         tr.status = ch.status
     return results
+
+
+# --------------------------------------------------------------------------------------
+# Acquisition, circshift family — float64 restatements
+# --------------------------------------------------------------------------------------
+def _if_complex(if_bytes: np.ndarray, first: int, n: int) -> np.ndarray:
+    seg = if_bytes[2 * first:2 * (first + n)].astype(np.float64)
+    return seg[0::2] + 1j * seg[1::2]
+
+
+def _second_peak_ratio(corr: np.ndarray, code_phase: int, exclude: int, period: int) -> float:
+    e1, e2 = code_phase - exclude, code_phase + exclude
+    if e1 < 2:
+        rng = np.arange(e2, period + e1 + 1)
+    elif e2 >= period:
+        rng = np.arange(e2 - period + 1, e1 + 1)
+    else:
+        rng = np.concatenate([np.arange(1, e1 + 1), np.arange(e2, period + 1)])
+    return float(np.max(corr[rng - 1]))
+
+
+def acquisition_b1i(if_bytes: np.ndarray, settings, first_sample: int = 0):
+    """BDS/B1I/include/acquisition.m:34-176 (resampling off, stepSize = 125 -> Nshifts = 2): two consecutive 4-ms
+    blocks, per carrier shift one FFT each; per PRN and Doppler bin circshift(spectrum, bin-1) .* conj(fft(local
+    code)), ifft, abs; the (shift, block, bin) with the largest peak wins by the sequential rule of :98-119; metric =
+    peak / second peak outside +-1 chip within one code period (:139-160)."""
+    ncodes, nblocks = 2, 4
+    fs = settings.samplingFreq
+    spb = int(matlab_round(fs / (settings.codeFreqBasis / (nblocks * settings.codeLength))))
+    sig = [_if_complex(if_bytes, first_sample, spb), _if_complex(if_bytes, first_sample + spb, spb)]
+    ts = 1.0 / fs
+    phase_points = np.arange(spb) * 2 * math.pi * ts
+    freq_res = fs / spb
+    nbins = int(matlab_round(settings.acqSearchBand * 1e3 / freq_res)) + 1
+    steps = np.arange(1, freq_res / 2 + 1e-9, 0.25)
+    steps = steps[np.remainder(freq_res, steps) == 0]
+    diff = steps - settings.stepSize
+    m = int(np.argmin(np.abs(diff)))
+    step = settings.stepSize if settings.stepSize == freq_res else (steps[m - 1] if diff[m] > 0 else steps[m])
+    nshifts = int(freq_res / step)
+    spc2 = int(matlab_round(fs / (settings.codeFreqBasis / (ncodes * settings.codeLength))))
+    tc = 1.0 / settings.codeFreqBasis
+    init_freq = settings.IF + (settings.acqSearchBand / 2) * 1000
+    acq = SimpleNamespace(carrFreq=np.zeros(58), codePhase=np.zeros(58), peakMetric=np.zeros(58))
+    chip = int(matlab_round(fs / settings.codeFreqBasis))
+    spectra = []
+    for it in range(nshifts):
+        f = init_freq + it * (freq_res / nshifts)
+        carr = np.exp(-1j * f * phase_points)
+        spectra.append([np.fft.fft(carr * s) for s in sig])
+    for prn in settings.acqSatelliteList:
+        ca = generate_b1i_code(prn)
+        ca2 = np.concatenate([ca, ca])
+        idx = np.ceil(ts * np.arange(1, spc2 + 1) / tc).astype(np.int64)
+        idx[-1] = ncodes * 2046
+        local = np.concatenate([ca2[idx - 1], np.zeros(spb // ncodes)])
+        code_fd = np.conj(np.fft.fft(local))
+        prevmax, corr_vec, freq_shift, bin_idx = 0.0, np.zeros(spb), 0, 0
+        for it in range(nshifts):
+            for b in range(1, nbins + 1):
+                if b == nbins and it > 0:
+                    continue
+                r1 = np.abs(np.fft.ifft(np.roll(spectra[it][0], b - 1) * code_fd))
+                r2 = np.abs(np.fft.ifft(np.roll(spectra[it][1], b - 1) * code_fd))
+                p1, p2 = r1.max(), r2.max()
+                if p1 > prevmax or p2 > prevmax:
+                    if p1 > p2:
+                        prevmax, corr_vec = p1, r1
+                    else:
+                        prevmax, corr_vec = p2, r2
+                    freq_shift, bin_idx = it + 1, b
+        code_phase = int(np.argmax(corr_vec)) + 1
+        max_peak = float(corr_vec[code_phase - 1])
+        second = _second_peak_ratio(corr_vec, code_phase, chip, spb // nblocks)
+        acq.peakMetric[prn - 1] = max_peak / second
+        if max_peak / second > settings.acqThreshold:
+            acq.codePhase[prn - 1] = code_phase
+            acq.carrFreq[prn - 1] = init_freq - freq_res * (bin_idx - 1) + (freq_res / nshifts) * (freq_shift - 1)
+    return acq

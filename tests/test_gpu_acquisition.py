@@ -147,3 +147,34 @@ def test_long_fft_sizes(engine):
         got = engine.debug_fft(x)
         ref = np.fft.fft(x.astype(np.complex128), axis=1)
         assert np.max(np.abs(got - ref)) < 3e-6 * np.max(np.abs(ref)) * np.log2(n), n
+
+
+def test_b1i_circshift_family_acquisition(engine):
+    """BDS/B1I/include/acquisition.m: Doppler bins as circular shifts of one 72 000-point signal
+    spectrum per 4-ms block and carrier shift; first/second-peak metric.  codePhase, the winning (shift, block, bin)
+    and therefore carrFreq must equal the float64 oracle exactly; the metric within float32 FFT accuracy."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B1I
+    S = initSettings_BDS_B1I()
+    fs = S.samplingFreq
+    S.acqSatelliteList = [7, 12, 23, 30]          # 12 is absent from the scene
+    rng = np.random.default_rng(81)
+    sats = [P.synth.SatSpec(prn=p, doppler=d, code_phase_samples=float(rng.uniform(0, 18000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=c) for p, d, c in ((7, 2310.0, 50.0), (23, -3890.0, 47.0), (30, 40.0, 52.0))]
+    n = int(0.010 * fs)
+    iq = P.synth.generate_if(sats, n, fs, S.IF, P.codes.generateCAcode53, S.codeFreqBasis, 2046, seed=82, carrier_ratio=763.0 * 2,
+                             bit_periods=20)
+    engine.load_if(iq, fs=fs)
+    got = P.acq_shift.acquisition_B1I(engine, S, first_sample=0)
+    ref = O.acquisition_b1i(iq, S, 0)
+    for prn in S.acqSatelliteList:
+        k = prn - 1
+        assert got.codePhase[k] == ref.codePhase[k], prn
+        assert got.carrFreq[k] == ref.carrFreq[k], prn
+        assert abs(got.peakMetric[k] - ref.peakMetric[k]) < 2e-3 * ref.peakMetric[k], prn
+    for s in sats:
+        k = s.prn - 1
+        assert got.peakMetric[k] > S.acqThreshold
+        assert abs(got.carrFreq[k] - (S.IF + s.doppler)) <= 62.5 + 1e-9           # half the 125-Hz grid
+        assert abs((got.codePhase[k] - 1 - s.code_phase_samples) % 18000) < 3 or abs((got.codePhase[k] - 1 - s.code_phase_samples) % 18000 - 18000) < 3
+    assert got.carrFreq[11] == 0 and got.peakMetric[11] < S.acqThreshold
