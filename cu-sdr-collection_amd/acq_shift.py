@@ -106,3 +106,141 @@ def acquisition_B1I(engine, settings, first_sample: int | None = None):
             acq.codePhase[prn - 1] = code_phase
             acq.carrFreq[prn - 1] = init_freq - freq_res * (bin_idx - 1) + (freq_res / nshifts) * (freq_shift - 1)  # :168
     return acq
+
+
+# ---------------------------------------------------------------------------------------------
+# GPS L2C
+# ---------------------------------------------------------------------------------------------
+def acquisition_L2C(engine, settings, first_sample: int | None = None):
+    """acqResults = acquisition(longSignal, settings) of GPS/GPS_L2C/include/acquisition.m: CM search over a
+    40-ms block (Nblocks = 2), then — with pilotTRKflag — which of the 75 CL segments the CM period found lies in."""
+    if first_sample is None:
+        first_sample = int(settings.skipNumberOfBytes)
+    nblocks = 2                                                                    # :13
+    fs = settings.samplingFreq
+    spc = _round(fs / (settings.codeFreqBasis / settings.codeLength))              # :14-15
+    chip = _round(fs / settings.codeFreqBasis)                                     # :16 samplesPerChip
+    spb = spc * nblocks                                                            # :17
+    ts = 1.0 / fs
+    freq_res = fs / spb                                                            # :22
+    nbins = _round(settings.acqSearchBand * 1e3 / freq_res) + 1                    # :23
+    nshifts = int(freq_res / settings.acqStep)                                     # :25
+    init_freq = settings.IF + (settings.acqSearchBand / 2) * 1000                  # :33
+    p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=init_freq, carrier_step=-(freq_res / nshifts), first_sample=first_sample,
+                              n=spb, n_signals=1, n_carriers=nshifts, n_bins=nbins, n_arms_max=1)
+    engine.acq_shift_prepare(p)
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(32))
+    tc = 1.0 / (settings.codeFreqBasis * 2)
+    for prn in settings.acqSatelliteList:
+        cm = codes.generateCMcode(prn, int(settings.codeLength))
+        table = _sampled(cm, spc, ts, tc, False, int(settings.codeLength) * 2, first_one=True)   # makeCMTable.m
+        local = np.concatenate([table, np.zeros(spc, dtype=np.int8)])               # :44
+        rmax, _ = engine.acq_shift_search(local[None, :])
+        rmax = rmax.reshape(nshifts, nbins)
+        prevmax, best, freq_shift, bin_idx = 0.0, None, 0, 0
+        for it in range(nshifts):                                                  # :46-66
+            for b in range(nbins):
+                if b == nbins - 1 and it > 0:
+                    continue
+                if float(rmax[it, b]) > prevmax:
+                    prevmax, best = float(rmax[it, b]), (it, b)
+                    freq_shift, bin_idx = it + 1, b + 1
+        if best is None:
+            continue
+        corr = engine.acq_shift_row(best[0] * nbins + best[1])
+        code_phase = int(np.argmax(corr)) + 1                                      # :72
+        max_peak = float(corr[code_phase - 1])
+        second = _second_peak(corr, code_phase, chip, spb // nblocks)
+        acq.peakMetric[prn - 1] = max_peak / second                                # :94
+        if max_peak / second > settings.acqThreshold:                              # :97
+            f = init_freq - freq_res * (bin_idx - 1) - (freq_res / nshifts) * (freq_shift - 1)   # :101
+            acq.carrFreq[prn - 1] = f
+            acq.codePhase[prn - 1] = code_phase
+            if getattr(settings, "pilotTRKflag", 0) == 1:                          # :140-166, 75 short correlations
+                raw = engine.read_if(first_sample + code_phase - 1, spc).astype(np.float64)
+                sig = raw[0::2] + 1j * raw[1::2]
+                sig = sig - np.mean(sig)
+                carr = np.exp(-1j * f * (np.arange(spc) * 2 * math.pi * ts))
+                cl = codes.generateCLcode(prn, int(settings.CLCodeLength)).astype(np.float64)
+                idx = np.ceil(ts * np.arange(spc) / tc).astype(np.int64)
+                idx[0] = 1
+                idx[-1] = int(settings.codeLength) * (1 if settings.acqCohT <= 10 else 2)
+                power = np.empty(75)
+                for ind in range(75):
+                    power[ind] = abs(np.sum(sig * cl[idx - 1 + int(settings.codeLength) * 2 * ind] * carr))
+                acq.CLCodePhase[prn - 1] = int(np.argmax(power)) + 1
+    return acq
+
+
+# ---------------------------------------------------------------------------------------------
+# BDS B1C
+# ---------------------------------------------------------------------------------------------
+def _b1c_table(code: np.ndarray, settings, spc: int) -> np.ndarray:
+    """makeDataTable.m / makePilotTable.m: BOC(1,1) half-chip code sampled at ceil(ts*(1:spc)/tc), first index
+    forced to 1, last to 2*codeLength."""
+    return _sampled(code, spc, 1.0 / settings.samplingFreq, 1.0 / settings.codeFreqBasis / 2, True,
+                    int(settings.codeLength) * 2, first_one=True)
+
+
+def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: int | None = None):
+    """acqResults = acquisition(longSignal, settings) of BDS/B1C/include/acquisition.m (resampling off): one
+    (10 + acqCohT)-ms spectrum, Doppler bins as circular shifts, data and pilot BOC(1,1) replicas combined
+    sqrt(11):sqrt(29), GLRT-style metric peak/sigPower, then a 25-Hz fine search on one code period.
+    n_long = length(longSignal) (the reference pulls the code phase back by one period if too close to its end)."""
+    if first_sample is None:
+        first_sample = int(settings.skipNumberOfBytes)
+    fs = settings.samplingFreq
+    spc = _round(fs / (settings.codeFreqBasis / settings.codeLength))              # :108-109
+    xlen = _round(spc / 10 * settings.acqCohT)                                      # :111 samplesXmsLen
+    n = _round(spc / 10 * (10 + settings.acqCohT))                                  # :113 len10PlusXms
+    ts = 1.0 / fs
+    nbins = _round(settings.acqSearchBand * 2 / settings.acqStep) + 1              # :120
+    pilot = getattr(settings, "pilotACQflag", 0) == 1
+    fine_step = 25                                                                 # :129
+    nfine = _round(settings.acqStep / 25) * 2 + 1                                  # :130
+    if n_long is None:
+        n_long = int(engine.if_buffer()[1]) - first_sample
+    raw = engine.read_if(first_sample, xlen).astype(np.float64)                    # sigPower, :138
+    x = raw[0::2] + 1j * raw[1::2]
+    sig_power = math.sqrt(np.var(x, ddof=1) * xlen)
+    init_freq = settings.IF + settings.acqSearchBand                               # :141
+    p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=init_freq, carrier_step=0.0, first_sample=first_sample,
+                              n=n, n_signals=1, n_carriers=1, n_bins=nbins, n_arms_max=2)
+    engine.acq_shift_prepare(p)
+    nmax = max(settings.acqSatelliteList)
+    acq = SimpleNamespace(carrFreq=np.zeros(nmax), codePhase=np.zeros(nmax), peakMetric=np.zeros(nmax))
+    fine_phase = np.arange(spc) * 2 * math.pi * ts
+    for prn in settings.acqSatelliteList:
+        dtab = _b1c_table(codes.generateDataBOC11(prn), settings, spc)
+        arms = [np.concatenate([dtab[:xlen], np.zeros(n - xlen, dtype=np.int8)])]   # :155-156
+        weights = None
+        if pilot:
+            ptab = _b1c_table(codes.generatePilotBOC11(prn), settings, spc)
+            arms.append(np.concatenate([ptab[:xlen], np.zeros(n - xlen, dtype=np.int8)]))
+            weights = [math.sqrt(11) / math.sqrt(40), math.sqrt(29) / math.sqrt(40)]   # :186-187
+        rmax, rarg = engine.acq_shift_search(np.stack(arms), weights)
+        bin_idx = int(np.argmax(rmax)) + 1                                         # :193 max(max(results,[],2))
+        sel_freq = init_freq - (bin_idx - 1) * settings.acqStep                    # :194
+        # [peakSize, codePhase] = max(max(results)): column maxima, first column holding the global maximum
+        peak = float(rmax.max())
+        code_phase = int(min(int(rarg[r]) for r in range(nbins) if rmax[r] == rmax.max())) + 1
+        acq.peakMetric[prn - 1] = peak / sig_power                                 # :199
+        if code_phase + spc - 1 > n_long:                                          # :232-234
+            code_phase -= spc
+        if acq.peakMetric[prn - 1] > settings.acqThreshold:
+            raw = engine.read_if(first_sample + code_phase - 1, spc).astype(np.float64)
+            s0 = raw[0::2] + 1j * raw[1::2]                                         # the reference does not remove the mean here
+            xc = s0 * dtab
+            xp = s0 * ptab if pilot else None
+            fine = np.empty(nfine)
+            freqs = np.empty(nfine)
+            for k in range(nfine):                                                 # :242-250
+                freqs[k] = sel_freq + settings.acqStep - fine_step * k
+                c = np.exp(-1j * freqs[k] * fine_phase)
+                fine[k] = abs(np.sum(xc * c))
+                if pilot:
+                    fine[k] = (fine[k] * 11 + abs(np.sum(xp * c)) * 29) / 40
+            f = float(freqs[int(np.argmax(fine))])
+            acq.carrFreq[prn - 1] = f if f != 0 else 1                             # :253-255
+            acq.codePhase[prn - 1] = code_phase
+    return acq

@@ -192,6 +192,7 @@ def initSettings_BDS_B1C() -> SimpleNamespace:
     s.acqCohT = 10                   # :95
     s.acqStep = 1000 / s.acqCohT / 2  # :97
     s.acqThreshold = 10              # :99
+    s.pilotACQflag = 1               # :69
     s.dllDampingRatio = 0.7          # :107
     s.dllNoiseBandwidth = 1          # :108
     s.dllCorrelatorSpacing = 0.06    # :111

@@ -1077,3 +1077,119 @@ def acquisition_b1i(if_bytes: np.ndarray, settings, first_sample: int = 0):
             acq.codePhase[prn - 1] = code_phase
             acq.carrFreq[prn - 1] = init_freq - freq_res * (bin_idx - 1) + (freq_res / nshifts) * (freq_shift - 1)
     return acq
+
+
+def acquisition_l2c(if_bytes: np.ndarray, settings, first_sample: int = 0):
+    """GPS/GPS_L2C/include/acquisition.m:13-170: CM code over a 2-period block, carriers initFreq - (binIter-1)*
+    freqResolution/Nshifts, bins by circshift, first/second peak metric, CL segment search with pilotTRKflag."""
+    nblocks = 2
+    fs = settings.samplingFreq
+    spc = int(matlab_round(fs / (settings.codeFreqBasis / settings.codeLength)))
+    chip = int(matlab_round(fs / settings.codeFreqBasis))
+    spb = spc * nblocks
+    long_signal = _if_complex(if_bytes, first_sample, if_bytes.shape[0] // 2 - first_sample)
+    signal = long_signal[:spb]
+    ts = 1.0 / fs
+    phase_points = np.arange(spb) * 2 * math.pi * ts
+    freq_res = fs / spb
+    nbins = int(matlab_round(settings.acqSearchBand * 1e3 / freq_res)) + 1
+    nshifts = int(freq_res / settings.acqStep)
+    init_freq = settings.IF + (settings.acqSearchBand / 2) * 1000
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(32))
+    tc = 1.0 / (settings.codeFreqBasis * 2)
+    spectra = [np.fft.fft(np.exp(-1j * (init_freq - it * (freq_res / nshifts)) * phase_points) * signal) for it in range(nshifts)]
+    for prn in settings.acqSatelliteList:
+        cm = generate_l2c_code(prn, "CM", int(settings.codeLength))
+        idx = np.ceil(ts * np.arange(spc) / tc).astype(np.int64)     # makeCMTable.m
+        idx[-1] = int(settings.codeLength) * 2
+        idx[0] = 1
+        local = np.concatenate([cm[idx - 1], np.zeros(spc)])
+        code_fd = np.conj(np.fft.fft(local))
+        prevmax, corr_vec, freq_shift, bin_idx = 0.0, np.zeros(spb), 0, 0
+        for it in range(nshifts):
+            for b in range(1, nbins + 1):
+                if b == nbins and it > 0:
+                    continue
+                r = np.abs(np.fft.ifft(np.roll(spectra[it], b - 1) * code_fd))
+                if r.max() > prevmax:
+                    prevmax, corr_vec, freq_shift, bin_idx = r.max(), r, it + 1, b
+        code_phase = int(np.argmax(corr_vec)) + 1
+        max_peak = float(corr_vec[code_phase - 1])
+        second = _second_peak_ratio(corr_vec, code_phase, chip, spb // nblocks)
+        acq.peakMetric[prn - 1] = max_peak / second
+        if max_peak / second > settings.acqThreshold:
+            f = init_freq - freq_res * (bin_idx - 1) - (freq_res / nshifts) * (freq_shift - 1)
+            acq.carrFreq[prn - 1] = f
+            acq.codePhase[prn - 1] = code_phase
+            if getattr(settings, "pilotTRKflag", 0) == 1:
+                s0 = long_signal[code_phase - 1:code_phase - 1 + spc]
+                s0 = s0 - np.mean(s0)
+                carr = np.exp(-1j * f * (np.arange(spc) * 2 * math.pi * ts))
+                cl = generate_l2c_code(prn, "CL", int(settings.CLCodeLength))
+                cidx = np.ceil(ts * np.arange(spc) / tc).astype(np.int64)
+                cidx[0] = 1
+                cidx[-1] = int(settings.codeLength) * (1 if settings.acqCohT <= 10 else 2)
+                power = [abs(np.sum(s0 * cl[cidx - 1 + int(settings.codeLength) * 2 * ind] * carr)) for ind in range(75)]
+                acq.CLCodePhase[prn - 1] = int(np.argmax(power)) + 1
+    return acq
+
+
+def acquisition_b1c(if_bytes: np.ndarray, settings, first_sample: int = 0):
+    """BDS/B1C/include/acquisition.m:108-260 (resampling off)."""
+    fs = settings.samplingFreq
+    long_signal = _if_complex(if_bytes, first_sample, if_bytes.shape[0] // 2 - first_sample)
+    spc = int(matlab_round(fs / (settings.codeFreqBasis / settings.codeLength)))
+    xlen = int(matlab_round(spc / 10 * settings.acqCohT))
+    n = int(matlab_round(spc / 10 * (10 + settings.acqCohT)))
+    sig = long_signal[:n]
+    ts = 1.0 / fs
+    phase_points = np.arange(n) * 2 * math.pi * ts
+    nbins = int(matlab_round(settings.acqSearchBand * 2 / settings.acqStep)) + 1
+    nmax = max(settings.acqSatelliteList)
+    acq = SimpleNamespace(carrFreq=np.zeros(nmax), codePhase=np.zeros(nmax), peakMetric=np.zeros(nmax))
+    nfine = int(matlab_round(settings.acqStep / 25)) * 2 + 1
+    fine_phase = np.arange(spc) * 2 * math.pi * ts
+    sig_power = math.sqrt(np.var(sig[:xlen], ddof=1) * xlen)
+    init_freq = settings.IF + settings.acqSearchBand
+    iq_fd = np.fft.fft(np.exp(-1j * init_freq * phase_points) * sig)
+    pilot = getattr(settings, "pilotACQflag", 0) == 1
+    tc = 1.0 / settings.codeFreqBasis / 2
+
+    def table(code):
+        idx = np.ceil(ts * np.arange(1, spc + 1) / tc).astype(np.int64)
+        idx[-1] = int(settings.codeLength) * 2
+        idx[0] = 1
+        return code[idx - 1]
+    for prn in settings.acqSatelliteList:
+        dtab = table(generate_b1c_code(prn, "data"))
+        dfd = np.conj(np.fft.fft(np.concatenate([dtab[:xlen], np.zeros(n - xlen)])))
+        if pilot:
+            ptab = table(generate_b1c_code(prn, "pilot11"))
+            pfd = np.conj(np.fft.fft(np.concatenate([ptab[:xlen], np.zeros(n - xlen)])))
+        results = np.empty((nbins, n))
+        for b in range(1, nbins + 1):
+            sh = np.roll(iq_fd, b - 1)
+            results[b - 1] = np.abs(np.fft.ifft(sh * dfd))
+            if pilot:
+                results[b - 1] = (results[b - 1] * math.sqrt(11) + np.abs(np.fft.ifft(sh * pfd)) * math.sqrt(29)) / math.sqrt(40)
+        bin_idx = int(np.argmax(results.max(axis=1))) + 1
+        sel_freq = init_freq - (bin_idx - 1) * settings.acqStep
+        colmax = results.max(axis=0)
+        code_phase = int(np.argmax(colmax)) + 1
+        acq.peakMetric[prn - 1] = float(colmax.max()) / sig_power
+        if code_phase + spc - 1 > long_signal.shape[0]:
+            code_phase -= spc
+        if acq.peakMetric[prn - 1] > settings.acqThreshold:
+            s0 = long_signal[code_phase - 1:code_phase - 1 + spc]
+            xc = s0 * dtab
+            fine, freqs = np.empty(nfine), np.empty(nfine)
+            for k in range(nfine):
+                freqs[k] = sel_freq + settings.acqStep - 25 * k
+                c = np.exp(-1j * freqs[k] * fine_phase)
+                fine[k] = abs(np.sum(xc * c))
+                if pilot:
+                    fine[k] = (fine[k] * 11 + abs(np.sum(s0 * ptab * c)) * 29) / 40
+            f = float(freqs[int(np.argmax(fine))])
+            acq.carrFreq[prn - 1] = f if f != 0 else 1
+            acq.codePhase[prn - 1] = code_phase
+    return acq

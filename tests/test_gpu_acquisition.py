@@ -178,3 +178,60 @@ def test_b1i_circshift_family_acquisition(engine):
         assert abs(got.carrFreq[k] - (S.IF + s.doppler)) <= 62.5 + 1e-9           # half the 125-Hz grid
         assert abs((got.codePhase[k] - 1 - s.code_phase_samples) % 18000) < 3 or abs((got.codePhase[k] - 1 - s.code_phase_samples) % 18000 - 18000) < 3
     assert got.carrFreq[11] == 0 and got.peakMetric[11] < S.acqThreshold
+
+
+def test_l2c_circshift_acquisition_with_cl_phase(engine):
+    """GPS/GPS_L2C/include/acquisition.m: 320 000-point transforms (40 ms at 8 Msps), 25-Hz bins as circular shifts,
+    two carriers 12.5 Hz apart, then the CL segment (1..75) by 75 short correlations.  Search band narrowed to 1 kHz
+    to keep the float64 oracle quick."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GPS_L2C
+    S = initSettings_GPS_L2C()
+    S.pilotTRKflag = 1
+    S.acqSearchBand = 1          # kHz: 41 bins x 2 carriers
+    S.acqSatelliteList = [5, 9]  # 9 absent
+    fs = S.samplingFreq
+    seg = 31
+
+    def combined(prn):
+        cm, cl = P.codes.generateCMcode(prn).astype(np.float64), P.codes.generateCLcode(prn).astype(np.float64)
+        return np.roll(np.tile(cm, 75) + cl, -20460 * (seg - 1))
+    sats = [P.synth.SatSpec(prn=5, doppler=212.0, code_phase_samples=70003.4, carrier_phase=1.0, cn0_dbhz=45.0)]
+    n = int(0.25 * fs)
+    iq = P.synth.generate_if(sats, n, fs, S.IF, combined, 2 * S.codeFreqBasis, 20460 * 75, seed=91, carrier_ratio=1200.0, bit_periods=1)
+    engine.load_if(iq, fs=fs)
+    got = P.acq_shift.acquisition_L2C(engine, S, first_sample=0)
+    ref = O.acquisition_l2c(iq, S, 0)
+    for prn in S.acqSatelliteList:
+        k = prn - 1
+        assert got.codePhase[k] == ref.codePhase[k] and got.carrFreq[k] == ref.carrFreq[k] and got.CLCodePhase[k] == ref.CLCodePhase[k], prn
+        assert abs(got.peakMetric[k] - ref.peakMetric[k]) < 2e-3 * ref.peakMetric[k], prn
+    assert got.peakMetric[4] > S.acqThreshold and abs(got.carrFreq[4] - (S.IF + 212.0)) <= 6.25 + 1e-9
+    assert abs(got.codePhase[4] - 1 - 70003.4) < 3
+    assert got.CLCodePhase[4] == seg
+    assert got.carrFreq[8] == 0
+
+
+def test_b1c_circshift_acquisition_data_plus_pilot(engine):
+    """BDS/B1C/include/acquisition.m: 360 000-point transforms, 50-Hz bins by circular shift, data and pilot BOC(1,1)
+    replicas combined sqrt(11):sqrt(29), peak/sigPower metric, 25-Hz fine stage.  Band narrowed to +-1 kHz for the oracle."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B1C
+    S = initSettings_BDS_B1C()
+    S.acqSearchBand = 1000
+    S.acqSatelliteList = [8, 20]   # 20 absent
+    fs = S.samplingFreq
+    sats = [P.synth.SatSpec(prn=8, doppler=-430.0, code_phase_samples=123456.7, carrier_phase=2.0, cn0_dbhz=47.0)]
+    n = int(0.045 * fs)
+    iq = P.synth.generate_if(sats, n, fs, S.IF, P.codes.generateDataBOC11, 2 * S.codeFreqBasis, 20460, seed=93, bit_periods=1,
+                             pilot_fn=P.codes.generatePilotBOC11, pilot_phase=np.pi / 2)
+    engine.load_if(iq, fs=fs)
+    got = P.acq_shift.acquisition_B1C(engine, S, first_sample=0)
+    ref = O.acquisition_b1c(iq, S, 0)
+    for prn in S.acqSatelliteList:
+        k = prn - 1
+        assert got.codePhase[k] == ref.codePhase[k] and got.carrFreq[k] == ref.carrFreq[k], prn
+        assert abs(got.peakMetric[k] - ref.peakMetric[k]) < 2e-3 * ref.peakMetric[k], prn
+    assert got.peakMetric[7] > S.acqThreshold and abs(got.carrFreq[7] - (S.IF - 430.0)) <= 12.5 + 1e-9
+    assert abs(got.codePhase[7] - 1 - 123456.7) < 3
+    assert got.carrFreq[19] == 0
