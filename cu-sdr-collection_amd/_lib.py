@@ -56,6 +56,12 @@ class gc_acq_params(C.Structure):
                 ("non_coh_time", C.c_int32), ("reserved", C.c_int32), ("first_sample", C.c_int64)]
 
 
+class gc_fine_params(C.Structure):
+    _fields_ = [("sampling_freq", C.c_double), ("code_freq", C.c_double), ("f0", C.c_double), ("fstep", C.c_double),
+                ("first_sample", C.c_int64), ("spc", C.c_int32), ("ncodes", C.c_int32), ("nbins", C.c_int32),
+                ("code_len", C.c_int32), ("index_offset", C.c_int32), ("reserved", C.c_int32)]
+
+
 class gc_acq_shift_params(C.Structure):
     _fields_ = [("sampling_freq", C.c_double), ("carrier_f0", C.c_double), ("carrier_step", C.c_double),
                 ("first_sample", C.c_int64), ("n", C.c_int32), ("n_signals", C.c_int32), ("n_carriers", C.c_int32),
@@ -99,6 +105,7 @@ SYMBOLS = {
     "gc_acquire_coarse_multi": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,
                                        C.POINTER(C.c_double)]),
+    "gc_acquire_fine_sums": (C.c_int, [_P, C.POINTER(gc_fine_params), _P, C.POINTER(C.c_double)]),
     "gc_acq_shift_prepare": (C.c_int, [_P, C.POINTER(gc_acq_shift_params)]),
     "gc_acq_shift_search": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "gc_acq_shift_row": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),

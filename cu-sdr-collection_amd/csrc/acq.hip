@@ -303,14 +303,15 @@ __global__ void argmax_kernel(const float* __restrict__ r, int nbins, int ncols,
 // ---- fine frequency, GPS L1 C/A (acquisition.m:213-238): 40 per-code sums for each fine bin ---------------
 __global__ __launch_bounds__(256) void fine_kernel(const int8_t* __restrict__ x, long long first, int spc, int ncodes,
                                                     const int8_t* __restrict__ code, int code_len, double ts, double tc,
-                                                    double f0, double fstep, double fs, double* __restrict__ out) {
+                                                    double f0, double fstep, double fs, double* __restrict__ out, int index_offset = 0) {
   const int bin = blockIdx.x / ncodes, ci = blockIdx.x % ncodes;
   const double f = f0 - fstep * bin;
   double sr = 0.0, si = 0.0;
   for (int i = threadIdx.x; i < spc; i += blockDim.x) {
     const long long n = (long long)ci * spc + i;
     // codeValueIndex = floor((ts * n) / tc), exactly as acquisition.m:215-216 (float64)
-    const double cvi = floor(__ddiv_rn(__dmul_rn(ts, (double)n), tc));
+    // (index_offset = 1: the 10.23-Mcps packages index with (1:K*spc), e.g. GPS_L5C acquisition.m:231)
+    const double cvi = floor(__ddiv_rn(__dmul_rn(ts, (double)(n + index_offset)), tc));
     const int k = (int)fmod(cvi, (double)code_len);
     const float c = (float)code[k];
     const float xi = (float)x[2 * (first + n)], xq = (float)x[2 * (first + n) + 1];
@@ -629,6 +630,44 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   return GC_OK;
 }
 
+
+
+// Generic fine-frequency stage: per-code-period complex sums of signal x code x carrier for `nbins`
+// carriers f0 - k*fstep over `ncodes` periods from p->first_sample; the hypothesis search over bit edges / Neuman-
+// Hofman / secondary codes / data+pilot combinations is a few hundred flops and stays with the caller.
+extern "C" int gc_acquire_fine_sums(gc_context* ctx, const gc_fine_params* p, const int8_t* code, double* out) {
+  if (!ctx || !p || !code || !out || p->spc <= 0 || p->ncodes <= 0 || p->nbins <= 0 || p->code_len <= 0 || p->first_sample < 0) {
+    gc_set_error("gc_acquire_fine_sums: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  if ((uint64_t)p->first_sample + (uint64_t)p->ncodes * p->spc > ctx->if_nsamples) {
+    gc_set_error("gc_acquire_fine_sums: %d code periods from sample %lld exceed the IF buffer", p->ncodes, (long long)p->first_sample);
+    return GC_E_RANGE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  const size_t nout = (size_t)p->nbins * p->ncodes * 2;
+  int8_t* dcode = nullptr;
+  double* dout = nullptr;
+  if (hipMalloc((void**)&dcode, (size_t)p->code_len) != hipSuccess || hipMalloc((void**)&dout, nout * sizeof(double)) != hipSuccess) {
+    if (dcode) (void)hipFree(dcode);
+    gc_set_error("gc_acquire_fine_sums: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  hipError_t e = hipMemcpyAsync(dcode, code, (size_t)p->code_len, hipMemcpyHostToDevice, ctx->stream);
+  hipLaunchKernelGGL(fine_kernel, dim3(p->nbins * p->ncodes), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (long long)p->first_sample,
+                     p->spc, p->ncodes, (const int8_t*)dcode, p->code_len, 1.0 / p->sampling_freq, 1.0 / p->code_freq, p->f0, p->fstep,
+                     p->sampling_freq, dout, p->index_offset);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dcode);
+  (void)hipFree(dout);
+  if (e != hipSuccess) {
+    gc_set_error("gc_acquire_fine_sums: %s", hipGetErrorString(e));
+    return GC_E_HIP;
+  }
+  return GC_OK;
+}
 
 // ---- circshift search family ------------------------------------------------------------------------------
 // GPS_L2C/include/acquisition.m:40-75, BDS/B1I/include/acquisition.m:76-123, BDS/B1C/include/acquisition.m:137-170:

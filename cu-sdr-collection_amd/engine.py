@@ -170,6 +170,14 @@ class Engine:
                                                   codes.ctypes.data_as(C.c_void_p), res))
         return list(res)
 
+    def acquire_fine_sums(self, params: L.gc_fine_params, code: np.ndarray) -> np.ndarray:
+        """Per-code-period complex sums [nbins, ncodes] of the generic fine-frequency stage."""
+        c8 = np.ascontiguousarray(code, dtype=np.int8)
+        out = np.empty((params.nbins, params.ncodes, 2))
+        L.check(self._lib.gc_acquire_fine_sums(self._ctx, C.byref(params), c8.ctypes.data_as(C.c_void_p),
+                                               out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out[..., 0] + 1j * out[..., 1]
+
     def acq_shift_prepare(self, params: L.gc_acq_shift_params):
         self._shift = params
         L.check(self._lib.gc_acq_shift_prepare(self._ctx, C.byref(params)))

@@ -240,6 +240,26 @@ int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, i
 int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code,
                          int code_phase, double coarse_freq, double* carr_freq);
 
+/* ---- acquisition, generic fine-frequency stage (acquisition.m:206-260 and its per-package variants: GPS_L5C
+ * :228-252 Neuman-Hofman search, GAL_E5a 100-code secondary search, BDS/B2a non-coherent data+pilot, ...).
+ * out[(bin*ncodes + c)*2 + {0,1}] = sum over code period c of x[n] * code[floor(ts*(n + index_offset)/tc) mod
+ * code_len] * exp(-1i*2*pi*f_bin*n/fs), n counted from first_sample, f_bin = f0 - bin*fstep.  The hypothesis
+ * search over the per-code sums stays with the caller. */
+typedef struct gc_fine_params {
+  double sampling_freq;      /* settings.samplingFreq */
+  double code_freq;          /* settings.codeFreqBasis (tc = 1/code_freq) */
+  double f0, fstep;          /* FineFreqBins(k) = f0 - fstep*(k-1) */
+  int64_t first_sample;      /* absolute index of longSignal(codePhase) */
+  int32_t spc;               /* samplesPerCode */
+  int32_t ncodes;            /* code periods (40 L1CA, 20 L5/B2a, 100 E5a) */
+  int32_t nbins;
+  int32_t code_len;          /* settings.codeLength */
+  int32_t index_offset;      /* 0: codeValueIndex over (0:K*spc-1) (L1CA :210); 1: over (1:K*spc) (L5 :231) */
+  int32_t reserved;
+} gc_fine_params;
+
+int gc_acquire_fine_sums(gc_context* ctx, const gc_fine_params* p, const int8_t* code, double* out);
+
 /* ---- acquisition, circshift search family (replaces GPS_L2C/include/acquisition.m:40-75,
  * BDS/B1I/include/acquisition.m:76-123, BDS/B1C/include/acquisition.m:137-170): the signal block(s) are mixed with
  * n_carriers carriers and transformed once (gc_acq_shift_prepare); per PRN every Doppler bin is a circular shift of

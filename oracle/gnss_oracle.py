@@ -1193,3 +1193,52 @@ def acquisition_b1c(if_bytes: np.ndarray, settings, first_sample: int = 0):
             acq.carrFreq[prn - 1] = f if f != 0 else 1
             acq.codePhase[prn - 1] = code_phase
     return acq
+
+
+def acquisition_family_a(if_bytes: np.ndarray, settings, first_sample: int, coarse_codes, fine_codes, ncodes: int,
+                         fine_step: float, combine: str, secondary=None, n_results: int = 32):
+    """GPS_L5C / GAL_E5a / BDS B2a acquisition.m (resampling off): the L1CA coarse scheme with the per-PRN replica
+    list `coarse_codes(prn)` summed (|ifft| of each), metric peak/sigPower/acqNonCohTime, then the package's fine stage
+    on `fine_codes(prn)`: codeValueIndex = floor(ts*(1:K*spc)/tc), per-code sums, and
+      combine "circular": max over circular shifts of secondary(prn) of |sum(sumPerCode .* shifted)| (L5 NH20, E5a CS100)
+      combine "noncoh":   sum(abs(sumPerCode1)) + sum(abs(sumPerCode2))                               (B2a :207)."""
+    long_signal = _if_complex(if_bytes, first_sample, if_bytes.shape[0] // 2 - first_sample)
+    fs = settings.samplingFreq
+    spc = samples_per_code(settings)
+    ts, tc = 1.0 / fs, 1.0 / settings.codeFreqBasis
+    acq = SimpleNamespace(carrFreq=np.zeros(n_results), codePhase=np.zeros(n_results), peakMetric=np.zeros(n_results))
+    sig_power = math.sqrt(np.var(long_signal[:spc], ddof=1) * spc)
+    nfine = int(matlab_round(settings.acqSearchStep / fine_step)) + 1
+    fine_phase = np.arange(ncodes * spc) * 2 * math.pi * ts
+    idx_t = np.ceil(ts * np.arange(1, spc + 1) / tc).astype(np.int64)
+    idx_t[-1] = int(settings.codeLength)
+    for prn in settings.acqSatelliteList:
+        tables = [c[idx_t - 1] for c in coarse_codes(prn)]
+        results = acquisition_coarse_results(long_signal, prn, settings, tables=tables)
+        coarse_bin = int(np.argmax(results.max(axis=1))) + 1
+        colmax = results.max(axis=0)
+        code_phase = int(np.argmax(colmax)) + 1
+        acq.peakMetric[prn - 1] = float(colmax.max()) / sig_power / settings.acqNonCohTime
+        if acq.peakMetric[prn - 1] > settings.acqThreshold:
+            cvi = np.floor(ts * np.arange(1, ncodes * spc + 1) / tc).astype(np.int64)
+            longs = [c[np.remainder(cvi, int(settings.codeLength))] for c in fine_codes(prn)]
+            sig = long_signal[code_phase - 1:code_phase - 1 + ncodes * spc]
+            coarse_freq = settings.IF + settings.acqSearchBand - settings.acqSearchStep * (coarse_bin - 1)
+            fine, freqs = np.empty(nfine), np.empty(nfine)
+            for k in range(nfine):
+                freqs[k] = coarse_freq + settings.acqSearchStep / 2 - fine_step * k
+                carr = np.exp(-1j * freqs[k] * fine_phase)
+                per_code = [(lc * carr * sig).reshape(ncodes, spc).sum(axis=1) for lc in longs]
+                if combine == "circular":
+                    sec = np.asarray(secondary(prn), dtype=np.float64).copy()
+                    best = 0.0
+                    for _ in range(sec.shape[0]):
+                        best = max(best, abs(np.sum(per_code[0] * sec)))
+                        sec = np.roll(sec, 1)
+                    fine[k] = best
+                else:
+                    fine[k] = sum(float(np.sum(np.abs(pc))) for pc in per_code)
+            f = float(freqs[int(np.argmax(fine))])
+            acq.carrFreq[prn - 1] = f if f != 0 else 1
+            acq.codePhase[prn - 1] = code_phase
+    return acq
