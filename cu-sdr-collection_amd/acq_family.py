@@ -39,29 +39,44 @@ def _circular_code_search(sums: np.ndarray, sec: np.ndarray) -> float:
     return best
 
 
-def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, fine_step, combine, n_results=32):
+def _split_code_search(sums: np.ndarray, sec: np.ndarray) -> float:
+    """GAL_E1C acquisition.m:237-245 / BDS B3I acquisition.m:262-270: the secondary code aligned, then every
+    circular shift k = 1..len-1 with the sum SPLIT at the possible data-bit edge: |sum(1:k)| + |sum(k+1:end)|."""
+    best = abs(np.sum(sums * sec))
+    for k in range(1, sec.shape[0]):
+        t = sums * np.roll(sec, k)
+        best = max(best, abs(np.sum(t[:k])) + abs(np.sum(t[k:])))
+    return best
+
+
+def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, fine_step, combine, n_results=32,
+              table_fn=None, fine_code_freq=None, fine_code_len=None, index_offset=1):
     from .receiver import _acq_params
     if first_sample is None:
         first_sample = int(settings.skipNumberOfBytes)
     prns = list(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(n_results), codePhase=np.zeros(n_results), peakMetric=np.zeros(n_results))
     p = _acq_params(settings, first_sample)
-    tables = np.stack([np.stack([make_table(c, settings) for c in coarse_codes(prn)]) for prn in prns])   # [nprn, narms, spc]
+    table_fn = table_fn or make_table
+    tables = np.stack([np.stack([table_fn(c, settings) for c in coarse_codes(prn)]) for prn in prns])   # [nprn, narms, spc]
     res = engine.acquire_coarse(p, tables)
     spc = tables.shape[-1]
-    nfine = _round(settings.acqSearchStep / fine_step) + 1
+    nfine = _round(settings.acqSearchStep / fine_step) + 1 if fine_step else 0
     for prn, r in zip(prns, res):
         acq.peakMetric[prn - 1] = r.peak_metric
         if r.peak_metric > settings.acqThreshold:
-            fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=settings.codeFreqBasis,
+            acq.codePhase[prn - 1] = r.code_phase
+            if not fine_step:                      # GAL_E5b acquisition.m:227: the coarse bin is the answer
+                acq.carrFreq[prn - 1] = r.coarse_freq
+                continue
+            fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=fine_code_freq or settings.codeFreqBasis,
                                   f0=r.coarse_freq + settings.acqSearchStep / 2, fstep=fine_step,
                                   first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=ncodes, nbins=nfine,
-                                  code_len=int(settings.codeLength), index_offset=1)
+                                  code_len=int(fine_code_len or settings.codeLength), index_offset=index_offset)
             sums = [engine.acquire_fine_sums(fp, c) for c in fine_codes(prn)]       # each [nfine, ncodes]
             fine = np.array([combine(prn, [s[k] for s in sums]) for k in range(nfine)])
             f = fp.f0 - fine_step * int(np.argmax(fine))
             acq.carrFreq[prn - 1] = f if f != 0 else 1
-            acq.codePhase[prn - 1] = r.code_phase
     return acq
 
 
@@ -91,3 +106,47 @@ def acquisition_B2a(engine, settings, first_sample: int | None = None):
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)],
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)], ncodes, 25.0,
                      lambda prn, s: float(np.sum(np.abs(s[0])) + np.sum(np.abs(s[1]))), n_results=63)
+
+
+def acquisition_E5b(engine, settings, first_sample: int | None = None):
+    """GAL/GAL_E5b/include/acquisition.m: E5b-I + E5b-Q coarse search in 60-Hz bins and no fine stage (:227)."""
+    return _family_a(engine, settings, first_sample,
+                     lambda prn: [codes.generateE5bIcode(prn, 1), codes.generateE5bQcode(prn, 1)], None, 0, 0.0, None, n_results=36)
+
+
+def _b3i_combine(prn, s):
+    """BDS/B3I/include/acquisition.m:252-271: GEO satellites (PRN 1-5, 59-63; 2-ms D2 symbols) — the better of the two
+    pairings of adjacent codes; MEO/IGSO (PRN 6-58) — NH20 with the split-sum search."""
+    x = s[0]
+    if 1 <= prn <= 5 or 59 <= prn <= 63:
+        p1 = float(np.sum(np.abs(x.reshape(10, 2).sum(axis=1))))
+        p2 = float(np.sum(np.abs(x[[0, 19]])) + np.sum(np.abs(x[1:19].reshape(9, 2).sum(axis=1))))
+        return max(p1, p2)
+    return _split_code_search(x, NH20)
+
+
+def acquisition_B3I(engine, settings, first_sample: int | None = None):
+    """BDS/B3I/include/acquisition.m: single-component coarse search, 20-code fine stage indexed (0 : 20*spc-1)."""
+    return _family_a(engine, settings, first_sample, lambda prn: [codes.generateB3Icode(prn)], lambda prn: [codes.generateB3Icode(prn)],
+                     20, 25.0, _b3i_combine, n_results=63, index_offset=0)
+
+
+E1C_SECONDARY = np.array([1, 1, -1, -1, -1, 1, 1, 1, 1, 1, 1, 1, -1, 1, -1, 1, -1, -1, 1, -1, -1, 1, 1, -1, 1], dtype=np.float64)  # GAL_E1C acquisition.m:138
+
+
+def _make_boc_table(code: np.ndarray, settings) -> np.ndarray:
+    """makeE1BTable.m:43-55: half-chip code sampled at ceil(ts*(1:spc)/(tc/2)), first index forced to 1, last to 2L."""
+    spc = _round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength))
+    idx = np.ceil((1.0 / settings.samplingFreq) * np.arange(1, spc + 1) / (1.0 / settings.codeFreqBasis / 2)).astype(np.int64)
+    idx[-1] = int(settings.codeLength) * 2
+    idx[0] = 1
+    return code[idx - 1]
+
+
+def acquisition_E1C(engine, settings, first_sample: int | None = None):
+    """GAL/GAL_E1C/include/acquisition.m: E1-B + E1-C BOC(1,1) replicas (4-ms codes, 144 000-point transforms), fine
+    stage on the pilot over 25 codes in 10-Hz bins with the 25-chip secondary code and the split-sum search."""
+    return _family_a(engine, settings, first_sample,
+                     lambda prn: [codes.generateE1Bcode(prn), codes.generateE1Ccode(prn)], lambda prn: [codes.generateE1Ccode(prn)],
+                     25, 10.0, lambda prn, s: _split_code_search(s[0], E1C_SECONDARY), n_results=50, table_fn=_make_boc_table,
+                     fine_code_freq=settings.codeFreqBasis * 2, fine_code_len=int(settings.codeLength) * 2, index_offset=0)

@@ -1196,22 +1196,30 @@ def acquisition_b1c(if_bytes: np.ndarray, settings, first_sample: int = 0):
 
 
 def acquisition_family_a(if_bytes: np.ndarray, settings, first_sample: int, coarse_codes, fine_codes, ncodes: int,
-                         fine_step: float, combine: str, secondary=None, n_results: int = 32):
+                         fine_step: float, combine, secondary=None, n_results: int = 32, boc: bool = False,
+                         index_offset: int = 1):
     """GPS_L5C / GAL_E5a / BDS B2a acquisition.m (resampling off): the L1CA coarse scheme with the per-PRN replica
     list `coarse_codes(prn)` summed (|ifft| of each), metric peak/sigPower/acqNonCohTime, then the package's fine stage
     on `fine_codes(prn)`: codeValueIndex = floor(ts*(1:K*spc)/tc), per-code sums, and
       combine "circular": max over circular shifts of secondary(prn) of |sum(sumPerCode .* shifted)| (L5 NH20, E5a CS100)
-      combine "noncoh":   sum(abs(sumPerCode1)) + sum(abs(sumPerCode2))                               (B2a :207)."""
+      combine "noncoh":   sum(abs(sumPerCode1)) + sum(abs(sumPerCode2))                               (B2a :207)
+      combine "split":    secondary aligned, then shifts k with |sum(1:k)| + |sum(k+1:end)|  (E1C :237-245, B3I MEO)
+      combine callable(prn, per_code) for anything else (B3I GEO pairing :252-256); fine_step 0: no fine stage (E5b).
+    boc: half-chip tables and fine code at 2*codeFreqBasis over 2*codeLength entries (GAL_E1C); index_offset: the fine
+    codeValueIndex runs over (1:K*spc) (1) or (0:K*spc-1) (0)."""
     long_signal = _if_complex(if_bytes, first_sample, if_bytes.shape[0] // 2 - first_sample)
     fs = settings.samplingFreq
     spc = samples_per_code(settings)
-    ts, tc = 1.0 / fs, 1.0 / settings.codeFreqBasis
+    ts, tc = 1.0 / fs, 1.0 / settings.codeFreqBasis / (2 if boc else 1)
+    clen = int(settings.codeLength) * (2 if boc else 1)
     acq = SimpleNamespace(carrFreq=np.zeros(n_results), codePhase=np.zeros(n_results), peakMetric=np.zeros(n_results))
     sig_power = math.sqrt(np.var(long_signal[:spc], ddof=1) * spc)
-    nfine = int(matlab_round(settings.acqSearchStep / fine_step)) + 1
+    nfine = int(matlab_round(settings.acqSearchStep / fine_step)) + 1 if fine_step else 0
     fine_phase = np.arange(ncodes * spc) * 2 * math.pi * ts
     idx_t = np.ceil(ts * np.arange(1, spc + 1) / tc).astype(np.int64)
-    idx_t[-1] = int(settings.codeLength)
+    idx_t[-1] = clen
+    if boc:
+        idx_t[0] = 1
     for prn in settings.acqSatelliteList:
         tables = [c[idx_t - 1] for c in coarse_codes(prn)]
         results = acquisition_coarse_results(long_signal, prn, settings, tables=tables)
@@ -1220,16 +1228,29 @@ def acquisition_family_a(if_bytes: np.ndarray, settings, first_sample: int, coar
         code_phase = int(np.argmax(colmax)) + 1
         acq.peakMetric[prn - 1] = float(colmax.max()) / sig_power / settings.acqNonCohTime
         if acq.peakMetric[prn - 1] > settings.acqThreshold:
-            cvi = np.floor(ts * np.arange(1, ncodes * spc + 1) / tc).astype(np.int64)
-            longs = [c[np.remainder(cvi, int(settings.codeLength))] for c in fine_codes(prn)]
-            sig = long_signal[code_phase - 1:code_phase - 1 + ncodes * spc]
             coarse_freq = settings.IF + settings.acqSearchBand - settings.acqSearchStep * (coarse_bin - 1)
+            if not fine_step:
+                acq.carrFreq[prn - 1] = coarse_freq
+                acq.codePhase[prn - 1] = code_phase
+                continue
+            cvi = np.floor(ts * (np.arange(ncodes * spc) + index_offset) / tc).astype(np.int64)
+            longs = [c[np.remainder(cvi, clen)] for c in fine_codes(prn)]
+            sig = long_signal[code_phase - 1:code_phase - 1 + ncodes * spc]
             fine, freqs = np.empty(nfine), np.empty(nfine)
             for k in range(nfine):
                 freqs[k] = coarse_freq + settings.acqSearchStep / 2 - fine_step * k
                 carr = np.exp(-1j * freqs[k] * fine_phase)
                 per_code = [(lc * carr * sig).reshape(ncodes, spc).sum(axis=1) for lc in longs]
-                if combine == "circular":
+                if callable(combine):
+                    fine[k] = combine(prn, per_code)
+                elif combine == "split":
+                    sec = np.asarray(secondary(prn), dtype=np.float64)
+                    best = abs(np.sum(per_code[0] * sec))
+                    for kk in range(1, sec.shape[0]):
+                        t = per_code[0] * np.roll(sec, kk)
+                        best = max(best, abs(np.sum(t[:kk])) + abs(np.sum(t[kk:])))
+                    fine[k] = best
+                elif combine == "circular":
                     sec = np.asarray(secondary(prn), dtype=np.float64).copy()
                     best = 0.0
                     for _ in range(sec.shape[0]):

@@ -246,7 +246,7 @@ def _family_a_case(engine, S, product_fn, data_fn, pilot_fn, carrier_ratio, prns
                             carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0) for p in prns_present]
     n = int(ms * 1e-3 * fs)
     iq = P.synth.generate_if(sats, n, fs, S.IF, data_fn, S.codeFreqBasis, 10230, seed=102, carrier_ratio=carrier_ratio,
-                             bit_periods=1000, pilot_fn=pilot_fn, pilot_phase=np.pi / 2)
+                             bit_periods=1000, pilot_fn=pilot_fn, pilot_phase=np.pi / 2 if pilot_fn else 0.0)
     engine.load_if(iq, fs=fs)
     got = product_fn(engine, S, first_sample=0)
     ref = O.acquisition_family_a(iq, S, 0, **oracle_kw)
@@ -302,3 +302,63 @@ def test_beidou_b2a_acquisition_noncoherent_data_pilot_fine_stage(engine):
                                     ncodes=10, fine_step=25.0, combine="noncoh", n_results=63), 20)
     for s in sats:       # no overlay code in this fine stage: the 25-Hz grid must land next to the true carrier
         assert abs(got.carrFreq[s.prn - 1] - (S.IF + s.doppler)) <= 25.0
+
+
+def test_galileo_e5b_acquisition_without_fine_stage(engine):
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E5b
+    S = initSettings_GAL_E5b()
+    S.acqNonCohTime = 3
+    S.acqSearchBand = 4500
+    got, sats = _family_a_case(engine, S, P.acq_family.acquisition_E5b, lambda prn: P.codes.generateE5bIcode(prn, 1),
+                               lambda prn: P.codes.generateE5bQcode(prn, 1), 1180.0, (4,), 19,
+                               dict(coarse_codes=lambda prn: [O.generate_e5_primary("e5bi", prn), O.generate_e5_primary("e5bq", prn)],
+                                    fine_codes=None, ncodes=0, fine_step=0.0, combine=None, n_results=36), 12)
+
+
+def test_beidou_b3i_acquisition_geo_and_meo_fine_stages(engine):
+    """BDS/B3I/include/acquisition.m: PRN 3 takes the GEO branch (pairs of codes), PRN 30 the MEO branch (NH20, split sums)."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B3I
+    S = initSettings_BDS_B3I()
+    S.acqNonCohTime = 3
+    S.acqSearchBand = 4500
+
+    def geo_pairs(prn, per_code):
+        x = per_code[0]
+        if 1 <= prn <= 5 or 59 <= prn <= 63:
+            return max(float(np.sum(np.abs(x.reshape(10, 2).sum(axis=1)))),
+                       float(np.sum(np.abs(x[[0, 19]])) + np.sum(np.abs(x[1:19].reshape(9, 2).sum(axis=1)))))
+        sec = np.array([1, 1, 1, 1, 1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, -1, -1, -1, 1], dtype=np.float64)
+        best = abs(np.sum(x * sec))
+        for k in range(1, 20):
+            t = x * np.roll(sec, k)
+            best = max(best, abs(np.sum(t[:k])) + abs(np.sum(t[k:])))
+        return best
+    _family_a_case(engine, S, P.acq_family.acquisition_B3I, P.codes.generateB3Icode, None, 1240.0, (3, 30), 44,
+                   dict(coarse_codes=lambda prn: [O.generate_b3i_code(prn)], fine_codes=lambda prn: [O.generate_b3i_code(prn)], ncodes=20,
+                        fine_step=25.0, combine=geo_pairs, n_results=63, index_offset=0), 30)
+
+
+def test_galileo_e1_acquisition_with_secondary_code_split_sums(engine):
+    """GAL/GAL_E1C/include/acquisition.m: 144 000-point transforms (4-ms BOC(1,1) codes), band narrowed to +-1.5 kHz."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E1C
+    S = initSettings_GAL_E1C()
+    S.acqSearchBand, S.acqSearchStep, S.acqNonCohTime, S.acqThreshold = 1500, 150, 1, 10
+    S.acqSatelliteList = [4, 27]
+    fs = S.samplingFreq
+    sats = [P.synth.SatSpec(prn=4, doppler=820.0, code_phase_samples=33333.3, carrier_phase=0.5, cn0_dbhz=50.0)]
+    n = int(0.112 * fs)
+    iq = P.synth.generate_if(sats, n, fs, S.IF, P.codes.generateE1Bcode, 2 * S.codeFreqBasis, 8184, seed=111, bit_periods=1,
+                             pilot_fn=P.codes.generateE1Ccode)
+    engine.load_if(iq, fs=fs)
+    got = P.acq_family.acquisition_E1C(engine, S, first_sample=0)
+    ref = O.acquisition_family_a(iq, S, 0, coarse_codes=lambda prn: [O.generate_e1_code(prn, "B"), O.generate_e1_code(prn, "C")],
+                                 fine_codes=lambda prn: [O.generate_e1_code(prn, "C")], ncodes=25, fine_step=10.0, combine="split",
+                                 secondary=lambda prn: P.acq_family.E1C_SECONDARY, n_results=50, boc=True, index_offset=0)
+    for prn in S.acqSatelliteList:
+        k = prn - 1
+        assert got.codePhase[k] == ref.codePhase[k] and got.carrFreq[k] == ref.carrFreq[k], prn
+        assert abs(got.peakMetric[k] - ref.peakMetric[k]) < 2e-3 * ref.peakMetric[k], prn
+    assert got.peakMetric[3] > S.acqThreshold and abs(got.codePhase[3] - 1 - 33333.3) < 3 and got.carrFreq[26] == 0
