@@ -150,3 +150,68 @@ def acquisition_E1C(engine, settings, first_sample: int | None = None):
                      lambda prn: [codes.generateE1Bcode(prn), codes.generateE1Ccode(prn)], lambda prn: [codes.generateE1Ccode(prn)],
                      25, 10.0, lambda prn, s: _split_code_search(s[0], E1C_SECONDARY), n_results=50, table_fn=_make_boc_table,
                      fine_code_freq=settings.codeFreqBasis * 2, fine_code_len=int(settings.codeLength) * 2, index_offset=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# GLONASS L1OF (FDMA: one code, one search band per frequency number K)
+# ---------------------------------------------------------------------------------------------
+def _matlab_colon(a: float, d: float, b: float) -> np.ndarray:
+    """a:d:b as MATLAB builds it for non-integer steps: forwards from a, backwards from the snapped end point, mean
+    in the middle — floor() of these values decides the sampled GLONASS code (generateCAcode.m:113-118), and
+    k*511e3/fs hits exact integers every 12 000 samples."""
+    n = int(math.floor((b - a) / d + 0.5))
+    tol = 2.0 * np.finfo(np.float64).eps * max(abs(a), abs(b))
+    if a + n * d - b > tol:
+        n -= 1
+    c = a + n * d
+    if c - b > -tol:
+        c = b
+    out = np.empty(n + 1)
+    k = np.arange(0, n // 2 + 1)
+    out[k] = a + k.astype(np.float64) * d
+    out[n - k] = c - k.astype(np.float64) * d
+    if n % 2 == 0:
+        out[n // 2] = (a + c) / 2.0
+    return out
+
+
+def glonass_sampled_code(samp_freq: float, num_samples: int) -> np.ndarray:
+    """GLO/GLO_GL1/include/generateCAcode.m:112-118 with PRN 0: the 511-chip code sampled at floor(k*511e3/fs)."""
+    code = codes.generateGLOcode()
+    step = 511e3 / samp_freq
+    s = np.floor(_matlab_colon(0.0, step, num_samples * step - step)).astype(np.int64)
+    return code[np.remainder(s, 511)]
+
+
+def acquisition_GLO(engine, settings, first_sample: int | None = None):
+    """GLO/GLO_GL1/include/acquisition.m:120-200: for every frequency number K the L1CA scheme around
+    IF - freqSpacing*K with the common 511-chip code; fine stage over 40 codes in 25-Hz bins against the 10-ms meander:
+    |sum(10 codes) - sum(next 10)| at 20 alignments.  Results are indexed K + 8."""
+    from .receiver import _acq_params
+    if first_sample is None:
+        first_sample = int(settings.skipNumberOfBytes)
+    spc = _round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength))
+    acq = SimpleNamespace(carrFreq=np.zeros(21), codePhase=np.zeros(21), peakMetric=np.zeros(21))
+    table = glonass_sampled_code(settings.samplingFreq, spc)[None, :]
+    code40 = glonass_sampled_code(settings.samplingFreq, spc * 40)
+    nfine = _round(settings.acqSearchStep / 25) + 1
+    ts = 1.0 / settings.samplingFreq
+    phase = np.arange(40 * spc) * 2 * math.pi * ts
+    for K in settings.acqSatelliteList:
+        p = _acq_params(settings, first_sample)
+        p.intermediate_freq = settings.IF - settings.freqSpacing * K               # :146-147
+        r = engine.acquire_coarse(p, table)[0]
+        acq.peakMetric[K + 8] = r.peak_metric
+        if r.peak_metric > settings.acqThreshold:
+            # the 40-code replica is an arbitrary sampled sequence here, so the per-code sums are formed on the host from
+            # the device record (40 x 12 000 samples x 21 bins)
+            raw = engine.read_if(first_sample + r.code_phase - 1, 40 * spc).astype(np.float64)
+            x = (raw[0::2] + 1j * raw[1::2]) * code40
+            fine, freqs = np.empty(nfine), np.empty(nfine)
+            for k in range(nfine):
+                freqs[k] = r.coarse_freq + settings.acqSearchStep / 2 - 25 * k
+                per_code = (x * np.exp(-1j * freqs[k] * phase)).reshape(40, spc).sum(axis=1)
+                fine[k] = max(abs(np.sum(per_code[c:c + 10]) - np.sum(per_code[c + 10:c + 20])) for c in range(20))   # :180-185
+            acq.carrFreq[K + 8] = float(freqs[int(np.argmax(fine))])
+            acq.codePhase[K + 8] = r.code_phase
+    return acq

@@ -95,6 +95,11 @@ def initSettings_GLO_GL1() -> SimpleNamespace:
     """GLONASS L1OF defaults (GLO/GLO_GL1/initSettings.m): only the fields the hot path reads."""
     s = initSettings()
     s.freqSpacing = 562.5e3          # :73
+    s.acqSatelliteList = list(range(-7, 7))  # :89 frequency numbers K
+    s.acqSearchBand = 5000           # :91
+    s.acqNonCohTime = 20             # :93
+    s.acqThreshold = 2.0             # :95
+    s.acqSearchStep = 500            # :97
     s.IF = 0.0                       # :77  nominal IF of channel K = 0
     s.samplingFreq = 12e6            # :79
     s.codeFreqBasis = 0.511e6        # :80

@@ -1263,3 +1263,42 @@ def acquisition_family_a(if_bytes: np.ndarray, settings, first_sample: int, coar
             acq.carrFreq[prn - 1] = f if f != 0 else 1
             acq.codePhase[prn - 1] = code_phase
     return acq
+
+
+def acquisition_glo(if_bytes: np.ndarray, settings, first_sample: int = 0):
+    """GLO/GLO_GL1/include/acquisition.m:120-200 (resampling off)."""
+    long_signal = _if_complex(if_bytes, first_sample, if_bytes.shape[0] // 2 - first_sample)
+    fs = settings.samplingFreq
+    spc = samples_per_code(settings)
+    ts = 1.0 / fs
+    code = generate_glo_code()
+
+    def sampled(n):
+        step = 511e3 / fs
+        s = np.floor(colon(0.0, step, n * step - step)).astype(np.int64)
+        return code[np.remainder(s, 511)]
+    table = sampled(spc)
+    code40 = sampled(spc * 40)
+    nfine = int(matlab_round(settings.acqSearchStep / 25)) + 1
+    fine_phase = np.arange(40 * spc) * 2 * math.pi * ts
+    sig_power = math.sqrt(np.var(long_signal[:spc], ddof=1) * spc)
+    acq = SimpleNamespace(carrFreq=np.zeros(21), codePhase=np.zeros(21), peakMetric=np.zeros(21))
+    s2 = SimpleNamespace(**vars(settings))
+    for K in settings.acqSatelliteList:
+        s2.IF = settings.IF - settings.freqSpacing * K
+        results = acquisition_coarse_results(long_signal, 0, s2, tables=[table])
+        coarse_bin = int(np.argmax(results.max(axis=1))) + 1
+        colmax = results.max(axis=0)
+        code_phase = int(np.argmax(colmax)) + 1
+        acq.peakMetric[K + 8] = float(colmax.max()) / sig_power / settings.acqNonCohTime
+        if acq.peakMetric[K + 8] > settings.acqThreshold:
+            coarse_freq = s2.IF + settings.acqSearchBand - settings.acqSearchStep * (coarse_bin - 1)
+            x = long_signal[code_phase - 1:code_phase - 1 + 40 * spc] * code40
+            fine, freqs = np.empty(nfine), np.empty(nfine)
+            for k in range(nfine):
+                freqs[k] = coarse_freq + settings.acqSearchStep / 2 - 25 * k
+                per_code = (x * np.exp(-1j * freqs[k] * fine_phase)).reshape(40, spc).sum(axis=1)
+                fine[k] = max(abs(np.sum(per_code[c:c + 10]) - np.sum(per_code[c + 10:c + 20])) for c in range(20))
+            acq.carrFreq[K + 8] = float(freqs[int(np.argmax(fine))])
+            acq.codePhase[K + 8] = code_phase
+    return acq
