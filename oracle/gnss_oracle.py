@@ -1302,3 +1302,35 @@ def acquisition_glo(if_bytes: np.ndarray, settings, first_sample: int = 0):
             acq.carrFreq[K + 8] = float(freqs[int(np.argmax(fine))])
             acq.codePhase[K + 8] = code_phase
     return acq
+
+
+def acquisition_front_end(long_signal: np.ndarray, settings):
+    """acquisition.m:46-111 (SURVEY.md §8a row A0 — restated on the CPU only; `resamplingflag` is 0 in every package's
+    initSettings and the hot path never takes this branch): FIR(700) band-pass around IF with zero-phase filtering,
+    then band-pass-sampling decimation by index selection and IF remapping.
+    Returns (long_signal', settings') — settings' carries the new samplingFreq / IF plus oldFreq / oldIF — or the
+    inputs unchanged when the branch is not taken.
+    fir1(700, wp) = Hamming-window design scaled to unit gain at the pass-band centre = scipy.signal.firwin(701, wp,
+    pass_zero=False); filtfilt(b, 1, x) pads with 3*(length(b)-1) odd-reflected samples at both ends."""
+    if not (settings.samplingFreq > settings.resamplingThreshold and getattr(settings, "resamplingflag", 0) == 1):
+        return long_signal, settings
+    from scipy.signal import filtfilt, firwin
+    fs = settings.samplingFreq
+    bw = settings.codeFreqBasis * 2 + 0.5e6                      # :50
+    w1, w2 = settings.IF - bw / 2, settings.IF + bw / 2           # :52-53
+    b = firwin(701, [w1 * 2 / fs, w2 * 2 / fs], pass_zero=False)  # :56-58
+    x = filtfilt(b, [1.0], long_signal, padtype="odd", padlen=3 * (b.size - 1))   # :60
+    fu = settings.IF + bw / 2                                     # :63
+    n = max(1, int(math.floor(fu / bw)))                          # :66-69
+    lower = 2 * fu / n                                            # :70
+    fl = settings.IF - bw / 2
+    upper = 2 * fl / (n - 1) if n > 1 else lower                  # :73-77
+    s2 = SimpleNamespace(**vars(settings))
+    s2.oldFreq = fs
+    s2.samplingFreq = float(math.ceil((lower + upper) / 2))       # :81
+    sig_len = int(math.floor((x.shape[0] - 1) / fs * s2.samplingFreq))   # :84
+    index = np.ceil(np.arange(sig_len) / s2.samplingFreq * fs).astype(np.int64)   # :87
+    index[0] = 1
+    s2.oldIF = settings.IF
+    s2.IF = math.fmod(settings.IF, s2.samplingFreq)               # :95 rem()
+    return x[index - 1], s2

@@ -110,3 +110,31 @@ def test_short_read_returns_from_the_function(l1ca_scene):
     assert aborted and 27 <= done[0] < 30 and done[1] == 0
     assert py[0].status == "-" and not py[0].I_P[int(done[0]):].any() and py[0].I_P[:int(done[0])].all()
     assert len(py) == 2 and not py[1].I_P.any()
+
+
+def test_acquisition_front_end_bandpass_decimation():
+    """acquisition.m:46-111, CPU restatement only: a tone inside the band survives the zero-phase
+    FIR(700) and lands at rem(IF, fs') after the index decimation; a tone outside is rejected; off by default."""
+    from types import SimpleNamespace
+    S = SimpleNamespace(samplingFreq=53e6, resamplingThreshold=8e6, resamplingflag=1, codeFreqBasis=1.023e6, IF=14.58e6)
+    n = 200000
+    t = np.arange(n) / S.samplingFreq
+    x = np.exp(2j * np.pi * (S.IF + 300e3) * t) + np.exp(2j * np.pi * (S.IF + 6e6) * t)
+    y, S2 = O.acquisition_front_end(x, S)
+    assert S2.oldFreq == 53e6 and S2.oldIF == 14.58e6
+    bw = 2 * 1.023e6 + 0.5e6
+    nn = int(np.floor((S.IF + bw / 2) / bw))
+    lower, upper = 2 * (S.IF + bw / 2) / nn, 2 * (S.IF - bw / 2) / (nn - 1)
+    assert S2.samplingFreq == np.ceil((lower + upper) / 2)
+    assert S2.IF == np.fmod(S.IF, S2.samplingFreq)
+    assert y.shape[0] == int(np.floor((n - 1) / 53e6 * S2.samplingFreq))
+    spec = np.abs(np.fft.fft(y[2000:-2000] * np.hanning(y.shape[0] - 4000)))
+    f = np.fft.fftfreq(y.shape[0] - 4000, 1 / S2.samplingFreq)
+    peak = f[int(np.argmax(spec))]
+    want = np.fmod(S.IF + 300e3, S2.samplingFreq)
+    want = want - S2.samplingFreq if want > S2.samplingFreq / 2 else want
+    assert abs(peak - want) < 2 * S2.samplingFreq / spec.shape[0] + 200
+    assert np.mean(np.abs(y[2000:-2000])) > 0.9 and np.mean(np.abs(y[2000:-2000])) < 1.1     # out-of-band tone gone
+    S.resamplingflag = 0
+    y0, S0 = O.acquisition_front_end(x, S)
+    assert y0 is x and S0 is S
