@@ -83,6 +83,7 @@ SYMBOLS = {
     "gc_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "gc_synchronize": (C.c_int, [_P]),
     "gc_load_if": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int]),
+    "gc_load_if_packed2": (C.c_int, [_P, _P, C.c_uint64]),
     "gc_open_if_file": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
     "gc_attach_if": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int]),
     "gc_if_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),

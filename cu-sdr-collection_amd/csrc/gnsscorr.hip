@@ -185,6 +185,56 @@ int gc_load_if(gc_context* ctx, const void* samples, uint64_t nsamples, int dtyp
   return GC_OK;
 }
 
+// 2-bit sign-magnitude complex samples, two per byte (GPS_L5C/include/unpack_cplx.m:32-49 expands them on the CPU
+// into a four-times larger schar file): bits {0,2} = sign, magnitude of I1, {1,3} of Q1, {4,6} of I2, {5,7} of Q2,
+// value = (1 + 2*mag) * (1 - 2*sign).  Here the packed bytes cross PCIe and are expanded into the int8 I/Q record
+// in HBM: 4 input bytes -> one 16-byte store per thread.
+namespace {
+__global__ void unpack2bit_kernel(const uint32_t* __restrict__ in, uint4* __restrict__ out, uint64_t nwords) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  const uint32_t w = in[i];
+  uint32_t o[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const uint32_t v = (w >> (8 * b)) & 0xffu;
+    auto dec = [&](int sbit, int mbit) -> uint32_t {
+      const int val = (1 + 2 * (int)((v >> mbit) & 1u)) * (1 - 2 * (int)((v >> sbit) & 1u));
+      return (uint32_t)(uint8_t)(int8_t)val;
+    };
+    o[b] = dec(0, 2) | (dec(1, 3) << 8) | (dec(4, 6) << 16) | (dec(5, 7) << 24);
+  }
+  out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+}  // namespace
+
+int gc_load_if_packed2(gc_context* ctx, const void* packed, uint64_t nbytes) {
+  if (!ctx || !packed || nbytes == 0) {
+    gc_set_error("gc_load_if_packed2: bad arguments");
+    return GC_E_INVALID;
+  }
+  int rc = gc_alloc_if(ctx, nbytes * 2, GC_I8, GC_IQ);  // two complex samples per packed byte
+  if (rc) return rc;
+  const uint64_t nwords = (nbytes + 3) / 4;
+  uint32_t* d_in = nullptr;
+  GC_HIP(hipMalloc((void**)&d_in, nwords * 4));
+  GC_HIP(hipMemsetAsync(d_in + (nwords - 1), 0, 4, ctx->stream));
+  hipError_t e = hipMemcpyAsync(d_in, packed, nbytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    // the record's allocation is padded past its payload, so a last partial word may store its full 16 bytes
+    hipLaunchKernelGGL(unpack2bit_kernel, dim3((unsigned int)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_in,
+                       reinterpret_cast<uint4*>(ctx->d_if), nwords);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_in);
+  if (e != hipSuccess) {
+    gc_set_error("gc_load_if_packed2: %s", hipGetErrorString(e));
+    return GC_E_HIP;
+  }
+  return GC_OK;
+}
+
 int gc_open_if_file(gc_context* ctx, const char* path, uint64_t skip_bytes, uint64_t nsamples,
                     int dtype, int layout) {
   if (!ctx || !path) return GC_E_INVALID;

@@ -65,6 +65,13 @@ class Engine:
         if fs is not None:
             self.set_sampling_freq(fs)
 
+    def load_if_packed2(self, packed: np.ndarray, fs: float | None = None):
+        """packed: uint8 array, two 2-bit sign-magnitude complex samples per byte (unpack_cplx.m's input format)."""
+        b = np.ascontiguousarray(packed, dtype=np.uint8)
+        L.check(self._lib.gc_load_if_packed2(self._ctx, b.ctypes.data_as(C.c_void_p), b.shape[0]))
+        if fs is not None:
+            self.set_sampling_freq(fs)
+
     def open_if_file(self, path: str, skip_bytes: int = 0, nsamples: int = 0, dtype=np.int8,
                      layout: int = L.GC_IQ, fs: float | None = None):
         dt, _ = self._fmt(np.dtype(dtype), layout)

@@ -66,6 +66,10 @@ int gc_synchronize(gc_context* ctx);
  * integers to the device.  The raw bytes stay as they are in HBM; conversion happens in
  * the kernels.  Replaces any previously loaded buffer. */
 int gc_load_if(gc_context* ctx, const void* samples, uint64_t nsamples, int dtype, int layout);
+/* 2-bit sign-magnitude packed complex records (two samples per byte; the reference converts them to schar files on
+ * the CPU with GPS_L5C/include/unpack_cplx.m:32-49): upload the packed bytes and expand them on the GPU into the
+ * int8 I/Q record (2 * nbytes samples).  SURVEY.md §8f item 2. */
+int gc_load_if_packed2(gc_context* ctx, const void* packed, uint64_t nbytes);
 /* As gc_load_if, reading from a file: `skip_bytes` as postProcessing.m:74
  * (fseek(fid, dataAdaptCoeff*skipNumberOfBytes)); nsamples = 0 reads to end of file. */
 int gc_open_if_file(gc_context* ctx, const char* path, uint64_t skip_bytes, uint64_t nsamples,

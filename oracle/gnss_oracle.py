@@ -1334,3 +1334,16 @@ def acquisition_front_end(long_signal: np.ndarray, settings):
     s2.oldIF = settings.IF
     s2.IF = math.fmod(settings.IF, s2.samplingFreq)               # :95 rem()
     return x[index - 1], s2
+
+
+def unpack_cplx(packed: np.ndarray) -> np.ndarray:
+    """GPS/GPS_L5C/include/unpack_cplx.m:32-49 as arithmetic instead of four 256-entry tables: each byte holds two
+    complex samples of 2-bit sign-magnitude components — I1: sign bit 0, magnitude bit 2; Q1: bits 1, 3; I2: bits 4, 6;
+    Q2: bits 5, 7; value = (1 + 2*magnitude) * (1 - 2*sign).  Returns the schar stream I1, Q1, I2, Q2, ..."""
+    v = np.asarray(packed, dtype=np.uint8).astype(np.int64)
+
+    def dec(sbit, mbit):
+        return (1 + 2 * ((v >> mbit) & 1)) * (1 - 2 * ((v >> sbit) & 1))
+    out = np.empty(4 * v.shape[0], dtype=np.int8)
+    out[0::4], out[1::4], out[2::4], out[3::4] = dec(0, 2), dec(1, 3), dec(4, 6), dec(5, 7)
+    return out

@@ -228,3 +228,16 @@ def test_tie_dense_blocks_use_the_references_two_roundings(engine, l1ca_scene):
                 assert np.abs(got - ref).max() < TOL * _scale(iq, d), (generic, d, got, ref)
         finally:
             engine.force_generic_kernel(False)
+
+
+def test_two_bit_packed_record_is_expanded_on_the_gpu(engine):
+    """gc_load_if_packed2: the packed bytes of unpack_cplx.m's input format cross PCIe and become the int8
+    I/Q record in HBM; bit-exact against the oracle's restatement of the reference's lookup tables, odd lengths included."""
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 4, 1021, 200001):
+        packed = rng.integers(0, 256, size=n, dtype=np.uint8)
+        engine.load_if_packed2(packed, fs=18e6)
+        _, ns = engine.if_buffer()
+        assert ns == 2 * n
+        got = engine.read_if(0, 2 * n)
+        assert np.array_equal(got, O.unpack_cplx(packed))

@@ -3,6 +3,7 @@ independent restatements (NumPy and C)."""
 import math
 
 import numpy as np
+import pytest
 
 from oracle import c_oracle as CO
 from oracle import gnss_oracle as O
@@ -138,3 +139,23 @@ def test_acquisition_front_end_bandpass_decimation():
     S.resamplingflag = 0
     y0, S0 = O.acquisition_front_end(x, S)
     assert y0 is x and S0 is S
+
+
+def test_unpack_cplx_rule_against_the_references_tables():
+    """The oracle states unpack_cplx.m's four 256-entry lookup tables as a bit rule; where the reference tree is
+    present (build container) the rule is checked against the tables themselves."""
+    import os
+    import re
+    all_bytes = np.arange(256, dtype=np.uint8)
+    out = O.unpack_cplx(all_bytes).reshape(256, 4)
+    assert set(np.unique(out)) == {-3, -1, 1, 3}
+    assert out[0].tolist() == [1, 1, 1, 1] and out[0b00000101].tolist() == [-3, 1, 1, 1] and out[0b11110000].tolist() == [1, 1, -3, -3]
+    path = "/root/reference/GPS/GPS_L5C/include/unpack_cplx.m"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present (GPU box)")
+    text = open(path, encoding="latin-1").read()
+    for col, name in enumerate(("LUT_I_long1", "LUT_Q_long1", "LUT_I_long2", "LUT_Q_long2")):
+        body = re.search(name + r"\s*=\s*\[(.*?)\];", text, re.S).group(1)
+        table = np.array([int(x) for x in re.findall(r"-?\d+", body)])
+        assert table.shape == (256,)
+        assert np.array_equal(out[:, col], table), name
