@@ -6,7 +6,7 @@ engine.py (context wrapper), receiver.py (acquisition / preRun / tracking with t
 names and struct fields), codes.py (code generators), settings.py (initSettings mirror),
 synth.py (synthetic IF records).  Nothing here imports `oracle/`; there is no CPU fallback.
 """
-from . import _lib, acq_family, acq_shift, codes, settings, signals, synth  # noqa: F401
+from . import _lib, acq_family, acq_shift, codes, nav_sync, settings, signals, synth  # noqa: F401
 from ._lib import GnssCorrError  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .receiver import CNoVSM, acquisition, preRun, tracking  # noqa: F401

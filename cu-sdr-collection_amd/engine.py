@@ -208,6 +208,14 @@ class Engine:
         L.check(self._lib.gc_acq_shift_row(self._ctx, int(row), out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def preamble_xcorr(self, i_p: np.ndarray, pattern: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(i_p, dtype=np.float64)
+        pat = np.ascontiguousarray(pattern, dtype=np.int8)
+        out = np.empty(x.shape[0], dtype=np.float32)
+        L.check(self._lib.gc_preamble_xcorr(self._ctx, x.ctypes.data_as(C.POINTER(C.c_double)), x.shape[0],
+                                            pat.ctypes.data_as(C.c_void_p), pat.shape[0], out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def debug_fft(self, x: np.ndarray, inverse: bool = False) -> np.ndarray:
         """x: complex64 [nbatch, n].  The library's FFT (test hook)."""
         x = np.ascontiguousarray(x, dtype=np.complex64)

@@ -291,6 +291,12 @@ int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const d
                         float* row_max, int32_t* row_argmax);
 int gc_acq_shift_row(gc_context* ctx, int row, float* out /* n floats */);
 
+/* ---- bit synchronisation front end of navigation decoding ------------------------------
+ * GPS_L1CA/include/NAVdecoding.m:62-76: out[l] = sum_k sgn(I_P[l+k]) * pattern[k] for lags l = 0 .. n-1 — the
+ * non-negative-lag half of xcorr(bits, preamble_ms) with bits = +1 where I_P > 0, else -1.  The threshold / 6000-ms
+ * spacing / parity logic (:78-100) stays with the caller (nav_sync.py). */
+int gc_preamble_xcorr(gc_context* ctx, const double* i_p, int64_t n, const int8_t* pattern, int m, float* out);
+
 /* Test hook (host only, no GPU): first sample i in [0, n) whose ramp value a + i*step is within eps chips of
  * an integer, or -1 — the exact near-tie analysis that lets the kernels skip their per-chunk filters. */
 long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps);

@@ -1347,3 +1347,44 @@ def unpack_cplx(packed: np.ndarray) -> np.ndarray:
     out = np.empty(4 * v.shape[0], dtype=np.int8)
     out[0::4], out[1::4], out[2::4], out[3::4] = dec(0, 2), dec(1, 3), dec(4, 6), dec(5, 7)
     return out
+
+
+def nav_parity_check(ndat) -> int:
+    """Common/navPartyChk.m in its own +-1 product form."""
+    n = [int(v) for v in ndat]
+    if n[1] != 1:
+        for k in range(2, 26):
+            n[k] = -n[k]
+    d = [None] + n   # 1-based like the .m
+
+    def prod(ix):
+        r = 1
+        for k in ix:
+            r *= d[k]
+        return r
+    parity = [prod([1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22, 25]),
+              prod([2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23, 26]),
+              prod([1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24]),
+              prod([2, 4, 6, 7, 8, 10, 11, 15, 16, 17, 18, 19, 22, 23, 25]),
+              prod([2, 3, 5, 7, 8, 9, 11, 12, 16, 17, 18, 19, 20, 23, 24, 26]),
+              prod([1, 5, 7, 8, 10, 11, 12, 13, 15, 17, 21, 24, 25, 26])]
+    return -n[1] if parity == n[26:32] else 0
+
+
+def find_subframe_start(i_p: np.ndarray, ms_to_process: int, search_start_offset: int = 0):
+    """GPS/GPS_L1CA/include/NAVdecoding.m:55-100: hard-limited prompt stream, xcorr with the 8-bit preamble stretched to
+    160 samples, |.| > 153, candidates 6000 ms apart, parity of the first two words."""
+    i_p = np.asarray(i_p, dtype=np.float64)
+    pre = np.kron(np.array([1, -1, -1, -1, 1, -1, 1, 1], dtype=np.float64), np.ones(20))
+    bits = np.where(i_p[search_start_offset:] > 0, 1.0, -1.0)
+    n = bits.shape[0]
+    full = np.correlate(np.concatenate([bits, np.zeros(pre.shape[0])]), pre, mode="valid")[:n]   # xcorr's lags 0..n-1
+    index = np.flatnonzero(np.abs(full) > 153) + 1 + search_start_offset
+    index = index[(index > 40) & (index < ms_to_process - (20 * 60 - 1))]
+    for i in index:
+        if np.any(index - i == 6000):
+            b = i_p[i - 40 - 1:i + 20 * 60 - 1].reshape(-1, 20).sum(axis=1)
+            b = np.where(b > 0, 1, -1)
+            if nav_parity_check(b[0:32]) != 0 and nav_parity_check(b[30:62]) != 0:
+                return int(i), full
+    return None, full

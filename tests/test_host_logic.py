@@ -100,3 +100,41 @@ def test_first_sample_near_edge_matches_brute_force():
         hits += ref >= 0
         assert got == ref, (a, st, n, eps, got, ref)
     assert 10 < hits < 110
+
+
+def _nav_stream(rng, start_ms, n_subframes, invert=False):
+    """A prompt in-phase stream (one value per ms) with valid LNAV sub-frames: every word's parity from IS-GPS-200."""
+    from cu_sdr_collection_amd import nav_sync
+    bits = []      # logic bits of consecutive 30-bit words
+    d29 = d30 = 0
+    for sf in range(n_subframes):
+        for w in range(10):
+            data = rng.integers(0, 2, size=24)
+            if w == 0:
+                data[:8] = [1, 0, 0, 0, 1, 0, 1, 1]
+            src = [d29, d30] + list(data)
+            par = [int(np.bitwise_xor.reduce([src[t - 1] for t in taps])) for taps in nav_sync._PARITY_TAPS]
+            word = [int(b) ^ d30 for b in data] + par          # transmitted data bits are XORed with D30*
+            bits += word
+            d29, d30 = word[28], word[29]
+    pm = np.array([1.0 if b else -1.0 for b in bits])
+    if invert:
+        pm = -pm
+    stream = np.repeat(pm, 20) * 2000.0
+    # random garbage, then the two bits D29* = D30* = 0 that the first word's parity was computed with
+    pad = np.concatenate([rng.choice([-1.0, 1.0], size=start_ms - 1 - 40), np.full(40, 1.0 if invert else -1.0)]) * 2000.0
+    x = np.concatenate([pad, stream, rng.choice([-1.0, 1.0], size=3000) * 2000.0])
+    return x + 300.0 * rng.standard_normal(x.shape[0])
+
+
+def test_nav_parity_and_subframe_search_oracle():
+    """Host logic of the bit-sync front end (NAVdecoding.m:78-100, navPartyChk.m) — oracle restatement, both polarities."""
+    rng = np.random.default_rng(3)
+    for invert in (False, True):
+        x = _nav_stream(rng, 777, 3, invert)
+        start, corr = O.find_subframe_start(x, x.shape[0])
+        assert start == 777
+        assert abs(corr[776]) == 160
+    from cu_sdr_collection_amd import nav_sync
+    w = rng.choice([-1, 1], size=32)
+    assert nav_sync.navPartyChk(w) == O.nav_parity_check(w)
