@@ -102,6 +102,8 @@ SYMBOLS = {
     "gc_timer_stop": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "gc_track": (C.c_int, [_P, C.POINTER(gc_track_params), C.c_int, C.POINTER(gc_channel_init),
                            C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "gc_track_device": (C.c_int, [_P, C.POINTER(gc_track_params), C.c_int, C.POINTER(gc_channel_init),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "gc_acquire_coarse": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_coarse_multi": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,

@@ -44,6 +44,8 @@ struct InlineBlocks {
   gc_block b[kInlineBlocks];
 };
 
+struct DevLoopArgs;
+
 struct KArgs {
   const uint8_t* if_base;
   const gc_block* blocks;
@@ -66,6 +68,7 @@ struct KArgs {
   // Up to kInlineBlocks descriptors travel in the kernel-argument segment (no PCIe read of the
   // host-mapped descriptor buffer at the start of every workgroup).
   int use_inline;
+  const struct DevLoopArgs* devloop;  // device-side loop closure (devloop.h); nullptr otherwise
   int wide;      // fast kernel variant with 4 waves per workgroup and int8-pair LDS tables
   int share_el;  // every block has el_spacing*R*M == 1/2: early and late taps share their step mask
 };
@@ -277,5 +280,6 @@ __device__ __forceinline__ gc_block load_block(const KArgs& p, long long lb) {
 int gc_launch_correlator_lane(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
                               int max_arms, bool share_el);
 // corr_fast.hip
+int gc_launch_devloop(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, bool spl16, bool share_el);
 int gc_launch_correlator_fast(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
                               int max_arms, bool spl16);

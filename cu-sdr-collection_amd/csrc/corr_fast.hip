@@ -19,6 +19,7 @@
 //     4e-6 of an integer (a sample within ~1e-7 chip of a chip edge, where float32 and the reference's
 //     float64 rounding could disagree) take the exact double-precision path.
 #include "corr_common.h"
+#include "devloop.h"
 
 using namespace gcorr;
 
@@ -39,7 +40,9 @@ constexpr int kFW = 64;  // one wavefront per workgroup
 // entry instead of 8): for tables that would otherwise leave one wave per SIMD (Galileo E1 B+C: 2 x 8186
 // entries = 131 KB as float2, 33 KB as int8 pairs).  Every wave owns its own blocks / splits; the only
 // barrier is the one after staging.
-template <int ARMS, int MODE, int SPL, bool CL, bool SHARE_EL, bool WIDE>
+// DEVLOOP = persistent launch with device-side loop closure (devloop.h): the block loop becomes the epoch loop of ONE
+// channel, descriptors come from the channel's device state, sums go to the team's slot array.
+template <int ARMS, int MODE, int SPL, bool CL, bool SHARE_EL, bool WIDE, bool DEVLOOP = false>
 __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = SPL * Fmt<MODE>::bps / 4;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   unsigned short* tab16[ARMS];
   {
     const long long lb0 = min(grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
-    const gc_block blk0 = CL ? load_block(p, lb0) : p.blocks[lb0];
+    const gc_block blk0 = DEVLOOP ? p.devloop->chan[lb0].blk : CL ? load_block(p, lb0) : p.blocks[lb0];
     const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
 #pragma unroll
     for (int a = 0; a < ARMS; ++a) {
@@ -113,10 +116,34 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   };
   if (wave_items && wq >= p.nblocks) return;
 
-  for (int bi = (WIDE && !wave_items) ? wave : 0; bi < p.bpw; bi += (WIDE && !wave_items) ? 4 : 1) {
-  const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
+  const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
+  for (int bi = (WIDE && !wave_items) ? wave : 0; bi < nloop; bi += (WIDE && !wave_items) ? 4 : 1) {
+  const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
-  const gc_block blk = CL ? load_block(p, lb) : p.blocks[lb];
+  gc_block blk;
+  if constexpr (DEVLOOP) {
+    // wait until the closing member of epoch bi - 1 has published this epoch's descriptor (bounded: a lost team
+    // member must not hang the device), then read it with loads that cannot be served from a stale cache
+    DevLoopChan* ch = p.devloop->chan + lb;
+    unsigned int spins = 0;
+    while (__hip_atomic_load(&ch->epoch_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)bi && ++spins <= (1u << 24))
+      __builtin_amdgcn_s_sleep(1);
+    if (spins > (1u << 24)) {
+      if (lane == 0) __hip_atomic_store(&ch->status, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    if (__hip_atomic_load(&ch->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;  // record exhausted / timed out
+    union {
+      gc_block b;
+      unsigned long long q[sizeof(gc_block) / 8];
+    } u;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&ch->blk);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) u.q[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    blk = u.b;
+  } else {
+    blk = CL ? load_block(p, lb) : p.blocks[lb];
+  }
   const DevChannel* __restrict__ chn = p.chans + blk.channel;
   const int arms_here = chn->arms;
 
@@ -354,7 +381,33 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
       tot[ar * 6 + 2 * x] = wave_sum_lane63(wc * accr[ar][x] + ws * acci[ar][x]);
       tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(wc * acci[ar][x] - ws * accr[ar][x]);
     }
-  if (CL) {
+  if constexpr (DEVLOOP) {
+    const DevLoopArgs* dl = p.devloop;
+    DevLoopChan* ch = dl->chan + lb;
+    float* slots = dl->partial + (size_t)lb * dl->splits * 6;
+    if (lane == 63) {
+#pragma unroll
+      for (int v = 0; v < 6; ++v) __hip_atomic_store(slots + split * 6 + v, tot[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned int prev = 0;
+    if (lane == 63) prev = __hip_atomic_fetch_add(&ch->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    prev = (unsigned int)__builtin_amdgcn_readlane((int)prev, 63);
+    if (prev == (unsigned int)dl->splits - 1u) {
+      // last to arrive: close the loop for this channel and epoch
+      double sums[6];
+#pragma unroll
+      for (int v = 0; v < 6; ++v) {
+        double s = 0.0;
+        for (int k = 0; k < dl->splits; ++k) s += (double)__hip_atomic_load(slots + k * 6 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sums[v] = s;
+      }
+      devloop_close(dl, ch, blk, lb, bi, sums, lane);
+      if (lane == 0) {
+        __hip_atomic_store(&ch->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ch->epoch_ready, (unsigned int)bi + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else if (CL) {
     // lane v takes total v (broadcast from lane 63) and stores its 16-byte tagged record
     TaggedSlot* ts = p.tagged + (lb * p.splits + split) * GC_OUT_STRIDE;
     float mine = 0.0f;
@@ -423,7 +476,29 @@ int launch_fast_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, di
   return GC_OK;
 }
 
+template <int SPL>
+int launch_devloop_mode(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share) {
+  void* args[2] = {(void*)&a, (void*)&ib};
+  const void* fn = nullptr;
+  const bool qi = ctx->if_layout == GC_QI;
+  if (share) fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, true, false, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, true, false, true>;
+  else fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, false, false, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, false, false, true>;
+  // cooperative: every team member must be resident while the others spin on the epoch flag
+  GC_HIP(hipLaunchCooperativeKernel(fn, grid, dim3(kFW), args, (unsigned int)smem, ctx->stream));
+  return GC_OK;
+}
+
 }  // namespace
+
+// Persistent single-arm int8 I/Q (Q/I) tracker with device-side loop closure: grid = channels x splits one-wave workgroups.
+int gc_launch_devloop(gc_context* ctx, const KArgs& a_in, unsigned int grid, bool spl16, bool share_el) {
+  KArgs a = a_in;
+  InlineBlocks ib;
+  std::memset(&ib, 0, sizeof ib);
+  a.red_off = 8 * ctx->max_lds_bytes;
+  const size_t smem = (size_t)a.red_off + 64;
+  return spl16 ? launch_devloop_mode<16>(ctx, a, ib, dim3(grid), smem, share_el) : launch_devloop_mode<8>(ctx, a, ib, dim3(grid), smem, share_el);
+}
 
 // spl16: every block satisfies 15*step*R*M < 1 and the samples are int8 I/Q
 int gc_launch_correlator_fast(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, int max_arms,

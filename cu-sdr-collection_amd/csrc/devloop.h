@@ -1,0 +1,125 @@
+// devloop.h — device-side loop closure: the tracking loop of tracking.m:184-348 without the
+// per-epoch host round trip.  ONE persistent launch runs all epochs; the workgroups that share a channel (its
+// "team": one per split) meet once per epoch through two device-scope atomics:
+//   every team member adds its partial sums to the channel's slot array and increments `arrive`;
+//   the member that arrives LAST closes the loop (discriminators, loop filters, next block geometry — the same
+//   float64 statements as gc_track's host loop, tracking.m:302-335), writes the epoch's records, publishes the next
+//   descriptor and releases `epoch_ready`; the others spin on it.
+// Channels never wait for each other.  All team workgroups must be co-resident: the launch is cooperative.
+#pragma once
+#include "gc_internal.h"
+
+namespace gcorr {
+
+struct DevLoopChan {
+  gc_block blk;             // descriptor of epoch `epoch_ready` (written by the closing member)
+  unsigned int epoch_ready;  // epochs whose descriptor has been published: blk is valid for epoch == epoch_ready - 1
+  unsigned int arrive;       // partial sums delivered for the current epoch
+  int status;                // 0 running, 1 all epochs done, 2 record exhausted (tracking.m:241-245), 3 wait timed out
+  int epochs_done;
+  // loop state, touched by the closing member only
+  long long pos;
+  double code_freq, code_freq_basis, rem_code;
+  double carr_freq, carr_basis, rem_carr;
+  double old_code_nco, old_code_err, old_carr_nco, old_carr_err;  // 2nd-order PLL / DLL
+  double d2_carr_err, d_carr_err;                                 // 3-state PLL
+  double pad[3];
+};
+
+struct DevLoopArgs {
+  DevLoopChan* chan;   // [nch]
+  float* partial;      // [nch][splits][6]
+  double* records;     // [nch][GC_TRK_NFIELDS][n_epochs]
+  gc_track_params prm;
+  double tau1code, tau2code, tau1carr, tau2carr;
+  unsigned long long if_nsamples;
+  int n_epochs;
+  int splits;
+  int code_index_scale_is_one;  // R == 1 (the only case wired up)
+  int reserved;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// Closing member: lane-uniform float64 restatement of tracking.m:273-348 for one channel and epoch.
+__device__ inline void devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopChan* ch, const gc_block& b, long long slot, int e,
+                                     const double (&sums)[6], int lane) {
+  const gc_track_params& p = dl->prm;
+  const double kPi = 3.141592653589793;
+  const int n = b.blksize;
+  const double step = b.code_phase_step;
+  double* o = dl->records + (size_t)slot * GC_TRK_NFIELDS * dl->n_epochs;
+  auto rec = [&](int f, double v) {
+    if (lane == 0) o[(size_t)f * dl->n_epochs + e] = v;
+  };
+  const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
+  rec(GC_TRK_ABSOLUTE_SAMPLE, (double)ch->pos);
+  rec(GC_TRK_REM_CODE_PHASE, ch->rem_code);
+  rec(GC_TRK_REM_CARR_PHASE, ch->rem_carr);
+  const double t_last = ((n - 1) * step + ch->rem_code);                       // tcode(blksize), :273 (R = 1)
+  const double rem_code_new = (t_last + step) - p.code_length;
+  const double time_n = (double)n / p.sampling_freq;                            // :280-283
+  const double trig_n = ((ch->carr_freq * 2.0 * kPi) * time_n) + ch->rem_carr;
+  const double rem_carr_new = fmod(trig_n, 2 * kPi);
+  const double carr_err = atan(q_p / i_p) / (2.0 * kPi);                        // :305
+  const double code_err = (sqrt(i_e * i_e + q_e * q_e) - sqrt(i_l * i_l + q_l * q_l)) /
+                          (sqrt(i_e * i_e + q_e * q_e) + sqrt(i_l * i_l + q_l * q_l));  // :322-323
+  double carr_nco;
+  double old_carr_nco = ch->old_carr_nco, old_carr_err = ch->old_carr_err, d2 = ch->d2_carr_err, d1 = ch->d_carr_err;
+  if (p.pll_kind == GC_PLL_2ND_ORDER) {
+    carr_nco = old_carr_nco + (dl->tau2carr / dl->tau1carr) * (carr_err - old_carr_err) + carr_err * (p.int_time / dl->tau1carr);  // :308-309
+    old_carr_nco = carr_nco;
+    old_carr_err = carr_err;
+  } else {
+    d2 = d2 + carr_err * p.pf3;  // GPS_L5C tracking.m:351-353
+    d1 = d2 + carr_err * p.pf2 + d1;
+    carr_nco = d1 + carr_err * p.pf1;
+  }
+  rec(GC_TRK_CARR_FREQ, ch->carr_freq);
+  const double carr_freq_new = ch->carr_basis + carr_nco;                        // :317
+  const double code_nco = ch->old_code_nco + (dl->tau2code / dl->tau1code) * (code_err - ch->old_code_err) + code_err * (p.int_time / dl->tau1code);
+  rec(GC_TRK_CODE_FREQ, ch->code_freq);
+  const double code_freq_new = ch->code_freq_basis - code_nco;                   // :335
+  rec(GC_TRK_DLL_DISCR, code_err);
+  rec(GC_TRK_DLL_DISCR_FILT, code_nco);
+  rec(GC_TRK_PLL_DISCR, carr_err);
+  rec(GC_TRK_PLL_DISCR_FILT, carr_nco);
+  rec(GC_TRK_I_E, i_e);
+  rec(GC_TRK_Q_E, q_e);
+  rec(GC_TRK_I_P, i_p);
+  rec(GC_TRK_Q_P, q_p);
+  rec(GC_TRK_I_L, i_l);
+  rec(GC_TRK_Q_L, q_l);
+  // next block geometry (:219-222) or the end
+  const long long pos_new = ch->pos + n;
+  const double step_new = code_freq_new / p.sampling_freq;
+  const int n_new = (int)ceil((p.code_length - rem_code_new) / step_new);
+  int status = 0;
+  if (e + 1 >= dl->n_epochs)
+    status = 1;
+  else if (pos_new < 0 || (unsigned long long)(pos_new + n_new) > dl->if_nsamples)
+    status = 2;
+  if (lane == 0) {
+    ch->pos = pos_new;
+    ch->rem_code = rem_code_new;
+    ch->rem_carr = rem_carr_new;
+    ch->carr_freq = carr_freq_new;
+    ch->code_freq = code_freq_new;
+    ch->old_code_nco = code_nco;
+    ch->old_code_err = code_err;
+    ch->old_carr_nco = old_carr_nco;
+    ch->old_carr_err = old_carr_err;
+    ch->d2_carr_err = d2;
+    ch->d_carr_err = d1;
+    ch->epochs_done = e + 1;
+    ch->blk.blksize = n_new;
+    ch->blk.first_sample = pos_new;
+    ch->blk.rem_code_phase = rem_code_new;
+    ch->blk.code_phase_step = step_new;
+    ch->blk.carr_freq = carr_freq_new;
+    ch->blk.rem_carr_phase = rem_carr_new;
+    ch->status = status;
+  }
+}
+#endif
+
+}  // namespace gcorr

@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "corr_common.h"
+#include "devloop.h"
 
 namespace {
 
@@ -366,6 +367,160 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   }
   if (any_range) {
     gc_set_error("Not able to read the specified number of samples for tracking");
+    return GC_E_RANGE;
+  }
+  return GC_OK;
+}
+
+// ---- device-side loop closure (devloop.h) -----------------------------------------------------------------------
+// Same contract as gc_track for the signals the persistent kernel is instantiated for: single-arm channels whose
+// blocks qualify for the transition-mask kernel with float2 tables (GPS L1 C/A, GLONASS L1OF, BDS B1I), int8 I/Q or Q/I
+// records, no pilot.  Anything else returns GC_E_UNSUPPORTED and the caller uses gc_track.
+extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
+                               double* out, int32_t* epochs_done) {
+  if (!ctx || !p || nch <= 0 || nch > GC_MAX_CHANNELS || !init || !out || !epochs_done || p->n_epochs <= 0) {
+    gc_set_error("gc_track_device: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if) {
+    gc_set_error("gc_track_device: no IF buffer loaded");
+    return GC_E_STATE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  ctx->fs = p->sampling_freq;
+  int rc = gc_sync_channels(ctx);
+  if (rc) return rc;
+  gc_scope_reset(ctx);
+  for (int c = 0; c < nch; ++c) {
+    const int ci = init[c].channel;
+    if (ci < 0 || ci >= GC_MAX_CHANNELS || !ctx->ch[ci].configured || !ctx->ch[ci].d_tab[0]) {
+      gc_set_error("gc_track_device: channel %d not configured", ci);
+      return GC_E_STATE;
+    }
+    if (ctx->ch[ci].arms != 1 || ctx->ch[ci].index_scale != 1.0 || ctx->ch[ci].mult[0] != 1.0) {
+      gc_set_error("gc_track_device: single-arm R = 1 channels only (use gc_track)");
+      return GC_E_UNSUPPORTED;
+    }
+    gc_scope_add(ctx, ci);
+  }
+  if (p->pilot_combine != 0 || p->table_phase_count != 0 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL ||
+      gc_fast_table_mode(ctx) != 0 || ctx->force_generic) {
+    gc_set_error("gc_track_device: configuration not covered by the persistent kernel (use gc_track)");
+    return GC_E_UNSUPPORTED;
+  }
+  const int n_epochs = p->n_epochs;
+  std::vector<gcorr::DevLoopChan> hc((size_t)nch);
+  std::memset(hc.data(), 0, sizeof(gcorr::DevLoopChan) * (size_t)nch);
+  int lowrate = 2;
+  bool share = true;
+  for (int c = 0; c < nch; ++c) {
+    gcorr::DevLoopChan& s = hc[c];
+    s.pos = p->skip_samples + init[c].code_phase - 1;  // tracking.m:150-152
+    s.code_freq = s.code_freq_basis = init[c].code_freq;
+    s.carr_freq = s.carr_basis = init[c].acquired_freq;
+    const double step = s.code_freq / p->sampling_freq;
+    const int n = (int)std::ceil((p->code_length - s.rem_code) / step);
+    gc_block& b = s.blk;
+    b.channel = init[c].channel;
+    b.blksize = n;
+    b.first_sample = s.pos;
+    b.rem_code_phase = 0.0;
+    b.code_phase_step = step;
+    b.el_spacing = p->el_spacing;
+    b.carr_freq = s.carr_freq;
+    b.rem_carr_phase = 0.0;
+    if (s.pos < 0 || (uint64_t)(s.pos + n) > ctx->if_nsamples) s.status = 2;  // not even one block: tracking.m:241-245
+    gc_block probe = b;
+    probe.code_phase_step = step * 1.001;  // head-room for the code NCO
+    lowrate = std::min(lowrate, gc_block_lowrate_level(ctx, probe));
+    share = share && gc_block_shares_el(ctx, b);
+  }
+  if (lowrate <= 0) {
+    gc_set_error("gc_track_device: code rate too high for the transition-mask kernel (use gc_track)");
+    return GC_E_UNSUPPORTED;
+  }
+  // team size: enough one-wave workgroups to fill the device, at least ~one lane-chunk per lane and split
+  const int spl = lowrate == 2 ? 16 : 8;
+  const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
+  int splits = std::max(1, std::min({64, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 64)}));
+  if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(64, std::atoi(e)));
+
+  gcorr::DevLoopArgs ha;
+  std::memset(&ha, 0, sizeof ha);
+  ha.prm = *p;
+  calc_loop_coef(p->dll_noise_bw, p->dll_damping, 1.0, &ha.tau1code, &ha.tau2code);
+  calc_loop_coef(p->pll_noise_bw, p->pll_damping, 0.25, &ha.tau1carr, &ha.tau2carr);
+  ha.if_nsamples = ctx->if_nsamples;
+  ha.n_epochs = n_epochs;
+  ha.splits = splits;
+  ha.code_index_scale_is_one = 1;
+  gcorr::DevLoopArgs* d_args = nullptr;
+  const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
+  hipError_t e = hipMalloc((void**)&ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
+  if (e == hipSuccess) e = hipMalloc((void**)&ha.partial, sizeof(float) * (size_t)nch * splits * 6);
+  if (e == hipSuccess) e = hipMalloc((void**)&ha.records, rec_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_args, sizeof ha);
+  if (e == hipSuccess) e = hipMemsetAsync(ha.records, 0, rec_bytes, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ha.partial, 0, sizeof(float) * (size_t)nch * splits * 6, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ha.chan, hc.data(), sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_args, &ha, sizeof ha, hipMemcpyHostToDevice, ctx->stream);
+  auto cleanup = [&]() {
+    if (ha.chan) (void)hipFree(ha.chan);
+    if (ha.partial) (void)hipFree(ha.partial);
+    if (ha.records) (void)hipFree(ha.records);
+    if (d_args) (void)hipFree(d_args);
+  };
+  if (e != hipSuccess) {
+    cleanup();
+    gc_set_error("gc_track_device: %s", hipGetErrorString(e));
+    return GC_E_NOMEM;
+  }
+  gcorr::KArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.if_base = ctx->d_if;
+  a.blocks = nullptr;
+  a.chans = ctx->d_channels;
+  a.fs = ctx->fs;
+  a.nblocks = nch;
+  a.splits = splits;
+  a.bpw = 1;
+  a.stride = 1;
+  a.share_el = share ? 1 : 0;
+  a.devloop = d_args;
+  rc = gc_launch_devloop(ctx, a, (unsigned int)(nch * splits), lowrate == 2, share);
+  if (rc == GC_OK) {
+    e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, ha.records, rec_bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hc.data(), ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      gc_set_error("gc_track_device: %s", hipGetErrorString(e));
+      rc = GC_E_HIP;
+    }
+  }
+  cleanup();
+  if (rc) return rc;
+  // same early-return semantics as gc_track: channels after the first exhausted one are never run
+  int first_aborted = nch;
+  bool timeout = false;
+  for (int c = 0; c < nch; ++c) {
+    timeout |= hc[c].status == 3;
+    if (hc[c].status == 2 && first_aborted == nch) first_aborted = c;
+  }
+  if (timeout) {
+    gc_set_error("gc_track_device: a team member timed out waiting for its epoch descriptor");
+    return GC_E_HIP;
+  }
+  for (int c = 0; c < nch; ++c) {
+    if (c > first_aborted) {
+      double* o = out + (size_t)c * GC_TRK_NFIELDS * n_epochs;
+      std::fill(o, o + (size_t)GC_TRK_NFIELDS * n_epochs, 0.0);
+      epochs_done[c] = 0;
+    } else {
+      epochs_done[c] = hc[c].epochs_done;
+    }
+  }
+  if (first_aborted < nch) {
+    gc_set_error("Not able to read the specified number of samples for tracking (channel slot %d)", first_aborted);
     return GC_E_RANGE;
   }
   return GC_OK;

@@ -152,14 +152,16 @@ class Engine:
         return ms.value
 
     # ---- closed-loop tracking ------------------------------------------------------------
-    def track(self, params: L.gc_track_params, inits):
-        """Runs gc_track.  Returns (fields dict name -> [nch, n_epochs], epochs_done, status)."""
+    def track(self, params: L.gc_track_params, inits, device_loop: bool = False):
+        """Runs gc_track (or gc_track_device: loop closed on the GPU, one persistent launch).
+        Returns (fields dict name -> [nch, n_epochs], epochs_done, status)."""
         nch = len(inits)
         arr = (L.gc_channel_init * nch)(*inits)
         n_ep = params.n_epochs
         out = np.zeros((nch, L.GC_TRK_NFIELDS, n_ep))
         done = (C.c_int32 * nch)()
-        st = self._lib.gc_track(self._ctx, C.byref(params), nch, arr,
+        fn = self._lib.gc_track_device if device_loop else self._lib.gc_track
+        st = fn(self._ctx, C.byref(params), nch, arr,
                                 out.ctypes.data_as(C.POINTER(C.c_double)), done)
         if st not in (L.GC_OK, L.GC_E_RANGE):
             L.check(st)

@@ -142,7 +142,7 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
     return p
 
 
-def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
+def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_loop: bool = False):
     """[trackResults, channel] = tracking(fid, channel, settings) — `signal` selects the reference
     package whose tracking.m is mirrored ("GPS_L1CA": GPS/GPS_L1CA/include/tracking.m;
     "GAL_E1C": GAL/GAL_E1C/include/tracking.m, data + pilot arms, BOC(1,1) half-chip tables).
@@ -182,7 +182,7 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA"):
         inits.append(L.gc_channel_init(channel=i, prn=ch.PRN, acquired_freq=ch.acquiredFreq,
                                        code_freq=cf, code_phase=int(ch.codePhase),
                                        table_phase=int(getattr(ch, "CLCodePhase", 0)) if (spec.doubled_code and pilot) else 0))
-    fields, done, status = fid.track(p, inits)
+    fields, done, status = fid.track(p, inits, device_loop=device_loop)   # device_loop: gc_track_device (include/gnsscorr.h)
     cno = getattr(settings, "CNo", None)   # B2a / B1C estimate C/N0 with Calc_CNo_PLD instead (not on the hot path)
     vsm = int(cno.VSMinterval) if cno is not None else 0
     for k, i in enumerate(active):

@@ -207,6 +207,13 @@ enum gc_track_field {
 int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
              double* out, int32_t* epochs_done);
 
+/* As gc_track, with the loop closed ON THE DEVICE: one persistent cooperative launch runs every
+ * epoch; the workgroups sharing a channel meet once per epoch through two device-scope atomics and the last to
+ * arrive executes tracking.m:302-335 in float64.  Instantiated for single-arm R = 1 channels on the transition-mask
+ * kernel (GPS L1 C/A, GLONASS L1OF, BDS B1I), int8 I/Q or Q/I, no pilot: anything else returns GC_E_UNSUPPORTED. */
+int gc_track_device(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
+                    double* out, int32_t* epochs_done);
+
 /* ---- acquisition (replaces acquisition.m:151-254, resampling off) ------------------- */
 typedef struct gc_acq_params {
   double sampling_freq;      /* settings.samplingFreq */

@@ -439,3 +439,40 @@ def test_gps_l2c_cm_cl(engine):
             assert np.max(np.abs(getattr(tr[k], f) - getattr(ref[k], f))) < tol, f   # f32 sums through the loop gains
         # both the CM and the CL arm see their code (the CL window follows the signal across the 75 -> 1 wrap)
         assert np.mean(np.hypot(tr[k].I_P, tr[k].Q_P)) > 5e4 and np.mean(np.hypot(tr[k].Pilot_I_P, tr[k].Pilot_Q_P)) > 5e4
+
+
+def test_device_side_loop_closure_matches_host_loop_and_oracle(engine, l1ca_scene, capsys):
+    """gc_track_device: one persistent cooperative launch, the last-arriving workgroup of each channel's
+    team closes the loop in float64 on the GPU.  Same records as the host-closed loop (identical partial sums, libm
+    differences of an ulp in atan/sqrt only) and as the oracle; the short-read exit behaves like tracking.m:241-245."""
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene
+    S.msToProcess = 200
+    S.numberOfChannels = 6
+    ch = _channels(S, sats, 6)
+    engine.load_if(iq, fs=S.samplingFreq)
+    host, _ = P.tracking(engine, ch, S)
+    dev, _ = P.tracking(engine, ch, S, device_loop=True)
+    ref, done, aborted = CO.track_l1ca(iq, ch, S)
+    for k, s in enumerate(sats):
+        assert dev[k].status == "T" and dev[k].PRN == s.prn
+        assert np.array_equal(dev[k].absoluteSample, ref["absoluteSample"][k])
+        assert np.array_equal(dev[k].absoluteSample, host[k].absoluteSample)
+        for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L"):
+            assert np.max(np.abs(getattr(dev[k], f) - getattr(host[k], f))) < 1e-6 * np.abs(ref["I_P"][k]).max(), f
+        assert np.max(np.abs(dev[k].carrFreq - host[k].carrFreq)) < 1e-4     # different split counts reorder the f32 sums
+        assert np.max(np.abs(dev[k].carrFreq - ref["carrFreq"][k])) < 1e-3
+        assert np.max(np.abs(dev[k].codeFreq - ref["codeFreq"][k])) < 1e-4
+        assert np.max(np.abs(dev[k].remCodePhase - ref["remCodePhase"][k])) < 1e-7
+        assert np.max(np.abs(dev[k].remCarrPhase - host[k].remCarrPhase)) < 1e-5
+        assert np.max(np.abs(dev[k].dllDiscrFilt - host[k].dllDiscrFilt)) < 1e-6
+        assert len(dev[k].CNo.VSMValue) == 5
+    # short read: the record ends inside epoch ~296 of channel 1
+    S.msToProcess = 300
+    n_short = int(0.2985 * S.samplingFreq)
+    engine.load_if(iq[:2 * n_short], fs=S.samplingFreq)
+    dev, _ = P.tracking(engine, ch[:2], S, device_loop=True)
+    assert "Not able to read the specified number of samples" in capsys.readouterr().out
+    assert dev[0].status == "-" and dev[1].status == "-"
+    n0 = int(np.count_nonzero(dev[0].absoluteSample))
+    assert 285 <= n0 < 300 and not dev[0].I_P[n0:].any() and not dev[1].I_P.any()
