@@ -93,6 +93,16 @@ def main() -> None:
     blks = np.ceil((S.codeLength - fields["remCodePhase"]) / (fields["codeFreq"] / fs)).astype(np.int64)
     chan_samples = int(blks.sum())
     closed_msps = chan_samples / t_closed / 1e6
+    # the same loop closed on the device (one persistent cooperative launch, include/gnsscorr.h gc_track_device)
+    t0 = time.time()
+    dfields, ddone, dst = eng.track(p, inits, device_loop=True)
+    t_dev = time.time() - t0
+    dev_loop = None
+    if dst == 0 and int(ddone.min()) == n_epochs:
+        dev_loop = {"corr_msps": round(chan_samples / t_dev / 1e6, 1), "x_realtime": round(chan_samples / t_dev / 1e6 / nch / (fs / 1e6), 2),
+                    "us_per_epoch": round(t_dev / n_epochs * 1e6, 2),
+                    "same_block_geometry_as_host_loop": bool(np.array_equal(dfields["absoluteSample"], fields["absoluteSample"])),
+                    "max_carr_freq_dev_hz": float(np.max(np.abs(dfields["carrFreq"] - fields["carrFreq"])))}
 
     # ---- replay descriptors, epoch-major so the channels of one epoch sit next to each other ----
     nb = nch * n_epochs
@@ -180,6 +190,7 @@ def main() -> None:
         "x_realtime_replay": round(value / world / nch / (fs / 1e6), 1),
         "closed_loop": {"corr_msps": round(closed_msps, 1), "x_realtime": round(closed_msps / nch / (fs / 1e6), 2),
                         "us_per_epoch": round(t_closed / n_epochs * 1e6, 2), "channels_locked": int(locked.sum())},
+        "closed_loop_device": dev_loop,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "kernel": "corr_epl_fast_kernel<ARMS=1, I8_IQ, SPL=16>", "kernel_ms": round(kernel_ms, 4),

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   constexpr int kShift = (SPL == 16) ? 4 : 3;
 
   long long wg = blockIdx.x;
-  if (p.xcd_swizzle) {
+  if (p.xcd_swizzle && !DEVLOOP) {
     const long long per = (long long)gridDim.x >> 3;
     wg = (wg & 7) * per + (wg >> 3);
   }
@@ -65,8 +65,10 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   // WIDE, periodic replay: the waves interleave over the workgroup's bpw blocks.
   const bool wave_items = WIDE && p.bpw == 1;
   const long long item = wave_items ? wg * 4 + wave : wg;
-  const long long wq = item / p.splits;
-  const int split = (int)(item - wq * p.splits);
+  // DEVLOOP with xcd_swizzle: a channel's whole team on ONE XCD (workgroup b runs on XCD b % 8), so that the team's
+  // atomics and partial sums meet in that XCD's L2: channel = (b % 8) + 8 * ((b / 8) / splits), split = (b / 8) % splits
+  const long long wq = (DEVLOOP && p.xcd_swizzle) ? (item & 7) + 8 * ((item >> 3) / p.splits) : item / p.splits;
+  const int split = (DEVLOOP && p.xcd_swizzle) ? (int)((item >> 3) % p.splits) : (int)(item - wq * p.splits);
   const long long grp = wq / p.stride;
   const int cslot = (int)(wq - grp * p.stride);
 
@@ -126,20 +128,26 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
     // member must not hang the device), then read it with loads that cannot be served from a stale cache
     DevLoopChan* ch = p.devloop->chan + lb;
     unsigned int spins = 0;
-    while (__hip_atomic_load(&ch->epoch_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)bi && ++spins <= (1u << 24))
+    while (__hip_atomic_load(&ch->epoch_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)bi && ++spins <= (1u << 24))
       __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (spins > (1u << 24)) {
       if (lane == 0) __hip_atomic_store(&ch->status, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
     if (__hip_atomic_load(&ch->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;  // record exhausted / timed out
+    // the nine 8-byte words of the descriptor: one load per lane (a serial chain of device-scope loads costs ~1 us each)
     union {
       gc_block b;
       unsigned long long q[sizeof(gc_block) / 8];
     } u;
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&ch->blk);
+    unsigned long long mine = 0;
+    if (lane < (int)(sizeof(gc_block) / 8)) mine = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) u.q[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i)
+      u.q[i] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(mine >> 32), i) << 32) |
+               (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)mine, i);
     blk = u.b;
   } else {
     blk = CL ? load_block(p, lb) : p.blocks[lb];
@@ -393,13 +401,29 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
     if (lane == 63) prev = __hip_atomic_fetch_add(&ch->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     prev = (unsigned int)__builtin_amdgcn_readlane((int)prev, 63);
     if (prev == (unsigned int)dl->splits - 1u) {
-      // last to arrive: close the loop for this channel and epoch
+      // last to arrive: close the loop for this channel and epoch.  The splits x 6 partial sums are fetched one per
+      // lane (in rounds of 64) and added in double through LDS.
+      double* red = reinterpret_cast<double*>(smem + p.red_off);
+      if (lane < 6) red[lane] = 0.0;
+      const int total = dl->splits * 6;
       double sums[6];
+      double acc = 0.0;  // lanes 0..5: running sum of component `lane`
+      for (int base0 = 0; base0 < total; base0 += 60) {   // 60 = ten splits per round
+        const int idx = base0 + lane;
+        double val = 0.0;
+        if (lane < 60 && idx < total) val = (double)__hip_atomic_load(slots + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[8 + lane] = val;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        if (lane < 6)
+          for (int k = 0; k < 10; ++k) acc += red[8 + k * 6 + lane];
+        __builtin_amdgcn_s_barrier();
+      }
 #pragma unroll
       for (int v = 0; v < 6; ++v) {
-        double s = 0.0;
-        for (int k = 0; k < dl->splits; ++k) s += (double)__hip_atomic_load(slots + k * 6 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sums[v] = s;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+        sums[v] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(bits >> 32), v) << 32) |
+                                                   (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, v)));
       }
       devloop_close(dl, ch, blk, lb, bi, sums, lane);
       if (lane == 0) {
@@ -496,7 +520,7 @@ int gc_launch_devloop(gc_context* ctx, const KArgs& a_in, unsigned int grid, boo
   InlineBlocks ib;
   std::memset(&ib, 0, sizeof ib);
   a.red_off = 8 * ctx->max_lds_bytes;
-  const size_t smem = (size_t)a.red_off + 64;
+  const size_t smem = (size_t)a.red_off + 8 * (8 + 64);  // + the closing member's scratch
   return spl16 ? launch_devloop_mode<16>(ctx, a, ib, dim3(grid), smem, share_el) : launch_devloop_mode<8>(ctx, a, ib, dim3(grid), smem, share_el);
 }
 

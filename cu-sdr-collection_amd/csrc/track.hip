@@ -442,8 +442,9 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   // team size: enough one-wave workgroups to fill the device, at least ~one lane-chunk per lane and split
   const int spl = lowrate == 2 ? 16 : 8;
   const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
-  int splits = std::max(1, std::min({64, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 64)}));
+  int splits = std::max(1, std::min({64, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 128)}));  // ~2 lane-chunks per lane
   if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(64, std::atoi(e)));
+  const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr;  // teams on one XCD each (default)
 
   gcorr::DevLoopArgs ha;
   std::memset(&ha, 0, sizeof ha);
@@ -487,7 +488,9 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   a.stride = 1;
   a.share_el = share ? 1 : 0;
   a.devloop = d_args;
-  rc = gc_launch_devloop(ctx, a, (unsigned int)(nch * splits), lowrate == 2, share);
+  a.xcd_swizzle = xcd_local ? 1 : 0;
+  const unsigned int grid = xcd_local ? (unsigned int)(((nch + 7) / 8) * 8 * splits) : (unsigned int)(nch * splits);
+  rc = gc_launch_devloop(ctx, a, grid, lowrate == 2, share);
   if (rc == GC_OK) {
     e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, ha.records, rec_bytes, hipMemcpyDeviceToHost);
