@@ -119,36 +119,42 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   if (wave_items && wq >= p.nblocks) return;
 
   const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
+  gc_block dl_next;  // DEVLOOP closer: the descriptor it prepared for the next epoch
+  (void)dl_next;
   for (int bi = (WIDE && !wave_items) ? wave : 0; bi < nloop; bi += (WIDE && !wave_items) ? 4 : 1) {
   const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
   gc_block blk;
   if constexpr (DEVLOOP) {
-    // wait until the closing member of epoch bi - 1 has published this epoch's descriptor (bounded: a lost team
-    // member must not hang the device), then read it with loads that cannot be served from a stale cache
-    DevLoopChan* ch = p.devloop->chan + lb;
-    unsigned int spins = 0;
-    while (__hip_atomic_load(&ch->epoch_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)bi && ++spins <= (1u << 24))
-      __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (spins > (1u << 24)) {
-      if (lane == 0) __hip_atomic_store(&ch->status, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
-    }
-    if (__hip_atomic_load(&ch->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;  // record exhausted / timed out
-    // the nine 8-byte words of the descriptor: one load per lane (a serial chain of device-scope loads costs ~1 us each)
-    union {
-      gc_block b;
-      unsigned long long q[sizeof(gc_block) / 8];
-    } u;
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&ch->blk);
-    unsigned long long mine = 0;
-    if (lane < (int)(sizeof(gc_block) / 8)) mine = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (split == 0 && bi > 0) {
+      blk = dl_next;  // the closer made this descriptor itself
+    } else {
+      // the ten descriptor messages, one per lane, polled until every one carries this epoch's tag (bounded: a lost
+      // team member must not hang the device)
+      const msg_t* dm = p.devloop->desc_msg + lb * kDescWords;
+      msg_t m = {0u, 0u, 0u, 0u};
+      unsigned int spins = 0;
+      while (true) {
+        if (lane < kDescWords) m = msg_load(dm + lane);
+        const bool ok = lane >= kDescWords || m.z == (unsigned int)bi + 1u;
+        if (__all(ok)) break;
+        if (++spins > (1u << 22)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (spins > (1u << 22)) {
+        if (lane == 0) p.devloop->chan[lb].status = 3;
+        break;
+      }
+      union {
+        gc_block b;
+        unsigned long long q[sizeof(gc_block) / 8];
+      } u;
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i)
-      u.q[i] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(mine >> 32), i) << 32) |
-               (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)mine, i);
-    blk = u.b;
+      for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i)
+        u.q[i] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)m.y, i) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)m.x, i);
+      if (__builtin_amdgcn_readlane((int)m.x, kDescWords - 1) != 0) break;  // status word: record exhausted
+      blk = u.b;
+    }
   } else {
     blk = CL ? load_block(p, lb) : p.blocks[lb];
   }
@@ -391,45 +397,67 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
     }
   if constexpr (DEVLOOP) {
     const DevLoopArgs* dl = p.devloop;
-    DevLoopChan* ch = dl->chan + lb;
-    float* slots = dl->partial + (size_t)lb * dl->splits * 6;
-    if (lane == 63) {
-#pragma unroll
-      for (int v = 0; v < 6; ++v) __hip_atomic_store(slots + split * 6 + v, tot[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned int prev = 0;
-    if (lane == 63) prev = __hip_atomic_fetch_add(&ch->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    prev = (unsigned int)__builtin_amdgcn_readlane((int)prev, 63);
-    if (prev == (unsigned int)dl->splits - 1u) {
-      // last to arrive: close the loop for this channel and epoch.  The splits x 6 partial sums are fetched one per
-      // lane (in rounds of 64) and added in double through LDS.
-      double* red = reinterpret_cast<double*>(smem + p.red_off);
-      if (lane < 6) red[lane] = 0.0;
-      const int total = dl->splits * 6;
-      double sums[6];
-      double acc = 0.0;  // lanes 0..5: running sum of component `lane`
-      for (int base0 = 0; base0 < total; base0 += 60) {   // 60 = ten splits per round
-        const int idx = base0 + lane;
-        double val = 0.0;
-        if (lane < 60 && idx < total) val = (double)__hip_atomic_load(slots + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        red[8 + lane] = val;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier();
-        if (lane < 6)
-          for (int k = 0; k < 10; ++k) acc += red[8 + k * 6 + lane];
-        __builtin_amdgcn_s_barrier();
+    msg_t* pm = dl->part_msg + (lb * dl->splits) * 2;
+    const unsigned int tag = (unsigned int)bi + 1u;
+    if (split != 0) {
+      if (lane == 63) {
+        msg_store(pm + split * 2, msg_t{__float_as_uint(tot[0]), __float_as_uint(tot[1]), __float_as_uint(tot[2]), tag});
+        msg_store(pm + split * 2 + 1, msg_t{__float_as_uint(tot[3]), __float_as_uint(tot[4]), __float_as_uint(tot[5]), tag});
       }
+    } else {
+      // the closer: own sums from lane 63, the others' messages polled one per lane, everything added in double
+      // through LDS (splits <= 32: at most 62 messages)
+      double* red = reinterpret_cast<double*>(smem + p.red_off);
+      const int nmsg = (dl->splits - 1) * 2;
+      msg_t m = {0u, 0u, 0u, 0u};
+      unsigned int spins = 0;
+      while (true) {
+        if (lane < nmsg) m = msg_load(pm + 2 + lane);
+        const bool ok = lane >= nmsg || m.w == tag;
+        if (__all(ok)) break;
+        if (++spins > (1u << 22)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (spins > (1u << 22)) {
+        if (lane == 0) dl->chan[lb].status = 3;
+        // tell the team to stop: a descriptor with a non-zero status word
+        if (lane < kDescWords) msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{3u, 0u, tag + 1u, 0u});
+        break;
+      }
+      // message 2k + h of member k + 1 holds components 3h .. 3h + 2
+      red[lane * 3 + 0] = (lane < nmsg) ? (double)__uint_as_float(m.x) : 0.0;
+      red[lane * 3 + 1] = (lane < nmsg) ? (double)__uint_as_float(m.y) : 0.0;
+      red[lane * 3 + 2] = (lane < nmsg) ? (double)__uint_as_float(m.z) : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_barrier();
+      double acc = 0.0;
+      if (lane < 6) {
+        const int hlf = lane / 3, cmp = lane % 3;
+        for (int k = 0; k < dl->splits - 1; ++k) acc += red[(2 * k + hlf) * 3 + cmp];
+      }
+      __builtin_amdgcn_s_barrier();
+      double sums[6];
 #pragma unroll
       for (int v = 0; v < 6; ++v) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
         sums[v] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(bits >> 32), v) << 32) |
-                                                   (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, v)));
+                                                   (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, v))) +
+                  (double)rl_f(tot[v], 63);
       }
-      devloop_close(dl, ch, blk, lb, bi, sums, lane);
-      if (lane == 0) {
-        __hip_atomic_store(&ch->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ch->epoch_ready, (unsigned int)bi + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      dl_next = blk;
+      const int st = devloop_close(dl, dl->chan + lb, dl_next, lb, bi, sums, lane);
+      // publish the next descriptor (or the stop word) as ten tagged messages, one store per lane
+      union {
+        gc_block b;
+        unsigned long long q[sizeof(gc_block) / 8];
+      } u;
+      u.b = dl_next;
+      unsigned long long word = (unsigned long long)(st == 2 ? 2 : 0);
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) word = (lane == i) ? u.q[i] : word;
+      if (lane < kDescWords && bi + 1 < nloop)
+        msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u});
+      if (st != 0) break;
     }
   } else if (CL) {
     // lane v takes total v (broadcast from lane 63) and stores its 16-byte tagged record
@@ -520,7 +548,7 @@ int gc_launch_devloop(gc_context* ctx, const KArgs& a_in, unsigned int grid, boo
   InlineBlocks ib;
   std::memset(&ib, 0, sizeof ib);
   a.red_off = 8 * ctx->max_lds_bytes;
-  const size_t smem = (size_t)a.red_off + 8 * (8 + 64);  // + the closing member's scratch
+  const size_t smem = (size_t)a.red_off + 8 * 3 * 64;  // + the closer's reduction scratch
   return spl16 ? launch_devloop_mode<16>(ctx, a, ib, dim3(grid), smem, share_el) : launch_devloop_mode<8>(ctx, a, ib, dim3(grid), smem, share_el);
 }
 

@@ -1,22 +1,29 @@
 // devloop.h — device-side loop closure: the tracking loop of tracking.m:184-348 without the
 // per-epoch host round trip.  ONE persistent launch runs all epochs; the workgroups that share a channel (its
-// "team": one per split) meet once per epoch through two device-scope atomics:
-//   every team member adds its partial sums to the channel's slot array and increments `arrive`;
-//   the member that arrives LAST closes the loop (discriminators, loop filters, next block geometry — the same
-//   float64 statements as gc_track's host loop, tracking.m:302-335), writes the epoch's records, publishes the next
-//   descriptor and releases `epoch_ready`; the others spin on it.
-// Channels never wait for each other.  All team workgroups must be co-resident: the launch is cooperative.
+// "team": one per split) exchange two kinds of self-validating 16-byte messages per epoch — {payload, epoch tag}
+// written by ONE store instruction and read by ONE load instruction, both at system scope (sc0 sc1: no cache on the
+// way), so no flag, counter, atomic or fence is needed:
+//   every member stores its six partial sums as two messages {f, f, f, tag};
+//   member 0 (the closer) polls the other members' messages, one per lane, adds everything in double, closes the loop
+//   (discriminators, loop filters, next block geometry — the same float64 statements as gc_track's host loop,
+//   tracking.m:302-335), writes the epoch's records and publishes the next descriptor as ten messages {word, tag};
+//   the other members poll those, one per lane.
+// Two one-way propagation delays per epoch instead of five dependent round trips.  Channels never wait for each other.
+// All team workgroups must be co-resident: the launch is cooperative.  Polls are bounded.
 #pragma once
 #include "gc_internal.h"
 
 namespace gcorr {
 
+constexpr int kDescWords = 10;  // gc_block (9 x 8 bytes) + status word
+
+typedef unsigned int msg_t __attribute__((ext_vector_type(4)));  // one 16-byte message
+
 struct DevLoopChan {
-  gc_block blk;             // descriptor of epoch `epoch_ready` (written by the closing member)
-  unsigned int epoch_ready;  // epochs whose descriptor has been published: blk is valid for epoch == epoch_ready - 1
-  unsigned int arrive;       // partial sums delivered for the current epoch
+  gc_block blk;              // initial descriptor (host) / last descriptor (closer)
   int status;                // 0 running, 1 all epochs done, 2 record exhausted (tracking.m:241-245), 3 wait timed out
   int epochs_done;
+  int pad0[2];
   // loop state, touched by the closing member only
   long long pos;
   double code_freq, code_freq_basis, rem_code;
@@ -28,7 +35,8 @@ struct DevLoopChan {
 
 struct DevLoopArgs {
   DevLoopChan* chan;   // [nch]
-  float* partial;      // [nch][splits][6]
+  msg_t* desc_msg;     // [nch][kDescWords]   {word lo, word hi, tag, 0}, tag = epoch + 1
+  msg_t* part_msg;     // [nch][splits][2]    {f, f, f, tag}
   double* records;     // [nch][GC_TRK_NFIELDS][n_epochs]
   gc_track_params prm;
   double tau1code, tau2code, tau1carr, tau2carr;
@@ -40,9 +48,18 @@ struct DevLoopArgs {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ msg_t msg_load(const msg_t* p) {
+  msg_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void msg_store(msg_t* p, msg_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // Closing member: lane-uniform float64 restatement of tracking.m:273-348 for one channel and epoch.
-__device__ inline void devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopChan* ch, const gc_block& b, long long slot, int e,
-                                     const double (&sums)[6], int lane) {
+__device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopChan* ch, gc_block& b, long long slot, int e,
+                                    const double (&sums)[6], int lane) {
   const gc_track_params& p = dl->prm;
   const double kPi = 3.141592653589793;
   const int n = b.blksize;
@@ -111,14 +128,15 @@ __device__ inline void devloop_close(const DevLoopArgs* __restrict__ dl, DevLoop
     ch->d2_carr_err = d2;
     ch->d_carr_err = d1;
     ch->epochs_done = e + 1;
-    ch->blk.blksize = n_new;
-    ch->blk.first_sample = pos_new;
-    ch->blk.rem_code_phase = rem_code_new;
-    ch->blk.code_phase_step = step_new;
-    ch->blk.carr_freq = carr_freq_new;
-    ch->blk.rem_carr_phase = rem_carr_new;
     ch->status = status;
   }
+  b.blksize = n_new;
+  b.first_sample = pos_new;
+  b.rem_code_phase = rem_code_new;
+  b.code_phase_step = step_new;
+  b.carr_freq = carr_freq_new;
+  b.rem_carr_phase = rem_carr_new;
+  return status;
 }
 #endif
 

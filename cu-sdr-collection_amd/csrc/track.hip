@@ -442,8 +442,8 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   // team size: enough one-wave workgroups to fill the device, at least ~one lane-chunk per lane and split
   const int spl = lowrate == 2 ? 16 : 8;
   const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
-  int splits = std::max(1, std::min({64, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 128)}));  // ~2 lane-chunks per lane
-  if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(64, std::atoi(e)));
+  int splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 48)}));  // just under one lane-chunk per lane: the epoch is a latency chain
+  if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
   const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr;  // teams on one XCD each (default)
 
   gcorr::DevLoopArgs ha;
@@ -458,16 +458,27 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   gcorr::DevLoopArgs* d_args = nullptr;
   const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
   hipError_t e = hipMalloc((void**)&ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
-  if (e == hipSuccess) e = hipMalloc((void**)&ha.partial, sizeof(float) * (size_t)nch * splits * 6);
+  const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * 2, desc_bytes = sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords;
+  if (e == hipSuccess) e = hipMalloc((void**)&ha.part_msg, part_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&ha.desc_msg, desc_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&ha.records, rec_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&d_args, sizeof ha);
   if (e == hipSuccess) e = hipMemsetAsync(ha.records, 0, rec_bytes, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(ha.partial, 0, sizeof(float) * (size_t)nch * splits * 6, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ha.part_msg, 0, part_bytes, ctx->stream);
+  std::vector<gcorr::msg_t> hdesc((size_t)nch * gcorr::kDescWords);
+  for (int c = 0; c < nch; ++c) {
+    unsigned long long q[gcorr::kDescWords] = {0};
+    std::memcpy(q, &hc[c].blk, sizeof(gc_block));
+    q[gcorr::kDescWords - 1] = (unsigned long long)(hc[c].status == 2 ? 2 : 0);
+    for (int i = 0; i < gcorr::kDescWords; ++i) hdesc[(size_t)c * gcorr::kDescWords + i] = gcorr::msg_t{(unsigned int)q[i], (unsigned int)(q[i] >> 32), 1u, 0u};
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(ha.desc_msg, hdesc.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(ha.chan, hc.data(), sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_args, &ha, sizeof ha, hipMemcpyHostToDevice, ctx->stream);
   auto cleanup = [&]() {
     if (ha.chan) (void)hipFree(ha.chan);
-    if (ha.partial) (void)hipFree(ha.partial);
+    if (ha.part_msg) (void)hipFree(ha.part_msg);
+    if (ha.desc_msg) (void)hipFree(ha.desc_msg);
     if (ha.records) (void)hipFree(ha.records);
     if (d_args) (void)hipFree(d_args);
   };
