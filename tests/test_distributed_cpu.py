@@ -13,7 +13,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from cu_sdr_collection_amd.sharding import shard_channels
+    from cu_sdr_collection_amd.sharding import merge_acq_results, shard_channels, shard_prns
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -25,7 +25,17 @@ def _worker(rank, world, port, q):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
-    q.put((rank, float(t[0]), gathered))
+    # acquisition shards by PRN: each rank fills its own entries of acqResults, rank 0 merges
+    import numpy as np
+    from types import SimpleNamespace
+    prns = list(range(1, 33))
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32))
+    for prn in shard_prns(prns, world, rank):
+        acq.carrFreq[prn - 1], acq.codePhase[prn - 1], acq.peakMetric[prn - 1] = 1000.0 + prn, prn * 7, 3.0 + 0.1 * prn
+    parts = [None] * world
+    dist.all_gather_object(parts, acq)
+    merged = merge_acq_results(parts)
+    q.put((rank, float(t[0]), gathered, merged.codePhase.tolist(), merged.peakMetric.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,7 +54,9 @@ def test_gloo_world_size_two_control_plane():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, tmax, gathered in res:
+    for rank, tmax, gathered, code_phase, metric in res:
+        assert code_phase == [prn * 7 for prn in range(1, 33)]
+        assert metric == [3.0 + 0.1 * prn for prn in range(1, 33)]
         assert tmax == 1.5  # MAX over ranks
         assert sorted(gathered[0] + gathered[1]) == list(range(13))
         assert not set(gathered[0]) & set(gathered[1])
