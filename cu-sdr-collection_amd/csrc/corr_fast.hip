@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
                   (double)rl_f(tot[v], 63);
       }
       dl_next = blk;
-      const int st = devloop_close(dl, dl->chan + lb, dl_next, lb, bi, sums, lane);
+      const int st = devloop_close(dl, dl->chan + lb, dl_next, lb, bi, sums, 1, 1.0, lane);
       // publish the next descriptor (or the stop word) as ten tagged messages, one store per lane
       union {
         gc_block b;

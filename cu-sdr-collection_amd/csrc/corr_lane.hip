@@ -29,6 +29,7 @@
 //   * 6*ARMS float accumulators per lane, DPP wavefront reduction, results as doubles or (closed loop) as
 //     host-mapped tagged 16-byte records.
 #include "corr_common.h"
+#include "devloop.h"
 
 using namespace gcorr;
 
@@ -41,7 +42,10 @@ constexpr int kLW = kLaneWaves;  // wavefronts per workgroup
 constexpr int kGRP = GC_LANE_GRP;  // samples per lane and group: the loads of the next group fly under this one
 
 // TAB: 0 = f32 tables, 1 = f32 tables + shared early/late ramp, 2 = f16 tables
-template <int ARMS, int MODE, bool CL, int TAB>
+// DEVLOOP = persistent launch with device-side loop closure (devloop.h): p.splits workgroups of 16 waves per channel, the
+// block loop becomes the channel's epoch loop; sums are combined in LDS per workgroup, between workgroups by tagged
+// messages, and wave 0 of the channel's first workgroup closes the loop.
+template <int ARMS, int MODE, bool CL, int TAB, bool DEVLOOP = false>
 __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int AP = ArmPitch<ARMS>::v;  // values per staged entry
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
   const tab_t* tab = reinterpret_cast<const tab_t*>(smem);  // [kGuard + maxn + kGuard][AP]
 
   long long wg = blockIdx.x;
-  if (p.xcd_swizzle) {
+  if (p.xcd_swizzle && !DEVLOOP) {
     // Workgroup b is dispatched to XCD b % 8.  Give every XCD one contiguous range of the descriptor list so
     // that neighbouring descriptors (the channels of one epoch, which read the same IF window) share an L2.
     const long long per = (long long)gridDim.x >> 3;  // host guarantees gridDim.x % 8 == 0 when swizzling
@@ -69,19 +73,22 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
   // bpw == 1 and p.wide: ONE block per workgroup, split 16 ways over its waves, combined through LDS (big
   // lists of unrelated blocks: no partial buffer, no second kernel).
   const bool wave_items = p.bpw == 1;
-  const bool wg_block = wave_items && p.wide != 0;
-  const int nsplit = wg_block ? kLW : p.splits;
+  const bool wg_block = !DEVLOOP && wave_items && p.wide != 0;
+  // DEVLOOP: p.splits member workgroups per channel; with xcd_swizzle a channel's members all run on one XCD
+  // (workgroup b -> XCD b % 8): channel = (b % 8) + 8 * ((b / 8) / members), member = (b / 8) % members
+  const int member = DEVLOOP ? (p.xcd_swizzle ? (int)((wg >> 3) % p.splits) : (int)(wg % p.splits)) : 0;
+  const int nsplit = DEVLOOP ? p.splits * kLW : wg_block ? kLW : p.splits;
   const long long item = wg_block ? wg * kLW + wave : wave_items ? wg * kLW + wave : wg;
-  const long long wq = item / nsplit;
-  const int split = (int)(item - wq * nsplit);
+  const long long wq = DEVLOOP ? (p.xcd_swizzle ? (wg & 7) + 8 * ((wg >> 3) / p.splits) : wg / p.splits) : item / nsplit;
+  const int split = DEVLOOP ? member * kLW + wave : (int)(item - wq * nsplit);
   const long long grp = wq / p.stride;
   const int cslot = (int)(wq - grp * p.stride);
 
   // ---- stage the tables once per workgroup (all its blocks share channel and table offsets) ----------
   int maxn = 0;
   {
-    const long long lb0 = min(wave_items ? (wg * kLW) / nsplit : grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
-    const gc_block blk0 = CL ? load_block(p, lb0) : p.blocks[lb0];
+    const long long lb0 = min(DEVLOOP ? wq : wave_items ? (wg * kLW) / nsplit : grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
+    const gc_block blk0 = DEVLOOP ? p.devloop->chan[lb0].blk : CL ? load_block(p, lb0) : p.blocks[lb0];
     const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
     const int arms0 = chn0->arms;
     int nent[ARMS];
@@ -123,10 +130,49 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
   }
   if (wave_items && wq >= p.nblocks) return;
 
-  for (int bi = wave_items ? 0 : wave; bi < p.bpw; bi += wave_items ? 1 : kLW) {
-  const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
+  // DEVLOOP scratch behind the tables: float red[16][GC_OUT_STRIDE] | gc_block + status | double dred[64]
+  gc_block* sblk = reinterpret_cast<gc_block*>(smem + p.red_off + kLW * GC_OUT_STRIDE * sizeof(float));
+  int* sstatus = reinterpret_cast<int*>(sblk + 1);
+  double* dred = reinterpret_cast<double*>(smem + p.red_off + kLW * GC_OUT_STRIDE * sizeof(float) + 128);
+  const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
+  for (int bi = (DEVLOOP || wave_items) ? 0 : wave; bi < nloop; bi += (DEVLOOP || wave_items) ? 1 : kLW) {
+  const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
-  const gc_block blk = CL ? load_block(p, lb) : p.blocks[lb];
+  gc_block blk;
+  if constexpr (DEVLOOP) {
+    if (wave == 0 && !(member == 0 && bi > 0)) {
+      // wave 0 polls the ten descriptor messages (one per lane) and hands the descriptor to the workgroup through LDS
+      const msg_t* dm = p.devloop->desc_msg + lb * kDescWords;
+      msg_t m = {0u, 0u, 0u, 0u};
+      unsigned int spins = 0;
+      while (true) {
+        if (lane < kDescWords) m = msg_load(dm + lane);
+        const bool ok = lane >= kDescWords || m.z == (unsigned int)bi + 1u;
+        if (__all(ok)) break;
+        if (++spins > (1u << 22)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      union {
+        gc_block b;
+        unsigned long long q[sizeof(gc_block) / 8];
+      } u;
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i)
+        u.q[i] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)m.y, i) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)m.x, i);
+      int st = __builtin_amdgcn_readlane((int)m.x, kDescWords - 1);
+      if (spins > (1u << 22)) st = 3;
+      if (lane == 0) {
+        *sblk = u.b;
+        *sstatus = st;
+        if (st == 3) p.devloop->chan[lb].status = 3;
+      }
+    }
+    __syncthreads();
+    if (*sstatus != 0) break;  // uniform over the workgroup: record exhausted / timed out
+    blk = *sblk;
+  } else {
+    blk = CL ? load_block(p, lb) : p.blocks[lb];
+  }
   const DevChannel* __restrict__ chn = p.chans + blk.channel;
   const int arms_here = chn->arms;
 
@@ -396,7 +442,74 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
       tot[ar * 6 + 2 * x] = wave_sum_lane63(accr[ar][x]);
       tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(acci[ar][x]);
     }
-  if (wg_block) {
+  if constexpr (DEVLOOP) {
+    const DevLoopArgs* dl = p.devloop;
+    constexpr int NS = ARMS * 6;
+    float* red = reinterpret_cast<float*>(smem + p.red_off);
+    if (lane == 63) {
+#pragma unroll
+      for (int v = 0; v < NS; ++v) red[wave * GC_OUT_STRIDE + v] = tot[v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const unsigned int tag = (unsigned int)bi + 1u;
+      double mine = 0.0;  // lanes 0 .. NS-1: this workgroup's sum of component `lane`
+      if (lane < NS)
+        for (int w = 0; w < kLW; ++w) mine += (double)red[w * GC_OUT_STRIDE + lane];
+      msg_t* pm = dl->part_msg + (lb * p.splits) * NS;
+      if (member != 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+        if (lane < NS) msg_store(pm + member * NS + lane, msg_t{(unsigned int)bits, (unsigned int)(bits >> 32), tag, 0u});
+      } else {
+        // the closer: the other workgroups' sums, one message per lane
+        const int nmsg = (p.splits - 1) * NS;
+        msg_t m = {0u, 0u, 0u, 0u};
+        unsigned int spins = 0;
+        while (true) {
+          if (lane < nmsg) m = msg_load(pm + NS + lane);
+          const bool ok = lane >= nmsg || m.z == tag;
+          if (__all(ok)) break;
+          if (++spins > (1u << 22)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        int st;
+        gc_block nxt = blk;
+        if (spins > (1u << 22)) {
+          st = 3;
+        } else {
+          dred[lane] = (lane < nmsg) ? __longlong_as_double((long long)(((unsigned long long)m.y << 32) | m.x)) : 0.0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          if (lane < NS)
+            for (int k = 0; k < p.splits - 1; ++k) mine += dred[k * NS + lane];
+          double sums[NS];
+#pragma unroll
+          for (int v = 0; v < NS; ++v) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+            sums[v] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(bits >> 32), v) << 32) |
+                                                       (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, v)));
+          }
+          st = devloop_close(dl, dl->chan + lb, nxt, lb, bi, sums, arms_here < ARMS ? arms_here : ARMS, R, lane);
+        }
+        if (lane == 0) {
+          *sblk = nxt;
+          *sstatus = (st == 1) ? 0 : st;  // 1 = all epochs done: the loop ends by itself
+          if (st == 3) dl->chan[lb].status = 3;
+        }
+        union {
+          gc_block b;
+          unsigned long long q[sizeof(gc_block) / 8];
+        } u;
+        u.b = nxt;
+        unsigned long long word = (unsigned long long)((st == 2 || st == 3) ? st : 0);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) word = (lane == i) ? u.q[i] : word;
+        if (lane < kDescWords && bi + 1 < nloop)
+          msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u});
+      }
+    }
+    __syncthreads();  // the closer's workgroup waits for the new descriptor; the scratch is free again
+  } else if (wg_block) {
     // one block per workgroup: lane 63 of every wave parks its sums in LDS, wave 0 adds them in double
     float* red = reinterpret_cast<float*>(smem + p.red_off);
     if (lane == 63) {
@@ -475,7 +588,35 @@ int launch_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 gr
   return GC_OK;
 }
 
+template <int ARMS, int MODE>
+int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share) {
+  void* args[2] = {(void*)&a, (void*)&ib};
+  const void* fn = share ? (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 1, true> : (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 0, true>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  GC_HIP(hipLaunchCooperativeKernel(fn, grid, dim3(kLW * 64), args, (unsigned int)smem, ctx->stream));
+  return GC_OK;
+}
+
 }  // namespace
+
+// Persistent tracker with device-side loop closure on the lane kernel: grid = channel slots x a.splits member workgroups.
+// f32 tables only (<= 96 KiB), int8 I/Q or Q/I records, one or two arms.
+int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid, int max_arms, bool share_el) {
+  KArgs a = a_in;
+  InlineBlocks ib;
+  std::memset(&ib, 0, sizeof ib);
+  const int ap = gc_arm_pitch(max_arms);
+  const size_t tab_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 4 + 15) / 16 * 16;
+  if (tab_bytes > 96 * 1024 || max_arms > 2 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
+    gc_set_error("device loop on the lane kernel: tables above 96 KiB as f32, three arms or non-int8-I/Q records are not instantiated");
+    return GC_E_UNSUPPORTED;
+  }
+  a.red_off = (int)tab_bytes;
+  const size_t smem = tab_bytes + kLW * GC_OUT_STRIDE * sizeof(float) + 128 + 64 * sizeof(double);
+  const bool qi = ctx->if_layout == GC_QI;
+  if (max_arms == 1) return qi ? launch_lane_devloop<1, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el) : launch_lane_devloop<1, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el);
+  return qi ? launch_lane_devloop<2, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el) : launch_lane_devloop<2, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el);
+}
 
 // share_el: every block of the launch has 2*el_spacing*R*M an exact positive integer
 int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBlocks& ib, unsigned int grid, int max_arms,

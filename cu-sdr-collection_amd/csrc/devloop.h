@@ -36,7 +36,7 @@ struct DevLoopChan {
 struct DevLoopArgs {
   DevLoopChan* chan;   // [nch]
   msg_t* desc_msg;     // [nch][kDescWords]   {word lo, word hi, tag, 0}, tag = epoch + 1
-  msg_t* part_msg;     // [nch][splits][2]    {f, f, f, tag}
+  msg_t* part_msg;     // [nch][splits][2]    {f, f, f, tag}  (fast kernel) | [nch][members][12] {double, tag, 0} (lane kernel)
   double* records;     // [nch][GC_TRK_NFIELDS][n_epochs]
   gc_track_params prm;
   double tau1code, tau2code, tau1carr, tau2carr;
@@ -57,9 +57,11 @@ __device__ __forceinline__ void msg_store(msg_t* p, msg_t v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
-// Closing member: lane-uniform float64 restatement of tracking.m:273-348 for one channel and epoch.
+// Closing member: lane-uniform float64 restatement of tracking.m:273-348 for one channel and epoch — the same statements
+// as gc_track's host loop (track.hip), pilot handling modes 0-3 included.  `sums`: 6 per arm; R: the channel's index scale.
+// On return b holds the next epoch's block geometry; the return value is the channel status (0 = keep going).
 __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopChan* ch, gc_block& b, long long slot, int e,
-                                    const double (&sums)[6], int lane) {
+                                    const double* sums, int arms, double R, int lane) {
   const gc_track_params& p = dl->prm;
   const double kPi = 3.141592653589793;
   const int n = b.blksize;
@@ -72,14 +74,48 @@ __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopC
   rec(GC_TRK_ABSOLUTE_SAMPLE, (double)ch->pos);
   rec(GC_TRK_REM_CODE_PHASE, ch->rem_code);
   rec(GC_TRK_REM_CARR_PHASE, ch->rem_carr);
-  const double t_last = ((n - 1) * step + ch->rem_code);                       // tcode(blksize), :273 (R = 1)
-  const double rem_code_new = (t_last + step) - p.code_length;
+  const double t_last = ((n - 1) * step + ch->rem_code) * R;                   // tcode(blksize), :273 / GAL_E1C :268
+  const double rem_code_new = (R != 1.0) ? (t_last / R + step) - p.code_length : (t_last + step) - p.code_length;
   const double time_n = (double)n / p.sampling_freq;                            // :280-283
   const double trig_n = ((ch->carr_freq * 2.0 * kPi) * time_n) + ch->rem_carr;
   const double rem_carr_new = fmod(trig_n, 2 * kPi);
-  const double carr_err = atan(q_p / i_p) / (2.0 * kPi);                        // :305
-  const double code_err = (sqrt(i_e * i_e + q_e * q_e) - sqrt(i_l * i_l + q_l * q_l)) /
-                          (sqrt(i_e * i_e + q_e * q_e) + sqrt(i_l * i_l + q_l * q_l));  // :322-323
+  double carr_err = atan(q_p / i_p) / (2.0 * kPi);                              // :305
+  double code_err = (sqrt(i_e * i_e + q_e * q_e) - sqrt(i_l * i_l + q_l * q_l)) /
+                    (sqrt(i_e * i_e + q_e * q_e) + sqrt(i_l * i_l + q_l * q_l));  // :322-323
+  if (p.pilot_combine != 0 && arms >= 2) {
+    const double pi_e = sums[6], pq_e = sums[7], pi_p = sums[8], pq_p = sums[9], pi_l = sums[10], pq_l = sums[11];
+    double carr_err_q;
+    if (p.pilot_combine == 1) {  // QI = (I_PQ + 1i*Q_PQ) * exp(-1i*pi/2), GPS_L5C tracking.m:340
+      const double cr = cos(kPi / 2), ci = -sin(kPi / 2);
+      const double re = pi_p * cr - pq_p * ci;
+      const double im = pi_p * ci + pq_p * cr;
+      carr_err_q = atan(im / re) / (2.0 * kPi);
+    } else if (p.pilot_combine == 3) {
+      carr_err_q = atan(-pi_p / pq_p) / (2.0 * kPi);  // BDS/B1C NB_tracking.m:341
+    } else {
+      carr_err_q = atan(pq_p / pi_p) / (2.0 * kPi);   // GAL_E1C tracking.m:309
+    }
+    double code_err_q = (sqrt(pi_e * pi_e + pq_e * pq_e) - sqrt(pi_l * pi_l + pq_l * pq_l)) /
+                        (sqrt(pi_e * pi_e + pq_e * pq_e) + sqrt(pi_l * pi_l + pq_l * pq_l));
+    const bool pll_w = p.pll_weight[0] != 0.0 || p.pll_weight[1] != 0.0;
+    const bool dll_w = p.dll_weight[0] != 0.0 || p.dll_weight[1] != 0.0;
+    if (p.dll_scale != 0.0) {
+      code_err = code_err * p.dll_scale;
+      code_err_q = code_err_q * p.dll_scale;
+    }
+    carr_err = pll_w ? (carr_err * p.pll_weight[0] + carr_err_q * p.pll_weight[1]) / (p.pll_weight[0] + p.pll_weight[1])
+                     : (carr_err + carr_err_q) / 2;
+    code_err = dll_w ? (code_err * p.dll_weight[0] + code_err_q * p.dll_weight[1]) / (p.dll_weight[0] + p.dll_weight[1])
+                     : (code_err + code_err_q) / 2;
+    rec(GC_TRK_PILOT_I_E, pi_e);
+    rec(GC_TRK_PILOT_Q_E, pq_e);
+    rec(GC_TRK_PILOT_I_P, pi_p);
+    rec(GC_TRK_PILOT_Q_P, pq_p);
+    rec(GC_TRK_PILOT_I_L, pi_l);
+    rec(GC_TRK_PILOT_Q_L, pq_l);
+  } else if (arms >= 2) {
+    for (int v = 0; v < 6; ++v) rec(GC_TRK_PILOT_I_E + v, sums[6 + v]);
+  }
   double carr_nco;
   double old_carr_nco = ch->old_carr_nco, old_carr_err = ch->old_carr_err, d2 = ch->d2_carr_err, d1 = ch->d_carr_err;
   if (p.pll_kind == GC_PLL_2ND_ORDER) {

@@ -391,21 +391,27 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
   gc_scope_reset(ctx);
+  int max_arms = 1;
+  bool single_r1 = true;
   for (int c = 0; c < nch; ++c) {
     const int ci = init[c].channel;
     if (ci < 0 || ci >= GC_MAX_CHANNELS || !ctx->ch[ci].configured || !ctx->ch[ci].d_tab[0]) {
       gc_set_error("gc_track_device: channel %d not configured", ci);
       return GC_E_STATE;
     }
-    if (ctx->ch[ci].arms != 1 || ctx->ch[ci].index_scale != 1.0 || ctx->ch[ci].mult[0] != 1.0) {
-      gc_set_error("gc_track_device: single-arm R = 1 channels only (use gc_track)");
-      return GC_E_UNSUPPORTED;
-    }
+    const HostChannel& hcn = ctx->ch[ci];
+    for (int a = 0; a < hcn.arms; ++a)
+      if (!hcn.d_tab[a] || hcn.mult[a] != 1.0 || hcn.window[a] != 0) {
+        gc_set_error("gc_track_device: windowed tables / ramp multipliers are not covered (use gc_track)");
+        return GC_E_UNSUPPORTED;
+      }
+    max_arms = std::max(max_arms, hcn.arms);
+    single_r1 = single_r1 && hcn.arms == 1 && hcn.index_scale == 1.0;
     gc_scope_add(ctx, ci);
   }
-  if (p->pilot_combine != 0 || p->table_phase_count != 0 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL ||
-      gc_fast_table_mode(ctx) != 0 || ctx->force_generic) {
-    gc_set_error("gc_track_device: configuration not covered by the persistent kernel (use gc_track)");
+  if (max_arms > 2 || p->pilot_combine > 3 || (p->pilot_combine != 0 && max_arms < 2) || p->table_phase_count != 0 ||
+      ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
+    gc_set_error("gc_track_device: configuration not covered by the persistent kernels (use gc_track)");
     return GC_E_UNSUPPORTED;
   }
   const int n_epochs = p->n_epochs;
@@ -435,15 +441,25 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     lowrate = std::min(lowrate, gc_block_lowrate_level(ctx, probe));
     share = share && gc_block_shares_el(ctx, b);
   }
-  if (lowrate <= 0) {
-    gc_set_error("gc_track_device: code rate too high for the transition-mask kernel (use gc_track)");
-    return GC_E_UNSUPPORTED;
-  }
-  // team size: enough one-wave workgroups to fill the device, at least ~one lane-chunk per lane and split
+  // transition-mask kernel (one-wave members) where it applies, else the lane kernel (16-wave member workgroups)
+  const bool use_fast = single_r1 && lowrate > 0 && p->pilot_combine == 0 && gc_fast_table_mode(ctx) == 0 && !ctx->force_generic;
+  int splits, msgs_per_member;
+  bool share_lane = true;
   const int spl = lowrate == 2 ? 16 : 8;
-  const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
-  int splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 48)}));  // just under one lane-chunk per lane: the epoch is a latency chain
-  if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
+  if (use_fast) {
+    // team size: just under one lane-chunk per lane and member — the epoch is a latency chain
+    const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
+    splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 48)}));
+    if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
+    msgs_per_member = 2;
+  } else {
+    for (int c = 0; c < nch; ++c) share_lane = share_lane && gc_block_shares_el_lane(ctx, hc[c].blk);
+    // member workgroups per channel: about four 64-sample steps per lane; the closer polls (members - 1) * 6 * arms <= 64 messages
+    const int nsamp = hc[0].blk.blksize;
+    splits = std::max(1, std::min({max_arms == 1 ? 8 : 6, nsamp / (64 * gcorr::kLaneWaves * 4), std::max(1, 2 * ctx->compute_units / nch)}));
+    if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(max_arms == 1 ? 8 : 6, std::atoi(e)));
+    msgs_per_member = 6 * max_arms;
+  }
   const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr;  // teams on one XCD each (default)
 
   gcorr::DevLoopArgs ha;
@@ -458,7 +474,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   gcorr::DevLoopArgs* d_args = nullptr;
   const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
   hipError_t e = hipMalloc((void**)&ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
-  const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * 2, desc_bytes = sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords;
+  const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * msgs_per_member, desc_bytes = sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords;
   if (e == hipSuccess) e = hipMalloc((void**)&ha.part_msg, part_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&ha.desc_msg, desc_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&ha.records, rec_bytes);
@@ -501,7 +517,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   a.devloop = d_args;
   a.xcd_swizzle = xcd_local ? 1 : 0;
   const unsigned int grid = xcd_local ? (unsigned int)(((nch + 7) / 8) * 8 * splits) : (unsigned int)(nch * splits);
-  rc = gc_launch_devloop(ctx, a, grid, lowrate == 2, share);
+  rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane);
   if (rc == GC_OK) {
     e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, ha.records, rec_bytes, hipMemcpyDeviceToHost);

@@ -476,3 +476,61 @@ def test_device_side_loop_closure_matches_host_loop_and_oracle(engine, l1ca_scen
     assert dev[0].status == "-" and dev[1].status == "-"
     n0 = int(np.count_nonzero(dev[0].absoluteSample))
     assert 285 <= n0 < 300 and not dev[0].I_P[n0:].any() and not dev[1].I_P.any()
+
+
+def test_device_side_loop_closure_two_arm_lane_kernel(engine):
+    """gc_track_device on the lane kernel (16-wave member workgroups, sums combined in LDS and by tagged messages):
+    GPS L5 I5 + Q5 with the pilot rotated by -pi/2 (pilot_combine 1, 3-state PLL) and Galileo E1 B + C (R = 2,
+    pilot_combine 2, 4-ms blocks) against the host-closed loop and the oracle."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E1C, initSettings_GPS_L5C
+    S = initSettings_GPS_L5C()
+    S.pilotTRKflag = 1
+    fs = S.samplingFreq
+    S.msToProcess = 60
+    S.numberOfChannels = 2
+    rng = np.random.default_rng(9)
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 18000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0) for p in (6, 30)]
+    iq = P.synth.generate_if(sats, int(0.064 * fs), fs, S.IF, P.codes.generateL5Icode, S.codeFreqBasis, 10230, seed=33,
+                             carrier_ratio=1150.0, bit_periods=10, pilot_fn=P.codes.generateL5Qcode, pilot_phase=np.pi / 2)
+    ch = []
+    for s in sats:
+        f = S.IF + s.doppler + 2.0
+        ch.append(SimpleNamespace(PRN=s.prn, acquiredFreq=f, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1,
+                                  codeFreq=S.codeFreqBasis + (f - S.IF) / S.carrFreqBasis * S.codeFreqBasis))
+    engine.load_if(iq, fs=fs)
+    host, _ = P.tracking(engine, ch, S, signal="GPS_L5C")
+    dev, _ = P.tracking(engine, ch, S, signal="GPS_L5C", device_loop=True)
+    spec = SimpleNamespace(tables=lambda prn: [O.pad_code(O.generate_l5_code(prn, "I")), O.pad_code(O.generate_l5_code(prn, "Q"))],
+                           r=1.0, pll="3state", coef_variant="a", pilot_combine=1, code_freq_from_channel=True)
+    ref = O.tracking_generic(iq, ch, S, spec)
+    fields = ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L", "Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L")
+    for k in range(2):
+        assert dev[k].status == "T"
+        assert np.array_equal(dev[k].absoluteSample, ref[k].absoluteSample)
+        for f in fields:
+            assert np.max(np.abs(getattr(dev[k], f) - getattr(ref[k], f))) < 1e-5 * 2.0 * 18000 * 28.0, (k, f)
+            assert np.max(np.abs(getattr(dev[k], f) - getattr(host[k], f))) < 1e-5 * 2.0 * 18000 * 28.0, (k, f)
+        assert np.max(np.abs(dev[k].carrFreq - ref[k].carrFreq)) < 1e-3 and np.max(np.abs(dev[k].codeFreq - ref[k].codeFreq)) < 1e-3
+
+    S = initSettings_GAL_E1C()
+    fs = S.samplingFreq
+    S.msToProcess = 80
+    S.numberOfChannels = 2
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 72000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=48.0) for p in (4, 19)]
+    iq = P.synth.generate_if(sats, int(0.090 * fs), fs, S.IF, P.codes.generateE1Bcode, 2 * S.codeFreqBasis, 8184, seed=21,
+                             bit_periods=1, pilot_fn=P.codes.generateE1Ccode)
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 2.0, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in sats]
+    engine.load_if(iq, fs=fs)
+    dev, _ = P.tracking(engine, ch, S, signal="GAL_E1C", device_loop=True)
+    spec = SimpleNamespace(tables=lambda prn: [O.pad_code(O.generate_e1_code(prn, "B")), O.pad_code(O.generate_e1_code(prn, "C"))],
+                           r=2.0, pll="3state", coef_variant="a", pilot_combine=2, code_freq_from_channel=False)
+    ref = O.tracking_generic(iq, ch, S, spec)
+    for k in range(2):
+        assert dev[k].status == "T" and np.array_equal(dev[k].absoluteSample, ref[k].absoluteSample)
+        for f in fields:
+            assert np.max(np.abs(getattr(dev[k], f) - getattr(ref[k], f))) < 1e-5 * 2.0 * 72000 * 28.0, (k, f)
+        assert np.max(np.abs(dev[k].carrFreq - ref[k].carrFreq)) < 1e-3
+        assert np.max(np.abs(dev[k].remCodePhase - ref[k].remCodePhase)) < 1e-7
