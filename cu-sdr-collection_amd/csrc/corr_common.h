@@ -277,7 +277,7 @@ __device__ __forceinline__ gc_block load_block(const KArgs& p, long long lb) {
 }  // namespace gcorr
 
 // corr_lane.hip
-int gc_launch_devloop_lane(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int max_arms, bool share_el);
+int gc_launch_devloop_lane(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int max_arms, bool share_el, int waves);
 int gc_launch_correlator_lane(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
                               int max_arms, bool share_el);
 // corr_fast.hip

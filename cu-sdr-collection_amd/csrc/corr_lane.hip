@@ -77,10 +77,11 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
   // DEVLOOP: p.splits member workgroups per channel; with xcd_swizzle a channel's members all run on one XCD
   // (workgroup b -> XCD b % 8): channel = (b % 8) + 8 * ((b / 8) / members), member = (b / 8) % members
   const int member = DEVLOOP ? (p.xcd_swizzle ? (int)((wg >> 3) % p.splits) : (int)(wg % p.splits)) : 0;
-  const int nsplit = DEVLOOP ? p.splits * kLW : wg_block ? kLW : p.splits;
+  const int nw = DEVLOOP ? (int)(blockDim.x >> 6) : kLW;  // waves of this workgroup (the device loop may launch fewer than 16)
+  const int nsplit = DEVLOOP ? p.splits * nw : wg_block ? kLW : p.splits;
   const long long item = wg_block ? wg * kLW + wave : wave_items ? wg * kLW + wave : wg;
   const long long wq = DEVLOOP ? (p.xcd_swizzle ? (wg & 7) + 8 * ((wg >> 3) / p.splits) : wg / p.splits) : item / nsplit;
-  const int split = DEVLOOP ? member * kLW + wave : (int)(item - wq * nsplit);
+  const int split = DEVLOOP ? member * nw + wave : (int)(item - wq * nsplit);
   const long long grp = wq / p.stride;
   const int cslot = (int)(wq - grp * p.stride);
 
@@ -109,11 +110,11 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
       uint4* dst = reinterpret_cast<uint4*>(smem);
       const int n16 = (kF16 ? chn0->tabh_bytes : 2 * chn0->tabh_bytes) >> 4;
 #pragma unroll 4
-      for (int i = threadIdx.x; i < n16; i += kLW * 64) dst[i] = src[i];
+      for (int i = threadIdx.x; i < n16; i += (int)blockDim.x) dst[i] = src[i];
     } else {
       tab_t* wtab = reinterpret_cast<tab_t*>(smem);
       const int total = maxn + 2 * kGuard;
-      for (int i = threadIdx.x; i < total; i += kLW * 64) {
+      for (int i = threadIdx.x; i < total; i += (int)blockDim.x) {
         const int e = i - kGuard;
 #pragma unroll
         for (int a = 0; a < AP; ++a) {
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, 
       const unsigned int tag = (unsigned int)bi + 1u;
       double mine = 0.0;  // lanes 0 .. NS-1: this workgroup's sum of component `lane`
       if (lane < NS)
-        for (int w = 0; w < kLW; ++w) mine += (double)red[w * GC_OUT_STRIDE + lane];
+        for (int w = 0; w < nw; ++w) mine += (double)red[w * GC_OUT_STRIDE + lane];
       msg_t* pm = dl->part_msg + (lb * p.splits) * NS;
       if (member != 0) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
@@ -589,11 +590,11 @@ int launch_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 gr
 }
 
 template <int ARMS, int MODE>
-int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share) {
+int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share, int waves) {
   void* args[2] = {(void*)&a, (void*)&ib};
   const void* fn = share ? (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 1, true> : (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 0, true>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  GC_HIP(hipLaunchCooperativeKernel(fn, grid, dim3(kLW * 64), args, (unsigned int)smem, ctx->stream));
+  GC_HIP(hipLaunchCooperativeKernel(fn, grid, dim3(waves * 64), args, (unsigned int)smem, ctx->stream));
   return GC_OK;
 }
 
@@ -601,7 +602,7 @@ int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 
 
 // Persistent tracker with device-side loop closure on the lane kernel: grid = channel slots x a.splits member workgroups.
 // f32 tables only (<= 96 KiB), int8 I/Q or Q/I records, one or two arms.
-int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid, int max_arms, bool share_el) {
+int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid, int max_arms, bool share_el, int waves) {
   KArgs a = a_in;
   InlineBlocks ib;
   std::memset(&ib, 0, sizeof ib);
@@ -614,8 +615,9 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   a.red_off = (int)tab_bytes;
   const size_t smem = tab_bytes + kLW * GC_OUT_STRIDE * sizeof(float) + 128 + 64 * sizeof(double);
   const bool qi = ctx->if_layout == GC_QI;
-  if (max_arms == 1) return qi ? launch_lane_devloop<1, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el) : launch_lane_devloop<1, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el);
-  return qi ? launch_lane_devloop<2, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el) : launch_lane_devloop<2, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el);
+  if (waves < 1 || waves > kLW) return GC_E_INVALID;
+  if (max_arms == 1) return qi ? launch_lane_devloop<1, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el, waves) : launch_lane_devloop<1, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el, waves);
+  return qi ? launch_lane_devloop<2, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el, waves) : launch_lane_devloop<2, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el, waves);
 }
 
 // share_el: every block of the launch has 2*el_spacing*R*M an exact positive integer

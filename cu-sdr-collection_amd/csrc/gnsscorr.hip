@@ -360,6 +360,10 @@ int gc_set_channel(gc_context* ctx, int channel, int arms, double index_scale) {
   c.configured = true;
   c.arms = arms;
   c.index_scale = index_scale;
+  for (int a = 0; a < GC_MAX_ARMS; ++a) {  // a re-configured channel starts from defaults: no window, multiplier 1
+    c.window[a] = 0;
+    c.mult[a] = 1.0;
+  }
   ctx->channels_dirty = true;
   return GC_OK;
 }

@@ -443,21 +443,23 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   }
   // transition-mask kernel (one-wave members) where it applies, else the lane kernel (16-wave member workgroups)
   const bool use_fast = single_r1 && lowrate > 0 && p->pilot_combine == 0 && gc_fast_table_mode(ctx) == 0 && !ctx->force_generic;
-  int splits, msgs_per_member;
+  int splits, msgs_per_member, lane_waves = gcorr::kLaneWaves;
   bool share_lane = true;
   const int spl = lowrate == 2 ? 16 : 8;
   if (use_fast) {
     // team size: just under one lane-chunk per lane and member — the epoch is a latency chain
     const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
     splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 48)}));
-    if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
+    if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
     msgs_per_member = 2;
   } else {
     for (int c = 0; c < nch; ++c) share_lane = share_lane && gc_block_shares_el_lane(ctx, hc[c].blk);
     // member workgroups per channel: about four 64-sample steps per lane; the closer polls (members - 1) * 6 * arms <= 64 messages
     const int nsamp = hc[0].blk.blksize;
-    splits = std::max(1, std::min({max_arms == 1 ? 8 : 6, nsamp / (64 * gcorr::kLaneWaves * 4), std::max(1, 2 * ctx->compute_units / nch)}));
-    if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(max_arms == 1 ? 8 : 6, std::atoi(e)));
+    lane_waves = 8;  // measured best for both the 1-ms and the 4-ms packages (scripts/devloop_lane_sweep.py)
+    if (const char* e = std::getenv("GC_DEVLOOP_WAVES")) lane_waves = std::max(1, std::min(gcorr::kLaneWaves, std::atoi(e)));
+    splits = std::max(1, std::min({max_arms == 1 ? 8 : 6, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch)}));
+    if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_arms == 1 ? 8 : 6, std::atoi(e)));
     msgs_per_member = 6 * max_arms;
   }
   const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr;  // teams on one XCD each (default)
@@ -517,7 +519,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   a.devloop = d_args;
   a.xcd_swizzle = xcd_local ? 1 : 0;
   const unsigned int grid = xcd_local ? (unsigned int)(((nch + 7) / 8) * 8 * splits) : (unsigned int)(nch * splits);
-  rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane);
+  rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane, lane_waves);
   if (rc == GC_OK) {
     e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, ha.records, rec_bytes, hipMemcpyDeviceToHost);

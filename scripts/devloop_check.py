@@ -27,9 +27,9 @@ t0 = time.time(); hf, hd, hs = eng.track(p, inits); th = time.time() - t0
 print("host loop us/epoch", round(th / p.n_epochs * 1e6, 2))
 for sp in (None, 2, 4, 8, 12, 17, 24, 32, 48, 64):
     if sp is None:
-        os.environ.pop("GC_TRACK_SPLITS", None)
+        os.environ.pop("GC_DEVLOOP_MEMBERS", None)
     else:
-        os.environ["GC_TRACK_SPLITS"] = str(sp)
+        os.environ["GC_DEVLOOP_MEMBERS"] = str(sp)
     t0 = time.time(); df, dd, ds = eng.track(p, inits, device_loop=True); td = time.time() - t0
     same = np.array_equal(df["absoluteSample"], hf["absoluteSample"])
     print("device loop splits", sp, "us/epoch", round(td / p.n_epochs * 1e6, 2), "status", ds, "same geometry", same,
@@ -48,7 +48,7 @@ for sp in (None, 2, 4, 8, 12, 17, 24, 32, 48, 64):
 if "--oracle" in sys.argv:
     from types import SimpleNamespace
     from oracle import c_oracle as CO
-    os.environ.pop("GC_TRACK_SPLITS", None)
+    os.environ.pop("GC_DEVLOOP_MEMBERS", None)
     nE = 8000
     S.msToProcess = nE
     p2 = track_params(S)
