@@ -281,6 +281,7 @@ int gc_launch_devloop_lane(gc_context* ctx, const gcorr::KArgs& a, unsigned int 
 int gc_launch_correlator_lane(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
                               int max_arms, bool share_el);
 // corr_fast.hip
+bool gc_fast_prefers_wide();  // compiled with the prefix-sum variant
 int gc_launch_devloop(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, bool spl16, bool share_el);
 int gc_launch_correlator_fast(gc_context* ctx, const gcorr::KArgs& a, const gcorr::InlineBlocks& ib, unsigned int grid,
                               int max_arms, bool spl16);

@@ -18,6 +18,8 @@
 //   * the transition position u = g/(step*R*M) is a float quotient; chunks where any u is within
 //     4e-6 of an integer (a sample within ~1e-7 chip of a chip edge, where float32 and the reference's
 //     float64 rounding could disagree) take the exact double-precision path.
+#include <cstdlib>
+
 #include "corr_common.h"
 #include "devloop.h"
 
@@ -28,6 +30,9 @@ namespace {
 constexpr float kBig = 8388608.0f;  // 2^23: clamp(kBig*(j-u)) is exactly 0 or 1 outside the tie band
 constexpr float kTieTol = 4e-6f;
 constexpr int kFW = 64;  // one wavefront per workgroup
+#ifndef GC_FAST_PREFIX
+#define GC_FAST_PREFIX 1
+#endif
 #ifndef GC_SCHED_GROUP
 #define GC_SCHED_GROUP 4
 #endif
@@ -116,6 +121,9 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
       return tab2[ar][k + 1];
     }
   };
+#if GC_FAST_PREFIX
+  float2* pfx = reinterpret_cast<float2*>(smem + p.red_off + (DEVLOOP ? 8 * 3 * 64 : 64)) + (WIDE ? wave * SPL * kFW : 0);  // [SPL][64] per wave
+#endif
   if (wave_items && wq >= p.nblocks) return;
 
   const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
@@ -337,6 +345,11 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
           const float yi = kReal ? -a * S[j] : fmaf(b, C[j], -a * S[j]);
           Tr += yr;
           Ti += yi;
+#if GC_FAST_PREFIX
+          // running prefix sums P[j] = y_0 + .. + y_j parked in LDS ([j][lane]: conflict-free 8-byte stores); the
+          // masked sums are then S = T - P[floor(u)] — two lookups per chunk instead of three ops per sample and tap
+          pfx[j * kFW + lane] = make_float2(Tr, Ti);
+#else
 #pragma unroll
           for (int sx = 0; sx < NS; ++sx) {
             // 1 iff j > u  (v_fma_f32 ... clamp)
@@ -344,7 +357,17 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
             Sr[sx] = fmaf(s, yr, Sr[sx]);
             Si[sx] = fmaf(s, yi, Si[sx]);
           }
+#endif
         });
+#if GC_FAST_PREFIX
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) {
+          const int m = min(SPL - 1, (int)(gh[sx] * uk));   // samples 0 .. m lie before the transition
+          const float2 P = pfx[m * kFW + lane];
+          Sr[sx] = Tr - P.x;
+          Si[sx] = Ti - P.y;
+        }
+#endif
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
 #pragma unroll
@@ -491,9 +514,16 @@ void launch_variant(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim
   if (a.wide) {
     // four-wave workgroups + int8-pair tables: instantiated for the 8-sample chunk, int8 I/Q records,
     // one or two arms (Galileo E1 B / B+C and similar 8000-20000-entry tables)
-    if constexpr (SPL == 8 && ARMS <= 2 && (MODE == I8_IQ || MODE == I8_QI)) {
-      if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
-      else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+    if constexpr (ARMS <= 2 && (MODE == I8_IQ || MODE == I8_QI)) {
+      if constexpr (SPL == 8) {
+        if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+        else if (share && GC_FAST_PREFIX) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, ARMS == 1, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+        else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+      } else if constexpr (GC_FAST_PREFIX != 0) {
+        // 16-sample chunks: replay only (chosen by the launcher for the prefix-sum variant)
+        if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, ARMS == 1, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+        else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+      }
     }
     return;
   }
@@ -548,16 +578,20 @@ int gc_launch_devloop(gc_context* ctx, const KArgs& a_in, unsigned int grid, boo
   InlineBlocks ib;
   std::memset(&ib, 0, sizeof ib);
   a.red_off = 8 * ctx->max_lds_bytes;
-  const size_t smem = (size_t)a.red_off + 8 * 3 * 64;  // + the closer's reduction scratch
+  const size_t smem = (size_t)a.red_off + 8 * 3 * 64 + (GC_FAST_PREFIX ? 16 * kFW * sizeof(float2) : 0);  // + the closer's reduction scratch
   return spl16 ? launch_devloop_mode<16>(ctx, a, ib, dim3(grid), smem, share_el) : launch_devloop_mode<8>(ctx, a, ib, dim3(grid), smem, share_el);
 }
+
+bool gc_fast_prefers_wide() { return GC_FAST_PREFIX != 0; }
 
 // spl16: every block satisfies 15*step*R*M < 1 and the samples are int8 I/Q
 int gc_launch_correlator_fast(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, int max_arms,
                               bool spl16) {
   // float2 tables: 8 bytes per staged entry (lds_off counts entries here)
-  const size_t smem = (size_t)a.red_off + 64;
-  const bool wide = !a.wide && spl16 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
+  const bool wide = (!a.wide || GC_FAST_PREFIX) && spl16 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // 16-sample chunks
+  // + per wave the running prefix sums of one lane-chunk ([SPL][64] float2) of the prefix-sum variant
+  size_t smem = (size_t)a.red_off + 64 + (GC_FAST_PREFIX ? (size_t)(a.wide ? 4 : 1) * (wide ? 16 : 8) * kFW * sizeof(float2) : 0);
+  if (const char* e = std::getenv("GC_FAST_EXTRA_LDS")) smem += (size_t)std::atoi(e);  // tuning: occupancy experiments
   if (wide) {
     switch (max_arms) {
       case 1: return launch_fast_mode<1, 16>(ctx, a, ib, dim3(grid), smem);

@@ -145,7 +145,13 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   long long total = (long long)nblocks * splits;
   int want_bpw = 8;
   if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
-  const bool wide_tables = fast > 0 && gc_fast_table_mode(ctx) == 1;
+  const bool must_wide = fast > 0 && gc_fast_table_mode(ctx) == 1;  // tables too large for single-wave workgroups
+  // by choice: with the prefix-sum variant (corr_fast.hip GC_FAST_PREFIX) every wave parks 8 KB of running sums in LDS, and
+  // only four waves sharing an int8-pair table keep 16 waves per CU resident (big periodic replay lists, int8 I/Q, <= 2 arms)
+  const bool big_list0 = nblocks >= 64 * (long long)period * ctx->compute_units;
+  const bool choose_wide = fast > 0 && !must_wide && gc_fast_prefers_wide() && period > 0 && splits == 1 && big_list0 && notify_tag == 0 &&
+                           ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && max_arms <= 2 && 2 * ctx->max_lds_bytes + 512 <= 40 * 1024;
+  const bool wide_tables = must_wide || choose_wide;
   const bool big_list = nblocks >= 64 * (long long)period * ctx->compute_units;
   if (fast == 0) {
     // lane kernel: 16 wavefronts per workgroup, one (block, split) item each
@@ -181,11 +187,14 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   }
   dim3 grid((unsigned int)total);
   int rc;
-  if (fast > 0 && gc_fast_table_mode(ctx) == 1) {
-    // WIDE fast kernel: 8-sample chunks, four waves per workgroup
+  if (fast > 0 && wide_tables) {
+    // WIDE fast kernel: four waves per workgroup, int8-pair tables (8-sample chunks and no early/late sharing unless
+    // chosen for the prefix-sum variant, which is instantiated for both chunk sizes)
     a.wide = 1;
-    fast = 1;
-    a.share_el = 0;
+    if (!choose_wide) {
+      fast = 1;
+      a.share_el = 0;
+    }
     if (a.bpw == 1) {
       if (splits % 4 != 0 && splits != 1) {
         gc_set_error("internal: WIDE correlator launch needs splits %% 4 == 0 (got %d)", splits);

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Tuning variants of libgnsscorr.so that differ in ONE translation unit's macros:
+#   scripts/variants.sh corr_fast "PFX:-DGC_FAST_PREFIX=1" ...   -> cu-sdr-collection_amd/lib/libgnsscorr_PFX.so
+set -e
+cd "$(dirname "$0")/../cu-sdr-collection_amd"
+unit="$1"; shift
+(cd .. && python -m cu_sdr_collection_amd.build >/dev/null)
+objs=""
+for o in gnsscorr corr_kernel corr_fast corr_lane track acq navsync; do [ "$o" != "$unit" ] && objs="$objs build/$o.o"; done
+for spec in "$@"; do
+  name="${spec%%:*}"; flags="${spec#*:}"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize -ffp-contract=off $flags -c csrc/$unit.hip -o build/${unit}_$name.o &
+done
+wait
+for spec in "$@"; do
+  name="${spec%%:*}"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $objs build/${unit}_$name.o -o lib/libgnsscorr_$name.so
+  echo built lib/libgnsscorr_$name.so
+done
