@@ -53,6 +53,7 @@ struct KArgs {
   double* out;      // [nblocks][GC_OUT_STRIDE] when splits == 1
   double* partial;  // [nblocks][splits][GC_OUT_STRIDE] when splits > 1
   double fs;
+  double inv_fs;  // 1 / fs
   int64_t nblocks;
   int splits;
   int xcd_swizzle;

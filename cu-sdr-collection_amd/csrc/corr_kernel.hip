@@ -121,6 +121,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   a.out = d_out;
   a.partial = d_partial;
   a.fs = ctx->fs;
+  a.inv_fs = 1.0 / ctx->fs;
   a.nblocks = nblocks;
   a.splits = splits;
   a.red_off = ctx->max_lds_bytes;

@@ -511,6 +511,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   a.blocks = nullptr;
   a.chans = ctx->d_channels;
   a.fs = ctx->fs;
+  a.inv_fs = 1.0 / ctx->fs;
   a.nblocks = nch;
   a.splits = splits;
   a.bpw = 1;
