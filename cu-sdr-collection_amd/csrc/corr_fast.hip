@@ -54,8 +54,8 @@ __device__ __forceinline__ void store_prefix(float tr, float ti, unsigned int ld
 // barrier is the one after staging.
 // DEVLOOP = persistent launch with device-side loop closure (devloop.h): the block loop becomes the epoch loop of ONE
 // channel, descriptors come from the channel's device state, sums go to the team's slot array.
-template <int ARMS, int MODE, int SPL, bool CL, bool SHARE_EL, bool WIDE, bool DEVLOOP = false>
-__global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
+template <int ARMS, int MODE, int SPL, bool CL, bool SHARE_EL, int WIDE, bool DEVLOOP = false>
+__global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = SPL * Fmt<MODE>::bps / 4;
   constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
@@ -71,11 +71,11 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
   // into LDS once per bpw blocks; neighbouring workgroups hold the other channels of the same
   // epochs and read the same IF window through the same L2.
   const int lane = threadIdx.x & 63;
-  const int wave = WIDE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // wave-uniform (SGPR)
+  const int wave = WIDE != 0 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // wave-uniform (SGPR)
   // WIDE, single block per item (closed loop / small lists): the four waves take four consecutive
   // (block, split) items — the host keeps splits a multiple of 4 so they share block and table;
   // WIDE, periodic replay: the waves interleave over the workgroup's bpw blocks.
-  const bool wave_items = WIDE && p.bpw == 1;
+  const bool wave_items = WIDE != 0 && p.bpw == 1;
   const long long item = wave_items ? wg * 4 + wave : wg;
   // DEVLOOP with xcd_swizzle: a channel's whole team on ONE XCD (workgroup b runs on XCD b % 8), so that the team's
   // atomics and partial sums meet in that XCD's L2: channel = (b % 8) + 8 * ((b / 8) / splits), split = (b / 8) % splits
@@ -86,8 +86,10 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
 
   // ---- stage {c[k], c[k+1]-c[k]} for k = -1 .. nent (c[-1] := c[0], c[>=nent] := 0), once per
   //      workgroup: the host guarantees that all blocks of a workgroup share channel and offsets
+  constexpr bool TABF = (WIDE == 2);  // WIDE with plain float code values c[k] (4 bytes per entry): small tables, no conversions
   float2* tab2[ARMS];
   unsigned short* tab16[ARMS];
+  float* tabf[ARMS];
   {
     const long long lb0 = min(grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
     const gc_block blk0 = DEVLOOP ? p.devloop->chan[lb0].blk : CL ? load_block(p, lb0) : p.blocks[lb0];
@@ -97,13 +99,19 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
       const int aa = (a < chn0->arms) ? a : 0;
       tab2[a] = reinterpret_cast<float2*>(smem + 8 * (size_t)chn0->lds_off[aa]);
       tab16[a] = reinterpret_cast<unsigned short*>(smem + 2 * (size_t)chn0->lds_off[aa]);
+      tabf[a] = reinterpret_cast<float*>(smem + 4 * (size_t)chn0->lds_off[aa]);
       if (a < chn0->arms) {
         const int off = blk0.table_offset[a];
         const int n = min(chn0->stage_len[a], chn0->nent[a] - off);
         // window-relative entry i <-> absolute entry off + i of the pre-differenced table; all loads
         // are independent coalesced reads (one wait), which matters for the closed loop where a
         // launch is only a few microseconds long
-        if constexpr (WIDE) {
+        if constexpr (TABF) {
+          const float2* __restrict__ src = chn0->tab2[a] + off;
+#pragma unroll 4
+          for (int i = threadIdx.x; i < n + 3; i += 256) tabf[a][i] = src[i].x;
+          if (threadIdx.x == 0) tabf[a][n + 3] = 0.0f;
+        } else if constexpr (WIDE != 0) {
           const unsigned short* __restrict__ src = chn0->tab2b[a] + off;
 #pragma unroll 4
           for (int i = threadIdx.x; i < n + 3; i += 256) tab16[a][i] = src[i];
@@ -116,9 +124,11 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
     }
     __syncthreads();
   }
-  // table entry k (k = -1 .. n+1) as {c[k], c[k+1] - c[k]}
+  // table entry k (k = -1 .. n+1) as {c[k], c[k+1] - c[k]} (TABF: {c[k], c[k+1]})
   auto table_entry = [&](int ar, int k) -> float2 {
-    if constexpr (WIDE) {
+    if constexpr (TABF) {
+      return make_float2(tabf[ar][k + 1], tabf[ar][k + 2]);
+    } else if constexpr (WIDE != 0) {
       const unsigned int e = tab16[ar][k + 1];
       float c, dc;
       asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(c) : "v"(e));
@@ -129,14 +139,14 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
     }
   };
   // running sums of a lane-chunk, per wave [SPL][re | im][64 lanes] floats
-  float* pfx = reinterpret_cast<float*>(smem + p.red_off + (DEVLOOP ? 8 * 3 * 64 : 64)) + (WIDE ? wave * SPL * 2 * kFW : 0);
+  float* pfx = reinterpret_cast<float*>(smem + p.red_off + (DEVLOOP ? 8 * 3 * 64 : 64)) + (WIDE != 0 ? wave * SPL * 2 * kFW : 0);
   unsigned int pfx_m0 = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)pfx);  // its LDS byte address (low half of the flat address)
   if (wave_items && wq >= p.nblocks) return;
 
   const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
   gc_block dl_next;  // DEVLOOP closer: the descriptor it prepared for the next epoch
   (void)dl_next;
-  for (int bi = (WIDE && !wave_items) ? wave : 0; bi < nloop; bi += (WIDE && !wave_items) ? 4 : 1) {
+  for (int bi = (WIDE != 0 && !wave_items) ? wave : 0; bi < nloop; bi += (WIDE != 0 && !wave_items) ? 4 : 1) {
   const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
   gc_block blk;
@@ -393,12 +403,14 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
           }
           store_prefix<(2 * j) * kFW * 4, (2 * j + 1) * kFW * 4>(Tr, Ti, pfx_m0);
         });
-        float Sr[NS], Si[NS];
+        float Sr[NS], Si[NS], Pr[NS], Pi[NS];  // sums after / before the transition
 #pragma unroll
         for (int sx = 0; sx < NS; ++sx) {
           const int m = min((int)(gh[sx] * uk), SPL - 1);  // samples 0 .. m lie before the transition (P[SPL-1] = T: none after)
-          Sr[sx] = Tr - pfx[(2 * m) * kFW + lane];
-          Si[sx] = Ti - pfx[(2 * m + 1) * kFW + lane];
+          Pr[sx] = pfx[(2 * m) * kFW + lane];
+          Pi[sx] = pfx[(2 * m + 1) * kFW + lane];
+          Sr[sx] = Tr - Pr[sx];
+          Si[sx] = Ti - Pi[sx];
         }
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
@@ -406,8 +418,9 @@ __global__ __launch_bounds__(WIDE ? 256 : kFW) void corr_epl_fast_kernel(const K
           for (int ar = 0; ar < ARMS; ++ar) {
             const int sx = (SHARE && x == 2) ? 0 : x;
             const float2 cd = table_entry(ar, kk[sx] + ((SHARE && x == 2) ? 1 : 0));
-            Ur[ar][x] = fmaf(cd.x, Tr, cd.y * Sr[sx]);
-            Ui[ar][x] = fmaf(cd.x, Ti, cd.y * Si[sx]);
+            // {c, dc}: c*T + dc*S;  {c1, c2}: c1*P + c2*S
+            Ur[ar][x] = fmaf(cd.x, TABF ? Pr[sx] : Tr, cd.y * Sr[sx]);
+            Ui[ar][x] = fmaf(cd.x, TABF ? Pi[sx] : Ti, cd.y * Si[sx]);
           }
         }
       }
@@ -549,31 +562,39 @@ void launch_variant(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim
   const bool cl = a.tagged != nullptr;
   // the shared-early/late instantiation exists for single-arm channels (GPS L1 C/A, B1I, GLONASS)
   const bool share = (ARMS == 1) && a.share_el != 0;
+  if (a.wide == 2) {
+    // four-wave workgroups + plain float tables (small single-arm tables, big replay lists)
+    if constexpr (ARMS == 1 && (MODE == I8_IQ || MODE == I8_QI)) {
+      if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, true, 2>), grid, dim3(256), smem, ctx->stream, a, ib);
+      else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, 2>), grid, dim3(256), smem, ctx->stream, a, ib);
+    }
+    return;
+  }
   if (a.wide) {
     // four-wave workgroups + int8-pair tables: instantiated for the 8-sample chunk, int8 I/Q records,
     // one or two arms (Galileo E1 B / B+C and similar 8000-20000-entry tables)
     if constexpr (ARMS <= 2 && (MODE == I8_IQ || MODE == I8_QI)) {
       if constexpr (SPL == 8) {
-        if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
-        else if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, ARMS == 1, true>), grid, dim3(256), smem, ctx->stream, a, ib);
-        else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+        if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, 1>), grid, dim3(256), smem, ctx->stream, a, ib);
+        else if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, ARMS == 1, 1>), grid, dim3(256), smem, ctx->stream, a, ib);
+        else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, 1>), grid, dim3(256), smem, ctx->stream, a, ib);
       } else {
         // 16-sample chunks: replay only (chosen by the launcher for the prefix-sum variant)
-        if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, ARMS == 1, true>), grid, dim3(256), smem, ctx->stream, a, ib);
-        else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, true>), grid, dim3(256), smem, ctx->stream, a, ib);
+        if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, ARMS == 1, 1>), grid, dim3(256), smem, ctx->stream, a, ib);
+        else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, 1>), grid, dim3(256), smem, ctx->stream, a, ib);
       }
     }
     return;
   }
   if constexpr (ARMS == 1) {
-    if (cl && share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, true, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    if (cl && share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, true, 0>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, 0>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else if (share) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, true, 0>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, 0>), grid, dim3(kFW), smem, ctx->stream, a, ib);
   } else {
     (void)share;
-    if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
-    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, false>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    if (cl) hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, true, false, 0>), grid, dim3(kFW), smem, ctx->stream, a, ib);
+    else hipLaunchKernelGGL((corr_epl_fast_kernel<ARMS, MODE, SPL, false, false, 0>), grid, dim3(kFW), smem, ctx->stream, a, ib);
   }
 }
 
@@ -601,8 +622,8 @@ int launch_devloop_mode(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 
   void* args[2] = {(void*)&a, (void*)&ib};
   const void* fn = nullptr;
   const bool qi = ctx->if_layout == GC_QI;
-  if (share) fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, true, false, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, true, false, true>;
-  else fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, false, false, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, false, false, true>;
+  if (share) fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, true, 0, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, true, 0, true>;
+  else fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, false, 0, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, false, 0, true>;
   // cooperative: every team member must be resident while the others spin on the epoch flag
   GC_HIP(hipLaunchCooperativeKernel(fn, grid, dim3(kFW), args, (unsigned int)smem, ctx->stream));
   return GC_OK;

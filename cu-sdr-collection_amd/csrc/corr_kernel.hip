@@ -195,6 +195,9 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     if (!choose_wide) {
       fast = 1;
       a.share_el = 0;
+    } else if (max_arms == 1 && a.bpw > 1 && !std::getenv("GC_NO_TABF") &&
+               4 * (size_t)ctx->max_lds_bytes + 4 * (size_t)(fast == 2 ? 8192 : 4096) + 64 <= 40 * 1024) {
+      a.wide = 2;  // small single-arm table: plain float code values, no conversions in the chunk loop; still 4 workgroups per CU
     }
     if (a.bpw == 1) {
       if (splits % 4 != 0 && splits != 1) {
@@ -230,7 +233,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     }
     rc = (hipGetLastError() == hipSuccess) ? GC_OK : GC_E_HIP;
   } else if (fast) {
-    a.red_off = (a.wide ? 2 : 8) * ctx->max_lds_bytes;  // float2 {c, dc} tables: 8 bytes per staged entry (int8 pairs: 2)
+    a.red_off = (a.wide == 2 ? 4 : a.wide ? 2 : 8) * ctx->max_lds_bytes;  // float2 {c, dc} tables: 8 bytes per staged entry (int8 pairs: 2, plain floats: 4)
     rc = gc_launch_correlator_fast(ctx, a, ib, (unsigned int)total, max_arms, fast == 2);
   } else {
     rc = gc_launch_correlator_lane(ctx, a, ib, (unsigned int)total, max_arms, ctx->scope_share_lane);
