@@ -2,17 +2,18 @@
 // advances by less than one entry over a lane-chunk of SPL samples ((SPL-1)*step*R*M < 1).
 //   SPL = 16: GPS L1 C/A (17.6 samples/chip at 18 Msps), GLONASS (23.5)
 //   SPL =  8: B1I / E1 BOC(1,1) / B1C BOC(1,1) (8.8), L2C (7.8), and L1 C/A at lower rates
-// Same arithmetic contract as corr_kernel.hip (tracking.m:247-300), ~3-4x fewer VALU instructions
-// per sample:
+// Same arithmetic contract as corr_kernel.hip (tracking.m:247-300); DESIGN.md 4.1 has the measurements.
 //
-//   * a lane-chunk sees at most ONE table transition per tap, so the replica over the chunk is
-//     c1 + dc*step(j - u): the six sums become c1*T + dc*S_x with T = sum_j y_j shared by all taps
-//     and arms and S_x = sum_j step(j - u_x)*y_j; step() is ONE full-rate VALU op
-//     (v_fma_f32 ... clamp), no compare / select / LDS gather per sample;
-//   * LDS holds {c[k], c[k+1]-c[k]} as float2, one ds_read_b64 per tap and arm per chunk;
+//   * a lane-chunk sees at most ONE table transition per tap, so the replica over the chunk is c1 before and c2
+//     after sample u: the six sums are c1*P_x + c2*(T - P_x) with T = sum_j y_j shared by all taps and arms and
+//     P_x = sum_{j <= u_x} y_j;
+//   * the running sums P_j are formed by two fused multiply-adds per component and sample and parked in LDS with
+//     ds_write_addtid_b32 (2 LDS cycles per wave-store; wider stores made the LDS store path the limit); P_x is
+//     one ds_read2_b32 per ramp: no per-sample work per tap, no compare / select / gather per sample;
 //   * int8/int16 samples are converted by SDWA sign-extending v_cvt_f32_i32 (one op per component);
-//   * one wavefront per workgroup: no barrier and no cross-wave reduction; the next chunk's 16-byte
-//     loads are issued before the current chunk is processed;
+//   * every lane of a wave walks the same number of chunks, so loop counter, load base and edge tests are scalar;
+//     two word buffers alternate: the next chunk's 16-byte loads are in flight while this one is processed;
+//   * LDS tables: float2 {c, dc} (one wave per workgroup), int8 pairs {c, dc} or plain floats c (four waves);
 //   * the carrier base rotation is applied Horner-style to the accumulators (acc = acc*conj(rho) + U)
 //     and once more at the end with the exact per-thread phase;
 //   * the transition position u = g/(step*R*M) is a float quotient; chunks where any u is within
