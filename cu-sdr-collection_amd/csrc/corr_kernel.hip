@@ -216,6 +216,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     }
     a.xcd_swizzle = (a.wide && total % 8 == 0 && total >= 64) ? 1 : 0;
   }
+  ctx->last_kernel = fast < 0 ? -1 : fast == 0 ? 0 : a.wide == 2 ? 3 : a.wide ? 2 : 1;
   if (fast < 0) {
     // mixed ramp multipliers: exact per-sample kernel
     int mode;

@@ -110,6 +110,7 @@ struct gc_context {
   int replay_period = 0;
   bool replay_share_el = false;  // channel pattern period of the replay list (0 = not periodic)
   bool force_generic = false;
+  int last_kernel = -2;  // gc_debug_last_kernel
 
   // acquisition scratch (acq.hip)
   void* acq_scratch = nullptr;

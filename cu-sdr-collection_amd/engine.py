@@ -131,6 +131,10 @@ class Engine:
         L.check(self._lib.gc_correlate(self._ctx, n, blocks, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def last_kernel(self) -> int:
+        """gc_debug_last_kernel: 0 lane, 1 fast (one wave), 2 fast (four waves, int8 pairs), 3 fast (four waves, floats), -1 mixed."""
+        return int(self._lib.gc_debug_last_kernel(self._ctx))
+
     def replay_prepare(self, blocks):
         self._replay_n = len(blocks)
         L.check(self._lib.gc_replay_prepare(self._ctx, len(blocks), blocks))

@@ -308,6 +308,12 @@ int gc_preamble_xcorr(gc_context* ctx, const double* i_p, int64_t n, const int8_
  * an integer, or -1 — the exact near-tie analysis that lets the kernels skip their per-chunk filters. */
 long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps);
 
+/* Test hook: which correlator kernel the last gc_correlate / gc_replay_launch / gc_track launch used:
+ * 0 lane kernel (any chipping rate), 1 fast kernel with one-wave workgroups (float2 tables), 2 fast kernel with
+ * four-wave workgroups and int8-pair tables, 3 the same with plain float tables, -1 exact per-sample kernel
+ * (mixed ramp multipliers); -2 before the first launch.  Lets the parity tests prove which path they covered. */
+int gc_debug_last_kernel(const gc_context* ctx);
+
 /* Test hook: the library's four-step mixed-radix FFT on `nbatch` host sequences of n complex64
  * values (n of the form 2^a 3^b 5^c); output in natural order, unnormalised. */
 int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in, float* out, int inverse);

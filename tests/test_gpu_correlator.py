@@ -254,3 +254,44 @@ def test_preamble_cross_correlation_and_subframe_start(engine):
     assert np.array_equal(got_corr, want_corr.astype(np.float32))
     assert P.nav_sync.find_subframe_start(engine, x, x.shape[0]) == want_start == 1234
     assert P.nav_sync.find_subframe_start(engine, -x, x.shape[0]) == 1234
+
+
+def test_big_periodic_replay_lists_take_the_four_wave_kernels_and_match_the_oracle(engine, monkeypatch):
+    """BASELINE-size replay lists (>= 64 blocks per channel and CU, periodic channel pattern) run the four-wave
+    instantiations of the fast kernel, which no small list reaches: float tables (GPS L1 C/A, shared early/late ramp),
+    int8-pair tables, and the unshared-ramp variant (spacing != 1/2 chip).  Sampled blocks against the C oracle,
+    2000 blocks against gc_correlate (one-wave kernel) on the same descriptors."""
+    rng = np.random.default_rng(77)
+    nsamp = 2_000_000
+    iq = rng.integers(-40, 41, size=2 * nsamp, dtype=np.int8)
+    engine.load_if(iq, fs=18e6)
+    tables = [O.pad_code(O.generate_ca_code(p)) for p in (5, 19)]
+    for k, t in enumerate(tables):
+        engine.set_channel(k, [t])
+    _, cus = engine.device_info()
+    nb = 64 * 2 * cus + 2 * 37                      # just over the launcher's big-list threshold, not a multiple of 8 epochs
+    for spacing, env, want in ((0.5, {}, 3), (0.5, {"GC_NO_TABF": "1"}, 2), (0.3, {}, 3)):
+        descs = _random_descs(rng, nb, nsamp, 2)
+        for i, d in enumerate(descs):
+            d["channel"] = i % 2
+            d["d"] = spacing
+        descs[0]["rem"] = 0.0                        # exact ties at samples 3000 k with the nominal step
+        descs[0]["step"] = 1.023e6 / 18e6
+        descs[0]["n"] = 18000
+        b = _blocks(engine, descs)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        engine.replay_prepare(b)
+        engine.replay_launch()
+        got = engine.replay_fetch()[:, 0]
+        assert engine.last_kernel() == want
+        for k in env:
+            monkeypatch.delenv(k)
+        for i in list(range(0, 8)) + [int(x) for x in rng.integers(0, nb, 40)] + [nb - 1]:
+            d = descs[i]
+            assert np.abs(got[i] - _oracle(iq, d, tables[d["channel"]])).max() < TOL * _scale(iq, d), (spacing, env, i)
+        sub = list(range(0, nb, nb // 2000))
+        small = engine.correlate(_blocks(engine, [descs[i] for i in sub]))[:, 0]
+        assert engine.last_kernel() == 1
+        scale = 18000 * 2 * 20.0
+        assert np.abs(got[sub] - small).max() < 2e-7 * scale
