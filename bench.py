@@ -66,7 +66,8 @@ def main() -> None:
     S.msToProcess = n_epochs
     S.numberOfChannels = nch
 
-    eng = P.Engine(local_rank)
+    # one GPU per rank; GC_BENCH_DEVICE pins every rank to one device (functional test of the N > 1 path on a 1-GPU box)
+    eng = P.Engine(int(os.environ.get("GC_BENCH_DEVICE", local_rank)))
     dev_name, cus = eng.device_info()
     sats = P.synth.scene(nch, 20241008 + 2, fs)
     t0 = time.time()
