@@ -99,6 +99,56 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// floor(i / d) for 0 <= i < 2^21 through the float reciprocal of d (exact: (i + 0.5) / d is at least 0.5 / d away from
+// every integer, far more than the float rounding of the product) - the runtime divisors of the index arithmetic would
+// otherwise cost a software division each
+__device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
+
+// One radix-R Stockham stage of the tile in LDS: the same arithmetic, in the same order, for every R (so results do not
+// depend on the plan), with R a compile-time constant: the R inputs and W_R^m live in registers.
+template <int R>
+__device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, const float2* src, float2* dst, int L, int C,
+                                          int ns, int tid, float sign) {
+  const int lr = L / R;
+  const int tws = n / (ns * R);  // table stride for W_{ns*R}
+  const int wr = n / R;          // W_R = tw[wr]
+  float2 wb[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    wb[m] = tw[m * wr];
+    wb[m].y *= sign;
+  }
+  const float inv_lr = 1.0f / (float)lr, inv_ns = 1.0f / (float)ns;
+  for (int idx = tid; idx < lr * C; idx += kFftThreads) {
+    const int c = fdiv_small(idx, inv_lr);
+    const int j = idx - c * lr;
+    const int k = j - fdiv_small(j, inv_ns) * ns;
+    float2 vq[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      float2 x = src[c * L + j + q * lr];
+      if (k != 0 && q != 0) {
+        float2 w = tw[k * q * tws];  // k*q*tws < ns*R*tws = n
+        w.y *= sign;
+        x = cmul(x, w);
+      }
+      vq[q] = x;
+    }
+    const int obase = c * L + (j - k) * R + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      float2 acc = vq[0];
+#pragma unroll
+      for (int pp = 1; pp < R; ++pp) {
+        const float2 t = cmul(vq[pp], wb[(pp * q) % R]);
+        acc.x += t.x;
+        acc.y += t.y;
+      }
+      dst[obase + q * ns] = acc;
+    }
+  }
+}
+
 // One workgroup: `cols` vectors of length L, Stockham autosort in LDS (ping-pong), one output
 // element group (j, column) per thread per stage.
 __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a) {
@@ -113,6 +163,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
   const int tid = threadIdx.x;
   const int nel = L * C;
   const float sign = a.inverse ? -1.0f : 1.0f;  // table holds exp(-i..): conjugate for the inverse
+  const float inv_L = 1.0f / (float)L, inv_C = 1.0f / (float)C;
 
   const int reps = (a.post == POST_ABS_ACC) ? a.nhops : 1;
   // POST_ABS_ACC keeps its accumulators in registers across the hop loop
@@ -126,11 +177,11 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
     for (int idx = tid; idx < nel; idx += kFftThreads) {
       int e, c;
       if (a.estride == 1) {
-        e = idx % L;
-        c = idx / L;
+        c = fdiv_small(idx, inv_L);
+        e = idx - c * L;
       } else {
-        c = idx % C;
-        e = idx / C;
+        e = fdiv_small(idx, inv_C);
+        c = idx - e * C;
       }
       const int v = v0 + c;
       float2 val = make_float2(0.f, 0.f);
@@ -177,34 +228,11 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
     int ns = 1;
     for (int s = 0; s < a.nrad; ++s) {
       const int r = a.rad[s];
-      const int lr = L / r;
-      const int tws = a.n / (ns * r);  // table stride for W_{ns*r}
-      for (int idx = tid; idx < lr * C; idx += kFftThreads) {
-        const int j = idx % lr, c = idx / lr;
-        const int k = j % ns;
-        float2 vq[5];
-        for (int q = 0; q < r; ++q) {
-          float2 x = src[c * L + j + q * lr];
-          if (k != 0 && q != 0) {
-            float2 w = a.tw[((long long)k * q * tws) % a.n];
-            w.y *= sign;
-            x = cmul(x, w);
-          }
-          vq[q] = x;
-        }
-        const int obase = c * L + (j - k) * r + k;
-        const int wr = a.n / r;  // W_r = tw[wr]
-        for (int q = 0; q < r; ++q) {
-          float2 acc = vq[0];
-          for (int pp = 1; pp < r; ++pp) {
-            float2 w = a.tw[((long long)pp * q % r) * wr];
-            w.y *= sign;
-            const float2 t = cmul(vq[pp], w);
-            acc.x += t.x;
-            acc.y += t.y;
-          }
-          dst[obase + q * ns] = acc;
-        }
+      switch (r) {
+        case 2: fft_stage<2>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
+        case 3: fft_stage<3>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
+        case 4: fft_stage<4>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
+        default: fft_stage<5>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
       }
       __syncthreads();
       float2* t = src;
@@ -220,18 +248,18 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       if (idx >= nel) continue;
       int e, c;
       if (a.estride == 1) {
-        e = idx % L;
-        c = idx / L;
+        c = fdiv_small(idx, inv_L);
+        e = idx - c * L;
       } else {
-        c = idx % C;
-        e = idx / C;
+        e = fdiv_small(idx, inv_C);
+        c = idx - e * C;
       }
       const int v = v0 + c;
       if (v >= a.nvec) continue;
       float2 val = src[c * L + e];
       const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
       if (a.post == POST_TWIDDLE) {
-        float2 w = a.tw[((long long)v * e) % a.n];
+        float2 w = a.tw[v * e];  // v < n2, e < n1: v*e < n
         w.y *= sign;
         val = cmul(val, w);
       }
@@ -251,11 +279,11 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       if (idx >= nel) continue;
       int e, c;
       if (a.estride == 1) {
-        e = idx % L;
-        c = idx / L;
+        c = fdiv_small(idx, inv_L);
+        e = idx - c * L;
       } else {
-        c = idx % C;
-        e = idx / C;
+        e = fdiv_small(idx, inv_C);
+        c = idx - e * C;
       }
       const int v = v0 + c;
       if (v >= a.nvec) continue;

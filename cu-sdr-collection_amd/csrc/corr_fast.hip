@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
       msg_t m = {0u, 0u, 0u, 0u};
       unsigned int spins = 0;
       while (true) {
-        if (lane < kDescWords) m = msg_load(dm + lane);
+        if (lane < kDescWords) m = msg_load(dm + lane, p.devloop->reserved);
         const bool ok = lane >= kDescWords || m.z == (unsigned int)bi + 1u;
         if (__all(ok)) break;
         if (++spins > (1u << 22)) break;
@@ -476,8 +476,8 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     const unsigned int tag = (unsigned int)bi + 1u;
     if (split != 0) {
       if (lane == 63) {
-        msg_store(pm + split * 2, msg_t{__float_as_uint(tot[0]), __float_as_uint(tot[1]), __float_as_uint(tot[2]), tag});
-        msg_store(pm + split * 2 + 1, msg_t{__float_as_uint(tot[3]), __float_as_uint(tot[4]), __float_as_uint(tot[5]), tag});
+        msg_store(pm + split * 2, msg_t{__float_as_uint(tot[0]), __float_as_uint(tot[1]), __float_as_uint(tot[2]), tag}, dl->reserved);
+        msg_store(pm + split * 2 + 1, msg_t{__float_as_uint(tot[3]), __float_as_uint(tot[4]), __float_as_uint(tot[5]), tag}, dl->reserved);
       }
     } else {
       // the closer: own sums from lane 63, the others' messages polled one per lane, everything added in double
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
       msg_t m = {0u, 0u, 0u, 0u};
       unsigned int spins = 0;
       while (true) {
-        if (lane < nmsg) m = msg_load(pm + 2 + lane);
+        if (lane < nmsg) m = msg_load(pm + 2 + lane, dl->reserved);
         const bool ok = lane >= nmsg || m.w == tag;
         if (__all(ok)) break;
         if (++spins > (1u << 22)) break;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
       if (spins > (1u << 22)) {
         if (lane == 0) dl->chan[lb].status = 3;
         // tell the team to stop: a descriptor with a non-zero status word
-        if (lane < kDescWords) msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{3u, 0u, tag + 1u, 0u});
+        if (lane < kDescWords) msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{3u, 0u, tag + 1u, 0u}, dl->reserved);
         break;
       }
       // message 2k + h of member k + 1 holds components 3h .. 3h + 2
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
 #pragma unroll
       for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) word = (lane == i) ? u.q[i] : word;
       if (lane < kDescWords && bi + 1 < nloop)
-        msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u});
+        msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u}, dl->reserved);
       if (st != 0) break;
     }
   } else if (CL) {

@@ -48,13 +48,26 @@ struct DevLoopArgs {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
-__device__ __forceinline__ msg_t msg_load(const msg_t* p) {
+// Message scope (g_msg_scope, set per launch from DevLoopArgs::reserved): 0 = system (sc0 sc1: past every cache),
+// 1 = workgroup (sc0: past the CU's L1 only — the team's L2 is the meeting point; valid when the whole team runs on ONE
+// XCD, which the launch arranges and the kernel verifies through HW_REG_XCC_ID before switching to it), 2 = agent (sc1).
+__device__ __forceinline__ msg_t msg_load(const msg_t* p, int scope = 0) {
   msg_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  if (scope == 1)
+    asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else if (scope == 2)
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
-__device__ __forceinline__ void msg_store(msg_t* p, msg_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void msg_store(msg_t* p, msg_t v, int scope = 0) {
+  if (scope == 1)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+  else if (scope == 2)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
 // Closing member: lane-uniform float64 restatement of tracking.m:273-348 for one channel and epoch — the same statements
