@@ -90,6 +90,11 @@ struct PassArgs {
   float* acc_out;
   int acc_add;  // POST_ABS_ACC: add to what acc_out already holds (second code arm of the same PRN)
   float acc_scale;  // POST_ABS_ACC: weight of this arm (B1C: sqrt(11/40), sqrt(29/40)); 0 means 1
+  // POST_ABS_ACC with few bins: the hops of a bin are split over hop_groups workgroups (otherwise tiles x bins
+  // workgroups, ~2 per CU, each walking all the hops); group g's raw sums go to acc_part[g][bin][n] and
+  // abs_combine_kernel adds them in group order
+  int hop_groups, acc_bins;
+  float* acc_part;
   // PRE_MUL_CONJ with circular spectrum shifts (the circshift search family): batch tb reads input transform
   // tb / shift_bins shifted by tb % shift_bins natural-frequency bins; n1, n2 give the [k1][k2] storage order
   int shift_bins, n1, n2;
@@ -107,8 +112,8 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 // One radix-R Stockham stage of the tile in LDS: the same arithmetic, in the same order, for every R (so results do not
 // depend on the plan), with R a compile-time constant: the R inputs and W_R^m live in registers.
 template <int R>
-__device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, const float2* src, float2* dst, int L, int C,
-                                          int ns, int tid, float sign) {
+__device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, const float2* src, float2* dst, float2* twl,
+                                          int L, int C, int ns, int tid, float sign) {
   const int lr = L / R;
   const int tws = n / (ns * R);  // table stride for W_{ns*R}
   const int wr = n / R;          // W_R = tw[wr]
@@ -117,6 +122,17 @@ __device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, 
   for (int m = 0; m < R; ++m) {
     wb[m] = tw[m * wr];
     wb[m].y *= sign;
+  }
+  // this stage's twiddles W_{ns*R}^{k*q} (k < ns, 0 < q < R) from the global table into LDS once per tile: the butterflies'
+  // own lookups were scattered 8-byte global loads, the dominant cost of the pass
+  if (ns > 1) {
+    for (int i = tid; i < ns * (R - 1); i += kFftThreads) {
+      const int k = i / (R - 1), q = i % (R - 1) + 1;
+      float2 w = tw[k * q * tws];  // k*q*tws < ns*R*tws = n
+      w.y *= sign;
+      twl[i] = w;
+    }
+    __syncthreads();
   }
   const float inv_lr = 1.0f / (float)lr, inv_ns = 1.0f / (float)ns;
   for (int idx = tid; idx < lr * C; idx += kFftThreads) {
@@ -127,11 +143,7 @@ __device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, 
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       float2 x = src[c * L + j + q * lr];
-      if (k != 0 && q != 0) {
-        float2 w = tw[k * q * tws];  // k*q*tws < ns*R*tws = n
-        w.y *= sign;
-        x = cmul(x, w);
-      }
+      if (k != 0 && q != 0) x = cmul(x, twl[k * (R - 1) + q - 1]);
       vq[q] = x;
     }
     const int obase = c * L + (j - k) * R + k;
@@ -156,23 +168,27 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
   const int L = a.len, C = a.cols;
   float2* buf0 = lds;
   float2* buf1 = lds + (size_t)L * C;
+  float2* twl = lds + (size_t)2 * L * C;  // [L] stage twiddles
   const int tiles = (a.nvec + C - 1) / C;
   const int tile = blockIdx.x % tiles;
-  const long long batch = blockIdx.x / tiles;
+  const int HG = (a.post == POST_ABS_ACC && a.hop_groups > 1) ? a.hop_groups : 1;
+  const long long bb = blockIdx.x / tiles;
+  const long long batch = bb / HG;
+  const int hg = (int)(bb - batch * HG);
   const int v0 = tile * C;
   const int tid = threadIdx.x;
   const int nel = L * C;
   const float sign = a.inverse ? -1.0f : 1.0f;  // table holds exp(-i..): conjugate for the inverse
   const float inv_L = 1.0f / (float)L, inv_C = 1.0f / (float)C;
 
-  const int reps = (a.post == POST_ABS_ACC) ? a.nhops : 1;
+  const int reps = (a.post == POST_ABS_ACC) ? a.nhops / HG : 1;
   // POST_ABS_ACC keeps its accumulators in registers across the hop loop
   float accv[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) accv[k] = 0.f;
 
   for (int rep = 0; rep < reps; ++rep) {
-    const long long tb = (a.post == POST_ABS_ACC) ? batch * a.nhops + rep : batch;
+    const long long tb = (a.post == POST_ABS_ACC) ? batch * a.nhops + (long long)hg * reps + rep : batch;
     // ---- load tile (coalesced along whichever index is contiguous in memory) ------------------------
     for (int idx = tid; idx < nel; idx += kFftThreads) {
       int e, c;
@@ -229,10 +245,10 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
     for (int s = 0; s < a.nrad; ++s) {
       const int r = a.rad[s];
       switch (r) {
-        case 2: fft_stage<2>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
-        case 3: fft_stage<3>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
-        case 4: fft_stage<4>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
-        default: fft_stage<5>(a.tw, a.n, src, dst, L, C, ns, tid, sign); break;
+        case 2: fft_stage<2>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+        case 3: fft_stage<3>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+        case 4: fft_stage<4>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+        default: fft_stage<5>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
       }
       __syncthreads();
       float2* t = src;
@@ -288,9 +304,23 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       const int v = v0 + c;
       if (v >= a.nvec) continue;
       const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
-      float* dstp = a.acc_out + batch * a.n + pos;
-      *dstp = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * (a.acc_scale != 0.0f ? a.acc_scale : 1.0f);
+      if (HG > 1) {
+        a.acc_part[((long long)hg * a.acc_bins + batch) * a.n + pos] = accv[slot];
+      } else {
+        float* dstp = a.acc_out + batch * a.n + pos;
+        *dstp = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * (a.acc_scale != 0.0f ? a.acc_scale : 1.0f);
+      }
     }
+  }
+}
+
+// POST_ABS_ACC with hop groups: results = (add ? results : 0) + (sum over groups, in group order) / n * scale
+__global__ void abs_combine_kernel(const float* __restrict__ part, int groups, long long total, float* __restrict__ out, int add,
+                                   float inv_n, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    for (int g = 0; g < groups; ++g) v += part[(long long)g * total + i];
+    out[i] = (add ? out[i] : 0.0f) + v * inv_n * scale;
   }
 }
 
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r
 
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
-  const size_t smem = (size_t)2 * a.len * a.cols * sizeof(float2);
+  const size_t smem = ((size_t)2 * a.len * a.cols + a.len) * sizeof(float2);
   hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned int)(tiles * nbatch_groups)), dim3(kFftThreads), smem, ctx->stream, a);
   GC_HIP(hipGetLastError());
   return GC_OK;
@@ -425,6 +455,8 @@ struct AcqScratch {
   float2* tmp = nullptr;      // nbh * n   scratch between passes
   float2* codespec = nullptr; // nprn * n
   float* results = nullptr;   // nbins * n
+  float* partial = nullptr;   // hop-group sums of the last inverse pass (launch_pass)
+  size_t partial_cap = 0;
   int8_t* codes = nullptr;    // nprn * spc
   long long* sums = nullptr;  // 3 + scratch for argmax
   double* fine = nullptr;     // fine sums
@@ -439,10 +471,41 @@ struct AcqScratch {
 
 void free_scratch(AcqScratch* s) {
   if (!s) return;
-  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->codes, s->sums, s->fine, s->rowmax, s->rowarg};
+  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->fine, s->rowmax, s->rowarg};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
+}
+
+// Last inverse pass (POST_ABS_ACC) over `nbins` bins.  With few bins the launch would have ~2 workgroups per CU, each
+// walking all nhops hops of its bin: the hops are then split over hop groups (a divisor of nhops), whose raw sums meet in
+// abs_combine_kernel - deterministic, group order fixed.
+int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins) {
+  const int tiles = (a.nvec + a.cols - 1) / a.cols;
+  int hg = 1;
+  for (int g = 1; g <= a.nhops; ++g)
+    if (a.nhops % g == 0 && (long long)tiles * nbins * hg < 8LL * ctx->compute_units) hg = g;
+  if (std::getenv("GC_ACQ_NO_HOP_GROUPS")) hg = 1;
+  a.hop_groups = hg;
+  if (hg == 1) return launch_pass(ctx, a, nbins);
+  const size_t need = (size_t)hg * (size_t)nbins * (size_t)a.n;
+  if (s->partial_cap < need) {
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    if (s->partial) (void)hipFree(s->partial);
+    s->partial = nullptr;
+    s->partial_cap = 0;
+    GC_HIP(hipMalloc((void**)&s->partial, need * sizeof(float)));
+    s->partial_cap = need;
+  }
+  a.acc_part = s->partial;
+  a.acc_bins = (int)nbins;
+  int rc = launch_pass(ctx, a, nbins * hg);
+  if (rc) return rc;
+  const long long total = nbins * (long long)a.n;
+  hipLaunchKernelGGL(abs_combine_kernel, dim3(1024), dim3(256), 0, ctx->stream, s->partial, hg, total, a.acc_out, a.acc_add,
+                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
 }
 
 }  // namespace
@@ -629,7 +692,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.in = s->tmp;
       a.acc_out = s->results;
       a.acc_add = arm > 0;
-      rc = launch_pass(ctx, a, nbins);
+      rc = launch_abs_pass(ctx, s, a, nbins);
       if (rc) return rc;
     }
     // peak pick
@@ -805,7 +868,7 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.acc_out = s->results;
     a.acc_add = arm > 0;
     a.acc_scale = arm_weight ? (float)arm_weight[arm] : 1.0f;
-    rc = launch_pass(ctx, a, rows);
+    rc = launch_abs_pass(ctx, s, a, rows);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(rowmax_kernel, dim3(rows), dim3(256), 0, ctx->stream, s->results, p.n, s->rowmax, s->rowarg);
