@@ -21,7 +21,7 @@ LIBS = {
     "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_lane.hip", "track.hip", "acq.hip", "navsync.hip"],
     "libgnsssynth.so": ["synth.hip"],
 }
-HEADERS = ["gc_internal.h", "corr_common.h", os.path.join("..", "..", "include", "gnsscorr.h")]
+HEADERS = ["gc_internal.h", "corr_common.h", "devloop.h", os.path.join("..", "..", "include", "gnsscorr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
          "-Wno-unused-function", "-fno-slp-vectorize"]
 # The correlator's exact paths restate the reference's float64 arithmetic operation by operation

@@ -45,6 +45,28 @@ __device__ __forceinline__ void store_prefix(float tr, float ti, unsigned int ld
                : "memory", "m0");
 }
 
+// Sum of a double over each 32-lane half of the wavefront with DPP row shifts / broadcast (the total of lanes 0..31
+// lands in lane 31, of lanes 32..63 in lane 63); the order of the additions is fixed.
+__device__ __forceinline__ double half_sum_f64(double v) {
+  auto dpp64 = [](double x, auto ctrl, auto row_mask) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  };
+  v += dpp64(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+  v += dpp64(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+  v += dpp64(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+  v += dpp64(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+  v += dpp64(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+  return v;
+}
+__device__ __forceinline__ double rl_f64(double x, int lane) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), lane) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, lane)));
+}
+
 // CL = closed-loop variant: descriptors from the kernel-argument segment, results as host-mapped tagged
 // records.  The replay instantiation (CL = false) carries none of that code.
 // SHARE = every block of the launch has earlyLateSpc*R*M == 1/2 (host-checked): early and late share one
@@ -147,6 +169,11 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
   gc_block dl_next;  // DEVLOOP closer: the descriptor it prepared for the next epoch
   (void)dl_next;
+  DevLoopChan dl_st;  // DEVLOOP closer: the channel's loop state, in registers across the epochs
+  if constexpr (DEVLOOP) {
+    if (split == 0) dl_st = p.devloop->chan[min(wq, (long long)p.nblocks - 1)];
+  }
+  (void)dl_st;
   for (int bi = (WIDE != 0 && !wave_items) ? wave : 0; bi < nloop; bi += (WIDE != 0 && !wave_items) ? 4 : 1) {
   const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
@@ -184,6 +211,8 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   } else {
     blk = CL ? load_block(p, lb) : p.blocks[lb];
   }
+  unsigned long long dl_t0 = 0;
+  if constexpr (DEVLOOP) dl_t0 = __builtin_amdgcn_s_memrealtime();
   const DevChannel* __restrict__ chn = p.chans + blk.channel;
   const int arms_here = chn->arms;
 
@@ -482,13 +511,18 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     } else {
       // the closer: own sums from lane 63, the others' messages polled one per lane, everything added in double
       // through LDS (splits <= 32: at most 62 messages)
-      double* red = reinterpret_cast<double*>(smem + p.red_off);
-      const int nmsg = (dl->splits - 1) * 2;
+      const unsigned long long dl_t1 = __builtin_amdgcn_s_memrealtime();
+      // what does not need the sums, while the other members' messages are still on their way
+      const DevLoopPre dl_pre = devloop_pre(dl, dl_st, blk, 1.0);
+      // message 2k + h of member k + 1 holds components 3h .. 3h + 2; lane 32h + k polls it, so that each half of the wave
+      // reduces one triple with DPP row shifts (no LDS round trips, no barrier): splits - 1 <= 32
+      const int mk = lane & 31, mh = lane >> 5;
+      const bool mine = mk < dl->splits - 1;
       msg_t m = {0u, 0u, 0u, 0u};
       unsigned int spins = 0;
       while (true) {
-        if (lane < nmsg) m = msg_load(pm + 2 + lane, dl->reserved);
-        const bool ok = lane >= nmsg || m.w == tag;
+        if (mine) m = msg_load(pm + 2 + 2 * mk + mh, dl->reserved);
+        const bool ok = !mine || m.w == tag;
         if (__all(ok)) break;
         if (++spins > (1u << 22)) break;
         __builtin_amdgcn_s_sleep(1);
@@ -499,28 +533,17 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
         if (lane < kDescWords) msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{3u, 0u, tag + 1u, 0u}, dl->reserved);
         break;
       }
-      // message 2k + h of member k + 1 holds components 3h .. 3h + 2
-      red[lane * 3 + 0] = (lane < nmsg) ? (double)__uint_as_float(m.x) : 0.0;
-      red[lane * 3 + 1] = (lane < nmsg) ? (double)__uint_as_float(m.y) : 0.0;
-      red[lane * 3 + 2] = (lane < nmsg) ? (double)__uint_as_float(m.z) : 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_s_barrier();
-      double acc = 0.0;
-      if (lane < 6) {
-        const int hlf = lane / 3, cmp = lane % 3;
-        for (int k = 0; k < dl->splits - 1; ++k) acc += red[(2 * k + hlf) * 3 + cmp];
-      }
-      __builtin_amdgcn_s_barrier();
+      const unsigned long long dl_t2 = __builtin_amdgcn_s_memrealtime();
+      double part[3] = {mine ? (double)__uint_as_float(m.x) : 0.0, mine ? (double)__uint_as_float(m.y) : 0.0,
+                        mine ? (double)__uint_as_float(m.z) : 0.0};
+#pragma unroll
+      for (int v = 0; v < 3; ++v) part[v] = half_sum_f64(part[v]);  // lanes 31 / 63: the sums of the two halves
       double sums[6];
 #pragma unroll
-      for (int v = 0; v < 6; ++v) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
-        sums[v] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(bits >> 32), v) << 32) |
-                                                   (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, v))) +
-                  (double)rl_f(tot[v], 63);
-      }
+      for (int v = 0; v < 6; ++v) sums[v] = rl_f64(part[v % 3], v < 3 ? 31 : 63) + (double)rl_f(tot[v], 63);
       dl_next = blk;
-      const int st = devloop_close(dl, dl->chan + lb, dl_next, lb, bi, sums, 1, 1.0, lane);
+      double dl_rv[GC_TRK_NFIELDS];
+      const int st = devloop_post(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
       // publish the next descriptor (or the stop word) as ten tagged messages, one store per lane
       union {
         gc_block b;
@@ -532,6 +555,14 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
       for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) word = (lane == i) ? u.q[i] : word;
       if (lane < kDescWords && bi + 1 < nloop)
         msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u}, dl->reserved);
+      devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, 1, lane);  // records and state, after the descriptor is on its way
+      if (dl->timing == 1 && lane == 0) {  // phase clocks (100 MHz): correlate | wait for partials | close + publish
+        const unsigned long long dl_t3 = __builtin_amdgcn_s_memrealtime();
+        DevLoopChan* cc = dl->chan + lb;
+        cc->pad[0] += (double)(dl_t1 - dl_t0);
+        cc->pad[1] += (double)(dl_t2 - dl_t1);
+        cc->pad[2] += (double)(dl_t3 - dl_t2);
+      }
       if (st != 0) break;
     }
   } else if (CL) {

@@ -40,11 +40,16 @@ struct DevLoopArgs {
   double* records;     // [nch][GC_TRK_NFIELDS][n_epochs]
   gc_track_params prm;
   double tau1code, tau2code, tau1carr, tau2carr;
+  // the loop filters' quotients (tau2/tau1, int_time/tau1: tracking.m:308-309,327-328), formed once on the host - four
+  // dependent float64 divisions per epoch otherwise
+  double k1code, k2code, k1carr, k2carr;
   unsigned long long if_nsamples;
   int n_epochs;
   int splits;
   int code_index_scale_is_one;  // R == 1 (the only case wired up)
-  int reserved;
+  int reserved;                 // message scope (msg_load / msg_store): 0 = system
+  int timing;                   // GC_DEVLOOP_TIMING: the closer accumulates its phase clocks in DevLoopChan::pad (costs ~1 us per epoch)
+  int pad_;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -71,27 +76,46 @@ __device__ __forceinline__ void msg_store(msg_t* p, msg_t v, int scope = 0) {
 }
 
 // Closing member: lane-uniform float64 restatement of tracking.m:273-348 for one channel and epoch — the same statements
-// as gc_track's host loop (track.hip), pilot handling modes 0-3 included.  `sums`: 6 per arm; R: the channel's index scale.
-// On return b holds the next epoch's block geometry; the return value is the channel status (0 = keep going).
-__device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopChan* ch, gc_block& b, long long slot, int e,
-                                    const double* sums, int arms, double R, int lane) {
+// as gc_track's host loop (track.hip), pilot handling modes 0-3 included — in two parts, so that the closer of the fast
+// kernel can run the first one while the other members' partial sums are still on their way:
+//   devloop_pre   what depends only on the epoch's own geometry and NCO state: the remainders the next block starts from
+//                 (tracking.m:273-283: one fmod, one division);
+//   devloop_post  what needs the sums: discriminators, loop filters, records, the next block (tracking.m:302-335, 219-222).
+// `st` is the caller's copy of the loop state (the fast kernel keeps it in registers across epochs), `gch` the channel's slot
+// in device memory, kept up to date for the host by lane 0.  `sums`: 6 per arm; R: the channel's index scale.  On return b
+// holds the next epoch's block geometry; the return value is the channel status (0 = keep going).
+struct DevLoopPre {
+  double rem_code_new, rem_carr_new;
+};
+
+__device__ inline DevLoopPre devloop_pre(const DevLoopArgs* __restrict__ dl, const DevLoopChan& st, const gc_block& b, double R) {
   const gc_track_params& p = dl->prm;
   const double kPi = 3.141592653589793;
   const int n = b.blksize;
   const double step = b.code_phase_step;
-  double* o = dl->records + (size_t)slot * GC_TRK_NFIELDS * dl->n_epochs;
-  auto rec = [&](int f, double v) {
-    if (lane == 0) o[(size_t)f * dl->n_epochs + e] = v;
-  };
-  const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
-  rec(GC_TRK_ABSOLUTE_SAMPLE, (double)ch->pos);
-  rec(GC_TRK_REM_CODE_PHASE, ch->rem_code);
-  rec(GC_TRK_REM_CARR_PHASE, ch->rem_carr);
-  const double t_last = ((n - 1) * step + ch->rem_code) * R;                   // tcode(blksize), :273 / GAL_E1C :268
-  const double rem_code_new = (R != 1.0) ? (t_last / R + step) - p.code_length : (t_last + step) - p.code_length;
+  DevLoopPre r;
+  const double t_last = ((n - 1) * step + st.rem_code) * R;                    // tcode(blksize), :273 / GAL_E1C :268
+  r.rem_code_new = (R != 1.0) ? (t_last / R + step) - p.code_length : (t_last + step) - p.code_length;
   const double time_n = (double)n / p.sampling_freq;                            // :280-283
-  const double trig_n = ((ch->carr_freq * 2.0 * kPi) * time_n) + ch->rem_carr;
-  const double rem_carr_new = fmod(trig_n, 2 * kPi);
+  const double trig_n = ((st.carr_freq * 2.0 * kPi) * time_n) + st.rem_carr;
+  r.rem_carr_new = fmod(trig_n, 2 * kPi);
+  return r;
+}
+
+template <class Rec>
+__device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopChan& st, gc_block& b, int e, const double* sums, int arms,
+                                   double R, const DevLoopPre& pre, Rec&& rec) {
+  // rec(field, value) takes the epoch's record: straight to device memory (lane kernel) or into registers, to be stored by
+  // devloop_commit AFTER the next descriptor is on its way (fast kernel)
+  const gc_track_params& p = dl->prm;
+  const double kPi = 3.141592653589793;
+  const int n = b.blksize;
+  const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
+  rec(GC_TRK_ABSOLUTE_SAMPLE, (double)st.pos);
+  rec(GC_TRK_REM_CODE_PHASE, st.rem_code);
+  rec(GC_TRK_REM_CARR_PHASE, st.rem_carr);
+  const double rem_code_new = pre.rem_code_new;
+  const double rem_carr_new = pre.rem_carr_new;
   double carr_err = atan(q_p / i_p) / (2.0 * kPi);                              // :305
   double code_err = (sqrt(i_e * i_e + q_e * q_e) - sqrt(i_l * i_l + q_l * q_l)) /
                     (sqrt(i_e * i_e + q_e * q_e) + sqrt(i_l * i_l + q_l * q_l));  // :322-323
@@ -127,12 +151,13 @@ __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopC
     rec(GC_TRK_PILOT_I_L, pi_l);
     rec(GC_TRK_PILOT_Q_L, pq_l);
   } else if (arms >= 2) {
+#pragma unroll
     for (int v = 0; v < 6; ++v) rec(GC_TRK_PILOT_I_E + v, sums[6 + v]);
   }
   double carr_nco;
-  double old_carr_nco = ch->old_carr_nco, old_carr_err = ch->old_carr_err, d2 = ch->d2_carr_err, d1 = ch->d_carr_err;
+  double old_carr_nco = st.old_carr_nco, old_carr_err = st.old_carr_err, d2 = st.d2_carr_err, d1 = st.d_carr_err;
   if (p.pll_kind == GC_PLL_2ND_ORDER) {
-    carr_nco = old_carr_nco + (dl->tau2carr / dl->tau1carr) * (carr_err - old_carr_err) + carr_err * (p.int_time / dl->tau1carr);  // :308-309
+    carr_nco = old_carr_nco + dl->k1carr * (carr_err - old_carr_err) + carr_err * dl->k2carr;  // :308-309
     old_carr_nco = carr_nco;
     old_carr_err = carr_err;
   } else {
@@ -140,11 +165,11 @@ __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopC
     d1 = d2 + carr_err * p.pf2 + d1;
     carr_nco = d1 + carr_err * p.pf1;
   }
-  rec(GC_TRK_CARR_FREQ, ch->carr_freq);
-  const double carr_freq_new = ch->carr_basis + carr_nco;                        // :317
-  const double code_nco = ch->old_code_nco + (dl->tau2code / dl->tau1code) * (code_err - ch->old_code_err) + code_err * (p.int_time / dl->tau1code);
-  rec(GC_TRK_CODE_FREQ, ch->code_freq);
-  const double code_freq_new = ch->code_freq_basis - code_nco;                   // :335
+  rec(GC_TRK_CARR_FREQ, st.carr_freq);
+  const double carr_freq_new = st.carr_basis + carr_nco;                        // :317
+  const double code_nco = st.old_code_nco + dl->k1code * (code_err - st.old_code_err) + code_err * dl->k2code;
+  rec(GC_TRK_CODE_FREQ, st.code_freq);
+  const double code_freq_new = st.code_freq_basis - code_nco;                   // :335
   rec(GC_TRK_DLL_DISCR, code_err);
   rec(GC_TRK_DLL_DISCR_FILT, code_nco);
   rec(GC_TRK_PLL_DISCR, carr_err);
@@ -156,7 +181,7 @@ __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopC
   rec(GC_TRK_I_L, i_l);
   rec(GC_TRK_Q_L, q_l);
   // next block geometry (:219-222) or the end
-  const long long pos_new = ch->pos + n;
+  const long long pos_new = st.pos + n;
   const double step_new = code_freq_new / p.sampling_freq;
   const int n_new = (int)ceil((p.code_length - rem_code_new) / step_new);
   int status = 0;
@@ -164,21 +189,19 @@ __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopC
     status = 1;
   else if (pos_new < 0 || (unsigned long long)(pos_new + n_new) > dl->if_nsamples)
     status = 2;
-  if (lane == 0) {
-    ch->pos = pos_new;
-    ch->rem_code = rem_code_new;
-    ch->rem_carr = rem_carr_new;
-    ch->carr_freq = carr_freq_new;
-    ch->code_freq = code_freq_new;
-    ch->old_code_nco = code_nco;
-    ch->old_code_err = code_err;
-    ch->old_carr_nco = old_carr_nco;
-    ch->old_carr_err = old_carr_err;
-    ch->d2_carr_err = d2;
-    ch->d_carr_err = d1;
-    ch->epochs_done = e + 1;
-    ch->status = status;
-  }
+  st.pos = pos_new;
+  st.rem_code = rem_code_new;
+  st.rem_carr = rem_carr_new;
+  st.carr_freq = carr_freq_new;
+  st.code_freq = code_freq_new;
+  st.old_code_nco = code_nco;
+  st.old_code_err = code_err;
+  st.old_carr_nco = old_carr_nco;
+  st.old_carr_err = old_carr_err;
+  st.d2_carr_err = d2;
+  st.d_carr_err = d1;
+  st.epochs_done = e + 1;
+  st.status = status;
   b.blksize = n_new;
   b.first_sample = pos_new;
   b.rem_code_phase = rem_code_new;
@@ -186,6 +209,41 @@ __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopC
   b.carr_freq = carr_freq_new;
   b.rem_carr_phase = rem_carr_new;
   return status;
+}
+
+// The epoch's record and the loop state to device memory (lane 0), off the critical path.
+__device__ inline void devloop_commit(const DevLoopArgs* __restrict__ dl, DevLoopChan* gch, const DevLoopChan& st, long long slot, int e,
+                                      const double (&rv)[GC_TRK_NFIELDS], int arms, int lane) {
+  if (lane != 0) return;
+  double* o = dl->records + (size_t)slot * GC_TRK_NFIELDS * dl->n_epochs;
+  const int nf = (arms >= 2) ? GC_TRK_NFIELDS : GC_TRK_PILOT_I_E;  // the pilot fields follow the fifteen common ones
+#pragma unroll
+  for (int f = 0; f < GC_TRK_NFIELDS; ++f)
+    if (f < nf) o[(size_t)f * dl->n_epochs + e] = rv[f];
+  gch->pos = st.pos;
+  gch->rem_code = st.rem_code;
+  gch->rem_carr = st.rem_carr;
+  gch->carr_freq = st.carr_freq;
+  gch->code_freq = st.code_freq;
+  gch->old_code_nco = st.old_code_nco;
+  gch->old_code_err = st.old_code_err;
+  gch->old_carr_nco = st.old_carr_nco;
+  gch->old_carr_err = st.old_carr_err;
+  gch->d2_carr_err = st.d2_carr_err;
+  gch->d_carr_err = st.d_carr_err;
+  gch->epochs_done = st.epochs_done;
+  gch->status = st.status;
+}
+
+// All parts back to back on the state held in device memory (lane kernel's closer): state read and written in place, records
+// stored as they are formed.
+__device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopChan* ch, gc_block& b, long long slot, int e,
+                                    const double* sums, int arms, double R, int lane) {
+  double* o = dl->records + (size_t)slot * GC_TRK_NFIELDS * dl->n_epochs;
+  const DevLoopPre pre = devloop_pre(dl, *ch, b, R);
+  return devloop_post(dl, *ch, b, e, sums, arms, R, pre, [&](int f, double v) {
+    if (lane == 0) o[(size_t)f * dl->n_epochs + e] = v;
+  });
 }
 #endif
 

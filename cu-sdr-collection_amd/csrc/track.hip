@@ -469,10 +469,15 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   ha.prm = *p;
   calc_loop_coef(p->dll_noise_bw, p->dll_damping, 1.0, &ha.tau1code, &ha.tau2code);
   calc_loop_coef(p->pll_noise_bw, p->pll_damping, 0.25, &ha.tau1carr, &ha.tau2carr);
+  ha.k1code = ha.tau2code / ha.tau1code;
+  ha.k2code = p->int_time / ha.tau1code;
+  ha.k1carr = ha.tau2carr / ha.tau1carr;
+  ha.k2carr = p->int_time / ha.tau1carr;
   ha.if_nsamples = ctx->if_nsamples;
   ha.n_epochs = n_epochs;
   ha.splits = splits;
   ha.code_index_scale_is_one = 1;
+  ha.timing = std::getenv("GC_DEVLOOP_TIMING") ? std::atoi(std::getenv("GC_DEVLOOP_TIMING")) : 0;  // 1: host + in-kernel phase clocks, 2: host only
   gcorr::DevLoopArgs* d_args = nullptr;
   const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
   hipError_t e = hipMalloc((void**)&ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
@@ -522,8 +527,15 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   const unsigned int grid = xcd_local ? (unsigned int)(((nch + 7) / 8) * 8 * splits) : (unsigned int)(nch * splits);
   rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane, lane_waves);
   if (rc == GC_OK) {
+    const auto t_l = std::chrono::steady_clock::now();
     e = hipStreamSynchronize(ctx->stream);
+    const auto t_k = std::chrono::steady_clock::now();
     if (e == hipSuccess) e = hipMemcpy(out, ha.records, rec_bytes, hipMemcpyDeviceToHost);
+    if (ha.timing)
+      std::fprintf(stderr, "devloop: launch + kernel %.3f ms (%.2f us per epoch), records to host %.3f ms\n",
+                   std::chrono::duration<double, std::milli>(t_k - t_l).count(),
+                   std::chrono::duration<double, std::micro>(t_k - t_l).count() / n_epochs,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k).count());
     if (e == hipSuccess) e = hipMemcpy(hc.data(), ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
       gc_set_error("gc_track_device: %s", hipGetErrorString(e));
@@ -537,6 +549,9 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   bool timeout = false;
   for (int c = 0; c < nch; ++c) {
     timeout |= hc[c].status == 3;
+    if (ha.timing == 1 && hc[c].epochs_done > 0)
+      std::fprintf(stderr, "devloop ch %d: correlate %.2f us, wait partials %.2f us, close+publish %.2f us per epoch (closer)\n", c,
+                   hc[c].pad[0] / hc[c].epochs_done * 0.01, hc[c].pad[1] / hc[c].epochs_done * 0.01, hc[c].pad[2] / hc[c].epochs_done * 0.01);
     if (hc[c].status == 2 && first_aborted == nch) first_aborted = c;
   }
   if (timeout) {
