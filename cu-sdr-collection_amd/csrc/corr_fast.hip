@@ -167,46 +167,23 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   if (wave_items && wq >= p.nblocks) return;
 
   const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
-  gc_block dl_next;  // DEVLOOP closer: the descriptor it prepared for the next epoch
+  gc_block dl_next;  // DEVLOOP: the descriptor this member computed for the next epoch
   (void)dl_next;
-  DevLoopChan dl_st;  // DEVLOOP closer: the channel's loop state, in registers across the epochs
-  if constexpr (DEVLOOP) {
-    if (split == 0) dl_st = p.devloop->chan[min(wq, (long long)p.nblocks - 1)];
-  }
+  DevLoopChan dl_st;  // DEVLOOP: the channel's loop state, in registers across the epochs (every member keeps its own copy)
+  if constexpr (DEVLOOP) dl_st = p.devloop->chan[min(wq, (long long)p.nblocks - 1)];
   (void)dl_st;
   for (int bi = (WIDE != 0 && !wave_items) ? wave : 0; bi < nloop; bi += (WIDE != 0 && !wave_items) ? 4 : 1) {
   const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
   gc_block blk;
   if constexpr (DEVLOOP) {
-    if (split == 0 && bi > 0) {
-      blk = dl_next;  // the closer made this descriptor itself
+    // every member closes the loop itself (all-gather of the partial sums, see below), so from the second epoch on the
+    // descriptor is the one it computed; the first one comes from the host
+    if (bi > 0) {
+      blk = dl_next;
     } else {
-      // the ten descriptor messages, one per lane, polled until every one carries this epoch's tag (bounded: a lost
-      // team member must not hang the device)
-      const msg_t* dm = p.devloop->desc_msg + lb * kDescWords;
-      msg_t m = {0u, 0u, 0u, 0u};
-      unsigned int spins = 0;
-      while (true) {
-        if (lane < kDescWords) m = msg_load(dm + lane, p.devloop->reserved);
-        const bool ok = lane >= kDescWords || m.z == (unsigned int)bi + 1u;
-        if (__all(ok)) break;
-        if (++spins > (1u << 22)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (spins > (1u << 22)) {
-        if (lane == 0) p.devloop->chan[lb].status = 3;
-        break;
-      }
-      union {
-        gc_block b;
-        unsigned long long q[sizeof(gc_block) / 8];
-      } u;
-#pragma unroll
-      for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i)
-        u.q[i] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)m.y, i) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)m.x, i);
-      if (__builtin_amdgcn_readlane((int)m.x, kDescWords - 1) != 0) break;  // status word: record exhausted
-      blk = u.b;
+      if (dl_st.status != 0) break;  // record exhausted before the first block (tracking.m:241-245)
+      blk = dl_st.blk;
     }
   } else {
     blk = CL ? load_block(p, lb) : p.blocks[lb];
@@ -500,71 +477,58 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
       tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(wc * acci[ar][x] - ws * accr[ar][x]);
     }
   if constexpr (DEVLOOP) {
+    // All-gather: every member posts its six partial sums as two messages {f, f, f, tag} into this epoch's half of the
+    // channel's message array (two halves alternate: a member can be at most one epoch ahead of the slowest reader), polls
+    // the whole team's messages — lane 32h + k takes message h of member k — adds them in double in a fixed order (DPP),
+    // and closes the loop itself: identical inputs, identical instructions, identical next descriptor in every member, so
+    // there is ONE message hop per epoch and no descriptor broadcast.  Member 0 alone writes records and host-visible state.
     const DevLoopArgs* dl = p.devloop;
-    msg_t* pm = dl->part_msg + (lb * dl->splits) * 2;
     const unsigned int tag = (unsigned int)bi + 1u;
-    if (split != 0) {
-      if (lane == 63) {
-        msg_store(pm + split * 2, msg_t{__float_as_uint(tot[0]), __float_as_uint(tot[1]), __float_as_uint(tot[2]), tag}, dl->reserved);
-        msg_store(pm + split * 2 + 1, msg_t{__float_as_uint(tot[3]), __float_as_uint(tot[4]), __float_as_uint(tot[5]), tag}, dl->reserved);
-      }
-    } else {
-      // the closer: own sums from lane 63, the others' messages polled one per lane, everything added in double
-      // through LDS (splits <= 32: at most 62 messages)
-      const unsigned long long dl_t1 = __builtin_amdgcn_s_memrealtime();
-      // what does not need the sums, while the other members' messages are still on their way
-      const DevLoopPre dl_pre = devloop_pre(dl, dl_st, blk, 1.0);
-      // message 2k + h of member k + 1 holds components 3h .. 3h + 2; lane 32h + k polls it, so that each half of the wave
-      // reduces one triple with DPP row shifts (no LDS round trips, no barrier): splits - 1 <= 32
-      const int mk = lane & 31, mh = lane >> 5;
-      const bool mine = mk < dl->splits - 1;
-      msg_t m = {0u, 0u, 0u, 0u};
-      unsigned int spins = 0;
-      while (true) {
-        if (mine) m = msg_load(pm + 2 + 2 * mk + mh, dl->reserved);
-        const bool ok = !mine || m.w == tag;
-        if (__all(ok)) break;
-        if (++spins > (1u << 22)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (spins > (1u << 22)) {
-        if (lane == 0) dl->chan[lb].status = 3;
-        // tell the team to stop: a descriptor with a non-zero status word
-        if (lane < kDescWords) msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{3u, 0u, tag + 1u, 0u}, dl->reserved);
-        break;
-      }
-      const unsigned long long dl_t2 = __builtin_amdgcn_s_memrealtime();
-      double part[3] = {mine ? (double)__uint_as_float(m.x) : 0.0, mine ? (double)__uint_as_float(m.y) : 0.0,
-                        mine ? (double)__uint_as_float(m.z) : 0.0};
+    msg_t* pm = dl->part_msg + ((lb * 2 + (bi & 1)) * dl->splits) * 2;
+    if (lane == 63) {
+      msg_store(pm + split * 2, msg_t{__float_as_uint(tot[0]), __float_as_uint(tot[1]), __float_as_uint(tot[2]), tag}, dl->reserved);
+      msg_store(pm + split * 2 + 1, msg_t{__float_as_uint(tot[3]), __float_as_uint(tot[4]), __float_as_uint(tot[5]), tag}, dl->reserved);
+    }
+    const unsigned long long dl_t1 = __builtin_amdgcn_s_memrealtime();
+    // what does not need the sums, while the messages are on their way
+    const DevLoopPre dl_pre = devloop_pre(dl, dl_st, blk, 1.0);
+    const int mk = lane & 31, mh = lane >> 5;
+    const bool mine = mk < dl->splits;  // splits <= 32
+    msg_t m = {0u, 0u, 0u, 0u};
+    unsigned int spins = 0;
+    while (true) {
+      if (mine) m = msg_load(pm + 2 * mk + mh, dl->reserved);
+      const bool ok = !mine || m.w == tag;
+      if (__all(ok)) break;
+      if (++spins > (1u << 22)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (spins > (1u << 22)) {  // a lost team member must not hang the device: everybody gives up after the same bound
+      if (lane == 0) dl->chan[lb].status = 3;
+      break;
+    }
+    const unsigned long long dl_t2 = __builtin_amdgcn_s_memrealtime();
+    double part[3] = {mine ? (double)__uint_as_float(m.x) : 0.0, mine ? (double)__uint_as_float(m.y) : 0.0,
+                      mine ? (double)__uint_as_float(m.z) : 0.0};
 #pragma unroll
-      for (int v = 0; v < 3; ++v) part[v] = half_sum_f64(part[v]);  // lanes 31 / 63: the sums of the two halves
-      double sums[6];
+    for (int v = 0; v < 3; ++v) part[v] = half_sum_f64(part[v]);  // lanes 31 / 63: the sums of the two halves
+    double sums[6];
 #pragma unroll
-      for (int v = 0; v < 6; ++v) sums[v] = rl_f64(part[v % 3], v < 3 ? 31 : 63) + (double)rl_f(tot[v], 63);
-      dl_next = blk;
-      double dl_rv[GC_TRK_NFIELDS];
-      const int st = devloop_post(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
-      // publish the next descriptor (or the stop word) as ten tagged messages, one store per lane
-      union {
-        gc_block b;
-        unsigned long long q[sizeof(gc_block) / 8];
-      } u;
-      u.b = dl_next;
-      unsigned long long word = (unsigned long long)(st == 2 ? 2 : 0);
-#pragma unroll
-      for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) word = (lane == i) ? u.q[i] : word;
-      if (lane < kDescWords && bi + 1 < nloop)
-        msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u}, dl->reserved);
-      devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, 1, lane);  // records and state, after the descriptor is on its way
-      if (dl->timing == 1 && lane == 0) {  // phase clocks (100 MHz): correlate | wait for partials | close + publish
+    for (int v = 0; v < 6; ++v) sums[v] = rl_f64(part[v % 3], v < 3 ? 31 : 63);
+    dl_next = blk;
+    double dl_rv[GC_TRK_NFIELDS];
+    const int st = devloop_post(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
+    if (split == 0) {
+      devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, 1, lane);
+      if (dl->timing == 1 && lane == 0) {  // phase clocks (100 MHz): correlate | wait for partials | close
         const unsigned long long dl_t3 = __builtin_amdgcn_s_memrealtime();
         DevLoopChan* cc = dl->chan + lb;
         cc->pad[0] += (double)(dl_t1 - dl_t0);
         cc->pad[1] += (double)(dl_t2 - dl_t1);
         cc->pad[2] += (double)(dl_t3 - dl_t2);
       }
-      if (st != 0) break;
     }
+    if (st != 0) break;
   } else if (CL) {
     // lane v takes total v (broadcast from lane 63) and stores its 16-byte tagged record
     TaggedSlot* ts = p.tagged + (lb * p.splits + split) * GC_OUT_STRIDE;

@@ -449,7 +449,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (use_fast) {
     // team size: just under one lane-chunk per lane and member — the epoch is a latency chain
     const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
-    splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 48)}));
+    splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 32)}));
     if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
     msgs_per_member = 2;
   } else {
@@ -477,11 +477,13 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   ha.n_epochs = n_epochs;
   ha.splits = splits;
   ha.code_index_scale_is_one = 1;
+  if (const char* e = std::getenv("GC_DEVLOOP_SCOPE")) ha.reserved = std::atoi(e);  // message scope (devloop.h): 0 system (default), 2 agent
   ha.timing = std::getenv("GC_DEVLOOP_TIMING") ? std::atoi(std::getenv("GC_DEVLOOP_TIMING")) : 0;  // 1: host + in-kernel phase clocks, 2: host only
   gcorr::DevLoopArgs* d_args = nullptr;
   const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
   hipError_t e = hipMalloc((void**)&ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
-  const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * msgs_per_member, desc_bytes = sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords;
+  const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * msgs_per_member * (use_fast ? 2 : 1),  // fast kernel: two alternating halves
+                desc_bytes = sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords;
   if (e == hipSuccess) e = hipMalloc((void**)&ha.part_msg, part_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&ha.desc_msg, desc_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&ha.records, rec_bytes);
