@@ -3,13 +3,14 @@
 // "team": one per split) exchange two kinds of self-validating 16-byte messages per epoch — {payload, epoch tag}
 // written by ONE store instruction and read by ONE load instruction, both at system scope (sc0 sc1: no cache on the
 // way), so no flag, counter, atomic or fence is needed:
-//   every member stores its six partial sums as two messages {f, f, f, tag};
-//   member 0 (the closer) polls the other members' messages, one per lane, adds everything in double, closes the loop
-//   (discriminators, loop filters, next block geometry — the same float64 statements as gc_track's host loop,
-//   tracking.m:302-335), writes the epoch's records and publishes the next descriptor as ten messages {word, tag};
-//   the other members poll those, one per lane.
-// Two one-way propagation delays per epoch instead of five dependent round trips.  Channels never wait for each other.
-// All team workgroups must be co-resident: the launch is cooperative.  Polls are bounded.
+//   fast kernel (corr_fast.hip): all-gather - every member stores its six partial sums as two messages {f, f, f, tag}, polls the
+//   whole team's messages (one per lane), adds them in double in a fixed order and closes the loop ITSELF (discriminators,
+//   loop filters, next block geometry - the same float64 statements as gc_track's host loop, tracking.m:302-335); identical
+//   inputs give identical descriptors, so nothing is broadcast: ONE one-way propagation delay per epoch.  Member 0 writes
+//   the epoch's records.
+//   lane kernel (corr_lane.hip): gather and broadcast - member 0 (the closer) polls the other members' messages, closes the
+//   loop, writes the records and publishes the next descriptor as ten messages {word, tag} that the other members poll.
+// Channels never wait for each other.  All team workgroups must be co-resident: the launch is cooperative.  Polls are bounded.
 #pragma once
 #include "gc_internal.h"
 
