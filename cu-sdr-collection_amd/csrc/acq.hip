@@ -109,20 +109,54 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 // otherwise cost a software division each
 __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
 
-// One radix-R Stockham stage of the tile in LDS: the same arithmetic, in the same order, for every R (so results do not
-// depend on the plan), with R a compile-time constant: the R inputs and W_R^m live in registers.
+// Radix-R DFT of (already twiddled) inputs, sign = +1: exp(-i..) (forward), -1: inverse.  Radix 2 and 4 need no
+// multiplications, 3 and 5 the classical real-constant forms (the generic R x R complex product they replace was the
+// passes' VALU bound).
+__device__ __forceinline__ float2 mul_mi(float2 a, float s) { return make_float2(s * a.y, -s * a.x); }  // a * (-i*s)
+template <int R>
+__device__ __forceinline__ void butterfly(const float2 (&v)[R], float s, float2 (&o)[R]) {
+  if constexpr (R == 2) {
+    o[0] = make_float2(v[0].x + v[1].x, v[0].y + v[1].y);
+    o[1] = make_float2(v[0].x - v[1].x, v[0].y - v[1].y);
+  } else if constexpr (R == 4) {
+    const float2 t0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
+    const float2 t2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
+    const float2 t3 = mul_mi(make_float2(v[1].x - v[3].x, v[1].y - v[3].y), s);
+    o[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+    o[1] = make_float2(t1.x + t3.x, t1.y + t3.y);
+    o[2] = make_float2(t0.x - t2.x, t0.y - t2.y);
+    o[3] = make_float2(t1.x - t3.x, t1.y - t3.y);
+  } else if constexpr (R == 3) {
+    const float2 t = make_float2(v[1].x + v[2].x, v[1].y + v[2].y);
+    const float2 d = make_float2(v[1].x - v[2].x, v[1].y - v[2].y);
+    const float2 m = make_float2(fmaf(-0.5f, t.x, v[0].x), fmaf(-0.5f, t.y, v[0].y));
+    const float2 n = mul_mi(make_float2(0.8660254037844386f * d.x, 0.8660254037844386f * d.y), s);
+    o[0] = make_float2(v[0].x + t.x, v[0].y + t.y);
+    o[1] = make_float2(m.x + n.x, m.y + n.y);
+    o[2] = make_float2(m.x - n.x, m.y - n.y);
+  } else {
+    static_assert(R == 5, "radices 2, 3, 4, 5");
+    constexpr float c1 = 0.30901699437494745f, c2 = -0.8090169943749473f, s1 = 0.9510565162951535f, s2 = 0.5877852522924731f;
+    const float2 a1 = make_float2(v[1].x + v[4].x, v[1].y + v[4].y), a2 = make_float2(v[2].x + v[3].x, v[2].y + v[3].y);
+    const float2 b1 = make_float2(v[1].x - v[4].x, v[1].y - v[4].y), b2 = make_float2(v[2].x - v[3].x, v[2].y - v[3].y);
+    const float2 m1 = make_float2(fmaf(c2, a2.x, fmaf(c1, a1.x, v[0].x)), fmaf(c2, a2.y, fmaf(c1, a1.y, v[0].y)));
+    const float2 m2 = make_float2(fmaf(c1, a2.x, fmaf(c2, a1.x, v[0].x)), fmaf(c1, a2.y, fmaf(c2, a1.y, v[0].y)));
+    const float2 n1 = mul_mi(make_float2(fmaf(s2, b2.x, s1 * b1.x), fmaf(s2, b2.y, s1 * b1.y)), s);
+    const float2 n2 = mul_mi(make_float2(fmaf(-s1, b2.x, s2 * b1.x), fmaf(-s1, b2.y, s2 * b1.y)), s);
+    o[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+    o[1] = make_float2(m1.x + n1.x, m1.y + n1.y);
+    o[4] = make_float2(m1.x - n1.x, m1.y - n1.y);
+    o[2] = make_float2(m2.x + n2.x, m2.y + n2.y);
+    o[3] = make_float2(m2.x - n2.x, m2.y - n2.y);
+  }
+}
+
+// One radix-R Stockham stage of the tile in LDS, R a compile-time constant: the R inputs live in registers.
 template <int R>
 __device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, const float2* src, float2* dst, float2* twl,
                                           int L, int C, int ns, int tid, float sign) {
   const int lr = L / R;
   const int tws = n / (ns * R);  // table stride for W_{ns*R}
-  const int wr = n / R;          // W_R = tw[wr]
-  float2 wb[R];
-#pragma unroll
-  for (int m = 0; m < R; ++m) {
-    wb[m] = tw[m * wr];
-    wb[m].y *= sign;
-  }
   // this stage's twiddles W_{ns*R}^{k*q} (k < ns, 0 < q < R) from the global table into LDS once per tile: the butterflies'
   // own lookups were scattered 8-byte global loads, the dominant cost of the pass
   if (ns > 1) {
@@ -137,27 +171,21 @@ __device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, 
   const float inv_lr = 1.0f / (float)lr, inv_ns = 1.0f / (float)ns;
   for (int idx = tid; idx < lr * C; idx += kFftThreads) {
     const int c = fdiv_small(idx, inv_lr);
-    const int j = idx - c * lr;
-    const int k = j - fdiv_small(j, inv_ns) * ns;
+    const int j = idx - __mul24(c, lr);
+    const int k = j - __mul24(fdiv_small(j, inv_ns), ns);
+    const int cL = __mul24(c, L);
     float2 vq[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-      float2 x = src[c * L + j + q * lr];
+      float2 x = src[cL + j + q * lr];
       if (k != 0 && q != 0) x = cmul(x, twl[k * (R - 1) + q - 1]);
       vq[q] = x;
     }
-    const int obase = c * L + (j - k) * R + k;
+    const int obase = cL + (j - k) * R + k;
+    float2 oq[R];
+    butterfly<R>(vq, sign, oq);
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-      float2 acc = vq[0];
-#pragma unroll
-      for (int pp = 1; pp < R; ++pp) {
-        const float2 t = cmul(vq[pp], wb[(pp * q) % R]);
-        acc.x += t.x;
-        acc.y += t.y;
-      }
-      dst[obase + q * ns] = acc;
-    }
+    for (int q = 0; q < R; ++q) dst[obase + q * ns] = oq[q];
   }
 }
 
@@ -202,11 +230,11 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       const int v = v0 + c;
       float2 val = make_float2(0.f, 0.f);
       if (v < a.nvec) {
-        const long long pos = (long long)e * a.estride + (long long)v * a.vstride;  // index within transform
+        const int pos = __mul24(e, a.estride) + __mul24(v, a.vstride);  // index within transform (< n <= 2^24)
         if (a.pre == PRE_IF_CARRIER) {
           // x[n] = (I + iQ) * exp(-1i * f_b * n*2*pi/fs)  (acquisition.m:169-181), batch = b*nhops + h
           const int b = (int)(tb / a.nhops), h = (int)(tb % a.nhops);
-          const long long s = a.first_sample + (long long)h * a.spc + pos;
+          const long long s = a.first_sample + (long long)h * a.spc + (long long)pos;
           const float xi = (float)a.if_base[2 * s], xq = (float)a.if_base[2 * s + 1];
           const double fb = a.f0 - a.fstep * b;
           const double ph = (fb / a.fs) * (double)pos;
@@ -234,7 +262,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
           }
         }
       }
-      buf0[c * L + e] = val;
+      buf0[__mul24(c, L) + e] = val;
     }
     __syncthreads();
 
@@ -272,10 +300,10 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       }
       const int v = v0 + c;
       if (v >= a.nvec) continue;
-      float2 val = src[c * L + e];
-      const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
+      float2 val = src[__mul24(c, L) + e];
+      const int pos = __mul24(e, a.estride) + __mul24(v, a.vstride);
       if (a.post == POST_TWIDDLE) {
-        float2 w = a.tw[v * e];  // v < n2, e < n1: v*e < n
+        float2 w = a.tw[__mul24(v, e)];  // v < n2, e < n1: v*e < n
         w.y *= sign;
         val = cmul(val, w);
       }
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       }
       const int v = v0 + c;
       if (v >= a.nvec) continue;
-      const long long pos = (long long)e * a.estride + (long long)v * a.vstride;
+      const int pos = __mul24(e, a.estride) + __mul24(v, a.vstride);
       if (HG > 1) {
         a.acc_part[((long long)hg * a.acc_bins + batch) * a.n + pos] = accv[slot];
       } else {
@@ -445,7 +473,11 @@ void fill_sub(PassArgs& a, const SubPlan& sp) {
 }
 
 // columns per tile: keep 2*L*C*8 bytes <= 64 KiB and L*C <= 8*256 (POST_ABS_ACC register slots)
-int choose_cols(int L) { return std::max(1, std::min(16, 2048 / L)); }
+int choose_cols(int L) {
+  int budget = 2048;
+  if (const char* e = std::getenv("GC_ACQ_TILE")) budget = std::max(256, std::atoi(e));  // tuning: elements per tile
+  return std::max(1, std::min(16, budget / L));
+}
 
 struct AcqScratch {
   int n = 0;
