@@ -295,3 +295,34 @@ def test_big_periodic_replay_lists_take_the_four_wave_kernels_and_match_the_orac
         assert engine.last_kernel() == 1
         scale = 18000 * 2 * 20.0
         assert np.abs(got[sub] - small).max() < 2e-7 * scale
+
+
+def test_big_periodic_replay_with_eight_sample_chunks(engine, monkeypatch):
+    """The same for a B1I-rate replica (2.046 Mcps at 18 Msps: 8.8 samples per chip -> 8-sample lane-chunks): four-wave
+    kernels with float tables and with int8-pair tables."""
+    rng = np.random.default_rng(78)
+    nsamp = 2_000_000
+    iq = rng.integers(-40, 41, size=2 * nsamp, dtype=np.int8)
+    engine.load_if(iq, fs=18e6)
+    tables = [O.pad_code(rng.choice(np.array([-1, 1], dtype=np.int8), size=2046)) for _ in range(2)]
+    for k, t in enumerate(tables):
+        engine.set_channel(k, [t])
+    _, cus = engine.device_info()
+    nb = 64 * 2 * cus + 2 * 11
+    for env, want in (({}, 3), ({"GC_NO_TABF": "1"}, 2)):
+        descs = _random_descs(rng, nb, nsamp, 2, fc=2.046e6, L=2046.0)
+        for i, d in enumerate(descs):
+            d["channel"] = i % 2
+        b = _blocks(engine, descs)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        engine.replay_prepare(b)
+        engine.replay_launch()
+        got = engine.replay_fetch()[:, 0]
+        assert engine.last_kernel() == want
+        for k in env:
+            monkeypatch.delenv(k)
+        for i in list(range(0, 4)) + [int(x) for x in rng.integers(0, nb, 30)] + [nb - 1]:
+            d = descs[i]
+            ref = _oracle(iq, d, tables[d["channel"]], code_length=2046.0)
+            assert np.abs(got[i] - ref).max() < TOL * _scale(iq, d), (env, i)
