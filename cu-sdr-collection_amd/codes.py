@@ -98,6 +98,13 @@ def generateE1Ccode(PRN: int) -> np.ndarray:
     return _boc11(_e1_primary("E1c", PRN))
 
 
+def generateE1C_BOC61(PRN: int) -> np.ndarray:
+    """E1-C pilot primary code with the BOC(6,1) subcarrier of CBOC(6,1,1/11): 49104 entries (12 per chip), chip x
+    [+1, -1] x 6 - same subcarrier phase convention as the BOC(1,1) table above (generateE1Bcode.m:59-65)."""
+    c = (1 - 2 * _e1_primary("E1c", PRN).astype(np.int8)).astype(np.int8)   # logic 1 -> -1, as _boc11
+    return (c[:, None] * np.tile(np.array([1, -1], dtype=np.int8), 6)[None, :]).reshape(-1)
+
+
 # ---------------------------------------------------------------------------------------------
 # GPS L5 I5 / Q5 (GPS/GPS_L5C/include/generateL5Icode.m, generateL5Qcode.m)
 # ---------------------------------------------------------------------------------------------

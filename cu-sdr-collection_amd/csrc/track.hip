@@ -74,8 +74,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     for (int a = 1; a < ctx->ch[ci].arms; ++a)
       if (ctx->ch[ci].mult[a] != ctx->ch[ci].mult[0]) any_mixed = true;  // B1C wide-band: exact per-sample kernel
   }
-  if (p->pilot_combine == 4 && max_arms < 3) {
-    gc_set_error("gc_track: pilot_combine 4 needs three arms {data, pilot BOC(1,1), pilot BOC(6,1)}");
+  if ((p->pilot_combine == 4 || p->pilot_combine == 5) && max_arms < 3) {
+    gc_set_error("gc_track: pilot_combine 4 / 5 need three arms {data, pilot BOC(1,1), pilot BOC(6,1)}");
     return GC_E_INVALID;
   }
   if (p->pilot_combine != 0 && max_arms < 2) {
@@ -270,6 +270,15 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
             const double i11 = sums[6 + 2 * x], q11 = sums[7 + 2 * x], i61 = sums[12 + 2 * x], q61 = sums[13 + 2 * x];
             pilot6[2 * x] = a61 * i61 + a11 * q11;
             pilot6[2 * x + 1] = a61 * q61 - a11 * i11;
+          }
+        } else if (p->pilot_combine == 5) {
+          // Galileo E1-C CBOC(6,1,1/11): pilot subcarrier sqrt(10/11) sc_BOC(1,1) - sqrt(1/11) sc_BOC(6,1), both in phase
+          // (Galileo OS SIS ICD 2.3.3; BASELINE config 3 - the reference itself tracks E1 with BOC(1,1) only)
+          const double a11 = std::sqrt(10.0 / 11.0), a61 = -std::sqrt(1.0 / 11.0);
+          for (int x = 0; x < 3; ++x) {
+            const double i11 = sums[6 + 2 * x], q11 = sums[7 + 2 * x], i61 = sums[12 + 2 * x], q61 = sums[13 + 2 * x];
+            pilot6[2 * x] = a11 * i11 + a61 * i61;
+            pilot6[2 * x + 1] = a11 * q11 + a61 * q61;
           }
         }
         const double pi_e = pilot6[0], pq_e = pilot6[1], pi_p = pilot6[2], pq_p = pilot6[3], pi_l = pilot6[4], pq_l = pilot6[5];

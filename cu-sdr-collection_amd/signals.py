@@ -37,6 +37,13 @@ def calcLoopCoefCarr(settings, variant: str = "a"):
     return wn ** 3 * t ** 2, a3 * wn ** 2 * t, b3 * wn
 
 
+def _e1_cboc_tables(prn, settings):
+    # arms {E1-B BOC(1,1), E1-C BOC(1,1), E1-C BOC(6,1)}: the pilot's two subcarrier components are correlated apart
+    # (int8 tables, ramp multipliers 1 and 6) and folded with sqrt(10/11), -sqrt(1/11) on the host (pilot_combine 5)
+    return [codes.padded_table(codes.generateE1Bcode(prn)), codes.padded_table(codes.generateE1Ccode(prn)),
+            codes.padded_table(codes.generateE1C_BOC61(prn))]
+
+
 def _l1ca_tables(prn, settings):
     return [codes.padded_table(codes.generateCAcode(prn))]                   # GPS_L1CA tracking.m:156-158
 
@@ -145,6 +152,9 @@ SIGNALS = {
     "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False),
     # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
     "GAL_E1C": SignalSpec("GAL_E1C", _e1_tables, 2.0, L.GC_PLL_3_STATE, "a", 2, False),
+    # BASELINE config 3: the E1-C pilot tracked with its CBOC(6,1,1/11) subcarrier (needs pilotTRKflag = 1 and a narrow
+    # correlator: dllCorrelatorSpacing * 12 < 1 table entry); an extension, the reference's package stops at BOC(1,1)
+    "GAL_E1C_CBOC": SignalSpec("GAL_E1C_CBOC", _e1_cboc_tables, 2.0, L.GC_PLL_3_STATE, "a", 5, False, arm_mult=(1.0, 1.0, 6.0)),
     # GLONASS: the record must be loaded with layout GC_QI (GLO_GL1 tracking.m:227 swaps the components);
     # channel.PRN carries the frequency number K (GLO_GL1 preRun.m:66), the FDMA offset lives in acquiredFreq
     "GLO_GL1": SignalSpec("GLO_GL1", _glo_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False),

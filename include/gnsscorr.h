@@ -159,7 +159,10 @@ typedef struct gc_track_params {
                                 3 = pilot in quadrature, atan(-I/Q) (BDS/B1C NB_tracking.m:340-342);
                                 4 = three arms {data, pilot BOC(1,1), pilot BOC(6,1)} folded into one pilot
                                     p = -sqrt(4/33)*p61 + sqrt(29/33)*(Q11, -I11) (WB_tracking.m:364-369),
-                                    which is also what the Pilot_* records then hold (:420-425) */
+                                    which is also what the Pilot_* records then hold (:420-425);
+                                5 = the same three arms folded IN PHASE for Galileo E1-C CBOC(6,1,1/11):
+                                    p = sqrt(10/11)*p11 - sqrt(1/11)*p61, then as 2 (BASELINE config 3; an extension:
+                                    the reference's GAL_E1C package uses the BOC(1,1) replica only) */
   double pf1, pf2, pf3;      /* 3-state filter coefficients (calcLoopCoefCarr.m), if used */
   int64_t skip_samples;      /* settings.skipNumberOfBytes, in samples */
   int32_t n_epochs;          /* codePeriods = settings.msToProcess (tracking.m:90) */

@@ -590,6 +590,12 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
                     for x in range(3):
                         pil += [a61 * p61[2 * x] + a11 * p11[2 * x + 1], a61 * p61[2 * x + 1] - a11 * p11[2 * x]]
                     pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = pil
+                elif spec.pilot_combine == 5:
+                    # Galileo E1-C CBOC(6,1,1/11) pilot (OS SIS ICD 2.3.3): sqrt(10/11) BOC(1,1) - sqrt(1/11) BOC(6,1), in phase;
+                    # not in the reference (GAL_E1C tracks with BOC(1,1) only): BASELINE config 3, parity against this oracle
+                    a11, a61 = math.sqrt(10 / 11), -math.sqrt(1 / 11)
+                    p11, p61 = [float(v) for v in sums[1]], [float(v) for v in sums[2]]
+                    pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = [a11 * p11[v] + a61 * p61[v] for v in range(6)]
                 else:
                     pi_e, pq_e, pi_p, pq_p, pi_l, pq_l = (float(v) for v in sums[1])
                 with np.errstate(divide="ignore", invalid="ignore"):

@@ -534,3 +534,69 @@ def test_device_side_loop_closure_two_arm_lane_kernel(engine):
             assert np.max(np.abs(getattr(dev[k], f) - getattr(ref[k], f))) < 1e-5 * 2.0 * 72000 * 28.0, (k, f)
         assert np.max(np.abs(dev[k].carrFreq - ref[k].carrFreq)) < 1e-3
         assert np.max(np.abs(dev[k].remCodePhase - ref[k].remCodePhase)) < 1e-7
+
+
+def test_galileo_e1c_cboc_pilot_tracking_matches_oracle(engine):
+    """BASELINE config 3: the E1-C pilot tracked with its CBOC(6,1,1/11) subcarrier in the replica — arms {E1-B BOC(1,1),
+    E1-C BOC(1,1), E1-C BOC(6,1) read through ceil(6 t)}, the two pilot components folded sqrt(10/11), -sqrt(1/11) in phase
+    (pilot_combine 5), otherwise GAL/GAL_E1C/include/tracking.m.  The reference implements BOC(1,1) only, so parity here is
+    against the oracle's own statement of the fold."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E1C
+    S = initSettings_GAL_E1C()
+    S.pilotTRKflag = 1
+    S.dllCorrelatorSpacing = 0.05   # narrow correlator: spacing * 12 table entries per chip must stay below one entry
+    fs = S.samplingFreq
+    S.msToProcess = 60  # 15 epochs of 4 ms
+    S.numberOfChannels = 2
+    rng = np.random.default_rng(18)
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 72000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=48.0) for p in (7, 23)]
+    iq = P.synth.generate_if(sats, int(0.070 * fs), fs, S.IF, P.codes.generateE1Bcode, 2 * S.codeFreqBasis, 8184, seed=22,
+                             bit_periods=1, pilot_fn=P.codes.generateE1Ccode)
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 2.0, status="T",
+                          codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in sats]
+    engine.load_if(iq, fs=fs)
+    tr, _ = P.tracking(engine, ch, S, signal="GAL_E1C_CBOC")
+
+    def tables(prn):
+        c11 = O.generate_e1_code(prn, "C")                      # chip x [+1, -1]
+        c61 = (c11[0::2][:, None] * np.tile(np.array([1, -1], dtype=np.int8), 6)[None, :]).reshape(-1)
+        assert np.array_equal(c61, P.codes.generateE1C_BOC61(prn))
+        return [O.pad_code(O.generate_e1_code(prn, "B")), O.pad_code(c11), O.pad_code(c61)]
+    spec = SimpleNamespace(tables=tables, r=2.0, pll="3state", coef_variant="a", pilot_combine=5, code_freq_from_channel=False,
+                           arm_mult=[1.0, 1.0, 6.0])
+    ref = O.tracking_generic(iq, ch, S, spec)
+    for k in range(2):
+        assert tr[k].status == "T" and ref[k].status == "T"
+        assert np.array_equal(tr[k].absoluteSample, ref[k].absoluteSample)
+        scale = 2.0 * 72000 * 28.0
+        for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L", "Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P",
+                  "Pilot_I_L", "Pilot_Q_L"):
+            assert np.max(np.abs(getattr(tr[k], f) - getattr(ref[k], f))) < 1e-5 * scale, f
+        assert np.max(np.abs(tr[k].carrFreq - ref[k].carrFreq)) < 1e-3
+        assert np.max(np.abs(tr[k].remCodePhase - ref[k].remCodePhase)) < 1e-7
+        # the synthetic pilot is BOC(1,1): the CBOC replica sees sqrt(10/11) of it (the BOC(6,1) component is orthogonal)
+        pm = np.hypot(tr[k].Pilot_I_P, tr[k].Pilot_Q_P)[4:]
+        dm = np.hypot(tr[k].I_P, tr[k].Q_P)[4:]
+        assert 0.85 < np.mean(pm) / np.mean(dm) < 1.05
+
+
+def test_config4_l5_and_b2a_at_50_msps(engine):
+    """BASELINE config 4: GPS L5 + BDS B2a, 10.23-Mcps codes, data + pilot arms, at a 50 Msps IF (the reference default is
+    18 Msps; blocks of 50 000 samples, 0.2 table entries per sample: the lane kernel with more than four samples per chip)."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B2a, initSettings_GPS_L5C
+    S = initSettings_GPS_L5C()
+    S.pilotTRKflag = 1
+    S.samplingFreq = 50e6
+    tr = _ten23_case(engine, S, "GPS_L5C", P.codes.generateL5Icode, P.codes.generateL5Qcode,
+                     lambda prn: [O.pad_code(O.generate_l5_code(prn, "I")), O.pad_code(O.generate_l5_code(prn, "Q"))],
+                     "a", 1150.0, (3, 27), 51)
+    assert np.all(np.abs(np.diff(tr[0].absoluteSample) - 50000) <= 1)
+    S = initSettings_BDS_B2a()
+    S.pilotTRKflag = 1
+    S.samplingFreq = 50e6
+    _ten23_case(engine, S, "BDS_B2a", P.codes.generateB2aDataCode, P.codes.generateB2aPilotCode,
+                lambda prn: [O.pad_code(O.generate_b2a_code(prn, "data")), O.pad_code(O.generate_b2a_code(prn, "pilot"))],
+                "a", 1150.0, (20, 44), 53)
