@@ -46,7 +46,8 @@ constexpr int kGRP = GC_LANE_GRP;  // samples per lane and group: the loads of t
 // block loop becomes the channel's epoch loop; sums are combined in LDS per workgroup, between workgroups by tagged
 // messages, and wave 0 of the channel's first workgroup closes the loop.
 template <int ARMS, int MODE, bool CL, int TAB, bool DEVLOOP = false>
-__global__ __launch_bounds__(kLW * 64) void corr_epl_lane_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
+__global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at most 8 waves per member (256 VGPRs, no spills)
+ void corr_epl_lane_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int AP = ArmPitch<ARMS>::v;  // values per staged entry
   constexpr bool kF16 = (TAB == 2);

@@ -466,7 +466,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     // member workgroups per channel: about four 64-sample steps per lane; the closer polls (members - 1) * 6 * arms <= 64 messages
     const int nsamp = hc[0].blk.blksize;
     lane_waves = 8;  // measured best for both the 1-ms and the 4-ms packages (scripts/devloop_lane_sweep.py)
-    if (const char* e = std::getenv("GC_DEVLOOP_WAVES")) lane_waves = std::max(1, std::min(gcorr::kLaneWaves, std::atoi(e)));
+    if (const char* e = std::getenv("GC_DEVLOOP_WAVES")) lane_waves = std::max(1, std::min(8, std::atoi(e)));  // the device-loop instantiations are bounded to 8 waves
     splits = std::max(1, std::min({max_arms == 1 ? 8 : 6, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch)}));
     if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_arms == 1 ? 8 : 6, std::atoi(e)));
     msgs_per_member = 6 * max_arms;
