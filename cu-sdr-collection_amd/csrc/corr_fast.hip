@@ -517,7 +517,7 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     for (int v = 0; v < 6; ++v) sums[v] = rl_f64(part[v % 3], v < 3 ? 31 : 63);
     dl_next = blk;
     double dl_rv[GC_TRK_NFIELDS];
-    const int st = devloop_post(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
+    const int st = devloop_post<1>(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
     if (split == 0) {
       devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, 1, lane);
       if (dl->timing == 1 && lane == 0) {  // phase clocks (100 MHz): correlate | wait for partials | close

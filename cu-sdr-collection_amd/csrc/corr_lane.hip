@@ -491,7 +491,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
             sums[v] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(bits >> 32), v) << 32) |
                                                        (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, v)));
           }
-          st = devloop_close(dl, dl->chan + lb, nxt, lb, bi, sums, arms_here < ARMS ? arms_here : ARMS, R, lane);
+          st = devloop_close<ARMS>(dl, dl->chan + lb, nxt, lb, bi, sums, arms_here < ARMS ? arms_here : ARMS, R, lane);
         }
         if (lane == 0) {
           *sblk = nxt;

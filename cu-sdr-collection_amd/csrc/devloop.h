@@ -103,9 +103,9 @@ __device__ inline DevLoopPre devloop_pre(const DevLoopArgs* __restrict__ dl, con
   return r;
 }
 
-template <class Rec>
-__device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopChan& st, gc_block& b, int e, const double* sums, int arms,
-                                   double R, const DevLoopPre& pre, Rec&& rec) {
+template <int MAXARMS, class Rec>
+__device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopChan& st, gc_block& b, int e, const double (&sums)[6 * MAXARMS],
+                                   int arms, double R, const DevLoopPre& pre, Rec&& rec) {
   // rec(field, value) takes the epoch's record: straight to device memory (lane kernel) or into registers, to be stored by
   // devloop_commit AFTER the next descriptor is on its way (fast kernel)
   const gc_track_params& p = dl->prm;
@@ -120,6 +120,7 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
   double carr_err = atan(q_p / i_p) / (2.0 * kPi);                              // :305
   double code_err = (sqrt(i_e * i_e + q_e * q_e) - sqrt(i_l * i_l + q_l * q_l)) /
                     (sqrt(i_e * i_e + q_e * q_e) + sqrt(i_l * i_l + q_l * q_l));  // :322-323
+  if constexpr (MAXARMS >= 2) {
   if (p.pilot_combine != 0 && arms >= 2) {
     const double pi_e = sums[6], pq_e = sums[7], pi_p = sums[8], pq_p = sums[9], pi_l = sums[10], pq_l = sums[11];
     double carr_err_q;
@@ -154,6 +155,7 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
   } else if (arms >= 2) {
 #pragma unroll
     for (int v = 0; v < 6; ++v) rec(GC_TRK_PILOT_I_E + v, sums[6 + v]);
+  }
   }
   double carr_nco;
   double old_carr_nco = st.old_carr_nco, old_carr_err = st.old_carr_err, d2 = st.d2_carr_err, d1 = st.d_carr_err;
@@ -238,11 +240,12 @@ __device__ inline void devloop_commit(const DevLoopArgs* __restrict__ dl, DevLoo
 
 // All parts back to back on the state held in device memory (lane kernel's closer): state read and written in place, records
 // stored as they are formed.
+template <int MAXARMS>
 __device__ inline int devloop_close(const DevLoopArgs* __restrict__ dl, DevLoopChan* ch, gc_block& b, long long slot, int e,
-                                    const double* sums, int arms, double R, int lane) {
+                                    const double (&sums)[6 * MAXARMS], int arms, double R, int lane) {
   double* o = dl->records + (size_t)slot * GC_TRK_NFIELDS * dl->n_epochs;
   const DevLoopPre pre = devloop_pre(dl, *ch, b, R);
-  return devloop_post(dl, *ch, b, e, sums, arms, R, pre, [&](int f, double v) {
+  return devloop_post<MAXARMS>(dl, *ch, b, e, sums, arms, R, pre, [&](int f, double v) {
     if (lane == 0) o[(size_t)f * dl->n_epochs + e] = v;
   });
 }
