@@ -19,6 +19,11 @@
  *   [trk, epochs, status] = gnsscorr_mex('track', h, params_struct, channels)   % channels: 5 x nch
  *   res  = gnsscorr_mex('acquire_coarse', h, acq_struct, sampledCodes)          % int8 spc x nprn
  *   f    = gnsscorr_mex('acquire_fine_l1ca', h, acq_struct, caCode, codePhase, coarseFreq)
+ *   [trk, epochs, status] = gnsscorr_mex('track_device', h, params_struct, channels)  % loop closed on the GPU; status
+ *          GC_E_UNSUPPORTED (-5) for configurations it does not cover: fall back to 'track'
+ *          gnsscorr_mex('load_if_packed2', h, uint8(packed))                     % 2-bit packed complex record
+ *   s    = gnsscorr_mex('fine_sums', h, fine_struct, int8(code))                 % (2*ncodes) x nbins per-code sums
+ *   c    = gnsscorr_mex('preamble_xcorr', h, I_P, int8(preamble_ms))             % single, non-negative lags
  */
 #include <string.h>
 
@@ -140,7 +145,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxFree(blk);
     if (rc == GC_E_RANGE) mexErrMsgIdAndTxt("gnsscorr:range", "%s", gc_last_error()); /* tracking.m:241-245 */
     if (rc) fail("gc_correlate");
-  } else if (!strcmp(cmd, "track")) {
+  } else if (!strcmp(cmd, "track") || !strcmp(cmd, "track_device")) {
     const mxArray* s = prhs[2];
     gc_track_params p;
     memset(&p, 0, sizeof p);
@@ -180,7 +185,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const mwSize dims[3] = {(mwSize)p.n_epochs, GC_TRK_NFIELDS, (mwSize)nch};
     plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); /* trk(epoch, field, channel) */
     int32_t* done = (int32_t*)mxCalloc((size_t)nch, sizeof *done);
-    int rc = gc_track(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done);
+    /* track_device: the same loop closed on the GPU in one persistent launch (gc_track_device); GC_E_UNSUPPORTED for the
+       configurations it does not cover - the caller then falls back to 'track' */
+    int rc = !strcmp(cmd, "track_device") ? gc_track_device(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done)
+                                          : gc_track(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done);
     if (nlhs > 1) {
       plhs[1] = mxCreateDoubleMatrix(1, (mwSize)nch, mxREAL);
       for (int i = 0; i < nch; ++i) mxGetDoubles(plhs[1])[i] = done[i];
@@ -188,7 +196,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(rc);
     mxFree(init);
     mxFree(done);
-    if (rc && rc != GC_E_RANGE) fail("gc_track"); /* GC_E_RANGE = the reference's short-read return */
+    if (rc && rc != GC_E_RANGE && !(rc == GC_E_UNSUPPORTED && nlhs > 2)) fail("gc_track"); /* GC_E_RANGE = the reference's short-read return */
   } else if (!strcmp(cmd, "acquire_coarse")) {
     gc_acq_params p;
     fill_acq(prhs[2], &p);
@@ -213,6 +221,33 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                              mxGetScalar(prhs[5]), &f))
       fail("gc_acquire_fine_l1ca");
     plhs[0] = mxCreateDoubleScalar(f);
+  } else if (!strcmp(cmd, "load_if_packed2")) {
+    /* gnsscorr_mex('load_if_packed2', h, uint8(packed)): 2-bit packed complex samples (unpack_cplx.m:32-49) expanded on the GPU */
+    if (gc_load_if_packed2(handle(prhs[1]), mxGetData(prhs[2]), (uint64_t)mxGetNumberOfElements(prhs[2]))) fail("gc_load_if_packed2");
+  } else if (!strcmp(cmd, "fine_sums")) {
+    /* s = gnsscorr_mex('fine_sums', h, fineParams, int8(code)): sumPerCode(bin, code) of the packages' fine-frequency stages */
+    const mxArray* s = prhs[2];
+    gc_fine_params p;
+    memset(&p, 0, sizeof p);
+    p.sampling_freq = field(s, "samplingFreq");
+    p.code_freq = field(s, "codeFreq");
+    p.f0 = field(s, "f0");
+    p.fstep = field(s, "fstep");
+    p.first_sample = (int64_t)field(s, "firstSample");
+    p.spc = (int32_t)field(s, "samplesPerCode");
+    p.ncodes = (int32_t)field(s, "ncodes");
+    p.nbins = (int32_t)field(s, "nbins");
+    p.code_len = (int32_t)field(s, "codeLength");
+    p.index_offset = mxGetField(s, 0, "indexOffset") ? (int32_t)field(s, "indexOffset") : 0;
+    plhs[0] = mxCreateDoubleMatrix((mwSize)(2 * p.ncodes), (mwSize)p.nbins, mxREAL); /* (re, im) pairs per code, one column per bin */
+    if (gc_acquire_fine_sums(handle(prhs[1]), &p, (const int8_t*)mxGetData(prhs[3]), mxGetDoubles(plhs[0]))) fail("gc_acquire_fine_sums");
+  } else if (!strcmp(cmd, "preamble_xcorr")) {
+    /* c = gnsscorr_mex('preamble_xcorr', h, I_P, int8(preamble_ms)): NAVdecoding.m:62-76, non-negative lags */
+    const mwSize n = mxGetNumberOfElements(prhs[2]);
+    plhs[0] = mxCreateNumericMatrix(1, n, mxSINGLE_CLASS, mxREAL);
+    if (gc_preamble_xcorr(handle(prhs[1]), mxGetDoubles(prhs[2]), (int64_t)n, (const int8_t*)mxGetData(prhs[3]),
+                          (int)mxGetNumberOfElements(prhs[3]), (float*)mxGetData(plhs[0])))
+      fail("gc_preamble_xcorr");
   } else {
     mexErrMsgIdAndTxt("gnsscorr:usage", "unknown command %s", cmd);
   }
