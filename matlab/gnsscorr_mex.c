@@ -20,7 +20,7 @@
  *   res  = gnsscorr_mex('acquire_coarse', h, acq_struct, sampledCodes)          % int8 spc x nprn
  *   f    = gnsscorr_mex('acquire_fine_l1ca', h, acq_struct, caCode, codePhase, coarseFreq)
  *   [trk, epochs, status] = gnsscorr_mex('track_device', h, params_struct, channels)  % loop closed on the GPU; status
- *          GC_E_UNSUPPORTED (-5) for configurations it does not cover: fall back to 'track'
+ *          GC_E_UNSUPPORTED (-6) for configurations it does not cover: fall back to 'track'
  *          gnsscorr_mex('load_if_packed2', h, uint8(packed))                     % 2-bit packed complex record
  *   s    = gnsscorr_mex('fine_sums', h, fine_struct, int8(code))                 % (2*ncodes) x nbins per-code sums
  *   c    = gnsscorr_mex('preamble_xcorr', h, I_P, int8(preamble_ms))             % single, non-negative lags
