@@ -72,6 +72,8 @@ struct KArgs {
   const struct DevLoopArgs* devloop;  // device-side loop closure (devloop.h); nullptr otherwise
   int wide;      // fast kernel variant with 4 waves per workgroup and int8-pair LDS tables
   int share_el;  // every block has el_spacing*R*M == 1/2: early and late taps share their step mask
+  int derived;   // lane kernel: three-arm channels whose third arm is derived from the second (DevChannel::derived)
+  int pad_;
 };
 
 // t = k0 - G / 2^64 ;  ceil(t + x) for x = xi + xf/2^64  is  k0 + xi + (xf > G)

@@ -133,6 +133,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   a.use_inline = 0;
   a.share_el = share_el ? 1 : 0;
   a.wide = 0;
+  a.derived = (fast == 0 && ctx->launch_derived) ? 1 : 0;
   a.devloop = nullptr;
   if (fast >= 0 && notify_tag != 0 && ctx->h_tagged_pinned) {
     // closed loop: d_blocks is the host-mapped descriptor buffer (readable by the host right here)

@@ -45,11 +45,15 @@ constexpr int kGRP = GC_LANE_GRP;  // samples per lane and group: the loads of t
 // DEVLOOP = persistent launch with device-side loop closure (devloop.h): p.splits workgroups of 16 waves per channel, the
 // block loop becomes the channel's epoch loop; sums are combined in LDS per workgroup, between workgroups by tagged
 // messages, and wave 0 of the channel's first workgroup closes the loop.
-template <int ARMS, int MODE, bool CL, int TAB, bool DEVLOOP = false>
+template <int ARMS, int MODE, bool CL, int TAB, bool DEVLOOP = false, bool DER = false>
 __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at most 8 waves per member (256 VGPRs, no spills)
  void corr_epl_lane_kernel(const KArgs p, const InlineBlocks /*read via the segment pointer*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int AP = ArmPitch<ARMS>::v;  // values per staged entry
+  // DER: the last arm has no table: it is arm LA - 1 read at six times the ramp rate with a sign pattern (BOC(6,1) from
+  // BOC(1,1): entry k6 of its padded table = entry p = (k6 + 5) / 6 of the neighbour's times (-1)^(p + k6), checked on the
+  // host: gc_channel_is_derived).  Three more ramps per sample instead of a 49 104- or 122 760-entry table.
+  constexpr int LA = DER ? ARMS - 1 : ARMS;  // arms with a table in LDS
+  constexpr int AP = ArmPitch<LA>::v;        // values per staged entry
   constexpr bool kF16 = (TAB == 2);
   constexpr bool kShare = (TAB == 1);
   constexpr int NT = kShare ? 2 : 3;  // ramps carried per sample
@@ -93,11 +97,11 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     const gc_block blk0 = DEVLOOP ? p.devloop->chan[lb0].blk : CL ? load_block(p, lb0) : p.blocks[lb0];
     const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
     const int arms0 = chn0->arms;
-    int nent[ARMS];
+    int nent[LA];
     const void* pre = kF16 ? (const void*)chn0->tabh : (const void*)chn0->tabf;
     bool plain = pre != nullptr && chn0->tabh_ap == AP;  // pre-interleaved copy usable as is
 #pragma unroll
-    for (int a = 0; a < ARMS; ++a) {
+    for (int a = 0; a < LA; ++a) {
       nent[a] = 0;
       if (a < arms0) {
         const int off = blk0.table_offset[a];
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
 #pragma unroll
         for (int a = 0; a < AP; ++a) {
           float v = 0.0f;
-          if (a < ARMS) {
-            const int aa = a < ARMS ? a : 0;
+          if (a < LA) {
+            const int aa = a < LA ? a : 0;
             if (a < arms0 && e >= 0 && e < nent[aa]) v = (float)chn0->tab[aa][blk0.table_offset[aa] + e];
           }
           wtab[i * AP + a] = (tab_t)v;
@@ -193,7 +197,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   const double aP = rem * R;
   const double sp = step * R;
   const double tau = blk.carr_freq / p.fs;  // carrier turns per sample
-  const bool tie_free = (blk.reserved & 1) != 0;  // host-proved: no sample within the window of a table edge
+  const double M6 = DER ? chn->mult[ARMS - 1] : 0.0;  // ramp multiplier of the derived arm
+  const bool tie_free = !DER && (blk.reserved & 1) != 0;  // host-proved: no sample within the window of a table edge (the
+                                                          // host's search does not cover a derived arm's ramp)
 
   // sample range of this split: a multiple of 64 samples per split
   const int per = (((N + nsplit - 1) / nsplit) + 63) / 64 * 64;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   const unsigned int tie_e = 0x7fffffffu;
   (void)gc_tie_window_units(0.0, 0);
 #else
-  const unsigned int tie_e = gc_tie_window_units((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fabs(M), (per >> 6) + 1);
+  const unsigned int tie_e = gc_tie_window_units((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fmax(fabs(M), fabs(M6)), (per >> 6) + 1);
 #endif
 
   // Per-sample ramp step sp*M as a 64.64 fixed-point number (exact: a double has at most 64 fractional bits
@@ -228,6 +234,20 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     rotC = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c_)));
     rotS = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_)));
     if (kShare) el_off = __builtin_amdgcn_readfirstlane((int)(2.0 * d * R * M));  // host-checked: exact integer
+  }
+  // the same for the derived arm's ramp (multiplier M6)
+  unsigned long long Sf6 = 0, dQ6 = 0;
+  int Si6 = 0;
+  if constexpr (DER) {
+    const double y = sp * M6;
+    const double yi = floor(y);
+    Sf6 = frac_to_u64(y - yi);
+    Sf6 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(Sf6 >> 32)) << 32) |
+          (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)Sf6);
+    Si6 = __builtin_amdgcn_readfirstlane((int)yi);
+    const unsigned long long df = Sf6 << 6;
+    const long long di = (long long)Si6 * 64 + (long long)(Sf6 >> 58);
+    dQ6 = ((unsigned long long)di << 32) + (df >> 32) + ((df >> 31) & 1ull);
   }
 
   float accr[ARMS][3], acci[ARMS][3];
@@ -259,6 +279,24 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         Q[x] = q;
       }
     }
+    unsigned long long Q6[DER ? 3 : 1];
+    if constexpr (DER) {
+      const double isp = __dmul_rn((double)ibeg, sp);
+      const double base3[3] = {__dmul_rn(__dadd_rn(aE, isp), M6), __dmul_rn(__dadd_rn(aP, isp), M6),
+                               __dmul_rn(__dadd_rn(aL, isp), M6)};
+      const unsigned __int128 prod = (unsigned __int128)Sf6 * (unsigned int)lane;
+      const unsigned long long F = (unsigned long long)prod;
+      const int I = lane * Si6 + (int)(unsigned long long)(prod >> 64);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const Fx f0 = to_fx(base3[x]);
+        const unsigned long long g = f0.G - F;
+        const int k = f0.k0 + I + (f0.G < F ? 1 : 0);
+        const unsigned long long gc = (g >> 32) + (((unsigned int)g != 0u) ? 1ull : 0ull);
+        Q6[x] = ((unsigned long long)(unsigned int)k << 32) + 0xffffffffull - gc;
+      }
+    }
+    (void)Q6;
     float wc, ws;  // exp(-i*theta_i) = wc - i*ws
     {
       const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
@@ -307,20 +345,33 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         typedef tab_t vec_t __attribute__((ext_vector_type(AP)));
         const vec_t e = reinterpret_cast<const vec_t*>(tab)[kGuard + k];
 #pragma unroll
-        for (int ar = 0; ar < ARMS; ++ar) {
+        for (int ar = 0; ar < LA; ++ar) {
           const float cf = (float)e[ar];
           accr[ar][x] = fmaf(cf, yr, accr[ar][x]);
           acci[ar][x] = fmaf(cf, yi, acci[ar][x]);
         }
       }
     };
+    // derived arm: padded-table entry k6 of the six-times-faster replica = entry p = (k6 + 5) / 6 of arm LA - 1 with the sign
+    // (-1)^(p + k6); the quotient by a float reciprocal (exact for k6 < 2^21)
+    auto accumulate_derived = [&](int x, int k6, float yr, float yi) {
+      const int pidx = (int)(((float)(k6 + 5) + 0.5f) * 0.16666667f);
+      const unsigned int sgn = ((unsigned int)(pidx + k6) & 1u) << 31;
+      const float cf = __uint_as_float(__float_as_uint((float)tab[(kGuard + pidx) * AP + (LA - 1)]) ^ sgn);
+      accr[ARMS - 1][x] = fmaf(cf, yr, accr[ARMS - 1][x]);
+      acci[ARMS - 1][x] = fmaf(cf, yi, acci[ARMS - 1][x]);
+    };
     // lean accumulate of one sample: y = x*exp(-i theta), one LDS read per tap serves every arm
-    auto lean_sample = [&](unsigned int word, const int (&k)[NT]) {
+    auto lean_sample = [&](unsigned int word, const int (&k)[NT], const int (&k6)[3]) {
       float yr, yi;
       mix(word, yr, yi);
       accumulate(0, k[0], yr, yi);
       accumulate(1, k[1], yr, yi);
       accumulate(2, kShare ? k[0] + el_off : k[NT - 1], yr, yi);
+      if constexpr (DER) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x) accumulate_derived(x, k6[x], yr, yi);
+      }
     };
     // exact accumulate of one sample: MATLAB colon element i (tracking.m:252-270) in float64 — forwards from
     // a for the first half, backwards from the end point b for the second, mean of both in the exact middle
@@ -345,6 +396,10 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
           t = __dadd_rn(ax, bx) / 2.0;
         const int kx = (int)fmin(fmax(ceil(__dmul_rn(t, M)), (double)-kGuard), (double)(maxn + kGuard - 1));
         accumulate(x, kx, yr, yi);
+        if constexpr (DER) {
+          const int k6 = (int)fmin(fmax(ceil(__dmul_rn(t, M6)), 0.0), (double)(6 * (maxn - 2) + 1));
+          accumulate_derived(x, k6, yr, yi);
+        }
       }
     };
     // ramp step of one tap: table index of the CURRENT sample (high word), the low word into the running
@@ -356,6 +411,14 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         dmax = max(dmax, (unsigned int)Q[x]);
       }
       Q[x] += dQ;
+      return k;
+    };
+
+    auto ramp_step6 = [&](int x, unsigned int& dmin, unsigned int& dmax) -> int {
+      const int k = (int)(unsigned int)(Q6[x] >> 32);
+      dmin = min(dmin, (unsigned int)Q6[x]);
+      dmax = max(dmax, (unsigned int)Q6[x]);
+      Q6[x] += dQ6;
       return k;
     };
 
@@ -372,7 +435,14 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       // and samples 3000k land exactly on edges.  Any suspect lane sends the wave's group through the exact
       // path.  Blocks the host proved tie-free (gc_mark_tie_free, an exact search) skip the test.
       int kg[kGRP][NT];
+      int kg6[kGRP][3];
       unsigned int dmin = 0xffffffffu, dmax = 0u;
+      if constexpr (DER) {
+#pragma unroll
+        for (int j = 0; j < kGRP; ++j)
+#pragma unroll
+          for (int x = 0; x < 3; ++x) kg6[j][x] = ramp_step6(x, dmin, dmax);
+      }
       if (tie_free) {
 #pragma unroll
         for (int j = 0; j < kGRP; ++j)
@@ -394,7 +464,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       } else {
 #pragma unroll
         for (int j = 0; j < kGRP; ++j) {
-          lean_sample(cur[j], kg[j]);
+          lean_sample(cur[j], kg[j], kg6[j]);
           rotate_w();
         }
       }
@@ -424,13 +494,18 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     for (; i < iend; i += 64, ptr += (long long)bps * 64) {
       const unsigned int word = load_sample(ptr);
       int k1[NT];
+      int k16[3] = {0, 0, 0};
       unsigned int dmin = 0xffffffffu, dmax = 0u;
 #pragma unroll
       for (int x = 0; x < NT; ++x) k1[x] = ramp_step(x, true, dmin, dmax);
+      if constexpr (DER) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x) k16[x] = ramp_step6(x, dmin, dmax);
+      }
       if (!tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)))
         exact_sample(word, i);
       else
-        lean_sample(word, k1);
+        lean_sample(word, k1, k16);
       rotate_w();
     }
   }
@@ -625,14 +700,14 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
 int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBlocks& ib, unsigned int grid, int max_arms,
                               bool share_el) {
   KArgs a = a_in;
-  const int ap = gc_arm_pitch(max_arms);
+  const int ap = gc_arm_pitch(a.derived ? 2 : max_arms);  // a derived third arm has no table of its own
   const size_t entries = (size_t)ctx->max_stage_len + 2 * kGuard;
   const size_t f32_bytes = (entries * ap * 4 + 15) / 16 * 16;
   const size_t f16_bytes = (entries * ap * 2 + 15) / 16 * 16;
   int tabkind;
   size_t smem;
   if (f32_bytes <= 96 * 1024) {  // f32 tables: one 16-wave workgroup per CU still fits next to a second one up to 80 KiB
-    tabkind = share_el ? 1 : 0;
+    tabkind = (share_el && !a.derived) ? 1 : 0;
     smem = f32_bytes;
     a.red_off = (int)f32_bytes;
   } else if (f16_bytes + 2048 <= 160 * 1024) {
@@ -644,6 +719,22 @@ int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBl
     return GC_E_UNSUPPORTED;
   }
   smem += kLW * GC_OUT_STRIDE * sizeof(float);  // cross-wave scratch of the one-block-per-workgroup mode
+  if (a.derived) {
+    if (max_arms != 3 || tabkind == 2 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
+      gc_set_error("internal: derived-arm launch with %d arms / table kind %d", max_arms, tabkind);
+      return GC_E_INVALID;
+    }
+    const bool cl = a.tagged != nullptr;
+    if (ctx->if_layout == GC_QI) {
+      if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 0, false, true>, a, ib, dim3(grid), smem);
+      else launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, false, 0, false, true>, a, ib, dim3(grid), smem);
+    } else {
+      if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 0, false, true>, a, ib, dim3(grid), smem);
+      else launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, false, 0, false, true>, a, ib, dim3(grid), smem);
+    }
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   switch (max_arms) {
     case 1: return launch_mode<1>(ctx, a, ib, dim3(grid), smem, tabkind);
     case 2: return launch_mode<2>(ctx, a, ib, dim3(grid), smem, tabkind);

@@ -42,6 +42,10 @@ struct DevChannel {
   const float* tabf;   // the same as f32 (2 * tabh_bytes bytes)
   int32_t tabh_ap;     // f16 values per entry (1, 2 or 4)
   int32_t tabh_bytes;  // multiple of 16
+  // arm 2 is arm 1 with a sign pattern at six times the ramp rate (BOC(6,1) next to BOC(1,1): entry k6 of its padded table
+  // equals entry p = (k6 + 5) / 6 of arm 1's times (-1)^(p + k6)): the lane kernel derives it instead of reading a table
+  int32_t derived;
+  int32_t pad_;
 };
 
 struct HostChannel {
@@ -57,6 +61,7 @@ struct HostChannel {
   std::vector<int8_t> h_tab[GC_MAX_ARMS];  // host copies (interleaved f16 form is built at sync time)
   uint16_t* d_tabh = nullptr;
   float* d_tabf = nullptr;
+  mutable int derived_state = -1;  // -1 unknown, else DevChannel::derived (gc_channel_is_derived; reset whenever the channel changes)
 };
 
 struct gc_context {
@@ -107,9 +112,11 @@ struct gc_context {
   int64_t replay_nblocks = 0;
   int replay_max_arms = 1;
   int replay_fast = 0;
+  bool replay_derived = false;
   int replay_period = 0;
   bool replay_share_el = false;  // channel pattern period of the replay list (0 = not periodic)
   bool force_generic = false;
+  bool launch_derived = false;  // the launch being prepared runs the lane kernel's derived-arm instantiation
   int last_kernel = -2;  // gc_debug_last_kernel
 
   // acquisition scratch (acq.hip)
@@ -138,3 +145,4 @@ int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps);
 void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps);
 // 0 = float2 tables / single-wave workgroups, 1 = WIDE (int8 pairs, four waves), -1 = tables too large for the fast kernel
 int gc_fast_table_mode(const gc_context* ctx);
+bool gc_channel_is_derived(const HostChannel& c);  // cached in HostChannel::derived_state

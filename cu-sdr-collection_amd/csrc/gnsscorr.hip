@@ -364,6 +364,7 @@ int gc_set_channel(gc_context* ctx, int channel, int arms, double index_scale) {
     c.window[a] = 0;
     c.mult[a] = 1.0;
   }
+  c.derived_state = -1;
   ctx->channels_dirty = true;
   return GC_OK;
 }
@@ -417,6 +418,7 @@ int gc_set_code(gc_context* ctx, int channel, int arm, const int8_t* table, int 
   c.h_tab[arm].assign(table, table + n_entries);
   c.nent[arm] = n_entries;
   c.mult[arm] = arm_mult;
+  c.derived_state = -1;
   ctx->channels_dirty = true;
   return GC_OK;
 }
@@ -428,11 +430,36 @@ int gc_set_code_window(gc_context* ctx, int channel, int arm, int window_entries
       window_entries < 0)
     return GC_E_INVALID;
   ctx->ch[channel].window[arm] = window_entries;
+  ctx->ch[channel].derived_state = -1;
   ctx->channels_dirty = true;
   return GC_OK;
 }
 
 }  // extern "C"
+
+// Three arms {a, b, b'} where b' is b with a sign pattern at six times the ramp rate — BOC(6,1) next to BOC(1,1) (BDS B1C
+// wide-band pilot, Galileo E1-C CBOC): entry k6 of b' (padded like every table) is entry p = (k6 + 5) / 6 of b times
+// (-1)^(p + k6).  Then the lane kernel needs no third table (csrc/corr_lane.hip, DER).
+static bool channel_is_derived_uncached(const HostChannel& c) {
+  if (std::getenv("GC_NO_DERIVED_ARM")) return false;
+  if (c.arms != 3 || c.mult[0] != c.mult[1] || c.mult[2] != 6.0 * c.mult[1]) return false;
+  for (int a = 0; a < 3; ++a)
+    if (c.window[a] != 0 || (int)c.h_tab[a].size() != c.nent[a]) return false;
+  const int n1 = c.nent[1] - 2, n6 = c.nent[2] - 2;
+  if (n1 < 1 || n6 != 6 * n1) return false;
+  // instantiated with f32 tables only: two interleaved arms must fit the lane kernel's 96-KiB f32 budget
+  if (((size_t)std::max(c.nent[0], c.nent[1]) + 2 * gcorr::kGuard) * 2 * 4 > 96 * 1024) return false;
+  for (int k6 = 0; k6 < c.nent[2]; ++k6) {
+    const int pidx = (k6 + 5) / 6;
+    const int want = c.h_tab[1][pidx] * (((pidx + k6) & 1) ? -1 : 1);
+    if (c.h_tab[2][k6] != want) return false;
+  }
+  return true;
+}
+bool gc_channel_is_derived(const HostChannel& c) {
+  if (c.derived_state < 0) c.derived_state = channel_is_derived_uncached(c) ? 1 : 0;
+  return c.derived_state == 1;
+}
 
 int gc_sync_channels(gc_context* ctx) {
   if (!ctx->channels_dirty) return GC_OK;
@@ -458,6 +485,10 @@ int gc_sync_channels(gc_context* ctx) {
     }
     bool mixed = false;
     for (int a = 1; a < c.arms; ++a) mixed |= c.mult[a] != c.mult[0];
+    const bool derived = mixed && gc_channel_is_derived(c);
+    d.derived = derived ? 1 : 0;
+    const int larms = derived ? 2 : c.arms;  // arms with a table in LDS
+    if (derived) mixed = false;
     d.lds_bytes = off;
     // generic kernel: interleaved f16 copy of the whole tables (when no arm is windowed)
     HostChannel& hc = ctx->ch[i];
@@ -467,17 +498,17 @@ int gc_sync_channels(gc_context* ctx) {
     hc.d_tabf = nullptr;
     bool whole = !mixed;
     int maxn = 0;
-    for (int a = 0; a < c.arms; ++a) {
+    for (int a = 0; a < larms; ++a) {
       whole &= c.d_tab[a] != nullptr && c.window[a] == 0 && (int)c.h_tab[a].size() == c.nent[a];
       maxn = std::max(maxn, d.stage_len[a]);
     }
     if (whole && maxn <= 65536) {
-      const int ap = gcorr::gc_arm_pitch(c.arms);
+      const int ap = gcorr::gc_arm_pitch(larms);
       const size_t entries = (size_t)maxn + 2 * gcorr::kGuard;
       const size_t bytes = (entries * ap * 2 + 15) / 16 * 16;
       std::vector<uint16_t> t(bytes / 2, 0);
       std::vector<float> tf(bytes / 2, 0.0f);
-      for (int a = 0; a < c.arms; ++a)
+      for (int a = 0; a < larms; ++a)
         for (int e = 0; e < c.nent[a]; ++e) {
           const int8_t v = c.h_tab[a][e];
           t[((size_t)e + gcorr::kGuard) * ap + a] = v > 0 ? 0x3C00 : v < 0 ? 0xBC00 : 0;  // f16 +1 / -1 / 0
@@ -635,6 +666,10 @@ void gc_scope_add(gc_context* ctx, int channel) {
     mixed |= c.mult[a] != c.mult[0];
   }
   ctx->max_arms_configured = std::max(ctx->max_arms_configured, c.arms);
+  if (mixed && gc_channel_is_derived(c)) {  // third arm derived from the second: only two tables go to LDS
+    ctx->max_stage_len = std::max(ctx->max_stage_len, std::max(c.nent[0], c.nent[1]));
+    return;
+  }
   if (mixed) return;  // mixed-multiplier channels use the LDS-free exact kernel
   ctx->max_lds_bytes = std::max(ctx->max_lds_bytes, off);
   ctx->max_stage_len = std::max(ctx->max_stage_len, maxn);
@@ -658,6 +693,8 @@ bool gc_fast_lds_ok(const gc_context* ctx) {
 static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* all_lowrate, bool* all_share = nullptr) {
   *all_lowrate = 2;
   if (all_share) *all_share = true;
+  bool any_derived = false, any_plain_mixed = false, any_three_plain = false;
+  ctx->launch_derived = false;
   if (!ctx->d_if) {
     gc_set_error("no IF buffer loaded");
     return GC_E_STATE;
@@ -686,7 +723,10 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
         gc_set_error("block %lld: channel %d arm %d has no code table", (long long)i, k.channel, a);
         return GC_E_STATE;
       }
-      if (c.mult[a] != c.mult[0]) *all_lowrate = -1;  // mixed multipliers: exact per-sample kernel
+      if (c.mult[a] != c.mult[0]) {  // mixed multipliers: exact per-sample kernel, unless the odd arm can be derived
+        if (gc_channel_is_derived(c)) any_derived = true;
+        else any_plain_mixed = true;
+      }
       if (k.table_offset[a] < 0 || k.table_offset[a] + 3 > c.nent[a]) {
         gc_set_error("block %lld: table offset out of range", (long long)i);
         return GC_E_INVALID;
@@ -722,6 +762,16 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
     if (*all_lowrate >= 0) *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
     if (all_share && !gc_block_shares_el(ctx, k)) *all_share = false;
     if (ctx->scope_share_lane && !gc_block_shares_el_lane(ctx, k)) ctx->scope_share_lane = false;
+    if (c.arms == 3 && !gc_channel_is_derived(c)) any_three_plain = true;
+  }
+  // mixed ramp multipliers: the exact per-sample kernel (-1), unless every such channel's odd arm can be derived from its
+  // neighbour (BOC(6,1) from BOC(1,1)) and the record is int8 I/Q: then the lane kernel's derived-arm instantiation (0)
+  if (any_plain_mixed || (any_derived && (any_three_plain || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL))) {
+    *all_lowrate = -1;
+  } else if (any_derived) {
+    *all_lowrate = 0;
+    ctx->launch_derived = true;
+    ctx->scope_share_lane = false;
   }
   return max_arms;
 }
@@ -816,6 +866,7 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   ctx->replay_scope[1] = ctx->max_stage_len;
   ctx->replay_scope[2] = ctx->max_arms_configured;
   ctx->replay_share_lane = ctx->scope_share_lane;
+  ctx->replay_derived = ctx->launch_derived;
   ctx->replay_fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
@@ -866,6 +917,7 @@ int gc_replay_launch(gc_context* ctx) {
   ctx->max_stage_len = ctx->replay_scope[1];
   ctx->max_arms_configured = ctx->replay_scope[2];
   ctx->scope_share_lane = ctx->replay_share_lane;
+  ctx->launch_derived = ctx->replay_derived;
   int splits = 1;
   if (ctx->replay_fast == 0) {
     // lane kernel: periodic lists with enough blocks run one block per wavefront (bpw path of the launcher),

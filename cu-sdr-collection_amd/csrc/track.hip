@@ -56,7 +56,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   if (rc) return rc;
 
   int max_arms = 1;
-  bool any_mixed = false;
+  bool any_mixed = false, all_mixed_derived = true, any_three_plain = false;
   gc_scope_reset(ctx);
   for (int c = 0; c < nch; ++c) {
     const int ci = init[c].channel;
@@ -70,9 +70,13 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
         return GC_E_STATE;
       }
     max_arms = std::max(max_arms, ctx->ch[ci].arms);
+    if (ctx->ch[ci].arms == 3 && !gc_channel_is_derived(ctx->ch[ci])) any_three_plain = true;
     gc_scope_add(ctx, ci);
     for (int a = 1; a < ctx->ch[ci].arms; ++a)
-      if (ctx->ch[ci].mult[a] != ctx->ch[ci].mult[0]) any_mixed = true;  // B1C wide-band: exact per-sample kernel
+      if (ctx->ch[ci].mult[a] != ctx->ch[ci].mult[0]) {  // B1C wide-band / E1 CBOC: exact per-sample kernel, or the lane
+        any_mixed = true;                                  // kernel's derived-arm instantiation when every such channel allows it
+        if (!gc_channel_is_derived(ctx->ch[ci])) all_mixed_derived = false;
+      }
   }
   if ((p->pilot_combine == 4 || p->pilot_combine == 5) && max_arms < 3) {
     gc_set_error("gc_track: pilot_combine 4 / 5 need three arms {data, pilot BOC(1,1), pilot BOC(6,1)}");
@@ -95,6 +99,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     probe.code_phase_step = init[c].code_freq * 1.001 / p->sampling_freq;
     fast_nominal = std::min(fast_nominal, gc_block_lowrate_level(ctx, probe));
   }
+  if (any_mixed && all_mixed_derived && !any_three_plain && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL)
+    fast_nominal = 0;  // derived-arm channels run on the lane kernel
   int splits;
   if (fast_nominal) {
     const int chunks_nominal = approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8);
@@ -185,7 +191,9 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       ++nb;
     }
     if (nb == 0) break;
-    int fast = any_mixed ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
+    const bool derived = any_mixed && all_mixed_derived && !any_three_plain && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
+    ctx->launch_derived = derived;
+    int fast = derived ? 0 : any_mixed ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
     for (int k = 0; k < nb && fast > 0; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
     bool share = true;
     for (int k = 0; k < nb && share; ++k) share = gc_block_shares_el(ctx, blocks[k]);

@@ -558,6 +558,9 @@ def test_galileo_e1c_cboc_pilot_tracking_matches_oracle(engine):
                           codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in sats]
     engine.load_if(iq, fs=fs)
     tr, _ = P.tracking(engine, ch, S, signal="GAL_E1C_CBOC")
+    # the BOC(6,1) arm is recognised as the BOC(1,1) arm at six times the ramp rate with a sign pattern: lane kernel with a
+    # derived third arm (no 49 106-entry table in LDS) instead of the exact per-sample kernel
+    assert engine.last_kernel() == 0
 
     def tables(prn):
         c11 = O.generate_e1_code(prn, "C")                      # chip x [+1, -1]
@@ -580,6 +583,18 @@ def test_galileo_e1c_cboc_pilot_tracking_matches_oracle(engine):
         pm = np.hypot(tr[k].Pilot_I_P, tr[k].Pilot_Q_P)[4:]
         dm = np.hypot(tr[k].I_P, tr[k].Q_P)[4:]
         assert 0.85 < np.mean(pm) / np.mean(dm) < 1.05
+    # the same through the exact per-sample kernel
+    import os
+    os.environ["GC_NO_DERIVED_ARM"] = "1"
+    try:
+        tr2, _ = P.tracking(engine, ch, S, signal="GAL_E1C_CBOC")
+        assert engine.last_kernel() == -1
+    finally:
+        del os.environ["GC_NO_DERIVED_ARM"]
+    for k in range(2):
+        assert np.array_equal(tr2[k].absoluteSample, tr[k].absoluteSample)
+        for f in ("I_P", "Q_P", "Pilot_I_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L"):
+            assert np.max(np.abs(getattr(tr2[k], f) - getattr(tr[k], f))) < 1e-5 * 2.0 * 72000 * 28.0, f
 
 
 def test_config4_l5_and_b2a_at_50_msps(engine):
