@@ -720,16 +720,20 @@ int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBl
   }
   smem += kLW * GC_OUT_STRIDE * sizeof(float);  // cross-wave scratch of the one-block-per-workgroup mode
   if (a.derived) {
-    if (max_arms != 3 || tabkind == 2 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
+    if (max_arms != 3 || tabkind == 1 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
       gc_set_error("internal: derived-arm launch with %d arms / table kind %d", max_arms, tabkind);
       return GC_E_INVALID;
     }
-    const bool cl = a.tagged != nullptr;
-    if (ctx->if_layout == GC_QI) {
-      if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 0, false, true>, a, ib, dim3(grid), smem);
+    const bool cl = a.tagged != nullptr, qi = ctx->if_layout == GC_QI, h = tabkind == 2;
+    if (qi) {
+      if (cl && h) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 2, false, true>, a, ib, dim3(grid), smem);
+      else if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 0, false, true>, a, ib, dim3(grid), smem);
+      else if (h) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, false, 2, false, true>, a, ib, dim3(grid), smem);
       else launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, false, 0, false, true>, a, ib, dim3(grid), smem);
     } else {
-      if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 0, false, true>, a, ib, dim3(grid), smem);
+      if (cl && h) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 2, false, true>, a, ib, dim3(grid), smem);
+      else if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 0, false, true>, a, ib, dim3(grid), smem);
+      else if (h) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, false, 2, false, true>, a, ib, dim3(grid), smem);
       else launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, false, 0, false, true>, a, ib, dim3(grid), smem);
     }
     GC_HIP(hipGetLastError());

@@ -447,8 +447,8 @@ static bool channel_is_derived_uncached(const HostChannel& c) {
     if (c.window[a] != 0 || (int)c.h_tab[a].size() != c.nent[a]) return false;
   const int n1 = c.nent[1] - 2, n6 = c.nent[2] - 2;
   if (n1 < 1 || n6 != 6 * n1) return false;
-  // instantiated with f32 tables only: two interleaved arms must fit the lane kernel's 96-KiB f32 budget
-  if (((size_t)std::max(c.nent[0], c.nent[1]) + 2 * gcorr::kGuard) * 2 * 4 > 96 * 1024) return false;
+  // the two interleaved arms must fit the lane kernel's LDS budget as f16 at least (f32 up to 96 KiB)
+  if (((size_t)std::max(c.nent[0], c.nent[1]) + 2 * gcorr::kGuard) * 2 * 2 + 2048 > 160 * 1024) return false;
   for (int k6 = 0; k6 < c.nent[2]; ++k6) {
     const int pidx = (k6 + 5) / 6;
     const int want = c.h_tab[1][pidx] * (((pidx + k6) & 1) ? -1 : 1);

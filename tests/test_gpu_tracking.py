@@ -395,6 +395,9 @@ def test_beidou_b1c_wide_band(engine):
                                                           O.pad_code(O.generate_b1c_code(prn, "pilot61"))],
                                       arm_mult=[1.0, 1.0, 6.0], pilot_combine=4, pll_weight=(1.0, 3.0),
                                       dll_weight=signals._b1c_wb_dll_weight(S)), 5, False)
+    # the BOC(6,1) arm is derived from the pilot's BOC(1,1) table (lane kernel, f16 tables: 2 x 20 462 entries), not read from
+    # its own 122 762-entry table by the exact per-sample kernel
+    assert engine.last_kernel() == 0
 
 
 def test_gps_l2c_cm_cl(engine):
