@@ -440,21 +440,27 @@ int gc_set_code_window(gc_context* ctx, int channel, int arm, int window_entries
 // Three arms {a, b, b'} where b' is b with a sign pattern at six times the ramp rate — BOC(6,1) next to BOC(1,1) (BDS B1C
 // wide-band pilot, Galileo E1-C CBOC): entry k6 of b' (padded like every table) is entry p = (k6 + 5) / 6 of b times
 // (-1)^(p + k6).  Then the lane kernel needs no third table (csrc/corr_lane.hip, DER).
+static bool tables_derivable(const int8_t* t1, int nent1, const int8_t* t6, int nent6) {
+  const int n1 = nent1 - 2, n6 = nent6 - 2;
+  if (n1 < 1 || n6 != 6 * n1) return false;
+  for (int k6 = 0; k6 < nent6; ++k6) {
+    const int pidx = (k6 + 5) / 6;
+    if (t6[k6] != t1[pidx] * (((pidx + k6) & 1) ? -1 : 1)) return false;
+  }
+  return true;
+}
+extern "C" int gc_debug_tables_derivable(const int8_t* t1, int n1, const int8_t* t6, int n6) {
+  return (t1 && t6 && tables_derivable(t1, n1, t6, n6)) ? 1 : 0;
+}
+
 static bool channel_is_derived_uncached(const HostChannel& c) {
   if (std::getenv("GC_NO_DERIVED_ARM")) return false;
   if (c.arms != 3 || c.mult[0] != c.mult[1] || c.mult[2] != 6.0 * c.mult[1]) return false;
   for (int a = 0; a < 3; ++a)
     if (c.window[a] != 0 || (int)c.h_tab[a].size() != c.nent[a]) return false;
-  const int n1 = c.nent[1] - 2, n6 = c.nent[2] - 2;
-  if (n1 < 1 || n6 != 6 * n1) return false;
   // the two interleaved arms must fit the lane kernel's LDS budget as f16 at least (f32 up to 96 KiB)
   if (((size_t)std::max(c.nent[0], c.nent[1]) + 2 * gcorr::kGuard) * 2 * 2 + 2048 > 160 * 1024) return false;
-  for (int k6 = 0; k6 < c.nent[2]; ++k6) {
-    const int pidx = (k6 + 5) / 6;
-    const int want = c.h_tab[1][pidx] * (((pidx + k6) & 1) ? -1 : 1);
-    if (c.h_tab[2][k6] != want) return false;
-  }
-  return true;
+  return tables_derivable(c.h_tab[1].data(), c.nent[1], c.h_tab[2].data(), c.nent[2]);
 }
 bool gc_channel_is_derived(const HostChannel& c) {
   if (c.derived_state < 0) c.derived_state = channel_is_derived_uncached(c) ? 1 : 0;

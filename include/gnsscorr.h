@@ -314,6 +314,11 @@ int gc_preamble_xcorr(gc_context* ctx, const double* i_p, int64_t n, const int8_
  * an integer, or -1 — the exact near-tie analysis that lets the kernels skip their per-chunk filters. */
 long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps);
 
+/* Test hook (host only, no GPU): 1 if the padded table `t6` (n6 entries, read at six times the ramp rate) is the padded
+ * table `t1` (n1 entries) with the sign pattern t6[k] = t1[(k + 5) / 6] * (-1)^((k + 5) / 6 + k) - BOC(6,1) next to
+ * BOC(1,1) - which lets the lane kernel derive that arm instead of staging its table; 0 otherwise. */
+int gc_debug_tables_derivable(const int8_t* t1, int n1, const int8_t* t6, int n6);
+
 /* Test hook: which correlator kernel the last gc_correlate / gc_replay_launch / gc_track launch used:
  * 0 lane kernel (any chipping rate), 1 fast kernel with one-wave workgroups (float2 tables), 2 fast kernel with
  * four-wave workgroups and int8-pair tables, 3 the same with plain float tables, -1 exact per-sample kernel

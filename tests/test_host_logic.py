@@ -138,3 +138,30 @@ def test_nav_parity_and_subframe_search_oracle():
     from cu_sdr_collection_amd import nav_sync
     w = rng.choice([-1, 1], size=32)
     assert nav_sync.navPartyChk(w) == O.nav_parity_check(w)
+
+
+def test_boc61_tables_are_recognised_as_derived_from_boc11():
+    """gc_debug_tables_derivable (host only): the identity behind the lane kernel's derived arm — entry k of the padded
+    BOC(6,1) table = entry p = (k + 5) // 6 of the padded BOC(1,1) table times (-1)^(p + k) — holds for the reference's
+    B1C pilot tables (generatePilotBOC11.m / generatePilotBOC61.m:89-96) and for the E1-C CBOC extension, with either
+    sub-carrier sign convention, and for nothing that merely has the right sizes."""
+    import ctypes as C
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    lib = L.load()
+
+    def derivable(t1, t6):
+        a, b = np.ascontiguousarray(t1, dtype=np.int8), np.ascontiguousarray(t6, dtype=np.int8)
+        return lib.gc_debug_tables_derivable(a.ctypes.data_as(C.c_void_p), len(a), b.ctypes.data_as(C.c_void_p), len(b))
+
+    pad = P.codes.padded_table
+    assert derivable(pad(P.codes.generatePilotBOC11(7)), pad(P.codes.generatePilotBOC61(7))) == 1        # (-1, +1) convention
+    assert derivable(pad(P.codes.generateE1Ccode(3)), pad(P.codes.generateE1C_BOC61(3))) == 1             # (+1, -1) convention
+    assert derivable(pad(O.generate_b1c_code(19, "pilot11")), pad(O.generate_b1c_code(19, "pilot61"))) == 1
+    assert derivable(pad(P.codes.generatePilotBOC11(7)), pad(P.codes.generatePilotBOC61(8))) == 0        # another PRN's chips
+    bad = pad(P.codes.generateE1C_BOC61(3)).copy()
+    bad[1234] = -bad[1234]
+    assert derivable(pad(P.codes.generateE1Ccode(3)), bad) == 0                                            # one entry off
+    assert derivable(pad(P.codes.generateE1Ccode(3)), pad(P.codes.generateE1C_BOC61(3))[:-6]) == 0         # wrong length
+    rng = np.random.default_rng(4)
+    assert derivable(rng.choice(np.array([-1, 1], np.int8), 22), rng.choice(np.array([-1, 1], np.int8), 122)) == 0
