@@ -40,7 +40,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=60.0, help="length of the IF record")
     ap.add_argument("--channels", type=int, default=12)
-    ap.add_argument("--cpu-epochs", type=int, default=1000, help="epochs per channel timed on the CPU baseline")
+    ap.add_argument("--cpu-epochs", type=int, default=4000, help="epochs per channel timed on the CPU baseline (4000: ~13 s of one core)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
