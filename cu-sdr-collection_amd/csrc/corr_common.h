@@ -71,7 +71,7 @@ struct KArgs {
   int use_inline;
   const struct DevLoopArgs* devloop;  // device-side loop closure (devloop.h); nullptr otherwise
   int wide;      // fast kernel variant with 4 waves per workgroup and int8-pair LDS tables
-  int share_el;  // every block has el_spacing*R*M == 1/2: early and late taps share their step mask
+  int share_el;  // every block has el_spacing*R*M == 1/2: early and late taps share one ramp
   int derived;   // lane kernel: three-arm channels whose third arm is derived from the second (DevChannel::derived)
   int pad_;
 };

@@ -70,7 +70,7 @@ __device__ __forceinline__ double rl_f64(double x, int lane) {
 // CL = closed-loop variant: descriptors from the kernel-argument segment, results as host-mapped tagged
 // records.  The replay instantiation (CL = false) carries none of that code.
 // SHARE = every block of the launch has earlyLateSpc*R*M == 1/2 (host-checked): early and late share one
-// step mask.  A separate instantiation per value — both variants inside one kernel measured 25 % slower.
+// ramp and one pair of partial sums.  A separate instantiation per value — both variants inside one kernel measured 25 % slower.
 // WIDE = four wavefronts per workgroup sharing ONE staged table kept as int8 pairs {c, dc} (2 bytes per
 // entry instead of 8): for tables that would otherwise leave one wave per SIMD (Galileo E1 B+C: 2 x 8186
 // entries = 131 KB as float2, 33 KB as int8 pairs).  Every wave owns its own blocks / splits; the only

@@ -148,7 +148,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   int want_bpw = 8;
   if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
   const bool must_wide = fast > 0 && gc_fast_table_mode(ctx) == 1;  // tables too large for single-wave workgroups
-  // by choice: with the prefix-sum variant (corr_fast.hip GC_FAST_PREFIX) every wave parks 8 KB of running sums in LDS, and
+  // by choice: every wave of the fast kernel parks 4-8 KB of running sums in LDS (corr_fast.hip), and
   // only four waves sharing an int8-pair table keep 16 waves per CU resident (big periodic replay lists, int8 I/Q, <= 2 arms)
   const bool big_list0 = nblocks >= 64 * (long long)period * ctx->compute_units;
   const bool choose_wide = fast > 0 && !must_wide && gc_fast_prefers_wide() && period > 0 && splits == 1 && big_list0 && notify_tag == 0 &&
