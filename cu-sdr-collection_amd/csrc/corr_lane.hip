@@ -141,6 +141,11 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   int* sstatus = reinterpret_cast<int*>(sblk + 1);
   double* dred = reinterpret_cast<double*>(smem + p.red_off + kLW * GC_OUT_STRIDE * sizeof(float) + 128);
   const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
+  DevLoopChan dl_st;  // DEVLOOP closer (member 0, wave 0): the channel's loop state, in registers across the epochs
+  if constexpr (DEVLOOP) {
+    if (member == 0 && wave == 0) dl_st = p.devloop->chan[min(wq, (long long)p.nblocks - 1)];
+  }
+  (void)dl_st;
   for (int bi = (DEVLOOP || wave_items) ? 0 : wave; bi < nloop; bi += (DEVLOOP || wave_items) ? 1 : kLW) {
   const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
@@ -538,7 +543,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
         if (lane < NS) msg_store(pm + member * NS + lane, msg_t{(unsigned int)bits, (unsigned int)(bits >> 32), tag, 0u});
       } else {
-        // the closer: the other workgroups' sums, one message per lane
+        // the closer: what does not need the sums first (the messages are still on their way), then the other workgroups'
+        // sums, one message per lane
+        const DevLoopPre dl_pre = devloop_pre(dl, dl_st, blk, R);
         const int nmsg = (p.splits - 1) * NS;
         msg_t m = {0u, 0u, 0u, 0u};
         unsigned int spins = 0;
@@ -551,6 +558,8 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         }
         int st;
         gc_block nxt = blk;
+        double dl_rv[GC_TRK_NFIELDS];
+        const int dl_arms = arms_here < ARMS ? arms_here : ARMS;
         if (spins > (1u << 22)) {
           st = 3;
         } else {
@@ -566,7 +575,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
             sums[v] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(bits >> 32), v) << 32) |
                                                        (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, v)));
           }
-          st = devloop_close<ARMS>(dl, dl->chan + lb, nxt, lb, bi, sums, arms_here < ARMS ? arms_here : ARMS, R, lane);
+#pragma unroll
+          for (int f = 0; f < GC_TRK_NFIELDS; ++f) dl_rv[f] = 0.0;
+          st = devloop_post<ARMS>(dl, dl_st, nxt, bi, sums, dl_arms, R, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
         }
         if (lane == 0) {
           *sblk = nxt;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) word = (lane == i) ? u.q[i] : word;
         if (lane < kDescWords && bi + 1 < nloop)
           msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u});
+        if (st != 3) devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, dl_arms, lane);  // records and state, off the critical path
       }
     }
     __syncthreads();  // the closer's workgroup waits for the new descriptor; the scratch is free again
