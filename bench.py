@@ -6,8 +6,8 @@ E/P/L correlators, 60 s of synthetic int8 I/Q IF at 18 Msps (2.16 GB resident in
 Doppler U(-5,5) kHz, seed 20241008+2.
 
   1. the record is synthesised in HBM (csrc/synth.hip);
-  2. closed-loop tracking (gc_track: one correlator launch per epoch for all channels, discriminators
-     and loop filters on the host) produces the per-epoch state -> reported as x real-time (closed loop);
+  2. closed-loop tracking (gc_track: discriminators and loop filters on the host, the correlator in a persistent
+     host-fed kernel) produces the per-epoch state -> reported as x real-time (closed loop);
   3. a "step" = ONE batched replay pass of the hot path over the whole record: all
      channels x epochs blocks (720 000) in one launch, descriptors and IF resident in HBM.
      `value` = channel-samples through the correlators per second (whole job, all ranks).

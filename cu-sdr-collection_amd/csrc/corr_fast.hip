@@ -179,7 +179,36 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   if constexpr (DEVLOOP) {
     // every member closes the loop itself (all-gather of the partial sums, see below), so from the second epoch on the
     // descriptor is the one it computed; the first one comes from the host
-    if (bi > 0) {
+    if (p.devloop->host_loop) {
+      // host-fed: member 0 polls the ten descriptor messages in host memory (one PCIe read per lane and round) and relays
+      // them to the team; the others poll the relay.  Bounded: a lost host must not hang the device.
+      const DevLoopArgs* dl = p.devloop;
+      const msg_t* dm = (split == 0 ? dl->host_desc : dl->desc_msg) + lb * kDescWords;
+      msg_t m = {0u, 0u, 0u, 0u};
+      unsigned int spins = 0;
+      while (true) {
+        if (lane < kDescWords) m = msg_load(dm + lane);
+        const bool ok = lane >= kDescWords || m.z == (unsigned int)bi + 1u || m.z == 0xffffffffu;  // 0xffffffff: stop, any epoch
+        if (__all(ok)) break;
+        if (++spins > (1u << 22)) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (spins > (1u << 22)) {
+        if (lane == 0) dl->chan[lb].status = 3;
+        if (split == 0 && lane < kDescWords) msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{3u, 0u, (unsigned int)bi + 1u, 0u});
+        break;
+      }
+      if (split == 0 && lane < kDescWords) msg_store(dl->desc_msg + lb * kDescWords + lane, m);
+      union {
+        gc_block b;
+        unsigned long long q[sizeof(gc_block) / 8];
+      } u;
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i)
+        u.q[i] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)m.y, i) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)m.x, i);
+      if (__builtin_amdgcn_readlane((int)m.x, kDescWords - 1) != 0) break;  // status word: channel finished / record exhausted
+      blk = u.b;
+    } else if (bi > 0) {
       blk = dl_next;
     } else {
       if (dl_st.status != 0) break;  // record exhausted before the first block (tracking.m:241-245)
@@ -515,6 +544,25 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     double sums[6];
 #pragma unroll
     for (int v = 0; v < 6; ++v) sums[v] = rl_f64(part[v % 3], v < 3 ? 31 : 63);
+    if (dl->host_loop) {
+      // host-fed: member 0 hands the team's six sums to the host as tagged records (one 16-byte store per lane) and the
+      // loop goes back to waiting for the host's next descriptor
+      if (split == 0) {
+        TaggedSlot* ts = reinterpret_cast<TaggedSlot*>(dl->host_tagged) + lb * GC_OUT_STRIDE;
+        double mine = 0.0;
+#pragma unroll
+        for (int v = 0; v < 6; ++v) mine = (lane == v) ? sums[v] : mine;
+        if (lane < 6) {
+          TaggedSlot rec;
+          rec.value = mine;
+          rec.tag = tag;
+          rec.zero = 0u;
+          *reinterpret_cast<uint4*>(ts + lane) = *reinterpret_cast<const uint4*>(&rec);
+        }
+        __threadfence_system();  // out of the L2 now: this wave goes on polling, not to a kernel end
+      }
+      continue;
+    }
     dl_next = blk;
     double dl_rv[GC_TRK_NFIELDS];
     const int st = devloop_post<1>(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; });

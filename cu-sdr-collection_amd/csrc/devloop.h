@@ -50,7 +50,13 @@ struct DevLoopArgs {
   int code_index_scale_is_one;  // R == 1 (the only case wired up)
   int reserved;                 // message scope (msg_load / msg_store): 0 = system
   int timing;                   // GC_DEVLOOP_TIMING: the closer accumulates its phase clocks in DevLoopChan::pad (costs ~1 us per epoch)
-  int pad_;
+  // Host-fed variant (gc_track's persistent mode): the HOST closes the loop (tracking.m:302-335 stay where the reference has
+  // them) but nothing is launched per epoch: member 0 of a team polls the channel's descriptor messages in host-mapped
+  // memory (tag = epoch + 1), relays them to its team through desc_msg, and every member writes its six partial sums as
+  // tagged 16-byte records straight into host-mapped memory, where the host polls them.
+  int host_loop;
+  const msg_t* host_desc;       // [nch][kDescWords], host-mapped
+  void* host_tagged;            // TaggedSlot [nch][splits][GC_OUT_STRIDE], host-mapped
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)

@@ -145,6 +145,113 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   const int n_epochs = p->n_epochs;
   std::fill(out, out + (size_t)nch * GC_TRK_NFIELDS * n_epochs, 0.0);
 
+  // Persistent mode: the loop is still closed HERE (tracking.m:302-335 below), but nothing is launched per epoch - one
+  // cooperative launch of the fast kernel's persistent instantiation polls the descriptors this loop writes into
+  // host-mapped memory and answers with tagged records (devloop.h, host_loop).  Launch-per-epoch costs ~5 us of dispatch
+  // latency and ~13 us of kernel wall time per epoch; the persistent kernel answers in a few microseconds.  Covered:
+  // single-arm R = 1 channels on the transition-mask kernel with one-wave workgroups, int8 I/Q or Q/I (GPS L1 C/A, BDS B1I,
+  // GLONASS); everything else keeps launching.
+  bool persist = poll && !any_mixed && max_arms == 1 && fast_nominal > 0 && gc_fast_table_mode(ctx) == 0 && p->pilot_combine == 0 &&
+                 p->table_phase_count == 0 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && n_epochs > 0 &&
+                 !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
+  for (int c = 0; c < nch && persist; ++c) {
+    const HostChannel& hcn = ctx->ch[init[c].channel];
+    persist = hcn.arms == 1 && hcn.index_scale == 1.0 && hcn.mult[0] == 1.0 && hcn.window[0] == 0;
+  }
+  gcorr::DevLoopArgs pa;
+  std::memset(&pa, 0, sizeof pa);
+  gcorr::DevLoopArgs* d_pargs = nullptr;
+  gcorr::msg_t* h_desc = nullptr;  // host-mapped descriptor messages [nch][kDescWords]
+  auto persist_free = [&]() {
+    if (pa.chan) (void)hipFree(pa.chan);
+    if (pa.desc_msg) (void)hipFree(pa.desc_msg);
+    if (pa.part_msg) (void)hipFree(pa.part_msg);
+    pa.part_msg = nullptr;
+    if (d_pargs) (void)hipFree(d_pargs);
+    if (h_desc) (void)hipHostFree(h_desc);
+    pa.chan = nullptr;
+    pa.desc_msg = nullptr;
+    d_pargs = nullptr;
+    h_desc = nullptr;
+  };
+  // descriptor of team c for epoch e (tag e + 1): payload first, tag last - a device read that sees the tag sees the payload
+  auto write_desc = [&](int c, int e, const gc_block* b, unsigned long long status_word) {
+    unsigned long long q[gcorr::kDescWords] = {0};
+    if (b) std::memcpy(q, b, sizeof(gc_block));
+    q[gcorr::kDescWords - 1] = status_word;
+    volatile unsigned int* w = reinterpret_cast<volatile unsigned int*>(h_desc + (size_t)c * gcorr::kDescWords);
+    for (int i = 0; i < gcorr::kDescWords; ++i) {
+      w[4 * i + 0] = (unsigned int)q[i];
+      w[4 * i + 1] = (unsigned int)(q[i] >> 32);
+      w[4 * i + 3] = 0u;
+    }
+    std::atomic_thread_fence(std::memory_order_release);
+    for (int i = 0; i < gcorr::kDescWords; ++i) w[4 * i + 2] = (unsigned int)e + 1u;
+    std::atomic_thread_fence(std::memory_order_release);
+  };
+  // every team stops whatever epoch it is waiting for (tag 0xffffffff is accepted for any epoch)
+  auto persist_stop = [&]() {
+    for (int c = 0; c < nch; ++c) {
+      volatile unsigned int* w = reinterpret_cast<volatile unsigned int*>(h_desc + (size_t)c * gcorr::kDescWords);
+      for (int i = 0; i < gcorr::kDescWords; ++i) {
+        w[4 * i + 0] = 3u;
+        w[4 * i + 1] = 0u;
+      }
+      std::atomic_thread_fence(std::memory_order_release);
+      for (int i = 0; i < gcorr::kDescWords; ++i) w[4 * i + 2] = 0xffffffffu;
+    }
+    std::atomic_thread_fence(std::memory_order_release);
+  };
+  // members per team of the persistent kernel (its all-gather covers up to 32); the host sees ONE record group per channel
+  int psplits_dev = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8) / 48)}));
+  if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(32, std::atoi(ev)));
+  if (persist) {
+    pa.n_epochs = n_epochs;
+    pa.splits = psplits_dev;
+    pa.if_nsamples = ctx->if_nsamples;
+    pa.host_loop = 1;
+    pa.host_tagged = ctx->h_tagged_pinned;
+    std::vector<gcorr::DevLoopChan> hc((size_t)nch);
+    std::memset(hc.data(), 0, sizeof(gcorr::DevLoopChan) * (size_t)nch);
+    for (int c = 0; c < nch; ++c) hc[c].blk.channel = init[c].channel;  // table staging needs the channel of each team
+    hipError_t e = hipMalloc((void**)&pa.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
+    if (e == hipSuccess) e = hipMalloc((void**)&pa.desc_msg, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords);
+    const size_t ppart = sizeof(gcorr::msg_t) * (size_t)nch * 2 * psplits_dev * 2;  // all-gather message halves of the teams
+    if (e == hipSuccess) e = hipMalloc((void**)&pa.part_msg, ppart);
+    if (e == hipSuccess) e = hipMemsetAsync(pa.part_msg, 0, ppart, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_pargs, sizeof pa);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h_desc, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords, hipHostMallocMapped);
+    if (e == hipSuccess) {
+      std::memset(h_desc, 0, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords);
+      pa.host_desc = h_desc;
+      e = hipMemsetAsync(pa.desc_msg, 0, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(pa.chan, hc.data(), sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pargs, &pa, sizeof pa, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) {
+      gcorr::KArgs a;
+      std::memset(&a, 0, sizeof a);
+      a.if_base = ctx->d_if;
+      a.chans = ctx->d_channels;
+      a.fs = ctx->fs;
+      a.inv_fs = 1.0 / ctx->fs;
+      a.nblocks = nch;
+      a.splits = psplits_dev;
+      a.bpw = 1;
+      a.stride = 1;
+      a.share_el = (p->el_spacing == 0.5) ? 1 : 0;
+      a.devloop = d_pargs;
+      a.xcd_swizzle = 0;
+      if (gc_launch_devloop(ctx, a, (unsigned int)(nch * psplits_dev), fast_nominal == 2, a.share_el != 0) != GC_OK) e = hipErrorUnknown;
+    }
+    if (e != hipSuccess) {  // could not set the persistent kernel up: launch per epoch
+      (void)hipGetLastError();
+      persist_free();
+      persist = false;
+    }
+  }
+
   double tau1code, tau2code, tau1carr, tau2carr;
   calc_loop_coef(p->dll_noise_bw, p->dll_damping, 1.0, &tau1code, &tau2code);   // tracking.m:100-102
   calc_loop_coef(p->pll_noise_bw, p->pll_damping, 0.25, &tau1carr, &tau2carr);  // tracking.m:109-110
@@ -162,6 +269,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
 
   std::vector<int> slot((size_t)nch);
   bool any_range = false;
+  double t_launch = 0.0, t_wait = 0.0;  // GC_TRACK_TIMING: host time in the launch call / until the records arrived
+  const auto t_loop0 = std::chrono::steady_clock::now();
   for (int e = 0; e < n_epochs; ++e) {
     int nb = 0;
     for (int c = 0; c < nch; ++c) {
@@ -173,6 +282,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
         s.active = false;
         s.aborted = true;
         any_range = true;
+        if (persist) write_desc(c, e, nullptr, 2ull);  // this channel's team stops
         continue;
       }
       gc_block& b = blocks[nb];
@@ -201,21 +311,30 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     for (int k = 0; k < nb && ctx->scope_share_lane; ++k) ctx->scope_share_lane = gc_block_shares_el_lane(ctx, blocks[k]);
     const unsigned int tag = (unsigned int)(e + 1);
     const bool polled = poll && fast >= 0;
-    rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast, 0,
-                              polled ? tag : 0u, share);
-    if (rc) return rc;
+    const auto tt0 = std::chrono::steady_clock::now();
+    if (persist) {
+      for (int k = 0; k < nb; ++k) write_desc(slot[k], e, &blocks[k], 0ull);
+    } else {
+      rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast, 0,
+                                polled ? tag : 0u, share);
+      if (rc) return rc;
+    }
+    const auto tt1 = std::chrono::steady_clock::now();
     bool signalled = false;
     if (polled) {
       // wait until every record of this launch carries the epoch tag (bounded: never hang here)
       const auto t0 = std::chrono::steady_clock::now();
       const int arms6 = max_arms * 6;
       signalled = true;
-      for (int k = 0; k < nb * splits && signalled; ++k)
+      const int hs = persist ? 1 : splits;  // record groups per block as the host sees them (the persistent kernel's teams add up on the device)
+      for (int k = 0; k < nb * hs && signalled; ++k)
         for (int v = 0; v < arms6; ++v) {
-          volatile gcorr::TaggedSlot* s = tagged + (size_t)k * GC_OUT_STRIDE + v;
+          // record group of (block, split): blocks are numbered per launch, teams of the persistent kernel per channel
+          const size_t grp = persist ? (size_t)slot[k] : (size_t)k;
+          volatile gcorr::TaggedSlot* s = tagged + grp * GC_OUT_STRIDE + v;
           unsigned int spins = 0;
           while (s->tag != tag) {
-            if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds((persist && e == 0) ? 5000 : 50)) {  // first epoch of the persistent kernel: code load + cooperative launch
               signalled = false;
               break;
             }
@@ -224,9 +343,20 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
         }
       std::atomic_thread_fence(std::memory_order_acquire);
     }
+    const auto tt2 = std::chrono::steady_clock::now();
+    t_launch += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
+    t_wait += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
     if (!signalled) {
+      if (persist && std::getenv("GC_TRACK_TIMING")) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        std::fprintf(stderr, "gc_track persistent: epoch %d records missing; stream: %s; first tags:", e, hipGetErrorString(q));
+        for (int k = 0; k < std::min(nb, 16); ++k) std::fprintf(stderr, " %u", tagged[(size_t)slot[k] * GC_OUT_STRIDE].tag);
+        std::fprintf(stderr, "\n");
+      }
+      if (persist) persist_stop();
       GC_HIP(hipStreamSynchronize(ctx->stream));
       if (polled) {
+        persist_free();
         gc_set_error("gc_track: result records of epoch %d did not arrive", e);
         return GC_E_HIP;
       }
@@ -240,8 +370,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       double sums[GC_OUT_STRIDE];
       for (int v = 0; v < GC_OUT_STRIDE; ++v) {
         double acc = 0.0;
-        for (int sp = 0; sp < splits; ++sp)
-          acc += polled ? ((v < max_arms * 6) ? tagged[((size_t)k * splits + sp) * GC_OUT_STRIDE + v].value : 0.0)
+        for (int sp = 0; sp < (persist ? 1 : splits); ++sp)
+          acc += polled ? ((v < max_arms * 6) ? tagged[(persist ? (size_t)c : (size_t)k * splits + sp) * GC_OUT_STRIDE + v].value : 0.0)
                         : partial[((size_t)k * splits + sp) * GC_OUT_STRIDE + v];
         sums[v] = acc;
       }
@@ -382,6 +512,17 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       epochs_done[c] = st[c].epochs;
     }
   }
+  const bool persist_was = persist;
+  if (persist) {  // teams that were not told to stop leave after n_epochs by themselves; the others were stopped above
+    persist_stop();
+    (void)hipStreamSynchronize(ctx->stream);
+    persist_free();
+  }
+  if (std::getenv("GC_TRACK_TIMING") && n_epochs > 0)
+    std::fprintf(stderr, "gc_track: per epoch %.2f us in the launch call / descriptor writes, %.2f us until the records arrived, %.2f us total (%s, %d workgroups per block)\n",
+                 t_launch / n_epochs, t_wait / n_epochs,
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count() / n_epochs,
+                 persist_was ? "persistent kernel" : "launch per epoch", persist_was ? psplits_dev : splits);
   if (any_range) {
     gc_set_error("Not able to read the specified number of samples for tracking");
     return GC_E_RANGE;
