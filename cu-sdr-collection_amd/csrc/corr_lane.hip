@@ -153,16 +153,19 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   if constexpr (DEVLOOP) {
     if (wave == 0 && !(member == 0 && bi > 0)) {
       // wave 0 polls the ten descriptor messages (one per lane) and hands the descriptor to the workgroup through LDS
-      const msg_t* dm = p.devloop->desc_msg + lb * kDescWords;
+      // host-fed run (DevLoopArgs::host_loop): the first descriptor comes from host memory to member 0, which relays it
+      const bool from_host = p.devloop->host_loop && member == 0;
+      const msg_t* dm = (from_host ? p.devloop->host_desc : p.devloop->desc_msg) + lb * kDescWords;
       msg_t m = {0u, 0u, 0u, 0u};
       unsigned int spins = 0;
       while (true) {
         if (lane < kDescWords) m = msg_load(dm + lane);
-        const bool ok = lane >= kDescWords || m.z == (unsigned int)bi + 1u;
+        const bool ok = lane >= kDescWords || m.z == (unsigned int)bi + 1u || m.z == 0xffffffffu;  // 0xffffffff: stop, any epoch
         if (__all(ok)) break;
         if (++spins > (1u << 22)) break;
         __builtin_amdgcn_s_sleep(1);
       }
+      if (from_host && lane < kDescWords && spins <= (1u << 22)) msg_store(p.devloop->desc_msg + lb * kDescWords + lane, m);
       union {
         gc_block b;
         unsigned long long q[sizeof(gc_block) / 8];
@@ -577,7 +580,42 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
           }
 #pragma unroll
           for (int f = 0; f < GC_TRK_NFIELDS; ++f) dl_rv[f] = 0.0;
-          st = devloop_post<ARMS>(dl, dl_st, nxt, bi, sums, dl_arms, R, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
+          if (dl->host_loop) {
+            // host-fed: the team's sums go to the host as tagged records (lane v holds component v), a system fence pushes them
+            // out of the L2, and the next descriptor comes back from host memory (tag bi + 2); the relay below is the usual one
+            if (lane < NS) {
+              TaggedSlot rec;
+              rec.value = mine;
+              rec.tag = tag;
+              rec.zero = 0u;
+              *reinterpret_cast<uint4*>(reinterpret_cast<TaggedSlot*>(dl->host_tagged) + lb * GC_OUT_STRIDE + lane) = *reinterpret_cast<const uint4*>(&rec);
+            }
+            __threadfence_system();
+            st = 1;
+            if (bi + 1 < nloop) {
+              const msg_t* hd = dl->host_desc + lb * kDescWords;
+              msg_t hm = {0u, 0u, 0u, 0u};
+              unsigned int hs = 0;
+              while (true) {
+                if (lane < kDescWords) hm = msg_load(hd + lane);
+                const bool ok = lane >= kDescWords || hm.z == tag + 1u || hm.z == 0xffffffffu;
+                if (__all(ok)) break;
+                if (++hs > (1u << 22)) break;
+                __builtin_amdgcn_s_sleep(2);
+              }
+              union {
+                gc_block b;
+                unsigned long long q[sizeof(gc_block) / 8];
+              } hu;
+#pragma unroll
+              for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i)
+                hu.q[i] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hm.y, i) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)hm.x, i);
+              nxt = hu.b;
+              st = (hs > (1u << 22)) ? 3 : __builtin_amdgcn_readlane((int)hm.x, kDescWords - 1);  // status word of the host's descriptor
+            }
+          } else {
+            st = devloop_post<ARMS>(dl, dl_st, nxt, bi, sums, dl_arms, R, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
+          }
         }
         if (lane == 0) {
           *sblk = nxt;
@@ -594,7 +632,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         for (int i = 0; i < (int)(sizeof(gc_block) / 8); ++i) word = (lane == i) ? u.q[i] : word;
         if (lane < kDescWords && bi + 1 < nloop)
           msg_store(dl->desc_msg + lb * kDescWords + lane, msg_t{(unsigned int)word, (unsigned int)(word >> 32), tag + 1u, 0u});
-        if (st != 3) devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, dl_arms, lane);  // records and state, off the critical path
+        if (st != 3 && !dl->host_loop) devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, dl_arms, lane);  // records and state, off the critical path
       }
     }
     __syncthreads();  // the closer's workgroup waits for the new descriptor; the scratch is free again

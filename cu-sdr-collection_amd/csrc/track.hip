@@ -158,6 +158,23 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     const HostChannel& hcn = ctx->ch[init[c].channel];
     persist = hcn.arms == 1 && hcn.index_scale == 1.0 && hcn.mult[0] == 1.0 && hcn.window[0] == 0;
   }
+  // ... and on the lane kernel's persistent instantiation (corr_lane.hip, host_loop) for one- and two-arm channels of any
+  // rate and index scale (GPS L5, BDS B2a / B3I, Galileo E5a / E5b / E1 B+C, BDS B1C narrow-band): member 0's first wave
+  // gathers the team's sums, hands them to the host and relays the host's next descriptor
+  bool persist_lane = !persist && poll && !any_mixed && max_arms <= 2 && p->table_phase_count == 0 && ctx->if_dtype == GC_I8 &&
+                      ctx->if_layout != GC_REAL && n_epochs > 0 &&
+                      !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
+  bool share_lane_nominal = true;
+  for (int c = 0; c < nch && persist_lane; ++c) {
+    const HostChannel& hcn = ctx->ch[init[c].channel];
+    for (int a = 0; a < hcn.arms; ++a) persist_lane = persist_lane && hcn.window[a] == 0;
+    gc_block probe;
+    std::memset(&probe, 0, sizeof probe);
+    probe.channel = init[c].channel;
+    probe.el_spacing = p->el_spacing;
+    share_lane_nominal = share_lane_nominal && gc_block_shares_el_lane(ctx, probe);
+  }
+  if (persist_lane) persist = true;
   gcorr::DevLoopArgs pa;
   std::memset(&pa, 0, sizeof pa);
   gcorr::DevLoopArgs* d_pargs = nullptr;
@@ -204,7 +221,9 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   };
   // members per team of the persistent kernel (its all-gather covers up to 32); the host sees ONE record group per channel
   int psplits_dev = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8) / 48)}));
-  if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(32, std::atoi(ev)));
+  if (persist_lane)  // members of a lane-kernel team: workgroups of 8 waves (as gc_track_device)
+    psplits_dev = std::max(1, std::min({max_arms == 1 ? 8 : 6, approx_chunks * 8 / (64 * 8 * 2), std::max(1, 2 * ctx->compute_units / nch)}));
+  if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(persist_lane ? (max_arms == 1 ? 8 : 6) : 32, std::atoi(ev)));
   if (persist) {
     pa.n_epochs = n_epochs;
     pa.splits = psplits_dev;
@@ -216,7 +235,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     for (int c = 0; c < nch; ++c) hc[c].blk.channel = init[c].channel;  // table staging needs the channel of each team
     hipError_t e = hipMalloc((void**)&pa.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
     if (e == hipSuccess) e = hipMalloc((void**)&pa.desc_msg, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords);
-    const size_t ppart = sizeof(gcorr::msg_t) * (size_t)nch * 2 * psplits_dev * 2;  // all-gather message halves of the teams
+    const size_t ppart = sizeof(gcorr::msg_t) * (size_t)nch * psplits_dev * (persist_lane ? 6 * max_arms : 2 * 2);  // the teams' partial-sum messages
     if (e == hipSuccess) e = hipMalloc((void**)&pa.part_msg, ppart);
     if (e == hipSuccess) e = hipMemsetAsync(pa.part_msg, 0, ppart, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&d_pargs, sizeof pa);
@@ -243,12 +262,18 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       a.share_el = (p->el_spacing == 0.5) ? 1 : 0;
       a.devloop = d_pargs;
       a.xcd_swizzle = 0;
-      if (gc_launch_devloop(ctx, a, (unsigned int)(nch * psplits_dev), fast_nominal == 2, a.share_el != 0) != GC_OK) e = hipErrorUnknown;
+      if (persist_lane) {
+        a.share_el = 0;
+        if (gc_launch_devloop_lane(ctx, a, (unsigned int)(nch * psplits_dev), max_arms, share_lane_nominal, 8) != GC_OK) e = hipErrorUnknown;
+      } else if (gc_launch_devloop(ctx, a, (unsigned int)(nch * psplits_dev), fast_nominal == 2, a.share_el != 0) != GC_OK) {
+        e = hipErrorUnknown;
+      }
     }
     if (e != hipSuccess) {  // could not set the persistent kernel up: launch per epoch
       (void)hipGetLastError();
       persist_free();
       persist = false;
+      persist_lane = false;
     }
   }
 
@@ -522,7 +547,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     std::fprintf(stderr, "gc_track: per epoch %.2f us in the launch call / descriptor writes, %.2f us until the records arrived, %.2f us total (%s, %d workgroups per block)\n",
                  t_launch / n_epochs, t_wait / n_epochs,
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count() / n_epochs,
-                 persist_was ? "persistent kernel" : "launch per epoch", persist_was ? psplits_dev : splits);
+                 persist_was ? (persist_lane ? "persistent lane kernel" : "persistent kernel") : "launch per epoch", persist_was ? psplits_dev : splits);
   if (any_range) {
     gc_set_error("Not able to read the specified number of samples for tracking");
     return GC_E_RANGE;
