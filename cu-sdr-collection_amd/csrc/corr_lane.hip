@@ -732,9 +732,10 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   KArgs a = a_in;
   InlineBlocks ib;
   std::memset(&ib, 0, sizeof ib);
-  const int ap = gc_arm_pitch(max_arms);
+  const bool der = a.derived != 0 && max_arms == 3;  // third arm derived from the second: two tables in LDS (host-fed runs only)
+  const int ap = gc_arm_pitch(der ? 2 : max_arms);
   const size_t tab_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 4 + 15) / 16 * 16;
-  if (tab_bytes > 96 * 1024 || max_arms > 2 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
+  if (tab_bytes > 96 * 1024 || (max_arms > 2 && !der) || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
     gc_set_error("device loop on the lane kernel: tables above 96 KiB as f32, three arms or non-int8-I/Q records are not instantiated");
     return GC_E_UNSUPPORTED;
   }
@@ -742,6 +743,13 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   const size_t smem = tab_bytes + kLW * GC_OUT_STRIDE * sizeof(float) + 128 + 64 * sizeof(double);
   const bool qi = ctx->if_layout == GC_QI;
   if (waves < 1 || waves > kLW) return GC_E_INVALID;
+  if (der) {
+    void* args[2] = {(void*)&a, (void*)&ib};
+    const void* fn = qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 0, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>;
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    GC_HIP(hipLaunchCooperativeKernel(fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem, ctx->stream));
+    return GC_OK;
+  }
   if (max_arms == 1) return qi ? launch_lane_devloop<1, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el, waves) : launch_lane_devloop<1, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el, waves);
   return qi ? launch_lane_devloop<2, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el, waves) : launch_lane_devloop<2, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el, waves);
 }

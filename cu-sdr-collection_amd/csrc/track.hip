@@ -161,7 +161,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   // ... and on the lane kernel's persistent instantiation (corr_lane.hip, host_loop) for one- and two-arm channels of any
   // rate and index scale (GPS L5, BDS B2a / B3I, Galileo E5a / E5b / E1 B+C, BDS B1C narrow-band): member 0's first wave
   // gathers the team's sums, hands them to the host and relays the host's next descriptor
-  bool persist_lane = !persist && poll && !any_mixed && max_arms <= 2 && p->table_phase_count == 0 && ctx->if_dtype == GC_I8 &&
+  const bool derived_nominal = any_mixed && all_mixed_derived && !any_three_plain;  // three arms, the third derived (E1-C CBOC)
+  bool persist_lane = !persist && poll && ((!any_mixed && max_arms <= 2) || derived_nominal) && p->table_phase_count == 0 && ctx->if_dtype == GC_I8 &&
                       ctx->if_layout != GC_REAL && n_epochs > 0 &&
                       !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
   bool share_lane_nominal = true;
@@ -222,8 +223,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   // members per team of the persistent kernel (its all-gather covers up to 32); the host sees ONE record group per channel
   int psplits_dev = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8) / 48)}));
   if (persist_lane)  // members of a lane-kernel team: workgroups of 8 waves (as gc_track_device)
-    psplits_dev = std::max(1, std::min({max_arms == 1 ? 8 : 6, approx_chunks * 8 / (64 * 8 * 2), std::max(1, 2 * ctx->compute_units / nch)}));
-  if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(persist_lane ? (max_arms == 1 ? 8 : 6) : 32, std::atoi(ev)));
+    psplits_dev = std::max(1, std::min({max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4, approx_chunks * 8 / (64 * 8 * 2), std::max(1, 2 * ctx->compute_units / nch)}));
+  if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(persist_lane ? (max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4) : 32, std::atoi(ev)));
   if (persist) {
     pa.n_epochs = n_epochs;
     pa.splits = psplits_dev;
@@ -264,11 +265,13 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       a.xcd_swizzle = 0;
       if (persist_lane) {
         a.share_el = 0;
-        if (gc_launch_devloop_lane(ctx, a, (unsigned int)(nch * psplits_dev), max_arms, share_lane_nominal, 8) != GC_OK) e = hipErrorUnknown;
+        a.derived = derived_nominal ? 1 : 0;
+        if (gc_launch_devloop_lane(ctx, a, (unsigned int)(nch * psplits_dev), max_arms, share_lane_nominal && !derived_nominal, 8) != GC_OK) e = hipErrorUnknown;
       } else if (gc_launch_devloop(ctx, a, (unsigned int)(nch * psplits_dev), fast_nominal == 2, a.share_el != 0) != GC_OK) {
         e = hipErrorUnknown;
       }
     }
+    if (e == hipSuccess) ctx->last_kernel = persist_lane ? 0 : 1;  // gc_debug_last_kernel: lane / fast kernel (persistent instantiation)
     if (e != hipSuccess) {  // could not set the persistent kernel up: launch per epoch
       (void)hipGetLastError();
       persist_free();
