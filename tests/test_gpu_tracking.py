@@ -618,3 +618,27 @@ def test_config4_l5_and_b2a_at_50_msps(engine):
     _ten23_case(engine, S, "BDS_B2a", P.codes.generateB2aDataCode, P.codes.generateB2aPilotCode,
                 lambda prn: [O.pad_code(O.generate_b2a_code(prn, "data")), O.pad_code(O.generate_b2a_code(prn, "pilot"))],
                 "a", 1150.0, (20, 44), 53)
+
+
+def test_persistent_and_launch_per_epoch_host_loops_agree(engine, l1ca_scene, monkeypatch):
+    """gc_track closes the loop on the host either way; the correlator runs as one persistent, host-fed kernel (default where
+    the configuration allows it) or as one launch per epoch (GC_TRACK_PERSIST=0).  Same block geometry, sums within the
+    float32 tolerance (the partial sums are cut differently: 23 team members against 8 workgroups per block)."""
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene
+    S.msToProcess = 150
+    S.numberOfChannels = 4
+    ch = _channels(S, sats, 4)
+    engine.load_if(iq, fs=S.samplingFreq)
+    a, _ = P.tracking(engine, ch, S)
+    assert engine.last_kernel() == 1
+    monkeypatch.setenv("GC_TRACK_PERSIST", "0")
+    b, _ = P.tracking(engine, ch, S)
+    monkeypatch.delenv("GC_TRACK_PERSIST")
+    scale = 2.0 * 18000 * 28.0
+    for k in range(4):
+        assert a[k].status == "T" and b[k].status == "T"
+        assert np.array_equal(a[k].absoluteSample, b[k].absoluteSample)
+        for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L"):
+            assert np.max(np.abs(getattr(a[k], f) - getattr(b[k], f))) < 1e-6 * scale, (k, f)
+        assert np.max(np.abs(a[k].carrFreq - b[k].carrFreq)) < 1e-4
