@@ -128,7 +128,16 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
                     (sqrt(i_e * i_e + q_e * q_e) + sqrt(i_l * i_l + q_l * q_l));  // :322-323
   if constexpr (MAXARMS >= 2) {
   if (p.pilot_combine != 0 && arms >= 2) {
-    const double pi_e = sums[6], pq_e = sums[7], pi_p = sums[8], pq_p = sums[9], pi_l = sums[10], pq_l = sums[11];
+    double p6[6] = {sums[6], sums[7], sums[8], sums[9], sums[10], sums[11]};  // the pilot arm as correlated
+    if constexpr (MAXARMS >= 3) {
+      if (p.pilot_combine == 5 && arms >= 3) {
+        // Galileo E1-C CBOC(6,1,1/11): arms {data, pilot BOC(1,1), pilot BOC(6,1)} folded in phase, then as mode 2 (track.hip)
+        const double a11 = sqrt(10.0 / 11.0), a61 = -sqrt(1.0 / 11.0);
+#pragma unroll
+        for (int v = 0; v < 6; ++v) p6[v] = a11 * sums[6 + v] + a61 * sums[12 + v];
+      }
+    }
+    const double pi_e = p6[0], pq_e = p6[1], pi_p = p6[2], pq_p = p6[3], pi_l = p6[4], pq_l = p6[5];
     double carr_err_q;
     if (p.pilot_combine == 1) {  // QI = (I_PQ + 1i*Q_PQ) * exp(-1i*pi/2), GPS_L5C tracking.m:340
       const double cr = cos(kPi / 2), ci = -sin(kPi / 2);

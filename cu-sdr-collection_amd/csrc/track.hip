@@ -578,7 +578,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (rc) return rc;
   gc_scope_reset(ctx);
   int max_arms = 1;
-  bool single_r1 = true;
+  bool single_r1 = true, all_derived = true;
   for (int c = 0; c < nch; ++c) {
     const int ci = init[c].channel;
     if (ci < 0 || ci >= GC_MAX_CHANNELS || !ctx->ch[ci].configured || !ctx->ch[ci].d_tab[0]) {
@@ -586,8 +586,10 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
       return GC_E_STATE;
     }
     const HostChannel& hcn = ctx->ch[ci];
+    const bool hder = gc_channel_is_derived(hcn);  // three arms, the third derived from the second inside the lane kernel
+    all_derived = all_derived && hder;
     for (int a = 0; a < hcn.arms; ++a)
-      if (!hcn.d_tab[a] || hcn.mult[a] != 1.0 || hcn.window[a] != 0) {
+      if (!hcn.d_tab[a] || (hcn.mult[a] != 1.0 && !(hder && a == 2)) || hcn.window[a] != 0) {
         gc_set_error("gc_track_device: windowed tables / ramp multipliers are not covered (use gc_track)");
         return GC_E_UNSUPPORTED;
       }
@@ -595,7 +597,8 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     single_r1 = single_r1 && hcn.arms == 1 && hcn.index_scale == 1.0;
     gc_scope_add(ctx, ci);
   }
-  if (max_arms > 2 || p->pilot_combine > 3 || (p->pilot_combine != 0 && max_arms < 2) || p->table_phase_count != 0 ||
+  const bool cboc = max_arms == 3 && all_derived && p->pilot_combine == 5;  // Galileo E1-C CBOC: three arms, the third derived
+  if ((max_arms > 2 && !cboc) || (p->pilot_combine > 3 && !cboc) || (p->pilot_combine != 0 && max_arms < 2) || p->table_phase_count != 0 ||
       ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
     gc_set_error("gc_track_device: configuration not covered by the persistent kernels (use gc_track)");
     return GC_E_UNSUPPORTED;
@@ -644,8 +647,9 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     const int nsamp = hc[0].blk.blksize;
     lane_waves = 8;  // measured best for both the 1-ms and the 4-ms packages (scripts/devloop_lane_sweep.py)
     if (const char* e = std::getenv("GC_DEVLOOP_WAVES")) lane_waves = std::max(1, std::min(8, std::atoi(e)));  // the device-loop instantiations are bounded to 8 waves
-    splits = std::max(1, std::min({max_arms == 1 ? 8 : 6, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch)}));
-    if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_arms == 1 ? 8 : 6, std::atoi(e)));
+    const int max_members = max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4;  // (members - 1) * 6 * arms messages <= 64 lanes
+    splits = std::max(1, std::min({max_members, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch)}));
+    if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_members, std::atoi(e)));
     msgs_per_member = 6 * max_arms;
   }
   const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr;  // teams on one XCD each (default)
@@ -713,7 +717,8 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   a.devloop = d_args;
   a.xcd_swizzle = xcd_local ? 1 : 0;
   const unsigned int grid = xcd_local ? (unsigned int)(((nch + 7) / 8) * 8 * splits) : (unsigned int)(nch * splits);
-  rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane, lane_waves);
+  a.derived = cboc ? 1 : 0;
+  rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane && !cboc, lane_waves);
   if (rc == GC_OK) {
     const auto t_l = std::chrono::steady_clock::now();
     e = hipStreamSynchronize(ctx->stream);

@@ -215,8 +215,9 @@ int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channe
  * no fences) and execute tracking.m:302-335 in float64 themselves (csrc/devloop.h).  Covered: int8 I/Q or Q/I records;
  * single-arm R = 1 channels on the transition-mask kernel (GPS L1 C/A, GLONASS L1OF, BDS B1I) and one- or two-arm
  * channels of any rate and index scale with pilot_combine 0-3 on the lane kernel (GPS L5, BDS B2a / B3I, Galileo E5a /
- * E5b / E1 B+C, BDS B1C narrow-band).  Three-arm or mixed-multiplier channels (pilot_combine 4, 5), windowed tables
- * (GPS L2C CL), int16 and real records return GC_E_UNSUPPORTED: use gc_track. */
+ * E5b / E1 B+C, BDS B1C narrow-band), and the three-arm Galileo E1-C CBOC fold (pilot_combine 5, third arm derived).
+ * Other three-arm or mixed-multiplier channels (pilot_combine 4), windowed tables (GPS L2C CL), int16 and real records
+ * return GC_E_UNSUPPORTED: use gc_track. */
 int gc_track_device(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
                     double* out, int32_t* epochs_done);
 

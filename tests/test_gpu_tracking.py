@@ -586,6 +586,13 @@ def test_galileo_e1c_cboc_pilot_tracking_matches_oracle(engine):
         pm = np.hypot(tr[k].Pilot_I_P, tr[k].Pilot_Q_P)[4:]
         dm = np.hypot(tr[k].I_P, tr[k].Q_P)[4:]
         assert 0.85 < np.mean(pm) / np.mean(dm) < 1.05
+    # the loop closed on the device as well (lane kernel, derived arm, pilot fold in devloop_post)
+    dev, _ = P.tracking(engine, ch, S, signal="GAL_E1C_CBOC", device_loop=True)
+    for k in range(2):
+        assert dev[k].status == "T" and np.array_equal(dev[k].absoluteSample, ref[k].absoluteSample)
+        for f in ("I_P", "Q_P", "Pilot_I_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L"):
+            assert np.max(np.abs(getattr(dev[k], f) - getattr(ref[k], f))) < 1e-5 * 2.0 * 72000 * 28.0, f
+        assert np.max(np.abs(dev[k].carrFreq - ref[k].carrFreq)) < 1e-3
     # the same through the exact per-sample kernel
     import os
     os.environ["GC_NO_DERIVED_ARM"] = "1"
