@@ -32,3 +32,30 @@ def merge_acq_results(per_rank):
     for f in vars(per_rank[0]):
         setattr(out, f, np.sum([np.asarray(getattr(r, f)) for r in per_rank], axis=0))
     return out
+
+
+def broadcast_record(record, src: int = 0, device=None):
+    """The one exchange step of the sharded path: the rank that read the IF file hands the raw record to the
+    ranks that track other channels of the same band.  `record`: a 1-D torch int8 / int16 tensor on rank `src` (ignored
+    elsewhere).  With tensors on the GPUs and the process group's backend "nccl" this is one RCCL broadcast over xGMI (288 GB
+    of HBM per GPU: the whole record in one piece, no chunking); on CPU tensors (gloo) the same call is the test double.
+    Returns the record on every rank; hand it to the engine without a copy:
+        t = broadcast_record(t, device=f"cuda:{local_rank}");  engine.attach_if(t.data_ptr(), t.numel() // 2)
+    """
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        if record.dim() != 1 or record.dtype not in (torch.int8, torch.int16):
+            raise ValueError("broadcast_record: a 1-D int8 or int16 tensor is expected")
+        meta = [(int(record.numel()), str(record.dtype))]
+    dist.broadcast_object_list(meta, src=src)
+    n, dt = meta[0]
+    dtype = torch.int8 if dt == "torch.int8" else torch.int16
+    if rank == src:
+        t = record if device is None else record.to(device)
+    else:
+        t = torch.empty(n, dtype=dtype, device=device if device is not None else "cpu")
+    dist.broadcast(t, src=src)
+    return t

@@ -13,7 +13,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from cu_sdr_collection_amd.sharding import merge_acq_results, shard_channels, shard_prns
+    from cu_sdr_collection_amd.sharding import broadcast_record, merge_acq_results, shard_channels, shard_prns
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -35,7 +35,10 @@ def _worker(rank, world, port, q):
     parts = [None] * world
     dist.all_gather_object(parts, acq)
     merged = merge_acq_results(parts)
-    q.put((rank, float(t[0]), gathered, merged.codePhase.tolist(), merged.peakMetric.tolist()))
+    # the one exchange step: the rank that read the file broadcasts the raw record (RCCL over xGMI on the GPUs, gloo here)
+    rec = torch.arange(-100, 100, dtype=torch.int8).repeat(50) if rank == 0 else None
+    rec = broadcast_record(rec, src=0)
+    q.put((rank, float(t[0]), gathered, merged.codePhase.tolist(), merged.peakMetric.tolist(), (int(rec.numel()), int(rec.to(torch.int64).sum()), int(rec[137]))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,7 +57,8 @@ def test_gloo_world_size_two_control_plane():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, tmax, gathered, code_phase, metric in res:
+    for rank, tmax, gathered, code_phase, metric, rec in res:
+        assert rec == (10000, -5000, 37)
         assert code_phase == [prn * 7 for prn in range(1, 33)]
         assert metric == [3.0 + 0.1 * prn for prn in range(1, 33)]
         assert tmax == 1.5  # MAX over ranks
