@@ -41,6 +41,9 @@ def broadcast_record(record, src: int = 0, device=None):
     of HBM per GPU: the whole record in one piece, no chunking); on CPU tensors (gloo) the same call is the test double.
     Returns the record on every rank; hand it to the engine without a copy:
         t = broadcast_record(t, device=f"cuda:{local_rank}");  engine.attach_if(t.data_ptr(), t.numel() // 2)
+    Process order matters when torch drives the GPU in the same process as the engine: torch ships its own copy of the HIP
+    runtime, so initialise torch's CUDA side (torch.cuda.set_device) BEFORE the first Engine() -- with the engine first, torch
+    finds no device (tests/test_gpu_correlator.py::test_broadcast_record_is_adopted_without_a_copy runs in that order).
     """
     import torch
     import torch.distributed as dist

@@ -13,6 +13,9 @@ import pytest
 from oracle import c_oracle as CO
 from oracle import gnss_oracle as O
 
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 TOL = 2e-6
 
@@ -326,3 +329,48 @@ def test_big_periodic_replay_with_eight_sample_chunks(engine, monkeypatch):
             d = descs[i]
             ref = _oracle(iq, d, tables[d["channel"]], code_length=2046.0)
             assert np.abs(got[i] - ref).max() < TOL * _scale(iq, d), (env, i)
+
+
+def test_broadcast_record_is_adopted_without_a_copy():
+    """sharding.broadcast_record on the GPU (backend nccl = RCCL; world size 1 here, the eight-GPU run is the driver's) and
+    gc_attach_if: the engine correlates straight out of the torch tensor that received the broadcast.  In its own process,
+    torch first: torch brings its own copy of the HIP runtime, and whichever copy is loaded first serves the process."""
+    import subprocess
+    import sys
+    code = r"""
+import socket, sys
+import numpy as np
+import torch, torch.distributed as dist
+assert torch.cuda.is_available()
+torch.cuda.set_device(0)
+sys.path.insert(0, %r)
+import cu_sdr_collection_amd as P
+from cu_sdr_collection_amd.sharding import broadcast_record
+from oracle import gnss_oracle as O
+S = P.initSettings()
+sats = P.synth.scene(2, 5, S.samplingFreq)
+iq = P.synth.generate_if(sats, int(0.05 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023, seed=9)
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+t = broadcast_record(torch.from_numpy(iq.copy()), src=0, device="cuda:0")
+torch.cuda.synchronize()
+assert t.is_cuda and t.dtype == torch.int8 and t.numel() == iq.size
+eng = P.Engine(0)
+eng.set_channel(0, [O.pad_code(O.generate_ca_code(sats[0].prn))])
+b = eng.make_blocks(3)
+for k in range(3):
+    b[k].channel = 0; b[k].first_sample = 1000 + 20000 * k; b[k].blksize = 18000; b[k].rem_code_phase = 0.25 * k
+    b[k].code_phase_step = 1.023e6 / 18e6; b[k].el_spacing = 0.5; b[k].carr_freq = 20e3 + 100 * k; b[k].rem_carr_phase = 0.3
+eng.load_if(iq, fs=S.samplingFreq)
+want = eng.correlate(b).copy()
+eng.attach_if(t.data_ptr(), iq.size // 2)
+eng.set_sampling_freq(S.samplingFreq)
+got = eng.correlate(b)
+assert np.array_equal(got, want) and np.abs(got).max() > 0
+eng.close()
+dist.destroy_process_group()
+print("BROADCAST_ATTACH_OK")
+""" % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BROADCAST_ATTACH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
