@@ -24,6 +24,14 @@
  *          gnsscorr_mex('load_if_packed2', h, uint8(packed))                     % 2-bit packed complex record
  *   s    = gnsscorr_mex('fine_sums', h, fine_struct, int8(code))                 % (2*ncodes) x nbins per-code sums
  *   c    = gnsscorr_mex('preamble_xcorr', h, I_P, int8(preamble_ms))             % single, non-negative lags
+ *          gnsscorr_mex('set_channel', h, ch, {codes...}, indexScale, armMult, windowEntries)   % optional per-arm vectors:
+ *          armMult = [1 1 6] for a BOC(6,1) arm (WB_tracking.m:293), windowEntries for GPS L2C CL (gc_set_code_window)
+ *   res  = gnsscorr_mex('acquire_coarse_multi', h, acq_struct, sampledCodes, narms)    % int8 spc x (nprn*narms), data+pilot
+ *   nrows = gnsscorr_mex('acq_shift_prepare', h, shift_struct)                    % circular-shift family (BDS B1I, GPS L2C, BDS B1C)
+ *   [rowMax, rowArg] = gnsscorr_mex('acq_shift_search', h, int8(codes), weights, nrows)  % codes n x narms; weights [] = ones
+ *   row  = gnsscorr_mex('acq_shift_row', h, row0, n)                              % one results row (single), for the 2nd-peak rule
+ *   x    = gnsscorr_mex('read_if', h, firstSample0, n, 'int8'|'int16', valuesPerSample)   % raw record samples back
+ *   [name, cus] = gnsscorr_mex('device_info', h)
  */
 #include <string.h>
 
@@ -118,9 +126,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       } else {
         memcpy(tmp, mxGetData(t), (size_t)n);
       }
-      int rc = gc_set_code(c, ch, a, tmp, n, 1.0);
+      /* optional: per-arm ramp multipliers (6 for a BOC(6,1) arm, WB_tracking.m:293) and table windows (GPS L2C CL) */
+      double mult = nrhs > 5 && (int)mxGetNumberOfElements(prhs[5]) > a ? mxGetDoubles(prhs[5])[a] : 1.0;
+      int rc = gc_set_code(c, ch, a, tmp, n, mult);
       mxFree(tmp);
       if (rc) fail("gc_set_code");
+      if (nrhs > 6 && (int)mxGetNumberOfElements(prhs[6]) > a && mxGetDoubles(prhs[6])[a] > 0)
+        if (gc_set_code_window(c, ch, a, (int)mxGetDoubles(prhs[6])[a])) fail("gc_set_code_window");
     }
   } else if (!strcmp(cmd, "correlate")) {
     /* blocks rows: channel, first_sample (0-based), blksize, remCodePhase, codePhaseStep,
@@ -197,12 +209,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxFree(init);
     mxFree(done);
     if (rc && rc != GC_E_RANGE && !(rc == GC_E_UNSUPPORTED && nlhs > 2)) fail("gc_track"); /* GC_E_RANGE = the reference's short-read return */
-  } else if (!strcmp(cmd, "acquire_coarse")) {
+  } else if (!strcmp(cmd, "acquire_coarse") || !strcmp(cmd, "acquire_coarse_multi")) {
+    /* acquire_coarse_multi: narms sampled codes per PRN in consecutive columns (data, pilot: GPS_L5C/include/acquisition.m:175-216) */
     gc_acq_params p;
     fill_acq(prhs[2], &p);
-    int nprn = (int)mxGetN(prhs[3]);
+    const int narms = !strcmp(cmd, "acquire_coarse_multi") ? (int)mxGetScalar(prhs[4]) : 1;
+    if (narms < 1 || mxGetN(prhs[3]) % (mwSize)narms) mexErrMsgIdAndTxt("gnsscorr:usage", "sampledCodes: spc x (nprn*narms)");
+    int nprn = (int)mxGetN(prhs[3]) / narms;
     gc_acq_result* r = (gc_acq_result*)mxCalloc((size_t)nprn, sizeof *r);
-    if (gc_acquire_coarse(handle(prhs[1]), &p, nprn, (const int8_t*)mxGetData(prhs[3]), r)) fail("gc_acquire_coarse");
+    if (gc_acquire_coarse_multi(handle(prhs[1]), &p, nprn, narms, (const int8_t*)mxGetData(prhs[3]), r)) fail("gc_acquire_coarse_multi");
     plhs[0] = mxCreateDoubleMatrix(5, (mwSize)nprn, mxREAL); /* rows: bin, codePhase, peak, peakMetric, coarseFreq */
     for (int i = 0; i < nprn; ++i) {
       double* o = mxGetDoubles(plhs[0]) + 5 * i;
@@ -248,6 +263,53 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (gc_preamble_xcorr(handle(prhs[1]), mxGetDoubles(prhs[2]), (int64_t)n, (const int8_t*)mxGetData(prhs[3]),
                           (int)mxGetNumberOfElements(prhs[3]), (float*)mxGetData(plhs[0])))
       fail("gc_preamble_xcorr");
+  } else if (!strcmp(cmd, "acq_shift_prepare")) {
+    /* the circular-shift search of BDS/B1I acquisition.m:100-167, GPS_L2C :119-190, BDS/B1C :120-200: wipe-off + forward
+       transforms of the signal blocks, once per call */
+    const mxArray* s = prhs[2];
+    gc_acq_shift_params p;
+    memset(&p, 0, sizeof p);
+    p.sampling_freq = field(s, "samplingFreq");
+    p.carrier_f0 = field(s, "carrierF0");
+    p.carrier_step = field(s, "carrierStep");
+    p.first_sample = (int64_t)field(s, "firstSample");
+    p.n = (int32_t)field(s, "samplesPerBlock");
+    p.n_signals = (int32_t)field(s, "nSignals");
+    p.n_carriers = (int32_t)field(s, "nCarriers");
+    p.n_bins = (int32_t)field(s, "nBins");
+    p.n_arms_max = mxGetField(s, 0, "nArmsMax") ? (int32_t)field(s, "nArmsMax") : 1;
+    if (gc_acq_shift_prepare(handle(prhs[1]), &p)) fail("gc_acq_shift_prepare");
+    plhs[0] = mxCreateDoubleScalar((double)p.n_carriers * p.n_signals * p.n_bins); /* number of result rows */
+  } else if (!strcmp(cmd, "acq_shift_search")) {
+    /* codes: int8 n x narms, zero-padded replicas; rows ordered ((carrier*nSignals + signal)*nBins + bin); nrows from prepare */
+    const int narms = (int)mxGetN(prhs[2]);
+    const int nrows = (int)mxGetScalar(prhs[4]);
+    const double* w = nrhs > 3 && !mxIsEmpty(prhs[3]) ? mxGetDoubles(prhs[3]) : NULL;
+    plhs[0] = mxCreateNumericMatrix(1, (mwSize)nrows, mxSINGLE_CLASS, mxREAL);
+    mxArray* arg = mxCreateNumericMatrix(1, (mwSize)nrows, mxINT32_CLASS, mxREAL);
+    if (gc_acq_shift_search(handle(prhs[1]), narms, (const int8_t*)mxGetData(prhs[2]), w, (float*)mxGetData(plhs[0]),
+                            (int32_t*)mxGetData(arg)))
+      fail("gc_acq_shift_search");
+    if (nlhs > 1) plhs[1] = arg; /* 0-based first position of each row's maximum */
+    else mxDestroyArray(arg);
+  } else if (!strcmp(cmd, "acq_shift_row")) {
+    plhs[0] = mxCreateNumericMatrix(1, (mwSize)mxGetScalar(prhs[3]), mxSINGLE_CLASS, mxREAL);
+    if (gc_acq_shift_row(handle(prhs[1]), (int)mxGetScalar(prhs[2]), (float*)mxGetData(plhs[0]))) fail("gc_acq_shift_row");
+  } else if (!strcmp(cmd, "read_if")) {
+    /* x = gnsscorr_mex('read_if', h, firstSample0, n, class): raw record samples back, class 'int8' | 'int16', 2 values per
+       complex sample */
+    char cls[16] = "int8";
+    if (nrhs > 4) mxGetString(prhs[4], cls, sizeof cls);
+    const mwSize n = (mwSize)mxGetScalar(prhs[3]);
+    const mwSize per = nrhs > 5 ? (mwSize)mxGetScalar(prhs[5]) : 2; /* values per sample: 2 (I/Q) or 1 (real) */
+    plhs[0] = mxCreateNumericMatrix(1, n * per, !strcmp(cls, "int16") ? mxINT16_CLASS : mxINT8_CLASS, mxREAL);
+    if (gc_read_if(handle(prhs[1]), (uint64_t)mxGetScalar(prhs[2]), (uint64_t)n, mxGetData(plhs[0]))) fail("gc_read_if");
+  } else if (!strcmp(cmd, "device_info")) {
+    char name[128] = "";
+    int cus = 0;
+    if (gc_device_info(handle(prhs[1]), name, (int)sizeof name, &cus)) fail("gc_device_info");
+    plhs[0] = mxCreateString(name);
+    if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(cus);
   } else {
     mexErrMsgIdAndTxt("gnsscorr:usage", "unknown command %s", cmd);
   }
