@@ -14,6 +14,7 @@
 //   * the peak pick reproduces max(max(.)) first-occurrence semantics with exact float compares.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "gc_internal.h"
 
@@ -21,6 +22,7 @@ namespace {
 
 constexpr int kMaxRadices = 12;
 constexpr int kFftThreads = 256;
+constexpr int kFftSlots = 8;  // tile elements per thread at most: L*C <= kFftSlots * kFftThreads
 
 struct SubPlan {
   int len;
@@ -33,18 +35,66 @@ struct Plan {
   SubPlan p1, p2;
 };
 
+// Radices a stage can take: 2, 3, 4, 5 directly, the others as two nested butterflies with compile-time inner twiddles
+// (butterfly<R> below).  A pass spends most of its time between stages (LDS round trip, barrier, index arithmetic), so
+// the plan is the factorisation with the FEWEST stages; among those the one whose largest radix is smallest (registers).
+// Largest radix compiled into the pass kernel.  Measured (default L1 C/A search, MI355X): stages with radices up to 20
+// halve the stage count of the 180- and 200-point passes but need 162 VGPRs (3 waves per SIMD instead of the 4 the
+// tile's LDS allows) and the search gets 10 % SLOWER; up to 8 stays at 112 VGPRs and is 1 % faster than {5,4,3,2}.
+#ifndef GC_FFT_MAXR
+#define GC_FFT_MAXR 8
+#endif
+constexpr int kRadixSet[] = {20, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+
+int max_radix() {
+  static const int m = [] {
+    const char* e = std::getenv("GC_ACQ_MAX_RADIX");  // tuning: largest radix a stage may take (2 .. 20)
+    return std::min(GC_FFT_MAXR, e ? std::max(5, std::atoi(e)) : 20);
+  }();
+  return m;
+}
+
+bool factor_rec(int r, int depth, int maxr, int* cur, int* best, int* best_n, int* best_max) {
+  if (r == 1) {
+    if (depth < *best_n || (depth == *best_n && maxr < *best_max)) {
+      *best_n = depth;
+      *best_max = maxr;
+      for (int i = 0; i < depth; ++i) best[i] = cur[i];
+    }
+    return true;
+  }
+  if (depth >= kMaxRadices || depth + 1 > *best_n) return false;
+  bool any = false;
+  for (int c : kRadixSet) {
+    if (r % c || c > max_radix()) continue;
+    if (depth > 0 && c > cur[depth - 1]) continue;  // non-increasing: each multiset once
+    cur[depth] = c;
+    any |= factor_rec(r / c, depth + 1, std::max(maxr, c), cur, best, best_n, best_max);
+  }
+  return any;
+}
+
 bool factor(int len, SubPlan* sp) {
   sp->len = len;
   sp->nrad = 0;
-  int r = len;
-  const int cand[4] = {5, 4, 3, 2};
-  for (int c : cand)
-    while (r % c == 0) {
-      if (sp->nrad >= kMaxRadices) return false;
-      sp->rad[sp->nrad++] = c;
-      r /= c;
-    }
-  return r == 1;
+  if (len == 1) return true;
+  int cur[kMaxRadices], best[kMaxRadices], best_n = kMaxRadices + 1, best_max = 1 << 30;
+  const bool simple = std::getenv("GC_ACQ_SIMPLE_RADIX") != nullptr;  // tuning: radices 5, 4, 3, 2 only
+  if (simple) {
+    int r = len;
+    for (int c : {5, 4, 3, 2})
+      while (r % c == 0) {
+        if (sp->nrad >= kMaxRadices) return false;
+        sp->rad[sp->nrad++] = c;
+        r /= c;
+      }
+    return r == 1;
+  }
+  factor_rec(len, 0, 1, cur, best, &best_n, &best_max);
+  if (best_n > kMaxRadices) return false;
+  sp->nrad = best_n;
+  for (int i = 0; i < best_n; ++i) sp->rad[i] = best[i];
+  return true;
 }
 
 bool make_plan(int n, Plan* pl) {
@@ -113,9 +163,100 @@ __device__ __forceinline__ int fdiv_small(int i, float inv_d) { return (int)(((f
 // multiplications, 3 and 5 the classical real-constant forms (the generic R x R complex product they replace was the
 // passes' VALU bound).
 __device__ __forceinline__ float2 mul_mi(float2 a, float s) { return make_float2(s * a.y, -s * a.x); }  // a * (-i*s)
+// cos / sin of 2*pi*m/R at compile time (Taylor series on an argument reduced to [-pi, pi]; double, rounded once to float)
+constexpr double cx_angle(int m, int R) {
+  const double t = 6.283185307179586476925286766559 * (double)(m % R) / (double)R;
+  return t > 3.14159265358979323846 ? t - 6.283185307179586476925286766559 : t;
+}
+constexpr double cx_cos(int m, int R) {
+  const double x = cx_angle(m, R);
+  double term = 1.0, sum = 1.0;
+  for (int n = 1; n < 20; ++n) {
+    term *= -x * x / (double)((2 * n - 1) * (2 * n));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double cx_sin(int m, int R) {
+  const double x = cx_angle(m, R);
+  double term = x, sum = x;
+  for (int n = 1; n < 20; ++n) {
+    term *= -x * x / (double)((2 * n) * (2 * n + 1));
+    sum += term;
+  }
+  return sum;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// composite radices R = A * B: B inner butterflies of size A, compile-time twiddles W_R^(q2*k1), A butterflies of size B
+template <int R> struct RadixSplit { static constexpr int a = 0, b = 0; };
+template <> struct RadixSplit<6> { static constexpr int a = 3, b = 2; };
+template <> struct RadixSplit<8> { static constexpr int a = 4, b = 2; };
+#if GC_FFT_MAXR >= 9
+template <> struct RadixSplit<9> { static constexpr int a = 3, b = 3; };
+#endif
+#if GC_FFT_MAXR >= 10
+template <> struct RadixSplit<10> { static constexpr int a = 5, b = 2; };
+#endif
+#if GC_FFT_MAXR >= 12
+template <> struct RadixSplit<12> { static constexpr int a = 4, b = 3; };
+#endif
+#if GC_FFT_MAXR >= 15
+template <> struct RadixSplit<15> { static constexpr int a = 5, b = 3; };
+#endif
+#if GC_FFT_MAXR >= 16
+template <> struct RadixSplit<16> { static constexpr int a = 4, b = 4; };
+#endif
+#if GC_FFT_MAXR >= 20
+template <> struct RadixSplit<20> { static constexpr int a = 5, b = 4; };
+#endif
+
 template <int R>
 __device__ __forceinline__ void butterfly(const float2 (&v)[R], float s, float2 (&o)[R]) {
-  if constexpr (R == 2) {
+  if constexpr (RadixSplit<R>::a != 0) {
+    // X[k1 + A*k2] = sum_q2 W_B^(q2*k2) * W_R^(q2*k1) * sum_q1 v[q1*B + q2] * W_A^(q1*k1)
+    constexpr int A = RadixSplit<R>::a, B = RadixSplit<R>::b;
+    float2 t[B][A];
+    static_for<0, B>([&](auto q2c) __attribute__((always_inline)) {
+      constexpr int q2 = decltype(q2c)::value;
+      float2 in[A], out[A];
+#pragma unroll
+      for (int q1 = 0; q1 < A; ++q1) in[q1] = v[q1 * B + q2];
+      butterfly<A>(in, s, out);
+      static_for<0, A>([&](auto k1c) __attribute__((always_inline)) {
+        constexpr int k1 = decltype(k1c)::value;
+        constexpr int m = (q2 * k1) % R;
+        if constexpr (m == 0) {
+          t[q2][k1] = out[k1];
+        } else if constexpr ((4 * m) % R == 0) {  // quarter turns: W = (-i*s)^(4m/R)
+          constexpr int qt = 4 * m / R;
+          if constexpr (qt == 1) t[q2][k1] = mul_mi(out[k1], s);
+          else if constexpr (qt == 2) t[q2][k1] = make_float2(-out[k1].x, -out[k1].y);
+          else t[q2][k1] = mul_mi(out[k1], -s);
+        } else {
+          constexpr float c = (float)cx_cos(m, R), sn = (float)cx_sin(m, R);
+          const float wy = -s * sn;  // table convention: exp(-i..) for s = +1
+          t[q2][k1] = make_float2(out[k1].x * c - out[k1].y * wy, out[k1].x * wy + out[k1].y * c);
+        }
+      });
+    });
+    static_for<0, A>([&](auto k1c) __attribute__((always_inline)) {
+      constexpr int k1 = decltype(k1c)::value;
+      float2 in[B], out[B];
+#pragma unroll
+      for (int q2 = 0; q2 < B; ++q2) in[q2] = t[q2][k1];
+      butterfly<B>(in, s, out);
+#pragma unroll
+      for (int k2 = 0; k2 < B; ++k2) o[k1 + A * k2] = out[k2];
+    });
+  } else if constexpr (R == 2) {
     o[0] = make_float2(v[0].x + v[1].x, v[0].y + v[1].y);
     o[1] = make_float2(v[0].x - v[1].x, v[0].y - v[1].y);
   } else if constexpr (R == 4) {
@@ -135,7 +276,7 @@ __device__ __forceinline__ void butterfly(const float2 (&v)[R], float s, float2 
     o[1] = make_float2(m.x + n.x, m.y + n.y);
     o[2] = make_float2(m.x - n.x, m.y - n.y);
   } else {
-    static_assert(R == 5, "radices 2, 3, 4, 5");
+    static_assert(R == 5, "radices 2, 3, 4, 5 and their pairwise products up to 20");
     constexpr float c1 = 0.30901699437494745f, c2 = -0.8090169943749473f, s1 = 0.9510565162951535f, s2 = 0.5877852522924731f;
     const float2 a1 = make_float2(v[1].x + v[4].x, v[1].y + v[4].y), a2 = make_float2(v[2].x + v[3].x, v[2].y + v[3].y);
     const float2 b1 = make_float2(v[1].x - v[4].x, v[1].y - v[4].y), b2 = make_float2(v[2].x - v[3].x, v[2].y - v[3].y);
@@ -211,9 +352,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
 
   const int reps = (a.post == POST_ABS_ACC) ? a.nhops / HG : 1;
   // POST_ABS_ACC keeps its accumulators in registers across the hop loop
-  float accv[8];
+  float accv[kFftSlots];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) accv[k] = 0.f;
+  for (int k = 0; k < kFftSlots; ++k) accv[k] = 0.f;
 
   for (int rep = 0; rep < reps; ++rep) {
     const long long tb = (a.post == POST_ABS_ACC) ? batch * a.nhops + (long long)hg * reps + rep : batch;
@@ -276,7 +417,32 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
         case 2: fft_stage<2>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
         case 3: fft_stage<3>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
         case 4: fft_stage<4>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
-        default: fft_stage<5>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+        case 5: fft_stage<5>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#if GC_FFT_MAXR >= 6
+        case 6: fft_stage<6>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+#if GC_FFT_MAXR >= 8
+        case 8: fft_stage<8>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+#if GC_FFT_MAXR >= 9
+        case 9: fft_stage<9>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+#if GC_FFT_MAXR >= 10
+        case 10: fft_stage<10>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+#if GC_FFT_MAXR >= 12
+        case 12: fft_stage<12>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+#if GC_FFT_MAXR >= 15
+        case 15: fft_stage<15>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+#if GC_FFT_MAXR >= 16
+        case 16: fft_stage<16>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+#if GC_FFT_MAXR >= 20
+        case 20: fft_stage<20>(a.tw, a.n, src, dst, twl, L, C, ns, tid, sign); break;
+#endif
+        default: break;
       }
       __syncthreads();
       float2* t = src;
@@ -287,7 +453,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
 
     // ---- store -------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int slot = 0; slot < 8; ++slot) {
+    for (int slot = 0; slot < kFftSlots; ++slot) {
       const int idx = tid + slot * kFftThreads;
       if (idx >= nel) continue;
       int e, c;
@@ -318,7 +484,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
   if (a.post == POST_ABS_ACC) {
     const float inv_n = 1.0f / (float)a.n;
 #pragma unroll
-    for (int slot = 0; slot < 8; ++slot) {
+    for (int slot = 0; slot < kFftSlots; ++slot) {
       const int idx = tid + slot * kFftThreads;
       if (idx >= nel) continue;
       int e, c;
