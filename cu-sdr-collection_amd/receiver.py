@@ -36,6 +36,43 @@ def CNoVSM(I, Q, T):
     return float(10 * np.log10(abs((1 / T) * Pav / (2 * Nv))))
 
 
+def Calc_CNo_PLD(trackResults, settings, loopCnt, straight_pilot: bool = False):
+    """[CNo, PllDetector] = Calc_CNo_PLD(trackResults, settings, loopCnt) of BDS/B2a and BDS/B1C (host side, like CNoVSM):
+    variance-summing C/N0 of the data arm, of the pilot arm and of their sum over the last settings.CNoInterval epochs, and
+    the narrow-band PLL lock detector NBD/NBP of each arm with the data bits wiped by sign (B2a Calc_CNo_PLD.m:35-97).  The
+    pilot prompt pair is read swapped (the pilot is tracked in quadrature) except for the B1C wide-band loop
+    (`straight_pilot`; pilotTRKflag == 2 in BDS/B1C/include/Calc_CNo_PLD.m).  CNo[1], PllDetector[1] stay 0 without a pilot."""
+    n = int(settings.CNoInterval)
+    T = settings.intTime
+    sl = slice(loopCnt - n, loopCnt)
+
+    def arm(I, Q):
+        Z = I ** 2 + Q ** 2
+        Zm = np.mean(Z)
+        Zv = np.var(Z, ddof=1)
+        Pav = np.sqrt(complex(Zm ** 2 - Zv))          # MATLAB's sqrt of a negative number is complex; abs() below
+        Nv = 0.5 * (Zm - Pav)
+        lin = abs((1 / T) * Pav / (2 * Nv))
+        wiped = np.sum(I[I > 0]) - np.sum(I[I < 0])
+        nbp = wiped ** 2 + np.sum(Q) ** 2
+        nbd = wiped ** 2 - np.sum(Q) ** 2
+        return lin, nbd / nbp
+
+    CNo = np.zeros(3)
+    PllDetector = np.zeros(2)
+    data, PllDetector[0] = arm(np.asarray(trackResults.I_P[sl], dtype=np.float64), np.asarray(trackResults.Q_P[sl], dtype=np.float64))
+    CNo[0] = 10 * np.log10(data)
+    pilot = 0.0
+    if getattr(settings, "pilotTRKflag", 0) in (1, 2) and hasattr(trackResults, "Pilot_I_P"):
+        pi = np.asarray(trackResults.Pilot_I_P[sl], dtype=np.float64)
+        pq = np.asarray(trackResults.Pilot_Q_P[sl], dtype=np.float64)
+        pilot, PllDetector[1] = arm(pi, pq) if straight_pilot else arm(pq, pi)
+        CNo[1] = 10 * np.log10(pilot)
+    with np.errstate(divide="ignore"):
+        CNo[2] = 10 * np.log10(data + pilot)
+    return CNo, PllDetector
+
+
 # ---------------------------------------------------------------------------------------------
 # acquisition
 # ---------------------------------------------------------------------------------------------
@@ -183,7 +220,9 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_lo
                                        code_freq=cf, code_phase=int(ch.codePhase),
                                        table_phase=int(getattr(ch, "CLCodePhase", 0)) if (spec.doubled_code and pilot) else 0))
     fields, done, status = fid.track(p, inits, device_loop=device_loop)   # device_loop: gc_track_device (include/gnsscorr.h)
-    cno = getattr(settings, "CNo", None)   # B2a / B1C estimate C/N0 with Calc_CNo_PLD instead (not on the hot path)
+    # B2a / B1C estimate C/N0 with Calc_CNo_PLD every settings.CNoInterval epochs (below); the other packages with CNoVSM
+    pld = int(getattr(settings, "CNoInterval", 0))
+    cno = None if pld else getattr(settings, "CNo", None)
     vsm = int(cno.VSMinterval) if cno is not None else 0
     for k, i in enumerate(active):
         tr = results[i]
@@ -200,6 +239,25 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_lo
         for loop in (range(vsm, n_done + 1, vsm) if vsm else ()):                     # tracking.m:351-358
             tr.CNo.VSMValue.append(CNoVSM(tr.I_P[loop - vsm:loop], tr.Q_P[loop - vsm:loop], settings.CNo.accTime))
             tr.CNo.VSMIndex.append(loop)
+        if pld:
+            # BDS/B2a/include/tracking.m:85-92,191-192,409-432 (B1C NB_tracking.m:92-98,397-418, WB_tracking.m:443-461):
+            # every CNoInterval epochs, the estimate averaged 0.5/0.5 with the previous one (zeros before the first)
+            nrec = n_ep // pld
+            combined = "B2a_CNo" if signal.startswith("BDS_B2a") else "B1C_CNo"
+            names = ("DataCNo", "DataPLD") + (("PilotCNo", "PilotPLD", combined) if pilot else ())
+            for f in names:
+                setattr(tr, f, np.zeros(nrec))
+            prev = np.zeros(3)
+            for loop in range(pld, n_done + 1, pld):
+                c, d = Calc_CNo_PLD(tr, settings, loop, straight_pilot=signal.endswith("_WB"))
+                k = loop // pld - 1
+                tr.DataCNo[k] = c[0] * 0.5 + prev[0] * 0.5
+                tr.DataPLD[k] = d[0]
+                if pilot:
+                    tr.PilotCNo[k] = c[1] * 0.5 + prev[1] * 0.5
+                    getattr(tr, combined)[k] = c[2] * 0.5 + prev[2] * 0.5
+                    tr.PilotPLD[k] = d[1]
+                prev = c
         if n_done == n_ep:
             tr.status = channel[i].status                                             # tracking.m:365
     if status == L.GC_E_RANGE:

@@ -20,6 +20,7 @@ normalised by N-1.
 """
 from __future__ import annotations
 
+import cmath
 import math
 import os
 from types import SimpleNamespace
@@ -1340,6 +1341,38 @@ def acquisition_front_end(long_signal: np.ndarray, settings):
     s2.oldIF = settings.IF
     s2.IF = math.fmod(settings.IF, s2.samplingFreq)               # :95 rem()
     return x[index - 1], s2
+
+
+def calc_cno_pld(i_p, q_p, pilot_i_p, pilot_q_p, loop_cnt: int, interval: int, int_time: float, pilot_flag: int):
+    """BDS/B2a/include/Calc_CNo_PLD.m:35-97 and BDS/B1C/include/Calc_CNo_PLD.m (same file plus the pilotTRKflag == 2
+    branch): returns (CNo[3], PllDetector[2]).  Per arm over epochs loop_cnt-interval+1 .. loop_cnt (1-based):
+    Z = I^2+Q^2, Pav = sqrt(mean(Z)^2 - var(Z)), Nv = (mean(Z) - Pav)/2, C/N0 = |Pav / (2 Nv T)|;
+    NBP/NBD from sum|I| (data wipe-off by sign) and sum Q.  The pilot arm reads (I, Q) = (Pilot_Q_P, Pilot_I_P) when
+    pilot_flag == 1 and (Pilot_I_P, Pilot_Q_P) when pilot_flag == 2."""
+    lo = loop_cnt - interval
+
+    def one(I, Q):
+        zs = [float(a) * float(a) + float(b) * float(b) for a, b in zip(I, Q)]
+        zm = math.fsum(zs) / len(zs)
+        zv = math.fsum((z - zm) ** 2 for z in zs) / (len(zs) - 1)
+        pav = cmath.sqrt(zm * zm - zv)
+        nv = 0.5 * (zm - pav)
+        lin = abs((1.0 / int_time) * pav / (2.0 * nv))
+        wiped = math.fsum(abs(float(a)) for a in I)
+        sq = math.fsum(float(b) for b in Q)
+        return lin, (wiped * wiped - sq * sq) / (wiped * wiped + sq * sq)
+
+    cno = [0.0, 0.0, 0.0]
+    pld = [0.0, 0.0]
+    data, pld[0] = one(i_p[lo:loop_cnt], q_p[lo:loop_cnt])
+    cno[0] = 10.0 * math.log10(data)
+    pilot = 0.0
+    if pilot_flag in (1, 2):
+        a, b = pilot_i_p[lo:loop_cnt], pilot_q_p[lo:loop_cnt]
+        pilot, pld[1] = one(a, b) if pilot_flag == 2 else one(b, a)
+        cno[1] = 10.0 * math.log10(pilot)
+    cno[2] = 10.0 * math.log10(data + pilot)
+    return cno, pld
 
 
 def unpack_cplx(packed: np.ndarray) -> np.ndarray:

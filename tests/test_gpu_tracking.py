@@ -293,9 +293,19 @@ def test_beidou_b2a_data_pilot(engine):
     from cu_sdr_collection_amd.settings import initSettings_BDS_B2a
     S = initSettings_BDS_B2a()
     S.pilotTRKflag = 1
-    _ten23_case(engine, S, "BDS_B2a", P.codes.generateB2aDataCode, P.codes.generateB2aPilotCode,
-                lambda prn: [O.pad_code(O.generate_b2a_code(prn, "data")), O.pad_code(O.generate_b2a_code(prn, "pilot"))],
-                "a", 1150.0, (20, 44), 41)
+    S.CNoInterval = 25           # two C/N0 + lock-detector records inside the 50 epochs (initSettings.m:125 has 200)
+    tr = _ten23_case(engine, S, "BDS_B2a", P.codes.generateB2aDataCode, P.codes.generateB2aPilotCode,
+                     lambda prn: [O.pad_code(O.generate_b2a_code(prn, "data")), O.pad_code(O.generate_b2a_code(prn, "pilot"))],
+                     "a", 1150.0, (20, 44), 41)
+    # BDS/B2a/include/tracking.m:409-432 + Calc_CNo_PLD.m on the recorded prompt streams (host side)
+    for t in tr:
+        c1, d1 = O.calc_cno_pld(t.I_P, t.Q_P, t.Pilot_I_P, t.Pilot_Q_P, 25, 25, S.intTime, 1)
+        c2, d2 = O.calc_cno_pld(t.I_P, t.Q_P, t.Pilot_I_P, t.Pilot_Q_P, 50, 25, S.intTime, 1)
+        assert np.allclose(t.DataCNo, [0.5 * c1[0], 0.5 * (c1[0] + c2[0])], atol=1e-9)
+        assert np.allclose(t.PilotCNo, [0.5 * c1[1], 0.5 * (c1[1] + c2[1])], atol=1e-9)
+        assert np.allclose(t.B2a_CNo, [0.5 * c1[2], 0.5 * (c1[2] + c2[2])], atol=1e-9)
+        assert np.allclose(t.DataPLD, [d1[0], d2[0]], atol=1e-12) and np.allclose(t.PilotPLD, [d1[1], d2[1]], atol=1e-12)
+        assert c2[2] > 40.0 and d2[1] > 0.8       # 50 dB-Hz scene, pilot locked in quadrature
 
 
 def test_beidou_b3i(engine):

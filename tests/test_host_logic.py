@@ -165,3 +165,28 @@ def test_boc61_tables_are_recognised_as_derived_from_boc11():
     assert derivable(pad(P.codes.generateE1Ccode(3)), pad(P.codes.generateE1C_BOC61(3))[:-6]) == 0         # wrong length
     rng = np.random.default_rng(4)
     assert derivable(rng.choice(np.array([-1, 1], np.int8), 22), rng.choice(np.array([-1, 1], np.int8), 122)) == 0
+
+
+def test_calc_cno_pld_matches_oracle_and_the_expected_level():
+    """BDS/B2a + BDS/B1C Calc_CNo_PLD.m (host side): the receiver mirror against the oracle's restatement for the three
+    pilot conventions, and against the level the synthetic prompt stream was built with."""
+    from cu_sdr_collection_amd.receiver import Calc_CNo_PLD
+    rng = np.random.default_rng(77)
+    n, T, cn0_db = 400, 1e-3, 45.0
+    amp = np.sqrt(2 * 10 ** (cn0_db / 10) * T)             # unit-variance I and Q noise: C/N0 = A^2 / (2 T)
+    bits = rng.choice([-1.0, 1.0], n)
+    tr = SimpleNamespace(I_P=amp * bits + rng.standard_normal(n), Q_P=rng.standard_normal(n),
+                         Pilot_I_P=rng.standard_normal(n), Pilot_Q_P=-amp + rng.standard_normal(n))
+    for flag, straight in ((0, False), (1, False), (2, True)):
+        S = SimpleNamespace(CNoInterval=200, intTime=T, pilotTRKflag=flag)
+        for loop in (200, 400):
+            cno, pld = Calc_CNo_PLD(tr, S, loop, straight_pilot=straight)
+            rc, rp = O.calc_cno_pld(tr.I_P, tr.Q_P, tr.Pilot_I_P, tr.Pilot_Q_P, loop, 200, T, flag)
+            assert np.allclose(cno, rc, rtol=0, atol=1e-9) and np.allclose(pld, rp, rtol=0, atol=1e-12), (flag, loop)
+            assert abs(cno[0] - cn0_db) < 1.0 and pld[0] > 0.9
+            if flag == 1:      # quadrature pilot read as (I, Q) = (Pilot_Q_P, Pilot_I_P): locked
+                assert abs(cno[1] - cn0_db) < 1.0 and pld[1] > 0.9 and abs(cno[2] - (cn0_db + 3.01)) < 1.0
+            if flag == 2:      # the same stream read straight: all the power in Q, detector at -1
+                assert pld[1] < -0.9
+            if flag == 0:
+                assert cno[1] == 0 and pld[1] == 0 and abs(cno[2] - cno[0]) < 1e-12
