@@ -14,6 +14,30 @@ def shard_channels(n_channels: int, world_size: int, rank: int) -> list[int]:
     return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
+def shard_bands(band_channels: dict, world_size: int) -> list:
+    """BASELINE config 4 (all-constellation mix, 64 channels on 8 GPUs): channels of several IF
+    records (bands) placed so that every rank holds the same number of channels (+-1) while each band's record lives on as
+    few GPUs as possible -- a rank needs the record of every band it tracks, and a band shared by k ranks costs k - 1
+    peer copies (`broadcast_record`) and k x its size in HBM.  `band_channels`: {band: number of channels}.
+    Returns plan[rank] = [(band, channel index within the band), ...].  Bands are laid out largest first (ties by name) and
+    cut only at rank boundaries, so a band of n channels touches at most ceil(n / per_rank) + 1 ranks."""
+    if world_size < 1 or any(n < 0 for n in band_channels.values()):
+        raise ValueError("bad sharding arguments")
+    flat = [(b, i) for b, n in sorted(band_channels.items(), key=lambda kv: (-kv[1], kv[0])) for i in range(n)]
+    return [[flat[i] for i in shard_channels(len(flat), world_size, r)] for r in range(world_size)]
+
+
+def band_ranks(plan) -> dict:
+    """{band: sorted ranks that track at least one of its channels}; the first rank of each list reads the band's file and is
+    the `src` of its `broadcast_record` (process group = that list of ranks)."""
+    out: dict = {}
+    for r, items in enumerate(plan):
+        for b, _ in items:
+            if r not in out.setdefault(b, []):
+                out[b].append(r)
+    return out
+
+
 def shard_prns(prn_list, world_size: int, rank: int) -> list:
     """Acquisition shards by PRN: every rank computes the PRN-independent signal spectra itself (they are
     hoisted out of the PRN loop and cost one forward FFT pass) and searches its round-robin share of the list, so ranks

@@ -190,3 +190,24 @@ def test_calc_cno_pld_matches_oracle_and_the_expected_level():
                 assert pld[1] < -0.9
             if flag == 0:
                 assert cno[1] == 0 and pld[1] == 0 and abs(cno[2] - cno[0]) < 1e-12
+
+
+def test_shard_bands_config4_mix():
+    """BASELINE config 4: 64 channels of the twelve signals on 8 GPUs -- balanced, every channel once, bands contiguous."""
+    from cu_sdr_collection_amd.sharding import band_ranks, shard_bands
+    # records (bands): signals that share a front end share a record (SURVEY.md §8d item 5)
+    bands = {"L1 (GPS L1CA + GAL E1 + BDS B1C)": 18, "B1I": 5, "L5 (GPS L5 + GAL E5a + BDS B2a)": 16, "E5b": 5, "B3I": 5,
+             "L2 (GPS L2C)": 5, "GLO L1": 5, "GLO L2": 5}
+    plan = shard_bands(bands, 8)
+    assert [len(p) for p in plan] == [8] * 8
+    seen = sorted(x for p in plan for x in p)
+    assert seen == sorted((b, i) for b, n in bands.items() for i in range(n))
+    ranks = band_ranks(plan)
+    for b, n in bands.items():
+        rs = ranks[b]
+        assert rs == list(range(rs[0], rs[-1] + 1)) and len(rs) <= -(-n // 8) + 1, b
+    assert ranks["L1 (GPS L1CA + GAL E1 + BDS B1C)"] == [0, 1, 2] and ranks["L5 (GPS L5 + GAL E5a + BDS B2a)"] == [2, 3, 4]
+    assert sum(len(rs) for rs in ranks.values()) <= len(bands) + 7          # at most one extra copy per rank boundary
+    # uneven worlds and empty bands
+    assert [len(p) for p in shard_bands({"a": 3, "b": 0, "c": 4}, 3)] == [3, 2, 2]
+    assert shard_bands({}, 2) == [[], []]
