@@ -344,11 +344,13 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       yr = kReal ? a * wc : fmaf(a, wc, b * ws);
       yi = kReal ? -a * ws : fmaf(b, wc, -a * ws);
     };
-    auto accumulate = [&](int x, int k, float yr, float yi) {
+    // returns the entry of the last LDS arm (the one a derived arm is built from)
+    auto accumulate = [&](int x, int k, float yr, float yi) -> float {
       if constexpr (AP == 1) {
         const float cf = (float)tab[kGuard + k];
         accr[0][x] = fmaf(cf, yr, accr[0][x]);
         acci[0][x] = fmaf(cf, yi, acci[0][x]);
+        return cf;
       } else {
         typedef tab_t vec_t __attribute__((ext_vector_type(AP)));
         const vec_t e = reinterpret_cast<const vec_t*>(tab)[kGuard + k];
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
           accr[ar][x] = fmaf(cf, yr, accr[ar][x]);
           acci[ar][x] = fmaf(cf, yi, acci[ar][x]);
         }
+        return (float)e[LA - 1];
       }
     };
     // derived arm: padded-table entry k6 of the six-times-faster replica = entry p = (k6 + 5) / 6 of arm LA - 1 with the sign
@@ -373,12 +376,17 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     auto lean_sample = [&](unsigned int word, const int (&k)[NT], const int (&k6)[3]) {
       float yr, yi;
       mix(word, yr, yi);
-      accumulate(0, k[0], yr, yi);
-      accumulate(1, k[1], yr, yi);
-      accumulate(2, kShare ? k[0] + el_off : k[NT - 1], yr, yi);
-      if constexpr (DER) {
+      const int kk[3] = {k[0], k[1], kShare ? k[0] + el_off : k[NT - 1]};
 #pragma unroll
-        for (int x = 0; x < 3; ++x) accumulate_derived(x, k6[x], yr, yi);
+      for (int x = 0; x < 3; ++x) {
+        const float base = accumulate(x, kk[x], yr, yi);
+        if constexpr (DER) {
+          // away from ties (the caller redoes those exactly) ceil(ceil(6t) / 6) == ceil(t): the entry the derived arm needs
+          // is the one this tap just read, and only the sign (-1)^(p + k6) is left to apply
+          const float cf = __uint_as_float(__float_as_uint(base) ^ ((unsigned int)(kk[x] + k6[x]) << 31));
+          accr[ARMS - 1][x] = fmaf(cf, yr, accr[ARMS - 1][x]);
+          acci[ARMS - 1][x] = fmaf(cf, yi, acci[ARMS - 1][x]);
+        }
       }
     };
     // exact accumulate of one sample: MATLAB colon element i (tracking.m:252-270) in float64 — forwards from
