@@ -536,8 +536,14 @@ __global__ void sigpower_kernel(const int8_t* __restrict__ x, long long first, i
 // pass 1: global max (positive floats order like their bit patterns)
 __global__ void max_kernel(const float* __restrict__ r, long long n, unsigned int* gmax) {
   unsigned int m = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    m = max(m, __float_as_uint(r[i]));
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+  const long long n4 = n >> 2;
+  const float4* r4 = reinterpret_cast<const float4*>(r);  // r is the start of a hipMalloc'ed buffer
+  for (long long i = gid; i < n4; i += stride) {
+    const float4 v = r4[i];
+    m = max(max(m, max(__float_as_uint(v.x), __float_as_uint(v.y))), max(__float_as_uint(v.z), __float_as_uint(v.w)));
+  }
+  for (long long i = (n4 << 2) + gid; i < n; i += stride) m = max(m, __float_as_uint(r[i]));
   for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_down((int)m, off, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(gmax, m);
 }
@@ -665,11 +671,13 @@ struct AcqScratch {
   float* rowmax = nullptr;
   int* rowarg = nullptr;
   int shift_rows = 0;
+  int* peaks = nullptr;       // per-PRN peak slots {max bits, bin, column, -} of gc_acquire_coarse_multi
+  int peaks_cap = 0;
 };
 
 void free_scratch(AcqScratch* s) {
   if (!s) return;
-  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->fine, s->rowmax, s->rowarg};
+  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->fine, s->rowmax, s->rowarg, s->peaks};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -858,6 +866,20 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   rc = forward(ctx, s, base, PRE_CODE, (long long)nprn * narms, s->codespec);
   if (rc) return rc;
 
+  if (s->peaks_cap < nprn) {
+    if (s->peaks) (void)hipFree(s->peaks);
+    s->peaks = nullptr;
+    s->peaks_cap = 0;
+    GC_HIP(hipMalloc((void**)&s->peaks, (size_t)nprn * 4 * sizeof(int)));
+    s->peaks_cap = nprn;
+  }
+  int* const peaks = s->peaks;
+  {
+    std::vector<int> init((size_t)nprn * 4, 0x7fffffff);
+    for (int ip = 0; ip < nprn; ++ip) init[4 * (size_t)ip] = 0;
+    GC_HIP(hipMemcpy(peaks, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+
   for (int ip = 0; ip < nprn; ++ip) {
     for (int arm = 0; arm < narms; ++arm) {
       // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
@@ -893,23 +915,20 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       rc = launch_abs_pass(ctx, s, a, nbins);
       if (rc) return rc;
     }
-    // peak pick
-    unsigned int* gmax = (unsigned int*)(s->sums + 4);
-    int* arg = (int*)(s->sums + 6);
-    const int init[2] = {0x7fffffff, 0x7fffffff};
-    GC_HIP(hipMemsetAsync(gmax, 0, sizeof(unsigned int), ctx->stream));
-    GC_HIP(hipMemcpyAsync(arg, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    // peak pick: per-PRN slot {max bits, bin, column, -}; read back once after the last PRN (no host round trip per PRN)
     const long long total = (long long)nbins * n;
-    hipLaunchKernelGGL(max_kernel, dim3(512), dim3(256), 0, ctx->stream, s->results, total, gmax);
-    hipLaunchKernelGGL(argmax_kernel, dim3(512), dim3(256), 0, ctx->stream, s->results, nbins, n, gmax, arg);
+    int* slot = peaks + 4 * ip;
+    hipLaunchKernelGGL(max_kernel, dim3(256), dim3(256), 0, ctx->stream, s->results, total, (unsigned int*)slot);
+    hipLaunchKernelGGL(argmax_kernel, dim3(512), dim3(256), 0, ctx->stream, s->results, nbins, n, (const unsigned int*)slot, slot + 1);
     GC_HIP(hipGetLastError());
-    unsigned int hmax;
-    int harg[2];
-    GC_HIP(hipMemcpyAsync(&hmax, gmax, sizeof hmax, hipMemcpyDeviceToHost, ctx->stream));
-    GC_HIP(hipMemcpyAsync(harg, arg, sizeof harg, hipMemcpyDeviceToHost, ctx->stream));
-    GC_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<int> hpeaks((size_t)nprn * 4);
+  GC_HIP(hipMemcpyAsync(hpeaks.data(), peaks, hpeaks.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  for (int ip = 0; ip < nprn; ++ip) {
+    const int harg[2] = {hpeaks[4 * ip + 1], hpeaks[4 * ip + 2]};
     float peak;
-    std::memcpy(&peak, &hmax, sizeof peak);
+    std::memcpy(&peak, &hpeaks[4 * ip], sizeof peak);
     out[ip].coarse_bin = harg[0] + 1;   // 1-based like MATLAB
     out[ip].code_phase = harg[1] + 1;
     out[ip].peak = (double)peak;
