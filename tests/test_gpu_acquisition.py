@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_fft_matches_numpy(engine):
     rng = np.random.default_rng(0)
-    for n in (36000, 24000, 8000, 72000):
+    for n in (36000, 24000, 8000, 72000, 240, 60, 16, 1250):   # small lengths too
         x = (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n))).astype(np.complex64)
         got = engine.debug_fft(x)
         ref = np.fft.fft(x.astype(np.complex128), axis=1)
