@@ -103,6 +103,10 @@ def main() -> None:
         dev_loop = {"corr_msps": round(chan_samples / t_dev / 1e6, 1), "x_realtime": round(chan_samples / t_dev / 1e6 / nch / (fs / 1e6), 2),
                     "us_per_epoch": round(t_dev / n_epochs * 1e6, 2),
                     "same_block_geometry_as_host_loop": bool(np.array_equal(dfields["absoluteSample"], fields["absoluteSample"])),
+                    # two closed loops part ways by one sample of block boundary at a knife edge of ceil() sooner or later
+                    # (DESIGN.md 4.3b); until then they cut identical blocks
+                    "epochs_with_the_host_loops_block_geometry": int(np.argmax(np.any(dfields["absoluteSample"] != fields["absoluteSample"], axis=0)))
+                    if np.any(dfields["absoluteSample"] != fields["absoluteSample"]) else int(n_epochs),
                     "max_carr_freq_dev_hz": float(np.max(np.abs(dfields["carrFreq"] - fields["carrFreq"])))}
 
     # ---- replay descriptors, epoch-major so the channels of one epoch sit next to each other ----
