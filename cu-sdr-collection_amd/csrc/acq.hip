@@ -659,10 +659,14 @@ void fill_sub(PassArgs& a, const SubPlan& sp) {
 }
 
 // columns per tile: keep 2*L*C*8 bytes <= 64 KiB and L*C <= 8*256 (POST_ABS_ACC register slots)
-int choose_cols(int L) {
+int choose_cols(int L, int estride = 1) {
   int budget = 2048;
   if (const char* e = std::getenv("GC_ACQ_TILE")) budget = std::max(256, std::atoi(e));  // tuning: elements per tile
-  return std::max(1, std::min(16, budget / L));
+  int c = std::max(1, std::min(16, budget / L));
+  // strided vectors (the column passes): a tile row is c consecutive float2; whole 64-byte sectors when c is a multiple of 8
+  static const int align = [] { const char* e = std::getenv("GC_ACQ_COLS_ALIGN"); return e ? std::atoi(e) : 8; }();
+  if (estride != 1 && align > 1 && c >= align) c -= c % align;
+  return c;
 }
 
 struct AcqScratch {
@@ -791,7 +795,7 @@ static int forward(gc_context* ctx, AcqScratch* s, PassArgs base, int pre, long 
   a.nvec = pl.n2;
   a.estride = pl.n2;
   a.vstride = 1;
-  a.cols = choose_cols(a.len);
+  a.cols = choose_cols(a.len, a.estride);
   a.pre = pre;
   a.post = POST_TWIDDLE;
   a.out = s->tmp;
@@ -803,7 +807,7 @@ static int forward(gc_context* ctx, AcqScratch* s, PassArgs base, int pre, long 
   a.nvec = pl.n1;
   a.estride = 1;
   a.vstride = pl.n2;
-  a.cols = choose_cols(a.len);
+  a.cols = choose_cols(a.len, a.estride);
   a.pre = PRE_NONE;
   a.post = POST_STORE;
   a.in = s->tmp;
@@ -905,7 +909,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.nvec = pl.n1;
       a.estride = 1;
       a.vstride = pl.n2;
-      a.cols = choose_cols(a.len);
+      a.cols = choose_cols(a.len, a.estride);
       a.pre = PRE_MUL_CONJ;
       a.post = POST_TWIDDLE;
       a.in = s->sig;
@@ -920,7 +924,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.nvec = pl.n2;
       a.estride = pl.n2;
       a.vstride = 1;
-      a.cols = choose_cols(a.len);
+      a.cols = choose_cols(a.len, a.estride);
       a.pre = PRE_NONE;
       a.post = POST_ABS_ACC;
       a.in = s->tmp;
@@ -1074,7 +1078,7 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.nvec = pl.n1;
     a.estride = 1;
     a.vstride = pl.n2;
-    a.cols = choose_cols(a.len);
+    a.cols = choose_cols(a.len, a.estride);
     a.pre = PRE_MUL_CONJ;
     a.post = POST_TWIDDLE;
     a.in = s->sig;
@@ -1091,7 +1095,7 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.nvec = pl.n2;
     a.estride = pl.n2;
     a.vstride = 1;
-    a.cols = choose_cols(a.len);
+    a.cols = choose_cols(a.len, a.estride);
     a.pre = PRE_NONE;
     a.shift_bins = 0;
     a.post = POST_ABS_ACC;
@@ -1141,7 +1145,7 @@ extern "C" int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in,
   a.nvec = pl.n2;
   a.estride = pl.n2;
   a.vstride = 1;
-  a.cols = choose_cols(a.len);
+  a.cols = choose_cols(a.len, a.estride);
   a.pre = PRE_NONE;
   a.post = POST_TWIDDLE;
   a.in = s->sig;
@@ -1154,7 +1158,7 @@ extern "C" int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in,
   a.nvec = pl.n1;
   a.estride = 1;
   a.vstride = pl.n2;
-  a.cols = choose_cols(a.len);
+  a.cols = choose_cols(a.len, a.estride);
   a.post = POST_STORE;
   a.in = s->tmp;
   a.out = s->sig;
