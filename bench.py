@@ -33,6 +33,26 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def _spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without torch.distributed.run: start N copies of this script, one rank per GPU
+    (LOCAL_RANK selects the device; GC_BENCH_DEVICE pins every rank to one device on a 1-GPU box), rendezvous on
+    127.0.0.1.  Rank 0 prints the result line; the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,9 +64,16 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args.gpus))     # no external launcher: one process per GPU, started here
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         "they must agree (n_gpus in the result line is the number of ranks that ran)")
     dist = None
     if world > 1 or os.environ.get("GC_BENCH_FORCE_DIST"):
         import torch.distributed as dist  # control plane only: gloo on CPU tensors

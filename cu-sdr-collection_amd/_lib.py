@@ -50,6 +50,12 @@ class gc_channel_init(C.Structure):
                 ("code_freq", C.c_double), ("code_phase", C.c_int64), ("table_phase", C.c_int32), ("reserved", C.c_int32)]
 
 
+class gc_track_job(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("params", C.POINTER(gc_track_params)), ("init", C.POINTER(gc_channel_init)),
+                ("out", C.POINTER(C.c_double)), ("epochs_done", C.POINTER(C.c_int32)), ("nch", C.c_int32),
+                ("device_loop", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32), ("error", C.c_char * 240)]
+
+
 class gc_acq_params(C.Structure):
     _fields_ = [("sampling_freq", C.c_double), ("code_freq_basis", C.c_double), ("code_length", C.c_double),
                 ("intermediate_freq", C.c_double), ("search_band", C.c_double), ("search_step", C.c_double),
@@ -104,6 +110,8 @@ SYMBOLS = {
                            C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "gc_track_device": (C.c_int, [_P, C.POINTER(gc_track_params), C.c_int, C.POINTER(gc_channel_init),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "gc_share_if": (C.c_int, [_P, _P]),
+    "gc_track_multi": (C.c_int, [C.c_int, C.POINTER(gc_track_job)]),
     "gc_acquire_coarse": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_coarse_multi": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,

@@ -12,6 +12,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib as L
+from .settings import skip_samples
 from . import codes
 
 NH20 = np.array([1, 1, 1, 1, 1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, -1, -1, -1, 1], dtype=np.float64)  # GPS_L5C acquisition.m:131
@@ -53,7 +54,7 @@ def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, 
               table_fn=None, fine_code_freq=None, fine_code_len=None, index_offset=1):
     from .receiver import _acq_params
     if first_sample is None:
-        first_sample = int(settings.skipNumberOfBytes)
+        first_sample = skip_samples(settings)
     prns = list(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(n_results), codePhase=np.zeros(n_results), peakMetric=np.zeros(n_results))
     p = _acq_params(settings, first_sample)
@@ -189,7 +190,7 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None):
     |sum(10 codes) - sum(next 10)| at 20 alignments.  Results are indexed K + 8."""
     from .receiver import _acq_params
     if first_sample is None:
-        first_sample = int(settings.skipNumberOfBytes)
+        first_sample = skip_samples(settings)
     spc = _round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength))
     acq = SimpleNamespace(carrFreq=np.zeros(21), codePhase=np.zeros(21), peakMetric=np.zeros(21))
     table = glonass_sampled_code(settings.samplingFreq, spc)[None, :]

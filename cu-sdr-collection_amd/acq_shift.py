@@ -11,6 +11,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib as L
+from .settings import skip_samples
 from . import codes
 
 
@@ -61,7 +62,7 @@ def _b1i_step_size(settings, freq_resolution: float, nblocks: int) -> float:
 def acquisition_B1I(engine, settings, first_sample: int | None = None):
     """acqResults = acquisition(longSignal, settings) of BDS/B1I/include/acquisition.m (resampling off)."""
     if first_sample is None:
-        first_sample = int(settings.skipNumberOfBytes)
+        first_sample = skip_samples(settings)
     ncodes, nblocks = 2, 4                                                         # :34-35
     fs = settings.samplingFreq
     spb = _round(fs / (settings.codeFreqBasis / (nblocks * settings.codeLength)))  # :36-37 samplesPerBlock
@@ -115,7 +116,7 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
     """acqResults = acquisition(longSignal, settings) of GPS/GPS_L2C/include/acquisition.m: CM search over a
     40-ms block (Nblocks = 2), then — with pilotTRKflag — which of the 75 CL segments the CM period found lies in."""
     if first_sample is None:
-        first_sample = int(settings.skipNumberOfBytes)
+        first_sample = skip_samples(settings)
     nblocks = 2                                                                    # :13
     fs = settings.samplingFreq
     spc = _round(fs / (settings.codeFreqBasis / settings.codeLength))              # :14-15
@@ -188,7 +189,7 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
     sqrt(11):sqrt(29), GLRT-style metric peak/sigPower, then a 25-Hz fine search on one code period.
     n_long = length(longSignal) (the reference pulls the code phase back by one period if too close to its end)."""
     if first_sample is None:
-        first_sample = int(settings.skipNumberOfBytes)
+        first_sample = skip_samples(settings)
     fs = settings.samplingFreq
     spc = _round(fs / (settings.codeFreqBasis / settings.codeLength))              # :108-109
     xlen = _round(spc / 10 * settings.acqCohT)                                      # :111 samplesXmsLen

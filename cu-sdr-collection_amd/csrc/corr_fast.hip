@@ -669,7 +669,7 @@ int launch_devloop_mode(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 
   if (share) fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, true, 0, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, true, 0, true>;
   else fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, false, 0, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, false, 0, true>;
   // cooperative: every team member must be resident while the others spin on the epoch flag
-  GC_HIP(hipLaunchCooperativeKernel(fn, grid, dim3(kFW), args, (unsigned int)smem, ctx->stream));
+  GC_HIP(gc_launch_persistent(ctx, fn, grid, dim3(kFW), args, (unsigned int)smem));
   return GC_OK;
 }
 

@@ -728,7 +728,7 @@ int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 
   void* args[2] = {(void*)&a, (void*)&ib};
   const void* fn = share ? (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 1, true> : (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 0, true>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  GC_HIP(hipLaunchCooperativeKernel(fn, grid, dim3(waves * 64), args, (unsigned int)smem, ctx->stream));
+  GC_HIP(gc_launch_persistent(ctx, fn, grid, dim3(waves * 64), args, (unsigned int)smem));
   return GC_OK;
 }
 
@@ -755,7 +755,7 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
     void* args[2] = {(void*)&a, (void*)&ib};
     const void* fn = qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 0, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    GC_HIP(hipLaunchCooperativeKernel(fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem, ctx->stream));
+    GC_HIP(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
     return GC_OK;
   }
   if (max_arms == 1) return qi ? launch_lane_devloop<1, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el, waves) : launch_lane_devloop<1, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el, waves);

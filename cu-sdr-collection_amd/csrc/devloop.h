@@ -22,7 +22,8 @@ typedef unsigned int msg_t __attribute__((ext_vector_type(4)));  // one 16-byte 
 
 struct DevLoopChan {
   gc_block blk;              // initial descriptor (host) / last descriptor (closer)
-  int status;                // 0 running, 1 all epochs done, 2 record exhausted (tracking.m:241-245), 3 wait timed out
+  int status;                // 0 running, 1 all epochs done, 2 record exhausted (tracking.m:241-245), 3 wait timed out,
+                             // 4 code NCO diverged: codeFreq not finite / not positive (MATLAB's fread(fid, NaN) errors there)
   int epochs_done;
   int pad0[2];
   // loop state, touched by the closing member only
@@ -205,6 +206,8 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
   int status = 0;
   if (e + 1 >= dl->n_epochs)
     status = 1;
+  else if (!(step_new > 0.0) || !(step_new < 1e6) || !(carr_freq_new == carr_freq_new))
+    status = 4;  // non-finite or non-positive code step (all-zero sums give atan(0/0) = NaN): no block can be cut from it
   else if (pos_new < 0 || (unsigned long long)(pos_new + n_new) > dl->if_nsamples)
     status = 2;
   st.pos = pos_new;

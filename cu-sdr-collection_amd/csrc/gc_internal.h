@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -121,7 +122,24 @@ struct gc_context {
 
   // acquisition scratch (acq.hip)
   void* acq_scratch = nullptr;
+
+  // gc_track_multi: this context's tracking call runs next to other contexts' on the same device.  Its persistent kernels
+  // are then launched with a plain launch instead of a cooperative one (gc_launch_persistent below).
+  bool concurrent_jobs = false;
+  int concurrent_channels = 0;  // channels of all jobs on this device (sizes the persistent kernels' teams)
 };
+
+// Launch of a persistent (host-fed or device-loop) kernel whose workgroups wait for each other's messages and therefore must
+// all be resident.  Alone on the device: a cooperative launch, the runtime guarantees residency.  Next to other contexts'
+// persistent kernels (gc_track_multi): cooperative launches of different streams do not overlap, and a host-fed kernel that
+// waits behind another one never gets its descriptors consumed - so those are plain launches, co-resident because
+// gc_track_multi admits only job sets whose grids fit the device together.  GC_PERSIST_COOP=0/1 forces either (experiments).
+inline hipError_t gc_launch_persistent(const gc_context* ctx, const void* fn, dim3 grid, dim3 block, void** args, unsigned int smem) {
+  bool coop = !ctx->concurrent_jobs;
+  if (const char* e = std::getenv("GC_PERSIST_COOP")) coop = std::atoi(e) != 0;
+  return coop ? hipLaunchCooperativeKernel(fn, grid, block, args, smem, ctx->stream)
+              : hipLaunchKernel(fn, grid, block, args, smem, ctx->stream);
+}
 
 int gc_bytes_per_sample(int dtype, int layout);
 void gc_acq_free(gc_context* ctx);  // acq.hip

@@ -38,6 +38,46 @@ void calc_loop_coef(double lbw, double zeta, double k, double* tau1, double* tau
 
 const double kPi = 3.141592653589793;  // MATLAB pi
 
+// What gc_correlate checks per descriptor (validate_blocks, gnsscorr.hip), for the blocks a tracking loop will cut from one
+// channel: every ramp stays inside the reference's [c(end) c c(1)] padding (tracking.m:158,252-270) for ANY code step, because
+// (blksize-1)*step + rem < codeLength by construction of blksize (:222): the largest index is ceil((codeLength + spacing)*R*M).
+int validate_track_channel(const gc_context* ctx, const gc_track_params* p, const gc_channel_init& in, const char* who) {
+  const HostChannel& c = ctx->ch[in.channel];
+  if (!(p->sampling_freq > 0) || !(p->code_length > 0) || !(p->el_spacing >= 0) || !(p->int_time > 0) || !(in.code_freq > 0) ||
+      !std::isfinite(in.code_freq) || !std::isfinite(in.acquired_freq) || in.code_phase < 0) {
+    gc_set_error("%s: channel %d: invalid parameters (samplingFreq %g, codeLength %g, spacing %g, codeFreq %g, acquiredFreq %g)", who,
+                 in.channel, p->sampling_freq, p->code_length, p->el_spacing, in.code_freq, in.acquired_freq);
+    return GC_E_INVALID;
+  }
+  for (int a = 0; a < c.arms; ++a) {
+    const double rm = c.index_scale * c.mult[a];
+    if (!(p->el_spacing * rm < 1.0)) {
+      gc_set_error("%s: channel %d arm %d: dllCorrelatorSpacing * index scale * ramp multiplier = %g table entries; the early/late "
+                   "ramps must stay within one entry of the prompt ramp ([c(end) c c(1)] has one pad entry either side)", who,
+                   in.channel, a, p->el_spacing * rm);
+      return GC_E_INVALID;
+    }
+    int offset_max = 0;
+    if (a == 1 && p->table_phase_count > 0) {  // GPS_L2C tracking.m:261: window offset codeLength*(CLCodePhase-1), CLCodePhase <= count
+      if (in.table_phase < 0 || in.table_phase > p->table_phase_count) {
+        gc_set_error("%s: channel %d: table_phase %d outside 1..%d", who, in.channel, in.table_phase, p->table_phase_count);
+        return GC_E_INVALID;
+      }
+      offset_max = (int)p->code_length * (p->table_phase_count - 1);
+    }
+    const int stage = (c.window[a] > 0) ? std::min(c.window[a], c.nent[a]) : c.nent[a];
+    const int avail = std::min(stage, c.nent[a] - offset_max);
+    const double top = std::ceil((p->code_length + p->el_spacing) * rm);
+    if (top > avail - 1) {
+      gc_set_error("%s: channel %d arm %d: the code ramps reach table index %g but the table (window) holds %d entries - "
+                   "settings.codeLength (%g) x index scale x multiplier does not match the table set with gc_set_code", who,
+                   in.channel, a, top, avail, p->code_length);
+      return GC_E_INVALID;
+    }
+  }
+  return GC_OK;
+}
+
 }  // namespace
 
 extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
@@ -52,6 +92,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   }
   GC_HIP(hipSetDevice(ctx->device));
   ctx->fs = p->sampling_freq;
+  // channels that share the device during this call (gc_track_multi): teams are sized for all of them
+  const int nch_dev = ctx->concurrent_jobs ? std::max(nch, ctx->concurrent_channels) : nch;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
 
@@ -69,6 +111,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
         gc_set_error("gc_track: channel %d arm %d has no code table", ci, a);
         return GC_E_STATE;
       }
+    if ((rc = validate_track_channel(ctx, p, init[c], "gc_track"))) return rc;
     max_arms = std::max(max_arms, ctx->ch[ci].arms);
     if (ctx->ch[ci].arms == 3 && !gc_channel_is_derived(ctx->ch[ci])) any_three_plain = true;
     gc_scope_add(ctx, ci);
@@ -104,7 +147,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   int splits;
   if (fast_nominal) {
     const int chunks_nominal = approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8);
-    splits = (8 * ctx->compute_units + nch - 1) / nch;
+    splits = (8 * ctx->compute_units + nch_dev - 1) / nch_dev;
     splits = std::max(1, std::min(std::min(splits, 32), std::max(1, chunks_nominal / (2 * 64))));
     if (gc_fast_table_mode(ctx) == 1) splits = std::max(4, std::min(32, (splits / 4) * 4));  // WIDE: 4 waves per workgroup
   } else {
@@ -127,6 +170,8 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   // Results of the fast kernel arrive as host-mapped tagged 16-byte records (corr_common.h TaggedSlot): a
   // stream synchronise costs ~15-20 us of wake-up latency per epoch, polling the tags does not.
   const bool poll = std::getenv("GC_TRACK_NO_POLL") == nullptr;
+  int poll_timeout_ms = 2000;  // per epoch; GC_TRACK_POLL_TIMEOUT_MS overrides
+  if (const char* ev = std::getenv("GC_TRACK_POLL_TIMEOUT_MS")) poll_timeout_ms = std::max(1, std::atoi(ev));
   const int64_t need_slots = (int64_t)nch * 32 * GC_OUT_STRIDE;
   if (ctx->tagged_cap < need_slots) {
     GC_HIP(hipStreamSynchronize(ctx->stream));
@@ -221,9 +266,9 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     std::atomic_thread_fence(std::memory_order_release);
   };
   // members per team of the persistent kernel (its all-gather covers up to 32); the host sees ONE record group per channel
-  int psplits_dev = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8) / 48)}));
+  int psplits_dev = std::max(1, std::min({32, (4 * ctx->compute_units + nch_dev - 1) / nch_dev, std::max(1, approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8) / 48)}));
   if (persist_lane)  // members of a lane-kernel team: workgroups of 8 waves (as gc_track_device)
-    psplits_dev = std::max(1, std::min({max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4, approx_chunks * 8 / (64 * 8 * 2), std::max(1, 2 * ctx->compute_units / nch)}));
+    psplits_dev = std::max(1, std::min({max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4, approx_chunks * 8 / (64 * 8 * 2), std::max(1, 2 * ctx->compute_units / nch_dev)}));
   if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(persist_lane ? (max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4) : 32, std::atoi(ev)));
   if (persist) {
     pa.n_epochs = n_epochs;
@@ -296,7 +341,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   }
 
   std::vector<int> slot((size_t)nch);
-  bool any_range = false;
+  bool any_range = false, any_diverged = false;
   double t_launch = 0.0, t_wait = 0.0;  // GC_TRACK_TIMING: host time in the launch call / until the records arrived
   const auto t_loop0 = std::chrono::steady_clock::now();
   for (int e = 0; e < n_epochs; ++e) {
@@ -305,6 +350,14 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       ChanState& s = st[c];
       if (!s.active) continue;
       const double step = s.code_freq / p->sampling_freq;                      // :219
+      if (!(step > 0.0) || !(step < 1e6) || !std::isfinite(s.carr_freq)) {
+        // all-zero sums make atan(0/0) = NaN of the carrier and code NCOs; MATLAB then fails in fread(fid, NaN): stop the channel
+        s.active = false;
+        s.aborted = true;
+        any_diverged = true;
+        if (persist) write_desc(c, e, nullptr, 2ull);
+        continue;
+      }
       const int n = (int)std::ceil((p->code_length - s.rem_code) / step);     // :222
       if (s.pos < 0 || (uint64_t)(s.pos + n) > ctx->if_nsamples) {            // :241-245
         s.active = false;
@@ -350,25 +403,27 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     const auto tt1 = std::chrono::steady_clock::now();
     bool signalled = false;
     if (polled) {
-      // wait until every record of this launch carries the epoch tag (bounded: never hang here)
-      const auto t0 = std::chrono::steady_clock::now();
+      // wait until every record of this launch carries the epoch tag (bounded: never hang here).  A busy device (other
+      // contexts' kernels in front of ours) can delay a launch by much more than its own few microseconds: when the poll
+      // budget runs out, the launch-per-epoch mode falls back to a stream synchronise and looks once more before giving up.
       const int arms6 = max_arms * 6;
-      signalled = true;
       const int hs = persist ? 1 : splits;  // record groups per block as the host sees them (the persistent kernel's teams add up on the device)
-      for (int k = 0; k < nb * hs && signalled; ++k)
-        for (int v = 0; v < arms6; ++v) {
-          // record group of (block, split): blocks are numbered per launch, teams of the persistent kernel per channel
-          const size_t grp = persist ? (size_t)slot[k] : (size_t)k;
-          volatile gcorr::TaggedSlot* s = tagged + grp * GC_OUT_STRIDE + v;
-          unsigned int spins = 0;
-          while (s->tag != tag) {
-            if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds((persist && e == 0) ? 5000 : 50)) {  // first epoch of the persistent kernel: code load + cooperative launch
-              signalled = false;
-              break;
-            }
+      auto wait_tags = [&](std::chrono::milliseconds budget) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < nb * hs; ++k)
+          for (int v = 0; v < arms6; ++v) {
+            // record group of (block, split): blocks are numbered per launch, teams of the persistent kernel per channel
+            const size_t grp = persist ? (size_t)slot[k] : (size_t)k;
+            volatile gcorr::TaggedSlot* s = tagged + grp * GC_OUT_STRIDE + v;
+            unsigned int spins = 0;
+            while (s->tag != tag)
+              if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > budget) return false;
           }
-          if (!signalled) break;
-        }
+        return true;
+      };
+      // first epoch of the persistent kernel: code load + launch of the whole grid
+      signalled = wait_tags(std::chrono::milliseconds((persist && e == 0) ? std::max(5000, poll_timeout_ms) : poll_timeout_ms));
+      if (!signalled && !persist && hipStreamSynchronize(ctx->stream) == hipSuccess) signalled = wait_tags(std::chrono::milliseconds(1));
       std::atomic_thread_fence(std::memory_order_acquire);
     }
     const auto tt2 = std::chrono::steady_clock::now();
@@ -551,6 +606,10 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
                  t_launch / n_epochs, t_wait / n_epochs,
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count() / n_epochs,
                  persist_was ? (persist_lane ? "persistent lane kernel" : "persistent kernel") : "launch per epoch", persist_was ? psplits_dev : splits);
+  if (any_diverged) {
+    gc_set_error("gc_track: a channel's code / carrier NCO became non-finite (all-zero correlator sums?); its records end there");
+    return GC_E_INVALID;
+  }
   if (any_range) {
     gc_set_error("Not able to read the specified number of samples for tracking");
     return GC_E_RANGE;
@@ -574,6 +633,8 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   }
   GC_HIP(hipSetDevice(ctx->device));
   ctx->fs = p->sampling_freq;
+  // channels that share the device during this call (gc_track_multi): teams are sized for all of them
+  const int nch_dev = ctx->concurrent_jobs ? std::max(nch, ctx->concurrent_channels) : nch;
   int rc = gc_sync_channels(ctx);
   if (rc) return rc;
   gc_scope_reset(ctx);
@@ -593,6 +654,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
         gc_set_error("gc_track_device: windowed tables / ramp multipliers are not covered (use gc_track)");
         return GC_E_UNSUPPORTED;
       }
+    if ((rc = validate_track_channel(ctx, p, init[c], "gc_track_device"))) return rc;
     max_arms = std::max(max_arms, hcn.arms);
     single_r1 = single_r1 && hcn.arms == 1 && hcn.index_scale == 1.0;
     gc_scope_add(ctx, ci);
@@ -638,7 +700,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (use_fast) {
     // team size: just under one lane-chunk per lane and member — the epoch is a latency chain
     const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
-    splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch - 1) / nch, std::max(1, chunks / 32)}));
+    splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch_dev - 1) / nch_dev, std::max(1, chunks / 32)}));
     if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
     msgs_per_member = 2;
   } else {
@@ -648,7 +710,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     lane_waves = 8;  // measured best for both the 1-ms and the 4-ms packages (scripts/devloop_lane_sweep.py)
     if (const char* e = std::getenv("GC_DEVLOOP_WAVES")) lane_waves = std::max(1, std::min(8, std::atoi(e)));  // the device-loop instantiations are bounded to 8 waves
     const int max_members = max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4;  // (members - 1) * 6 * arms messages <= 64 lanes
-    splits = std::max(1, std::min({max_members, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch)}));
+    splits = std::max(1, std::min({max_members, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch_dev)}));
     if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_members, std::atoi(e)));
     msgs_per_member = 6 * max_arms;
   }
@@ -739,13 +801,14 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (rc) return rc;
   // same early-return semantics as gc_track: channels after the first exhausted one are never run
   int first_aborted = nch;
-  bool timeout = false;
+  bool timeout = false, diverged = false;
   for (int c = 0; c < nch; ++c) {
     timeout |= hc[c].status == 3;
+    diverged |= hc[c].status == 4;
     if (ha.timing == 1 && hc[c].epochs_done > 0)
       std::fprintf(stderr, "devloop ch %d: correlate %.2f us, wait partials %.2f us, close+publish %.2f us per epoch (closer)\n", c,
                    hc[c].pad[0] / hc[c].epochs_done * 0.01, hc[c].pad[1] / hc[c].epochs_done * 0.01, hc[c].pad[2] / hc[c].epochs_done * 0.01);
-    if (hc[c].status == 2 && first_aborted == nch) first_aborted = c;
+    if ((hc[c].status == 2 || hc[c].status == 4) && first_aborted == nch) first_aborted = c;
   }
   if (timeout) {
     gc_set_error("gc_track_device: a team member timed out waiting for its epoch descriptor");
@@ -759,6 +822,10 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     } else {
       epochs_done[c] = hc[c].epochs_done;
     }
+  }
+  if (diverged) {
+    gc_set_error("gc_track_device: a channel's code / carrier NCO became non-finite (all-zero correlator sums?); its records end there");
+    return GC_E_INVALID;
   }
   if (first_aborted < nch) {
     gc_set_error("Not able to read the specified number of samples for tracking (channel slot %d)", first_aborted);

@@ -87,6 +87,11 @@ class Engine:
         dt, _ = self._fmt(np.dtype(dtype), layout)
         L.check(self._lib.gc_attach_if(self._ctx, C.c_void_p(device_ptr), nsamples, dt, layout))
 
+    def share_if(self, owner: "Engine"):
+        """Read `owner`'s IF record from this context too (same GPU, no copy): gc_share_if."""
+        L.check(self._lib.gc_share_if(self._ctx, owner._ctx))
+        self._if_owner = owner  # keep the owner (and with it the device allocation) alive
+
     def if_buffer(self):
         p = C.c_void_p()
         n = C.c_uint64()
@@ -171,6 +176,37 @@ class Engine:
             L.check(st)
         fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
         return fields, np.array(list(done)), st
+
+    @staticmethod
+    def track_multi(jobs, device_loop: bool = False):
+        """gc_track_multi: jobs = [(engine, gc_track_params, [gc_channel_init, ...]), ...], one engine (context) per job,
+        all tracking loops run concurrently.  Returns [(fields, epochs_done, status), ...] in job order."""
+        lib = L.load()
+        n = len(jobs)
+        arr = (L.gc_track_job * n)()
+        keep = []
+        for k, (eng, params, inits) in enumerate(jobs):
+            nch = len(inits)
+            ia = (L.gc_channel_init * nch)(*inits)
+            out = np.zeros((nch, L.GC_TRK_NFIELDS, params.n_epochs))
+            done = (C.c_int32 * nch)()
+            keep.append((ia, out, done, params))
+            arr[k].ctx = eng._ctx
+            arr[k].params = C.pointer(params)
+            arr[k].init = ia
+            arr[k].out = out.ctypes.data_as(C.POINTER(C.c_double))
+            arr[k].epochs_done = done
+            arr[k].nch = nch
+            arr[k].device_loop = int(bool(device_loop))
+        st = lib.gc_track_multi(n, arr)
+        res = []
+        for k, (ia, out, done, params) in enumerate(keep):
+            if arr[k].status not in (L.GC_OK, L.GC_E_RANGE):
+                raise L.GnssCorrError(arr[k].status, f"job {k}: " + arr[k].error.decode("utf-8", "replace"))
+            res.append(({name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}, np.array(list(done)), int(arr[k].status)))
+        if st not in (L.GC_OK, L.GC_E_RANGE):
+            L.check(st)
+        return res
 
     # ---- acquisition ---------------------------------------------------------------------
     def acquire_coarse(self, params: L.gc_acq_params, sampled_codes: np.ndarray):

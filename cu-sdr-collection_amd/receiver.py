@@ -16,6 +16,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib as L
+from .settings import skip_samples
 from . import codes
 from .engine import Engine
 
@@ -99,7 +100,7 @@ def acquisition(engine: Engine, settings, first_sample: int | None = None):
     if settings.samplingFreq > settings.resamplingThreshold and settings.resamplingflag == 1:
         raise NotImplementedError("acquisition resampling front end (acquisition.m:50-111) is out of scope")
     if first_sample is None:
-        first_sample = int(settings.skipNumberOfBytes)
+        first_sample = skip_samples(settings)
     prns = list(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32))
     p = _acq_params(settings, first_sample)
@@ -117,17 +118,37 @@ def acquisition(engine: Engine, settings, first_sample: int | None = None):
 # ---------------------------------------------------------------------------------------------
 # preRun
 # ---------------------------------------------------------------------------------------------
-def preRun(acqResults, settings):
+def preRun(acqResults, settings, signal: str = "GPS_L1CA"):
+    """channel = preRun(acqResults, settings) of package `signal` (include/preRun.m of each package): the strongest
+    detections first, one struct per channel.  Per-package fields: `codeFreq` for the packages whose tracking.m starts the code
+    NCO from it (GPS_L5C preRun.m:69-71: codeFreqBasis + (acquiredFreq - IF)/carrFreqBasis*codeFreqBasis; also GAL_E5a / E5b,
+    BDS B1C / B2a / B3I), `CLCodePhase` for GPS L2C with the pilot on (GPS_L2C preRun.m:70-72), `K = index - 8` instead of
+    `PRN` for GLONASS (GLO_GL1 preRun.m:66).  Indices run over the whole acqResults arrays, whatever their length (32, 50, 63
+    PRNs; 14 frequency numbers at K + 8)."""
+    from . import signals
+    spec = signals.SIGNALS[signal]
     n_ch = int(settings.numberOfChannels)
-    channel = [SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-") for _ in range(n_ch)]
-    order = np.argsort(-np.asarray(acqResults.peakMetric), kind="stable")   # preRun.m:60
+    glo = spec.id_field == "K"
+    channel = []
+    for _ in range(n_ch):
+        ch = SimpleNamespace(acquiredFreq=0.0, codePhase=0, status="-")
+        setattr(ch, spec.id_field, 0)
+        if spec.code_freq_from_channel:
+            ch.codeFreq = 0.0
+        channel.append(ch)
+    order = np.argsort(-np.asarray(acqResults.peakMetric, dtype=np.float64), kind="stable")   # preRun.m:60 (sort ... 'descend' is stable)
     n_found = int(np.sum(np.asarray(acqResults.carrFreq) != 0))
     for ii in range(min(n_ch, n_found)):                                      # :65
         p = int(order[ii])
-        channel[ii].PRN = p + 1
-        channel[ii].acquiredFreq = float(acqResults.carrFreq[p])
-        channel[ii].codePhase = int(acqResults.codePhase[p])
-        channel[ii].status = "T"
+        ch = channel[ii]
+        setattr(ch, spec.id_field, p + 1 - 8 if glo else p + 1)
+        ch.acquiredFreq = float(acqResults.carrFreq[p])
+        ch.codePhase = int(acqResults.codePhase[p])
+        if spec.code_freq_from_channel:
+            ch.codeFreq = settings.codeFreqBasis + (ch.acquiredFreq - settings.IF) / settings.carrFreqBasis * settings.codeFreqBasis
+        if spec.doubled_code and getattr(settings, "pilotTRKflag", 0):
+            ch.CLCodePhase = int(acqResults.CLCodePhase[p])
+        ch.status = "T"
     return channel
 
 
@@ -166,7 +187,12 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
                 getattr(p, name)[0], getattr(p, name)[1] = float(w[0]), float(w[1])
         if spec.dll_scale_spacing:
             p.dll_scale = 1.0 - settings.dllCorrelatorSpacing
-    p.skip_samples = int(settings.skipNumberOfBytes)
+    # tracking.m:145-153: dataAdaptCoeff*(skipNumberOfBytes + codePhase-1) bytes of schar components, or
+    # dataAdaptCoeff*(skipNumberOfBytes + (codePhase-1)*2) bytes of int16 components = skipNumberOfBytes/2 + codePhase-1 samples
+    if str(getattr(settings, "dataType", "schar")) == "int16" and not spec.int16_branch:
+        raise NotImplementedError(f"{signal}: the reference's tracking.m has no int16 branch (its fseek assumes one byte per "
+                                  "component and would start at half the code phase); convert the record to schar")
+    p.skip_samples = skip_samples(settings)
     p.n_epochs = signals.epochs_to_process(settings)
     if spec.doubled_code:
         # GPS_L2C/include/tracking.m:107-109: spacing and code length in units of the RZ-doubled code; :153 seeks to
@@ -174,24 +200,19 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
         p.el_spacing = settings.dllCorrelatorSpacing * 2
         p.code_length = settings.codeLength * 2
         p.code_freq_basis = settings.codeFreqBasis * 2
-        p.skip_samples = int(settings.skipNumberOfBytes) + 1
+        p.skip_samples = skip_samples(settings) + 1
         p.table_phase_count = 75 if pilot else 0
     return p
 
 
-def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_loop: bool = False):
-    """[trackResults, channel] = tracking(fid, channel, settings) — `signal` selects the reference
-    package whose tracking.m is mirrored ("GPS_L1CA": GPS/GPS_L1CA/include/tracking.m;
-    "GAL_E1C": GAL/GAL_E1C/include/tracking.m, data + pilot arms, BOC(1,1) half-chip tables).
-
-    Returns (trackResults, channel).  On a short read the reference prints a message and
-    returns what it has (tracking.m:241-245); here the partially filled results are returned
-    the same way and `trackResults[i].status` stays '-' for channels that did not finish.
-    """
+def _tracking_prepare(fid: Engine, channel, settings, signal: str):
+    """The part of tracking() in front of the loops: result structs (tracking.m:47-86), code tables (:156-158), per-channel
+    start state (:145-170).  Returns a job record for _tracking_finish."""
     from . import signals
     spec = signals.SIGNALS[signal]
-    if settings.fileType != 2 or settings.dataType not in ("schar", "int8", "int16"):
-        raise NotImplementedError("tracking(): fileType 2 (I/Q) schar/int16 input only in this build")
+    if settings.fileType not in (1, 2) or settings.dataType not in ("schar", "int8", "int16"):
+        raise ValueError("tracking(): settings.fileType must be 1 (real) or 2 (I/Q), settings.dataType 'schar' or 'int16'")
+    # fileType 1 (real samples, tracking.m:126-130,232-236): the record must have been loaded with layout GC_REAL
     n_ep = signals.epochs_to_process(settings)
     p = track_params(settings, signal)
     pilot = p.pilot_combine != 0
@@ -203,28 +224,33 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_lo
             setattr(tr, f, np.zeros(n_ep))
         tr.CNo = SimpleNamespace(VSMValue=[], VSMIndex=[])
         results.append(tr)
-        if ch.PRN != 0:
-            tr.PRN = ch.PRN
-            fid.set_channel(i, spec.tables(ch.PRN, settings), index_scale=spec.index_scale, arm_mult=spec.arm_mult,
+        sat = getattr(ch, spec.id_field, getattr(ch, "PRN", 0))
+        if (ch.status != "-") if spec.id_field == "K" else (sat != 0):                # tracking.m:136 / GLO_GL1 tracking.m:138
+            tr.PRN = sat                                                               # :138 / GLO :141
+            fid.set_channel(i, spec.tables(sat, settings), index_scale=spec.index_scale, arm_mult=spec.arm_mult,
                             windows=spec.windows)
             active.append(i)
-    if not active:
-        return results, channel
     inits = []
     for i in active:
         ch = channel[i]
         cf = ch.codeFreq if spec.code_freq_from_channel else settings.codeFreqBasis
         if spec.doubled_code:
             cf = settings.codeFreqBasis * 2                                           # GPS_L2C tracking.m:171
-        inits.append(L.gc_channel_init(channel=i, prn=ch.PRN, acquired_freq=ch.acquiredFreq,
+        inits.append(L.gc_channel_init(channel=i, prn=int(results[i].PRN), acquired_freq=ch.acquiredFreq,
                                        code_freq=cf, code_phase=int(ch.codePhase),
                                        table_phase=int(getattr(ch, "CLCodePhase", 0)) if (spec.doubled_code and pilot) else 0))
-    fields, done, status = fid.track(p, inits, device_loop=device_loop)   # device_loop: gc_track_device (include/gnsscorr.h)
+    return SimpleNamespace(fid=fid, channel=channel, settings=settings, signal=signal, spec=spec, n_ep=n_ep, p=p, pilot=pilot,
+                           results=results, active=active, inits=inits)
+
+
+def _tracking_finish(job, fields, done, status):
+    """The part of tracking() behind the loops: records into the trackResults structs, C/N0 (tracking.m:351-358), status."""
+    settings, signal, spec, pilot, n_ep, results, channel = job.settings, job.signal, job.spec, job.pilot, job.n_ep, job.results, job.channel
     # B2a / B1C estimate C/N0 with Calc_CNo_PLD every settings.CNoInterval epochs (below); the other packages with CNoVSM
     pld = int(getattr(settings, "CNoInterval", 0))
     cno = None if pld else getattr(settings, "CNo", None)
     vsm = int(cno.VSMinterval) if cno is not None else 0
-    for k, i in enumerate(active):
+    for k, i in enumerate(job.active):
         tr = results[i]
         for f in _REC_FIELDS + (_PILOT_FIELDS if pilot else ()):
             getattr(tr, f)[:] = fields[f][k]
@@ -250,16 +276,46 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_lo
             prev = np.zeros(3)
             for loop in range(pld, n_done + 1, pld):
                 c, d = Calc_CNo_PLD(tr, settings, loop, straight_pilot=signal.endswith("_WB"))
-                k = loop // pld - 1
-                tr.DataCNo[k] = c[0] * 0.5 + prev[0] * 0.5
-                tr.DataPLD[k] = d[0]
+                kk = loop // pld - 1
+                tr.DataCNo[kk] = c[0] * 0.5 + prev[0] * 0.5
+                tr.DataPLD[kk] = d[0]
                 if pilot:
-                    tr.PilotCNo[k] = c[1] * 0.5 + prev[1] * 0.5
-                    getattr(tr, combined)[k] = c[2] * 0.5 + prev[2] * 0.5
-                    tr.PilotPLD[k] = d[1]
+                    tr.PilotCNo[kk] = c[1] * 0.5 + prev[1] * 0.5
+                    getattr(tr, combined)[kk] = c[2] * 0.5 + prev[2] * 0.5
+                    tr.PilotPLD[kk] = d[1]
                 prev = c
         if n_done == n_ep:
             tr.status = channel[i].status                                             # tracking.m:365
     if status == L.GC_E_RANGE:
         print("Not able to read the specified number of samples  for tracking, exiting!")
     return results, channel
+
+
+def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_loop: bool = False):
+    """[trackResults, channel] = tracking(fid, channel, settings) — `signal` selects the reference
+    package whose tracking.m is mirrored ("GPS_L1CA": GPS/GPS_L1CA/include/tracking.m;
+    "GAL_E1C": GAL/GAL_E1C/include/tracking.m, data + pilot arms, BOC(1,1) half-chip tables; ... signals.SIGNALS).
+
+    Returns (trackResults, channel).  On a short read the reference prints a message and
+    returns what it has (tracking.m:241-245); here the partially filled results are returned
+    the same way and `trackResults[i].status` stays '-' for channels that did not finish.
+    """
+    job = _tracking_prepare(fid, channel, settings, signal)
+    if not job.active:
+        return job.results, channel
+    fields, done, status = fid.track(job.p, job.inits, device_loop=device_loop)   # device_loop: gc_track_device (include/gnsscorr.h)
+    return _tracking_finish(job, fields, done, status)
+
+
+def tracking_multi(calls, device_loop: bool = False):
+    """Several packages' tracking() at once (BASELINE config 5, include/gnsscorr.h gc_track_multi):
+    calls = [(fid, channel, settings, signal), ...] with one Engine per call - engines that read the same record share it
+    with Engine.share_if.  Returns [(trackResults, channel), ...] in call order, each exactly what tracking() returns."""
+    jobs = [_tracking_prepare(*c) for c in calls]
+    live = [j for j in jobs if j.active]
+    got = Engine.track_multi([(j.fid, j.p, j.inits) for j in live], device_loop=device_loop) if live else []
+    out = []
+    it = iter(got)
+    for j in jobs:
+        out.append(_tracking_finish(j, *next(it)) if j.active else (j.results, j.channel))
+    return out

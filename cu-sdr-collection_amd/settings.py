@@ -5,6 +5,19 @@ from __future__ import annotations
 from types import SimpleNamespace
 
 
+def skip_samples(settings) -> int:
+    """Samples in front of the acquisition buffer and of every tracking seek.  The reference seeks
+    dataAdaptCoeff*settings.skipNumberOfBytes BYTES (postProcessing.m:74; tracking.m:145-153; GLONASS names the field
+    skipNumberOfSamples, GLO_GL1/include/postProcessing.m:74): with schar components that is skipNumberOfBytes samples,
+    with int16 components (2 bytes each) skipNumberOfBytes/2 - an odd value would start in the middle of a component."""
+    skip = int(getattr(settings, "skipNumberOfSamples", getattr(settings, "skipNumberOfBytes", 0)))
+    if str(getattr(settings, "dataType", "schar")) == "int16":
+        if skip % 2:
+            raise ValueError("int16 record: dataAdaptCoeff*skipNumberOfBytes bytes is not a whole number of samples")
+        return skip // 2
+    return skip
+
+
 def initSettings() -> SimpleNamespace:
     """GPS L1 C/A defaults (GPS/GPS_L1CA/initSettings.m:44-136)."""
     s = SimpleNamespace()
@@ -95,6 +108,8 @@ def initSettings_GLO_GL1() -> SimpleNamespace:
     """GLONASS L1OF defaults (GLO/GLO_GL1/initSettings.m): only the fields the hot path reads."""
     s = initSettings()
     s.freqSpacing = 562.5e3          # :73
+    del s.skipNumberOfBytes
+    s.skipNumberOfSamples = 0        # :55 (this package names the field ...Samples; same dataAdaptCoeff* arithmetic)
     s.acqSatelliteList = list(range(-7, 7))  # :89 frequency numbers K
     s.acqSearchBand = 5000           # :91
     s.acqNonCohTime = 20             # :93
@@ -109,6 +124,14 @@ def initSettings_GLO_GL1() -> SimpleNamespace:
     s.pllNoiseBandwidth = 25         # :112
     s.intTime = 0.001                # :114
     s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=40)  # :144-146
+    return s
+
+
+def initSettings_GLO_GL2() -> SimpleNamespace:
+    """GLONASS L2OF defaults: GLO/GLO_GL2/initSettings.m differs from GLO_GL1's in the file name (:61) and in
+    freqSpacing = 437.5 kHz (:73) only."""
+    s = initSettings_GLO_GL1()
+    s.freqSpacing = 437.5e3          # :73
     return s
 
 

@@ -58,12 +58,13 @@ def merge_acq_results(per_rank):
     return out
 
 
-def broadcast_record(record, src: int = 0, device=None):
+def broadcast_record(record, src: int = 0, device=None, group=None):
     """The one exchange step of the sharded path: the rank that read the IF file hands the raw record to the
     ranks that track other channels of the same band.  `record`: a 1-D torch int8 / int16 tensor on rank `src` (ignored
-    elsewhere).  With tensors on the GPUs and the process group's backend "nccl" this is one RCCL broadcast over xGMI (288 GB
-    of HBM per GPU: the whole record in one piece, no chunking); on CPU tensors (gloo) the same call is the test double.
-    Returns the record on every rank; hand it to the engine without a copy:
+    elsewhere).  `src` is a GLOBAL rank; `group` the process group of the ranks that share the band (None: every rank) - only
+    its members call this function.  With tensors on the GPUs and the group's backend "nccl" this is one RCCL broadcast over
+    xGMI (288 GB of HBM per GPU: the whole record in one piece, no chunking); on CPU tensors (gloo) the same call is the test
+    double.  Returns the record on every member; hand it to the engine without a copy:
         t = broadcast_record(t, device=f"cuda:{local_rank}");  engine.attach_if(t.data_ptr(), t.numel() // 2)
     Process order matters when torch drives the GPU in the same process as the engine: torch ships its own copy of the HIP
     runtime, so initialise torch's CUDA side (torch.cuda.set_device) BEFORE the first Engine() -- with the engine first, torch
@@ -77,12 +78,38 @@ def broadcast_record(record, src: int = 0, device=None):
         if record.dim() != 1 or record.dtype not in (torch.int8, torch.int16):
             raise ValueError("broadcast_record: a 1-D int8 or int16 tensor is expected")
         meta = [(int(record.numel()), str(record.dtype))]
-    dist.broadcast_object_list(meta, src=src)
+    dist.broadcast_object_list(meta, src=src, group=group)
     n, dt = meta[0]
     dtype = torch.int8 if dt == "torch.int8" else torch.int16
     if rank == src:
         t = record if device is None else record.to(device)
     else:
         t = torch.empty(n, dtype=dtype, device=device if device is not None else "cpu")
-    dist.broadcast(t, src=src)
+    dist.broadcast(t, src=src, group=group)
     return t
+
+
+def distribute_band_records(plan, read_record, device=None):
+    """BASELINE config 5, the hand-over end to end: `plan` = shard_bands(...) (identical on every rank).  For every band the
+    first rank that tracks one of its channels reads the file (`read_record(band)` -> 1-D int8 / int16 tensor) and broadcasts
+    it to the other ranks of the band - one process group per band, so ranks that do not track the band neither take part
+    nor spend HBM on it.  Returns {band: tensor} for the bands of THIS rank.  Every rank must call it (torch.distributed
+    creates groups collectively, in the same order everywhere)."""
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    ranks = band_ranks(plan)
+    groups = {}
+    for band in sorted(ranks):                          # new_group is collective over the WORLD: same order on every rank
+        groups[band] = dist.new_group(ranks=ranks[band]) if len(ranks[band]) > 1 else None
+    out = {}
+    for band in sorted(ranks):
+        members = ranks[band]
+        if rank not in members:
+            continue
+        src = members[0]
+        rec = read_record(band) if rank == src else None
+        if len(members) == 1:
+            out[band] = rec if device is None else rec.to(device)
+        else:
+            out[band] = broadcast_record(rec, src=src, device=device, group=groups[band])
+    return out

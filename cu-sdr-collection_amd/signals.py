@@ -28,6 +28,10 @@ class SignalSpec:
     dll_scale_spacing: bool = False        # DLL discriminators times (1 - earlyLateSpc), NB_tracking.m:346-348
     windows: tuple | None = None           # per-arm LDS staging window in entries (L2C CL: one block's worth)
     doubled_code: bool = False             # GPS L2C: the loop runs on the RZ-doubled code (tracking.m:107-109,171)
+    int16_branch: bool = False             # tracking.m has the int16 seek / ftell branch (GPS_L1CA tracking.m:145-148,212-213;
+                                           # also GAL_E5a, GAL_E5b, BDS/B3I); the other packages assume one byte per component
+    id_field: str = "PRN"                  # channel field naming the satellite: 'K' for GLONASS (GLO_GL1 preRun.m:66), whose
+                                           # channels are active when status ~= '-' (K = 0 is a valid frequency number, tracking.m:138)
 
 
 def calcLoopCoefCarr(settings, variant: str = "a"):
@@ -149,7 +153,7 @@ def _b1c_wb_dll_weight(settings):
 
 
 SIGNALS = {
-    "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False),
+    "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False, int16_branch=True),
     # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
     "GAL_E1C": SignalSpec("GAL_E1C", _e1_tables, 2.0, L.GC_PLL_3_STATE, "a", 2, False),
     # BASELINE config 3: the E1-C pilot tracked with its CBOC(6,1,1/11) subcarrier (needs pilotTRKflag = 1 and a narrow
@@ -157,14 +161,16 @@ SIGNALS = {
     "GAL_E1C_CBOC": SignalSpec("GAL_E1C_CBOC", _e1_cboc_tables, 2.0, L.GC_PLL_3_STATE, "a", 5, False, arm_mult=(1.0, 1.0, 6.0)),
     # GLONASS: the record must be loaded with layout GC_QI (GLO_GL1 tracking.m:227 swaps the components);
     # channel.PRN carries the frequency number K (GLO_GL1 preRun.m:66), the FDMA offset lives in acquiredFreq
-    "GLO_GL1": SignalSpec("GLO_GL1", _glo_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False),
+    "GLO_GL1": SignalSpec("GLO_GL1", _glo_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False, id_field="K"),
+    # GLONASS L2OF: the same package with freqSpacing 437.5 kHz (GLO_GL2/initSettings.m:73; tracking.m identical to GLO_GL1's)
+    "GLO_GL2": SignalSpec("GLO_GL2", _glo_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False, id_field="K"),
     "BDS_B1I": SignalSpec("BDS_B1I", _b1i_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False),
     "GPS_L5C": SignalSpec("GPS_L5C", _l5_tables, 1.0, L.GC_PLL_3_STATE, "a", 1, True),
     # the 10.23-Mcps family shares GPS L5's loop closure (pilot rotated by -pi/2, discriminators averaged) and
     # differs in codes, loop-coefficient variant (Common/calcLoopCoefCarr.m of each package) and bandwidths
     "BDS_B2a": SignalSpec("BDS_B2a", _b2a_tables, 1.0, L.GC_PLL_3_STATE, "a", 1, True),
-    "BDS_B3I": SignalSpec("BDS_B3I", _b3i_tables, 1.0, L.GC_PLL_3_STATE, "b", 0, True),
-    "GAL_E5a": SignalSpec("GAL_E5a", _e5_tables(codes.generateE5aIcode, codes.generateE5aQcode), 1.0, L.GC_PLL_3_STATE, "a", 1, True),
+    "BDS_B3I": SignalSpec("BDS_B3I", _b3i_tables, 1.0, L.GC_PLL_3_STATE, "b", 0, True, int16_branch=True),
+    "GAL_E5a": SignalSpec("GAL_E5a", _e5_tables(codes.generateE5aIcode, codes.generateE5aQcode), 1.0, L.GC_PLL_3_STATE, "a", 1, True, int16_branch=True),
     # BDS B1C: 10-ms blocks, BOC(1,1) half-chip tables (R = 2).  Narrow-band: data + pilot BOC(1,1), pilot in
     # quadrature, 11:29 weights; wide-band: + the pilot's BOC(6,1) arm read through ceil(6*t), folded 1:3 / factor
     "BDS_B1C_NB": SignalSpec("BDS_B1C_NB", _b1c_nb_tables, 2.0, L.GC_PLL_3_STATE, "b", 3, True,
@@ -173,7 +179,7 @@ SIGNALS = {
                              pll_weight=(1.0, 3.0), dll_weight=_b1c_wb_dll_weight, dll_scale_spacing=True),
     # GPS L2C: RZ-interleaved CM (+ CL through a moving window of its 1.5-s table), everything in doubled-code units
     "GPS_L2C": SignalSpec("GPS_L2C", _l2c_tables, 1.0, L.GC_PLL_3_STATE, "a", 2, False, windows=(0, 20464), doubled_code=True),
-    "GAL_E5b": SignalSpec("GAL_E5b", _e5_tables(codes.generateE5bIcode, codes.generateE5bQcode), 1.0, L.GC_PLL_3_STATE, "b", 1, True),
+    "GAL_E5b": SignalSpec("GAL_E5b", _e5_tables(codes.generateE5bIcode, codes.generateE5bQcode), 1.0, L.GC_PLL_3_STATE, "b", 1, True, int16_branch=True),
 }
 
 

@@ -80,6 +80,66 @@ def generate_if(sats, n_samples: int, fs: float, intermediate_freq: float, code_
     return out
 
 
+@dataclass
+class SignalGroup:
+    """One signal family inside a record: the satellites that transmit it and how it is spread."""
+    sats: list
+    code_fn: object            # prn -> +-1 (or 0) chips, length code_len
+    code_rate: float           # chips per second of that table (2 x 1.023e6 for BOC(1,1) half-chip tables)
+    code_len: int
+    bit_periods: int = 20      # code periods per data bit
+    pilot_fn: object = None    # optional pilot component (no data bits)
+    pilot_phase: float = 0.0   # carrier phase offset of the pilot (rad): 0 Galileo E1-C, +pi/2 GPS L5-Q
+    carrier_ratio: float = 1540.0   # code Doppler = doppler / carrier_ratio * (code_rate / 1.023e6)
+    intermediate_freq: float | None = None   # None: the record's IF
+
+
+def _group_signal(g: SignalGroup, n: np.ndarray, fs: float, intermediate_freq: float, sigma: float, rng) -> np.ndarray:
+    """Noise-free complex baseband-at-IF contribution of one signal family at sample indices n."""
+    acc = np.zeros(n.shape[0], dtype=np.complex128)
+    f_if = intermediate_freq if g.intermediate_freq is None else g.intermediate_freq
+    for s in g.sats:
+        key = (id(g), s.prn)
+        if key not in rng["codes"]:
+            rng["codes"][key] = np.asarray(g.code_fn(s.prn), dtype=np.float64)
+            rng["pilots"][key] = np.asarray(g.pilot_fn(s.prn), dtype=np.float64) if g.pilot_fn else None
+            rng["bits"][key] = rng["rng"].integers(0, 2, size=int(rng["n_total"] / fs * g.code_rate / g.code_len / g.bit_periods) + 8) * 2.0 - 1.0
+        amp = sigma * np.sqrt(2.0 * 10 ** (s.cn0_dbhz / 10.0) / fs)
+        fcode = g.code_rate + s.doppler / g.carrier_ratio * (g.code_rate / 1.023e6)
+        cp = (n - s.code_phase_samples) * (fcode / fs)      # chips since the reference code start
+        chip = np.floor(cp).astype(np.int64)
+        period = np.floor_divide(chip, g.code_len)
+        bit_idx = np.floor_divide(period, g.bit_periods)
+        b = rng["bits"][key]
+        data = b[np.mod(bit_idx, b.shape[0])]
+        comp = data * rng["codes"][key][np.mod(chip, g.code_len)]
+        theta = 2 * np.pi * (f_if + s.doppler) * (n / fs) + s.carrier_phase
+        if rng["pilots"][key] is not None:
+            comp = comp + rng["pilots"][key][np.mod(chip, g.code_len)] * np.exp(1j * g.pilot_phase)
+        acc += amp * comp * np.exp(1j * theta)
+    return acc
+
+
+def generate_if_mix(groups, n_samples: int, fs: float, intermediate_freq: float, seed: int, sigma: float = 20.0,
+                    chunk: int = 1 << 21, noise: bool = True) -> np.ndarray:
+    """A record holding several signal families at once (BASELINE config 5: GPS L1 C/A, Galileo E1 and BDS B1C share the
+    L1 band).  Returns int8[2*n_samples] interleaved I,Q."""
+    r = np.random.default_rng(seed)
+    state = {"rng": r, "codes": {}, "pilots": {}, "bits": {}, "n_total": n_samples}
+    out = np.empty(2 * n_samples, dtype=np.int8)
+    for start in range(0, n_samples, chunk):
+        n = np.arange(start, min(n_samples, start + chunk), dtype=np.float64)
+        acc = np.zeros(n.shape[0], dtype=np.complex128)
+        for g in groups:
+            acc += _group_signal(g, n, fs, intermediate_freq, sigma, state)
+        if noise:
+            acc += sigma * (r.standard_normal(n.shape[0]) + 1j * r.standard_normal(n.shape[0]))
+        sl = slice(2 * start, 2 * (start + n.shape[0]))
+        out[sl][0::2] = np.clip(np.rint(acc.real), -127, 127).astype(np.int8)
+        out[sl][1::2] = np.clip(np.rint(acc.imag), -127, 127).astype(np.int8)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # GPU generator (libgnsssynth.so, csrc/synth.hip) — same signal model, counter-based noise
 # ---------------------------------------------------------------------------------------------

@@ -221,6 +221,31 @@ int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channe
 int gc_track_device(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
                     double* out, int32_t* epochs_done);
 
+/* ---- several tracking() calls at once (BASELINE config 5: the all-constellation mix) ---------------------------
+ * The reference tracks the channels of ONE package per call (tracking.m:133 loops over settings.numberOfChannels with one
+ * `settings`); its packages run one after the other.  Channels are independent, so the loops of different packages can
+ * run side by side on one GPU - GPS L1 C/A, Galileo E1 and BDS B1C channels on the same L1-band record, L5 / E5a / B2a
+ * channels on another - or on several GPUs driven by one host process.  One context per (record, package): own stream,
+ * code tables and result buffers; a record loaded into one context is shared with the others by gc_share_if (no copy). */
+int gc_share_if(gc_context* dst, gc_context* src);   /* dst reads src's IF record (same device; src must outlive the use) */
+
+typedef struct gc_track_job {
+  gc_context* ctx;                /* one job per context */
+  const gc_track_params* params;  /* this package's settings */
+  const gc_channel_init* init;    /* nch channels, as gc_track */
+  double* out;                    /* nch * GC_TRK_NFIELDS * n_epochs doubles, as gc_track */
+  int32_t* epochs_done;           /* nch */
+  int32_t nch;
+  int32_t device_loop;            /* 0: gc_track; 1: gc_track_device, falling back to gc_track where it returns GC_E_UNSUPPORTED */
+  int32_t status;                 /* out: the job's return code (GC_E_RANGE = short read, partial records, tracking.m:241-245) */
+  int32_t reserved;
+  char error[240];                /* out: the job's error text */
+} gc_track_job;
+
+/* Runs every job's tracking loop concurrently (one host thread per job for the loop closure, tracking.m:302-335) and
+ * returns when all are done: GC_OK, or the first failure (a short read only if nothing worse happened). */
+int gc_track_multi(int njobs, gc_track_job* jobs);
+
 /* ---- acquisition (replaces acquisition.m:151-254, resampling off) ------------------- */
 typedef struct gc_acq_params {
   double sampling_freq;      /* settings.samplingFreq */

@@ -277,6 +277,25 @@ TRACK_FIELDS = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "
                 "remCarrPhase")
 
 
+def first_sample(settings, code_phase, int16_branch: bool = True, minus_one: bool = True) -> int:
+    """Where a channel's first fread starts, in samples (complex samples for fileType 2), from the reference's fseek:
+    schar   fseek(fid, dataAdaptCoeff*(skipNumberOfBytes + codePhase-1))            tracking.m:150-152
+    int16   fseek(fid, dataAdaptCoeff*(skipNumberOfBytes + (codePhase-1)*2))        tracking.m:145-148
+    One sample is dataAdaptCoeff components of 1 (schar) or 2 (int16) bytes, so the int16 branch starts at sample
+    skipNumberOfBytes/2 + codePhase-1 (the same place postProcessing.m:74 starts the acquisition buffer,
+    dataAdaptCoeff*skipNumberOfBytes bytes in).  Only GPS_L1CA, GAL_E5a, GAL_E5b and BDS/B3I have the int16 branch
+    (`int16_branch`); GPS_L2C seeks without the -1 (GPS_L2C/include/tracking.m:153, `minus_one` False)."""
+    cp = int(code_phase) - (1 if minus_one else 0)
+    skip = int(getattr(settings, "skipNumberOfBytes", 0))
+    if str(getattr(settings, "dataType", "schar")) == "int16":
+        if not int16_branch:
+            raise ValueError("this package's tracking.m has no int16 branch: its fseek assumes one byte per component")
+        if skip % 2:
+            raise ValueError("int16 record: dataAdaptCoeff*skipNumberOfBytes bytes is not a whole number of samples")
+        return skip // 2 + cp
+    return skip + cp
+
+
 def tracking_l1ca(if_bytes: np.ndarray, channel, settings, correlate=None):
     """Closed-loop restatement of GPS/GPS_L1CA/include/tracking.m.
 
@@ -305,7 +324,7 @@ def tracking_l1ca(if_bytes: np.ndarray, channel, settings, correlate=None):
         if ch.PRN == 0:
             continue
         tr.PRN = ch.PRN
-        pos = int(settings.skipNumberOfBytes + ch.codePhase - 1)  # tracking.m:150-152
+        pos = first_sample(settings, ch.codePhase)  # tracking.m:145-153
         table = pad_code(generate_ca_code(ch.PRN))  # :156-158
         code_freq = settings.codeFreqBasis
         rem_code = 0.0
@@ -550,7 +569,7 @@ def tracking_generic(if_bytes: np.ndarray, channel, settings, spec, correlate=No
         if ch.PRN == 0:
             continue
         tr.PRN = ch.PRN
-        pos = int(settings.skipNumberOfBytes + ch.codePhase - 1)
+        pos = first_sample(settings, ch.codePhase, int16_branch=getattr(spec, "int16_branch", False))
         tables = spec.tables(ch.PRN)  # GLONASS: one code for every channel, PRN carries K (GLO tracking.m:88-89,136)
         basis = ch.codeFreq if spec.code_freq_from_channel else settings.codeFreqBasis
         code_freq = basis

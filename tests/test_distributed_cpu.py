@@ -64,3 +64,60 @@ def test_gloo_world_size_two_control_plane():
         assert tmax == 1.5  # MAX over ranks
         assert sorted(gathered[0] + gathered[1]) == list(range(13))
         assert not set(gathered[0]) & set(gathered[1])
+
+
+def _band_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from cu_sdr_collection_amd.sharding import band_ranks, distribute_band_records, shard_bands
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    plan = shard_bands({"L1": 5, "L5": 2, "E5b": 1}, world)        # every rank computes the same plan
+    reads = []
+
+    def read_record(band):                                          # stands for fopen + fread of the band's IF file
+        reads.append(band)
+        g = torch.Generator().manual_seed(sum(map(ord, band)))
+        return torch.randint(-128, 128, (2000 + 100 * len(band),), dtype=torch.int8, generator=g)
+
+    recs = distribute_band_records(plan, read_record)
+    mine = sorted({b for b, _ in plan[rank]})
+    q.put((rank, plan[rank], band_ranks(plan), reads, {b: (int(t.numel()), int(t.to(torch.int64).sum())) for b, t in recs.items()}, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_band_plan_end_to_end():
+    """BASELINE config 5's hand-over on CPU: shard_bands -> one process group per band -> the band's first rank reads and
+    broadcasts -> every rank ends up with exactly the records of the bands it tracks (a band spanning both ranks is read
+    once and broadcast; single-rank bands are never sent anywhere)."""
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    def expect(band):
+        g = torch.Generator().manual_seed(sum(map(ord, band)))
+        t = torch.randint(-128, 128, (2000 + 100 * len(band),), dtype=torch.int8, generator=g)
+        return int(t.numel()), int(t.to(torch.int64).sum())
+
+    (r0, plan0, ranks0, reads0, recs0, mine0), (r1, plan1, ranks1, reads1, recs1, mine1) = res
+    assert len(plan0) == len(plan1) == 4 and ranks0 == ranks1 == {"L1": [0, 1], "L5": [1], "E5b": [1]}
+    assert mine0 == ["L1"] and mine1 == ["E5b", "L1", "L5"]
+    assert reads0 == ["L1"] and sorted(reads1) == ["E5b", "L5"]      # L1 is read once, on rank 0, and travels
+    assert set(recs0) == {"L1"} and set(recs1) == {"L1", "L5", "E5b"}
+    for recs in (recs0, recs1):
+        for b, v in recs.items():
+            assert v == expect(b)

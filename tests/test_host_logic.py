@@ -211,3 +211,80 @@ def test_shard_bands_config4_mix():
     # uneven worlds and empty bands
     assert [len(p) for p in shard_bands({"a": 3, "b": 0, "c": 4}, 3)] == [3, 2, 2]
     assert shard_bands({}, 2) == [[], []]
+
+
+def test_prerun_per_package_fields():
+    """include/preRun.m of each package: codeFreq for the packages whose tracking.m starts the code NCO from it (GPS_L5C
+    preRun.m:69-71), CLCodePhase for GPS L2C with the pilot on (GPS_L2C preRun.m:70-72), K = index - 8 for GLONASS
+    (GLO_GL1 preRun.m:66), result arrays of any length (acquisition -> preRun -> tracking raised AttributeError
+    for 7 of the 12 packages)."""
+    from types import SimpleNamespace
+
+    import numpy as np
+
+    from cu_sdr_collection_amd import receiver, signals
+    from cu_sdr_collection_amd.settings import (initSettings_BDS_B3I, initSettings_GLO_GL1, initSettings_GPS_L2C,
+                                                 initSettings_GPS_L5C)
+    S = initSettings_GPS_L5C()
+    S.numberOfChannels = 3
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32))
+    for prn, f, cp, m in ((5, 20e3 + 1500.0, 1234, 9.0), (17, 20e3 - 2500.0, 77, 12.0)):
+        acq.carrFreq[prn - 1], acq.codePhase[prn - 1], acq.peakMetric[prn - 1] = f, cp, m
+    acq.peakMetric[30] = 4.0                                   # below threshold: carrFreq stayed 0, never assigned
+    ch = receiver.preRun(acq, S, "GPS_L5C")
+    assert [c.PRN for c in ch] == [17, 5, 0] and [c.status for c in ch] == ["T", "T", "-"]
+    for c in ch[:2]:
+        assert c.codeFreq == S.codeFreqBasis + (c.acquiredFreq - S.IF) / S.carrFreqBasis * S.codeFreqBasis
+    assert ch[2].codeFreq == 0.0 and ch[2].codePhase == 0
+    assert all(signals.SIGNALS[s].code_freq_from_channel for s in ("GPS_L5C", "BDS_B2a", "BDS_B3I", "GAL_E5a", "GAL_E5b", "BDS_B1C_NB", "BDS_B1C_WB"))
+    # 63-entry result arrays (BDS B3I)
+    S3 = initSettings_BDS_B3I()
+    S3.numberOfChannels = 2
+    acq3 = SimpleNamespace(carrFreq=np.zeros(63), codePhase=np.zeros(63), peakMetric=np.zeros(63))
+    acq3.carrFreq[62], acq3.codePhase[62], acq3.peakMetric[62] = 21e3, 5, 7.0
+    ch3 = receiver.preRun(acq3, S3, "BDS_B3I")
+    assert ch3[0].PRN == 63 and ch3[0].codeFreq > 0 and ch3[1].PRN == 0
+    # GPS L2C
+    S2 = initSettings_GPS_L2C()
+    S2.numberOfChannels, S2.pilotTRKflag = 1, 1
+    acq2 = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(32))
+    acq2.carrFreq[8], acq2.codePhase[8], acq2.peakMetric[8], acq2.CLCodePhase[8] = 19e3, 100, 3.0, 42
+    c2 = receiver.preRun(acq2, S2, "GPS_L2C")[0]
+    assert (c2.PRN, c2.CLCodePhase, c2.codePhase) == (9, 42, 100) and not hasattr(c2, "codeFreq")
+    S2.pilotTRKflag = 0
+    assert not hasattr(receiver.preRun(acq2, S2, "GPS_L2C")[0], "CLCodePhase")
+    # GLONASS: 14 frequency numbers stored at K + 8
+    SG = initSettings_GLO_GL1()
+    SG.numberOfChannels = 3
+    acqg = SimpleNamespace(carrFreq=np.zeros(14), codePhase=np.zeros(14), peakMetric=np.zeros(14))
+    for k, m in ((-7, 5.0), (0, 9.0)):
+        acqg.carrFreq[k + 7], acqg.codePhase[k + 7], acqg.peakMetric[k + 7] = SG.IF + k * SG.freqSpacing + 100.0, 50 + k, m
+    chg = receiver.preRun(acqg, SG, "GLO_GL1")
+    assert [c.K for c in chg] == [0, -7, 0] and [c.status for c in chg] == ["T", "T", "-"] and not hasattr(chg[0], "PRN")
+
+
+def test_skip_samples_rule():
+    """postProcessing.m:74 / tracking.m:145-153: dataAdaptCoeff*skipNumberOfBytes bytes = skipNumberOfBytes samples of schar
+    components, skipNumberOfBytes/2 samples of int16 components; GLONASS calls the field skipNumberOfSamples."""
+    import pytest
+
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.receiver import track_params
+    from cu_sdr_collection_amd.settings import initSettings_GLO_GL1, initSettings_GPS_L2C, skip_samples
+    from oracle import gnss_oracle as O
+    S = P.initSettings()
+    S.skipNumberOfBytes = 5000
+    assert skip_samples(S) == 5000 and track_params(S).skip_samples == 5000 and O.first_sample(S, 11) == 5010
+    S.dataType = "int16"
+    assert skip_samples(S) == 2500 and track_params(S).skip_samples == 2500 and O.first_sample(S, 11) == 2510
+    S.skipNumberOfBytes = 5001
+    with pytest.raises(ValueError):
+        skip_samples(S)
+    with pytest.raises(ValueError):
+        O.first_sample(S, 11)
+    G = initSettings_GLO_GL1()
+    G.skipNumberOfSamples = 77
+    assert skip_samples(G) == 77 and track_params(G, "GLO_GL1").skip_samples == 77
+    L2 = initSettings_GPS_L2C()
+    L2.skipNumberOfBytes = 10
+    assert track_params(L2, "GPS_L2C").skip_samples == 11        # GPS_L2C tracking.m:153 seeks without the -1
