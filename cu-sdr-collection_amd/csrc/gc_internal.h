@@ -65,6 +65,32 @@ struct HostChannel {
   mutable int derived_state = -1;  // -1 unknown, else DevChannel::derived (gc_channel_is_derived; reset whenever the channel changes)
 };
 
+// Grow-only scratch kept by the context.  hipFree / hipHostFree wait for EVERY stream of the device, so a tracking call
+// that frees its message and record buffers on the way out stalls behind the other contexts' persistent kernels
+// (gc_track_multi measured fully serialised that way); these buffers are released by gc_destroy only.
+struct GcBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool host = false;
+};
+inline hipError_t gc_buf_reserve(GcBuf& b, size_t bytes, bool host_mapped) {
+  if (b.p && b.cap >= bytes && b.host == host_mapped) return hipSuccess;
+  if (b.p) (void)(b.host ? hipHostFree(b.p) : hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  b.host = host_mapped;
+  const size_t cap = (bytes + 4095) / 4096 * 4096;
+  const hipError_t e = host_mapped ? hipHostMalloc(&b.p, cap, hipHostMallocMapped) : hipMalloc(&b.p, cap);
+  if (e == hipSuccess) b.cap = cap;
+  else b.p = nullptr;
+  return e;
+}
+inline void gc_buf_free(GcBuf& b) {
+  if (b.p) (void)(b.host ? hipHostFree(b.p) : hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+}
+
 struct gc_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -125,6 +151,8 @@ struct gc_context {
 
   // gc_track_multi: this context's tracking call runs next to other contexts' on the same device.  Its persistent kernels
   // are then launched with a plain launch instead of a cooperative one (gc_launch_persistent below).
+  enum { TRK_CHAN = 0, TRK_DESC, TRK_PART, TRK_ARGS, TRK_RECORDS, TRK_HDESC, TRK_NBUF };
+  GcBuf trk[TRK_NBUF];  // gc_track / gc_track_device: channel state, descriptor and partial-sum messages, arguments, records
   bool concurrent_jobs = false;
   int concurrent_channels = 0;  // channels of all jobs on this device (sizes the persistent kernels' teams)
 };

@@ -96,6 +96,7 @@ int gc_destroy(gc_context* ctx) {
   if (ctx->h_tagged_pinned) (void)hipHostFree(ctx->h_tagged_pinned);
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
   if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
+  for (GcBuf& b : ctx->trk) gc_buf_free(b);
   gc_acq_free(ctx);
   (void)hipEventDestroy(ctx->ev_start);
   (void)hipEventDestroy(ctx->ev_stop);

@@ -10,6 +10,7 @@
 // (MATLAB's interpreter thread behind the MEX gateway) drives all GPUs of a node through one call.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -70,6 +71,13 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
     jobs[i].ctx->concurrent_jobs = same > 1;
     jobs[i].ctx->concurrent_channels = channels;
   }
+  // Code-table uploads (and the frees of the tables they replace: hipFree waits for every stream of the device) happen here,
+  // one context after the other, before any persistent kernel is running.
+  for (int i = 0; i < njobs; ++i) {
+    GC_HIP(hipSetDevice(jobs[i].ctx->device));
+    const int rc = gc_sync_channels(jobs[i].ctx);
+    if (rc) return rc;
+  }
   if (njobs == 1) {  // nothing to overlap: run on the caller's thread
     gc_track_job& j = jobs[0];
     j.status = j.device_loop ? gc_track_device(j.ctx, j.params, j.nch, j.init, j.out, j.epochs_done) : GC_E_UNSUPPORTED;
@@ -80,14 +88,22 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
   }
   std::vector<std::thread> workers;
   workers.reserve((size_t)njobs);
+  const bool timing = std::getenv("GC_TRACK_TIMING") != nullptr;
+  const auto t_call = std::chrono::steady_clock::now();
   for (int i = 0; i < njobs; ++i)
-    workers.emplace_back([&jobs, i]() {
+    workers.emplace_back([&jobs, i, timing, t_call]() {
       gc_track_job& j = jobs[i];
+      const auto t0 = std::chrono::steady_clock::now();
       int st = GC_E_UNSUPPORTED;
       if (j.device_loop) st = gc_track_device(j.ctx, j.params, j.nch, j.init, j.out, j.epochs_done);
       if (st == GC_E_UNSUPPORTED) st = gc_track(j.ctx, j.params, j.nch, j.init, j.out, j.epochs_done);
       j.status = st;
       if (st != GC_OK) std::snprintf(j.error, sizeof j.error, "%s", gc_last_error());  // the error text is per thread
+      if (timing) {
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "gc_track_multi: job %d (%d channels, %d epochs) ran from %.3f to %.3f ms after the call\n", i, j.nch, j.params->n_epochs,
+                     std::chrono::duration<double, std::milli>(t0 - t_call).count(), std::chrono::duration<double, std::milli>(t1 - t_call).count());
+      }
     });
   for (auto& w : workers) w.join();
   int first = GC_OK;

@@ -225,15 +225,10 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
   std::memset(&pa, 0, sizeof pa);
   gcorr::DevLoopArgs* d_pargs = nullptr;
   gcorr::msg_t* h_desc = nullptr;  // host-mapped descriptor messages [nch][kDescWords]
-  auto persist_free = [&]() {
-    if (pa.chan) (void)hipFree(pa.chan);
-    if (pa.desc_msg) (void)hipFree(pa.desc_msg);
-    if (pa.part_msg) (void)hipFree(pa.part_msg);
-    pa.part_msg = nullptr;
-    if (d_pargs) (void)hipFree(d_pargs);
-    if (h_desc) (void)hipHostFree(h_desc);
+  auto persist_free = [&]() {  // the buffers stay with the context (GcBuf: freeing would wait for every stream of the device)
     pa.chan = nullptr;
     pa.desc_msg = nullptr;
+    pa.part_msg = nullptr;
     d_pargs = nullptr;
     h_desc = nullptr;
   };
@@ -279,13 +274,21 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     std::vector<gcorr::DevLoopChan> hc((size_t)nch);
     std::memset(hc.data(), 0, sizeof(gcorr::DevLoopChan) * (size_t)nch);
     for (int c = 0; c < nch; ++c) hc[c].blk.channel = init[c].channel;  // table staging needs the channel of each team
-    hipError_t e = hipMalloc((void**)&pa.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
-    if (e == hipSuccess) e = hipMalloc((void**)&pa.desc_msg, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords);
+    auto take = [&](int slot, size_t bytes, bool host) -> hipError_t { return gc_buf_reserve(ctx->trk[slot], bytes, host); };
+    hipError_t e = take(gc_context::TRK_CHAN, sizeof(gcorr::DevLoopChan) * (size_t)nch, false);
+    if (e == hipSuccess) e = take(gc_context::TRK_DESC, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords, false);
     const size_t ppart = sizeof(gcorr::msg_t) * (size_t)nch * psplits_dev * (persist_lane ? 6 * max_arms : 2 * 2);  // the teams' partial-sum messages
-    if (e == hipSuccess) e = hipMalloc((void**)&pa.part_msg, ppart);
-    if (e == hipSuccess) e = hipMemsetAsync(pa.part_msg, 0, ppart, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_pargs, sizeof pa);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h_desc, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords, hipHostMallocMapped);
+    if (e == hipSuccess) e = take(gc_context::TRK_PART, ppart, false);
+    if (e == hipSuccess) e = take(gc_context::TRK_ARGS, sizeof pa, false);
+    if (e == hipSuccess) e = take(gc_context::TRK_HDESC, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords, true);
+    if (e == hipSuccess) {
+      pa.chan = (gcorr::DevLoopChan*)ctx->trk[gc_context::TRK_CHAN].p;
+      pa.desc_msg = (gcorr::msg_t*)ctx->trk[gc_context::TRK_DESC].p;
+      pa.part_msg = (gcorr::msg_t*)ctx->trk[gc_context::TRK_PART].p;
+      d_pargs = (gcorr::DevLoopArgs*)ctx->trk[gc_context::TRK_ARGS].p;
+      h_desc = (gcorr::msg_t*)ctx->trk[gc_context::TRK_HDESC].p;
+      e = hipMemsetAsync(pa.part_msg, 0, ppart, ctx->stream);
+    }
     if (e == hipSuccess) {
       std::memset(h_desc, 0, sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords);
       pa.host_desc = h_desc;
@@ -714,7 +717,10 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_members, std::atoi(e)));
     msgs_per_member = 6 * max_arms;
   }
-  const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr;  // teams on one XCD each (default)
+  // Teams on one XCD each (default).  Not next to other contexts' persistent kernels (gc_track_multi): two kernels that pin
+  // their teams to the same XCDs were measured to run one after the other (E1 lane kernel 32 ms = its own 11 ms + the L1 C/A
+  // kernel's 21 ms beside it), spread over the device they overlap completely and lose nothing alone (88.7 vs 89.7 ms).
+  const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr && !ctx->concurrent_jobs;
 
   gcorr::DevLoopArgs ha;
   std::memset(&ha, 0, sizeof ha);
@@ -733,13 +739,22 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   ha.timing = std::getenv("GC_DEVLOOP_TIMING") ? std::atoi(std::getenv("GC_DEVLOOP_TIMING")) : 0;  // 1: host + in-kernel phase clocks, 2: host only
   gcorr::DevLoopArgs* d_args = nullptr;
   const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
-  hipError_t e = hipMalloc((void**)&ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch);
   const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * msgs_per_member * (use_fast ? 2 : 1),  // fast kernel: two alternating halves
                 desc_bytes = sizeof(gcorr::msg_t) * (size_t)nch * gcorr::kDescWords;
-  if (e == hipSuccess) e = hipMalloc((void**)&ha.part_msg, part_bytes);
-  if (e == hipSuccess) e = hipMalloc((void**)&ha.desc_msg, desc_bytes);
-  if (e == hipSuccess) e = hipMalloc((void**)&ha.records, rec_bytes);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_args, sizeof ha);
+  hipError_t e = gc_buf_reserve(ctx->trk[gc_context::TRK_CHAN], sizeof(gcorr::DevLoopChan) * (size_t)nch, false);
+  if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_PART], part_bytes, false);
+  if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_DESC], desc_bytes, false);
+  if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_RECORDS], rec_bytes, false);
+  if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_ARGS], sizeof ha, false);
+  if (e != hipSuccess) {
+    gc_set_error("gc_track_device: %s", hipGetErrorString(e));
+    return GC_E_NOMEM;
+  }
+  ha.chan = (gcorr::DevLoopChan*)ctx->trk[gc_context::TRK_CHAN].p;
+  ha.part_msg = (gcorr::msg_t*)ctx->trk[gc_context::TRK_PART].p;
+  ha.desc_msg = (gcorr::msg_t*)ctx->trk[gc_context::TRK_DESC].p;
+  ha.records = (double*)ctx->trk[gc_context::TRK_RECORDS].p;
+  d_args = (gcorr::DevLoopArgs*)ctx->trk[gc_context::TRK_ARGS].p;
   if (e == hipSuccess) e = hipMemsetAsync(ha.records, 0, rec_bytes, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(ha.part_msg, 0, part_bytes, ctx->stream);
   std::vector<gcorr::msg_t> hdesc((size_t)nch * gcorr::kDescWords);
@@ -752,13 +767,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (e == hipSuccess) e = hipMemcpyAsync(ha.desc_msg, hdesc.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(ha.chan, hc.data(), sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_args, &ha, sizeof ha, hipMemcpyHostToDevice, ctx->stream);
-  auto cleanup = [&]() {
-    if (ha.chan) (void)hipFree(ha.chan);
-    if (ha.part_msg) (void)hipFree(ha.part_msg);
-    if (ha.desc_msg) (void)hipFree(ha.desc_msg);
-    if (ha.records) (void)hipFree(ha.records);
-    if (d_args) (void)hipFree(d_args);
-  };
+  auto cleanup = [&]() {};  // the buffers stay with the context (GcBuf)
   if (e != hipSuccess) {
     cleanup();
     gc_set_error("gc_track_device: %s", hipGetErrorString(e));

@@ -178,3 +178,53 @@ def generate_if_gpu(engine, sats, n_samples: int, fs: float, intermediate_freq: 
                          sigma, seed)
     if rc != 0:
         raise RuntimeError(f"gs_generate failed with {rc}")
+
+
+def generate_if_mix_gpu(engine, groups, n_samples: int, fs: float, intermediate_freq: float, seed: int, sigma: float = 20.0,
+                        dtype=np.int8) -> None:
+    """generate_if_mix on the GPU (libgnsssynth.so gs_generate2): allocates the engine's IF buffer (int8 or int16 I/Q)
+    and fills it in HBM.  Same signal model; data bits and noise come from a counter-based hash instead of NumPy's
+    generator, so the two generators agree in distribution, not sample for sample."""
+    import ctypes as C
+    import os
+
+    class gs_sat2(C.Structure):
+        _fields_ = [("prn", C.c_int32), ("code_len", C.c_int32), ("code_offset", C.c_int32), ("pilot_offset", C.c_int32),
+                    ("bit_periods", C.c_int32), ("reserved", C.c_int32), ("doppler", C.c_double),
+                    ("code_phase_samples", C.c_double), ("carrier_phase", C.c_double), ("amplitude", C.c_double),
+                    ("code_rate", C.c_double), ("pilot_phase", C.c_double), ("intermediate_freq", C.c_double)]
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgnsssynth.so")
+    lib = C.CDLL(path)
+    lib.gs_generate2.restype = C.c_int
+    lib.gs_generate2.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,
+                                 C.c_double, C.c_uint64, C.c_int]
+    i16 = np.dtype(dtype) == np.int16
+    engine.alloc_if(n_samples, np.int16 if i16 else np.int8)
+    engine.synchronize()
+    ptr, _ = engine.if_buffer()
+    flat, sats = [], []
+    off = 0
+    for g in groups:
+        for s in g.sats:
+            c = np.asarray(g.code_fn(s.prn), dtype=np.int8)
+            assert c.shape[0] == g.code_len
+            flat.append(c)
+            e = gs_sat2(prn=s.prn, code_len=g.code_len, code_offset=off, pilot_offset=-1, bit_periods=g.bit_periods)
+            off += g.code_len
+            if g.pilot_fn is not None:
+                flat.append(np.asarray(g.pilot_fn(s.prn), dtype=np.int8))
+                e.pilot_offset = off
+                off += g.code_len
+            e.doppler, e.code_phase_samples, e.carrier_phase = s.doppler, s.code_phase_samples, s.carrier_phase
+            e.amplitude = sigma * np.sqrt(2.0 * 10 ** (s.cn0_dbhz / 10.0) / fs)
+            e.code_rate = g.code_rate + s.doppler / g.carrier_ratio * (g.code_rate / 1.023e6)
+            e.pilot_phase = g.pilot_phase
+            e.intermediate_freq = intermediate_freq if g.intermediate_freq is None else g.intermediate_freq
+            sats.append(e)
+    codes = np.ascontiguousarray(np.concatenate(flat))
+    arr = (gs_sat2 * len(sats))(*sats)
+    rc = lib.gs_generate2(C.c_void_p(ptr), n_samples, engine.device_id, fs, codes.ctypes.data_as(C.c_void_p), codes.shape[0],
+                          arr, len(sats), sigma, seed, int(i16))
+    if rc != 0:
+        raise RuntimeError(f"gs_generate2 failed with {rc}")
