@@ -158,6 +158,20 @@ def preRun(acqResults, settings, signal: str = "GPS_L1CA"):
 _REC_FIELDS = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
                "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase")
 _PILOT_FIELDS = ("Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L")
+# tracking.m:47-86: these eight are created with inf(1, n), the others with zeros(1, n); epochs a channel never reaches keep them
+_INF_FIELDS = ("codeFreq", "carrFreq", "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase")
+# "reference": trackResults carries exactly the Pilot_* fields the package's tracking.m records (signals.SignalSpec.recorded_pilot);
+# "all": all six pilot sums whenever a pilot arm is correlated (the reference computes the early / late ones but drops them)
+DEFAULT_PILOT_FIELDS = "reference"
+
+
+def _recorded_pilot_fields(spec, pilot: bool, mode: str | None):
+    if not pilot:
+        return ()
+    mode = mode or DEFAULT_PILOT_FIELDS
+    if mode == "all" or spec.recorded_pilot == "all":
+        return _PILOT_FIELDS
+    return ("Pilot_I_P", "Pilot_Q_P") if spec.recorded_pilot == "prompt" else ()
 
 
 def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
@@ -174,7 +188,9 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
     p.pll_noise_bw = settings.pllNoiseBandwidth
     p.pll_damping = settings.pllDampingRatio
     p.pll_kind = spec.pll_kind
-    pilot = spec.pilot_combine if getattr(settings, "pilotTRKflag", 0) == 1 else 0
+    flag = getattr(settings, "pilotTRKflag", 0)
+    # BDS/B1C/include/postProcessing.m:69-74: pilotTRKflag 1 runs NB_tracking, 2 runs WB_tracking (both track the pilot)
+    pilot = spec.pilot_combine if (flag == 1 or (flag == 2 and signal == "BDS_B1C_WB")) else 0
     p.pilot_combine = pilot
     if spec.pll_kind == L.GC_PLL_3_STATE:
         p.pf3, p.pf2, p.pf1 = signals.calcLoopCoefCarr(settings, spec.coef_variant)
@@ -205,7 +221,7 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
     return p
 
 
-def _tracking_prepare(fid: Engine, channel, settings, signal: str):
+def _tracking_prepare(fid: Engine, channel, settings, signal: str, pilot_fields: str | None = None):
     """The part of tracking() in front of the loops: result structs (tracking.m:47-86), code tables (:156-158), per-channel
     start state (:145-170).  Returns a job record for _tracking_finish."""
     from . import signals
@@ -216,12 +232,13 @@ def _tracking_prepare(fid: Engine, channel, settings, signal: str):
     n_ep = signals.epochs_to_process(settings)
     p = track_params(settings, signal)
     pilot = p.pilot_combine != 0
+    rec_pilot = _recorded_pilot_fields(spec, pilot, pilot_fields)
     results = []
     active = []
     for i, ch in enumerate(channel):
         tr = SimpleNamespace(status="-", PRN=0)
-        for f in _REC_FIELDS + (_PILOT_FIELDS if pilot else ()):
-            setattr(tr, f, np.zeros(n_ep))
+        for f in _REC_FIELDS + rec_pilot:
+            setattr(tr, f, np.full(n_ep, np.inf) if f in _INF_FIELDS else np.zeros(n_ep))
         tr.CNo = SimpleNamespace(VSMValue=[], VSMIndex=[])
         results.append(tr)
         sat = getattr(ch, spec.id_field, getattr(ch, "PRN", 0))
@@ -240,7 +257,7 @@ def _tracking_prepare(fid: Engine, channel, settings, signal: str):
                                        code_freq=cf, code_phase=int(ch.codePhase),
                                        table_phase=int(getattr(ch, "CLCodePhase", 0)) if (spec.doubled_code and pilot) else 0))
     return SimpleNamespace(fid=fid, channel=channel, settings=settings, signal=signal, spec=spec, n_ep=n_ep, p=p, pilot=pilot,
-                           results=results, active=active, inits=inits)
+                           rec_pilot=rec_pilot, results=results, active=active, inits=inits)
 
 
 def _tracking_finish(job, fields, done, status):
@@ -252,9 +269,9 @@ def _tracking_finish(job, fields, done, status):
     vsm = int(cno.VSMinterval) if cno is not None else 0
     for k, i in enumerate(job.active):
         tr = results[i]
-        for f in _REC_FIELDS + (_PILOT_FIELDS if pilot else ()):
-            getattr(tr, f)[:] = fields[f][k]
         n_done = int(done[k])
+        for f in _REC_FIELDS + job.rec_pilot:
+            getattr(tr, f)[:n_done] = fields[f][k][:n_done]          # epochs never reached keep their inf / 0 (tracking.m:47-86)
         if spec.doubled_code:
             # GPS_L2C tracking.m:226,250,376,382-383: what the reference RECORDS is in single-code units, and
             # absoluteSample is pushed back by the code-phase remainder expressed in samples
@@ -291,7 +308,7 @@ def _tracking_finish(job, fields, done, status):
     return results, channel
 
 
-def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_loop: bool = False):
+def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_loop: bool = False, pilot_fields: str | None = None):
     """[trackResults, channel] = tracking(fid, channel, settings) — `signal` selects the reference
     package whose tracking.m is mirrored ("GPS_L1CA": GPS/GPS_L1CA/include/tracking.m;
     "GAL_E1C": GAL/GAL_E1C/include/tracking.m, data + pilot arms, BOC(1,1) half-chip tables; ... signals.SIGNALS).
@@ -300,18 +317,18 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_lo
     returns what it has (tracking.m:241-245); here the partially filled results are returned
     the same way and `trackResults[i].status` stays '-' for channels that did not finish.
     """
-    job = _tracking_prepare(fid, channel, settings, signal)
+    job = _tracking_prepare(fid, channel, settings, signal, pilot_fields)
     if not job.active:
         return job.results, channel
     fields, done, status = fid.track(job.p, job.inits, device_loop=device_loop)   # device_loop: gc_track_device (include/gnsscorr.h)
     return _tracking_finish(job, fields, done, status)
 
 
-def tracking_multi(calls, device_loop: bool = False):
+def tracking_multi(calls, device_loop: bool = False, pilot_fields: str | None = None):
     """Several packages' tracking() at once (BASELINE config 5, include/gnsscorr.h gc_track_multi):
     calls = [(fid, channel, settings, signal), ...] with one Engine per call - engines that read the same record share it
     with Engine.share_if.  Returns [(trackResults, channel), ...] in call order, each exactly what tracking() returns."""
-    jobs = [_tracking_prepare(*c) for c in calls]
+    jobs = [_tracking_prepare(*c, pilot_fields=pilot_fields) for c in calls]
     live = [j for j in jobs if j.active]
     got = Engine.track_multi([(j.fid, j.p, j.inits) for j in live], device_loop=device_loop) if live else []
     out = []

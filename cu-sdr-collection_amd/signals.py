@@ -30,6 +30,9 @@ class SignalSpec:
     doubled_code: bool = False             # GPS L2C: the loop runs on the RZ-doubled code (tracking.m:107-109,171)
     int16_branch: bool = False             # tracking.m has the int16 seek / ftell branch (GPS_L1CA tracking.m:145-148,212-213;
                                            # also GAL_E5a, GAL_E5b, BDS/B3I); the other packages assume one byte per component
+    recorded_pilot: str = "prompt"         # which Pilot_* fields the package's trackResults holds when the pilot is tracked: "prompt"
+                                           # (Pilot_I_P, Pilot_Q_P: GPS_L5C tracking.m:71-74, B2a, E5a, E5b, B1C NB), "all" six (BDS/B1C
+                                           # WB_tracking.m:79-86, GPS_L2C tracking.m:397-402), "none" (GAL_E1C records the data arm only)
     id_field: str = "PRN"                  # channel field naming the satellite: 'K' for GLONASS (GLO_GL1 preRun.m:66), whose
                                            # channels are active when status ~= '-' (K = 0 is a valid frequency number, tracking.m:138)
 
@@ -155,10 +158,10 @@ def _b1c_wb_dll_weight(settings):
 SIGNALS = {
     "GPS_L1CA": SignalSpec("GPS_L1CA", _l1ca_tables, 1.0, L.GC_PLL_2ND_ORDER, "a", 0, False, int16_branch=True),
     # pilot_combine is applied only when settings.pilotTRKflag == 1 (see receiver.tracking)
-    "GAL_E1C": SignalSpec("GAL_E1C", _e1_tables, 2.0, L.GC_PLL_3_STATE, "a", 2, False),
+    "GAL_E1C": SignalSpec("GAL_E1C", _e1_tables, 2.0, L.GC_PLL_3_STATE, "a", 2, False, recorded_pilot="none"),
     # BASELINE config 3: the E1-C pilot tracked with its CBOC(6,1,1/11) subcarrier (needs pilotTRKflag = 1 and a narrow
     # correlator: dllCorrelatorSpacing * 12 < 1 table entry); an extension, the reference's package stops at BOC(1,1)
-    "GAL_E1C_CBOC": SignalSpec("GAL_E1C_CBOC", _e1_cboc_tables, 2.0, L.GC_PLL_3_STATE, "a", 5, False, arm_mult=(1.0, 1.0, 6.0)),
+    "GAL_E1C_CBOC": SignalSpec("GAL_E1C_CBOC", _e1_cboc_tables, 2.0, L.GC_PLL_3_STATE, "a", 5, False, arm_mult=(1.0, 1.0, 6.0), recorded_pilot="none"),
     # GLONASS: the record must be loaded with layout GC_QI (GLO_GL1 tracking.m:227 swaps the components);
     # channel.PRN carries the frequency number K (GLO_GL1 preRun.m:66), the FDMA offset lives in acquiredFreq
     "GLO_GL1": SignalSpec("GLO_GL1", _glo_tables, 1.0, L.GC_PLL_3_STATE, "a", 0, False, id_field="K"),
@@ -176,9 +179,9 @@ SIGNALS = {
     "BDS_B1C_NB": SignalSpec("BDS_B1C_NB", _b1c_nb_tables, 2.0, L.GC_PLL_3_STATE, "b", 3, True,
                              pll_weight=(11.0, 29.0), dll_weight=(11.0, 29.0), dll_scale_spacing=True),
     "BDS_B1C_WB": SignalSpec("BDS_B1C_WB", _b1c_wb_tables, 2.0, L.GC_PLL_3_STATE, "b", 4, True, arm_mult=(1.0, 1.0, 6.0),
-                             pll_weight=(1.0, 3.0), dll_weight=_b1c_wb_dll_weight, dll_scale_spacing=True),
+                             pll_weight=(1.0, 3.0), dll_weight=_b1c_wb_dll_weight, dll_scale_spacing=True, recorded_pilot="all"),
     # GPS L2C: RZ-interleaved CM (+ CL through a moving window of its 1.5-s table), everything in doubled-code units
-    "GPS_L2C": SignalSpec("GPS_L2C", _l2c_tables, 1.0, L.GC_PLL_3_STATE, "a", 2, False, windows=(0, 20464), doubled_code=True),
+    "GPS_L2C": SignalSpec("GPS_L2C", _l2c_tables, 1.0, L.GC_PLL_3_STATE, "a", 2, False, windows=(0, 20464), doubled_code=True, recorded_pilot="all"),
     "GAL_E5b": SignalSpec("GAL_E5b", _e5_tables(codes.generateE5bIcode, codes.generateE5bQcode), 1.0, L.GC_PLL_3_STATE, "b", 1, True, int16_branch=True),
 }
 

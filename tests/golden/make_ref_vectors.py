@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_*.npz / ref_*.json by EXECUTING THE REFERENCE'S OWN .m FILES (read in place under
+/root/reference) with the mini-MATLAB interpreter of oracle/mlab on the synthetic scenes of tests/ref_scenes.py.
+
+Runs in the build container only (the GPU box has neither the reference nor any need for it: the fixtures are data).
+Nothing of the reference's source text is stored: inputs are seeds, outputs are numbers.
+
+    python tests/golden/make_ref_vectors.py [track|acq|codes|settings|prerun ...] [--only NAME]
+
+Fixtures:
+    ref_track_<scene>.npz   [trackResults, channel] = tracking(fid, channel, settings) of every package (14 tracking files)
+    ref_acq_<scene>.npz     acqResults = acquisition(longSignal, settings) of every package
+    ref_codes.npz           sha-256 + leading chips of every code generator / sampled-table maker, all PRNs
+    ref_settings.json       settings = initSettings() of the 12 packages (the fields the hot path reads)
+    ref_prerun.npz          channel = preRun(acqResults, settings) of the package families
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+REF = os.environ.get("GC_REFERENCE_ROOT", "/root/reference")
+
+import cu_sdr_collection_amd as P  # noqa: E402
+import ref_scenes as RS  # noqa: E402
+from oracle import mlab  # noqa: E402
+
+
+def interpreter(pkg):
+    d = os.path.join(REF, pkg)
+    return mlab.Interpreter([os.path.join(d, "include"), os.path.join(d, "Common"), d])
+
+
+def reference_settings(I, overrides):
+    Sm = I.call("initSettings")
+    for k, v in overrides.items():
+        Sm.add_field(k)
+        Sm.elems[0][k] = mlab.to_matlab(v if isinstance(v, str) else float(v))
+    return Sm
+
+
+def _num_channel(c):
+    d = {}
+    for k, v in vars(c).items():
+        d[k] = v if isinstance(v, str) else float(v)
+    return SimpleNamespace(**d)
+
+
+def gen_track(sc: RS.TrackScene):
+    t0 = time.time()
+    S, rec, layout, ch = RS.scene_inputs(P, sc)
+    I = interpreter(sc.pkg)
+    Sm = reference_settings(I, sc.overrides)
+    fid = mlab.register_file(I, rec.tobytes(), "scene.bin")
+    mch = mlab.to_matlab([_num_channel(c) for c in ch])
+    tr, chout = I.call(sc.fn, fid, mch, Sm, nargout=2)
+    tr = mlab.from_matlab(tr)
+    tr = tr if isinstance(tr, list) else [tr]
+    out = {"record_crc32": np.array([RS.crc(rec)], dtype=np.uint32), "record_len": np.array([rec.shape[0]]),
+           "overrides": np.array(json.dumps(sc.overrides)), "fn": np.array(sc.fn), "pkg": np.array(sc.pkg),
+           "stdout": np.array("".join(I.out)[-2000:])}
+    names = [f for f in vars(tr[0]) if isinstance(getattr(tr[0], f), (np.ndarray, float))]
+    for f in names:
+        vals = [np.asarray(getattr(t, f), dtype=np.float64).reshape(-1) for t in tr]
+        n = max(v.shape[0] for v in vals)
+        arr = np.full((len(tr), n), np.nan)
+        for k, v in enumerate(vals):
+            arr[k, :v.shape[0]] = v
+        out["f_" + f] = arr
+    out["status"] = np.array([t.status if isinstance(t.status, str) else "" for t in tr])
+    prn = []
+    for t in tr:
+        p = getattr(t, "PRN", 0.0)
+        prn.append(float(p) if np.size(p) == 1 else 0.0)
+    out["PRN_set"] = np.array([np.size(getattr(t, "PRN", 0.0)) == 1 for t in tr])
+    out["PRN"] = np.array(prn)
+    if hasattr(tr[0], "CNo") and isinstance(tr[0].CNo, SimpleNamespace):
+        for f in vars(tr[0].CNo):
+            vals = [np.asarray(getattr(t.CNo, f), dtype=np.float64).reshape(-1) for t in tr]
+            n = max(v.shape[0] for v in vals)
+            arr = np.full((len(tr), n), np.nan)
+            for k, v in enumerate(vals):
+                arr[k, :v.shape[0]] = v
+            out["cno_" + f] = arr
+    path = os.path.join(HERE, f"ref_track_{sc.name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[track] {sc.name}: {sc.pkg}/include/{sc.fn}.m, {len(tr)} channels, fields {len(names)}, {time.time() - t0:.1f} s -> {os.path.basename(path)} "
+          f"({os.path.getsize(path) // 1024} KiB)", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["track", "acq", "codes", "settings", "prerun"])
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        raise SystemExit(f"{REF} not found: the reference is only available in the build container")
+    if "track" in a.what:
+        for sc in RS.TRACK_SCENES:
+            if a.only and a.only != sc.name:
+                continue
+            gen_track(sc)
+    import make_ref_more as MORE
+    for what in ("acq", "codes", "settings", "prerun"):
+        if what in a.what:
+            getattr(MORE, "gen_" + what)(a.only)
+
+
+if __name__ == "__main__":
+    main()

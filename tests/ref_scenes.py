@@ -1,0 +1,265 @@
+"""Synthetic scenes shared by tests/golden/make_ref_vectors.py (which runs the REFERENCE's own .m files on them through
+oracle/mlab, in the build container) and by the tests that compare the oracle and the HIP path with the stored results.
+
+A scene is fully determined by seeds: the tests regenerate the same record bytes (the fixture holds their CRC-32) and the same
+channel / settings values, so nothing but numbers travels to the GPU box."""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+
+import numpy as np
+
+GC_REAL, GC_IQ, GC_QI = 0, 1, 2
+TRACK_FIELDS = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L", "dllDiscr", "dllDiscrFilt",
+                "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase")
+PILOT_FIELDS = ("Pilot_I_E", "Pilot_Q_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L", "Pilot_Q_L")
+
+
+def crc(a: np.ndarray) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@dataclass
+class TrackScene:
+    name: str                     # fixture: tests/golden/ref_track_<name>.npz
+    pkg: str                      # reference package directory, relative to the reference root
+    signal: str                   # cu_sdr_collection_amd.signals.SIGNALS key
+    settings_fn: str              # cu_sdr_collection_amd.settings function mirroring the package's initSettings.m
+    overrides: dict               # settings fields changed for the scene (applied to the mirror AND to the reference's struct)
+    build: object                 # (P, S) -> (record ndarray, layout, channels list)
+    fn: str = "tracking"          # function file of the package (BDS/B1C: NB_tracking / WB_tracking)
+    pilot: bool = False
+    oracle: object = None         # (O, record, channels, S) -> list of trackResults from the oracle
+    extra_fields: tuple = ()
+    notes: str = ""
+
+
+def _sats(P, prns, seed, period, cn0, dmax=3e3):
+    rng = np.random.default_rng(seed)
+    return [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-dmax, dmax)), code_phase_samples=float(rng.uniform(0, period)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=cn0) for p in prns]
+
+
+def _channels(S, sats, df, code_freq=False, pad=1, extra=None):
+    ch = []
+    for s in sats:
+        f = S.IF + s.doppler + df
+        c = SimpleNamespace(PRN=s.prn, acquiredFreq=f, codePhase=int(np.ceil(s.code_phase_samples)) + 1, status="T")
+        if code_freq:
+            c.codeFreq = S.codeFreqBasis + (f - S.IF) / S.carrFreqBasis * S.codeFreqBasis      # preRun.m of the package
+        if extra:
+            extra(c, s)
+        ch.append(c)
+    for _ in range(pad):
+        c = SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-")
+        if code_freq:
+            c.codeFreq = 0.0
+        if extra:
+            extra(c, None)
+        ch.append(c)
+    return ch
+
+
+# ---- record / channel builders -------------------------------------------------------------------------------------
+def _l1ca(P, S):
+    sats = _sats(P, (7, 19), 1001, 18000, 47.0, 5e3)
+    iq = P.synth.generate_if(sats, int((S.msToProcess + 6) * 1e-3 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateCAcode,
+                             S.codeFreqBasis, 1023, seed=1002)
+    return iq, GC_IQ, _channels(S, sats, 3.0)
+
+
+def _l1ca_int16_skip(P, S):
+    iq, _, ch = _l1ca(P, S)
+    return (iq.astype(np.int16) * 5), GC_IQ, ch
+
+
+def _l1ca_real(P, S):
+    sats = _sats(P, (5, 23), 1011, 18000, 50.0, 5e3)
+    iq = P.synth.generate_if(sats, int((S.msToProcess + 6) * 1e-3 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateCAcode,
+                             S.codeFreqBasis, 1023, seed=1012)
+    return np.ascontiguousarray(iq[0::2]), GC_REAL, _channels(S, sats, 3.0)
+
+
+def _e1(P, S):
+    sats = _sats(P, (4, 19), 1021, 72000, 48.0)
+    iq = P.synth.generate_if(sats, int((S.msToProcess + 10) * 1e-3 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateE1Bcode,
+                             2 * S.codeFreqBasis, 8184, seed=1022, bit_periods=1, pilot_fn=P.codes.generateE1Ccode)
+    return iq, GC_IQ, _channels(S, sats, 2.0)
+
+
+def _ten23(data, pilot, ratio, prns, seed, pilot_phase=np.pi / 2):
+    def build(P, S):
+        sats = _sats(P, prns, seed, 18000, 50.0)
+        use_pilot = pilot is not None and getattr(S, "pilotTRKflag", 0) == 1
+        iq = P.synth.generate_if(sats, int((S.msToProcess + 4) * 1e-3 * S.samplingFreq), S.samplingFreq, S.IF, getattr(P.codes, data) if isinstance(data, str) else data(P),
+                                 S.codeFreqBasis, 10230, seed=seed + 1, carrier_ratio=ratio, bit_periods=10,
+                                 pilot_fn=(getattr(P.codes, pilot) if isinstance(pilot, str) else pilot(P)) if use_pilot else None, pilot_phase=pilot_phase)
+        return iq, GC_IQ, _channels(S, sats, 2.0, code_freq=True)
+    return build
+
+
+def _single(code, rate_attr, code_len, ratio, prns, seed, layout=GC_IQ, glonass=False):
+    def build(P, S):
+        fs = S.samplingFreq
+        rng = np.random.default_rng(seed)
+        acc = np.zeros(2 * int((S.msToProcess + 4) * 1e-3 * fs))
+        sats, ifs = [], []
+        for p in prns:
+            s = P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-2e3, 2e3)), code_phase_samples=float(rng.uniform(0, fs * 1e-3)),
+                                carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0)
+            f_if = S.IF + (p * S.freqSpacing if glonass else 0.0)
+            sats.append(s)
+            ifs.append(f_if)
+            acc += P.synth.generate_if([s], acc.shape[0] // 2, fs, f_if, code(P), S.codeFreqBasis, code_len, seed=seed + 100 + p, carrier_ratio=ratio,
+                                       noise=False)
+        iq = np.clip(np.rint(acc + 20.0 * rng.standard_normal(acc.shape[0])), -127, 127).astype(np.int8)
+        if layout == GC_QI:
+            rec = np.empty_like(iq)
+            rec[0::2], rec[1::2] = iq[1::2], iq[0::2]
+        else:
+            rec = iq
+        ch = []
+        for s, f_if in zip(sats, ifs):
+            c = SimpleNamespace(acquiredFreq=f_if + s.doppler + 2.0, codePhase=int(np.ceil(s.code_phase_samples)) + 1, status="T")
+            setattr(c, "K" if glonass else "PRN", s.prn)
+            ch.append(c)
+        pad = SimpleNamespace(acquiredFreq=0.0, codePhase=0, status="-")
+        setattr(pad, "K" if glonass else "PRN", 0)
+        ch.append(pad)
+        return rec, layout, ch
+    return build
+
+
+def _b1c(P, S):
+    sats = _sats(P, (8, 41), 1061, 180000, 47.0)
+    iq = P.synth.generate_if(sats, int((S.msToProcess + 12) * 1e-3 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateDataBOC11,
+                             2 * S.codeFreqBasis, 20460, seed=1062, bit_periods=1, pilot_fn=P.codes.generatePilotBOC11, pilot_phase=np.pi / 2)
+    return iq, GC_IQ, _channels(S, sats, 1.0, code_freq=True)
+
+
+_L2C_START = {5: 74, 17: 3}
+
+
+def _l2c(P, S):
+    def combined(prn):
+        cm, cl = P.codes.generateCMcode(prn).astype(np.float64), P.codes.generateCLcode(prn).astype(np.float64)
+        return np.roll(np.tile(cm, 75) + cl, -20460 * (_L2C_START[prn] - 1))
+    sats = _sats(P, (5, 17), 1071, 160000, 45.0, 2e3)
+    iq = P.synth.generate_if(sats, int((S.msToProcess + 24) * 1e-3 * S.samplingFreq), S.samplingFreq, S.IF, combined, 2 * S.codeFreqBasis,
+                             20460 * 75, seed=1072, carrier_ratio=1200.0, bit_periods=1)
+    ch = []
+    for s in sats:
+        ch.append(SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 0.5, status="T", codePhase=int(np.ceil(s.code_phase_samples)),
+                                  CLCodePhase=_L2C_START[s.prn]))
+    ch.append(SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-", CLCodePhase=0))
+    return iq, GC_IQ, ch
+
+
+# ---- oracle runners ------------------------------------------------------------------------------------------------------
+def _o_l1ca(O, rec, ch, S):
+    return O.tracking_l1ca(rec, ch, S)
+
+
+def _o_generic(**kw):
+    def run(O, rec, ch, S):
+        k = dict(kw)
+        tables = k.pop("tables")
+        spec = SimpleNamespace(tables=lambda prn: tables(O, prn), **k)
+        och = [SimpleNamespace(**{**vars(c), "PRN": (1 if c.status != "-" else 0) if hasattr(c, "K") else c.PRN}) for c in ch]
+        if not hasattr(S, "skipNumberOfBytes"):
+            S = SimpleNamespace(**vars(S), skipNumberOfBytes=getattr(S, "skipNumberOfSamples", 0))
+        return O.tracking_generic(rec, och, S, spec)
+    return run
+
+
+def _pad(O, c):
+    return O.pad_code(c)
+
+
+def _e5_tables(i_sig, q_sig):
+    def t(O, prn):
+        tiered = O.generate_e5_code(i_sig, prn, 2)
+        data = np.concatenate([[tiered[10229]], tiered, [tiered[0]]])[:10232]
+        return [data, O.pad_code(O.generate_e5_primary(q_sig, prn))]
+    return t
+
+
+def _o_b1c_wb(O, rec, ch, S):
+    from cu_sdr_collection_amd import signals
+    run = _o_generic(tables=lambda O_, prn: [O_.pad_code(O_.generate_b1c_code(prn, "data")), O_.pad_code(O_.generate_b1c_code(prn, "pilot11")),
+                                             O_.pad_code(O_.generate_b1c_code(prn, "pilot61"))],
+                     arm_mult=[1.0, 1.0, 6.0], r=2.0, pll="3state", coef_variant="b", pilot_combine=4, code_freq_from_channel=True,
+                     dll_scale_spacing=True, pll_weight=(1.0, 3.0), dll_weight=signals._b1c_wb_dll_weight(S))
+    return run(O, rec, ch, S)
+
+
+TRACK_SCENES = [
+    TrackScene("GPS_L1CA", "GPS/GPS_L1CA", "GPS_L1CA", "initSettings", dict(msToProcess=80, numberOfChannels=3), _l1ca, oracle=_o_l1ca),
+    TrackScene("GPS_L1CA_int16_skip", "GPS/GPS_L1CA", "GPS_L1CA", "initSettings",
+               dict(msToProcess=40, numberOfChannels=3, dataType="int16", skipNumberOfBytes=7200), _l1ca_int16_skip, oracle=_o_l1ca,
+               notes="tracking.m:145-148,212-213: the int16 seek / ftell arithmetic with a non-zero skipNumberOfBytes"),
+    TrackScene("GPS_L1CA_real", "GPS/GPS_L1CA", "GPS_L1CA", "initSettings", dict(msToProcess=40, numberOfChannels=3, fileType=1, IF=4.5e6),
+               _l1ca_real, oracle=_o_l1ca, notes="tracking.m:126-130,232-236: fileType 1, real samples"),
+    TrackScene("GAL_E1C", "GAL/GAL_E1C", "GAL_E1C", "initSettings_GAL_E1C", dict(msToProcess=100, numberOfChannels=3), _e1, pilot=True,
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_e1_code(prn, "B")), O.pad_code(O.generate_e1_code(prn, "C"))],
+                                 r=2.0, pll="3state", coef_variant="a", pilot_combine=2, code_freq_from_channel=False)),
+    TrackScene("GPS_L5C", "GPS/GPS_L5C", "GPS_L5C", "initSettings_GPS_L5C", dict(msToProcess=50, numberOfChannels=3, pilotTRKflag=1),
+               _ten23("generateL5Icode", "generateL5Qcode", 1150.0, (6, 30), 1031), pilot=True,
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_l5_code(prn, "I")), O.pad_code(O.generate_l5_code(prn, "Q"))],
+                                 r=1.0, pll="3state", coef_variant="a", pilot_combine=1, code_freq_from_channel=True)),
+    TrackScene("GPS_L5C_data_only", "GPS/GPS_L5C", "GPS_L5C", "initSettings_GPS_L5C", dict(msToProcess=30, numberOfChannels=3, pilotTRKflag=0),
+               _ten23("generateL5Icode", "generateL5Qcode", 1150.0, (6, 30), 1035),
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_l5_code(prn, "I"))],
+                                 r=1.0, pll="3state", coef_variant="a", pilot_combine=0, code_freq_from_channel=True)),
+    TrackScene("BDS_B2a", "BDS/B2a", "BDS_B2a", "initSettings_BDS_B2a", dict(msToProcess=50, numberOfChannels=3, pilotTRKflag=1, CNoInterval=25),
+               _ten23("generateB2aDataCode", "generateB2aPilotCode", 1150.0, (20, 44), 1041), pilot=True,
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_b2a_code(prn, "data")), O.pad_code(O.generate_b2a_code(prn, "pilot"))],
+                                 r=1.0, pll="3state", coef_variant="a", pilot_combine=1, code_freq_from_channel=True),
+               extra_fields=("DataCNo", "PilotCNo", "B2a_CNo", "DataPLD", "PilotPLD")),
+    TrackScene("BDS_B3I", "BDS/B3I", "BDS_B3I", "initSettings_BDS_B3I", dict(msToProcess=50, numberOfChannels=3),
+               _ten23("generateB3Icode", None, 1240.0, (3, 37), 1043),
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_b3i_code(prn))], r=1.0, pll="3state", coef_variant="b",
+                                 pilot_combine=0, code_freq_from_channel=True, int16_branch=True)),
+    TrackScene("GAL_E5a", "GAL/GAL_E5a", "GAL_E5a", "initSettings_GAL_E5a", dict(msToProcess=50, numberOfChannels=3),
+               _ten23(lambda P: (lambda prn: P.codes.generateE5aIcode(prn, 1)), lambda P: (lambda prn: P.codes.generateE5aQcode(prn, 1)), 1150.0, (2, 33), 1047),
+               pilot=True, oracle=_o_generic(tables=_e5_tables("e5ai", "e5aq"), r=1.0, pll="3state", coef_variant="a", pilot_combine=1,
+                                             code_freq_from_channel=True, int16_branch=True)),
+    TrackScene("GAL_E5b", "GAL/GAL_E5b", "GAL_E5b", "initSettings_GAL_E5b", dict(msToProcess=50, numberOfChannels=3),
+               _ten23(lambda P: (lambda prn: P.codes.generateE5bIcode(prn, 1)), lambda P: (lambda prn: P.codes.generateE5bQcode(prn, 1)), 1180.0, (11, 36), 1053),
+               pilot=True, oracle=_o_generic(tables=_e5_tables("e5bi", "e5bq"), r=1.0, pll="3state", coef_variant="b", pilot_combine=1,
+                                             code_freq_from_channel=True, int16_branch=True)),
+    TrackScene("BDS_B1I", "BDS/B1I", "BDS_B1I", "initSettings_BDS_B1I", dict(msToProcess=60, numberOfChannels=3),
+               _single(lambda P: P.codes.generateCAcode53, "codeFreqBasis", 2046, 1526.0, (7, 23), 1017),
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_b1i_code(prn))], r=1.0, pll="3state", coef_variant="a",
+                                 pilot_combine=0, code_freq_from_channel=False)),
+    TrackScene("GLO_GL1", "GLO/GLO_GL1", "GLO_GL1", "initSettings_GLO_GL1", dict(msToProcess=60, numberOfChannels=3),
+               _single(lambda P: (lambda prn: P.codes.generateGLOcode()), "codeFreqBasis", 511, 3135.0, (-3, 5), 1019, layout=GC_QI, glonass=True),
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_glo_code())], r=1.0, pll="3state", coef_variant="a",
+                                 pilot_combine=0, code_freq_from_channel=False, swap_iq=True)),
+    TrackScene("GLO_GL2", "GLO/GLO_GL2", "GLO_GL2", "initSettings_GLO_GL2", dict(msToProcess=40, numberOfChannels=3),
+               _single(lambda P: (lambda prn: P.codes.generateGLOcode()), "codeFreqBasis", 511, 2438.0, (0, -7), 1023, layout=GC_QI, glonass=True),
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_glo_code())], r=1.0, pll="3state", coef_variant="a",
+                                 pilot_combine=0, code_freq_from_channel=False, swap_iq=True)),
+    TrackScene("BDS_B1C_NB", "BDS/B1C", "BDS_B1C_NB", "initSettings_BDS_B1C", dict(msToProcess=80, numberOfChannels=3, CNoInterval=4), _b1c,
+               fn="NB_tracking", pilot=True,
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_b1c_code(prn, "data")), O.pad_code(O.generate_b1c_code(prn, "pilot11"))],
+                                 r=2.0, pll="3state", coef_variant="b", pilot_combine=3, code_freq_from_channel=True, dll_scale_spacing=True,
+                                 pll_weight=(11.0, 29.0), dll_weight=(11.0, 29.0))),
+    TrackScene("BDS_B1C_WB", "BDS/B1C", "BDS_B1C_WB", "initSettings_BDS_B1C", dict(msToProcess=50, numberOfChannels=3, CNoInterval=5, pilotTRKflag=2), _b1c,
+               fn="WB_tracking", pilot=True, oracle=_o_b1c_wb,
+               notes="the DLL weighting factor comes from CalcWeighingFactor.m's four integral() calls"),
+    TrackScene("GPS_L2C", "GPS/GPS_L2C", "GPS_L2C", "initSettings_GPS_L2C", dict(msToProcess=100, numberOfChannels=3, pilotTRKflag=1), _l2c,
+               pilot=True, oracle=lambda O, rec, ch, S: O.tracking_l2c(rec, ch, S)),
+]
+
+
+def scene_inputs(P, sc: TrackScene):
+    """(settings mirror with the overrides applied, record, layout, channels)."""
+    from cu_sdr_collection_amd import settings as SET
+    S = getattr(SET, sc.settings_fn)()
+    for k, v in sc.overrides.items():
+        setattr(S, k, v)
+    rec, layout, ch = sc.build(P, S)
+    return S, rec, layout, ch

@@ -13,6 +13,14 @@ from oracle import gnss_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _all_six_pilot_sums(monkeypatch):
+    """These tests compare the pilot arm's early / late sums with the oracle too; the reference's trackResults keeps the prompt
+    pair only for most packages (receiver.DEFAULT_PILOT_FIELDS; the reference's exact field sets: tests/test_gpu_ref_vectors.py)."""
+    from cu_sdr_collection_amd import receiver
+    monkeypatch.setattr(receiver, "DEFAULT_PILOT_FIELDS", "all")
+
 _SUMS = ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")
 _PILOT = tuple("Pilot_" + f for f in _SUMS)
 

@@ -10,6 +10,14 @@ from oracle import gnss_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _all_six_pilot_sums(monkeypatch):
+    """These tests compare the pilot arm's early / late sums with the oracle too; the reference's trackResults keeps the prompt
+    pair only for most packages (receiver.DEFAULT_PILOT_FIELDS; the reference's exact field sets: tests/test_gpu_ref_vectors.py)."""
+    from cu_sdr_collection_amd import receiver
+    monkeypatch.setattr(receiver, "DEFAULT_PILOT_FIELDS", "all")
+
+
 def _channels(S, sats, nch):
     ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 4.0,
                           codePhase=int(np.ceil(s.code_phase_samples)) + 1, status="T") for s in sats]
