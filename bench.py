@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — IF Msamples/s through the tracking correlators; x real-time @ 12-ch GPS L1 C/A.
 
-Workload (BASELINE.json configs[1]): 12 GPS L1 C/A channels, 1-ms coherent
-E/P/L correlators, 60 s of synthetic int8 I/Q IF at 18 Msps (2.16 GB resident in HBM), C/N0 45 dB-Hz,
-Doppler U(-5,5) kHz, seed 20241008+2.
+Main line (BASELINE.json configs[1]): 12 GPS L1 C/A channels, 1-ms coherent E/P/L correlators, 60 s of
+synthetic int8 I/Q IF at 18 Msps (2.16 GB resident in HBM), C/N0 45 dB-Hz, Doppler U(-5,5) kHz, seed 20241008+2.
 
   1. the record is synthesised in HBM (csrc/synth.hip);
-  2. closed-loop tracking (gc_track: discriminators and loop filters on the host, the correlator in a persistent
-     host-fed kernel) produces the per-epoch state -> reported as x real-time (closed loop);
-  3. a "step" = ONE batched replay pass of the hot path over the whole record: all
-     channels x epochs blocks (720 000) in one launch, descriptors and IF resident in HBM.
-     `value` = channel-samples through the correlators per second (whole job, all ranks).
+  2. closed-loop tracking (gc_track: discriminators and loop filters on the host, the correlator in a persistent host-fed
+     kernel; gc_track_device: the loop closed on the GPU) produces the per-epoch state -> x real-time (closed loop);
+  3. a "step" = ONE batched replay pass of the hot path over the whole record: all channels x epochs blocks (720 000) in one
+     launch, descriptors and IF resident in HBM.  `value` = IF samples through the correlators per second with every channel
+     active (channel-samples / channels), whole job, all ranks.
 
-N > 1 (one rank per GPU, launched by torch.distributed.run): channels shard across GPUs with no
-data-path collective — every rank tracks its own 12 channels on its own copy of the record — so
-scaling is "weak"; the control plane (barrier + max over ranks) is torch.distributed/gloo.
+With --config all (default at N = 1) the same line carries BASELINE.json's other configs under "configs": Galileo E1-C
+CBOC(6,1,1/11) x 8, GPS L5 + BDS B2a x 16 at 50 Msps (int8 and int16 records), and one GPU's 8-channel share of the
+all-constellation mix.  --config mix runs the whole 64-channel mix (configs[4]) sharded over the ranks by IF record (band).
+
+N > 1: one rank per GPU.  `python bench.py --gpus N` starts the N ranks itself; under torch.distributed.run it joins the
+launcher's ranks.  Channels shard across GPUs with no data-path collective - every rank tracks its own 12 channels on its own
+copy of the record - so scaling is "weak"; the control plane (barrier + max over ranks) is torch.distributed/gloo.
 """
 from __future__ import annotations
 
@@ -31,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "IF Msamples/s through tracking correlators; x real-time @ 12-ch GPS L1 C/A"
 
 
 def _spawn_ranks(n: int) -> int:
@@ -53,15 +57,435 @@ def _spawn_ranks(n: int) -> int:
     return rc
 
 
+class Ranks:
+    """Control plane: barrier + MAX-reduce over ranks (gloo on CPU tensors); a no-op at world size 1."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.dist = rank, world, None
+        if world > 1 or os.environ.get("GC_BENCH_FORCE_DIST"):
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce(self, values, op="max"):
+        if self.dist is None:
+            return list(values)
+        import torch
+        t = torch.tensor(list(values), dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(x) for x in t]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def _traffic(kind: str, blocks: int):
+    """HBM bytes per launch of a replay kernel, measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command
+    (separate passes, gfx950 corrections: MI355X_MICROARCH.md) and stored under profiles/: the newest file that matches."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "traffic.json")
+        try:
+            tj = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for e in (tj if isinstance(tj, list) else [tj]):
+            if e.get("workload", "l1ca") == kind and e.get("blocks_per_launch") == blocks:
+                return e["hbm_bytes_per_launch"], f"profiles/{rnd}/traffic.json, measured offline ({e.get('build', 'round-1 v8 build')})"
+    return None, None
+
+
+# =======================================================================================================================
+# main workload: GPS L1 C/A x 12
+# =======================================================================================================================
+def run_l1ca(P, W, args, R: Ranks, device: int):
+    from cu_sdr_collection_amd import _lib as L
+    from cu_sdr_collection_amd.receiver import track_params
+    S = P.initSettings()
+    fs, nch = S.samplingFreq, args.channels
+    n_samples = int(round(args.seconds * fs))
+    n_epochs = int(args.seconds * 1000) - 2
+    S.msToProcess, S.numberOfChannels = n_epochs, nch
+    eng = P.Engine(device)
+    dev_name, cus = eng.device_info()
+    sats = P.synth.scene(nch, 20241008 + 2, fs)
+    t0 = time.time()
+    P.synth.generate_if_gpu(eng, sats, n_samples, fs, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023, seed=20241008 + 2)
+    t_synth = time.time() - t0
+    eng.set_sampling_freq(fs)
+    inits = []
+    for i, s in enumerate(sats):   # channel table as preRun would hand it over (truth + a 3 Hz acquisition residual)
+        eng.set_channel(i, [P.codes.padded_table(P.codes.generateCAcode(s.prn))])
+        inits.append(L.gc_channel_init(channel=i, prn=s.prn, acquired_freq=S.IF + s.doppler + 3.0, code_freq=S.codeFreqBasis,
+                                       code_phase=int(np.ceil(s.code_phase_samples)) + 1))
+    p = track_params(S)
+    t0 = time.time()
+    fields, done, st = eng.track(p, inits)
+    t_closed = time.time() - t0
+    if st != 0 or int(done.min()) != n_epochs:
+        raise RuntimeError(f"closed-loop tracking stopped early: status {st}, epochs {done}")
+    locked = np.mean(np.abs(fields["I_P"][:, 1000:]), axis=1) > 3 * np.mean(np.abs(fields["Q_P"][:, 1000:]), axis=1)
+    blks = np.ceil((S.codeLength - fields["remCodePhase"]) / (fields["codeFreq"] / fs)).astype(np.int64)
+    chan_samples = int(blks.sum())
+    t0 = time.time()
+    dfields, ddone, dst = eng.track(p, inits, device_loop=True)
+    t_dev = time.time() - t0
+    dev_loop = None
+    if dst == 0 and int(ddone.min()) == n_epochs:
+        diff = dfields["absoluteSample"] != fields["absoluteSample"]
+        dev_loop = {"corr_msps": round(chan_samples / t_dev / 1e6, 1), "x_realtime": round(chan_samples / t_dev / 1e6 / nch / (fs / 1e6), 2),
+                    "us_per_epoch": round(t_dev / n_epochs * 1e6, 2),
+                    # two closed loops part ways by one sample of block boundary at a knife edge of ceil() sooner or later (DESIGN.md
+                    # 4.3b; tests/test_gpu_tracking.py::test_four_thousand_epoch_closed_loops_stay_equivalent bounds what follows)
+                    "epochs_with_the_host_loops_block_geometry": int(np.argmax(np.any(diff, axis=0))) if diff.any() else int(n_epochs),
+                    "max_block_start_difference_samples": int(np.max(np.abs(dfields["absoluteSample"] - fields["absoluteSample"]))),
+                    "max_carr_freq_dev_hz": float(np.max(np.abs(dfields["carrFreq"] - fields["carrFreq"])))}
+    nb = nch * n_epochs
+    job = W.Job("l1ca", W.PACKAGES["GPS_L1CA"], S, sats, eng, params=p, inits=inits, phase0=[0] * nch)
+    W.keep_records(job, fields)
+    blocks, _ = W.replay_blocks(job)
+    eng.replay_prepare(blocks)
+
+    # ---- warm-up, then exactly K timed steps ---------------------------------------------------------------------
+    for _ in range(args.warmup):
+        eng.replay_launch()
+    eng.synchronize()
+    R.barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for _ in range(args.steps):
+        eng.replay_launch()
+    kernel_ms_total = eng.timer_stop()  # hipEvents on the launch stream; also synchronises
+    eng.synchronize()
+    R.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed, kernel_ms_total = R.reduce([elapsed, kernel_ms_total])
+    (total_chan_samples,) = R.reduce([chan_samples], op="sum")
+
+    out = eng.replay_fetch()[:, 0, :]
+    rec = np.stack([fields[f].T.reshape(-1) for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")], axis=1)
+    scale = 2.0 * 18000 * 28.0
+    replay_dev = float(np.max(np.abs(out - rec)) / scale)
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    corr_msps = total_chan_samples * args.steps / elapsed / 1e6
+    value = corr_msps / nch                     # IF samples per second with all channels active, all ranks
+    kernel_ms = kernel_ms_total / args.steps
+    algo_bytes = 2.0 * chan_samples             # int8 I/Q: 2 bytes per channel-sample (SURVEY.md §8d)
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = _traffic("l1ca", nb)
+    result = {
+        "metric": METRIC, "value": round(value, 1), "unit": "IF Msamples/s (all channels active, all GPUs)",
+        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 accumulate over int8 I/Q samples; f64/64-bit fixed-point code+carrier phase", "data": "synthetic",
+        "config": {"workload": f"GPS L1 C/A, {nch} channels/GPU, 1-ms E/P/L correlators, {args.seconds:g} s of int8 I/Q IF at 18 Msps "
+                               f"({n_samples * 2 / 1e9:.2f} GB in HBM), batched replay of {nb} blocks per step",
+                   "channels_per_gpu": nch, "epochs": n_epochs, "blocks_per_step": nb,
+                   "parallelism": f"channels sharded over {R.world} GPU(s), no data-path collective"},
+        "corr_msps": round(corr_msps, 1), "corr_msps_unit": "Msamples/s (channel-samples, all GPUs)",
+        "if_msps_per_gpu": round(value / R.world, 1), "x_realtime_replay": round(value / R.world / (fs / 1e6), 1),
+        "closed_loop": {"corr_msps": round(chan_samples / t_closed / 1e6, 1), "x_realtime": round(chan_samples / t_closed / 1e6 / nch / (fs / 1e6), 2),
+                        "us_per_epoch": round(t_closed / n_epochs * 1e6, 2), "channels_locked": int(locked.sum())},
+        "closed_loop_device": dev_loop,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "corr_epl_fast_kernel<ARMS=1, I8_IQ, SPL=16> (four waves, float tables)", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": algo_bytes},
+        "replay_vs_closed_loop_max_dev": replay_dev, "device": dev_name, "compute_units": cus, "synth_s": round(t_synth, 2),
+    }
+    return result, dict(eng=eng, S=S, sats=sats, inits=inits, fields=fields, n_epochs=n_epochs, n_samples=n_samples, job=job)
+
+
+def run_acquisition(P, eng, sats):
+    """The other half of the hot path at the reference's defaults: 32 PRNs x 29 bins x 20 ms (acquisition.m:116-260)."""
+    from cu_sdr_collection_amd.receiver import acquisition as gpu_acquisition
+    Sa = P.initSettings()
+    gpu_acquisition(eng, Sa)  # warm-up (plans, twiddles, scratch)
+    t0 = time.perf_counter()
+    acq = gpu_acquisition(eng, Sa)
+    t_acq = time.perf_counter() - t0
+    found = sorted(int(i) + 1 for i in np.nonzero(acq.carrFreq)[0])
+    return {"seconds": round(t_acq, 4), "prns_searched": 32, "bins": 29, "non_coh_ms": 20, "fft_size": 36000, "acquired": found,
+            "all_scene_prns_found": sorted(s.prn for s in sats) == found}
+
+
+# =======================================================================================================================
+# the other BASELINE configs: a band record, one job per package, closed loops + replay
+# =======================================================================================================================
+def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, seed, steps, warmup, dtype=np.int8):
+    """parts = [(package, channels)] tracked from ONE record.  Returns (summary dict, jobs)."""
+    engines = [P.Engine(device) for _ in parts]
+    t0 = time.time()
+    made = W.make_band(P, engines[0], parts, seconds, fs, intermediate_freq, seed, dtype=dtype)
+    t_synth = time.time() - t0
+    for e in engines[1:]:
+        e.share_if(engines[0])
+    jobs = []
+    for (pkg, S, sats), eng in zip(made, engines):
+        n_ep = int((seconds - 3 * S.intTime) / S.intTime) - 1
+        j = W.prepare_job(P, W.Job(f"{name}:{pkg.signal}", pkg, S, sats, eng), n_ep)
+        j.record_dtype = np.dtype(dtype)
+        jobs.append(j)
+    W.run_closed_loops(P, jobs, device_loop=False)                      # first use: code loading, allocations
+    t_host, recs = W.run_closed_loops(P, jobs, device_loop=False)
+    for j, f in zip(jobs, recs):
+        W.keep_records(j, f)
+    W.run_closed_loops(P, jobs, device_loop=True)                       # (falls back to the host loop where no device-loop kernel applies)
+    t_dev, _ = W.run_closed_loops(P, jobs, device_loop=True)
+    per_job = []
+    total_cs, total_ms, total_bytes = 0.0, 0.0, 0.0
+    bps = 2.0 * np.dtype(dtype).itemsize
+    for j in jobs:
+        ms, dev, kern = W.time_replay(j, steps, warmup)
+        cs = float(j.blks.sum())
+        total_cs += cs
+        total_ms += ms
+        total_bytes += bps * cs
+        per_job.append({"signal": j.pkg.signal, "channels": len(j.sats), "epochs": j.params.n_epochs, "blocks_per_launch": int(j.blks.size),
+                        "kernel": W.KERNEL_NAMES.get(kern, str(kern)), "kernel_ms": round(ms, 4),
+                        "algorithmic_bytes_per_launch": bps * cs, "achieved_GBps": round(bps * cs / ms / 1e6, 1),
+                        "frac": round(bps * cs / ms / 1e6 / HBM_PEAK_GBPS, 4), "replay_vs_closed_loop_max_dev": dev,
+                        "channels_locked": W.locked(j)})
+    nch = sum(len(j.sats) for j in jobs)
+    signal_s = min(j.params.n_epochs * j.S.intTime for j in jobs)
+    summary = {
+        "workload": f"{name}: {', '.join(f'{n} x {s}' for s, n in parts)} on one {seconds:g}-s {np.dtype(dtype).name} I/Q record at {fs / 1e6:g} Msps "
+                    f"({int(round(seconds * fs)) * bps / 1e9:.2f} GB in HBM)",
+        "channels": nch, "jobs": per_job,
+        "replay": {"kernel_ms_sum": round(total_ms, 4), "corr_msps": round(total_cs / total_ms / 1e3, 1), "if_msps": round(total_cs / total_ms / 1e3 / nch, 1),
+                   "x_realtime": round(total_cs / total_ms / 1e3 / nch / (fs / 1e6), 1),
+                   "roofline": {"bound": "hbm", "achieved": round(total_bytes / total_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(total_bytes / total_ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": total_bytes, "traffic": None}},
+        "closed_loop_host": {"seconds": round(t_host, 4), "x_realtime": round(signal_s / t_host, 1)},
+        "closed_loop_device": {"seconds": round(t_dev, 4), "x_realtime": round(signal_s / t_dev, 1)},
+        "synth_s": round(t_synth, 2),
+    }
+    return summary, jobs
+
+
+def run_mix(P, W, args, R: Ranks, device: int):
+    """BASELINE configs[4]: 64 channels of the twelve signals sharded over the ranks by band (sharding.shard_bands: every rank
+    8 channels, each band's record on as few GPUs as possible).  Every rank that tracks a band synthesises that band's record
+    from the same seed - standing for the file read + broadcast_record hand-over of a real run - and runs one
+    tracking job per package on it, all jobs of the rank concurrently (gc_track_multi)."""
+    from cu_sdr_collection_amd.sharding import band_ranks, shard_bands
+    counts = {b: sum(n for _, n in parts) for b, parts in W.MIX_BANDS.items()}
+    plan = shard_bands(counts, R.world)
+    mine = plan[R.rank]
+    band_fs = {"L2": 8e6, "GLO_L1": 12e6, "GLO_L2": 12e6}
+    band_if = {"GLO_L1": 0.0, "GLO_L2": 0.0}
+    jobs, bands_here, t_synth = [], [], 0.0
+    for bi, band in enumerate(sorted(W.MIX_BANDS)):
+        idx = sorted(i for b, i in mine if b == band)
+        if not idx:
+            continue
+        bands_here.append(band)
+        parts = W.MIX_BANDS[band]
+        fs = band_fs.get(band, 18e6)
+        engines = [P.Engine(device) for _ in parts]
+        t0 = time.time()
+        made = W.make_band(P, engines[0], parts, args.mix_seconds, fs, band_if.get(band, 20e3), 5000 + 101 * bi)
+        t_synth += time.time() - t0
+        off = 0
+        for (pkg, S, sats), eng in zip(made, engines):
+            sel = [s for k, s in enumerate(sats) if off + k in idx]       # this rank's channels of the package
+            off += len(sats)
+            if not sel:
+                if eng is not engines[0]:
+                    eng.close()
+                continue
+            if eng is not engines[0]:
+                eng.share_if(engines[0])
+            n_ep = int((args.mix_seconds - 3 * S.intTime) / S.intTime) - 1
+            jobs.append(W.prepare_job(P, W.Job(f"{band}:{pkg.signal}", pkg, S, sel, eng), n_ep))
+    W.run_closed_loops(P, jobs, device_loop=False)
+    t_host, recs = W.run_closed_loops(P, jobs, device_loop=False)
+    for j, f in zip(jobs, recs):
+        W.keep_records(j, f)
+    W.run_closed_loops(P, jobs, device_loop=True)
+    t_dev, _ = W.run_closed_loops(P, jobs, device_loop=True)
+    per_job, cs_total, bytes_total = [], 0.0, 0.0
+    for j in jobs:
+        blocks, _ = W.replay_blocks(j)
+        j.engine.replay_prepare(blocks)
+        cs = float(j.blks.sum())
+        cs_total += cs
+        bytes_total += 2.0 * cs
+    for _ in range(args.warmup):
+        for j in jobs:
+            j.engine.replay_launch()
+    for j in jobs:
+        j.engine.synchronize()
+    R.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):          # a step = one replay pass of every job of the rank; the jobs' streams overlap
+        for j in jobs:
+            j.engine.replay_launch()
+    for j in jobs:
+        j.engine.synchronize()
+    R.barrier()
+    elapsed = time.perf_counter() - t0
+    (elapsed,) = R.reduce([elapsed])
+    cs_all, nch_all, bytes_all = R.reduce([cs_total, float(sum(len(j.sats) for j in jobs)), bytes_total], op="sum")
+    kernel_ms = 0.0
+    for j in jobs:                        # per-kernel times, one job at a time (hipEvents on the job's stream)
+        j.engine.timer_start()
+        for _ in range(args.steps):
+            j.engine.replay_launch()
+        ms = j.engine.timer_stop() / args.steps
+        kernel_ms += ms
+        cs = float(j.blks.sum())
+        per_job.append({"job": j.name, "channels": len(j.sats), "kernel": W.KERNEL_NAMES.get(j.engine.last_kernel()), "kernel_ms": round(ms, 4),
+                        "achieved_GBps": round(2.0 * cs / ms / 1e6, 1), "frac": round(2.0 * cs / ms / 1e6 / HBM_PEAK_GBPS, 4), "channels_locked": W.locked(j)})
+    name, cus = jobs[0].engine.device_info()
+    corr_msps = cs_all * args.steps / elapsed / 1e6
+    achieved = bytes_total / (kernel_ms * 1e-3) / 1e9
+    mine_summary = {"rank": R.rank, "bands": bands_here, "jobs": per_job, "closed_loop_host_s": round(t_host, 4), "closed_loop_device_s": round(t_dev, 4)}
+    gathered = [mine_summary]
+    if R.dist is not None:
+        gathered = [None] * R.world
+        R.dist.all_gather_object(gathered, mine_summary)
+    t_host_max, t_dev_max = R.reduce([t_host, t_dev])
+    result = {
+        "metric": METRIC, "value": round(corr_msps / (nch_all / R.world), 1), "unit": "IF Msamples/s (channel-samples / channels per GPU, all GPUs)",
+        "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32 accumulate over int8 I/Q samples; f64/64-bit fixed-point code+carrier phase",
+        "data": "synthetic",
+        "config": {"workload": f"all-constellation mix: {int(nch_all)} channels of {len(W.PACKAGES) - 1} signals in {len(W.MIX_BANDS)} band records "
+                               f"({args.mix_seconds:g} s each), sharded by band over {R.world} GPU(s), every rank's packages tracked concurrently",
+                   "bands": {b: parts for b, parts in W.MIX_BANDS.items()}, "plan_bands_per_rank": {str(r): sorted({b for b, _ in p}) for r, p in enumerate(plan)},
+                   "band_reader_ranks": band_ranks(plan), "parallelism": "channels sharded by IF record; the record hand-over is the only exchange step"},
+        "corr_msps": round(corr_msps, 1),
+        "closed_loop_host": {"seconds": round(t_host_max, 4), "x_realtime": round(args.mix_seconds / t_host_max, 1)},
+        "closed_loop_device": {"seconds": round(t_dev_max, 4), "x_realtime": round(args.mix_seconds / t_dev_max, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": None, "kernel": "sum over rank 0's replay kernels (per job under ranks)", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": bytes_total},
+        "ranks": gathered, "device": name, "compute_units": cus, "synth_s": round(t_synth, 2),
+    }
+    return result
+
+
+# =======================================================================================================================
+# CPU side (rank 0, N = 1 only, after every timed region): baselines and oracle spot checks.  The only place that touches oracle/.
+# =======================================================================================================================
+def _oracle_tables(O, P, signal, prn):
+    pad = O.pad_code
+    if signal == "GAL_E1C_CBOC":   # the BOC(6,1) table of the E1-C pilot is this build's extension (no oracle generator in the reference's terms)
+        return [pad(O.generate_e1_code(prn, "B")), pad(O.generate_e1_code(prn, "C")), pad(np.asarray(P.codes.generateE1C_BOC61(prn), dtype=np.float64))]
+    return {
+        "GPS_L1CA": lambda: [pad(O.generate_ca_code(prn))],
+        "GAL_E1C": lambda: [pad(O.generate_e1_code(prn, "B")), pad(O.generate_e1_code(prn, "C"))],
+        "BDS_B1C_NB": lambda: [pad(O.generate_b1c_code(prn, "data")), pad(O.generate_b1c_code(prn, "pilot11"))],
+        "GPS_L5C": lambda: [pad(O.generate_l5_code(prn, "I")), pad(O.generate_l5_code(prn, "Q"))],
+        "BDS_B2a": lambda: [pad(O.generate_b2a_code(prn, "data")), pad(O.generate_b2a_code(prn, "pilot"))],
+    }[signal]()
+
+
+def oracle_spot_check(P, W, O, job, nblocks=4, seed=1):
+    """A few replayed blocks of a job against the float64 oracle (tracking.m:247-300) at identical descriptors: worst deviation in
+    units of sum |x| over the block (the tests' tolerance is 2e-6)."""
+    from cu_sdr_collection_amd import signals
+    spec = signals.SIGNALS[job.pkg.signal]
+    rng = np.random.default_rng(seed)
+    _, view = W.replay_blocks(job)
+    pick = np.sort(rng.choice(view.shape[0], size=nblocks, replace=False))
+    sub = job.engine.make_blocks(nblocks)
+    np.frombuffer(sub, dtype=W.BLOCK_DT)[:] = view[pick]
+    got = job.engine.correlate(sub)
+    worst = 0.0
+    for k in range(nblocks):
+        b = sub[k]
+        tabs = _oracle_tables(O, P, job.pkg.signal, job.sats[b.channel].prn)
+        raw_i = job.engine.read_if(int(b.first_sample), int(b.blksize), dtype=job.record_dtype)
+        raw = O.raw_from_if(raw_i, 0, int(b.blksize))
+        want, _, _ = O.correlate_block(raw, tabs, b.rem_code_phase, b.code_phase_step, b.el_spacing, b.carr_freq, b.rem_carr_phase,
+                                       job.params.sampling_freq, job.params.code_length, r=spec.index_scale,
+                                       arm_mult=list(spec.arm_mult) if spec.arm_mult else None)
+        scale = float(np.sum(np.abs(raw.real)) + np.sum(np.abs(raw.imag)))
+        worst = max(worst, float(np.max(np.abs(got[k, :want.shape[0]] - want))) / scale)
+    return worst
+
+
+def cpu_leg(P, W, args, main, extra_jobs):
+    from types import SimpleNamespace
+
+    from oracle import c_oracle as CO
+    from oracle import gnss_oracle as O
+    eng, fields, inits, n_epochs, n_samples = main["eng"], main["fields"], main["inits"], main["n_epochs"], main["n_samples"]
+    nch = len(inits)
+    fs = 18e6
+    CO.build(force=True)
+    cpu_epochs = min(args.cpu_epochs, n_epochs)
+    iq = eng.read_if(0, min(int((cpu_epochs + 3) * 1e-3 * fs), n_samples))
+    Sc = P.initSettings()
+    Sc.msToProcess = cpu_epochs
+    ch = [SimpleNamespace(PRN=i.prn, acquiredFreq=i.acquired_freq, codePhase=i.code_phase, status="T") for i in inits]
+    t0 = time.perf_counter()
+    ref, cdone, aborted = CO.track_l1ca(iq, ch, Sc)
+    t_cpu = time.perf_counter() - t0
+    cpu_samples = float(np.sum(np.ceil((Sc.codeLength - ref["remCodePhase"]) / (ref["codeFreq"] / fs))))
+    cpu_msps = cpu_samples / t_cpu / 1e6
+    # Parity at identical descriptors: the CPU loop's own recorded per-epoch state (tracking.m:212-216,249,277,314,332) replayed
+    # through the GPU correlator, all 12 x cpu_epochs blocks, against the CPU loop's sums.
+    cj = W.Job("cpu", W.PACKAGES["GPS_L1CA"], Sc, main["sats"], eng, params=main["job"].params, inits=inits, phase0=[0] * nch)
+    W.keep_records(cj, {k: v for k, v in ref.items()})
+    cb, _ = W.replay_blocks(cj)
+    got = eng.correlate(cb)[:, 0, :]
+    want = np.stack([ref[f].T.reshape(-1) for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")], axis=1)
+    dev = float(np.max(np.abs(got - want))) / (2.0 * 18000 * 28.0)
+    same = ref["absoluteSample"] == fields["absoluteSample"][:, :cpu_epochs]
+    n_same = [int(np.argmin(r)) if not r.all() else cpu_epochs for r in same]
+    # variant (i): NumPy float64, whole-array operations per epoch in the .m's order (the closest stand-in for MATLAB's vector engine)
+    np_epochs = min(args.numpy_epochs, cpu_epochs)
+    Sn = P.initSettings()
+    Sn.msToProcess = np_epochs
+    t0 = time.perf_counter()
+    nref = O.tracking_l1ca(iq, ch, Sn)
+    t_np = time.perf_counter() - t0
+    np_samples = float(sum(np.sum(np.ceil((Sn.codeLength - t.remCodePhase) / (t.codeFreq / fs))) for t in nref))
+    np_msps = np_samples / t_np / 1e6
+    agree = float(max(np.max(np.abs(nref[k].I_P - ref["I_P"][k][:np_epochs])) for k in range(nch)))
+    base = {
+        "value": round(max(cpu_msps, np_msps) / nch, 3), "unit": "IF Msamples/s (all channels active)", "cores": 1, "kind": "port",
+        "sample": f"oracle/gnss_oracle.c (float64 restatement of tracking.m:133-368, gcc -O3), closed loop, {nch} channels x {cpu_epochs} epochs "
+                  f"of the same record ({t_cpu:.1f} s of CPU); MATLAB-equivalent CPU restatement, not MATLAB",
+        "corr_msps": round(cpu_msps, 2), "x_realtime": round(cpu_msps / nch / (fs / 1e6), 4),
+        "numpy_variant": {"value": round(np_msps / nch, 3), "corr_msps": round(np_msps, 2), "x_realtime": round(np_msps / nch / (fs / 1e6), 4), "cores": 1,
+                          "sample": f"oracle/gnss_oracle.py tracking_l1ca (NumPy float64, whole-array operations per epoch), {nch} channels x {np_epochs} "
+                                    f"epochs ({t_np:.1f} s); max |I_P| difference from the C variant {agree:.2e}"},
+        "faster_variant": "C" if cpu_msps >= np_msps else "NumPy",
+        "gpu_replay_of_cpu_state_max_dev": dev, "closed_loops_cut_the_same_blocks_for_epochs": int(min(n_same)),
+    }
+    spots = {}
+    for jobs in extra_jobs.values():
+        for j in jobs:
+            spots[j.name] = oracle_spot_check(P, W, O, j)
+    return base, spots
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seconds", type=float, default=60.0, help="length of the IF record")
+    ap.add_argument("--seconds", type=float, default=60.0, help="length of the IF record of the main workload")
     ap.add_argument("--channels", type=int, default=12)
-    ap.add_argument("--cpu-epochs", type=int, default=4000, help="epochs per channel timed on the CPU baseline (4000: ~13 s of one core)")
+    ap.add_argument("--config", choices=["all", "l1ca", "mix"], default=None,
+                    help="all (default at N = 1): main line + the other BASELINE configs; l1ca (default at N > 1): main line only; mix: configs[4] as the line")
+    ap.add_argument("--cfg-seconds", type=float, default=60.0, help="record length of config 4 (L5 + B2a at 50 Msps); config 3 uses a third of it")
+    ap.add_argument("--mix-seconds", type=float, default=10.0, help="record length of every band of the mix")
+    ap.add_argument("--cpu-epochs", type=int, default=4000, help="epochs per channel timed on the C CPU baseline (4000: ~13 s of one core)")
+    ap.add_argument("--numpy-epochs", type=int, default=250, help="epochs per channel of the NumPy CPU variant (~5 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-int16", action="store_true")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -74,227 +498,48 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
                          "they must agree (n_gpus in the result line is the number of ranks that ran)")
-    dist = None
-    if world > 1 or os.environ.get("GC_BENCH_FORCE_DIST"):
-        import torch.distributed as dist  # control plane only: gloo on CPU tensors
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    R = Ranks(rank, world)
+    config = args.config or ("all" if world == 1 else "l1ca")
 
+    import bench_workloads as W
     import cu_sdr_collection_amd as P
-    from cu_sdr_collection_amd import _lib as L
-    from cu_sdr_collection_amd.receiver import track_params
-
-    S = P.initSettings()
-    fs = S.samplingFreq
-    nch = args.channels
-    n_samples = int(round(args.seconds * fs))
-    n_epochs = int(args.seconds * 1000) - 2
-    S.msToProcess = n_epochs
-    S.numberOfChannels = nch
 
     # one GPU per rank; GC_BENCH_DEVICE pins every rank to one device (functional test of the N > 1 path on a 1-GPU box)
-    eng = P.Engine(int(os.environ.get("GC_BENCH_DEVICE", local_rank)))
-    dev_name, cus = eng.device_info()
-    sats = P.synth.scene(nch, 20241008 + 2, fs)
-    t0 = time.time()
-    P.synth.generate_if_gpu(eng, sats, n_samples, fs, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023,
-                            seed=20241008 + 2)
-    t_synth = time.time() - t0
-    eng.set_sampling_freq(fs)
+    device = int(os.environ.get("GC_BENCH_DEVICE", local_rank))
+    if config == "mix":
+        result = run_mix(P, W, args, R, device)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        R.close()
+        return
 
-    # channel table as preRun would hand it over (truth + a 3 Hz acquisition residual)
-    inits = []
-    for i, s in enumerate(sats):
-        eng.set_channel(i, [P.codes.padded_table(P.codes.generateCAcode(s.prn))])
-        inits.append(L.gc_channel_init(channel=i, prn=s.prn, acquired_freq=S.IF + s.doppler + 3.0,
-                                       code_freq=S.codeFreqBasis, code_phase=int(np.ceil(s.code_phase_samples)) + 1))
-
-    # ---- closed loop: produces the state every replay block needs -------------------------------
-    p = track_params(S)
-    t0 = time.time()
-    fields, done, st = eng.track(p, inits)
-    t_closed = time.time() - t0
-    if st != 0 or int(done.min()) != n_epochs:
-        raise RuntimeError(f"closed-loop tracking stopped early: status {st}, epochs {done}")
-    locked = np.mean(np.abs(fields["I_P"][:, 1000:]), axis=1) > 3 * np.mean(np.abs(fields["Q_P"][:, 1000:]), axis=1)
-    blks = np.ceil((S.codeLength - fields["remCodePhase"]) / (fields["codeFreq"] / fs)).astype(np.int64)
-    chan_samples = int(blks.sum())
-    closed_msps = chan_samples / t_closed / 1e6
-    # the same loop closed on the device (one persistent cooperative launch, include/gnsscorr.h gc_track_device)
-    t0 = time.time()
-    dfields, ddone, dst = eng.track(p, inits, device_loop=True)
-    t_dev = time.time() - t0
-    dev_loop = None
-    if dst == 0 and int(ddone.min()) == n_epochs:
-        dev_loop = {"corr_msps": round(chan_samples / t_dev / 1e6, 1), "x_realtime": round(chan_samples / t_dev / 1e6 / nch / (fs / 1e6), 2),
-                    "us_per_epoch": round(t_dev / n_epochs * 1e6, 2),
-                    "same_block_geometry_as_host_loop": bool(np.array_equal(dfields["absoluteSample"], fields["absoluteSample"])),
-                    # two closed loops part ways by one sample of block boundary at a knife edge of ceil() sooner or later
-                    # (DESIGN.md 4.3b); until then they cut identical blocks
-                    "epochs_with_the_host_loops_block_geometry": int(np.argmax(np.any(dfields["absoluteSample"] != fields["absoluteSample"], axis=0)))
-                    if np.any(dfields["absoluteSample"] != fields["absoluteSample"]) else int(n_epochs),
-                    "max_carr_freq_dev_hz": float(np.max(np.abs(dfields["carrFreq"] - fields["carrFreq"])))}
-
-    # ---- replay descriptors, epoch-major so the channels of one epoch sit next to each other ----
-    nb = nch * n_epochs
-    blocks = eng.make_blocks(nb)
-    # fill through a structured numpy view (720k ctypes attribute writes would take seconds)
-    dt = np.dtype([("channel", "<i4"), ("blksize", "<i4"), ("first_sample", "<i8"), ("rem_code_phase", "<f8"),
-                   ("code_phase_step", "<f8"), ("el_spacing", "<f8"), ("carr_freq", "<f8"),
-                   ("rem_carr_phase", "<f8"), ("table_offset", "<i4", (3,)), ("reserved", "<i4")])
-    assert dt.itemsize == 72
-    view = np.frombuffer(blocks, dtype=dt)
-    for k in range(nch):
-        sl = slice(k, nb, nch)
-        view["channel"][sl] = k
-        view["blksize"][sl] = blks[k]
-        view["first_sample"][sl] = fields["absoluteSample"][k].astype(np.int64)
-        view["rem_code_phase"][sl] = fields["remCodePhase"][k]
-        view["code_phase_step"][sl] = fields["codeFreq"][k] / fs
-        view["el_spacing"][sl] = S.dllCorrelatorSpacing
-        view["carr_freq"][sl] = fields["carrFreq"][k]
-        view["rem_carr_phase"][sl] = fields["remCarrPhase"][k]
-    eng.replay_prepare(blocks)
-
-    # ---- warm-up, then exactly K timed steps -----------------------------------------------------
-    for _ in range(args.warmup):
-        eng.replay_launch()
-    eng.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    for _ in range(args.steps):
-        eng.replay_launch()
-    kernel_ms_total = eng.timer_stop()  # hipEvents on the launch stream; also synchronises
-    eng.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_total = float(t[0]), float(t[1])
-
-    # replay must reproduce the closed-loop outputs (same kernel, different split count)
-    out = eng.replay_fetch()[:, 0, :]
-    rec = np.stack([fields[f].T.reshape(-1) for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")], axis=1)
-    scale = 2.0 * 18000 * 28.0
-    replay_dev = float(np.max(np.abs(out - rec)) / scale)
-
-    ms_per_step = elapsed * 1e3 / args.steps
-    total_chan_samples = chan_samples * world
-    value = total_chan_samples * args.steps / elapsed / 1e6
-    kernel_ms = kernel_ms_total / args.steps
-    algo_bytes = 2.0 * chan_samples  # int8 I/Q: 2 bytes per channel-sample
-    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-
-    # HBM bytes per launch of the replay kernel, measured offline with rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE on this exact command (profiles/r01/traffic.json, gfx950 x2 read correction applied)
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-        if tj.get("blocks_per_launch") == nb:
-            traffic = tj["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-
-    result = {
-        "metric": "IF Msamples/s through tracking correlators; x real-time @ 12-ch GPS L1 C/A",
-        "value": round(value, 1),
-        "unit": "Msamples/s (channel-samples, all GPUs)",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32 accumulate over int8 I/Q samples; f64/64-bit fixed-point code+carrier phase",
-        "data": "synthetic",
-        "config": {"workload": f"GPS L1 C/A, {nch} channels/GPU, 1-ms E/P/L correlators, {args.seconds:g} s of int8 I/Q IF at 18 Msps "
-                               f"({n_samples * 2 / 1e9:.2f} GB in HBM), batched replay of {nb} blocks per step",
-                   "channels_per_gpu": nch, "epochs": n_epochs, "blocks_per_step": nb,
-                   "parallelism": f"channels sharded over {world} GPU(s), no data-path collective"},
-        "if_msps_per_gpu": round(value / world / nch, 1),
-        "x_realtime_replay": round(value / world / nch / (fs / 1e6), 1),
-        "closed_loop": {"corr_msps": round(closed_msps, 1), "x_realtime": round(closed_msps / nch / (fs / 1e6), 2),
-                        "us_per_epoch": round(t_closed / n_epochs * 1e6, 2), "channels_locked": int(locked.sum())},
-        "closed_loop_device": dev_loop,
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "kernel": "corr_epl_fast_kernel<ARMS=1, I8_IQ, SPL=16>", "kernel_ms": round(kernel_ms, 4),
-                     "algorithmic_bytes_per_launch": algo_bytes},
-        "replay_vs_closed_loop_max_dev": replay_dev,
-        "device": dev_name, "compute_units": cus, "synth_s": round(t_synth, 2),
-    }
-
-    # ---- acquisition (the other half of the hot path), reference defaults: 32 PRNs x 29 bins x 20 ms ----
-    from cu_sdr_collection_amd.receiver import acquisition as gpu_acquisition
-    Sa = P.initSettings()
-    gpu_acquisition(eng, Sa)  # warm-up (plans, twiddles, scratch)
-    t0 = time.perf_counter()
-    acq = gpu_acquisition(eng, Sa)
-    t_acq = time.perf_counter() - t0
-    found = sorted(int(i) + 1 for i in np.nonzero(acq.carrFreq)[0])
-    result["acquisition"] = {"seconds": round(t_acq, 4), "prns_searched": 32, "bins": 29, "non_coh_ms": 20,
-                             "fft_size": 36000, "acquired": found,
-                             "all_scene_prns_found": sorted(s.prn for s in sats) == found}
-
-    # ---- CPU baseline: the oracle's C restatement of tracking.m, closed loop, 1 core ------------
+    result, main_ctx = run_l1ca(P, W, args, R, device)
+    result["acquisition"] = run_acquisition(P, main_ctx["eng"], main_ctx["sats"])
+    extra_jobs = {}
+    if config == "all" and world == 1:
+        cfgs = {}
+        # configs[2]: Galileo E1-C CBOC(6,1,1/11) x 8 (the replica as BASELINE words it; the reference's package tracks BOC(1,1))
+        cfgs["galileo_e1c_cboc_x8"], extra_jobs["cboc"] = run_band_jobs(P, W, "config 3", device, [("GAL_E1C_CBOC", 8)], args.cfg_seconds / 3, 18e6, 20e3, 3003,
+                                                                          args.steps, args.warmup)
+        # configs[3]: GPS L5 + BDS B2a, pilot + data arms, 16 channels, 50 Msps - two packages on ONE record
+        cfgs["l5_b2a_x16_50msps_int8"], extra_jobs["l5b2a"] = run_band_jobs(P, W, "config 4", device, [("GPS_L5C", 8), ("BDS_B2a", 8)], args.cfg_seconds, 50e6, 20e3,
+                                                                             4004, args.steps, args.warmup)
+        if not args.no_int16:
+            cfgs["l5_b2a_x16_50msps_int16"], extra_jobs["l5b2a_int16"] = run_band_jobs(P, W, "config 4 (int16 record)", device, [("GPS_L5C", 8), ("BDS_B2a", 8)],
+                                                                                       args.cfg_seconds, 50e6, 20e3, 4004, max(2, args.steps // 4), 1, dtype=np.int16)
+        # configs[4], one GPU's share: 8 channels of three packages on the L1-band record
+        cfgs["mix_share_l1_band_x8"], extra_jobs["mix"] = run_band_jobs(P, W, "config 5 (one GPU's share)", device, [("GPS_L1CA", 3), ("GAL_E1C", 3), ("BDS_B1C_NB", 2)],
+                                                                         args.mix_seconds, 18e6, 20e3, 5005, args.steps, args.warmup)
+        result["configs"] = cfgs
     if rank == 0 and world == 1 and not args.no_cpu:
-        from types import SimpleNamespace
-
-        from oracle import c_oracle as CO
-        CO.build(force=True)
-        cpu_epochs = min(args.cpu_epochs, n_epochs)
-        n_cpu = int((cpu_epochs + 3) * 1e-3 * fs)
-        iq = eng.read_if(0, min(n_cpu, n_samples))
-        Sc = P.initSettings()
-        Sc.msToProcess = cpu_epochs
-        ch = [SimpleNamespace(PRN=i.prn, acquiredFreq=i.acquired_freq, codePhase=i.code_phase, status="T") for i in inits]
-        t0 = time.perf_counter()
-        ref, cdone, aborted = CO.track_l1ca(iq, ch, Sc)
-        t_cpu = time.perf_counter() - t0
-        cpu_samples = float(np.sum(np.ceil((Sc.codeLength - ref["remCodePhase"]) / (ref["codeFreq"] / fs))))
-        cpu_msps = cpu_samples / t_cpu / 1e6
-        # Parity at identical descriptors: the CPU loop's own recorded per-epoch state (tracking.m:212-216,249,277,314,332)
-        # replayed through the GPU correlator, all 12 x cpu_epochs blocks, against the CPU loop's sums.  (The two CLOSED
-        # loops cannot be compared sample for sample for long: float32 partial sums make their NCO states differ by ~1e-8
-        # chip after a few thousand epochs, enough to put a sample that sits on a chip edge on the other side, and
-        # eventually to tip ceil((L - rem)/step) at a knife edge - DESIGN.md 4.3b; the first such epoch is reported.)
-        cb = eng.make_blocks(nch * cpu_epochs)
-        cv = np.frombuffer(cb, dtype=dt)
-        for k in range(nch):
-            sl = slice(k, nch * cpu_epochs, nch)
-            cv["channel"][sl] = k
-            cv["blksize"][sl] = np.ceil((Sc.codeLength - ref["remCodePhase"][k]) / (ref["codeFreq"][k] / fs)).astype(np.int64)
-            cv["first_sample"][sl] = ref["absoluteSample"][k].astype(np.int64)
-            cv["rem_code_phase"][sl] = ref["remCodePhase"][k]
-            cv["code_phase_step"][sl] = ref["codeFreq"][k] / fs
-            cv["el_spacing"][sl] = Sc.dllCorrelatorSpacing
-            cv["carr_freq"][sl] = ref["carrFreq"][k]
-            cv["rem_carr_phase"][sl] = ref["remCarrPhase"][k]
-        got = eng.correlate(cb)[:, 0, :]
-        want = np.stack([ref[f].T.reshape(-1) for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")], axis=1)
-        dev = float(np.max(np.abs(got - want))) / scale
-        same = ref["absoluteSample"] == fields["absoluteSample"][:, :cpu_epochs]
-        n_same = [int(np.argmin(r)) if not r.all() else cpu_epochs for r in same]
-        result["cpu_baseline"] = {
-            "value": round(cpu_msps, 2), "unit": "Msamples/s (channel-samples)", "cores": 1, "kind": "port",
-            "sample": f"oracle/gnss_oracle.c (float64 restatement of tracking.m:133-368, gcc -O3), closed loop, "
-                      f"{nch} channels x {cpu_epochs} epochs of the same record ({t_cpu:.1f} s of CPU)",
-            "x_realtime": round(cpu_msps / nch / (fs / 1e6), 4),
-            "gpu_replay_of_cpu_state_max_dev": dev,
-            "closed_loops_cut_the_same_blocks_for_epochs": int(min(n_same)),
-        }
+        base, spots = cpu_leg(P, W, args, main_ctx, extra_jobs)
+        result["cpu_baseline"] = base
+        if spots:
+            result["oracle_spot_checks_max_dev_rel_sum_abs_x"] = spots
     if rank == 0:
         print(json.dumps(result), flush=True)
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    main_ctx["eng"].close()
+    R.close()
 
 
 if __name__ == "__main__":

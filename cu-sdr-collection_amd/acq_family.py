@@ -96,7 +96,7 @@ def acquisition_E5a(engine, settings, first_sample: int | None = None):
     return _family_a(engine, settings, first_sample,
                      lambda prn: [codes.generateE5aIcode(prn, 1), codes.generateE5aQcode(prn, 1)],
                      lambda prn: [codes.generateE5aQcode(prn, 1)], 100, 5.0,
-                     lambda prn, s: _circular_code_search(s[0], codes.generateE5aQ_secondary(prn).astype(np.float64)), n_results=36)
+                     lambda prn, s: _circular_code_search(s[0], codes.generateE5aQ_secondary(prn).astype(np.float64)), n_results=50)   # acquisition.m:139 zeros(1, 50)
 
 
 def acquisition_B2a(engine, settings, first_sample: int | None = None):
@@ -106,13 +106,14 @@ def acquisition_B2a(engine, settings, first_sample: int | None = None):
     return _family_a(engine, settings, first_sample,
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)],
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)], ncodes, 25.0,
-                     lambda prn, s: float(np.sum(np.abs(s[0])) + np.sum(np.abs(s[1]))), n_results=63)
+                     lambda prn, s: float(np.sum(np.abs(s[0])) + np.sum(np.abs(s[1]))),
+                     n_results=int(max(settings.acqSatelliteList)))   # BDS/B2a acquisition.m:139 zeros(1, max(acqSatelliteList))
 
 
 def acquisition_E5b(engine, settings, first_sample: int | None = None):
     """GAL/GAL_E5b/include/acquisition.m: E5b-I + E5b-Q coarse search in 60-Hz bins and no fine stage (:227)."""
     return _family_a(engine, settings, first_sample,
-                     lambda prn: [codes.generateE5bIcode(prn, 1), codes.generateE5bQcode(prn, 1)], None, 0, 0.0, None, n_results=36)
+                     lambda prn: [codes.generateE5bIcode(prn, 1), codes.generateE5bQcode(prn, 1)], None, 0, 0.0, None, n_results=50)   # acquisition.m:138 zeros(1, 50)
 
 
 def _b3i_combine(prn, s):
@@ -187,7 +188,8 @@ def glonass_sampled_code(samp_freq: float, num_samples: int) -> np.ndarray:
 def acquisition_GLO(engine, settings, first_sample: int | None = None):
     """GLO/GLO_GL1/include/acquisition.m:120-200: for every frequency number K the L1CA scheme around
     IF - freqSpacing*K with the common 511-chip code; fine stage over 40 codes in 25-Hz bins against the 10-ms meander:
-    |sum(10 codes) - sum(next 10)| at 20 alignments.  Results are indexed K + 8."""
+    |sum(10 codes) - sum(next 10)| at 20 alignments.  Results are stored at the 1-based index K + 8 of 21-entry arrays (acquisition.m:138-142,200;
+    preRun.m:66 reads them back as K = index - 8): element K + 7 here."""
     from .receiver import _acq_params
     if first_sample is None:
         first_sample = skip_samples(settings)
@@ -202,7 +204,7 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None):
         p = _acq_params(settings, first_sample)
         p.intermediate_freq = settings.IF - settings.freqSpacing * K               # :146-147
         r = engine.acquire_coarse(p, table)[0]
-        acq.peakMetric[K + 8] = r.peak_metric
+        acq.peakMetric[K + 7] = r.peak_metric
         if r.peak_metric > settings.acqThreshold:
             # the 40-code replica is an arbitrary sampled sequence here, so the per-code sums are formed on the host from
             # the device record (40 x 12 000 samples x 21 bins)
@@ -213,6 +215,6 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None):
                 freqs[k] = r.coarse_freq + settings.acqSearchStep / 2 - 25 * k
                 per_code = (x * np.exp(-1j * freqs[k] * phase)).reshape(40, spc).sum(axis=1)
                 fine[k] = max(abs(np.sum(per_code[c:c + 10]) - np.sum(per_code[c + 10:c + 20])) for c in range(20))   # :180-185
-            acq.carrFreq[K + 8] = float(freqs[int(np.argmax(fine))])
-            acq.codePhase[K + 8] = r.code_phase
+            acq.carrFreq[K + 7] = float(freqs[int(np.argmax(fine))])
+            acq.codePhase[K + 7] = r.code_phase
     return acq

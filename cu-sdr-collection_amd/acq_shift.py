@@ -130,7 +130,7 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
     p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=init_freq, carrier_step=-(freq_res / nshifts), first_sample=first_sample,
                               n=spb, n_signals=1, n_carriers=nshifts, n_bins=nbins, n_arms_max=1)
     engine.acq_shift_prepare(p)
-    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(32))
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(0))
     tc = 1.0 / (settings.codeFreqBasis * 2)
     for prn in settings.acqSatelliteList:
         cm = codes.generateCMcode(prn, int(settings.codeLength))
@@ -169,6 +169,8 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
                 power = np.empty(75)
                 for ind in range(75):
                     power[ind] = abs(np.sum(sig * cl[idx - 1 + int(settings.codeLength) * 2 * ind] * carr))
+                if acq.CLCodePhase.shape[0] < prn:       # the field is created by this assignment and grows with it (GPS_L2C acquisition.m:165):
+                    acq.CLCodePhase = np.concatenate([acq.CLCodePhase, np.zeros(prn - acq.CLCodePhase.shape[0])])   # numel = highest PRN found
                 acq.CLCodePhase[prn - 1] = int(np.argmax(power)) + 1
     return acq
 

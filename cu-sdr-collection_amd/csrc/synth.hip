@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void synth_kernel(int8_t* __restrict__ out, co
 struct Params2 {
   gs_sat2 sat[kMaxSats];
   int nsat;
-  int out_i16;
+  int out_i16;   // bit 0: int16 output; bit 1: Q,I sample order (GLONASS front ends, GLO_GL1/include/tracking.m:227)
   double fs, sigma;
   uint64_t seed, nsamples;
 };
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void synth2_kernel(void* __restrict__ out, con
       }
     }
   }
-  const float lim = p.out_i16 ? 32767.f : 127.f;
+  const bool i16 = (p.out_i16 & 1) != 0, qi = (p.out_i16 & 2) != 0;
+  const float lim = i16 ? 32767.f : 127.f;
   short v16[16];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(256) void synth2_kernel(void* __restrict__ out, con
     float sn, cs;
     sincospif(2.0f * u2, &sn, &cs);
     float vi = rintf(accI[j] + r * cs), vq = rintf(accQ[j] + r * sn);
-    v16[2 * j] = (short)fminf(fmaxf(vi, -lim), lim);
-    v16[2 * j + 1] = (short)fminf(fmaxf(vq, -lim), lim);
+    v16[2 * j + (qi ? 1 : 0)] = (short)fminf(fmaxf(vi, -lim), lim);
+    v16[2 * j + (qi ? 0 : 1)] = (short)fminf(fmaxf(vq, -lim), lim);
   }
   const uint64_t nvalid = (n0 + 8 <= p.nsamples) ? 8 : p.nsamples - n0;
-  if (p.out_i16) {
+  if (i16) {
     short* o = reinterpret_cast<short*>(out) + 2 * n0;
     for (uint64_t j = 0; j < 2 * nvalid; ++j) o[j] = v16[j];
   } else {

@@ -97,7 +97,7 @@ def acquisition(engine: Engine, settings, first_sample: int | None = None):
     Only the resampling-off path (initSettings.m:93 default) is implemented; the optional
     FIR/decimation front end (acquisition.m:50-111) is out of scope.
     """
-    if settings.samplingFreq > settings.resamplingThreshold and settings.resamplingflag == 1:
+    if settings.samplingFreq > settings.resamplingThreshold and getattr(settings, "resamplingflag", getattr(settings, "resamplingFlag", 0)) == 1:
         raise NotImplementedError("acquisition resampling front end (acquisition.m:50-111) is out of scope")
     if first_sample is None:
         first_sample = skip_samples(settings)
@@ -240,6 +240,11 @@ def _tracking_prepare(fid: Engine, channel, settings, signal: str, pilot_fields:
         for f in _REC_FIELDS + rec_pilot:
             setattr(tr, f, np.full(n_ep, np.inf) if f in _INF_FIELDS else np.zeros(n_ep))
         tr.CNo = SimpleNamespace(VSMValue=[], VSMIndex=[])
+        pld_n = int(getattr(settings, "CNoInterval", 0))
+        if pld_n:   # BDS/B2a tracking.m:85-92, B1C NB_tracking.m:92-98: created for every channel, zeros until a record is due
+            combined = "B2a_CNo" if signal.startswith("BDS_B2a") else "B1C_CNo"
+            for f in ("DataCNo", "DataPLD") + (("PilotCNo", "PilotPLD", combined) if pilot else ()):
+                setattr(tr, f, np.zeros(n_ep // pld_n))
         results.append(tr)
         sat = getattr(ch, spec.id_field, getattr(ch, "PRN", 0))
         if (ch.status != "-") if spec.id_field == "K" else (sat != 0):                # tracking.m:136 / GLO_GL1 tracking.m:138
@@ -285,11 +290,7 @@ def _tracking_finish(job, fields, done, status):
         if pld:
             # BDS/B2a/include/tracking.m:85-92,191-192,409-432 (B1C NB_tracking.m:92-98,397-418, WB_tracking.m:443-461):
             # every CNoInterval epochs, the estimate averaged 0.5/0.5 with the previous one (zeros before the first)
-            nrec = n_ep // pld
             combined = "B2a_CNo" if signal.startswith("BDS_B2a") else "B1C_CNo"
-            names = ("DataCNo", "DataPLD") + (("PilotCNo", "PilotPLD", combined) if pilot else ())
-            for f in names:
-                setattr(tr, f, np.zeros(nrec))
             prev = np.zeros(3)
             for loop in range(pld, n_done + 1, pld):
                 c, d = Calc_CNo_PLD(tr, settings, loop, straight_pilot=signal.endswith("_WB"))

@@ -65,7 +65,10 @@ def initSettings_GAL_E1C() -> SimpleNamespace:
     s.codeFreqBasis = 1.023e6        # :71
     s.samplingFreq = 18e6            # :70
     s.IF = 20e3                      # :69
-    s.acqSatelliteList = list(range(1, 51))
+    s.acqSatelliteList = list(range(1, 37))   # the package searches Galileo SVIDs 1..36 (results are sized for 50)
+    s.resamplingThreshold = 50e6
+    s.navSolPeriod = 200
+    s.elevationMask = 10
     s.acqSearchBand = 7000           # :83
     s.acqNonCohTime = 1              # :85
     s.acqSearchStep = 150            # :87
@@ -101,6 +104,7 @@ def initSettings_GPS_L5C() -> SimpleNamespace:
     s.pilotTRKflag = 0               # :99
     s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=400)  # :128-130
     s.carrFreqBasis = 1176.45e6      # :132
+    s.resamplingThreshold = 50e6
     return s
 
 
@@ -124,6 +128,8 @@ def initSettings_GLO_GL1() -> SimpleNamespace:
     s.pllNoiseBandwidth = 25         # :112
     s.intTime = 0.001                # :114
     s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=40)  # :144-146
+    s.resamplingThreshold = 18e6
+    s.startOffset = 65.0
     return s
 
 
@@ -153,6 +159,12 @@ def initSettings_BDS_B1I() -> SimpleNamespace:
     s.pllNoiseBandwidth = 35         # :105
     s.intTime = 0.001                # :107
     s.CNo = SimpleNamespace(accTime=0.001, VSMinterval=400)  # :141-143
+    s.resamplingThreshold = 9e6
+    s.elevationMask = 10
+    s.startOffset = 120.0
+    s.saveResults = 0
+    s.skipNumberOfSamples = 0        # declared next to skipNumberOfBytes; tracking.m and postProcessing.m read ...Bytes
+    del s.acqNonCohTime, s.acqSearchStep     # this package's circshift search has neither (acqSearchBand is in kHz, stepSize in Hz)
     return s
 
 
@@ -167,8 +179,11 @@ def _ten23(s, **kw):
     s.dllCorrelatorSpacing = 0.5
     s.pllDampingRatio = 0.7
     s.intTime = 0.001
+    drop = kw.pop("_drop", ())
     for k, v in kw.items():
         setattr(s, k, v)
+    for k in drop:
+        delattr(s, k)
     return s
 
 
@@ -177,7 +192,7 @@ def initSettings_BDS_B2a() -> SimpleNamespace:
     return _ten23(initSettings(), numberOfChannels=12, acqSatelliteList=list(range(19, 31)) + list(range(32, 47)) + [59, 60],  # :45,73
                   acqNonCohTime=15, acqThreshold=5, acqSearchStep=500,          # :78-82
                   dllNoiseBandwidth=2, pllNoiseBandwidth=15, pilotTRKflag=0,    # :90,94,98
-                  CNoInterval=200, carrFreqBasis=1176.45e6)  # :125 (B2a estimates C/N0 with Calc_CNo_PLD), :127
+                  CNoInterval=200, carrFreqBasis=1176.45e6, resamplingThreshold=50e6, _drop=("CNo",))  # :125 (B2a estimates C/N0 with Calc_CNo_PLD), :127
 
 
 def initSettings_BDS_B3I() -> SimpleNamespace:
@@ -185,7 +200,8 @@ def initSettings_BDS_B3I() -> SimpleNamespace:
     return _ten23(initSettings(), numberOfChannels=15, acqSatelliteList=list(range(1, 64)),      # :45,76
                   acqNonCohTime=10, acqThreshold=3, acqSearchStep=500,          # :80-84
                   dllNoiseBandwidth=2, pllNoiseBandwidth=15,                    # :92,96
-                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=40), carrFreqBasis=1268.520e6)  # :127-132
+                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=40), carrFreqBasis=1268.520e6,  # :127-132
+                  resamplingThreshold=45e6, startOffset=94.0, resamplingFlag=0, _drop=("resamplingflag",))   # this package spells it resamplingFlag
 
 
 def initSettings_GAL_E5a() -> SimpleNamespace:
@@ -193,7 +209,7 @@ def initSettings_GAL_E5a() -> SimpleNamespace:
     return _ten23(initSettings(), numberOfChannels=12, acqSatelliteList=list(range(1, 37)),      # :9,44
                   acqNonCohTime=15, acqThreshold=4.5, acqSearchStep=500,        # :49-53
                   dllNoiseBandwidth=1.5, pllNoiseBandwidth=15, pilotTRKflag=1,  # :61,66,70
-                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=100), carrFreqBasis=1176.45e6)  # :100-104
+                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=100), carrFreqBasis=1176.45e6, resamplingThreshold=45e6)  # :100-104
 
 
 def initSettings_GAL_E5b() -> SimpleNamespace:
@@ -201,7 +217,7 @@ def initSettings_GAL_E5b() -> SimpleNamespace:
     return _ten23(initSettings(), numberOfChannels=12, acqSatelliteList=list(range(1, 37)),      # :47,83
                   acqNonCohTime=15, acqThreshold=4.5, acqSearchStep=60,         # :88-92
                   dllNoiseBandwidth=1.5, pllNoiseBandwidth=25, pilotTRKflag=1,  # :104,108,112
-                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=100), carrFreqBasis=1207.14e6)  # :140-144
+                  CNo=SimpleNamespace(accTime=0.001, VSMinterval=100), carrFreqBasis=1207.14e6, resamplingThreshold=45e6)  # :140-144
 
 
 def initSettings_BDS_B1C() -> SimpleNamespace:
@@ -230,6 +246,9 @@ def initSettings_BDS_B1C() -> SimpleNamespace:
     s.CNoInterval = 50               # :143
     if hasattr(s, "CNo"):
         del s.CNo                    # B1C estimates C/N0 with Calc_CNo_PLD (not on the hot path)
+    s.resamplingThreshold = 15e6
+    s.navSolPeriod = 200
+    del s.acqNonCohTime, s.acqSearchStep     # circshift search: acqCohT / acqStep instead
     return s
 
 
@@ -255,5 +274,6 @@ def initSettings_GPS_L2C() -> SimpleNamespace:
     s.intTime = 0.02                 # :109
     s.pilotTRKflag = 0               # :111
     s.CNo = SimpleNamespace(accTime=0.02, VSMinterval=40)  # :141-143
-    s.carrFreqBasis = 1227.60e6
+    s.resamplingThreshold = 6e6
+    del s.acqNonCohTime, s.acqSearchStep     # circshift search: acqCohT / acqStep instead
     return s

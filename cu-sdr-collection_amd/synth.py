@@ -181,7 +181,7 @@ def generate_if_gpu(engine, sats, n_samples: int, fs: float, intermediate_freq: 
 
 
 def generate_if_mix_gpu(engine, groups, n_samples: int, fs: float, intermediate_freq: float, seed: int, sigma: float = 20.0,
-                        dtype=np.int8) -> None:
+                        dtype=np.int8, qi_order: bool = False) -> None:
     """generate_if_mix on the GPU (libgnsssynth.so gs_generate2): allocates the engine's IF buffer (int8 or int16 I/Q)
     and fills it in HBM.  Same signal model; data bits and noise come from a counter-based hash instead of NumPy's
     generator, so the two generators agree in distribution, not sample for sample."""
@@ -200,7 +200,8 @@ def generate_if_mix_gpu(engine, groups, n_samples: int, fs: float, intermediate_
     lib.gs_generate2.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,
                                  C.c_double, C.c_uint64, C.c_int]
     i16 = np.dtype(dtype) == np.int16
-    engine.alloc_if(n_samples, np.int16 if i16 else np.int8)
+    from . import _lib as L
+    engine.alloc_if(n_samples, np.int16 if i16 else np.int8, layout=L.GC_QI if qi_order else L.GC_IQ)
     engine.synchronize()
     ptr, _ = engine.if_buffer()
     flat, sats = [], []
@@ -225,6 +226,6 @@ def generate_if_mix_gpu(engine, groups, n_samples: int, fs: float, intermediate_
     codes = np.ascontiguousarray(np.concatenate(flat))
     arr = (gs_sat2 * len(sats))(*sats)
     rc = lib.gs_generate2(C.c_void_p(ptr), n_samples, engine.device_id, fs, codes.ctypes.data_as(C.c_void_p), codes.shape[0],
-                          arr, len(sats), sigma, seed, int(i16))
+                          arr, len(sats), sigma, seed, int(i16) | (2 if qi_order else 0))
     if rc != 0:
         raise RuntimeError(f"gs_generate2 failed with {rc}")

@@ -1121,7 +1121,7 @@ def acquisition_l2c(if_bytes: np.ndarray, settings, first_sample: int = 0):
     nbins = int(matlab_round(settings.acqSearchBand * 1e3 / freq_res)) + 1
     nshifts = int(freq_res / settings.acqStep)
     init_freq = settings.IF + (settings.acqSearchBand / 2) * 1000
-    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(32))
+    acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(0))
     tc = 1.0 / (settings.codeFreqBasis * 2)
     spectra = [np.fft.fft(np.exp(-1j * (init_freq - it * (freq_res / nshifts)) * phase_points) * signal) for it in range(nshifts)]
     for prn in settings.acqSatelliteList:
@@ -1156,6 +1156,8 @@ def acquisition_l2c(if_bytes: np.ndarray, settings, first_sample: int = 0):
                 cidx[0] = 1
                 cidx[-1] = int(settings.codeLength) * (1 if settings.acqCohT <= 10 else 2)
                 power = [abs(np.sum(s0 * cl[cidx - 1 + int(settings.codeLength) * 2 * ind] * carr)) for ind in range(75)]
+                if acq.CLCodePhase.shape[0] < prn:       # the field is created by this assignment and grows with it (GPS_L2C acquisition.m:165):
+                    acq.CLCodePhase = np.concatenate([acq.CLCodePhase, np.zeros(prn - acq.CLCodePhase.shape[0])])   # numel = highest PRN found
                 acq.CLCodePhase[prn - 1] = int(np.argmax(power)) + 1
     return acq
 
@@ -1316,8 +1318,8 @@ def acquisition_glo(if_bytes: np.ndarray, settings, first_sample: int = 0):
         coarse_bin = int(np.argmax(results.max(axis=1))) + 1
         colmax = results.max(axis=0)
         code_phase = int(np.argmax(colmax)) + 1
-        acq.peakMetric[K + 8] = float(colmax.max()) / sig_power / settings.acqNonCohTime
-        if acq.peakMetric[K + 8] > settings.acqThreshold:
+        acq.peakMetric[K + 7] = float(colmax.max()) / sig_power / settings.acqNonCohTime
+        if acq.peakMetric[K + 7] > settings.acqThreshold:
             coarse_freq = s2.IF + settings.acqSearchBand - settings.acqSearchStep * (coarse_bin - 1)
             x = long_signal[code_phase - 1:code_phase - 1 + 40 * spc] * code40
             fine, freqs = np.empty(nfine), np.empty(nfine)
@@ -1325,8 +1327,8 @@ def acquisition_glo(if_bytes: np.ndarray, settings, first_sample: int = 0):
                 freqs[k] = coarse_freq + settings.acqSearchStep / 2 - 25 * k
                 per_code = (x * np.exp(-1j * freqs[k] * fine_phase)).reshape(40, spc).sum(axis=1)
                 fine[k] = max(abs(np.sum(per_code[c:c + 10]) - np.sum(per_code[c + 10:c + 20])) for c in range(20))
-            acq.carrFreq[K + 8] = float(freqs[int(np.argmax(fine))])
-            acq.codePhase[K + 8] = code_phase
+            acq.carrFreq[K + 7] = float(freqs[int(np.argmax(fine))])
+            acq.codePhase[K + 7] = code_phase
     return acq
 
 

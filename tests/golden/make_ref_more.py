@@ -1,17 +1,190 @@
-"""Second half of make_ref_vectors.py: acquisition, code generators, settings, preRun (filled in below)."""
+"""Second half of make_ref_vectors.py: acquisition, code generators, settings, preRun through the reference's own .m files."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+import cu_sdr_collection_amd as P
+import ref_scenes as RS
+from oracle import mlab
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("GC_REFERENCE_ROOT", "/root/reference")
+
+PACKAGES = {   # package directory -> mirror in cu_sdr_collection_amd.settings
+    "GPS/GPS_L1CA": "initSettings", "GPS/GPS_L5C": "initSettings_GPS_L5C", "GPS/GPS_L2C": "initSettings_GPS_L2C",
+    "GAL/GAL_E1C": "initSettings_GAL_E1C", "GAL/GAL_E5a": "initSettings_GAL_E5a", "GAL/GAL_E5b": "initSettings_GAL_E5b",
+    "BDS/B1I": "initSettings_BDS_B1I", "BDS/B1C": "initSettings_BDS_B1C", "BDS/B2a": "initSettings_BDS_B2a", "BDS/B3I": "initSettings_BDS_B3I",
+    "GLO/GLO_GL1": "initSettings_GLO_GL1", "GLO/GLO_GL2": "initSettings_GLO_GL2",
+}
+
+
+def interpreter(pkg):
+    d = os.path.join(REF, pkg)
+    return mlab.Interpreter([os.path.join(d, "include"), os.path.join(d, "Common"), d])
+
+
+def _set(Sm, overrides):
+    for k, v in overrides.items():
+        Sm.add_field(k)
+        Sm.elems[0][k] = mlab.to_matlab(v if isinstance(v, str) else ([float(x) for x in v] if isinstance(v, (list, tuple)) else float(v)))
+    return Sm
 
 
 def gen_acq(only=None):
-    print("[acq] not implemented yet")
+    for sc in RS.ACQ_SCENES:
+        if only and only != sc.name:
+            continue
+        t0 = time.time()
+        S, rec = RS.acq_inputs(P, sc)
+        I = interpreter(sc.pkg)
+        Sm = _set(I.call("initSettings"), sc.overrides)
+        x = rec.astype(np.float64)
+        long_signal = (x[0::2] + 1j * x[1::2]).reshape(1, -1)          # postProcessing.m:92-96: data1 + 1i .* data2
+        acq = mlab.from_matlab(I.call("acquisition", long_signal, Sm))
+        out = {"record_crc32": np.array([RS.crc(rec)], dtype=np.uint32), "overrides": np.array(json.dumps(sc.overrides)), "pkg": np.array(sc.pkg),
+               "stdout": np.array("".join(I.out)[-1000:])}
+        for f in vars(acq):
+            v = getattr(acq, f)
+            if isinstance(v, (np.ndarray, float)):
+                out["f_" + f] = np.asarray(v, dtype=np.float64).reshape(-1)
+        path = os.path.join(HERE, f"ref_acq_{sc.name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"[acq] {sc.name}: {sc.pkg}/include/acquisition.m, fields {[k for k in out if k.startswith('f_')]}, {time.time() - t0:.1f} s", flush=True)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a, dtype=np.int8)).tobytes()).hexdigest()
 
 
 def gen_codes(only=None):
-    print("[codes] not implemented yet")
+    """Every code generator / sampled-table maker of the tree, all PRNs of its package's acqSatelliteList (or the
+    documented range): length, sum, first 24 chips, sha-256 of the int8 chips."""
+    out = {}
+    jobs = [
+        ("GPS/GPS_L1CA", "generateCAcode", list(range(1, 33)), lambda I, p: I.call("generateCAcode", p)),
+        ("GPS/GPS_L5C", "generateL5Icode", list(range(1, 33)), lambda I, p, S=None: I.call("generateL5Icode", p, S)),
+        ("GPS/GPS_L5C", "generateL5Qcode", list(range(1, 33)), lambda I, p, S=None: I.call("generateL5Qcode", p, S)),
+    ]
+    print("[codes] see gen_codes_all")
+    gen_codes_all(only)
+
+
+def _call_code(I, fn, prn, Sm):
+    """The generators' signatures differ (prn | prn, settings | prn, flag): try the forms the tree uses."""
+    f = I.find_function(fn)
+    n = len(f.params)
+    if n == 1:
+        return I.call(fn, float(prn))
+    return I.call(fn, float(prn), Sm)
+
+
+CODE_JOBS = [
+    # (package, function, PRNs, second argument: None = settings struct if the function takes two, else a literal)
+    ("GPS/GPS_L1CA", "generateCAcode", range(1, 33), None),
+    ("GPS/GPS_L5C", "generateL5Icode", range(1, 33), None),
+    ("GPS/GPS_L5C", "generateL5Qcode", range(1, 33), None),
+    ("GPS/GPS_L2C", "generateCMcode", range(1, 33), None),
+    ("GPS/GPS_L2C", "generateCLcode", (1, 17), None),
+    ("GAL/GAL_E1C", "generateE1Bcode", range(1, 51), None),
+    ("GAL/GAL_E1C", "generateE1Ccode", range(1, 51), None),
+    ("GAL/GAL_E5a", "generateE5aIcode", range(1, 37), 1.0),
+    ("GAL/GAL_E5a", "generateE5aQcode", range(1, 37), 1.0),
+    ("GAL/GAL_E5a", "generateE5aQ_secondary", range(1, 37), None),
+    ("GAL/GAL_E5b", "generateE5bIcode", range(1, 37), 1.0),
+    ("GAL/GAL_E5b", "generateE5bQcode", range(1, 37), 1.0),
+    ("BDS/B1I", "generateCAcode53", range(1, 64), None),
+    ("BDS/B3I", "generateB3Icode", range(1, 64), None),
+    ("BDS/B2a", "generateB2aDataCode", range(1, 64), None),
+    ("BDS/B2a", "generateB2aPilotCode", range(1, 64), None),
+    ("BDS/B1C", "generateDataBOC11", range(1, 64), None),
+    ("BDS/B1C", "generatePilotBOC11", range(1, 64), None),
+    ("BDS/B1C", "generatePilotBOC61", (1, 30, 63), None),
+]
+
+
+def gen_codes_all(only=None):
+    out = {}
+    for pkg, fn, prns, arg2 in CODE_JOBS:
+        if only and only != fn:
+            continue
+        t0 = time.time()
+        I = interpreter(pkg)
+        Sm = I.call("initSettings")
+        f = I.find_function(fn)
+        rows = []
+        for prn in prns:
+            if len(f.params) == 1:
+                c = I.call(fn, float(prn))
+            elif arg2 is None:
+                c = I.call(fn, float(prn), Sm)
+            else:
+                c = I.call(fn, float(prn), arg2)
+            c = np.asarray(mlab.from_matlab(c)).reshape(-1)
+            if not np.all(c == np.rint(c)) or np.max(np.abs(c)) > 1:
+                raise SystemExit(f"{fn}({prn}): not a +-1 / 0 code")
+            rows.append((int(prn), int(c.shape[0]), int(np.sum(c)), _sha(c), [int(v) for v in c[:24]]))
+        out[f"{pkg}:{fn}"] = rows
+        print(f"[codes] {pkg}/include/{fn}.m: {len(rows)} PRNs, length {rows[0][1]}, {time.time() - t0:.1f} s", flush=True)
+    # GLONASS: generateCAcode(PRN, fs, n) returns the SAMPLED code (GLO_GL1/include/generateCAcode.m:93-119)
+    if not only or only == "GLO":
+        I = interpreter("GLO/GLO_GL1")
+        c = np.asarray(mlab.from_matlab(I.call("generateCAcode", 0.0, 511e3, 511.0))).reshape(-1)
+        out["GLO/GLO_GL1:generateCAcode(0,511e3,511)"] = [(0, int(c.shape[0]), int(np.sum(c)), _sha(c), [int(v) for v in c[:24]])]
+        c2 = np.asarray(mlab.from_matlab(I.call("generateCAcode", 0.0, 12e6, 24000.0))).reshape(-1)
+        out["GLO/GLO_GL1:generateCAcode(0,12e6,24000)"] = [(0, int(c2.shape[0]), int(np.sum(c2)), _sha(c2), [int(v) for v in c2[:24]])]
+    path = os.path.join(HERE, "ref_codes.json")
+    prev = json.load(open(path)) if (only and os.path.exists(path)) else {}
+    prev.update(out)
+    json.dump(prev, open(path, "w"), indent=0)
+    print(f"[codes] -> ref_codes.json ({os.path.getsize(path) // 1024} KiB)")
+
+
+def _plain(v):
+    if isinstance(v, SimpleNamespace):
+        return {k: _plain(x) for k, x in vars(v).items()}
+    if isinstance(v, np.ndarray):
+        return [float(x) for x in v.reshape(-1)]
+    if isinstance(v, (float, int, str, bool)):
+        return v
+    if isinstance(v, complex):
+        return [v.real, v.imag]
+    if isinstance(v, list):
+        return [_plain(x) for x in v]
+    return str(v)
 
 
 def gen_settings(only=None):
-    print("[settings] not implemented yet")
+    out = {}
+    for pkg in PACKAGES:
+        I = interpreter(pkg)
+        out[pkg] = _plain(mlab.from_matlab(I.call("initSettings")))
+        print(f"[settings] {pkg}/initSettings.m: {len(out[pkg])} fields", flush=True)
+    json.dump(out, open(os.path.join(HERE, "ref_settings.json"), "w"), indent=1, sort_keys=True)
 
 
 def gen_prerun(only=None):
-    print("[prerun] not implemented yet")
+    """channel = preRun(acqResults, settings) of one package per family, on a made-up acqResults with ties in peakMetric."""
+    out = {}
+    rng = np.random.default_rng(77)
+    for pkg, n, extra in (("GPS/GPS_L1CA", 32, None), ("GPS/GPS_L5C", 32, None), ("BDS/B3I", 63, None), ("GPS/GPS_L2C", 32, "CLCodePhase"),
+                          ("GLO/GLO_GL1", 14, None), ("GAL/GAL_E5a", 36, None), ("BDS/B1C", 63, None)):
+        I = interpreter(pkg)
+        Sm = _set(I.call("initSettings"), dict(numberOfChannels=12, pilotTRKflag=1))
+        metric = np.round(rng.uniform(1, 12, n), 1)
+        metric[3] = metric[9]                              # a tie: sort(..., 'descend') keeps the lower index first
+        carr = np.where(metric > 6.0, 20e3 + np.round(rng.uniform(-4e3, 4e3, n)), 0.0)
+        cp = np.where(carr != 0, np.round(rng.uniform(1, 18000, n)), 0.0)
+        acq = SimpleNamespace(carrFreq=carr, codePhase=cp, peakMetric=metric)
+        if extra:
+            setattr(acq, extra, np.where(carr != 0, np.round(rng.uniform(1, 75, n)), 0.0))
+        ch = mlab.from_matlab(I.call("preRun", mlab.to_matlab({k: v for k, v in vars(acq).items()}), Sm))
+        rec = {"acq": {k: [float(x) for x in v] for k, v in vars(acq).items()}, "channel": [_plain(c) for c in ch]}
+        out[pkg] = rec
+        print(f"[prerun] {pkg}/include/preRun.m: {sum(1 for c in ch if c.status == 'T')} channels assigned, fields {sorted(vars(ch[0]))}", flush=True)
+    json.dump(out, open(os.path.join(HERE, "ref_prerun.json"), "w"), indent=0)

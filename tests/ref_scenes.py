@@ -263,3 +263,164 @@ def scene_inputs(P, sc: TrackScene):
         setattr(S, k, v)
     rec, layout, ch = sc.build(P, S)
     return S, rec, layout, ch
+
+
+# =====================================================================================================================
+# acquisition scenes: acqResults = acquisition(longSignal, settings) of every package
+# =====================================================================================================================
+@dataclass
+class AcqScene:
+    name: str                     # fixture: tests/golden/ref_acq_<name>.npz
+    pkg: str
+    settings_fn: str
+    overrides: dict
+    build: object                 # (P, S) -> int8 I/Q record (longSignal = the whole record as data1 + 1i*data2)
+    product: object               # (P, engine, S) -> acqResults of the HIP path (record already loaded, first sample 0)
+    oracle: object = None         # (O, P, rec, S) -> acqResults of the oracle
+    fields: tuple = ("carrFreq", "codePhase", "peakMetric")
+    metric_rtol: float = 2e-3     # float32 FFTs on the GPU; the oracle must agree to 1e-9
+
+
+def _acq_family_record(data, pilot, ratio, present, seed, ms, code_len=10230, rate_mult=1.0, bit_periods=1000, pilot_phase=np.pi / 2, cn0=50.0, dmax=4e3):
+    def build(P, S):
+        fs = S.samplingFreq
+        sats = _sats(P, present, seed, fs * 1e-3, cn0, dmax)
+        dfn = getattr(P.codes, data) if isinstance(data, str) else data(P)
+        pfn = None if pilot is None else (getattr(P.codes, pilot) if isinstance(pilot, str) else pilot(P))
+        return P.synth.generate_if(sats, int(ms * 1e-3 * fs), fs, S.IF, dfn, rate_mult * S.codeFreqBasis, code_len, seed=seed + 1,
+                                   carrier_ratio=ratio, bit_periods=bit_periods, pilot_fn=pfn, pilot_phase=pilot_phase if pfn else 0.0)
+    return build
+
+
+def _acq_l1ca_record(P, S):
+    rng = np.random.default_rng(5)
+    sats = [P.synth.SatSpec(prn=p, doppler=float(rng.uniform(-5e3, 5e3)), code_phase_samples=float(rng.uniform(0, 18000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=cn0) for p, cn0 in ((7, 50.0), (14, 47.0), (22, 44.0), (31, 52.0))]
+    return P.synth.generate_if(sats, 44 * 18000, S.samplingFreq, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023, seed=12)
+
+
+def _acq_l2c_record(P, S):
+    seg = 31
+
+    def combined(prn):
+        cm, cl = P.codes.generateCMcode(prn).astype(np.float64), P.codes.generateCLcode(prn).astype(np.float64)
+        return np.roll(np.tile(cm, 75) + cl, -20460 * (seg - 1))
+    sats = [P.synth.SatSpec(prn=5, doppler=212.0, code_phase_samples=70003.4, carrier_phase=1.0, cn0_dbhz=45.0)]
+    return P.synth.generate_if(sats, int(0.25 * S.samplingFreq), S.samplingFreq, S.IF, combined, 2 * S.codeFreqBasis, 20460 * 75, seed=91,
+                               carrier_ratio=1200.0, bit_periods=1)
+
+
+def _acq_b1i_record(P, S):
+    rng = np.random.default_rng(81)
+    sats = [P.synth.SatSpec(prn=p, doppler=d, code_phase_samples=float(rng.uniform(0, 18000)), carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=c)
+            for p, d, c in ((7, 2310.0, 50.0), (23, -3890.0, 47.0), (30, 40.0, 52.0))]
+    return P.synth.generate_if(sats, int(0.012 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateCAcode53, S.codeFreqBasis, 2046, seed=82,
+                               carrier_ratio=1526.0, bit_periods=20)
+
+
+def _acq_b1c_record(P, S):
+    sats = [P.synth.SatSpec(prn=8, doppler=-430.0, code_phase_samples=123456.7, carrier_phase=2.0, cn0_dbhz=47.0)]
+    return P.synth.generate_if(sats, int(0.045 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateDataBOC11, 2 * S.codeFreqBasis, 20460, seed=93,
+                               bit_periods=1, pilot_fn=P.codes.generatePilotBOC11, pilot_phase=np.pi / 2)
+
+
+def _acq_e1_record(P, S):
+    sats = [P.synth.SatSpec(prn=4, doppler=820.0, code_phase_samples=33333.3, carrier_phase=0.5, cn0_dbhz=50.0)]
+    return P.synth.generate_if(sats, int(0.112 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateE1Bcode, 2 * S.codeFreqBasis, 8184, seed=111,
+                               bit_periods=1, pilot_fn=P.codes.generateE1Ccode)
+
+
+def _acq_glo_record(spacing_sign_ks, seed):
+    def build(P, S):
+        fs = S.samplingFreq
+        rng = np.random.default_rng(seed)
+        acc = np.zeros(2 * int(0.050 * fs))
+        for K in spacing_sign_ks:
+            s = P.synth.SatSpec(prn=1, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 12000)),
+                                carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0)
+            acc += P.synth.generate_if([s], acc.shape[0] // 2, fs, S.IF - S.freqSpacing * K, lambda prn: P.codes.generateGLOcode(), S.codeFreqBasis, 511,
+                                       seed=seed + 100 + K, carrier_ratio=3135.0, noise=False, bit_periods=10)
+        return np.clip(np.rint(acc + 20.0 * rng.standard_normal(acc.shape[0])), -127, 127).astype(np.int8)
+    return build
+
+
+_NH20 = [1, 1, 1, 1, 1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, -1, -1, -1, 1]
+
+
+def _b3i_combine(prn, per_code):
+    x = per_code[0]
+    if 1 <= prn <= 5 or 59 <= prn <= 63:
+        return max(float(np.sum(np.abs(x.reshape(10, 2).sum(axis=1)))),
+                   float(np.sum(np.abs(x[[0, 19]])) + np.sum(np.abs(x[1:19].reshape(9, 2).sum(axis=1)))))
+    sec = np.array(_NH20, dtype=np.float64)
+    best = abs(np.sum(x * sec))
+    for k in range(1, 20):
+        t = x * np.roll(sec, k)
+        best = max(best, abs(np.sum(t[:k])) + abs(np.sum(t[k:])))
+    return best
+
+
+def _fam(**kw):
+    def run(O, P, rec, S):
+        k = {a: (b(O, P) if callable(b) and a in ("coarse_codes", "fine_codes", "secondary") else b) for a, b in kw.items()}
+        return O.acquisition_family_a(rec, S, 0, **k)
+    return run
+
+
+ACQ_SCENES = [
+    AcqScene("GPS_L1CA", "GPS/GPS_L1CA", "initSettings", dict(acqNonCohTime=4, acqSatelliteList=[3, 7, 11, 14, 19, 22, 28, 31]), _acq_l1ca_record,
+             product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0),
+             oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=1e-4),
+    AcqScene("GPS_L5C", "GPS/GPS_L5C", "initSettings_GPS_L5C", dict(acqNonCohTime=4, acqSearchBand=4500, acqSatelliteList=[3, 22, 9]),
+             _acq_family_record("generateL5Icode", "generateL5Qcode", 1150.0, (3, 22), 101, 30),
+             product=lambda P, eng, S: P.acq_family.acquisition_L5(eng, S, first_sample=0),
+             oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_l5_code(prn, "I"), O.generate_l5_code(prn, "Q")]),
+                         fine_codes=lambda O, P: (lambda prn: [O.generate_l5_code(prn, "Q")]), ncodes=20, fine_step=25.0, combine="circular",
+                         secondary=lambda O, P: (lambda prn: _NH20))),
+    AcqScene("GAL_E5a", "GAL/GAL_E5a", "initSettings_GAL_E5a", dict(acqNonCohTime=3, acqSearchBand=4500, acqSatelliteList=[11, 30]),
+             _acq_family_record(lambda P: (lambda prn: P.codes.generateE5aIcode(prn, 1)), lambda P: (lambda prn: P.codes.generateE5aQcode(prn, 1)), 1150.0, (11,), 101, 110),
+             product=lambda P, eng, S: P.acq_family.acquisition_E5a(eng, S, first_sample=0),
+             oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_e5_primary("e5ai", prn), O.generate_e5_primary("e5aq", prn)]),
+                         fine_codes=lambda O, P: (lambda prn: [O.generate_e5_primary("e5aq", prn)]), ncodes=100, fine_step=5.0, combine="circular",
+                         secondary=lambda O, P: (lambda prn: O.generate_e5_secondary100("e5aq", prn)), n_results=50)),
+    AcqScene("BDS_B2a", "BDS/B2a", "initSettings_BDS_B2a", dict(acqNonCohTime=4, acqSearchBand=4500, acqSatelliteList=[21, 45, 33]),
+             _acq_family_record("generateB2aDataCode", "generateB2aPilotCode", 1150.0, (21, 45), 101, 20),
+             product=lambda P, eng, S: P.acq_family.acquisition_B2a(eng, S, first_sample=0),
+             oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_b2a_code(prn, "data"), O.generate_b2a_code(prn, "pilot")]),
+                         fine_codes=lambda O, P: (lambda prn: [O.generate_b2a_code(prn, "data"), O.generate_b2a_code(prn, "pilot")]),
+                         ncodes=10, fine_step=25.0, combine="noncoh", n_results=45)),
+    AcqScene("GAL_E5b", "GAL/GAL_E5b", "initSettings_GAL_E5b", dict(acqNonCohTime=3, acqSearchBand=4500, acqSatelliteList=[4, 19]),
+             _acq_family_record(lambda P: (lambda prn: P.codes.generateE5bIcode(prn, 1)), lambda P: (lambda prn: P.codes.generateE5bQcode(prn, 1)), 1180.0, (4,), 101, 12),
+             product=lambda P, eng, S: P.acq_family.acquisition_E5b(eng, S, first_sample=0),
+             oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_e5_primary("e5bi", prn), O.generate_e5_primary("e5bq", prn)]),
+                         fine_codes=None, ncodes=0, fine_step=0.0, combine=None, n_results=50)),
+    AcqScene("BDS_B3I", "BDS/B3I", "initSettings_BDS_B3I", dict(acqNonCohTime=3, acqSearchBand=4500, acqSatelliteList=[3, 30, 44]),
+             _acq_family_record("generateB3Icode", None, 1240.0, (3, 30), 101, 30),
+             product=lambda P, eng, S: P.acq_family.acquisition_B3I(eng, S, first_sample=0),
+             oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_b3i_code(prn)]), fine_codes=lambda O, P: (lambda prn: [O.generate_b3i_code(prn)]),
+                         ncodes=20, fine_step=25.0, combine=_b3i_combine, n_results=63, index_offset=0)),
+    AcqScene("GAL_E1C", "GAL/GAL_E1C", "initSettings_GAL_E1C", dict(acqSearchBand=1500, acqSearchStep=150, acqNonCohTime=1, acqThreshold=10, acqSatelliteList=[4, 27]),
+             _acq_e1_record, product=lambda P, eng, S: P.acq_family.acquisition_E1C(eng, S, first_sample=0),
+             oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_e1_code(prn, "B"), O.generate_e1_code(prn, "C")]),
+                         fine_codes=lambda O, P: (lambda prn: [O.generate_e1_code(prn, "C")]), ncodes=25, fine_step=10.0, combine="split",
+                         secondary=lambda O, P: (lambda prn: P.acq_family.E1C_SECONDARY), n_results=50, boc=True, index_offset=0)),
+    AcqScene("GLO_GL1", "GLO/GLO_GL1", "initSettings_GLO_GL1", dict(acqNonCohTime=4, acqSatelliteList=[-3, 0, 5]), _acq_glo_record((-3, 5), 121),
+             product=lambda P, eng, S: P.acq_family.acquisition_GLO(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_glo(rec, S, 0)),
+    AcqScene("GLO_GL2", "GLO/GLO_GL2", "initSettings_GLO_GL2", dict(acqNonCohTime=3, acqSatelliteList=[-7, 2, 6]), _acq_glo_record((-7, 6), 131),
+             product=lambda P, eng, S: P.acq_family.acquisition_GLO(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_glo(rec, S, 0)),
+    AcqScene("BDS_B1I", "BDS/B1I", "initSettings_BDS_B1I", dict(acqSatelliteList=[7, 12, 23, 30]), _acq_b1i_record,
+             product=lambda P, eng, S: P.acq_shift.acquisition_B1I(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_b1i(rec, S, 0)),
+    AcqScene("GPS_L2C", "GPS/GPS_L2C", "initSettings_GPS_L2C", dict(pilotTRKflag=1, acqSearchBand=1, acqSatelliteList=[5, 9]), _acq_l2c_record,
+             product=lambda P, eng, S: P.acq_shift.acquisition_L2C(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_l2c(rec, S, 0),
+             fields=("carrFreq", "codePhase", "peakMetric", "CLCodePhase")),
+    AcqScene("BDS_B1C", "BDS/B1C", "initSettings_BDS_B1C", dict(acqSearchBand=1000, acqSatelliteList=[8, 20]), _acq_b1c_record,
+             product=lambda P, eng, S: P.acq_shift.acquisition_B1C(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_b1c(rec, S, 0)),
+]
+
+
+def acq_inputs(P, sc: AcqScene):
+    from cu_sdr_collection_amd import settings as SET
+    S = getattr(SET, sc.settings_fn)()
+    for k, v in sc.overrides.items():
+        setattr(S, k, v)
+    return S, sc.build(P, S)

@@ -204,8 +204,9 @@ def test_l2c_circshift_acquisition_with_cl_phase(engine):
     ref = O.acquisition_l2c(iq, S, 0)
     for prn in S.acqSatelliteList:
         k = prn - 1
-        assert got.codePhase[k] == ref.codePhase[k] and got.carrFreq[k] == ref.carrFreq[k] and got.CLCodePhase[k] == ref.CLCodePhase[k], prn
+        assert got.codePhase[k] == ref.codePhase[k] and got.carrFreq[k] == ref.carrFreq[k], prn
         assert abs(got.peakMetric[k] - ref.peakMetric[k]) < 2e-3 * ref.peakMetric[k], prn
+    assert np.array_equal(got.CLCodePhase, ref.CLCodePhase) and got.CLCodePhase.shape == (5,)    # the field grows to the highest PRN found (:165)
     assert got.peakMetric[4] > S.acqThreshold and abs(got.carrFreq[4] - (S.IF + 212.0)) <= 6.25 + 1e-9
     assert abs(got.codePhase[4] - 1 - 70003.4) < 3
     assert got.CLCodePhase[4] == seg
@@ -286,7 +287,7 @@ def test_galileo_e5a_acquisition_with_secondary_code_fine_stage(engine):
                    1150.0, (11,), 30,
                    dict(coarse_codes=lambda prn: [O.generate_e5_primary("e5ai", prn), O.generate_e5_primary("e5aq", prn)],
                         fine_codes=lambda prn: [O.generate_e5_primary("e5aq", prn)], ncodes=100, fine_step=5.0, combine="circular",
-                        secondary=lambda prn: O.generate_e5_secondary100("e5aq", prn), n_results=36), 110)
+                        secondary=lambda prn: O.generate_e5_secondary100("e5aq", prn), n_results=50), 110)
 
 
 def test_beidou_b2a_acquisition_noncoherent_data_pilot_fine_stage(engine):
@@ -299,7 +300,7 @@ def test_beidou_b2a_acquisition_noncoherent_data_pilot_fine_stage(engine):
                                (21, 45), 33,
                                dict(coarse_codes=lambda prn: [O.generate_b2a_code(prn, "data"), O.generate_b2a_code(prn, "pilot")],
                                     fine_codes=lambda prn: [O.generate_b2a_code(prn, "data"), O.generate_b2a_code(prn, "pilot")],
-                                    ncodes=10, fine_step=25.0, combine="noncoh", n_results=63), 20)
+                                    ncodes=10, fine_step=25.0, combine="noncoh", n_results=45), 20)
     for s in sats:       # no overlay code in this fine stage: the 25-Hz grid must land next to the true carrier
         assert abs(got.carrFreq[s.prn - 1] - (S.IF + s.doppler)) <= 25.0
 
@@ -313,7 +314,7 @@ def test_galileo_e5b_acquisition_without_fine_stage(engine):
     got, sats = _family_a_case(engine, S, P.acq_family.acquisition_E5b, lambda prn: P.codes.generateE5bIcode(prn, 1),
                                lambda prn: P.codes.generateE5bQcode(prn, 1), 1180.0, (4,), 19,
                                dict(coarse_codes=lambda prn: [O.generate_e5_primary("e5bi", prn), O.generate_e5_primary("e5bq", prn)],
-                                    fine_codes=None, ncodes=0, fine_step=0.0, combine=None, n_results=36), 12)
+                                    fine_codes=None, ncodes=0, fine_step=0.0, combine=None, n_results=50), 12)
 
 
 def test_beidou_b3i_acquisition_geo_and_meo_fine_stages(engine):
@@ -389,9 +390,9 @@ def test_glonass_fdma_acquisition_with_meander_fine_stage(engine):
     got = P.acq_family.acquisition_GLO(engine, S, first_sample=0)
     ref = O.acquisition_glo(iq, S, 0)
     for K in S.acqSatelliteList:
-        assert got.codePhase[K + 8] == ref.codePhase[K + 8] and got.carrFreq[K + 8] == ref.carrFreq[K + 8], K
-        assert abs(got.peakMetric[K + 8] - ref.peakMetric[K + 8]) < 2e-3 * ref.peakMetric[K + 8], K
+        assert got.codePhase[K + 7] == ref.codePhase[K + 7] and got.carrFreq[K + 7] == ref.carrFreq[K + 7], K
+        assert abs(got.peakMetric[K + 7] - ref.peakMetric[K + 7]) < 2e-3 * ref.peakMetric[K + 7], K
     for K, s in sats.items():
-        assert got.peakMetric[K + 8] > S.acqThreshold
-        assert abs((got.codePhase[K + 8] - 1 - s.code_phase_samples + 6000) % 12000 - 6000) < 3
-    assert got.peakMetric[8] < 0.5 * min(got.peakMetric[5], got.peakMetric[13])   # K = 0: noise only (threshold 2.0 is tuned for 20 hops)
+        assert got.peakMetric[K + 7] > S.acqThreshold
+        assert abs((got.codePhase[K + 7] - 1 - s.code_phase_samples + 6000) % 12000 - 6000) < 3
+    assert got.peakMetric[7] < 0.5 * min(got.peakMetric[4], got.peakMetric[12])   # K = 0: noise only (threshold 2.0 is tuned for 20 hops)
