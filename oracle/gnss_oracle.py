@@ -6,12 +6,16 @@ It is the *checker* for the HIP kernels; it is never imported by the product pac
 (`cu-sdr-collection_amd/`).  Only `tests/`, `__graft_entry__.smoke()` and the
 `cpu_baseline` leg of `bench.py` may import it.
 
-PARITY STATUS: "parity unpinned by the reference" — the reference ships no tests, golden
-vectors or fixtures and neither MATLAB nor Octave exists in the build container or on the
-GPU box, so this restatement cannot be run against the reference itself.  What pins it
-instead (tests/test_oracle_*.py): public-ICD known-answer tests for the code generators,
-analytic correlator identities, a second independent restatement in C
-(`oracle/gnss_oracle.c`) that must agree to the last few ulps, and closed-loop lock tests.
+PARITY STATUS: pinned against the reference's own source text, executed - not against MATLAB itself.  The reference
+ships no tests, golden vectors or fixtures and neither MATLAB nor Octave exists in the build container or on the GPU box.
+Round 2 added oracle/mlab, a minimal interpreter for the MATLAB subset of the hot-path files; tests/golden/make_ref_vectors.py
+runs the reference's tracking.m / NB_tracking.m / WB_tracking.m / acquisition.m / preRun.m / initSettings.m / generate*.m of
+all twelve packages through it (read in place from /root/reference, build container only) and tests/test_ref_vectors.py
+holds this file to the stored results: <= 1e-12 relative on every tracking record, identical acquisition indices.  The
+interpreter's built-ins (colon, rem, var, max, sort, fft ...) are restatements of MATLAB's documented behaviour, so a
+misreading of a BUILT-IN would be common to fixtures and oracle; a misreading of the REFERENCE is caught.  Also: public-ICD
+known-answer tests for the code generators, analytic correlator identities, a second independent restatement in C
+(`oracle/gnss_oracle.c`) that must agree to the last few ulps, closed-loop lock tests (tests/test_oracle_*.py).
 
 All citations are file:line under /root/reference/.  MATLAB semantics modelled
 explicitly: colon-operator construction, `ceil` on exact integers, `rem` keeping the sign
