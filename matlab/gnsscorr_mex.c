@@ -12,7 +12,8 @@
  * Usage:  out = gnsscorr_mex(cmd, args...)
  *   h    = gnsscorr_mex('create', device_id)
  *          gnsscorr_mex('destroy', h)
- *          gnsscorr_mex('open_if_file', h, fileName, skipBytes, nSamples, dataType, fileType, samplingFreq)
+ *          gnsscorr_mex('open_if_file', h, fileName, skipBytes, nSamples, dataType, fileType, samplingFreq[, 'IQ'|'QI'])
+ *          gnsscorr_mex('share_if', hDst, hSrc)        % hDst reads hSrc's record (same GPU, no copy): one record, several packages
  *          gnsscorr_mex('load_if', h, int8_or_int16_vector, fileType, samplingFreq)
  *          gnsscorr_mex('set_channel', h, channelIdx0, {paddedCode1, ...}, indexScale)
  *   sums = gnsscorr_mex('correlate', h, blocks)      % blocks: 8 x nblocks double, see below
@@ -99,10 +100,17 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxGetString(prhs[2], path, sizeof path);
     mxGetString(prhs[5], dtype, sizeof dtype);
     int layout = (int)mxGetScalar(prhs[6]) == 1 ? GC_REAL : GC_IQ;
+    if (nrhs > 8 && layout == GC_IQ) { /* optional sample order 'IQ' | 'QI' (GLONASS front ends: GLO_GL1/include/tracking.m:227) */
+      char order[8] = "";
+      mxGetString(prhs[8], order, sizeof order);
+      if (!strcmp(order, "QI")) layout = GC_QI;
+    }
     if (gc_open_if_file(handle(prhs[1]), path, (uint64_t)mxGetScalar(prhs[3]), (uint64_t)mxGetScalar(prhs[4]),
                         !strcmp(dtype, "int16") ? GC_I16 : GC_I8, layout))
       fail("gc_open_if_file");
     if (gc_set_sampling_freq(handle(prhs[1]), mxGetScalar(prhs[7]))) fail("gc_set_sampling_freq");
+  } else if (!strcmp(cmd, "share_if")) {
+    if (gc_share_if(handle(prhs[1]), handle(prhs[2]))) fail("gc_share_if");
   } else if (!strcmp(cmd, "load_if")) {
     int dt = mxIsInt16(prhs[2]) ? GC_I16 : GC_I8;
     if (!mxIsInt8(prhs[2]) && !mxIsInt16(prhs[2])) mexErrMsgIdAndTxt("gnsscorr:type", "IF samples must be int8 or int16");
@@ -171,12 +179,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.pll_noise_bw = field(s, "pllNoiseBandwidth");
     p.pll_damping = field(s, "pllDampingRatio");
     p.pll_kind = mxGetField(s, 0, "pllKind") ? (int32_t)field(s, "pllKind") : GC_PLL_2ND_ORDER;
-    p.skip_samples = (int64_t)field(s, "skipNumberOfBytes");
-    p.n_epochs = (int32_t)field(s, "msToProcess");
+    /* skipSamples: where the record's first sample sits, in SAMPLES (tracking.m:145-153: skipNumberOfBytes for schar components,
+       skipNumberOfBytes/2 for int16 components); a plain settings struct still works for schar records */
+    p.skip_samples = (int64_t)(mxGetField(s, 0, "skipSamples") ? field(s, "skipSamples") : field(s, "skipNumberOfBytes"));
+    p.n_epochs = (int32_t)(mxGetField(s, 0, "numEpochs") ? field(s, "numEpochs") : field(s, "msToProcess"));
     /* optional (API v2): pilot handling of the multi-component packages, see gc_track_params in gnsscorr.h */
     if (mxGetField(s, 0, "pilotCombine")) p.pilot_combine = (int32_t)field(s, "pilotCombine");
     if (mxGetField(s, 0, "pf1")) { p.pf1 = field(s, "pf1"); p.pf2 = field(s, "pf2"); p.pf3 = field(s, "pf3"); }
-    if (mxGetField(s, 0, "numEpochs")) p.n_epochs = (int32_t)field(s, "numEpochs"); /* NumToProcess of the 4/10/20-ms packages */
     if (mxGetField(s, 0, "pllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "pllWeight")); p.pll_weight[0] = w[0]; p.pll_weight[1] = w[1]; }
     if (mxGetField(s, 0, "dllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "dllWeight")); p.dll_weight[0] = w[0]; p.dll_weight[1] = w[1]; }
     if (mxGetField(s, 0, "dllScale")) p.dll_scale = field(s, "dllScale");
@@ -194,8 +203,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       init[i].code_phase = (int64_t)c[crow * i + 4];
       if (crow >= 6) init[i].table_phase = (int32_t)c[crow * i + 5];
     }
-    const mwSize dims[3] = {(mwSize)p.n_epochs, GC_TRK_NFIELDS, (mwSize)nch};
-    plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); /* trk(epoch, field, channel) */
+    /* trk(epoch, (channel-1)*GC_TRK_NFIELDS + field): one column per (channel, field), fields in gc_track_field order */
+    plhs[0] = mxCreateDoubleMatrix((mwSize)p.n_epochs, (mwSize)GC_TRK_NFIELDS * (mwSize)nch, mxREAL);
     int32_t* done = (int32_t*)mxCalloc((size_t)nch, sizeof *done);
     /* track_device: the same loop closed on the GPU in one persistent launch (gc_track_device); GC_E_UNSUPPORTED for the
        configurations it does not cover - the caller then falls back to 'track' */

@@ -1,0 +1,173 @@
+function [trackResults, channel] = gnsscorr_tracking(fid, channel, settings, name)
+%GNSSCORR_TRACKING  [trackResults, channel] = tracking(fid, channel, settings) of package NAME with the correlator on an MI355X.
+%   Same arguments and results as the package's include/tracking.m (NB_tracking.m / WB_tracking.m for BDS B1C), so that
+%   postProcessing.m:124 is called unchanged: fid is the open IF file (fopen(fid) names it; it is uploaded to HBM once and kept
+%   for later calls), channel comes from preRun.m, settings from initSettings.m.  The per-epoch loop of tracking.m:133-368 -
+%   block sizing, replica ramps, carrier wipe-off, six (12, 18) sums, discriminators, loop filters - runs inside libgnsscorr
+%   (gc_track: correlator kernels on the GPU, tracking.m:302-335 in C++ on the host, as BASELINE.json's north_star wants);
+%   this file builds the package's code tables with the package's own generators, fills trackResults exactly as the
+%   package creates it, and runs the package's own C/N0 estimator over the recorded prompt sums.
+%   Written for this repository; not a copy of any reference file.
+
+pkg = gnsscorr_package(name, settings);
+n = pkg.numEpochs;
+nCh = settings.numberOfChannels;
+
+%--- result structure as the package's tracking.m creates it (tracking.m:47-86) ---------------------------------------
+trackResults.status         = '-';
+trackResults.absoluteSample = zeros(1, n);
+trackResults.codeFreq       = inf(1, n);
+trackResults.carrFreq       = inf(1, n);
+trackResults.I_P = zeros(1, n);  trackResults.I_E = zeros(1, n);  trackResults.I_L = zeros(1, n);
+trackResults.Q_E = zeros(1, n);  trackResults.Q_P = zeros(1, n);  trackResults.Q_L = zeros(1, n);
+pilotNames = {};
+if pkg.pilotOn && strcmp(pkg.pilotFields, 'prompt'), pilotNames = {'Pilot_I_P', 'Pilot_Q_P'}; end
+if pkg.pilotOn && strcmp(pkg.pilotFields, 'all')
+    pilotNames = {'Pilot_I_P', 'Pilot_I_E', 'Pilot_I_L', 'Pilot_Q_E', 'Pilot_Q_P', 'Pilot_Q_L'};
+end
+for k = 1:numel(pilotNames), trackResults.(pilotNames{k}) = zeros(1, n); end
+trackResults.dllDiscr       = inf(1, n);
+trackResults.dllDiscrFilt   = inf(1, n);
+trackResults.pllDiscr       = inf(1, n);
+trackResults.pllDiscrFilt   = inf(1, n);
+trackResults.remCodePhase   = inf(1, n);
+trackResults.remCarrPhase   = inf(1, n);
+if strcmp(pkg.cno, 'VSM')
+    trackResults.CNo.VSMValue = zeros(1, floor(n / settings.CNo.VSMinterval));
+    trackResults.CNo.VSMIndex = zeros(1, floor(n / settings.CNo.VSMinterval));
+else
+    nRec = floor(n / settings.CNoInterval);
+    trackResults.DataCNo = zeros(1, nRec);  trackResults.DataPLD = zeros(1, nRec);
+    if pkg.pilotOn
+        combined = 'B1C_CNo';
+        if strcmp(name, 'BDS_B2a'), combined = 'B2a_CNo'; end
+        trackResults.PilotCNo = zeros(1, nRec);  trackResults.PilotPLD = zeros(1, nRec);  trackResults.(combined) = zeros(1, nRec);
+    end
+end
+trackResults = repmat(trackResults, 1, nCh);
+
+%--- which channels run (tracking.m:136; GLO_GL1 tracking.m:138) ---------------------------------------------------------
+active = [];
+for c = 1:nCh
+    if pkg.byStatus
+        on = channel(c).status ~= '-';
+    else
+        on = channel(c).(pkg.idField) ~= 0;
+    end
+    if on, active(end+1) = c; end %#ok<AGROW>
+end
+if isempty(active), return; end
+
+%--- the record: uploaded once per file, from byte 0, so that absoluteSample stays file-relative (ftell, tracking.m:212-216) ---
+fileName = fopen(fid);
+h = gnsscorr_context(fileName);
+if isempty(h)
+    h = gnsscorr_context(fileName, 'new');
+    order = 'IQ';
+    if pkg.qiOrder, order = 'QI'; end
+    gnsscorr_mex('open_if_file', h, fileName, 0, 0, settings.dataType, settings.fileType, settings.samplingFreq, order);
+end
+
+%--- start of the first block in samples (tracking.m:145-153) --------------------------------------------------------------
+skip = settings.(pkg.skipField);
+if strcmp(settings.dataType, 'int16')
+    if ~pkg.int16Branch
+        error('gnsscorr:int16', '%s: the package''s tracking.m has no int16 branch (its fseek assumes one byte per component)', name);
+    end
+    if rem(skip, 2) ~= 0, error('gnsscorr:int16', 'int16 record: dataAdaptCoeff*skipNumberOfBytes bytes is not a whole number of samples'); end
+    skip = skip / 2;                 % dataAdaptCoeff*(skip + (codePhase-1)*2) bytes of 2-byte components
+end
+if ~pkg.minusOne, skip = skip + 1; end
+
+%--- loop parameters (tracking.m:94-110; GPS_L5C tracking.m:106-111) ----------------------------------------------------------
+p.samplingFreq = settings.samplingFreq;
+p.codeFreqBasis = settings.codeFreqBasis;       p.codeLength = settings.codeLength;
+p.dllCorrelatorSpacing = settings.dllCorrelatorSpacing;
+if pkg.doubledCode                                 % GPS_L2C tracking.m:107-109,171: everything in units of the RZ-doubled code
+    p.codeFreqBasis = 2 * settings.codeFreqBasis;  p.codeLength = 2 * settings.codeLength;
+    p.dllCorrelatorSpacing = 2 * settings.dllCorrelatorSpacing;
+end
+p.intTime = settings.intTime;
+p.dllNoiseBandwidth = settings.dllNoiseBandwidth;  p.dllDampingRatio = settings.dllDampingRatio;
+p.pllNoiseBandwidth = settings.pllNoiseBandwidth;  p.pllDampingRatio = settings.pllDampingRatio;
+p.pllKind = pkg.pllKind;
+if pkg.pllKind == 1
+    [p.pf3, p.pf2, p.pf1] = calcLoopCoefCarr(settings);      % the package's own Common/calcLoopCoefCarr.m
+end
+p.pilotCombine = pkg.pilotMode;
+if ~isempty(pkg.pllWeight), p.pllWeight = pkg.pllWeight; end
+if ~isempty(pkg.dllWeight), p.dllWeight = pkg.dllWeight; end
+if pkg.dllScale ~= 0, p.dllScale = pkg.dllScale; end
+p.tablePhaseCount = pkg.phaseCount;
+p.skipSamples = skip;
+p.numEpochs = n;
+
+%--- code tables and the channel table (tracking.m:156-170) ----------------------------------------------------------------------
+chanTable = zeros(6, numel(active));
+for k = 1:numel(active)
+    c = active(k);
+    id = channel(c).(pkg.idField);
+    trackResults(c).PRN = id;                                   % tracking.m:138
+    tables = pkg.tables(id, settings);
+    for a = 1:numel(tables), tables{a} = int8(tables{a}); end
+    gnsscorr_mex('set_channel', h, c - 1, tables, pkg.indexScale, pkg.armMult, pkg.windows);
+    codeFreq = p.codeFreqBasis;
+    if pkg.codeFreqFromChannel, codeFreq = channel(c).codeFreq; end
+    clPhase = 0;
+    if pkg.phaseCount > 0, clPhase = channel(c).CLCodePhase; end
+    chanTable(:, k) = [c - 1; id; channel(c).acquiredFreq; codeFreq; channel(c).codePhase; clPhase];
+end
+
+%--- the loops -----------------------------------------------------------------------------------------------------------------------
+[trk, epochs, status] = gnsscorr_mex('track', h, p, chanTable);      % trk(epoch, (k-1)*21 + field), fields as gc_track_field
+
+%--- records (tracking.m:212-216,249,277,314,332,338-348) ------------------------------------------------------------------------
+names = {'absoluteSample','codeFreq','carrFreq','I_E','Q_E','I_P','Q_P','I_L','Q_L','dllDiscr','dllDiscrFilt','pllDiscr','pllDiscrFilt', ...
+         'remCodePhase','remCarrPhase','Pilot_I_E','Pilot_Q_E','Pilot_I_P','Pilot_Q_P','Pilot_I_L','Pilot_Q_L'};
+for k = 1:numel(active)
+    c = active(k);
+    m = epochs(k);
+    for f = 1:numel(names)
+        if f > 15 && ~any(strcmp(names{f}, pilotNames)), continue; end
+        trackResults(c).(names{f})(1:m) = trk(1:m, (k - 1) * numel(names) + f).';
+    end
+    if pkg.doubledCode && m > 0
+        % GPS_L2C tracking.m:223,250,376,382-383: records are in single-code units; absoluteSample is pushed back by the
+        % code-phase remainder expressed in samples
+        step = trackResults(c).codeFreq(1:m) / settings.samplingFreq;
+        trackResults(c).absoluteSample(1:m) = trackResults(c).absoluteSample(1:m) + 1 - trackResults(c).remCodePhase(1:m) ./ step;
+        trackResults(c).remCodePhase(1:m) = trackResults(c).remCodePhase(1:m) / 2;
+        trackResults(c).codeFreq(1:m)     = trackResults(c).codeFreq(1:m) / 2;
+        trackResults(c).dllDiscr(1:m)     = trackResults(c).dllDiscr(1:m) / 2;
+        trackResults(c).dllDiscrFilt(1:m) = trackResults(c).dllDiscrFilt(1:m) / 2;
+    end
+    if strcmp(pkg.cno, 'VSM')                                    % tracking.m:351-358 with the package's own CNoVSM.m
+        vsm = settings.CNo.VSMinterval;
+        cnt = 0;
+        for e = vsm:vsm:m
+            cnt = cnt + 1;
+            trackResults(c).CNo.VSMValue(cnt) = CNoVSM(trackResults(c).I_P(e-vsm+1:e), trackResults(c).Q_P(e-vsm+1:e), settings.CNo.accTime);
+            trackResults(c).CNo.VSMIndex(cnt) = e;
+        end
+    else                                                         % BDS/B2a tracking.m:409-432 with the package's own Calc_CNo_PLD.m
+        iv = settings.CNoInterval;
+        prev = zeros(1, 3);
+        for e = iv:iv:m
+            [cnoValue, pld] = Calc_CNo_PLD(trackResults(c), settings, e);
+            cnt = e / iv;
+            trackResults(c).DataCNo(cnt) = cnoValue(1) * 0.5 + prev(1) * 0.5;
+            trackResults(c).DataPLD(cnt) = pld(1);
+            if pkg.pilotOn
+                trackResults(c).PilotCNo(cnt) = cnoValue(2) * 0.5 + prev(2) * 0.5;
+                trackResults(c).(combined)(cnt) = cnoValue(3) * 0.5 + prev(3) * 0.5;
+                trackResults(c).PilotPLD(cnt) = pld(2);
+            end
+            prev = cnoValue;
+        end
+    end
+    if m == n, trackResults(c).status = channel(c).status; end   % tracking.m:365
+end
+if status == -2                                                 % GC_E_RANGE: the reference's short read (tracking.m:241-245)
+    disp('Not able to read the specified number of samples  for tracking, exiting!')
+end
+end

@@ -323,8 +323,13 @@ def set_index(cur, idx, value):
         if v.size != 1 and v.size != pos.size:
             raise MError(f"In an assignment A(I) = B, the number of elements in B and I must be the same ({v.size} vs {pos.size})")
         nr = max(a.shape[0], 1)
-        vals = v.reshape(-1, order="F") if v.size != 1 else v.flat[0]
-        a[pos % nr, pos // nr] = vals          # column-major linear index -> (row, column)
+        if a.dtype == object:                  # cell storage: element-wise, the elements may be arrays themselves
+            src = v.reshape(-1, order="F")
+            for k, q in enumerate(pos):
+                a[q % nr, q // nr] = src[k if src.size != 1 else 0]
+        else:
+            vals = v.reshape(-1, order="F") if v.size != 1 else v.flat[0]
+            a[pos % nr, pos // nr] = vals      # column-major linear index -> (row, column)
     elif len(idx) == 2:
         r, _ = _to_positions(idx[0], a.shape[0])
         c, _ = _to_positions(idx[1], a.shape[1])
@@ -338,7 +343,14 @@ def set_index(cur, idx, value):
             g = np.zeros((nr, nc), dtype=dt)
             g[:a.shape[0], :a.shape[1]] = a
             a = g
-        if v.size == 1:
+        if a.dtype == object:
+            src = v.reshape(-1, order="F")
+            k = 0
+            for cc in c:
+                for rr in r:
+                    a[rr, cc] = src[k if src.size != 1 else 0]
+                    k += 1
+        elif v.size == 1:
             a[np.ix_(r, c)] = v.flat[0]
         else:
             if v.shape != (r.size, c.size):

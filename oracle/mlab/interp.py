@@ -85,6 +85,8 @@ class Interpreter:
         self.call_depth = 0
         self.stats = {"calls": {}}
         self.tic = None
+        self.extra_builtins = {}  # name -> fn(interp, args, nargout): test doubles / host bindings of one session
+        self.persist = {}         # (file, variable) -> value of `persistent` variables
 
     # ---- function lookup ------------------------------------------------------------------------
     def find_function(self, name, local_funcs=None):
@@ -130,15 +132,24 @@ class Interpreter:
         if isinstance(fn, tuple) and fn[0] == "script":
             raise MError("scripts cannot be called with arguments")
         self.stats["calls"][fn.name] = self.stats["calls"].get(fn.name, 0) + 1
-        if len(args) > len(fn.params):
-            raise MError(f"{fn.name}: too many input arguments")
         ws = {}
-        for p, a in zip(fn.params, args):
+        fixed = fn.params
+        if fn.params and fn.params[-1] == "varargin":
+            fixed = fn.params[:-1]
+            extra = list(args[len(fixed):])
+            box = np.empty((1, len(extra)), dtype=object)
+            for k, a in enumerate(extra):
+                box[0, k] = a
+            ws["varargin"] = MCell(box)
+        elif len(args) > len(fn.params):
+            raise MError(f"{fn.name}: too many input arguments")
+        for p, a in zip(fixed, args):
             if p != "~":
                 ws[p] = mcopy(a) if p in fn.mutated else a
         ws["nargin"] = M(float(len(args)))
         ws["nargout"] = M(float(nargout))
         frame = Frame(self, ws, fn.local_funcs, fn.fname)
+        frame.func_name = fn.name
         self.call_depth += 1
         if self.call_depth > 200:
             raise MError("recursion limit")
@@ -168,7 +179,8 @@ class Frame:
         self.local_funcs = local_funcs
         self.fname = fname
         self.end_stack = []     # (value being indexed, position, number of index arguments)
-        self.global_names = set()
+        self.global_names = {}  # local name -> key in Interpreter.globals (global: the name; persistent: (file, function, name))
+        self.func_name = ""
 
     # ---- statements -------------------------------------------------------------------------------
     def exec_block(self, stmts):
@@ -229,10 +241,11 @@ class Frame:
                 raise _Return()
             elif k == "global":
                 for n in s[1]:
-                    self.global_names.add(n)
-                    if n not in self.I.globals:
-                        self.I.globals[n] = empty()
-                    self.ws[n] = self.I.globals[n]
+                    key = n if s[2] == "global" else (self.fname, self.func_name, n)
+                    self.global_names[n] = key
+                    if key not in self.I.globals:
+                        self.I.globals[key] = empty()
+                    self.ws[n] = self.I.globals[key]
             elif k == "command":
                 pass
             else:
@@ -322,7 +335,7 @@ class Frame:
         new = self.assign_into(cur, accs, value)
         self.ws[name] = new
         if name in self.global_names:
-            self.I.globals[name] = new
+            self.I.globals[self.global_names[name]] = new
 
     @staticmethod
     def _field_name(v):
@@ -508,7 +521,7 @@ class Frame:
         return [B.get_index(base, idx)]
 
     def call_function(self, name, args, nargout):
-        fn = self.I.find_function(name, self.local_funcs)
+        fn = None if name in self.I.extra_builtins else self.I.find_function(name, self.local_funcs)
         if fn is not None:
             if isinstance(fn, tuple):   # a script: runs in the caller's workspace
                 try:
@@ -525,7 +538,7 @@ class Frame:
             if kind in ("", "file", "builtin") and (self.I.find_function(what, self.local_funcs) is not None or what in B.TABLE):
                 return [M(2.0)]
             return [M(0.0)]
-        bf = B.TABLE.get(name)
+        bf = self.I.extra_builtins.get(name) or B.TABLE.get(name)
         if bf is None:
             raise MError(f"Undefined function or variable '{name}'")
         r = bf(self.I, args, nargout)

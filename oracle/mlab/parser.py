@@ -204,7 +204,7 @@ class Parser:
                 while self.t.kind == "ID":
                     names.append(self.t.val)
                     self.i += 1
-                return ("global", names, line)
+                return ("global", names, kw, line)
             self.err(f"unexpected keyword {kw}")
         # command syntax: `format long`, `addpath include`, `close all`
         if t.kind == "ID" and t.val in COMMAND_WORDS:

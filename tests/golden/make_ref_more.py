@@ -63,15 +63,6 @@ def _sha(a):
 
 
 def gen_codes(only=None):
-    """Every code generator / sampled-table maker of the tree, all PRNs of its package's acqSatelliteList (or the
-    documented range): length, sum, first 24 chips, sha-256 of the int8 chips."""
-    out = {}
-    jobs = [
-        ("GPS/GPS_L1CA", "generateCAcode", list(range(1, 33)), lambda I, p: I.call("generateCAcode", p)),
-        ("GPS/GPS_L5C", "generateL5Icode", list(range(1, 33)), lambda I, p, S=None: I.call("generateL5Icode", p, S)),
-        ("GPS/GPS_L5C", "generateL5Qcode", list(range(1, 33)), lambda I, p, S=None: I.call("generateL5Qcode", p, S)),
-    ]
-    print("[codes] see gen_codes_all")
     gen_codes_all(only)
 
 
@@ -102,9 +93,9 @@ CODE_JOBS = [
     ("BDS/B3I", "generateB3Icode", range(1, 64), None),
     ("BDS/B2a", "generateB2aDataCode", range(1, 64), None),
     ("BDS/B2a", "generateB2aPilotCode", range(1, 64), None),
-    ("BDS/B1C", "generateDataBOC11", range(1, 64), None),
-    ("BDS/B1C", "generatePilotBOC11", range(1, 64), None),
-    ("BDS/B1C", "generatePilotBOC61", (1, 30, 63), None),
+    ("BDS/B1C", "generateDataBOC11", range(1, 64), "settings_first"),      # generateDataBOC11(settings, PRN)
+    ("BDS/B1C", "generatePilotBOC11", range(1, 64), "settings_first"),
+    ("BDS/B1C", "generatePilotBOC61", (1, 30, 63), "settings_first"),
 ]
 
 
@@ -119,7 +110,9 @@ def gen_codes_all(only=None):
         f = I.find_function(fn)
         rows = []
         for prn in prns:
-            if len(f.params) == 1:
+            if arg2 == "settings_first":
+                c = I.call(fn, Sm, float(prn))
+            elif len(f.params) == 1:
                 c = I.call(fn, float(prn))
             elif arg2 is None:
                 c = I.call(fn, float(prn), Sm)
@@ -130,6 +123,7 @@ def gen_codes_all(only=None):
                 raise SystemExit(f"{fn}({prn}): not a +-1 / 0 code")
             rows.append((int(prn), int(c.shape[0]), int(np.sum(c)), _sha(c), [int(v) for v in c[:24]]))
         out[f"{pkg}:{fn}"] = rows
+        _merge_codes({f"{pkg}:{fn}": rows})
         print(f"[codes] {pkg}/include/{fn}.m: {len(rows)} PRNs, length {rows[0][1]}, {time.time() - t0:.1f} s", flush=True)
     # GLONASS: generateCAcode(PRN, fs, n) returns the SAMPLED code (GLO_GL1/include/generateCAcode.m:93-119)
     if not only or only == "GLO":
@@ -138,11 +132,20 @@ def gen_codes_all(only=None):
         out["GLO/GLO_GL1:generateCAcode(0,511e3,511)"] = [(0, int(c.shape[0]), int(np.sum(c)), _sha(c), [int(v) for v in c[:24]])]
         c2 = np.asarray(mlab.from_matlab(I.call("generateCAcode", 0.0, 12e6, 24000.0))).reshape(-1)
         out["GLO/GLO_GL1:generateCAcode(0,12e6,24000)"] = [(0, int(c2.shape[0]), int(np.sum(c2)), _sha(c2), [int(v) for v in c2[:24]])]
+        _merge_codes({k: v for k, v in out.items() if k.startswith("GLO/")})
     path = os.path.join(HERE, "ref_codes.json")
-    prev = json.load(open(path)) if (only and os.path.exists(path)) else {}
-    prev.update(out)
-    json.dump(prev, open(path, "w"), indent=0)
     print(f"[codes] -> ref_codes.json ({os.path.getsize(path) // 1024} KiB)")
+
+
+def _merge_codes(new):
+    """ref_codes.json is updated after every generator (several generator processes may run side by side)."""
+    import fcntl
+    path = os.path.join(HERE, "ref_codes.json")
+    with open(path + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        prev = json.load(open(path)) if os.path.exists(path) else {}
+        prev.update(new)
+        json.dump(prev, open(path, "w"), indent=0, sort_keys=True)
 
 
 def _plain(v):

@@ -1,0 +1,104 @@
+"""Runs the repository's MATLAB wrappers (matlab/*.m) without MATLAB: the mini-MATLAB interpreter of oracle/mlab executes them,
+`gnsscorr_mex` is the REAL gateway (matlab/gnsscorr_mex.c compiled against the test-only mex.h, tests/mexstub/harness.py), and the
+functions a package keeps in MATLAB (its code generators, calcLoopCoefCarr.m, CNoVSM.m, Calc_CNo_PLD.m, CalcWeighingFactor.m) are
+played by doubles: the product's bit-level generators (pinned to the reference's generators by tests/test_ref_vectors.py) and the
+oracle's restatements of the helpers - the GPU box has no /root/reference to take the real ones from."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from oracle import gnss_oracle as O
+from oracle import mlab
+from oracle.mlab.values import M, MCell, MStr, MStruct, num
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _to_py(v):
+    """interpreter value -> what harness.Gateway.to_mx takes"""
+    if isinstance(v, MStr):
+        return v.s
+    if isinstance(v, MStruct):
+        return {k: _to_py(x) for k, x in v.elems[0].items()}
+    if isinstance(v, MCell):
+        return [_to_py(x) for x in v.a.reshape(-1, order="F")]
+    a = np.asarray(v)
+    if a.dtype == np.bool_:
+        a = a.astype(np.float64)
+    return a
+
+
+def _from_py(v):
+    if isinstance(v, str):
+        return MStr(v)
+    if isinstance(v, dict):
+        return MStruct([{k: _from_py(x) for k, x in v.items()}], list(v.keys()))
+    if v is None:
+        return np.zeros((0, 0))
+    a = np.asarray(v)
+    return M(a.astype(np.float64) if a.dtype != np.float64 else a)
+
+
+def install(I, gateway, P, signal: str):
+    """Registers gnsscorr_mex and the package doubles in interpreter I."""
+    from cu_sdr_collection_amd import receiver, signals
+    spec = signals.SIGNALS[signal]
+
+    def mex(_I, args, nargout):
+        cmd = args[0].s
+        vals = [_to_py(a) for a in args[1:]]
+        if cmd == "load_if":            # the interpreter has no integer classes: int8(...) / int16(...) keep double storage
+            x = np.asarray(vals[1])
+            vals[1] = x.astype(np.int8) if np.all(np.abs(x) <= 127) else x.astype(np.int16)
+        if cmd in ("acquire_coarse", "acquire_coarse_multi") or cmd in ("fine_sums", "acquire_fine_l1ca", "acq_shift_search"):
+            k = 2 if cmd != "acq_shift_search" else 1
+            vals[k] = np.asarray(vals[k]).astype(np.int8)
+        r = gateway.call(cmd, *vals, nargout=max(nargout, 1))
+        if nargout <= 1:
+            return _from_py(r) if nargout == 1 or r is not None else None
+        return tuple(_from_py(x) for x in r)
+
+    C = P.codes
+    st = lambda a: mlab.from_matlab(a)   # noqa: E731
+    row = lambda c: np.asarray(c, dtype=np.float64).reshape(1, -1)   # noqa: E731
+
+    def gen(fn):
+        return lambda _I, a, n: row(fn(*a))
+
+    def prn_of(a, k=0):
+        return int(num(a[k]).flat[0])
+
+    doubles = {
+        "generateCAcode": lambda _I, a, n: row(C.generateGLOcode()) if len(a) == 3 else row(C.generateCAcode(prn_of(a))),
+        "generateCAcode53": lambda _I, a, n: row(C.generateCAcode53(prn_of(a))),
+        "generateB3Icode": lambda _I, a, n: row(C.generateB3Icode(prn_of(a))),
+        "generateL5Icode": lambda _I, a, n: row(C.generateL5Icode(prn_of(a))),
+        "generateL5Qcode": lambda _I, a, n: row(C.generateL5Qcode(prn_of(a))),
+        "generateB2aDataCode": lambda _I, a, n: row(C.generateB2aDataCode(prn_of(a))),
+        "generateB2aPilotCode": lambda _I, a, n: row(C.generateB2aPilotCode(prn_of(a))),
+        "generateE5aIcode": lambda _I, a, n: row(C.generateE5aIcode(prn_of(a), prn_of(a, 1))),
+        "generateE5aQcode": lambda _I, a, n: row(C.generateE5aQcode(prn_of(a), prn_of(a, 1))),
+        "generateE5bIcode": lambda _I, a, n: row(C.generateE5bIcode(prn_of(a), prn_of(a, 1))),
+        "generateE5bQcode": lambda _I, a, n: row(C.generateE5bQcode(prn_of(a), prn_of(a, 1))),
+        "generateE1Bcode": lambda _I, a, n: row(C.generateE1Bcode(prn_of(a))),
+        "generateE1Ccode": lambda _I, a, n: row(C.generateE1Ccode(prn_of(a))),
+        "generateDataBOC11": lambda _I, a, n: row(C.generateDataBOC11(prn_of(a, 1))),
+        "generatePilotBOC11": lambda _I, a, n: row(C.generatePilotBOC11(prn_of(a, 1))),
+        "generatePilotBOC61": lambda _I, a, n: row(C.generatePilotBOC61(prn_of(a, 1))),
+        "generateCMcode": lambda _I, a, n: row(C.generateCMcode(prn_of(a))),
+        "generateCLcode": lambda _I, a, n: row(C.generateCLcode(prn_of(a))),
+        "calcLoopCoefCarr": lambda _I, a, n: tuple(O.calc_loop_coef_carr(st(a[0]), spec.coef_variant)),
+        "CNoVSM": lambda _I, a, n: O.cno_vsm(num(a[0]).reshape(-1), num(a[1]).reshape(-1), float(num(a[2]).flat[0])),
+        "CalcWeighingFactor": lambda _I, a, n: signals.CalcWeighingFactor(st(a[0])),
+        "Calc_CNo_PLD": lambda _I, a, n: tuple(np.asarray(x, dtype=np.float64).reshape(1, -1) for x in receiver.Calc_CNo_PLD(
+            st(a[0]), st(a[1]), int(num(a[2]).flat[0]), straight_pilot=signal.endswith("_WB"))),
+        "gnsscorr_mex": mex,
+    }
+    I.extra_builtins.update(doubles)
+    return I
+
+
+def interpreter_for(package_dir: str):
+    return mlab.Interpreter([os.path.join(ROOT, "matlab", "packages", package_dir), os.path.join(ROOT, "matlab")])

@@ -1,0 +1,136 @@
+"""The drop-in boundary exercised end to end on the GPU, without MATLAB:
+
+  * matlab/gnsscorr_mex.c, the MEX gateway a maintainer builds with `mex`, is compiled here against a test-only mex.h
+    (tests/mexstub) and its mexFunction is driven command by command;
+  * the MATLAB drop-ins themselves - matlab/packages/<package>/tracking.m -> matlab/gnsscorr_tracking.m, called with the
+    REFERENCE'S signature [trackResults, channel] = tracking(fid, channel, settings) - are executed by the mini-MATLAB
+    interpreter of oracle/mlab with `gnsscorr_mex` bound to that compiled gateway, and must reproduce what the reference's own
+    tracking.m computed on the same record (tests/golden/ref_track_*.npz), field for field."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import ref_scenes as RS
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mexstub"))
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gateway():
+    import harness
+    g = harness.Gateway()
+    yield g
+    g.lib.stub_run_atexit()          # mexAtExit: destroys whatever contexts are left
+
+
+def test_mex_gateway_commands(gateway, l1ca_scene):
+    import cu_sdr_collection_amd as P
+    import harness
+    from oracle import c_oracle as CO
+    S, sats, iq = l1ca_scene
+    h = gateway.call("create", 0)
+    assert gateway.lib.stub_lock_count() >= 1                            # mexLock while a context lives
+    name, cus = gateway.call("device_info", h, nargout=2)
+    assert "MI355" in name or "gfx950" in name or cus.item() >= 200
+    gateway.call("load_if", h, iq, 2, S.samplingFreq, nargout=0)
+    back = gateway.call("read_if", h, 100, 50, "int8", 2)
+    assert np.array_equal(back.reshape(-1), iq[200:300])
+    n_ep = 40
+    for k, s in enumerate(sats[:2]):
+        code = P.codes.generateCAcode(s.prn).astype(np.float64)
+        gateway.call("set_channel", h, k, [np.concatenate([code[-1:], code, code[:1]])], 1, nargout=0)      # double tables: cast in the gateway
+    params = dict(samplingFreq=S.samplingFreq, codeFreqBasis=S.codeFreqBasis, codeLength=S.codeLength, dllCorrelatorSpacing=S.dllCorrelatorSpacing,
+                  intTime=S.intTime, dllNoiseBandwidth=S.dllNoiseBandwidth, dllDampingRatio=S.dllDampingRatio, pllNoiseBandwidth=S.pllNoiseBandwidth,
+                  pllDampingRatio=S.pllDampingRatio, pllKind=0, skipSamples=0, numEpochs=n_ep)
+    chan = np.array([[k, s.prn, S.IF + s.doppler + 4.0, S.codeFreqBasis, int(np.ceil(s.code_phase_samples)) + 1, 0] for k, s in enumerate(sats[:2])], dtype=np.float64).T
+    trk, epochs, status = gateway.call("track", h, params, chan, nargout=3)
+    assert trk.shape == (n_ep, 21 * 2) and list(epochs.reshape(-1)) == [n_ep, n_ep] and status.item() == 0
+    from types import SimpleNamespace
+    S.msToProcess = n_ep
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 4.0, codePhase=int(np.ceil(s.code_phase_samples)) + 1, status="T") for s in sats[:2]]
+    ref, done, aborted = CO.track_l1ca(iq, ch, S)
+    for k in range(2):
+        assert np.array_equal(trk[:, 21 * k + 0], ref["absoluteSample"][k])
+        assert np.max(np.abs(trk[:, 21 * k + 5] - ref["I_P"][k])) < 1e-5 * 2 * 18000 * 28
+    # coarse acquisition through the gateway
+    acq = dict(samplingFreq=S.samplingFreq, codeFreqBasis=S.codeFreqBasis, codeLength=S.codeLength, IF=S.IF, acqSearchBand=7000, acqSearchStep=500,
+               acqNonCohTime=4, firstSample=0)
+    prns = [sats[0].prn, 1 if sats[0].prn != 1 else 2]
+    tabs = np.stack([P.codes.makeCaTable(p, S) for p in prns]).astype(np.int8).T          # spc x nprn, column per PRN
+    res = gateway.call("acquire_coarse", h, acq, np.asfortranarray(tabs))
+    assert res.shape == (5, 2) and res[3, 0] > 3.5
+    assert abs((res[1, 0] - 1 - sats[0].code_phase_samples + 9000) % 18000 - 9000) < 3
+    # errors come back as MATLAB errors (mexErrMsgIdAndTxt), with the library's message
+    with pytest.raises(harness.MexError) as e:
+        gateway.call("track", 7, params, chan, nargout=3)
+    assert "invalid context handle" in str(e.value)
+    bad = dict(params, dllCorrelatorSpacing=1.5)
+    with pytest.raises(harness.MexError) as e:
+        gateway.call("track", h, bad, chan, nargout=3)
+    assert "gc_track" in str(e.value) and "table" in str(e.value)
+    with pytest.raises(harness.MexError):
+        gateway.call("no_such_command", h)
+    gateway.call("destroy", h, nargout=0)
+    with pytest.raises(harness.MexError):
+        gateway.call("device_info", h, nargout=2)
+
+
+_WRAPPER_DIR = {"GPS_L1CA": "GPS_L1CA", "GPS_L5C": "GPS_L5C", "GPS_L2C": "GPS_L2C", "GAL_E1C": "GAL_E1C", "GAL_E5a": "GAL_E5a", "GAL_E5b": "GAL_E5b",
+                "BDS_B1I": "BDS_B1I", "BDS_B2a": "BDS_B2a", "BDS_B3I": "BDS_B3I", "GLO_GL1": "GLO_GL1", "GLO_GL2": "GLO_GL2", "BDS_B1C_NB": "BDS_B1C",
+                "BDS_B1C_WB": "BDS_B1C"}
+
+
+@pytest.mark.parametrize("sc", RS.TRACK_SCENES, ids=[s.name for s in RS.TRACK_SCENES])
+def test_matlab_drop_in_reproduces_the_references_tracking_m(gateway, sc, tmp_path):
+    import bridge
+    import cu_sdr_collection_amd as P
+    from oracle import mlab
+    z = np.load(os.path.join(GOLD, f"ref_track_{sc.name}.npz"))
+    S, rec, layout, ch = RS.scene_inputs(P, sc)
+    assert RS.crc(rec) == int(z["record_crc32"][0])
+    path = str(tmp_path / "record.bin")
+    rec.tofile(path)
+    I = bridge.install(bridge.interpreter_for(_WRAPPER_DIR[sc.signal]), gateway, P, sc.signal)
+    fid = mlab.register_file(I, rec.tobytes(), path)           # fopen(fid) answers with the file name, as in MATLAB
+    from types import SimpleNamespace
+    mch = mlab.to_matlab([SimpleNamespace(**{k: (v if isinstance(v, str) else float(v)) for k, v in vars(c).items()}) for c in ch])
+    try:
+        tr, chout = I.call(sc.fn, fid, mch, mlab.to_matlab(S), nargout=2)      # the reference's signature, the reference's file name
+    finally:
+        I.call("gnsscorr_context", "", "clear")
+    tr = mlab.from_matlab(tr)
+    ref_fields = [k[2:] for k in z.files if k.startswith("f_") and k != "f_PRN"]
+    comp = 1 if layout == RS.GC_REAL else 2
+    full = comp * S.samplingFreq * S.intTime * 28.0 * (5.0 if rec.dtype == np.int16 else 1.0)
+    assert [t.status for t in tr] == [str(s) for s in z["status"]]
+    for k, t in enumerate(tr):
+        have = {f for f in vars(t) if isinstance(getattr(t, f), (np.ndarray, float)) and f != "PRN"}
+        assert have == set(ref_fields), (sc.name, sorted(have ^ set(ref_fields)))
+        for f in ref_fields:
+            want, got = z["f_" + f][k], np.atleast_1d(np.asarray(getattr(t, f), dtype=np.float64))
+            assert got.shape == want.shape, (sc.name, f)
+            assert np.array_equal(np.isinf(got), np.isinf(want)), (sc.name, k, f)
+            m = np.isfinite(want)
+            if not m.any():
+                continue
+            d = float(np.max(np.abs(got[m] - want[m])))
+            if f == "absoluteSample":
+                assert d < 1e-6, (sc.name, k, d)
+            elif f[-3:] in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L"):
+                assert d < 1e-5 * full, (sc.name, k, f, d / full)
+            elif f in ("carrFreq", "codeFreq", "DataCNo", "PilotCNo", "B2a_CNo", "B1C_CNo"):
+                assert d < 1e-3, (sc.name, k, f, d)
+            elif f == "remCarrPhase":
+                dd = np.abs(got[m] - want[m])
+                assert np.max(np.minimum(dd, np.abs(dd - 2 * np.pi))) < 1e-5
+            else:
+                assert d < 2e-5 * max(1.0, float(np.max(np.abs(want[m])))), (sc.name, k, f, d)
+        if "cno_VSMValue" in z.files and t.status == "T":
+            assert np.allclose(np.atleast_1d(t.CNo.VSMValue), z["cno_VSMValue"][k], atol=1e-3)
+            assert np.array_equal(np.atleast_1d(t.CNo.VSMIndex), z["cno_VSMIndex"][k])
+        if bool(z["PRN_set"][k]):
+            assert float(t.PRN) == float(z["PRN"][k])
