@@ -1393,7 +1393,18 @@ def _warning(I, a, n):
 
 @builtin("strcmp")
 def _strcmp(I, a, n):
-    return isinstance(a[0], MStr) and isinstance(a[1], MStr) and a[0].s == a[1].s
+    x, y = a[0], a[1]
+    if isinstance(x, MCell) or isinstance(y, MCell):       # strcmp(str, cellOfStr) -> logical array of the cell's shape
+        c, s_ = (x, y) if isinstance(x, MCell) else (y, x)
+        out = np.zeros(c.a.shape, dtype=bool)
+        for idx, v in np.ndenumerate(c.a):
+            if isinstance(s_, MCell):
+                w = s_.a[idx] if s_.a.shape == c.a.shape else None
+                out[idx] = isinstance(v, MStr) and isinstance(w, MStr) and v.s == w.s
+            else:
+                out[idx] = isinstance(v, MStr) and isinstance(s_, MStr) and v.s == s_.s
+        return out
+    return isinstance(x, MStr) and isinstance(y, MStr) and x.s == y.s
 
 
 @builtin("strcmpi")

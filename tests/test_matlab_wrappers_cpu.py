@@ -70,6 +70,10 @@ def test_wrapper_builds_the_references_trackresults(sc):
         assert have == ref_fields, sorted(have ^ ref_fields)
         for f in ref_fields:
             assert np.atleast_1d(getattr(t, f)).shape == z["f_" + f][k].shape, f
+    for f in ref_fields:        # every recorded field of an active channel took the gateway's values (ones), pilot fields included
+        if f.startswith("Pilot_") or f in ("I_P", "Q_E", "carrFreq"):
+            if not (sc.signal == "GPS_L2C" and f in ("codeFreq",)):
+                assert np.all(np.atleast_1d(getattr(tr[0], f)) == 1), f
     idle = tr[-1]
     assert idle.status == "-" and np.all(np.isinf(idle.codeFreq)) and not np.any(idle.I_P)
     # the short-read channel keeps its '-' status and its untouched tail (tracking.m:241-245,365)
