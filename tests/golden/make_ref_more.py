@@ -89,7 +89,7 @@ CODE_JOBS = [
     ("GAL/GAL_E5a", "generateE5aQ_secondary", range(1, 37), None),
     ("GAL/GAL_E5b", "generateE5bIcode", range(1, 37), 1.0),
     ("GAL/GAL_E5b", "generateE5bQcode", range(1, 37), 1.0),
-    ("BDS/B1I", "generateCAcode53", range(1, 64), None),
+    ("BDS/B1I", "generateCAcode53", range(1, 59), None),
     ("BDS/B3I", "generateB3Icode", range(1, 64), None),
     ("BDS/B2a", "generateB2aDataCode", range(1, 64), None),
     ("BDS/B2a", "generateB2aPilotCode", range(1, 64), None),

@@ -71,7 +71,11 @@ def install(I, gateway, P, signal: str):
         return int(num(a[k]).flat[0])
 
     doubles = {
-        "generateCAcode": lambda _I, a, n: row(C.generateGLOcode()) if len(a) == 3 else row(C.generateCAcode(prn_of(a))),
+        # GLONASS: generateCAcode(PRN, fs, n) returns n samples of the 511-chip code taken at rate fs (GLO_GL1/include/generateCAcode.m:93-119)
+        "generateCAcode": lambda _I, a, n: (row(P.acq_family.glonass_sampled_code(float(num(a[1]).flat[0]), int(num(a[2]).flat[0]))) if len(a) == 3
+                                            else row(C.generateCAcode(prn_of(a)))),
+        "generateE5aQ_secondary": lambda _I, a, n: row(C.generateE5aQ_secondary(prn_of(a))),
+        "generateE5bQ_secondary": lambda _I, a, n: row(C.generateE5bQ_secondary(prn_of(a))),
         "generateCAcode53": lambda _I, a, n: row(C.generateCAcode53(prn_of(a))),
         "generateB3Icode": lambda _I, a, n: row(C.generateB3Icode(prn_of(a))),
         "generateL5Icode": lambda _I, a, n: row(C.generateL5Icode(prn_of(a))),

@@ -84,7 +84,8 @@ class Gateway:
         dims = (C.c_size_t * a.ndim)(*a.shape)
         m = L.mxCreateNumericArray(a.ndim, dims, cls, 0)
         if a.size:
-            C.memmove(L.mxGetData(m), np.asfortranarray(a).ctypes.data, a.nbytes)
+            col_major = np.asfortranarray(a)          # kept alive until the copy is done
+            C.memmove(L.mxGetData(m), col_major.ctypes.data, a.nbytes)
         return m
 
     # ---- mxArray -> Python ------------------------------------------------------------------------------------
