@@ -41,7 +41,7 @@ constexpr int kLW = kLaneWaves;  // wavefronts per workgroup
 #endif
 constexpr int kGRP = GC_LANE_GRP;  // samples per lane and group: the loads of the next group fly under this one
 
-// TAB: 0 = f32 tables, 1 = f32 tables + shared early/late ramp, 2 = f16 tables
+// TAB: 0 = f32 tables, 1 = f32 tables + ONE ramp for all three taps (earlyLateSpc*R*M == 1/2: HALF, below), 2 = f16 tables
 // DEVLOOP = persistent launch with device-side loop closure (devloop.h): p.splits workgroups of 16 waves per channel, the
 // block loop becomes the channel's epoch loop; sums are combined in LDS per workgroup, between workgroups by tagged
 // messages, and wave 0 of the channel's first workgroup closes the loop.
@@ -55,8 +55,13 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   constexpr int LA = DER ? ARMS - 1 : ARMS;  // arms with a table in LDS
   constexpr int AP = ArmPitch<LA>::v;        // values per staged entry
   constexpr bool kF16 = (TAB == 2);
-  constexpr bool kShare = (TAB == 1);
-  constexpr int NT = kShare ? 2 : 3;  // ramps carried per sample
+  // HALF: with earlyLateSpc*R*M == 1/2 (the reference's default 0.5-chip spacing on a 1x table: GPS L5, BDS B2a / B3I, Galileo
+  // E5a / E5b, GPS L2C in doubled-code units) the late ramp is the early ramp + 1 exactly, and the prompt ramp t = u_E + 1/2 has
+  // ceil(t) = ceil(u_E) + (frac(u_E) > 1/2): ONE ramp Q_E serves all three taps - table entries k_E and k_E + 1 come back from
+  // one ds_read2, the prompt tap selects between them by the sign bit of Q_E's low word.  Per sample and two arms that is one
+  // 64-bit add, one LDS instruction and two selects instead of two adds, three address computations and three LDS reads.
+  constexpr bool kHalf = (TAB == 1);
+  constexpr int NT = kHalf ? 1 : 3;  // ramps carried per sample
   constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
   constexpr int bps = Fmt<MODE>::bps;
   typedef typename std::conditional<kF16, _Float16, float>::type tab_t;
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   const double sp = step * R;
   const double tau = blk.carr_freq / p.fs;  // carrier turns per sample
   const double M6 = DER ? chn->mult[ARMS - 1] : 0.0;  // ramp multiplier of the derived arm
-  const bool tie_free = !DER && (blk.reserved & 1) != 0;  // host-proved: no sample within the window of a table edge (the
-                                                          // host's search does not cover a derived arm's ramp)
+  const bool tie_free = (blk.reserved & 1) != 0;  // host-proved: no sample within the window of a table edge, on any ramp of the
+                                                  // channel (gc_mark_tie_free searches the derived arm's six-times ramp too)
 
   // sample range of this split: a multiple of 64 samples per split
   const int per = (((N + nsplit - 1) / nsplit) + 63) / 64 * 64;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     sincospif(2.0f * (float)(x - floor(x)), &s_, &c_);  // range reduction in double, sincos in float
     rotC = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c_)));
     rotS = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_)));
-    if (kShare) el_off = __builtin_amdgcn_readfirstlane((int)(2.0 * d * R * M));  // host-checked: exact integer
+    (void)el_off;  // HALF: host-checked 2*d*R*M == 1 exactly (gc_block_shares_el_lane)
   }
   // the same for the derived arm's ramp (multiplier M6)
   unsigned long long Sf6 = 0, dQ6 = 0;
@@ -372,11 +377,37 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       accr[ARMS - 1][x] = fmaf(cf, yr, accr[ARMS - 1][x]);
       acci[ARMS - 1][x] = fmaf(cf, yi, acci[ARMS - 1][x]);
     };
-    // lean accumulate of one sample: y = x*exp(-i theta), one LDS read per tap serves every arm
-    auto lean_sample = [&](unsigned int word, const int (&k)[NT], const int (&k6)[3]) {
+    // lean accumulate of one sample: y = x*exp(-i theta), one LDS read per tap serves every arm.  `lo` (HALF only): low word of
+    // the early ramp's Q, whose sign bit says whether the prompt tap sits on the early (0) or the late (1) entry
+    auto lean_sample = [&](unsigned int word, const int (&k)[NT], const int (&k6)[3], unsigned int lo) {
       float yr, yi;
       mix(word, yr, yi);
-      const int kk[3] = {k[0], k[1], kShare ? k[0] + el_off : k[NT - 1]};
+      if constexpr (kHalf) {
+        typedef tab_t vec_t __attribute__((ext_vector_type(AP)));
+        const vec_t* tv = reinterpret_cast<const vec_t*>(tab) + (kGuard + k[0]);
+        const vec_t e0 = tv[0], e1 = tv[1];        // early and late entries of every arm: one ds_read2
+        const bool on_late = (int)lo < 0;
+#pragma unroll
+        for (int ar = 0; ar < LA; ++ar) {
+          float cE, cL;
+          if constexpr (AP == 1) {
+            cE = (float)e0[0];
+            cL = (float)e1[0];
+          } else {
+            cE = (float)e0[ar];
+            cL = (float)e1[ar];
+          }
+          const float cP = on_late ? cL : cE;
+          accr[ar][0] = fmaf(cE, yr, accr[ar][0]);
+          acci[ar][0] = fmaf(cE, yi, acci[ar][0]);
+          accr[ar][1] = fmaf(cP, yr, accr[ar][1]);
+          acci[ar][1] = fmaf(cP, yi, acci[ar][1]);
+          accr[ar][2] = fmaf(cL, yr, accr[ar][2]);
+          acci[ar][2] = fmaf(cL, yi, acci[ar][2]);
+        }
+        return;
+      } else {
+      const int kk[3] = {k[0], k[NT > 1 ? 1 : 0], k[NT - 1]};
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
         const float base = accumulate(x, kk[x], yr, yi);
@@ -387,6 +418,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
           accr[ARMS - 1][x] = fmaf(cf, yr, accr[ARMS - 1][x]);
           acci[ARMS - 1][x] = fmaf(cf, yi, acci[ARMS - 1][x]);
         }
+      }
       }
     };
     // exact accumulate of one sample: MATLAB colon element i (tracking.m:252-270) in float64 — forwards from
@@ -420,11 +452,16 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     };
     // ramp step of one tap: table index of the CURRENT sample (high word), the low word into the running
     // min / max of the near-tie test, then Q += dQ
-    auto ramp_step = [&](int x, bool test, unsigned int& dmin, unsigned int& dmax) -> int {
+    auto ramp_step = [&](int x, bool test, unsigned int& dmin, unsigned int& dmax, unsigned int& lo) -> int {
       const int k = (int)(unsigned int)(Q[x] >> 32);
+      lo = (unsigned int)Q[x];
       if (test) {
-        dmin = min(dmin, (unsigned int)Q[x]);
-        dmax = max(dmax, (unsigned int)Q[x]);
+        dmin = min(dmin, lo);
+        dmax = max(dmax, lo);
+        if constexpr (kHalf) {  // the prompt ramp crosses an entry where the early ramp's fraction passes 1/2
+          dmin = min(dmin, lo ^ 0x80000000u);
+          dmax = max(dmax, lo ^ 0x80000000u);
+        }
       }
       Q[x] += dQ;
       return k;
@@ -452,6 +489,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       // path.  Blocks the host proved tie-free (gc_mark_tie_free, an exact search) skip the test.
       int kg[kGRP][NT];
       int kg6[kGRP][3];
+      unsigned int lo[kGRP];
       unsigned int dmin = 0xffffffffu, dmax = 0u;
       if constexpr (DER) {
 #pragma unroll
@@ -463,12 +501,12 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
 #pragma unroll
         for (int j = 0; j < kGRP; ++j)
 #pragma unroll
-          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, false, dmin, dmax);
+          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, false, dmin, dmax, lo[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < kGRP; ++j)
 #pragma unroll
-          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, true, dmin, dmax);
+          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, true, dmin, dmax, lo[j]);
       }
       const bool suspect = !tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u));
       if (__builtin_expect(__any(suspect) != 0, 0)) {
@@ -480,7 +518,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       } else {
 #pragma unroll
         for (int j = 0; j < kGRP; ++j) {
-          lean_sample(cur[j], kg[j], kg6[j]);
+          lean_sample(cur[j], kg[j], kg6[j], lo[j]);
           rotate_w();
         }
       }
@@ -511,9 +549,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       const unsigned int word = load_sample(ptr);
       int k1[NT];
       int k16[3] = {0, 0, 0};
-      unsigned int dmin = 0xffffffffu, dmax = 0u;
+      unsigned int dmin = 0xffffffffu, dmax = 0u, lo1 = 0u;
 #pragma unroll
-      for (int x = 0; x < NT; ++x) k1[x] = ramp_step(x, true, dmin, dmax);
+      for (int x = 0; x < NT; ++x) k1[x] = ramp_step(x, true, dmin, dmax, lo1);
       if constexpr (DER) {
 #pragma unroll
         for (int x = 0; x < 3; ++x) k16[x] = ramp_step6(x, dmin, dmax);
@@ -521,7 +559,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       if (!tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)))
         exact_sample(word, i);
       else
-        lean_sample(word, k1, k16);
+        lean_sample(word, k1, k16, lo1);
       rotate_w();
     }
   }

@@ -180,7 +180,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
                          unsigned int notify_tag = 0, bool share_el = false);
 // el_spacing * R * M == 1/2 exactly: early and late ramps differ by one whole table entry
 bool gc_block_shares_el(const gc_context* ctx, const gc_block& b);
-// 2 * el_spacing * R * M is an exact positive integer: the late tap reads the early tap's entry + that integer
+// 2 * el_spacing * R * M == 1 exactly: early, prompt and late taps read table entries k and k + 1 of ONE ramp (lane kernel, HALF)
 bool gc_block_shares_el_lane(const gc_context* ctx, const gc_block& b);
 // Kernel class a block qualifies for: 0 = generic only, 1 = fast kernel with 8-sample lane-chunks,
 // 2 = fast kernel with 16-sample lane-chunks (at most one table transition per chunk and tap).

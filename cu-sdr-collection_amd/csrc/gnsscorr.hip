@@ -616,9 +616,15 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
     if (off) continue;
     const HostChannel& c = ctx->ch[k.channel];
     if (c.mult[0] != 1.0) continue;
+    // a derived third arm (BOC(6,1) from BOC(1,1), gc_channel_is_derived) runs its own ramp at mult[2] times the rate: its edges
+    // are searched as well, with the window the kernel uses for both ramp sets (the larger multiplier's)
+    const double m6 = (c.arms == 3 && gc_channel_is_derived(c)) ? c.mult[2] : 0.0;
+    bool plain_mults = true;
+    for (int a = 1; a < c.arms; ++a) plain_mults = plain_mults && (c.mult[a] == 1.0 || (a == 2 && m6 != 0.0));
+    if (!plain_mults) continue;
     const double R = c.index_scale, sp = k.code_phase_step * R;
-    const double maxv = std::fabs(k.rem_code_phase - k.el_spacing) * R + std::fabs(k.rem_code_phase + k.el_spacing) * R +
-                        (double)k.blksize * std::fabs(sp) + 1.0;
+    const double maxv = (std::fabs(k.rem_code_phase - k.el_spacing) * R + std::fabs(k.rem_code_phase + k.el_spacing) * R +
+                         (double)k.blksize * std::fabs(sp) + 1.0) * std::max(1.0, m6);
     // band: the lane kernel's own window (corr_common.h, splits = 1 is the widest) plus 3 units, or the float
     // step quotient's resolution (eps_unit_steps samples of ramp) for the fast kernel
     const double eps = std::max((gcorr::gc_tie_window_units(maxv, k.blksize / 64 + 2) + 3.0) / 4294967296.0, eps_unit_steps * sp);
@@ -626,6 +632,7 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
                               (k.rem_code_phase + k.el_spacing) * R};
     bool clean = true;
     for (int t = 0; t < 3 && clean; ++t) clean = gc_first_sample_near_edge(starts[t], sp, k.blksize, eps) < 0;
+    for (int t = 0; t < 3 && clean && m6 != 0.0; ++t) clean = gc_first_sample_near_edge(starts[t] * m6, sp * m6, k.blksize, eps) < 0;
     if (clean) k.reserved |= 1;
   }
 }
@@ -646,7 +653,7 @@ int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b) {
 bool gc_block_shares_el_lane(const gc_context* ctx, const gc_block& b) {
   const HostChannel& c = ctx->ch[b.channel];
   const double v = 2.0 * b.el_spacing * c.index_scale * c.mult[0];
-  return v >= 1.0 && v <= 64.0 && v == std::floor(v);
+  return v == 1.0;  // exactly half a table entry between prompt and early / late: the lane kernel's one-ramp (HALF) variant
 }
 
 bool gc_block_shares_el(const gc_context* ctx, const gc_block& b) {
