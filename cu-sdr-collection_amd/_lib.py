@@ -117,6 +117,10 @@ SYMBOLS = {
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,
                                        C.POINTER(C.c_double)]),
     "gc_acquire_fine_sums": (C.c_int, [_P, C.POINTER(gc_fine_params), _P, C.POINTER(C.c_double)]),
+    "gc_acquire_fine_l1ca_batch": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gc_acquire_fine_sums_batch": (C.c_int, [_P, C.POINTER(gc_fine_params), C.c_int, _P, C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gc_acq_shift_prepare": (C.c_int, [_P, C.POINTER(gc_acq_shift_params)]),
     "gc_acq_shift_search": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "gc_acq_shift_row": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),

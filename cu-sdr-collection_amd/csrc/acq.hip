@@ -522,14 +522,294 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
   }
 }
 
-// POST_ABS_ACC with hop groups: results = (add ? results : 0) + (sum over groups, in group order) / n * scale
-__global__ void abs_combine_kernel(const float* __restrict__ part, int groups, long long total, float* __restrict__ out, int add,
-                                   float inv_n, float scale) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    float v = 0.0f;
-    for (int g = 0; g < groups; ++g) v += part[(long long)g * total + i];
-    out[i] = (add ? out[i] : 0.0f) + v * inv_n * scale;
+// ---- pass kernels generated per shape ------------------------------------------------------------------------------
+// fft_pass_kernel above takes every size at run time and pays for it: ~170 VALU instructions per element and pass, most
+// of them index arithmetic (run-time divisors, strides, radix dispatch, bounds tests).  fft_pass_ct is the same pass with
+// the vector length, the other dimension, the tile width, the radices, the pre/post operation and the direction as
+// template parameters: divisions by constants, LDS addresses with immediate offsets, the stage twiddles of ALL stages
+// staged once per workgroup (not per stage and hop), no bounds tests (the tile width divides the vector count), sign
+// flips folded into the butterflies.  launch_pass picks it for the shapes listed in GC_CT_SHAPES (the FFT sizes of the
+// reference's default front ends) and falls back to the generic kernel for everything else; GC_ACQ_GENERIC=1 forces the
+// generic kernel.
+template <int R, int L, int C, int NS, bool INV>
+__device__ __forceinline__ void stage_ct(const float2* __restrict__ src, float2* __restrict__ dst, const float2* __restrict__ twl,
+                                         unsigned tid) {
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+  constexpr float sign = INV ? -1.0f : 1.0f;
+#pragma unroll
+  for (unsigned it = 0; it < ITERS; ++it) {
+    const unsigned b = tid + it * kFftThreads;
+    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    const unsigned c = b / LR, j = b - c * LR;
+    const unsigned k = NS == 1 ? 0u : j % (unsigned)NS;
+    const float2* s = src + c * L + j;
+    float2 vq[R], oq[R];
+    vq[0] = s[0];
+#pragma unroll
+    for (int q = 1; q < R; ++q) {
+      float2 x = s[q * LR];
+      if constexpr (NS > 1) x = cmul(x, twl[k * (R - 1) + q - 1]);  // row k = 0 holds ones
+      vq[q] = x;
+    }
+    butterfly<R>(vq, sign, oq);
+    float2* d = dst + c * L + (j - k) * R + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) d[q * NS] = oq[q];
   }
+}
+
+// W_{NS*R}^{k*q} (k < NS, 0 < q < R) of one stage from the global table exp(-2*pi*i*m/N)
+template <int R, int NS, int N, bool INV>
+__device__ __forceinline__ void stage_twiddles_ct(const float2* __restrict__ tw, float2* twl, unsigned tid) {
+  if constexpr (R > 1 && NS > 1) {
+    constexpr unsigned CNT = NS * (R - 1), TWS = N / (NS * R);
+    static_assert(N % (NS * R) == 0, "stage size divides the transform size");
+    for (unsigned i = tid; i < CNT; i += kFftThreads) {
+      const unsigned k = i / (R - 1), q = i % (R - 1) + 1;
+      float2 w = tw[k * q * TWS];
+      if (INV) w.y = -w.y;
+      twl[i] = w;
+    }
+  }
+}
+
+template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, int R0, int R1, int R2, int R3>
+__global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
+  static_assert(R0 * R1 * R2 * R3 == L && OTHER % C == 0, "radices multiply to L; whole tiles only");
+  constexpr unsigned N = L * OTHER, NEL = L * C, SLOTS = (NEL + kFftThreads - 1) / kFftThreads, TILES = OTHER / C;
+  static_assert(SLOTS <= kFftSlots, "tile too large");
+  constexpr unsigned ESTR = CONTIG ? 1 : OTHER, VSTR = CONTIG ? L : 1;
+  constexpr int NS1 = R0, NS2 = R0 * R1, NS3 = R0 * R1 * R2;
+  constexpr unsigned T1 = R1 > 1 ? NS1 * (R1 - 1) : 0, T2 = R2 > 1 ? NS2 * (R2 - 1) : 0, T3 = R3 > 1 ? NS3 * (R3 - 1) : 0;
+  constexpr int NST = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+  constexpr unsigned EH = ((L - 1) >> 4) + 1, TW2 = EH + 16;
+  __shared__ __attribute__((aligned(16))) float2 buf0[NEL];
+  __shared__ __attribute__((aligned(16))) float2 buf1[NEL];
+  __shared__ float2 twl[T1 + T2 + T3 + 1];
+  __shared__ float2 tw2[POST == POST_TWIDDLE ? C * TW2 : 1];
+  const unsigned tid = threadIdx.x;
+  const unsigned tile = blockIdx.x % TILES;
+  const unsigned bb = blockIdx.x / TILES;
+  const unsigned HG = (POST == POST_ABS_ACC && a.hop_groups > 1) ? (unsigned)a.hop_groups : 1u;
+  const unsigned batch = bb / HG, hg = bb - batch * HG;
+  const unsigned v0 = tile * C;
+  const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : 1;
+
+  stage_twiddles_ct<R1, NS1, N, INV>(a.tw, twl, tid);
+  stage_twiddles_ct<R2, NS2, N, INV>(a.tw, twl + T1, tid);
+  stage_twiddles_ct<R3, NS3, N, INV>(a.tw, twl + T1 + T2, tid);
+  if constexpr (POST == POST_TWIDDLE) {
+    // W_N^(v*e) = W_N^(v*16*(e>>4)) * W_N^(v*(e&15)): C * (EH + 16) table entries per tile
+    for (unsigned i = tid; i < C * TW2; i += kFftThreads) {
+      const unsigned c = i / TW2, j = i - c * TW2;
+      const unsigned v = v0 + c;
+      float2 w = a.tw[j < EH ? v * (j << 4) : v * (j - EH)];  // v * e < N for every e < L
+      if (INV) w.y = -w.y;
+      tw2[i] = w;
+    }
+  }
+
+  float accv[SLOTS];
+#pragma unroll
+  for (unsigned k = 0; k < SLOTS; ++k) accv[k] = 0.f;
+
+  for (int rep = 0; rep < reps; ++rep) {
+    const long long tb = POST == POST_ABS_ACC ? (long long)batch * a.nhops + (long long)hg * reps + rep : (long long)batch;
+    // ---- load --------------------------------------------------------------------------------------------
+    [[maybe_unused]] int cb = 0, ch = 0;
+    [[maybe_unused]] double fcyc = 0.0;
+    if constexpr (PRE == PRE_IF_CARRIER) {
+      cb = (int)(tb / a.nhops);
+      ch = (int)(tb % a.nhops);
+      fcyc = (a.f0 - a.fstep * cb) / a.fs;  // cycles per sample of bin cb (acquisition.m:169-181)
+    }
+#pragma unroll
+    for (unsigned slot = 0; slot < SLOTS; ++slot) {
+      const unsigned idx = tid + slot * kFftThreads;
+      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      unsigned pos, li;
+      if constexpr (CONTIG) {
+        pos = v0 * L + idx;  // the tile is C whole vectors: one contiguous run of the transform
+        li = idx;
+      } else {
+        const unsigned e = idx / C, c = idx - e * C;
+        pos = e * ESTR + (v0 + c) * VSTR;
+        li = c * L + e;
+      }
+      float2 val;
+      if constexpr (PRE == PRE_IF_CARRIER) {
+        const long long s = a.first_sample + (long long)ch * a.spc + (long long)pos;
+        const char2 x = *reinterpret_cast<const char2*>(a.if_base + 2 * s);
+        const float xi = (float)x.x, xq = (float)x.y;
+        const double ph = fcyc * (double)pos;
+        float sn, cs;
+        sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
+        val = make_float2(xi * cs + xq * sn, xq * cs - xi * sn);
+      } else if constexpr (PRE == PRE_CODE) {
+        val = (int)pos < a.spc ? make_float2((float)a.codes[tb * a.spc + pos], 0.f) : make_float2(0.f, 0.f);
+      } else {
+        val = a.in[tb * a.in_batch_stride + pos];
+        if constexpr (PRE == PRE_MUL_CONJ) {
+          const float2 o = a.other[pos];
+          val = make_float2(val.x * o.x + val.y * o.y, val.y * o.x - val.x * o.y);
+        }
+      }
+      buf0[li] = val;
+    }
+    __syncthreads();
+
+    // ---- stages: buf0 -> buf1 -> buf0 -> ... -------------------------------------------------------------
+    stage_ct<R0, L, C, 1, INV>(buf0, buf1, twl, tid);
+    __syncthreads();
+    if constexpr (R1 > 1) {
+      stage_ct<R1, L, C, NS1, INV>(buf1, buf0, twl, tid);
+      __syncthreads();
+    }
+    if constexpr (R2 > 1) {
+      stage_ct<R2, L, C, NS2, INV>(buf0, buf1, twl + T1, tid);
+      __syncthreads();
+    }
+    if constexpr (R3 > 1) {
+      stage_ct<R3, L, C, NS3, INV>(buf1, buf0, twl + T1 + T2, tid);
+      __syncthreads();
+    }
+    const float2* res = (NST & 1) ? buf1 : buf0;
+
+    // ---- store -------------------------------------------------------------------------------------------
+#pragma unroll
+    for (unsigned slot = 0; slot < SLOTS; ++slot) {
+      const unsigned idx = tid + slot * kFftThreads;
+      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      unsigned pos, li, e, c;
+      if constexpr (CONTIG) {
+        c = idx / L;
+        e = idx - c * L;
+        pos = v0 * L + idx;
+        li = idx;
+      } else {
+        e = idx / C;
+        c = idx - e * C;
+        pos = e * ESTR + (v0 + c) * VSTR;
+        li = c * L + e;
+      }
+      float2 val = res[li];
+      if constexpr (POST == POST_TWIDDLE) val = cmul(val, cmul(tw2[c * TW2 + (e >> 4)], tw2[c * TW2 + EH + (e & 15)]));
+      if constexpr (POST == POST_ABS_ACC) {
+        accv[slot] += sqrtf(val.x * val.x + val.y * val.y);
+      } else {
+        a.out[tb * a.out_batch_stride + pos] = val;
+      }
+    }
+    // the next hop's load overwrites buf0: safe without a barrier when the result sits in buf1 (the barrier after the
+    // load orders this hop's reads of buf1 before the next first stage writes it)
+    if constexpr (POST == POST_ABS_ACC && !(NST & 1)) __syncthreads();
+  }
+  if constexpr (POST == POST_ABS_ACC) {
+    const float inv_n = 1.0f / (float)N, scale = a.acc_scale != 0.0f ? a.acc_scale : 1.0f;
+#pragma unroll
+    for (unsigned slot = 0; slot < SLOTS; ++slot) {
+      const unsigned idx = tid + slot * kFftThreads;
+      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      unsigned pos;
+      if constexpr (CONTIG) {
+        pos = v0 * L + idx;
+      } else {
+        const unsigned e = idx / C, c = idx - e * C;
+        pos = e * ESTR + (v0 + c) * VSTR;
+      }
+      if (HG > 1) {
+        a.acc_part[((long long)hg * a.acc_bins + batch) * N + pos] = accv[slot];
+      } else {
+        float* dstp = a.acc_out + (long long)batch * N + pos;
+        *dstp = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * scale;
+      }
+    }
+  }
+}
+
+// Peak pick with MATLAB's first-occurrence semantics (acquisition.m:196-198: max(max(results, [], 2)) and max(max(results))):
+// the largest value, the smallest bin holding it and the smallest column holding it (not necessarily the same element).
+// Positive floats order like their bit patterns, so two 64-bit atomic maxima do it: (bits << 32) | ~bin and
+// (bits << 32) | ~column.
+struct PeakTrack {
+  unsigned int m = 0, bin = 0xffffffffu, col = 0xffffffffu;
+  __device__ __forceinline__ void see(float v, unsigned int b, unsigned int c) {
+    const unsigned int u = __float_as_uint(v);
+    if (u > m) {
+      m = u;
+      bin = b;
+      col = c;
+    } else if (u == m) {
+      bin = min(bin, b);
+      col = min(col, c);
+    }
+  }
+  // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
+  // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
+  __device__ __forceinline__ void publish(unsigned long long* keys) const {
+    __shared__ unsigned int sm[4], sb[4], sc[4];
+    unsigned int wm = m;
+    for (int off = 32; off > 0; off >>= 1) wm = max(wm, (unsigned int)__shfl_xor((int)wm, off, 64));
+    unsigned int b = m == wm ? bin : 0xffffffffu, c = m == wm ? col : 0xffffffffu;
+    for (int off = 32; off > 0; off >>= 1) {
+      b = min(b, (unsigned int)__shfl_xor((int)b, off, 64));
+      c = min(c, (unsigned int)__shfl_xor((int)c, off, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      sm[wave] = wm;
+      sb[wave] = b;
+      sc[wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nw = (blockDim.x + 63) >> 6;
+      for (int w = 1; w < nw; ++w) {
+        if (sm[w] > wm) {
+          wm = sm[w];
+          b = sb[w];
+          c = sc[w];
+        } else if (sm[w] == wm) {
+          b = min(b, sb[w]);
+          c = min(c, sc[w]);
+        }
+      }
+      if (b != 0xffffffffu) {
+        const unsigned long long ka = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - b);
+        const unsigned long long kb = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - c);
+        if (ka > __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[0], ka);
+        if (kb > __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[1], kb);
+      }
+    }
+  }
+};
+
+// POST_ABS_ACC with hop groups: results = (add ? results : 0) + (sum over groups, in group order) / n * scale;
+// `keys` != nullptr: also the peak pick of the finished results (last code arm of a PRN)
+__global__ __launch_bounds__(256) void abs_combine_kernel(const float* __restrict__ part, int groups, int nbins, int n,
+                                                          float* __restrict__ out, int add, float inv_n, float scale,
+                                                          unsigned long long* keys) {
+  PeakTrack pk;
+  const long long total = (long long)nbins * n;
+  for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+      const long long i = (long long)bin * n + c;
+      float v = 0.0f;
+      for (int g = 0; g < groups; ++g) v += part[(long long)g * total + i];
+      v = (add ? out[i] : 0.0f) + v * inv_n * scale;
+      out[i] = v;
+      pk.see(v, (unsigned int)bin, (unsigned int)c);
+    }
+  if (keys) pk.publish(keys);
+}
+
+// the peak pick alone (results written by the pass kernel itself: no hop groups)
+__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ r, int nbins, int n, unsigned long long* keys) {
+  PeakTrack pk;
+  for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+      pk.see(r[(long long)bin * n + c], (unsigned int)bin, (unsigned int)c);
+  pk.publish(keys);
 }
 
 // ---- sigPower inputs: exact integer sums of the first spc samples (acquisition.m:151) -------------------
@@ -546,67 +826,84 @@ __global__ void sigpower_kernel(const int8_t* __restrict__ x, long long first, i
   atomicAdd((unsigned long long*)&out3[2], (unsigned long long)s2);
 }
 
-// ---- peak pick with MATLAB first-occurrence semantics (acquisition.m:196-198) ---------------------------
-// pass 1: global max (positive floats order like their bit patterns)
-__global__ void max_kernel(const float* __restrict__ r, long long n, unsigned int* gmax) {
-  unsigned int m = 0;
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-  const long long n4 = n >> 2;
-  const float4* r4 = reinterpret_cast<const float4*>(r);  // r is the start of a hipMalloc'ed buffer
-  for (long long i = gid; i < n4; i += stride) {
-    const float4 v = r4[i];
-    m = max(max(m, max(__float_as_uint(v.x), __float_as_uint(v.y))), max(__float_as_uint(v.z), __float_as_uint(v.w)));
-  }
-  for (long long i = (n4 << 2) + gid; i < n; i += stride) m = max(m, __float_as_uint(r[i]));
-  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_down((int)m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(gmax, m);
-}
-// pass 2: smallest bin and smallest column holding that value
-__global__ void argmax_kernel(const float* __restrict__ r, int nbins, int ncols, const unsigned int* gmax, int* out2) {
-  const unsigned int m = *gmax;
-  const long long n = (long long)nbins * ncols;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    if (__float_as_uint(r[i]) == m) {
-      atomicMin(&out2[0], (int)(i / ncols));
-      atomicMin(&out2[1], (int)(i % ncols));
-    }
-}
+// ---- fine frequency (acquisition.m:213-238): per-code-period sums of x[n] * code[floor(ts*(n + offset)/tc) mod len] *
+// exp(-1i*2*pi*f_bin*n/fs) for every fine bin, several detections per launch (blockIdx.x = code period, .y = detection,
+// .z = group of kFineBins bins).  The first version of this kernel evaluated sincos and the float64 code index once per
+// (bin, sample) - 21 times the work for the 21 bins of a 500-Hz coarse step - in a launch of its own per detection.  Here
+// a sample is read, its code chip looked up and the carrier of the group's middle bin evaluated once; the other bins'
+// carriers follow by rotating with exp(-+i*2*pi*fstep*n/fs) (at most kFineBins/2 rotations away from an evaluated
+// sincos: ~1e-6 relative, the float32 level of the sums themselves).  Per-thread sums in float64 as before.
+struct FineDet {
+  long long first;  // absolute index of the detection's first sample
+  double f0;        // its first fine bin, Hz
+};
+constexpr int kFineBins = 24;
 
-// ---- fine frequency, GPS L1 C/A (acquisition.m:213-238): 40 per-code sums for each fine bin ---------------
-__global__ __launch_bounds__(256) void fine_kernel(const int8_t* __restrict__ x, long long first, int spc, int ncodes,
-                                                    const int8_t* __restrict__ code, int code_len, double ts, double tc,
-                                                    double f0, double fstep, double fs, double* __restrict__ out, int index_offset = 0) {
-  const int bin = blockIdx.x / ncodes, ci = blockIdx.x % ncodes;
-  const double f = f0 - fstep * bin;
-  double sr = 0.0, si = 0.0;
-  for (int i = threadIdx.x; i < spc; i += blockDim.x) {
+__global__ __launch_bounds__(256) void fine_multi_kernel(const int8_t* __restrict__ x, const FineDet* __restrict__ det, int spc,
+                                                          int ncodes, const int8_t* __restrict__ codes, int code_len, double ts,
+                                                          double tc, double fstep, double fs, int nbins, int index_offset,
+                                                          double* __restrict__ out) {
+  constexpr int MID = kFineBins / 2;
+  const int ci = blockIdx.x, d = blockIdx.y, b0 = blockIdx.z * kFineBins;
+  const int nb = min(kFineBins, nbins - b0);
+  const FineDet dd = det[d];
+  const int8_t* code = codes + (size_t)d * code_len;
+  const double fmid = (dd.f0 - fstep * (double)(b0 + MID)) / fs, fst = fstep / fs;  // cycles per sample
+  double sr[kFineBins], si[kFineBins];
+#pragma unroll
+  for (int k = 0; k < kFineBins; ++k) sr[k] = si[k] = 0.0;
+  for (int i = threadIdx.x; i < spc; i += 256) {
     const long long n = (long long)ci * spc + i;
-    // codeValueIndex = floor((ts * n) / tc), exactly as acquisition.m:215-216 (float64)
-    // (index_offset = 1: the 10.23-Mcps packages index with (1:K*spc), e.g. GPS_L5C acquisition.m:231)
-    const double cvi = floor(__ddiv_rn(__dmul_rn(ts, (double)(n + index_offset)), tc));
-    const int k = (int)fmod(cvi, (double)code_len);
-    const float c = (float)code[k];
-    const float xi = (float)x[2 * (first + n)], xq = (float)x[2 * (first + n) + 1];
-    const double ph = (f / fs) * (double)n;
-    float sn, cs;
+    const double cvi = floor(__ddiv_rn(__dmul_rn(ts, (double)(n + index_offset)), tc));  // acquisition.m:215-216
+    const float c = (float)code[(int)fmod(cvi, (double)code_len)];
+    const char2 xs = *reinterpret_cast<const char2*>(x + 2 * (dd.first + n));
+    const float cr = c * (float)xs.x, cq = c * (float)xs.y;
+    const double ph = fmid * (double)n, dp = fst * (double)n;
+    float sn, cs, sd, cd;
     sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
-    sr += (double)(c * (xi * cs + xq * sn));
-    si += (double)(c * (xq * cs - xi * sn));
-  }
-  __shared__ double red[2][256];
-  red[0][threadIdx.x] = sr;
-  red[1][threadIdx.x] = si;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + off];
-      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    sincospif(2.0f * (float)(dp - floor(dp)), &sd, &cd);
+    sr[MID] += (double)(cr * cs + cq * sn);
+    si[MID] += (double)(cq * cs - cr * sn);
+    float wr = cs, wi = sn;  // exp(+i*2*pi*ph_k); bin k+1 is fstep lower: multiply by exp(-i*2*pi*dp)
+#pragma unroll
+    for (int k = MID + 1; k < kFineBins; ++k) {
+      const float tr = wr * cd + wi * sd, ti = wi * cd - wr * sd;
+      wr = tr;
+      wi = ti;
+      if (k < nb) {
+        sr[k] += (double)(cr * wr + cq * wi);
+        si[k] += (double)(cq * wr - cr * wi);
+      }
     }
-    __syncthreads();
+    wr = cs;
+    wi = sn;
+#pragma unroll
+    for (int k = MID - 1; k >= 0; --k) {
+      const float tr = wr * cd - wi * sd, ti = wi * cd + wr * sd;
+      wr = tr;
+      wi = ti;
+      sr[k] += (double)(cr * wr + cq * wi);
+      si[k] += (double)(cq * wr - cr * wi);
+    }
   }
-  if (threadIdx.x == 0) {
-    out[2 * blockIdx.x] = red[0][0];
-    out[2 * blockIdx.x + 1] = red[1][0];
+  __shared__ double red[4][kFineBins][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kFineBins; ++k) {
+    double a = sr[k], b = si[k];
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off, 64);
+      b += __shfl_down(b, off, 64);
+    }
+    if (lane == 0) {
+      red[wave][k][0] = a;
+      red[wave][k][1] = b;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * nb) {
+    const int k = threadIdx.x >> 1, q = threadIdx.x & 1;
+    out[(((size_t)d * nbins + b0 + k) * ncodes + ci) * 2 + q] = ((red[0][k][q] + red[1][k][q]) + red[2][k][q]) + red[3][k][q];
   }
 }
 
@@ -644,7 +941,40 @@ __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r
   }
 }
 
+// Launches fft_pass_ct<...> when `a` describes exactly that instantiation (its tile width C replaces a.cols).
+template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, int R0, int R1, int R2, int R3>
+bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
+  constexpr int rad[4] = {R0, R1, R2, R3};
+  constexpr int nst = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+  if (a.len != L || a.nvec != OTHER || a.n != L * OTHER || a.pre != PRE || a.post != POST ||
+      (a.inverse != 0) != INV || a.shift_bins > 0 || a.nrad != nst)
+    return false;
+  if (CONTIG ? (a.estride != 1 || a.vstride != L) : (a.estride != OTHER || a.vstride != 1)) return false;
+  for (int i = 0; i < nst; ++i)
+    if (a.rad[i] != rad[i]) return false;
+  hipLaunchKernelGGL((fft_pass_ct<L, OTHER, CONTIG, C, PRE, POST, INV, R0, R1, R2, R3>),
+                     dim3((unsigned int)((OTHER / C) * nbatch_groups)), dim3(kFftThreads), 0, ctx->stream, a);
+  return true;
+}
+
+// the five passes of a search over N = N1 x N2 (columns: length N1, C1 per tile, radices A..; rows: length N2, C2, B..)
+#define GC_CT_SHAPE(N1, N2, C1, A0, A1, A2, A3, C2, B0, B1, B2, B3)                                              \
+  (try_ct<N1, N2, false, C1, PRE_IF_CARRIER, POST_TWIDDLE, false, A0, A1, A2, A3>(ctx, a, nbatch_groups) ||      \
+   try_ct<N1, N2, false, C1, PRE_CODE, POST_TWIDDLE, false, A0, A1, A2, A3>(ctx, a, nbatch_groups) ||            \
+   try_ct<N2, N1, true, C2, PRE_NONE, POST_STORE, false, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||               \
+   try_ct<N2, N1, true, C2, PRE_MUL_CONJ, POST_TWIDDLE, true, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||          \
+   try_ct<N1, N2, false, C1, PRE_NONE, POST_ABS_ACC, true, A0, A1, A2, A3>(ctx, a, nbatch_groups))
+
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
+  static const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;
+  if (!generic) {
+    // N = 36 000: 18 Msps, 1 ms codes (GPS L1 C/A, L5, Galileo E5a/E5b, BDS B2a/B3I: initSettings.m of each package);
+    // N = 24 000: GLONASS L1/L2 at 12 Msps
+    if (GC_CT_SHAPE(180, 200, 8, 6, 6, 5, 1, 10, 8, 5, 5, 1) || GC_CT_SHAPE(150, 160, 8, 6, 5, 5, 1, 10, 8, 5, 4, 1)) {
+      GC_HIP(hipGetLastError());
+      return GC_OK;
+    }
+  }
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   const size_t smem = ((size_t)2 * a.len * a.cols + a.len + (size_t)a.cols * (((a.len - 1) >> 4) + 17)) * sizeof(float2);
   hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned int)(tiles * nbatch_groups)), dim3(kFftThreads), smem, ctx->stream, a);
@@ -681,7 +1011,6 @@ struct AcqScratch {
   size_t partial_cap = 0;
   int8_t* codes = nullptr;    // nprn * spc
   long long* sums = nullptr;  // 3 + scratch for argmax
-  double* fine = nullptr;     // fine sums
   long long nbh = 0;
   int nprn = 0, nbins = 0;
   // circshift search family (gc_acq_shift_*)
@@ -689,13 +1018,13 @@ struct AcqScratch {
   float* rowmax = nullptr;
   int* rowarg = nullptr;
   int shift_rows = 0;
-  int* peaks = nullptr;       // per-PRN peak slots {max bits, bin, column, -} of gc_acquire_coarse_multi
+  unsigned long long* peaks = nullptr;  // per-PRN peak keys of gc_acquire_coarse_multi
   int peaks_cap = 0;
 };
 
 void free_scratch(AcqScratch* s) {
   if (!s) return;
-  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->fine, s->rowmax, s->rowarg, s->peaks};
+  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->rowmax, s->rowarg, s->peaks};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -704,14 +1033,21 @@ void free_scratch(AcqScratch* s) {
 // Last inverse pass (POST_ABS_ACC) over `nbins` bins.  With few bins the launch would have ~2 workgroups per CU, each
 // walking all nhops hops of its bin: the hops are then split over hop groups (a divisor of nhops), whose raw sums meet in
 // abs_combine_kernel - deterministic, group order fixed.
-int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins) {
+int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr) {
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   int hg = 1;
   for (int g = 1; g <= a.nhops; ++g)
     if (a.nhops % g == 0 && (long long)tiles * nbins * hg < 8LL * ctx->compute_units) hg = g;
   if (std::getenv("GC_ACQ_NO_HOP_GROUPS")) hg = 1;
   a.hop_groups = hg;
-  if (hg == 1) return launch_pass(ctx, a, nbins);
+  const dim3 pgrid((unsigned int)std::max(1, std::min((a.n + 1023) / 1024, 64)), (unsigned int)std::min<long long>(nbins, 65535));
+  if (hg == 1) {
+    int rc = launch_pass(ctx, a, nbins);
+    if (rc || !keys) return rc;
+    hipLaunchKernelGGL(peak_kernel, pgrid, dim3(256), 0, ctx->stream, a.acc_out, (int)nbins, a.n, keys);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+  }
   const size_t need = (size_t)hg * (size_t)nbins * (size_t)a.n;
   if (s->partial_cap < need) {
     GC_HIP(hipStreamSynchronize(ctx->stream));
@@ -725,9 +1061,8 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   a.acc_bins = (int)nbins;
   int rc = launch_pass(ctx, a, nbins * hg);
   if (rc) return rc;
-  const long long total = nbins * (long long)a.n;
-  hipLaunchKernelGGL(abs_combine_kernel, dim3(1024), dim3(256), 0, ctx->stream, s->partial, hg, total, a.acc_out, a.acc_add,
-                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f);
+  hipLaunchKernelGGL(abs_combine_kernel, pgrid, dim3(256), 0, ctx->stream, s->partial, hg, (int)nbins, a.n, a.acc_out, a.acc_add,
+                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, keys);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -766,8 +1101,7 @@ static int ensure_scratch(gc_context* ctx, int n, long long nbh, int nprn, int n
       hipMalloc((void**)&s->codespec, (size_t)nprn * ne * sizeof(float2)) != hipSuccess ||
       hipMalloc((void**)&s->results, (size_t)nbins * ne * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&s->codes, (size_t)nprn * spc) != hipSuccess ||
-      hipMalloc((void**)&s->sums, 16 * sizeof(long long)) != hipSuccess ||
-      hipMalloc((void**)&s->fine, 4096 * 2 * sizeof(double)) != hipSuccess) {
+      hipMalloc((void**)&s->sums, 16 * sizeof(long long)) != hipSuccess) {
     free_scratch(s);
     gc_set_error("acquisition: device allocation failed");
     return GC_E_NOMEM;
@@ -888,15 +1222,12 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     if (s->peaks) (void)hipFree(s->peaks);
     s->peaks = nullptr;
     s->peaks_cap = 0;
-    GC_HIP(hipMalloc((void**)&s->peaks, (size_t)nprn * 4 * sizeof(int)));
+    GC_HIP(hipMalloc((void**)&s->peaks, (size_t)nprn * 2 * sizeof(unsigned long long)));
     s->peaks_cap = nprn;
   }
-  int* const peaks = s->peaks;
-  {
-    std::vector<int> init((size_t)nprn * 4, 0x7fffffff);
-    for (int ip = 0; ip < nprn; ++ip) init[4 * (size_t)ip] = 0;
-    GC_HIP(hipMemcpy(peaks, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice));
-  }
+  // per-PRN peak keys {(bits << 32) | ~bin, (bits << 32) | ~column}, read back once after the last PRN
+  unsigned long long* const peaks = s->peaks;
+  GC_HIP(hipMemsetAsync(peaks, 0, (size_t)nprn * 2 * sizeof(unsigned long long), ctx->stream));
 
   for (int ip = 0; ip < nprn; ++ip) {
     for (int arm = 0; arm < narms; ++arm) {
@@ -930,23 +1261,19 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.in = s->tmp;
       a.acc_out = s->results;
       a.acc_add = arm > 0;
-      rc = launch_abs_pass(ctx, s, a, nbins);
+      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr);
       if (rc) return rc;
     }
-    // peak pick: per-PRN slot {max bits, bin, column, -}; read back once after the last PRN (no host round trip per PRN)
-    const long long total = (long long)nbins * n;
-    int* slot = peaks + 4 * ip;
-    hipLaunchKernelGGL(max_kernel, dim3(256), dim3(256), 0, ctx->stream, s->results, total, (unsigned int*)slot);
-    hipLaunchKernelGGL(argmax_kernel, dim3(512), dim3(256), 0, ctx->stream, s->results, nbins, n, (const unsigned int*)slot, slot + 1);
-    GC_HIP(hipGetLastError());
   }
-  std::vector<int> hpeaks((size_t)nprn * 4);
-  GC_HIP(hipMemcpyAsync(hpeaks.data(), peaks, hpeaks.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<unsigned long long> hpeaks((size_t)nprn * 2);
+  GC_HIP(hipMemcpyAsync(hpeaks.data(), peaks, hpeaks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
   for (int ip = 0; ip < nprn; ++ip) {
-    const int harg[2] = {hpeaks[4 * ip + 1], hpeaks[4 * ip + 2]};
+    const int harg[2] = {(int)(0xffffffffu - (unsigned int)(hpeaks[2 * ip] & 0xffffffffu)),
+                         (int)(0xffffffffu - (unsigned int)(hpeaks[2 * ip + 1] & 0xffffffffu))};
+    const unsigned int bits = (unsigned int)(hpeaks[2 * ip] >> 32);
     float peak;
-    std::memcpy(&peak, &hpeaks[4 * ip], sizeof peak);
+    std::memcpy(&peak, &bits, sizeof peak);
     out[ip].coarse_bin = harg[0] + 1;   // 1-based like MATLAB
     out[ip].code_phase = harg[1] + 1;
     out[ip].peak = (double)peak;
@@ -959,40 +1286,56 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
 
 
 // Generic fine-frequency stage: per-code-period complex sums of signal x code x carrier for `nbins`
-// carriers f0 - k*fstep over `ncodes` periods from p->first_sample; the hypothesis search over bit edges / Neuman-
+// carriers f0 - k*fstep over `ncodes` periods from first_sample; the hypothesis search over bit edges / Neuman-
 // Hofman / secondary codes / data+pilot combinations is a few hundred flops and stays with the caller.
-extern "C" int gc_acquire_fine_sums(gc_context* ctx, const gc_fine_params* p, const int8_t* code, double* out) {
-  if (!ctx || !p || !code || !out || p->spc <= 0 || p->ncodes <= 0 || p->nbins <= 0 || p->code_len <= 0 || p->first_sample < 0) {
+// `ndet` detections (code d*code_len.., first_sample[d], f0[d]) share one launch and one read-back.
+extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params* p, int ndet, const int8_t* codes,
+                                          const int64_t* first_sample, const double* f0, double* out) {
+  if (!ctx || !p || ndet <= 0 || ndet > 65535 || !codes || !first_sample || !f0 || !out || p->spc <= 0 || p->ncodes <= 0 ||
+      p->nbins <= 0 || p->code_len <= 0) {
     gc_set_error("gc_acquire_fine_sums: bad arguments");
     return GC_E_INVALID;
   }
   if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
-  if ((uint64_t)p->first_sample + (uint64_t)p->ncodes * p->spc > ctx->if_nsamples) {
-    gc_set_error("gc_acquire_fine_sums: %d code periods from sample %lld exceed the IF buffer", p->ncodes, (long long)p->first_sample);
-    return GC_E_RANGE;
+  std::vector<FineDet> hdet((size_t)ndet);
+  for (int d = 0; d < ndet; ++d) {
+    if (first_sample[d] < 0 || (uint64_t)first_sample[d] + (uint64_t)p->ncodes * p->spc > ctx->if_nsamples) {
+      gc_set_error("gc_acquire_fine_sums: %d code periods from sample %lld exceed the IF buffer", p->ncodes, (long long)first_sample[d]);
+      return first_sample[d] < 0 ? GC_E_INVALID : GC_E_RANGE;
+    }
+    hdet[d].first = first_sample[d];
+    hdet[d].f0 = f0[d];
   }
   GC_HIP(hipSetDevice(ctx->device));
-  const size_t nout = (size_t)p->nbins * p->ncodes * 2;
-  int8_t* dcode = nullptr;
-  double* dout = nullptr;
-  if (hipMalloc((void**)&dcode, (size_t)p->code_len) != hipSuccess || hipMalloc((void**)&dout, nout * sizeof(double)) != hipSuccess) {
-    if (dcode) (void)hipFree(dcode);
+  const size_t nout = (size_t)ndet * p->nbins * p->ncodes * 2;
+  GcBuf& bcode = ctx->acqbuf[gc_context::ACQ_FINE_CODE];
+  GcBuf& bdet = ctx->acqbuf[gc_context::ACQ_FINE_DET];
+  GcBuf& bout = ctx->acqbuf[gc_context::ACQ_FINE_OUT];
+  if (gc_buf_reserve(bcode, (size_t)ndet * p->code_len, false) != hipSuccess ||
+      gc_buf_reserve(bdet, (size_t)ndet * sizeof(FineDet), false) != hipSuccess ||
+      gc_buf_reserve(bout, nout * sizeof(double), false) != hipSuccess) {
     gc_set_error("gc_acquire_fine_sums: device allocation failed");
     return GC_E_NOMEM;
   }
-  hipError_t e = hipMemcpyAsync(dcode, code, (size_t)p->code_len, hipMemcpyHostToDevice, ctx->stream);
-  hipLaunchKernelGGL(fine_kernel, dim3(p->nbins * p->ncodes), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (long long)p->first_sample,
-                     p->spc, p->ncodes, (const int8_t*)dcode, p->code_len, 1.0 / p->sampling_freq, 1.0 / p->code_freq, p->f0, p->fstep,
-                     p->sampling_freq, dout, p->index_offset);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(dcode);
-  (void)hipFree(dout);
-  if (e != hipSuccess) {
-    gc_set_error("gc_acquire_fine_sums: %s", hipGetErrorString(e));
-    return GC_E_HIP;
-  }
+  GC_HIP(hipMemcpyAsync(bcode.p, codes, (size_t)ndet * p->code_len, hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipMemcpyAsync(bdet.p, hdet.data(), (size_t)ndet * sizeof(FineDet), hipMemcpyHostToDevice, ctx->stream));
+  const dim3 grid((unsigned int)p->ncodes, (unsigned int)ndet, (unsigned int)((p->nbins + kFineBins - 1) / kFineBins));
+  hipLaunchKernelGGL(fine_multi_kernel, grid, dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (const FineDet*)bdet.p, p->spc,
+                     p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq, 1.0 / p->code_freq, p->fstep,
+                     p->sampling_freq, p->nbins, p->index_offset, (double*)bout.p);
+  GC_HIP(hipGetLastError());
+  GC_HIP(hipMemcpyAsync(out, bout.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));  // also keeps hdet / codes alive until the copies are done
   return GC_OK;
+}
+
+extern "C" int gc_acquire_fine_sums(gc_context* ctx, const gc_fine_params* p, const int8_t* code, double* out) {
+  if (!p) {
+    gc_set_error("gc_acquire_fine_sums: bad arguments");
+    return GC_E_INVALID;
+  }
+  const int64_t first = p->first_sample;
+  return gc_acquire_fine_sums_batch(ctx, p, 1, code, &first, &p->f0, out);
 }
 
 // ---- circshift search family ------------------------------------------------------------------------------
@@ -1174,66 +1517,69 @@ extern "C" int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in,
   return GC_OK;
 }
 
-extern "C" int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code, int code_phase,
-                                    double coarse_freq, double* carr_freq) {
-  if (!ctx || !p || !code || !carr_freq || code_phase < 1) {
+extern "C" int gc_acquire_fine_l1ca_batch(gc_context* ctx, const gc_acq_params* p, int ndet, const int8_t* codes,
+                                          const int32_t* code_phase, const double* coarse_freq, double* carr_freq) {
+  if (!ctx || !p || ndet <= 0 || !codes || !code_phase || !coarse_freq || !carr_freq) {
     gc_set_error("gc_acquire_fine_l1ca: bad arguments");
     return GC_E_INVALID;
   }
-  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
-  GC_HIP(hipSetDevice(ctx->device));
   const double x = p->sampling_freq / (p->code_freq_basis / p->code_length);
   const int spc = (int)std::floor(x + 0.5);
   const int ncodes = 40;
   const double fine_step = 25;                                                   // acquisition.m:138
   const int nfine = (int)std::floor(p->search_step / fine_step + 0.5) + 1;      // :140
-  const long long first = p->first_sample + code_phase - 1;                      // sig40cm, :221
-  if ((uint64_t)first + (uint64_t)ncodes * spc > ctx->if_nsamples) {
-    gc_set_error("gc_acquire_fine_l1ca: 40 code periods from sample %lld exceed the IF buffer", first);
-    return GC_E_RANGE;
+  gc_fine_params fp;
+  std::memset(&fp, 0, sizeof fp);
+  fp.sampling_freq = p->sampling_freq;
+  fp.code_freq = p->code_freq_basis;
+  fp.fstep = fine_step;
+  fp.spc = spc;
+  fp.ncodes = ncodes;
+  fp.nbins = nfine;
+  fp.code_len = (int)p->code_length;
+  fp.index_offset = 0;                                                           // codeValueIndex over (0 : 40*spc-1), :210
+  std::vector<int64_t> first((size_t)ndet);
+  std::vector<double> f0((size_t)ndet);
+  for (int d = 0; d < ndet; ++d) {
+    if (code_phase[d] < 1) {
+      gc_set_error("gc_acquire_fine_l1ca: bad arguments");
+      return GC_E_INVALID;
+    }
+    first[d] = p->first_sample + code_phase[d] - 1;                              // sig40cm, :221
+    f0[d] = coarse_freq[d] + p->search_step / 2;                                 // fineFreqBins(1), :227-228
   }
-  AcqScratch* s = (AcqScratch*)ctx->acq_scratch;
-  if (!s) {
-    gc_set_error("gc_acquire_fine_l1ca: call gc_acquire_coarse first");
-    return GC_E_STATE;
-  }
-  if (nfine * ncodes > 4096) return GC_E_UNSUPPORTED;
-  const int code_len = (int)p->code_length;
-  int8_t* dcode = nullptr;
-  GC_HIP(hipMalloc((void**)&dcode, (size_t)code_len));
-  GC_HIP(hipMemcpy(dcode, code, (size_t)code_len, hipMemcpyHostToDevice));
-  const double ts = 1.0 / p->sampling_freq, tc = 1.0 / p->code_freq_basis;
-  const double f0 = coarse_freq + p->search_step / 2;                            // fineFreqBins(1), :227-228
-  hipLaunchKernelGGL(fine_kernel, dim3(nfine * ncodes), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, first, spc,
-                     ncodes, (const int8_t*)dcode, code_len, ts, tc, f0, fine_step, p->sampling_freq, s->fine);
-  std::vector<double> h((size_t)nfine * ncodes * 2);
-  hipError_t e = hipMemcpyAsync(h.data(), s->fine, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(dcode);
-  if (e != hipSuccess) {
-    gc_set_error("gc_acquire_fine_l1ca: %s", hipGetErrorString(e));
-    return GC_E_HIP;
-  }
-  // 20 navigation-bit-edge hypotheses, max |sum of 20 consecutive per-code sums| (:242-249); first max (:253)
-  double best = -1.0;
-  int best_bin = 0;
-  for (int b = 0; b < nfine; ++b) {
-    double max_power = 0.0;
-    for (int c0 = 0; c0 < 20; ++c0) {
-      double sr = 0.0, si = 0.0;
-      for (int c = c0; c < c0 + 20; ++c) {
-        sr += h[2 * ((size_t)b * ncodes + c)];
-        si += h[2 * ((size_t)b * ncodes + c) + 1];
+  std::vector<double> h((size_t)ndet * nfine * ncodes * 2);
+  const int rc = gc_acquire_fine_sums_batch(ctx, &fp, ndet, codes, first.data(), f0.data(), h.data());
+  if (rc) return rc;
+  for (int d = 0; d < ndet; ++d) {
+    // 20 navigation-bit-edge hypotheses, max |sum of 20 consecutive per-code sums| (:242-249); first max (:253)
+    const double* hd = h.data() + (size_t)d * nfine * ncodes * 2;
+    double best = -1.0;
+    int best_bin = 0;
+    for (int b = 0; b < nfine; ++b) {
+      double max_power = 0.0;
+      for (int c0 = 0; c0 < 20; ++c0) {
+        double sr = 0.0, si = 0.0;
+        for (int c = c0; c < c0 + 20; ++c) {
+          sr += hd[2 * ((size_t)b * ncodes + c)];
+          si += hd[2 * ((size_t)b * ncodes + c) + 1];
+        }
+        max_power = std::max(max_power, std::sqrt(sr * sr + si * si));
       }
-      max_power = std::max(max_power, std::sqrt(sr * sr + si * si));
+      if (max_power > best) {
+        best = max_power;
+        best_bin = b;
+      }
     }
-    if (max_power > best) {
-      best = max_power;
-      best_bin = b;
-    }
+    double f = f0[d] - fine_step * best_bin;
+    if (f == 0) f = 1;  // :258-260
+    carr_freq[d] = f;
   }
-  double f = f0 - fine_step * best_bin;
-  if (f == 0) f = 1;  // :258-260
-  *carr_freq = f;
   return GC_OK;
+}
+
+extern "C" int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code, int code_phase,
+                                    double coarse_freq, double* carr_freq) {
+  const int32_t cp = code_phase;
+  return gc_acquire_fine_l1ca_batch(ctx, p, 1, code, &cp, &coarse_freq, carr_freq);
 }

@@ -148,6 +148,8 @@ struct gc_context {
 
   // acquisition scratch (acq.hip)
   void* acq_scratch = nullptr;
+  enum { ACQ_FINE_CODE = 0, ACQ_FINE_DET, ACQ_FINE_OUT, ACQ_NBUF };
+  GcBuf acqbuf[ACQ_NBUF];  // fine-frequency stage: codes, detections, per-code sums
 
   // gc_track_multi: this context's tracking call runs next to other contexts' on the same device.  Its persistent kernels
   // are then launched with a plain launch instead of a cooperative one (gc_launch_persistent below).

@@ -227,6 +227,21 @@ class Engine:
                                                out.ctypes.data_as(C.POINTER(C.c_double))))
         return out[..., 0] + 1j * out[..., 1]
 
+    def acquire_fine_sums_batch(self, params: L.gc_fine_params, codes: np.ndarray, first_sample, f0) -> np.ndarray:
+        """The same for several detections in one launch: codes [ndet, code_len], first_sample [ndet], f0 [ndet]
+        -> complex [ndet, nbins, ncodes]."""
+        c8 = np.ascontiguousarray(codes, dtype=np.int8)
+        ndet = c8.shape[0]
+        fs = np.ascontiguousarray(first_sample, dtype=np.int64)
+        ff = np.ascontiguousarray(f0, dtype=np.float64)
+        if c8.ndim != 2 or c8.shape[1] != params.code_len or fs.shape != (ndet,) or ff.shape != (ndet,):
+            raise ValueError("acquire_fine_sums_batch: codes [ndet, code_len], first_sample [ndet], f0 [ndet]")
+        out = np.empty((ndet, params.nbins, params.ncodes, 2))
+        L.check(self._lib.gc_acquire_fine_sums_batch(self._ctx, C.byref(params), ndet, c8.ctypes.data_as(C.c_void_p),
+                                                     fs.ctypes.data_as(C.POINTER(C.c_int64)), ff.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out[..., 0] + 1j * out[..., 1]
+
     def acq_shift_prepare(self, params: L.gc_acq_shift_params):
         self._shift = params
         L.check(self._lib.gc_acq_shift_prepare(self._ctx, C.byref(params)))
@@ -273,3 +288,17 @@ class Engine:
         L.check(self._lib.gc_acquire_fine_l1ca(self._ctx, C.byref(params), c8.ctypes.data_as(C.c_void_p),
                                                int(code_phase), float(coarse_freq), C.byref(f)))
         return f.value
+
+    def acquire_fine_l1ca_batch(self, params: L.gc_acq_params, codes: np.ndarray, code_phase, coarse_freq) -> np.ndarray:
+        """Fine stage of all detected PRNs in one launch: codes [ndet, code_length] -> carrFreq [ndet]."""
+        c8 = np.ascontiguousarray(codes, dtype=np.int8)
+        ndet = c8.shape[0]
+        cp = np.ascontiguousarray(code_phase, dtype=np.int32)
+        cf = np.ascontiguousarray(coarse_freq, dtype=np.float64)
+        if c8.ndim != 2 or c8.shape[1] != int(params.code_length) or cp.shape != (ndet,) or cf.shape != (ndet,):
+            raise ValueError("acquire_fine_l1ca_batch: codes [ndet, code_length], code_phase [ndet], coarse_freq [ndet]")
+        out = np.empty(ndet)
+        L.check(self._lib.gc_acquire_fine_l1ca_batch(self._ctx, C.byref(params), ndet, c8.ctypes.data_as(C.c_void_p),
+                                                     cp.ctypes.data_as(C.POINTER(C.c_int32)), cf.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out

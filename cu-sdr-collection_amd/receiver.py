@@ -106,11 +106,16 @@ def acquisition(engine: Engine, settings, first_sample: int | None = None):
     p = _acq_params(settings, first_sample)
     tables = np.stack([codes.makeCaTable(prn, settings) for prn in prns])
     res = engine.acquire_coarse(p, tables)
+    found = []
     for prn, r in zip(prns, res):
         acq.peakMetric[prn - 1] = r.peak_metric                      # acquisition.m:200
         if r.peak_metric > settings.acqThreshold:                    # :206
-            f = engine.acquire_fine_l1ca(p, codes.generateCAcode(prn), r.code_phase, r.coarse_freq)
-            acq.carrFreq[prn - 1] = f                                # :254-260
+            found.append((prn, r))
+    if found:                                                        # the fine stage of every detection in one launch
+        f = engine.acquire_fine_l1ca_batch(p, np.stack([codes.generateCAcode(prn) for prn, _ in found]),
+                                           [r.code_phase for _, r in found], [r.coarse_freq for _, r in found])
+        for (prn, r), fk in zip(found, f):
+            acq.carrFreq[prn - 1] = fk                               # :254-260
             acq.codePhase[prn - 1] = r.code_phase                    # :256
     return acq
 

@@ -282,6 +282,10 @@ int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, i
  * Returns the fine carrier frequency (with the "0 -> 1 Hz" rule of :258-260 applied). */
 int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, const int8_t* code,
                          int code_phase, double coarse_freq, double* carr_freq);
+/* The same for `ndet` detections in one launch and one read-back (the loop over the detected PRNs of
+ * acquisition.m:206-260): codes = ndet rows of code_length chips. */
+int gc_acquire_fine_l1ca_batch(gc_context* ctx, const gc_acq_params* p, int ndet, const int8_t* codes,
+                               const int32_t* code_phase, const double* coarse_freq, double* carr_freq);
 
 /* ---- acquisition, generic fine-frequency stage (acquisition.m:206-260 and its per-package variants: GPS_L5C
  * :228-252 Neuman-Hofman search, GAL_E5a 100-code secondary search, BDS/B2a non-coherent data+pilot, ...).
@@ -302,6 +306,10 @@ typedef struct gc_fine_params {
 } gc_fine_params;
 
 int gc_acquire_fine_sums(gc_context* ctx, const gc_fine_params* p, const int8_t* code, double* out);
+/* `ndet` detections per call: detection d uses codes + d*code_len, first_sample[d] and f0[d] instead of the fields of
+ * `p`; out[((d*nbins + bin)*ncodes + c)*2 + {0,1}]. */
+int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params* p, int ndet, const int8_t* codes,
+                               const int64_t* first_sample, const double* f0, double* out);
 
 /* ---- acquisition, circshift search family (replaces GPS_L2C/include/acquisition.m:40-75,
  * BDS/B1I/include/acquisition.m:76-123, BDS/B1C/include/acquisition.m:137-170): the signal block(s) are mixed with
