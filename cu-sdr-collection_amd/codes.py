@@ -55,14 +55,29 @@ def samplesPerCode(settings) -> int:
     return int(math.floor(x + 0.5))  # MATLAB round() for positive x
 
 
+_CA_INDEX = {}
+
+
+def _ca_table_index(settings) -> np.ndarray:
+    """codeValueIndex of makeCaTable.m:52-58, the same for every PRN of a front end (kept per (fs, chip rate, spc))."""
+    spc = samplesPerCode(settings)
+    key = (float(settings.samplingFreq), float(settings.codeFreqBasis), spc)
+    idx = _CA_INDEX.get(key)
+    if idx is None:
+        ts = 1.0 / settings.samplingFreq
+        tc = 1.0 / settings.codeFreqBasis
+        idx = np.ceil((ts * np.arange(1, spc + 1, dtype=np.float64)) / tc).astype(np.int64)
+        idx[-1] = 1023
+        idx -= 1
+        if len(_CA_INDEX) > 16:
+            _CA_INDEX.clear()
+        _CA_INDEX[key] = idx
+    return idx
+
+
 def makeCaTable(PRN: int, settings) -> np.ndarray:
     """Sampled C/A code for acquisition (makeCaTable.m:43-67): index ceil(ts*(1:spc)/tc), last = 1023."""
-    spc = samplesPerCode(settings)
-    ts = 1.0 / settings.samplingFreq
-    tc = 1.0 / settings.codeFreqBasis
-    idx = np.ceil((ts * np.arange(1, spc + 1, dtype=np.float64)) / tc).astype(np.int64)
-    idx[-1] = 1023
-    return generateCAcode(PRN)[idx - 1]
+    return generateCAcode(PRN)[_ca_table_index(settings)]
 
 
 # ---------------------------------------------------------------------------------------------

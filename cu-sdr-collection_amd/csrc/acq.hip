@@ -148,6 +148,9 @@ struct PassArgs {
   // PRE_MUL_CONJ with circular spectrum shifts (the circshift search family): batch tb reads input transform
   // tb / shift_bins shifted by tb % shift_bins natural-frequency bins; n1, n2 give the [k1][k2] storage order
   int shift_bins, n1, n2;
+  // the same with batch tb = bin * nhops + hop (coarse search whose bin spacing is a whole number of FFT bins): reads input
+  // transform `hop` shifted by bin * shift_q
+  int shift_q;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -385,11 +388,11 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
         } else if (a.pre == PRE_CODE) {
           val = (pos < a.spc) ? make_float2((float)a.codes[tb * a.spc + pos], 0.f) : make_float2(0.f, 0.f);
         } else {
-          if (a.pre == PRE_MUL_CONJ && a.shift_bins > 0) {
+          if (a.pre == PRE_MUL_CONJ && (a.shift_bins > 0 || a.shift_q > 0)) {
             // circshift(X, s): Y[k] = X[(k - s) mod n] in natural frequency order; storage position of frequency
             // k = k1 + n1*k2 is k1*n2 + k2
-            const long long src = tb / a.shift_bins;
-            const int sft = (int)(tb % a.shift_bins);
+            const long long src = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
+            const int sft = a.shift_q > 0 ? (int)(tb / a.nhops) * a.shift_q : (int)(tb % a.shift_bins);
             const int k1 = (int)(pos / a.n2), k2 = (int)(pos % a.n2);
             int k = k1 + a.n1 * k2 - sft;
             if (k < 0) k += a.n;
@@ -573,9 +576,10 @@ __device__ __forceinline__ void stage_twiddles_ct(const float2* __restrict__ tw,
   }
 }
 
-template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, int R0, int R1, int R2, int R3>
+template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, bool SHIFT, int R0, int R1, int R2, int R3>
 __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   static_assert(R0 * R1 * R2 * R3 == L && OTHER % C == 0, "radices multiply to L; whole tiles only");
+  static_assert(!SHIFT || (CONTIG && PRE == PRE_MUL_CONJ), "shifted reads belong to the rows pass of the inverse transform");
   constexpr unsigned N = L * OTHER, NEL = L * C, SLOTS = (NEL + kFftThreads - 1) / kFftThreads, TILES = OTHER / C;
   static_assert(SLOTS <= kFftSlots, "tile too large");
   constexpr unsigned ESTR = CONTIG ? 1 : OTHER, VSTR = CONTIG ? L : 1;
@@ -618,6 +622,14 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
     // ---- load --------------------------------------------------------------------------------------------
     [[maybe_unused]] int cb = 0, ch = 0;
     [[maybe_unused]] double fcyc = 0.0;
+    [[maybe_unused]] long long shsrc = 0;
+    [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
+    if constexpr (SHIFT) {
+      const unsigned sft = a.shift_q > 0 ? (unsigned)(tb / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
+      shsrc = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
+      sh2 = sft / OTHER;
+      sh1 = sft - sh2 * OTHER;
+    }
     if constexpr (PRE == PRE_IF_CARRIER) {
       cb = (int)(tb / a.nhops);
       ch = (int)(tb % a.nhops);
@@ -648,7 +660,19 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
       } else if constexpr (PRE == PRE_CODE) {
         val = (int)pos < a.spc ? make_float2((float)a.codes[tb * a.spc + pos], 0.f) : make_float2(0.f, 0.f);
       } else {
-        val = a.in[tb * a.in_batch_stride + pos];
+        if constexpr (SHIFT) {
+          // Y[k] = X[(k - s) mod N], k = k1 + N1*k2 stored at k1*N2 + k2 (N1 = OTHER rows of N2 = L): row v of Y is row
+          // (v - s1) mod N1 of X rotated by s2 (+1 when the row index wrapped), s = s1 + N1*s2
+          const unsigned c = idx / L, e = idx - c * L;
+          int k1 = (int)(v0 + c) - (int)sh1;
+          const int bor = k1 < 0;
+          k1 += bor ? OTHER : 0;
+          int e2 = (int)e - (int)sh2 - bor;
+          e2 += e2 < 0 ? L : 0;
+          val = a.in[shsrc * a.in_batch_stride + k1 * L + e2];
+        } else {
+          val = a.in[tb * a.in_batch_stride + pos];
+        }
         if constexpr (PRE == PRE_MUL_CONJ) {
           const float2 o = a.other[pos];
           val = make_float2(val.x * o.x + val.y * o.y, val.y * o.x - val.x * o.y);
@@ -942,28 +966,30 @@ __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r
 }
 
 // Launches fft_pass_ct<...> when `a` describes exactly that instantiation (its tile width C replaces a.cols).
-template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, int R0, int R1, int R2, int R3>
+template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, bool SHIFT, int R0, int R1, int R2, int R3>
 bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
   constexpr int rad[4] = {R0, R1, R2, R3};
   constexpr int nst = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
-  if (a.len != L || a.nvec != OTHER || a.n != L * OTHER || a.pre != PRE || a.post != POST ||
-      (a.inverse != 0) != INV || a.shift_bins > 0 || a.nrad != nst)
+  if (a.len != L || a.nvec != OTHER || a.n != L * OTHER || a.pre != PRE || a.post != POST || (a.inverse != 0) != INV ||
+      (a.pre == PRE_MUL_CONJ && (a.shift_bins > 0 || a.shift_q > 0)) != SHIFT || a.nrad != nst)
     return false;
+  if (SHIFT && (a.n1 != OTHER || a.n2 != L)) return false;
   if (CONTIG ? (a.estride != 1 || a.vstride != L) : (a.estride != OTHER || a.vstride != 1)) return false;
   for (int i = 0; i < nst; ++i)
     if (a.rad[i] != rad[i]) return false;
-  hipLaunchKernelGGL((fft_pass_ct<L, OTHER, CONTIG, C, PRE, POST, INV, R0, R1, R2, R3>),
+  hipLaunchKernelGGL((fft_pass_ct<L, OTHER, CONTIG, C, PRE, POST, INV, SHIFT, R0, R1, R2, R3>),
                      dim3((unsigned int)((OTHER / C) * nbatch_groups)), dim3(kFftThreads), 0, ctx->stream, a);
   return true;
 }
 
-// the five passes of a search over N = N1 x N2 (columns: length N1, C1 per tile, radices A..; rows: length N2, C2, B..)
-#define GC_CT_SHAPE(N1, N2, C1, A0, A1, A2, A3, C2, B0, B1, B2, B3)                                              \
-  (try_ct<N1, N2, false, C1, PRE_IF_CARRIER, POST_TWIDDLE, false, A0, A1, A2, A3>(ctx, a, nbatch_groups) ||      \
-   try_ct<N1, N2, false, C1, PRE_CODE, POST_TWIDDLE, false, A0, A1, A2, A3>(ctx, a, nbatch_groups) ||            \
-   try_ct<N2, N1, true, C2, PRE_NONE, POST_STORE, false, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||               \
-   try_ct<N2, N1, true, C2, PRE_MUL_CONJ, POST_TWIDDLE, true, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||          \
-   try_ct<N1, N2, false, C1, PRE_NONE, POST_ABS_ACC, true, A0, A1, A2, A3>(ctx, a, nbatch_groups))
+// the passes of a search over N = N1 x N2 (columns: length N1, C1 per tile, radices A..; rows: length N2, C2, B..)
+#define GC_CT_SHAPE(N1, N2, C1, A0, A1, A2, A3, C2, B0, B1, B2, B3)                                                     \
+  (try_ct<N1, N2, false, C1, PRE_IF_CARRIER, POST_TWIDDLE, false, false, A0, A1, A2, A3>(ctx, a, nbatch_groups) ||      \
+   try_ct<N1, N2, false, C1, PRE_CODE, POST_TWIDDLE, false, false, A0, A1, A2, A3>(ctx, a, nbatch_groups) ||            \
+   try_ct<N2, N1, true, C2, PRE_NONE, POST_STORE, false, false, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||               \
+   try_ct<N2, N1, true, C2, PRE_MUL_CONJ, POST_TWIDDLE, true, false, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||          \
+   try_ct<N2, N1, true, C2, PRE_MUL_CONJ, POST_TWIDDLE, true, true, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||           \
+   try_ct<N1, N2, false, C1, PRE_NONE, POST_ABS_ACC, true, false, A0, A1, A2, A3>(ctx, a, nbatch_groups))
 
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
   static const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;
@@ -1211,7 +1237,15 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   base.f0 = p->intermediate_freq + p->search_band;  // coarseFreqBin(1), :169
   base.fstep = p->search_step;
   base.fs = p->sampling_freq;
-  rc = forward(ctx, s, base, PRE_IF_CARRIER, (long long)nbins * H, s->sig);
+  // When the bin spacing is a whole number q of FFT bins (500 Hz x 2 ms = 1 at every default front end), the spectrum of
+  // bin b is the spectrum of bin 0 moved by b*q positions: x .* exp(-1i*(f0 - b*step)*phasePoints) =
+  // (x .* exp(-1i*f0*phasePoints)) .* exp(+2i*pi*b*q*n/N).  H spectra are then computed instead of nbins*H and the
+  // inverse transforms read them shifted (5.8 MB that stay in cache instead of 167 MB from HBM per PRN).
+  const double qd = p->search_step * (double)n / p->sampling_freq;
+  const long long q = (long long)std::floor(qd + 0.5);
+  const bool shifted = q >= 1 && std::fabs(qd - (double)q) <= 1e-12 * qd && (long long)(nbins - 1) * q < n &&
+                       std::getenv("GC_ACQ_NO_SHIFT") == nullptr;
+  rc = forward(ctx, s, base, PRE_IF_CARRIER, shifted ? (long long)H : (long long)nbins * H, s->sig);
   if (rc) return rc;
   // code spectra (conj applied at the product)
   base.codes = s->codes;
@@ -1245,6 +1279,9 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.post = POST_TWIDDLE;
       a.in = s->sig;
       a.in_batch_stride = pl.n;
+      a.shift_q = shifted ? (int)q : 0;
+      a.n1 = pl.n1;
+      a.n2 = pl.n2;
       a.other = s->codespec + ((size_t)ip * narms + arm) * pl.n;
       a.out = s->tmp;
       a.out_batch_stride = pl.n;
