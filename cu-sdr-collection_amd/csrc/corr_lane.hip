@@ -63,6 +63,11 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   constexpr bool kHalf = (TAB == 1);
   constexpr int NT = kHalf ? 1 : 3;  // ramps carried per sample
   constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
+#ifdef GC_LANE_GRP_DER
+  constexpr int GRP = DER ? GC_LANE_GRP_DER : kGRP;
+#else
+  constexpr int GRP = DER ? 2 : kGRP;  // samples per lane and group (the derived arm's three extra ramps: 128 VGPRs hold two steps' indices, not four)
+#endif
   constexpr int bps = Fmt<MODE>::bps;
   typedef typename std::conditional<kF16, _Float16, float>::type tab_t;
   const tab_t* tab = reinterpret_cast<const tab_t*>(smem);  // [kGuard + maxn + kGuard][AP]
@@ -205,11 +210,18 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   const long long s0 = blk.first_sample;
   // colon() arguments exactly as the reference writes them (tracking.m:252-268; GAL_E1C tracking.m:236-262
   // for R = 2); x*1.0 is exact so R = 1 needs no special case.
-  const double aE = (rem - d) * R;
-  const double aL = (rem + d) * R;
-  const double aP = rem * R;
-  const double sp = step * R;
-  const double tau = blk.carr_freq / p.fs;  // carrier turns per sample
+  // block-uniform float64 values live in scalar registers (there is no scalar FP64 unit: computed on the VALU they would
+  // each occupy a VGPR pair for the whole block, next to the 6*ARMS accumulators and the ramp state)
+  auto uni = [](double v) __attribute__((always_inline)) -> double {
+    const unsigned long long u = __double_as_longlong(v);
+    return __longlong_as_double(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                (unsigned int)__builtin_amdgcn_readfirstlane((int)u));
+  };
+  const double aE = uni((rem - d) * R);
+  const double aL = uni((rem + d) * R);
+  const double aP = uni(rem * R);
+  const double sp = uni(step * R);
+  const double tau = uni(blk.carr_freq / p.fs);  // carrier turns per sample
   const double M6 = DER ? chn->mult[ARMS - 1] : 0.0;  // ramp multiplier of the derived arm
   const bool tie_free = (blk.reserved & 1) != 0;  // host-proved: no sample within the window of a table edge, on any ramp of the
                                                   // channel (gc_mark_tie_free searches the derived arm's six-times ramp too)
@@ -316,12 +328,12 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
     }
     const uint8_t* ptr = p.if_base + (long long)bps * (s0 + i);
-    auto load_sample = [](const uint8_t* q) -> unsigned int {
+    auto load_sample = [](const uint8_t* q) __attribute__((always_inline)) -> unsigned int {
       if constexpr (bps == 2) return *reinterpret_cast<const unsigned short*>(q);
       else if constexpr (bps == 4) return *reinterpret_cast<const unsigned int*>(q);
       else return *q;
     };
-    auto sample_of = [](unsigned int word, float& a, float& b) {
+    auto sample_of = [](unsigned int word, float& a, float& b) __attribute__((always_inline)) {
       float x0, x1 = 0.0f;
       if constexpr (MODE == I8_IQ || MODE == I8_QI) {
         x0 = cvt_byte<0>(word);
@@ -337,20 +349,20 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       a = Fmt<MODE>::swap ? x1 : x0;
       b = Fmt<MODE>::swap ? x0 : x1;
     };
-    auto rotate_w = [&]() {
+    auto rotate_w = [&]() __attribute__((always_inline)) {
       const float nwc = fmaf(wc, rotC, -(ws * rotS));
       const float nws = fmaf(wc, rotS, ws * rotC);
       wc = nwc;
       ws = nws;
     };
-    auto mix = [&](unsigned int word, float& yr, float& yi) {
+    auto mix = [&](unsigned int word, float& yr, float& yi) __attribute__((always_inline)) {
       float a, b;
       sample_of(word, a, b);
       yr = kReal ? a * wc : fmaf(a, wc, b * ws);
       yi = kReal ? -a * ws : fmaf(b, wc, -a * ws);
     };
     // returns the entry of the last LDS arm (the one a derived arm is built from)
-    auto accumulate = [&](int x, int k, float yr, float yi) -> float {
+    auto accumulate = [&](int x, int k, float yr, float yi) __attribute__((always_inline)) -> float {
       if constexpr (AP == 1) {
         const float cf = (float)tab[kGuard + k];
         accr[0][x] = fmaf(cf, yr, accr[0][x]);
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     };
     // derived arm: padded-table entry k6 of the six-times-faster replica = entry p = (k6 + 5) / 6 of arm LA - 1 with the sign
     // (-1)^(p + k6); the quotient by a float reciprocal (exact for k6 < 2^21)
-    auto accumulate_derived = [&](int x, int k6, float yr, float yi) {
+    auto accumulate_derived = [&](int x, int k6, float yr, float yi) __attribute__((always_inline)) {
       const int pidx = (int)(((float)(k6 + 5) + 0.5f) * 0.16666667f);
       const unsigned int sgn = ((unsigned int)(pidx + k6) & 1u) << 31;
       const float cf = __uint_as_float(__float_as_uint((float)tab[(kGuard + pidx) * AP + (LA - 1)]) ^ sgn);
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     };
     // exact accumulate of one sample: MATLAB colon element i (tracking.m:252-270) in float64 — forwards from
     // a for the first half, backwards from the end point b for the second, mean of both in the exact middle
-    auto exact_sample = [&](unsigned int word, int is) {
+    auto exact_sample = [&](unsigned int word, int is) __attribute__((always_inline)) {
       float yr, yi;
       mix(word, yr, yi);
       // colon() end points b = ((N-1)*step + rem -/+ d) * R, evaluated in the reference's order
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     };
     // ramp step of one tap: table index of the CURRENT sample (high word), the low word into the running
     // min / max of the near-tie test, then Q += dQ
-    auto ramp_step = [&](int x, bool test, unsigned int& dmin, unsigned int& dmax, unsigned int& lo) -> int {
+    auto ramp_step = [&](int x, bool test, unsigned int& dmin, unsigned int& dmax, unsigned int& lo) __attribute__((always_inline)) -> int {
       const int k = (int)(unsigned int)(Q[x] >> 32);
       lo = (unsigned int)Q[x];
       if (test) {
@@ -464,87 +476,92 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         }
       }
       Q[x] += dQ;
+      asm volatile("" : "+v"(Q[x]));  // keep the ramp a chain of adds: Q + j*dQ from precomputed multiples costs a register pair per (tap, j)
       return k;
     };
 
-    auto ramp_step6 = [&](int x, unsigned int& dmin, unsigned int& dmax) -> int {
+    auto ramp_step6 = [&](int x, unsigned int& dmin, unsigned int& dmax) __attribute__((always_inline)) -> int {
       const int k = (int)(unsigned int)(Q6[x] >> 32);
       dmin = min(dmin, (unsigned int)Q6[x]);
       dmax = max(dmax, (unsigned int)Q6[x]);
       Q6[x] += dQ6;
+      asm volatile("" : "+v"(Q6[x]));
       return k;
     };
 
-    // one group: the loads of the NEXT group go out first, into the other buffer
-    auto group = [&](unsigned int (&cur)[kGRP], unsigned int (&nxt)[kGRP]) -> bool {
-      const bool more = i + (2 * kGRP - 1) * 64 < iend;
-      if (more) {
-#pragma unroll
-        for (int j = 0; j < kGRP; ++j) nxt[j] = load_sample(ptr + (long long)(kGRP + j) * bps * 64);
-      }
-      // Ramp stage for the whole group, with the near-tie test: a sample lies within e chips of a table edge
-      // iff the low word of its Q is within e*2^32 of 0 (mod 2^32).  Not measure-zero: with remCodePhase = 0
-      // and the nominal code rate (every channel's first block, tracking.m:163-165) 1.023e6/18e6 is rational
-      // and samples 3000k land exactly on edges.  Any suspect lane sends the wave's group through the exact
-      // path.  Blocks the host proved tie-free (gc_mark_tie_free, an exact search) skip the test.
-      int kg[kGRP][NT];
-      int kg6[kGRP][3];
-      unsigned int lo[kGRP];
+    // One group of GRP steps per lane.  TF (the block is tie-free, host-proved by gc_mark_tie_free's exact search): no
+    // near-tie test and no exact path, so the accumulators never meet a control-flow join inside the loop.  Otherwise the
+    // ramp stage tests the whole group: a sample lies within e chips of a table edge iff the low word of its Q is within
+    // e*2^32 of 0 (mod 2^32).  Not measure-zero: with remCodePhase = 0 and the nominal code rate (every channel's first
+    // block, tracking.m:163-165) 1.023e6/18e6 is rational and samples 3000k land exactly on edges.  Any suspect lane
+    // sends the wave's group through the exact path.
+    auto group = [&](const unsigned int (&cur)[GRP], auto tf) {
+      constexpr bool TF = decltype(tf)::value;
+      int kg[GRP][NT];
+      int kg6[GRP][3];
+      unsigned int lo[GRP];
       unsigned int dmin = 0xffffffffu, dmax = 0u;
       if constexpr (DER) {
 #pragma unroll
-        for (int j = 0; j < kGRP; ++j)
+        for (int j = 0; j < GRP; ++j)
 #pragma unroll
           for (int x = 0; x < 3; ++x) kg6[j][x] = ramp_step6(x, dmin, dmax);
       }
-      if (tie_free) {
 #pragma unroll
-        for (int j = 0; j < kGRP; ++j)
+      for (int j = 0; j < GRP; ++j)
 #pragma unroll
-          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, false, dmin, dmax, lo[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < kGRP; ++j)
-#pragma unroll
-          for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, true, dmin, dmax, lo[j]);
-      }
-      const bool suspect = !tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u));
-      if (__builtin_expect(__any(suspect) != 0, 0)) {
+        for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, !TF, dmin, dmax, lo[j]);
+      bool exact = false;
+      if constexpr (!TF) exact = __any((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)) != 0;
+      if (__builtin_expect(exact, 0)) {
 #pragma unroll 1
-        for (int j = 0; j < kGRP; ++j) {
-          exact_sample(load_sample(ptr + (long long)j * bps * 64), i + j * 64);
+        for (int j = 0; j < GRP; ++j) {
+          exact_sample(cur[j], i + j * 64);
           rotate_w();
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < kGRP; ++j) {
+        for (int j = 0; j < GRP; ++j) {
           lean_sample(cur[j], kg[j], kg6[j], lo[j]);
           rotate_w();
         }
       }
-      i += kGRP * 64;
-      ptr += (long long)kGRP * bps * 64;
-      return more;
+      i += GRP * 64;
+      ptr += (long long)GRP * bps * 64;
     };
-    unsigned int xa[kGRP], xb[kGRP];
-    bool have = i + (kGRP - 1) * 64 < iend;
-    if (have) {
+    auto load_group = [&](unsigned int (&dst)[GRP], int ahead) {
 #pragma unroll
-      for (int j = 0; j < kGRP; ++j) xa[j] = load_sample(ptr + (long long)j * bps * 64);
-    }
-    int pairs = 0;
-    while (have) {
-      have = group(xa, xb);
-      if (!have) break;
-      have = group(xb, xa);
-      // the phasor recurrence drifts by ~1 ulp per step: re-seed it from the exact float64 phase every
-      // 256 steps (matters for the 10-20 ms blocks of B1C / L2C, thousands of steps per lane)
-      if ((++pairs & 31) == 0) {
-        const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
-        sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+      for (int j = 0; j < GRP; ++j) dst[j] = load_sample(ptr + (long long)(ahead * GRP + j) * bps * 64);
+    };
+    // Whole groups first.  Their number is the same for every lane of the wave (the split's range starts on a multiple of
+    // 64 samples; only its last 64-sample step can be partial), so the loop control and the prefetch of the next group are
+    // scalar: no exec masking around the loads, no copies of the sample registers between the two buffers.
+    const int groups = __builtin_amdgcn_readfirstlane(((iend - ibeg) >> 6) / GRP);
+    // two sample buffers, one loop exit (exits from the middle of the pair made the compiler copy all accumulators into
+    // the registers the other exit expected, every group)
+    auto main_loop = [&](auto tf) __attribute__((always_inline)) {
+      unsigned int xa[GRP], xb[GRP];
+      load_group(xa, 0);
+      const int pairs = groups >> 1;
+      for (int pp = 0; pp < pairs; ++pp) {
+        load_group(xb, 1);
+        group(xa, tf);
+        if (2 * pp + 2 < groups) load_group(xa, 1);
+        group(xb, tf);
+        // the phasor recurrence drifts by ~1 ulp per step: re-seed it from the exact float64 phase every
+        // 256 steps (matters for the 10-20 ms blocks of B1C / L2C, thousands of steps per lane)
+        if ((pp & 31) == 31) {
+          const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
+          sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+        }
       }
+      if (groups & 1) group(xa, tf);
+    };
+    if (groups > 0) {
+      if (tie_free) main_loop(std::true_type{});
+      else main_loop(std::false_type{});
     }
-    // tail: fewer than kGRP samples left for this lane
+    // tail: fewer than GRP samples left for this lane
     for (; i < iend; i += 64, ptr += (long long)bps * 64) {
       const unsigned int word = load_sample(ptr);
       int k1[NT];
@@ -721,6 +738,12 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   }  // bpw loop
 }
 
+#ifdef GC_LANE_PROBE
+// ISA probe (scripts/lane_probe.sh): only the instantiations whose inner loops are being looked at
+template __global__ void corr_epl_lane_kernel<2, I8_IQ, false, 1>(const KArgs, const InlineBlocks);
+template __global__ void corr_epl_lane_kernel<3, I8_IQ, false, 0, false, true>(const KArgs, const InlineBlocks);
+}  // namespace
+#else
 template <typename K>
 void launch_one(gc_context* ctx, K kernel, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem) {
   if (smem > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
@@ -849,3 +872,5 @@ int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBl
     default: return launch_mode<3>(ctx, a, ib, dim3(grid), smem, tabkind);
   }
 }
+
+#endif  // GC_LANE_PROBE
