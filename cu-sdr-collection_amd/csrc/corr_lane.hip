@@ -322,6 +322,17 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       }
     }
     (void)Q6;
+    // The three taps' ramps differ by block-uniform amounts (the same lane offset was subtracted from each): ONE ramp per
+    // set stays in vector registers, the prompt and late values are that plus a scalar pair
+    auto uni64 = [](unsigned long long u) __attribute__((always_inline)) -> unsigned long long {
+      return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+             (unsigned int)__builtin_amdgcn_readfirstlane((int)u);
+    };
+    unsigned long long Q0 = Q[0], Q60 = Q6[0];
+    const unsigned long long dTap[3] = {0ull, uni64(Q[NT > 1 ? 1 : 0] - Q[0]), uni64(Q[NT - 1] - Q[0])};
+    const unsigned long long dTap6[3] = {0ull, uni64(Q6[DER ? 1 : 0] - Q6[0]), uni64(Q6[DER ? 2 : 0] - Q6[0])};
+    (void)dTap6;
+    (void)Q60;
     float wc, ws;  // exp(-i*theta_i) = wc - i*ws
     {
       const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
@@ -464,29 +475,40 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     };
     // ramp step of one tap: table index of the CURRENT sample (high word), the low word into the running
     // min / max of the near-tie test, then Q += dQ
-    auto ramp_step = [&](int x, bool test, unsigned int& dmin, unsigned int& dmax, unsigned int& lo) __attribute__((always_inline)) -> int {
-      const int k = (int)(unsigned int)(Q[x] >> 32);
-      lo = (unsigned int)Q[x];
-      if (test) {
-        dmin = min(dmin, lo);
-        dmax = max(dmax, lo);
-        if constexpr (kHalf) {  // the prompt ramp crosses an entry where the early ramp's fraction passes 1/2
-          dmin = min(dmin, lo ^ 0x80000000u);
-          dmax = max(dmax, lo ^ 0x80000000u);
+    // ramp step of all taps: table index of the CURRENT sample (high word), the low word into the running min / max of the
+    // near-tie test, then Q0 += dQ
+    auto ramp_step = [&](int (&k)[NT], bool test, unsigned int& dmin, unsigned int& dmax, unsigned int& lo) __attribute__((always_inline)) {
+#pragma unroll
+      for (int x = 0; x < NT; ++x) {
+        const unsigned long long q = x == 0 ? Q0 : Q0 + dTap[NT == 3 ? x : 0];
+        k[x] = (int)(unsigned int)(q >> 32);
+        const unsigned int l = (unsigned int)q;
+        if (x == 0) lo = l;
+        if (test) {
+          dmin = min(dmin, l);
+          dmax = max(dmax, l);
+          if constexpr (kHalf) {  // the prompt ramp crosses an entry where the early ramp's fraction passes 1/2
+            dmin = min(dmin, l ^ 0x80000000u);
+            dmax = max(dmax, l ^ 0x80000000u);
+          }
         }
       }
-      Q[x] += dQ;
-      asm volatile("" : "+v"(Q[x]));  // keep the ramp a chain of adds: Q + j*dQ from precomputed multiples costs a register pair per (tap, j)
-      return k;
+      Q0 += dQ;
+      asm volatile("" : "+v"(Q0));  // keep the ramp a chain of adds: Q + j*dQ from precomputed multiples costs a register pair per j
     };
 
-    auto ramp_step6 = [&](int x, unsigned int& dmin, unsigned int& dmax) __attribute__((always_inline)) -> int {
-      const int k = (int)(unsigned int)(Q6[x] >> 32);
-      dmin = min(dmin, (unsigned int)Q6[x]);
-      dmax = max(dmax, (unsigned int)Q6[x]);
-      Q6[x] += dQ6;
-      asm volatile("" : "+v"(Q6[x]));
-      return k;
+    auto ramp_step6 = [&](int (&k)[3], bool test, unsigned int& dmin, unsigned int& dmax) __attribute__((always_inline)) {
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const unsigned long long q = x == 0 ? Q60 : Q60 + dTap6[x];
+        k[x] = (int)(unsigned int)(q >> 32);
+        if (test) {
+          dmin = min(dmin, (unsigned int)q);
+          dmax = max(dmax, (unsigned int)q);
+        }
+      }
+      Q60 += dQ6;
+      asm volatile("" : "+v"(Q60));
     };
 
     // One group of GRP steps per lane.  TF (the block is tie-free, host-proved by gc_mark_tie_free's exact search): no
@@ -503,14 +525,10 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       unsigned int dmin = 0xffffffffu, dmax = 0u;
       if constexpr (DER) {
 #pragma unroll
-        for (int j = 0; j < GRP; ++j)
-#pragma unroll
-          for (int x = 0; x < 3; ++x) kg6[j][x] = ramp_step6(x, dmin, dmax);
+        for (int j = 0; j < GRP; ++j) ramp_step6(kg6[j], !TF, dmin, dmax);
       }
 #pragma unroll
-      for (int j = 0; j < GRP; ++j)
-#pragma unroll
-        for (int x = 0; x < NT; ++x) kg[j][x] = ramp_step(x, !TF, dmin, dmax, lo[j]);
+      for (int j = 0; j < GRP; ++j) ramp_step(kg[j], !TF, dmin, dmax, lo[j]);
       bool exact = false;
       if constexpr (!TF) exact = __any((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)) != 0;
       if (__builtin_expect(exact, 0)) {
@@ -567,12 +585,8 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       int k1[NT];
       int k16[3] = {0, 0, 0};
       unsigned int dmin = 0xffffffffu, dmax = 0u, lo1 = 0u;
-#pragma unroll
-      for (int x = 0; x < NT; ++x) k1[x] = ramp_step(x, true, dmin, dmax, lo1);
-      if constexpr (DER) {
-#pragma unroll
-        for (int x = 0; x < 3; ++x) k16[x] = ramp_step6(x, dmin, dmax);
-      }
+      ramp_step(k1, true, dmin, dmax, lo1);
+      if constexpr (DER) ramp_step6(k16, true, dmin, dmax);
       if (!tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)))
         exact_sample(word, i);
       else
