@@ -164,6 +164,14 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
       if (std::getenv("GC_REPLAY_BPW")) a.bpw = std::max(kLaneWaves, want_bpw / kLaneWaves * kLaneWaves);
       a.stride = period;
       total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
+      if (total < 2LL * ctx->compute_units && nblocks > total && !std::getenv("GC_REPLAY_BPW")) {
+        // few, long blocks (two BDS B1C channels, 10-ms epochs: 996 blocks would make 32 workgroups): one block per
+        // workgroup, split over its 16 waves, fills the device; the table is staged per block instead of per 16-32 blocks
+        a.bpw = 1;
+        a.stride = 1;
+        a.wide = 1;
+        total = nblocks;
+      }
     } else if (splits == 1) {
       a.wide = 1;  // one block per workgroup, split over its 16 waves in-kernel
       total = nblocks;

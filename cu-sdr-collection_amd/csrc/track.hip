@@ -389,8 +389,6 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     ctx->launch_derived = derived;
     int fast = derived ? 0 : any_mixed ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
     for (int k = 0; k < nb && fast > 0; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
-    // exact host-side search for samples on a table edge (a few hundred ns per block): clean blocks skip the kernels' own test
-    gc_mark_tie_free(ctx, blocks, nb, fast > 0 ? 8e-6 : 0.0);
     bool share = true;
     for (int k = 0; k < nb && share; ++k) share = gc_block_shares_el(ctx, blocks[k]);
     ctx->scope_share_lane = true;
