@@ -1,0 +1,230 @@
+function acqResults = gnsscorr_acquisition_shift(longSignal, settings, name)
+%GNSSCORR_ACQUISITION_SHIFT  acqResults = acquisition(longSignal, settings) of the packages whose Doppler bins are circular
+%   shifts of ONE signal spectrum - BDS B1I, GPS L2C, BDS B1C (SURVEY.md section 8a row A5) - with the transforms on an MI355X.
+%   Same arguments and result as the package's include/acquisition.m (resampling off), so postProcessing.m:100 is called
+%   unchanged.  The GPU mixes the signal block(s) with the package's carriers and transforms them once ('acq_shift_prepare'),
+%   then forms every bin of a PRN as a shifted product with the code spectrum inside the inverse transform and returns each
+%   result row's maximum and its first position ('acq_shift_search'); the packages' selection rules (which row wins, the
+%   second-peak exclusion range, thresholds, the CL segment search, B1C's 25-Hz fine search) are a few hundred operations on
+%   those maxima and on the one winning row ('acq_shift_row') and stay here.
+%   Written for this repository; not a copy of any reference file.
+
+x = [real(longSignal); imag(longSignal)];
+x = x(:).';
+if any(x ~= round(x)) || max(abs(x)) > 127
+    error('gnsscorr:acquisition', 'longSignal does not hold integer int8 sample values');
+end
+h = gnsscorr_context('longSignal', 'new');
+gnsscorr_mex('load_if', h, int8(x), 2, settings.samplingFreq);
+nLong = numel(longSignal);
+switch name
+    case 'BDS_B1I', acqResults = b1i(h, settings);
+    case 'GPS_L2C', acqResults = l2c(h, settings);
+    case 'BDS_B1C', acqResults = b1c(h, settings, nLong);
+    otherwise, error('gnsscorr:acquisition', 'package %s is not served by this wrapper', name);
+end
+end
+
+%---------------------------------------------------------------------------------------------------------------------------
+function t = sampled(code, k, ts, tc, last, firstOne)
+% code(ceil(ts*k/tc)) with the end points the packages' table makers force
+idx = ceil(ts * k / tc);
+if firstOne, idx(1) = 1; end
+if last > 0, idx(end) = last; end
+t = code(idx);
+end
+
+function s = secondPeak(corr, codePhase, exclude, period)
+% largest value of one code period outside +-exclude samples of the peak; the three range cases of
+% BDS/B1I acquisition.m:141-156 and GPS_L2C acquisition.m:77-91
+e1 = codePhase - exclude;  e2 = codePhase + exclude;
+if e1 < 2
+    rng = e2:(period + e1);
+elseif e2 >= period
+    rng = (e2 - period + 1):e1;
+else
+    rng = [1:e1, e2:period];
+end
+s = max(corr(rng));
+end
+
+function [best, freqShift, binIdx] = sequentialBest(rmax, nShifts, nSignals, nBins)
+% The packages walk shift by shift and bin by bin and keep a running maximum (BDS/B1I acquisition.m:87-122, GPS_L2C :46-66);
+% the last bin is skipped for every shift but the first.  rmax: the row maxima in the library's order
+% ((shift * nSignals + signal) * nBins + bin); best = [shift signal bin] (1-based) or [].
+prevMax = 0;  best = [];  freqShift = 0;  binIdx = 0;
+for it = 1:nShifts
+    for b = 1:nBins
+        if b == nBins && it > 1, continue; end
+        if nSignals == 2
+            p1 = rmax((it - 1) * 2 * nBins + b);  p2 = rmax(((it - 1) * 2 + 1) * nBins + b);
+            if p1 > prevMax || p2 > prevMax
+                if p1 > p2
+                    prevMax = p1;  best = [it 1 b];
+                else
+                    prevMax = p2;  best = [it 2 b];
+                end
+                freqShift = it;  binIdx = b;
+            end
+        elseif rmax((it - 1) * nBins + b) > prevMax
+            prevMax = rmax((it - 1) * nBins + b);  best = [it 1 b];
+            freqShift = it;  binIdx = b;
+        end
+    end
+end
+end
+
+%---------------------------------------------------------------------------------------------------------------------------
+function acqResults = b1i(h, settings)
+% BDS/B1I/include/acquisition.m: two 4-ms signal blocks, Nshifts interleaved carriers, the 2-code replica zero-padded
+Ncodes = 2;  Nblocks = 4;                                                                  % :34-35
+fs = settings.samplingFreq;  ts = 1 / fs;
+spb = round(fs / (settings.codeFreqBasis / (Nblocks * settings.codeLength)));               % :36-37
+freqRes = fs / spb;                                                                         % :43
+nBins = round(settings.acqSearchBand * 1e3 / freqRes) + 1;                                  % :44
+if ~isfield(settings, 'stepSize') || isempty(settings.stepSize)                             % :46-59
+    stepSize = 0.5 / (Nblocks * settings.codeLength / settings.codeFreqBasis);
+elseif settings.stepSize == freqRes
+    stepSize = settings.stepSize;
+else
+    cand = 1:0.25:freqRes / 2;
+    cand = cand(rem(freqRes, cand) == 0);
+    d = cand - settings.stepSize;
+    [~, m] = min(abs(d));
+    if d(m) > 0, stepSize = cand(m - 1); else, stepSize = cand(m); end
+end
+nShifts = freqRes / stepSize;                                                               % :61
+spc2 = round(fs / (settings.codeFreqBasis / (Ncodes * settings.codeLength)));               % makeCaTableDMA.m
+initFreq = settings.IF + (settings.acqSearchBand / 2) * 1000;                               % :66
+q.samplingFreq = fs;  q.carrierF0 = initFreq;  q.carrierStep = freqRes / nShifts;  q.firstSample = 0;
+q.samplesPerBlock = spb;  q.nSignals = 2;  q.nCarriers = nShifts;  q.nBins = nBins;  q.nArmsMax = 1;
+nRows = gnsscorr_mex('acq_shift_prepare', h, q);
+acqResults.carrFreq = zeros(1, 58);  acqResults.codePhase = zeros(1, 58);  acqResults.peakMetric = zeros(1, 58);
+chip = round(fs / settings.codeFreqBasis);                                                  % :139
+for PRN = settings.acqSatelliteList
+    ca = generateCAcode53(PRN);
+    table = sampled([ca ca], 1:spc2, ts, 1 / settings.codeFreqBasis, Ncodes * 2046, false);
+    local = [table, zeros(1, spb / Ncodes)];                                                % :86
+    rmax = double(gnsscorr_mex('acq_shift_search', h, int8(local(:)), [], nRows));
+    [best, freqShift, binIdx] = sequentialBest(rmax, nShifts, 2, nBins);
+    if isempty(best), continue; end
+    corr = double(gnsscorr_mex('acq_shift_row', h, ((best(1) - 1) * 2 + best(2) - 1) * nBins + best(3) - 1, spb));
+    [maxPeak, codePhase] = max(corr);                                                       % :126
+    second = secondPeak(corr, codePhase, chip, spb / Nblocks);
+    acqResults.peakMetric(PRN) = maxPeak / second;                                          % :160
+    if maxPeak / second > settings.acqThreshold                                             % :163
+        acqResults.codePhase(PRN) = codePhase;
+        acqResults.carrFreq(PRN) = initFreq - freqRes * (binIdx - 1) + (freqRes / nShifts) * (freqShift - 1);   % :168
+    end
+end
+end
+
+%---------------------------------------------------------------------------------------------------------------------------
+function acqResults = l2c(h, settings)
+% GPS/GPS_L2C/include/acquisition.m: CM search over a 40-ms block, then (pilot on) which of the 75 CL segments it lies in
+Nblocks = 2;                                                                                % :13
+fs = settings.samplingFreq;  ts = 1 / fs;
+spc = round(fs / (settings.codeFreqBasis / settings.codeLength));                           % :14-15
+chip = round(fs / settings.codeFreqBasis);                                                  % :16
+spb = spc * Nblocks;                                                                        % :17
+freqRes = fs / spb;                                                                         % :22
+nBins = round(settings.acqSearchBand * 1e3 / freqRes) + 1;                                  % :23
+nShifts = freqRes / settings.acqStep;                                                       % :25
+initFreq = settings.IF + (settings.acqSearchBand / 2) * 1000;                               % :33
+q.samplingFreq = fs;  q.carrierF0 = initFreq;  q.carrierStep = -(freqRes / nShifts);  q.firstSample = 0;
+q.samplesPerBlock = spb;  q.nSignals = 1;  q.nCarriers = nShifts;  q.nBins = nBins;  q.nArmsMax = 1;
+nRows = gnsscorr_mex('acq_shift_prepare', h, q);
+acqResults.carrFreq = zeros(1, 32);  acqResults.codePhase = zeros(1, 32);  acqResults.peakMetric = zeros(1, 32);
+tc = 1 / (settings.codeFreqBasis * 2);
+for PRN = settings.acqSatelliteList
+    cm = generateCMcode(PRN, settings);
+    table = sampled(cm, 0:spc - 1, ts, tc, settings.codeLength * 2, true);                  % makeCMTable.m
+    local = [table, zeros(1, spc)];                                                         % :44
+    rmax = double(gnsscorr_mex('acq_shift_search', h, int8(local(:)), [], nRows));
+    [best, freqShift, binIdx] = sequentialBest(rmax, nShifts, 1, nBins);
+    if isempty(best), continue; end
+    corr = double(gnsscorr_mex('acq_shift_row', h, (best(1) - 1) * nBins + best(3) - 1, spb));
+    [maxPeak, codePhase] = max(corr);                                                       % :72
+    second = secondPeak(corr, codePhase, chip, spb / Nblocks);
+    acqResults.peakMetric(PRN) = maxPeak / second;                                          % :94
+    if maxPeak / second > settings.acqThreshold                                             % :97
+        carr = initFreq - freqRes * (binIdx - 1) - (freqRes / nShifts) * (freqShift - 1);   % :101
+        acqResults.carrFreq(PRN) = carr;
+        acqResults.codePhase(PRN) = codePhase;
+        if settings.pilotTRKflag == 1                                                       % :140-166: 75 one-period correlations
+            raw = double(gnsscorr_mex('read_if', h, codePhase - 1, spc, 'int8', 2));
+            sig = raw(1:2:end) + 1i * raw(2:2:end);
+            sig = sig - mean(sig);
+            carrier = exp(-1i * carr * ((0:spc - 1) * 2 * pi * ts));
+            cl = generateCLcode(PRN, settings);
+            idx = ceil(ts * (0:spc - 1) / tc);
+            idx(1) = 1;
+            if settings.acqCohT <= 10, idx(end) = settings.codeLength; else, idx(end) = settings.codeLength * 2; end
+            power = zeros(1, 75);
+            for ind = 1:75
+                power(ind) = abs(sum(sig .* cl(idx + settings.codeLength * 2 * (ind - 1)) .* carrier));
+            end
+            [~, seg] = max(power);
+            acqResults.CLCodePhase(PRN) = seg;                                              % :165 (the field grows to the highest PRN found)
+        end
+    end
+end
+end
+
+%---------------------------------------------------------------------------------------------------------------------------
+function acqResults = b1c(h, settings, nLong)
+% BDS/B1C/include/acquisition.m: one (10 + acqCohT)-ms spectrum, bins as shifts, data and pilot BOC(1,1) replicas combined
+% sqrt(11):sqrt(29), metric peak/sigPower, 25-Hz fine search over one code period
+fs = settings.samplingFreq;  ts = 1 / fs;
+spc = round(fs / (settings.codeFreqBasis / settings.codeLength));                           % :108-109
+xLen = round(spc / 10 * settings.acqCohT);                                                  % :111
+n = round(spc / 10 * (10 + settings.acqCohT));                                              % :113
+nBins = round(settings.acqSearchBand * 2 / settings.acqStep) + 1;                           % :120
+pilot = settings.pilotACQflag == 1;
+fineStep = 25;  nFine = round(settings.acqStep / 25) * 2 + 1;                                % :129-130
+raw = double(gnsscorr_mex('read_if', h, 0, xLen, 'int8', 2));
+sigPower = sqrt(var(raw(1:2:end) + 1i * raw(2:2:end)) * xLen);                              % :138
+initFreq = settings.IF + settings.acqSearchBand;                                            % :141
+q.samplingFreq = fs;  q.carrierF0 = initFreq;  q.carrierStep = 0;  q.firstSample = 0;
+q.samplesPerBlock = n;  q.nSignals = 1;  q.nCarriers = 1;  q.nBins = nBins;  q.nArmsMax = 2;
+nRows = gnsscorr_mex('acq_shift_prepare', h, q);
+nMax = max(settings.acqSatelliteList);
+acqResults.carrFreq = zeros(1, nMax);  acqResults.codePhase = zeros(1, nMax);  acqResults.peakMetric = zeros(1, nMax);
+tc = 1 / settings.codeFreqBasis / 2;
+finePhase = (0:spc - 1) * 2 * pi * ts;
+for PRN = settings.acqSatelliteList
+    dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);   % makeDataTable.m
+    arms = [dtab(1:xLen), zeros(1, n - xLen)].';                                            % :155-156
+    w = [];
+    if pilot
+        ptab = sampled(generatePilotBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);
+        arms = [arms, [ptab(1:xLen), zeros(1, n - xLen)].'];
+        w = [sqrt(11) / sqrt(40), sqrt(29) / sqrt(40)];                                     % :186-187
+    end
+    [rmax, rarg] = gnsscorr_mex('acq_shift_search', h, int8(arms), w, nRows);
+    rmax = double(rmax);  rarg = double(rarg);
+    [peak, binIdx] = max(rmax);                                                             % :193 max(max(results, [], 2))
+    selFreq = initFreq - (binIdx - 1) * settings.acqStep;                                   % :194
+    codePhase = min(rarg(rmax == peak)) + 1;                                                % [~, codePhase] = max(max(results))
+    acqResults.peakMetric(PRN) = peak / sigPower;                                           % :199
+    if codePhase + spc - 1 > nLong, codePhase = codePhase - spc; end                        % :232-234
+    if acqResults.peakMetric(PRN) > settings.acqThreshold
+        raw = double(gnsscorr_mex('read_if', h, codePhase - 1, spc, 'int8', 2));
+        s0 = raw(1:2:end) + 1i * raw(2:2:end);
+        xc = s0 .* dtab;
+        if pilot, xp = s0 .* ptab; end
+        fine = zeros(1, nFine);  freqs = zeros(1, nFine);
+        for k = 1:nFine                                                                     % :242-250
+            freqs(k) = selFreq + settings.acqStep - fineStep * (k - 1);
+            c = exp(-1i * freqs(k) * finePhase);
+            fine(k) = abs(sum(xc .* c));
+            if pilot, fine(k) = (fine(k) * 11 + abs(sum(xp .* c)) * 29) / 40; end
+        end
+        [~, m] = max(fine);
+        carr = freqs(m);
+        if carr == 0, carr = 1; end                                                         % :253-255
+        acqResults.carrFreq(PRN) = carr;
+        acqResults.codePhase(PRN) = codePhase;
+    end
+end
+end
