@@ -50,6 +50,14 @@ class gc_channel_init(C.Structure):
                 ("code_freq", C.c_double), ("code_phase", C.c_int64), ("table_phase", C.c_int32), ("reserved", C.c_int32)]
 
 
+class gc_channel_state(C.Structure):
+    """What tracking.m keeps between two blocks of a channel (include/gnsscorr.h: gc_track_resume / gc_track_file)."""
+    _fields_ = [("next_sample", C.c_int64), ("code_freq", C.c_double), ("rem_code_phase", C.c_double), ("carr_freq", C.c_double),
+                ("rem_carr_phase", C.c_double), ("old_code_nco", C.c_double), ("old_code_error", C.c_double),
+                ("old_carr_nco", C.c_double), ("old_carr_error", C.c_double), ("d_carr_error", C.c_double),
+                ("d2_carr_error", C.c_double), ("table_phase", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int64)]
+
+
 class gc_track_job(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("params", C.POINTER(gc_track_params)), ("init", C.POINTER(gc_channel_init)),
                 ("out", C.POINTER(C.c_double)), ("epochs_done", C.POINTER(C.c_int32)), ("nch", C.c_int32),
@@ -110,6 +118,10 @@ SYMBOLS = {
                            C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "gc_track_device": (C.c_int, [_P, C.POINTER(gc_track_params), C.c_int, C.POINTER(gc_channel_init),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "gc_track_resume": (C.c_int, [_P, C.POINTER(gc_track_params), C.c_int, C.POINTER(gc_channel_init), C.POINTER(gc_channel_state),
+                                  C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gc_track_file": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.POINTER(gc_track_params), C.c_int,
+                                C.POINTER(gc_channel_init), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "gc_share_if": (C.c_int, [_P, _P]),
     "gc_track_multi": (C.c_int, [C.c_int, C.POINTER(gc_track_job)]),
     "gc_acquire_coarse": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(gc_acq_result)]),

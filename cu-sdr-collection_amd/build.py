@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
 LIBS = {
-    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_lane.hip", "track.hip", "multi.hip", "acq.hip", "navsync.hip"],
+    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_lane.hip", "track.hip", "multi.hip", "stream.hip", "acq.hip", "navsync.hip"],
     "libgnsssynth.so": ["synth.hip"],
 }
 HEADERS = ["gc_internal.h", "corr_common.h", "devloop.h", os.path.join("..", "..", "include", "gnsscorr.h")]

@@ -171,6 +171,17 @@ inline hipError_t gc_launch_persistent(const gc_context* ctx, const void* fn, di
               : hipLaunchKernel(fn, grid, block, args, smem, ctx->stream);
 }
 
+// gc_track over one window of a record (gc_track_resume / gc_track_file, track.hip + stream.hip)
+struct GcTrackResume {
+  gc_channel_state* state = nullptr;  // [nch] in (resume) / out
+  bool resume = false;                // state holds the end state of the previous window
+  bool pause_at_end = false;          // more of the record follows this window
+  int64_t origin = 0;                 // record index of the IF buffer's first sample
+  bool paused = false;                // out: stopped because a block did not fit this window
+};
+int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init, double* out,
+                    int32_t* epochs_done, GcTrackResume* r);
+
 int gc_bytes_per_sample(int dtype, int layout);
 void gc_acq_free(gc_context* ctx);  // acq.hip
 int gc_sync_channels(gc_context* ctx);

@@ -82,7 +82,17 @@ int validate_track_channel(const gc_context* ctx, const gc_track_params* p, cons
 
 extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
                         double* out, int32_t* epochs_done) {
-  if (!ctx || !p || nch <= 0 || nch > GC_MAX_CHANNELS || !init || !out || !epochs_done || p->n_epochs <= 0) {
+  return gc_track_window(ctx, p, nch, init, out, epochs_done, nullptr);
+}
+
+// gc_track over one window of a record (GcTrackResume, gc_internal.h): channel state comes from / goes back to r->state,
+// positions there count from the start of the RECORD (the IF buffer holds its samples from r->origin on), and with
+// r->pause_at_end the call stops every channel, in lock step, at the first epoch whose block one of them cannot read from
+// this window - more of the record follows - instead of ending that channel (tracking.m:241-245 is the END of the file).
+int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init, double* out,
+                    int32_t* epochs_done, GcTrackResume* r) {
+  if (r) r->paused = false;
+  if (!ctx || !p || nch <= 0 || nch > GC_MAX_CHANNELS || !init || !out || !epochs_done || p->n_epochs <= 0 || (r && !r->state)) {
     gc_set_error("gc_track: bad arguments");
     return GC_E_INVALID;
   }
@@ -341,13 +351,46 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
     s.table_phase = init[c].table_phase;
     s.code_freq = s.code_freq_basis = init[c].code_freq;  // :163 / GPS_L5C :165
     s.carr_freq = s.carr_basis = init[c].acquired_freq;   // :167-168
+    if (r && r->resume) {  // continue where the previous window stopped
+      const gc_channel_state& g = r->state[c];
+      s.active = g.status == 0;
+      s.aborted = g.status == 2;
+      s.pos = g.next_sample - r->origin;
+      s.code_freq = g.code_freq;
+      s.rem_code = g.rem_code_phase;
+      s.carr_freq = g.carr_freq;
+      s.rem_carr = g.rem_carr_phase;
+      s.old_code_nco = g.old_code_nco;
+      s.old_code_err = g.old_code_error;
+      s.old_carr_nco = g.old_carr_nco;
+      s.old_carr_err = g.old_carr_error;
+      s.d_carr_err = g.d_carr_error;
+      s.d2_carr_err = g.d2_carr_error;
+      s.table_phase = g.table_phase;
+    }
   }
+  const int64_t origin = r ? r->origin : 0;
 
   std::vector<int> slot((size_t)nch);
   bool any_range = false, any_diverged = false;
   double t_launch = 0.0, t_wait = 0.0;  // GC_TRACK_TIMING: host time in the launch call / until the records arrived
   const auto t_loop0 = std::chrono::steady_clock::now();
   for (int e = 0; e < n_epochs; ++e) {
+    if (r && r->pause_at_end) {
+      bool fits = true;
+      for (int c = 0; c < nch && fits; ++c) {
+        const ChanState& s = st[c];
+        if (!s.active) continue;
+        const double step = s.code_freq / p->sampling_freq;
+        if (!(step > 0.0) || !(step < 1e6)) continue;  // handled below (diverged NCO)
+        const int n = (int)std::ceil((p->code_length - s.rem_code) / step);
+        fits = s.pos >= 0 && (uint64_t)(s.pos + n) <= ctx->if_nsamples;
+      }
+      if (!fits) {
+        r->paused = true;
+        break;
+      }
+    }
     int nb = 0;
     for (int c = 0; c < nch; ++c) {
       ChanState& s = st[c];
@@ -464,7 +507,7 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
       double* o = out + (size_t)c * GC_TRK_NFIELDS * n_epochs;
       auto rec = [&](int f, double v) { o[(size_t)f * n_epochs + e] = v; };
-      rec(GC_TRK_ABSOLUTE_SAMPLE, (double)s.pos);  // :212-216
+      rec(GC_TRK_ABSOLUTE_SAMPLE, (double)(s.pos + origin));  // :212-216
       rec(GC_TRK_REM_CODE_PHASE, s.rem_code);      // :249
       rec(GC_TRK_REM_CARR_PHASE, s.rem_carr);      // :277
       const int n = b.blksize;
@@ -596,6 +639,26 @@ extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, cons
       epochs_done[c] = 0;
     } else {
       epochs_done[c] = st[c].epochs;
+    }
+  }
+  if (r) {
+    for (int c = 0; c < nch; ++c) {
+      const ChanState& s = st[c];
+      gc_channel_state& g = r->state[c];
+      g.next_sample = s.pos + origin;
+      g.code_freq = s.code_freq;
+      g.rem_code_phase = s.rem_code;
+      g.carr_freq = s.carr_freq;
+      g.rem_carr_phase = s.rem_carr;
+      g.old_code_nco = s.old_code_nco;
+      g.old_code_error = s.old_code_err;
+      g.old_carr_nco = s.old_carr_nco;
+      g.old_carr_error = s.old_carr_err;
+      g.d_carr_error = s.d_carr_err;
+      g.d2_carr_error = s.d2_carr_err;
+      g.table_phase = s.table_phase;
+      g.status = s.aborted ? 2 : 0;
+      g.reserved = 0;
     }
   }
   const bool persist_was = persist;

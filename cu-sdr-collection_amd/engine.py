@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -176,6 +177,38 @@ class Engine:
             L.check(st)
         fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
         return fields, np.array(list(done)), st
+
+    def track_resume(self, params: L.gc_track_params, inits, state=None, origin: int = 0, pause_at_end: bool = False):
+        """gc_track_resume on the window currently loaded (its first sample = record sample `origin`): continues from `state`
+        (a ctypes array of gc_channel_state from a previous call; None starts from `inits`).
+        Returns (fields, epochs_done, status, state, paused)."""
+        nch = len(inits)
+        arr = (L.gc_channel_init * nch)(*inits)
+        flags = (1 if state is not None else 0) | (2 if pause_at_end else 0)
+        if state is None:
+            state = (L.gc_channel_state * nch)()
+        out = np.zeros((nch, L.GC_TRK_NFIELDS, params.n_epochs))
+        done = (C.c_int32 * nch)()
+        paused = C.c_int32(0)
+        st = self._lib.gc_track_resume(self._ctx, C.byref(params), nch, arr, state, flags, int(origin),
+                                       out.ctypes.data_as(C.POINTER(C.c_double)), done, C.byref(paused))
+        if st not in (L.GC_OK, L.GC_E_RANGE):
+            L.check(st)
+        return {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}, np.array(list(done)), st, state, bool(paused.value)
+
+    def track_file(self, path: str, params: L.gc_track_params, inits, window_samples: int, dtype: int = L.GC_I8,
+                   layout: int = L.GC_IQ, skip_bytes: int = 0):
+        """gc_track_file: tracking(fid, channel, settings) on a file of any size, at most 2 * window_samples samples resident
+        (the next window is read and uploaded while the current one is tracked).  Returns as track()."""
+        nch = len(inits)
+        arr = (L.gc_channel_init * nch)(*inits)
+        out = np.zeros((nch, L.GC_TRK_NFIELDS, params.n_epochs))
+        done = (C.c_int32 * nch)()
+        st = self._lib.gc_track_file(self._ctx, os.fsencode(path), int(skip_bytes), int(dtype), int(layout), int(window_samples),
+                                     C.byref(params), nch, arr, out.ctypes.data_as(C.POINTER(C.c_double)), done)
+        if st not in (L.GC_OK, L.GC_E_RANGE):
+            L.check(st)
+        return {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}, np.array(list(done)), st
 
     @staticmethod
     def track_multi(jobs, device_loop: bool = False):

@@ -330,6 +330,23 @@ def tracking(fid: Engine, channel, settings, signal: str = "GPS_L1CA", device_lo
     return _tracking_finish(job, fields, done, status)
 
 
+def tracking_file(fid: Engine, path: str, channel, settings, window_samples: int, signal: str = "GPS_L1CA", pilot_fields: str | None = None):
+    """tracking(fid, channel, settings) on a record FILE that need not fit the device: at most 2 * window_samples samples are
+    resident at any time (include/gnsscorr.h gc_track_file: two alternating device windows, the next one read and uploaded
+    while the current one is tracked).  The reference freads block by block (tracking.m:226-245) and so handles any file
+    length; results are identical to tracking() on the fully loaded record.  settings.fileType / dataType / the package's
+    sample order say how the file is laid out, as in postProcessing.m:59-96."""
+    job = _tracking_prepare(fid, channel, settings, signal, pilot_fields)
+    if not job.active:
+        return job.results, channel
+    dtype = L.GC_I16 if str(settings.dataType) == "int16" else L.GC_I8
+    # GLONASS front ends deliver Q first (GLO_GL1/include/tracking.m:227)
+    layout = L.GC_REAL if settings.fileType == 1 else (L.GC_QI if signal.startswith("GLO_") else L.GC_IQ)
+    fid.set_sampling_freq(settings.samplingFreq)
+    fields, done, status = fid.track_file(path, job.p, job.inits, int(window_samples), dtype=dtype, layout=layout)
+    return _tracking_finish(job, fields, done, status)
+
+
 def tracking_multi(calls, device_loop: bool = False, pilot_fields: str | None = None):
     """Several packages' tracking() at once (BASELINE config 5, include/gnsscorr.h gc_track_multi):
     calls = [(fid, channel, settings, signal), ...] with one Engine per call - engines that read the same record share it

@@ -210,6 +210,36 @@ enum gc_track_field {
 int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
              double* out, int32_t* epochs_done);
 
+/* ---- records larger than the device: tracking window by window ------------------------------------------------------
+ * tracking.m reads its file block by block (fread at :226-245) and so handles a record of any length
+ * (postProcessing.m:61-96 never loads it whole).  gc_track works on the resident IF buffer; these two entry points carry a
+ * channel's loop state from one window of the record to the next. */
+typedef struct gc_channel_state {   /* what tracking.m keeps in its local variables between two blocks of a channel */
+  int64_t next_sample;       /* first sample of the next block, counted from the start of the RECORD (ftell/dataAdaptCoeff) */
+  double code_freq, rem_code_phase;        /* codeFreq, remCodePhase (:219,273) */
+  double carr_freq, rem_carr_phase;        /* carrFreq, remCarrPhase (:283,317) */
+  double old_code_nco, old_code_error;     /* oldCodeNco, oldCodeError (:326-330) */
+  double old_carr_nco, old_carr_error;     /* oldCarrNco, oldCarrError (:308-312) */
+  double d_carr_error, d2_carr_error;      /* third-order PLL integrators (GPS_L5C tracking.m:351-353) */
+  int32_t table_phase;       /* CLCodePhase (GPS_L2C) */
+  int32_t status;            /* 0 running, 2 the record ended inside this channel's next block (tracking.m:241-245) */
+  int64_t reserved;
+} gc_channel_state;
+#define GC_TRACK_RESUME 1        /* `state` holds the end state of the previous window (else it is only written) */
+#define GC_TRACK_PAUSE_AT_END 2  /* more of the record follows: stop all channels, in lock step, at the first epoch one of
+                                    them cannot read from this window (*paused = 1) instead of ending that channel */
+/* gc_track on the window currently in the IF buffer, whose first sample is sample `origin` of the record.  Runs at most
+ * p->n_epochs epochs from the given state; `out` / `epochs_done` count from this call's first epoch; absoluteSample is
+ * recorded in record coordinates. */
+int gc_track_resume(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
+                    gc_channel_state* state, int flags, int64_t origin, double* out, int32_t* epochs_done,
+                    int32_t* paused);
+/* tracking(fid, channel, settings) on a file of any size: the record is read in windows of `window_samples` samples into two
+ * device buffers (the next window's read + upload runs while the current one is tracked: at most 2 * window_samples
+ * samples are resident), results as gc_track's.  `skip_bytes`: file offset of record sample 0.  Host-closed loop. */
+int gc_track_file(gc_context* ctx, const char* path, uint64_t skip_bytes, int dtype, int layout, uint64_t window_samples,
+                  const gc_track_params* p, int nch, const gc_channel_init* init, double* out, int32_t* epochs_done);
+
 /* As gc_track, with the loop closed ON THE DEVICE: one persistent cooperative launch runs every
  * epoch; the workgroups sharing a channel exchange self-validating 16-byte {payload, epoch tag} messages (no atomics,
  * no fences) and execute tracking.m:302-335 in float64 themselves (csrc/devloop.h).  Covered: int8 I/Q or Q/I records;

@@ -75,6 +75,52 @@ static void fill_acq(const mxArray* s, gc_acq_params* p) {
   p->first_sample = (int64_t)field(s, "firstSample");
 }
 
+/* gc_track_params from the struct gnsscorr_tracking.m builds (settings fields + the per-package extras) */
+static void track_params_from(const mxArray* s, gc_track_params* out) {
+  gc_track_params p;
+  memset(&p, 0, sizeof p);
+  p.sampling_freq = field(s, "samplingFreq");
+  p.code_freq_basis = field(s, "codeFreqBasis");
+  p.code_length = field(s, "codeLength");
+  p.el_spacing = field(s, "dllCorrelatorSpacing");
+  p.int_time = field(s, "intTime");
+  p.dll_noise_bw = field(s, "dllNoiseBandwidth");
+  p.dll_damping = field(s, "dllDampingRatio");
+  p.pll_noise_bw = field(s, "pllNoiseBandwidth");
+  p.pll_damping = field(s, "pllDampingRatio");
+  p.pll_kind = mxGetField(s, 0, "pllKind") ? (int32_t)field(s, "pllKind") : GC_PLL_2ND_ORDER;
+  /* skipSamples: where the record's first sample sits, in SAMPLES (tracking.m:145-153: skipNumberOfBytes for schar components,
+     skipNumberOfBytes/2 for int16 components); a plain settings struct still works for schar records */
+  p.skip_samples = (int64_t)(mxGetField(s, 0, "skipSamples") ? field(s, "skipSamples") : field(s, "skipNumberOfBytes"));
+  p.n_epochs = (int32_t)(mxGetField(s, 0, "numEpochs") ? field(s, "numEpochs") : field(s, "msToProcess"));
+  /* optional (API v2): pilot handling of the multi-component packages, see gc_track_params in gnsscorr.h */
+  if (mxGetField(s, 0, "pilotCombine")) p.pilot_combine = (int32_t)field(s, "pilotCombine");
+  if (mxGetField(s, 0, "pf1")) { p.pf1 = field(s, "pf1"); p.pf2 = field(s, "pf2"); p.pf3 = field(s, "pf3"); }
+  if (mxGetField(s, 0, "pllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "pllWeight")); p.pll_weight[0] = w[0]; p.pll_weight[1] = w[1]; }
+  if (mxGetField(s, 0, "dllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "dllWeight")); p.dll_weight[0] = w[0]; p.dll_weight[1] = w[1]; }
+  if (mxGetField(s, 0, "dllScale")) p.dll_scale = field(s, "dllScale");
+  if (mxGetField(s, 0, "tablePhaseCount")) p.table_phase_count = (int32_t)field(s, "tablePhaseCount");
+  *out = p;
+}
+
+/* channels: 5 (or 6) x nch rows = channel index, PRN, acquiredFreq, codeFreq, codePhase[, CLCodePhase] (preRun.m:65-73) */
+static gc_channel_init* channel_inits_from(const mxArray* a, int* nch_out) {
+  const int crow = (int)mxGetM(a);
+  const int nch = (int)mxGetN(a);
+  const double* c = mxGetDoubles(a);
+  gc_channel_init* init = (gc_channel_init*)mxCalloc((size_t)nch, sizeof *init);
+  for (int i = 0; i < nch; ++i) {
+    init[i].channel = (int32_t)c[crow * i];
+    init[i].prn = (int32_t)c[crow * i + 1];
+    init[i].acquired_freq = c[crow * i + 2];
+    init[i].code_freq = c[crow * i + 3];
+    init[i].code_phase = (int64_t)c[crow * i + 4];
+    if (crow >= 6) init[i].table_phase = (int32_t)c[crow * i + 5];
+  }
+  *nch_out = nch;
+  return init;
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   char cmd[32];
   if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("gnsscorr:usage", "first argument: command string");
@@ -165,51 +211,37 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxFree(blk);
     if (rc == GC_E_RANGE) mexErrMsgIdAndTxt("gnsscorr:range", "%s", gc_last_error()); /* tracking.m:241-245 */
     if (rc) fail("gc_correlate");
-  } else if (!strcmp(cmd, "track") || !strcmp(cmd, "track_device")) {
-    const mxArray* s = prhs[2];
+  } else if (!strcmp(cmd, "track") || !strcmp(cmd, "track_device") || !strcmp(cmd, "track_file")) {
+    /* [trk, epochs, status] = gnsscorr_mex('track', h, p, chanTable)
+       [trk, epochs, status] = gnsscorr_mex('track_file', h, p, chanTable, fileName, windowSamples, dataType, fileType[, 'QI']):
+       the same on a file of any size, at most 2 * windowSamples samples resident (gc_track_file) */
     gc_track_params p;
-    memset(&p, 0, sizeof p);
-    p.sampling_freq = field(s, "samplingFreq");
-    p.code_freq_basis = field(s, "codeFreqBasis");
-    p.code_length = field(s, "codeLength");
-    p.el_spacing = field(s, "dllCorrelatorSpacing");
-    p.int_time = field(s, "intTime");
-    p.dll_noise_bw = field(s, "dllNoiseBandwidth");
-    p.dll_damping = field(s, "dllDampingRatio");
-    p.pll_noise_bw = field(s, "pllNoiseBandwidth");
-    p.pll_damping = field(s, "pllDampingRatio");
-    p.pll_kind = mxGetField(s, 0, "pllKind") ? (int32_t)field(s, "pllKind") : GC_PLL_2ND_ORDER;
-    /* skipSamples: where the record's first sample sits, in SAMPLES (tracking.m:145-153: skipNumberOfBytes for schar components,
-       skipNumberOfBytes/2 for int16 components); a plain settings struct still works for schar records */
-    p.skip_samples = (int64_t)(mxGetField(s, 0, "skipSamples") ? field(s, "skipSamples") : field(s, "skipNumberOfBytes"));
-    p.n_epochs = (int32_t)(mxGetField(s, 0, "numEpochs") ? field(s, "numEpochs") : field(s, "msToProcess"));
-    /* optional (API v2): pilot handling of the multi-component packages, see gc_track_params in gnsscorr.h */
-    if (mxGetField(s, 0, "pilotCombine")) p.pilot_combine = (int32_t)field(s, "pilotCombine");
-    if (mxGetField(s, 0, "pf1")) { p.pf1 = field(s, "pf1"); p.pf2 = field(s, "pf2"); p.pf3 = field(s, "pf3"); }
-    if (mxGetField(s, 0, "pllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "pllWeight")); p.pll_weight[0] = w[0]; p.pll_weight[1] = w[1]; }
-    if (mxGetField(s, 0, "dllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "dllWeight")); p.dll_weight[0] = w[0]; p.dll_weight[1] = w[1]; }
-    if (mxGetField(s, 0, "dllScale")) p.dll_scale = field(s, "dllScale");
-    if (mxGetField(s, 0, "tablePhaseCount")) p.table_phase_count = (int32_t)field(s, "tablePhaseCount");
-    /* channels: 5 (or 6) x nch rows = channel index, PRN, acquiredFreq, codeFreq, codePhase[, CLCodePhase] (preRun.m:65-73) */
-    const int crow = (int)mxGetM(prhs[3]);
-    int nch = (int)mxGetN(prhs[3]);
-    const double* c = mxGetDoubles(prhs[3]);
-    gc_channel_init* init = (gc_channel_init*)mxCalloc((size_t)nch, sizeof *init);
-    for (int i = 0; i < nch; ++i) {
-      init[i].channel = (int32_t)c[crow * i];
-      init[i].prn = (int32_t)c[crow * i + 1];
-      init[i].acquired_freq = c[crow * i + 2];
-      init[i].code_freq = c[crow * i + 3];
-      init[i].code_phase = (int64_t)c[crow * i + 4];
-      if (crow >= 6) init[i].table_phase = (int32_t)c[crow * i + 5];
-    }
+    track_params_from(prhs[2], &p);
+    int nch = 0;
+    gc_channel_init* init = channel_inits_from(prhs[3], &nch);
     /* trk(epoch, (channel-1)*GC_TRK_NFIELDS + field): one column per (channel, field), fields in gc_track_field order */
     plhs[0] = mxCreateDoubleMatrix((mwSize)p.n_epochs, (mwSize)GC_TRK_NFIELDS * (mwSize)nch, mxREAL);
     int32_t* done = (int32_t*)mxCalloc((size_t)nch, sizeof *done);
-    /* track_device: the same loop closed on the GPU in one persistent launch (gc_track_device); GC_E_UNSUPPORTED for the
-       configurations it does not cover - the caller then falls back to 'track' */
-    int rc = !strcmp(cmd, "track_device") ? gc_track_device(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done)
-                                          : gc_track(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done);
+    int rc;
+    if (!strcmp(cmd, "track_file")) {
+      char path[4096], dtype[16];
+      mxGetString(prhs[4], path, sizeof path);
+      mxGetString(prhs[6], dtype, sizeof dtype);
+      int layout = (int)mxGetScalar(prhs[7]) == 1 ? GC_REAL : GC_IQ;
+      if (nrhs > 8 && layout == GC_IQ) {
+        char order[8] = "";
+        mxGetString(prhs[8], order, sizeof order);
+        if (!strcmp(order, "QI")) layout = GC_QI;
+      }
+      if (gc_set_sampling_freq(handle(prhs[1]), p.sampling_freq)) fail("gc_set_sampling_freq");
+      rc = gc_track_file(handle(prhs[1]), path, 0, !strcmp(dtype, "int16") ? GC_I16 : GC_I8, layout, (uint64_t)mxGetScalar(prhs[5]), &p,
+                         nch, init, mxGetDoubles(plhs[0]), done);
+    } else {
+      /* track_device: the same loop closed on the GPU in one persistent launch (gc_track_device); GC_E_UNSUPPORTED for the
+         configurations it does not cover - the caller then falls back to 'track' */
+      rc = !strcmp(cmd, "track_device") ? gc_track_device(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done)
+                                        : gc_track(handle(prhs[1]), &p, nch, init, mxGetDoubles(plhs[0]), done);
+    }
     if (nlhs > 1) {
       plhs[1] = mxCreateDoubleMatrix(1, (mwSize)nch, mxREAL);
       for (int i = 0; i < nch; ++i) mxGetDoubles(plhs[1])[i] = done[i];

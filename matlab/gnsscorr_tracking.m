@@ -59,13 +59,18 @@ end
 if isempty(active), return; end
 
 %--- the record: uploaded once per file, from byte 0, so that absoluteSample stays file-relative (ftell, tracking.m:212-216) ---
+% A record larger than the device: settings.gnsscorrWindowSamples > 0 tracks it window by window instead (gc_track_file: two
+% alternating device buffers of that many samples, the next window read and uploaded while the current one is tracked).
 fileName = fopen(fid);
+order = 'IQ';
+if pkg.qiOrder, order = 'QI'; end
+windowed = isfield(settings, 'gnsscorrWindowSamples') && settings.gnsscorrWindowSamples > 0;
 h = gnsscorr_context(fileName);
 if isempty(h)
     h = gnsscorr_context(fileName, 'new');
-    order = 'IQ';
-    if pkg.qiOrder, order = 'QI'; end
-    gnsscorr_mex('open_if_file', h, fileName, 0, 0, settings.dataType, settings.fileType, settings.samplingFreq, order);
+    if ~windowed
+        gnsscorr_mex('open_if_file', h, fileName, 0, 0, settings.dataType, settings.fileType, settings.samplingFreq, order);
+    end
 end
 
 %--- start of the first block in samples (tracking.m:145-153) --------------------------------------------------------------
@@ -119,7 +124,12 @@ for k = 1:numel(active)
 end
 
 %--- the loops -----------------------------------------------------------------------------------------------------------------------
-[trk, epochs, status] = gnsscorr_mex('track', h, p, chanTable);      % trk(epoch, (k-1)*21 + field), fields as gc_track_field
+if windowed
+    [trk, epochs, status] = gnsscorr_mex('track_file', h, p, chanTable, fileName, settings.gnsscorrWindowSamples, settings.dataType, ...
+                                         settings.fileType, order);
+else
+    [trk, epochs, status] = gnsscorr_mex('track', h, p, chanTable);  % trk(epoch, (k-1)*21 + field), fields as gc_track_field
+end
 
 %--- records (tracking.m:212-216,249,277,314,332,338-348) ------------------------------------------------------------------------
 names = {'absoluteSample','codeFreq','carrFreq','I_E','Q_E','I_P','Q_P','I_L','Q_L','dllDiscr','dllDiscrFilt','pllDiscr','pllDiscrFilt', ...

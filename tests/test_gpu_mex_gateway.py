@@ -164,3 +164,34 @@ def test_matlab_drop_in_reproduces_the_references_acquisition_m(gateway, sc):
             assert np.max(np.abs(got - want)) <= sc.metric_rtol * np.max(np.abs(want)), sc.name
         else:
             assert np.array_equal(got, want), (sc.name, f, got[got != want], want[got != want])
+
+
+def test_matlab_drop_in_tracks_a_record_larger_than_the_window(gateway, tmp_path):
+    """settings.gnsscorrWindowSamples: the drop-in tracks the file window by window (gnsscorr_mex('track_file') -> gc_track_file)
+    and returns exactly what it returns with the whole record resident."""
+    import bridge
+    import cu_sdr_collection_amd as P
+    from oracle import mlab
+    from types import SimpleNamespace
+    sc = next(s for s in RS.TRACK_SCENES if s.name == "GPS_L1CA")
+    S, rec, layout, ch = RS.scene_inputs(P, sc)
+    path = str(tmp_path / "record.bin")
+    rec.tofile(path)
+    mch = mlab.to_matlab([SimpleNamespace(**{k: (v if isinstance(v, str) else float(v)) for k, v in vars(c).items()}) for c in ch])
+    out = []
+    for window in (0, int(S.samplingFreq * S.intTime * 14.5)):
+        I = bridge.install(bridge.interpreter_for("GPS_L1CA"), gateway, P, sc.signal)
+        fid = mlab.register_file(I, rec.tobytes(), path)
+        if window:
+            S.gnsscorrWindowSamples = float(window)
+        Sm = mlab.to_matlab(S)
+        try:
+            tr, _ = I.call("tracking", fid, mch, Sm, nargout=2)
+        finally:
+            I.call("gnsscorr_context", "", "clear")
+        out.append(mlab.from_matlab(tr))
+    for a, b in zip(*out):
+        assert a.status == b.status
+        for f in vars(a):
+            if isinstance(getattr(a, f), np.ndarray):
+                assert np.array_equal(getattr(a, f), getattr(b, f)), f

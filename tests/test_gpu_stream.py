@@ -1,0 +1,128 @@
+"""Records larger than the residency cap: gc_track_file (two alternating device windows, the next one read and uploaded while the
+current one is tracked) and gc_track_resume (a channel's loop state carried from one call to the next) against gc_track on
+the fully resident record - postProcessing.m:61-96 / tracking.m:226-245 read a file of any length block by block.
+The window origins are multiples of 256 samples, so every block keeps its address alignment and the results must be
+IDENTICAL, bit for bit, to the resident run."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _channels(S, sats, nch):
+    ch = [SimpleNamespace(PRN=s.prn, acquiredFreq=S.IF + s.doppler + 4.0, codePhase=int(np.ceil(s.code_phase_samples)) + 1, status="T")
+          for s in sats]
+    while len(ch) < nch:
+        ch.append(SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0, status="-"))
+    return ch
+
+
+def _job(P, engine, S, ch, signal="GPS_L1CA"):
+    from cu_sdr_collection_amd import receiver
+    return receiver._tracking_prepare(engine, ch, S, signal)
+
+
+def _same(a, b):
+    fa, da, sa = a[:3]
+    fb, db, sb = b[:3]
+    assert sa == sb and np.array_equal(da, db), (sa, sb, da, db)
+    for name in fa:
+        assert np.array_equal(fa[name], fb[name]), (name, float(np.max(np.abs(fa[name] - fb[name]))))
+
+
+def test_windowed_file_equals_the_resident_record(engine, l1ca_scene, tmp_path):
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene                    # 0.3 s at 18 Msps
+    S.msToProcess, S.numberOfChannels = 280, 4
+    path = os.path.join(tmp_path, "record.bin")
+    iq.tofile(path)
+    job = _job(P, engine, S, _channels(S, sats, 4))
+    engine.load_if(iq, fs=S.samplingFreq)
+    resident = engine.track(job.p, job.inits)
+    assert resident[2] == 0 and all(resident[1] == 280)
+    for window_ms in (25, 64.3):                # 12 and 5 windows; the cap is 2 x window
+        windowed = engine.track_file(path, job.p, job.inits, int(window_ms * 1e-3 * S.samplingFreq))
+        _same(resident, windowed)
+    engine.load_if(iq, fs=S.samplingFreq)       # the context is usable again after the windows are gone
+    _same(resident, engine.track(job.p, job.inits))
+
+
+def test_windowed_file_ends_like_the_resident_record(engine, l1ca_scene, tmp_path):
+    """More epochs asked for than the file holds: 'Not able to read the specified number of samples for tracking' (tracking.m:241-245)
+    - the first channel's records stop there, the channels after it are never run - in both modes."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    S, sats, iq = l1ca_scene
+    S.msToProcess, S.numberOfChannels = 400, 3
+    path = os.path.join(tmp_path, "record.bin")
+    iq.tofile(path)
+    job = _job(P, engine, S, _channels(S, sats, 3))
+    engine.load_if(iq, fs=S.samplingFreq)
+    resident = engine.track(job.p, job.inits)
+    assert resident[2] == L.GC_E_RANGE and 290 < resident[1][0] < 300 and not resident[1][1:].any()
+    _same(resident, engine.track_file(path, job.p, job.inits, int(0.05 * S.samplingFreq)))
+
+
+def test_windowed_int16_lane_kernel_record(engine, tmp_path):
+    """A 10.23-Mcps data + pilot signal (lane kernel, two arms) on an int16 record with a file offset."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    import ref_scenes as RS
+    sc = next(s for s in RS.TRACK_SCENES if s.name == "GPS_L5C")
+    S, rec, layout, ch = RS.scene_inputs(P, sc)
+    rec16 = (rec.astype(np.int16) * 5)
+    path = os.path.join(tmp_path, "record16.bin")
+    with open(path, "wb") as f:
+        f.write(b"\0" * 512)                    # a header in front of record sample 0
+        rec16.tofile(f)
+    job = _job(P, engine, S, ch, sc.signal)       # the loop parameters of the schar record (GPS_L5C tracking.m has no int16 seek rule)
+    engine.load_if(rec16, layout=layout, fs=S.samplingFreq)
+    resident = engine.track(job.p, job.inits)
+    n = rec16.size // 2
+    windowed = engine.track_file(path, job.p, job.inits, n // 3, dtype=L.GC_I16, layout=layout, skip_bytes=512)
+    _same(resident, windowed)
+
+
+def test_resume_continues_a_tracking_call(engine, l1ca_scene):
+    """gc_track_resume: 120 epochs, then 160 more from the returned state = one call of 280 epochs (checkpoint / resume)."""
+    import copy
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene
+    S.msToProcess, S.numberOfChannels = 280, 4
+    job = _job(P, engine, S, _channels(S, sats, 4))
+    engine.load_if(iq, fs=S.samplingFreq)
+    whole = engine.track(job.p, job.inits)
+    p1 = copy.copy(job.p)
+    p1.n_epochs = 120
+    f1, d1, s1, state, paused = engine.track_resume(p1, job.inits)
+    assert not paused and all(d1 == 120)
+    p2 = copy.copy(job.p)
+    p2.n_epochs = 160
+    f2, d2, s2, state, paused = engine.track_resume(p2, job.inits, state=state)
+    assert not paused and all(d2 == 160)
+    for name in whole[0]:
+        assert np.array_equal(np.concatenate([f1[name], f2[name]], axis=1), whole[0][name]), name
+    assert [int(st.next_sample) for st in state] == [int(whole[0]["absoluteSample"][k, -1]) + int(np.ceil(
+        (S.codeLength - whole[0]["remCodePhase"][k, -1]) / (whole[0]["codeFreq"][k, -1] / S.samplingFreq))) for k in range(4)]
+
+
+def test_receiver_tracking_file_equals_tracking(engine, l1ca_scene, tmp_path):
+    """The reference-shaped entry point: tracking_file(fid, path, channel, settings, window) = tracking(fid, channel, settings)."""
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene
+    S.msToProcess, S.numberOfChannels = 250, 5
+    ch = _channels(S, sats, 5)
+    path = os.path.join(tmp_path, "record.bin")
+    iq.tofile(path)
+    engine.load_if(iq, fs=S.samplingFreq)
+    a, _ = P.tracking(engine, ch, S)
+    b, _ = P.tracking_file(engine, path, ch, S, window_samples=int(0.04 * S.samplingFreq))
+    for x, y in zip(a, b):
+        assert x.status == y.status and x.PRN == y.PRN
+        for f in vars(x):
+            if isinstance(getattr(x, f), np.ndarray):
+                assert np.array_equal(getattr(x, f), getattr(y, f)), f
+        assert x.CNo.VSMValue == y.CNo.VSMValue and x.CNo.VSMIndex == y.CNo.VSMIndex
