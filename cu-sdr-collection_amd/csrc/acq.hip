@@ -151,6 +151,10 @@ struct PassArgs {
   // the same with batch tb = bin * nhops + hop (coarse search whose bin spacing is a whole number of FFT bins): reads input
   // transform `hop` shifted by bin * shift_q
   int shift_q;
+  // PRE_IF_CARRIER on a transform longer than the reference's 2*spc (sizes the radix-{2..8} plan cannot take are padded to
+  // the next one it can, launch in gc_acquire_coarse_multi): positions wrap_len .. wrap_len + spc - 1 repeat the first spc
+  // (mixed) samples, everything behind is zero
+  int wrap_len;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -378,13 +382,20 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
         if (a.pre == PRE_IF_CARRIER) {
           // x[n] = (I + iQ) * exp(-1i * f_b * n*2*pi/fs)  (acquisition.m:169-181), batch = b*nhops + h
           const int b = (int)(tb / a.nhops), h = (int)(tb % a.nhops);
-          const long long s = a.first_sample + (long long)h * a.spc + (long long)pos;
+          int p2 = pos;
+          bool live = true;
+          if (a.wrap_len > 0 && pos >= a.wrap_len) {
+            p2 = pos - a.wrap_len;
+            live = p2 < a.spc;
+            p2 = live ? p2 : 0;
+          }
+          const long long s = a.first_sample + (long long)h * a.spc + (long long)p2;
           const float xi = (float)a.if_base[2 * s], xq = (float)a.if_base[2 * s + 1];
           const double fb = a.f0 - a.fstep * b;
-          const double ph = (fb / a.fs) * (double)pos;
+          const double ph = (fb / a.fs) * (double)p2;
           float sn, cs;
           sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
-          val = make_float2(xi * cs + xq * sn, xq * cs - xi * sn);
+          val = live ? make_float2(xi * cs + xq * sn, xq * cs - xi * sn) : make_float2(0.f, 0.f);
         } else if (a.pre == PRE_CODE) {
           val = (pos < a.spc) ? make_float2((float)a.codes[tb * a.spc + pos], 0.f) : make_float2(0.f, 0.f);
         } else {
@@ -809,10 +820,10 @@ struct PeakTrack {
 };
 
 // POST_ABS_ACC with hop groups: results = (add ? results : 0) + (sum over groups, in group order) / n * scale;
-// `keys` != nullptr: also the peak pick of the finished results (last code arm of a PRN)
+// `keys` != nullptr: also the peak pick of the finished results (last code arm of a PRN) over their first `valid` columns
 __global__ __launch_bounds__(256) void abs_combine_kernel(const float* __restrict__ part, int groups, int nbins, int n,
                                                           float* __restrict__ out, int add, float inv_n, float scale,
-                                                          unsigned long long* keys) {
+                                                          unsigned long long* keys, int valid) {
   PeakTrack pk;
   const long long total = (long long)nbins * n;
   for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
@@ -822,16 +833,16 @@ __global__ __launch_bounds__(256) void abs_combine_kernel(const float* __restric
       for (int g = 0; g < groups; ++g) v += part[(long long)g * total + i];
       v = (add ? out[i] : 0.0f) + v * inv_n * scale;
       out[i] = v;
-      pk.see(v, (unsigned int)bin, (unsigned int)c);
+      if (c < valid) pk.see(v, (unsigned int)bin, (unsigned int)c);
     }
   if (keys) pk.publish(keys);
 }
 
 // the peak pick alone (results written by the pass kernel itself: no hop groups)
-__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ r, int nbins, int n, unsigned long long* keys) {
+__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ r, int nbins, int n, unsigned long long* keys, int valid) {
   PeakTrack pk;
   for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < valid; c += gridDim.x * blockDim.x)
       pk.see(r[(long long)bin * n + c], (unsigned int)bin, (unsigned int)c);
   pk.publish(keys);
 }
@@ -971,7 +982,7 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
   constexpr int rad[4] = {R0, R1, R2, R3};
   constexpr int nst = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
   if (a.len != L || a.nvec != OTHER || a.n != L * OTHER || a.pre != PRE || a.post != POST || (a.inverse != 0) != INV ||
-      (a.pre == PRE_MUL_CONJ && (a.shift_bins > 0 || a.shift_q > 0)) != SHIFT || a.nrad != nst)
+      (a.pre == PRE_MUL_CONJ && (a.shift_bins > 0 || a.shift_q > 0)) != SHIFT || a.nrad != nst || a.wrap_len > 0)
     return false;
   if (SHIFT && (a.n1 != OTHER || a.n2 != L)) return false;
   if (CONTIG ? (a.estride != 1 || a.vstride != L) : (a.estride != OTHER || a.vstride != 1)) return false;
@@ -1059,7 +1070,8 @@ void free_scratch(AcqScratch* s) {
 // Last inverse pass (POST_ABS_ACC) over `nbins` bins.  With few bins the launch would have ~2 workgroups per CU, each
 // walking all nhops hops of its bin: the hops are then split over hop groups (a divisor of nhops), whose raw sums meet in
 // abs_combine_kernel - deterministic, group order fixed.
-int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr) {
+int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr, int valid = 0) {
+  if (valid <= 0) valid = a.n;
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   int hg = 1;
   for (int g = 1; g <= a.nhops; ++g)
@@ -1070,7 +1082,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   if (hg == 1) {
     int rc = launch_pass(ctx, a, nbins);
     if (rc || !keys) return rc;
-    hipLaunchKernelGGL(peak_kernel, pgrid, dim3(256), 0, ctx->stream, a.acc_out, (int)nbins, a.n, keys);
+    hipLaunchKernelGGL(peak_kernel, pgrid, dim3(256), 0, ctx->stream, a.acc_out, (int)nbins, a.n, keys, valid);
     GC_HIP(hipGetLastError());
     return GC_OK;
   }
@@ -1088,7 +1100,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   int rc = launch_pass(ctx, a, nbins * hg);
   if (rc) return rc;
   hipLaunchKernelGGL(abs_combine_kernel, pgrid, dim3(256), 0, ctx->stream, s->partial, hg, (int)nbins, a.n, a.acc_out, a.acc_add,
-                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, keys);
+                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, keys, valid);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -1202,8 +1214,30 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   const int spc = (int)std::floor(x + 0.5);                                     // acquisition.m:116
   const int nbins = (int)std::floor(p->search_band * 2 / p->search_step + 0.5) + 1;  // :124
   const int H = p->non_coh_time;
-  const int n = 2 * spc;
   if (spc <= 0 || nbins <= 0 || H <= 0 || p->first_sample < 0) return GC_E_INVALID;
+  // The reference transforms 2*spc points (one code period + one of zeros).  Where the radix-{2..8} plan cannot take that
+  // length (2*spc = 32 736 = 2^5*3*11*31 at the common 16.368-Msps front ends, 5 172 = 2^2*3*431 after the A0 resampling),
+  // the circular correlation is computed inside a longer transform instead: the 2*spc mixed samples followed by a repeat
+  // of their first spc and zeros up to the next size M >= 3*spc the plan takes - for the code of spc samples the first
+  // 2*spc lags of that M-point circular correlation ARE the reference's 2*spc-point one, term by term.
+  int n = 2 * spc;
+  bool padded = false;
+  {
+    Plan probe;
+    if (!make_plan(n, &probe) || std::getenv("GC_ACQ_PAD")) {
+      padded = true;
+      n = 0;
+      for (int m = 3 * spc; m < 3 * spc + (1 << 20); ++m)
+        if (make_plan(m, &probe)) {
+          n = m;
+          break;
+        }
+      if (n == 0) {
+        gc_set_error("acquisition: no transform size at or above %d fits the plan", 3 * spc);
+        return GC_E_UNSUPPORTED;
+      }
+    }
+  }
   if ((uint64_t)p->first_sample + (uint64_t)(H + 1) * spc > ctx->if_nsamples) {
     gc_set_error("gc_acquire_coarse: needs %lld samples from %lld, buffer holds %llu", (long long)(H + 1) * spc,
                  (long long)p->first_sample, (unsigned long long)ctx->if_nsamples);
@@ -1243,8 +1277,9 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   // inverse transforms read them shifted (5.8 MB that stay in cache instead of 167 MB from HBM per PRN).
   const double qd = p->search_step * (double)n / p->sampling_freq;
   const long long q = (long long)std::floor(qd + 0.5);
-  const bool shifted = q >= 1 && std::fabs(qd - (double)q) <= 1e-12 * qd && (long long)(nbins - 1) * q < n &&
+  const bool shifted = !padded && q >= 1 && std::fabs(qd - (double)q) <= 1e-12 * qd && (long long)(nbins - 1) * q < n &&
                        std::getenv("GC_ACQ_NO_SHIFT") == nullptr;
+  base.wrap_len = padded ? 2 * spc : 0;
   rc = forward(ctx, s, base, PRE_IF_CARRIER, shifted ? (long long)H : (long long)nbins * H, s->sig);
   if (rc) return rc;
   // code spectra (conj applied at the product)
@@ -1298,7 +1333,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.in = s->tmp;
       a.acc_out = s->results;
       a.acc_add = arm > 0;
-      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr);
+      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr, 2 * spc);
       if (rc) return rc;
     }
   }
