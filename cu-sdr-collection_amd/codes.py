@@ -192,26 +192,32 @@ def generateGLOcode() -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------
-# BDS B1I (BDS/B1I/include/generateCAcode53.m), PRN 1..37
+# BDS B1I (BDS/B1I/include/generateCAcode53.m), PRN 1..58
 # ---------------------------------------------------------------------------------------------
 _B1I_PHASE = ((1, 3), (1, 4), (1, 5), (1, 6), (1, 8), (1, 9), (1, 10), (1, 11), (2, 7), (3, 4), (3, 5), (3, 6), (3, 8),
               (3, 9), (3, 10), (3, 11), (4, 5), (4, 6), (4, 8), (4, 9), (4, 10), (4, 11), (5, 6), (5, 8), (5, 9), (5, 10),
-              (5, 11), (6, 8), (6, 9), (6, 10), (6, 11), (8, 9), (8, 10), (8, 11), (9, 10), (9, 11), (10, 11))
+              (5, 11), (6, 8), (6, 9), (6, 10), (6, 11), (8, 9), (8, 10), (8, 11), (9, 10), (9, 11), (10, 11),
+              # PRN 38..58 (BDS-3 satellites, BDS-SIS-ICD-B1I-3.0 Table 4-1): three phase-selector stages
+              (1, 2, 7), (1, 3, 4), (1, 3, 6), (1, 3, 8), (1, 3, 10), (1, 3, 11), (1, 4, 5), (1, 4, 9), (1, 5, 6), (1, 5, 8),
+              (1, 5, 10), (1, 5, 11), (1, 6, 9), (1, 8, 9), (1, 9, 10), (1, 9, 11), (2, 3, 7), (2, 5, 7), (2, 7, 9), (3, 4, 5),
+              (3, 4, 9))
 
 
 def generateCAcode53(PRN: int) -> np.ndarray:
     """BDS B1I ranging code, 2046 chips int8 +-1 (logic 1 -> +1 after the reference's final negation).
     11-stage G1 (taps 1,7,8,9,10,11) and G2 (taps 1,2,3,4,5,8,9,11), initial state 01010101010,
-    G2 tapped at the PRN's two phase-selector stages (BDS-SIS-ICD-B1I Table 4-1)."""
+    G2 tapped at the PRN's two (PRN <= 37) or three phase-selector stages (BDS-SIS-ICD-B1I Table 4-1)."""
     if not 1 <= PRN <= len(_B1I_PHASE):
         raise ValueError(f"BDS B1I PRN {PRN} out of range")
     init = [0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0]
-    s1, s2 = _B1I_PHASE[PRN - 1]
+    sel = _B1I_PHASE[PRN - 1]
     r1, r2 = list(init), list(init)
     out = np.empty(2046, dtype=np.int8)
     for i in range(2046):
         g1 = r1[10]
-        g2 = r2[s1 - 1] ^ r2[s2 - 1]
+        g2 = 0
+        for st in sel:
+            g2 ^= r2[st - 1]
         out[i] = 2 * (g1 ^ g2) - 1
         f1 = r1[0] ^ r1[6] ^ r1[7] ^ r1[8] ^ r1[9] ^ r1[10]
         f2 = r2[0] ^ r2[1] ^ r2[2] ^ r2[3] ^ r2[4] ^ r2[7] ^ r2[8] ^ r2[10]

@@ -728,15 +728,19 @@ def generate_glo_code() -> np.ndarray:
     return code
 
 
-# G2 phase-selector taps for PRN 1..37 (BDS-SIS-ICD-B1I; generateCAcode53.m:58-70)
-_B1I_S1 = [1, 1, 1, 1, 1, 1, 1, 1, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 6, 6, 6, 6, 8, 8, 8, 9, 9, 10]
-_B1I_S2 = [3, 4, 5, 6, 8, 9, 10, 11, 7, 4, 5, 6, 8, 9, 10, 11, 5, 6, 8, 9, 10, 11, 6, 8, 9, 10, 11, 8, 9, 10, 11, 9, 10, 11, 10, 11, 11]
+# G2 phase-selector taps for PRN 1..58 (BDS-SIS-ICD-B1I-3.0 Table 4-1; generateCAcode53.m:58-76): two stages up to PRN 37, a
+# third one from PRN 38 on (:78-86)
+_B1I_S1 = [1, 1, 1, 1, 1, 1, 1, 1, 2, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 6, 6, 6, 6, 8, 8, 8, 9, 9, 10] + \
+          [1] * 16 + [2] * 3 + [3] * 2
+_B1I_S2 = [3, 4, 5, 6, 8, 9, 10, 11, 7, 4, 5, 6, 8, 9, 10, 11, 5, 6, 8, 9, 10, 11, 6, 8, 9, 10, 11, 8, 9, 10, 11, 9, 10, 11, 10, 11, 11] + \
+          [2] + [3] * 5 + [4] * 2 + [5] * 4 + [6, 8, 9, 9, 3, 5, 7, 4, 4]
+_B1I_S3 = [7, 4, 6, 8, 10, 11, 5, 9, 6, 8, 10, 11, 9, 9, 10, 11, 7, 7, 9, 5, 9]
 
 
 def generate_b1i_code(prn: int) -> np.ndarray:
     """2046 chips; G1 taps {1,7,8,9,10,11}, G2 taps {1,2,3,4,5,8,9,11}, both registers start at
     -1*[-1 1 -1 1 ...] (:43,:55), G2 output = product of the PRN's two selector stages (:94),
-    CAcode = -(g1.*g2) (:103).  PRN 1..37."""
+    CAcode = -(g1.*g2) (:103).  PRN 1..58."""
     init = -1.0 * np.array([-1, 1, -1, 1, -1, 1, -1, 1, -1, 1, -1], dtype=np.float64)
     reg = init.copy()
     g1 = np.empty(2046)
@@ -748,8 +752,9 @@ def generate_b1i_code(prn: int) -> np.ndarray:
     reg = init.copy()
     g2 = np.empty(2046)
     s1, s2 = _B1I_S1[prn - 1] - 1, _B1I_S2[prn - 1] - 1
+    s3 = _B1I_S3[prn - 38] - 1 if prn > 37 else None
     for i in range(2046):
-        g2[i] = reg[s1] * reg[s2]
+        g2[i] = reg[s1] * reg[s2] * (reg[s3] if s3 is not None else 1.0)
         save = reg[0] * reg[1] * reg[2] * reg[3] * reg[4] * reg[7] * reg[8] * reg[10]
         reg[1:11] = reg[0:10].copy()
         reg[0] = save
