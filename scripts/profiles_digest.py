@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Turns a scripts/collect_profiles.sh output directory (gpurun_out/<tag>) into profiles/<round>/: copies the condensed rocprofv3
+summaries and the bench line, and derives traffic.json (HBM bytes per launch of every replay kernel: FETCH_SIZE x 2 on gfx950 +
+WRITE_SIZE, MI355X_MICROARCH.md "HBM") and digest.md (per kernel: launches, average duration, VALU / LDS instructions per
+channel-sample).   usage: scripts/profiles_digest.py gpurun_out/r02h profiles/r02 "<build description>" """
+import json
+import os
+import re
+import shutil
+import sys
+
+src, dst, build = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
+LINE = re.compile(r"^(?P<k>.+?) grid=(?P<g>\d+): (?P<c>[A-Z_0-9a-z]+) mean=(?P<v>[-+.e0-9]+) n=(?P<n>\d+)")
+CALLS = re.compile(r"^(?P<k>.+?) grid=(?P<g>\d+): calls=(?P<n>\d+) total_ns=\d+ avg_ns=(?P<a>\d+) min_ns=(?P<mn>\d+)")
+
+
+def parse(path):
+    cnt, dur = {}, {}
+    if not os.path.exists(path):
+        return cnt, dur
+    for l in open(path):
+        m = LINE.match(l)
+        if m:
+            cnt.setdefault((m["k"], int(m["g"])), {})[m["c"]] = (float(m["v"]), int(m["n"]))
+        m = CALLS.match(l)
+        if m:
+            dur[(m["k"], int(m["g"]))] = (int(m["n"]), int(m["a"]), int(m["mn"]))
+    return cnt, dur
+
+
+def replay_kernel(cnt_or_dur, want):
+    """the correlator kernel with the most threads (the replay launch; closed-loop launches of the same kernel are small)"""
+    ks = [k for k in cnt_or_dur if want in k[0]]
+    return max(ks, key=lambda k: k[1]) if ks else None
+
+
+for f in sorted(os.listdir(src)):
+    if f.endswith((".txt", ".json")) and f not in ("collect.log",) and os.path.getsize(os.path.join(src, f)) > 0:
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+traffic, lines = [], ["# digest of " + src + " (" + build + ")", ""]
+shapes = [("l1ca", "corr_epl_fast_kernel", bench["config"]["blocks_per_step"], None)]
+for s in ("l5", "cboc", "e1x8", "b1c"):
+    t = os.path.join(src, s + ".txt")
+    if os.path.exists(t):
+        m = re.search(r"\{'shape'.*\}", open(t).read())
+        if m:
+            d = eval(m.group(0))
+            shapes.append((s, "corr_epl_lane_kernel" if "lane" in d["kernel"] else "corr_epl_fast_kernel", None, d))
+lines.append("| workload | replay kernel (grid) | launches | avg ms (profiler) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes / launch | VALU instr per channel-sample | LDS instr per channel-sample |")
+lines.append("|---|---|---|---|---|---|---|---|---|")
+for name, want, blocks, d in shapes:
+    fc, fd = parse(os.path.join(src, f"{name}_pmc_FETCH_SIZE.txt"))
+    wc, _ = parse(os.path.join(src, f"{name}_pmc_WRITE_SIZE.txt"))
+    sc, sd = parse(os.path.join(src, f"{name}_pmc_sq.txt"))
+    _, st = parse(os.path.join(src, "bench_stats.txt" if name == "l1ca" else f"{name}_stats.txt"))
+    k = replay_kernel(fc, want)
+    if k is None:
+        continue
+    fetch = fc[k].get("FETCH_SIZE", (None, 0))[0]
+    write = wc.get(k, {}).get("WRITE_SIZE", (None, 0))[0]
+    hbm = None if fetch is None else int(2 * fetch * 1024 + (write or 0) * 1024)
+    ks = replay_kernel(sc, want)
+    cs = (12 * 59998 * 18000.0 * bench["config"]["blocks_per_step"] / (12 * 59998)) if name == "l1ca" else d["channel_samples_per_launch"]
+    valu = sc[ks]["SQ_INSTS_VALU"][0] * 64 / cs if ks and "SQ_INSTS_VALU" in sc[ks] else None
+    lds = sc[ks]["SQ_INSTS_LDS"][0] * 64 / cs if ks and "SQ_INSTS_LDS" in sc[ks] else None
+    kd = replay_kernel(st, want)
+    calls, avg = (st[kd][0], st[kd][1] / 1e6) if kd else (None, None)
+    lines.append(f"| {name} | `{k[0][:64]}` ({k[1]}) | {calls} | {avg if avg is None else round(avg, 4)} | {fetch} | {write} | {hbm} | "
+                 f"{None if valu is None else round(valu, 2)} | {None if lds is None else round(lds, 2)} |")
+    e = {"workload": name, "kernel": k[0], "grid": k[1], "fetch_size_kb_mean": fetch, "write_size_kb_mean": write, "gfx950_fetch_correction": 2.0,
+         "hbm_bytes_per_launch": hbm, "build": build,
+         "note": "FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE uncorrected" +
+                 ("" if write is not None else "; WRITE_SIZE not collected for this shape (outputs are 96-144 B per block)")}
+    if blocks:
+        e["blocks_per_launch"] = blocks
+    traffic.append(e)
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+# acquisition
+ac, _ = parse(os.path.join(src, "acq_pmc_sq.txt"))
+_, ad = parse(os.path.join(src, "acq_stats.txt"))
+lines += ["", "Acquisition (scripts/acq_time.py: default GPS L1 C/A search, 32 PRNs x 29 bins x 20 ms, N = 36 000):", ""]
+lines.append("| kernel (grid) | launches | avg us | VALU instr per element | LDS instr per element | LDS bank-conflict cycles / LDS instr |")
+lines.append("|---|---|---|---|---|---|")
+for k, (calls, avg, mn) in sorted(ad.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8]:
+    c = ac.get(k, {})
+    el = k[1]
+    v = c.get("SQ_INSTS_VALU", (None,))[0]
+    l = c.get("SQ_INSTS_LDS", (None,))[0]
+    b = c.get("SQ_LDS_BANK_CONFLICT", (None,))[0]
+    # elements a launch transforms: one LDS tile (2000 or 1440 elements) per workgroup, times the hops a workgroup of the
+    # |.|-accumulating pass walks (20 hops in 4 hop groups at the default search)
+    tile = (2000 if "<200" in k[0] else 1440) * (5 if ", 0, 2, true" in k[0] else 1)
+    per = (lambda x: None if x is None else round(x * 64 / (el / 256 * tile), 1)) if "fft_pass" in k[0] else (lambda x: None)
+    lines.append(f"| `{k[0][:70]}` ({k[1]}) | {calls} | {round(avg / 1e3, 1)} | {per(v)} | {per(l)} | {None if not l or b is None else round(b / l, 2)} |")
+open(os.path.join(dst, "digest.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
