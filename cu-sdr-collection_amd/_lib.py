@@ -50,6 +50,16 @@ class gc_channel_init(C.Structure):
                 ("code_freq", C.c_double), ("code_phase", C.c_int64), ("table_phase", C.c_int32), ("reserved", C.c_int32)]
 
 
+class gc_acq_front_params(C.Structure):
+    """acquisition.m:46-111 input conditioning (gc_acq_condition)."""
+    _fields_ = [("sampling_freq", C.c_double), ("intermediate_freq", C.c_double), ("bandwidth", C.c_double), ("first_sample", C.c_int64),
+                ("n_samples", C.c_int64), ("fir_order", C.c_int32), ("reserved", C.c_int32)]
+
+
+class gc_acq_front_result(C.Structure):
+    _fields_ = [("sampling_freq", C.c_double), ("intermediate_freq", C.c_double), ("n_samples", C.c_int64)]
+
+
 class gc_channel_state(C.Structure):
     """What tracking.m keeps between two blocks of a channel (include/gnsscorr.h: gc_track_resume / gc_track_file)."""
     _fields_ = [("next_sample", C.c_int64), ("code_freq", C.c_double), ("rem_code_phase", C.c_double), ("carr_freq", C.c_double),
@@ -67,13 +77,13 @@ class gc_track_job(C.Structure):
 class gc_acq_params(C.Structure):
     _fields_ = [("sampling_freq", C.c_double), ("code_freq_basis", C.c_double), ("code_length", C.c_double),
                 ("intermediate_freq", C.c_double), ("search_band", C.c_double), ("search_step", C.c_double),
-                ("non_coh_time", C.c_int32), ("reserved", C.c_int32), ("first_sample", C.c_int64)]
+                ("non_coh_time", C.c_int32), ("source", C.c_int32), ("first_sample", C.c_int64)]
 
 
 class gc_fine_params(C.Structure):
     _fields_ = [("sampling_freq", C.c_double), ("code_freq", C.c_double), ("f0", C.c_double), ("fstep", C.c_double),
                 ("first_sample", C.c_int64), ("spc", C.c_int32), ("ncodes", C.c_int32), ("nbins", C.c_int32),
-                ("code_len", C.c_int32), ("index_offset", C.c_int32), ("reserved", C.c_int32)]
+                ("code_len", C.c_int32), ("index_offset", C.c_int32), ("source", C.c_int32)]
 
 
 class gc_acq_shift_params(C.Structure):
@@ -129,6 +139,8 @@ SYMBOLS = {
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,
                                        C.POINTER(C.c_double)]),
     "gc_acquire_fine_sums": (C.c_int, [_P, C.POINTER(gc_fine_params), _P, C.POINTER(C.c_double)]),
+    "gc_acq_condition": (C.c_int, [_P, C.POINTER(gc_acq_front_params), C.POINTER(gc_acq_front_result)]),
+    "gc_acq_conditioned": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_float)]),
     "gc_acquire_fine_l1ca_batch": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(C.c_int32),
                                              C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gc_acquire_fine_sums_batch": (C.c_int, [_P, C.POINTER(gc_fine_params), C.c_int, _P, C.POINTER(C.c_int64),

@@ -129,6 +129,7 @@ struct PassArgs {
   const float2* tw;   // exp(-2*pi*i*k/n), k = 0..n-1
   // PRE_IF_CARRIER
   const int8_t* if_base;
+  const float2* if_f32;  // the conditioned signal of gc_acq_condition instead of the int8 record (nullptr: the record)
   long long first_sample;
   int spc, nhops;
   double f0, fstep, fs;  // bin frequency f_b = f0 - fstep*b (Hz)
@@ -390,7 +391,15 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
             p2 = live ? p2 : 0;
           }
           const long long s = a.first_sample + (long long)h * a.spc + (long long)p2;
-          const float xi = (float)a.if_base[2 * s], xq = (float)a.if_base[2 * s + 1];
+          float xi, xq;
+          if (a.if_f32) {
+            const float2 z = a.if_f32[s];
+            xi = z.x;
+            xq = z.y;
+          } else {
+            xi = (float)a.if_base[2 * s];
+            xq = (float)a.if_base[2 * s + 1];
+          }
           const double fb = a.f0 - a.fstep * b;
           const double ph = (fb / a.fs) * (double)p2;
           float sn, cs;
@@ -662,8 +671,16 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
       float2 val;
       if constexpr (PRE == PRE_IF_CARRIER) {
         const long long s = a.first_sample + (long long)ch * a.spc + (long long)pos;
-        const char2 x = *reinterpret_cast<const char2*>(a.if_base + 2 * s);
-        const float xi = (float)x.x, xq = (float)x.y;
+        float xi, xq;
+        if (a.if_f32) {
+          const float2 z = a.if_f32[s];
+          xi = z.x;
+          xq = z.y;
+        } else {
+          const char2 x = *reinterpret_cast<const char2*>(a.if_base + 2 * s);
+          xi = (float)x.x;
+          xq = (float)x.y;
+        }
         const double ph = fcyc * (double)pos;
         float sn, cs;
         sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
@@ -861,6 +878,86 @@ __global__ void sigpower_kernel(const int8_t* __restrict__ x, long long first, i
   atomicAdd((unsigned long long*)&out3[2], (unsigned long long)s2);
 }
 
+// the same sums for the conditioned (complex float) signal: one workgroup, fixed summation order, float64
+__global__ __launch_bounds__(1024) void sigpower_f32_kernel(const float2* __restrict__ x, long long first, int n, double* out3) {
+  double si = 0.0, sq = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float2 z = x[first + i];
+    si += (double)z.x;
+    sq += (double)z.y;
+    s2 += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+  }
+  __shared__ double red[3][1024];
+  red[0][threadIdx.x] = si;
+  red[1][threadIdx.x] = sq;
+  red[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out3[threadIdx.x] = red[threadIdx.x][0];
+}
+
+// ---- input conditioning (acquisition.m:46-111, row A0) -------------------------------------------------------------------
+// filtfilt(b, 1, x) = the signal extended by nfact odd-reflected samples at both ends, filtered forwards with the filter
+// starting in the steady state of the first extended sample (for an FIR filter: as if that sample had been there for
+// ever), reversed, filtered again the same way, reversed, the extensions dropped.
+__global__ void cond_extend_kernel(const int8_t* __restrict__ x, long long first, long long n, int nfact, float2* __restrict__ xe) {
+  const long long ne = n + 2LL * nfact;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < ne; j += (long long)gridDim.x * blockDim.x) {
+    auto at = [&](long long i) { return make_float2((float)x[2 * (first + i)], (float)x[2 * (first + i) + 1]); };
+    float2 v;
+    if (j < nfact) {  // 2*x(1) - x(nfact+1:-1:2)
+      const float2 e = at(0), r = at(nfact - j);
+      v = make_float2(2.f * e.x - r.x, 2.f * e.y - r.y);
+    } else if (j < nfact + n) {
+      v = at(j - nfact);
+    } else {          // 2*x(end) - x(end-1:-1:end-nfact)
+      const float2 e = at(n - 1), r = at(n - 2 - (j - nfact - n));
+      v = make_float2(2.f * e.x - r.x, 2.f * e.y - r.y);
+    }
+    xe[j] = v;
+  }
+}
+
+// out[m] = sum_k b[k] * in[m - k] (BACK: in[m + k]) with the index clamped to the array: the steady-state start
+template <bool BACK>
+__global__ __launch_bounds__(256) void cond_fir_kernel(const float2* __restrict__ in, long long ne, const float* __restrict__ b, int nb,
+                                                       float2* __restrict__ out) {
+  extern __shared__ float2 tile[];  // 256 + nb - 1 inputs
+  const long long m0 = (long long)blockIdx.x * 256;
+  const int span = 256 + nb - 1;
+  for (int i = threadIdx.x; i < span; i += 256) {
+    long long j = BACK ? m0 + i : m0 - (nb - 1) + i;
+    j = j < 0 ? 0 : (j >= ne ? ne - 1 : j);
+    tile[i] = in[j];
+  }
+  __syncthreads();
+  const long long m = m0 + threadIdx.x;
+  if (m >= ne) return;
+  float sr = 0.f, si = 0.f;
+  const float2* t = tile + threadIdx.x + (BACK ? 0 : nb - 1);
+  for (int k = 0; k < nb; ++k) {
+    const float2 v = BACK ? t[k] : t[-k];
+    const float c = b[k];
+    sr = fmaf(c, v.x, sr);
+    si = fmaf(c, v.y, si);
+  }
+  out[m] = make_float2(sr, si);
+}
+
+// longSignal(index), index = ceil((0:len-1)/newFs*oldFs), index(1) = 1 (acquisition.m:84-91)
+__global__ void cond_decimate_kernel(const float2* __restrict__ y, int nfact, double old_fs, double new_fs, long long len,
+                                     float2* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+    long long idx = (long long)ceil(__dmul_rn(__ddiv_rn((double)i, new_fs), old_fs));
+    if (i == 0) idx = 1;
+    out[i] = y[nfact + idx - 1];
+  }
+}
+
 // ---- fine frequency (acquisition.m:213-238): per-code-period sums of x[n] * code[floor(ts*(n + offset)/tc) mod len] *
 // exp(-1i*2*pi*f_bin*n/fs) for every fine bin, several detections per launch (blockIdx.x = code period, .y = detection,
 // .z = group of kFineBins bins).  The first version of this kernel evaluated sincos and the float64 code index once per
@@ -874,7 +971,8 @@ struct FineDet {
 };
 constexpr int kFineBins = 24;
 
-__global__ __launch_bounds__(256) void fine_multi_kernel(const int8_t* __restrict__ x, const FineDet* __restrict__ det, int spc,
+template <bool F32>  // F32: the conditioned complex float signal instead of the int8 record
+__global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict__ xv, const FineDet* __restrict__ det, int spc,
                                                           int ncodes, const int8_t* __restrict__ codes, int code_len, double ts,
                                                           double tc, double fstep, double fs, int nbins, int index_offset,
                                                           double* __restrict__ out) {
@@ -891,8 +989,17 @@ __global__ __launch_bounds__(256) void fine_multi_kernel(const int8_t* __restric
     const long long n = (long long)ci * spc + i;
     const double cvi = floor(__ddiv_rn(__dmul_rn(ts, (double)(n + index_offset)), tc));  // acquisition.m:215-216
     const float c = (float)code[(int)fmod(cvi, (double)code_len)];
-    const char2 xs = *reinterpret_cast<const char2*>(x + 2 * (dd.first + n));
-    const float cr = c * (float)xs.x, cq = c * (float)xs.y;
+    float xr, xq;
+    if constexpr (F32) {
+      const float2 z = reinterpret_cast<const float2*>(xv)[dd.first + n];
+      xr = z.x;
+      xq = z.y;
+    } else {
+      const char2 xs = *reinterpret_cast<const char2*>(reinterpret_cast<const int8_t*>(xv) + 2 * (dd.first + n));
+      xr = (float)xs.x;
+      xq = (float)xs.y;
+    }
+    const float cr = c * xr, cq = c * xq;
     const double ph = fmid * (double)n, dp = fst * (double)n;
     float sn, cs, sd, cd;
     sincospif(2.0f * (float)(ph - floor(ph)), &sn, &cs);
@@ -1205,10 +1312,18 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     gc_set_error("gc_acquire_coarse: bad arguments");
     return GC_E_INVALID;
   }
-  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
+  const bool cond = p->source == GC_ACQ_SOURCE_CONDITIONED;
+  if (cond) {
+    if (ctx->acq_cond_n <= 0) {
+      gc_set_error("gc_acquire_coarse: no conditioned signal (call gc_acq_condition first)");
+      return GC_E_STATE;
+    }
+  } else if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
     gc_set_error("gc_acquire_coarse: needs an int8 I/Q IF buffer");
     return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
   }
+  const uint64_t avail = cond ? (uint64_t)ctx->acq_cond_n : ctx->if_nsamples;
+  const float2* const cond_sig = cond ? (const float2*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p : nullptr;
   GC_HIP(hipSetDevice(ctx->device));
   const double x = p->sampling_freq / (p->code_freq_basis / p->code_length);
   const int spc = (int)std::floor(x + 0.5);                                     // acquisition.m:116
@@ -1238,9 +1353,9 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       }
     }
   }
-  if ((uint64_t)p->first_sample + (uint64_t)(H + 1) * spc > ctx->if_nsamples) {
+  if ((uint64_t)p->first_sample + (uint64_t)(H + 1) * spc > avail) {
     gc_set_error("gc_acquire_coarse: needs %lld samples from %lld, buffer holds %llu", (long long)(H + 1) * spc,
-                 (long long)p->first_sample, (unsigned long long)ctx->if_nsamples);
+                 (long long)p->first_sample, (unsigned long long)avail);
     return GC_E_RANGE;
   }
   AcqScratch* s = nullptr;
@@ -1251,20 +1366,27 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
 
   // sigPower = sqrt(var(x(1:spc)) * spc), var normalised by N-1 (acquisition.m:151)
   GC_HIP(hipMemsetAsync(s->sums, 0, 16 * sizeof(long long), ctx->stream));
-  hipLaunchKernelGGL(sigpower_kernel, dim3(64), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (long long)p->first_sample,
-                     spc, s->sums);
+  if (cond)
+    hipLaunchKernelGGL(sigpower_f32_kernel, dim3(1), dim3(1024), 0, ctx->stream, cond_sig, (long long)p->first_sample, spc, (double*)s->sums);
+  else
+    hipLaunchKernelGGL(sigpower_kernel, dim3(64), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (long long)p->first_sample,
+                       spc, s->sums);
   long long hs[3];
   GC_HIP(hipMemcpyAsync(hs, s->sums, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipMemcpyAsync(s->codes, sampled_codes, (size_t)nprn * narms * spc, hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
-  const double mr = (double)hs[0] / spc, mi = (double)hs[1] / spc;
-  const double var = ((double)hs[2] - spc * (mr * mr + mi * mi)) / (spc - 1);
+  double sum3[3];
+  if (cond) std::memcpy(sum3, hs, sizeof sum3);  // the float kernel wrote doubles
+  else for (int k = 0; k < 3; ++k) sum3[k] = (double)hs[k];
+  const double mr = sum3[0] / spc, mi = sum3[1] / spc;
+  const double var = (sum3[2] - spc * (mr * mr + mi * mi)) / (spc - 1);
   const double sig_power = std::sqrt(var * spc);
 
   // signal spectra for every (bin, hop)
   PassArgs base;
   std::memset(&base, 0, sizeof base);
   base.if_base = (const int8_t*)ctx->d_if;
+  base.if_f32 = cond_sig;
   base.first_sample = p->first_sample;
   base.spc = spc;
   base.nhops = H;
@@ -1357,6 +1479,97 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
 
 
 
+// ---- input conditioning (row A0) ----------------------------------------------------------------------------------------
+// fir1(order, [w1 w2]): Hamming-windowed ideal band-pass, scaled to unit gain at the centre of the pass band (float64 here)
+static std::vector<double> fir1_bandpass(int order, double w1, double w2) {
+  const int nb = order + 1;
+  const double alpha = 0.5 * order, pi = 3.14159265358979323846;
+  std::vector<double> h((size_t)nb);
+  auto sinc = [&](double x) { return x == 0.0 ? 1.0 : std::sin(pi * x) / (pi * x); };
+  for (int n = 0; n < nb; ++n) {
+    const double m = n - alpha;
+    h[n] = (w2 * sinc(w2 * m) - w1 * sinc(w1 * m)) * (0.54 - 0.46 * std::cos(2.0 * pi * n / order));
+  }
+  const double fc = 0.5 * (w1 + w2);
+  double g = 0.0;
+  for (int n = 0; n < nb; ++n) g += h[n] * std::cos(pi * (n - alpha) * fc);
+  for (double& v : h) v /= g;
+  return h;
+}
+
+extern "C" int gc_acq_condition(gc_context* ctx, const gc_acq_front_params* p, gc_acq_front_result* out) {
+  if (!ctx || !p || !out || p->n_samples <= 0 || p->first_sample < 0 || p->fir_order < 2 || p->fir_order > 4096 ||
+      !(p->sampling_freq > 0) || !(p->bandwidth > 0)) {
+    gc_set_error("gc_acq_condition: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
+    gc_set_error("gc_acq_condition: needs an int8 I/Q IF buffer");
+    return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  }
+  const long long n = p->n_samples;
+  const int nb = p->fir_order + 1, nfact = 3 * (nb - 1);  // filtfilt's edge length
+  if ((uint64_t)p->first_sample + (uint64_t)n > ctx->if_nsamples || n <= nfact) {
+    gc_set_error("gc_acq_condition: %lld samples from %lld: outside the record, or not longer than filtfilt's %d edge samples", n,
+                 (long long)p->first_sample, nfact);
+    return GC_E_RANGE;
+  }
+  const double fs = p->sampling_freq, IF = p->intermediate_freq, BW = p->bandwidth;
+  const double w1 = (IF - BW / 2) * 2 / fs, w2 = (IF + BW / 2) * 2 / fs;  // acquisition.m:60-62
+  if (!(w1 > 0.0) || !(w2 < 1.0)) {
+    gc_set_error("gc_acq_condition: band edges %g .. %g of the Nyquist frequency (fir1 needs 0 < w < 1)", w1, w2);
+    return GC_E_INVALID;
+  }
+  const std::vector<double> hd = fir1_bandpass(p->fir_order, w1, w2);
+  std::vector<float> hf(hd.begin(), hd.end());
+  // resampling frequency from the band-pass sampling bounds (:70-89)
+  const double fu = IF + BW / 2, fl = IF - BW / 2;
+  double nz = std::floor(fu / BW);
+  if (nz < 1) nz = 1;
+  const double lower = 2 * fu / nz, upper = nz > 1 ? 2 * fl / (nz - 1) : lower;
+  const double new_fs = std::ceil((lower + upper) / 2);
+  const long long len = (long long)std::floor((double)(n - 1) / fs * new_fs);  // :84
+  if (len <= 0) return GC_E_INVALID;
+  GC_HIP(hipSetDevice(ctx->device));
+  const long long ne = n + 2LL * nfact;
+  GcBuf& bsig = ctx->acqbuf[gc_context::ACQ_COND_SIG];
+  GcBuf& ba = ctx->acqbuf[gc_context::ACQ_COND_A];
+  GcBuf& bb = ctx->acqbuf[gc_context::ACQ_COND_B];
+  GcBuf& bt = ctx->acqbuf[gc_context::ACQ_COND_TAPS];
+  ctx->acq_cond_n = 0;
+  if (gc_buf_reserve(bsig, (size_t)len * sizeof(float2), false) != hipSuccess || gc_buf_reserve(ba, (size_t)ne * sizeof(float2), false) != hipSuccess ||
+      gc_buf_reserve(bb, (size_t)ne * sizeof(float2), false) != hipSuccess || gc_buf_reserve(bt, (size_t)nb * sizeof(float), false) != hipSuccess) {
+    gc_set_error("gc_acq_condition: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  GC_HIP(hipMemcpyAsync(bt.p, hf.data(), (size_t)nb * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  const unsigned int nblk = (unsigned int)((ne + 255) / 256);
+  const size_t smem = (size_t)(256 + nb - 1) * sizeof(float2);
+  hipLaunchKernelGGL(cond_extend_kernel, dim3(std::min(nblk, 65535u)), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if,
+                     (long long)p->first_sample, n, nfact, (float2*)ba.p);
+  hipLaunchKernelGGL(cond_fir_kernel<false>, dim3(nblk), dim3(256), smem, ctx->stream, (const float2*)ba.p, ne, (const float*)bt.p, nb, (float2*)bb.p);
+  hipLaunchKernelGGL(cond_fir_kernel<true>, dim3(nblk), dim3(256), smem, ctx->stream, (const float2*)bb.p, ne, (const float*)bt.p, nb, (float2*)ba.p);
+  hipLaunchKernelGGL(cond_decimate_kernel, dim3((unsigned int)std::min<long long>((len + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
+                     (const float2*)ba.p, nfact, fs, new_fs, len, (float2*)bsig.p);
+  GC_HIP(hipGetLastError());
+  GC_HIP(hipStreamSynchronize(ctx->stream));  // hf must outlive its copy
+  ctx->acq_cond_n = len;
+  out->sampling_freq = new_fs;
+  out->intermediate_freq = std::fmod(IF, new_fs);  // rem(), :95
+  out->n_samples = len;
+  return GC_OK;
+}
+
+extern "C" int gc_acq_conditioned(gc_context* ctx, int64_t first, int64_t n, float* dst) {
+  if (!ctx || !dst || first < 0 || n <= 0 || first + n > ctx->acq_cond_n) {
+    gc_set_error("gc_acq_conditioned: range outside the conditioned signal");
+    return GC_E_RANGE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  GC_HIP(hipMemcpy(dst, (const float2*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p + first, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+  return GC_OK;
+}
+
 // Generic fine-frequency stage: per-code-period complex sums of signal x code x carrier for `nbins`
 // carriers f0 - k*fstep over `ncodes` periods from first_sample; the hypothesis search over bit edges / Neuman-
 // Hofman / secondary codes / data+pilot combinations is a few hundred flops and stays with the caller.
@@ -1368,10 +1581,19 @@ extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params*
     gc_set_error("gc_acquire_fine_sums: bad arguments");
     return GC_E_INVALID;
   }
-  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  const bool cond = p->source == GC_ACQ_SOURCE_CONDITIONED;
+  if (cond) {
+    if (ctx->acq_cond_n <= 0) {
+      gc_set_error("gc_acquire_fine_sums: no conditioned signal (call gc_acq_condition first)");
+      return GC_E_STATE;
+    }
+  } else if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
+    return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  }
+  const uint64_t avail = cond ? (uint64_t)ctx->acq_cond_n : ctx->if_nsamples;
   std::vector<FineDet> hdet((size_t)ndet);
   for (int d = 0; d < ndet; ++d) {
-    if (first_sample[d] < 0 || (uint64_t)first_sample[d] + (uint64_t)p->ncodes * p->spc > ctx->if_nsamples) {
+    if (first_sample[d] < 0 || (uint64_t)first_sample[d] + (uint64_t)p->ncodes * p->spc > avail) {
       gc_set_error("gc_acquire_fine_sums: %d code periods from sample %lld exceed the IF buffer", p->ncodes, (long long)first_sample[d]);
       return first_sample[d] < 0 ? GC_E_INVALID : GC_E_RANGE;
     }
@@ -1392,9 +1614,14 @@ extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params*
   GC_HIP(hipMemcpyAsync(bcode.p, codes, (size_t)ndet * p->code_len, hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipMemcpyAsync(bdet.p, hdet.data(), (size_t)ndet * sizeof(FineDet), hipMemcpyHostToDevice, ctx->stream));
   const dim3 grid((unsigned int)p->ncodes, (unsigned int)ndet, (unsigned int)((p->nbins + kFineBins - 1) / kFineBins));
-  hipLaunchKernelGGL(fine_multi_kernel, grid, dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (const FineDet*)bdet.p, p->spc,
-                     p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq, 1.0 / p->code_freq, p->fstep,
-                     p->sampling_freq, p->nbins, p->index_offset, (double*)bout.p);
+  if (cond)
+    hipLaunchKernelGGL(fine_multi_kernel<true>, grid, dim3(256), 0, ctx->stream, (const void*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p,
+                       (const FineDet*)bdet.p, p->spc, p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq,
+                       1.0 / p->code_freq, p->fstep, p->sampling_freq, p->nbins, p->index_offset, (double*)bout.p);
+  else
+    hipLaunchKernelGGL(fine_multi_kernel<false>, grid, dim3(256), 0, ctx->stream, (const void*)ctx->d_if, (const FineDet*)bdet.p, p->spc,
+                       p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq, 1.0 / p->code_freq, p->fstep,
+                       p->sampling_freq, p->nbins, p->index_offset, (double*)bout.p);
   GC_HIP(hipGetLastError());
   GC_HIP(hipMemcpyAsync(out, bout.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));  // also keeps hdet / codes alive until the copies are done
@@ -1610,6 +1837,7 @@ extern "C" int gc_acquire_fine_l1ca_batch(gc_context* ctx, const gc_acq_params* 
   fp.nbins = nfine;
   fp.code_len = (int)p->code_length;
   fp.index_offset = 0;                                                           // codeValueIndex over (0 : 40*spc-1), :210
+  fp.source = p->source;
   std::vector<int64_t> first((size_t)ndet);
   std::vector<double> f0((size_t)ndet);
   for (int d = 0; d < ndet; ++d) {

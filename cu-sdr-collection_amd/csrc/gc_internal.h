@@ -148,8 +148,9 @@ struct gc_context {
 
   // acquisition scratch (acq.hip)
   void* acq_scratch = nullptr;
-  enum { ACQ_FINE_CODE = 0, ACQ_FINE_DET, ACQ_FINE_OUT, ACQ_NBUF };
-  GcBuf acqbuf[ACQ_NBUF];  // fine-frequency stage: codes, detections, per-code sums
+  enum { ACQ_FINE_CODE = 0, ACQ_FINE_DET, ACQ_FINE_OUT, ACQ_COND_SIG, ACQ_COND_A, ACQ_COND_B, ACQ_COND_TAPS, ACQ_NBUF };
+  GcBuf acqbuf[ACQ_NBUF];  // fine-frequency stage: codes, detections, per-code sums; conditioned signal of gc_acq_condition + its scratch
+  long long acq_cond_n = 0;  // complex float samples in acqbuf[ACQ_COND_SIG] (gc_acq_params.source = 1 searches them)
 
   // gc_track_multi: this context's tracking call runs next to other contexts' on the same device.  Its persistent kernels
   // are then launched with a plain launch instead of a cooperative one (gc_launch_persistent below).

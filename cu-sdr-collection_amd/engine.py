@@ -260,6 +260,23 @@ class Engine:
                                                out.ctypes.data_as(C.POINTER(C.c_double))))
         return out[..., 0] + 1j * out[..., 1]
 
+    def acq_condition(self, sampling_freq: float, intermediate_freq: float, bandwidth: float, first_sample: int, n_samples: int,
+                      fir_order: int = 700):
+        """gc_acq_condition: the zero-phase band-pass + decimation front end of acquisition.m:46-111 on the record's samples
+        [first_sample, first_sample + n_samples).  Returns (new sampling frequency, new IF, conditioned length); searches read
+        the conditioned signal with gc_acq_params.source = 1."""
+        fp = L.gc_acq_front_params(sampling_freq=sampling_freq, intermediate_freq=intermediate_freq, bandwidth=bandwidth,
+                                   first_sample=int(first_sample), n_samples=int(n_samples), fir_order=int(fir_order))
+        res = L.gc_acq_front_result()
+        L.check(self._lib.gc_acq_condition(self._ctx, C.byref(fp), C.byref(res)))
+        return res.sampling_freq, res.intermediate_freq, int(res.n_samples)
+
+    def acq_conditioned(self, first: int, n: int) -> np.ndarray:
+        """The conditioned signal back as complex64 (test hook)."""
+        out = np.empty(2 * int(n), dtype=np.float32)
+        L.check(self._lib.gc_acq_conditioned(self._ctx, int(first), int(n), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out[0::2] + 1j * out[1::2]
+
     def acquire_fine_sums_batch(self, params: L.gc_fine_params, codes: np.ndarray, first_sample, f0) -> np.ndarray:
         """The same for several detections in one launch: codes [ndet, code_len], first_sample [ndet], f0 [ndet]
         -> complex [ndet, nbins, ncodes]."""

@@ -90,26 +90,39 @@ def _acq_params(settings, first_sample: int) -> L.gc_acq_params:
     return p
 
 
-def acquisition(engine: Engine, settings, first_sample: int | None = None):
+def acquisition(engine: Engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """acqResults = acquisition(longSignal, settings) with longSignal = the IF buffer from
     `first_sample` (default settings.skipNumberOfBytes, as postProcessing.m:74-96 reads it).
 
-    Only the resampling-off path (initSettings.m:93 default) is implemented; the optional
-    FIR/decimation front end (acquisition.m:50-111) is out of scope.
+    With settings.resamplingflag == 1 and samplingFreq above settings.resamplingThreshold the search runs on the conditioned
+    signal of acquisition.m:46-111 (zero-phase FIR(700) band-pass + band-pass-sampling decimation, Engine.acq_condition) and the
+    results are mapped back to the record's sampling rate and IF (:264-276).  `n_long` = length(longSignal) for that case
+    (default: max(42, acqNonCohTime + 2) code periods, postProcessing.m:82-83, or what the buffer holds).
     """
-    if settings.samplingFreq > settings.resamplingThreshold and getattr(settings, "resamplingflag", getattr(settings, "resamplingFlag", 0)) == 1:
-        raise NotImplementedError("acquisition resampling front end (acquisition.m:50-111) is out of scope")
+    import copy
+    import math
     if first_sample is None:
         first_sample = skip_samples(settings)
-    prns = list(settings.acqSatelliteList)
+    flag = getattr(settings, "resamplingflag", getattr(settings, "resamplingFlag", 0))
+    resampled = settings.samplingFreq > settings.resamplingThreshold and flag == 1
+    S = settings
+    if resampled:
+        if n_long is None:
+            n_long = min(int(engine.if_buffer()[1]) - int(first_sample), max(42, int(settings.acqNonCohTime) + 2) * codes.samplesPerCode(settings))
+        bw = settings.codeFreqBasis * 2 + 0.5e6                      # acquisition.m:58
+        new_fs, new_if, _ = engine.acq_condition(settings.samplingFreq, settings.IF, bw, first_sample, n_long)
+        S = copy.copy(settings)
+        S.samplingFreq, S.IF = new_fs, new_if                        # :81,95
+    prns = list(S.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32))
-    p = _acq_params(settings, first_sample)
-    tables = np.stack([codes.makeCaTable(prn, settings) for prn in prns])
+    p = _acq_params(S, 0 if resampled else first_sample)
+    p.source = 1 if resampled else 0
+    tables = np.stack([codes.makeCaTable(prn, S) for prn in prns])
     res = engine.acquire_coarse(p, tables)
     found = []
     for prn, r in zip(prns, res):
         acq.peakMetric[prn - 1] = r.peak_metric                      # acquisition.m:200
-        if r.peak_metric > settings.acqThreshold:                    # :206
+        if r.peak_metric > S.acqThreshold:                           # :206
             found.append((prn, r))
     if found:                                                        # the fine stage of every detection in one launch
         f = engine.acquire_fine_l1ca_batch(p, np.stack([codes.generateCAcode(prn) for prn, _ in found]),
@@ -117,6 +130,13 @@ def acquisition(engine: Engine, settings, first_sample: int | None = None):
         for (prn, r), fk in zip(found, f):
             acq.carrFreq[prn - 1] = fk                               # :254-260
             acq.codePhase[prn - 1] = r.code_phase                    # :256
+            if resampled:                                            # :264-276: back to the record's rate and IF
+                acq.codePhase[prn - 1] = math.floor((r.code_phase - 1) / S.samplingFreq * settings.samplingFreq) + 1
+                if S.IF >= S.samplingFreq / 2:
+                    doppler = (S.samplingFreq - S.IF) - fk
+                else:
+                    doppler = fk - S.IF
+                acq.carrFreq[prn - 1] = doppler + settings.IF
     return acq
 
 

@@ -285,9 +285,10 @@ typedef struct gc_acq_params {
   double search_band;        /* settings.acqSearchBand (Hz, single-sided) */
   double search_step;        /* settings.acqSearchStep */
   int32_t non_coh_time;      /* settings.acqNonCohTime */
-  int32_t reserved;
-  int64_t first_sample;      /* start of longSignal within the IF buffer */
+  int32_t source;            /* 0: the IF record (int8 I/Q); GC_ACQ_SOURCE_CONDITIONED: the signal gc_acq_condition left */
+  int64_t first_sample;      /* start of longSignal within the IF buffer (or within the conditioned signal) */
 } gc_acq_params;
+#define GC_ACQ_SOURCE_CONDITIONED 1
 
 typedef struct gc_acq_result {
   int32_t coarse_bin;        /* 1-based frequency-bin index, acquisition.m:196 */
@@ -296,6 +297,31 @@ typedef struct gc_acq_result {
   double peak_metric;        /* peak/sigPower/acqNonCohTime, :200 */
   double coarse_freq;        /* coarseFreqBin(acqCoarseBin), :169-170 */
 } gc_acq_result;
+
+/* ---- acquisition, optional input conditioning (acquisition.m:46-111; the same block with its own
+ * bandwidth in ten packages; settings.resamplingflag, off by default): zero-phase band-pass around IF -
+ * longSignal = filtfilt(fir1(order, [IF - BW/2, IF + BW/2]*2/fs), 1, longSignal) with filtfilt's 3*order odd-reflected edge
+ * samples - then band-pass-sampling decimation by index selection, longSignal(ceil((0:len-1)/newFs*fs)) with the first index
+ * forced to 1, newFs = ceil of the centre of the admissible range, and IF -> rem(IF, newFs).  The conditioned complex float
+ * signal stays on the device; searches read it with gc_acq_params.source = GC_ACQ_SOURCE_CONDITIONED and the returned
+ * sampling frequency / IF (the caller maps code phase and carrier frequency back as acquisition.m:264-276 does). */
+typedef struct gc_acq_front_params {
+  double sampling_freq;      /* settings.samplingFreq */
+  double intermediate_freq;  /* settings.IF */
+  double bandwidth;          /* BW (acquisition.m:58: codeFreqBasis*2 + 0.5e6; per-package constants elsewhere) */
+  int64_t first_sample;      /* start of longSignal within the IF record */
+  int64_t n_samples;         /* length(longSignal) */
+  int32_t fir_order;         /* 700 */
+  int32_t reserved;
+} gc_acq_front_params;
+typedef struct gc_acq_front_result {
+  double sampling_freq;      /* settings.samplingFreq after the block (:81) */
+  double intermediate_freq;  /* settings.IF after the block (:95) */
+  int64_t n_samples;         /* signalLen (:84) */
+} gc_acq_front_result;
+int gc_acq_condition(gc_context* ctx, const gc_acq_front_params* p, gc_acq_front_result* out);
+/* test hook: the conditioned signal back as n complex floats (re, im interleaved) */
+int gc_acq_conditioned(gc_context* ctx, int64_t first, int64_t n, float* dst);
 
 /* `sampled_codes`: nprn rows of samplesPerCode int8 (makeCaTable.m:59-67 output).
  * For each PRN returns the coarse peak (acquisition.m:158-200). */
@@ -332,7 +358,7 @@ typedef struct gc_fine_params {
   int32_t nbins;
   int32_t code_len;          /* settings.codeLength */
   int32_t index_offset;      /* 0: codeValueIndex over (0:K*spc-1) (L1CA :210); 1: over (1:K*spc) (L5 :231) */
-  int32_t reserved;
+  int32_t source;            /* as gc_acq_params.source */
 } gc_fine_params;
 
 int gc_acquire_fine_sums(gc_context* ctx, const gc_fine_params* p, const int8_t* code, double* out);

@@ -17,11 +17,26 @@ if max(abs(x)) <= 127, x = int8(x); else, x = int16(x); end
 h = gnsscorr_context('longSignal', 'new');
 gnsscorr_mex('load_if', h, x, 2, settings.samplingFreq);
 
+%--- optional input conditioning (acquisition.m:46-111): zero-phase FIR(700) band-pass + band-pass-sampling decimation -----
+flag = 0;
+if isfield(settings, 'resamplingflag'), flag = settings.resamplingflag; end
+if isfield(settings, 'resamplingFlag'), flag = settings.resamplingFlag; end      % BDS/B3I spells it so
+resampled = settings.samplingFreq > settings.resamplingThreshold && flag == 1;
+if resampled
+    if ~strcmp(name, 'GPS_L1CA')
+        error('gnsscorr:acquisition', 'the resampling front end is wired for GPS_L1CA only (gnsscorr_mex(''acq_condition'') takes any bandwidth)');
+    end
+    c.samplingFreq = settings.samplingFreq;  c.IF = settings.IF;  c.bandwidth = settings.codeFreqBasis * 2 + 0.5e6;   % :58
+    c.firstSample = 0;  c.nSamples = numel(longSignal);
+    oldFreq = settings.samplingFreq;  oldIF = settings.IF;
+    [settings.samplingFreq, settings.IF] = gnsscorr_mex('acq_condition', h, c);                                      % :81,95
+end
+
 fs = settings.samplingFreq;  ts = 1 / fs;
 spc = round(fs / (settings.codeFreqBasis / settings.codeLength));      % acquisition.m:116
 a.samplingFreq = fs;  a.codeFreqBasis = settings.codeFreqBasis;  a.codeLength = settings.codeLength;  a.IF = settings.IF;
 a.acqSearchBand = settings.acqSearchBand;  a.acqSearchStep = settings.acqSearchStep;  a.acqNonCohTime = settings.acqNonCohTime;
-a.firstSample = 0;
+a.firstSample = 0;  a.source = double(resampled);
 NH20 = [1 1 1 1 1 -1 1 1 -1 -1 1 -1 1 -1 1 1 -1 -1 -1 1];              % GPS_L5C acquisition.m:131
 CS25 = [1 1 -1 -1 -1 1 1 1 1 1 1 1 -1 1 -1 1 -1 -1 1 -1 -1 1 1 -1 1];  % GAL_E1C acquisition.m:138
 
@@ -94,7 +109,7 @@ for k = 1:numel(prns)
         otherwise
             q.samplingFreq = fs;  q.codeFreq = 1 / tc;  q.f0 = res(5, k) + settings.acqSearchStep / 2;  q.fstep = f.fineStep;
             q.firstSample = res(2, k) - 1;  q.samplesPerCode = spc;  q.ncodes = f.ncodes;  q.nbins = nfine;
-            q.codeLength = L;  q.indexOffset = f.indexOffset;
+            q.codeLength = L;  q.indexOffset = f.indexOffset;  q.source = double(resampled);
             codes = f.fine(p);
             sums = cell(1, numel(codes));
             for m = 1:numel(codes)
@@ -125,6 +140,15 @@ for k = 1:numel(prns)
             carr = q.f0 - f.fineStep * (best - 1);
     end
     if carr == 0, carr = 1; end                                             % :258-260
+    if resampled                                                            % :264-276: back to the record's rate and IF
+        acqResults.codePhase(p) = floor((res(2, k) - 1) / settings.samplingFreq * oldFreq) + 1;
+        if settings.IF >= settings.samplingFreq / 2
+            doppler = (settings.samplingFreq - settings.IF) - carr;
+        else
+            doppler = carr - settings.IF;
+        end
+        carr = doppler + oldIF;
+    end
     acqResults.carrFreq(p) = carr;
 end
 end

@@ -73,6 +73,7 @@ static void fill_acq(const mxArray* s, gc_acq_params* p) {
   p->search_step = field(s, "acqSearchStep");
   p->non_coh_time = (int32_t)field(s, "acqNonCohTime");
   p->first_sample = (int64_t)field(s, "firstSample");
+  p->source = mxGetField(s, 0, "source") ? (int32_t)field(s, "source") : 0; /* 1: the signal 'acq_condition' left on the device */
 }
 
 /* gc_track_params from the struct gnsscorr_tracking.m builds (settings fields + the per-package extras) */
@@ -277,6 +278,24 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                              mxGetScalar(prhs[5]), &f))
       fail("gc_acquire_fine_l1ca");
     plhs[0] = mxCreateDoubleScalar(f);
+  } else if (!strcmp(cmd, "acq_condition")) {
+    /* [newFs, newIF, n] = gnsscorr_mex('acq_condition', h, struct(samplingFreq, IF, bandwidth, firstSample, nSamples[, firOrder])):
+       acquisition.m:46-111 on the GPU - zero-phase FIR band-pass + band-pass-sampling decimation of longSignal; later searches
+       with .source = 1 read the conditioned signal */
+    const mxArray* s = prhs[2];
+    gc_acq_front_params p;
+    gc_acq_front_result r;
+    memset(&p, 0, sizeof p);
+    p.sampling_freq = field(s, "samplingFreq");
+    p.intermediate_freq = field(s, "IF");
+    p.bandwidth = field(s, "bandwidth");
+    p.first_sample = (int64_t)field(s, "firstSample");
+    p.n_samples = (int64_t)field(s, "nSamples");
+    p.fir_order = mxGetField(s, 0, "firOrder") ? (int32_t)field(s, "firOrder") : 700;
+    if (gc_acq_condition(handle(prhs[1]), &p, &r)) fail("gc_acq_condition");
+    plhs[0] = mxCreateDoubleScalar(r.sampling_freq);
+    if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(r.intermediate_freq);
+    if (nlhs > 2) plhs[2] = mxCreateDoubleScalar((double)r.n_samples);
   } else if (!strcmp(cmd, "load_if_packed2")) {
     /* gnsscorr_mex('load_if_packed2', h, uint8(packed)): 2-bit packed complex samples (unpack_cplx.m:32-49) expanded on the GPU */
     if (gc_load_if_packed2(handle(prhs[1]), mxGetData(prhs[2]), (uint64_t)mxGetNumberOfElements(prhs[2]))) fail("gc_load_if_packed2");
@@ -295,6 +314,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.nbins = (int32_t)field(s, "nbins");
     p.code_len = (int32_t)field(s, "codeLength");
     p.index_offset = mxGetField(s, 0, "indexOffset") ? (int32_t)field(s, "indexOffset") : 0;
+    p.source = mxGetField(s, 0, "source") ? (int32_t)field(s, "source") : 0;
     plhs[0] = mxCreateDoubleMatrix((mwSize)(2 * p.ncodes), (mwSize)p.nbins, mxREAL); /* (re, im) pairs per code, one column per bin */
     if (gc_acquire_fine_sums(handle(prhs[1]), &p, (const int8_t*)mxGetData(prhs[3]), mxGetDoubles(plhs[0]))) fail("gc_acquire_fine_sums");
   } else if (!strcmp(cmd, "preamble_xcorr")) {

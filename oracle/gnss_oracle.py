@@ -438,11 +438,14 @@ def acquisition_coarse_results(long_signal: np.ndarray, prn: int, settings, tabl
 def acquisition_l1ca(long_signal: np.ndarray, settings, want_results: bool = False):
     """acqResults = acquisition(longSignal, settings) (acquisition.m:113-260).
 
-    Only the resampling-off path (initSettings.m:93 default) is restated.
+    With settings.resamplingflag == 1 above the resampling threshold the search runs on the conditioned signal
+    (acquisition_front_end, :46-111) and the results are mapped back (:264-276).
     Returns SimpleNamespace(carrFreq, codePhase, peakMetric) with 32 entries each and, for
     test use, coarseBin (1-based, 0 = not computed).
     """
-    assert not (settings.samplingFreq > settings.resamplingThreshold and settings.resamplingflag == 1)
+    original = settings
+    long_signal, settings = acquisition_front_end(long_signal, settings)
+    resampled = settings is not original
     spc = samples_per_code(settings)
     ts = 1.0 / settings.samplingFreq
     n_bins = int(matlab_round(settings.acqSearchBand * 2 / settings.acqSearchStep)) + 1
@@ -488,6 +491,13 @@ def acquisition_l1ca(long_signal: np.ndarray, settings, want_results: bool = Fal
             acq.codePhase[prn - 1] = code_phase
             if acq.carrFreq[prn - 1] == 0:  # :258-260
                 acq.carrFreq[prn - 1] = 1
+            if resampled:  # :264-276
+                acq.codePhase[prn - 1] = math.floor((code_phase - 1) / settings.samplingFreq * settings.oldFreq) + 1
+                if settings.IF >= settings.samplingFreq / 2:
+                    doppler = (settings.samplingFreq - settings.IF) - acq.carrFreq[prn - 1]
+                else:
+                    doppler = acq.carrFreq[prn - 1] - settings.IF
+                acq.carrFreq[prn - 1] = doppler + settings.oldIF
     if want_results:
         return acq, all_results
     return acq

@@ -371,6 +371,11 @@ ACQ_SCENES = [
     AcqScene("GPS_L1CA", "GPS/GPS_L1CA", "initSettings", dict(acqNonCohTime=4, acqSatelliteList=[3, 7, 11, 14, 19, 22, 28, 31]), _acq_l1ca_record,
              product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0),
              oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=1e-4),
+    # acquisition.m:46-111 (row A0): zero-phase FIR(700) band-pass + band-pass-sampling decimation, 18 Msps / IF 4.5 MHz ->
+    # 6 113 500 Hz (12 228 = 2^2*3*1019 points per search), results mapped back (:264-276)
+    AcqScene("GPS_L1CA_resampled", "GPS/GPS_L1CA", "initSettings", dict(acqNonCohTime=3, acqSatelliteList=[3, 7, 14, 22, 28, 31], IF=4.5e6, resamplingflag=1),
+             _acq_l1ca_record, product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0, n_long=44 * 18000),
+             oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=2e-3),
     AcqScene("GPS_L5C", "GPS/GPS_L5C", "initSettings_GPS_L5C", dict(acqNonCohTime=4, acqSearchBand=4500, acqSatelliteList=[3, 22, 9]),
              _acq_family_record("generateL5Icode", "generateL5Qcode", 1150.0, (3, 22), 101, 30),
              product=lambda P, eng, S: P.acq_family.acquisition_L5(eng, S, first_sample=0),

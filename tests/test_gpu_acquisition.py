@@ -422,3 +422,24 @@ def test_acquisition_at_sampling_rates_the_radix_plan_cannot_factor(engine, fs):
         assert abs(got.peakMetric[k] - ref.peakMetric[k]) < 1e-4 * ref.peakMetric[k], prn
         assert (ref.peakMetric[k] > S.acqThreshold) == (prn in {s.prn for s in sats}), prn
         assert got.codePhase[k] == ref.codePhase[k] and got.carrFreq[k] == ref.carrFreq[k], prn
+
+
+def test_input_conditioning_matches_filtfilt_and_the_references_decimation(engine):
+    """gc_acq_condition (acquisition.m:46-111, row A0) against the oracle's float64 restatement (scipy's fir1 / filtfilt
+    equivalents): the conditioned signal sample by sample, the new sampling frequency, IF and length exactly."""
+    import cu_sdr_collection_amd as P
+    import ref_scenes as RS
+    sc = next(s for s in RS.ACQ_SCENES if s.name == "GPS_L1CA_resampled")
+    S, rec = RS.acq_inputs(P, sc)
+    engine.load_if(rec, fs=S.samplingFreq)
+    n = rec.size // 2
+    new_fs, new_if, m = engine.acq_condition(S.samplingFreq, S.IF, S.codeFreqBasis * 2 + 0.5e6, 0, n)
+    x = rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64)
+    want, S2 = O.acquisition_front_end(x, S)
+    assert (new_fs, new_if, m) == (S2.samplingFreq, S2.IF, want.shape[0]) and new_fs == 6113500.0
+    got = engine.acq_conditioned(0, m)
+    assert np.max(np.abs(got - want)) < 2e-5 * np.max(np.abs(want))          # float32 accumulation over 2 x 701 taps
+    # edges included: the first and last 2100 output samples see filtfilt's reflected extension
+    assert np.max(np.abs(got[:800] - want[:800])) < 2e-5 * np.max(np.abs(want))
+    with pytest.raises(P.GnssCorrError):
+        engine.acq_condition(S.samplingFreq, 20e3, S.codeFreqBasis * 2 + 0.5e6, 0, n)     # lower band edge below 0: fir1 refuses it too
