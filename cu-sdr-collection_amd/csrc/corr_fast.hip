@@ -661,28 +661,38 @@ int launch_fast_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, di
   return GC_OK;
 }
 
-template <int SPL>
-int launch_devloop_mode(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share) {
+template <int MODE, int SPL>
+int launch_devloop_one(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share) {
   void* args[2] = {(void*)&a, (void*)&ib};
-  const void* fn = nullptr;
-  const bool qi = ctx->if_layout == GC_QI;
-  if (share) fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, true, 0, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, true, 0, true>;
-  else fn = qi ? (const void*)corr_epl_fast_kernel<1, I8_QI, SPL, false, false, 0, true> : (const void*)corr_epl_fast_kernel<1, I8_IQ, SPL, false, false, 0, true>;
+  const void* fn = share ? (const void*)corr_epl_fast_kernel<1, MODE, SPL, false, true, 0, true>
+                         : (const void*)corr_epl_fast_kernel<1, MODE, SPL, false, false, 0, true>;
   // cooperative: every team member must be resident while the others spin on the epoch flag
   GC_HIP(gc_launch_persistent(ctx, fn, grid, dim3(kFW), args, (unsigned int)smem));
   return GC_OK;
 }
 
+// 16-sample chunks exist for int8 I/Q and Q/I records only; every other record format takes 8-sample chunks
+int launch_devloop_mode(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share, bool spl16) {
+  const int lay = ctx->if_layout;
+  if (ctx->if_dtype == GC_I8 && lay != GC_REAL) {
+    if (spl16) return lay == GC_QI ? launch_devloop_one<I8_QI, 16>(ctx, a, ib, grid, smem, share) : launch_devloop_one<I8_IQ, 16>(ctx, a, ib, grid, smem, share);
+    return lay == GC_QI ? launch_devloop_one<I8_QI, 8>(ctx, a, ib, grid, smem, share) : launch_devloop_one<I8_IQ, 8>(ctx, a, ib, grid, smem, share);
+  }
+  if (ctx->if_dtype == GC_I8) return launch_devloop_one<I8_REAL, 8>(ctx, a, ib, grid, smem, share);
+  if (lay == GC_REAL) return launch_devloop_one<I16_REAL, 8>(ctx, a, ib, grid, smem, share);
+  return lay == GC_QI ? launch_devloop_one<I16_QI, 8>(ctx, a, ib, grid, smem, share) : launch_devloop_one<I16_IQ, 8>(ctx, a, ib, grid, smem, share);
+}
+
 }  // namespace
 
-// Persistent single-arm int8 I/Q (Q/I) tracker with device-side loop closure: grid = channels x splits one-wave workgroups.
+// Persistent single-arm tracker (any record format) with device-side loop closure: grid = channels x splits one-wave workgroups.
 int gc_launch_devloop(gc_context* ctx, const KArgs& a_in, unsigned int grid, bool spl16, bool share_el) {
   KArgs a = a_in;
   InlineBlocks ib;
   std::memset(&ib, 0, sizeof ib);
   a.red_off = 8 * ctx->max_lds_bytes;
   const size_t smem = (size_t)a.red_off + 8 * 3 * 64 + (size_t)16 * kFW * sizeof(float2);  // + the closer's reduction scratch + prefix sums
-  return spl16 ? launch_devloop_mode<16>(ctx, a, ib, dim3(grid), smem, share_el) : launch_devloop_mode<8>(ctx, a, ib, dim3(grid), smem, share_el);
+  return launch_devloop_mode(ctx, a, ib, dim3(grid), smem, share_el, spl16 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL);
 }
 
 bool gc_fast_prefers_wide() { return true; }

@@ -818,8 +818,10 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   const bool der = a.derived != 0 && max_arms == 3;  // third arm derived from the second: two tables in LDS (host-fed runs only)
   const int ap = gc_arm_pitch(der ? 2 : max_arms);
   const size_t tab_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 4 + 15) / 16 * 16;
-  if (tab_bytes > 96 * 1024 || (max_arms > 2 && !der) || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
-    gc_set_error("device loop on the lane kernel: tables above 96 KiB as f32, three arms or non-int8-I/Q records are not instantiated");
+  const bool i8c = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I
+  if (tab_bytes > 96 * 1024 || (max_arms > 2 && !der) || (der && !i8c)) {
+    gc_set_error("device loop on the lane kernel: tables above 96 KiB as f32, three arms, or a derived arm on a record other than int8 "
+                 "I/Q are not instantiated");
     return GC_E_UNSUPPORTED;
   }
   a.red_off = (int)tab_bytes;
@@ -833,8 +835,30 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
     GC_HIP(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
     return GC_OK;
   }
-  if (max_arms == 1) return qi ? launch_lane_devloop<1, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el, waves) : launch_lane_devloop<1, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el, waves);
-  return qi ? launch_lane_devloop<2, I8_QI>(ctx, a, ib, dim3(grid), smem, share_el, waves) : launch_lane_devloop<2, I8_IQ>(ctx, a, ib, dim3(grid), smem, share_el, waves);
+  int mode;
+  if (ctx->if_dtype == GC_I8)
+    mode = ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
+  else
+    mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
+  const dim3 g(grid);
+  if (max_arms == 1) {
+    switch (mode) {
+      case I8_IQ: return launch_lane_devloop<1, I8_IQ>(ctx, a, ib, g, smem, share_el, waves);
+      case I8_QI: return launch_lane_devloop<1, I8_QI>(ctx, a, ib, g, smem, share_el, waves);
+      case I16_IQ: return launch_lane_devloop<1, I16_IQ>(ctx, a, ib, g, smem, share_el, waves);
+      case I16_QI: return launch_lane_devloop<1, I16_QI>(ctx, a, ib, g, smem, share_el, waves);
+      case I8_REAL: return launch_lane_devloop<1, I8_REAL>(ctx, a, ib, g, smem, share_el, waves);
+      default: return launch_lane_devloop<1, I16_REAL>(ctx, a, ib, g, smem, share_el, waves);
+    }
+  }
+  switch (mode) {
+    case I8_IQ: return launch_lane_devloop<2, I8_IQ>(ctx, a, ib, g, smem, share_el, waves);
+    case I8_QI: return launch_lane_devloop<2, I8_QI>(ctx, a, ib, g, smem, share_el, waves);
+    case I16_IQ: return launch_lane_devloop<2, I16_IQ>(ctx, a, ib, g, smem, share_el, waves);
+    case I16_QI: return launch_lane_devloop<2, I16_QI>(ctx, a, ib, g, smem, share_el, waves);
+    case I8_REAL: return launch_lane_devloop<2, I8_REAL>(ctx, a, ib, g, smem, share_el, waves);
+    default: return launch_lane_devloop<2, I16_REAL>(ctx, a, ib, g, smem, share_el, waves);
+  }
 }
 
 // share_el: every block of the launch has 2*el_spacing*R*M an exact positive integer

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -38,6 +39,42 @@ extern "C" int gc_share_if(gc_context* dst, gc_context* src) {
   if (src->fs > 0) dst->fs = src->fs;
   return GC_OK;
 }
+
+namespace {
+// Streams for the concurrent jobs of one device.  Two persistent kernels overlap only when their streams sit on different
+// hardware queues, and the runtime maps streams to its few queues (GPU_MAX_HW_QUEUES, 4) by its own bookkeeping: whether the
+// contexts' own streams collide depended on how many streams the process had created before (bench.py: config 4's two jobs
+// took 1.32 s when they shared a queue and 0.66 s when they did not; GPU_MAX_HW_QUEUES = 2 / 8 moved the collision to other
+// configs).  Streams of different PRIORITY come from different queue pools, so three streams - normal, high, low - are on
+// three different queues whatever else the process did.  Created once per device, never destroyed.
+struct MultiStreams {
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  int n = 0;
+};
+MultiStreams* multi_streams(int device) {
+  static std::mutex mu;
+  static MultiStreams pool[64];
+  static bool made[64] = {false};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  MultiStreams& m = pool[device];
+  if (!made[device]) {
+    made[device] = true;
+    if (std::getenv("GC_MULTI_OWN_STREAMS") == nullptr && hipSetDevice(device) == hipSuccess) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      const int prio[3] = {0, greatest, least};
+      for (int k = 0; k < 3; ++k) {
+        if (k > 0 && (prio[k] == 0 || (k == 2 && prio[2] == prio[1]))) break;  // fewer distinct priorities than three
+        if (hipStreamCreateWithPriority(&m.s[m.n], hipStreamNonBlocking, prio[k]) != hipSuccess) break;
+        ++m.n;
+      }
+      (void)hipGetLastError();
+    }
+  }
+  return &m;
+}
+}  // namespace
 
 extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
   if (njobs <= 0 || !jobs) {
@@ -86,6 +123,20 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
     j.ctx->concurrent_jobs = false;
     return j.status;
   }
+  // jobs of one device onto streams of different hardware queues (multi_streams above); a device's fourth and later job keeps
+  // its context's own stream
+  std::vector<hipStream_t> own((size_t)njobs, nullptr);
+  for (int i = 0; i < njobs; ++i) {
+    int idx = 0;
+    for (int k = 0; k < i; ++k) idx += jobs[k].ctx->device == jobs[i].ctx->device;
+    MultiStreams* ms = multi_streams(jobs[i].ctx->device);
+    if (ms && idx < ms->n && jobs[i].ctx->concurrent_jobs) {
+      GC_HIP(hipSetDevice(jobs[i].ctx->device));
+      GC_HIP(hipStreamSynchronize(jobs[i].ctx->stream));
+      own[i] = jobs[i].ctx->stream;
+      jobs[i].ctx->stream = ms->s[idx];
+    }
+  }
   std::vector<std::thread> workers;
   workers.reserve((size_t)njobs);
   const bool timing = std::getenv("GC_TRACK_TIMING") != nullptr;
@@ -108,6 +159,11 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
   for (auto& w : workers) w.join();
   int first = GC_OK;
   for (int i = 0; i < njobs; ++i) {
+    if (own[i]) {
+      (void)hipSetDevice(jobs[i].ctx->device);
+      (void)hipStreamSynchronize(jobs[i].ctx->stream);
+      jobs[i].ctx->stream = own[i];
+    }
     jobs[i].ctx->concurrent_jobs = false;
     // a short read of one package (GC_E_RANGE, partial records returned) must not hide a failure of another
     if (jobs[i].status != GC_OK && (first == GC_OK || first == GC_E_RANGE)) {

@@ -204,11 +204,12 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   // cooperative launch of the fast kernel's persistent instantiation polls the descriptors this loop writes into
   // host-mapped memory and answers with tagged records (devloop.h, host_loop).  Launch-per-epoch costs ~5 us of dispatch
   // latency and ~13 us of kernel wall time per epoch; the persistent kernel answers in a few microseconds.  Covered:
-  // single-arm R = 1 channels on the transition-mask kernel with one-wave workgroups, int8 I/Q or Q/I (GPS L1 C/A, BDS B1I,
+  // single-arm R = 1 channels on the transition-mask kernel with one-wave workgroups, any record format (GPS L1 C/A, BDS B1I,
   // GLONASS); everything else keeps launching.
   bool persist = poll && !any_mixed && max_arms == 1 && fast_nominal > 0 && gc_fast_table_mode(ctx) == 0 && p->pilot_combine == 0 &&
-                 p->table_phase_count == 0 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && n_epochs > 0 &&
+                 p->table_phase_count == 0 && n_epochs > 0 &&
                  !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
+  const bool i8c_rec = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I (the derived-arm instantiation's only format)
   for (int c = 0; c < nch && persist; ++c) {
     const HostChannel& hcn = ctx->ch[init[c].channel];
     persist = hcn.arms == 1 && hcn.index_scale == 1.0 && hcn.mult[0] == 1.0 && hcn.window[0] == 0;
@@ -217,8 +218,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   // rate and index scale (GPS L5, BDS B2a / B3I, Galileo E5a / E5b / E1 B+C, BDS B1C narrow-band): member 0's first wave
   // gathers the team's sums, hands them to the host and relays the host's next descriptor
   const bool derived_nominal = any_mixed && all_mixed_derived && !any_three_plain;  // three arms, the third derived (E1-C CBOC)
-  bool persist_lane = !persist && poll && ((!any_mixed && max_arms <= 2) || derived_nominal) && p->table_phase_count == 0 && ctx->if_dtype == GC_I8 &&
-                      ctx->if_layout != GC_REAL && n_epochs > 0 &&
+  bool persist_lane = !persist && poll && ((!any_mixed && max_arms <= 2) || (derived_nominal && i8c_rec)) && p->table_phase_count == 0 && n_epochs > 0 &&
                       !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
   bool share_lane_nominal = true;
   for (int c = 0; c < nch && persist_lane; ++c) {
@@ -726,8 +726,9 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     gc_scope_add(ctx, ci);
   }
   const bool cboc = max_arms == 3 && all_derived && p->pilot_combine == 5;  // Galileo E1-C CBOC: three arms, the third derived
+  const bool i8c = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I record
   if ((max_arms > 2 && !cboc) || (p->pilot_combine > 3 && !cboc) || (p->pilot_combine != 0 && max_arms < 2) || p->table_phase_count != 0 ||
-      ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
+      (cboc && !i8c)) {
     gc_set_error("gc_track_device: configuration not covered by the persistent kernels (use gc_track)");
     return GC_E_UNSUPPORTED;
   }
@@ -758,6 +759,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     lowrate = std::min(lowrate, gc_block_lowrate_level(ctx, probe));
     share = share && gc_block_shares_el(ctx, b);
   }
+  if (!i8c) lowrate = std::min(lowrate, 1);  // 16-sample chunks are an int8 I/Q format (corr_fast.hip)
   // transition-mask kernel (one-wave members) where it applies, else the lane kernel (16-wave member workgroups)
   const bool use_fast = single_r1 && lowrate > 0 && p->pilot_combine == 0 && gc_fast_table_mode(ctx) == 0 && !ctx->force_generic;
   int splits, msgs_per_member, lane_waves = gcorr::kLaneWaves;

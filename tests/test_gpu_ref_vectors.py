@@ -21,14 +21,30 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _SUMS = ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")
 
 
+# scenes the device-closed loop (gc_track_device) is instantiated for: one- and two-arm channels, any record format; not the
+# windowed CL table of L2C, not B1C (f16 tables / the wide-band fold)
+_DEVICE_LOOP_SCENES = ("GPS_L1CA", "GPS_L1CA_int16_skip", "GPS_L1CA_real", "GPS_L5C", "GPS_L5C_data_only", "BDS_B2a", "BDS_B3I", "BDS_B1I",
+                       "GAL_E1C", "GAL_E5a", "GAL_E5b", "GLO_GL1", "GLO_GL2")
+
+
+@pytest.mark.parametrize("sc", [s for s in RS.TRACK_SCENES if s.name in _DEVICE_LOOP_SCENES], ids=[s.name for s in RS.TRACK_SCENES if s.name in _DEVICE_LOOP_SCENES])
+def test_device_closed_loop_equals_the_references_tracking_m(engine, sc):
+    """The same comparison with the loop closed on the GPU (one persistent launch, tracking.m:302-335 executed by the kernel)."""
+    _tracking_against_the_reference(engine, sc, device_loop=True)
+
+
 @pytest.mark.parametrize("sc", RS.TRACK_SCENES, ids=[s.name for s in RS.TRACK_SCENES])
 def test_hip_tracking_equals_the_references_tracking_m(engine, sc):
+    _tracking_against_the_reference(engine, sc, device_loop=False)
+
+
+def _tracking_against_the_reference(engine, sc, device_loop):
     import cu_sdr_collection_amd as P
     z = np.load(os.path.join(GOLD, f"ref_track_{sc.name}.npz"))
     S, rec, layout, ch = RS.scene_inputs(P, sc)
     assert RS.crc(rec) == int(z["record_crc32"][0]), "the synthetic record is not the one the fixture was generated from"
     engine.load_if(rec, layout=layout, fs=S.samplingFreq)
-    tr, _ = P.tracking(engine, ch, S, signal=sc.signal)
+    tr, _ = P.tracking(engine, ch, S, signal=sc.signal, device_loop=device_loop)
     ref_fields = [k[2:] for k in z.files if k.startswith("f_") and k != "f_PRN"]
     comp = 1 if layout == RS.GC_REAL else 2
     amp = 5.0 if rec.dtype == np.int16 else 1.0
