@@ -101,10 +101,11 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   const int cslot = (int)(wq - grp * p.stride);
 
   // ---- stage the tables once per workgroup (all its blocks share channel and table offsets) ----------
+  // DEVLOOP with a windowed table (GPS L2C's CL arm: 20 462 of 1 534 502 entries, the window moves on every epoch,
+  // GPS_L2C/include/tracking.m:261): staged again per epoch from the descriptor's table offsets
   int maxn = 0;
-  {
-    const long long lb0 = min(DEVLOOP ? wq : wave_items ? (wg * kLW) / nsplit : grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
-    const gc_block blk0 = DEVLOOP ? p.devloop->chan[lb0].blk : CL ? load_block(p, lb0) : p.blocks[lb0];
+  bool windowed = false;
+  auto stage_tables = [&](const gc_block& blk0) __attribute__((always_inline)) {
     const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
     const int arms0 = chn0->arms;
     int nent[LA];
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         nent[a] = min(chn0->stage_len[a], chn0->nent[a] - off);
         maxn = max(maxn, nent[a]);
         plain &= off == 0 && chn0->stage_len[a] == chn0->nent[a];
+        windowed |= chn0->stage_len[a] != chn0->nent[a];
       }
     }
     if (plain) {
@@ -143,6 +145,10 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       }
     }
     __syncthreads();  // the only barrier
+  };
+  {
+    const long long lb0 = min(DEVLOOP ? wq : wave_items ? (wg * kLW) / nsplit : grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
+    stage_tables(DEVLOOP ? p.devloop->chan[lb0].blk : CL ? load_block(p, lb0) : p.blocks[lb0]);
   }
   if (wave_items && wq >= p.nblocks) return;
 
@@ -194,6 +200,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     __syncthreads();
     if (*sstatus != 0) break;  // uniform over the workgroup: record exhausted / timed out
     blk = *sblk;
+    // every wave is past the barrier above: nobody reads the old window any more (host-fed runs stage their first window here too:
+    // the team's initial block carries no table offsets)
+    if (windowed && (bi > 0 || p.devloop->host_loop)) stage_tables(blk);
   } else {
     blk = CL ? load_block(p, lb) : p.blocks[lb];
   }
@@ -817,11 +826,14 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   std::memset(&ib, 0, sizeof ib);
   const bool der = a.derived != 0 && max_arms == 3;  // third arm derived from the second: two tables in LDS (host-fed runs only)
   const int ap = gc_arm_pitch(der ? 2 : max_arms);
-  const size_t tab_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 4 + 15) / 16 * 16;
+  const size_t f32_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 4 + 15) / 16 * 16;
+  const size_t f16_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 2 + 15) / 16 * 16;
+  const bool half_tables = f32_bytes > 96 * 1024;  // BDS B1C: two 20 462-entry arms = 164 KB as f32, 82 KB as f16
+  const size_t tab_bytes = half_tables ? f16_bytes : f32_bytes;
   const bool i8c = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I
-  if (tab_bytes > 96 * 1024 || (max_arms > 2 && !der) || (der && !i8c)) {
-    gc_set_error("device loop on the lane kernel: tables above 96 KiB as f32, three arms, or a derived arm on a record other than int8 "
-                 "I/Q are not instantiated");
+  if ((half_tables && (f16_bytes + 4096 > 160 * 1024 || !i8c)) || (max_arms > 2 && !der) || (der && !i8c)) {
+    gc_set_error("device loop on the lane kernel: tables above 156 KiB as f16, f16 tables or a derived arm on a record other than int8 I/Q, "
+                 "or three independent arms are not instantiated");
     return GC_E_UNSUPPORTED;
   }
   a.red_off = (int)tab_bytes;
@@ -830,7 +842,16 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   if (waves < 1 || waves > kLW) return GC_E_INVALID;
   if (der) {
     void* args[2] = {(void*)&a, (void*)&ib};
-    const void* fn = qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 0, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>;
+    const void* fn = half_tables ? (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 2, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 2, true, true>)
+                                 : (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 0, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>);
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    GC_HIP(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
+    return GC_OK;
+  }
+  if (half_tables) {  // f16 tables: int8 I/Q and Q/I
+    void* args[2] = {(void*)&a, (void*)&ib};
+    const void* fn = max_arms == 1 ? (qi ? (const void*)corr_epl_lane_kernel<1, I8_QI, false, 2, true> : (const void*)corr_epl_lane_kernel<1, I8_IQ, false, 2, true>)
+                                   : (qi ? (const void*)corr_epl_lane_kernel<2, I8_QI, false, 2, true> : (const void*)corr_epl_lane_kernel<2, I8_IQ, false, 2, true>);
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     GC_HIP(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
     return GC_OK;

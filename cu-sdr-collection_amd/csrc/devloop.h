@@ -33,6 +33,8 @@ struct DevLoopChan {
   double old_code_nco, old_code_err, old_carr_nco, old_carr_err;  // 2nd-order PLL / DLL
   double d2_carr_err, d_carr_err;                                 // 3-state PLL
   double pad[3];
+  int table_phase;  // GPS L2C CLCodePhase (1-based segment of the CL code; 0: none), GPS_L2C/include/tracking.m:261,357-360
+  int pad_i;
 };
 
 struct DevLoopArgs {
@@ -136,6 +138,15 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
         const double a11 = sqrt(10.0 / 11.0), a61 = -sqrt(1.0 / 11.0);
 #pragma unroll
         for (int v = 0; v < 6; ++v) p6[v] = a11 * sums[6 + v] + a61 * sums[12 + v];
+      } else if (p.pilot_combine == 4 && arms >= 3) {
+        // BDS B1C wide-band: arms {data, pilot BOC(1,1), pilot BOC(6,1)} -> one pilot (WB_tracking.m:364-369; track.hip)
+        const double a61 = -sqrt(4.0 / 33.0), a11 = sqrt(29.0 / 33.0);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const double i11 = sums[6 + 2 * x], q11 = sums[7 + 2 * x], i61 = sums[12 + 2 * x], q61 = sums[13 + 2 * x];
+          p6[2 * x] = a61 * i61 + a11 * q11;
+          p6[2 * x + 1] = a61 * q61 - a11 * i11;
+        }
       }
     }
     const double pi_e = p6[0], pq_e = p6[1], pi_p = p6[2], pq_p = p6[3], pi_l = p6[4], pq_l = p6[5];
@@ -160,8 +171,11 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
     }
     carr_err = pll_w ? (carr_err * p.pll_weight[0] + carr_err_q * p.pll_weight[1]) / (p.pll_weight[0] + p.pll_weight[1])
                      : (carr_err + carr_err_q) / 2;
-    code_err = dll_w ? (code_err * p.dll_weight[0] + code_err_q * p.dll_weight[1]) / (p.dll_weight[0] + p.dll_weight[1])
-                     : (code_err + code_err_q) / 2;
+    if (dll_w && p.pilot_combine == 4)  // codeError*factor + p_codeError*(1-factor), WB_tracking.m:403
+      code_err = code_err * p.dll_weight[0] + code_err_q * p.dll_weight[1];
+    else
+      code_err = dll_w ? (code_err * p.dll_weight[0] + code_err_q * p.dll_weight[1]) / (p.dll_weight[0] + p.dll_weight[1])
+                       : (code_err + code_err_q) / 2;
     rec(GC_TRK_PILOT_I_E, pi_e);
     rec(GC_TRK_PILOT_Q_E, pq_e);
     rec(GC_TRK_PILOT_I_P, pi_p);
@@ -223,6 +237,13 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
   st.d_carr_err = d1;
   st.epochs_done = e + 1;
   st.status = status;
+  if (p.table_phase_count > 0 && st.table_phase > 0) {  // GPS_L2C tracking.m:357-360, then :261 for the next block
+    if (p.pilot_combine != 0) {
+      st.table_phase += 1;
+      if (st.table_phase >= p.table_phase_count + 1) st.table_phase = 1;
+    }
+    b.table_offset[1] = (int)p.code_length * (st.table_phase - 1);
+  }
   b.blksize = n_new;
   b.first_sample = pos_new;
   b.rem_code_phase = rem_code_new;
@@ -254,6 +275,7 @@ __device__ inline void devloop_commit(const DevLoopArgs* __restrict__ dl, DevLoo
   gch->d_carr_err = st.d_carr_err;
   gch->epochs_done = st.epochs_done;
   gch->status = st.status;
+  gch->table_phase = st.table_phase;
 }
 
 // All parts back to back on the state held in device memory (lane kernel's closer): state read and written in place, records

@@ -218,12 +218,10 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   // rate and index scale (GPS L5, BDS B2a / B3I, Galileo E5a / E5b / E1 B+C, BDS B1C narrow-band): member 0's first wave
   // gathers the team's sums, hands them to the host and relays the host's next descriptor
   const bool derived_nominal = any_mixed && all_mixed_derived && !any_three_plain;  // three arms, the third derived (E1-C CBOC)
-  bool persist_lane = !persist && poll && ((!any_mixed && max_arms <= 2) || (derived_nominal && i8c_rec)) && p->table_phase_count == 0 && n_epochs > 0 &&
+  bool persist_lane = !persist && poll && ((!any_mixed && max_arms <= 2) || (derived_nominal && i8c_rec)) && n_epochs > 0 &&
                       !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
   bool share_lane_nominal = true;
   for (int c = 0; c < nch && persist_lane; ++c) {
-    const HostChannel& hcn = ctx->ch[init[c].channel];
-    for (int a = 0; a < hcn.arms; ++a) persist_lane = persist_lane && hcn.window[a] == 0;
     gc_block probe;
     std::memset(&probe, 0, sizeof probe);
     probe.channel = init[c].channel;
@@ -716,8 +714,8 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     const bool hder = gc_channel_is_derived(hcn);  // three arms, the third derived from the second inside the lane kernel
     all_derived = all_derived && hder;
     for (int a = 0; a < hcn.arms; ++a)
-      if (!hcn.d_tab[a] || (hcn.mult[a] != 1.0 && !(hder && a == 2)) || hcn.window[a] != 0) {
-        gc_set_error("gc_track_device: windowed tables / ramp multipliers are not covered (use gc_track)");
+      if (!hcn.d_tab[a] || (hcn.mult[a] != 1.0 && !(hder && a == 2))) {
+        gc_set_error("gc_track_device: ramp multipliers other than a derived third arm are not covered (use gc_track)");
         return GC_E_UNSUPPORTED;
       }
     if ((rc = validate_track_channel(ctx, p, init[c], "gc_track_device"))) return rc;
@@ -725,10 +723,10 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     single_r1 = single_r1 && hcn.arms == 1 && hcn.index_scale == 1.0;
     gc_scope_add(ctx, ci);
   }
-  const bool cboc = max_arms == 3 && all_derived && p->pilot_combine == 5;  // Galileo E1-C CBOC: three arms, the third derived
+  // three arms, the third derived from the second: Galileo E1-C CBOC (fold 5), BDS B1C wide-band (fold 4)
+  const bool cboc = max_arms == 3 && all_derived && (p->pilot_combine == 5 || p->pilot_combine == 4);
   const bool i8c = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I record
-  if ((max_arms > 2 && !cboc) || (p->pilot_combine > 3 && !cboc) || (p->pilot_combine != 0 && max_arms < 2) || p->table_phase_count != 0 ||
-      (cboc && !i8c)) {
+  if ((max_arms > 2 && !cboc) || (p->pilot_combine > 3 && !cboc) || (p->pilot_combine != 0 && max_arms < 2) || (cboc && !i8c)) {
     gc_set_error("gc_track_device: configuration not covered by the persistent kernels (use gc_track)");
     return GC_E_UNSUPPORTED;
   }
@@ -742,10 +740,13 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     s.pos = p->skip_samples + init[c].code_phase - 1;  // tracking.m:150-152
     s.code_freq = s.code_freq_basis = init[c].code_freq;
     s.carr_freq = s.carr_basis = init[c].acquired_freq;
+    s.table_phase = init[c].table_phase;
     const double step = s.code_freq / p->sampling_freq;
     const int n = (int)std::ceil((p->code_length - s.rem_code) / step);
     gc_block& b = s.blk;
     b.channel = init[c].channel;
+    if (p->table_phase_count > 0 && s.table_phase > 0)  // GPS_L2C tracking.m:261: index + codeLength*(CLCodePhase-1)
+      b.table_offset[1] = (int32_t)p->code_length * (s.table_phase - 1);
     b.blksize = n;
     b.first_sample = s.pos;
     b.rem_code_phase = 0.0;
@@ -761,7 +762,10 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   }
   if (!i8c) lowrate = std::min(lowrate, 1);  // 16-sample chunks are an int8 I/Q format (corr_fast.hip)
   // transition-mask kernel (one-wave members) where it applies, else the lane kernel (16-wave member workgroups)
-  const bool use_fast = single_r1 && lowrate > 0 && p->pilot_combine == 0 && gc_fast_table_mode(ctx) == 0 && !ctx->force_generic;
+  bool any_window = false;
+  for (int c = 0; c < nch; ++c)
+    for (int a = 0; a < ctx->ch[init[c].channel].arms; ++a) any_window = any_window || ctx->ch[init[c].channel].window[a] != 0;
+  const bool use_fast = single_r1 && lowrate > 0 && p->pilot_combine == 0 && gc_fast_table_mode(ctx) == 0 && !ctx->force_generic && !any_window;
   int splits, msgs_per_member, lane_waves = gcorr::kLaneWaves;
   bool share_lane = true;
   const int spl = lowrate == 2 ? 16 : 8;

@@ -21,10 +21,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _SUMS = ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")
 
 
-# scenes the device-closed loop (gc_track_device) is instantiated for: one- and two-arm channels, any record format; not the
-# windowed CL table of L2C, not B1C (f16 tables / the wide-band fold)
+# scenes the device-closed loop (gc_track_device) is instantiated for: all of them
 _DEVICE_LOOP_SCENES = ("GPS_L1CA", "GPS_L1CA_int16_skip", "GPS_L1CA_real", "GPS_L5C", "GPS_L5C_data_only", "BDS_B2a", "BDS_B3I", "BDS_B1I",
-                       "GAL_E1C", "GAL_E5a", "GAL_E5b", "GLO_GL1", "GLO_GL2")
+                       "GAL_E1C", "GAL_E5a", "GAL_E5b", "GLO_GL1", "GLO_GL2", "BDS_B1C_NB", "BDS_B1C_WB", "GPS_L2C")
 
 
 @pytest.mark.parametrize("sc", [s for s in RS.TRACK_SCENES if s.name in _DEVICE_LOOP_SCENES], ids=[s.name for s in RS.TRACK_SCENES if s.name in _DEVICE_LOOP_SCENES])
