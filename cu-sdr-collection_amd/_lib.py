@@ -42,7 +42,8 @@ class gc_track_params(C.Structure):
                 ("pll_kind", C.c_int32), ("pilot_combine", C.c_int32),
                 ("pf1", C.c_double), ("pf2", C.c_double), ("pf3", C.c_double),
                 ("skip_samples", C.c_int64), ("n_epochs", C.c_int32), ("table_phase_count", C.c_int32),
-                ("pll_weight", C.c_double * 2), ("dll_weight", C.c_double * 2), ("dll_scale", C.c_double)]
+                ("pll_weight", C.c_double * 2), ("dll_weight", C.c_double * 2), ("dll_scale", C.c_double),
+                ("cno_interval", C.c_int32), ("reserved3", C.c_int32), ("cno_acc_time", C.c_double)]
 
 
 class gc_channel_init(C.Structure):
@@ -132,6 +133,7 @@ SYMBOLS = {
                                   C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gc_track_file": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.POINTER(gc_track_params), C.c_int,
                                 C.POINTER(gc_channel_init), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "gc_set_cno_output": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int64]),
     "gc_share_if": (C.c_int, [_P, _P]),
     "gc_track_multi": (C.c_int, [C.c_int, C.POINTER(gc_track_job)]),
     "gc_acquire_coarse": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(gc_acq_result)]),

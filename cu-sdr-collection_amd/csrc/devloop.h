@@ -34,7 +34,9 @@ struct DevLoopChan {
   double d2_carr_err, d_carr_err;                                 // 3-state PLL
   double pad[3];
   int table_phase;  // GPS L2C CLCodePhase (1-based segment of the CL code; 0: none), GPS_L2C/include/tracking.m:261,357-360
-  int pad_i;
+  int cno_n;        // C/N0 intervals completed; cno_value is the latest one when cno_ready
+  double cno_z0, cno_s1, cno_s2, cno_value;  // running sums of Z - Z0 and (Z - Z0)^2 over the current interval (Z = I_P^2 + Q_P^2)
+  int cno_ready, pad_i;
 };
 
 struct DevLoopArgs {
@@ -57,6 +59,9 @@ struct DevLoopArgs {
   // them) but nothing is launched per epoch: member 0 of a team polls the channel's descriptor messages in host-mapped
   // memory (tag = epoch + 1), relays them to its team through desc_msg, and every member writes its six partial sums as
   // tagged 16-byte records straight into host-mapped memory, where the host polls them.
+  // C/N0 by the variance-summing method inside the loop (gc_track_params::cno_interval): [nch][cno_nk], device memory
+  double* cno;
+  int cno_nk, pad_cno;
   int host_loop;
   const msg_t* host_desc;       // [nch][kDescWords], host-mapped
   void* host_tagged;            // TaggedSlot [nch][splits][GC_OUT_STRIDE], host-mapped
@@ -121,6 +126,37 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
   const double kPi = 3.141592653589793;
   const int n = b.blksize;
   const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
+  if (p.cno_interval > 0 && dl->cno) {
+    // CNoVSM(I_P(loopCnt-K+1:loopCnt), Q_P(...), T) when rem(loopCnt, K) == 0 (tracking.m:351-358; Common/CNoVSM.m:38-47):
+    // Z = I^2 + Q^2, Zm = mean(Z), Zv = var(Z) (N-1), Pav = sqrt(Zm^2 - Zv), Nv = (Zm - Pav)/2, 10*log10(|Pav/(2*Nv)/T|).
+    // Sums of Z - Z0 (Z0 = the interval's first Z) keep the one-pass variance free of cancellation.
+    const int K = p.cno_interval, kk = e % K;
+    const double z = i_p * i_p + q_p * q_p;
+    if (kk == 0) {
+      st.cno_z0 = z;
+      st.cno_s1 = 0.0;
+      st.cno_s2 = 0.0;
+    }
+    const double dz = z - st.cno_z0;
+    st.cno_s1 += dz;
+    st.cno_s2 += dz * dz;
+    st.cno_ready = 0;
+    if (kk == K - 1 && K > 1) {
+      const double m = st.cno_s1 / K, zm = st.cno_z0 + m, zv = (st.cno_s2 - st.cno_s1 * m) / (K - 1);
+      const double d = zm * zm - zv;
+      double ratio;  // |Pav / (2*Nv)|
+      if (d >= 0.0) {
+        const double pav = sqrt(d);
+        ratio = fabs(pav / (zm - pav));
+      } else {  // Pav imaginary: |i*s / (Zm - i*s)|
+        const double s2 = -d;
+        ratio = sqrt(s2 / (zm * zm + s2));
+      }
+      st.cno_value = 10.0 * log10(ratio / p.cno_acc_time);
+      st.cno_n = (e + 1) / K;
+      st.cno_ready = 1;
+    }
+  }
   rec(GC_TRK_ABSOLUTE_SAMPLE, (double)st.pos);
   rec(GC_TRK_REM_CODE_PHASE, st.rem_code);
   rec(GC_TRK_REM_CARR_PHASE, st.rem_carr);
@@ -276,6 +312,7 @@ __device__ inline void devloop_commit(const DevLoopArgs* __restrict__ dl, DevLoo
   gch->epochs_done = st.epochs_done;
   gch->status = st.status;
   gch->table_phase = st.table_phase;
+  if (dl->cno && st.cno_ready && st.cno_n >= 1 && st.cno_n <= dl->cno_nk) dl->cno[slot * dl->cno_nk + st.cno_n - 1] = st.cno_value;
 }
 
 // All parts back to back on the state held in device memory (lane kernel's closer): state read and written in place, records

@@ -154,8 +154,10 @@ struct gc_context {
 
   // gc_track_multi: this context's tracking call runs next to other contexts' on the same device.  Its persistent kernels
   // are then launched with a plain launch instead of a cooperative one (gc_launch_persistent below).
-  enum { TRK_CHAN = 0, TRK_DESC, TRK_PART, TRK_ARGS, TRK_RECORDS, TRK_HDESC, TRK_NBUF };
+  enum { TRK_CHAN = 0, TRK_DESC, TRK_PART, TRK_ARGS, TRK_RECORDS, TRK_HDESC, TRK_CNO, TRK_NBUF };
   GcBuf trk[TRK_NBUF];  // gc_track / gc_track_device: channel state, descriptor and partial-sum messages, arguments, records
+  double* cno_out = nullptr;  // gc_set_cno_output: caller-owned C/N0 buffer of the next tracking calls
+  long long cno_cap = 0;
   bool concurrent_jobs = false;
   int concurrent_channels = 0;  // channels of all jobs on this device (sizes the persistent kernels' teams)
 };
@@ -182,6 +184,9 @@ struct GcTrackResume {
 };
 int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init, double* out,
                     int32_t* epochs_done, GcTrackResume* r);
+
+// trackResults.CNo.VSMValue of finished records on the host (the host-closed loops; the device loop has its own copy in devloop.h)
+void gc_fill_cno_host(gc_context* ctx, const gc_track_params* p, int nch, const double* out, const int32_t* epochs_done);
 
 int gc_bytes_per_sample(int dtype, int layout);
 void gc_acq_free(gc_context* ctx);  // acq.hip

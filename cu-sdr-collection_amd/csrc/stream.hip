@@ -253,5 +253,6 @@ extern "C" int gc_track_file(gc_context* ctx, const char* path, uint64_t skip_by
       epochs_done[c] = done_total[c];
     }
   }
+  gc_fill_cno_host(ctx, p, nch, out, epochs_done);
   return last_rc;
 }

@@ -82,7 +82,56 @@ int validate_track_channel(const gc_context* ctx, const gc_track_params* p, cons
 
 extern "C" int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
                         double* out, int32_t* epochs_done) {
-  return gc_track_window(ctx, p, nch, init, out, epochs_done, nullptr);
+  const int rc = gc_track_window(ctx, p, nch, init, out, epochs_done, nullptr);
+  if (rc == GC_OK || rc == GC_E_RANGE) gc_fill_cno_host(ctx, p, nch, out, epochs_done);
+  return rc;
+}
+
+extern "C" int gc_set_cno_output(gc_context* ctx, double* cno, int64_t capacity) {
+  if (!ctx || capacity < 0 || (cno && capacity == 0)) {
+    gc_set_error("gc_set_cno_output: bad arguments");
+    return GC_E_INVALID;
+  }
+  ctx->cno_out = cno;
+  ctx->cno_cap = cno ? capacity : 0;
+  return GC_OK;
+}
+
+// CNoVSM over the recorded data-arm prompt sums, interval by interval, exactly as tracking.m:351-358 calls it (two-pass mean and
+// N-1 variance like MATLAB's; Common/CNoVSM.m:38-47)
+void gc_fill_cno_host(gc_context* ctx, const gc_track_params* p, int nch, const double* out, const int32_t* epochs_done) {
+  const int K = p->cno_interval;
+  if (!ctx->cno_out || K <= 1) return;
+  const int n_epochs = p->n_epochs, nk = n_epochs / K;
+  if ((long long)nch * nk > ctx->cno_cap) return;
+  for (int c = 0; c < nch; ++c) {
+    const double* ip = out + ((size_t)c * GC_TRK_NFIELDS + GC_TRK_I_P) * n_epochs;
+    const double* qp = out + ((size_t)c * GC_TRK_NFIELDS + GC_TRK_Q_P) * n_epochs;
+    for (int k = 0; k < nk; ++k) {
+      double v = 0.0;
+      if ((k + 1) * K <= epochs_done[c]) {
+        double zm = 0.0;
+        for (int e = k * K; e < (k + 1) * K; ++e) zm += ip[e] * ip[e] + qp[e] * qp[e];
+        zm /= K;
+        double zv = 0.0;
+        for (int e = k * K; e < (k + 1) * K; ++e) {
+          const double dz = ip[e] * ip[e] + qp[e] * qp[e] - zm;
+          zv += dz * dz;
+        }
+        zv /= (K - 1);
+        const double d = zm * zm - zv;
+        double ratio;
+        if (d >= 0.0) {
+          const double pav = std::sqrt(d);
+          ratio = std::fabs(pav / (zm - pav));
+        } else {
+          ratio = std::sqrt(-d / (zm * zm - d));
+        }
+        v = 10.0 * std::log10(ratio / p->cno_acc_time);
+      }
+      ctx->cno_out[(size_t)c * nk + k] = v;
+    }
+  }
 }
 
 // gc_track over one window of a record (GcTrackResume, gc_internal.h): channel state comes from / goes back to r->state,
@@ -815,9 +864,18 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_DESC], desc_bytes, false);
   if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_RECORDS], rec_bytes, false);
   if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_ARGS], sizeof ha, false);
+  const int cno_nk = (p->cno_interval > 1 && ctx->cno_out) ? n_epochs / p->cno_interval : 0;
+  const bool want_cno = cno_nk > 0 && (long long)nch * cno_nk <= ctx->cno_cap;
+  const size_t cno_bytes = sizeof(double) * (size_t)nch * (size_t)std::max(cno_nk, 1);
+  if (e == hipSuccess && want_cno) e = gc_buf_reserve(ctx->trk[gc_context::TRK_CNO], cno_bytes, false);
   if (e != hipSuccess) {
     gc_set_error("gc_track_device: %s", hipGetErrorString(e));
     return GC_E_NOMEM;
+  }
+  if (want_cno) {
+    ha.cno = (double*)ctx->trk[gc_context::TRK_CNO].p;
+    ha.cno_nk = cno_nk;
+    if (hipMemsetAsync(ha.cno, 0, cno_bytes, ctx->stream) != hipSuccess) return GC_E_HIP;
   }
   ha.chan = (gcorr::DevLoopChan*)ctx->trk[gc_context::TRK_CHAN].p;
   ha.part_msg = (gcorr::msg_t*)ctx->trk[gc_context::TRK_PART].p;
@@ -870,6 +928,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
                    std::chrono::duration<double, std::micro>(t_k - t_l).count() / n_epochs,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k).count());
     if (e == hipSuccess) e = hipMemcpy(hc.data(), ha.chan, sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && want_cno) e = hipMemcpy(ctx->cno_out, ha.cno, cno_bytes, hipMemcpyDeviceToHost);  // computed by the closer (devloop.h)
     if (e != hipSuccess) {
       gc_set_error("gc_track_device: %s", hipGetErrorString(e));
       rc = GC_E_HIP;

@@ -171,12 +171,28 @@ class Engine:
         out = np.zeros((nch, L.GC_TRK_NFIELDS, n_ep))
         done = (C.c_int32 * nch)()
         fn = self._lib.gc_track_device if device_loop else self._lib.gc_track
-        st = fn(self._ctx, C.byref(params), nch, arr,
-                                out.ctypes.data_as(C.POINTER(C.c_double)), done)
+        cno = self._cno_buffer(params, nch)
+        try:
+            st = fn(self._ctx, C.byref(params), nch, arr,
+                                    out.ctypes.data_as(C.POINTER(C.c_double)), done)
+        finally:
+            if cno is not None:
+                self._lib.gc_set_cno_output(self._ctx, None, 0)
         if st not in (L.GC_OK, L.GC_E_RANGE):
             L.check(st)
         fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
+        if cno is not None:
+            fields["CNoVSM"] = cno          # [nch, n_epochs // cno_interval], 0 where an interval was not completed
         return fields, np.array(list(done)), st
+
+    def _cno_buffer(self, params, nch):
+        """Registers the C/N0 output of the next tracking call when the parameters ask for it (gc_set_cno_output)."""
+        k = int(params.cno_interval)
+        if k <= 1 or params.n_epochs // k == 0:
+            return None
+        cno = np.zeros((nch, params.n_epochs // k))
+        L.check(self._lib.gc_set_cno_output(self._ctx, cno.ctypes.data_as(C.POINTER(C.c_double)), cno.size))
+        return cno
 
     def track_resume(self, params: L.gc_track_params, inits, state=None, origin: int = 0, pause_at_end: bool = False):
         """gc_track_resume on the window currently loaded (its first sample = record sample `origin`): continues from `state`
@@ -204,11 +220,19 @@ class Engine:
         arr = (L.gc_channel_init * nch)(*inits)
         out = np.zeros((nch, L.GC_TRK_NFIELDS, params.n_epochs))
         done = (C.c_int32 * nch)()
-        st = self._lib.gc_track_file(self._ctx, os.fsencode(path), int(skip_bytes), int(dtype), int(layout), int(window_samples),
-                                     C.byref(params), nch, arr, out.ctypes.data_as(C.POINTER(C.c_double)), done)
+        cno = self._cno_buffer(params, nch)
+        try:
+            st = self._lib.gc_track_file(self._ctx, os.fsencode(path), int(skip_bytes), int(dtype), int(layout), int(window_samples),
+                                         C.byref(params), nch, arr, out.ctypes.data_as(C.POINTER(C.c_double)), done)
+        finally:
+            if cno is not None:
+                self._lib.gc_set_cno_output(self._ctx, None, 0)
         if st not in (L.GC_OK, L.GC_E_RANGE):
             L.check(st)
-        return {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}, np.array(list(done)), st
+        fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
+        if cno is not None:
+            fields["CNoVSM"] = cno
+        return fields, np.array(list(done)), st
 
     @staticmethod
     def track_multi(jobs, device_loop: bool = False):

@@ -212,6 +212,10 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
     p.dll_damping = settings.dllDampingRatio
     p.pll_noise_bw = settings.pllNoiseBandwidth
     p.pll_damping = settings.pllDampingRatio
+    cno = getattr(settings, "CNo", None)
+    if cno is not None and not int(getattr(settings, "CNoInterval", 0)) and int(getattr(cno, "VSMinterval", 0)) > 1:
+        p.cno_interval = int(cno.VSMinterval)          # tracking.m:351-358: CNoVSM every VSMinterval epochs, inside the loop
+        p.cno_acc_time = float(cno.accTime)
     p.pll_kind = spec.pll_kind
     flag = getattr(settings, "pilotTRKflag", 0)
     # BDS/B1C/include/postProcessing.m:69-74: pilotTRKflag 1 runs NB_tracking, 2 runs WB_tracking (both track the pilot)
@@ -309,8 +313,12 @@ def _tracking_finish(job, fields, done, status):
             tr.absoluteSample[:n_done] = tr.absoluteSample[:n_done] + 1 - tr.remCodePhase[:n_done] / step
             for f in ("remCodePhase", "codeFreq", "dllDiscr", "dllDiscrFilt"):
                 getattr(tr, f)[:n_done] /= 2
+        lib_cno = fields.get("CNoVSM")                                                # computed inside the loop (gc_track_params.cno_interval)
         for loop in (range(vsm, n_done + 1, vsm) if vsm else ()):                     # tracking.m:351-358
-            tr.CNo.VSMValue.append(CNoVSM(tr.I_P[loop - vsm:loop], tr.Q_P[loop - vsm:loop], settings.CNo.accTime))
+            if lib_cno is not None:
+                tr.CNo.VSMValue.append(float(lib_cno[k][loop // vsm - 1]))
+            else:
+                tr.CNo.VSMValue.append(CNoVSM(tr.I_P[loop - vsm:loop], tr.Q_P[loop - vsm:loop], settings.CNo.accTime))
             tr.CNo.VSMIndex.append(loop)
         if pld:
             # BDS/B2a/include/tracking.m:85-92,191-192,409-432 (B1C NB_tracking.m:92-98,397-418, WB_tracking.m:443-461):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GC_API_VERSION 2
+#define GC_API_VERSION 3
 
 typedef struct gc_context gc_context;
 
@@ -177,6 +177,12 @@ typedef struct gc_track_params {
   double dll_weight[2];
   double dll_scale;          /* both DLL discriminators are multiplied by it: 1 - earlyLateSpc for B1C
                                 (NB_tracking.m:346-348); 0 means 1 */
+  /* API version 3: C/N0 by the variance-summing method inside the loop (tracking.m:351-358, Common/CNoVSM.m:38-47): after
+   * every cno_interval epochs (settings.CNo.VSMinterval; 0 = off) CNoVSM(I_P, Q_P, cno_acc_time) of those epochs' data-arm
+   * prompt sums goes to the buffer registered with gc_set_cno_output.  It feeds nothing back into the loop. */
+  int32_t cno_interval;
+  int32_t reserved3;
+  double cno_acc_time;       /* settings.CNo.accTime */
 } gc_track_params;
 
 typedef struct gc_channel_init {
@@ -209,6 +215,10 @@ enum gc_track_field {
  * the reference's early return, tracking.m:241-245). */
 int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
              double* out, int32_t* epochs_done);
+/* Where the next tracking calls of this context put trackResults.CNo.VSMValue: cno[ch * (n_epochs / cno_interval) + k] for
+ * the k-th completed interval of channel slot ch (caller-owned, `capacity` doubles; NULL unregisters).  With the device loop
+ * (gc_track_device) the estimator runs in the kernel that closes the loop. */
+int gc_set_cno_output(gc_context* ctx, double* cno, int64_t capacity);
 
 /* ---- records larger than the device: tracking window by window ------------------------------------------------------
  * tracking.m reads its file block by block (fread at :226-245) and so handles a record of any length

@@ -101,6 +101,8 @@ static void track_params_from(const mxArray* s, gc_track_params* out) {
   if (mxGetField(s, 0, "dllWeight")) { const double* w = mxGetDoubles(mxGetField(s, 0, "dllWeight")); p.dll_weight[0] = w[0]; p.dll_weight[1] = w[1]; }
   if (mxGetField(s, 0, "dllScale")) p.dll_scale = field(s, "dllScale");
   if (mxGetField(s, 0, "tablePhaseCount")) p.table_phase_count = (int32_t)field(s, "tablePhaseCount");
+  /* optional (API v3): C/N0 by CNoVSM inside the loop every cnoInterval epochs (settings.CNo.VSMinterval, .accTime) -> 4th output */
+  if (mxGetField(s, 0, "cnoInterval")) { p.cno_interval = (int32_t)field(s, "cnoInterval"); p.cno_acc_time = field(s, "cnoAccTime"); }
   *out = p;
 }
 
@@ -223,6 +225,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     /* trk(epoch, (channel-1)*GC_TRK_NFIELDS + field): one column per (channel, field), fields in gc_track_field order */
     plhs[0] = mxCreateDoubleMatrix((mwSize)p.n_epochs, (mwSize)GC_TRK_NFIELDS * (mwSize)nch, mxREAL);
     int32_t* done = (int32_t*)mxCalloc((size_t)nch, sizeof *done);
+    /* [trk, epochs, status, cno] = ...: cno(k, channel) = CNoVSM of the k-th interval (p.cnoInterval > 1), computed inside the loop */
+    const mwSize nk = p.cno_interval > 1 ? (mwSize)(p.n_epochs / p.cno_interval) : 0;
+    mxArray* cno = NULL;
+    if (nlhs > 3 && nk > 0) {
+      cno = mxCreateDoubleMatrix(nk, (mwSize)nch, mxREAL);
+      if (gc_set_cno_output(handle(prhs[1]), mxGetDoubles(cno), (int64_t)(nk * (mwSize)nch))) fail("gc_set_cno_output");
+    }
     int rc;
     if (!strcmp(cmd, "track_file")) {
       char path[4096], dtype[16];
@@ -248,6 +257,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       for (int i = 0; i < nch; ++i) mxGetDoubles(plhs[1])[i] = done[i];
     }
     if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(rc);
+    if (cno) (void)gc_set_cno_output(handle(prhs[1]), NULL, 0);
+    if (nlhs > 3) plhs[3] = cno ? cno : mxCreateDoubleMatrix(0, 0, mxREAL);
     mxFree(init);
     mxFree(done);
     if (rc && rc != GC_E_RANGE && !(rc == GC_E_UNSUPPORTED && nlhs > 2)) fail("gc_track"); /* GC_E_RANGE = the reference's short-read return */

@@ -709,3 +709,33 @@ def test_four_thousand_epoch_closed_loops_stay_equivalent(engine):
         # data bits: the sign pattern of the prompt arm is the same bit stream (up to the 180-degree PLL ambiguity)
         sg = np.sign(host[k].I_P[500:]) * np.sign(ref["I_P"][k][500:])
         assert abs(np.mean(sg)) > 0.999
+
+
+def test_cno_inside_the_loops_equals_cnovsm_over_the_records(engine, l1ca_scene):
+    """gc_track_params.cno_interval: trackResults.CNo.VSMValue (tracking.m:351-358, Common/CNoVSM.m:38-47) computed by the host
+    loop from its records and by the DEVICE loop's closer, epoch by epoch with running sums, against CNoVSM() over the
+    recorded prompt sums."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import receiver
+    S, sats, iq = l1ca_scene
+    S.msToProcess, S.numberOfChannels = 290, 4
+    S.CNo.VSMinterval = 40
+    ch = _channels(S, sats, 4)
+    engine.load_if(iq, fs=S.samplingFreq)
+    job = receiver._tracking_prepare(engine, ch, S, "GPS_L1CA")
+    assert job.p.cno_interval == 40 and job.p.cno_acc_time == S.CNo.accTime
+    for device_loop in (False, True):
+        fields, done, st = engine.track(job.p, job.inits, device_loop=device_loop)
+        cno = fields["CNoVSM"]
+        assert cno.shape == (4, 7)
+        for k in range(4):
+            for j in range(7):
+                want = P.CNoVSM(fields["I_P"][k][40 * j:40 * (j + 1)], fields["Q_P"][k][40 * j:40 * (j + 1)], S.CNo.accTime)
+                assert abs(cno[k, j] - want) < 1e-9, (device_loop, k, j, cno[k, j], want)
+            assert 40 < cno[k, -1] < 52
+    tr, _ = P.tracking(engine, ch, S, device_loop=True)
+    assert len(tr[0].CNo.VSMValue) == 7 and tr[0].CNo.VSMIndex == [40 * (j + 1) for j in range(7)]
+    # noise-only prompt sums: Zm^2 - Zv < 0, Pav imaginary - the estimator's complex branch
+    rng = np.random.default_rng(2)
+    i_p, q_p = rng.standard_normal(40) * 1e3, rng.standard_normal(40) * 1e3
+    assert np.isfinite(P.CNoVSM(i_p, q_p, 0.001))
