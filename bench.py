@@ -101,6 +101,25 @@ def _traffic(kind: str, blocks: int):
     return None, None
 
 
+_SHAPE_OF = {"GPS_L5C": "l5", "BDS_B2a": "l5", "GAL_E1C_CBOC": "cboc", "GAL_E1C": "e1x8", "BDS_B1C_NB": "b1c"}
+
+
+def _traffic_scaled(signal: str, channel_samples: float, bytes_per_sample: float):
+    """HBM bytes of one replay launch of a BASELINE shape, scaled from the counter passes on the 5-s record of the same shape
+    (profiles/r0x/traffic.json: FETCH_SIZE x 2 per channel-sample; int16 records scale with the sample size)."""
+    shape = _SHAPE_OF.get(signal)
+    for rnd in ("r02",):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+        except (OSError, ValueError):
+            continue
+        for e in tj:
+            if e.get("workload") == shape and e.get("channel_samples_per_launch") and e.get("hbm_bytes_per_launch"):
+                per = e["hbm_bytes_per_launch"] / e["channel_samples_per_launch"] * (bytes_per_sample / 2.0)
+                return int(per * channel_samples), f"profiles/{rnd}/traffic.json: {per:.2f} B per channel-sample measured on the 5-s '{shape}' shape, scaled"
+    return None, None
+
+
 # =======================================================================================================================
 # main workload: GPS L1 C/A x 12
 # =======================================================================================================================
@@ -241,6 +260,7 @@ def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, see
     t_dev, _ = W.run_closed_loops(P, jobs, device_loop=True)
     per_job = []
     total_cs, total_ms, total_bytes = 0.0, 0.0, 0.0
+    total_traffic = 0
     bps = 2.0 * np.dtype(dtype).itemsize
     for j in jobs:
         ms, dev, kern = W.time_replay(j, steps, warmup)
@@ -248,7 +268,10 @@ def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, see
         total_cs += cs
         total_ms += ms
         total_bytes += bps * cs
+        tr, tr_src = _traffic_scaled(j.pkg.signal, cs, bps)
+        total_traffic = None if (tr is None or total_traffic is None) else total_traffic + tr
         per_job.append({"signal": j.pkg.signal, "channels": len(j.sats), "epochs": j.params.n_epochs, "blocks_per_launch": int(j.blks.size),
+                        "traffic": tr, "traffic_source": tr_src,
                         "kernel": W.KERNEL_NAMES.get(kern, str(kern)), "kernel_ms": round(ms, 4),
                         "algorithmic_bytes_per_launch": bps * cs, "achieved_GBps": round(bps * cs / ms / 1e6, 1),
                         "frac": round(bps * cs / ms / 1e6 / HBM_PEAK_GBPS, 4), "replay_vs_closed_loop_max_dev": dev,
@@ -262,7 +285,8 @@ def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, see
         "replay": {"kernel_ms_sum": round(total_ms, 4), "corr_msps": round(total_cs / total_ms / 1e3, 1), "if_msps": round(total_cs / total_ms / 1e3 / nch, 1),
                    "x_realtime": round(total_cs / total_ms / 1e3 / nch / (fs / 1e6), 1),
                    "roofline": {"bound": "hbm", "achieved": round(total_bytes / total_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": round(total_bytes / total_ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": total_bytes, "traffic": None}},
+                                "frac": round(total_bytes / total_ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": total_bytes,
+                                "traffic": total_traffic or None}},
         "closed_loop_host": {"seconds": round(t_host, 4), "x_realtime": round(signal_s / t_host, 1)},
         "closed_loop_device": {"seconds": round(t_dev, 4), "x_realtime": round(signal_s / t_dev, 1)},
         "synth_s": round(t_synth, 2),
