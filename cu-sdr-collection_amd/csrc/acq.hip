@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   static_assert(R0 * R1 * R2 * R3 == L && OTHER % C == 0, "radices multiply to L; whole tiles only");
   static_assert(!SHIFT || (CONTIG && PRE == PRE_MUL_CONJ), "shifted reads belong to the rows pass of the inverse transform");
   constexpr unsigned N = L * OTHER, NEL = L * C, SLOTS = (NEL + kFftThreads - 1) / kFftThreads, TILES = OTHER / C;
-  static_assert(SLOTS <= kFftSlots, "tile too large");
+  static_assert(SLOTS <= kFftSlots + 2, "tile too large");
   constexpr unsigned ESTR = CONTIG ? 1 : OTHER, VSTR = CONTIG ? L : 1;
   constexpr int NS1 = R0, NS2 = R0 * R1, NS3 = R0 * R1 * R2;
   constexpr unsigned T1 = R1 > 1 ? NS1 * (R1 - 1) : 0, T2 = R2 > 1 ? NS2 * (R2 - 1) : 0, T3 = R3 > 1 ? NS3 * (R3 - 1) : 0;
@@ -1114,7 +1114,11 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
   if (!generic) {
     // N = 36 000: 18 Msps, 1 ms codes (GPS L1 C/A, L5, Galileo E5a/E5b, BDS B2a/B3I: initSettings.m of each package);
     // N = 24 000: GLONASS L1/L2 at 12 Msps
-    if (GC_CT_SHAPE(180, 200, 8, 6, 6, 5, 1, 10, 8, 5, 5, 1) || GC_CT_SHAPE(150, 160, 8, 6, 5, 5, 1, 10, 8, 5, 4, 1)) {
+    // N = 144 000: Galileo E1 (4-ms codes at 18 Msps); N = 72 000 / 360 000 / 320 000: the circular-shift searches of BDS B1I
+    // (4-ms blocks), BDS B1C (20 ms) and GPS L2C (40 ms at 8 Msps)
+    if (GC_CT_SHAPE(180, 200, 8, 6, 6, 5, 1, 10, 8, 5, 5, 1) || GC_CT_SHAPE(150, 160, 8, 6, 5, 5, 1, 10, 8, 5, 4, 1) ||
+        GC_CT_SHAPE(375, 384, 4, 5, 5, 5, 3, 5, 8, 8, 6, 1) || GC_CT_SHAPE(250, 288, 8, 5, 5, 5, 2, 5, 8, 6, 6, 1) ||
+        GC_CT_SHAPE(600, 600, 3, 6, 5, 5, 4, 3, 6, 5, 5, 4) || GC_CT_SHAPE(512, 625, 5, 8, 8, 8, 1, 2, 5, 5, 5, 5)) {
       GC_HIP(hipGetLastError());
       return GC_OK;
     }
