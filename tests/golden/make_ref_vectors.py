@@ -108,7 +108,7 @@ def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"{REF} not found: the reference is only available in the build container")
     if "track" in a.what:
-        for sc in RS.TRACK_SCENES:
+        for sc in RS.TRACK_SCENES + RS.LONG_TRACK_SCENES:
             if a.only and a.only != sc.name:
                 continue
             gen_track(sc)

@@ -255,6 +255,13 @@ TRACK_SCENES = [
 ]
 
 
+# a long closed loop of the reference's own tracking.m (1200 epochs: 30 PLL time constants, every 40-epoch C/N0 interval)
+LONG_TRACK_SCENES = [
+    TrackScene("GPS_L1CA_long", "GPS/GPS_L1CA", "GPS_L1CA", "initSettings", dict(msToProcess=1200, numberOfChannels=3), _l1ca, oracle=_o_l1ca,
+               notes="tracking.m:133-368 over 1.2 s: long-run equivalence of the loops, not only of single epochs"),
+]
+
+
 def scene_inputs(P, sc: TrackScene):
     """(settings mirror with the overrides applied, record, layout, channels)."""
     from cu_sdr_collection_amd import settings as SET

@@ -47,6 +47,25 @@ def test_oracle_tracking_equals_the_references_tracking_m(sc):
         assert float(z["PRN"][k]) == float(getattr(ch[k], "K", getattr(ch[k], "PRN", 0)))
 
 
+def test_c_oracle_follows_the_references_tracking_m_for_1200_epochs():
+    """The long scene (tests/golden/ref_track_GPS_L1CA_long.npz: the reference's tracking.m over 1.2 s, 30 PLL time constants) against
+    the float64 C restatement (oracle/gnss_oracle.c, the CPU baseline of bench.py): identical block starts for all 1200 epochs,
+    loop state to 1e-9 relative - the restatement does not drift away from the reference over a long run."""
+    import cu_sdr_collection_amd as P
+    from oracle import c_oracle as CO
+    sc = RS.LONG_TRACK_SCENES[0]
+    z = _load(f"ref_track_{sc.name}.npz")
+    S, rec, layout, ch = RS.scene_inputs(P, sc)
+    assert RS.crc(rec) == int(z["record_crc32"][0])
+    ref, done, aborted = CO.track_l1ca(rec, ch, S)
+    assert not aborted
+    for k in range(2):
+        assert np.array_equal(ref["absoluteSample"][k], z["f_absoluteSample"][k])
+        for f in ("carrFreq", "codeFreq", "remCodePhase", "I_P", "Q_P", "I_E", "Q_L", "dllDiscrFilt", "pllDiscrFilt"):
+            want = z["f_" + f][k]
+            assert np.max(np.abs(ref[f][k] - want)) <= 1e-9 * (np.max(np.abs(want)) + 1e-300), (k, f)
+
+
 def test_reference_trackresults_field_sets_and_initial_values():
     """tracking.m:47-86 and its per-package variants: which Pilot_* fields exist, which fields start as inf."""
     from cu_sdr_collection_amd import receiver, signals
