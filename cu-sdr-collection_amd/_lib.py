@@ -54,7 +54,8 @@ class gc_channel_init(C.Structure):
 class gc_acq_front_params(C.Structure):
     """acquisition.m:46-111 input conditioning (gc_acq_condition)."""
     _fields_ = [("sampling_freq", C.c_double), ("intermediate_freq", C.c_double), ("bandwidth", C.c_double), ("first_sample", C.c_int64),
-                ("n_samples", C.c_int64), ("fir_order", C.c_int32), ("reserved", C.c_int32)]
+                ("n_samples", C.c_int64), ("fir_order", C.c_int32), ("reserved", C.c_int32),
+                ("band_margin", C.c_double)]
 
 
 class gc_acq_front_result(C.Structure):

@@ -51,13 +51,34 @@ def _split_code_search(sums: np.ndarray, sec: np.ndarray) -> float:
 
 
 def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, fine_step, combine, n_results=32,
-              table_fn=None, fine_code_freq=None, fine_code_len=None, index_offset=1):
+              table_fn=None, fine_code_freq=None, fine_code_len=None, index_offset=1, bandwidth=None, n_long=None,
+              band_margin=0.0, mirror=True):
+    """`bandwidth`: BW of the package's input-conditioning block (acquisition.m:46-111 of each package: 2*fc + 0.5 MHz for the
+    10.23-Mcps packages, 20.46 / 20.552 MHz for Galileo E5 / E1, 9 MHz for GLONASS), taken when settings.resamplingflag asks for it;
+    `n_long` = length(longSignal) for that case; `band_margin`: the 0.002 by which GPS_L5C / BDS_B2a widen fir1's normalised band edges
+    (GPS_L5C acquisition.m:69); `mirror`: whether the package maps an IF in the upper half of the new Nyquist band back as
+    newFs - IF (GPS_L5C :304-309, BDS_B2a :301-306) or always as carrFreq - IF (GAL_E5a :292, GAL_E5b :240, GAL_E1C :281, BDS_B3I :295)."""
+    import copy
     from .receiver import _acq_params
     if first_sample is None:
         first_sample = skip_samples(settings)
+    original = settings
+    flag = getattr(settings, "resamplingflag", getattr(settings, "resamplingFlag", 0))
+    resampled = settings.samplingFreq > settings.resamplingThreshold and flag == 1
+    if resampled:
+        if bandwidth is None:
+            raise NotImplementedError("this package's acquisition has no input-conditioning block")
+        if n_long is None:
+            n_long = int(engine.if_buffer()[1]) - int(first_sample)
+        new_fs, new_if, _ = engine.acq_condition(settings.samplingFreq, settings.IF, bandwidth, first_sample, n_long,
+                                                 band_margin=band_margin)
+        settings = copy.copy(settings)
+        settings.samplingFreq, settings.IF = new_fs, new_if
+        first_sample = 0
     prns = list(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(n_results), codePhase=np.zeros(n_results), peakMetric=np.zeros(n_results))
     p = _acq_params(settings, first_sample)
+    p.source = 1 if resampled else 0
     table_fn = table_fn or make_table
     tables = np.stack([np.stack([table_fn(c, settings) for c in coarse_codes(prn)]) for prn in prns])   # [nprn, narms, spc]
     res = engine.acquire_coarse(p, tables)
@@ -73,33 +94,45 @@ def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, 
             fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=fine_code_freq or settings.codeFreqBasis,
                                   f0=r.coarse_freq + settings.acqSearchStep / 2, fstep=fine_step,
                                   first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=ncodes, nbins=nfine,
-                                  code_len=int(fine_code_len or settings.codeLength), index_offset=index_offset)
+                                  code_len=int(fine_code_len or settings.codeLength), index_offset=index_offset,
+                                  source=1 if resampled else 0)
             sums = [engine.acquire_fine_sums(fp, c) for c in fine_codes(prn)]       # each [nfine, ncodes]
             fine = np.array([combine(prn, [s[k] for s in sums]) for k in range(nfine)])
             f = fp.f0 - fine_step * int(np.argmax(fine))
             acq.carrFreq[prn - 1] = f if f != 0 else 1
+    if resampled:                                  # back to the record's rate and IF (GPS_L5C acquisition.m:293-305)
+        for prn in prns:
+            if acq.carrFreq[prn - 1] != 0:
+                acq.codePhase[prn - 1] = math.floor((acq.codePhase[prn - 1] - 1) / settings.samplingFreq * original.samplingFreq) + 1
+                if mirror and settings.IF >= settings.samplingFreq / 2:
+                    doppler = (settings.samplingFreq - settings.IF) - acq.carrFreq[prn - 1]
+                else:
+                    doppler = acq.carrFreq[prn - 1] - settings.IF
+                acq.carrFreq[prn - 1] = doppler + original.IF
     return acq
 
 
-def acquisition_L5(engine, settings, first_sample: int | None = None):
+def acquisition_L5(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """GPS/GPS_L5C/include/acquisition.m: I5 + Q5 coarse search, fine stage on the Q5 pilot over 20 codes with the
     20-bit Neuman-Hofman code tried at every circular shift (:228-252)."""
     return _family_a(engine, settings, first_sample,
                      lambda prn: [codes.generateL5Icode(prn), codes.generateL5Qcode(prn)],
                      lambda prn: [codes.generateL5Qcode(prn)], 20, 25.0,
-                     lambda prn, s: _circular_code_search(s[0], NH20))
+                     lambda prn, s: _circular_code_search(s[0], NH20), bandwidth=settings.codeFreqBasis * 2 + 0.5e6, n_long=n_long,   # BW: :62
+                     band_margin=0.002)                                                                                                 # :69
 
 
-def acquisition_E5a(engine, settings, first_sample: int | None = None):
+def acquisition_E5a(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """GAL/GAL_E5a/include/acquisition.m: E5a-I + E5a-Q primary codes in the coarse search, fine stage on the pilot over
     100 codes in 5-Hz bins with the PRN's CS100 secondary code at every circular shift."""
     return _family_a(engine, settings, first_sample,
                      lambda prn: [codes.generateE5aIcode(prn, 1), codes.generateE5aQcode(prn, 1)],
                      lambda prn: [codes.generateE5aQcode(prn, 1)], 100, 5.0,
-                     lambda prn, s: _circular_code_search(s[0], codes.generateE5aQ_secondary(prn).astype(np.float64)), n_results=50)   # acquisition.m:139 zeros(1, 50)
+                     lambda prn, s: _circular_code_search(s[0], codes.generateE5aQ_secondary(prn).astype(np.float64)), n_results=50,   # acquisition.m:139 zeros(1, 50)
+                     bandwidth=20.46e6, n_long=n_long, mirror=False)                                                                   # BW: :57
 
 
-def acquisition_B2a(engine, settings, first_sample: int | None = None):
+def acquisition_B2a(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """BDS/B2a/include/acquisition.m: data + pilot coarse search; fine stage = sum over max(10, acqNonCohTime) codes of
     |per-code sum| of both components (no secondary-code hypothesis needed)."""
     ncodes = max(10, int(settings.acqNonCohTime))                                    # :156
@@ -107,13 +140,15 @@ def acquisition_B2a(engine, settings, first_sample: int | None = None):
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)],
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)], ncodes, 25.0,
                      lambda prn, s: float(np.sum(np.abs(s[0])) + np.sum(np.abs(s[1]))),
-                     n_results=int(max(settings.acqSatelliteList)))   # BDS/B2a acquisition.m:139 zeros(1, max(acqSatelliteList))
+                     n_results=int(max(settings.acqSatelliteList)),   # BDS/B2a acquisition.m:139 zeros(1, max(acqSatelliteList))
+                     bandwidth=settings.codeFreqBasis * 2 + 0.5e6, n_long=n_long, band_margin=0.002)   # BW: :60, wp: :64
 
 
-def acquisition_E5b(engine, settings, first_sample: int | None = None):
+def acquisition_E5b(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """GAL/GAL_E5b/include/acquisition.m: E5b-I + E5b-Q coarse search in 60-Hz bins and no fine stage (:227)."""
     return _family_a(engine, settings, first_sample,
-                     lambda prn: [codes.generateE5bIcode(prn, 1), codes.generateE5bQcode(prn, 1)], None, 0, 0.0, None, n_results=50)   # acquisition.m:138 zeros(1, 50)
+                     lambda prn: [codes.generateE5bIcode(prn, 1), codes.generateE5bQcode(prn, 1)], None, 0, 0.0, None, n_results=50,   # acquisition.m:138 zeros(1, 50)
+                     bandwidth=20.46e6, n_long=n_long, mirror=False)
 
 
 def _b3i_combine(prn, s):
@@ -127,10 +162,11 @@ def _b3i_combine(prn, s):
     return _split_code_search(x, NH20)
 
 
-def acquisition_B3I(engine, settings, first_sample: int | None = None):
+def acquisition_B3I(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """BDS/B3I/include/acquisition.m: single-component coarse search, 20-code fine stage indexed (0 : 20*spc-1)."""
     return _family_a(engine, settings, first_sample, lambda prn: [codes.generateB3Icode(prn)], lambda prn: [codes.generateB3Icode(prn)],
-                     20, 25.0, _b3i_combine, n_results=63, index_offset=0)
+                     20, 25.0, _b3i_combine, n_results=63, index_offset=0, bandwidth=settings.codeFreqBasis * 2 + 0.5e6, n_long=n_long,
+                     mirror=False)
 
 
 E1C_SECONDARY = np.array([1, 1, -1, -1, -1, 1, 1, 1, 1, 1, 1, 1, -1, 1, -1, 1, -1, -1, 1, -1, -1, 1, 1, -1, 1], dtype=np.float64)  # GAL_E1C acquisition.m:138
@@ -145,13 +181,14 @@ def _make_boc_table(code: np.ndarray, settings) -> np.ndarray:
     return code[idx - 1]
 
 
-def acquisition_E1C(engine, settings, first_sample: int | None = None):
+def acquisition_E1C(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """GAL/GAL_E1C/include/acquisition.m: E1-B + E1-C BOC(1,1) replicas (4-ms codes, 144 000-point transforms), fine
     stage on the pilot over 25 codes in 10-Hz bins with the 25-chip secondary code and the split-sum search."""
     return _family_a(engine, settings, first_sample,
                      lambda prn: [codes.generateE1Bcode(prn), codes.generateE1Ccode(prn)], lambda prn: [codes.generateE1Ccode(prn)],
                      25, 10.0, lambda prn, s: _split_code_search(s[0], E1C_SECONDARY), n_results=50, table_fn=_make_boc_table,
-                     fine_code_freq=settings.codeFreqBasis * 2, fine_code_len=int(settings.codeLength) * 2, index_offset=0)
+                     fine_code_freq=settings.codeFreqBasis * 2, fine_code_len=int(settings.codeLength) * 2, index_offset=0,
+                     bandwidth=20.552e6, n_long=n_long, mirror=False)
 
 
 # ---------------------------------------------------------------------------------------------

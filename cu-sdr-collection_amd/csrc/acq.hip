@@ -1519,7 +1519,7 @@ extern "C" int gc_acq_condition(gc_context* ctx, const gc_acq_front_params* p, g
     return GC_E_RANGE;
   }
   const double fs = p->sampling_freq, IF = p->intermediate_freq, BW = p->bandwidth;
-  const double w1 = (IF - BW / 2) * 2 / fs, w2 = (IF + BW / 2) * 2 / fs;  // acquisition.m:60-62
+  const double w1 = (IF - BW / 2) * 2 / fs - p->band_margin, w2 = (IF + BW / 2) * 2 / fs + p->band_margin;  // acquisition.m:60-62, L5 :69
   if (!(w1 > 0.0) || !(w2 < 1.0)) {
     gc_set_error("gc_acq_condition: band edges %g .. %g of the Nyquist frequency (fir1 needs 0 < w < 1)", w1, w2);
     return GC_E_INVALID;

@@ -285,12 +285,13 @@ class Engine:
         return out[..., 0] + 1j * out[..., 1]
 
     def acq_condition(self, sampling_freq: float, intermediate_freq: float, bandwidth: float, first_sample: int, n_samples: int,
-                      fir_order: int = 700):
+                      fir_order: int = 700, band_margin: float = 0.0):
         """gc_acq_condition: the zero-phase band-pass + decimation front end of acquisition.m:46-111 on the record's samples
         [first_sample, first_sample + n_samples).  Returns (new sampling frequency, new IF, conditioned length); searches read
         the conditioned signal with gc_acq_params.source = 1."""
         fp = L.gc_acq_front_params(sampling_freq=sampling_freq, intermediate_freq=intermediate_freq, bandwidth=bandwidth,
-                                   first_sample=int(first_sample), n_samples=int(n_samples), fir_order=int(fir_order))
+                                   first_sample=int(first_sample), n_samples=int(n_samples), fir_order=int(fir_order),
+                                   band_margin=float(band_margin))
         res = L.gc_acq_front_result()
         L.check(self._lib.gc_acq_condition(self._ctx, C.byref(fp), C.byref(res)))
         return res.sampling_freq, res.intermediate_freq, int(res.n_samples)

@@ -323,6 +323,8 @@ typedef struct gc_acq_front_params {
   int64_t n_samples;         /* length(longSignal) */
   int32_t fir_order;         /* 700 */
   int32_t reserved;
+  double band_margin;        /* widening of both normalised band edges: wp = [w1*2/fs - m, w2*2/fs + m]; 0.002 in GPS_L5C / BDS_B2a /
+                              * BDS_B1C (GPS_L5C/include/acquisition.m:69), 0 in the other packages (GPS_L1CA :62) */
 } gc_acq_front_params;
 typedef struct gc_acq_front_result {
   double sampling_freq;      /* settings.samplingFreq after the block (:81) */

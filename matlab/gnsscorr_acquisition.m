@@ -23,10 +23,15 @@ if isfield(settings, 'resamplingflag'), flag = settings.resamplingflag; end
 if isfield(settings, 'resamplingFlag'), flag = settings.resamplingFlag; end      % BDS/B3I spells it so
 resampled = settings.samplingFreq > settings.resamplingThreshold && flag == 1;
 if resampled
-    if ~strcmp(name, 'GPS_L1CA')
-        error('gnsscorr:acquisition', 'the resampling front end is wired for GPS_L1CA only (gnsscorr_mex(''acq_condition'') takes any bandwidth)');
+    switch name                                                       % BW of the package's block (acquisition.m:58 and its twins)
+        case {'GPS_L1CA', 'GPS_L5C', 'BDS_B2a', 'BDS_B3I'}, c.bandwidth = settings.codeFreqBasis * 2 + 0.5e6;
+        case {'GAL_E5a', 'GAL_E5b'}, c.bandwidth = 20.46e6;
+        case 'GAL_E1C', c.bandwidth = 20.552e6;
+        otherwise, error('gnsscorr:acquisition', 'the resampling front end of %s is not wired (GLONASS: its fine stage reads the raw record)', name);
     end
-    c.samplingFreq = settings.samplingFreq;  c.IF = settings.IF;  c.bandwidth = settings.codeFreqBasis * 2 + 0.5e6;   % :58
+    c.bandMargin = 0.002 * any(strcmp(name, {'GPS_L5C', 'BDS_B2a'}));            % wp = [w1*2/fs-0.002 w2*2/fs+0.002] (GPS_L5C acquisition.m:69)
+    mirror = any(strcmp(name, {'GPS_L1CA', 'GPS_L5C', 'BDS_B2a'}));              % the other packages map back as carrFreq - IF only (GAL_E5a :292)
+    c.samplingFreq = settings.samplingFreq;  c.IF = settings.IF;
     c.firstSample = 0;  c.nSamples = numel(longSignal);
     oldFreq = settings.samplingFreq;  oldIF = settings.IF;
     [settings.samplingFreq, settings.IF] = gnsscorr_mex('acq_condition', h, c);                                      % :81,95
@@ -142,7 +147,7 @@ for k = 1:numel(prns)
     if carr == 0, carr = 1; end                                             % :258-260
     if resampled                                                            % :264-276: back to the record's rate and IF
         acqResults.codePhase(p) = floor((res(2, k) - 1) / settings.samplingFreq * oldFreq) + 1;
-        if settings.IF >= settings.samplingFreq / 2
+        if mirror && settings.IF >= settings.samplingFreq / 2
             doppler = (settings.samplingFreq - settings.IF) - carr;
         else
             doppler = carr - settings.IF;

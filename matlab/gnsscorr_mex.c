@@ -303,6 +303,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.first_sample = (int64_t)field(s, "firstSample");
     p.n_samples = (int64_t)field(s, "nSamples");
     p.fir_order = mxGetField(s, 0, "firOrder") ? (int32_t)field(s, "firOrder") : 700;
+    p.band_margin = mxGetField(s, 0, "bandMargin") ? field(s, "bandMargin") : 0.0;
     if (gc_acq_condition(handle(prhs[1]), &p, &r)) fail("gc_acq_condition");
     plhs[0] = mxCreateDoubleScalar(r.sampling_freq);
     if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(r.intermediate_freq);

@@ -389,6 +389,12 @@ ACQ_SCENES = [
              oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_l5_code(prn, "I"), O.generate_l5_code(prn, "Q")]),
                          fine_codes=lambda O, P: (lambda prn: [O.generate_l5_code(prn, "Q")]), ncodes=20, fine_step=25.0, combine="circular",
                          secondary=lambda O, P: (lambda prn: _NH20))),
+    # the same conditioning block in a data + pilot package (GPS_L5C acquisition.m:56-118, BW = 2*10.23 MHz + 0.5 MHz): 60 Msps /
+    # IF 15 MHz -> 50 960 000 Hz, 101 920-point searches, NH20 fine stage on the conditioned signal
+    AcqScene("GPS_L5C_resampled", "GPS/GPS_L5C", "initSettings_GPS_L5C",
+             dict(acqNonCohTime=2, acqSearchBand=2000, acqSatelliteList=[3, 22], samplingFreq=60e6, IF=15e6, resamplingflag=1),
+             _acq_family_record("generateL5Icode", "generateL5Qcode", 1150.0, (3, 22), 105, 30, dmax=1.5e3),
+             product=lambda P, eng, S: P.acq_family.acquisition_L5(eng, S, first_sample=0), oracle=None, metric_rtol=2e-3),
     AcqScene("GAL_E5a", "GAL/GAL_E5a", "initSettings_GAL_E5a", dict(acqNonCohTime=3, acqSearchBand=4500, acqSatelliteList=[11, 30]),
              _acq_family_record(lambda P: (lambda prn: P.codes.generateE5aIcode(prn, 1)), lambda P: (lambda prn: P.codes.generateE5aQcode(prn, 1)), 1150.0, (11,), 101, 110),
              product=lambda P, eng, S: P.acq_family.acquisition_E5a(eng, S, first_sample=0),
@@ -406,6 +412,12 @@ ACQ_SCENES = [
              product=lambda P, eng, S: P.acq_family.acquisition_E5b(eng, S, first_sample=0),
              oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_e5_primary("e5bi", prn), O.generate_e5_primary("e5bq", prn)]),
                          fine_codes=None, ncodes=0, fine_step=0.0, combine=None, n_results=50)),
+    # a package whose map back to the record's IF has no mirror branch (GAL_E5b acquisition.m:234-243), with the IF in the upper half of
+    # the new Nyquist band: 100 Msps / IF 32 MHz -> 42 885 000 Hz (BW = 20.46 MHz, n = 2), 85 770-point searches, coarse bin = answer
+    AcqScene("GAL_E5b_resampled", "GAL/GAL_E5b", "initSettings_GAL_E5b",
+             dict(acqNonCohTime=2, acqSearchBand=1500, acqSatelliteList=[4, 19], samplingFreq=100e6, IF=32e6, resamplingflag=1),
+             _acq_family_record(lambda P: (lambda prn: P.codes.generateE5bIcode(prn, 1)), lambda P: (lambda prn: P.codes.generateE5bQcode(prn, 1)), 1180.0, (4,), 107, 5, dmax=1.2e3),
+             product=lambda P, eng, S: P.acq_family.acquisition_E5b(eng, S, first_sample=0), oracle=None, metric_rtol=2e-3),
     AcqScene("BDS_B3I", "BDS/B3I", "initSettings_BDS_B3I", dict(acqNonCohTime=3, acqSearchBand=4500, acqSatelliteList=[3, 30, 44]),
              _acq_family_record("generateB3Icode", None, 1240.0, (3, 30), 101, 30),
              product=lambda P, eng, S: P.acq_family.acquisition_B3I(eng, S, first_sample=0),

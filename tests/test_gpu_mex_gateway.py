@@ -136,7 +136,7 @@ def test_matlab_drop_in_reproduces_the_references_tracking_m(gateway, sc, tmp_pa
             assert float(t.PRN) == float(z["PRN"][k])
 
 
-_ACQ_WRAPPED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "BDS_B2a", "GAL_E5b", "BDS_B3I", "GAL_E1C", "GLO_GL1", "GLO_GL2", "BDS_B1I", "GPS_L2C", "BDS_B1C", "GPS_L1CA_resampled")
+_ACQ_WRAPPED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "BDS_B2a", "GAL_E5b", "BDS_B3I", "GAL_E1C", "GLO_GL1", "GLO_GL2", "BDS_B1I", "GPS_L2C", "BDS_B1C", "GPS_L1CA_resampled", "GPS_L5C_resampled", "GAL_E5b_resampled")
 
 
 @pytest.mark.parametrize("sc", [s for s in RS.ACQ_SCENES if s.name in _ACQ_WRAPPED], ids=[s.name for s in RS.ACQ_SCENES if s.name in _ACQ_WRAPPED])
@@ -151,8 +151,9 @@ def test_matlab_drop_in_reproduces_the_references_acquisition_m(gateway, sc):
     assert RS.crc(rec) == int(z["record_crc32"][0])
     x = rec.astype(np.float64)
     long_signal = (x[0::2] + 1j * x[1::2]).reshape(1, -1)
-    signal = {"BDS_B1C": "BDS_B1C_NB", "GPS_L1CA_resampled": "GPS_L1CA"}.get(sc.name, sc.name)
-    I = bridge.install(bridge.interpreter_for({"GPS_L1CA_resampled": "GPS_L1CA"}.get(sc.name, sc.name)), gateway, P, signal)
+    pkg = sc.name.replace("_resampled", "")
+    signal = {"BDS_B1C": "BDS_B1C_NB"}.get(pkg, pkg)
+    I = bridge.install(bridge.interpreter_for(pkg), gateway, P, signal)
     try:
         acq = mlab.from_matlab(I.call("acquisition", long_signal, mlab.to_matlab(S)))
     finally:

@@ -220,6 +220,8 @@ def test_oracle_acquisition_equals_the_references_acquisition_m(sc):
     z = _load(f"ref_acq_{sc.name}.npz")
     S, rec = RS.acq_inputs(P, sc)
     assert RS.crc(rec) == int(z["record_crc32"][0])
+    if sc.oracle is None:
+        pytest.skip("no oracle runner for this scene (the HIP path is checked against the fixture directly: tests/test_gpu_ref_vectors.py)")
     got = sc.oracle(O, P, rec, S)
     for f in sc.fields:
         want = z["f_" + f]
