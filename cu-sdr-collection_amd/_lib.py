@@ -14,6 +14,8 @@ GC_REAL, GC_IQ, GC_QI = 0, 1, 2
 GC_MAX_ARMS = 3
 GC_OUT_STRIDE = 6 * GC_MAX_ARMS
 GC_PLL_2ND_ORDER, GC_PLL_3_STATE = 0, 1
+GC_CNO_VSM, GC_CNO_PLD, GC_CNO_PLD_PILOT_SWAPPED, GC_CNO_PLD_PILOT = 0, 1, 2, 3   # gc_cno_mode
+GC_CNO_NPLD = 5
 
 TRK_FIELDS = ["absoluteSample", "codeFreq", "carrFreq", "I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L",
               "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase",
@@ -43,7 +45,7 @@ class gc_track_params(C.Structure):
                 ("pf1", C.c_double), ("pf2", C.c_double), ("pf3", C.c_double),
                 ("skip_samples", C.c_int64), ("n_epochs", C.c_int32), ("table_phase_count", C.c_int32),
                 ("pll_weight", C.c_double * 2), ("dll_weight", C.c_double * 2), ("dll_scale", C.c_double),
-                ("cno_interval", C.c_int32), ("reserved3", C.c_int32), ("cno_acc_time", C.c_double)]
+                ("cno_interval", C.c_int32), ("cno_mode", C.c_int32), ("cno_acc_time", C.c_double)]
 
 
 class gc_channel_init(C.Structure):

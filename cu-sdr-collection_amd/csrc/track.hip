@@ -97,12 +97,75 @@ extern "C" int gc_set_cno_output(gc_context* ctx, double* cno, int64_t capacity)
   return GC_OK;
 }
 
+// Calc_CNo_PLD.m (BDS/B2a, BDS/B1C) over the recorded prompt sums with the per-interval bookkeeping of BDS/B2a/include/
+// tracking.m:409-432: two-pass mean and N-1 variance like MATLAB's mean / var, sqrt of a negative number complex, abs() of
+// the complex quotient.
+static void fill_cno_pld(gc_context* ctx, const gc_track_params* p, int nch, const double* out, const int32_t* epochs_done) {
+  const int K = p->cno_interval, n_epochs = p->n_epochs, nk = n_epochs / K;
+  if ((long long)nch * nk * GC_CNO_NPLD > ctx->cno_cap) return;
+  const double T = p->cno_acc_time;
+  auto arm = [&](const double* I, const double* Q, double& lin, double& pld) {  // Calc_CNo_PLD.m:47-68
+    double zm = 0.0;
+    for (int e = 0; e < K; ++e) zm += I[e] * I[e] + Q[e] * Q[e];
+    zm /= K;
+    double zv = 0.0, wiped = 0.0, sq = 0.0;
+    for (int e = 0; e < K; ++e) {
+      const double dz = I[e] * I[e] + Q[e] * Q[e] - zm;
+      zv += dz * dz;
+      wiped += std::fabs(I[e]);  // sum(I_P(I_P>0)) - sum(I_P(I_P<0))
+      sq += Q[e];
+    }
+    zv /= (K - 1);
+    const double d = zm * zm - zv;
+    double ratio;  // |Pav / (2*Nv)|, Nv = (Zm - Pav)/2
+    if (d >= 0.0) {
+      const double pav = std::sqrt(d);
+      ratio = std::fabs(pav / (zm - pav));
+    } else {
+      ratio = std::sqrt(-d / (zm * zm - d));
+    }
+    lin = ratio / T;
+    pld = (wiped * wiped - sq * sq) / (wiped * wiped + sq * sq);
+  };
+  for (int c = 0; c < nch; ++c) {
+    const double* rec = out + (size_t)c * GC_TRK_NFIELDS * n_epochs;
+    double prev[3] = {0.0, 0.0, 0.0};  // tempCNoValue, tracking.m:192,432
+    for (int k = 0; k < nk; ++k) {
+      double* o = ctx->cno_out + ((size_t)c * nk + k) * GC_CNO_NPLD;
+      for (int j = 0; j < GC_CNO_NPLD; ++j) o[j] = 0.0;
+      if ((k + 1) * K > epochs_done[c]) continue;
+      const size_t e0 = (size_t)k * K;
+      double data = 0.0, pilot = 0.0, cur[3] = {0.0, 0.0, 0.0};
+      arm(rec + (size_t)GC_TRK_I_P * n_epochs + e0, rec + (size_t)GC_TRK_Q_P * n_epochs + e0, data, o[3]);
+      cur[0] = 10.0 * std::log10(data);
+      if (p->cno_mode != GC_CNO_PLD) {
+        const double* pi = rec + (size_t)GC_TRK_PILOT_I_P * n_epochs + e0;
+        const double* pq = rec + (size_t)GC_TRK_PILOT_Q_P * n_epochs + e0;
+        if (p->cno_mode == GC_CNO_PLD_PILOT_SWAPPED)
+          arm(pq, pi, pilot, o[4]);
+        else
+          arm(pi, pq, pilot, o[4]);
+        cur[1] = 10.0 * std::log10(pilot);
+      }
+      cur[2] = 10.0 * std::log10(data + pilot);
+      for (int j = 0; j < 3; ++j) {
+        o[j] = cur[j] * 0.5 + prev[j] * 0.5;
+        prev[j] = cur[j];
+      }
+    }
+  }
+}
+
 // CNoVSM over the recorded data-arm prompt sums, interval by interval, exactly as tracking.m:351-358 calls it (two-pass mean and
 // N-1 variance like MATLAB's; Common/CNoVSM.m:38-47)
 void gc_fill_cno_host(gc_context* ctx, const gc_track_params* p, int nch, const double* out, const int32_t* epochs_done) {
   const int K = p->cno_interval;
   if (!ctx->cno_out || K <= 1) return;
   const int n_epochs = p->n_epochs, nk = n_epochs / K;
+  if (p->cno_mode != GC_CNO_VSM) {
+    fill_cno_pld(ctx, p, nch, out, epochs_done);
+    return;
+  }
   if ((long long)nch * nk > ctx->cno_cap) return;
   for (int c = 0; c < nch; ++c) {
     const double* ip = out + ((size_t)c * GC_TRK_NFIELDS + GC_TRK_I_P) * n_epochs;
@@ -864,7 +927,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_DESC], desc_bytes, false);
   if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_RECORDS], rec_bytes, false);
   if (e == hipSuccess) e = gc_buf_reserve(ctx->trk[gc_context::TRK_ARGS], sizeof ha, false);
-  const int cno_nk = (p->cno_interval > 1 && ctx->cno_out) ? n_epochs / p->cno_interval : 0;
+  const int cno_nk = (p->cno_interval > 1 && ctx->cno_out && p->cno_mode == GC_CNO_VSM) ? n_epochs / p->cno_interval : 0;
   const bool want_cno = cno_nk > 0 && (long long)nch * cno_nk <= ctx->cno_cap;
   const size_t cno_bytes = sizeof(double) * (size_t)nch * (size_t)std::max(cno_nk, 1);
   if (e == hipSuccess && want_cno) e = gc_buf_reserve(ctx->trk[gc_context::TRK_CNO], cno_bytes, false);
@@ -960,6 +1023,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
       epochs_done[c] = hc[c].epochs_done;
     }
   }
+  if (p->cno_mode != GC_CNO_VSM) gc_fill_cno_host(ctx, p, nch, out, epochs_done);  // Calc_CNo_PLD: from the records, as everywhere
   if (diverged) {
     gc_set_error("gc_track_device: a channel's code / carrier NCO became non-finite (all-zero correlator sums?); its records end there");
     return GC_E_INVALID;

@@ -182,7 +182,8 @@ class Engine:
             L.check(st)
         fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
         if cno is not None:
-            fields["CNoVSM"] = cno          # [nch, n_epochs // cno_interval], 0 where an interval was not completed
+            # [nch, n_epochs // cno_interval], 0 where an interval was not completed; Calc_CNo_PLD modes: [nch, nk, GC_CNO_NPLD]
+            fields["CNoVSM" if cno.ndim == 2 else "CNoPLD"] = cno
         return fields, np.array(list(done)), st
 
     def _cno_buffer(self, params, nch):
@@ -190,7 +191,7 @@ class Engine:
         k = int(params.cno_interval)
         if k <= 1 or params.n_epochs // k == 0:
             return None
-        cno = np.zeros((nch, params.n_epochs // k))
+        cno = np.zeros((nch, params.n_epochs // k) + ((L.GC_CNO_NPLD,) if params.cno_mode != L.GC_CNO_VSM else ()))
         L.check(self._lib.gc_set_cno_output(self._ctx, cno.ctypes.data_as(C.POINTER(C.c_double)), cno.size))
         return cno
 
@@ -231,7 +232,7 @@ class Engine:
             L.check(st)
         fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
         if cno is not None:
-            fields["CNoVSM"] = cno
+            fields["CNoVSM" if cno.ndim == 2 else "CNoPLD"] = cno
         return fields, np.array(list(done)), st
 
     @staticmethod
@@ -247,7 +248,7 @@ class Engine:
             ia = (L.gc_channel_init * nch)(*inits)
             out = np.zeros((nch, L.GC_TRK_NFIELDS, params.n_epochs))
             done = (C.c_int32 * nch)()
-            keep.append((ia, out, done, params))
+            keep.append((ia, out, done, params, eng._cno_buffer(params, nch), eng))
             arr[k].ctx = eng._ctx
             arr[k].params = C.pointer(params)
             arr[k].init = ia
@@ -255,12 +256,20 @@ class Engine:
             arr[k].epochs_done = done
             arr[k].nch = nch
             arr[k].device_loop = int(bool(device_loop))
-        st = lib.gc_track_multi(n, arr)
+        try:
+            st = lib.gc_track_multi(n, arr)
+        finally:
+            for item in keep:
+                if item[4] is not None:
+                    lib.gc_set_cno_output(item[5]._ctx, None, 0)
         res = []
-        for k, (ia, out, done, params) in enumerate(keep):
+        for k, (ia, out, done, params, cno, _) in enumerate(keep):
             if arr[k].status not in (L.GC_OK, L.GC_E_RANGE):
                 raise L.GnssCorrError(arr[k].status, f"job {k}: " + arr[k].error.decode("utf-8", "replace"))
-            res.append(({name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}, np.array(list(done)), int(arr[k].status)))
+            fields = {name: out[:, i, :] for i, name in enumerate(L.TRK_FIELDS)}
+            if cno is not None:
+                fields["CNoVSM" if cno.ndim == 2 else "CNoPLD"] = cno
+            res.append((fields, np.array(list(done)), int(arr[k].status)))
         if st not in (L.GC_OK, L.GC_E_RANGE):
             L.check(st)
         return res

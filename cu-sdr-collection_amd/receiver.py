@@ -221,6 +221,12 @@ def track_params(settings, signal: str = "GPS_L1CA") -> L.gc_track_params:
     # BDS/B1C/include/postProcessing.m:69-74: pilotTRKflag 1 runs NB_tracking, 2 runs WB_tracking (both track the pilot)
     pilot = spec.pilot_combine if (flag == 1 or (flag == 2 and signal == "BDS_B1C_WB")) else 0
     p.pilot_combine = pilot
+    if int(getattr(settings, "CNoInterval", 0)) > 1:
+        # BDS/B2a tracking.m:409-432, B1C NB_tracking.m:397-418, WB_tracking.m:441-461: Calc_CNo_PLD every CNoInterval epochs; the
+        # pilot prompt pair is read swapped (pilotTRKflag == 1, Calc_CNo_PLD.m:72-75) or straight (== 2, the B1C wide-band loop)
+        p.cno_interval = int(settings.CNoInterval)
+        p.cno_acc_time = float(settings.intTime)
+        p.cno_mode = L.GC_CNO_PLD if not pilot else (L.GC_CNO_PLD_PILOT if signal.endswith("_WB") else L.GC_CNO_PLD_PILOT_SWAPPED)
     if spec.pll_kind == L.GC_PLL_3_STATE:
         p.pf3, p.pf2, p.pf1 = signals.calcLoopCoefCarr(settings, spec.coef_variant)
     if pilot:
@@ -325,9 +331,17 @@ def _tracking_finish(job, fields, done, status):
             # every CNoInterval epochs, the estimate averaged 0.5/0.5 with the previous one (zeros before the first)
             combined = "B2a_CNo" if signal.startswith("BDS_B2a") else "B1C_CNo"
             prev = np.zeros(3)
+            lib_pld = fields.get("CNoPLD")                                            # [nch, nk, 5], evaluated by the library (gc_cno_mode)
             for loop in range(pld, n_done + 1, pld):
-                c, d = Calc_CNo_PLD(tr, settings, loop, straight_pilot=signal.endswith("_WB"))
                 kk = loop // pld - 1
+                if lib_pld is not None:
+                    v = lib_pld[k][kk]
+                    tr.DataCNo[kk], tr.DataPLD[kk] = v[0], v[3]
+                    if pilot:
+                        tr.PilotCNo[kk], tr.PilotPLD[kk] = v[1], v[4]
+                        getattr(tr, combined)[kk] = v[2]
+                    continue
+                c, d = Calc_CNo_PLD(tr, settings, loop, straight_pilot=signal.endswith("_WB"))
                 tr.DataCNo[kk] = c[0] * 0.5 + prev[0] * 0.5
                 tr.DataPLD[kk] = d[0]
                 if pilot:

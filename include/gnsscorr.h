@@ -181,9 +181,20 @@ typedef struct gc_track_params {
    * every cno_interval epochs (settings.CNo.VSMinterval; 0 = off) CNoVSM(I_P, Q_P, cno_acc_time) of those epochs' data-arm
    * prompt sums goes to the buffer registered with gc_set_cno_output.  It feeds nothing back into the loop. */
   int32_t cno_interval;
-  int32_t reserved3;
-  double cno_acc_time;       /* settings.CNo.accTime */
+  int32_t cno_mode;          /* gc_cno_mode: which estimator runs every cno_interval epochs */
+  double cno_acc_time;       /* settings.CNo.accTime (GC_CNO_VSM) / settings.intTime (GC_CNO_PLD*) */
 } gc_track_params;
+
+/* GC_CNO_VSM: Common/CNoVSM.m, one value per interval (trackResults.CNo.VSMValue).
+ * GC_CNO_PLD*: BDS/B2a + BDS/B1C Calc_CNo_PLD.m with the bookkeeping of B2a tracking.m:409-432 (cno_interval =
+ * settings.CNoInterval): GC_CNO_NPLD values per interval - DataCNo, PilotCNo, B2a_CNo / B1C_CNo (each the 0.5/0.5 average of
+ * this interval's estimate with the previous one, zeros before the first) and DataPLD, PilotPLD (the narrow-band lock
+ * detectors NBD/NBP with the data bits wiped by sign).  _PILOT_SWAPPED reads the pilot prompt pair as (Q, I)
+ * (pilotTRKflag == 1, Calc_CNo_PLD.m:72-75), _PILOT as (I, Q) (pilotTRKflag == 2 of BDS/B1C), plain GC_CNO_PLD has no pilot
+ * arm (PilotCNo = PilotPLD = 0, the third value = DataCNo's estimate).  The library evaluates these from the epoch records
+ * when the tracking call returns, in every loop mode; they feed nothing back. */
+enum gc_cno_mode { GC_CNO_VSM = 0, GC_CNO_PLD = 1, GC_CNO_PLD_PILOT_SWAPPED = 2, GC_CNO_PLD_PILOT = 3 };
+#define GC_CNO_NPLD 5
 
 typedef struct gc_channel_init {
   int32_t channel;           /* gc_set_channel index holding this PRN's tables */
@@ -216,7 +227,8 @@ enum gc_track_field {
 int gc_track(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
              double* out, int32_t* epochs_done);
 /* Where the next tracking calls of this context put trackResults.CNo.VSMValue: cno[ch * (n_epochs / cno_interval) + k] for
- * the k-th completed interval of channel slot ch (caller-owned, `capacity` doubles; NULL unregisters).  With the device loop
+ * the k-th completed interval of channel slot ch (caller-owned, `capacity` doubles; NULL unregisters); with a GC_CNO_PLD*
+ * mode cno[(ch * (n_epochs / cno_interval) + k) * GC_CNO_NPLD + j].  With the device loop
  * (gc_track_device) the estimator runs in the kernel that closes the loop. */
 int gc_set_cno_output(gc_context* ctx, double* cno, int64_t capacity);
 

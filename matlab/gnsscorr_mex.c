@@ -103,6 +103,8 @@ static void track_params_from(const mxArray* s, gc_track_params* out) {
   if (mxGetField(s, 0, "tablePhaseCount")) p.table_phase_count = (int32_t)field(s, "tablePhaseCount");
   /* optional (API v3): C/N0 by CNoVSM inside the loop every cnoInterval epochs (settings.CNo.VSMinterval, .accTime) -> 4th output */
   if (mxGetField(s, 0, "cnoInterval")) { p.cno_interval = (int32_t)field(s, "cnoInterval"); p.cno_acc_time = field(s, "cnoAccTime"); }
+  /* cnoMode (gc_cno_mode): 0 CNoVSM; 1..3 Calc_CNo_PLD of BDS B2a / B1C (no pilot / pilot pair swapped / straight), cnoAccTime = intTime */
+  if (mxGetField(s, 0, "cnoMode")) p.cno_mode = (int32_t)field(s, "cnoMode");
   *out = p;
 }
 
@@ -225,12 +227,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     /* trk(epoch, (channel-1)*GC_TRK_NFIELDS + field): one column per (channel, field), fields in gc_track_field order */
     plhs[0] = mxCreateDoubleMatrix((mwSize)p.n_epochs, (mwSize)GC_TRK_NFIELDS * (mwSize)nch, mxREAL);
     int32_t* done = (int32_t*)mxCalloc((size_t)nch, sizeof *done);
-    /* [trk, epochs, status, cno] = ...: cno(k, channel) = CNoVSM of the k-th interval (p.cnoInterval > 1), computed inside the loop */
+    /* [trk, epochs, status, cno] = ...: cno(k, channel) = CNoVSM of the k-th interval (p.cnoInterval > 1), computed inside the loop;
+       with p.cnoMode > 0: cno(j, k, channel), j = DataCNo, PilotCNo, combined CNo, DataPLD, PilotPLD (Calc_CNo_PLD.m + tracking.m:409-432) */
     const mwSize nk = p.cno_interval > 1 ? (mwSize)(p.n_epochs / p.cno_interval) : 0;
+    const mwSize nv = p.cno_mode != GC_CNO_VSM ? GC_CNO_NPLD : 1;
     mxArray* cno = NULL;
     if (nlhs > 3 && nk > 0) {
-      cno = mxCreateDoubleMatrix(nk, (mwSize)nch, mxREAL);
-      if (gc_set_cno_output(handle(prhs[1]), mxGetDoubles(cno), (int64_t)(nk * (mwSize)nch))) fail("gc_set_cno_output");
+      cno = mxCreateDoubleMatrix(nv * nk, (mwSize)nch, mxREAL);  /* column-major: element (j + nv*k, channel) */
+      if (gc_set_cno_output(handle(prhs[1]), mxGetDoubles(cno), (int64_t)(nv * nk * (mwSize)nch))) fail("gc_set_cno_output");
     }
     int rc;
     if (!strcmp(cmd, "track_file")) {

@@ -2,8 +2,9 @@ function pkg = gnsscorr_package(name, settings)
 %GNSSCORR_PACKAGE  Per-package table of the GPU drop-ins (gnsscorr_tracking.m / gnsscorr_acquisition.m).
 %   pkg = gnsscorr_package(name, settings) describes how package NAME of CU-SDR-Collection builds its code replicas, closes its
 %   loops and records its results, so that ONE generic tracking / acquisition wrapper serves all twelve packages.  Every entry
-%   cites the lines of the package's own tracking.m it stands for.  The code generators, calcLoopCoef*.m, CNoVSM.m and
-%   Calc_CNo_PLD.m called from here are the PACKAGE'S OWN files (they stay MATLAB, SURVEY.md section 8b).
+%   cites the lines of the package's own tracking.m it stands for.  The code generators and calcLoopCoef*.m called from here
+%   are the PACKAGE'S OWN files (they stay MATLAB, SURVEY.md section 8b); CNoVSM / Calc_CNo_PLD are evaluated by the library
+%   with the loops and come back with the records.
 %   Written for this repository; not a copy of any reference file.
 
 pkg.name        = name;

@@ -106,6 +106,16 @@ if pkg.dllScale ~= 0, p.dllScale = pkg.dllScale; end
 p.tablePhaseCount = pkg.phaseCount;
 p.skipSamples = skip;
 p.numEpochs = n;
+% C/N0 and the lock detector come back with the records (4th output): CNoVSM every CNo.VSMinterval epochs inside the loops
+% (tracking.m:351-358), Calc_CNo_PLD every CNoInterval epochs with the bookkeeping of BDS/B2a tracking.m:409-432
+if strcmp(pkg.cno, 'VSM')
+    p.cnoInterval = settings.CNo.VSMinterval;  p.cnoAccTime = settings.CNo.accTime;  p.cnoMode = 0;
+else
+    p.cnoInterval = settings.CNoInterval;  p.cnoAccTime = settings.intTime;
+    p.cnoMode = 1;                                              % data arm only
+    if pkg.pilotOn, p.cnoMode = 2; end                          % Calc_CNo_PLD.m:72-75: pilot prompt pair read as (Q, I)
+    if pkg.pilotOn && pkg.pilotMode == 4, p.cnoMode = 3; end    % B1C wide-band loop (pilotTRKflag == 2): as (I, Q)
+end
 
 %--- code tables and the channel table (tracking.m:156-170) ----------------------------------------------------------------------
 chanTable = zeros(6, numel(active));
@@ -125,10 +135,10 @@ end
 
 %--- the loops -----------------------------------------------------------------------------------------------------------------------
 if windowed
-    [trk, epochs, status] = gnsscorr_mex('track_file', h, p, chanTable, fileName, settings.gnsscorrWindowSamples, settings.dataType, ...
-                                         settings.fileType, order);
+    [trk, epochs, status, cno] = gnsscorr_mex('track_file', h, p, chanTable, fileName, settings.gnsscorrWindowSamples, settings.dataType, ...
+                                              settings.fileType, order);
 else
-    [trk, epochs, status] = gnsscorr_mex('track', h, p, chanTable);  % trk(epoch, (k-1)*21 + field), fields as gc_track_field
+    [trk, epochs, status, cno] = gnsscorr_mex('track', h, p, chanTable);  % trk(epoch, (k-1)*21 + field), fields as gc_track_field
 end
 
 %--- records (tracking.m:212-216,249,277,314,332,338-348) ------------------------------------------------------------------------
@@ -151,28 +161,29 @@ for k = 1:numel(active)
         trackResults(c).dllDiscr(1:m)     = trackResults(c).dllDiscr(1:m) / 2;
         trackResults(c).dllDiscrFilt(1:m) = trackResults(c).dllDiscrFilt(1:m) / 2;
     end
-    if strcmp(pkg.cno, 'VSM')                                    % tracking.m:351-358 with the package's own CNoVSM.m
+    if strcmp(pkg.cno, 'VSM')                                    % tracking.m:351-358
         vsm = settings.CNo.VSMinterval;
         cnt = 0;
         for e = vsm:vsm:m
             cnt = cnt + 1;
-            trackResults(c).CNo.VSMValue(cnt) = CNoVSM(trackResults(c).I_P(e-vsm+1:e), trackResults(c).Q_P(e-vsm+1:e), settings.CNo.accTime);
+            if isempty(cno)                                      % VSMinterval = 1: nothing to average inside the loop
+                trackResults(c).CNo.VSMValue(cnt) = CNoVSM(trackResults(c).I_P(e-vsm+1:e), trackResults(c).Q_P(e-vsm+1:e), settings.CNo.accTime);
+            else
+                trackResults(c).CNo.VSMValue(cnt) = cno(cnt, k);
+            end
             trackResults(c).CNo.VSMIndex(cnt) = e;
         end
-    else                                                         % BDS/B2a tracking.m:409-432 with the package's own Calc_CNo_PLD.m
+    else                                                         % BDS/B2a tracking.m:409-432
         iv = settings.CNoInterval;
-        prev = zeros(1, 3);
         for e = iv:iv:m
-            [cnoValue, pld] = Calc_CNo_PLD(trackResults(c), settings, e);
             cnt = e / iv;
-            trackResults(c).DataCNo(cnt) = cnoValue(1) * 0.5 + prev(1) * 0.5;
-            trackResults(c).DataPLD(cnt) = pld(1);
+            trackResults(c).DataCNo(cnt) = cno(5 * (cnt - 1) + 1, k);
+            trackResults(c).DataPLD(cnt) = cno(5 * (cnt - 1) + 4, k);
             if pkg.pilotOn
-                trackResults(c).PilotCNo(cnt) = cnoValue(2) * 0.5 + prev(2) * 0.5;
-                trackResults(c).(combined)(cnt) = cnoValue(3) * 0.5 + prev(3) * 0.5;
-                trackResults(c).PilotPLD(cnt) = pld(2);
+                trackResults(c).PilotCNo(cnt) = cno(5 * (cnt - 1) + 2, k);
+                trackResults(c).(combined)(cnt) = cno(5 * (cnt - 1) + 3, k);
+                trackResults(c).PilotPLD(cnt) = cno(5 * (cnt - 1) + 5, k);
             end
-            prev = cnoValue;
         end
     end
     if m == n, trackResults(c).status = channel(c).status; end   % tracking.m:365

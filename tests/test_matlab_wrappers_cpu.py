@@ -44,7 +44,10 @@ class _MockGateway:
             nch = chan.shape[1]
             done = np.full((1, nch), float(n))
             done[0, -1] = n - 3                    # the last active channel stops three epochs early (a short read)
-            return np.ones((n, 21 * nch)), done, np.array([[-2.0]])
+            # 4th output: C/N0 per interval and channel (CNoVSM: one value; Calc_CNo_PLD modes: five), as gnsscorr_mex.c lays it out
+            k = int(np.asarray(p["cnoInterval"]).flat[0])
+            nv = 5 if int(np.asarray(p["cnoMode"]).flat[0]) else 1
+            return np.ones((n, 21 * nch)), done, np.array([[-2.0]]), np.full((nv * (n // k), nch), 45.0)
         return None
 
 
