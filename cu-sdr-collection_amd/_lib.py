@@ -87,7 +87,8 @@ class gc_acq_params(C.Structure):
 class gc_fine_params(C.Structure):
     _fields_ = [("sampling_freq", C.c_double), ("code_freq", C.c_double), ("f0", C.c_double), ("fstep", C.c_double),
                 ("first_sample", C.c_int64), ("spc", C.c_int32), ("ncodes", C.c_int32), ("nbins", C.c_int32),
-                ("code_len", C.c_int32), ("index_offset", C.c_int32), ("source", C.c_int32)]
+                ("code_len", C.c_int32), ("index_offset", C.c_int32), ("source", C.c_int32),
+                ("dc_re", C.c_double), ("dc_im", C.c_double)]
 
 
 class gc_acq_shift_params(C.Structure):
@@ -148,6 +149,8 @@ SYMBOLS = {
     "gc_acq_conditioned": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_float)]),
     "gc_acquire_fine_l1ca_batch": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(C.c_int32),
                                              C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gc_acq_signal_stats": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double)]),
     "gc_acquire_fine_sums_batch": (C.c_int, [_P, C.POINTER(gc_fine_params), C.c_int, _P, C.POINTER(C.c_int64),
                                              C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gc_acq_shift_prepare": (C.c_int, [_P, C.POINTER(gc_acq_shift_params)]),

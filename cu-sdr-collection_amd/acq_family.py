@@ -235,23 +235,19 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None):
     table = glonass_sampled_code(settings.samplingFreq, spc)[None, :]
     code40 = glonass_sampled_code(settings.samplingFreq, spc * 40)
     nfine = _round(settings.acqSearchStep / 25) + 1
-    ts = 1.0 / settings.samplingFreq
-    phase = np.arange(40 * spc) * 2 * math.pi * ts
     for K in settings.acqSatelliteList:
         p = _acq_params(settings, first_sample)
         p.intermediate_freq = settings.IF - settings.freqSpacing * K               # :146-147
         r = engine.acquire_coarse(p, table)[0]
         acq.peakMetric[K + 7] = r.peak_metric
         if r.peak_metric > settings.acqThreshold:
-            # the 40-code replica is an arbitrary sampled sequence here, so the per-code sums are formed on the host from
-            # the device record (40 x 12 000 samples x 21 bins)
-            raw = engine.read_if(first_sample + r.code_phase - 1, 40 * spc).astype(np.float64)
-            x = (raw[0::2] + 1j * raw[1::2]) * code40
-            fine, freqs = np.empty(nfine), np.empty(nfine)
-            for k in range(nfine):
-                freqs[k] = r.coarse_freq + settings.acqSearchStep / 2 - 25 * k
-                per_code = (x * np.exp(-1j * freqs[k] * phase)).reshape(40, spc).sum(axis=1)
-                fine[k] = max(abs(np.sum(per_code[c:c + 10]) - np.sum(per_code[c + 10:c + 20])) for c in range(20))   # :180-185
-            acq.carrFreq[K + 7] = float(freqs[int(np.argmax(fine))])
+            # the 40-code replica is a sequence sampled by the reference's own rule (one entry per sample: gc_fine_params.code_freq = 0);
+            # per-code sums for the 21 bins on the GPU, the 20 meander alignments of 40 complex numbers here
+            fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=0.0, f0=r.coarse_freq + settings.acqSearchStep / 2, fstep=25.0,
+                                  first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=40, nbins=nfine, code_len=40 * spc,
+                                  index_offset=0, source=0)
+            sums = engine.acquire_fine_sums(fp, code40)                                                                # [nfine, 40]
+            fine = np.array([max(abs(np.sum(s[c:c + 10]) - np.sum(s[c + 10:c + 20])) for c in range(20)) for s in sums])   # :180-185
+            acq.carrFreq[K + 7] = float(fp.f0 - 25.0 * int(np.argmax(fine)))
             acq.codePhase[K + 7] = r.code_phase
     return acq

@@ -158,17 +158,17 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
             acq.carrFreq[prn - 1] = f
             acq.codePhase[prn - 1] = code_phase
             if getattr(settings, "pilotTRKflag", 0) == 1:                          # :140-166, 75 short correlations
-                raw = engine.read_if(first_sample + code_phase - 1, spc).astype(np.float64)
-                sig = raw[0::2] + 1j * raw[1::2]
-                sig = sig - np.mean(sig)
-                carr = np.exp(-1j * f * (np.arange(spc) * 2 * math.pi * ts))
-                cl = codes.generateCLcode(prn, int(settings.CLCodeLength)).astype(np.float64)
+                # sig - mean(sig), wiped with the carrier and with each of the 75 CL segments sampled like the CM table: one
+                # launch, the segments as 75 replicas of one entry per sample (gc_fine_params.code_freq = 0)
+                mean, _ = engine.acq_signal_stats(first_sample + code_phase - 1, spc)
+                cl = codes.generateCLcode(prn, int(settings.CLCodeLength))
                 idx = np.ceil(ts * np.arange(spc) / tc).astype(np.int64)
                 idx[0] = 1
                 idx[-1] = int(settings.codeLength) * (1 if settings.acqCohT <= 10 else 2)
-                power = np.empty(75)
-                for ind in range(75):
-                    power[ind] = abs(np.sum(sig * cl[idx - 1 + int(settings.codeLength) * 2 * ind] * carr))
+                windows = np.stack([cl[idx - 1 + int(settings.codeLength) * 2 * ind] for ind in range(75)]).astype(np.int8)
+                fp = L.gc_fine_params(sampling_freq=fs, code_freq=0.0, f0=f, fstep=0.0, first_sample=first_sample + code_phase - 1, spc=spc,
+                                      ncodes=1, nbins=1, code_len=spc, index_offset=0, source=0, dc_re=mean.real, dc_im=mean.imag)
+                power = np.abs(engine.acquire_fine_sums_batch(fp, windows, np.full(75, fp.first_sample), np.full(75, f))[:, 0, 0])
                 if acq.CLCodePhase.shape[0] < prn:       # the field is created by this assignment and grows with it (GPS_L2C acquisition.m:165):
                     acq.CLCodePhase = np.concatenate([acq.CLCodePhase, np.zeros(prn - acq.CLCodePhase.shape[0])])   # numel = highest PRN found
                 acq.CLCodePhase[prn - 1] = int(np.argmax(power)) + 1
@@ -203,16 +203,14 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
     nfine = _round(settings.acqStep / 25) * 2 + 1                                  # :130
     if n_long is None:
         n_long = int(engine.if_buffer()[1]) - first_sample
-    raw = engine.read_if(first_sample, xlen).astype(np.float64)                    # sigPower, :138
-    x = raw[0::2] + 1j * raw[1::2]
-    sig_power = math.sqrt(np.var(x, ddof=1) * xlen)
+    _, var = engine.acq_signal_stats(first_sample, xlen)                           # sigPower, :138
+    sig_power = math.sqrt(var * xlen)
     init_freq = settings.IF + settings.acqSearchBand                               # :141
     p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=init_freq, carrier_step=0.0, first_sample=first_sample,
                               n=n, n_signals=1, n_carriers=1, n_bins=nbins, n_arms_max=2)
     engine.acq_shift_prepare(p)
     nmax = max(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(nmax), codePhase=np.zeros(nmax), peakMetric=np.zeros(nmax))
-    fine_phase = np.arange(spc) * 2 * math.pi * ts
     for prn in settings.acqSatelliteList:
         dtab = _b1c_table(codes.generateDataBOC11(prn), settings, spc)
         arms = [np.concatenate([dtab[:xlen], np.zeros(n - xlen, dtype=np.int8)])]   # :155-156
@@ -231,19 +229,15 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
         if code_phase + spc - 1 > n_long:                                          # :232-234
             code_phase -= spc
         if acq.peakMetric[prn - 1] > settings.acqThreshold:
-            raw = engine.read_if(first_sample + code_phase - 1, spc).astype(np.float64)
-            s0 = raw[0::2] + 1j * raw[1::2]                                         # the reference does not remove the mean here
-            xc = s0 * dtab
-            xp = s0 * ptab if pilot else None
-            fine = np.empty(nfine)
-            freqs = np.empty(nfine)
-            for k in range(nfine):                                                 # :242-250
-                freqs[k] = sel_freq + settings.acqStep - fine_step * k
-                c = np.exp(-1j * freqs[k] * fine_phase)
-                fine[k] = abs(np.sum(xc * c))
-                if pilot:
-                    fine[k] = (fine[k] * 11 + abs(np.sum(xp * c)) * 29) / 40
-            f = float(freqs[int(np.argmax(fine))])
+            # one code period against the sampled BOC tables at nfine carriers (:242-250; the reference does not remove the mean
+            # here): the tables are replicas of one entry per sample (gc_fine_params.code_freq = 0), data and pilot in one launch
+            fp = L.gc_fine_params(sampling_freq=fs, code_freq=0.0, f0=sel_freq + settings.acqStep, fstep=float(fine_step),
+                                  first_sample=first_sample + code_phase - 1, spc=spc, ncodes=1, nbins=nfine, code_len=spc,
+                                  index_offset=0, source=0)
+            tabs = np.stack([dtab, ptab]) if pilot else dtab[None, :]
+            s = np.abs(engine.acquire_fine_sums_batch(fp, tabs, np.full(len(tabs), fp.first_sample), np.full(len(tabs), fp.f0))[:, :, 0])
+            fine = (s[0] * 11 + s[1] * 29) / 40 if pilot else s[0]
+            f = float(fp.f0 - fine_step * int(np.argmax(fine)))
             acq.carrFreq[prn - 1] = f if f != 0 else 1                             # :253-255
             acq.codePhase[prn - 1] = code_phase
     return acq

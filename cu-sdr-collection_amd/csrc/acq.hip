@@ -975,7 +975,7 @@ template <bool F32>  // F32: the conditioned complex float signal instead of the
 __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict__ xv, const FineDet* __restrict__ det, int spc,
                                                           int ncodes, const int8_t* __restrict__ codes, int code_len, double ts,
                                                           double tc, double fstep, double fs, int nbins, int index_offset,
-                                                          double* __restrict__ out) {
+                                                          float dcr, float dcq, double* __restrict__ out) {
   constexpr int MID = kFineBins / 2;
   const int ci = blockIdx.x, d = blockIdx.y, b0 = blockIdx.z * kFineBins;
   const int nb = min(kFineBins, nbins - b0);
@@ -987,7 +987,8 @@ __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict_
   for (int k = 0; k < kFineBins; ++k) sr[k] = si[k] = 0.0;
   for (int i = threadIdx.x; i < spc; i += 256) {
     const long long n = (long long)ci * spc + i;
-    const double cvi = floor(__ddiv_rn(__dmul_rn(ts, (double)(n + index_offset)), tc));  // acquisition.m:215-216
+    // acquisition.m:215-216; tc == 0: the replica is already one entry per sample
+    const double cvi = tc > 0.0 ? floor(__ddiv_rn(__dmul_rn(ts, (double)(n + index_offset)), tc)) : (double)(n + index_offset);
     const float c = (float)code[(int)fmod(cvi, (double)code_len)];
     float xr, xq;
     if constexpr (F32) {
@@ -999,6 +1000,8 @@ __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict_
       xr = (float)xs.x;
       xq = (float)xs.y;
     }
+    xr -= dcr;
+    xq -= dcq;
     const float cr = c * xr, cq = c * xq;
     const double ph = fmid * (double)n, dp = fst * (double)n;
     float sn, cs, sd, cd;
@@ -1618,17 +1621,65 @@ extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params*
   GC_HIP(hipMemcpyAsync(bcode.p, codes, (size_t)ndet * p->code_len, hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipMemcpyAsync(bdet.p, hdet.data(), (size_t)ndet * sizeof(FineDet), hipMemcpyHostToDevice, ctx->stream));
   const dim3 grid((unsigned int)p->ncodes, (unsigned int)ndet, (unsigned int)((p->nbins + kFineBins - 1) / kFineBins));
+  const double tc = p->code_freq > 0.0 ? 1.0 / p->code_freq : 0.0;  // 0: sampled replica, one entry per sample
   if (cond)
     hipLaunchKernelGGL(fine_multi_kernel<true>, grid, dim3(256), 0, ctx->stream, (const void*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p,
                        (const FineDet*)bdet.p, p->spc, p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq,
-                       1.0 / p->code_freq, p->fstep, p->sampling_freq, p->nbins, p->index_offset, (double*)bout.p);
+                       tc, p->fstep, p->sampling_freq, p->nbins, p->index_offset, (float)p->dc_re, (float)p->dc_im, (double*)bout.p);
   else
     hipLaunchKernelGGL(fine_multi_kernel<false>, grid, dim3(256), 0, ctx->stream, (const void*)ctx->d_if, (const FineDet*)bdet.p, p->spc,
-                       p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq, 1.0 / p->code_freq, p->fstep,
-                       p->sampling_freq, p->nbins, p->index_offset, (double*)bout.p);
+                       p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq, tc, p->fstep,
+                       p->sampling_freq, p->nbins, p->index_offset, (float)p->dc_re, (float)p->dc_im, (double*)bout.p);
   GC_HIP(hipGetLastError());
   GC_HIP(hipMemcpyAsync(out, bout.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));  // also keeps hdet / codes alive until the copies are done
+  return GC_OK;
+}
+
+extern "C" int gc_acq_signal_stats(gc_context* ctx, int64_t first_sample, int64_t n, int32_t source, double* mean_re, double* mean_im,
+                                   double* var) {
+  if (!ctx || first_sample < 0 || n < 2 || n > 0x7fffffff || !mean_re || !mean_im || !var) {
+    gc_set_error("gc_acq_signal_stats: bad arguments");
+    return GC_E_INVALID;
+  }
+  const bool cond = source == GC_ACQ_SOURCE_CONDITIONED;
+  if (cond) {
+    if (ctx->acq_cond_n <= 0) {
+      gc_set_error("gc_acq_signal_stats: no conditioned signal (call gc_acq_condition first)");
+      return GC_E_STATE;
+    }
+  } else if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
+    gc_set_error("gc_acq_signal_stats: needs an int8 I/Q IF buffer");
+    return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  }
+  if ((uint64_t)first_sample + (uint64_t)n > (cond ? (uint64_t)ctx->acq_cond_n : ctx->if_nsamples)) {
+    gc_set_error("gc_acq_signal_stats: %lld samples from %lld exceed the signal", (long long)n, (long long)first_sample);
+    return GC_E_RANGE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  GcBuf& b = ctx->acqbuf[gc_context::ACQ_FINE_DET];
+  if (gc_buf_reserve(b, 64, false) != hipSuccess) {
+    gc_set_error("gc_acq_signal_stats: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  GC_HIP(hipMemsetAsync(b.p, 0, 64, ctx->stream));
+  if (cond)
+    hipLaunchKernelGGL(sigpower_f32_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const float2*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p,
+                       (long long)first_sample, (int)n, (double*)b.p);
+  else
+    hipLaunchKernelGGL(sigpower_kernel, dim3(64), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (long long)first_sample, (int)n,
+                       (long long*)b.p);
+  GC_HIP(hipGetLastError());
+  long long hs[3];
+  GC_HIP(hipMemcpyAsync(hs, b.p, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  double s3[3];
+  if (cond) std::memcpy(s3, hs, sizeof s3);
+  else for (int k = 0; k < 3; ++k) s3[k] = (double)hs[k];
+  const double mr = s3[0] / (double)n, mi = s3[1] / (double)n;
+  *mean_re = mr;
+  *mean_im = mi;
+  *var = (s3[2] - (double)n * (mr * mr + mi * mi)) / (double)(n - 1);
   return GC_OK;
 }
 

@@ -326,6 +326,12 @@ class Engine:
                                                      out.ctypes.data_as(C.POINTER(C.c_double))))
         return out[..., 0] + 1j * out[..., 1]
 
+    def acq_signal_stats(self, first_sample: int, n: int, source: int = 0):
+        """gc_acq_signal_stats: (mean(x), var(x)) of n samples of the record (or of the conditioned signal) as MATLAB's mean / var."""
+        mr, mi, v = C.c_double(), C.c_double(), C.c_double()
+        L.check(self._lib.gc_acq_signal_stats(self._ctx, int(first_sample), int(n), int(source), C.byref(mr), C.byref(mi), C.byref(v)))
+        return complex(mr.value, mi.value), v.value
+
     def acq_shift_prepare(self, params: L.gc_acq_shift_params):
         self._shift = params
         L.check(self._lib.gc_acq_shift_prepare(self._ctx, C.byref(params)))

@@ -374,7 +374,10 @@ int gc_acquire_fine_l1ca_batch(gc_context* ctx, const gc_acq_params* p, int ndet
  * search over the per-code sums stays with the caller. */
 typedef struct gc_fine_params {
   double sampling_freq;      /* settings.samplingFreq */
-  double code_freq;          /* settings.codeFreqBasis (tc = 1/code_freq) */
+  double code_freq;          /* settings.codeFreqBasis (tc = 1/code_freq); 0: `code` is a replica already sampled at the
+                                sampling rate, one entry per sample - index (n + index_offset) mod code_len (GLONASS' sampled
+                                40-code replica, GLO_GL1 acquisition.m:159-164; BDS B1C's table, acquisition.m:236-250; the CL
+                                windows of GPS_L2C acquisition.m:140-163) */
   double f0, fstep;          /* FineFreqBins(k) = f0 - fstep*(k-1) */
   int64_t first_sample;      /* absolute index of longSignal(codePhase) */
   int32_t spc;               /* samplesPerCode */
@@ -383,7 +386,14 @@ typedef struct gc_fine_params {
   int32_t code_len;          /* settings.codeLength */
   int32_t index_offset;      /* 0: codeValueIndex over (0:K*spc-1) (L1CA :210); 1: over (1:K*spc) (L5 :231) */
   int32_t source;            /* as gc_acq_params.source */
+  double dc_re, dc_im;       /* subtracted from every sample first: sig - mean(sig), GPS_L2C acquisition.m:144 (0: nothing) */
 } gc_fine_params;
+
+/* mean(x) and var(x) (MATLAB's: normalised by n - 1, of a complex vector) of the n samples from first_sample of the IF record
+ * or the conditioned signal (`source` as in gc_acq_params): sigPower = sqrt(var * n) of BDS/B1C acquisition.m:138, the mean
+ * of GPS_L2C acquisition.m:144.  Exact integer sums for the int8 record. */
+int gc_acq_signal_stats(gc_context* ctx, int64_t first_sample, int64_t n, int32_t source, double* mean_re, double* mean_im,
+                        double* var);
 
 int gc_acquire_fine_sums(gc_context* ctx, const gc_fine_params* p, const int8_t* code, double* out);
 /* `ndet` detections per call: detection d uses codes + d*code_len, first_sample[d] and f0[d] instead of the fields of

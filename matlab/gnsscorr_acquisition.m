@@ -183,18 +183,20 @@ fs = settings.samplingFreq;  ts = 1 / fs;
 table = generateCAcode(0, fs, spc);
 code40 = generateCAcode(0, fs, 40 * spc);
 nfine = round(settings.acqSearchStep / 25) + 1;
-phase = (0:(40 * spc - 1)) * 2 * pi * ts;
 for K = settings.acqSatelliteList
     a.IF = settings.IF - settings.freqSpacing * K;
     r = gnsscorr_mex('acquire_coarse_multi', h, a, int8(table(:)), 1);
     acqResults.peakMetric(K + 8) = r(4);
     if r(4) <= settings.acqThreshold, continue; end
-    raw = double(gnsscorr_mex('read_if', h, r(2) - 1, 40 * spc, 'int8', 2));
-    x = (raw(1:2:end) + 1i * raw(2:2:end)) .* code40;
+    % the 40-code replica goes to the GPU as it is, one entry per sample (codeFreq = 0); the 40 per-code sums of every bin come back
+    q = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', r(5) + settings.acqSearchStep / 2, 'fstep', 25, 'firstSample', r(2) - 1, ...
+               'samplesPerCode', spc, 'ncodes', 40, 'nbins', nfine, 'codeLength', 40 * spc, 'indexOffset', 0);
+    s = gnsscorr_mex('fine_sums', h, q, int8(code40(:)));
+    s = s(1:2:end, :) + 1i * s(2:2:end, :);                                 % 40 x nfine
     power = zeros(1, nfine);  freqs = zeros(1, nfine);
     for b = 1:nfine
-        freqs(b) = r(5) + settings.acqSearchStep / 2 - 25 * (b - 1);
-        perCode = sum(reshape(x .* exp(-1i * freqs(b) * phase), spc, 40), 1);
+        freqs(b) = q.f0 - 25 * (b - 1);
+        perCode = s(:, b).';
         best = 0;
         for c = 1:20
             best = max(best, abs(sum(perCode(c:c+9)) - sum(perCode(c+10:c+19))));

@@ -152,18 +152,21 @@ for PRN = settings.acqSatelliteList
         acqResults.carrFreq(PRN) = carr;
         acqResults.codePhase(PRN) = codePhase;
         if settings.pilotTRKflag == 1                                                       % :140-166: 75 one-period correlations
-            raw = double(gnsscorr_mex('read_if', h, codePhase - 1, spc, 'int8', 2));
-            sig = raw(1:2:end) + 1i * raw(2:2:end);
-            sig = sig - mean(sig);
-            carrier = exp(-1i * carr * ((0:spc - 1) * 2 * pi * ts));
+            % sig - mean(sig) wiped with the carrier and each of the 75 CL segments sampled like the CM table: the segments go to
+            % the GPU as 75 replicas of one entry per sample (codeFreq = 0), the mean as the dc term
+            st = gnsscorr_mex('signal_stats', h, codePhase - 1, spc);
             cl = generateCLcode(PRN, settings);
             idx = ceil(ts * (0:spc - 1) / tc);
             idx(1) = 1;
             if settings.acqCohT <= 10, idx(end) = settings.codeLength; else, idx(end) = settings.codeLength * 2; end
-            power = zeros(1, 75);
+            windows = zeros(spc, 75);
             for ind = 1:75
-                power(ind) = abs(sum(sig .* cl(idx + settings.codeLength * 2 * (ind - 1)) .* carrier));
+                windows(:, ind) = cl(idx + settings.codeLength * 2 * (ind - 1)).';
             end
+            q2 = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', carr, 'fstep', 0, 'firstSample', codePhase - 1, 'samplesPerCode', spc, ...
+                        'ncodes', 1, 'nbins', 1, 'codeLength', spc, 'indexOffset', 0, 'dcRe', st(1), 'dcIm', st(2));
+            s = gnsscorr_mex('fine_sums', h, q2, int8(windows));                            % 2 x 75
+            power = abs(s(1, :) + 1i * s(2, :));
             [~, seg] = max(power);
             acqResults.CLCodePhase(PRN) = seg;                                              % :165 (the field grows to the highest PRN found)
         end
@@ -182,8 +185,8 @@ n = round(spc / 10 * (10 + settings.acqCohT));                                  
 nBins = round(settings.acqSearchBand * 2 / settings.acqStep) + 1;                           % :120
 pilot = settings.pilotACQflag == 1;
 fineStep = 25;  nFine = round(settings.acqStep / 25) * 2 + 1;                                % :129-130
-raw = double(gnsscorr_mex('read_if', h, 0, xLen, 'int8', 2));
-sigPower = sqrt(var(raw(1:2:end) + 1i * raw(2:2:end)) * xLen);                              % :138
+st = gnsscorr_mex('signal_stats', h, 0, xLen);
+sigPower = sqrt(st(3) * xLen);                                                              % :138
 initFreq = settings.IF + settings.acqSearchBand;                                            % :141
 q.samplingFreq = fs;  q.carrierF0 = initFreq;  q.carrierStep = 0;  q.firstSample = 0;
 q.samplesPerBlock = n;  q.nSignals = 1;  q.nCarriers = 1;  q.nBins = nBins;  q.nArmsMax = 2;
@@ -191,7 +194,6 @@ nRows = gnsscorr_mex('acq_shift_prepare', h, q);
 nMax = max(settings.acqSatelliteList);
 acqResults.carrFreq = zeros(1, nMax);  acqResults.codePhase = zeros(1, nMax);  acqResults.peakMetric = zeros(1, nMax);
 tc = 1 / settings.codeFreqBasis / 2;
-finePhase = (0:spc - 1) * 2 * pi * ts;
 for PRN = settings.acqSatelliteList
     dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);   % makeDataTable.m
     arms = [dtab(1:xLen), zeros(1, n - xLen)].';                                            % :155-156
@@ -209,19 +211,18 @@ for PRN = settings.acqSatelliteList
     acqResults.peakMetric(PRN) = peak / sigPower;                                           % :199
     if codePhase + spc - 1 > nLong, codePhase = codePhase - spc; end                        % :232-234
     if acqResults.peakMetric(PRN) > settings.acqThreshold
-        raw = double(gnsscorr_mex('read_if', h, codePhase - 1, spc, 'int8', 2));
-        s0 = raw(1:2:end) + 1i * raw(2:2:end);
-        xc = s0 .* dtab;
-        if pilot, xp = s0 .* ptab; end
-        fine = zeros(1, nFine);  freqs = zeros(1, nFine);
-        for k = 1:nFine                                                                     % :242-250
-            freqs(k) = selFreq + settings.acqStep - fineStep * (k - 1);
-            c = exp(-1i * freqs(k) * finePhase);
-            fine(k) = abs(sum(xc .* c));
-            if pilot, fine(k) = (fine(k) * 11 + abs(sum(xp .* c)) * 29) / 40; end
-        end
+        % one code period against the sampled BOC tables at nFine carriers (:242-250): the tables go to the GPU as replicas of one
+        % entry per sample (codeFreq = 0), data and pilot in one call
+        tabs = dtab(:);
+        if pilot, tabs = [dtab(:), ptab(:)]; end
+        q3 = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', selFreq + settings.acqStep, 'fstep', fineStep, 'firstSample', codePhase - 1, ...
+                    'samplesPerCode', spc, 'ncodes', 1, 'nbins', nFine, 'codeLength', spc, 'indexOffset', 0);
+        s = gnsscorr_mex('fine_sums', h, q3, int8(tabs));                                   % 2 x (nFine * narms)
+        s = abs(s(1, :) + 1i * s(2, :));
+        fine = s(1:nFine);
+        if pilot, fine = (s(1:nFine) * 11 + s(nFine + 1:2 * nFine) * 29) / 40; end
         [~, m] = max(fine);
-        carr = freqs(m);
+        carr = q3.f0 - fineStep * (m - 1);
         if carr == 0, carr = 1; end                                                         % :253-255
         acqResults.carrFreq(PRN) = carr;
         acqResults.codePhase(PRN) = codePhase;

@@ -316,7 +316,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     /* gnsscorr_mex('load_if_packed2', h, uint8(packed)): 2-bit packed complex samples (unpack_cplx.m:32-49) expanded on the GPU */
     if (gc_load_if_packed2(handle(prhs[1]), mxGetData(prhs[2]), (uint64_t)mxGetNumberOfElements(prhs[2]))) fail("gc_load_if_packed2");
   } else if (!strcmp(cmd, "fine_sums")) {
-    /* s = gnsscorr_mex('fine_sums', h, fineParams, int8(code)): sumPerCode(bin, code) of the packages' fine-frequency stages */
+    /* s = gnsscorr_mex('fine_sums', h, fineParams, int8(code)): sumPerCode(bin, code) of the packages' fine-frequency stages.
+       codeFreq = 0: `code` is a replica already sampled, one entry per sample.  Several replicas at once: int8 codeLength x nrep,
+       s = 2*ncodes x (nbins*nrep), replica-major.  dcRe / dcIm: the mean removed from the samples first (GPS_L2C acquisition.m:144) */
     const mxArray* s = prhs[2];
     gc_fine_params p;
     memset(&p, 0, sizeof p);
@@ -331,8 +333,29 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.code_len = (int32_t)field(s, "codeLength");
     p.index_offset = mxGetField(s, 0, "indexOffset") ? (int32_t)field(s, "indexOffset") : 0;
     p.source = mxGetField(s, 0, "source") ? (int32_t)field(s, "source") : 0;
-    plhs[0] = mxCreateDoubleMatrix((mwSize)(2 * p.ncodes), (mwSize)p.nbins, mxREAL); /* (re, im) pairs per code, one column per bin */
-    if (gc_acquire_fine_sums(handle(prhs[1]), &p, (const int8_t*)mxGetData(prhs[3]), mxGetDoubles(plhs[0]))) fail("gc_acquire_fine_sums");
+    if (mxGetField(s, 0, "dcRe")) { p.dc_re = field(s, "dcRe"); p.dc_im = field(s, "dcIm"); }
+    const mwSize nrep = mxGetNumberOfElements(prhs[3]) / (mwSize)p.code_len;
+    if (nrep < 1 || nrep * (mwSize)p.code_len != mxGetNumberOfElements(prhs[3]))
+      mexErrMsgIdAndTxt("gnsscorr:args", "fine_sums: the code holds %d entries, not a multiple of codeLength = %d",
+                        (int)mxGetNumberOfElements(prhs[3]), (int)p.code_len);
+    plhs[0] = mxCreateDoubleMatrix((mwSize)(2 * p.ncodes), (mwSize)p.nbins * nrep, mxREAL); /* (re, im) pairs per code, one column per bin */
+    int64_t* first = (int64_t*)mxCalloc(nrep, sizeof *first);
+    double* f0 = (double*)mxCalloc(nrep, sizeof *f0);
+    for (mwSize i = 0; i < nrep; ++i) { first[i] = p.first_sample; f0[i] = p.f0; }
+    const int rc = gc_acquire_fine_sums_batch(handle(prhs[1]), &p, (int)nrep, (const int8_t*)mxGetData(prhs[3]), first, f0, mxGetDoubles(plhs[0]));
+    mxFree(first);
+    mxFree(f0);
+    if (rc) fail("gc_acquire_fine_sums");
+  } else if (!strcmp(cmd, "signal_stats")) {
+    /* s = gnsscorr_mex('signal_stats', h, firstSample, n[, source]): [real(mean(x)), imag(mean(x)), var(x)] of n samples on the device */
+    double mr, mi, v;
+    if (gc_acq_signal_stats(handle(prhs[1]), (int64_t)mxGetScalar(prhs[2]), (int64_t)mxGetScalar(prhs[3]),
+                            nrhs > 4 ? (int32_t)mxGetScalar(prhs[4]) : 0, &mr, &mi, &v))
+      fail("gc_acq_signal_stats");
+    plhs[0] = mxCreateDoubleMatrix(1, 3, mxREAL);
+    mxGetDoubles(plhs[0])[0] = mr;
+    mxGetDoubles(plhs[0])[1] = mi;
+    mxGetDoubles(plhs[0])[2] = v;
   } else if (!strcmp(cmd, "preamble_xcorr")) {
     /* c = gnsscorr_mex('preamble_xcorr', h, I_P, int8(preamble_ms)): NAVdecoding.m:62-76, non-negative lags */
     const mwSize n = mxGetNumberOfElements(prhs[2]);
