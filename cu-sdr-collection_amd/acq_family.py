@@ -222,14 +222,28 @@ def glonass_sampled_code(samp_freq: float, num_samples: int) -> np.ndarray:
     return code[np.remainder(s, 511)]
 
 
-def acquisition_GLO(engine, settings, first_sample: int | None = None):
+def acquisition_GLO(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """GLO/GLO_GL1/include/acquisition.m:120-200: for every frequency number K the L1CA scheme around
     IF - freqSpacing*K with the common 511-chip code; fine stage over 40 codes in 25-Hz bins against the 10-ms meander:
     |sum(10 codes) - sum(next 10)| at 20 alignments.  Results are stored at the 1-based index K + 8 of 21-entry arrays (acquisition.m:138-142,200;
-    preRun.m:66 reads them back as K = index - 8): element K + 7 here."""
+    preRun.m:66 reads them back as K = index - 8): element K + 7 here.
+    With settings.resamplingflag the input-conditioning block (:50-119, BW = 9 MHz) runs first; the code phase is mapped back
+    to the record's rate, the carrier frequency is NOT: the reference assigns the mapped value to a field it spells
+    `carrFreqcarrFreq` (:284), which is what comes back here too."""
+    import copy
     from .receiver import _acq_params
     if first_sample is None:
         first_sample = skip_samples(settings)
+    original = settings
+    resampled = settings.samplingFreq > settings.resamplingThreshold and getattr(settings, "resamplingflag", 0) == 1
+    if resampled:
+        if n_long is None:
+            n_long = int(engine.if_buffer()[1]) - int(first_sample)
+        new_fs, new_if, _ = engine.acq_condition(settings.samplingFreq, settings.IF, 9e6, first_sample, n_long)    # BW: :57
+        settings = copy.copy(settings)
+        settings.samplingFreq, settings.IF = new_fs, new_if
+        first_sample = 0
+    src = 1 if resampled else 0
     spc = _round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength))
     acq = SimpleNamespace(carrFreq=np.zeros(21), codePhase=np.zeros(21), peakMetric=np.zeros(21))
     table = glonass_sampled_code(settings.samplingFreq, spc)[None, :]
@@ -237,6 +251,7 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None):
     nfine = _round(settings.acqSearchStep / 25) + 1
     for K in settings.acqSatelliteList:
         p = _acq_params(settings, first_sample)
+        p.source = src
         p.intermediate_freq = settings.IF - settings.freqSpacing * K               # :146-147
         r = engine.acquire_coarse(p, table)[0]
         acq.peakMetric[K + 7] = r.peak_metric
@@ -245,9 +260,22 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None):
             # per-code sums for the 21 bins on the GPU, the 20 meander alignments of 40 complex numbers here
             fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=0.0, f0=r.coarse_freq + settings.acqSearchStep / 2, fstep=25.0,
                                   first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=40, nbins=nfine, code_len=40 * spc,
-                                  index_offset=0, source=0)
+                                  index_offset=0, source=src)
             sums = engine.acquire_fine_sums(fp, code40)                                                                # [nfine, 40]
             fine = np.array([max(abs(np.sum(s[c:c + 10]) - np.sum(s[c + 10:c + 20])) for c in range(20)) for s in sums])   # :180-185
             acq.carrFreq[K + 7] = float(fp.f0 - 25.0 * int(np.argmax(fine)))
             acq.codePhase[K + 7] = r.code_phase
+            if acq.carrFreq[K + 7] == 0:                                                                               # :263-265
+                acq.carrFreq[K + 7] = 1
+            if resampled:                                                                                              # :267-285
+                acq.codePhase[K + 7] = math.floor((r.code_phase - 1) / settings.samplingFreq * original.samplingFreq) + 1
+                if settings.IF >= settings.samplingFreq / 2:
+                    doppler = (settings.samplingFreq - settings.IF) - acq.carrFreq[K + 7]
+                else:
+                    doppler = acq.carrFreq[K + 7] - settings.IF
+                mapped = getattr(acq, "carrFreqcarrFreq", np.zeros(0))                   # :284: a new field, grown by the assignment
+                if mapped.shape[0] < K + 8:
+                    mapped = np.concatenate([mapped, np.zeros(K + 8 - mapped.shape[0])])
+                mapped[K + 7] = doppler + original.IF
+                acq.carrFreqcarrFreq = mapped
     return acq

@@ -27,7 +27,8 @@ if resampled
         case {'GPS_L1CA', 'GPS_L5C', 'BDS_B2a', 'BDS_B3I'}, c.bandwidth = settings.codeFreqBasis * 2 + 0.5e6;
         case {'GAL_E5a', 'GAL_E5b'}, c.bandwidth = 20.46e6;
         case 'GAL_E1C', c.bandwidth = 20.552e6;
-        otherwise, error('gnsscorr:acquisition', 'the resampling front end of %s is not wired (GLONASS: its fine stage reads the raw record)', name);
+        case {'GLO_GL1', 'GLO_GL2'}, c.bandwidth = 9e6;                                                            % GLO_GL1 acquisition.m:57
+        otherwise, error('gnsscorr:acquisition', 'the resampling front end of %s is not wired', name);
     end
     c.bandMargin = 0.002 * any(strcmp(name, {'GPS_L5C', 'BDS_B2a'}));            % wp = [w1*2/fs-0.002 w2*2/fs+0.002] (GPS_L5C acquisition.m:69)
     mirror = any(strcmp(name, {'GPS_L1CA', 'GPS_L5C', 'BDS_B2a'}));              % the other packages map back as carrFreq - IF only (GAL_E5a :292)
@@ -79,7 +80,11 @@ acqResults.carrFreq   = zeros(1, f.nResults);
 acqResults.codePhase  = zeros(1, f.nResults);
 acqResults.peakMetric = zeros(1, f.nResults);
 if f.glonass
-    acqResults = glonass(acqResults, h, a, settings, spc);
+    if resampled
+        acqResults = glonass(acqResults, h, a, settings, spc, oldFreq, oldIF);
+    else
+        acqResults = glonass(acqResults, h, a, settings, spc, 0, 0);
+    end
     return
 end
 
@@ -176,7 +181,7 @@ for k = 1:numel(sec) - 1
 end
 end
 
-function acqResults = glonass(acqResults, h, a, settings, spc)
+function acqResults = glonass(acqResults, h, a, settings, spc, oldFreq, oldIF)
 % GLO_GL1/include/acquisition.m:120-200: per frequency number K the L1CA scheme around IF - freqSpacing*K with the common
 % 511-chip code; fine stage over 40 codes in 25-Hz bins against the 10-ms meander.  Results at index K + 8.
 fs = settings.samplingFreq;  ts = 1 / fs;
@@ -190,7 +195,7 @@ for K = settings.acqSatelliteList
     if r(4) <= settings.acqThreshold, continue; end
     % the 40-code replica goes to the GPU as it is, one entry per sample (codeFreq = 0); the 40 per-code sums of every bin come back
     q = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', r(5) + settings.acqSearchStep / 2, 'fstep', 25, 'firstSample', r(2) - 1, ...
-               'samplesPerCode', spc, 'ncodes', 40, 'nbins', nfine, 'codeLength', 40 * spc, 'indexOffset', 0);
+               'samplesPerCode', spc, 'ncodes', 40, 'nbins', nfine, 'codeLength', 40 * spc, 'indexOffset', 0, 'source', a.source);
     s = gnsscorr_mex('fine_sums', h, q, int8(code40(:)));
     s = s(1:2:end, :) + 1i * s(2:2:end, :);                                 % 40 x nfine
     power = zeros(1, nfine);  freqs = zeros(1, nfine);
@@ -206,5 +211,17 @@ for K = settings.acqSatelliteList
     [~, best] = max(power);
     acqResults.carrFreq(K + 8) = freqs(best);
     acqResults.codePhase(K + 8) = r(2);
+    if acqResults.carrFreq(K + 8) == 0, acqResults.carrFreq(K + 8) = 1; end      % :263-265
+    if oldFreq > 0                                                                % :267-285, after the input conditioning
+        acqResults.codePhase(K + 8) = floor((r(2) - 1) / fs * oldFreq) + 1;
+        if settings.IF >= fs / 2
+            doppler = (fs - settings.IF) - acqResults.carrFreq(K + 8);
+        else
+            doppler = acqResults.carrFreq(K + 8) - settings.IF;
+        end
+        % the reference assigns the mapped frequency to a field it spells carrFreqcarrFreq (:284) and leaves carrFreq in the
+        % resampled band; a drop-in returns what the reference returns
+        acqResults.carrFreqcarrFreq(K + 8) = doppler + oldIF;
+    end
 end
 end

@@ -432,6 +432,12 @@ ACQ_SCENES = [
              product=lambda P, eng, S: P.acq_family.acquisition_GLO(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_glo(rec, S, 0)),
     AcqScene("GLO_GL2", "GLO/GLO_GL2", "initSettings_GLO_GL2", dict(acqNonCohTime=3, acqSatelliteList=[-7, 2, 6]), _acq_glo_record((-7, 6), 131),
              product=lambda P, eng, S: P.acq_family.acquisition_GLO(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_glo(rec, S, 0)),
+    # GLONASS with the input-conditioning block (GLO_GL1 acquisition.m:50-119, BW = 9 MHz): 30 Msps / IF 7 MHz -> 23 Msps; the code phase is
+    # mapped back, the carrier frequency lands in the field the reference spells carrFreqcarrFreq (:284) and carrFreq stays in the new band
+    AcqScene("GLO_GL1_resampled", "GLO/GLO_GL1", "initSettings_GLO_GL1",
+             dict(acqNonCohTime=2, acqSearchBand=2000, acqSatelliteList=[-3, 0, 5], samplingFreq=30e6, IF=7e6, resamplingflag=1), _acq_glo_record((-3, 5), 141),
+             product=lambda P, eng, S: P.acq_family.acquisition_GLO(eng, S, first_sample=0), oracle=None, metric_rtol=2e-3,
+             fields=("carrFreq", "codePhase", "peakMetric", "carrFreqcarrFreq")),
     AcqScene("BDS_B1I", "BDS/B1I", "initSettings_BDS_B1I", dict(acqSatelliteList=[7, 12, 23, 30]), _acq_b1i_record,
              product=lambda P, eng, S: P.acq_shift.acquisition_B1I(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_b1i(rec, S, 0)),
     AcqScene("GPS_L2C", "GPS/GPS_L2C", "initSettings_GPS_L2C", dict(pilotTRKflag=1, acqSearchBand=1, acqSatelliteList=[5, 9]), _acq_l2c_record,
