@@ -25,11 +25,18 @@ inline int gc_arm_pitch(int arms) { return arms <= 1 ? 1 : arms == 2 ? 2 : 4; }
 
 constexpr int kLaneWaves = 16;  // wavefronts per workgroup of the lane kernel (corr_lane.hip)
 
+// Every kLaneReseedSteps steps of a lane (64 samples each) the lane kernel re-seeds its carrier phasor from the exact float64
+// phase and takes the rounding drift out of its 32.32 ramp (the ramp's 64-sample increment is rounded to 2^-32 chip; what
+// kLaneReseedSteps of them miss is a block-uniform integer, added back in one instruction).
+constexpr int kLaneReseedSteps = 128;
+
 // Near-tie window of the lane kernel in 2^-32-chip units: 16 ulp of the largest ramp value (the reference's
-// float64 rounding of a + i*d and its two-sided colon), one unit per ramp step of a lane (the 32.32 increment
-// is rounded to 2^-33 chip), and 2 units of slack.  Host (gc_mark_tie_free) and device use the same formula.
+// float64 rounding of a + i*d and its two-sided colon), one unit per ramp step of a lane since the last drift correction
+// (the 32.32 increment is rounded to 2^-33 chip) plus one per correction (each is rounded too), and 2 units of slack.
+// Host (gc_mark_tie_free) and device use the same formula.
 __host__ __device__ inline unsigned int gc_tie_window_units(double max_ramp, int lane_steps) {
-  return 2u + (unsigned int)lane_steps + (unsigned int)(max_ramp * (16.0 * 2.220446049250313e-16 * 4294967296.0));
+  const int drift = lane_steps <= kLaneReseedSteps ? lane_steps : kLaneReseedSteps + lane_steps / kLaneReseedSteps + 1;
+  return 2u + (unsigned int)drift + (unsigned int)(max_ramp * (16.0 * 2.220446049250313e-16 * 4294967296.0));
 }
 
 struct TaggedSlot {

@@ -248,6 +248,14 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
 
   // Per-sample ramp step sp*M as a 64.64 fixed-point number (exact: a double has at most 64 fractional bits
   // here); one step of a lane = 64 samples = that number << 6, rounded to 32 fractional bits for Q.
+  // corrQ: what kLaneReseedSteps steps of the rounded increment dQ miss of the exact advance, in 2^-32 units (block-uniform)
+  auto drift_correction = [](unsigned long long sf, int si, unsigned long long dq) __attribute__((always_inline)) -> unsigned long long {
+    const unsigned __int128 adv = (unsigned __int128)sf * (unsigned int)(64 * kLaneReseedSteps);  // fraction part, 64 fractional bits
+    const unsigned long long fr = (unsigned long long)adv;
+    const long long whole = (long long)si * (64 * kLaneReseedSteps) + (long long)(unsigned long long)(adv >> 64);
+    const unsigned long long exact = ((unsigned long long)whole << 32) + (fr >> 32) + ((fr >> 31) & 1ull);
+    return exact - dq * (unsigned long long)kLaneReseedSteps;  // mod 2^64: a small signed number
+  };
   unsigned long long Sf, dQ;
   int Si;
   float rotC, rotS;
@@ -283,6 +291,13 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     const long long di = (long long)Si6 * 64 + (long long)(Sf6 >> 58);
     dQ6 = ((unsigned long long)di << 32) + (df >> 32) + ((df >> 31) & 1ull);
   }
+  auto uni_u64 = [](unsigned long long u) __attribute__((always_inline)) -> unsigned long long {
+    return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+           (unsigned int)__builtin_amdgcn_readfirstlane((int)u);
+  };
+  const unsigned long long corrQ = uni_u64(drift_correction(Sf, Si, dQ));
+  const unsigned long long corrQ6 = DER ? uni_u64(drift_correction(Sf6, Si6, dQ6)) : 0ull;
+  (void)corrQ6;
 
   float accr[ARMS][3], acci[ARMS][3];
 #pragma unroll
@@ -575,11 +590,18 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         group(xa, tf);
         if (2 * pp + 2 < groups) load_group(xa, 1);
         group(xb, tf);
-        // the phasor recurrence drifts by ~1 ulp per step: re-seed it from the exact float64 phase every
-        // 256 steps (matters for the 10-20 ms blocks of B1C / L2C, thousands of steps per lane)
-        if ((pp & 31) == 31) {
+        // the phasor recurrence drifts by ~1 ulp per step: re-seed it from the exact float64 phase every kLaneReseedSteps
+        // steps (matters for the 10-20 ms blocks of B1C / L2C, thousands of steps per lane); the ramps' rounding drift goes
+        // out at the same place (corr_common.h: it keeps the near-tie window, and with it the share of blocks that need the
+        // test at all, independent of the block length)
+        static_assert(kLaneReseedSteps % (2 * GRP) == 0, "re-seed interval: a whole number of group pairs");
+        constexpr int kPairs = kLaneReseedSteps / (2 * GRP);
+        static_assert((kPairs & (kPairs - 1)) == 0, "re-seed interval in pairs: a power of two");
+        if ((pp & (kPairs - 1)) == kPairs - 1) {
           const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
           sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+          Q0 += corrQ;
+          if constexpr (DER) Q60 += corrQ6;
         }
       }
       if (groups & 1) group(xa, tf);
