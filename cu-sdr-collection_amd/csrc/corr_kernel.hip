@@ -150,11 +150,14 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   const bool must_wide = fast > 0 && gc_fast_table_mode(ctx) == 1;  // tables too large for single-wave workgroups
   // by choice: every wave of the fast kernel parks 4-8 KB of running sums in LDS (corr_fast.hip), and
   // only four waves sharing an int8-pair table keep 16 waves per CU resident (big periodic replay lists, int8 I/Q, <= 2 arms)
-  const bool big_list0 = nblocks >= 64 * (long long)period * ctx->compute_units;
+  // (measured, scripts/replay_scaling.py: the four-wave float-table kernel wins from 4 epochs per CU on - 12 channels x 2 s: 0.70 of
+  // the HBM figure against 0.52 with single-wave workgroups, 3 channels x 10 s: 0.55 against 0.39; the first version waited for 64)
+  static const int wide_min = std::getenv("GC_WIDE_MIN") ? std::max(1, std::atoi(std::getenv("GC_WIDE_MIN"))) : 4;
+  const bool big_list0 = nblocks >= wide_min * (long long)period * ctx->compute_units;
   const bool choose_wide = fast > 0 && !must_wide && gc_fast_prefers_wide() && period > 0 && splits == 1 && big_list0 && notify_tag == 0 &&
                            ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && max_arms <= 2 && 2 * ctx->max_lds_bytes + 512 <= 40 * 1024;
   const bool wide_tables = must_wide || choose_wide;
-  const bool big_list = nblocks >= 64 * (long long)period * ctx->compute_units;
+  const bool big_list = choose_wide || nblocks >= 64 * (long long)period * ctx->compute_units;  // tables that MUST be shared: 8 epochs per workgroup only for long lists
   if (fast == 0) {
     // lane kernel: 16 wavefronts per workgroup, one (block, split) item each
     if (splits == 1 && period > 0) {
