@@ -78,6 +78,7 @@ struct KArgs {
   int use_inline;
   const struct DevLoopArgs* devloop;  // device-side loop closure (devloop.h); nullptr otherwise
   int wide;      // fast kernel variant with 4 waves per workgroup and int8-pair LDS tables
+  long long total_wg;  // xcd_swizzle outside the device loop: workgroups of the launch that have work (the grid is that rounded up to 8)
   int share_el;  // every block has el_spacing*R*M == 1/2: early and late taps share one ramp
   int derived;   // lane kernel: three-arm channels whose third arm is derived from the second (DevChannel::derived)
   int pad_;

@@ -86,8 +86,9 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
 
   long long wg = blockIdx.x;
   if (p.xcd_swizzle && !DEVLOOP) {
-    const long long per = (long long)gridDim.x >> 3;
+    const long long per = (long long)gridDim.x >> 3;  // the host rounds the grid up to a multiple of 8 when swizzling
     wg = (wg & 7) * per + (wg >> 3);
+    if (wg >= p.total_wg) return;                     // (at most seven workgroups of the rounded grid)
   }
   // Workgroup -> blocks.  With bpw > 1 (replay lists that interleave `stride` channels epoch by
   // epoch) one workgroup walks bpw consecutive epochs of ONE channel, so the code table is staged

@@ -76,8 +76,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   if (p.xcd_swizzle && !DEVLOOP) {
     // Workgroup b is dispatched to XCD b % 8.  Give every XCD one contiguous range of the descriptor list so
     // that neighbouring descriptors (the channels of one epoch, which read the same IF window) share an L2.
-    const long long per = (long long)gridDim.x >> 3;  // host guarantees gridDim.x % 8 == 0 when swizzling
+    const long long per = (long long)gridDim.x >> 3;  // the host rounds the grid up to a multiple of 8 when swizzling
     wg = (wg & 7) * per + (wg >> 3);
+    if (wg >= p.total_wg) return;                     // (at most seven workgroups of the rounded grid)
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform (SGPR)
