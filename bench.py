@@ -504,7 +504,7 @@ def main() -> None:
     ap.add_argument("--channels", type=int, default=12)
     ap.add_argument("--config", choices=["all", "l1ca", "mix"], default=None,
                     help="all (default at N = 1): main line + the other BASELINE configs; l1ca (default at N > 1): main line only; mix: configs[4] as the line")
-    ap.add_argument("--cfg-seconds", type=float, default=60.0, help="record length of config 4 (L5 + B2a at 50 Msps); config 3 uses a third of it")
+    ap.add_argument("--cfg-seconds", type=float, default=60.0, help="record length of configs 3 (8 x E1 CBOC at 18 Msps: 15 000 four-millisecond epochs per channel) and 4 (L5 + B2a at 50 Msps)")
     ap.add_argument("--mix-seconds", type=float, default=10.0, help="record length of every band of the mix")
     ap.add_argument("--cpu-epochs", type=int, default=4000, help="epochs per channel timed on the C CPU baseline (4000: ~13 s of one core)")
     ap.add_argument("--numpy-epochs", type=int, default=250, help="epochs per channel of the NumPy CPU variant (~5 s)")
@@ -543,7 +543,7 @@ def main() -> None:
     if config == "all" and world == 1:
         cfgs = {}
         # configs[2]: Galileo E1-C CBOC(6,1,1/11) x 8 (the replica as BASELINE words it; the reference's package tracks BOC(1,1))
-        cfgs["galileo_e1c_cboc_x8"], extra_jobs["cboc"] = run_band_jobs(P, W, "config 3", device, [("GAL_E1C_CBOC", 8)], args.cfg_seconds / 3, 18e6, 20e3, 3003,
+        cfgs["galileo_e1c_cboc_x8"], extra_jobs["cboc"] = run_band_jobs(P, W, "config 3", device, [("GAL_E1C_CBOC", 8)], args.cfg_seconds, 18e6, 20e3, 3003,
                                                                           args.steps, args.warmup)
         # configs[3]: GPS L5 + BDS B2a, pilot + data arms, 16 channels, 50 Msps - two packages on ONE record
         cfgs["l5_b2a_x16_50msps_int8"], extra_jobs["l5b2a"] = run_band_jobs(P, W, "config 4", device, [("GPS_L5C", 8), ("BDS_B2a", 8)], args.cfg_seconds, 50e6, 20e3,
