@@ -423,11 +423,21 @@ ACQ_SCENES = [
              product=lambda P, eng, S: P.acq_family.acquisition_B3I(eng, S, first_sample=0),
              oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_b3i_code(prn)]), fine_codes=lambda O, P: (lambda prn: [O.generate_b3i_code(prn)]),
                          ncodes=20, fine_step=25.0, combine=_b3i_combine, n_results=63, index_offset=0)),
+    # BDS B3I spells the switch resamplingFlag (BDS/B3I/include/acquisition.m:47) and maps back without the mirror branch (:289-298)
+    AcqScene("BDS_B3I_resampled", "BDS/B3I", "initSettings_BDS_B3I",
+             dict(acqNonCohTime=2, acqSearchBand=2000, acqSatelliteList=[3, 30, 44], samplingFreq=60e6, IF=15e6, resamplingFlag=1),
+             _acq_family_record("generateB3Icode", None, 1240.0, (3, 30), 109, 30, dmax=1.5e3),
+             product=lambda P, eng, S: P.acq_family.acquisition_B3I(eng, S, first_sample=0), oracle=None, metric_rtol=2e-3),
     AcqScene("GAL_E1C", "GAL/GAL_E1C", "initSettings_GAL_E1C", dict(acqSearchBand=1500, acqSearchStep=150, acqNonCohTime=1, acqThreshold=10, acqSatelliteList=[4, 27]),
              _acq_e1_record, product=lambda P, eng, S: P.acq_family.acquisition_E1C(eng, S, first_sample=0),
              oracle=_fam(coarse_codes=lambda O, P: (lambda prn: [O.generate_e1_code(prn, "B"), O.generate_e1_code(prn, "C")]),
                          fine_codes=lambda O, P: (lambda prn: [O.generate_e1_code(prn, "C")]), ncodes=25, fine_step=10.0, combine="split",
                          secondary=lambda O, P: (lambda prn: P.acq_family.E1C_SECONDARY), n_results=50, boc=True, index_offset=0)),
+    # Galileo E1 with the conditioning block (BW = 20.552 MHz, GAL_E1C acquisition.m:57): 60 Msps / IF 15 MHz -> 50 552 000 Hz; the BOC(1,1)
+    # tables are sampled at the new rate (makeE1BTable.m with the overwritten settings.samplingFreq), 404 416-point searches
+    AcqScene("GAL_E1C_resampled", "GAL/GAL_E1C", "initSettings_GAL_E1C",
+             dict(acqSearchBand=900, acqSearchStep=150, acqNonCohTime=1, acqThreshold=10, acqSatelliteList=[4, 27], samplingFreq=60e6, IF=15e6, resamplingflag=1),
+             _acq_e1_record, product=lambda P, eng, S: P.acq_family.acquisition_E1C(eng, S, first_sample=0), oracle=None, metric_rtol=2e-3),
     AcqScene("GLO_GL1", "GLO/GLO_GL1", "initSettings_GLO_GL1", dict(acqNonCohTime=4, acqSatelliteList=[-3, 0, 5]), _acq_glo_record((-3, 5), 121),
              product=lambda P, eng, S: P.acq_family.acquisition_GLO(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_glo(rec, S, 0)),
     AcqScene("GLO_GL2", "GLO/GLO_GL2", "initSettings_GLO_GL2", dict(acqNonCohTime=3, acqSatelliteList=[-7, 2, 6]), _acq_glo_record((-7, 6), 131),
