@@ -25,7 +25,7 @@ def main():
     job = W.prepare_job(P, W.Job(shape, pkg, S, sats, eng), n_ep)
     _, recs = W.run_closed_loops(P, [job], device_loop=False)
     W.keep_records(job, recs[0])
-    ms, dev, kern = W.time_replay(job, launches, 2)
+    ms, dev, kern = W.time_replay(job, launches, 2, warm=W.warm_engine(P, job))
     cs = float(job.blks.sum())
     print({"shape": shape, "kernel": W.KERNEL_NAMES.get(kern), "ms": round(ms, 4), "GBps": round(2 * cs / ms / 1e6, 1), "frac": round(2 * cs / ms / 1e6 / 8000, 4),
            "channel_samples_per_launch": cs, "dev": dev, "locked": W.locked(job)})

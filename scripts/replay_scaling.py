@@ -12,7 +12,7 @@ for name, nch, fs in (("GPS_L1CA", 3, 18e6), ("GPS_L1CA", 12, 18e6), ("GAL_E1C",
         _, recs = W.run_closed_loops(P, jobs, device_loop=True)
         j = jobs[0]
         W.keep_records(j, recs[0])
-        ms, dev, kern = W.time_replay(j, 20, 3)
+        ms, dev, kern = W.time_replay(j, 20, 3, warm=W.warm_engine(P, j))
         cs = float(j.blks.sum())
         print(f"{name} x{nch} {secs:5.1f} s: {ms:.4f} ms, {2 * cs / ms / 1e6 / 8000:.3f} of 8 TB/s, kernel {kern}, blocks {j.blks.size}", flush=True)
         for e in engines: e.close()
