@@ -81,7 +81,9 @@ class gc_track_job(C.Structure):
 class gc_acq_params(C.Structure):
     _fields_ = [("sampling_freq", C.c_double), ("code_freq_basis", C.c_double), ("code_length", C.c_double),
                 ("intermediate_freq", C.c_double), ("search_band", C.c_double), ("search_step", C.c_double),
-                ("non_coh_time", C.c_int32), ("source", C.c_int32), ("first_sample", C.c_int64)]
+                ("non_coh_time", C.c_int32), ("source", C.c_int32), ("first_sample", C.c_int64),
+                ("block_len", C.c_int32), ("code_samples", C.c_int32), ("n_bins", C.c_int32), ("reserved", C.c_int32),
+                ("arm_weight", C.c_double * 4)]
 
 
 class gc_fine_params(C.Structure):

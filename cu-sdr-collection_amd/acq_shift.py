@@ -185,6 +185,61 @@ def _b1c_table(code: np.ndarray, settings, spc: int) -> np.ndarray:
                     int(settings.codeLength) * 2, first_one=True)
 
 
+def _acquisition_B1C_conditioned(engine, original, first_sample: int, n_long: int | None):
+    """BDS/B1C/include/acquisition.m with settings.resamplingflag: the conditioning block (:50-122: BW = 9 MHz, band edges
+    widened by 0.002) runs first and every length below follows the new rate, so the (10 + acqCohT)-ms transform is no longer a
+    size the radix plan takes.  The search then runs carrier by carrier (gc_acq_params.block_len / code_samples / n_bins /
+    arm_weight): circshift(IQfreqDom, k) is the carrier moved by k*fs/N, and the N-point circular correlation with the replica's
+    samplesXmsLen samples is the linear one of the block followed by a repeat of its first samplesXmsLen samples.  Fine stage,
+    sigPower and the end-of-record rule as in acquisition_B1C; code phase and frequency mapped back as :280-296."""
+    import copy
+    if n_long is None:
+        n_long = int(engine.if_buffer()[1]) - int(first_sample)
+    new_fs, new_if, n_cond = engine.acq_condition(original.samplingFreq, original.IF, 9e6, first_sample, n_long, band_margin=0.002)   # :61-69
+    settings = copy.copy(original)
+    settings.samplingFreq, settings.IF = new_fs, new_if
+    fs = new_fs
+    spc = _round(fs / (settings.codeFreqBasis / settings.codeLength))
+    xlen = _round(spc / 10 * settings.acqCohT)
+    n = _round(spc / 10 * (10 + settings.acqCohT))
+    nbins = _round(settings.acqSearchBand * 2 / settings.acqStep) + 1
+    pilot = getattr(settings, "pilotACQflag", 0) == 1
+    fine_step = 25
+    nfine = _round(settings.acqStep / 25) * 2 + 1
+    init_freq = settings.IF + settings.acqSearchBand
+    # search_step: one position of circshift (:170-176); selFreq below is labelled with acqStep like the reference's
+    p = L.gc_acq_params(sampling_freq=fs, code_freq_basis=settings.codeFreqBasis, code_length=settings.codeLength, intermediate_freq=settings.IF,
+                        search_band=settings.acqSearchBand, search_step=fs / n, non_coh_time=1, source=1, first_sample=0)
+    p.block_len, p.code_samples, p.n_bins = n, xlen, nbins
+    if pilot:
+        p.arm_weight[0], p.arm_weight[1] = math.sqrt(11) / math.sqrt(40), math.sqrt(29) / math.sqrt(40)   # :186-187
+    nmax = max(settings.acqSatelliteList)
+    acq = SimpleNamespace(carrFreq=np.zeros(nmax), codePhase=np.zeros(nmax), peakMetric=np.zeros(nmax))
+    prns = list(settings.acqSatelliteList)
+    dtabs = {prn: _b1c_table(codes.generateDataBOC11(prn), settings, spc) for prn in prns}
+    ptabs = {prn: _b1c_table(codes.generatePilotBOC11(prn), settings, spc) for prn in prns} if pilot else {}
+    tables = np.stack([np.stack([dtabs[prn][:xlen]] + ([ptabs[prn][:xlen]] if pilot else [])) for prn in prns])      # [nprn, narms, xlen]
+    res = engine.acquire_coarse(p, tables)
+    for prn, r in zip(prns, res):
+        sel_freq = init_freq - (r.coarse_bin - 1) * settings.acqStep               # :194
+        code_phase = int(r.code_phase)
+        acq.peakMetric[prn - 1] = r.peak_metric                                    # :199 (sigPower over samplesXmsLen samples, one hop)
+        if code_phase + spc - 1 > n_cond:                                          # :232-234
+            code_phase -= spc
+        if acq.peakMetric[prn - 1] > settings.acqThreshold:
+            fp = L.gc_fine_params(sampling_freq=fs, code_freq=0.0, f0=sel_freq + settings.acqStep, fstep=float(fine_step),
+                                  first_sample=code_phase - 1, spc=spc, ncodes=1, nbins=nfine, code_len=spc, index_offset=0, source=1)
+            tabs = np.stack([dtabs[prn], ptabs[prn]]) if pilot else dtabs[prn][None, :]
+            s = np.abs(engine.acquire_fine_sums_batch(fp, tabs, np.full(len(tabs), fp.first_sample), np.full(len(tabs), fp.f0))[:, :, 0])
+            fine = (s[0] * 11 + s[1] * 29) / 40 if pilot else s[0]
+            f = float(fp.f0 - fine_step * int(np.argmax(fine)))
+            f = f if f != 0 else 1                                                 # :253-255
+            acq.codePhase[prn - 1] = math.floor((code_phase - 1) / fs * original.samplingFreq) + 1          # :280-284
+            doppler = (fs - settings.IF) - f if settings.IF >= fs / 2 else f - settings.IF                  # :288-294
+            acq.carrFreq[prn - 1] = doppler + original.IF                                                    # :296
+    return acq
+
+
 def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: int | None = None):
     """acqResults = acquisition(longSignal, settings) of BDS/B1C/include/acquisition.m (resampling off): one
     (10 + acqCohT)-ms spectrum, Doppler bins as circular shifts, data and pilot BOC(1,1) replicas combined
@@ -192,6 +247,8 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
     n_long = length(longSignal) (the reference pulls the code phase back by one period if too close to its end)."""
     if first_sample is None:
         first_sample = skip_samples(settings)
+    if settings.samplingFreq > settings.resamplingThreshold and getattr(settings, "resamplingflag", 0) == 1:
+        return _acquisition_B1C_conditioned(engine, settings, first_sample, n_long)
     fs = settings.samplingFreq
     spc = _round(fs / (settings.codeFreqBasis / settings.codeLength))              # :108-109
     xlen = _round(spc / 10 * settings.acqCohT)                                      # :111 samplesXmsLen

@@ -1161,6 +1161,7 @@ struct AcqScratch {
   float* partial = nullptr;   // hop-group sums of the last inverse pass (launch_pass)
   size_t partial_cap = 0;
   int8_t* codes = nullptr;    // nprn * spc
+  size_t codes_cap = 0;
   long long* sums = nullptr;  // 3 + scratch for argmax
   long long nbh = 0;
   int nprn = 0, nbins = 0;
@@ -1228,7 +1229,7 @@ void gc_acq_free(gc_context* ctx) {
 
 static int ensure_scratch(gc_context* ctx, int n, long long nbh, int nprn, int nbins, int spc, AcqScratch** out) {
   AcqScratch* s = (AcqScratch*)ctx->acq_scratch;
-  if (s && s->n == n && s->nbh >= nbh && s->nprn >= nprn && s->nbins >= nbins) {
+  if (s && s->n == n && s->nbh >= nbh && s->nprn >= nprn && s->nbins >= nbins && s->codes_cap >= (size_t)nprn * spc) {
     *out = s;
     return GC_OK;
   }
@@ -1246,13 +1247,14 @@ static int ensure_scratch(gc_context* ctx, int n, long long nbh, int nprn, int n
   s->nbh = nbh;
   s->nprn = nprn;
   s->nbins = nbins;
+  s->codes_cap = (size_t)nprn * (size_t)std::max(spc, n);
   const size_t ne = (size_t)n;
   if (hipMalloc((void**)&s->tw, ne * sizeof(float2)) != hipSuccess ||
       hipMalloc((void**)&s->sig, (size_t)nbh * ne * sizeof(float2)) != hipSuccess ||
       hipMalloc((void**)&s->tmp, (size_t)nbh * ne * sizeof(float2)) != hipSuccess ||
       hipMalloc((void**)&s->codespec, (size_t)nprn * ne * sizeof(float2)) != hipSuccess ||
       hipMalloc((void**)&s->results, (size_t)nbins * ne * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&s->codes, (size_t)nprn * spc) != hipSuccess ||
+      hipMalloc((void**)&s->codes, (size_t)nprn * (size_t)std::max(spc, n)) != hipSuccess ||
       hipMalloc((void**)&s->sums, 16 * sizeof(long long)) != hipSuccess) {
     free_scratch(s);
     gc_set_error("acquisition: device allocation failed");
@@ -1334,39 +1336,46 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   GC_HIP(hipSetDevice(ctx->device));
   const double x = p->sampling_freq / (p->code_freq_basis / p->code_length);
   const int spc = (int)std::floor(x + 0.5);                                     // acquisition.m:116
-  const int nbins = (int)std::floor(p->search_band * 2 / p->search_step + 0.5) + 1;  // :124
+  const int nbins = p->n_bins > 0 ? p->n_bins : (int)std::floor(p->search_band * 2 / p->search_step + 0.5) + 1;  // :124
   const int H = p->non_coh_time;
   if (spc <= 0 || nbins <= 0 || H <= 0 || p->first_sample < 0) return GC_E_INVALID;
+  // block and replica lengths: 2*spc and spc in the L1 C/A family; len10PlusXms and samplesXmsLen for a B1C-type search
+  const int blk = p->block_len > 0 ? p->block_len : 2 * spc;
+  const int cl = p->code_samples > 0 ? p->code_samples : spc;
+  if ((p->block_len > 0 || p->code_samples > 0) && (H != 1 || cl > blk)) {
+    gc_set_error("gc_acquire_coarse: block_len / code_samples need non_coh_time == 1 and code_samples <= block_len");
+    return GC_E_INVALID;
+  }
   // The reference transforms 2*spc points (one code period + one of zeros).  Where the radix-{2..8} plan cannot take that
   // length (2*spc = 32 736 = 2^5*3*11*31 at the common 16.368-Msps front ends, 5 172 = 2^2*3*431 after the A0 resampling),
   // the circular correlation is computed inside a longer transform instead: the 2*spc mixed samples followed by a repeat
   // of their first spc and zeros up to the next size M >= 3*spc the plan takes - for the code of spc samples the first
   // 2*spc lags of that M-point circular correlation ARE the reference's 2*spc-point one, term by term.
-  int n = 2 * spc;
+  int n = blk;
   bool padded = false;
   {
     Plan probe;
     if (!make_plan(n, &probe) || std::getenv("GC_ACQ_PAD")) {
       padded = true;
       n = 0;
-      for (int m = 3 * spc; m < 3 * spc + (1 << 20); ++m)
+      for (int m = blk + cl; m < blk + cl + (1 << 20); ++m)
         if (make_plan(m, &probe)) {
           n = m;
           break;
         }
       if (n == 0) {
-        gc_set_error("acquisition: no transform size at or above %d fits the plan", 3 * spc);
+        gc_set_error("acquisition: no transform size at or above %d fits the plan", blk + cl);
         return GC_E_UNSUPPORTED;
       }
     }
   }
-  if ((uint64_t)p->first_sample + (uint64_t)(H + 1) * spc > avail) {
-    gc_set_error("gc_acquire_coarse: needs %lld samples from %lld, buffer holds %llu", (long long)(H + 1) * spc,
+  if ((uint64_t)p->first_sample + (uint64_t)(H - 1) * spc + (uint64_t)blk > avail) {
+    gc_set_error("gc_acquire_coarse: needs %lld samples from %lld, buffer holds %llu", (long long)(H - 1) * spc + blk,
                  (long long)p->first_sample, (unsigned long long)avail);
     return GC_E_RANGE;
   }
   AcqScratch* s = nullptr;
-  int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn * narms, nbins, spc, &s);
+  int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn * narms, nbins, cl, &s);
   if (rc) return rc;
   s->shift.n = 0;  // the signal spectra of a circshift search, if any, are overwritten below
   const Plan& pl = s->plan;
@@ -1374,20 +1383,20 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   // sigPower = sqrt(var(x(1:spc)) * spc), var normalised by N-1 (acquisition.m:151)
   GC_HIP(hipMemsetAsync(s->sums, 0, 16 * sizeof(long long), ctx->stream));
   if (cond)
-    hipLaunchKernelGGL(sigpower_f32_kernel, dim3(1), dim3(1024), 0, ctx->stream, cond_sig, (long long)p->first_sample, spc, (double*)s->sums);
+    hipLaunchKernelGGL(sigpower_f32_kernel, dim3(1), dim3(1024), 0, ctx->stream, cond_sig, (long long)p->first_sample, cl, (double*)s->sums);
   else
     hipLaunchKernelGGL(sigpower_kernel, dim3(64), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if, (long long)p->first_sample,
-                       spc, s->sums);
+                       cl, s->sums);
   long long hs[3];
   GC_HIP(hipMemcpyAsync(hs, s->sums, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
-  GC_HIP(hipMemcpyAsync(s->codes, sampled_codes, (size_t)nprn * narms * spc, hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipMemcpyAsync(s->codes, sampled_codes, (size_t)nprn * narms * cl, hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
   double sum3[3];
   if (cond) std::memcpy(sum3, hs, sizeof sum3);  // the float kernel wrote doubles
   else for (int k = 0; k < 3; ++k) sum3[k] = (double)hs[k];
-  const double mr = sum3[0] / spc, mi = sum3[1] / spc;
-  const double var = (sum3[2] - spc * (mr * mr + mi * mi)) / (spc - 1);
-  const double sig_power = std::sqrt(var * spc);
+  const double mr = sum3[0] / cl, mi = sum3[1] / cl;
+  const double var = (sum3[2] - cl * (mr * mr + mi * mi)) / (cl - 1);
+  const double sig_power = std::sqrt(var * cl);
 
   // signal spectra for every (bin, hop)
   PassArgs base;
@@ -1395,7 +1404,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   base.if_base = (const int8_t*)ctx->d_if;
   base.if_f32 = cond_sig;
   base.first_sample = p->first_sample;
-  base.spc = spc;
+  base.spc = (p->block_len > 0 || p->code_samples > 0) ? cl : spc;  // hop stride and replica length coincide in the L1 C/A family; one hop otherwise
   base.nhops = H;
   base.f0 = p->intermediate_freq + p->search_band;  // coarseFreqBin(1), :169
   base.fstep = p->search_step;
@@ -1408,7 +1417,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   const long long q = (long long)std::floor(qd + 0.5);
   const bool shifted = !padded && q >= 1 && std::fabs(qd - (double)q) <= 1e-12 * qd && (long long)(nbins - 1) * q < n &&
                        std::getenv("GC_ACQ_NO_SHIFT") == nullptr;
-  base.wrap_len = padded ? 2 * spc : 0;
+  base.wrap_len = padded ? blk : 0;
   rc = forward(ctx, s, base, PRE_IF_CARRIER, shifted ? (long long)H : (long long)nbins * H, s->sig);
   if (rc) return rc;
   // code spectra (conj applied at the product)
@@ -1462,7 +1471,8 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.in = s->tmp;
       a.acc_out = s->results;
       a.acc_add = arm > 0;
-      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr, 2 * spc);
+      a.acc_scale = (float)p->arm_weight[arm];  // 0: 1
+      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr, blk);
       if (rc) return rc;
     }
   }

@@ -70,6 +70,7 @@ static void free_if(gc_context* ctx) {
   ctx->if_owned = false;
   ctx->if_nsamples = 0;
   ctx->if_capacity_bytes = 0;
+  ctx->acq_cond_n = 0;  // a conditioned signal (gc_acq_condition) belongs to the record it was made from
 }
 
 int gc_destroy(gc_context* ctx) {

@@ -309,6 +309,17 @@ typedef struct gc_acq_params {
   int32_t non_coh_time;      /* settings.acqNonCohTime */
   int32_t source;            /* 0: the IF record (int8 I/Q); GC_ACQ_SOURCE_CONDITIONED: the signal gc_acq_condition left */
   int64_t first_sample;      /* start of longSignal within the IF buffer (or within the conditioned signal) */
+  /* API version 3, all optional (0 = the GPS L1 C/A scheme above).  They let the search family whose bins are circular shifts
+   * of ONE spectrum (BDS/B1C/include/acquisition.m:137-200) run as a carrier-per-bin search when its transform length cannot be
+   * taken by the radix plan - after the input conditioning, where samplesPerCode follows ceil(newFs): circshift(X, k) is the
+   * carrier moved by k*fs/N, and the N-point circular correlation with a replica of code_samples samples is the linear one of
+   * the block followed by a repeat of its first code_samples samples. */
+  int32_t block_len;         /* samples per search block (len10PlusXms, B1C :113); 0: 2*samplesPerCode (acquisition.m:174) */
+  int32_t code_samples;      /* samples of each sampled-code row, zeros beyond (samplesXmsLen, B1C :111); 0: samplesPerCode.
+                                sigPower is taken over that many samples (B1C :138).  Needs non_coh_time == 1 when set. */
+  int32_t n_bins;            /* number of frequency bins; 0: round(2*search_band/search_step) + 1 (acquisition.m:124) */
+  int32_t reserved;
+  double arm_weight[4];      /* results = sum_arm arm_weight * |ifft(...)| (B1C :186-187: sqrt(11/40), sqrt(29/40)); all 0: 1 */
 } gc_acq_params;
 #define GC_ACQ_SOURCE_CONDITIONED 1
 

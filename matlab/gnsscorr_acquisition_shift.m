@@ -20,7 +20,12 @@ nLong = numel(longSignal);
 switch name
     case 'BDS_B1I', acqResults = b1i(h, settings);
     case 'GPS_L2C', acqResults = l2c(h, settings);
-    case 'BDS_B1C', acqResults = b1c(h, settings, nLong);
+    case 'BDS_B1C'
+        if settings.samplingFreq > settings.resamplingThreshold && settings.resamplingflag == 1
+            acqResults = b1cConditioned(h, settings, nLong);
+        else
+            acqResults = b1c(h, settings, nLong);
+        end
     otherwise, error('gnsscorr:acquisition', 'package %s is not served by this wrapper', name);
 end
 end
@@ -170,6 +175,68 @@ for PRN = settings.acqSatelliteList
             [~, seg] = max(power);
             acqResults.CLCodePhase(PRN) = seg;                                              % :165 (the field grows to the highest PRN found)
         end
+    end
+end
+end
+
+%---------------------------------------------------------------------------------------------------------------------------
+function acqResults = b1cConditioned(h, settings, nLong)
+% BDS/B1C/include/acquisition.m with settings.resamplingflag: the conditioning block (:50-122, BW = 9 MHz, band edges widened by
+% 0.002) runs on the GPU and every length follows the new rate, so the (10 + acqCohT)-ms transform is no longer a size the
+% transforms take.  The search runs carrier by carrier instead ('acquire_coarse_multi' with blockLen / codeSamples / nBins /
+% armWeight): circshift(IQfreqDom, k) is the carrier moved by k*fs/N, and the N-point circular correlation with the replica's
+% samplesXmsLen samples is the linear one of the block followed by a repeat of its first samplesXmsLen samples.
+c.samplingFreq = settings.samplingFreq;  c.IF = settings.IF;  c.bandwidth = 9e6;  c.bandMargin = 0.002;     % :61-67
+c.firstSample = 0;  c.nSamples = nLong;
+oldFreq = settings.samplingFreq;  oldIF = settings.IF;
+[settings.samplingFreq, settings.IF, nCond] = gnsscorr_mex('acq_condition', h, c);
+fs = settings.samplingFreq;  ts = 1 / fs;
+spc = round(fs / (settings.codeFreqBasis / settings.codeLength));
+xLen = round(spc / 10 * settings.acqCohT);
+n = round(spc / 10 * (10 + settings.acqCohT));
+nBins = round(settings.acqSearchBand * 2 / settings.acqStep) + 1;
+pilot = settings.pilotACQflag == 1;
+fineStep = 25;  nFine = round(settings.acqStep / 25) * 2 + 1;
+initFreq = settings.IF + settings.acqSearchBand;
+a = struct('samplingFreq', fs, 'codeFreqBasis', settings.codeFreqBasis, 'codeLength', settings.codeLength, 'IF', settings.IF, ...
+           'acqSearchBand', settings.acqSearchBand, 'acqSearchStep', fs / n, 'acqNonCohTime', 1, 'firstSample', 0, 'source', 1, ...
+           'blockLen', n, 'codeSamples', xLen, 'nBins', nBins);
+narms = 1;
+if pilot, a.armWeight = [sqrt(11) / sqrt(40), sqrt(29) / sqrt(40)];  narms = 2; end            % :186-187
+nMax = max(settings.acqSatelliteList);
+acqResults.carrFreq = zeros(1, nMax);  acqResults.codePhase = zeros(1, nMax);  acqResults.peakMetric = zeros(1, nMax);
+tc = 1 / settings.codeFreqBasis / 2;
+for PRN = settings.acqSatelliteList
+    dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);
+    tabs = dtab(1:xLen).';
+    if pilot
+        ptab = sampled(generatePilotBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);
+        tabs = [tabs, ptab(1:xLen).'];
+    end
+    r = gnsscorr_mex('acquire_coarse_multi', h, a, int8(tabs), narms);                      % rows: bin, codePhase, peak, metric, freq
+    selFreq = initFreq - (r(1) - 1) * settings.acqStep;                                     % :194
+    codePhase = r(2);
+    acqResults.peakMetric(PRN) = r(4);                                                      % :199
+    if codePhase + spc - 1 > nCond, codePhase = codePhase - spc; end                        % :232-234
+    if acqResults.peakMetric(PRN) > settings.acqThreshold
+        full = dtab(:);
+        if pilot, full = [dtab(:), ptab(:)]; end
+        q3 = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', selFreq + settings.acqStep, 'fstep', fineStep, 'firstSample', codePhase - 1, ...
+                    'samplesPerCode', spc, 'ncodes', 1, 'nbins', nFine, 'codeLength', spc, 'indexOffset', 0, 'source', 1);
+        s = gnsscorr_mex('fine_sums', h, q3, int8(full));
+        s = abs(s(1, :) + 1i * s(2, :));
+        fine = s(1:nFine);
+        if pilot, fine = (s(1:nFine) * 11 + s(nFine + 1:2 * nFine) * 29) / 40; end
+        [~, m] = max(fine);
+        carr = q3.f0 - fineStep * (m - 1);
+        if carr == 0, carr = 1; end                                                         % :253-255
+        acqResults.codePhase(PRN) = floor((codePhase - 1) / fs * oldFreq) + 1;              % :280-284
+        if settings.IF >= fs / 2
+            doppler = (fs - settings.IF) - carr;
+        else
+            doppler = carr - settings.IF;
+        end
+        acqResults.carrFreq(PRN) = doppler + oldIF;                                         % :296
     end
 end
 end

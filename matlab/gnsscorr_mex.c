@@ -74,6 +74,14 @@ static void fill_acq(const mxArray* s, gc_acq_params* p) {
   p->non_coh_time = (int32_t)field(s, "acqNonCohTime");
   p->first_sample = (int64_t)field(s, "firstSample");
   p->source = mxGetField(s, 0, "source") ? (int32_t)field(s, "source") : 0; /* 1: the signal 'acq_condition' left on the device */
+  /* optional: a B1C-type search as a carrier-per-bin search (gc_acq_params.block_len ...) */
+  if (mxGetField(s, 0, "blockLen")) p->block_len = (int32_t)field(s, "blockLen");
+  if (mxGetField(s, 0, "codeSamples")) p->code_samples = (int32_t)field(s, "codeSamples");
+  if (mxGetField(s, 0, "nBins")) p->n_bins = (int32_t)field(s, "nBins");
+  if (mxGetField(s, 0, "armWeight")) {
+    const mxArray* w = mxGetField(s, 0, "armWeight");
+    for (mwSize i = 0; i < mxGetNumberOfElements(w) && i < 4; ++i) p->arm_weight[i] = mxGetDoubles(w)[i];
+  }
 }
 
 /* gc_track_params from the struct gnsscorr_tracking.m builds (settings fields + the per-package extras) */

@@ -455,6 +455,11 @@ ACQ_SCENES = [
              fields=("carrFreq", "codePhase", "peakMetric", "CLCodePhase")),
     AcqScene("BDS_B1C", "BDS/B1C", "initSettings_BDS_B1C", dict(acqSearchBand=1000, acqSatelliteList=[8, 20]), _acq_b1c_record,
              product=lambda P, eng, S: P.acq_shift.acquisition_B1C(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_b1c(rec, S, 0)),
+    # BDS B1C with its conditioning block (BW = 9 MHz, band edges widened by 0.002): 30 Msps / IF 6.5 MHz -> 22 Msps, where the
+    # 20-ms transform is 440 000 = 2^6*5^4*11 points - no size for the radix plan: the bins run carrier by carrier on the padded transform
+    AcqScene("BDS_B1C_resampled", "BDS/B1C", "initSettings_BDS_B1C",
+             dict(acqSearchBand=500, acqSatelliteList=[8, 20], samplingFreq=30e6, IF=6.5e6, resamplingflag=1), _acq_b1c_record,
+             product=lambda P, eng, S: P.acq_shift.acquisition_B1C(eng, S, first_sample=0), oracle=None, metric_rtol=2e-3),
 ]
 
 

@@ -136,7 +136,7 @@ def test_matlab_drop_in_reproduces_the_references_tracking_m(gateway, sc, tmp_pa
             assert float(t.PRN) == float(z["PRN"][k])
 
 
-_ACQ_WRAPPED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "BDS_B2a", "GAL_E5b", "BDS_B3I", "GAL_E1C", "GLO_GL1", "GLO_GL2", "BDS_B1I", "GPS_L2C", "BDS_B1C", "GPS_L1CA_resampled", "GPS_L5C_resampled", "GAL_E5b_resampled", "GLO_GL1_resampled", "BDS_B3I_resampled", "GAL_E1C_resampled")
+_ACQ_WRAPPED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "BDS_B2a", "GAL_E5b", "BDS_B3I", "GAL_E1C", "GLO_GL1", "GLO_GL2", "BDS_B1I", "GPS_L2C", "BDS_B1C", "GPS_L1CA_resampled", "GPS_L5C_resampled", "GAL_E5b_resampled", "GLO_GL1_resampled", "BDS_B3I_resampled", "GAL_E1C_resampled", "BDS_B1C_resampled")
 
 
 @pytest.mark.parametrize("sc", [s for s in RS.ACQ_SCENES if s.name in _ACQ_WRAPPED], ids=[s.name for s in RS.ACQ_SCENES if s.name in _ACQ_WRAPPED])
