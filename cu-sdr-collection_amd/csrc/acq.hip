@@ -1053,10 +1053,10 @@ __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict_
 }
 
 // One workgroup per row: maximum and its first position (MATLAB's max returns the first maximum).
-__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r, int ncols, float* vmax, int* amax) {
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r, int ncols, int stride, float* vmax, int* amax) {
   __shared__ float sv[256];
   __shared__ int si[256];
-  const float* row = r + (long long)blockIdx.x * ncols;
+  const float* row = r + (long long)blockIdx.x * stride;
   float best = -1.0f;
   int bi = 0x7fffffff;
   for (int i = threadIdx.x; i < ncols; i += 256) {
@@ -1167,6 +1167,7 @@ struct AcqScratch {
   int nprn = 0, nbins = 0;
   // circshift search family (gc_acq_shift_*)
   gc_acq_shift_params shift;  // what `sig` currently holds (n == 0: nothing)
+  bool shift_padded = false;  // the block length is no size for the plan: every row has its own carrier, transforms of s->n >= 2*shift.n points
   float* rowmax = nullptr;
   int* rowarg = nullptr;
   int shift_rows = 0;
@@ -1723,8 +1724,30 @@ extern "C" int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* 
   }
   GC_HIP(hipSetDevice(ctx->device));
   const int rows = p->n_carriers * p->n_signals * p->n_bins;
+  // A block length the radix plan cannot take (16.368-Msps front ends: 2*16 368*... has the factors 11 and 31): the shifted
+  // product needs a transform of exactly n points, so every row gets its own carrier instead - circshift(X, b) is the
+  // carrier moved down by b*fs/n - and the n-point circular correlation is read off a transform of M >= 2n points fed
+  // with the block twice and zeros (for a replica that ends inside the block the first n lags are the same sums).
+  int m = p->n;
+  bool padded = false;
+  {
+    Plan probe;
+    if (!make_plan(m, &probe) || std::getenv("GC_ACQ_PAD")) {
+      padded = true;
+      m = 0;
+      for (int c = 2 * p->n; c < 2 * p->n + (1 << 20); ++c)
+        if (make_plan(c, &probe)) {
+          m = c;
+          break;
+        }
+      if (m == 0) {
+        gc_set_error("gc_acq_shift_prepare: no transform size at or above %d fits the plan", 2 * p->n);
+        return GC_E_UNSUPPORTED;
+      }
+    }
+  }
   AcqScratch* s = nullptr;
-  int rc = ensure_scratch(ctx, p->n, rows, p->n_arms_max, rows, p->n, &s);
+  int rc = ensure_scratch(ctx, m, rows, p->n_arms_max, rows, p->n, &s);
   if (rc) return rc;
   if (s->shift_rows < rows) {
     if (s->rowmax) (void)hipFree(s->rowmax);
@@ -1747,16 +1770,36 @@ extern "C" int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* 
   base.f0 = p->carrier_f0;
   base.fstep = -p->carrier_step;  // kernel: f_b = f0 - fstep*b
   base.fs = p->sampling_freq;
-  rc = forward(ctx, s, base, PRE_IF_CARRIER, (long long)p->n_carriers * p->n_signals, s->sig);
-  if (rc) return rc;
+  s->shift.n = 0;
+  if (!padded) {
+    rc = forward(ctx, s, base, PRE_IF_CARRIER, (long long)p->n_carriers * p->n_signals, s->sig);
+    if (rc) return rc;
+  } else {
+    // internal row order: ((carrier * n_bins + bin) * n_signals + signal)
+    base.wrap_len = p->n;
+    base.fstep = p->sampling_freq / (double)p->n;  // one position of circshift
+    for (int i = 0; i < p->n_carriers; ++i) {
+      base.f0 = p->carrier_f0 + p->carrier_step * i;
+      rc = forward(ctx, s, base, PRE_IF_CARRIER, (long long)p->n_bins * p->n_signals,
+                   s->sig + (size_t)i * p->n_bins * p->n_signals * (size_t)m);
+      if (rc) return rc;
+    }
+  }
   s->shift = *p;
+  s->shift_padded = padded;
   return GC_OK;
+}
+
+// public row ((carrier * n_signals + signal) * n_bins + bin) -> row of the padded mode's internal order
+static int shift_internal_row(const gc_acq_shift_params& p, int row) {
+  const int bin = row % p.n_bins, cs = row / p.n_bins, signal = cs % p.n_signals, carrier = cs / p.n_signals;
+  return (carrier * p.n_bins + bin) * p.n_signals + signal;
 }
 
 extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
                                    float* row_max, int32_t* row_argmax) {
   AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
-  if (!s || s->shift.n <= 0 || s->shift.n != s->n) {
+  if (!s || s->shift.n <= 0 || (s->shift_padded ? s->n < 2 * s->shift.n : s->shift.n != s->n)) {
     gc_set_error("gc_acq_shift_search: call gc_acq_shift_prepare first");
     return GC_E_STATE;
   }
@@ -1793,7 +1836,7 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.other = s->codespec + (size_t)arm * pl.n;
     a.out = s->tmp;
     a.out_batch_stride = pl.n;
-    a.shift_bins = p.n_bins;
+    a.shift_bins = s->shift_padded ? 0 : p.n_bins;  // padded: every row is a spectrum of its own
     a.n1 = pl.n1;
     a.n2 = pl.n2;
     rc = launch_pass(ctx, a, rows);
@@ -1813,11 +1856,23 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     rc = launch_abs_pass(ctx, s, a, rows);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(rowmax_kernel, dim3(rows), dim3(256), 0, ctx->stream, s->results, p.n, s->rowmax, s->rowarg);
+  hipLaunchKernelGGL(rowmax_kernel, dim3(rows), dim3(256), 0, ctx->stream, s->results, p.n, pl.n, s->rowmax, s->rowarg);
   GC_HIP(hipGetLastError());
-  GC_HIP(hipMemcpyAsync(row_max, s->rowmax, sizeof(float) * rows, hipMemcpyDeviceToHost, ctx->stream));
-  GC_HIP(hipMemcpyAsync(row_argmax, s->rowarg, sizeof(int) * rows, hipMemcpyDeviceToHost, ctx->stream));
+  if (!s->shift_padded) {
+    GC_HIP(hipMemcpyAsync(row_max, s->rowmax, sizeof(float) * rows, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipMemcpyAsync(row_argmax, s->rowarg, sizeof(int) * rows, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+  }
+  std::vector<float> hv((size_t)rows);
+  std::vector<int> ha((size_t)rows);
+  GC_HIP(hipMemcpyAsync(hv.data(), s->rowmax, sizeof(float) * rows, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipMemcpyAsync(ha.data(), s->rowarg, sizeof(int) * rows, hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
+  for (int r = 0; r < rows; ++r) {
+    row_max[r] = hv[(size_t)shift_internal_row(p, r)];
+    row_argmax[r] = ha[(size_t)shift_internal_row(p, r)];
+  }
   return GC_OK;
 }
 
@@ -1828,7 +1883,8 @@ extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
     return GC_E_INVALID;
   }
   GC_HIP(hipSetDevice(ctx->device));
-  GC_HIP(hipMemcpyAsync(out, s->results + (size_t)row * s->shift.n, sizeof(float) * s->shift.n, hipMemcpyDeviceToHost, ctx->stream));
+  const size_t at = s->shift_padded ? (size_t)shift_internal_row(s->shift, row) * (size_t)s->n : (size_t)row * s->shift.n;
+  GC_HIP(hipMemcpyAsync(out, s->results + at, sizeof(float) * s->shift.n, hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
   return GC_OK;
 }

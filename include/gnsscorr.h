@@ -422,7 +422,8 @@ typedef struct gc_acq_shift_params {
   double carrier_f0;         /* first wipe-off carrier in Hz: initFreq */
   double carrier_step;       /* carrier i = carrier_f0 + i*carrier_step (B1I: +freqResolution/Nshifts, L2C: minus) */
   int64_t first_sample;      /* signal block k starts at first_sample + k*n */
-  int32_t n;                 /* samplesPerBlock = transform length (2^a 3^b 5^c) */
+  int32_t n;                 /* samplesPerBlock = the reference's transform length; any value: lengths other than 2^a 3^b 5^c run one
+                                carrier per row on a longer transform, same rows and results */
   int32_t n_signals;         /* consecutive signal blocks (B1I: signal1, signal2) */
   int32_t n_carriers;        /* Nshifts */
   int32_t n_bins;            /* numberOfFrqBins: circshift(IQfreqDom, bin), bin = 0 .. n_bins-1 */
