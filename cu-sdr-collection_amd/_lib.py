@@ -96,7 +96,7 @@ class gc_fine_params(C.Structure):
 class gc_acq_shift_params(C.Structure):
     _fields_ = [("sampling_freq", C.c_double), ("carrier_f0", C.c_double), ("carrier_step", C.c_double),
                 ("first_sample", C.c_int64), ("n", C.c_int32), ("n_signals", C.c_int32), ("n_carriers", C.c_int32),
-                ("n_bins", C.c_int32), ("n_arms_max", C.c_int32), ("reserved", C.c_int32)]
+                ("n_bins", C.c_int32), ("n_arms_max", C.c_int32), ("source", C.c_int32)]
 
 
 class gc_acq_result(C.Structure):
@@ -151,6 +151,9 @@ SYMBOLS = {
     "gc_acq_conditioned": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_float)]),
     "gc_acquire_fine_l1ca_batch": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(C.c_int32),
                                              C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gc_if_format": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gc_acq_signal_from_record": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "gc_acq_set_signal": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int64]),
     "gc_acq_signal_stats": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double)]),
     "gc_acquire_fine_sums_batch": (C.c_int, [_P, C.POINTER(gc_fine_params), C.c_int, _P, C.POINTER(C.c_int64),

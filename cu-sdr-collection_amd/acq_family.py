@@ -75,10 +75,13 @@ def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, 
         settings = copy.copy(settings)
         settings.samplingFreq, settings.IF = new_fs, new_if
         first_sample = 0
+    src = 1
+    if not resampled:
+        src, first_sample, _ = engine.acq_input(first_sample, settings.samplingFreq, n_long)    # int16 / Q-I / real records: float copy
     prns = list(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(n_results), codePhase=np.zeros(n_results), peakMetric=np.zeros(n_results))
     p = _acq_params(settings, first_sample)
-    p.source = 1 if resampled else 0
+    p.source = src
     table_fn = table_fn or make_table
     tables = np.stack([np.stack([table_fn(c, settings) for c in coarse_codes(prn)]) for prn in prns])   # [nprn, narms, spc]
     res = engine.acquire_coarse(p, tables)
@@ -95,7 +98,7 @@ def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, 
                                   f0=r.coarse_freq + settings.acqSearchStep / 2, fstep=fine_step,
                                   first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=ncodes, nbins=nfine,
                                   code_len=int(fine_code_len or settings.codeLength), index_offset=index_offset,
-                                  source=1 if resampled else 0)
+                                  source=src)
             sums = [engine.acquire_fine_sums(fp, c) for c in fine_codes(prn)]       # each [nfine, ncodes]
             fine = np.array([combine(prn, [s[k] for s in sums]) for k in range(nfine)])
             f = fp.f0 - fine_step * int(np.argmax(fine))
@@ -243,7 +246,9 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None, n_long: i
         settings = copy.copy(settings)
         settings.samplingFreq, settings.IF = new_fs, new_if
         first_sample = 0
-    src = 1 if resampled else 0
+    src = 1
+    if not resampled:
+        src, first_sample, _ = engine.acq_input(first_sample, settings.samplingFreq, n_long)
     spc = _round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength))
     acq = SimpleNamespace(carrFreq=np.zeros(21), codePhase=np.zeros(21), peakMetric=np.zeros(21))
     table = glonass_sampled_code(settings.samplingFreq, spc)[None, :]

@@ -63,6 +63,7 @@ def acquisition_B1I(engine, settings, first_sample: int | None = None):
     """acqResults = acquisition(longSignal, settings) of BDS/B1I/include/acquisition.m (resampling off)."""
     if first_sample is None:
         first_sample = skip_samples(settings)
+    src, first_sample, _ = engine.acq_input(first_sample, settings.samplingFreq)   # int16 / Q-I / real records: float copy on the device
     ncodes, nblocks = 2, 4                                                         # :34-35
     fs = settings.samplingFreq
     spb = _round(fs / (settings.codeFreqBasis / (nblocks * settings.codeLength)))  # :36-37 samplesPerBlock
@@ -74,7 +75,7 @@ def acquisition_B1I(engine, settings, first_sample: int | None = None):
     spc2 = _round(fs / (settings.codeFreqBasis / (ncodes * settings.codeLength)))  # makeCaTableDMA.m
     init_freq = settings.IF + (settings.acqSearchBand / 2) * 1000                  # :66
     p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=init_freq, carrier_step=freq_res / nshifts, first_sample=first_sample,
-                              n=spb, n_signals=2, n_carriers=nshifts, n_bins=nbins, n_arms_max=1)
+                              n=spb, n_signals=2, n_carriers=nshifts, n_bins=nbins, n_arms_max=1, source=src)
     engine.acq_shift_prepare(p)
     acq = SimpleNamespace(carrFreq=np.zeros(58), codePhase=np.zeros(58), peakMetric=np.zeros(58))
     chip = _round(fs / settings.codeFreqBasis)                                     # :139
@@ -117,6 +118,7 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
     40-ms block (Nblocks = 2), then — with pilotTRKflag — which of the 75 CL segments the CM period found lies in."""
     if first_sample is None:
         first_sample = skip_samples(settings)
+    src, first_sample, _ = engine.acq_input(first_sample, settings.samplingFreq)   # int16 / Q-I / real records: float copy on the device
     nblocks = 2                                                                    # :13
     fs = settings.samplingFreq
     spc = _round(fs / (settings.codeFreqBasis / settings.codeLength))              # :14-15
@@ -128,7 +130,7 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
     nshifts = int(freq_res / settings.acqStep)                                     # :25
     init_freq = settings.IF + (settings.acqSearchBand / 2) * 1000                  # :33
     p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=init_freq, carrier_step=-(freq_res / nshifts), first_sample=first_sample,
-                              n=spb, n_signals=1, n_carriers=nshifts, n_bins=nbins, n_arms_max=1)
+                              n=spb, n_signals=1, n_carriers=nshifts, n_bins=nbins, n_arms_max=1, source=src)
     engine.acq_shift_prepare(p)
     acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(0))
     tc = 1.0 / (settings.codeFreqBasis * 2)
@@ -160,14 +162,14 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
             if getattr(settings, "pilotTRKflag", 0) == 1:                          # :140-166, 75 short correlations
                 # sig - mean(sig), wiped with the carrier and with each of the 75 CL segments sampled like the CM table: one
                 # launch, the segments as 75 replicas of one entry per sample (gc_fine_params.code_freq = 0)
-                mean, _ = engine.acq_signal_stats(first_sample + code_phase - 1, spc)
+                mean, _ = engine.acq_signal_stats(first_sample + code_phase - 1, spc, source=src)
                 cl = codes.generateCLcode(prn, int(settings.CLCodeLength))
                 idx = np.ceil(ts * np.arange(spc) / tc).astype(np.int64)
                 idx[0] = 1
                 idx[-1] = int(settings.codeLength) * (1 if settings.acqCohT <= 10 else 2)
                 windows = np.stack([cl[idx - 1 + int(settings.codeLength) * 2 * ind] for ind in range(75)]).astype(np.int8)
                 fp = L.gc_fine_params(sampling_freq=fs, code_freq=0.0, f0=f, fstep=0.0, first_sample=first_sample + code_phase - 1, spc=spc,
-                                      ncodes=1, nbins=1, code_len=spc, index_offset=0, source=0, dc_re=mean.real, dc_im=mean.imag)
+                                      ncodes=1, nbins=1, code_len=spc, index_offset=0, source=src, dc_re=mean.real, dc_im=mean.imag)
                 power = np.abs(engine.acquire_fine_sums_batch(fp, windows, np.full(75, fp.first_sample), np.full(75, f))[:, 0, 0])
                 if acq.CLCodePhase.shape[0] < prn:       # the field is created by this assignment and grows with it (GPS_L2C acquisition.m:165):
                     acq.CLCodePhase = np.concatenate([acq.CLCodePhase, np.zeros(prn - acq.CLCodePhase.shape[0])])   # numel = highest PRN found
@@ -258,13 +260,14 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
     pilot = getattr(settings, "pilotACQflag", 0) == 1
     fine_step = 25                                                                 # :129
     nfine = _round(settings.acqStep / 25) * 2 + 1                                  # :130
+    src, first_sample, n_avail = engine.acq_input(first_sample, fs, n_long)         # int16 / Q-I / real records: float copy on the device
     if n_long is None:
-        n_long = int(engine.if_buffer()[1]) - first_sample
-    _, var = engine.acq_signal_stats(first_sample, xlen)                           # sigPower, :138
+        n_long = n_avail
+    _, var = engine.acq_signal_stats(first_sample, xlen, source=src)               # sigPower, :138
     sig_power = math.sqrt(var * xlen)
     init_freq = settings.IF + settings.acqSearchBand                               # :141
     p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=init_freq, carrier_step=0.0, first_sample=first_sample,
-                              n=n, n_signals=1, n_carriers=1, n_bins=nbins, n_arms_max=2)
+                              n=n, n_signals=1, n_carriers=1, n_bins=nbins, n_arms_max=2, source=src)
     engine.acq_shift_prepare(p)
     nmax = max(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(nmax), codePhase=np.zeros(nmax), peakMetric=np.zeros(nmax))
@@ -290,7 +293,7 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
             # here): the tables are replicas of one entry per sample (gc_fine_params.code_freq = 0), data and pilot in one launch
             fp = L.gc_fine_params(sampling_freq=fs, code_freq=0.0, f0=sel_freq + settings.acqStep, fstep=float(fine_step),
                                   first_sample=first_sample + code_phase - 1, spc=spc, ncodes=1, nbins=nfine, code_len=spc,
-                                  index_offset=0, source=0)
+                                  index_offset=0, source=src)
             tabs = np.stack([dtab, ptab]) if pilot else dtab[None, :]
             s = np.abs(engine.acquire_fine_sums_batch(fp, tabs, np.full(len(tabs), fp.first_sample), np.full(len(tabs), fp.f0))[:, :, 0])
             fine = (s[0] * 11 + s[1] * 29) / 40 if pilot else s[0]

@@ -904,10 +904,42 @@ __global__ __launch_bounds__(1024) void sigpower_f32_kernel(const float2* __rest
 // filtfilt(b, 1, x) = the signal extended by nfact odd-reflected samples at both ends, filtered forwards with the filter
 // starting in the steady state of the first extended sample (for an FIR filter: as if that sample had been there for
 // ever), reversed, filtered again the same way, reversed, the extensions dropped.
-__global__ void cond_extend_kernel(const int8_t* __restrict__ x, long long first, long long n, int nfact, float2* __restrict__ xe) {
+// Sample i of the IF record as data1 + 1i*data2 (postProcessing.m:88-96): int8 / int16, I/Q, Q/I (GLONASS: tracking.m:227 of its
+// packages reads the pair the other way round) or real samples.
+__device__ __forceinline__ float2 record_sample(const void* __restrict__ rec, int dtype, int layout, long long i) {
+  float a, b = 0.0f;
+  if (dtype == GC_I16) {
+    const short* x = reinterpret_cast<const short*>(rec);
+    if (layout == GC_REAL) {
+      a = (float)x[i];
+    } else {
+      a = (float)x[2 * i];
+      b = (float)x[2 * i + 1];
+    }
+  } else {
+    const int8_t* x = reinterpret_cast<const int8_t*>(rec);
+    if (layout == GC_REAL) {
+      a = (float)x[i];
+    } else {
+      a = (float)x[2 * i];
+      b = (float)x[2 * i + 1];
+    }
+  }
+  return layout == GC_QI ? make_float2(b, a) : make_float2(a, b);
+}
+
+// The record's samples [first, first + n) as the complex float signal the searches read with source = CONDITIONED: records that
+// are not int8 I/Q (int16 files, postProcessing.m:61-96 dataType; Q/I order; real samples) go through this instead of a kernel
+// variant per format in every acquisition pass.
+__global__ void record_to_float_kernel(const void* __restrict__ rec, int dtype, int layout, long long first, long long n, float2* __restrict__ out) {
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long long)gridDim.x * blockDim.x)
+    out[j] = record_sample(rec, dtype, layout, first + j);
+}
+
+__global__ void cond_extend_kernel(const void* __restrict__ x, int dtype, int layout, long long first, long long n, int nfact, float2* __restrict__ xe) {
   const long long ne = n + 2LL * nfact;
   for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < ne; j += (long long)gridDim.x * blockDim.x) {
-    auto at = [&](long long i) { return make_float2((float)x[2 * (first + i)], (float)x[2 * (first + i) + 1]); };
+    auto at = [&](long long i) { return record_sample(x, dtype, layout, first + i); };
     float2 v;
     if (j < nfact) {  // 2*x(1) - x(nfact+1:-1:2)
       const float2 e = at(0), r = at(nfact - j);
@@ -1521,9 +1553,9 @@ extern "C" int gc_acq_condition(gc_context* ctx, const gc_acq_front_params* p, g
     gc_set_error("gc_acq_condition: bad arguments");
     return GC_E_INVALID;
   }
-  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
-    gc_set_error("gc_acq_condition: needs an int8 I/Q IF buffer");
-    return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
+  if (!ctx->d_if) {
+    gc_set_error("gc_acq_condition: no IF record loaded");
+    return GC_E_STATE;
   }
   const long long n = p->n_samples;
   const int nb = p->fir_order + 1, nfact = 3 * (nb - 1);  // filtfilt's edge length
@@ -1563,8 +1595,8 @@ extern "C" int gc_acq_condition(gc_context* ctx, const gc_acq_front_params* p, g
   GC_HIP(hipMemcpyAsync(bt.p, hf.data(), (size_t)nb * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   const unsigned int nblk = (unsigned int)((ne + 255) / 256);
   const size_t smem = (size_t)(256 + nb - 1) * sizeof(float2);
-  hipLaunchKernelGGL(cond_extend_kernel, dim3(std::min(nblk, 65535u)), dim3(256), 0, ctx->stream, (const int8_t*)ctx->d_if,
-                     (long long)p->first_sample, n, nfact, (float2*)ba.p);
+  hipLaunchKernelGGL(cond_extend_kernel, dim3(std::min(nblk, 65535u)), dim3(256), 0, ctx->stream, (const void*)ctx->d_if, ctx->if_dtype,
+                     ctx->if_layout, (long long)p->first_sample, n, nfact, (float2*)ba.p);
   hipLaunchKernelGGL(cond_fir_kernel<false>, dim3(nblk), dim3(256), smem, ctx->stream, (const float2*)ba.p, ne, (const float*)bt.p, nb, (float2*)bb.p);
   hipLaunchKernelGGL(cond_fir_kernel<true>, dim3(nblk), dim3(256), smem, ctx->stream, (const float2*)bb.p, ne, (const float*)bt.p, nb, (float2*)ba.p);
   hipLaunchKernelGGL(cond_decimate_kernel, dim3((unsigned int)std::min<long long>((len + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
@@ -1575,6 +1607,53 @@ extern "C" int gc_acq_condition(gc_context* ctx, const gc_acq_front_params* p, g
   out->sampling_freq = new_fs;
   out->intermediate_freq = std::fmod(IF, new_fs);  // rem(), :95
   out->n_samples = len;
+  return GC_OK;
+}
+
+// The searches' other source (gc_acq_params.source = CONDITIONED) filled without the conditioning block: from the record in
+// whatever format it has, or from the caller's own complex samples (acquisition(longSignal, settings) takes any complex row).
+extern "C" int gc_acq_signal_from_record(gc_context* ctx, int64_t first_sample, int64_t n) {
+  if (!ctx || first_sample < 0 || n <= 0) {
+    gc_set_error("gc_acq_signal_from_record: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (!ctx->d_if) {
+    gc_set_error("gc_acq_signal_from_record: no IF record loaded");
+    return GC_E_STATE;
+  }
+  if ((uint64_t)first_sample + (uint64_t)n > ctx->if_nsamples) {
+    gc_set_error("gc_acq_signal_from_record: %lld samples from %lld: outside the record", (long long)n, (long long)first_sample);
+    return GC_E_RANGE;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  GcBuf& bsig = ctx->acqbuf[gc_context::ACQ_COND_SIG];
+  ctx->acq_cond_n = 0;
+  if (gc_buf_reserve(bsig, (size_t)n * sizeof(float2), false) != hipSuccess) {
+    gc_set_error("gc_acq_signal_from_record: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  hipLaunchKernelGGL(record_to_float_kernel, dim3((unsigned int)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
+                     (const void*)ctx->d_if, ctx->if_dtype, ctx->if_layout, (long long)first_sample, (long long)n, (float2*)bsig.p);
+  GC_HIP(hipGetLastError());
+  ctx->acq_cond_n = n;
+  return GC_OK;
+}
+
+extern "C" int gc_acq_set_signal(gc_context* ctx, const float* iq, int64_t n) {
+  if (!ctx || !iq || n <= 0) {
+    gc_set_error("gc_acq_set_signal: bad arguments");
+    return GC_E_INVALID;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  GcBuf& bsig = ctx->acqbuf[gc_context::ACQ_COND_SIG];
+  ctx->acq_cond_n = 0;
+  if (gc_buf_reserve(bsig, (size_t)n * sizeof(float2), false) != hipSuccess) {
+    gc_set_error("gc_acq_set_signal: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  GC_HIP(hipMemcpyAsync(bsig.p, iq, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->acq_cond_n = n;
   return GC_OK;
 }
 
@@ -1713,13 +1792,20 @@ extern "C" int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* 
     gc_set_error("gc_acq_shift_prepare: bad arguments");
     return GC_E_INVALID;
   }
-  if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
-    gc_set_error("gc_acq_shift_prepare: needs an int8 I/Q IF buffer");
+  const bool cond = p->source == GC_ACQ_SOURCE_CONDITIONED;
+  if (cond) {
+    if (ctx->acq_cond_n <= 0) {
+      gc_set_error("gc_acq_shift_prepare: no conditioned signal (gc_acq_condition / gc_acq_signal_from_record / gc_acq_set_signal first)");
+      return GC_E_STATE;
+    }
+  } else if (!ctx->d_if || ctx->if_dtype != GC_I8 || ctx->if_layout != GC_IQ) {
+    gc_set_error("gc_acq_shift_prepare: needs an int8 I/Q IF buffer (other records: gc_acq_signal_from_record, then source = 1)");
     return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
   }
-  if ((uint64_t)p->first_sample + (uint64_t)p->n_signals * p->n > ctx->if_nsamples) {
-    gc_set_error("gc_acq_shift_prepare: needs %lld samples from %lld, buffer holds %llu", (long long)p->n_signals * p->n,
-                 (long long)p->first_sample, (unsigned long long)ctx->if_nsamples);
+  const uint64_t avail = cond ? (uint64_t)ctx->acq_cond_n : ctx->if_nsamples;
+  if ((uint64_t)p->first_sample + (uint64_t)p->n_signals * p->n > avail) {
+    gc_set_error("gc_acq_shift_prepare: needs %lld samples from %lld, the signal holds %llu", (long long)p->n_signals * p->n,
+                 (long long)p->first_sample, (unsigned long long)avail);
     return GC_E_RANGE;
   }
   GC_HIP(hipSetDevice(ctx->device));
@@ -1764,6 +1850,7 @@ extern "C" int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* 
   PassArgs base;
   std::memset(&base, 0, sizeof base);
   base.if_base = (const int8_t*)ctx->d_if;
+  base.if_f32 = cond ? (const float2*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p : nullptr;
   base.first_sample = p->first_sample;
   base.spc = p->n;              // signal k starts k*n samples later; the carrier phase restarts with every block
   base.nhops = p->n_signals;

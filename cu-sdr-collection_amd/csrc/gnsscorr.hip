@@ -334,6 +334,13 @@ int gc_if_buffer(gc_context* ctx, void** device_ptr, uint64_t* nsamples) {
   return GC_OK;
 }
 
+int gc_if_format(gc_context* ctx, int* dtype, int* layout) {
+  if (!ctx) return GC_E_INVALID;
+  if (dtype) *dtype = ctx->if_dtype;
+  if (layout) *layout = ctx->if_layout;
+  return GC_OK;
+}
+
 int gc_read_if(gc_context* ctx, uint64_t first, uint64_t n, void* dst) {
   if (!ctx || !dst) return GC_E_INVALID;
   if (!ctx->d_if) {

@@ -99,6 +99,29 @@ class Engine:
         L.check(self._lib.gc_if_buffer(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def if_format(self):
+        """(dtype, layout) of the loaded record: GC_I8 / GC_I16, GC_IQ / GC_QI / GC_REAL."""
+        dt, lay = C.c_int(), C.c_int()
+        L.check(self._lib.gc_if_format(self._ctx, C.byref(dt), C.byref(lay)))
+        return dt.value, lay.value
+
+    def acq_input(self, first_sample: int, fs: float, n_long: int | None = None):
+        """What an acquisition's searches read: (source, first_sample, samples available from there).  int8 I/Q records are read
+        in place; any other format (int16 files, Q/I order, real samples) goes through a float copy of longSignal on the device
+        (gc_acq_signal_from_record; n_long samples, by default what the record holds up to 0.3 s)."""
+        dt, lay = self.if_format()
+        avail = int(self.if_buffer()[1]) - int(first_sample)
+        if dt == L.GC_I8 and lay == L.GC_IQ:
+            return 0, int(first_sample), avail if n_long is None else min(avail, int(n_long))
+        n = min(avail, int(n_long) if n_long is not None else int(0.3 * fs))
+        L.check(self._lib.gc_acq_signal_from_record(self._ctx, int(first_sample), n))
+        return 1, 0, n
+
+    def acq_set_signal(self, x: np.ndarray):
+        """gc_acq_set_signal: longSignal itself (any complex row) as the searches' source = 1."""
+        z = np.ascontiguousarray(x, dtype=np.complex64)
+        L.check(self._lib.gc_acq_set_signal(self._ctx, z.view(np.float32).ctypes.data_as(C.POINTER(C.c_float)), z.shape[0]))
+
     def read_if(self, first: int, n: int, dtype=np.int8, layout: int = L.GC_IQ) -> np.ndarray:
         comp = 1 if layout == L.GC_REAL else 2
         out = np.empty(n * comp, dtype=dtype)

@@ -115,8 +115,9 @@ def acquisition(engine: Engine, settings, first_sample: int | None = None, n_lon
         S.samplingFreq, S.IF = new_fs, new_if                        # :81,95
     prns = list(S.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32))
-    p = _acq_params(S, 0 if resampled else first_sample)
-    p.source = 1 if resampled else 0
+    src, first = (1, 0) if resampled else engine.acq_input(first_sample, settings.samplingFreq, n_long)[:2]   # int16 / Q-I / real records: float copy
+    p = _acq_params(S, first)
+    p.source = src
     tables = np.stack([codes.makeCaTable(prn, S) for prn in prns])
     res = engine.acquire_coarse(p, tables)
     found = []

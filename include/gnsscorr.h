@@ -78,6 +78,8 @@ int gc_open_if_file(gc_context* ctx, const char* path, uint64_t skip_bytes, uint
 int gc_attach_if(gc_context* ctx, void* device_ptr, uint64_t nsamples, int dtype, int layout);
 /* Device pointer and size of the current IF buffer (for tools that fill it in place). */
 int gc_if_buffer(gc_context* ctx, void** device_ptr, uint64_t* nsamples);
+/* sample type and order of the loaded record (GC_I8 / GC_I16, GC_IQ / GC_QI / GC_REAL) */
+int gc_if_format(gc_context* ctx, int* dtype, int* layout);
 /* Allocate an uninitialised device IF buffer owned by the context. */
 int gc_alloc_if(gc_context* ctx, uint64_t nsamples, int dtype, int layout);
 /* Read back raw samples [first, first+n) to the host (tests, CPU-baseline sampling). */
@@ -355,6 +357,13 @@ typedef struct gc_acq_front_result {
   int64_t n_samples;         /* signalLen (:84) */
 } gc_acq_front_result;
 int gc_acq_condition(gc_context* ctx, const gc_acq_front_params* p, gc_acq_front_result* out);
+/* The same device-side signal filled WITHOUT the conditioning block, for what the searches do not read directly (they read int8
+ * I/Q records): n samples of the loaded record from first_sample in whatever format it has - int16 files (postProcessing.m:61-96,
+ * settings.dataType), Q/I order, real samples - or the caller's own complex samples (re, im interleaved floats;
+ * acquisition(longSignal, settings) accepts any complex row).  Then source = GC_ACQ_SOURCE_CONDITIONED and first_sample counts
+ * from the signal's start.  gc_acq_condition itself takes the record in any format. */
+int gc_acq_signal_from_record(gc_context* ctx, int64_t first_sample, int64_t n);
+int gc_acq_set_signal(gc_context* ctx, const float* iq, int64_t n);
 /* test hook: the conditioned signal back as n complex floats (re, im interleaved) */
 int gc_acq_conditioned(gc_context* ctx, int64_t first, int64_t n, float* dst);
 
@@ -428,7 +437,7 @@ typedef struct gc_acq_shift_params {
   int32_t n_carriers;        /* Nshifts */
   int32_t n_bins;            /* numberOfFrqBins: circshift(IQfreqDom, bin), bin = 0 .. n_bins-1 */
   int32_t n_arms_max;        /* code components per PRN that gc_acq_shift_search will be given (1..4) */
-  int32_t reserved;
+  int32_t source;            /* as gc_acq_params.source */
 } gc_acq_shift_params;
 
 int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* p);

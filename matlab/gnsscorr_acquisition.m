@@ -8,20 +8,16 @@ function acqResults = gnsscorr_acquisition(longSignal, settings, name)
 %   fine stage (:206-248) run on the GPU; the package's hypothesis search over those 20-100 complex numbers per bin is below.
 %   Written for this repository; not a copy of any reference file.
 
-x = [real(longSignal); imag(longSignal)];
-x = x(:).';
-if any(x ~= round(x)) || max(abs(x)) > 32767
-    error('gnsscorr:acquisition', 'longSignal does not hold integer int8 / int16 sample values');
-end
-if max(abs(x)) <= 127, x = int8(x); else, x = int16(x); end
-h = gnsscorr_context('longSignal', 'new');
-gnsscorr_mex('load_if', h, x, 2, settings.samplingFreq);
+[h, src, hasRecord] = gnsscorr_upload(longSignal, settings);
 
 %--- optional input conditioning (acquisition.m:46-111): zero-phase FIR(700) band-pass + band-pass-sampling decimation -----
 flag = 0;
 if isfield(settings, 'resamplingflag'), flag = settings.resamplingflag; end
 if isfield(settings, 'resamplingFlag'), flag = settings.resamplingFlag; end      % BDS/B3I spells it so
 resampled = settings.samplingFreq > settings.resamplingThreshold && flag == 1;
+if resampled && ~hasRecord
+    error('gnsscorr:acquisition', 'the conditioning block runs on integer sample values (int8 / int16 records)');
+end
 if resampled
     switch name                                                       % BW of the package's block (acquisition.m:58 and its twins)
         case {'GPS_L1CA', 'GPS_L5C', 'BDS_B2a', 'BDS_B3I'}, c.bandwidth = settings.codeFreqBasis * 2 + 0.5e6;
@@ -42,7 +38,7 @@ fs = settings.samplingFreq;  ts = 1 / fs;
 spc = round(fs / (settings.codeFreqBasis / settings.codeLength));      % acquisition.m:116
 a.samplingFreq = fs;  a.codeFreqBasis = settings.codeFreqBasis;  a.codeLength = settings.codeLength;  a.IF = settings.IF;
 a.acqSearchBand = settings.acqSearchBand;  a.acqSearchStep = settings.acqSearchStep;  a.acqNonCohTime = settings.acqNonCohTime;
-a.firstSample = 0;  a.source = double(resampled);
+a.firstSample = 0;  a.source = max(double(resampled), src);
 NH20 = [1 1 1 1 1 -1 1 1 -1 -1 1 -1 1 -1 1 1 -1 -1 -1 1];              % GPS_L5C acquisition.m:131
 CS25 = [1 1 -1 -1 -1 1 1 1 1 1 1 1 -1 1 -1 1 -1 -1 1 -1 -1 1 1 -1 1];  % GAL_E1C acquisition.m:138
 
@@ -119,7 +115,7 @@ for k = 1:numel(prns)
         otherwise
             q.samplingFreq = fs;  q.codeFreq = 1 / tc;  q.f0 = res(5, k) + settings.acqSearchStep / 2;  q.fstep = f.fineStep;
             q.firstSample = res(2, k) - 1;  q.samplesPerCode = spc;  q.ncodes = f.ncodes;  q.nbins = nfine;
-            q.codeLength = L;  q.indexOffset = f.indexOffset;  q.source = double(resampled);
+            q.codeLength = L;  q.indexOffset = f.indexOffset;  q.source = a.source;
             codes = f.fine(p);
             sums = cell(1, numel(codes));
             for m = 1:numel(codes)

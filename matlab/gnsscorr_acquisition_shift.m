@@ -9,19 +9,15 @@ function acqResults = gnsscorr_acquisition_shift(longSignal, settings, name)
 %   those maxima and on the one winning row ('acq_shift_row') and stay here.
 %   Written for this repository; not a copy of any reference file.
 
-x = [real(longSignal); imag(longSignal)];
-x = x(:).';
-if any(x ~= round(x)) || max(abs(x)) > 127
-    error('gnsscorr:acquisition', 'longSignal does not hold integer int8 sample values');
-end
-h = gnsscorr_context('longSignal', 'new');
-gnsscorr_mex('load_if', h, int8(x), 2, settings.samplingFreq);
+[h, src, hasRecord] = gnsscorr_upload(longSignal, settings);
+settings.gnsscorrSource = src;              % 0: the searches read the int8 record; 1: its float copy / longSignal itself
 nLong = numel(longSignal);
 switch name
     case 'BDS_B1I', acqResults = b1i(h, settings);
     case 'GPS_L2C', acqResults = l2c(h, settings);
     case 'BDS_B1C'
         if settings.samplingFreq > settings.resamplingThreshold && settings.resamplingflag == 1
+            if ~hasRecord, error('gnsscorr:acquisition', 'the conditioning block runs on integer sample values (int8 / int16 records)'); end
             acqResults = b1cConditioned(h, settings, nLong);
         else
             acqResults = b1c(h, settings, nLong);
@@ -102,7 +98,7 @@ nShifts = freqRes / stepSize;                                                   
 spc2 = round(fs / (settings.codeFreqBasis / (Ncodes * settings.codeLength)));               % makeCaTableDMA.m
 initFreq = settings.IF + (settings.acqSearchBand / 2) * 1000;                               % :66
 q.samplingFreq = fs;  q.carrierF0 = initFreq;  q.carrierStep = freqRes / nShifts;  q.firstSample = 0;
-q.samplesPerBlock = spb;  q.nSignals = 2;  q.nCarriers = nShifts;  q.nBins = nBins;  q.nArmsMax = 1;
+q.samplesPerBlock = spb;  q.nSignals = 2;  q.nCarriers = nShifts;  q.nBins = nBins;  q.nArmsMax = 1;  q.source = settings.gnsscorrSource;
 nRows = gnsscorr_mex('acq_shift_prepare', h, q);
 acqResults.carrFreq = zeros(1, 58);  acqResults.codePhase = zeros(1, 58);  acqResults.peakMetric = zeros(1, 58);
 chip = round(fs / settings.codeFreqBasis);                                                  % :139
@@ -137,7 +133,7 @@ nBins = round(settings.acqSearchBand * 1e3 / freqRes) + 1;                      
 nShifts = freqRes / settings.acqStep;                                                       % :25
 initFreq = settings.IF + (settings.acqSearchBand / 2) * 1000;                               % :33
 q.samplingFreq = fs;  q.carrierF0 = initFreq;  q.carrierStep = -(freqRes / nShifts);  q.firstSample = 0;
-q.samplesPerBlock = spb;  q.nSignals = 1;  q.nCarriers = nShifts;  q.nBins = nBins;  q.nArmsMax = 1;
+q.samplesPerBlock = spb;  q.nSignals = 1;  q.nCarriers = nShifts;  q.nBins = nBins;  q.nArmsMax = 1;  q.source = settings.gnsscorrSource;
 nRows = gnsscorr_mex('acq_shift_prepare', h, q);
 acqResults.carrFreq = zeros(1, 32);  acqResults.codePhase = zeros(1, 32);  acqResults.peakMetric = zeros(1, 32);
 tc = 1 / (settings.codeFreqBasis * 2);
@@ -159,7 +155,7 @@ for PRN = settings.acqSatelliteList
         if settings.pilotTRKflag == 1                                                       % :140-166: 75 one-period correlations
             % sig - mean(sig) wiped with the carrier and each of the 75 CL segments sampled like the CM table: the segments go to
             % the GPU as 75 replicas of one entry per sample (codeFreq = 0), the mean as the dc term
-            st = gnsscorr_mex('signal_stats', h, codePhase - 1, spc);
+            st = gnsscorr_mex('signal_stats', h, codePhase - 1, spc, settings.gnsscorrSource);
             cl = generateCLcode(PRN, settings);
             idx = ceil(ts * (0:spc - 1) / tc);
             idx(1) = 1;
@@ -169,7 +165,7 @@ for PRN = settings.acqSatelliteList
                 windows(:, ind) = cl(idx + settings.codeLength * 2 * (ind - 1)).';
             end
             q2 = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', carr, 'fstep', 0, 'firstSample', codePhase - 1, 'samplesPerCode', spc, ...
-                        'ncodes', 1, 'nbins', 1, 'codeLength', spc, 'indexOffset', 0, 'dcRe', st(1), 'dcIm', st(2));
+                        'ncodes', 1, 'nbins', 1, 'codeLength', spc, 'indexOffset', 0, 'dcRe', st(1), 'dcIm', st(2), 'source', settings.gnsscorrSource);
             s = gnsscorr_mex('fine_sums', h, q2, int8(windows));                            % 2 x 75
             power = abs(s(1, :) + 1i * s(2, :));
             [~, seg] = max(power);
@@ -252,11 +248,11 @@ n = round(spc / 10 * (10 + settings.acqCohT));                                  
 nBins = round(settings.acqSearchBand * 2 / settings.acqStep) + 1;                           % :120
 pilot = settings.pilotACQflag == 1;
 fineStep = 25;  nFine = round(settings.acqStep / 25) * 2 + 1;                                % :129-130
-st = gnsscorr_mex('signal_stats', h, 0, xLen);
+st = gnsscorr_mex('signal_stats', h, 0, xLen, settings.gnsscorrSource);
 sigPower = sqrt(st(3) * xLen);                                                              % :138
 initFreq = settings.IF + settings.acqSearchBand;                                            % :141
 q.samplingFreq = fs;  q.carrierF0 = initFreq;  q.carrierStep = 0;  q.firstSample = 0;
-q.samplesPerBlock = n;  q.nSignals = 1;  q.nCarriers = 1;  q.nBins = nBins;  q.nArmsMax = 2;
+q.samplesPerBlock = n;  q.nSignals = 1;  q.nCarriers = 1;  q.nBins = nBins;  q.nArmsMax = 2;  q.source = settings.gnsscorrSource;
 nRows = gnsscorr_mex('acq_shift_prepare', h, q);
 nMax = max(settings.acqSatelliteList);
 acqResults.carrFreq = zeros(1, nMax);  acqResults.codePhase = zeros(1, nMax);  acqResults.peakMetric = zeros(1, nMax);
@@ -283,7 +279,7 @@ for PRN = settings.acqSatelliteList
         tabs = dtab(:);
         if pilot, tabs = [dtab(:), ptab(:)]; end
         q3 = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', selFreq + settings.acqStep, 'fstep', fineStep, 'firstSample', codePhase - 1, ...
-                    'samplesPerCode', spc, 'ncodes', 1, 'nbins', nFine, 'codeLength', spc, 'indexOffset', 0);
+                    'samplesPerCode', spc, 'ncodes', 1, 'nbins', nFine, 'codeLength', spc, 'indexOffset', 0, 'source', settings.gnsscorrSource);
         s = gnsscorr_mex('fine_sums', h, q3, int8(tabs));                                   % 2 x (nFine * narms)
         s = abs(s(1, :) + 1i * s(2, :));
         fine = s(1:nFine);

@@ -354,6 +354,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxFree(first);
     mxFree(f0);
     if (rc) fail("gc_acquire_fine_sums");
+  } else if (!strcmp(cmd, "acq_from_record")) {
+    /* gnsscorr_mex('acq_from_record', h, firstSample, n): the record's samples (int16, Q/I, real: any format) as the complex float
+       signal the searches read with .source = 1 */
+    if (gc_acq_signal_from_record(handle(prhs[1]), (int64_t)mxGetScalar(prhs[2]), (int64_t)mxGetScalar(prhs[3]))) fail("gc_acq_signal_from_record");
+  } else if (!strcmp(cmd, "acq_set_signal")) {
+    /* gnsscorr_mex('acq_set_signal', h, single([re; im])): longSignal itself - any complex row - as that signal */
+    if (!mxIsSingle(prhs[2])) mexErrMsgIdAndTxt("gnsscorr:args", "acq_set_signal: single([re; im]) expected");
+    if (gc_acq_set_signal(handle(prhs[1]), (const float*)mxGetData(prhs[2]), (int64_t)(mxGetNumberOfElements(prhs[2]) / 2))) fail("gc_acq_set_signal");
   } else if (!strcmp(cmd, "signal_stats")) {
     /* s = gnsscorr_mex('signal_stats', h, firstSample, n[, source]): [real(mean(x)), imag(mean(x)), var(x)] of n samples on the device */
     double mr, mi, v;
@@ -386,6 +394,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.n_carriers = (int32_t)field(s, "nCarriers");
     p.n_bins = (int32_t)field(s, "nBins");
     p.n_arms_max = mxGetField(s, 0, "nArmsMax") ? (int32_t)field(s, "nArmsMax") : 1;
+    p.source = mxGetField(s, 0, "source") ? (int32_t)field(s, "source") : 0;
     if (gc_acq_shift_prepare(handle(prhs[1]), &p)) fail("gc_acq_shift_prepare");
     plhs[0] = mxCreateDoubleScalar((double)p.n_carriers * p.n_signals * p.n_bins); /* number of result rows */
   } else if (!strcmp(cmd, "acq_shift_search")) {

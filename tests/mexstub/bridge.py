@@ -52,6 +52,8 @@ def install(I, gateway, P, signal: str):
         if cmd == "load_if":            # the interpreter has no integer classes: int8(...) / int16(...) keep double storage
             x = np.asarray(vals[1])
             vals[1] = x.astype(np.int8) if np.all(np.abs(x) <= 127) else x.astype(np.int16)
+        if cmd == "acq_set_signal":     # single(...) keeps double storage in the interpreter too
+            vals[1] = np.asarray(vals[1]).astype(np.float32)
         if cmd in ("acquire_coarse", "acquire_coarse_multi") or cmd in ("fine_sums", "acquire_fine_l1ca", "acq_shift_search"):
             k = 2 if cmd != "acq_shift_search" else 1
             vals[k] = np.asarray(vals[k]).astype(np.int8)

@@ -196,3 +196,42 @@ def test_matlab_drop_in_tracks_a_record_larger_than_the_window(gateway, tmp_path
         for f in vars(a):
             if isinstance(getattr(a, f), np.ndarray):
                 assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+_ACQ_FORMATS = ("GPS_L1CA", "GPS_L5C", "GLO_GL1", "BDS_B1I", "GPS_L2C", "BDS_B1C", "GPS_L5C_resampled")
+
+
+@pytest.mark.parametrize("scale", [100.0, 0.37], ids=["int16-valued", "any-complex-row"])
+@pytest.mark.parametrize("sc", [s for s in RS.ACQ_SCENES if s.name in _ACQ_FORMATS], ids=[s.name for s in RS.ACQ_SCENES if s.name in _ACQ_FORMATS])
+def test_matlab_drop_in_takes_longsignal_as_the_reference_does(gateway, sc, scale):
+    """acquisition(longSignal, settings) takes a complex double row, whatever the file's dataType was (postProcessing.m:61-96 reads
+    int8 or int16).  The results do not depend on the signal's scale (codePhase and carrFreq are positions, peakMetric a ratio), so
+    the reference's results for the int8 record must come back for the same samples times 100 - int16 values, uploaded as an int16
+    record whose float copy the searches read - and times 0.37 - no integers at all, longSignal itself goes up in single precision
+    (the conditioning block, which wants a record, then refuses)."""
+    import bridge
+    import cu_sdr_collection_amd as P
+    from oracle import mlab
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    x = rec.astype(np.float64) * scale
+    long_signal = (x[0::2] + 1j * x[1::2]).reshape(1, -1)
+    pkg = sc.name.replace("_resampled", "")
+    signal = {"BDS_B1C": "BDS_B1C_NB"}.get(pkg, pkg)
+    I = bridge.install(bridge.interpreter_for(pkg), gateway, P, signal)
+    try:
+        if sc.name.endswith("_resampled") and scale != round(scale):
+            with pytest.raises(mlab.MError) as e:
+                I.call("acquisition", long_signal, mlab.to_matlab(S))
+            assert "gnsscorr:acquisition" in str(e.value)      # (the interpreter keeps the identifier; the text names the conditioning block)
+            return
+        acq = mlab.from_matlab(I.call("acquisition", long_signal, mlab.to_matlab(S)))
+    finally:
+        I.call("gnsscorr_context", "", "clear")
+    for f in sc.fields:
+        want, got = z["f_" + f], np.asarray(getattr(acq, f), dtype=np.float64).reshape(-1)
+        assert got.shape == want.shape, (sc.name, f, got.shape, want.shape)
+        if f == "peakMetric":
+            assert np.max(np.abs(got - want)) <= sc.metric_rtol * np.max(np.abs(want)), sc.name
+        else:
+            assert np.array_equal(got, want), (sc.name, f, got[got != want], want[got != want])

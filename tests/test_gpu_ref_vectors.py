@@ -132,3 +132,26 @@ def test_hip_acquisition_equals_the_references_acquisition_m(engine, sc):
         else:
             assert np.array_equal(have, want), (sc.name, f, np.flatnonzero(have != want), have[have != want], want[have != want])
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
+
+
+_ACQ_INT16 = ("GPS_L1CA", "GPS_L5C", "GAL_E1C", "GLO_GL1", "BDS_B1I", "GPS_L2C", "BDS_B1C", "GPS_L1CA_resampled", "BDS_B1C_resampled")
+
+
+@pytest.mark.parametrize("sc", [s for s in RS.ACQ_SCENES if s.name in _ACQ_INT16], ids=[s.name for s in RS.ACQ_SCENES if s.name in _ACQ_INT16])
+def test_hip_acquisition_of_an_int16_record_equals_the_references_acquisition_m(engine, sc):
+    """settings.dataType = 'int16' (postProcessing.m:61-96): the record's samples times 100 as an int16 record.  The searches read
+    its float copy on the device (gc_acq_signal_from_record), the conditioning block reads the int16 record itself; positions and
+    the scale-free metric must be the reference's for the int8 record."""
+    import cu_sdr_collection_amd as P
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    engine.load_if(rec.astype(np.int16) * 100, fs=S.samplingFreq)
+    got = sc.product(P, engine, S)
+    for f in sc.fields:
+        want = z["f_" + f]
+        have = np.asarray(getattr(got, f), dtype=np.float64)
+        assert have.shape == want.shape, (sc.name, f)
+        if f == "peakMetric":
+            assert np.max(np.abs(have - want)) <= sc.metric_rtol * np.max(np.abs(want)), (sc.name, np.max(np.abs(have - want)) / np.max(np.abs(want)))
+        else:
+            assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
