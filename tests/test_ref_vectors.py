@@ -200,11 +200,16 @@ def test_code_generators_equal_the_references_generators():
     assert len(ref) >= 20
     n = 0
     for key, rows in ref.items():
-        for prn, length, total, sha, head in rows:
+        for k, (prn, length, total, sha, head) in enumerate(rows):
             c = np.asarray(_product_code(P, key, prn))
             assert c.shape[0] == length and int(c.sum()) == total and [int(v) for v in c[:24]] == head and _sha(c) == sha, ("product", key, prn)
+            # the oracle's generators are plain Python shift-register loops (0.2 s per 10 230-chip code): every PRN of the short codes,
+            # every fourth and the last of the long ones, the first of the 1.5-Mchip CL code
+            if not (length <= 5000 or (length <= 30000 and (k % 4 == 0 or k == len(rows) - 1)) or k == 0):
+                n += 1
+                continue
             o = _oracle_code(key, prn)
-            if o is not None and (length <= 30000 or prn == rows[0][0]):
+            if o is not None:
                 o = np.asarray(o)
                 assert o.shape[0] == length and _sha(o) == sha, ("oracle", key, prn)
             n += 1
