@@ -1379,6 +1379,11 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     gc_set_error("gc_acquire_coarse: block_len / code_samples need non_coh_time == 1 and code_samples <= block_len");
     return GC_E_INVALID;
   }
+  if ((uint64_t)p->first_sample + (uint64_t)(H - 1) * spc + (uint64_t)blk > avail) {
+    gc_set_error("gc_acquire_coarse: needs %lld samples from %lld, buffer holds %llu", (long long)(H - 1) * spc + blk,
+                 (long long)p->first_sample, (unsigned long long)avail);
+    return GC_E_RANGE;
+  }
   // The reference transforms 2*spc points (one code period + one of zeros).  Where the radix-{2..8} plan cannot take that
   // length (2*spc = 32 736 = 2^5*3*11*31 at the common 16.368-Msps front ends, 5 172 = 2^2*3*431 after the A0 resampling),
   // the circular correlation is computed inside a longer transform instead: the 2*spc mixed samples followed by a repeat
@@ -1401,11 +1406,6 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
         return GC_E_UNSUPPORTED;
       }
     }
-  }
-  if ((uint64_t)p->first_sample + (uint64_t)(H - 1) * spc + (uint64_t)blk > avail) {
-    gc_set_error("gc_acquire_coarse: needs %lld samples from %lld, buffer holds %llu", (long long)(H - 1) * spc + blk,
-                 (long long)p->first_sample, (unsigned long long)avail);
-    return GC_E_RANGE;
   }
   AcqScratch* s = nullptr;
   int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn * narms, nbins, cl, &s);

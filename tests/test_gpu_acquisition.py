@@ -524,3 +524,33 @@ def test_circshift_family_at_a_rate_whose_block_the_radix_plan_cannot_take(engin
         assert got.codePhase[k] == ref.codePhase[k] and got.carrFreq[k] == ref.carrFreq[k], prn
         assert abs(got.peakMetric[k] - ref.peakMetric[k]) < 2e-3 * ref.peakMetric[k], prn
     assert np.array_equal(got.CLCodePhase, ref.CLCodePhase) and got.CLCodePhase[4] == seg
+
+
+def test_block_and_replica_lengths_of_the_coarse_search_are_checked(engine, acq_scene):
+    """gc_acq_params.block_len / code_samples (a B1C-type search run carrier by carrier): one hop only, the replica inside the
+    block, the block inside the signal; and the L1 C/A defaults are what 0 means."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    from cu_sdr_collection_amd.receiver import _acq_params
+    S, sats, iq = acq_scene
+    engine.load_if(iq, fs=S.samplingFreq)
+    spc = 18000
+    table = P.codes.makeCaTable(sats[0].prn, S)[None, :]
+    p = _acq_params(S, 0)
+    p.non_coh_time = 1
+    ref = engine.acquire_coarse(p, table)[0]
+    p.block_len, p.code_samples = 2 * spc, spc                      # spelled out: the same search
+    same = engine.acquire_coarse(p, table)[0]
+    assert (same.code_phase, same.coarse_bin, same.peak) == (ref.code_phase, ref.coarse_bin, ref.peak)
+    p.non_coh_time = 2
+    with pytest.raises(P.GnssCorrError) as e:
+        engine.acquire_coarse(p, table)
+    assert e.value.status == L.GC_E_INVALID
+    p.non_coh_time, p.block_len, p.code_samples = 1, spc, 2 * spc   # replica longer than the block
+    with pytest.raises(P.GnssCorrError) as e:
+        engine.acquire_coarse(p, np.tile(table, 2))
+    assert e.value.status == L.GC_E_INVALID
+    p.block_len, p.code_samples = iq.shape[0], spc                  # block longer than the record (2 components per sample)
+    with pytest.raises(P.GnssCorrError) as e:
+        engine.acquire_coarse(p, table)
+    assert e.value.status == L.GC_E_RANGE
