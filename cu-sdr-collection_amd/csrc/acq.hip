@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int kMaxRadices = 12;
+constexpr int kMaxPassLen = 2048;  // longest vector of a pass: one tile of 2048 complex values (choose_cols), i.e. transforms of up to 2048 x 2048 points
 constexpr int kFftThreads = 256;
 constexpr int kFftSlots = 8;  // tile elements per thread at most: L*C <= kFftSlots * kFftThreads
 
@@ -104,7 +105,7 @@ bool make_plan(int n, Plan* pl) {
   pl->n = n;
   pl->n1 = best;
   pl->n2 = n / best;
-  return factor(pl->n1, &pl->p1) && factor(pl->n2, &pl->p2) && pl->n2 <= 1024;
+  return factor(pl->n1, &pl->p1) && factor(pl->n2, &pl->p2) && pl->n2 <= kMaxPassLen;
 }
 
 enum PreOp { PRE_NONE = 0, PRE_IF_CARRIER, PRE_CODE, PRE_MUL_CONJ };
