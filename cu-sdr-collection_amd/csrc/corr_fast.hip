@@ -566,7 +566,10 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     }
     dl_next = blk;
     double dl_rv[GC_TRK_NFIELDS];
-    const int st = devloop_post<1>(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; });
+    // member 0 writes the records, member 1 (the only one when the team has one member: then member 0) keeps the C/N0 sums
+    const bool cno_member = split == (p.splits > 1 ? 1 : 0);
+    const int st = devloop_post<1>(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; }, cno_member,
+                                   cno_member && lane == 0 ? (long long)lb : -1LL);
     if (split == 0) {
       devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, 1, lane);
       if (dl->timing == 1 && lane == 0) {  // phase clocks (100 MHz): correlate | wait for partials | close

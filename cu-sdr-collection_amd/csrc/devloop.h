@@ -119,14 +119,17 @@ __device__ inline DevLoopPre devloop_pre(const DevLoopArgs* __restrict__ dl, con
 
 template <int MAXARMS, class Rec>
 __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopChan& st, gc_block& b, int e, const double (&sums)[6 * MAXARMS],
-                                   int arms, double R, const DevLoopPre& pre, Rec&& rec) {
+                                   int arms, double R, const DevLoopPre& pre, Rec&& rec, bool do_cno = true, long long cno_slot = -1) {
   // rec(field, value) takes the epoch's record: straight to device memory (lane kernel) or into registers, to be stored by
   // devloop_commit AFTER the next descriptor is on its way (fast kernel)
   const gc_track_params& p = dl->prm;
   const double kPi = 3.141592653589793;
   const int n = b.blksize;
   const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
-  if (p.cno_interval > 0 && dl->cno) {
+  // do_cno: in an all-gather team every member runs this closure, ONE of them (not the one that writes the records) keeps the
+  // C/N0 sums - they feed nothing back, so the other members need not carry them on the epoch's critical path; that member
+  // stores the finished value itself (cno_slot >= 0), the single closer of the lane kernel leaves it to devloop_commit
+  if (do_cno && p.cno_interval > 0 && dl->cno) {
     // CNoVSM(I_P(loopCnt-K+1:loopCnt), Q_P(...), T) when rem(loopCnt, K) == 0 (tracking.m:351-358; Common/CNoVSM.m:38-47):
     // Z = I^2 + Q^2, Zm = mean(Z), Zv = var(Z) (N-1), Pav = sqrt(Zm^2 - Zv), Nv = (Zm - Pav)/2, 10*log10(|Pav/(2*Nv)/T|).
     // Sums of Z - Z0 (Z0 = the interval's first Z) keep the one-pass variance free of cancellation.
@@ -155,6 +158,10 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
       st.cno_value = 10.0 * log10(ratio / p.cno_acc_time);
       st.cno_n = (e + 1) / K;
       st.cno_ready = 1;
+      if (cno_slot >= 0 && st.cno_n >= 1 && st.cno_n <= dl->cno_nk) {
+        dl->cno[cno_slot * dl->cno_nk + st.cno_n - 1] = st.cno_value;
+        st.cno_ready = 0;
+      }
     }
   }
   rec(GC_TRK_ABSOLUTE_SAMPLE, (double)st.pos);
@@ -290,6 +297,8 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
 }
 
 // The epoch's record and the loop state to device memory (lane 0), off the critical path.
+// (Measured and dropped: every member of an all-gather team storing one field of the record it also holds, instead of member 0
+// storing all fifteen - 6.33 us per epoch against 5.84.)
 __device__ inline void devloop_commit(const DevLoopArgs* __restrict__ dl, DevLoopChan* gch, const DevLoopChan& st, long long slot, int e,
                                       const double (&rv)[GC_TRK_NFIELDS], int arms, int lane) {
   if (lane != 0) return;
