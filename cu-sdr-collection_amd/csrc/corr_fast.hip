@@ -570,8 +570,12 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     const bool cno_member = split == (p.splits > 1 ? 1 : 0);
     const int st = devloop_post<1>(dl, dl_st, dl_next, bi, sums, 1, 1.0, dl_pre, [&](int f, double v) { dl_rv[f] = v; }, cno_member,
                                    cno_member && lane == 0 ? (long long)lb : -1LL);
+    {
+      // teams of 17 members or more: member f + 2 stores field f of the record every member holds (member 0 keeps the state, member 1 the C/N0 sums)
+      const bool spread = !dl->one_writer && p.splits >= GC_TRK_PILOT_I_E + 2;
+      if (spread || split == 0) devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, 1, lane, split, spread);
+    }
     if (split == 0) {
-      devloop_commit(dl, dl->chan + lb, dl_st, lb, bi, dl_rv, 1, lane);
       if (dl->timing == 1 && lane == 0) {  // phase clocks (100 MHz): correlate | wait for partials | close
         const unsigned long long dl_t3 = __builtin_amdgcn_s_memrealtime();
         DevLoopChan* cc = dl->chan + lb;

@@ -61,7 +61,7 @@ struct DevLoopArgs {
   // tagged 16-byte records straight into host-mapped memory, where the host polls them.
   // C/N0 by the variance-summing method inside the loop (gc_track_params::cno_interval): [nch][cno_nk], device memory
   double* cno;
-  int cno_nk, pad_cno;
+  int cno_nk, one_writer;  // GC_DEVLOOP_ONE_WRITER (tuning): member 0 stores the whole record
   int host_loop;
   const msg_t* host_desc;       // [nch][kDescWords], host-mapped
   void* host_tagged;            // TaggedSlot [nch][splits][GC_OUT_STRIDE], host-mapped
@@ -297,16 +297,19 @@ __device__ inline int devloop_post(const DevLoopArgs* __restrict__ dl, DevLoopCh
 }
 
 // The epoch's record and the loop state to device memory (lane 0), off the critical path.
-// (Measured and dropped: every member of an all-gather team storing one field of the record it also holds, instead of member 0
-// storing all fifteen - 6.33 us per epoch against 5.84.)
+// spread: every member of an all-gather team holds the same record (it ran the same closure on the same sums), so in teams of
+// 17 members or more member f + 2 stores field f - one store instead of fifteen by the member whose partial sums the next epoch
+// then waits for (5.77 us per epoch against 5.90; selecting the fields with a runtime modulo instead of a compare cost 0.5 us).
+// Member 0 keeps the state.
 __device__ inline void devloop_commit(const DevLoopArgs* __restrict__ dl, DevLoopChan* gch, const DevLoopChan& st, long long slot, int e,
-                                      const double (&rv)[GC_TRK_NFIELDS], int arms, int lane) {
+                                      const double (&rv)[GC_TRK_NFIELDS], int arms, int lane, int member = 0, bool spread = false) {
   if (lane != 0) return;
   double* o = dl->records + (size_t)slot * GC_TRK_NFIELDS * dl->n_epochs;
   const int nf = (arms >= 2) ? GC_TRK_NFIELDS : GC_TRK_PILOT_I_E;  // the pilot fields follow the fifteen common ones
 #pragma unroll
   for (int f = 0; f < GC_TRK_NFIELDS; ++f)
-    if (f < nf) o[(size_t)f * dl->n_epochs + e] = rv[f];
+    if (f < nf && (!spread || f + 2 == member)) o[(size_t)f * dl->n_epochs + e] = rv[f];
+  if (member != 0) return;
   gch->pos = st.pos;
   gch->rem_code = st.rem_code;
   gch->rem_carr = st.rem_carr;

@@ -935,6 +935,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     gc_set_error("gc_track_device: %s", hipGetErrorString(e));
     return GC_E_NOMEM;
   }
+  ha.one_writer = std::getenv("GC_DEVLOOP_ONE_WRITER") != nullptr;
   if (want_cno) {
     ha.cno = (double*)ctx->trk[gc_context::TRK_CNO].p;
     ha.cno_nk = cno_nk;
