@@ -310,6 +310,9 @@ __device__ inline void devloop_commit(const DevLoopArgs* __restrict__ dl, DevLoo
   for (int f = 0; f < GC_TRK_NFIELDS; ++f)
     if (f < nf && (!spread || f + 2 == member)) o[(size_t)f * dl->n_epochs + e] = rv[f];
   if (member != 0) return;
+  // the state in device memory is what the host reads when the launch has ended (status, epochs done, the loop state a resumed
+  // call starts from): the last epoch's is the one that counts; every 256th keeps a hung run diagnosable
+  if (spread && st.status == 0 && (e & 255) != 255) return;
   gch->pos = st.pos;
   gch->rem_code = st.rem_code;
   gch->rem_carr = st.rem_carr;
