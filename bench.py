@@ -144,6 +144,7 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
         inits.append(L.gc_channel_init(channel=i, prn=s.prn, acquired_freq=S.IF + s.doppler + 3.0, code_freq=S.codeFreqBasis,
                                        code_phase=int(np.ceil(s.code_phase_samples)) + 1))
     p = track_params(S)
+    eng.track(p, inits)                         # first use: code loading, pinned and device allocations (as for the other configs' loops)
     t0 = time.time()
     fields, done, st = eng.track(p, inits)
     t_closed = time.time() - t0
@@ -152,6 +153,7 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
     locked = np.mean(np.abs(fields["I_P"][:, 1000:]), axis=1) > 3 * np.mean(np.abs(fields["Q_P"][:, 1000:]), axis=1)
     blks = np.ceil((S.codeLength - fields["remCodePhase"]) / (fields["codeFreq"] / fs)).astype(np.int64)
     chan_samples = int(blks.sum())
+    eng.track(p, inits, device_loop=True)       # first use
     t0 = time.time()
     dfields, ddone, dst = eng.track(p, inits, device_loop=True)
     t_dev = time.time() - t0
