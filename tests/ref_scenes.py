@@ -259,6 +259,11 @@ TRACK_SCENES = [
 LONG_TRACK_SCENES = [
     TrackScene("GPS_L1CA_long", "GPS/GPS_L1CA", "GPS_L1CA", "initSettings", dict(msToProcess=1200, numberOfChannels=3), _l1ca, oracle=_o_l1ca,
                notes="tracking.m:133-368 over 1.2 s: long-run equivalence of the loops, not only of single epochs"),
+    # the 3-state PLL of the other packages with a data + pilot pair, 800 epochs (GPS_L5C/include/tracking.m:255-382)
+    TrackScene("GPS_L5C_long", "GPS/GPS_L5C", "GPS_L5C", "initSettings_GPS_L5C", dict(msToProcess=800, numberOfChannels=3, pilotTRKflag=1),
+               _ten23("generateL5Icode", "generateL5Qcode", 1150.0, (6, 30), 1037), pilot=True,
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_l5_code(prn, "I")), O.pad_code(O.generate_l5_code(prn, "Q"))],
+                                 r=1.0, pll="3state", coef_variant="a", pilot_combine=1, code_freq_from_channel=True)),
 ]
 
 

@@ -88,19 +88,21 @@ def _tracking_against_the_reference(engine, sc, device_loop):
 
 
 @pytest.mark.parametrize("device_loop", [False, True], ids=["host_loop", "device_loop"])
-def test_long_closed_loop_stays_with_the_references_tracking_m(engine, device_loop):
-    """1200 epochs of the reference's own tracking.m (tests/golden/ref_track_GPS_L1CA_long.npz) against the HIP closed loops.  The
+@pytest.mark.parametrize("sc", RS.LONG_TRACK_SCENES, ids=[s.name for s in RS.LONG_TRACK_SCENES])
+def test_long_closed_loop_stays_with_the_references_tracking_m(engine, sc, device_loop):
+    """1200 epochs of the reference's own tracking.m (tests/golden/ref_track_GPS_L1CA_long.npz; 800 of GPS L5's with its 3-state PLL
+    and the data + pilot pair, ref_track_GPS_L5C_long.npz) against the HIP closed loops.  The
     GPU sums are float32-accumulated, so the loop state carries a small noise-like difference; what must hold over the whole run:
     block starts within one sample (two float implementations of ceil((L - rem)/step) may split a knife edge differently), NCOs
     within a small fraction of the loops' own jitter, identical lock, data bits and C/N0."""
     import cu_sdr_collection_amd as P
-    sc = RS.LONG_TRACK_SCENES[0]
     z = np.load(os.path.join(GOLD, f"ref_track_{sc.name}.npz"))
     S, rec, layout, ch = RS.scene_inputs(P, sc)
     assert RS.crc(rec) == int(z["record_crc32"][0])
     engine.load_if(rec, layout=layout, fs=S.samplingFreq)
     tr, _ = P.tracking(engine, ch, S, signal=sc.signal, device_loop=device_loop)
     assert [t.status for t in tr] == [str(s) for s in z["status"]]
+    n_ep = int(S.msToProcess)
     for k in range(2):
         t = tr[k]
         assert np.max(np.abs(t.absoluteSample - z["f_absoluteSample"][k])) <= 1.0
@@ -112,7 +114,9 @@ def test_long_closed_loop_stays_with_the_references_tracking_m(engine, device_lo
         full = 2 * 18000 * 28.0
         assert np.max(np.abs(t.I_P - z["f_I_P"][k])[same]) < 1e-4 * full and np.max(np.abs(t.Q_P - z["f_Q_P"][k])[same]) < 1e-4 * full
         assert np.array_equal(np.sign(t.I_P[100:]), np.sign(z["f_I_P"][k][100:]))                  # the same navigation bits
-        assert np.allclose(t.CNo.VSMValue, z["cno_VSMValue"][k], atol=1e-2) and len(t.CNo.VSMValue) == 1200 // int(S.CNo.VSMinterval)
+        assert np.allclose(t.CNo.VSMValue, z["cno_VSMValue"][k], atol=1e-2) and len(t.CNo.VSMValue) == n_ep // int(S.CNo.VSMinterval)
+        if sc.pilot:
+            assert np.max(np.abs(t.Pilot_I_P - z["f_Pilot_I_P"][k])[same]) < 1e-4 * full and np.max(np.abs(t.Pilot_Q_P - z["f_Pilot_Q_P"][k])[same]) < 1e-4 * full
 
 
 @pytest.mark.parametrize("sc", RS.ACQ_SCENES, ids=[s.name for s in RS.ACQ_SCENES])

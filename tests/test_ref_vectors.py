@@ -18,7 +18,10 @@ def _load(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 
 
-@pytest.mark.parametrize("sc", RS.TRACK_SCENES, ids=[s.name for s in RS.TRACK_SCENES])
+_ORACLE_TRACK = RS.TRACK_SCENES + RS.LONG_TRACK_SCENES[1:]     # (the 1200-epoch L1 C/A run has its own test below, with the C oracle)
+
+
+@pytest.mark.parametrize("sc", _ORACLE_TRACK, ids=[s.name for s in _ORACLE_TRACK])
 def test_oracle_tracking_equals_the_references_tracking_m(sc):
     """[trackResults, channel] = tracking(fid, channel, settings) of every package: every recorded field of every epoch.
     Tolerance 1e-12 relative (the float64 restatement differs from the interpreter's NumPy evaluation by summation order at most;
