@@ -259,6 +259,10 @@ TRACK_SCENES = [
 LONG_TRACK_SCENES = [
     TrackScene("GPS_L1CA_long", "GPS/GPS_L1CA", "GPS_L1CA", "initSettings", dict(msToProcess=1200, numberOfChannels=3), _l1ca, oracle=_o_l1ca,
                notes="tracking.m:133-368 over 1.2 s: long-run equivalence of the loops, not only of single epochs"),
+    # BOC(1,1) tables, 4-ms blocks, pilot averaged in phase (GAL_E1C/include/tracking.m:236-348): 300 epochs = 1.2 s
+    TrackScene("GAL_E1C_long", "GAL/GAL_E1C", "GAL_E1C", "initSettings_GAL_E1C", dict(msToProcess=1200, numberOfChannels=3), _e1, pilot=True,
+               oracle=_o_generic(tables=lambda O, prn: [O.pad_code(O.generate_e1_code(prn, "B")), O.pad_code(O.generate_e1_code(prn, "C"))],
+                                 r=2.0, pll="3state", coef_variant="a", pilot_combine=2, code_freq_from_channel=False)),
     # the 3-state PLL of the other packages with a data + pilot pair, 800 epochs (GPS_L5C/include/tracking.m:255-382)
     TrackScene("GPS_L5C_long", "GPS/GPS_L5C", "GPS_L5C", "initSettings_GPS_L5C", dict(msToProcess=800, numberOfChannels=3, pilotTRKflag=1),
                _ten23("generateL5Icode", "generateL5Qcode", 1150.0, (6, 30), 1037), pilot=True,

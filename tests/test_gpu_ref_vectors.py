@@ -102,7 +102,7 @@ def test_long_closed_loop_stays_with_the_references_tracking_m(engine, sc, devic
     engine.load_if(rec, layout=layout, fs=S.samplingFreq)
     tr, _ = P.tracking(engine, ch, S, signal=sc.signal, device_loop=device_loop)
     assert [t.status for t in tr] == [str(s) for s in z["status"]]
-    n_ep = int(S.msToProcess)
+    n_ep = tr[0].carrFreq.shape[0]
     for k in range(2):
         t = tr[k]
         assert np.max(np.abs(t.absoluteSample - z["f_absoluteSample"][k])) <= 1.0
@@ -110,13 +110,22 @@ def test_long_closed_loop_stays_with_the_references_tracking_m(engine, sc, devic
         assert same.mean() > 0.99
         jitter = float(np.std(z["f_carrFreq"][k][200:]))
         assert np.max(np.abs(t.carrFreq - z["f_carrFreq"][k])[same]) < max(2e-2, 0.02 * jitter), (k, jitter)
-        assert np.max(np.abs(t.codeFreq - z["f_codeFreq"][k])[same]) < 1e-3
-        full = 2 * 18000 * 28.0
-        assert np.max(np.abs(t.I_P - z["f_I_P"][k])[same]) < 1e-4 * full and np.max(np.abs(t.Q_P - z["f_Q_P"][k])[same]) < 1e-4 * full
+        # The code NCO: 1e-3 Hz for the 1-ms packages.  A 4-ms E1 block has 72 000 samples x 3 taps on half-chip entries: once the
+        # code phase has drifted 5e-8 chip from the reference's (float32 partial sums) a sample within that distance of a table edge -
+        # one in twenty-five epochs - lands on the other side, +-25 counts on one tap's sum; the DLL answers it, the code phases
+        # move apart a little more, more samples flip: the two loops decorrelate their sampling noise (epoch 261 of this scene) and
+        # from there differ like two noise realisations of it - up to 0.13 sigma of the loop's own code-NCO jitter (0.95 Hz), 0.4 % of
+        # the prompt sum - while every single block replayed from the reference's state still equals the oracle's to 0.02 counts.
+        code_jitter = float(np.std(z["f_codeFreq"][k][z["f_codeFreq"][k].shape[0] // 5:]))
+        tol_code = 1e-3 if S.intTime <= 0.001 else 0.25 * code_jitter
+        assert np.max(np.abs(t.codeFreq - z["f_codeFreq"][k])[same]) < tol_code, (k, code_jitter)
+        full = 2 * S.samplingFreq * S.intTime * 28.0
+        tol_sum = 1e-4 * full if S.intTime <= 0.001 else 0.01 * float(np.median(np.abs(z["f_I_P"][k])))
+        assert np.max(np.abs(t.I_P - z["f_I_P"][k])[same]) < tol_sum and np.max(np.abs(t.Q_P - z["f_Q_P"][k])[same]) < tol_sum
         assert np.array_equal(np.sign(t.I_P[100:]), np.sign(z["f_I_P"][k][100:]))                  # the same navigation bits
         assert np.allclose(t.CNo.VSMValue, z["cno_VSMValue"][k], atol=1e-2) and len(t.CNo.VSMValue) == n_ep // int(S.CNo.VSMinterval)
-        if sc.pilot:
-            assert np.max(np.abs(t.Pilot_I_P - z["f_Pilot_I_P"][k])[same]) < 1e-4 * full and np.max(np.abs(t.Pilot_Q_P - z["f_Pilot_Q_P"][k])[same]) < 1e-4 * full
+        if "f_Pilot_I_P" in z.files:
+            assert np.max(np.abs(t.Pilot_I_P - z["f_Pilot_I_P"][k])[same]) < tol_sum and np.max(np.abs(t.Pilot_Q_P - z["f_Pilot_Q_P"][k])[same]) < tol_sum
 
 
 @pytest.mark.parametrize("sc", RS.ACQ_SCENES, ids=[s.name for s in RS.ACQ_SCENES])
@@ -159,3 +168,49 @@ def test_hip_acquisition_of_an_int16_record_equals_the_references_acquisition_m(
             assert np.max(np.abs(have - want)) <= sc.metric_rtol * np.max(np.abs(want)), (sc.name, np.max(np.abs(have - want)) / np.max(np.abs(want)))
         else:
             assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
+
+
+@pytest.mark.parametrize("sc", RS.LONG_TRACK_SCENES, ids=[s.name for s in RS.LONG_TRACK_SCENES])
+def test_correlator_replayed_from_the_references_own_state_returns_the_references_sums(engine, sc):
+    """tracking.m records, per epoch, the state its block was cut from (absoluteSample, remCodePhase, codeFreq, carrFreq,
+    remCarrPhase: :212-216,249,277,314,332) next to the six sums: the HIP correlator fed with the REFERENCE's state - every epoch of
+    the long reference-executed runs, one batched launch - must return the reference's sums.  This takes the loop out of the
+    comparison: closed loops that differ by 5e-8 chip of code phase end up with different samples on the table edges and drift apart
+    like two noise realisations (the long closed-loop test above), the correlator itself does not."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import signals
+    z = np.load(os.path.join(GOLD, f"ref_track_{sc.name}.npz"))
+    S, rec, layout, ch = RS.scene_inputs(P, sc)
+    engine.load_if(rec, layout=layout, fs=S.samplingFreq)
+    spec = signals.SIGNALS[sc.signal]
+    nch, n_ep = 2, z["f_carrFreq"].shape[1]
+    for k in range(nch):
+        engine.set_channel(k, spec.tables(int(z["PRN"][k]), S), index_scale=spec.index_scale, arm_mult=spec.arm_mult, windows=spec.windows)
+    blocks = engine.make_blocks(nch * n_ep)
+    fs = S.samplingFreq
+    for e in range(n_ep):
+        for k in range(nch):
+            b = blocks[e * nch + k]
+            step = float(z["f_codeFreq"][k][e]) / fs
+            rem = float(z["f_remCodePhase"][k][e])
+            b.channel = k
+            b.first_sample = int(z["f_absoluteSample"][k][e])
+            b.rem_code_phase = rem
+            b.code_phase_step = step
+            b.blksize = int(np.ceil((S.codeLength - rem) / step))                                   # tracking.m:219-222
+            b.el_spacing = S.dllCorrelatorSpacing
+            b.carr_freq = float(z["f_carrFreq"][k][e])
+            b.rem_carr_phase = float(z["f_remCarrPhase"][k][e])
+    engine.replay_prepare(blocks)
+    engine.replay_launch()
+    out = engine.replay_fetch().reshape(n_ep, nch, -1, 6)
+    full = 2 * fs * S.intTime * 28.0
+    names = ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")
+    for k in range(nch):
+        want = np.stack([z["f_" + n][k] for n in names], axis=1)
+        d = np.max(np.abs(out[:, k, 0, :] - want)) / full
+        assert d < 2e-6, (sc.name, k, d)
+        if "f_Pilot_I_P" in z.files and spec.pilot_combine in (1, 2, 3):
+            # GPS L5 records the pilot arm as correlated (Pilot_I_P / Pilot_Q_P, GPS_L5C/include/tracking.m:321-326)
+            dp = max(np.max(np.abs(out[:, k, 1, 2] - z["f_Pilot_I_P"][k])), np.max(np.abs(out[:, k, 1, 3] - z["f_Pilot_Q_P"][k]))) / full
+            assert dp < 2e-6, (sc.name, k, dp)
