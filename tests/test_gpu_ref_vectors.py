@@ -170,11 +170,17 @@ def test_hip_acquisition_of_an_int16_record_equals_the_references_acquisition_m(
             assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
 
 
-@pytest.mark.parametrize("sc", RS.LONG_TRACK_SCENES, ids=[s.name for s in RS.LONG_TRACK_SCENES])
+# (GPS L2C records its positions and code phases in single-code units, shifted by the remainder: GPS_L2C tracking.m:223,250,376 - its
+# correlator is compared through the closed loops above)
+_REPLAY_SCENES = [s for s in RS.TRACK_SCENES if s.name != "GPS_L2C"] + RS.LONG_TRACK_SCENES
+
+
+@pytest.mark.parametrize("sc", _REPLAY_SCENES, ids=[s.name for s in _REPLAY_SCENES])
 def test_correlator_replayed_from_the_references_own_state_returns_the_references_sums(engine, sc):
     """tracking.m records, per epoch, the state its block was cut from (absoluteSample, remCodePhase, codeFreq, carrFreq,
     remCarrPhase: :212-216,249,277,314,332) next to the six sums: the HIP correlator fed with the REFERENCE's state - every epoch of
-    the long reference-executed runs, one batched launch - must return the reference's sums.  This takes the loop out of the
+    the reference-executed runs (fifteen packages / record formats and the three long runs), one batched launch each - must return
+    the reference's sums.  This takes the loop out of the
     comparison: closed loops that differ by 5e-8 chip of code phase end up with different samples on the table edges and drift apart
     like two noise realisations (the long closed-loop test above), the correlator itself does not."""
     import cu_sdr_collection_amd as P
@@ -183,7 +189,8 @@ def test_correlator_replayed_from_the_references_own_state_returns_the_reference
     S, rec, layout, ch = RS.scene_inputs(P, sc)
     engine.load_if(rec, layout=layout, fs=S.samplingFreq)
     spec = signals.SIGNALS[sc.signal]
-    nch, n_ep = 2, z["f_carrFreq"].shape[1]
+    nch, n_ep = sum(1 for s in z["status"] if str(s) == "T"), z["f_carrFreq"].shape[1]
+    assert nch == 2 and np.all(np.isfinite(z["f_absoluteSample"][:nch]))
     for k in range(nch):
         engine.set_channel(k, spec.tables(int(z["PRN"][k]), S), index_scale=spec.index_scale, arm_mult=spec.arm_mult, windows=spec.windows)
     blocks = engine.make_blocks(nch * n_ep)
@@ -204,7 +211,8 @@ def test_correlator_replayed_from_the_references_own_state_returns_the_reference
     engine.replay_prepare(blocks)
     engine.replay_launch()
     out = engine.replay_fetch().reshape(n_ep, nch, -1, 6)
-    full = 2 * fs * S.intTime * 28.0
+    comp = 1 if layout == RS.GC_REAL else 2
+    full = comp * fs * S.intTime * 28.0 * (5.0 if rec.dtype == np.int16 else 1.0)
     names = ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")
     for k in range(nch):
         want = np.stack([z["f_" + n][k] for n in names], axis=1)
