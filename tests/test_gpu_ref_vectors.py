@@ -170,9 +170,7 @@ def test_hip_acquisition_of_an_int16_record_equals_the_references_acquisition_m(
             assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
 
 
-# (GPS L2C records its positions and code phases in single-code units, shifted by the remainder: GPS_L2C tracking.m:223,250,376 - its
-# correlator is compared through the closed loops above)
-_REPLAY_SCENES = [s for s in RS.TRACK_SCENES if s.name != "GPS_L2C"] + RS.LONG_TRACK_SCENES
+_REPLAY_SCENES = RS.TRACK_SCENES + RS.LONG_TRACK_SCENES
 
 
 @pytest.mark.parametrize("sc", _REPLAY_SCENES, ids=[s.name for s in _REPLAY_SCENES])
@@ -195,17 +193,26 @@ def test_correlator_replayed_from_the_references_own_state_returns_the_reference
         engine.set_channel(k, spec.tables(int(z["PRN"][k]), S), index_scale=spec.index_scale, arm_mult=spec.arm_mult, windows=spec.windows)
     blocks = engine.make_blocks(nch * n_ep)
     fs = S.samplingFreq
+    l2c = spec.doubled_code
     for e in range(n_ep):
         for k in range(nch):
             b = blocks[e * nch + k]
             step = float(z["f_codeFreq"][k][e]) / fs
             rem = float(z["f_remCodePhase"][k][e])
+            pos = float(z["f_absoluteSample"][k][e])
+            length, spacing = S.codeLength, S.dllCorrelatorSpacing
+            if l2c:
+                # GPS L2C works on the RZ-doubled code (GPS_L2C tracking.m:107-109,171) and RECORDS in single-code units, the position
+                # pushed back by the remainder in samples (:223,250,376,382-383): undo that to get the block the sums were taken over
+                step, rem, length, spacing = 2 * step, 2 * rem, 2 * S.codeLength, 2 * S.dllCorrelatorSpacing
+                pos = float(np.rint(pos - 1 + rem / step))
+                b.table_offset[1] = int(length) * ((int(ch[k].CLCodePhase) - 1 + e) % 75)       # :261,357-360
             b.channel = k
-            b.first_sample = int(z["f_absoluteSample"][k][e])
+            b.first_sample = int(pos)
             b.rem_code_phase = rem
             b.code_phase_step = step
-            b.blksize = int(np.ceil((S.codeLength - rem) / step))                                   # tracking.m:219-222
-            b.el_spacing = S.dllCorrelatorSpacing
+            b.blksize = int(np.ceil((length - rem) / step))                                         # tracking.m:219-222
+            b.el_spacing = spacing
             b.carr_freq = float(z["f_carrFreq"][k][e])
             b.rem_carr_phase = float(z["f_remCarrPhase"][k][e])
     engine.replay_prepare(blocks)
