@@ -229,3 +229,12 @@ def test_correlator_replayed_from_the_references_own_state_returns_the_reference
             # GPS L5 records the pilot arm as correlated (Pilot_I_P / Pilot_Q_P, GPS_L5C/include/tracking.m:321-326)
             dp = max(np.max(np.abs(out[:, k, 1, 2] - z["f_Pilot_I_P"][k])), np.max(np.abs(out[:, k, 1, 3] - z["f_Pilot_Q_P"][k]))) / full
             assert dp < 2e-6, (sc.name, k, dp)
+        if spec.pilot_combine == 4:
+            # BDS B1C wide-band records ONE pilot: the BOC(6,1) and BOC(1,1) pilot arms folded sqrt(4/33) : sqrt(29/33) in
+            # quadrature (WB_tracking.m:364-369) - formed here from the two arms the correlator returns
+            a61, a11 = -np.sqrt(4.0 / 33.0), np.sqrt(29.0 / 33.0)
+            for x, tap in enumerate(("E", "P", "L")):
+                i11, q11, i61, q61 = out[:, k, 1, 2 * x], out[:, k, 1, 2 * x + 1], out[:, k, 2, 2 * x], out[:, k, 2, 2 * x + 1]
+                di = np.max(np.abs(a61 * i61 + a11 * q11 - z["f_Pilot_I_" + tap][k])) / full
+                dq = np.max(np.abs(a61 * q61 - a11 * i11 - z["f_Pilot_Q_" + tap][k])) / full
+                assert di < 2e-6 and dq < 2e-6, (sc.name, k, tap, di, dq)
