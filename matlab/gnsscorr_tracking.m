@@ -138,7 +138,15 @@ if windowed
     [trk, epochs, status, cno] = gnsscorr_mex('track_file', h, p, chanTable, fileName, settings.gnsscorrWindowSamples, settings.dataType, ...
                                               settings.fileType, order);
 else
-    [trk, epochs, status, cno] = gnsscorr_mex('track', h, p, chanTable);  % trk(epoch, (k-1)*21 + field), fields as gc_track_field
+    status = -6;
+    if isfield(settings, 'gnsscorrDeviceLoop') && settings.gnsscorrDeviceLoop
+        % tracking.m:302-335 closed on the GPU as well, one persistent launch for all epochs (gc_track_device); -6 = a
+        % configuration it does not cover (three-arm channels whose third arm is not derivable): the host-closed loop then
+        [trk, epochs, status, cno] = gnsscorr_mex('track_device', h, p, chanTable);
+    end
+    if status == -6
+        [trk, epochs, status, cno] = gnsscorr_mex('track', h, p, chanTable);  % trk(epoch, (k-1)*21 + field), fields as gc_track_field
+    end
 end
 
 %--- records (tracking.m:212-216,249,277,314,332,338-348) ------------------------------------------------------------------------
