@@ -16,8 +16,15 @@ CBOC(6,1,1/11) x 8, GPS L5 + BDS B2a x 16 at 50 Msps (int8 and int16 records), a
 all-constellation mix.  --config mix runs the whole 64-channel mix (configs[4]) sharded over the ranks by IF record (band).
 
 N > 1: one rank per GPU.  `python bench.py --gpus N` starts the N ranks itself; under torch.distributed.run it joins the
-launcher's ranks.  Channels shard across GPUs with no data-path collective - every rank tracks its own 12 channels on its own
-copy of the record - so scaling is "weak"; the control plane (barrier + max over ranks) is torch.distributed/gloo.
+launcher's ranks.  Channels shard across GPUs (tracking.m:133: channels share nothing but the read-only record), every rank
+tracks its own 12 channels, so scaling is "weak".  The one exchange step of the sharded path is the record hand-over: the rank
+that holds the IF record (rank 0; in the mix the first rank of each band) broadcasts it to the ranks that track other channels of
+it - sharding.broadcast_record / distribute_band_records, RCCL over xGMI (process group "cpu:gloo,cuda:nccl"), adopted by the
+engines without a copy (gc_attach_if) - and it is timed and reported (`handover`) next to the tracking numbers; --no-handover
+lets every rank synthesise its own copy instead (A/B).  Acquisition shards by PRN (sharding.shard_prns / merge_acq_results).
+The control plane (barrier + max over ranks) uses the same group's gloo side.  GC_BENCH_DEVICE=i puts every rank on device i
+(functional check of the N > 1 path on a 1-GPU box): RCCL refuses two ranks on one GPU, so there the record travels through the
+hosts (gloo) and the ranks take turns for their closed loops (persistent kernels need their whole grid resident).
 """
 from __future__ import annotations
 
@@ -58,16 +65,34 @@ def _spawn_ranks(n: int) -> int:
 
 
 class Ranks:
-    """Control plane: barrier + MAX-reduce over ranks (gloo on CPU tensors); a no-op at world size 1."""
+    """Control plane (barrier, MAX / SUM over ranks: gloo on CPU tensors) and data plane (the record hand-over: RCCL on GPU
+    tensors) of the N ranks; a no-op at world size 1.  torch's side of the GPU is initialised here, BEFORE the first Engine:
+    torch ships its own copy of the HIP runtime and whichever copy touches the device first serves the process."""
 
-    def __init__(self, rank, world):
-        self.rank, self.world, self.dist = rank, world, None
+    def __init__(self, rank, world, device=0):
+        self.rank, self.world, self.dist, self.device = rank, world, None, device
+        self.shared_device = world > 1 and "GC_BENCH_DEVICE" in os.environ     # every rank on ONE GPU: no RCCL communicator possible
+        self.rccl = False
         if world > 1 or os.environ.get("GC_BENCH_FORCE_DIST"):
+            import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            backend = "gloo"
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device)
+                torch.cuda.init()
+                if not self.shared_device and os.environ.get("GC_BENCH_BACKEND", "rccl") != "gloo":
+                    backend, self.rccl = "cpu:gloo,cuda:nccl", True
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
             self.dist = dist
+
+    @property
+    def data_backend(self):
+        return "nccl (RCCL over xGMI)" if self.rccl else "gloo through the hosts (ranks share one GPU: RCCL needs one GPU per rank)"
+
+    def torch_device(self):
+        return f"cuda:{self.device}"
 
     def barrier(self):
         if self.dist is not None:
@@ -81,9 +106,47 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
         return [float(x) for x in t]
 
+    def gather(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def turn(self):
+        """Context manager around a closed-loop phase: ranks that share one GPU run theirs one after the other (a persistent
+        kernel spins until its whole grid is resident, and the library's admission ledger sees its own process only)."""
+        import contextlib
+        if not self.shared_device:
+            return contextlib.nullcontext()
+        import fcntl
+
+        @contextlib.contextmanager
+        def locked():
+            with open(f"/tmp/gc_bench_device{self.device}.lock", "w") as f:
+                fcntl.flock(f, fcntl.LOCK_EX)
+                try:
+                    yield
+                finally:
+                    fcntl.flock(f, fcntl.LOCK_UN)
+        return locked()
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
+
+
+def _record_tensor(R: "Ranks", eng, n_samples: int, dtype=np.int8, layout=None):
+    """A torch tensor on this rank's GPU holding one IF record, adopted by `eng` (gc_attach_if): what the source rank synthesises
+    into and what it then broadcasts."""
+    import torch
+    from cu_sdr_collection_amd import _lib as L
+    comp = 2
+    t = torch.empty(n_samples * comp + 64, dtype=torch.int16 if np.dtype(dtype) == np.int16 else torch.int8, device=R.torch_device())
+    t[-64:] = 0
+    torch.cuda.synchronize()
+    eng.attach_if(t.data_ptr(), n_samples, dtype=dtype, layout=L.GC_IQ if layout is None else layout)
+    return t
 
 
 def _traffic(kind: str, blocks: int):
@@ -133,10 +196,39 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
     S.msToProcess, S.numberOfChannels = n_epochs, nch
     eng = P.Engine(device)
     dev_name, cus = eng.device_info()
-    sats = P.synth.scene(nch, 20241008 + 2, fs)
-    t0 = time.time()
-    P.synth.generate_if_gpu(eng, sats, n_samples, fs, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023, seed=20241008 + 2)
-    t_synth = time.time() - t0
+    # N = 1: the 12 satellites of SURVEY.md §8d config 2.  N > 1: ONE record for all ranks carrying min(32, 12 N) satellites, of
+    # which rank r tracks twelve (its channel shard; with more than 32 channels in all, PRNs are tracked by more than one rank)
+    n_sats = nch if R.world == 1 else min(32, nch * R.world)
+    scene = P.synth.scene(n_sats, 20241008 + 2, fs)
+    sats = [scene[(nch * R.rank + i) % n_sats] for i in range(nch)]
+    handover, rec_t = None, None
+    seed = 20241008 + 2
+    if R.world > 1 and not args.no_handover:
+        # the sharded path's one exchange step: rank 0 holds the record (synthesised into a torch tensor, standing
+        # for fread + upload), broadcasts it over RCCL, and every rank's engine adopts what arrived without a copy
+        from cu_sdr_collection_amd.sharding import broadcast_record
+        import torch
+        t0 = time.time()
+        if R.rank == 0:
+            rec_t = _record_tensor(R, eng, n_samples)
+            P.synth.generate_if_gpu(eng, scene, n_samples, fs, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023, seed=seed, attached=True)
+            eng.synchronize()
+        t_synth = time.time() - t0
+        R.barrier()
+        t0 = time.perf_counter()
+        rec_t = broadcast_record(rec_t, src=0, device=R.torch_device(), via_host=not R.rccl)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+        if R.rank != 0:
+            eng.attach_if(rec_t.data_ptr(), n_samples)
+        (t_bcast,) = R.reduce([t_bcast])
+        nbytes = int(rec_t.numel())
+        handover = {"what": "rank 0 -> all ranks: sharding.broadcast_record of the IF record, adopted by gc_attach_if", "backend": R.data_backend,
+                    "bytes": nbytes, "seconds": round(t_bcast, 4), "GBps_per_receiver": round(nbytes / t_bcast / 1e9, 2)}
+    else:
+        t0 = time.time()
+        P.synth.generate_if_gpu(eng, scene, n_samples, fs, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023, seed=seed)
+        t_synth = time.time() - t0
     eng.set_sampling_freq(fs)
     inits = []
     for i, s in enumerate(sats):   # channel table as preRun would hand it over (truth + a 3 Hz acquisition residual)
@@ -144,19 +236,21 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
         inits.append(L.gc_channel_init(channel=i, prn=s.prn, acquired_freq=S.IF + s.doppler + 3.0, code_freq=S.codeFreqBasis,
                                        code_phase=int(np.ceil(s.code_phase_samples)) + 1))
     p = track_params(S)
-    eng.track(p, inits)                         # first use: code loading, pinned and device allocations (as for the other configs' loops)
-    t0 = time.time()
-    fields, done, st = eng.track(p, inits)
-    t_closed = time.time() - t0
+    with R.turn():
+        eng.track(p, inits)                         # first use: code loading, pinned and device allocations (as for the other configs' loops)
+        t0 = time.time()
+        fields, done, st = eng.track(p, inits)
+        t_closed = time.time() - t0
     if st != 0 or int(done.min()) != n_epochs:
         raise RuntimeError(f"closed-loop tracking stopped early: status {st}, epochs {done}")
     locked = np.mean(np.abs(fields["I_P"][:, 1000:]), axis=1) > 3 * np.mean(np.abs(fields["Q_P"][:, 1000:]), axis=1)
     blks = np.ceil((S.codeLength - fields["remCodePhase"]) / (fields["codeFreq"] / fs)).astype(np.int64)
     chan_samples = int(blks.sum())
-    eng.track(p, inits, device_loop=True)       # first use
-    t0 = time.time()
-    dfields, ddone, dst = eng.track(p, inits, device_loop=True)
-    t_dev = time.time() - t0
+    with R.turn():
+        eng.track(p, inits, device_loop=True)       # first use
+        t0 = time.time()
+        dfields, ddone, dst = eng.track(p, inits, device_loop=True)
+        t_dev = time.time() - t0
     dev_loop = None
     if dst == 0 and int(ddone.min()) == n_epochs:
         diff = dfields["absoluteSample"] != fields["absoluteSample"]
@@ -212,7 +306,8 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
         "config": {"workload": f"GPS L1 C/A, {nch} channels/GPU, 1-ms E/P/L correlators, {args.seconds:g} s of int8 I/Q IF at 18 Msps "
                                f"({n_samples * 2 / 1e9:.2f} GB in HBM), batched replay of {nb} blocks per step",
                    "channels_per_gpu": nch, "epochs": n_epochs, "blocks_per_step": nb, "prewarm_ms": args.prewarm_ms,
-                   "parallelism": f"channels sharded over {R.world} GPU(s), no data-path collective"},
+                   "parallelism": (f"channels sharded over {R.world} GPU(s); one exchange step: the record hand-over ({R.data_backend})" if handover
+                                   else f"channels sharded over {R.world} GPU(s), every rank synthesises its own copy of the record (no hand-over)")},
         "corr_msps": round(corr_msps, 1), "corr_msps_unit": "Msamples/s (channel-samples, all GPUs)",
         "if_msps_per_gpu": round(value / R.world, 1), "x_realtime_replay": round(value / R.world / (fs / 1e6), 1),
         "closed_loop": {"corr_msps": round(chan_samples / t_closed / 1e6, 1), "x_realtime": round(chan_samples / t_closed / 1e6 / nch / (fs / 1e6), 2),
@@ -224,20 +319,38 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
                      "algorithmic_bytes_per_launch": algo_bytes},
         "replay_vs_closed_loop_max_dev": replay_dev, "device": dev_name, "compute_units": cus, "synth_s": round(t_synth, 2),
     }
-    return result, dict(eng=eng, S=S, sats=sats, inits=inits, fields=fields, n_epochs=n_epochs, n_samples=n_samples, job=job)
+    if handover:
+        result["handover"] = handover
+    if R.world > 1:
+        lock = R.gather({"rank": R.rank, "channels_locked": int(locked.sum()), "prns": [s.prn for s in sats], "replay_vs_closed_loop_max_dev": replay_dev,
+                         "kernel_ms": round(kernel_ms, 4), "frac": round(achieved / HBM_PEAK_GBPS, 4)})
+        result["ranks"] = lock
+    return result, dict(eng=eng, S=S, sats=sats, scene=scene, inits=inits, fields=fields, n_epochs=n_epochs, n_samples=n_samples, job=job, record=rec_t)
 
 
-def run_acquisition(P, eng, sats):
-    """The other half of the hot path at the reference's defaults: 32 PRNs x 29 bins x 20 ms (acquisition.m:116-260)."""
+def run_acquisition(P, eng, sats, R: Ranks):
+    """The other half of the hot path at the reference's defaults: 32 PRNs x 29 bins x 20 ms (acquisition.m:116-260).  N > 1: the
+    PRN list shards over the ranks (sharding.shard_prns: every rank transforms the record's 20 hops itself - they are hoisted out
+    of the PRN loop - and searches its share); rank 0 merges the acqResults (merge_acq_results, disjoint shares: exact)."""
     from cu_sdr_collection_amd.receiver import acquisition as gpu_acquisition
+    from cu_sdr_collection_amd.sharding import merge_acq_results, shard_prns
     Sa = P.initSettings()
+    full = list(Sa.acqSatelliteList)
+    Sa.acqSatelliteList = shard_prns(full, R.world, R.rank)
     gpu_acquisition(eng, Sa)  # warm-up (plans, twiddles, scratch)
+    eng.synchronize()
+    R.barrier()
     t0 = time.perf_counter()
     acq = gpu_acquisition(eng, Sa)
     t_acq = time.perf_counter() - t0
+    (t_acq,) = R.reduce([t_acq])
+    acq = merge_acq_results(R.gather(acq))
     found = sorted(int(i) + 1 for i in np.nonzero(acq.carrFreq)[0])
-    return {"seconds": round(t_acq, 4), "prns_searched": 32, "bins": 29, "non_coh_ms": 20, "fft_size": 36000, "acquired": found,
-            "all_scene_prns_found": sorted(s.prn for s in sats) == found}
+    truth = {s.prn: s for s in sats}
+    phase_ok = all(abs(((int(acq.codePhase[p - 1]) - 1 - truth[p].code_phase_samples + 9000) % 18000) - 9000) <= 2.0 for p in found if p in truth)
+    return {"seconds": round(t_acq, 4), "prns_searched": len(full), "prns_per_rank": len(Sa.acqSatelliteList), "bins": 29, "non_coh_ms": 20, "fft_size": 36000,
+            "acquired": found, "all_scene_prns_found": sorted(truth) == found, "code_phases_within_two_samples_of_the_scene": bool(phase_ok),
+            "sharding": f"PRN list round-robin over {R.world} rank(s)"}
 
 
 # =======================================================================================================================
@@ -303,28 +416,72 @@ def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, see
 
 def run_mix(P, W, args, R: Ranks, device: int):
     """BASELINE configs[4]: 64 channels of the twelve signals sharded over the ranks by band (sharding.shard_bands: every rank
-    8 channels, each band's record on as few GPUs as possible).  Every rank that tracks a band synthesises that band's record
-    from the same seed - standing for the file read + broadcast_record hand-over of a real run - and runs one
-    tracking job per package on it, all jobs of the rank concurrently (gc_track_multi)."""
-    from cu_sdr_collection_amd.sharding import band_ranks, shard_bands
+    8 channels, each band's record on as few GPUs as possible).  The hand-over of a real run, end to end: for every band the first
+    rank that tracks one of its channels holds the record (synthesised into a torch tensor on its GPU, standing for fread +
+    upload), sharding.distribute_band_records broadcasts it to the band's other ranks - one process group per band, RCCL over
+    xGMI - and every rank's engines adopt what arrived (gc_attach_if).  Then one tracking job per package, all jobs of a rank
+    concurrently (gc_track_multi).  --no-handover: every rank of a band synthesises its own copy from the same seed."""
+    from cu_sdr_collection_amd import _lib as L
+    from cu_sdr_collection_amd.sharding import band_ranks, distribute_band_records, shard_bands
     counts = {b: sum(n for _, n in parts) for b, parts in W.MIX_BANDS.items()}
     plan = shard_bands(counts, R.world)
     mine = plan[R.rank]
+    readers = band_ranks(plan)
     band_fs = {"L2": 8e6, "GLO_L1": 12e6, "GLO_L2": 12e6}
     band_if = {"GLO_L1": 0.0, "GLO_L2": 0.0}
-    jobs, bands_here, t_synth = [], [], 0.0
-    for bi, band in enumerate(sorted(W.MIX_BANDS)):
+    band_order = sorted(W.MIX_BANDS)
+    fs_of = lambda b: band_fs.get(b, 18e6)
+    seed_of = lambda b: 5000 + 101 * band_order.index(b)
+    nsamp_of = lambda b: int(round(args.mix_seconds * fs_of(b)))
+    first_engine, t_synth = {}, [0.0]
+    handover = None
+    if R.world > 1 and not args.no_handover:
+        import torch
+
+        def read_record(band):           # runs on the band's first rank only
+            eng = P.Engine(device)
+            t0 = time.time()
+            t = _record_tensor(R, eng, nsamp_of(band), layout=L.GC_QI if W.band_is_qi(W.MIX_BANDS[band]) else L.GC_IQ)
+            W.make_band(P, eng, W.MIX_BANDS[band], args.mix_seconds, fs_of(band), band_if.get(band, 20e3), seed_of(band), attached=True)
+            eng.synchronize()
+            t_synth[0] += time.time() - t0
+            first_engine[band] = eng
+            return t
+
+        timings = {}
+        R.barrier()
+        t0 = time.perf_counter()
+        records = distribute_band_records(plan, read_record, device=R.torch_device(), via_host=not R.rccl, timings=timings)
+        torch.cuda.synchronize()
+        R.barrier()
+        t_all = time.perf_counter() - t0 - t_synth[0]
+        per_band = {b: {"seconds": round(dt, 4), "bytes": nb, "GBps": round(nb / dt / 1e9, 2)} for b, (dt, nb) in timings.items()}
+        handover = {"what": "per band: first rank -> the band's other ranks (sharding.distribute_band_records, one process group per band), adopted by gc_attach_if",
+                    "backend": R.data_backend, "bands_received_or_sent_here": per_band, "seconds_all_bands_this_rank": round(max(t_all, 0.0), 4)}
+    jobs, bands_here = [], []
+    for band in band_order:
         idx = sorted(i for b, i in mine if b == band)
         if not idx:
             continue
         bands_here.append(band)
         parts = W.MIX_BANDS[band]
-        fs = band_fs.get(band, 18e6)
-        engines = [P.Engine(device) for _ in parts]
-        t0 = time.time()
-        made = W.make_band(P, engines[0], parts, args.mix_seconds, fs, band_if.get(band, 20e3), 5000 + 101 * bi)
-        t_synth += time.time() - t0
+        fs = fs_of(band)
+        if handover is not None:
+            made, _ = W.band_scene(P, parts, fs, seed_of(band))
+            eng0 = first_engine.get(band)
+            if eng0 is None:               # the record arrived over the wire
+                eng0 = P.Engine(device)
+                eng0.attach_if(records[band].data_ptr(), nsamp_of(band), layout=L.GC_QI if W.band_is_qi(parts) else L.GC_IQ)
+            eng0.set_sampling_freq(fs)
+            eng0._record_tensor = records[band]          # keep the tensor alive as long as the engine reads it
+            engines = [eng0] + [P.Engine(device) for _ in parts[1:]]
+        else:
+            engines = [P.Engine(device) for _ in parts]
+            t0 = time.time()
+            made = W.make_band(P, engines[0], parts, args.mix_seconds, fs, band_if.get(band, 20e3), seed_of(band))
+            t_synth[0] += time.time() - t0
         off = 0
+        owner_used = False
         for (pkg, S, sats), eng in zip(made, engines):
             sel = [s for k, s in enumerate(sats) if off + k in idx]       # this rank's channels of the package
             off += len(sats)
@@ -336,12 +493,16 @@ def run_mix(P, W, args, R: Ranks, device: int):
                 eng.share_if(engines[0])
             n_ep = int((args.mix_seconds - 3 * S.intTime) / S.intTime) - 1
             jobs.append(W.prepare_job(P, W.Job(f"{band}:{pkg.signal}", pkg, S, sel, eng), n_ep))
-    W.run_closed_loops(P, jobs, device_loop=False)
-    t_host, recs = W.run_closed_loops(P, jobs, device_loop=False)
+            jobs[-1].record_dtype = np.dtype(np.int8)
+            jobs[-1].swap_iq = W.band_is_qi(parts)
+    with R.turn():
+        W.run_closed_loops(P, jobs, device_loop=False)
+        t_host, recs = W.run_closed_loops(P, jobs, device_loop=False)
     for j, f in zip(jobs, recs):
         W.keep_records(j, f)
-    W.run_closed_loops(P, jobs, device_loop=True)
-    t_dev, _ = W.run_closed_loops(P, jobs, device_loop=True)
+    with R.turn():
+        W.run_closed_loops(P, jobs, device_loop=True)
+        t_dev, drecs = W.run_closed_loops(P, jobs, device_loop=True)
     per_job, cs_total, bytes_total = [], 0.0, 0.0
     for j in jobs:
         blocks, _ = W.replay_blocks(j)
@@ -366,24 +527,35 @@ def run_mix(P, W, args, R: Ranks, device: int):
     (elapsed,) = R.reduce([elapsed])
     cs_all, nch_all, bytes_all = R.reduce([cs_total, float(sum(len(j.sats) for j in jobs)), bytes_total], op="sum")
     kernel_ms = 0.0
-    for j in jobs:                        # per-kernel times, one job at a time (hipEvents on the job's stream)
+    spots = {}
+    if args.spot_check:                   # CPU side, after every timed region: the only place of this function that touches oracle/
+        from oracle import gnss_oracle as O
+        for j in jobs:
+            spots[j.name] = oracle_spot_check(P, W, O, j, nblocks=3)
+    for j, df in zip(jobs, drecs):        # per-kernel times, one job at a time (hipEvents on the job's stream)
         j.engine.timer_start()
         for _ in range(args.steps):
             j.engine.replay_launch()
         ms = j.engine.timer_stop() / args.steps
         kernel_ms += ms
         cs = float(j.blks.sum())
-        per_job.append({"job": j.name, "channels": len(j.sats), "kernel": W.KERNEL_NAMES.get(j.engine.last_kernel()), "kernel_ms": round(ms, 4),
-                        "achieved_GBps": round(2.0 * cs / ms / 1e6, 1), "frac": round(2.0 * cs / ms / 1e6 / HBM_PEAK_GBPS, 4), "channels_locked": W.locked(j)})
+        out = j.engine.replay_fetch()[:, 0, :]
+        rec = np.stack([j.fields[f].T.reshape(-1) for f in ("I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L")], axis=1)
+        replay_dev = float(np.max(np.abs(out - rec)) / (2.0 * float(j.blks.mean()) * 28.0))
+        dj = W.Job(j.name, j.pkg, j.S, j.sats, j.engine, params=j.params)
+        W.keep_records(dj, df)
+        per_job.append({"job": j.name, "channels": len(j.sats), "epochs": j.params.n_epochs, "kernel": W.KERNEL_NAMES.get(j.engine.last_kernel()),
+                        "kernel_ms": round(ms, 4), "achieved_GBps": round(2.0 * cs / ms / 1e6, 1), "frac": round(2.0 * cs / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                        "channels_locked": W.locked(j), "channels_locked_device_loop": W.locked(dj), "replay_vs_closed_loop_max_dev": replay_dev,
+                        "oracle_spot_check_max_dev_rel_sum_abs_x": spots.get(j.name)})
     name, cus = jobs[0].engine.device_info()
     corr_msps = cs_all * args.steps / elapsed / 1e6
     achieved = bytes_total / (kernel_ms * 1e-3) / 1e9
-    mine_summary = {"rank": R.rank, "bands": bands_here, "jobs": per_job, "closed_loop_host_s": round(t_host, 4), "closed_loop_device_s": round(t_dev, 4)}
-    gathered = [mine_summary]
-    if R.dist is not None:
-        gathered = [None] * R.world
-        R.dist.all_gather_object(gathered, mine_summary)
+    mine_summary = {"rank": R.rank, "bands": bands_here, "jobs": per_job, "closed_loop_host_s": round(t_host, 4), "closed_loop_device_s": round(t_dev, 4),
+                    "handover": handover}
+    gathered = R.gather(mine_summary)
     t_host_max, t_dev_max = R.reduce([t_host, t_dev])
+    all_jobs = [j for r in gathered for j in r["jobs"]]
     result = {
         "metric": METRIC, "value": round(corr_msps / (nch_all / R.world), 1), "unit": "IF Msamples/s (channel-samples / channels per GPU, all GPUs)",
         "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
@@ -392,14 +564,19 @@ def run_mix(P, W, args, R: Ranks, device: int):
         "config": {"workload": f"all-constellation mix: {int(nch_all)} channels of {len(W.PACKAGES) - 1} signals in {len(W.MIX_BANDS)} band records "
                                f"({args.mix_seconds:g} s each), sharded by band over {R.world} GPU(s), every rank's packages tracked concurrently",
                    "bands": {b: parts for b, parts in W.MIX_BANDS.items()}, "plan_bands_per_rank": {str(r): sorted({b for b, _ in p}) for r, p in enumerate(plan)},
-                   "band_reader_ranks": band_ranks(plan), "parallelism": "channels sharded by IF record; the record hand-over is the only exchange step"},
+                   "band_reader_ranks": readers,
+                   "parallelism": (f"channels sharded by IF record; exchange step: the band records' hand-over ({R.data_backend})" if handover
+                                   else "channels sharded by IF record; every rank of a band synthesises its own copy (no hand-over)")},
         "corr_msps": round(corr_msps, 1),
+        "channels": int(nch_all), "channels_locked": int(sum(j["channels_locked"] for j in all_jobs)),
+        "channels_locked_device_loop": int(sum(j["channels_locked_device_loop"] for j in all_jobs)),
+        "signals": sorted({j["job"].split(":")[1] for j in all_jobs}),
         "closed_loop_host": {"seconds": round(t_host_max, 4), "x_realtime": round(args.mix_seconds / t_host_max, 1)},
         "closed_loop_device": {"seconds": round(t_dev_max, 4), "x_realtime": round(args.mix_seconds / t_dev_max, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": None, "kernel": "sum over rank 0's replay kernels (per job under ranks)", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": bytes_total},
-        "ranks": gathered, "device": name, "compute_units": cus, "synth_s": round(t_synth, 2),
+        "ranks": gathered, "device": name, "compute_units": cus, "synth_s": round(t_synth[0], 2),
     }
     return result
 
@@ -407,22 +584,35 @@ def run_mix(P, W, args, R: Ranks, device: int):
 # =======================================================================================================================
 # CPU side (rank 0, N = 1 only, after every timed region): baselines and oracle spot checks.  The only place that touches oracle/.
 # =======================================================================================================================
-def _oracle_tables(O, P, signal, prn):
+def _oracle_tables(O, P, signal, prn, code_length=10230):
     pad = O.pad_code
     if signal == "GAL_E1C_CBOC":   # the BOC(6,1) table of the E1-C pilot is this build's extension (no oracle generator in the reference's terms)
         return [pad(O.generate_e1_code(prn, "B")), pad(O.generate_e1_code(prn, "C")), pad(np.asarray(P.codes.generateE1C_BOC61(prn), dtype=np.float64))]
+
+    def e5(i_sig, q_sig):          # GAL_E5a tracking.m:148-156: the data table is the head of the TIERED code, the pilot the primary code
+        tiered = O.generate_e5_code(i_sig, prn, 2)
+        return [np.concatenate([[tiered[code_length - 1]], tiered, [tiered[0]]])[:code_length + 2], pad(O.generate_e5_primary(q_sig, prn))]
+
     return {
         "GPS_L1CA": lambda: [pad(O.generate_ca_code(prn))],
         "GAL_E1C": lambda: [pad(O.generate_e1_code(prn, "B")), pad(O.generate_e1_code(prn, "C"))],
         "BDS_B1C_NB": lambda: [pad(O.generate_b1c_code(prn, "data")), pad(O.generate_b1c_code(prn, "pilot11"))],
         "GPS_L5C": lambda: [pad(O.generate_l5_code(prn, "I")), pad(O.generate_l5_code(prn, "Q"))],
         "BDS_B2a": lambda: [pad(O.generate_b2a_code(prn, "data")), pad(O.generate_b2a_code(prn, "pilot"))],
+        "BDS_B1I": lambda: [pad(O.generate_b1i_code(prn))],
+        "BDS_B3I": lambda: [pad(O.generate_b3i_code(prn))],
+        "GAL_E5a": lambda: e5("e5ai", "e5aq"),
+        "GAL_E5b": lambda: e5("e5bi", "e5bq"),
+        "GLO_GL1": lambda: [pad(O.generate_glo_code())],
+        "GLO_GL2": lambda: [pad(O.generate_glo_code())],
+        "GPS_L2C": lambda: [pad(O.generate_l2c_code(prn, "CM", 10230))],   # the CM arm (the CL arm's 1.5-s table is not regenerated here)
     }[signal]()
 
 
 def oracle_spot_check(P, W, O, job, nblocks=4, seed=1):
     """A few replayed blocks of a job against the float64 oracle (tracking.m:247-300) at identical descriptors: worst deviation in
     units of sum |x| over the block (the tests' tolerance is 2e-6)."""
+    from cu_sdr_collection_amd import _lib as L
     from cu_sdr_collection_amd import signals
     spec = signals.SIGNALS[job.pkg.signal]
     rng = np.random.default_rng(seed)
@@ -431,15 +621,16 @@ def oracle_spot_check(P, W, O, job, nblocks=4, seed=1):
     sub = job.engine.make_blocks(nblocks)
     np.frombuffer(sub, dtype=W.BLOCK_DT)[:] = view[pick]
     got = job.engine.correlate(sub)
+    swap = bool(getattr(job, "swap_iq", False))         # GLONASS records hold Q,I (GLO_GL1 tracking.m:227)
     worst = 0.0
     for k in range(nblocks):
         b = sub[k]
         tabs = _oracle_tables(O, P, job.pkg.signal, job.sats[b.channel].prn)
-        raw_i = job.engine.read_if(int(b.first_sample), int(b.blksize), dtype=job.record_dtype)
-        raw = O.raw_from_if(raw_i, 0, int(b.blksize))
+        raw_i = job.engine.read_if(int(b.first_sample), int(b.blksize), dtype=getattr(job, "record_dtype", np.int8), layout=L.GC_QI if swap else L.GC_IQ)
+        raw = O.raw_from_if(raw_i, 0, int(b.blksize), swap_iq=swap)
         want, _, _ = O.correlate_block(raw, tabs, b.rem_code_phase, b.code_phase_step, b.el_spacing, b.carr_freq, b.rem_carr_phase,
                                        job.params.sampling_freq, job.params.code_length, r=spec.index_scale,
-                                       arm_mult=list(spec.arm_mult) if spec.arm_mult else None)
+                                       arm_mult=list(spec.arm_mult)[:len(tabs)] if spec.arm_mult else None)
         scale = float(np.sum(np.abs(raw.real)) + np.sum(np.abs(raw.imag)))
         worst = max(worst, float(np.max(np.abs(got[k, :want.shape[0]] - want))) / scale)
     return worst
@@ -518,6 +709,8 @@ def main() -> None:
     ap.add_argument("--numpy-epochs", type=int, default=250, help="epochs per channel of the NumPy CPU variant (~5 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-int16", action="store_true")
+    ap.add_argument("--no-handover", action="store_true", help="N > 1: every rank synthesises its own copy of the record(s) instead of receiving them from the source rank (A/B of the exchange step)")
+    ap.add_argument("--spot-check", action="store_true", help="--config mix: every rank checks a few replayed blocks of each of its jobs against the float64 oracle (CPU)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -530,14 +723,14 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
                          "they must agree (n_gpus in the result line is the number of ranks that ran)")
-    R = Ranks(rank, world)
+    # one GPU per rank; GC_BENCH_DEVICE pins every rank to one device (functional test of the N > 1 path on a 1-GPU box)
+    device = int(os.environ.get("GC_BENCH_DEVICE", local_rank))
+    R = Ranks(rank, world, device)
     config = args.config or ("all" if world == 1 else "l1ca")
 
     import bench_workloads as W
     import cu_sdr_collection_amd as P
 
-    # one GPU per rank; GC_BENCH_DEVICE pins every rank to one device (functional test of the N > 1 path on a 1-GPU box)
-    device = int(os.environ.get("GC_BENCH_DEVICE", local_rank))
     if config == "mix":
         result = run_mix(P, W, args, R, device)
         if rank == 0:
@@ -546,7 +739,7 @@ def main() -> None:
         return
 
     result, main_ctx = run_l1ca(P, W, args, R, device)
-    result["acquisition"] = run_acquisition(P, main_ctx["eng"], main_ctx["sats"])
+    result["acquisition"] = run_acquisition(P, main_ctx["eng"], main_ctx["scene"], R)
     extra_jobs = {}
     if config == "all" and world == 1:
         cfgs = {}

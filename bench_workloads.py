@@ -259,9 +259,9 @@ KERNEL_NAMES = {0: "corr_epl_lane_kernel", 1: "corr_epl_fast_kernel (one-wave wo
                 3: "corr_epl_fast_kernel (four waves, float tables)", -1: "corr_epl_mixed_kernel"}
 
 
-def make_band(P, engine, parts, seconds: float, fs: float, intermediate_freq: float, seed: int, dtype=np.int8, cn0: float = 46.0):
-    """Synthesises one band record in the engine's HBM: parts = [(package name, number of channels)]; returns
-    [(Package, settings, sats)] in the same order."""
+def band_scene(P, parts, fs: float, seed: int, cn0: float = 46.0):
+    """The satellites of one band record, the same on every rank: parts = [(package name, number of channels)] ->
+    ([(Package, settings, sats)] in the same order, the synthesiser's signal groups)."""
     groups, out = [], []
     for k, (name, n) in enumerate(parts):
         pkg = PACKAGES[name]
@@ -270,7 +270,19 @@ def make_band(P, engine, parts, seconds: float, fs: float, intermediate_freq: fl
         sats = make_sats(P, pkg, S, n, seed + 17 * k, cn0=cn0)
         groups += signal_group(P, pkg, S, sats)
         out.append((pkg, S, sats))
+    return out, groups
+
+
+def band_is_qi(parts) -> bool:
+    return any(PACKAGES[name].glonass for name, _ in parts)
+
+
+def make_band(P, engine, parts, seconds: float, fs: float, intermediate_freq: float, seed: int, dtype=np.int8, cn0: float = 46.0,
+              attached: bool = False):
+    """Synthesises one band record in the engine's HBM (attached=True: into the caller-owned buffer the engine already reads);
+    returns band_scene's [(Package, settings, sats)]."""
+    out, groups = band_scene(P, parts, fs, seed, cn0)
     P.synth.generate_if_mix_gpu(engine, groups, int(round(seconds * fs)), fs, intermediate_freq, seed, dtype=dtype,
-                                qi_order=any(PACKAGES[name].glonass for name, _ in parts))
+                                qi_order=band_is_qi(parts), attached=attached)
     engine.set_sampling_freq(fs)
     return out

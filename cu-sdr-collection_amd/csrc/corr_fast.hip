@@ -675,7 +675,7 @@ int launch_devloop_one(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 g
   const void* fn = share ? (const void*)corr_epl_fast_kernel<1, MODE, SPL, false, true, 0, true>
                          : (const void*)corr_epl_fast_kernel<1, MODE, SPL, false, false, 0, true>;
   // cooperative: every team member must be resident while the others spin on the epoch flag
-  GC_HIP(gc_launch_persistent(ctx, fn, grid, dim3(kFW), args, (unsigned int)smem));
+  GC_PERSIST(gc_launch_persistent(ctx, fn, grid, dim3(kFW), args, (unsigned int)smem));
   return GC_OK;
 }
 

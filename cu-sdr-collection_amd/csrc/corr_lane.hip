@@ -835,7 +835,7 @@ int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 
   void* args[2] = {(void*)&a, (void*)&ib};
   const void* fn = share ? (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 1, true> : (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 0, true>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  GC_HIP(gc_launch_persistent(ctx, fn, grid, dim3(waves * 64), args, (unsigned int)smem));
+  GC_PERSIST(gc_launch_persistent(ctx, fn, grid, dim3(waves * 64), args, (unsigned int)smem));
   return GC_OK;
 }
 
@@ -868,7 +868,7 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
     const void* fn = half_tables ? (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 2, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 2, true, true>)
                                  : (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 0, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>);
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    GC_HIP(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
+    GC_PERSIST(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
     return GC_OK;
   }
   if (half_tables) {  // f16 tables: int8 I/Q and Q/I
@@ -876,7 +876,7 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
     const void* fn = max_arms == 1 ? (qi ? (const void*)corr_epl_lane_kernel<1, I8_QI, false, 2, true> : (const void*)corr_epl_lane_kernel<1, I8_IQ, false, 2, true>)
                                    : (qi ? (const void*)corr_epl_lane_kernel<2, I8_QI, false, 2, true> : (const void*)corr_epl_lane_kernel<2, I8_IQ, false, 2, true>);
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    GC_HIP(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
+    GC_PERSIST(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
     return GC_OK;
   }
   int mode;

@@ -145,6 +145,7 @@ struct gc_context {
   bool force_generic = false;
   bool launch_derived = false;  // the launch being prepared runs the lane kernel's derived-arm instantiation
   int last_kernel = -2;  // gc_debug_last_kernel
+  int last_track_mode = -1;  // gc_debug_last_track_mode: 0 launch per epoch, 1 persistent host-fed kernel, 2 device loop
 
   // acquisition scratch (acq.hip)
   void* acq_scratch = nullptr;
@@ -165,14 +166,27 @@ struct gc_context {
 // Launch of a persistent (host-fed or device-loop) kernel whose workgroups wait for each other's messages and therefore must
 // all be resident.  Alone on the device: a cooperative launch, the runtime guarantees residency.  Next to other contexts'
 // persistent kernels (gc_track_multi): cooperative launches of different streams do not overlap, and a host-fed kernel that
-// waits behind another one never gets its descriptors consumed - so those are plain launches, co-resident because
-// gc_track_multi admits only job sets whose grids fit the device together.  GC_PERSIST_COOP=0/1 forces either (experiments).
-inline hipError_t gc_launch_persistent(const gc_context* ctx, const void* fn, dim3 grid, dim3 block, void** args, unsigned int smem) {
-  bool coop = !ctx->concurrent_jobs;
-  if (const char* e = std::getenv("GC_PERSIST_COOP")) coop = std::atoi(e) != 0;
-  return coop ? hipLaunchCooperativeKernel(fn, grid, block, args, smem, ctx->stream)
-              : hipLaunchKernel(fn, grid, block, args, smem, ctx->stream);
-}
+// waits behind another one never gets its descriptors consumed - so those are plain launches, admitted by a per-device
+// ledger of the persistent kernels in flight (multi.hip): a grid goes ahead only when, together with the grids already
+// resident, every one of its workgroups finds room whatever order the dispatcher places them in; otherwise the call returns
+// hipErrorCooperativeLaunchTooLarge - what a cooperative launch answers to a grid that does not fit - and the caller falls
+// back (gc_track: a launch per epoch; gc_track_device: GC_E_UNSUPPORTED, i.e. gc_track).  GC_PERSIST_COOP=0/1 forces either
+// launch kind (experiments).  gc_persistent_done takes the context's entry out of the ledger when its kernel has ended.
+hipError_t gc_launch_persistent(gc_context* ctx, const void* fn, dim3 grid, dim3 block, void** args, unsigned int smem);
+void gc_persistent_done(gc_context* ctx);
+#define GC_PERSIST(call)                                                                                     \
+  do {                                                                                                       \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ == hipErrorCooperativeLaunchTooLarge) {                                                           \
+      (void)hipGetLastError();                                                                               \
+      gc_set_error("the persistent kernel's grid does not fit the device next to the kernels in flight");    \
+      return GC_E_UNSUPPORTED;                                                                               \
+    }                                                                                                        \
+    if (e_ != hipSuccess) {                                                                                  \
+      gc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);               \
+      return GC_E_HIP;                                                                                       \
+    }                                                                                                        \
+  } while (0)
 
 // gc_track over one window of a record (gc_track_resume / gc_track_file, track.hip + stream.hip)
 struct GcTrackResume {

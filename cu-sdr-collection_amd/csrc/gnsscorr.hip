@@ -647,6 +647,7 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
 }
 
 extern "C" int gc_debug_last_kernel(const gc_context* ctx) { return ctx ? ctx->last_kernel : -2; }
+extern "C" int gc_debug_last_track_mode(const gc_context* ctx) { return ctx ? ctx->last_track_mode : -1; }
 
 extern "C" long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps) {
   return gc_first_sample_near_edge(a, step, n, eps);

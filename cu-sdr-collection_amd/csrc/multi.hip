@@ -40,6 +40,67 @@ extern "C" int gc_share_if(gc_context* dst, gc_context* src) {
   return GC_OK;
 }
 
+// ---- admission of persistent kernels that share a device (gc_launch_persistent, gc_internal.h) --------------------------------
+// Workgroups of a persistent kernel spin on their team mates' messages, so a grid that is only partly resident never ends, and
+// two partly resident grids block each other for good.  Workgroup b of a launch goes to XCD b mod 8 and there to any CU with room
+// left.  A workgroup of kernel i takes at most 1 / occ_i of every CU resource (occ_i = workgroups of that kernel per CU when it is
+// alone: hipOccupancyMaxActiveBlocksPerMultiprocessor with its LDS size), so per XCD the set of kernels in flight loads the CUs
+// with sum_i w_i / occ_i CU-equivalents, w_i = ceil(grid_i / 8).  A workgroup that needs 1 / occ of a CU is shut out of a CU
+// only while that CU carries more than 1 - 1 / occ; with r = the largest 1 / occ_i of the set, fewer than load / (1 - r) CUs can
+// be that full - and when some kernel needs whole CUs (r = 1), a CU is shut for it as soon as it holds ANY workgroup, so the
+// workgroups of the set must not outnumber the XCD's CUs.  Under either condition every workgroup of every admitted grid finds a
+// CU whatever the dispatch order.  The ledger knows this process' kernels; ranks of other processes on the same device are
+// outside it (bench.py serialises their closed loops when GC_BENCH_DEVICE puts several ranks on one GPU).
+namespace {
+struct ResidentGrid {
+  const gc_context* ctx;
+  int wg_per_xcd;
+  int occ;
+};
+std::mutex g_ledger_mu;
+std::vector<ResidentGrid> g_ledger[64];
+
+bool ledger_fits(const std::vector<ResidentGrid>& set, const ResidentGrid& add, int cus) {
+  const double cu_per_xcd = std::max(1, cus / 8);
+  double load = (double)add.wg_per_xcd / add.occ, rmax = 1.0 / add.occ;
+  long long wgs = add.wg_per_xcd;
+  for (const ResidentGrid& g : set) {
+    load += (double)g.wg_per_xcd / g.occ;
+    rmax = std::max(rmax, 1.0 / g.occ);
+    wgs += g.wg_per_xcd;
+  }
+  if (rmax >= 1.0) return (double)wgs <= cu_per_xcd;
+  return load <= cu_per_xcd * (1.0 - rmax);
+}
+}  // namespace
+
+hipError_t gc_launch_persistent(gc_context* ctx, const void* fn, dim3 grid, dim3 block, void** args, unsigned int smem) {
+  bool coop = !ctx->concurrent_jobs;
+  if (const char* e = std::getenv("GC_PERSIST_COOP")) coop = std::atoi(e) != 0;
+  if (coop) return hipLaunchCooperativeKernel(fn, grid, block, args, smem, ctx->stream);
+  if (ctx->device < 0 || ctx->device >= 64) return hipErrorInvalidDevice;
+  int occ = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)block.x, smem);
+  if (e != hipSuccess) return e;
+  if (const char* ev = std::getenv("GC_PERSIST_OCC")) occ = std::min(occ, std::atoi(ev));  // tests: pretend the kernel needs more of a CU
+  if (occ < 1) return hipErrorCooperativeLaunchTooLarge;
+  const ResidentGrid mine{ctx, (int)((grid.x + 7) / 8), occ};
+  std::lock_guard<std::mutex> lock(g_ledger_mu);
+  std::vector<ResidentGrid>& set = g_ledger[ctx->device];
+  set.erase(std::remove_if(set.begin(), set.end(), [&](const ResidentGrid& g) { return g.ctx == ctx; }), set.end());
+  if (!ledger_fits(set, mine, ctx->compute_units)) return hipErrorCooperativeLaunchTooLarge;
+  e = hipLaunchKernel(fn, grid, block, args, smem, ctx->stream);
+  if (e == hipSuccess) set.push_back(mine);
+  return e;
+}
+
+void gc_persistent_done(gc_context* ctx) {
+  if (!ctx || ctx->device < 0 || ctx->device >= 64) return;
+  std::lock_guard<std::mutex> lock(g_ledger_mu);
+  std::vector<ResidentGrid>& set = g_ledger[ctx->device];
+  set.erase(std::remove_if(set.begin(), set.end(), [&](const ResidentGrid& g) { return g.ctx == ctx; }), set.end());
+}
+
 namespace {
 // Streams for the concurrent jobs of one device.  Two persistent kernels overlap only when their streams sit on different
 // hardware queues, and the runtime maps streams to its few queues (GPU_MAX_HW_QUEUES, 4) by its own bookkeeping: whether the
@@ -95,9 +156,9 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
         return GC_E_INVALID;
       }
   }
-  // Persistent kernels of jobs on the same device must be resident together (gc_launch_persistent): admit them only when
-  // the device has room to spare - at most 32 workgroups per channel (track.hip) of at most 8 wavefronts each, against
-  // 8+ wavefront slots per SIMD; above that the jobs still run, launching their correlators per epoch.
+  // Persistent kernels of jobs on the same device must be resident together: each context's launch goes through the ledger of
+  // gc_launch_persistent, which admits a grid only when it fits next to those in flight; a job whose kernel is refused runs its
+  // loop with a launch per epoch (gc_track) - slower, never stuck.  Teams are sized for all channels of the device.
   for (int i = 0; i < njobs; ++i) {
     int same = 0, channels = 0;
     for (int k = 0; k < njobs; ++k)
@@ -108,6 +169,26 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
     jobs[i].ctx->concurrent_jobs = same > 1;
     jobs[i].ctx->concurrent_channels = channels;
   }
+  // Whatever way this call ends, every context leaves it with its own stream and out of multi-job state (a later gc_track on a
+  // context left in that state would launch its persistent kernel plainly, teams spread, on a stream shared with other contexts).
+  struct Restore {
+    int njobs;
+    gc_track_job* jobs;
+    std::vector<hipStream_t> own;
+    ~Restore() {
+      for (int i = 0; i < njobs; ++i) {
+        gc_context* c = jobs[i].ctx;
+        if (own[(size_t)i]) {
+          (void)hipSetDevice(c->device);
+          (void)hipStreamSynchronize(c->stream);
+          c->stream = own[(size_t)i];
+        }
+        c->concurrent_jobs = false;
+        c->concurrent_channels = 0;
+        gc_persistent_done(c);
+      }
+    }
+  } restore{njobs, jobs, std::vector<hipStream_t>((size_t)njobs, nullptr)};
   // Code-table uploads (and the frees of the tables they replace: hipFree waits for every stream of the device) happen here,
   // one context after the other, before any persistent kernel is running.
   for (int i = 0; i < njobs; ++i) {
@@ -120,12 +201,10 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
     j.status = j.device_loop ? gc_track_device(j.ctx, j.params, j.nch, j.init, j.out, j.epochs_done) : GC_E_UNSUPPORTED;
     if (!j.device_loop || j.status == GC_E_UNSUPPORTED) j.status = gc_track(j.ctx, j.params, j.nch, j.init, j.out, j.epochs_done);
     if (j.status != GC_OK) std::snprintf(j.error, sizeof j.error, "%s", gc_last_error());
-    j.ctx->concurrent_jobs = false;
     return j.status;
   }
   // jobs of one device onto streams of different hardware queues (multi_streams above); a device's fourth and later job keeps
   // its context's own stream
-  std::vector<hipStream_t> own((size_t)njobs, nullptr);
   for (int i = 0; i < njobs; ++i) {
     int idx = 0;
     for (int k = 0; k < i; ++k) idx += jobs[k].ctx->device == jobs[i].ctx->device;
@@ -133,7 +212,7 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
     if (ms && idx < ms->n && jobs[i].ctx->concurrent_jobs) {
       GC_HIP(hipSetDevice(jobs[i].ctx->device));
       GC_HIP(hipStreamSynchronize(jobs[i].ctx->stream));
-      own[i] = jobs[i].ctx->stream;
+      restore.own[(size_t)i] = jobs[i].ctx->stream;
       jobs[i].ctx->stream = ms->s[idx];
     }
   }
@@ -159,12 +238,6 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
   for (auto& w : workers) w.join();
   int first = GC_OK;
   for (int i = 0; i < njobs; ++i) {
-    if (own[i]) {
-      (void)hipSetDevice(jobs[i].ctx->device);
-      (void)hipStreamSynchronize(jobs[i].ctx->stream);
-      jobs[i].ctx->stream = own[i];
-    }
-    jobs[i].ctx->concurrent_jobs = false;
     // a short read of one package (GC_E_RANGE, partial records returned) must not hide a failure of another
     if (jobs[i].status != GC_OK && (first == GC_OK || first == GC_E_RANGE)) {
       first = jobs[i].status;

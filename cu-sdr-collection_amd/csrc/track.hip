@@ -318,6 +318,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   // latency and ~13 us of kernel wall time per epoch; the persistent kernel answers in a few microseconds.  Covered:
   // single-arm R = 1 channels on the transition-mask kernel with one-wave workgroups, any record format (GPS L1 C/A, BDS B1I,
   // GLONASS); everything else keeps launching.
+  ctx->last_track_mode = 0;
   bool persist = poll && !any_mixed && max_arms == 1 && fast_nominal > 0 && gc_fast_table_mode(ctx) == 0 && p->pilot_combine == 0 &&
                  p->table_phase_count == 0 && n_epochs > 0 &&
                  !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
@@ -346,6 +347,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   gcorr::DevLoopArgs* d_pargs = nullptr;
   gcorr::msg_t* h_desc = nullptr;  // host-mapped descriptor messages [nch][kDescWords]
   auto persist_free = [&]() {  // the buffers stay with the context (GcBuf: freeing would wait for every stream of the device)
+    gc_persistent_done(ctx);  // the kernel has ended (or was never launched): its grid leaves the device's ledger
     pa.chan = nullptr;
     pa.desc_msg = nullptr;
     pa.part_msg = nullptr;
@@ -439,6 +441,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
         e = hipErrorUnknown;
       }
     }
+    ctx->last_track_mode = e == hipSuccess ? 1 : 0;
     if (e == hipSuccess) ctx->last_kernel = persist_lane ? 0 : 1;  // gc_debug_last_kernel: lane / fast kernel (persistent instantiation)
     if (e != hipSuccess) {  // could not set the persistent kernel up: launch per epoch
       (void)hipGetLastError();
@@ -958,7 +961,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   if (e == hipSuccess) e = hipMemcpyAsync(ha.desc_msg, hdesc.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(ha.chan, hc.data(), sizeof(gcorr::DevLoopChan) * (size_t)nch, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_args, &ha, sizeof ha, hipMemcpyHostToDevice, ctx->stream);
-  auto cleanup = [&]() {};  // the buffers stay with the context (GcBuf)
+  auto cleanup = [&]() { gc_persistent_done(ctx); };  // the buffers stay with the context (GcBuf); the grid leaves the device's ledger
   if (e != hipSuccess) {
     cleanup();
     gc_set_error("gc_track_device: %s", hipGetErrorString(e));
@@ -982,6 +985,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   a.derived = cboc ? 1 : 0;
   rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane && !cboc, lane_waves);
   if (rc == GC_OK) {
+    ctx->last_track_mode = 2;
     const auto t_l = std::chrono::steady_clock::now();
     e = hipStreamSynchronize(ctx->stream);
     const auto t_k = std::chrono::steady_clock::now();

@@ -164,6 +164,10 @@ class Engine:
         """gc_debug_last_kernel: 0 lane, 1 fast (one wave), 2 fast (four waves, int8 pairs), 3 fast (four waves, floats), -1 mixed."""
         return int(self._lib.gc_debug_last_kernel(self._ctx))
 
+    def last_track_mode(self) -> int:
+        """gc_debug_last_track_mode: 0 a launch per epoch, 1 persistent host-fed kernel, 2 device loop."""
+        return int(self._lib.gc_debug_last_track_mode(self._ctx))
+
     def replay_prepare(self, blocks):
         self._replay_n = len(blocks)
         L.check(self._lib.gc_replay_prepare(self._ctx, len(blocks), blocks))

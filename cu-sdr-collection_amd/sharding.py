@@ -58,7 +58,7 @@ def merge_acq_results(per_rank):
     return out
 
 
-def broadcast_record(record, src: int = 0, device=None, group=None):
+def broadcast_record(record, src: int = 0, device=None, group=None, via_host: bool = False):
     """The one exchange step of the sharded path: the rank that read the IF file hands the raw record to the
     ranks that track other channels of the same band.  `record`: a 1-D torch int8 / int16 tensor on rank `src` (ignored
     elsewhere).  `src` is a GLOBAL rank; `group` the process group of the ranks that share the band (None: every rank) - only
@@ -69,6 +69,8 @@ def broadcast_record(record, src: int = 0, device=None, group=None):
     Process order matters when torch drives the GPU in the same process as the engine: torch ships its own copy of the HIP
     runtime, so initialise torch's CUDA side (torch.cuda.set_device) BEFORE the first Engine() -- with the engine first, torch
     finds no device (tests/test_gpu_correlator.py::test_broadcast_record_is_adopted_without_a_copy runs in that order).
+    `via_host`: the record crosses as a CPU tensor (the group's CPU backend) and is uploaded to `device` on arrival - for ranks
+    that share ONE GPU (RCCL refuses two ranks on a device: functional checks on a 1-GPU box) or a group without a GPU backend.
     """
     import torch
     import torch.distributed as dist
@@ -81,20 +83,28 @@ def broadcast_record(record, src: int = 0, device=None, group=None):
     dist.broadcast_object_list(meta, src=src, group=group)
     n, dt = meta[0]
     dtype = torch.int8 if dt == "torch.int8" else torch.int16
+    wire = "cpu" if (via_host or device is None) else device
     if rank == src:
-        t = record if device is None else record.to(device)
+        home = record if device is None else record.to(device)       # what this rank keeps (no copy when it is there already)
+        t = home if wire != "cpu" else record.to("cpu")
     else:
-        t = torch.empty(n, dtype=dtype, device=device if device is not None else "cpu")
+        home = None
+        t = torch.empty(n, dtype=dtype, device=wire)
     dist.broadcast(t, src=src, group=group)
-    return t
+    if rank == src:
+        return home
+    return t if device is None else t.to(device)
 
 
-def distribute_band_records(plan, read_record, device=None):
+def distribute_band_records(plan, read_record, device=None, via_host: bool = False, timings: dict | None = None):
     """BASELINE config 5, the hand-over end to end: `plan` = shard_bands(...) (identical on every rank).  For every band the
     first rank that tracks one of its channels reads the file (`read_record(band)` -> 1-D int8 / int16 tensor) and broadcasts
     it to the other ranks of the band - one process group per band, so ranks that do not track the band neither take part
     nor spend HBM on it.  Returns {band: tensor} for the bands of THIS rank.  Every rank must call it (torch.distributed
-    creates groups collectively, in the same order everywhere)."""
+    creates groups collectively, in the same order everywhere).  `timings`, if given, receives {band: (seconds of the
+    broadcast as this rank saw it, bytes)} for the bands that travelled."""
+    import time
+    import torch
     import torch.distributed as dist
     rank = dist.get_rank()
     ranks = band_ranks(plan)
@@ -111,5 +121,10 @@ def distribute_band_records(plan, read_record, device=None):
         if len(members) == 1:
             out[band] = rec if device is None else rec.to(device)
         else:
-            out[band] = broadcast_record(rec, src=src, device=device, group=groups[band])
+            t0 = time.perf_counter()
+            out[band] = broadcast_record(rec, src=src, device=device, group=groups[band], via_host=via_host)
+            if out[band].is_cuda:
+                torch.cuda.synchronize(out[band].device)
+            if timings is not None:
+                timings[band] = (time.perf_counter() - t0, int(out[band].numel()) * out[band].element_size())
     return out

@@ -145,8 +145,9 @@ def generate_if_mix(groups, n_samples: int, fs: float, intermediate_freq: float,
 # ---------------------------------------------------------------------------------------------
 def generate_if_gpu(engine, sats, n_samples: int, fs: float, intermediate_freq: float, code_fn,
                     code_rate: float, code_len: int, seed: int, sigma: float = 20.0,
-                    carrier_ratio: float = 1540.0, bit_periods: int = 20) -> None:
-    """Allocates the engine's IF buffer (int8 I/Q) and fills it on the GPU."""
+                    carrier_ratio: float = 1540.0, bit_periods: int = 20, attached: bool = False) -> None:
+    """Allocates the engine's IF buffer (int8 I/Q) and fills it on the GPU.  attached=True: the engine already reads a buffer
+    of n_samples int8 I/Q samples that the caller owns (Engine.attach_if, e.g. a torch tensor about to be broadcast) - fill that."""
     import ctypes as C
     import os
 
@@ -160,9 +161,12 @@ def generate_if_gpu(engine, sats, n_samples: int, fs: float, intermediate_freq: 
     lib.gs_generate.restype = C.c_int
     lib.gs_generate.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_uint64]
-    engine.alloc_if(n_samples, np.int8)
+    if not attached:
+        engine.alloc_if(n_samples, np.int8)
     engine.synchronize()
     ptr, n = engine.if_buffer()
+    if n != n_samples:
+        raise ValueError(f"generate_if_gpu: the engine's buffer holds {n} samples, {n_samples} wanted")
     codes = np.ascontiguousarray(np.stack([np.asarray(code_fn(s.prn), dtype=np.int8) for s in sats]))
     arr = (gs_sat * len(sats))()
     for i, s in enumerate(sats):
@@ -181,10 +185,11 @@ def generate_if_gpu(engine, sats, n_samples: int, fs: float, intermediate_freq: 
 
 
 def generate_if_mix_gpu(engine, groups, n_samples: int, fs: float, intermediate_freq: float, seed: int, sigma: float = 20.0,
-                        dtype=np.int8, qi_order: bool = False) -> None:
+                        dtype=np.int8, qi_order: bool = False, attached: bool = False) -> None:
     """generate_if_mix on the GPU (libgnsssynth.so gs_generate2): allocates the engine's IF buffer (int8 or int16 I/Q)
     and fills it in HBM.  Same signal model; data bits and noise come from a counter-based hash instead of NumPy's
-    generator, so the two generators agree in distribution, not sample for sample."""
+    generator, so the two generators agree in distribution, not sample for sample.  attached=True: fill the buffer the engine
+    already reads (Engine.attach_if on caller-owned memory of the same size and format) instead of allocating one."""
     import ctypes as C
     import os
 
@@ -201,9 +206,12 @@ def generate_if_mix_gpu(engine, groups, n_samples: int, fs: float, intermediate_
                                  C.c_double, C.c_uint64, C.c_int]
     i16 = np.dtype(dtype) == np.int16
     from . import _lib as L
-    engine.alloc_if(n_samples, np.int16 if i16 else np.int8, layout=L.GC_QI if qi_order else L.GC_IQ)
+    if not attached:
+        engine.alloc_if(n_samples, np.int16 if i16 else np.int8, layout=L.GC_QI if qi_order else L.GC_IQ)
     engine.synchronize()
-    ptr, _ = engine.if_buffer()
+    ptr, have = engine.if_buffer()
+    if have != n_samples:
+        raise ValueError(f"generate_if_mix_gpu: the engine's buffer holds {have} samples, {n_samples} wanted")
     flat, sats = [], []
     off = 0
     for g in groups:

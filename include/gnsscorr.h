@@ -470,6 +470,12 @@ int gc_debug_tables_derivable(const int8_t* t1, int n1, const int8_t* t6, int n6
  * (mixed ramp multipliers); -2 before the first launch.  Lets the parity tests prove which path they covered. */
 int gc_debug_last_kernel(const gc_context* ctx);
 
+/* Test hook: how the last gc_track / gc_track_device call on this context ran its loop: 0 a correlator launch per epoch,
+ * 1 the persistent host-fed kernel, 2 the device loop; -1 before the first call.  A persistent kernel needs all its workgroups
+ * resident: next to other contexts' persistent kernels (gc_track_multi) a grid that does not fit the device together with
+ * those in flight is refused and the call runs with a launch per epoch instead (same records). */
+int gc_debug_last_track_mode(const gc_context* ctx);
+
 /* Test hook: the library's four-step mixed-radix FFT on `nbatch` host sequences of n complex64
  * values (n of the form 2^a 3^b 5^c); output in natural order, unnormalised. */
 int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in, float* out, int inverse);

@@ -196,3 +196,46 @@ def test_track_multi_argument_checks(engine, l1ca_scene):
     with pytest.raises(L.GnssCorrError) as e:
         engine.track(longer, init, device_loop=True)
     assert e.value.status == L.GC_E_INVALID
+
+
+def test_job_set_whose_persistent_grids_do_not_fit_together_falls_back_to_a_launch_per_epoch(engine):
+    """gc_track_multi launches the jobs' persistent kernels plainly (cooperative launches of different streams do not
+    overlap), so nothing but the library's own admission check keeps partly resident grids from spinning on each other for good.
+    Twelve GPS L1 C/A channels make 12 x 32 one-wave members = 48 workgroups per XCD; the Galileo E1 job's members need a CU
+    each (82 KB of tables, eight waves of ~170 VGPRs): 51 workgroups for an XCD's 32 CUs.  Whichever kernel comes second is
+    refused and its loop runs with a launch per epoch - the same records as the packages tracked one after the other."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd.settings import initSettings_GAL_E1C
+    from cu_sdr_collection_amd.synth import SatSpec, SignalGroup, generate_if_mix
+    fs = 18e6
+    rng = np.random.default_rng(707)
+
+    def sats(prns, period_samples, cn0):
+        return [SatSpec(prn=int(p), doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, period_samples)),
+                        carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=cn0) for p in prns]
+
+    l1 = sats(rng.choice(np.arange(1, 33), size=12, replace=False), 18000, 47.0)
+    e1 = sats((5, 11, 24), 72000, 47.0)
+    groups = [SignalGroup(l1, P.codes.generateCAcode, 1.023e6, 1023),
+              SignalGroup(e1, P.codes.generateE1Bcode, 2.046e6, 8184, bit_periods=1, pilot_fn=P.codes.generateE1Ccode)]
+    iq = generate_if_mix(groups, int(0.05 * fs), fs, 20e3, seed=708)
+    S1 = P.initSettings()
+    S1.msToProcess, S1.numberOfChannels = 40, 12
+    S2 = initSettings_GAL_E1C()
+    S2.msToProcess, S2.numberOfChannels = 40, 3
+    ch1 = [SimpleNamespace(PRN=s.prn, acquiredFreq=S1.IF + s.doppler + 2.0, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in l1]
+    ch2 = [SimpleNamespace(PRN=s.prn, acquiredFreq=S2.IF + s.doppler + 2.0, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in e1]
+    engine.load_if(iq, fs=fs)
+    with P.Engine(0) as e2:
+        e2.share_if(engine)
+        (tr1, _), (tr2, _) = P.receiver.tracking_multi([(engine, ch1, S1, "GPS_L1CA"), (e2, ch2, S2, "GAL_E1C")])
+        modes = (engine.last_track_mode(), e2.last_track_mode())
+        assert sorted(modes) == [0, 1], modes          # one persistent kernel admitted, the other job launched per epoch
+        seq1, _ = P.tracking(engine, ch1, S1)
+        seq2, _ = P.tracking(e2, ch2, S2, signal="GAL_E1C")
+        assert (engine.last_track_mode(), e2.last_track_mode()) == (1, 1)   # alone on the device both take their persistent kernel
+    for a, b in ((tr1, seq1), (tr2, seq2)):
+        for x, y in zip(a, b):
+            assert x.status == y.status == "T" and np.array_equal(x.absoluteSample, y.absoluteSample)
+            for f in ("carrFreq", "codeFreq", "I_P", "Q_P", "I_E", "Q_L", "remCodePhase", "remCarrPhase"):
+                assert np.allclose(getattr(x, f), getattr(y, f), rtol=1e-6, atol=1e-6 * np.abs(y.I_P).max() + 1e-12), f
