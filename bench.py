@@ -86,10 +86,29 @@ class Ranks:
                     backend, self.rccl = "cpu:gloo,cuda:nccl", True
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
             self.dist = dist
+            self.rccl_error = None
+            if self.rccl:      # one small all-reduce over RCCL before anything depends on it; every rank learns whether ALL of them got through
+                ok = 1.0
+                try:
+                    x = torch.ones(1, device=f"cuda:{device}")
+                    dist.all_reduce(x)
+                    torch.cuda.synchronize()
+                    ok = float(x.item() == world)
+                except Exception as exc:  # noqa: BLE001 - whatever RCCL raises, the bench goes on through the hosts and says so
+                    ok, self.rccl_error = 0.0, repr(exc)[:300]
+                flag = torch.tensor([ok], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag[0]) < 1.0:
+                    self.rccl = False
+                    self.rccl_error = self.rccl_error or "another rank's RCCL probe failed"
 
     @property
     def data_backend(self):
-        return "nccl (RCCL over xGMI)" if self.rccl else "gloo through the hosts (ranks share one GPU: RCCL needs one GPU per rank)"
+        if self.rccl:
+            return "nccl (RCCL over xGMI)"
+        if self.shared_device:
+            return "gloo through the hosts (ranks share one GPU: RCCL needs one GPU per rank)"
+        return f"gloo through the hosts (RCCL unavailable: {getattr(self, 'rccl_error', None)})"
 
     def torch_device(self):
         return f"cuda:{self.device}"
@@ -203,7 +222,7 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
     sats = [scene[(nch * R.rank + i) % n_sats] for i in range(nch)]
     handover, rec_t = None, None
     seed = 20241008 + 2
-    if R.world > 1 and not args.no_handover:
+    if R.dist is not None and not args.no_handover:
         # the sharded path's one exchange step: rank 0 holds the record (synthesised into a torch tensor, standing
         # for fread + upload), broadcasts it over RCCL, and every rank's engine adopts what arrived without a copy
         from cu_sdr_collection_amd.sharding import broadcast_record
@@ -435,7 +454,7 @@ def run_mix(P, W, args, R: Ranks, device: int):
     nsamp_of = lambda b: int(round(args.mix_seconds * fs_of(b)))
     first_engine, t_synth = {}, [0.0]
     handover = None
-    if R.world > 1 and not args.no_handover:
+    if R.dist is not None and not args.no_handover:
         import torch
 
         def read_record(band):           # runs on the band's first rank only

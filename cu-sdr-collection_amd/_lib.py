@@ -12,6 +12,7 @@ GC_OK, GC_E_INVALID, GC_E_RANGE, GC_E_NOMEM, GC_E_HIP, GC_E_STATE, GC_E_UNSUPPOR
 GC_I8, GC_I16 = 0, 1
 GC_REAL, GC_IQ, GC_QI = 0, 1, 2
 GC_MAX_ARMS = 3
+GC_SYNC_ZERO_IS_PLUS = 1   # gc_sync_xcorr flag
 GC_OUT_STRIDE = 6 * GC_MAX_ARMS
 GC_PLL_2ND_ORDER, GC_PLL_3_STATE = 0, 1
 GC_CNO_VSM, GC_CNO_PLD, GC_CNO_PLD_PILOT_SWAPPED, GC_CNO_PLD_PILOT = 0, 1, 2, 3   # gc_cno_mode
@@ -161,7 +162,9 @@ SYMBOLS = {
     "gc_acq_shift_prepare": (C.c_int, [_P, C.POINTER(gc_acq_shift_params)]),
     "gc_acq_shift_search": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "gc_acq_shift_row": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "gc_acq_shift_dims": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gc_preamble_xcorr": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int64, _P, C.c_int, C.POINTER(C.c_float)]),
+    "gc_sync_xcorr": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int64, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "gc_debug_first_sample_near_edge": (C.c_longlong, [C.c_double, C.c_double, C.c_longlong, C.c_double]),
     "gc_debug_last_kernel": (C.c_int, [_P]),
     "gc_debug_last_track_mode": (C.c_int, [_P]),

@@ -1964,6 +1964,18 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
   return GC_OK;
 }
 
+extern "C" int gc_acq_shift_dims(gc_context* ctx, int32_t* n, int32_t* rows, int32_t* n_arms_max) {
+  AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
+  if (!s || s->shift.n <= 0) {
+    gc_set_error("gc_acq_shift_dims: call gc_acq_shift_prepare first");
+    return GC_E_STATE;
+  }
+  if (n) *n = s->shift.n;
+  if (rows) *rows = s->shift.n_carriers * s->shift.n_signals * s->shift.n_bins;
+  if (n_arms_max) *n_arms_max = s->shift.n_arms_max;
+  return GC_OK;
+}
+
 extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
   AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
   if (!s || s->shift.n <= 0 || !out || row < 0 || row >= s->shift.n_carriers * s->shift.n_signals * s->shift.n_bins) {

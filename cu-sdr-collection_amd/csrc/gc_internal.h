@@ -157,6 +157,7 @@ struct gc_context {
   // are then launched with a plain launch instead of a cooperative one (gc_launch_persistent below).
   enum { TRK_CHAN = 0, TRK_DESC, TRK_PART, TRK_ARGS, TRK_RECORDS, TRK_HDESC, TRK_CNO, TRK_NBUF };
   GcBuf trk[TRK_NBUF];  // gc_track / gc_track_device: channel state, descriptor and partial-sum messages, arguments, records
+  GcBuf nav[3];  // gc_sync_xcorr: prompt stream, pattern, result
   double* cno_out = nullptr;  // gc_set_cno_output: caller-owned C/N0 buffer of the next tracking calls
   long long cno_cap = 0;
   bool concurrent_jobs = false;

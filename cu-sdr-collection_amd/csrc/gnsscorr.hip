@@ -98,6 +98,7 @@ int gc_destroy(gc_context* ctx) {
   if (ctx->d_replay_blocks) (void)hipFree(ctx->d_replay_blocks);
   if (ctx->d_replay_out) (void)hipFree(ctx->d_replay_out);
   for (GcBuf& b : ctx->trk) gc_buf_free(b);
+  for (GcBuf& b : ctx->nav) gc_buf_free(b);
   for (GcBuf& b : ctx->acqbuf) gc_buf_free(b);
   gc_acq_free(ctx);
   (void)hipEventDestroy(ctx->ev_start);

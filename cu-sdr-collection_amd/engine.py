@@ -382,13 +382,17 @@ class Engine:
         L.check(self._lib.gc_acq_shift_row(self._ctx, int(row), out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
-    def preamble_xcorr(self, i_p: np.ndarray, pattern: np.ndarray) -> np.ndarray:
+    def sync_xcorr(self, i_p: np.ndarray, pattern: np.ndarray, zero_is_plus: bool = False) -> np.ndarray:
+        """gc_sync_xcorr: the non-negative lags of xcorr(hard-limited I_P, pattern) (NAVdecoding.m of every package)."""
         x = np.ascontiguousarray(i_p, dtype=np.float64)
         pat = np.ascontiguousarray(pattern, dtype=np.int8)
         out = np.empty(x.shape[0], dtype=np.float32)
-        L.check(self._lib.gc_preamble_xcorr(self._ctx, x.ctypes.data_as(C.POINTER(C.c_double)), x.shape[0],
-                                            pat.ctypes.data_as(C.c_void_p), pat.shape[0], out.ctypes.data_as(C.POINTER(C.c_float))))
+        L.check(self._lib.gc_sync_xcorr(self._ctx, x.ctypes.data_as(C.POINTER(C.c_double)), x.shape[0], pat.ctypes.data_as(C.c_void_p),
+                                        pat.shape[0], L.GC_SYNC_ZERO_IS_PLUS if zero_is_plus else 0, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def preamble_xcorr(self, i_p: np.ndarray, pattern: np.ndarray) -> np.ndarray:
+        return self.sync_xcorr(i_p, pattern)
 
     def debug_fft(self, x: np.ndarray, inverse: bool = False) -> np.ndarray:
         """x: complex64 [nbatch, n].  The library's FFT (test hook)."""

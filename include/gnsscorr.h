@@ -448,11 +448,21 @@ int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* p);
 int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
                         float* row_max, int32_t* row_argmax);
 int gc_acq_shift_row(gc_context* ctx, int row, float* out /* n floats */);
+/* What the prepared search writes: samples per row (n), rows of gc_acq_shift_search's outputs (n_carriers * n_signals *
+ * n_bins) and the largest narms it takes - for callers that size their buffers (the MEX gateway); any pointer may be NULL. */
+int gc_acq_shift_dims(gc_context* ctx, int32_t* n, int32_t* rows, int32_t* n_arms_max);
 
 /* ---- bit synchronisation front end of navigation decoding ------------------------------
- * GPS_L1CA/include/NAVdecoding.m:62-76: out[l] = sum_k sgn(I_P[l+k]) * pattern[k] for lags l = 0 .. n-1 — the
- * non-negative-lag half of xcorr(bits, preamble_ms) with bits = +1 where I_P > 0, else -1.  The threshold / 6000-ms
- * spacing / parity logic (:78-100) stays with the caller (nav_sync.py). */
+ * What every package's NAVdecoding.m does first with a channel's prompt in-phase stream: hard-limit it and cross-correlate it
+ * with the sync pattern stretched to the stream's rate - GPS_L1CA/include/NAVdecoding.m:69-85 (160-sample TLM preamble),
+ * GAL_E1C :79-88, GAL_E5a :69-95, GAL_E5b :80-100, BDS/B1I :71-105, BDS/B3I :72-97, GLO_GL1 :69-86.
+ * out[l] = sum_k s(I_P[l+k]) * pattern[k] for lags l = 0 .. n-1 - the non-negative-lag half of xcorr(bits, pattern),
+ * tlmXcorrResult(xcorrLength : 2*xcorrLength - 1) - with s(x) = +1 for x > 0 and -1 otherwise, or with
+ * GC_SYNC_ZERO_IS_PLUS +1 for x >= 0 (Galileo E1: bits = (I_P < 0), GAL_E1C/include/NAVdecoding.m:84-85).
+ * pattern: m <= 8192 values in {-1, 0, +1}.  The packages' thresholds, spacing rules and word checks (GPS :94-145 ...)
+ * stay with the caller (nav_sync.py).  gc_preamble_xcorr is gc_sync_xcorr with flags = 0. */
+#define GC_SYNC_ZERO_IS_PLUS 1
+int gc_sync_xcorr(gc_context* ctx, const double* i_p, int64_t n, const int8_t* pattern, int m, int flags, float* out);
 int gc_preamble_xcorr(gc_context* ctx, const double* i_p, int64_t n, const int8_t* pattern, int m, float* out);
 
 /* Test hook (host only, no GPU): first sample i in [0, n) whose ramp value a + i*step is within eps chips of

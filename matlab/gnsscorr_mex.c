@@ -372,13 +372,17 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxGetDoubles(plhs[0])[0] = mr;
     mxGetDoubles(plhs[0])[1] = mi;
     mxGetDoubles(plhs[0])[2] = v;
-  } else if (!strcmp(cmd, "preamble_xcorr")) {
-    /* c = gnsscorr_mex('preamble_xcorr', h, I_P, int8(preamble_ms)): NAVdecoding.m:62-76, non-negative lags */
+  } else if (!strcmp(cmd, "preamble_xcorr") || !strcmp(cmd, "sync_xcorr")) {
+    /* c = gnsscorr_mex('sync_xcorr', h, I_P, int8(pattern)[, zeroIsPlus]): the non-negative lags of xcorr(hard-limited I_P, pattern)
+       of every package's NAVdecoding.m (GPS_L1CA :69-85 ...); zeroIsPlus = 1: Galileo E1's bits = (I_P < 0) */
+    if (nrhs < 4 || !mxIsDouble(prhs[2]) || !mxIsInt8(prhs[3]))
+      mexErrMsgIdAndTxt("gnsscorr:args", "sync_xcorr: (h, double I_P, int8 pattern[, zeroIsPlus])");
     const mwSize n = mxGetNumberOfElements(prhs[2]);
+    const int flags = (nrhs > 4 && mxGetScalar(prhs[4]) != 0) ? GC_SYNC_ZERO_IS_PLUS : 0;
     plhs[0] = mxCreateNumericMatrix(1, n, mxSINGLE_CLASS, mxREAL);
-    if (gc_preamble_xcorr(handle(prhs[1]), mxGetDoubles(prhs[2]), (int64_t)n, (const int8_t*)mxGetData(prhs[3]),
-                          (int)mxGetNumberOfElements(prhs[3]), (float*)mxGetData(plhs[0])))
-      fail("gc_preamble_xcorr");
+    if (gc_sync_xcorr(handle(prhs[1]), mxGetDoubles(prhs[2]), (int64_t)n, (const int8_t*)mxGetData(prhs[3]),
+                      (int)mxGetNumberOfElements(prhs[3]), flags, (float*)mxGetData(plhs[0])))
+      fail("gc_sync_xcorr");
   } else if (!strcmp(cmd, "acq_shift_prepare")) {
     /* the circular-shift search of BDS/B1I acquisition.m:100-167, GPS_L2C :119-190, BDS/B1C :120-200: wipe-off + forward
        transforms of the signal blocks, once per call */
@@ -398,10 +402,22 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (gc_acq_shift_prepare(handle(prhs[1]), &p)) fail("gc_acq_shift_prepare");
     plhs[0] = mxCreateDoubleScalar((double)p.n_carriers * p.n_signals * p.n_bins); /* number of result rows */
   } else if (!strcmp(cmd, "acq_shift_search")) {
-    /* codes: int8 n x narms, zero-padded replicas; rows ordered ((carrier*nSignals + signal)*nBins + bin); nrows from prepare */
+    /* codes: int8 n x narms, zero-padded replicas; rows ordered ((carrier*nSignals + signal)*nBins + bin).  The outputs are sized
+       from what the context prepared (gc_acq_shift_dims), never from the caller's numbers: the library writes `rows` values and
+       reads n * narms code samples whatever the arguments say. */
+    int32_t n = 0, nrows = 0, amax = 0;
+    if (gc_acq_shift_dims(handle(prhs[1]), &n, &nrows, &amax)) fail("gc_acq_shift_dims");
     const int narms = (int)mxGetN(prhs[2]);
-    const int nrows = (int)mxGetScalar(prhs[4]);
-    const double* w = nrhs > 3 && !mxIsEmpty(prhs[3]) ? mxGetDoubles(prhs[3]) : NULL;
+    if (!mxIsInt8(prhs[2]) || (int32_t)mxGetM(prhs[2]) != n || narms < 1 || narms > amax)
+      mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search: codes must be int8 of %d rows (samplesPerBlock) and 1..%d columns", (int)n, (int)amax);
+    if (nrhs > 4 && (int32_t)mxGetScalar(prhs[4]) != nrows)
+      mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search: the prepared search has %d rows, not %d", (int)nrows, (int)mxGetScalar(prhs[4]));
+    const double* w = NULL;
+    if (nrhs > 3 && !mxIsEmpty(prhs[3])) {
+      if (!mxIsDouble(prhs[3]) || (int)mxGetNumberOfElements(prhs[3]) < narms)
+        mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search: one double weight per code arm");
+      w = mxGetDoubles(prhs[3]);
+    }
     plhs[0] = mxCreateNumericMatrix(1, (mwSize)nrows, mxSINGLE_CLASS, mxREAL);
     mxArray* arg = mxCreateNumericMatrix(1, (mwSize)nrows, mxINT32_CLASS, mxREAL);
     if (gc_acq_shift_search(handle(prhs[1]), narms, (const int8_t*)mxGetData(prhs[2]), w, (float*)mxGetData(plhs[0]),
@@ -410,16 +426,30 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nlhs > 1) plhs[1] = arg; /* 0-based first position of each row's maximum */
     else mxDestroyArray(arg);
   } else if (!strcmp(cmd, "acq_shift_row")) {
-    plhs[0] = mxCreateNumericMatrix(1, (mwSize)mxGetScalar(prhs[3]), mxSINGLE_CLASS, mxREAL);
+    /* r = gnsscorr_mex('acq_shift_row', h, row0[, n]): one correlation row; its length is the prepared samplesPerBlock */
+    int32_t n = 0;
+    if (gc_acq_shift_dims(handle(prhs[1]), &n, NULL, NULL)) fail("gc_acq_shift_dims");
+    if (nrhs > 3 && (int32_t)mxGetScalar(prhs[3]) != n)
+      mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_row: a row of the prepared search has %d samples, not %d", (int)n, (int)mxGetScalar(prhs[3]));
+    plhs[0] = mxCreateNumericMatrix(1, (mwSize)n, mxSINGLE_CLASS, mxREAL);
     if (gc_acq_shift_row(handle(prhs[1]), (int)mxGetScalar(prhs[2]), (float*)mxGetData(plhs[0]))) fail("gc_acq_shift_row");
   } else if (!strcmp(cmd, "read_if")) {
-    /* x = gnsscorr_mex('read_if', h, firstSample0, n, class): raw record samples back, class 'int8' | 'int16', 2 values per
-       complex sample */
-    char cls[16] = "int8";
-    if (nrhs > 4) mxGetString(prhs[4], cls, sizeof cls);
+    /* x = gnsscorr_mex('read_if', h, firstSample0, n[, class[, valuesPerSample]]): raw record samples back in the record's own
+       class and order ('int8' | 'int16', 2 values per complex sample, 1 per real one): taken from the context (gc_if_format) -
+       gc_read_if writes n * bytes-per-sample of the RECORD; a class / count that disagrees with it is an error, not an overflow */
+    int dt = 0, lay = 0;
+    if (gc_if_format(handle(prhs[1]), &dt, &lay)) fail("gc_if_format");
     const mwSize n = (mwSize)mxGetScalar(prhs[3]);
-    const mwSize per = nrhs > 5 ? (mwSize)mxGetScalar(prhs[5]) : 2; /* values per sample: 2 (I/Q) or 1 (real) */
-    plhs[0] = mxCreateNumericMatrix(1, n * per, !strcmp(cls, "int16") ? mxINT16_CLASS : mxINT8_CLASS, mxREAL);
+    const mwSize per = lay == GC_REAL ? 1 : 2;
+    if (nrhs > 4) {
+      char cls[16] = "";
+      mxGetString(prhs[4], cls, sizeof cls);
+      if (strcmp(cls, dt == GC_I16 ? "int16" : "int8"))
+        mexErrMsgIdAndTxt("gnsscorr:args", "read_if: the record holds %s samples, not %s", dt == GC_I16 ? "int16" : "int8", cls);
+    }
+    if (nrhs > 5 && (mwSize)mxGetScalar(prhs[5]) != per)
+      mexErrMsgIdAndTxt("gnsscorr:args", "read_if: the record holds %d value(s) per sample", (int)per);
+    plhs[0] = mxCreateNumericMatrix(1, n * per, dt == GC_I16 ? mxINT16_CLASS : mxINT8_CLASS, mxREAL);
     if (gc_read_if(handle(prhs[1]), (uint64_t)mxGetScalar(prhs[2]), (uint64_t)n, mxGetData(plhs[0]))) fail("gc_read_if");
   } else if (!strcmp(cmd, "device_info")) {
     char name[128] = "";

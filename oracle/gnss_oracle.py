@@ -1467,3 +1467,101 @@ def find_subframe_start(i_p: np.ndarray, ms_to_process: int, search_start_offset
             if nav_parity_check(b[0:32]) != 0 and nav_parity_check(b[30:62]) != 0:
                 return int(i), full
     return None, full
+
+
+# --------------------------------------------------------------------------------------
+# Bit / frame synchronisation of every package (the block NAVdecoding.m starts with)
+# --------------------------------------------------------------------------------------
+_NH20 = np.array([-1, -1, -1, -1, -1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, 1, 1, 1, -1], dtype=np.float64)
+_BDS_PRE = np.array([1, 1, 1, -1, -1, -1, 1, -1, -1, 1, -1], dtype=np.float64)
+
+
+def xcorr_nonneg(bits: np.ndarray, pattern: np.ndarray) -> np.ndarray:
+    """tlmXcorrResult(xcorrLength : 2*xcorrLength - 1) of xcorr(bits, pattern): lags 0 .. n-1, the shorter input zero-padded."""
+    n = bits.shape[0]
+    return np.correlate(np.concatenate([bits, np.zeros(pattern.shape[0])]), pattern, mode="valid")[:n]
+
+
+def bch_15_11_errors(bits15) -> int:
+    """cnumerr of bchdec(gf(bits, 1), 15, 11) for hard bits, first = highest power of x: 0 when g(x) = x^4 + x + 1 divides the
+    word, else 1 (the (15,11) Hamming code corrects every single error, so a non-zero syndrome always decodes)."""
+    r = 0
+    for b in bits15:
+        r = (r << 1) | int(b)
+        if r & 0x10:
+            r ^= 0x13
+    return 0 if r == 0 else 1
+
+
+def nav_sync(package: str, i_p: np.ndarray, ms_to_process: int, prn: int = 0):
+    """The synchronisation block of <package>/include/NAVdecoding.m on one channel's prompt stream.  Returns
+    (xcorr over the non-negative lags, index as it stands when the candidate loop starts, candidates passing the spacing rule,
+    first verified start or None).  Lines restated:
+      GPS_L1CA  GPS/GPS_L1CA/include/NAVdecoding.m:66-145      GAL_E1C  GAL/GAL_E1C/include/NAVdecoding.m:59,79-110
+      GAL_E5a   GAL/GAL_E5a/include/NAVdecoding.m:54,69-108    GAL_E5b  GAL/GAL_E5b/include/NAVdecoding.m:59,80-119
+      BDS_B1I   BDS/B1I/include/NAVdecoding.m:68-170           BDS_B3I  BDS/B3I/include/NAVdecoding.m:69-164
+      GLO_GL1   GLO/GLO_GL1/include/NAVdecoding.m:66-105 (GLO_GL2: the same file)"""
+    x = np.asarray(i_p, dtype=np.float64).reshape(-1)
+    n = x.shape[0]
+    off = 1000 if package in ("BDS_B1I", "BDS_B3I") else 0
+    seg = x[off:]
+    if package == "GAL_E1C":
+        bits = 1.0 - 2.0 * (seg < 0)                                     # :84-85
+    else:
+        bits = np.where(seg > 0, 1.0, -1.0)                              # bits(bits > 0) = 1; bits(bits <= 0) = -1
+    c = 1
+    if package == "GPS_L1CA":
+        pat = np.kron(np.array([1, -1, -1, -1, 1, -1, 1, 1.0]), np.ones(20))
+    elif package == "GAL_E1C":
+        pat = np.array([1, -1, 1, -1, -1, 1, 1, 1, 1, 1.0])
+    elif package == "GAL_E5a":
+        cs = 1.0 - 2.0 * np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 1, 1, 0, 1, 0, 0, 1])
+        pat = np.kron(np.array([-1, 1, -1, -1, 1, -1, -1, -1, 1, 1, 1, 1.0]), cs)
+    elif package == "GAL_E5b":
+        pat = np.kron(np.array([1, -1, 1, -1, -1, 1, 1, 1, 1, 1.0]), np.array([-1, -1, -1, 1.0]))
+    elif package in ("BDS_B1I", "BDS_B3I"):
+        geo = prn <= 5 if package == "BDS_B1I" else (1 <= prn <= 5 or 59 <= prn <= 63)
+        c = 2 if geo else 20
+        pat = np.kron(_BDS_PRE, np.ones(2)) if geo else np.kron(_BDS_PRE, -_NH20)
+    elif package in ("GLO_GL1", "GLO_GL2"):
+        pat = np.kron(np.array([1, 1, 1, 1, 1, -1, -1, -1, 1, 1, -1, 1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, 1, -1, -1, 1, -1, 1, 1, -1.0]), np.ones(10))
+    else:
+        raise ValueError(package)
+    r = xcorr_nonneg(bits, pat)
+    a = np.abs(r)
+    rnd = np.floor(a + 0.5)
+    hit = {"GPS_L1CA": a > 153, "GAL_E1C": rnd >= 9.99, "GAL_E5a": rnd >= 239.99, "GAL_E5b": a > 39.99,
+           "BDS_B1I": a >= c * 10, "BDS_B3I": a >= c * 10, "GLO_GL1": a > 271, "GLO_GL2": a > 271}[package]
+    index = np.flatnonzero(hit) + 1 + off + (300 if package.startswith("GLO") else 0)
+    first = None
+    if package == "GPS_L1CA":
+        index = index[(index > 40) & (index < ms_to_process - (20 * 60 - 1))]
+        cand = [int(i) for i in index if np.any(index - i == 6000)]
+        for i in cand:
+            b = x[i - 40 - 1:i + 20 * 60 - 1].reshape(-1, 20).sum(axis=1)
+            b = np.where(b > 0, 1, -1)
+            if nav_parity_check(b[0:32]) != 0 and nav_parity_check(b[30:62]) != 0:
+                first = i
+                break
+    elif package == "GAL_E1C":
+        cand = [int(i) for i in index if np.any(index - i == 250) and np.any(index - i == 500) and i < ms_to_process / 4 - 7500]
+    elif package == "GAL_E5a":
+        cand = [int(i) for i in index if np.any(np.abs(index - i) == 10e3)]      # :102-108: index = newIndex
+        index = np.array(cand, dtype=np.int64)
+    elif package == "GAL_E5b":
+        cand = [int(i) for i in index if np.any(index - i == 250 * 4) and bits[i - 1:].shape[0] > 7500 * 4]
+    elif package in ("BDS_B1I", "BDS_B3I"):
+        if package == "BDS_B3I":
+            index = index[index < ms_to_process - 1500 * 20 + 300 * c]
+        cand = [int(i) for i in index if np.any(index - i == 300 * c)]
+        for i in cand:
+            if i + 30 * c - 1 > n:
+                break
+            b = x[i - 1:i + 30 * c - 1].reshape(-1, c).sum(axis=1)
+            b = (b > 0).astype(np.int64)
+            if bch_15_11_errors(b[15:30]) == 0:
+                first = i
+                break
+    else:
+        cand = [int(i) for i in index if np.any(index - i == 2000)]
+    return r, index.astype(np.int64), np.array(cand, dtype=np.int64), first

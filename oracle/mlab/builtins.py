@@ -976,6 +976,17 @@ def _ndims(I, a, n):
     return 2.0
 
 
+@builtin("height")
+def _height(I, a, n):
+    """height(A): number of rows (size(A, 1)), also for plain arrays since R2020b - NAVdecoding.m loops `1:height(index)`."""
+    return float(_size_of(a[0])[0])
+
+
+@builtin("width")
+def _width(I, a, n):
+    return float(_size_of(a[0])[1])
+
+
 @builtin("isempty")
 def _isempty(I, a, n):
     r, c = _size_of(a[0])

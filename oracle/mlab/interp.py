@@ -128,6 +128,28 @@ class Interpreter:
             pass
         return ws
 
+    def run_lines(self, fname, ranges, ws=None):
+        """Executes the statements of `fname` that lie on the given 1-based inclusive line ranges, as a script in `ws` - a SECTION
+        of a reference function whose other parts need toolboxes this interpreter does not restate (the bit-synchronisation
+        block of NAVdecoding.m without its Viterbi / CRC / ephemeris tail).  Lines outside the ranges are blanked, so line
+        numbers in error messages stay the file's own."""
+        lines = open(fname, encoding="latin-1").read().splitlines()
+        keep = [False] * len(lines)
+        for a, b in ranges:
+            for k in range(a - 1, min(b, len(lines))):
+                keep[k] = True
+        text = "\n".join(ln if k else "" for ln, k in zip(lines, keep)) + "\n"
+        funcs, script = parse(text, fname)
+        if funcs:
+            raise MError("run_lines: the ranges must not contain a function header")
+        ws = {} if ws is None else ws
+        frame = Frame(self, ws, {}, fname)
+        try:
+            frame.exec_block(script)
+        except _Return:
+            pass
+        return ws
+
     def call_user(self, fn, args, nargout):
         if isinstance(fn, tuple) and fn[0] == "script":
             raise MError("scripts cannot be called with arguments")

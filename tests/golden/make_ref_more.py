@@ -191,3 +191,72 @@ def gen_prerun(only=None):
         out[pkg] = rec
         print(f"[prerun] {pkg}/include/preRun.m: {sum(1 for c in ch if c.status == 'T')} channels assigned, fields {sorted(vars(ch[0]))}", flush=True)
     json.dump(out, open(os.path.join(HERE, "ref_prerun.json"), "w"), indent=0)
+
+
+def _bchdec_standin(I, a, nargout):
+    """bchdec(code, 15, 11) for the one use the reference makes of it (BDS/B1I NAVdecoding.m:151-155: `[~, cnumerr] = bchdec(...)`
+    on 15 hard bits): MATLAB documents the code word as a row with the first element the highest power, the narrow-sense
+    generator x^4 + x + 1 for (15, 11), and cnumerr = the number of corrected errors (0 for a code word; the perfect code corrects
+    exactly one error for every other word).  A stand-in for a Communications Toolbox built-in: restated from its documentation."""
+    bits = [int(round(float(v))) for v in np.asarray(mlab.from_matlab(a[0]), dtype=np.float64).reshape(-1)]
+    assert len(bits) == 15 and int(mlab.from_matlab(a[1])) == 15 and int(mlab.from_matlab(a[2])) == 11
+    r = 0
+    for b in bits:
+        r = (r << 1) | b
+        if r & 0x10:
+            r ^= 0x13
+    if r:                                     # correct the single error the syndrome points at
+        for k in range(15):
+            t = list(bits)
+            t[k] ^= 1
+            rr = 0
+            for b in t:
+                rr = (rr << 1) | b
+                if rr & 0x10:
+                    rr ^= 0x13
+            if rr == 0:
+                bits = t
+                break
+    dec = mlab.to_matlab(np.array([bits[:11]], dtype=np.float64))
+    return (dec, 0.0 if r == 0 else 1.0)[:max(nargout, 1)] if nargout > 1 else dec
+
+
+def gen_navsync(only=None):
+    """Executes the synchronisation block of every package's NAVdecoding.m - the lines of NavSyncScene.ranges, in place, as they
+    stand - on the scene's prompt stream and stores tlmXcorrResult's non-negative lags (SHA-256 of the int16 values + the first
+    4096 of them), `index` as the block leaves it, and, where the range includes the verification loop, what it found."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), ".."))
+    from cu_sdr_collection_amd import nav_sync
+    from oracle import gnss_oracle as O
+    for sc in RS.NAVSYNC_SCENES:
+        if only and only != sc.name:
+            continue
+        t0 = time.time()
+        pat = nav_sync.SYNC[sc.package].pattern(sc.prn)
+        x = RS.navsync_stream(sc, pat, parity_check=O.nav_parity_check)
+        I = interpreter(sc.pkg)
+        I.extra_builtins["gf"] = lambda I_, a, n: a[0]                     # gf(bits, 1): GF(2) array of the same 0 / 1 values
+        I.extra_builtins["bchdec"] = _bchdec_standin
+        ws = {sc.stream_var: mlab.to_matlab(x.reshape(1, -1)), "PRN": mlab.to_matlab(float(sc.prn)),
+              "settings": mlab.to_matlab(SimpleNamespace(msToProcess=float(sc.ms_to_process))),
+              "subFrameStart": mlab.to_matlab(float("inf")), "firstSubFrame": mlab.to_matlab(float("inf")),
+              "TOW": mlab.to_matlab(float("inf")), "SOW": mlab.to_matlab(float("inf"))}
+        ws = I.run_lines(os.path.join(REF, sc.pkg, "include", "NAVdecoding.m"), sc.ranges, ws)
+        full = np.asarray(mlab.from_matlab(ws["tlmXcorrResult"]), dtype=np.float64).reshape(-1)
+        half = (full.shape[0] + 1) // 2
+        r = full[half - 1:]
+        assert np.array_equal(r, np.rint(r)) and np.abs(r).max() < 32768
+        r16 = r.astype(np.int16)
+        index = np.asarray(mlab.from_matlab(ws["index"]), dtype=np.float64).reshape(-1)
+        out = {"stream_crc32": np.array([RS.crc(x)], dtype=np.uint32), "pkg": np.array(sc.pkg), "ranges": np.array(sc.ranges, dtype=np.int64),
+               "xcorr_len": np.array([r16.shape[0]]), "xcorr_sha256": np.array(hashlib.sha256(r16.tobytes()).hexdigest()),
+               "xcorr_head": r16[:4096], "xcorr_at_index_minus_shift": np.zeros(0, dtype=np.int16), "index": index.astype(np.int64),
+               "stdout": np.array("".join(I.out)[-500:])}
+        if sc.loop_var:
+            v = float(np.asarray(mlab.from_matlab(ws[sc.loop_var])).reshape(-1)[0])
+            out["first"] = np.array([-1 if not np.isfinite(v) else int(v)], dtype=np.int64)
+        path = os.path.join(HERE, f"ref_navsync_{sc.name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"[navsync] {sc.name}: {sc.pkg}/include/NAVdecoding.m lines {sc.ranges}, {r16.shape[0]} lags, index {index.astype(int).tolist()[:12]}"
+              f"{'...' if index.size > 12 else ''}, first {out.get('first', ['-'])[0]}, {time.time() - t0:.1f} s", flush=True)

@@ -13,6 +13,7 @@ Fixtures:
     ref_codes.npz           sha-256 + leading chips of every code generator / sampled-table maker, all PRNs
     ref_settings.json       settings = initSettings() of the 12 packages (the fields the hot path reads)
     ref_prerun.npz          channel = preRun(acqResults, settings) of the package families
+    ref_navsync_<scene>.npz the synchronisation block of NAVdecoding.m (pattern, xcorr, index, candidate loop) of every package
 """
 from __future__ import annotations
 
@@ -102,7 +103,7 @@ def gen_track(sc: RS.TrackScene):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", nargs="*", default=["track", "acq", "codes", "settings", "prerun"])
+    ap.add_argument("what", nargs="*", default=["track", "acq", "codes", "settings", "prerun", "navsync"])
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -113,7 +114,7 @@ def main():
                 continue
             gen_track(sc)
     import make_ref_more as MORE
-    for what in ("acq", "codes", "settings", "prerun"):
+    for what in ("acq", "codes", "settings", "prerun", "navsync"):
         if what in a.what:
             getattr(MORE, "gen_" + what)(a.only)
 

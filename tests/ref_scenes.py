@@ -478,3 +478,111 @@ def acq_inputs(P, sc: AcqScene):
     for k, v in sc.overrides.items():
         setattr(S, k, v)
     return S, sc.build(P, S)
+
+
+# =========================================================================================================================
+# Bit / frame synchronisation: prompt streams for the sync block of every package's NAVdecoding.m
+# =========================================================================================================================
+@dataclass
+class NavSyncScene:
+    name: str                     # fixture: tests/golden/ref_navsync_<name>.npz
+    pkg: str                      # reference package directory
+    package: str                  # cu_sdr_collection_amd.nav_sync.SYNC key
+    ranges: tuple                 # 1-based inclusive line ranges of <pkg>/include/NAVdecoding.m that are executed (the sync block)
+    stream_var: str               # name of the prompt stream in the file (function argument)
+    prn: int
+    n: int                        # values in the stream
+    ms_to_process: int
+    frame: int                    # samples between two sync patterns
+    first: int                    # 0-based position of the first pattern
+    sps: int                      # samples per data symbol
+    spread: tuple = ()            # what a data symbol is multiplied by, sample by sample (secondary / NH code); () = ones
+    sigma: float = 0.4            # noise sigma in units of the symbol amplitude
+    seed: int = 0
+    verified: str = ""            # "gps": TLM / HOW words with valid parity after the preamble; "bds": valid BCH(15,11) second half
+    loop_var: str = ""            # workspace variable the executed loop leaves the verified start in ('' = the range ends before the loop)
+
+
+def _gps_words(rng, parity_check, polarity, prev):
+    """One 300-bit sub-frame as +-1 values whose every word passes navPartyChk: word 1 starts with the TLM preamble (x polarity),
+    the 24 information bits of a word are random, its six parity bits are the one combination (of 64) that checks."""
+    out = []
+    for w in range(10):
+        t = rng.integers(0, 2, 24) * 2 - 1
+        if w == 0:
+            t[:8] = polarity * np.array([1, -1, -1, -1, 1, -1, 1, 1])
+        for c in range(64):
+            par = np.array([1 if (c >> k) & 1 else -1 for k in range(6)])
+            word = np.concatenate([prev, t, par])
+            if parity_check(word) != 0:
+                break
+        else:
+            raise AssertionError("no parity combination checks")
+        out.append(word[2:])
+        prev = word[30:32]
+    return np.concatenate(out), prev
+
+
+def navsync_stream(sc: NavSyncScene, pattern: np.ndarray, parity_check=None) -> np.ndarray:
+    """The scene's prompt in-phase stream (float64[n]): random data symbols (each spread by sc.spread), the sync pattern at
+    sc.first + k * sc.frame with alternating-ish polarity, Gaussian noise, a handful of exact zeros.  `pattern`: the package's sync
+    pattern at the stream's rate; `parity_check`: navPartyChk (needed for verified == "gps")."""
+    rng = np.random.default_rng(sc.seed)
+    spread = np.asarray(sc.spread if sc.spread else np.ones(sc.sps), dtype=np.float64)
+    assert spread.shape[0] == sc.sps
+    nsym = sc.n // sc.sps + 2
+    x = np.kron(rng.integers(0, 2, nsym) * 2.0 - 1.0, spread)
+    shift = sc.first % sc.sps                       # data symbol boundaries line up with the frames
+    x = np.concatenate([x[sc.sps - shift:], x[:sc.sps - shift]])[:sc.n] if shift else x[:sc.n]
+    prev = np.array([1, 1])
+    k = 0
+    while sc.first + k * sc.frame < sc.n:
+        s0 = sc.first + k * sc.frame
+        pol = 1 if (k % 3) != 1 else -1
+        if sc.verified == "gps":
+            words, prev = _gps_words(rng, parity_check, pol, prev)
+            seg = np.kron(words.astype(np.float64), spread)
+        else:
+            seg = pol * pattern.astype(np.float64)
+            if sc.verified == "bds":                # 11 preamble bits, 4 free bits, then a BCH(15,11) code word (first bit = highest power)
+                msg = rng.integers(0, 2, 11)
+                r = 0
+                for b in list(msg) + [0, 0, 0, 0]:
+                    r = (r << 1) | int(b)
+                    if r & 0x10:
+                        r ^= 0x13
+                cw = np.concatenate([msg, [(r >> 3) & 1, (r >> 2) & 1, (r >> 1) & 1, r & 1]])
+                if k % 4 == 2:
+                    cw[5] ^= 1                      # every fourth frame carries a corrupted word: found by the correlation, refused by the check
+                bits = np.concatenate([rng.integers(0, 2, 4), cw]) * 2.0 - 1.0
+                # the reference sums a bit's samples WITHOUT wiping the NH code off (BDS/B1I NAVdecoding.m:146-147): bit x spread
+                seg = np.concatenate([seg, pol * np.kron(bits, spread)])
+        m = min(seg.shape[0], sc.n - s0)
+        x[s0:s0 + m] = seg[:m]
+        k += 1
+    x = 1000.0 * (x + sc.sigma * rng.standard_normal(sc.n))
+    x[rng.integers(0, sc.n, 12)] = 0.0              # exact zeros: `bits <= 0` vs Galileo E1's `I_P < 0`
+    for j in range(0, sc.n - sc.first, sc.frame):   # ... some of them inside a sync pattern, where the rule decides a detection
+        x[sc.first + j + (3 * (j // sc.frame)) % max(1, pattern.shape[0])] = 0.0
+    return x
+
+
+_NH20 = (-1, -1, -1, -1, -1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, 1, 1, 1, -1)
+NAVSYNC_SCENES = [
+    NavSyncScene("GPS_L1CA", "GPS/GPS_L1CA", "GPS_L1CA", ((66, 145),), "I_P_InputBits", 7, 20000, 20000, 6000, 777, 20, sigma=0.42, seed=8101,
+                 verified="gps", loop_var="subFrameStart"),
+    NavSyncScene("GAL_E1C", "GAL/GAL_E1C", "GAL_E1C", ((59, 59), (79, 97)), "I_P", 11, 9500, 38000, 250, 123, 1, sigma=0.55, seed=8102),
+    NavSyncScene("GAL_E5a", "GAL/GAL_E5a", "GAL_E5a", ((54, 54), (69, 71), (84, 108)), "I_P", 12, 32000, 32000, 10000, 1501, 20,
+                 spread=tuple(1 - 2 * np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 1, 1, 0, 1, 0, 0, 1])), sigma=0.22, seed=8103),
+    NavSyncScene("GAL_E5b", "GAL/GAL_E5b", "GAL_E5b", ((59, 59), (80, 85), (88, 107)), "I_P", 19, 36000, 36000, 1000, 333, 4, spread=(-1, -1, -1, 1),
+                 sigma=0.3, seed=8104),
+    NavSyncScene("BDS_B1I_MEO", "BDS/B1I", "BDS_B1I", ((68, 170),), "I_P_InputBits", 12, 20000, 20000, 6000, 1404, 20, spread=tuple(-v for v in _NH20),
+                 sigma=0.35, seed=8105, verified="bds", loop_var="subFrameStart"),
+    NavSyncScene("BDS_B1I_GEO", "BDS/B1I", "BDS_B1I", ((68, 170),), "I_P_InputBits", 3, 6000, 6000, 600, 1111, 2, sigma=0.5, seed=8106,
+                 verified="bds", loop_var="subFrameStart"),
+    NavSyncScene("BDS_B3I_MEO", "BDS/B3I", "BDS_B3I", ((69, 164),), "I_P_InputBits", 30, 44000, 44000, 6000, 2222, 20, spread=tuple(-v for v in _NH20),
+                 sigma=0.35, seed=8107, verified="bds", loop_var="subFrameStart"),
+    NavSyncScene("BDS_B3I_GEO", "BDS/B3I", "BDS_B3I", ((69, 164),), "I_P_InputBits", 60, 34000, 34000, 600, 1051, 2, sigma=0.5, seed=8108,
+                 verified="bds", loop_var="subFrameStart"),
+    NavSyncScene("GLO_GL1", "GLO/GLO_GL1", "GLO_GL1", ((66, 97),), "I_P_InputBits", 0, 12000, 12000, 2000, 455, 10, sigma=0.5, seed=8109),
+]

@@ -64,3 +64,22 @@ def test_sharded_l1ca_line_hands_the_record_over_and_shards_acquisition_by_prn()
     res2 = _bench("--gpus", "2", "--seconds", "4", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-handover")
     assert "handover" not in res2 and [r["channels_locked"] for r in res2["ranks"]] == [12, 12]
     assert res2["acquisition"]["acquired"] == a["acquired"]
+
+
+def test_rccl_process_group_carries_the_hand_over_at_world_size_one():
+    """The process group the driver's 8-GPU run uses - "cpu:gloo,cuda:nccl", RCCL probe, broadcast of the GPU tensor, gc_attach_if -
+    with the one rank a 1-GPU box allows (GC_BENCH_FORCE_DIST): the record's hand-over runs over backend nccl."""
+    env = dict(os.environ, GC_BENCH_FORCE_DIST="1")
+    env.pop("GC_BENCH_DEVICE", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "l1ca", "--seconds", "4", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["handover"]["backend"].startswith("nccl"), res["handover"]
+    assert res["closed_loop"]["channels_locked"] == 12 and res["replay_vs_closed_loop_max_dev"] < 2e-5

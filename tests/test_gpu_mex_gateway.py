@@ -74,6 +74,30 @@ def test_mex_gateway_commands(gateway, l1ca_scene):
     assert "gc_track" in str(e.value) and "table" in str(e.value)
     with pytest.raises(harness.MexError):
         gateway.call("no_such_command", h)
+    # outputs are sized from the context, not from the caller's numbers - a class or a length that disagrees with
+    # what the library will write is an error in MATLAB's terms, never a write past an mxArray
+    assert gateway.call("read_if", h, 100, 50).dtype == np.int8                # class and values per sample default to the record's
+    with pytest.raises(harness.MexError) as e:
+        gateway.call("read_if", h, 100, 50, "int16", 2)
+    assert "int8" in str(e.value)
+    with pytest.raises(harness.MexError):
+        gateway.call("read_if", h, 100, 50, "int8", 1)
+    gateway.call("load_if", h, iq[:40000].astype(np.int16), 2, S.samplingFreq, nargout=0)
+    back16 = gateway.call("read_if", h, 10, 20)
+    assert back16.dtype == np.int16 and np.array_equal(back16.reshape(-1), iq[20:60].astype(np.int16))
+    with pytest.raises(harness.MexError) as e:
+        gateway.call("read_if", h, 10, 20, "int8", 2)                           # the r2 default: would have written 80 bytes into 40
+    assert "int16" in str(e.value)
+    with pytest.raises(harness.MexError) as e:
+        gateway.call("acq_shift_row", h, 0, 123)                                # nothing prepared
+    assert "gc_acq_shift_prepare" in str(e.value)
+    # sync_xcorr: classes checked, the Galileo E1 zero rule as a flag
+    x = np.array([3.0, 0.0, -2.0, 5.0, 0.0, 1.0])
+    pat = np.array([1, -1, 1], dtype=np.int8)
+    assert list(gateway.call("sync_xcorr", h, x, pat).reshape(-1)) == [1 + 1 - 1, -1 + 1 + 1, -1 - 1 - 1, 1 + 1 + 1, -1 - 1, 1]
+    assert list(gateway.call("sync_xcorr", h, x, pat, 1).reshape(-1)) == [1 - 1 - 1, 1 + 1 + 1, -1 - 1 + 1, 1 - 1 + 1, 1 - 1, 1]
+    with pytest.raises(harness.MexError):
+        gateway.call("sync_xcorr", h, x, pat.astype(np.float64))
     gateway.call("destroy", h, nargout=0)
     with pytest.raises(harness.MexError):
         gateway.call("device_info", h, nargout=2)

@@ -238,3 +238,47 @@ def test_correlator_replayed_from_the_references_own_state_returns_the_reference
                 di = np.max(np.abs(a61 * i61 + a11 * q11 - z["f_Pilot_I_" + tap][k])) / full
                 dq = np.max(np.abs(a61 * q61 - a11 * i11 - z["f_Pilot_Q_" + tap][k])) / full
                 assert di < 2e-6 and dq < 2e-6, (sc.name, k, tap, di, dq)
+
+
+@pytest.mark.parametrize("sc", RS.NAVSYNC_SCENES, ids=[s.name for s in RS.NAVSYNC_SCENES])
+def test_hip_bit_sync_equals_the_references_navdecoding_m(engine, sc):
+    """SURVEY §8f.4, no oracle in between: gc_sync_xcorr + nav_sync's table against what the synchronisation block of the package's
+    own NAVdecoding.m computes on the same prompt stream (tests/golden/ref_navsync_*: the file's lines executed in place) -
+    tlmXcorrResult over the non-negative lags bit for bit, `index`, and the verified start where the block has a verification."""
+    import hashlib
+    import cu_sdr_collection_amd as P
+    from oracle import gnss_oracle as O
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"ref_navsync_{sc.name}.npz"), allow_pickle=False)
+    x = RS.navsync_stream(sc, P.nav_sync.SYNC[sc.package].pattern(sc.prn), parity_check=O.nav_parity_check)
+    assert RS.crc(x) == int(ref["stream_crc32"][0])
+    got = P.nav_sync.find_sync(engine, sc.package, x, sc.ms_to_process, prn=sc.prn)
+    r = got.xcorr
+    assert r.dtype == np.float32 and r.shape[0] == int(ref["xcorr_len"][0]) and np.array_equal(r, np.rint(r))
+    assert hashlib.sha256(r.astype(np.int16).tobytes()).hexdigest() == str(ref["xcorr_sha256"])
+    assert np.array_equal(r[:4096].astype(np.int16), ref["xcorr_head"])
+    assert np.array_equal(got.index, ref["index"]) and got.index.size > 0
+    if sc.loop_var:
+        assert (got.first if got.first is not None else -1) == int(ref["first"][0])
+    # the spacing rule of the packages whose verification is the navigation decoder proper: the oracle's restatement
+    _, _, cand, _ = O.nav_sync(sc.package, x, sc.ms_to_process, sc.prn)
+    assert np.array_equal(got.candidates, cand)
+
+
+def test_sync_xcorr_edges_and_arguments(engine):
+    """Streams shorter than the pattern, lengths around the kernel's 1024-lag tiles, the two zero rules, argument errors."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    from oracle import gnss_oracle as O
+    rng = np.random.default_rng(77)
+    for n, m in ((5, 160), (1023, 300), (1024, 10), (1025, 240), (3000, 1), (4097, 8192)):
+        x = rng.standard_normal(n)
+        x[rng.integers(0, n, 3)] = 0.0
+        pat = rng.integers(-1, 2, m).astype(np.int8)
+        for zp in (False, True):
+            bits = (1.0 - 2.0 * (x < 0)) if zp else np.where(x > 0, 1.0, -1.0)
+            assert np.array_equal(engine.sync_xcorr(x, pat, zero_is_plus=zp), O.xcorr_nonneg(bits, pat.astype(np.float64)).astype(np.float32)), (n, m, zp)
+    with pytest.raises(L.GnssCorrError) as e:
+        engine.sync_xcorr(np.ones(10), np.ones(8193, dtype=np.int8))
+    assert e.value.status == L.GC_E_INVALID
+    with pytest.raises(ValueError):
+        P.nav_sync.find_sync(engine, "BDS_B1I", np.ones(900), prn=8)          # the stream ends before searchStartOffset = 1000

@@ -240,3 +240,26 @@ def test_oracle_acquisition_equals_the_references_acquisition_m(sc):
         else:
             assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
+
+
+@pytest.mark.parametrize("sc", RS.NAVSYNC_SCENES, ids=[s.name for s in RS.NAVSYNC_SCENES])
+def test_oracle_bit_sync_equals_the_references_navdecoding_m(sc):
+    """the synchronisation block of every package's NAVdecoding.m, executed in place by oracle/mlab
+    (tests/golden/make_ref_more.py::gen_navsync), against the oracle's restatement: tlmXcorrResult over the non-negative lags
+    (integers: bit for bit), `index` as the block leaves it, and - where the executed lines include the verification loop
+    (GPS: navPartyChk.m executed as it stands; BDS: bchdec through a documented stand-in) - the start it settles on."""
+    import hashlib
+    from cu_sdr_collection_amd import nav_sync
+    ref = _load(f"ref_navsync_{sc.name}.npz")
+    x = RS.navsync_stream(sc, nav_sync.SYNC[sc.package].pattern(sc.prn), parity_check=O.nav_parity_check)
+    assert RS.crc(x) == int(ref["stream_crc32"][0])
+    r, index, cand, first = O.nav_sync(sc.package, x, sc.ms_to_process, sc.prn)
+    assert r.shape[0] == int(ref["xcorr_len"][0]) and np.array_equal(r, np.rint(r))
+    assert hashlib.sha256(r.astype(np.int16).tobytes()).hexdigest() == str(ref["xcorr_sha256"])
+    assert np.array_equal(r[:4096].astype(np.int16), ref["xcorr_head"])
+    assert np.array_equal(index, ref["index"]) and index.size > 0
+    if sc.loop_var:
+        assert (first if first is not None else -1) == int(ref["first"][0])
+        assert first in cand
+    if sc.name == "GAL_E5a":          # the executed range ends behind the file's own spacing filter (newIndex, :102-108)
+        assert np.array_equal(cand, index)
