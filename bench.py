@@ -168,38 +168,77 @@ def _record_tensor(R: "Ranks", eng, n_samples: int, dtype=np.int8, layout=None):
     return t
 
 
-def _traffic(kind: str, blocks: int):
-    """HBM bytes per launch of a replay kernel, measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command
-    (separate passes, gfx950 corrections: MI355X_MICROARCH.md) and stored under profiles/: the newest file that matches."""
-    for rnd in ("r02", "r01"):
+_LIB_SHA = None
+
+
+def _lib_sha() -> str:
+    """SHA-256 of the libgnsscorr.so this process loaded (cu_sdr_collection_amd.build.verify also ties it to the sources)."""
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        import hashlib
+        path = os.path.join(ROOT, "cu-sdr-collection_amd", "lib", "libgnsscorr.so")
+        _LIB_SHA = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    return _LIB_SHA
+
+
+def _traffic_entries():
+    """Counter passes committed under profiles/ (scripts/collect_profiles.sh + profiles_digest.py: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, gfx950 corrections of MI355X_MICROARCH.md), newest round first.  An entry counts only when it
+    was measured on THIS build (its lib_sha256 = the loaded library's): a kernel change without a re-profile drops the traffic
+    figure instead of carrying a stale one."""
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         try:
             tj = json.load(open(path))
         except (OSError, ValueError):
             continue
         for e in (tj if isinstance(tj, list) else [tj]):
-            if e.get("workload", "l1ca") == kind and e.get("blocks_per_launch") == blocks:
-                return e["hbm_bytes_per_launch"], f"profiles/{rnd}/traffic.json, measured offline ({e.get('build', 'round-1 v8 build')})"
-    return None, None
+            yield rnd, e
 
 
-_SHAPE_OF = {"GPS_L5C": "l5", "BDS_B2a": "l5", "GAL_E1C_CBOC": "cboc", "GAL_E1C": "e1x8", "BDS_B1C_NB": "b1c"}
+def _traffic(kind: str, blocks: int):
+    """HBM bytes per launch of a replay kernel from the counter passes of this build: (bytes, source) or (None, why not)."""
+    stale = None
+    for rnd, e in _traffic_entries():
+        if e.get("workload", "l1ca") == kind and e.get("blocks_per_launch") == blocks and e.get("hbm_bytes_per_launch"):
+            if e.get("lib_sha256") == _lib_sha():
+                return e["hbm_bytes_per_launch"], f"profiles/{rnd}/traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this command on this build (libgnsscorr.so {_lib_sha()[:12]})"
+            stale = stale or f"profiles/{rnd}/traffic.json was measured on another build ({str(e.get('lib_sha256'))[:12]}, {e.get('build')}); this one is {_lib_sha()[:12]}: dropped"
+    return None, stale
+
+
+_SHAPE_OF = {"GPS_L5C": "l5", "BDS_B2a": "l5", "GAL_E1C_CBOC": "cboc", "GAL_E1C": "e1x8", "BDS_B1C_NB": "b1c", "GPS_L1CA": "l1ca3"}
 
 
 def _traffic_scaled(signal: str, channel_samples: float, bytes_per_sample: float):
-    """HBM bytes of one replay launch of a BASELINE shape, scaled from the counter passes on the 5-s record of the same shape
-    (profiles/r0x/traffic.json: FETCH_SIZE x 2 per channel-sample; int16 records scale with the sample size)."""
+    """HBM bytes of one replay launch of a BASELINE shape, scaled from the counter passes on the 5-s record of the same shape and
+    the same build (FETCH_SIZE x 2 per channel-sample; int16 records scale with the sample size)."""
     shape = _SHAPE_OF.get(signal)
-    for rnd in ("r02",):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
-        except (OSError, ValueError):
-            continue
-        for e in tj:
-            if e.get("workload") == shape and e.get("channel_samples_per_launch") and e.get("hbm_bytes_per_launch"):
-                per = e["hbm_bytes_per_launch"] / e["channel_samples_per_launch"] * (bytes_per_sample / 2.0)
-                return int(per * channel_samples), f"profiles/{rnd}/traffic.json: {per:.2f} B per channel-sample measured on the 5-s '{shape}' shape, scaled"
-    return None, None
+    stale = None
+    for rnd, e in _traffic_entries():
+        if e.get("workload") == shape and e.get("channel_samples_per_launch") and e.get("hbm_bytes_per_launch"):
+            if e.get("lib_sha256") != _lib_sha():
+                stale = stale or f"profiles/{rnd}/traffic.json ('{shape}') was measured on another build: dropped"
+                continue
+            per = e["hbm_bytes_per_launch"] / e["channel_samples_per_launch"] * (bytes_per_sample / 2.0)
+            return int(per * channel_samples), f"profiles/{rnd}/traffic.json: {per:.2f} B per channel-sample measured on the 5-s '{shape}' shape of this build, scaled"
+    return None, stale
+
+
+def _cpu_model():
+    """Model name and counts of the host CPU the baseline ran on (/proc/cpuinfo)."""
+    model, sockets, cores = None, set(), 0
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model is None:
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                sockets.add(ln.split(":", 1)[1].strip())
+            elif ln.startswith("processor"):
+                cores += 1
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": cores or os.cpu_count(), "sockets": len(sockets) or None}
 
 
 # =======================================================================================================================
@@ -337,6 +376,7 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
                      "kernel": "corr_epl_fast_kernel<ARMS=1, I8_IQ, SPL=16> (four waves, float tables)", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": algo_bytes},
         "replay_vs_closed_loop_max_dev": replay_dev, "device": dev_name, "compute_units": cus, "synth_s": round(t_synth, 2),
+        "libgnsscorr_sha256": _lib_sha(),
     }
     if handover:
         result["handover"] = handover
@@ -696,6 +736,7 @@ def cpu_leg(P, W, args, main, extra_jobs):
     agree = float(max(np.max(np.abs(nref[k].I_P - ref["I_P"][k][:np_epochs])) for k in range(nch)))
     base = {
         "value": round(max(cpu_msps, np_msps) / nch, 3), "unit": "IF Msamples/s (all channels active)", "cores": 1, "kind": "port",
+        "host_cpu": _cpu_model(),
         "sample": f"oracle/gnss_oracle.c (float64 restatement of tracking.m:133-368, gcc -O3), closed loop, {nch} channels x {cpu_epochs} epochs "
                   f"of the same record ({t_cpu:.1f} s of CPU); MATLAB-equivalent CPU restatement, not MATLAB",
         "corr_msps": round(cpu_msps, 2), "x_realtime": round(cpu_msps / nch / (fs / 1e6), 4),
