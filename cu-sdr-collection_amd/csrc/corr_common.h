@@ -39,6 +39,13 @@ __host__ __device__ inline unsigned int gc_tie_window_units(double max_ramp, int
   return 2u + (unsigned int)drift + (unsigned int)(max_ramp * (16.0 * 2.220446049250313e-16 * 4294967296.0));
 }
 
+// The same for a derived arm (corr_lane.hip): its position is the base ramp's fraction times m6 (6), so the base ramp's rounding
+// (the 2 + drift units above) counts m6 times, in units of 2^-32 of ITS entries; the float64 term is already in those units.
+__host__ __device__ inline unsigned int gc_tie_window_units6(double max_ramp, int lane_steps, double m6) {
+  const int drift = lane_steps <= kLaneReseedSteps ? lane_steps : kLaneReseedSteps + lane_steps / kLaneReseedSteps + 1;
+  return (unsigned int)(m6 * (double)(4 + drift)) + 8u + (unsigned int)(max_ramp * (16.0 * 2.220446049250313e-16 * 4294967296.0));
+}
+
 struct TaggedSlot {
   double value;
   unsigned int tag;
@@ -81,7 +88,7 @@ struct KArgs {
   long long total_wg;  // xcd_swizzle outside the device loop: workgroups of the launch that have work (the grid is that rounded up to 8)
   int share_el;  // every block has el_spacing*R*M == 1/2: early and late taps share one ramp
   int derived;   // lane kernel: three-arm channels whose third arm is derived from the second (DevChannel::derived)
-  int pad_;
+  int rho_off;   // lane kernel: byte offset in dynamic LDS of the waves' carrier-step tables (kLaneReseedSteps float2 per wave)
 };
 
 // t = k0 - G / 2^64 ;  ceil(t + x) for x = xi + xf/2^64  is  k0 + xi + (xf > G)

@@ -51,10 +51,14 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // DER: the last arm has no table: it is arm LA - 1 read at six times the ramp rate with a sign pattern (BOC(6,1) from
   // BOC(1,1): entry k6 of its padded table = entry p = (k6 + 5) / 6 of the neighbour's times (-1)^(p + k6), checked on the
-  // host: gc_channel_is_derived).  Three more ramps per sample instead of a 49 104- or 122 760-entry table.
+  // host: gc_channel_is_derived).  Its sign comes out of the base ramp's fraction (lean_sample): no 49 104- or 122 760-entry table,
+  // no ramp of its own.
   constexpr int LA = DER ? ARMS - 1 : ARMS;  // arms with a table in LDS
-  constexpr int AP = ArmPitch<LA>::v;        // values per staged entry
   constexpr bool kF16 = (TAB == 2);
+  // PN: the derived arm's f32 image carries a third column, arm LA - 1 times (-1)^entry (gc_sync_channels): the sign of the
+  // derived entry is then the sign of that column times one bit of the base ramp's fraction (below)
+  constexpr bool PN = DER && !kF16;
+  constexpr int AP = PN ? 4 : ArmPitch<LA>::v;  // values per staged entry
   // HALF: with earlyLateSpc*R*M == 1/2 (the reference's default 0.5-chip spacing on a 1x table: GPS L5, BDS B2a / B3I, Galileo
   // E5a / E5b, GPS L2C in doubled-code units) the late ramp is the early ramp + 1 exactly, and the prompt ramp t = u_E + 1/2 has
   // ceil(t) = ceil(u_E) + (frac(u_E) > 1/2): ONE ramp Q_E serves all three taps - table entries k_E and k_E + 1 come back from
@@ -66,7 +70,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
 #ifdef GC_LANE_GRP_DER
   constexpr int GRP = DER ? GC_LANE_GRP_DER : kGRP;
 #else
-  constexpr int GRP = DER ? 2 : kGRP;  // samples per lane and group (the derived arm's three extra ramps: 128 VGPRs hold two steps' indices, not four)
+  // samples per lane and group (the derived arm's three extra ramps: 128 VGPRs hold two steps' indices, not four; the persistent
+  // instantiations carry the closer's loop state in registers next to all this and are latency-, not throughput-bound: two as well)
+  constexpr int GRP = (DER || DEVLOOP) ? 2 : kGRP;
 #endif
   constexpr int bps = Fmt<MODE>::bps;
   typedef typename std::conditional<kF16, _Float16, float>::type tab_t;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     const int arms0 = chn0->arms;
     int nent[LA];
     const void* pre = kF16 ? (const void*)chn0->tabh : (const void*)chn0->tabf;
-    bool plain = pre != nullptr && chn0->tabh_ap == AP;  // pre-interleaved copy usable as is
+    bool plain = pre != nullptr && (kF16 ? chn0->tabh_ap : chn0->tabf_ap) == AP;  // pre-interleaved copy usable as is
 #pragma unroll
     for (int a = 0; a < LA; ++a) {
       nent[a] = 0;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     if (plain) {
       const uint4* __restrict__ src = reinterpret_cast<const uint4*>(pre);
       uint4* dst = reinterpret_cast<uint4*>(smem);
-      const int n16 = (kF16 ? chn0->tabh_bytes : 2 * chn0->tabh_bytes) >> 4;
+      const int n16 = (kF16 ? chn0->tabh_bytes : chn0->tabf_bytes) >> 4;
 #pragma unroll 4
       for (int i = threadIdx.x; i < n16; i += (int)blockDim.x) dst[i] = src[i];
     } else {
@@ -140,6 +146,8 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
           if (a < LA) {
             const int aa = a < LA ? a : 0;
             if (a < arms0 && e >= 0 && e < nent[aa]) v = (float)chn0->tab[aa][blk0.table_offset[aa] + e];
+          } else if (PN && a == LA) {  // arm LA - 1 times (-1)^entry
+            if (e >= 0 && e < nent[LA - 1]) v = (float)chn0->tab[LA - 1][blk0.table_offset[LA - 1] + e] * ((e & 1) ? -1.0f : 1.0f);
           }
           wtab[i * AP + a] = (tab_t)v;
         }
@@ -246,6 +254,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
 #else
   const unsigned int tie_e = gc_tie_window_units((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fmax(fabs(M), fabs(M6)), (per >> 6) + 1);
 #endif
+  // the derived arm reads its position out of the base ramp's fraction times six: so its window is that ramp's, times six
+  const unsigned int tie_e6 = DER ? gc_tie_window_units6((fabs(aE) + fabs(aL) + (double)N * fabs(sp) + 1.0) * fmax(fabs(M), fabs(M6)), (per >> 6) + 1, M6) : 0u;
+  (void)tie_e6;
 
   // Per-sample ramp step sp*M as a 64.64 fixed-point number (exact: a double has at most 64 fractional bits
   // here); one step of a lane = 64 samples = that number << 6, rounded to 32 fractional bits for Q.
@@ -259,8 +270,30 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   };
   unsigned long long Sf, dQ;
   int Si;
-  float rotC, rotS;
   int el_off = 0;
+  // Carrier.  exp(-i*theta) of sample ibeg + lane + 64*s factors into the lane's phasor at its first sample, the BLOCK-UNIFORM
+  // rho_j = exp(-i*2*pi*64*j*tau) of step j inside a run of kLaneReseedSteps steps, and P^g (P = rho of a whole run) for run g.
+  // rho_j lives in a table of this wave in LDS (filled here, read as a broadcast: no VALU work per sample beyond the product
+  // x * rho_j itself); the sums run Horner-style - when run g >= 1 starts the accumulators turn by conj(P) - and are turned
+  // once, at the end of the block, by the lane's exact float64-reduced phasor.  (Until round 3 every lane carried its own
+  // phasor and rotated it by one step per sample: four more VALU instructions per sample and a recurrence to re-seed.)
+  float2* const rho = reinterpret_cast<float2*>(smem + p.rho_off) + wave * kLaneReseedSteps;
+  float turnC, turnS;  // conj(P) = turnC + i*turnS
+  {
+    const int nst = min((iend - ibeg + 63) >> 6, kLaneReseedSteps);  // steps this wave walks (uniform), at most one run's worth
+    for (int j = lane; j < nst; j += 64) {
+      const double x = (double)(64 * j) * tau;
+      float s_, c_;
+      sincospif(2.0f * (float)(x - floor(x)), &s_, &c_);  // range reduction in double, sincos in float
+      rho[j] = make_float2(c_, s_);
+    }
+    const double xr = (double)(64 * kLaneReseedSteps) * tau;
+    float s_, c_;
+    sincospif(2.0f * (float)(xr - floor(xr)), &s_, &c_);
+    turnC = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c_)));
+    turnS = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_)));
+    __builtin_amdgcn_wave_barrier();  // the table is this wave's own: its LDS operations execute in order, the compiler must not move the reads up
+  }
   {
     const double y = sp * M;
     const double yi = floor(y);
@@ -271,34 +304,13 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     const unsigned long long df = Sf << 6;  // fraction of the 64-sample step, 64 fractional bits
     const long long di = (long long)Si * 64 + (long long)(Sf >> 58);
     dQ = ((unsigned long long)di << 32) + (df >> 32) + ((df >> 31) & 1ull);
-    const double x = 64.0 * tau;
-    float s_, c_;
-    sincospif(2.0f * (float)(x - floor(x)), &s_, &c_);  // range reduction in double, sincos in float
-    rotC = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c_)));
-    rotS = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_)));
     (void)el_off;  // HALF: host-checked 2*d*R*M == 1 exactly (gc_block_shares_el_lane)
-  }
-  // the same for the derived arm's ramp (multiplier M6)
-  unsigned long long Sf6 = 0, dQ6 = 0;
-  int Si6 = 0;
-  if constexpr (DER) {
-    const double y = sp * M6;
-    const double yi = floor(y);
-    Sf6 = frac_to_u64(y - yi);
-    Sf6 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(Sf6 >> 32)) << 32) |
-          (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)Sf6);
-    Si6 = __builtin_amdgcn_readfirstlane((int)yi);
-    const unsigned long long df = Sf6 << 6;
-    const long long di = (long long)Si6 * 64 + (long long)(Sf6 >> 58);
-    dQ6 = ((unsigned long long)di << 32) + (df >> 32) + ((df >> 31) & 1ull);
   }
   auto uni_u64 = [](unsigned long long u) __attribute__((always_inline)) -> unsigned long long {
     return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
            (unsigned int)__builtin_amdgcn_readfirstlane((int)u);
   };
   const unsigned long long corrQ = uni_u64(drift_correction(Sf, Si, dQ));
-  const unsigned long long corrQ6 = DER ? uni_u64(drift_correction(Sf6, Si6, dQ6)) : 0ull;
-  (void)corrQ6;
 
   float accr[ARMS][3], acci[ARMS][3];
 #pragma unroll
@@ -329,73 +341,59 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         Q[x] = q;
       }
     }
-    unsigned long long Q6[DER ? 3 : 1];
-    if constexpr (DER) {
-      const double isp = __dmul_rn((double)ibeg, sp);
-      const double base3[3] = {__dmul_rn(__dadd_rn(aE, isp), M6), __dmul_rn(__dadd_rn(aP, isp), M6),
-                               __dmul_rn(__dadd_rn(aL, isp), M6)};
-      const unsigned __int128 prod = (unsigned __int128)Sf6 * (unsigned int)lane;
-      const unsigned long long F = (unsigned long long)prod;
-      const int I = lane * Si6 + (int)(unsigned long long)(prod >> 64);
-#pragma unroll
-      for (int x = 0; x < 3; ++x) {
-        const Fx f0 = to_fx(base3[x]);
-        const unsigned long long g = f0.G - F;
-        const int k = f0.k0 + I + (f0.G < F ? 1 : 0);
-        const unsigned long long gc = (g >> 32) + (((unsigned int)g != 0u) ? 1ull : 0ull);
-        Q6[x] = ((unsigned long long)(unsigned int)k << 32) + 0xffffffffull - gc;
-      }
-    }
-    (void)Q6;
     // The three taps' ramps differ by block-uniform amounts (the same lane offset was subtracted from each): ONE ramp per
     // set stays in vector registers, the prompt and late values are that plus a scalar pair
     auto uni64 = [](unsigned long long u) __attribute__((always_inline)) -> unsigned long long {
       return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
              (unsigned int)__builtin_amdgcn_readfirstlane((int)u);
     };
-    unsigned long long Q0 = Q[0], Q60 = Q6[0];
+    unsigned long long Q0 = Q[0];
     const unsigned long long dTap[3] = {0ull, uni64(Q[NT > 1 ? 1 : 0] - Q[0]), uni64(Q[NT - 1] - Q[0])};
-    const unsigned long long dTap6[3] = {0ull, uni64(Q6[DER ? 1 : 0] - Q6[0]), uni64(Q6[DER ? 2 : 0] - Q6[0])};
-    (void)dTap6;
-    (void)Q60;
-    float wc, ws;  // exp(-i*theta_i) = wc - i*ws
-    {
-      const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
-      sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
-    }
+    const int i_first = i;
+    int nturn = 0;  // runs completed so far (uniform): the accumulators have been turned by conj(P) that often
     const uint8_t* ptr = p.if_base + (long long)bps * (s0 + i);
-    auto load_sample = [](const uint8_t* q) __attribute__((always_inline)) -> unsigned int {
-      if constexpr (bps == 2) return *reinterpret_cast<const unsigned short*>(q);
-      else if constexpr (bps == 4) return *reinterpret_cast<const unsigned int*>(q);
-      else return *q;
-    };
-    auto sample_of = [](unsigned int word, float& a, float& b) __attribute__((always_inline)) {
+    // one sample as it lies in the record; 16-bit samples stay 16-bit values all the way into the SDWA converts (which select
+    // bytes 0 and 1 themselves): as 32-bit (or 16-bit integer) values the compiler zero-extended those that cross the loop's back edge, a v_and per sample
+    typedef typename std::conditional<bps == 2, _Float16, typename std::conditional<bps == 4, unsigned int, unsigned char>::type>::type word_t;  // _Float16: 16 bits without an integer's extension rules
+    auto load_sample = [](const uint8_t* q) __attribute__((always_inline)) -> word_t { return *reinterpret_cast<const word_t*>(q); };
+    auto sample_of = [](word_t word, float& a, float& b) __attribute__((always_inline)) {
       float x0, x1 = 0.0f;
       if constexpr (MODE == I8_IQ || MODE == I8_QI) {
-        x0 = cvt_byte<0>(word);
-        x1 = cvt_byte<1>(word);
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(x0) : "v"(word));
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(x1) : "v"(word));
       } else if constexpr (MODE == I16_IQ || MODE == I16_QI) {
         x0 = cvt_half<0>(word);
         x1 = cvt_half<1>(word);
       } else if constexpr (MODE == I8_REAL) {
-        x0 = cvt_byte<0>(word);
+        x0 = cvt_byte<0>((unsigned int)word);
       } else {
-        x0 = cvt_half<0>(word);
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(x0) : "v"(word));
       }
       a = Fmt<MODE>::swap ? x1 : x0;
       b = Fmt<MODE>::swap ? x0 : x1;
     };
-    auto rotate_w = [&]() __attribute__((always_inline)) {
-      const float nwc = fmaf(wc, rotC, -(ws * rotS));
-      const float nws = fmaf(wc, rotS, ws * rotC);
-      wc = nwc;
-      ws = nws;
-    };
-    auto mix = [&](unsigned int word, float& yr, float& yi) __attribute__((always_inline)) {
+    // y = x * rho_j, rho_j = wc - i*ws
+    auto mix = [&](word_t word, float2 r, float& yr, float& yi) __attribute__((always_inline)) {
       float a, b;
       sample_of(word, a, b);
+      const float wc = r.x, ws = r.y;
       yr = kReal ? a * wc : fmaf(a, wc, b * ws);
       yi = kReal ? -a * ws : fmaf(b, wc, -a * ws);
+    };
+    // a run of kLaneReseedSteps steps is complete: the accumulators turn by conj(P), the ramps' rounding drift goes out
+    // (corr_common.h: it keeps the near-tie window, and with it the share of blocks that need the test at all, independent of
+    // the block length)
+    auto turn = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < ARMS; ++a)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const float nr = fmaf(accr[a][x], turnC, -(acci[a][x] * turnS));
+          const float ni = fmaf(accr[a][x], turnS, acci[a][x] * turnC);
+          accr[a][x] = nr;
+          acci[a][x] = ni;
+        }
+      ++nturn;
     };
     // returns the entry of the last LDS arm (the one a derived arm is built from)
     auto accumulate = [&](int x, int k, float yr, float yi) __attribute__((always_inline)) -> float {
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
           accr[ar][x] = fmaf(cf, yr, accr[ar][x]);
           acci[ar][x] = fmaf(cf, yi, acci[ar][x]);
         }
-        return (float)e[LA - 1];
+        return (float)e[PN ? LA : LA - 1];  // what a derived arm is built from: the last table arm, PN: times (-1)^entry
       }
     };
     // derived arm: padded-table entry k6 of the six-times-faster replica = entry p = (k6 + 5) / 6 of arm LA - 1 with the sign
@@ -427,14 +425,14 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     };
     // lean accumulate of one sample: y = x*exp(-i theta), one LDS read per tap serves every arm.  `lo` (HALF only): low word of
     // the early ramp's Q, whose sign bit says whether the prompt tap sits on the early (0) or the late (1) entry
-    auto lean_sample = [&](unsigned int word, const int (&k)[NT], const int (&k6)[3], unsigned int lo) {
+    auto lean_sample = [&](word_t word, float2 r, const int (&k)[NT], const unsigned int (&lo)[NT]) {
       float yr, yi;
-      mix(word, yr, yi);
+      mix(word, r, yr, yi);
       if constexpr (kHalf) {
         typedef tab_t vec_t __attribute__((ext_vector_type(AP)));
         const vec_t* tv = reinterpret_cast<const vec_t*>(tab) + (kGuard + k[0]);
         const vec_t e0 = tv[0], e1 = tv[1];        // early and late entries of every arm: one ds_read2
-        const bool on_late = (int)lo < 0;
+        const bool on_late = (int)lo[0] < 0;
 #pragma unroll
         for (int ar = 0; ar < LA; ++ar) {
           float cE, cL;
@@ -460,9 +458,16 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       for (int x = 0; x < 3; ++x) {
         const float base = accumulate(x, kk[x], yr, yi);
         if constexpr (DER) {
-          // away from ties (the caller redoes those exactly) ceil(ceil(6t) / 6) == ceil(t): the entry the derived arm needs
-          // is the one this tap just read, and only the sign (-1)^(p + k6) is left to apply
-          const float cf = __uint_as_float(__float_as_uint(base) ^ ((unsigned int)(kk[x] + k6[x]) << 31));
+          // Away from ties (the caller redoes those exactly) ceil(ceil(6t) / 6) == ceil(t): the entry p the derived arm needs is
+          // the one this tap just read, and only the sign (-1)^(p + k6) is left.  With t = n + f (0 < f < 1): p = n + 1,
+          // k6 = 6n + floor(6f) + 1, so the sign is (-1)^(p + 1 + floor(6f)), and floor(6f) is odd exactly where frac(3f) >= 1/2 -
+          // bit 31 of three times the ramp's low word (which holds f * 2^32 - 1).  No ramp at six times the rate, no second index:
+          // one multiply-by-three, (PN: the table's third column carries (-1)^p already; else one add puts p's parity on that
+          // bit) and one three-input bit operation per tap.
+          const unsigned int lx = lo[NT == 3 ? x : 0];
+          unsigned int t3 = lx + (lx << 1);
+          if constexpr (!PN) t3 += (unsigned int)kk[x] << 31;
+          const float cf = __uint_as_float(__float_as_uint(base) ^ (~t3 & 0x80000000u));
           accr[ARMS - 1][x] = fmaf(cf, yr, accr[ARMS - 1][x]);
           acci[ARMS - 1][x] = fmaf(cf, yi, acci[ARMS - 1][x]);
         }
@@ -471,9 +476,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     };
     // exact accumulate of one sample: MATLAB colon element i (tracking.m:252-270) in float64 — forwards from
     // a for the first half, backwards from the end point b for the second, mean of both in the exact middle
-    auto exact_sample = [&](unsigned int word, int is) __attribute__((always_inline)) {
+    auto exact_sample = [&](word_t word, float2 r, int is) __attribute__((always_inline)) {
       float yr, yi;
-      mix(word, yr, yi);
+      mix(word, r, yr, yi);
       // colon() end points b = ((N-1)*step + rem -/+ d) * R, evaluated in the reference's order
       const double nm1s = __dmul_rn((double)(N - 1), step);
       const double bP = __dmul_rn(__dadd_rn(nm1s, rem), R);
@@ -502,13 +507,14 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     // min / max of the near-tie test, then Q += dQ
     // ramp step of all taps: table index of the CURRENT sample (high word), the low word into the running min / max of the
     // near-tie test, then Q0 += dQ
-    auto ramp_step = [&](int (&k)[NT], bool test, unsigned int& dmin, unsigned int& dmax, unsigned int& lo) __attribute__((always_inline)) {
+    auto ramp_step = [&](int (&k)[NT], bool test, unsigned int& dmin, unsigned int& dmax, unsigned int (&lo)[NT], unsigned int& dmin6,
+                         unsigned int& dmax6) __attribute__((always_inline)) {
 #pragma unroll
       for (int x = 0; x < NT; ++x) {
         const unsigned long long q = x == 0 ? Q0 : Q0 + dTap[NT == 3 ? x : 0];
         k[x] = (int)(unsigned int)(q >> 32);
         const unsigned int l = (unsigned int)q;
-        if (x == 0) lo = l;
+        lo[x] = l;
         if (test) {
           dmin = min(dmin, l);
           dmax = max(dmax, l);
@@ -516,24 +522,15 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
             dmin = min(dmin, l ^ 0x80000000u);
             dmax = max(dmax, l ^ 0x80000000u);
           }
+          if constexpr (DER) {    // the derived arm crosses a sub-entry where six times the fraction passes an integer
+            const unsigned int l6 = (l + (l << 1)) << 1;
+            dmin6 = min(dmin6, l6);
+            dmax6 = max(dmax6, l6);
+          }
         }
       }
       Q0 += dQ;
       asm volatile("" : "+v"(Q0));  // keep the ramp a chain of adds: Q + j*dQ from precomputed multiples costs a register pair per j
-    };
-
-    auto ramp_step6 = [&](int (&k)[3], bool test, unsigned int& dmin, unsigned int& dmax) __attribute__((always_inline)) {
-#pragma unroll
-      for (int x = 0; x < 3; ++x) {
-        const unsigned long long q = x == 0 ? Q60 : Q60 + dTap6[x];
-        k[x] = (int)(unsigned int)(q >> 32);
-        if (test) {
-          dmin = min(dmin, (unsigned int)q);
-          dmax = max(dmax, (unsigned int)q);
-        }
-      }
-      Q60 += dQ6;
-      asm volatile("" : "+v"(Q60));
     };
 
     // One group of GRP steps per lane.  TF (the block is tie-free, host-proved by gc_mark_tie_free's exact search): no
@@ -542,37 +539,53 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     // e*2^32 of 0 (mod 2^32).  Not measure-zero: with remCodePhase = 0 and the nominal code rate (every channel's first
     // block, tracking.m:163-165) 1.023e6/18e6 is rational and samples 3000k land exactly on edges.  Any suspect lane
     // sends the wave's group through the exact path.
-    auto group = [&](const unsigned int (&cur)[GRP], auto tf) {
+    auto group = [&](const word_t (&cur)[GRP], const float2 (&r)[GRP], auto tf) {
       constexpr bool TF = decltype(tf)::value;
       int kg[GRP][NT];
-      int kg6[GRP][3];
-      unsigned int lo[GRP];
-      unsigned int dmin = 0xffffffffu, dmax = 0u;
-      if constexpr (DER) {
+      unsigned int lo[GRP][NT];
+      unsigned int dmin = 0xffffffffu, dmax = 0u, dmin6 = 0xffffffffu, dmax6 = 0u;
 #pragma unroll
-        for (int j = 0; j < GRP; ++j) ramp_step6(kg6[j], !TF, dmin, dmax);
-      }
-#pragma unroll
-      for (int j = 0; j < GRP; ++j) ramp_step(kg[j], !TF, dmin, dmax, lo[j]);
+      for (int j = 0; j < GRP; ++j) ramp_step(kg[j], !TF, dmin, dmax, lo[j], dmin6, dmax6);
       bool exact = false;
-      if constexpr (!TF) exact = __any((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)) != 0;
+      if constexpr (!TF) {
+        bool near = (dmin <= tie_e) | (dmax >= 0u - tie_e - 1u);
+        if constexpr (DER) near |= (dmin6 <= tie_e6) | (dmax6 >= 0u - tie_e6 - 1u);
+        exact = __any(near) != 0;
+      }
       if (__builtin_expect(exact, 0)) {
+        // one copy of the exact path, walked GRP times; the step's sample and rho are picked by compare-and-select (an array
+        // indexed by the loop counter would live in scratch memory - and be stored there by every group of every block)
 #pragma unroll 1
         for (int j = 0; j < GRP; ++j) {
-          exact_sample(cur[j], i + j * 64);
-          rotate_w();
+          word_t w = cur[0];
+          float2 rr = r[0];
+#pragma unroll
+          for (int q = 1; q < GRP; ++q) {
+            w = (j == q) ? cur[q] : w;
+            rr.x = (j == q) ? r[q].x : rr.x;
+            rr.y = (j == q) ? r[q].y : rr.y;
+          }
+          exact_sample(w, rr, i + j * 64);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-          lean_sample(cur[j], kg[j], kg6[j], lo[j]);
-          rotate_w();
-        }
+        for (int j = 0; j < GRP; ++j) lean_sample(cur[j], r[j], kg[j], lo[j]);
       }
       i += GRP * 64;
       ptr += (long long)GRP * bps * 64;
     };
-    auto load_group = [&](unsigned int (&dst)[GRP], int ahead) {
+    // rho of GRP consecutive steps from step j0 (a multiple of GRP) of the current run: 16-byte broadcast reads
+    auto load_rho = [&](float2 (&r)[GRP], int j0) __attribute__((always_inline)) {
+      static_assert(GRP % 2 == 0, "two table entries per read");
+      const float4* r4 = reinterpret_cast<const float4*>(rho + j0);
+#pragma unroll
+      for (int j = 0; j < GRP / 2; ++j) {
+        const float4 v = r4[j];
+        r[2 * j] = make_float2(v.x, v.y);
+        r[2 * j + 1] = make_float2(v.z, v.w);
+      }
+    };
+    auto load_group = [&](word_t (&dst)[GRP], int ahead) {
 #pragma unroll
       for (int j = 0; j < GRP; ++j) dst[j] = load_sample(ptr + (long long)(ahead * GRP + j) * bps * 64);
     };
@@ -582,48 +595,84 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     const int groups = __builtin_amdgcn_readfirstlane(((iend - ibeg) >> 6) / GRP);
     // two sample buffers, one loop exit (exits from the middle of the pair made the compiler copy all accumulators into
     // the registers the other exit expected, every group)
+    static_assert(kLaneReseedSteps % (2 * GRP) == 0, "a run is a whole number of group pairs");
+    constexpr int kPairs = kLaneReseedSteps / (2 * GRP);
+    static_assert((kPairs & (kPairs - 1)) == 0, "pairs per run: a power of two");
+    // the ramps' rounding drift goes out where a run ends; the accumulators turn there
+    auto end_of_run = [&]() __attribute__((always_inline)) {
+      turn();
+      Q0 += corrQ;
+    };
+    // Two sample buffers; the loads of a group fly while the group before it is processed.  The prefetch inside the loop is
+    // unconditional and the last pair runs behind the loop without one: a prefetch under a condition made the two paths meet
+    // with different numbers of loads in flight, the compiler then waited for ALL of them (s_waitcnt vmcnt(0)) before the
+    // first use - the prefetch had never been ahead of anything.
     auto main_loop = [&](auto tf) __attribute__((always_inline)) {
-      unsigned int xa[GRP], xb[GRP];
+      word_t xa[GRP], xb[GRP];
+      float2 ra[GRP], rb[GRP];
       load_group(xa, 0);
       const int pairs = groups >> 1;
-      for (int pp = 0; pp < pairs; ++pp) {
+      auto pair_body = [&](int pp, auto more) __attribute__((always_inline)) {
+        const int j0 = (pp & (kPairs - 1)) * 2 * GRP;
+        if (pp > 0 && j0 == 0) end_of_run();
         load_group(xb, 1);
-        group(xa, tf);
-        if (2 * pp + 2 < groups) load_group(xa, 1);
-        group(xb, tf);
-        // the phasor recurrence drifts by ~1 ulp per step: re-seed it from the exact float64 phase every kLaneReseedSteps
-        // steps (matters for the 10-20 ms blocks of B1C / L2C, thousands of steps per lane); the ramps' rounding drift goes
-        // out at the same place (corr_common.h: it keeps the near-tie window, and with it the share of blocks that need the
-        // test at all, independent of the block length)
-        static_assert(kLaneReseedSteps % (2 * GRP) == 0, "re-seed interval: a whole number of group pairs");
-        constexpr int kPairs = kLaneReseedSteps / (2 * GRP);
-        static_assert((kPairs & (kPairs - 1)) == 0, "re-seed interval in pairs: a power of two");
-        if ((pp & (kPairs - 1)) == kPairs - 1) {
-          const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)i * tau;
-          sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
-          Q0 += corrQ;
-          if constexpr (DER) Q60 += corrQ6;
-        }
+        load_rho(ra, j0);
+        load_rho(rb, j0 + GRP);
+        group(xa, ra, tf);
+        if constexpr (decltype(more)::value) load_group(xa, 1);
+        group(xb, rb, tf);
+      };
+      const bool odd = (groups & 1) != 0;
+      for (int pp = 0; pp < pairs - 1; ++pp) pair_body(pp, std::true_type{});
+      if (pairs > 0) {
+        if (odd) pair_body(pairs - 1, std::true_type{});
+        else pair_body(pairs - 1, std::false_type{});
       }
-      if (groups & 1) group(xa, tf);
+      if (odd) {
+        const int st = (groups - 1) * GRP;
+        if (st > 0 && (st & (kLaneReseedSteps - 1)) == 0) end_of_run();
+        load_rho(ra, st & (kLaneReseedSteps - 1));
+        group(xa, ra, tf);
+      }
     };
     if (groups > 0) {
       if (tie_free) main_loop(std::true_type{});
       else main_loop(std::false_type{});
     }
-    // tail: fewer than GRP samples left for this lane
-    for (; i < iend; i += 64, ptr += (long long)bps * 64) {
-      const unsigned int word = load_sample(ptr);
-      int k1[NT];
-      int k16[3] = {0, 0, 0};
-      unsigned int dmin = 0xffffffffu, dmax = 0u, lo1 = 0u;
-      ramp_step(k1, true, dmin, dmax, lo1);
-      if constexpr (DER) ramp_step6(k16, true, dmin, dmax);
-      if (!tie_free && ((dmin <= tie_e) | (dmax >= 0u - tie_e - 1u)))
-        exact_sample(word, i);
-      else
-        lean_sample(word, k1, k16, lo1);
-      rotate_w();
+    // tail: fewer than GRP steps left for this wave (the step counter is uniform: a lane past its last sample adds nothing)
+    for (int st = groups * GRP; ibeg + 64 * st < iend; ++st) {
+      if (st > 0 && (st & (kLaneReseedSteps - 1)) == 0) end_of_run();
+      const float2 r1 = rho[st & (kLaneReseedSteps - 1)];
+      if (i < iend) {
+        const word_t word = load_sample(ptr);
+        int k1[NT];
+        unsigned int lo1[NT];
+        unsigned int dmin = 0xffffffffu, dmax = 0u, dmin6 = 0xffffffffu, dmax6 = 0u;
+        ramp_step(k1, true, dmin, dmax, lo1, dmin6, dmax6);
+        bool near = (dmin <= tie_e) | (dmax >= 0u - tie_e - 1u);
+        if constexpr (DER) near |= (dmin6 <= tie_e6) | (dmax6 >= 0u - tie_e6 - 1u);
+        if (!tie_free && near)
+          exact_sample(word, r1, i);
+        else
+          lean_sample(word, r1, k1, lo1);
+      }
+      i += 64;
+      ptr += (long long)bps * 64;
+    }
+    // the lane's own phasor: exp(-i*theta) at its first sample of the last run, from the exact float64 phase
+    {
+      const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)(i_first + 64 * kLaneReseedSteps * nturn) * tau;
+      float wc, ws;
+      sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+#pragma unroll
+      for (int a = 0; a < ARMS; ++a)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const float nr = fmaf(accr[a][x], wc, acci[a][x] * ws);
+          const float ni = fmaf(acci[a][x], wc, -(accr[a][x] * ws));
+          accr[a][x] = nr;
+          acci[a][x] = ni;
+        }
     }
   }
 
@@ -788,6 +837,8 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
 // ISA probe (scripts/lane_probe.sh): only the instantiations whose inner loops are being looked at
 template __global__ void corr_epl_lane_kernel<2, I8_IQ, false, 1>(const KArgs, const InlineBlocks);
 template __global__ void corr_epl_lane_kernel<3, I8_IQ, false, 0, false, true>(const KArgs, const InlineBlocks);
+template __global__ void corr_epl_lane_kernel<2, I8_IQ, false, 1, true>(const KArgs, const InlineBlocks);
+template __global__ void corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>(const KArgs, const InlineBlocks);
 }  // namespace
 #else
 template <typename K>
@@ -849,18 +900,21 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   std::memset(&ib, 0, sizeof ib);
   const bool der = a.derived != 0 && max_arms == 3;  // third arm derived from the second: two tables in LDS (host-fed runs only)
   const int ap = gc_arm_pitch(der ? 2 : max_arms);
-  const size_t f32_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 4 + 15) / 16 * 16;
+  // a derived arm's f32 image has four values per entry (the third: arm 1 times (-1)^entry, DevChannel::tabf_ap) and may take
+  // most of the LDS - a persistent member is alone on its CU anyway; every other f32 table stays below 96 KiB
+  const size_t f32_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * (der ? 4 : ap) * 4 + 15) / 16 * 16;
   const size_t f16_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 2 + 15) / 16 * 16;
-  const bool half_tables = f32_bytes > 96 * 1024;  // BDS B1C: two 20 462-entry arms = 164 KB as f32, 82 KB as f16
+  const bool half_tables = f32_bytes > (der ? 136u : 96u) * 1024;  // BDS B1C: two 20 462-entry arms = 164 KB as f32, 82 KB as f16
   const size_t tab_bytes = half_tables ? f16_bytes : f32_bytes;
   const bool i8c = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I
-  if ((half_tables && (f16_bytes + 4096 > 160 * 1024 || !i8c)) || (max_arms > 2 && !der) || (der && !i8c)) {
+  if ((half_tables && (f16_bytes + 4096 + kLW * kLaneReseedSteps * sizeof(float2) > 160 * 1024 || !i8c)) || (max_arms > 2 && !der) || (der && !i8c)) {
     gc_set_error("device loop on the lane kernel: tables above 156 KiB as f16, f16 tables or a derived arm on a record other than int8 I/Q, "
                  "or three independent arms are not instantiated");
     return GC_E_UNSUPPORTED;
   }
   a.red_off = (int)tab_bytes;
-  const size_t smem = tab_bytes + kLW * GC_OUT_STRIDE * sizeof(float) + 128 + 64 * sizeof(double);
+  a.rho_off = (int)(tab_bytes + kLW * GC_OUT_STRIDE * sizeof(float) + 128 + 64 * sizeof(double));  // a multiple of 16
+  const size_t smem = (size_t)a.rho_off + (size_t)kLW * kLaneReseedSteps * sizeof(float2);
   const bool qi = ctx->if_layout == GC_QI;
   if (waves < 1 || waves > kLW) return GC_E_INVALID;
   if (der) {
@@ -909,13 +963,14 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
 int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBlocks& ib, unsigned int grid, int max_arms,
                               bool share_el) {
   KArgs a = a_in;
-  const int ap = gc_arm_pitch(a.derived ? 2 : max_arms);  // a derived third arm has no table of its own
+  const int ap = gc_arm_pitch(a.derived ? 2 : max_arms);  // a derived third arm has no table of its own ...
   const size_t entries = (size_t)ctx->max_stage_len + 2 * kGuard;
-  const size_t f32_bytes = (entries * ap * 4 + 15) / 16 * 16;
+  // ... but its f32 image carries a third column, arm 1 times (-1)^entry: four values per entry (DevChannel::tabf_ap), up to 136 KiB
+  const size_t f32_bytes = (entries * (a.derived ? 4 : ap) * 4 + 15) / 16 * 16;
   const size_t f16_bytes = (entries * ap * 2 + 15) / 16 * 16;
   int tabkind;
   size_t smem;
-  if (f32_bytes <= 96 * 1024) {  // f32 tables: one 16-wave workgroup per CU still fits next to a second one up to 80 KiB
+  if (f32_bytes <= (a.derived ? 136u : 96u) * 1024) {  // f32 tables: one 16-wave workgroup per CU still fits next to a second one up to 80 KiB
     tabkind = (share_el && !a.derived) ? 1 : 0;
     smem = f32_bytes;
     a.red_off = (int)f32_bytes;
@@ -928,6 +983,13 @@ int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBl
     return GC_E_UNSUPPORTED;
   }
   smem += kLW * GC_OUT_STRIDE * sizeof(float);  // cross-wave scratch of the one-block-per-workgroup mode
+  smem = (smem + 15) / 16 * 16;
+  a.rho_off = (int)smem;
+  smem += (size_t)kLW * kLaneReseedSteps * sizeof(float2);  // the waves' carrier-step tables (16 KiB)
+  if (smem > 160 * 1024) {
+    gc_set_error("code tables need %zu bytes of LDS with the kernel's scratch (> 160 KiB); set a window with gc_set_code_window", smem);
+    return GC_E_UNSUPPORTED;
+  }
   if (a.derived) {
     if (max_arms != 3 || tabkind == 1 || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL) {
       gc_set_error("internal: derived-arm launch with %d arms / table kind %d", max_arms, tabkind);

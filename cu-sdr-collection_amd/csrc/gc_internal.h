@@ -46,6 +46,10 @@ struct DevChannel {
   // arm 2 is arm 1 with a sign pattern at six times the ramp rate (BOC(6,1) next to BOC(1,1): entry k6 of its padded table
   // equals entry p = (k6 + 5) / 6 of arm 1's times (-1)^(p + k6)): the lane kernel derives it instead of reading a table
   int32_t derived;
+  // derived channels stage their f32 image with four values per entry: {arm 0, arm 1, arm 1 * (-1)^entry, 0} - the third column
+  // is what the derived arm multiplies by the sign of its sixfold sub-entry (corr_lane.hip)
+  int32_t tabf_ap;     // f32 values per entry of tabf
+  int32_t tabf_bytes;  // multiple of 16
   int32_t pad_;
 };
 

@@ -521,24 +521,29 @@ int gc_sync_channels(gc_context* ctx) {
     }
     if (whole && maxn <= 65536) {
       const int ap = gcorr::gc_arm_pitch(larms);
+      const int apf = derived ? 4 : ap;  // derived: {arm 0, arm 1, arm 1 * (-1)^entry, 0}
       const size_t entries = (size_t)maxn + 2 * gcorr::kGuard;
       const size_t bytes = (entries * ap * 2 + 15) / 16 * 16;
+      const size_t fbytes = (entries * apf * 4 + 15) / 16 * 16;
       std::vector<uint16_t> t(bytes / 2, 0);
-      std::vector<float> tf(bytes / 2, 0.0f);
+      std::vector<float> tf(fbytes / 4, 0.0f);
       for (int a = 0; a < larms; ++a)
         for (int e = 0; e < c.nent[a]; ++e) {
           const int8_t v = c.h_tab[a][e];
           t[((size_t)e + gcorr::kGuard) * ap + a] = v > 0 ? 0x3C00 : v < 0 ? 0xBC00 : 0;  // f16 +1 / -1 / 0
-          tf[((size_t)e + gcorr::kGuard) * ap + a] = (float)v;
+          tf[((size_t)e + gcorr::kGuard) * apf + a] = (float)v;
+          if (derived && a == 1) tf[((size_t)e + gcorr::kGuard) * apf + 2] = (e & 1) ? -(float)v : (float)v;
         }
       GC_HIP(hipMalloc((void**)&hc.d_tabh, bytes));
       GC_HIP(hipMemcpy(hc.d_tabh, t.data(), bytes, hipMemcpyHostToDevice));
-      GC_HIP(hipMalloc((void**)&hc.d_tabf, 2 * bytes));
-      GC_HIP(hipMemcpy(hc.d_tabf, tf.data(), 2 * bytes, hipMemcpyHostToDevice));
+      GC_HIP(hipMalloc((void**)&hc.d_tabf, fbytes));
+      GC_HIP(hipMemcpy(hc.d_tabf, tf.data(), fbytes, hipMemcpyHostToDevice));
       d.tabf = hc.d_tabf;
       d.tabh = hc.d_tabh;
       d.tabh_ap = ap;
       d.tabh_bytes = (int32_t)bytes;
+      d.tabf_ap = apf;
+      d.tabf_bytes = (int32_t)fbytes;
     }
   }
   GC_HIP(hipMemcpyAsync(ctx->d_channels, dev.data(), sizeof(DevChannel) * GC_MAX_CHANNELS,
@@ -642,7 +647,9 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
                               (k.rem_code_phase + k.el_spacing) * R};
     bool clean = true;
     for (int t = 0; t < 3 && clean; ++t) clean = gc_first_sample_near_edge(starts[t], sp, k.blksize, eps) < 0;
-    for (int t = 0; t < 3 && clean && m6 != 0.0; ++t) clean = gc_first_sample_near_edge(starts[t] * m6, sp * m6, k.blksize, eps) < 0;
+    // the derived arm's sub-entry comes out of the base ramp's fraction times mult[2]: so does that ramp's rounding (gc_tie_window_units6)
+    const double eps6 = (gcorr::gc_tie_window_units6(maxv, k.blksize / 64 + 2, m6) + 3.0 * m6) / 4294967296.0;
+    for (int t = 0; t < 3 && clean && m6 != 0.0; ++t) clean = gc_first_sample_near_edge(starts[t] * m6, sp * m6, k.blksize, std::max(eps, eps6)) < 0;
     if (clean) k.reserved |= 1;
   }
 }
