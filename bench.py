@@ -400,14 +400,37 @@ def run_acquisition(P, eng, sats, R: Ranks):
     eng.synchronize()
     R.barrier()
     t0 = time.perf_counter()
+    eng.timer_start()
     acq = gpu_acquisition(eng, Sa)
+    ev_ms = eng.timer_stop()      # hipEvents on the engine's stream around the whole call (its kernels + the gaps of its three host steps)
     t_acq = time.perf_counter() - t0
     (t_acq,) = R.reduce([t_acq])
     acq = merge_acq_results(R.gather(acq))
     found = sorted(int(i) + 1 for i in np.nonzero(acq.carrFreq)[0])
     truth = {s.prn: s for s in sats}
     phase_ok = all(abs(((int(acq.codePhase[p - 1]) - 1 - truth[p].code_phase_samples + 9000) % 18000) - 9000) <= 2.0 for p in found if p in truth)
-    return {"seconds": round(t_acq, 4), "prns_searched": len(full), "prns_per_rank": len(Sa.acqSatelliteList), "bins": 29, "non_coh_ms": 20, "fft_size": 36000,
+    # Roofline of the search (acquisition.m:167-200 is the dominant row).  Algorithmic HBM bytes: what the search has
+    # to read and write at all - the (H + 1) code periods of int8 I/Q signal, one sampled code per PRN, the fine stage's 40 code
+    # periods per detection, a few words of result per PRN.  Algorithmic flops: one forward transform per hop, one per code, one
+    # inverse transform + product + |.| + accumulation per (PRN, bin, hop), 5 N log2 N per transform.  Everything between - the
+    # hop spectra, the rows pass's output the columns pass reads back (334 MB per PRN) - is traffic of THIS
+    # implementation, not of the problem: the byte figure shows how far from its input the search is, the flop figure how
+    # far from the vector units (157.3 TFLOP/s f32, MI355X_MICROARCH.md; FFT butterflies do not map to MFMA tiles).
+    import math
+    n_fft, hops, bins, nprn = 36000, 20, 29, len(Sa.acqSatelliteList)
+    spc = n_fft // 2
+    fft_flops = 5.0 * n_fft * math.log2(n_fft)
+    flops = (hops + nprn) * fft_flops + nprn * bins * hops * (fft_flops + 6.0 * n_fft + 4.0 * n_fft)
+    ndet = int(np.count_nonzero(acq.carrFreq))
+    abytes = (hops + 1) * spc * 2.0 + nprn * spc * 1.0 + ndet * 40 * spc * 2.0 + nprn * 32.0
+    roof = {"bound": "hbm", "achieved": round(abytes / (ev_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(abytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "traffic": None, "kernel_ms": round(ev_ms, 4),
+            "algorithmic_bytes": abytes, "kernels": "fft_pass_ct<...> (forward, code, inverse rows / columns + |.| + hop sums), abs_combine_kernel, fine_multi_kernel",
+            "compute": {"bound": "valu f32", "achieved": round(flops / (ev_ms * 1e-3) / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": round(flops / (ev_ms * 1e-3) / 1e12 / 157.3, 4), "algorithmic_flops": flops},
+            "note": "rank 0's share of the PRN list; the search is bound by neither figure yet: its passes bounce the inverse transforms' intermediate through "
+                    "the memory system (DESIGN.md §4.4)"}
+    return {"seconds": round(t_acq, 4), "roofline": roof, "prns_searched": len(full), "prns_per_rank": len(Sa.acqSatelliteList), "bins": 29, "non_coh_ms": 20, "fft_size": 36000,
             "acquired": found, "all_scene_prns_found": sorted(truth) == found, "code_phases_within_two_samples_of_the_scene": bool(phase_ok),
             "sharding": f"PRN list round-robin over {R.world} rank(s)"}
 
