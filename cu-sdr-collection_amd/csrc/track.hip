@@ -488,135 +488,45 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   bool any_range = false, any_diverged = false;
   double t_launch = 0.0, t_wait = 0.0;  // GC_TRACK_TIMING: host time in the launch call / until the records arrived
   const auto t_loop0 = std::chrono::steady_clock::now();
-  for (int e = 0; e < n_epochs; ++e) {
-    if (r && r->pause_at_end) {
-      bool fits = true;
-      for (int c = 0; c < nch && fits; ++c) {
-        const ChanState& s = st[c];
-        if (!s.active) continue;
-        const double step = s.code_freq / p->sampling_freq;
-        if (!(step > 0.0) || !(step < 1e6)) continue;  // handled below (diverged NCO)
-        const int n = (int)std::ceil((p->code_length - s.rem_code) / step);
-        fits = s.pos >= 0 && (uint64_t)(s.pos + n) <= ctx->if_nsamples;
-      }
-      if (!fits) {
-        r->paused = true;
-        break;
-      }
-    }
-    int nb = 0;
-    for (int c = 0; c < nch; ++c) {
-      ChanState& s = st[c];
-      if (!s.active) continue;
-      const double step = s.code_freq / p->sampling_freq;                      // :219
-      if (!(step > 0.0) || !(step < 1e6) || !std::isfinite(s.carr_freq)) {
-        // all-zero sums make atan(0/0) = NaN of the carrier and code NCOs; MATLAB then fails in fread(fid, NaN): stop the channel
-        s.active = false;
-        s.aborted = true;
-        any_diverged = true;
-        if (persist) write_desc(c, e, nullptr, 2ull);
-        continue;
-      }
-      const int n = (int)std::ceil((p->code_length - s.rem_code) / step);     // :222
-      if (s.pos < 0 || (uint64_t)(s.pos + n) > ctx->if_nsamples) {            // :241-245
-        s.active = false;
-        s.aborted = true;
-        any_range = true;
-        if (persist) write_desc(c, e, nullptr, 2ull);  // this channel's team stops
-        continue;
-      }
-      gc_block& b = blocks[nb];
-      std::memset(&b, 0, sizeof b);
-      b.channel = init[c].channel;
-      b.blksize = n;
-      b.first_sample = s.pos;
-      b.rem_code_phase = s.rem_code;
-      if (p->table_phase_count > 0 && s.table_phase > 0)  // GPS_L2C tracking.m:261: index + codeLength*(CLCodePhase-1)
-        b.table_offset[1] = (int32_t)p->code_length * (s.table_phase - 1);
-      b.code_phase_step = step;
-      b.el_spacing = p->el_spacing;
-      b.carr_freq = s.carr_freq;
-      b.rem_carr_phase = s.rem_carr;
-      slot[nb] = c;
-      ++nb;
-    }
-    if (nb == 0) break;
-    const bool derived = any_mixed && all_mixed_derived && !any_three_plain && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
-    ctx->launch_derived = derived;
-    int fast = derived ? 0 : any_mixed ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
-    for (int k = 0; k < nb && fast > 0; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
-    bool share = true;
-    for (int k = 0; k < nb && share; ++k) share = gc_block_shares_el(ctx, blocks[k]);
-    ctx->scope_share_lane = true;
-    for (int k = 0; k < nb && ctx->scope_share_lane; ++k) ctx->scope_share_lane = gc_block_shares_el_lane(ctx, blocks[k]);
-    const unsigned int tag = (unsigned int)(e + 1);
-    const bool polled = poll && fast >= 0;
-    const auto tt0 = std::chrono::steady_clock::now();
-    if (persist) {
-      for (int k = 0; k < nb; ++k) write_desc(slot[k], e, &blocks[k], 0ull);
-    } else {
-      rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast, 0,
-                                polled ? tag : 0u, share);
-      if (rc) return rc;
-    }
-    const auto tt1 = std::chrono::steady_clock::now();
-    bool signalled = false;
-    if (polled) {
-      // wait until every record of this launch carries the epoch tag (bounded: never hang here).  A busy device (other
-      // contexts' kernels in front of ours) can delay a launch by much more than its own few microseconds: when the poll
-      // budget runs out, the launch-per-epoch mode falls back to a stream synchronise and looks once more before giving up.
-      const int arms6 = max_arms * 6;
-      const int hs = persist ? 1 : splits;  // record groups per block as the host sees them (the persistent kernel's teams add up on the device)
-      auto wait_tags = [&](std::chrono::milliseconds budget) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < nb * hs; ++k)
-          for (int v = 0; v < arms6; ++v) {
-            // record group of (block, split): blocks are numbered per launch, teams of the persistent kernel per channel
-            const size_t grp = persist ? (size_t)slot[k] : (size_t)k;
-            volatile gcorr::TaggedSlot* s = tagged + grp * GC_OUT_STRIDE + v;
-            unsigned int spins = 0;
-            while (s->tag != tag)
-              if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > budget) return false;
-          }
-        return true;
-      };
-      // first epoch of the persistent kernel: code load + launch of the whole grid
-      signalled = wait_tags(std::chrono::milliseconds((persist && e == 0) ? std::max(5000, poll_timeout_ms) : poll_timeout_ms));
-      if (!signalled && !persist && hipStreamSynchronize(ctx->stream) == hipSuccess) signalled = wait_tags(std::chrono::milliseconds(1));
-      std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    const auto tt2 = std::chrono::steady_clock::now();
-    t_launch += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
-    t_wait += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
-    if (!signalled) {
-      if (persist && std::getenv("GC_TRACK_TIMING")) {
-        const hipError_t q = hipStreamQuery(ctx->stream);
-        std::fprintf(stderr, "gc_track persistent: epoch %d records missing; stream: %s; first tags:", e, hipGetErrorString(q));
-        for (int k = 0; k < std::min(nb, 16); ++k) std::fprintf(stderr, " %u", tagged[(size_t)slot[k] * GC_OUT_STRIDE].tag);
-        std::fprintf(stderr, "\n");
-      }
-      if (persist) persist_stop();
-      GC_HIP(hipStreamSynchronize(ctx->stream));
-      if (polled) {
-        persist_free();
-        gc_set_error("gc_track: result records of epoch %d did not arrive", e);
-        return GC_E_HIP;
-      }
-    }
 
-    for (int k = 0; k < nb; ++k) {
-      const int c = slot[k];
+  // tracking.m:219-245 for channel c at epoch e: block size and position -> descriptor.  false: the channel ends here (its NCO
+  // left the finite numbers, or the record holds no whole block any more); a persistent team is told to stop.
+  auto prepare = [&](int c, int e, gc_block& b) -> bool {
+    ChanState& s = st[c];
+    const double step = s.code_freq / p->sampling_freq;                      // :219
+    if (!(step > 0.0) || !(step < 1e6) || !std::isfinite(s.carr_freq)) {
+      // all-zero sums make atan(0/0) = NaN of the carrier and code NCOs; MATLAB then fails in fread(fid, NaN): stop the channel
+      s.active = false;
+      s.aborted = true;
+      any_diverged = true;
+      if (persist) write_desc(c, e, nullptr, 2ull);
+      return false;
+    }
+    const int n = (int)std::ceil((p->code_length - s.rem_code) / step);     // :222
+    if (s.pos < 0 || (uint64_t)(s.pos + n) > ctx->if_nsamples) {            // :241-245
+      s.active = false;
+      s.aborted = true;
+      any_range = true;
+      if (persist) write_desc(c, e, nullptr, 2ull);  // this channel's team stops
+      return false;
+    }
+    std::memset(&b, 0, sizeof b);
+    b.channel = init[c].channel;
+    b.blksize = n;
+    b.first_sample = s.pos;
+    b.rem_code_phase = s.rem_code;
+    if (p->table_phase_count > 0 && s.table_phase > 0)  // GPS_L2C tracking.m:261: index + codeLength*(CLCodePhase-1)
+      b.table_offset[1] = (int32_t)p->code_length * (s.table_phase - 1);
+    b.code_phase_step = step;
+    b.el_spacing = p->el_spacing;
+    b.carr_freq = s.carr_freq;
+    b.rem_carr_phase = s.rem_carr;
+    return true;
+  };
+  // tracking.m:249-348 for channel c at epoch e: the recorded state, the discriminators and loop filters, the next block's state
+  auto close_epoch = [&](int c, int e, const gc_block& b, const double (&sums)[GC_OUT_STRIDE]) {
       ChanState& s = st[c];
-      const gc_block& b = blocks[k];
       const double R = ctx->ch[b.channel].index_scale;
-      double sums[GC_OUT_STRIDE];
-      for (int v = 0; v < GC_OUT_STRIDE; ++v) {
-        double acc = 0.0;
-        for (int sp = 0; sp < (persist ? 1 : splits); ++sp)
-          acc += polled ? ((v < max_arms * 6) ? tagged[(persist ? (size_t)c : (size_t)k * splits + sp) * GC_OUT_STRIDE + v].value : 0.0)
-                        : partial[((size_t)k * splits + sp) * GC_OUT_STRIDE + v];
-        sums[v] = acc;
-      }
       const double i_e = sums[0], q_e = sums[1], i_p = sums[2], q_p = sums[3], i_l = sums[4], q_l = sums[5];
       double* o = out + (size_t)c * GC_TRK_NFIELDS * n_epochs;
       auto rec = [&](int f, double v) { o[(size_t)f * n_epochs + e] = v; };
@@ -734,6 +644,178 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
         if (s.table_phase >= p->table_phase_count + 1) s.table_phase = 1;
       }
       s.epochs = e + 1;
+  };
+
+  // ---- persistent kernel, every channel at its own pace ---------------------------------------------------------------
+  // The channels share nothing (tracking.m:133): each team of the persistent kernel waits for ITS descriptor and answers with
+  // ITS record group.  So the host does not wait for the slowest channel of an epoch before it closes any: whichever record
+  // group carries its channel's next tag is closed at once and that channel's next descriptor goes out, while the other teams
+  // are still correlating or their records are on the way.  Lock step (the loop below) cost an epoch the sum of the PCIe round
+  // trip, the team's work and the twelve closures; this way the round trip of one channel hides behind the others' work.
+  // (Not under pause_at_end: a window of a streamed record must end all channels at the same epoch.)
+  const bool async = persist && poll && !(r && r->pause_at_end) && std::getenv("GC_TRACK_LOCKSTEP") == nullptr;
+  if (async) {
+    const int arms6 = max_arms * 6;
+    std::vector<gc_block> cur((size_t)nch);
+    std::vector<int> ep((size_t)nch, 0);
+    std::vector<char> waiting((size_t)nch, 0);
+    std::vector<std::chrono::steady_clock::time_point> sent((size_t)nch);
+    int outstanding = 0;
+    const auto now0 = std::chrono::steady_clock::now();
+    for (int c = 0; c < nch; ++c) {
+      if (!st[c].active) continue;
+      if (!prepare(c, 0, cur[c])) continue;
+      write_desc(c, 0, &cur[c], 0ull);
+      waiting[c] = 1;
+      sent[c] = now0;
+      ++outstanding;
+    }
+    bool lost = false;
+    int lost_epoch = 0;
+    unsigned int idle = 0;
+    while (outstanding > 0 && !lost) {
+      bool progress = false;
+      for (int c = 0; c < nch; ++c) {
+        if (!waiting[c]) continue;
+        const unsigned int tag = (unsigned int)ep[c] + 1u;
+        volatile gcorr::TaggedSlot* grp = tagged + (size_t)c * GC_OUT_STRIDE;
+        bool ready = true;
+        for (int v = arms6 - 1; v >= 0 && ready; --v) ready = grp[v].tag == tag;
+        if (!ready) continue;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        double sums[GC_OUT_STRIDE];
+        for (int v = 0; v < GC_OUT_STRIDE; ++v) sums[v] = v < arms6 ? grp[v].value : 0.0;
+        close_epoch(c, ep[c], cur[c], sums);
+        progress = true;
+        ++ep[c];
+        if (ep[c] < n_epochs && prepare(c, ep[c], cur[c])) {
+          write_desc(c, ep[c], &cur[c], 0ull);
+          sent[c] = std::chrono::steady_clock::now();
+        } else {
+          waiting[c] = 0;  // all epochs done (the team leaves by itself) or the channel ended (prepare told its team)
+          --outstanding;
+        }
+      }
+      if (progress) {
+        idle = 0;
+      } else if ((++idle & 1023u) == 0) {
+        // first epoch of the persistent kernel: code load + launch of the whole grid
+        const auto now = std::chrono::steady_clock::now();
+        for (int c = 0; c < nch && !lost; ++c)
+          if (waiting[c] && now - sent[c] > std::chrono::milliseconds(ep[c] == 0 ? std::max(5000, poll_timeout_ms) : poll_timeout_ms)) {
+            lost = true;
+            lost_epoch = ep[c];
+          }
+      }
+    }
+    if (lost) {
+      persist_stop();
+      GC_HIP(hipStreamSynchronize(ctx->stream));
+      persist_free();
+      gc_set_error("gc_track: result records of epoch %d did not arrive", lost_epoch);
+      return GC_E_HIP;
+    }
+    t_wait = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count();
+  }
+
+  for (int e = 0; e < n_epochs && !async; ++e) {
+    if (r && r->pause_at_end) {
+      bool fits = true;
+      for (int c = 0; c < nch && fits; ++c) {
+        const ChanState& s = st[c];
+        if (!s.active) continue;
+        const double step = s.code_freq / p->sampling_freq;
+        if (!(step > 0.0) || !(step < 1e6)) continue;  // handled below (diverged NCO)
+        const int n = (int)std::ceil((p->code_length - s.rem_code) / step);
+        fits = s.pos >= 0 && (uint64_t)(s.pos + n) <= ctx->if_nsamples;
+      }
+      if (!fits) {
+        r->paused = true;
+        break;
+      }
+    }
+    int nb = 0;
+    for (int c = 0; c < nch; ++c) {
+      if (!st[c].active) continue;
+      if (!prepare(c, e, blocks[nb])) continue;
+      slot[nb] = c;
+      ++nb;
+    }
+    if (nb == 0) break;
+    const bool derived = any_mixed && all_mixed_derived && !any_three_plain && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;
+    ctx->launch_derived = derived;
+    int fast = derived ? 0 : any_mixed ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? 2 : 0;
+    for (int k = 0; k < nb && fast > 0; ++k) fast = std::min(fast, gc_block_lowrate_level(ctx, blocks[k]));
+    bool share = true;
+    for (int k = 0; k < nb && share; ++k) share = gc_block_shares_el(ctx, blocks[k]);
+    ctx->scope_share_lane = true;
+    for (int k = 0; k < nb && ctx->scope_share_lane; ++k) ctx->scope_share_lane = gc_block_shares_el_lane(ctx, blocks[k]);
+    const unsigned int tag = (unsigned int)(e + 1);
+    const bool polled = poll && fast >= 0;
+    const auto tt0 = std::chrono::steady_clock::now();
+    if (persist) {
+      for (int k = 0; k < nb; ++k) write_desc(slot[k], e, &blocks[k], 0ull);
+    } else {
+      rc = gc_launch_correlator(ctx, blocks, nb, splits, splits == 1 ? partial : nullptr, partial, max_arms, fast, 0,
+                                polled ? tag : 0u, share);
+      if (rc) return rc;
+    }
+    const auto tt1 = std::chrono::steady_clock::now();
+    bool signalled = false;
+    if (polled) {
+      // wait until every record of this launch carries the epoch tag (bounded: never hang here).  A busy device (other
+      // contexts' kernels in front of ours) can delay a launch by much more than its own few microseconds: when the poll
+      // budget runs out, the launch-per-epoch mode falls back to a stream synchronise and looks once more before giving up.
+      const int arms6 = max_arms * 6;
+      const int hs = persist ? 1 : splits;  // record groups per block as the host sees them (the persistent kernel's teams add up on the device)
+      auto wait_tags = [&](std::chrono::milliseconds budget) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < nb * hs; ++k)
+          for (int v = 0; v < arms6; ++v) {
+            // record group of (block, split): blocks are numbered per launch, teams of the persistent kernel per channel
+            const size_t grp = persist ? (size_t)slot[k] : (size_t)k;
+            volatile gcorr::TaggedSlot* s = tagged + grp * GC_OUT_STRIDE + v;
+            unsigned int spins = 0;
+            while (s->tag != tag)
+              if ((++spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > budget) return false;
+          }
+        return true;
+      };
+      // first epoch of the persistent kernel: code load + launch of the whole grid
+      signalled = wait_tags(std::chrono::milliseconds((persist && e == 0) ? std::max(5000, poll_timeout_ms) : poll_timeout_ms));
+      if (!signalled && !persist && hipStreamSynchronize(ctx->stream) == hipSuccess) signalled = wait_tags(std::chrono::milliseconds(1));
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    const auto tt2 = std::chrono::steady_clock::now();
+    t_launch += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
+    t_wait += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
+    if (!signalled) {
+      if (persist && std::getenv("GC_TRACK_TIMING")) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        std::fprintf(stderr, "gc_track persistent: epoch %d records missing; stream: %s; first tags:", e, hipGetErrorString(q));
+        for (int k = 0; k < std::min(nb, 16); ++k) std::fprintf(stderr, " %u", tagged[(size_t)slot[k] * GC_OUT_STRIDE].tag);
+        std::fprintf(stderr, "\n");
+      }
+      if (persist) persist_stop();
+      GC_HIP(hipStreamSynchronize(ctx->stream));
+      if (polled) {
+        persist_free();
+        gc_set_error("gc_track: result records of epoch %d did not arrive", e);
+        return GC_E_HIP;
+      }
+    }
+
+    for (int k = 0; k < nb; ++k) {
+      const int c = slot[k];
+      double sums[GC_OUT_STRIDE];
+      for (int v = 0; v < GC_OUT_STRIDE; ++v) {
+        double acc = 0.0;
+        for (int sp = 0; sp < (persist ? 1 : splits); ++sp)
+          acc += polled ? ((v < max_arms * 6) ? tagged[(persist ? (size_t)c : (size_t)k * splits + sp) * GC_OUT_STRIDE + v].value : 0.0)
+                        : partial[((size_t)k * splits + sp) * GC_OUT_STRIDE + v];
+        sums[v] = acc;
+      }
+      close_epoch(c, e, blocks[k], sums);
     }
   }
 
