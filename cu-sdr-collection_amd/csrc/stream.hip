@@ -20,6 +20,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cstdint>
+#include <climits>
+
 #include "gc_internal.h"
 
 extern "C" int gc_track_resume(gc_context* ctx, const gc_track_params* p, int nch, const gc_channel_init* init,
@@ -169,14 +172,21 @@ extern "C" int gc_track_file(gc_context* ctx, const char* path, uint64_t skip_by
 
   auto window_len = [&](uint64_t k) { return std::min<uint64_t>(W, total - k * stride); };
   auto is_last = [&](uint64_t k) { return k * stride + W >= total; };
-  if (!ld.load(dbuf[0], 0, window_len(0))) {
+  // The first window is the one the earliest channel starts in (settings.skipNumberOfBytes may put that gigabytes into the
+  // file: reading and uploading every window of the skipped part, each pausing with zero epochs, would be the price of
+  // starting at window 0).  Window origins are multiples of the 256-sample-aligned stride, so block alignment is as before.
+  int64_t first_start = INT64_MAX;
+  for (int c = 0; c < nch; ++c) first_start = std::min<int64_t>(first_start, p->skip_samples + init[c].code_phase - 1);
+  uint64_t k0 = first_start > 0 ? (uint64_t)first_start / stride : 0;
+  while (k0 > 0 && k0 * stride >= total) --k0;  // a start beyond the record: the last window reports the short read
+  if (!ld.load(dbuf[k0 & 1], k0 * stride, window_len(k0))) {
     cleanup();
-    gc_set_error("gc_track_file: %s while reading window 0", ld.error.c_str());
+    gc_set_error("gc_track_file: %s while reading window %llu", ld.error.c_str(), (unsigned long long)k0);
     return GC_E_RANGE;
   }
   int rc = GC_OK, last_rc = GC_OK;
   bool first_call = true, finished = false;
-  for (uint64_t k = 0; !finished; ++k) {
+  for (uint64_t k = k0; !finished; ++k) {
     const bool last = is_last(k);
     std::thread reader;
     std::atomic<bool> reader_ok{true};

@@ -460,7 +460,9 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   for (int c = 0; c < nch; ++c) {
     ChanState& s = st[c];
     s.active = true;
-    s.pos = p->skip_samples + init[c].code_phase - 1;  // tracking.m:150-152
+    // tracking.m:150-152; positions count from the IF buffer's first sample, which is record sample r->origin (gc_track_resume on a
+    // window: a run that starts in a window other than the record's first one must not read from that window's start)
+    s.pos = p->skip_samples + init[c].code_phase - 1 - (r ? r->origin : 0);
     s.table_phase = init[c].table_phase;
     s.code_freq = s.code_freq_basis = init[c].code_freq;  // :163 / GPS_L5C :165
     s.carr_freq = s.carr_basis = init[c].acquired_freq;   // :167-168
@@ -934,7 +936,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   bool share = true;
   for (int c = 0; c < nch; ++c) {
     gcorr::DevLoopChan& s = hc[c];
-    s.pos = p->skip_samples + init[c].code_phase - 1;  // tracking.m:150-152
+    s.pos = p->skip_samples + init[c].code_phase - 1;
     s.code_freq = s.code_freq_basis = init[c].code_freq;
     s.carr_freq = s.carr_basis = init[c].acquired_freq;
     s.table_phase = init[c].table_phase;

@@ -451,6 +451,18 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       mexErrMsgIdAndTxt("gnsscorr:args", "read_if: the record holds %d value(s) per sample", (int)per);
     plhs[0] = mxCreateNumericMatrix(1, n * per, dt == GC_I16 ? mxINT16_CLASS : mxINT8_CLASS, mxREAL);
     if (gc_read_if(handle(prhs[1]), (uint64_t)mxGetScalar(prhs[2]), (uint64_t)n, mxGetData(plhs[0]))) fail("gc_read_if");
+  } else if (!strcmp(cmd, "if_info")) {
+    /* info = gnsscorr_mex('if_info', h): [samples, class (0 int8 / 1 int16), order (0 real / 1 I,Q / 2 Q,I)] of the record the
+       context holds; samples = 0: none (never loaded, or a windowed run detached its last window) */
+    void* ptr = NULL;
+    uint64_t n = 0;
+    int dt = 0, lay = 0;
+    plhs[0] = mxCreateDoubleMatrix(1, 3, mxREAL);
+    if (gc_if_buffer(handle(prhs[1]), &ptr, &n) == GC_OK && ptr != NULL && n > 0 && gc_if_format(handle(prhs[1]), &dt, &lay) == GC_OK) {
+      mxGetDoubles(plhs[0])[0] = (double)n;
+      mxGetDoubles(plhs[0])[1] = (double)dt;
+      mxGetDoubles(plhs[0])[2] = (double)lay;
+    }
   } else if (!strcmp(cmd, "device_info")) {
     char name[128] = "";
     int cus = 0;

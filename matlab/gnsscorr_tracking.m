@@ -65,10 +65,19 @@ fileName = fopen(fid);
 order = 'IQ';
 if pkg.qiOrder, order = 'QI'; end
 windowed = isfield(settings, 'gnsscorrWindowSamples') && settings.gnsscorrWindowSamples > 0;
-h = gnsscorr_context(fileName);
+% One context per RECORD, not per file name: the key carries what decides the bytes in HBM - sample class, file type, sample
+% order and the file's size and date - so a different dataType / fileType or a rewritten file under the same name gets a fresh
+% context instead of a stale record, and the resident record is (re)loaded whenever the context does not hold one (a windowed
+% call leaves none behind: it attaches and detaches its own device windows).
+info = dir(fileName);
+key = sprintf('%s|%s|%d|%s|%d|%.6f', fileName, settings.dataType, settings.fileType, order, info(1).bytes, info(1).datenum);
+h = gnsscorr_context(key);
 if isempty(h)
-    h = gnsscorr_context(fileName, 'new');
-    if ~windowed
+    h = gnsscorr_context(key, 'new');
+end
+if ~windowed
+    loaded = gnsscorr_mex('if_info', h);           % [samples, class (0 int8 / 1 int16), order (0 real / 1 I,Q / 2 Q,I)]
+    if loaded(1) == 0
         gnsscorr_mex('open_if_file', h, fileName, 0, 0, settings.dataType, settings.fileType, settings.samplingFreq, order);
     end
 end

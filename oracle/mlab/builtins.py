@@ -1592,6 +1592,24 @@ def _fopen(I, a, nargout):
     return (-1.0, MStr(f"cannot open {name}")) if nargout > 1 else -1.0
 
 
+@builtin("dir")
+def _dir(I, a, n):
+    """dir(name) for one file: struct with the documented fields name, folder, date, bytes, isdir, datenum (a file registered
+    with register_file answers from its in-memory content)."""
+    name = a[0].s
+    for f in I.files.values():
+        if f.name == name:
+            if os.path.isfile(name):
+                break
+            return MStruct([{"name": MStr(os.path.basename(name)), "folder": MStr(os.path.dirname(name)), "date": MStr(""),
+                             "bytes": M(float(len(f.data))), "isdir": M(0.0), "datenum": M(0.0)}])
+    if not os.path.isfile(name):
+        return MStruct([])
+    st = os.stat(name)
+    return MStruct([{"name": MStr(os.path.basename(name)), "folder": MStr(os.path.dirname(os.path.abspath(name))), "date": MStr(""),
+                     "bytes": M(float(st.st_size)), "isdir": M(0.0), "datenum": M(st.st_mtime / 86400.0 + 719529.0)}])
+
+
 @builtin("fclose")
 def _fclose(I, a, n):
     if a and not isinstance(a[0], MStr):

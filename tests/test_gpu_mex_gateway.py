@@ -222,6 +222,47 @@ def test_matlab_drop_in_tracks_a_record_larger_than_the_window(gateway, tmp_path
                 assert np.array_equal(getattr(a, f), getattr(b, f)), f
 
 
+def test_matlab_drop_in_keeps_one_context_per_record_not_per_file_name(gateway, tmp_path):
+    """ADVICE r2 (gnsscorr_tracking.m:69): the cached context is keyed by what decides the bytes in HBM and reloads a record it does
+    not hold.  A windowed call first, then a resident one on the same file (was: 'no IF record'); the resident call again after a
+    windowed one; and the same file NAME rewritten as an int16 record (was: the stale int8 record, silently)."""
+    import bridge
+    import cu_sdr_collection_amd as P
+    from oracle import mlab
+    from types import SimpleNamespace
+    sc = next(s for s in RS.TRACK_SCENES if s.name == "GPS_L1CA")
+    S, rec, layout, ch = RS.scene_inputs(P, sc)
+    path = str(tmp_path / "record.bin")
+    rec.tofile(path)
+    mch = mlab.to_matlab([SimpleNamespace(**{k: (v if isinstance(v, str) else float(v)) for k, v in vars(c).items()}) for c in ch])
+    I = bridge.install(bridge.interpreter_for("GPS_L1CA"), gateway, P, sc.signal)
+    fid = mlab.register_file(I, rec.tobytes(), path)
+    window = float(int(S.samplingFreq * S.intTime * 14.5))
+    runs = []
+    try:
+        for w in (window, 0.0, window, 0.0):
+            S.gnsscorrWindowSamples = w
+            tr, _ = I.call("tracking", fid, mch, mlab.to_matlab(S), nargout=2)
+            runs.append(mlab.from_matlab(tr))
+        # the same name, another record: int16 samples with the same values -> the same results, through a context of its own
+        rec.astype(np.int16).tofile(path)
+        fid16 = mlab.register_file(I, rec.astype(np.int16).tobytes(), path)
+        S.gnsscorrWindowSamples = 0.0
+        S.dataType = "int16"
+        tr16, _ = I.call("tracking", fid16, mch, mlab.to_matlab(S), nargout=2)
+        runs.append(mlab.from_matlab(tr16))
+    finally:
+        I.call("gnsscorr_context", "", "clear")
+    for k, other in enumerate(runs[1:], 1):
+        for a, b in zip(runs[0], other):
+            assert a.status == b.status and np.array_equal(a.absoluteSample, b.absoluteSample)
+            for f in ("I_P", "Q_P", "carrFreq", "codeFreq"):
+                if k < 4:       # the same int8 record, windowed or resident: bit for bit
+                    assert np.array_equal(getattr(a, f), getattr(b, f)), (k, f)
+                else:           # the int16 record runs the 8-sample-chunk kernels: the same sums in another order of float additions
+                    assert np.allclose(getattr(a, f), getattr(b, f), rtol=0, atol=1e-5 * 2 * 18000 * 28 if f in ("I_P", "Q_P") else 1e-3), (k, f)
+
+
 @pytest.mark.parametrize("name", ["GPS_L1CA", "GPS_L5C", "BDS_B1C_WB"])
 def test_matlab_drop_in_with_the_loop_closed_on_the_gpu(gateway, name, tmp_path):
     """settings.gnsscorrDeviceLoop: the drop-in's loops run in one persistent launch (gnsscorr_mex('track_device') -> gc_track_device)

@@ -126,3 +126,36 @@ def test_receiver_tracking_file_equals_tracking(engine, l1ca_scene, tmp_path):
             if isinstance(getattr(x, f), np.ndarray):
                 assert np.array_equal(getattr(x, f), getattr(y, f)), f
         assert x.CNo.VSMValue == y.CNo.VSMValue and x.CNo.VSMIndex == y.CNo.VSMIndex
+
+
+def test_a_run_that_starts_deep_in_the_file_starts_in_that_window(engine, l1ca_scene, tmp_path):
+    """ADVICE r2 (track.hip:459, stream.hip): settings.skipNumberOfBytes puts the first block far from the start of the record.
+    gc_track_file opens the window that holds it (not window 0 and every window after it, each pausing with zero epochs), and
+    gc_track_resume on a window whose origin is not 0 reads the run's first block at its RECORD position - in both cases the
+    records of the resident run, bit for bit."""
+    import copy
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    S, sats, iq = l1ca_scene                    # 0.3 s at 18 Msps
+    S = copy.copy(S)                            # (the scene is shared by the session's tests)
+    skip_samples = int(0.150 * S.samplingFreq) + 77
+    S.skipNumberOfBytes = skip_samples          # tracking.m:150-152 seeks dataAdaptCoeff*(skipNumberOfBytes + codePhase - 1) bytes: the field counts samples of an I/Q file
+    S.msToProcess, S.numberOfChannels = 120, 3
+    path = os.path.join(tmp_path, "record.bin")
+    iq.tofile(path)
+    job = _job(P, engine, S, _channels(S, sats, 3))
+    assert job.p.skip_samples == skip_samples
+    engine.load_if(iq, fs=S.samplingFreq)
+    resident = engine.track(job.p, job.inits)
+    assert resident[2] == 0 and all(resident[1] == 120) and resident[0]["absoluteSample"].min() >= skip_samples
+    window = int(0.030 * S.samplingFreq)        # the run starts in the sixth window
+    _same(resident, engine.track_file(path, job.p, job.inits, window))
+    # the same through gc_track_resume by hand: one window cut out of the record at a 256-aligned origin before the first block
+    origin = (skip_samples - 5000) // 256 * 256
+    engine.load_if(iq[2 * origin:], fs=S.samplingFreq)
+    p1 = copy.copy(job.p)
+    p1.n_epochs = 120
+    f1, d1, s1, state, paused = engine.track_resume(p1, job.inits, origin=origin)
+    assert not paused and all(d1 == 120)
+    for name in f1:
+        assert np.array_equal(f1[name], resident[0][name]), name

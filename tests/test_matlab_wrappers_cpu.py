@@ -38,6 +38,8 @@ class _MockGateway:
         self.calls.append((cmd, a))
         if cmd == "create":
             return np.array([[0.0]])
+        if cmd == "if_info":                       # a fresh context holds no record
+            return np.zeros((1, 3))
         if cmd == "track":
             p, chan = a[1], np.asarray(a[2])
             n = int(np.asarray(p["numEpochs"]).flat[0])
