@@ -4,11 +4,12 @@
 # profiles/<round>/ afterwards with scripts/prof_summarize.py (see profiles/r02/README.md).
 #   usage: scripts/collect_profiles.sh <tag> [quick]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /root/repo
 export TMPDIR=/tmp
+sha256sum cu-sdr-collection_amd/lib/libgnsscorr.so | cut -d" " -f1 > "$OUT/lib_sha256.txt"   # ties every counter pass to the build it ran on (bench.py drops traffic of another build)
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp
 # per-kernel durations of the same command (no CPU leg: it adds nothing on the device)
@@ -17,13 +18,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- py
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/l1ca_pmc_$c" -- python /root/repo/bench.py --config l1ca --no-cpu --steps 4 --warmup 1 > /dev/null 2>&1
 done
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/l1ca_pmc_sq" -- python /root/repo/bench.py --config l1ca --no-cpu --steps 4 --warmup 1 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/l1ca_pmc_sq" -- python /root/repo/bench.py --config l1ca --no-cpu --steps 4 --warmup 1 > /dev/null 2>&1
 if [ "${2:-}" != "quick" ]; then
   # the other BASELINE shapes (scripts/prof_shapes.py: one replay kernel per shape)
-  for shape in l5 cboc e1x8 b1c; do
+  for shape in l5 cboc e1x8 b1c l1ca3; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${shape}_stats" -- python /root/repo/scripts/prof_shapes.py $shape 5 6 > "$OUT/${shape}.txt" 2>&1
     timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${shape}_pmc_FETCH_SIZE" -- python /root/repo/scripts/prof_shapes.py $shape 5 4 > /dev/null 2>&1
-    timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/${shape}_pmc_sq" -- python /root/repo/scripts/prof_shapes.py $shape 5 4 > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/${shape}_pmc_sq" -- python /root/repo/scripts/prof_shapes.py $shape 5 4 > /dev/null 2>&1
   done
   # acquisition
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/acq_stats" -- python /root/repo/scripts/acq_time.py > "$OUT/acq.txt" 2>&1

@@ -47,17 +47,21 @@ for f in sorted(os.listdir(src)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+try:
+    lib_sha = open(os.path.join(src, "lib_sha256.txt")).read().strip()
+except OSError:
+    lib_sha = bench.get("libgnsscorr_sha256")
 traffic, lines = [], ["# digest of " + src + " (" + build + ")", ""]
 shapes = [("l1ca", "corr_epl_fast_kernel", bench["config"]["blocks_per_step"], None)]
-for s in ("l5", "cboc", "e1x8", "b1c"):
+for s in ("l5", "cboc", "e1x8", "b1c", "l1ca3"):
     t = os.path.join(src, s + ".txt")
     if os.path.exists(t):
         m = re.search(r"\{'shape'.*\}", open(t).read())
         if m:
             d = eval(m.group(0))
             shapes.append((s, "corr_epl_lane_kernel" if "lane" in d["kernel"] else "corr_epl_fast_kernel", None, d))
-lines.append("| workload | replay kernel (grid) | launches | avg ms (profiler) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes / launch | VALU instr per channel-sample | LDS instr per channel-sample |")
-lines.append("|---|---|---|---|---|---|---|---|---|")
+lines.append("| workload | replay kernel (grid) | launches | avg ms (profiler) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes / launch | VALU instr per channel-sample | LDS instr per channel-sample | VALU-active share of wave cycles | instruction-wait share of wave cycles |")
+lines.append("|---|---|---|---|---|---|---|---|---|---|---|")
 for name, want, blocks, d in shapes:
     fc, fd = parse(os.path.join(src, f"{name}_pmc_FETCH_SIZE.txt"))
     wc, _ = parse(os.path.join(src, f"{name}_pmc_WRITE_SIZE.txt"))
@@ -75,10 +79,14 @@ for name, want, blocks, d in shapes:
     lds = sc[ks]["SQ_INSTS_LDS"][0] * 64 / cs if ks and "SQ_INSTS_LDS" in sc[ks] else None
     kd = replay_kernel(st, want)
     calls, avg = (st[kd][0], st[kd][1] / 1e6) if kd else (None, None)
+    wc = sc[ks].get("SQ_WAVE_CYCLES", (None,))[0] if ks else None
+    act = sc[ks].get("SQ_ACTIVE_INST_VALU", (None,))[0] if ks else None
+    wai = sc[ks].get("SQ_WAIT_INST_ANY", (None,))[0] if ks else None
     lines.append(f"| {name} | `{k[0][:64]}` ({k[1]}) | {calls} | {avg if avg is None else round(avg, 4)} | {fetch} | {write} | {hbm} | "
-                 f"{None if valu is None else round(valu, 2)} | {None if lds is None else round(lds, 2)} |")
+                 f"{None if valu is None else round(valu, 2)} | {None if lds is None else round(lds, 2)} | "
+                 f"{None if not wc or act is None else round(act / wc, 3)} | {None if not wc or wai is None else round(wai / wc, 3)} |")
     e = {"workload": name, "kernel": k[0], "grid": k[1], "fetch_size_kb_mean": fetch, "write_size_kb_mean": write, "gfx950_fetch_correction": 2.0,
-         "hbm_bytes_per_launch": hbm, "build": build,
+         "hbm_bytes_per_launch": hbm, "build": build, "lib_sha256": lib_sha,
          "note": "FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE uncorrected" +
                  ("" if write is not None else "; WRITE_SIZE not collected for this shape (outputs are 96-144 B per block)")}
     e["channel_samples_per_launch"] = cs
