@@ -40,6 +40,18 @@ constexpr int kLW = kLaneWaves;  // wavefronts per workgroup
 #define GC_LANE_GRP 4
 #endif
 constexpr int kGRP = GC_LANE_GRP;  // samples per lane and group: the loads of the next group fly under this one
+// The per-lane float32 sums are emptied into float64 totals (one set per wave, in LDS) every GC_LANE_FLUSH_RUNS runs of
+// kLaneReseedSteps steps and at the end of the block: with 2, no float32 partial sum covers more than 256 samples of a lane before
+// it meets the other lanes in a 64-lane float32 tree and goes to float64 (the reference sums in float64).  In the
+// closed loops a wave holds a fraction of a block (16 - 100 samples per lane) and the flush at the end of the block is the only one
+// that ever happens; the batched launches' waves walk whole blocks (up to 2 812 samples per lane for a 10-ms BDS B1C block).
+// Measured on one box (scripts/variants.sh, prof_shapes l5 / cboc, 10-s records): never flushing inside a block 2.414 / 1.758 ms,
+// every 4 runs 2.454 / 1.789 (+1.7 %), every 2 runs 2.504 / 1.816 (+3.5 %); the batched replay of a loop's own records comes back
+// 4x closer to the loop's sums (1.7e-8 -> 4e-9 of full scale).
+#ifndef GC_LANE_FLUSH_RUNS
+#define GC_LANE_FLUSH_RUNS 2
+#endif
+constexpr int kRhoPerWave = kLaneReseedSteps;
 
 // TAB: 0 = f32 tables, 1 = f32 tables + ONE ramp for all three taps (earlyLateSpc*R*M == 1/2: HALF, below), 2 = f16 tables
 // DEVLOOP = persistent launch with device-side loop closure (devloop.h): p.splits workgroups of 16 waves per channel, the
@@ -65,6 +77,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   // one ds_read2, the prompt tap selects between them by the sign bit of Q_E's low word.  Per sample and two arms that is one
   // 64-bit add, one LDS instruction and two selects instead of two adds, three address computations and three LDS reads.
   constexpr bool kHalf = (TAB == 1);
+  constexpr int kFlushRuns = GC_LANE_FLUSH_RUNS;
   constexpr int NT = kHalf ? 1 : 3;  // ramps carried per sample
   constexpr bool kReal = (MODE == I8_REAL || MODE == I16_REAL);
 #ifdef GC_LANE_GRP_DER
@@ -162,9 +175,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   if (wave_items && wq >= p.nblocks) return;
 
   // DEVLOOP scratch behind the tables: float red[16][GC_OUT_STRIDE] | gc_block + status | double dred[64]
-  gc_block* sblk = reinterpret_cast<gc_block*>(smem + p.red_off + kLW * GC_OUT_STRIDE * sizeof(float));
+  gc_block* sblk = reinterpret_cast<gc_block*>(smem + p.red_off + kLW * GC_OUT_STRIDE * sizeof(double));
   int* sstatus = reinterpret_cast<int*>(sblk + 1);
-  double* dred = reinterpret_cast<double*>(smem + p.red_off + kLW * GC_OUT_STRIDE * sizeof(float) + 128);
+  double* dred = reinterpret_cast<double*>(smem + p.red_off + kLW * GC_OUT_STRIDE * sizeof(double) + 128);
   const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
   DevLoopChan dl_st;  // DEVLOOP closer (member 0, wave 0): the channel's loop state, in registers across the epochs
   if constexpr (DEVLOOP) {
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   // x * rho_j itself); the sums run Horner-style - when run g >= 1 starts the accumulators turn by conj(P) - and are turned
   // once, at the end of the block, by the lane's exact float64-reduced phasor.  (Until round 3 every lane carried its own
   // phasor and rotated it by one step per sample: four more VALU instructions per sample and a recurrence to re-seed.)
-  float2* const rho = reinterpret_cast<float2*>(smem + p.rho_off) + wave * kLaneReseedSteps;
+  float2* const rho = reinterpret_cast<float2*>(smem + p.rho_off) + wave * kRhoPerWave;
   float turnC, turnS;  // conj(P) = turnC + i*turnS
   {
     const int nst = min((iend - ibeg + 63) >> 6, kLaneReseedSteps);  // steps this wave walks (uniform), at most one run's worth
@@ -317,9 +330,13 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   for (int a = 0; a < ARMS; ++a)
 #pragma unroll
     for (int x = 0; x < 3; ++x) accr[a][x] = acci[a][x] = 0.0f;
+  // this wave's float64 totals of the block: component v (I_E, Q_E, I_P, Q_P, I_L, Q_L per arm) in LDS, owned by lane v
+  double* const totw = reinterpret_cast<double*>(smem + p.red_off) + wave * GC_OUT_STRIDE;
+  if (lane < GC_OUT_STRIDE) totw[lane] = 0.0;
+  __builtin_amdgcn_wave_barrier();
 
   int i = ibeg + lane;  // this lane's samples: i, i + 64, i + 128, ...
-  if (i < iend) {
+  {  // every lane walks the block (one past its last sample adds nothing): the flushes below reduce across all 64 lanes
     // Ramp state of this lane's first sample: the block-uniform value at sample ibeg from the reference's
     // doubles ((a + ibeg*d) * M), advanced by `lane` steps in exact fixed-point arithmetic, then narrowed to
     // Q = floor(t * 2^32) + 2^32 - 1, whose high word is ceil(t) unless t is within 2^-32 of an integer.
@@ -394,6 +411,27 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
           acci[a][x] = ni;
         }
       ++nturn;
+    };
+    // empty the lane sums into the wave's float64 totals: turn them by the lane's own phasor - exp(-i*theta) at its first sample
+    // of the current run, from the exact float64 phase -, add the 64 lanes (DPP tree), lane v adds component v in float64
+    auto flush = [&]() __attribute__((always_inline)) {
+      const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)(i_first + 64 * kLaneReseedSteps * nturn) * tau;
+      float wc, ws;
+      sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+      float mine = 0.0f;
+#pragma unroll
+      for (int a = 0; a < ARMS; ++a)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const float nr = fmaf(accr[a][x], wc, acci[a][x] * ws);
+          const float ni = fmaf(acci[a][x], wc, -(accr[a][x] * ws));
+          const float sr = rl_f(wave_sum_lane63(nr), 63), si = rl_f(wave_sum_lane63(ni), 63);
+          mine = (lane == a * 6 + 2 * x) ? sr : mine;
+          mine = (lane == a * 6 + 2 * x + 1) ? si : mine;
+          accr[a][x] = 0.0f;
+          acci[a][x] = 0.0f;
+        }
+      if (lane < ARMS * 6) totw[lane] += (double)mine;
     };
     // returns the entry of the last LDS arm (the one a derived arm is built from)
     auto accumulate = [&](int x, int k, float yr, float yi) __attribute__((always_inline)) -> float {
@@ -600,7 +638,12 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     static_assert((kPairs & (kPairs - 1)) == 0, "pairs per run: a power of two");
     // the ramps' rounding drift goes out where a run ends; the accumulators turn there
     auto end_of_run = [&]() __attribute__((always_inline)) {
-      turn();
+      if (kFlushRuns > 0 && (nturn + 1) % kFlushRuns == 0) {
+        flush();   // (the emptied sums need no turn)
+        ++nturn;
+      } else {
+        turn();
+      }
       Q0 += corrQ;
     };
     // Two sample buffers; the loads of a group fly while the group before it is processed.  The prefetch inside the loop is
@@ -659,46 +702,21 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       i += 64;
       ptr += (long long)bps * 64;
     }
-    // the lane's own phasor: exp(-i*theta) at its first sample of the last run, from the exact float64 phase
-    {
-      const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)(i_first + 64 * kLaneReseedSteps * nturn) * tau;
-      float wc, ws;
-      sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
-#pragma unroll
-      for (int a = 0; a < ARMS; ++a)
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-          const float nr = fmaf(accr[a][x], wc, acci[a][x] * ws);
-          const float ni = fmaf(acci[a][x], wc, -(accr[a][x] * ws));
-          accr[a][x] = nr;
-          acci[a][x] = ni;
-        }
-    }
+    flush();  // what is left in the lane sums
   }
 
-  // ---- reduce across the wavefront (DPP) and store --------------------------------------------------
-  float tot[ARMS * 6];
-#pragma unroll
-  for (int ar = 0; ar < ARMS; ++ar)
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-      tot[ar * 6 + 2 * x] = wave_sum_lane63(accr[ar][x]);
-      tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(acci[ar][x]);
-    }
+  // ---- the wave's float64 totals sit in LDS, component v owned by lane v: combine / store ------------------
+  __builtin_amdgcn_wave_barrier();
+  const double* tot_all = reinterpret_cast<const double*>(smem + p.red_off);  // [waves][GC_OUT_STRIDE]
   if constexpr (DEVLOOP) {
     const DevLoopArgs* dl = p.devloop;
     constexpr int NS = ARMS * 6;
-    float* red = reinterpret_cast<float*>(smem + p.red_off);
-    if (lane == 63) {
-#pragma unroll
-      for (int v = 0; v < NS; ++v) red[wave * GC_OUT_STRIDE + v] = tot[v];
-    }
     __syncthreads();
     if (wave == 0) {
       const unsigned int tag = (unsigned int)bi + 1u;
       double mine = 0.0;  // lanes 0 .. NS-1: this workgroup's sum of component `lane`
       if (lane < NS)
-        for (int w = 0; w < nw; ++w) mine += (double)red[w * GC_OUT_STRIDE + lane];
+        for (int w = 0; w < nw; ++w) mine += tot_all[w * GC_OUT_STRIDE + lane];
       msg_t* pm = dl->part_msg + (lb * p.splits) * NS;
       if (member != 0) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
@@ -795,40 +813,27 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     }
     __syncthreads();  // the closer's workgroup waits for the new descriptor; the scratch is free again
   } else if (wg_block) {
-    // one block per workgroup: lane 63 of every wave parks its sums in LDS, wave 0 adds them in double
-    float* red = reinterpret_cast<float*>(smem + p.red_off);
-    if (lane == 63) {
-#pragma unroll
-      for (int v = 0; v < ARMS * 6; ++v) red[wave * GC_OUT_STRIDE + v] = tot[v];
-    }
+    // one block per workgroup: the 16 waves' float64 totals are added in a fixed order
     __syncthreads();
     if (threadIdx.x < GC_OUT_STRIDE) {
       double s = 0.0;
       if ((int)threadIdx.x < arms_here * 6 && (int)threadIdx.x < ARMS * 6)
-        for (int w = 0; w < kLW; ++w) s += (double)red[w * GC_OUT_STRIDE + threadIdx.x];
+        for (int w = 0; w < kLW; ++w) s += tot_all[w * GC_OUT_STRIDE + threadIdx.x];
       p.out[lb * GC_OUT_STRIDE + threadIdx.x] = s;
     }
   } else if (CL) {
-    // lane v takes total v (broadcast from lane 63) and stores its 16-byte tagged record
+    // lane v stores total v as its 16-byte tagged record
     TaggedSlot* ts = p.tagged + (lb * p.splits + split) * GC_OUT_STRIDE;
-    float mine = 0.0f;
-#pragma unroll
-    for (int v = 0; v < ARMS * 6; ++v) {
-      const float t = rl_f(tot[v], 63);
-      mine = (lane == v) ? t : mine;
-    }
     if (lane < ARMS * 6) {
       TaggedSlot rec;
-      rec.value = (lane < arms_here * 6) ? (double)mine : 0.0;
+      rec.value = (lane < arms_here * 6) ? totw[lane] : 0.0;
       rec.tag = p.notify_tag;
       rec.zero = 0u;
       *reinterpret_cast<uint4*>(ts + lane) = *reinterpret_cast<const uint4*>(&rec);
     }
-  } else if (lane == 63) {
+  } else if (lane < GC_OUT_STRIDE) {
     double* o = (p.splits == 1) ? p.out + lb * GC_OUT_STRIDE : p.partial + (lb * p.splits + split) * GC_OUT_STRIDE;
-#pragma unroll
-    for (int v = 0; v < ARMS * 6; ++v) o[v] = (v < arms_here * 6) ? (double)tot[v] : 0.0;
-    for (int v = ARMS * 6; v < GC_OUT_STRIDE; ++v) o[v] = 0.0;
+    o[lane] = (lane < ARMS * 6 && lane < arms_here * 6) ? totw[lane] : 0.0;
   }
   }  // bpw loop
 }
@@ -907,14 +912,14 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   const bool half_tables = f32_bytes > (der ? 136u : 96u) * 1024;  // BDS B1C: two 20 462-entry arms = 164 KB as f32, 82 KB as f16
   const size_t tab_bytes = half_tables ? f16_bytes : f32_bytes;
   const bool i8c = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I
-  if ((half_tables && (f16_bytes + 4096 + kLW * kLaneReseedSteps * sizeof(float2) > 160 * 1024 || !i8c)) || (max_arms > 2 && !der) || (der && !i8c)) {
+  if ((half_tables && (f16_bytes + 4096 + kLW * kRhoPerWave * sizeof(float2) > 160 * 1024 || !i8c)) || (max_arms > 2 && !der) || (der && !i8c)) {
     gc_set_error("device loop on the lane kernel: tables above 156 KiB as f16, f16 tables or a derived arm on a record other than int8 I/Q, "
                  "or three independent arms are not instantiated");
     return GC_E_UNSUPPORTED;
   }
   a.red_off = (int)tab_bytes;
-  a.rho_off = (int)(tab_bytes + kLW * GC_OUT_STRIDE * sizeof(float) + 128 + 64 * sizeof(double));  // a multiple of 16
-  const size_t smem = (size_t)a.rho_off + (size_t)kLW * kLaneReseedSteps * sizeof(float2);
+  a.rho_off = (int)(tab_bytes + kLW * GC_OUT_STRIDE * sizeof(double) + 128 + 64 * sizeof(double));  // a multiple of 16
+  const size_t smem = (size_t)a.rho_off + (size_t)kLW * kRhoPerWave * sizeof(float2);
   const bool qi = ctx->if_layout == GC_QI;
   if (waves < 1 || waves > kLW) return GC_E_INVALID;
   if (der) {
@@ -982,10 +987,10 @@ int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBl
     gc_set_error("code tables need %zu bytes of LDS (> 160 KiB); set a window with gc_set_code_window", f16_bytes);
     return GC_E_UNSUPPORTED;
   }
-  smem += kLW * GC_OUT_STRIDE * sizeof(float);  // cross-wave scratch of the one-block-per-workgroup mode
+  smem += kLW * GC_OUT_STRIDE * sizeof(double);  // the waves' float64 totals (also the cross-wave scratch of the one-block-per-workgroup mode)
   smem = (smem + 15) / 16 * 16;
   a.rho_off = (int)smem;
-  smem += (size_t)kLW * kLaneReseedSteps * sizeof(float2);  // the waves' carrier-step tables (16 KiB)
+  smem += (size_t)kLW * kRhoPerWave * sizeof(float2);  // the waves' carrier-step tables (16 KiB)
   if (smem > 160 * 1024) {
     gc_set_error("code tables need %zu bytes of LDS with the kernel's scratch (> 160 KiB); set a window with gc_set_code_window", smem);
     return GC_E_UNSUPPORTED;
