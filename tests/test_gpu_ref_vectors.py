@@ -147,6 +147,30 @@ def test_hip_acquisition_equals_the_references_acquisition_m(engine, sc):
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
 
 
+_ACQ_FUSED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "GAL_E5b", "BDS_B2a", "BDS_B3I", "GLO_GL1")   # searches of 36 000 / 24 000 points
+
+
+@pytest.mark.parametrize("sc", [s for s in RS.ACQ_SCENES if s.name in _ACQ_FUSED], ids=[s.name for s in RS.ACQ_SCENES if s.name in _ACQ_FUSED])
+def test_fused_inverse_transform_kernel_equals_the_references_acquisition_m(engine, sc, monkeypatch):
+    """GC_ACQ_FUSED=1: the inverse side of the search in one launch (acq_fused_kernel: radix-4 decimation-in-frequency step, four
+    N / 4-point transforms in LDS, |.| and hop sums in registers, no intermediate in memory) - the alternative DESIGN.md 4.4 measures
+    against the default two passes - returns the reference's codePhase / carrFreq / peakMetric as well (data + pilot arms, shifted
+    and unshifted hop spectra, GLONASS' 24 000 points)."""
+    import cu_sdr_collection_amd as P
+    monkeypatch.setenv("GC_ACQ_FUSED", "1")
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    engine.load_if(rec, fs=S.samplingFreq)
+    got = sc.product(P, engine, S)
+    for f in sc.fields:
+        want = z["f_" + f]
+        have = np.asarray(getattr(got, f), dtype=np.float64)
+        if f == "peakMetric":
+            assert np.max(np.abs(have - want)) <= sc.metric_rtol * np.max(np.abs(want)), (sc.name, f)
+        else:
+            assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
+
+
 _ACQ_INT16 = ("GPS_L1CA", "GPS_L5C", "GAL_E1C", "GLO_GL1", "BDS_B1I", "GPS_L2C", "BDS_B1C", "GPS_L1CA_resampled", "BDS_B1C_resampled")
 
 
