@@ -25,9 +25,11 @@
 //     absorbs: a wave-group containing a sample whose fraction lies inside the window (or any sample, in
 //     blocks the host could not prove tie-free) is redone in float64 exactly as the reference computes it;
 //   * with earlyLateSpc*R*M a multiple of 1/2 the late tap reads the early tap's entry + 2*spacing (SHARE);
-//   * carrier: per-lane phasor from an exact float64 phase, rotated by exp(-i*2*pi*64*f/fs) per step;
-//   * 6*ARMS float accumulators per lane, DPP wavefront reduction, results as doubles or (closed loop) as
-//     host-mapped tagged 16-byte records.
+//   * carrier: the sample times the BLOCK-UNIFORM step phasor exp(-i*2*pi*64*j*f/fs) of its step j inside a run of 128 steps (a
+//     128-entry table of the wave in LDS, read as a broadcast), the sums turned once per run (Horner) and, when they are emptied,
+//     by the lane's own phasor from the exact float64 phase - no per-lane recurrence;
+//   * 6*ARMS float accumulators per lane, emptied every 256 samples of the lane into float64 totals of the wave (DPP tree over the
+//     64 lanes, float64 add in LDS); results as doubles or (closed loop) as host-mapped tagged 16-byte records.
 #include "corr_common.h"
 #include "devloop.h"
 
