@@ -149,3 +149,35 @@ def test_file_reads_as_the_reference_does_them(tmp_path):
     r1, r2, r3, r4 = I.call(name, fid, nargout=4)
     assert vec(mlab.from_matlab(r1))[0] == 4 and np.array_equal(vec(mlab.from_matlab(r2)), data[4:10]) and vec(mlab.from_matlab(r3))[0] == 6
     assert vec(mlab.from_matlab(r4))[0] == 6                                                       # a short read returns what is left
+
+
+def test_xcorr_kron_height_and_logical_assignment_as_navdecoding_uses_them(tmp_path):
+    """The built-ins the bit-synchronisation blocks of NAVdecoding.m lean on (tests/golden/ref_navsync_*), against MATLAB's
+    documented behaviour: xcorr(x, y) of a row and a shorter row returns 2 * max(N, M) - 1 lags in a ROW, lag k at index N + k,
+    c(N + k) = sum_n x(n + k) * y(n) with the shorter input zero-padded; kron of two rows; height / width; `v(v > 0) = 1;
+    v(v <= 0) = -1` leaves zeros at -1; find(...)' of a row is a column (the loops run over height(index)); round half away."""
+    r = vec(run(tmp_path, "x = [1 2 3 4 5]; y = [1 -1]; r = xcorr(x, y);"))
+    assert r.size == 9
+    full = [sum((x if 0 <= (n + k) < 5 else 0) * ([1, -1][n] if n < 2 else 0) for n in range(5) for x in [[1, 2, 3, 4, 5][n + k] if 0 <= n + k < 5 else 0]) for k in range(-4, 5)]
+    assert np.array_equal(r, np.array(full, dtype=float))
+    assert np.array_equal(r[4:], [1 - 2, 2 - 3, 3 - 4, 4 - 5, 5])         # the non-negative lags the sync blocks look at
+    sz = vec(run(tmp_path, "a = xcorr([1 2 3], [1 1]); b = xcorr([1; 2; 3], [1; 1]); r = [size(a) size(b)];"))
+    assert np.array_equal(sz, [1, 5, 5, 1])
+    assert np.array_equal(vec(run(tmp_path, "r = kron([1 -1 1], [1 2]);")), [1, 2, -1, -2, 1, 2])
+    assert np.array_equal(vec(run(tmp_path, "v = [3 0 -2 0.5]; v(v > 0) = 1; v(v <= 0) = -1; r = v;")), [1, -1, -1, 1])
+    assert np.array_equal(vec(run(tmp_path, "idx = find([0 1 0 1 1] > 0)'; r = [height(idx) width(idx) size(idx)];")), [3, 1, 3, 1])
+    assert np.array_equal(vec(run(tmp_path, "r = round([9.5 -9.5 9.49 239.99]);")), [10, -10, 9, 240])
+
+
+def test_run_lines_executes_only_the_given_lines_of_a_file(tmp_path):
+    """Interpreter.run_lines: a SECTION of a function file as a script in a given workspace (the NAVdecoding.m sync blocks) - the
+    other lines are blanked, not removed: an error still names the file's own line."""
+    path = os.path.join(tmp_path, "section.m")
+    with open(path, "w") as f:
+        f.write("function r = section(x)\nunknownToolboxCall();\na = x * 2;\nb = a + 1;\nunknownToolboxCall();\nc = b * undefinedName;\nend\n")
+    I = mlab.Interpreter([str(tmp_path)])
+    ws = I.run_lines(path, [(3, 4)], {"x": mlab.to_matlab(5.0)})
+    assert float(mlab.from_matlab(ws["b"])) == 11.0 and "c" not in ws
+    with pytest.raises(mlab.MError) as e:
+        I.run_lines(path, [(3, 4), (6, 6)], {"x": mlab.to_matlab(5.0)})
+    assert "section.m:6" in str(e.value)
