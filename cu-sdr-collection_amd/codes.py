@@ -34,14 +34,20 @@ _G1 = _lfsr10((3, 10))
 _G2 = _lfsr10((2, 3, 6, 8, 9, 10))
 
 
+_CA_CODE = {}
+
+
 def generateCAcode(PRN: int) -> np.ndarray:
     """GPS C/A code of `PRN` as int8 +-1, logic 1 -> +1 (same convention as
     GPS/GPS_L1CA/include/generateCAcode.m:90)."""
     if not 1 <= PRN <= len(_CA_G2_DELAY):
         raise ValueError(f"PRN {PRN} out of range")
-    g2d = np.roll(_G2, _CA_G2_DELAY[PRN - 1])
-    logic = _G1 ^ g2d
-    return (2 * logic.astype(np.int8) - 1).astype(np.int8)
+    code = _CA_CODE.get(PRN)
+    if code is None:
+        g2d = np.roll(_G2, _CA_G2_DELAY[PRN - 1])
+        logic = _G1 ^ g2d
+        code = _CA_CODE[PRN] = (2 * logic.astype(np.int8) - 1).astype(np.int8)
+    return code.copy()
 
 
 def padded_table(code: np.ndarray) -> np.ndarray:
@@ -56,6 +62,7 @@ def samplesPerCode(settings) -> int:
 
 
 _CA_INDEX = {}
+_CA_TABLE = {}
 
 
 def _ca_table_index(settings) -> np.ndarray:
@@ -77,7 +84,16 @@ def _ca_table_index(settings) -> np.ndarray:
 
 def makeCaTable(PRN: int, settings) -> np.ndarray:
     """Sampled C/A code for acquisition (makeCaTable.m:43-67): index ceil(ts*(1:spc)/tc), last = 1023."""
-    return generateCAcode(PRN)[_ca_table_index(settings)]
+    idx = _ca_table_index(settings)
+    key = (int(PRN), float(settings.samplingFreq), float(settings.codeFreqBasis), idx.size)
+    tab = _CA_TABLE.get(key)
+    if tab is None:                      # 32 PRNs x 65 us per acquisition call otherwise: kept like the index (read-only)
+        tab = generateCAcode(PRN)[idx]
+        tab.setflags(write=False)
+        if len(_CA_TABLE) > 256:
+            _CA_TABLE.clear()
+        _CA_TABLE[key] = tab
+    return tab
 
 
 # ---------------------------------------------------------------------------------------------

@@ -146,6 +146,12 @@ struct PassArgs {
   // workgroups, ~2 per CU, each walking all the hops); group g's raw sums go to acc_part[g][bin][n] and
   // abs_combine_kernel adds them in group order
   int hop_groups, acc_bins;
+  // Hand-over between the inverse transform's two passes in the CONSUMER's tile order: element (row r, column k) of the [OTHER rows][L]
+  // intermediate at (k / B) * (rows * B) + r * B + k % B, B = the columns pass's tile width (a power of two) - its tile is then
+  // ONE contiguous run instead of `rows` segments of B values (half a 128-byte line each at B = 8).  out_blocked: log2(B) + 1 on
+  // the producing rows pass, in_blocked != 0 on the consuming columns pass; 0: natural order.
+  int out_blocked, in_blocked;
+  int no_xcd_pairs;  // GC_ACQ_NO_XCD_PAIRS: blockIdx -> tile without the pairing of the strided passes (A/B)
   float* acc_part;
   // PRE_MUL_CONJ with circular spectrum shifts (the circshift search family): batch tb reads input transform
   // tb / shift_bins shifted by tb % shift_bins natural-frequency bins; n1, n2 give the [k1][k2] storage order
@@ -610,8 +616,17 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   __shared__ float2 twl[T1 + T2 + T3 + 1];
   __shared__ float2 tw2[POST == POST_TWIDDLE ? C * TW2 : 1];
   const unsigned tid = threadIdx.x;
-  const unsigned tile = blockIdx.x % TILES;
-  const unsigned bb = blockIdx.x / TILES;
+  // Strided (column) passes: a tile row is C consecutive float2 - 64 bytes at C = 8, half of a 128-byte line.  The neighbouring
+  // tile reads the other half; consecutive workgroups go to consecutive XCDs, each with an L2 of its own, and both fetched
+  // the whole line (rocprofv3 FETCH_SIZE: 328 MB per launch of the inverse columns pass for the 167 MB it reads).  Blocks b
+  // and b + 8 of a group of 16 share an XCD and start together: they take neighbouring tiles.
+  unsigned bid = blockIdx.x;
+  if constexpr (!CONTIG && (C * 8) % 128 != 0) {
+    const unsigned g = bid & ~15u;
+    if (g + 16 <= gridDim.x && !a.no_xcd_pairs) bid = g + ((bid & 7u) << 1) + ((bid >> 3) & 1u);
+  }
+  const unsigned tile = bid % TILES;
+  const unsigned bb = bid / TILES;
   const unsigned HG = (POST == POST_ABS_ACC && a.hop_groups > 1) ? (unsigned)a.hop_groups : 1u;
   const unsigned batch = bb / HG, hg = bb - batch * HG;
   const unsigned v0 = tile * C;
@@ -664,6 +679,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
       } else {
         const unsigned e = idx / C, c = idx - e * C;
         pos = e * ESTR + (v0 + c) * VSTR;
+        if constexpr (PRE == PRE_NONE) {
+          if (a.in_blocked) pos = tile * NEL + idx;  // this tile's L x C values, in the order the threads take them
+        }
         li = c * L + e;
       }
       float2 val;
@@ -735,6 +753,12 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
         c = idx / L;
         e = idx - c * L;
         pos = v0 * L + idx;
+        if constexpr (POST == POST_TWIDDLE || POST == POST_STORE) {
+          if (a.out_blocked) {
+            const unsigned sh = (unsigned)a.out_blocked - 1u, eb = e >> sh;
+            pos = eb * (OTHER << sh) + ((v0 + c) << sh) + (e - (eb << sh));
+          }
+        }
         li = idx;
       } else {
         e = idx / C;
@@ -1029,7 +1053,8 @@ struct PeakTrack {
   }
   // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
   // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
-  __device__ __forceinline__ void publish(unsigned long long* keys) const {
+  // the workgroup's candidate in thread 0: {maximum's bits, smallest bin, smallest column among the lanes that hold it}
+  __device__ __forceinline__ bool reduce(unsigned long long& ka, unsigned long long& kb) const {
     __shared__ unsigned int sm[4], sb[4], sc[4];
     unsigned int wm = m;
     for (int off = 32; off > 0; off >>= 1) wm = max(wm, (unsigned int)__shfl_xor((int)wm, off, 64));
@@ -1045,45 +1070,121 @@ struct PeakTrack {
       sc[wave] = c;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const int nw = (blockDim.x + 63) >> 6;
-      for (int w = 1; w < nw; ++w) {
-        if (sm[w] > wm) {
-          wm = sm[w];
-          b = sb[w];
-          c = sc[w];
-        } else if (sm[w] == wm) {
-          b = min(b, sb[w]);
-          c = min(c, sc[w]);
-        }
+    ka = kb = 0;
+    if (threadIdx.x != 0) return false;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) {
+      if (sm[w] > wm) {
+        wm = sm[w];
+        b = sb[w];
+        c = sc[w];
+      } else if (sm[w] == wm) {
+        b = min(b, sb[w]);
+        c = min(c, sc[w]);
       }
-      if (b != 0xffffffffu) {
-        const unsigned long long ka = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - b);
-        const unsigned long long kb = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - c);
-        if (ka > __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[0], ka);
-        if (kb > __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[1], kb);
-      }
+    }
+    if (b == 0xffffffffu) return true;  // nothing seen: keys stay 0
+    ka = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - b);
+    kb = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - c);
+    return true;
+  }
+  // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
+  // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
+  __device__ __forceinline__ void publish(unsigned long long* keys) const {
+    unsigned long long ka, kb;
+    if (reduce(ka, kb) && ka) {
+      if (ka > __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[0], ka);
+      if (kb > __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[1], kb);
+    }
+  }
+  // the same candidate as a plain store into this workgroup's own slot (keys_reduce_kernel picks them up)
+  __device__ __forceinline__ void publish_slot(unsigned long long* slot) const {
+    unsigned long long ka, kb;
+    if (reduce(ka, kb)) {
+      slot[0] = ka;
+      slot[1] = kb;
     }
   }
 };
+
+// The peak keys of one PRN from the per-workgroup candidates abs_combine_kernel left in `slots` (2 keys per workgroup,
+// `per_prn` workgroups per PRN): one workgroup per PRN, launched once after the last PRN.  A thousand workgroups starting
+// together and all finding the keys at zero made the two atomics of PeakTrack::publish a 2 000-deep queue on two addresses -
+// a third of that kernel's time; plain stores and this one small launch replace them.
+__global__ __launch_bounds__(256) void keys_reduce_kernel(const unsigned long long* __restrict__ slots, int per_prn,
+                                                          unsigned long long* __restrict__ keys) {
+  __shared__ unsigned long long sa[4], sb[4];
+  const unsigned long long* mine = slots + (size_t)blockIdx.x * per_prn * 2;
+  unsigned long long ka = 0, kb = 0;
+  for (int i = threadIdx.x; i < per_prn; i += blockDim.x) {
+    ka = max(ka, mine[2 * i]);
+    kb = max(kb, mine[2 * i + 1]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    ka = max(ka, (unsigned long long)__shfl_xor((long long)ka, off, 64));
+    kb = max(kb, (unsigned long long)__shfl_xor((long long)kb, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sa[threadIdx.x >> 6] = ka;
+    sb[threadIdx.x >> 6] = kb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      ka = max(ka, sa[w]);
+      kb = max(kb, sb[w]);
+    }
+    keys[2 * blockIdx.x] = max(keys[2 * blockIdx.x], ka);
+    keys[2 * blockIdx.x + 1] = max(keys[2 * blockIdx.x + 1], kb);
+  }
+}
 
 // POST_ABS_ACC with hop groups: results = (add ? results : 0) + (sum over groups, in group order) / n * scale;
 // `keys` != nullptr: also the peak pick of the finished results (last code arm of a PRN) over their first `valid` columns
 __global__ __launch_bounds__(256) void abs_combine_kernel(const float* __restrict__ part, int groups, int nbins, int n,
                                                           float* __restrict__ out, int add, float inv_n, float scale,
                                                           unsigned long long* keys, int valid) {
+  // keys: this launch's slot region (2 keys per workgroup), nullptr: no peak pick
   PeakTrack pk;
   const long long total = (long long)nbins * n;
-  for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-      const long long i = (long long)bin * n + c;
-      float v = 0.0f;
-      for (int g = 0; g < groups; ++g) v += part[(long long)g * total + i];
-      v = (add ? out[i] : 0.0f) + v * inv_n * scale;
-      out[i] = v;
-      if (c < valid) pk.see(v, (unsigned int)bin, (unsigned int)c);
-    }
-  if (keys) pk.publish(keys);
+  // the finished results of a PRN feed nothing but its peak keys: they are not written back (16.7 MB per PRN at the default
+  // search); an earlier code arm's sums (keys == nullptr) are what the last arm adds to
+  const bool store = keys == nullptr;
+  if ((n & 3) == 0) {  // four columns per thread and step: 16-byte loads
+    const int n4 = n >> 2;
+    for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
+      for (int c4 = blockIdx.x * blockDim.x + threadIdx.x; c4 < n4; c4 += gridDim.x * blockDim.x) {
+        const long long i = (long long)bin * n + 4 * c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < groups; ++g) {
+          const float4 t = *reinterpret_cast<const float4*>(part + (long long)g * total + i);
+          v.x += t.x;
+          v.y += t.y;
+          v.z += t.z;
+          v.w += t.w;
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (add) o = *reinterpret_cast<const float4*>(out + i);
+        v = make_float4(o.x + v.x * inv_n * scale, o.y + v.y * inv_n * scale, o.z + v.z * inv_n * scale, o.w + v.w * inv_n * scale);
+        if (store) *reinterpret_cast<float4*>(out + i) = v;
+        const int c = 4 * c4;
+        if (c < valid) pk.see(v.x, (unsigned int)bin, (unsigned int)c);
+        if (c + 1 < valid) pk.see(v.y, (unsigned int)bin, (unsigned int)(c + 1));
+        if (c + 2 < valid) pk.see(v.z, (unsigned int)bin, (unsigned int)(c + 2));
+        if (c + 3 < valid) pk.see(v.w, (unsigned int)bin, (unsigned int)(c + 3));
+      }
+  } else {
+    for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
+      for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const long long i = (long long)bin * n + c;
+        float v = 0.0f;
+        for (int g = 0; g < groups; ++g) v += part[(long long)g * total + i];
+        v = (add ? out[i] : 0.0f) + v * inv_n * scale;
+        if (store) out[i] = v;
+        if (c < valid) pk.see(v, (unsigned int)bin, (unsigned int)c);
+      }
+  }
+  if (keys) pk.publish_slot(keys + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
 // the peak pick alone (results written by the pass kernel itself: no hop groups)
@@ -1377,6 +1478,8 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
 
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
   static const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;
+  static const bool no_pairs = std::getenv("GC_ACQ_NO_XCD_PAIRS") != nullptr;
+  a.no_xcd_pairs = no_pairs ? 1 : 0;
   if (!generic) {
     // N = 36 000: 18 Msps, 1 ms codes (GPS L1 C/A, L5, Galileo E5a/E5b, BDS B2a/B3I: initSettings.m of each package);
     // N = 24 000: GLONASS L1/L2 at 12 Msps
@@ -1389,11 +1492,27 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
       return GC_OK;
     }
   }
+  if (a.in_blocked || a.out_blocked) {  // handover_block() promised a specialised pair of passes for this plan
+    gc_set_error("acquisition: no specialised pass kernel for a blocked hand-over (length %d x %d)", a.len, a.nvec);
+    return GC_E_STATE;
+  }
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   const size_t smem = ((size_t)2 * a.len * a.cols + a.len + (size_t)a.cols * (((a.len - 1) >> 4) + 17)) * sizeof(float2);
   hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned int)(tiles * nbatch_groups)), dim3(kFftThreads), smem, ctx->stream, a);
   GC_HIP(hipGetLastError());
   return GC_OK;
+}
+
+// log2(B) + 1 for the blocked hand-over between the inverse transform's passes (PassArgs::out_blocked), B = the tile width of
+// the specialised columns pass of this plan (GC_CT_SHAPE above) where that is a power of two; 0: natural order (generic kernel,
+// the 600 x 600 and 512 x 625 plans with tiles of 3 and 5 columns, GC_ACQ_NATURAL_ORDER=1 for A/B runs).
+int handover_block(const Plan& pl) {
+  static const bool off = std::getenv("GC_ACQ_GENERIC") != nullptr || std::getenv("GC_ACQ_NATURAL_ORDER") != nullptr;
+  if (off) return 0;
+  static const struct { int n1, n2, log2b; } shapes[] = {{180, 200, 3}, {150, 160, 3}, {375, 384, 2}, {250, 288, 3}};
+  for (const auto& k : shapes)
+    if (pl.n1 == k.n1 && pl.n2 == k.n2) return k.log2b + 1;
+  return 0;
 }
 
 void fill_sub(PassArgs& a, const SubPlan& sp) {
@@ -1436,11 +1555,14 @@ struct AcqScratch {
   int shift_rows = 0;
   unsigned long long* peaks = nullptr;  // per-PRN peak keys of gc_acquire_coarse_multi
   int peaks_cap = 0;
+  unsigned long long* slots = nullptr;  // per-workgroup peak candidates of abs_combine_kernel, one region per PRN
+  size_t slots_cap = 0;
+  int slots_per_prn = 0;                // workgroups per region in the call under way (0: keys were published directly)
 };
 
 void free_scratch(AcqScratch* s) {
   if (!s) return;
-  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->rowmax, s->rowarg, s->peaks};
+  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->rowmax, s->rowarg, s->peaks, s->slots};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -1449,15 +1571,21 @@ void free_scratch(AcqScratch* s) {
 // Last inverse pass (POST_ABS_ACC) over `nbins` bins.  With few bins the launch would have ~2 workgroups per CU, each
 // walking all nhops hops of its bin: the hops are then split over hop groups (a divisor of nhops), whose raw sums meet in
 // abs_combine_kernel - deterministic, group order fixed.
-int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr, int valid = 0) {
+int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr, int valid = 0,
+                    int ip = 0, int nprn = 1) {
   if (valid <= 0) valid = a.n;
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   int hg = 1;
   for (int g = 1; g <= a.nhops; ++g)
     if (a.nhops % g == 0 && (long long)tiles * nbins * hg < 8LL * ctx->compute_units) hg = g;
   if (std::getenv("GC_ACQ_NO_HOP_GROUPS")) hg = 1;
+  if (const char* e = std::getenv("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count
+    const int g = std::atoi(e);
+    if (g >= 1 && a.nhops % g == 0) hg = g;
+  }
   a.hop_groups = hg;
-  const dim3 pgrid((unsigned int)std::max(1, std::min((a.n + 1023) / 1024, 64)), (unsigned int)std::min<long long>(nbins, 65535));
+  dim3 pgrid((unsigned int)std::max(1, std::min((a.n + 1023) / 1024, 64)), (unsigned int)std::min<long long>(nbins, 65535));
+  if (const char* e = std::getenv("GC_ACQ_COMBINE_GX")) pgrid.x = (unsigned int)std::max(1, std::atoi(e));
   if (hg == 1) {
     int rc = launch_pass(ctx, a, nbins);
     if (rc || !keys) return rc;
@@ -1478,8 +1606,24 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   a.acc_bins = (int)nbins;
   int rc = launch_pass(ctx, a, nbins * hg);
   if (rc) return rc;
+  unsigned long long* region = nullptr;
+  if (keys) {  // PRN ip of nprn: its own region of candidate slots, reduced into the keys after the last PRN (finish_keys)
+    const int per = (int)(pgrid.x * pgrid.y);
+    const size_t want = (size_t)nprn * per * 2;
+    if (s->slots_cap < want) {
+      GC_HIP(hipStreamSynchronize(ctx->stream));
+      if (s->slots) (void)hipFree(s->slots);
+      s->slots = nullptr;
+      s->slots_cap = 0;
+      GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
+      GC_HIP(hipMemsetAsync(s->slots, 0, want * sizeof(unsigned long long), ctx->stream));
+      s->slots_cap = want;
+    }
+    s->slots_per_prn = per;
+    region = s->slots + (size_t)ip * per * 2;
+  }
   hipLaunchKernelGGL(abs_combine_kernel, pgrid, dim3(256), 0, ctx->stream, s->partial, hg, (int)nbins, a.n, a.acc_out, a.acc_add,
-                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, keys, valid);
+                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, region, valid);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -1699,6 +1843,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   // per-PRN peak keys {(bits << 32) | ~bin, (bits << 32) | ~column}, read back once after the last PRN
   unsigned long long* const peaks = s->peaks;
   GC_HIP(hipMemsetAsync(peaks, 0, (size_t)nprn * 2 * sizeof(unsigned long long), ctx->stream));
+  s->slots_per_prn = 0;
 
   // GC_ACQ_FUSED=1: the whole inverse side in one launch where a fused kernel exists for the plan (acq_fused_kernel: N = 36 000 -
   // GPS L1 C/A, L5, Galileo E5a / E5b, BDS B2a / B3I at 18 Msps - and N = 24 000, GLONASS at 12 Msps).  Same results (the parity
@@ -1725,6 +1870,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       if (fused) GC_HIP(hipGetLastError());
     }
   }
+  const int hblock = base.wrap_len > 0 ? 0 : handover_block(pl);
   for (int ip = 0; ip < nprn && !fused; ++ip) {
     for (int arm = 0; arm < narms; ++arm) {
       // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
@@ -1747,9 +1893,12 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.other = s->codespec + ((size_t)ip * narms + arm) * pl.n;
       a.out = s->tmp;
       a.out_batch_stride = pl.n;
+      a.out_blocked = hblock;  // the intermediate in the columns pass's tile order
       rc = launch_pass(ctx, a, (long long)nbins * H);
       if (rc) return rc;
       // I2: columns (length n1, stride n2), inverse, |.|/n accumulated over the hops of each bin
+      a.out_blocked = 0;
+      a.in_blocked = hblock;
       fill_sub(a, pl.p1);
       a.nvec = pl.n2;
       a.estride = pl.n2;
@@ -1761,9 +1910,13 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.acc_out = s->results;
       a.acc_add = arm > 0;
       a.acc_scale = (float)p->arm_weight[arm];  // 0: 1
-      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr, blk);
+      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr, blk, ip, nprn);
       if (rc) return rc;
     }
+  }
+  if (!fused && s->slots_per_prn) {
+    hipLaunchKernelGGL(keys_reduce_kernel, dim3((unsigned int)nprn), dim3(256), 0, ctx->stream, s->slots, s->slots_per_prn, peaks);
+    GC_HIP(hipGetLastError());
   }
   std::vector<unsigned long long> hpeaks((size_t)nprn * 2);
   GC_HIP(hipMemcpyAsync(hpeaks.data(), peaks, hpeaks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
