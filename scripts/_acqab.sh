@@ -1,20 +1,13 @@
-OUT=/root/repo/gpurun_out/r3s
+OUT=gpurun_out/r3t
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
-for v in blocked natural; do
-  if [ $v = natural ]; then export GC_ACQ_NATURAL_ORDER=1; else unset GC_ACQ_NATURAL_ORDER; fi
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/acq_$v" -- python /root/repo/scripts/acq_time.py > "$OUT/acq_$v.txt" 2>&1
-  f=$(find $OUT/acq_$v -name '*kernel_stats.csv' | head -1)
-  echo "== $v"; grep "best of" $OUT/acq_$v.txt; head -4 "$f" | cut -c1-60,130-220
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/acq_pmc_$v" -- python /root/repo/scripts/acq_time.py > /dev/null 2>&1
+python -m pytest tests -x -q -m gpu -k "closed_loop or tracking or track or persistent or mix" > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
+for t in 1 2 3 4; do
+  GC_TRACK_THREADS=$t python bench.py --no-cpu > $OUT/b_$t.json 2> $OUT/b_$t.err
   python - <<PY
-import csv,glob,collections
-for f in glob.glob('$OUT/acq_pmc_$v/**/*counter_collection.csv',recursive=True):
-    d=collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        d[r['Kernel_Name'][:75]].append(float(r['Counter_Value']))
-    for k,v in d.items():
-        if 'fft_pass' in k and len(v)>100 or 'combine' in k: print(k, len(v), sum(v)/len(v))
+import json
+d=json.loads(open('$OUT/b_$t.json').read().strip().splitlines()[-1])
+c=d['configs']
+print('threads $t: l1ca', d['closed_loop']['us_per_epoch'], 'dev', d['closed_loop_device']['us_per_epoch'],
+      {k:(v.get('closed_loop_host') or {}).get('us_per_epoch') for k,v in c.items() if isinstance(v,dict)})
 PY
 done
-unset GC_ACQ_NATURAL_ORDER; cd /root/repo; python -m pytest tests -x -q -m gpu -k "acq or acquisition" 2>&1 | tail -3

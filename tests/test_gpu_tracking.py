@@ -669,6 +669,33 @@ def test_persistent_and_launch_per_epoch_host_loops_agree(engine, l1ca_scene, mo
         assert np.max(np.abs(a[k].carrFreq - b[k].carrFreq)) < 1e-4
 
 
+def test_host_loops_dealt_out_to_several_host_threads_give_the_same_records(engine, l1ca_scene, monkeypatch):
+    """GC_TRACK_THREADS: the persistent kernel's channels served by three host threads (measured, not faster, so one
+    thread is the default).  A channel's loop never depends on which thread closes it: bit-identical records, and the lock-step
+    walk (GC_TRACK_LOCKSTEP=1) gives them too."""
+    import copy
+    import cu_sdr_collection_amd as P
+    S, sats, iq = l1ca_scene
+    S = copy.copy(S)
+    S.msToProcess = 120
+    S.numberOfChannels = 4
+    ch = _channels(S, sats, 4)
+    engine.load_if(iq, fs=S.samplingFreq)
+    a, _ = P.tracking(engine, ch, S)
+    assert engine.last_track_mode() == 1
+    runs = {}
+    for name, env in (("threads", ("GC_TRACK_THREADS", "3")), ("lockstep", ("GC_TRACK_LOCKSTEP", "1"))):
+        monkeypatch.setenv(*env)
+        runs[name], _ = P.tracking(engine, ch, S)
+        assert engine.last_track_mode() == 1
+        monkeypatch.delenv(env[0])
+    for name, b in runs.items():
+        for k in range(4):
+            assert a[k].status == "T" and b[k].status == "T"
+            for f in ("absoluteSample", "I_E", "Q_E", "I_P", "Q_P", "I_L", "Q_L", "carrFreq", "codeFreq", "remCodePhase", "remCarrPhase"):
+                assert np.array_equal(getattr(a[k], f), getattr(b[k], f)), (name, k, f)
+
+
 def test_four_thousand_epoch_closed_loops_stay_equivalent(engine):
     """DESIGN.md 4.3b as an assertion.  Two closed loops over the same record (float64 C oracle of tracking.m, the GPU host loop,
     the GPU device loop) cannot stay bit-identical for thousands of epochs: f32 partial sums move the NCOs by ~1e-8 chip and
