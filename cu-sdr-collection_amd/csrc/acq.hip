@@ -1577,7 +1577,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   int hg = 1;
   for (int g = 1; g <= a.nhops; ++g)
-    if (a.nhops % g == 0 && (long long)tiles * nbins * hg < 8LL * ctx->compute_units) hg = g;
+    if (a.nhops % g == 0 && (long long)tiles * nbins * hg < 4LL * ctx->compute_units) hg = g;
   if (std::getenv("GC_ACQ_NO_HOP_GROUPS")) hg = 1;
   if (const char* e = std::getenv("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count
     const int g = std::atoi(e);

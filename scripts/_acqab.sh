@@ -1,13 +1,7 @@
-OUT=gpurun_out/r3t
+OUT=/root/repo/gpurun_out/r3s
 mkdir -p $OUT
-python -m pytest tests -x -q -m gpu -k "closed_loop or tracking or track or persistent or mix" > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
-for t in 1 2 3 4; do
-  GC_TRACK_THREADS=$t python bench.py --no-cpu > $OUT/b_$t.json 2> $OUT/b_$t.err
-  python - <<PY
-import json
-d=json.loads(open('$OUT/b_$t.json').read().strip().splitlines()[-1])
-c=d['configs']
-print('threads $t: l1ca', d['closed_loop']['us_per_epoch'], 'dev', d['closed_loop_device']['us_per_epoch'],
-      {k:(v.get('closed_loop_host') or {}).get('us_per_epoch') for k,v in c.items() if isinstance(v,dict)})
-PY
-done
+cd /root/repo; python -m pytest tests -x -q -m gpu -k "acq or acquisition" 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/acq_hg" -- python /root/repo/scripts/acq_time.py > "$OUT/acq_hg.txt" 2>&1
+f=$(find $OUT/acq_hg -name '*kernel_stats.csv' | head -1)
+grep "best of" $OUT/acq_hg.txt; head -5 "$f" | cut -c1-60,130-220
