@@ -258,6 +258,77 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// K wavefront sums at once, transposing as they go: on return the lane with wave_transpose_slot(lane) == c (c < K) holds the
+// 64-lane total of v[c].  A step over one lane bit pairs the values (2i, 2i + 1): the lanes with the bit clear keep value 2i and
+// add their partner's copy of it, the lanes with the bit set do the same for value 2i + 1 - one add per PAIR where K separate
+// trees take one per value and step, and no readlane / select to bring the totals to "their" lanes afterwards.  The first two steps
+// (most pairs) go over lane bits 2 and 3: masked row shifts, bank_mask picks the lanes whose partner lies above / below, so the two
+// masked adds write disjoint lanes of one register - two instructions per pair and no select.  Then bits 0 and 1 (quad_perm, two
+// selects + one add per pair), bit 4 (ds_swizzle), bit 5 (ds_bpermute).  K = 18 (three arms): ~45 cross-lane and select
+// instructions against 108 DPP adds + 36 readlanes + 36 selects.  Every lane of the wave must be active.
+__device__ __forceinline__ int wave_transpose_slot(int lane) {  // bits taken in the order 2, 3, 0, 1, 4
+  return ((lane >> 2) & 3) | ((lane & 3) << 2) | (lane & 16);
+}
+namespace wts {
+template <int CTRL>
+__device__ __forceinline__ float quad(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// x on the lanes whose mask bit is clear, y on the others; the mask is a wave-uniform constant (an SGPR pair, no compare per select)
+__device__ __forceinline__ float pick(float x, float y, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(mask));
+  return r;
+}
+// x + partner's x on the lanes whose bit is clear, y + partner's y on the lanes whose bit is set (S = 4 or 8 lanes apart, same row);
+// s_nop: the two wait states a DPP read wants after the VALU write of its source (the assembler cannot see into the block)
+template <int S>
+__device__ __forceinline__ float row_pair(float x, float y) {
+  float r;
+  if constexpr (S == 4)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(r) : "v"(x), "v"(y));
+  else
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(r) : "v"(x), "v"(y));
+  return r;
+}
+}  // namespace wts
+
+template <int K>
+__device__ __forceinline__ float wave_transpose_sum(const float (&v)[K], int lane) {
+  static_assert(K >= 1 && K <= 32, "one value per lane of half a wave at most");
+  constexpr int N1 = (K + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
+  constexpr unsigned long long kBit0 = 0xaaaaaaaaaaaaaaaaull, kBit1 = 0xccccccccccccccccull, kBit4 = 0xffff0000ffff0000ull;
+  float a1[N1], a2[N2], a3[N3], a4[N4];
+#pragma unroll
+  for (int i = 0; i < N1; ++i) a1[i] = wts::row_pair<4>(v[2 * i], v[2 * i + 1 < K ? 2 * i + 1 : 2 * i]);     // lane bit 2
+#pragma unroll
+  for (int i = 0; i < N2; ++i) a2[i] = wts::row_pair<8>(a1[2 * i], a1[2 * i + 1 < N1 ? 2 * i + 1 : 2 * i]);  // lane bit 3
+#pragma unroll
+  for (int i = 0; i < N3; ++i) {  // lane bit 0: quad_perm [1, 0, 3, 2]
+    if (2 * i + 1 < N2)
+      a3[i] = wts::pick(a2[2 * i], a2[2 * i + 1], kBit0) + wts::quad<0xB1>(wts::pick(a2[2 * i + 1], a2[2 * i], kBit0));
+    else
+      a3[i] = a2[2 * i] + wts::quad<0xB1>(a2[2 * i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N4; ++i) {  // lane bit 1: quad_perm [2, 3, 0, 1]
+    if (2 * i + 1 < N3)
+      a4[i] = wts::pick(a3[2 * i], a3[2 * i + 1], kBit1) + wts::quad<0x4E>(wts::pick(a3[2 * i + 1], a3[2 * i], kBit1));
+    else
+      a4[i] = a3[2 * i] + wts::quad<0x4E>(a3[2 * i]);
+  }
+  float r;  // lane bit 4: the other half of the 32-lane group (ds_swizzle, bit mode: and 0x1f, or 0, xor 0x10)
+  if constexpr (N4 == 2)
+    r = wts::pick(a4[0], a4[1], kBit4) + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(wts::pick(a4[1], a4[0], kBit4)), 0x401F));
+  else
+    r = a4[0] + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a4[0]), 0x401F));
+  return r + __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(r)));  // lane bit 5
+}
+
 __device__ __forceinline__ float rl_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }

@@ -28,8 +28,8 @@
 //   * carrier: the sample times the BLOCK-UNIFORM step phasor exp(-i*2*pi*64*j*f/fs) of its step j inside a run of 128 steps (a
 //     128-entry table of the wave in LDS, read as a broadcast), the sums turned once per run (Horner) and, when they are emptied,
 //     by the lane's own phasor from the exact float64 phase - no per-lane recurrence;
-//   * 6*ARMS float accumulators per lane, emptied every 256 samples of the lane into float64 totals of the wave (DPP tree over the
-//     64 lanes, float64 add in LDS); results as doubles or (closed loop) as host-mapped tagged 16-byte records.
+//   * 6*ARMS float accumulators per lane, emptied every 256 samples of the lane into float64 totals of the wave (all 6*ARMS sums over the
+//     64 lanes in one transposing reduction - wave_transpose_sum -, float64 add in LDS); results as doubles or (closed loop) as host-mapped tagged 16-byte records.
 #include "corr_common.h"
 #include "devloop.h"
 
@@ -415,25 +415,24 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
       ++nturn;
     };
     // empty the lane sums into the wave's float64 totals: turn them by the lane's own phasor - exp(-i*theta) at its first sample
-    // of the current run, from the exact float64 phase -, add the 64 lanes (DPP tree), lane v adds component v in float64
+    // of the current run, from the exact float64 phase -, add the 64 lanes (one transposing reduction for all components), the lane that ends up with component v adds it in float64
     auto flush = [&]() __attribute__((always_inline)) {
       const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)(i_first + 64 * kLaneReseedSteps * nturn) * tau;
       float wc, ws;
       sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
-      float mine = 0.0f;
+      float turned[ARMS * 6];
 #pragma unroll
       for (int a = 0; a < ARMS; ++a)
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-          const float nr = fmaf(accr[a][x], wc, acci[a][x] * ws);
-          const float ni = fmaf(acci[a][x], wc, -(accr[a][x] * ws));
-          const float sr = rl_f(wave_sum_lane63(nr), 63), si = rl_f(wave_sum_lane63(ni), 63);
-          mine = (lane == a * 6 + 2 * x) ? sr : mine;
-          mine = (lane == a * 6 + 2 * x + 1) ? si : mine;
+          turned[a * 6 + 2 * x] = fmaf(accr[a][x], wc, acci[a][x] * ws);
+          turned[a * 6 + 2 * x + 1] = fmaf(acci[a][x], wc, -(accr[a][x] * ws));
           accr[a][x] = 0.0f;
           acci[a][x] = 0.0f;
         }
-      if (lane < ARMS * 6) totw[lane] += (double)mine;
+      const float mine = wave_transpose_sum<ARMS * 6>(turned, lane);  // the wave's total of component `slot` in this lane
+      const int slot = wave_transpose_slot(lane);
+      if (slot < ARMS * 6) totw[slot] += (double)mine;
     };
     // returns the entry of the last LDS arm (the one a derived arm is built from)
     auto accumulate = [&](int x, int k, float yr, float yi) __attribute__((always_inline)) -> float {

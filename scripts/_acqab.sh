@@ -1,7 +1,10 @@
-OUT=/root/repo/gpurun_out/r3s
+OUT=gpurun_out/r3v
 mkdir -p $OUT
-cd /root/repo; python -m pytest tests -x -q -m gpu -k "acq or acquisition" 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/acq_hg" -- python /root/repo/scripts/acq_time.py > "$OUT/acq_hg.txt" 2>&1
-f=$(find $OUT/acq_hg -name '*kernel_stats.csv' | head -1)
-grep "best of" $OUT/acq_hg.txt; head -5 "$f" | cut -c1-60,130-220
+for rep in 1 2; do
+for v in OLD NEW; do
+  for shape in cboc l5; do
+    GC_LIB_PATH=$PWD/cu-sdr-collection_amd/lib/libgnsscorr_$v.so python scripts/prof_shapes.py $shape 10 8 2>/dev/null | tail -1 | cut -c1-200
+  done
+done
+done
+GC_LIB_PATH=$PWD/cu-sdr-collection_amd/lib/libgnsscorr_NEW.so python -m pytest tests -x -q -m gpu -k "not bench_ranks and not smoke and not build" 2>&1 | tail -4
