@@ -258,6 +258,13 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// Derived BOC(6,1) arm of the lane kernel: 1 = its f32 table image carries a third column, the base arm times (-1)^entry (16-byte
+// entries, one VALU instruction per tap less); 0 = 8-byte entries {arm 0, arm 1} and the entry's parity added to the sign word
+// (half the LDS bytes per tap).  Host image (gc_sync_channels) and kernel must agree.
+#ifndef GC_LANE_PN
+#define GC_LANE_PN 1
+#endif
+
 // K wavefront sums at once, transposing as they go: on return the lane with wave_transpose_slot(lane) == c (c < K) holds the
 // 64-lane total of v[c].  A step over one lane bit pairs the values (2i, 2i + 1): the lanes with the bit clear keep value 2i and
 // add their partner's copy of it, the lanes with the bit set do the same for value 2i + 1 - one add per PAIR where K separate

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
   constexpr bool kF16 = (TAB == 2);
   // PN: the derived arm's f32 image carries a third column, arm LA - 1 times (-1)^entry (gc_sync_channels): the sign of the
   // derived entry is then the sign of that column times one bit of the base ramp's fraction (below)
-  constexpr bool PN = DER && !kF16;
+  constexpr bool PN = DER && !kF16 && GC_LANE_PN != 0;
   constexpr int AP = PN ? 4 : ArmPitch<LA>::v;  // values per staged entry
   // HALF: with earlyLateSpc*R*M == 1/2 (the reference's default 0.5-chip spacing on a 1x table: GPS L5, BDS B2a / B3I, Galileo
   // E5a / E5b, GPS L2C in doubled-code units) the late ramp is the early ramp + 1 exactly, and the prompt ramp t = u_E + 1/2 has
@@ -908,7 +908,7 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   const int ap = gc_arm_pitch(der ? 2 : max_arms);
   // a derived arm's f32 image has four values per entry (the third: arm 1 times (-1)^entry, DevChannel::tabf_ap) and may take
   // most of the LDS - a persistent member is alone on its CU anyway; every other f32 table stays below 96 KiB
-  const size_t f32_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * (der ? 4 : ap) * 4 + 15) / 16 * 16;
+  const size_t f32_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ((der && GC_LANE_PN != 0) ? 4 : ap) * 4 + 15) / 16 * 16;
   const size_t f16_bytes = (((size_t)ctx->max_stage_len + 2 * kGuard) * ap * 2 + 15) / 16 * 16;
   const bool half_tables = f32_bytes > (der ? 136u : 96u) * 1024;  // BDS B1C: two 20 462-entry arms = 164 KB as f32, 82 KB as f16
   const size_t tab_bytes = half_tables ? f16_bytes : f32_bytes;
@@ -972,7 +972,7 @@ int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBl
   const int ap = gc_arm_pitch(a.derived ? 2 : max_arms);  // a derived third arm has no table of its own ...
   const size_t entries = (size_t)ctx->max_stage_len + 2 * kGuard;
   // ... but its f32 image carries a third column, arm 1 times (-1)^entry: four values per entry (DevChannel::tabf_ap), up to 136 KiB
-  const size_t f32_bytes = (entries * (a.derived ? 4 : ap) * 4 + 15) / 16 * 16;
+  const size_t f32_bytes = (entries * ((a.derived && GC_LANE_PN != 0) ? 4 : ap) * 4 + 15) / 16 * 16;
   const size_t f16_bytes = (entries * ap * 2 + 15) / 16 * 16;
   int tabkind;
   size_t smem;

@@ -521,7 +521,7 @@ int gc_sync_channels(gc_context* ctx) {
     }
     if (whole && maxn <= 65536) {
       const int ap = gcorr::gc_arm_pitch(larms);
-      const int apf = derived ? 4 : ap;  // derived: {arm 0, arm 1, arm 1 * (-1)^entry, 0}
+      const int apf = (derived && GC_LANE_PN != 0) ? 4 : ap;  // derived: {arm 0, arm 1, arm 1 * (-1)^entry, 0}
       const size_t entries = (size_t)maxn + 2 * gcorr::kGuard;
       const size_t bytes = (entries * ap * 2 + 15) / 16 * 16;
       const size_t fbytes = (entries * apf * 4 + 15) / 16 * 16;
@@ -532,7 +532,7 @@ int gc_sync_channels(gc_context* ctx) {
           const int8_t v = c.h_tab[a][e];
           t[((size_t)e + gcorr::kGuard) * ap + a] = v > 0 ? 0x3C00 : v < 0 ? 0xBC00 : 0;  // f16 +1 / -1 / 0
           tf[((size_t)e + gcorr::kGuard) * apf + a] = (float)v;
-          if (derived && a == 1) tf[((size_t)e + gcorr::kGuard) * apf + 2] = (e & 1) ? -(float)v : (float)v;
+          if (derived && GC_LANE_PN != 0 && a == 1) tf[((size_t)e + gcorr::kGuard) * apf + 2] = (e & 1) ? -(float)v : (float)v;
         }
       GC_HIP(hipMalloc((void**)&hc.d_tabh, bytes));
       GC_HIP(hipMemcpy(hc.d_tabh, t.data(), bytes, hipMemcpyHostToDevice));
