@@ -151,6 +151,9 @@ struct PassArgs {
   // ONE contiguous run instead of `rows` segments of B values (half a 128-byte line each at B = 8).  out_blocked: log2(B) + 1 on
   // the producing rows pass, in_blocked != 0 on the consuming columns pass; 0: natural order.
   int out_blocked, in_blocked;
+  // shifted rows pass of the inverse transform: one workgroup walks row_reps consecutive batches (hops of ONE bin: the shift, the
+  // source rows, the code-spectrum values and the twiddle tables are the same for all of them); 0 or 1: one batch per workgroup
+  int row_reps;
   int no_xcd_pairs;  // GC_ACQ_NO_XCD_PAIRS: blockIdx -> tile without the pairing of the strided passes (A/B)
   float* acc_part;
   // PRE_MUL_CONJ with circular spectrum shifts (the circshift search family): batch tb reads input transform
@@ -630,7 +633,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   const unsigned HG = (POST == POST_ABS_ACC && a.hop_groups > 1) ? (unsigned)a.hop_groups : 1u;
   const unsigned batch = bb / HG, hg = bb - batch * HG;
   const unsigned v0 = tile * C;
-  const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : 1;
+  constexpr bool RR = SHIFT && POST != POST_ABS_ACC;  // rows pass that may walk several hops of its bin (PassArgs::row_reps)
+  const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : (RR && a.row_reps > 1 && a.shift_q > 0) ? a.row_reps : 1;
 
   stage_twiddles_ct<R1, NS1, N, INV>(a.tw, twl, tid);
   stage_twiddles_ct<R2, NS2, N, INV>(a.tw, twl + T1, tid);
@@ -650,8 +654,33 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
 #pragma unroll
   for (unsigned k = 0; k < SLOTS; ++k) accv[k] = 0.f;
 
+  // RR: everything of the load that does not depend on the hop - where in the source spectrum each of the thread's values comes
+  // from (the rotation by the bin's shift) and the code-spectrum value it is multiplied with - is worked out once
+  [[maybe_unused]] unsigned rr_src[RR ? SLOTS : 1];
+  [[maybe_unused]] float2 rr_oth[RR ? SLOTS : 1];
+  if constexpr (RR) {
+    const long long tb0 = (long long)batch * reps;
+    const unsigned sft = a.shift_q > 0 ? (unsigned)(tb0 / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
+    const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
+#pragma unroll
+    for (unsigned slot = 0; slot < SLOTS; ++slot) {
+      const unsigned idx = tid + slot * kFftThreads;
+      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      const unsigned c = idx / L, e = idx - c * L;
+      int k1 = (int)(v0 + c) - (int)s1;
+      const int bor = k1 < 0;
+      k1 += bor ? OTHER : 0;
+      int e2 = (int)e - (int)s2 - bor;
+      e2 += e2 < 0 ? L : 0;
+      rr_src[RR ? slot : 0] = (unsigned)(k1 * L + e2);
+      rr_oth[RR ? slot : 0] = a.other[v0 * L + idx];
+    }
+  }
+
   for (int rep = 0; rep < reps; ++rep) {
-    const long long tb = POST == POST_ABS_ACC ? (long long)batch * a.nhops + (long long)hg * reps + rep : (long long)batch;
+    const long long tb = POST == POST_ABS_ACC ? (long long)batch * a.nhops + (long long)hg * reps + rep
+                         : RR                 ? (long long)batch * reps + rep
+                                              : (long long)batch;
     // ---- load --------------------------------------------------------------------------------------------
     [[maybe_unused]] int cb = 0, ch = 0;
     [[maybe_unused]] double fcyc = 0.0;
@@ -707,18 +736,24 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
         if constexpr (SHIFT) {
           // Y[k] = X[(k - s) mod N], k = k1 + N1*k2 stored at k1*N2 + k2 (N1 = OTHER rows of N2 = L): row v of Y is row
           // (v - s1) mod N1 of X rotated by s2 (+1 when the row index wrapped), s = s1 + N1*s2
-          const unsigned c = idx / L, e = idx - c * L;
-          int k1 = (int)(v0 + c) - (int)sh1;
-          const int bor = k1 < 0;
-          k1 += bor ? OTHER : 0;
-          int e2 = (int)e - (int)sh2 - bor;
-          e2 += e2 < 0 ? L : 0;
-          val = a.in[shsrc * a.in_batch_stride + k1 * L + e2];
+          if constexpr (RR) {
+            val = a.in[shsrc * a.in_batch_stride + rr_src[slot]];
+          } else {
+            const unsigned c = idx / L, e = idx - c * L;
+            int k1 = (int)(v0 + c) - (int)sh1;
+            const int bor = k1 < 0;
+            k1 += bor ? OTHER : 0;
+            int e2 = (int)e - (int)sh2 - bor;
+            e2 += e2 < 0 ? L : 0;
+            val = a.in[shsrc * a.in_batch_stride + k1 * L + e2];
+          }
         } else {
           val = a.in[tb * a.in_batch_stride + pos];
         }
         if constexpr (PRE == PRE_MUL_CONJ) {
-          const float2 o = a.other[pos];
+          float2 o;
+          if constexpr (RR) o = rr_oth[slot];
+          else o = a.other[pos];
           val = make_float2(val.x * o.x + val.y * o.y, val.y * o.x - val.x * o.y);
         }
       }
@@ -776,7 +811,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
     }
     // the next hop's load overwrites buf0: safe without a barrier when the result sits in buf1 (the barrier after the
     // load orders this hop's reads of buf1 before the next first stage writes it)
-    if constexpr (POST == POST_ABS_ACC && !(NST & 1)) __syncthreads();
+    if constexpr ((POST == POST_ABS_ACC || RR) && !(NST & 1)) __syncthreads();
   }
   if constexpr (POST == POST_ABS_ACC) {
     const float inv_n = 1.0f / (float)N, scale = a.acc_scale != 0.0f ? a.acc_scale : 1.0f;
@@ -1492,7 +1527,7 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
       return GC_OK;
     }
   }
-  if (a.in_blocked || a.out_blocked) {  // handover_block() promised a specialised pair of passes for this plan
+  if (a.in_blocked || a.out_blocked || a.row_reps > 1) {  // handover_block() promised a specialised pair of passes for this plan
     gc_set_error("acquisition: no specialised pass kernel for a blocked hand-over (length %d x %d)", a.len, a.nvec);
     return GC_E_STATE;
   }
@@ -1871,6 +1906,18 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     }
   }
   const int hblock = base.wrap_len > 0 ? 0 : handover_block(pl);
+  // shifted spectra on a specialised plan: a workgroup of the rows pass walks several hops of its bin (same rotation, same code
+  // spectrum values, same twiddle tables), as long as the launch keeps ~8 workgroups per CU; GC_ACQ_ROW_REPS overrides (a divisor of H)
+  int row_reps = 1;
+  if (hblock && shifted) {
+    const long long wgs = (long long)(pl.n1 / 10 > 0 ? pl.n1 / 10 : 1) * nbins * H;
+    for (int g = 1; g <= H && g <= 8; ++g)
+      if (H % g == 0 && wgs / g >= 8LL * ctx->compute_units) row_reps = g;
+    if (const char* e = std::getenv("GC_ACQ_ROW_REPS")) {
+      const int g = std::atoi(e);
+      if (g >= 1 && H % g == 0) row_reps = g;
+    }
+  }
   for (int ip = 0; ip < nprn && !fused; ++ip) {
     for (int arm = 0; arm < narms; ++arm) {
       // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
@@ -1894,10 +1941,12 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.out = s->tmp;
       a.out_batch_stride = pl.n;
       a.out_blocked = hblock;  // the intermediate in the columns pass's tile order
-      rc = launch_pass(ctx, a, (long long)nbins * H);
+      a.row_reps = row_reps;
+      rc = launch_pass(ctx, a, (long long)nbins * H / row_reps);
       if (rc) return rc;
       // I2: columns (length n1, stride n2), inverse, |.|/n accumulated over the hops of each bin
       a.out_blocked = 0;
+      a.row_reps = 0;
       a.in_blocked = hblock;
       fill_sub(a, pl.p1);
       a.nvec = pl.n2;
