@@ -106,10 +106,10 @@ for k, (calls, avg, mn) in sorted(ad.items(), key=lambda kv: -kv[1][0] * kv[1][1
     v = c.get("SQ_INSTS_VALU", (None,))[0]
     l = c.get("SQ_INSTS_LDS", (None,))[0]
     b = c.get("SQ_LDS_BANK_CONFLICT", (None,))[0]
-    # elements a launch transforms: one LDS tile (2000 or 1440 elements) per workgroup; the |.|-accumulating pass walks several
-    # hops per workgroup (hop groups), whatever their number a launch covers every (bin, hop) of the search
-    abs_pass = ", 0, 2, true" in k[0]
-    total = 29 * 20 * 36000 if abs_pass else el / 256 * (2000 if "<200" in k[0] else 1440)
+    # elements a launch transforms: one LDS tile (2000 or 1440 elements) per workgroup; the passes of the inverse transform walk
+    # several hops per workgroup, whatever their number a launch covers every (bin, hop) of the search
+    per_prn_pass = ", 0, 2, true" in k[0] or ", 3, 1, true" in k[0]  # the inverse transform's two passes (columns + |.|; shifted rows, several hops per workgroup)
+    total = 29 * 20 * 36000 if per_prn_pass else el / 256 * (2000 if "<200" in k[0] else 1440)
     per = (lambda x: None if x is None else round(x * 64 / total, 1)) if "fft_pass" in k[0] else (lambda x: None)
     lines.append(f"| `{k[0][:70]}` ({k[1]}) | {calls} | {round(avg / 1e3, 1)} | {per(v)} | {per(l)} | {None if not l or b is None else round(b / l, 2)} |")
 open(os.path.join(dst, "digest.md"), "w").write("\n".join(lines) + "\n")
