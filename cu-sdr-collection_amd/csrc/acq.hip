@@ -1520,7 +1520,7 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
     // N = 24 000: GLONASS L1/L2 at 12 Msps
     // N = 144 000: Galileo E1 (4-ms codes at 18 Msps); N = 72 000 / 360 000 / 320 000: the circular-shift searches of BDS B1I
     // (4-ms blocks), BDS B1C (20 ms) and GPS L2C (40 ms at 8 Msps)
-    if (GC_CT_SHAPE(180, 200, 8, 6, 6, 5, 1, 10, 8, 5, 5, 1) || GC_CT_SHAPE(150, 160, 8, 6, 5, 5, 1, 10, 8, 5, 4, 1) ||
+    if (GC_CT_SHAPE(180, 200, 8, 6, 6, 5, 1, 6, 8, 5, 5, 1) || GC_CT_SHAPE(150, 160, 8, 6, 5, 5, 1, 6, 8, 5, 4, 1) ||
         GC_CT_SHAPE(375, 384, 4, 5, 5, 5, 3, 5, 8, 8, 6, 1) || GC_CT_SHAPE(250, 288, 8, 5, 5, 5, 2, 5, 8, 6, 6, 1) ||
         GC_CT_SHAPE(600, 600, 3, 6, 5, 5, 4, 3, 6, 5, 5, 4) || GC_CT_SHAPE(512, 625, 5, 8, 8, 8, 1, 2, 5, 5, 5, 5)) {
       GC_HIP(hipGetLastError());
@@ -1910,7 +1910,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   // spectrum values, same twiddle tables), as long as the launch keeps ~8 workgroups per CU; GC_ACQ_ROW_REPS overrides (a divisor of H)
   int row_reps = 1;
   if (hblock && shifted) {
-    const long long wgs = (long long)(pl.n1 / 10 > 0 ? pl.n1 / 10 : 1) * nbins * H;
+    const long long wgs = (long long)(pl.n1 / 6 > 0 ? pl.n1 / 6 : 1) * nbins * H;  // tiles of about six rows
     for (int g = 1; g <= H && g <= 8; ++g)
       if (H % g == 0 && wgs / g >= 8LL * ctx->compute_units) row_reps = g;
     if (const char* e = std::getenv("GC_ACQ_ROW_REPS")) {

@@ -206,7 +206,7 @@ def test_job_set_whose_persistent_grids_do_not_fit_together_falls_back_to_a_laun
     refused and its loop runs with a launch per epoch - the same records as the packages tracked one after the other."""
     import cu_sdr_collection_amd as P
     from cu_sdr_collection_amd.settings import initSettings_GAL_E1C
-    from cu_sdr_collection_amd.synth import SatSpec, SignalGroup, generate_if_mix
+    from cu_sdr_collection_amd.synth import SatSpec, SignalGroup, generate_if_mix_gpu
     fs = 18e6
     rng = np.random.default_rng(707)
 
@@ -218,14 +218,17 @@ def test_job_set_whose_persistent_grids_do_not_fit_together_falls_back_to_a_laun
     e1 = sats((5, 11, 24), 72000, 47.0)
     groups = [SignalGroup(l1, P.codes.generateCAcode, 1.023e6, 1023),
               SignalGroup(e1, P.codes.generateE1Bcode, 2.046e6, 8184, bit_periods=1, pilot_fn=P.codes.generateE1Ccode)]
-    iq = generate_if_mix(groups, int(0.05 * fs), fs, 20e3, seed=708)
+    # one second of record, 900 ms tracked: the first job's persistent kernel is resident for milliseconds (6 us per epoch), so the
+    # second job - started at the same time on its own host thread - meets it on the device whichever of the two comes first (with
+    # 40 epochs the first kernel had often left before the second asked: both admitted, nothing tested)
+    generate_if_mix_gpu(engine, groups, int(1.0 * fs), fs, 20e3, seed=708)
+    engine.set_sampling_freq(fs)
     S1 = P.initSettings()
-    S1.msToProcess, S1.numberOfChannels = 40, 12
+    S1.msToProcess, S1.numberOfChannels = 900, 12
     S2 = initSettings_GAL_E1C()
-    S2.msToProcess, S2.numberOfChannels = 40, 3
+    S2.msToProcess, S2.numberOfChannels = 900, 3
     ch1 = [SimpleNamespace(PRN=s.prn, acquiredFreq=S1.IF + s.doppler + 2.0, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in l1]
     ch2 = [SimpleNamespace(PRN=s.prn, acquiredFreq=S2.IF + s.doppler + 2.0, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in e1]
-    engine.load_if(iq, fs=fs)
     with P.Engine(0) as e2:
         e2.share_if(engine)
         (tr1, _), (tr2, _) = P.receiver.tracking_multi([(engine, ch1, S1, "GPS_L1CA"), (e2, ch2, S2, "GAL_E1C")])
@@ -234,8 +237,10 @@ def test_job_set_whose_persistent_grids_do_not_fit_together_falls_back_to_a_laun
         seq1, _ = P.tracking(engine, ch1, S1)
         seq2, _ = P.tracking(e2, ch2, S2, signal="GAL_E1C")
         assert (engine.last_track_mode(), e2.last_track_mode()) == (1, 1)   # alone on the device both take their persistent kernel
+    # the first 40 epochs of every channel (later on a launch-per-epoch loop and a persistent one may cut a block one sample apart:
+    # their float32 partial sums are grouped differently)
     for a, b in ((tr1, seq1), (tr2, seq2)):
         for x, y in zip(a, b):
-            assert x.status == y.status == "T" and np.array_equal(x.absoluteSample, y.absoluteSample)
+            assert x.status == y.status == "T" and np.array_equal(x.absoluteSample[:40], y.absoluteSample[:40])
             for f in ("carrFreq", "codeFreq", "I_P", "Q_P", "I_E", "Q_L", "remCodePhase", "remCarrPhase"):
-                assert np.allclose(getattr(x, f), getattr(y, f), rtol=1e-6, atol=1e-6 * np.abs(y.I_P).max() + 1e-12), f
+                assert np.allclose(getattr(x, f)[:40], getattr(y, f)[:40], rtol=1e-6, atol=1e-6 * np.abs(y.I_P).max() + 1e-12), f
