@@ -114,8 +114,11 @@ class Ranks:
         return f"cuda:{self.device}"
 
     def barrier(self):
+        # an all-reduce of a CPU tensor: routed to gloo by the tensor's device whatever the group's other backend is doing
+        # (dist.barrier() on a "cpu:gloo,cuda:nccl" group picks the device itself - the GPU one where it can)
         if self.dist is not None:
-            self.dist.barrier()
+            import torch
+            self.dist.all_reduce(torch.zeros(1, dtype=torch.float64))
 
     def reduce(self, values, op="max"):
         if self.dist is None:
@@ -128,9 +131,20 @@ class Ranks:
     def gather(self, obj):
         if self.dist is None:
             return [obj]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out
+        # pickled bytes in CPU tensors (gloo), not all_gather_object: that one moves its buffers to the group's "current" device,
+        # i.e. through RCCL where a GPU backend exists - the control plane must not depend on the data plane's health
+        import pickle
+        import torch
+        raw = torch.frombuffer(bytearray(pickle.dumps(obj)), dtype=torch.uint8)
+        sizes = torch.zeros(self.world, dtype=torch.int64)
+        sizes[self.rank] = raw.numel()
+        self.dist.all_reduce(sizes)
+        width = int(sizes.max())
+        mine = torch.zeros(width, dtype=torch.uint8)
+        mine[:raw.numel()] = raw
+        parts = [torch.zeros(width, dtype=torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return [pickle.loads(bytes(parts[r][:int(sizes[r])].numpy().tobytes())) for r in range(self.world)]
 
     def turn(self):
         """Context manager around a closed-loop phase: ranks that share one GPU run theirs one after the other (a persistent

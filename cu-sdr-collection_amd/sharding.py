@@ -75,14 +75,21 @@ def broadcast_record(record, src: int = 0, device=None, group=None, via_host: bo
     import torch
     import torch.distributed as dist
     rank = dist.get_rank()
-    meta = [None]
+    meta = torch.zeros(2, dtype=torch.int64)            # a CPU tensor: the group's CPU backend carries it whatever its GPU backend is
     if rank == src:
         if record.dim() != 1 or record.dtype not in (torch.int8, torch.int16):
             raise ValueError("broadcast_record: a 1-D int8 or int16 tensor is expected")
-        meta = [(int(record.numel()), str(record.dtype))]
-    dist.broadcast_object_list(meta, src=src, group=group)
-    n, dt = meta[0]
-    dtype = torch.int8 if dt == "torch.int8" else torch.int16
+        meta[0], meta[1] = int(record.numel()), 1 if record.dtype == torch.int8 else 2
+    try:
+        dist.broadcast(meta, src=src, group=group)
+    except RuntimeError:                                 # a group with a GPU backend only ("nccl"): the same on every member
+        if device is None:
+            raise
+        m = meta.to(device)
+        dist.broadcast(m, src=src, group=group)
+        meta = m.cpu()
+    n = int(meta[0])
+    dtype = torch.int8 if int(meta[1]) == 1 else torch.int16
     wire = "cpu" if (via_host or device is None) else device
     if rank == src:
         home = record if device is None else record.to(device)       # what this rank keeps (no copy when it is there already)
