@@ -218,25 +218,26 @@ def test_job_set_whose_persistent_grids_do_not_fit_together_falls_back_to_a_laun
     e1 = sats((5, 11, 24), 72000, 47.0)
     groups = [SignalGroup(l1, P.codes.generateCAcode, 1.023e6, 1023),
               SignalGroup(e1, P.codes.generateE1Bcode, 2.046e6, 8184, bit_periods=1, pilot_fn=P.codes.generateE1Ccode)]
-    # one second of record, 900 ms tracked: the first job's persistent kernel is resident for milliseconds (6 us per epoch), so the
-    # second job - started at the same time on its own host thread - meets it on the device whichever of the two comes first (with
-    # 40 epochs the first kernel had often left before the second asked: both admitted, nothing tested)
-    generate_if_mix_gpu(engine, groups, int(1.0 * fs), fs, 20e3, seed=708)
+    # four seconds of record, 3.9 s tracked: the first job's persistent kernel is resident for tens of milliseconds (6 us per epoch),
+    # so the second job - started at the same time on its own host thread - meets it on the device whichever of the two comes first
+    # (with 40 epochs the first kernel had often left before the second asked: both admitted, nothing tested).  The sequential runs
+    # come first: they load both persistent kernels' code, which would otherwise be part of the race.
+    generate_if_mix_gpu(engine, groups, int(4.0 * fs), fs, 20e3, seed=708)
     engine.set_sampling_freq(fs)
     S1 = P.initSettings()
-    S1.msToProcess, S1.numberOfChannels = 900, 12
+    S1.msToProcess, S1.numberOfChannels = 3900, 12
     S2 = initSettings_GAL_E1C()
-    S2.msToProcess, S2.numberOfChannels = 900, 3
+    S2.msToProcess, S2.numberOfChannels = 3900, 3
     ch1 = [SimpleNamespace(PRN=s.prn, acquiredFreq=S1.IF + s.doppler + 2.0, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in l1]
     ch2 = [SimpleNamespace(PRN=s.prn, acquiredFreq=S2.IF + s.doppler + 2.0, status="T", codePhase=int(np.ceil(s.code_phase_samples)) + 1) for s in e1]
     with P.Engine(0) as e2:
         e2.share_if(engine)
-        (tr1, _), (tr2, _) = P.receiver.tracking_multi([(engine, ch1, S1, "GPS_L1CA"), (e2, ch2, S2, "GAL_E1C")])
-        modes = (engine.last_track_mode(), e2.last_track_mode())
-        assert sorted(modes) == [0, 1], modes          # one persistent kernel admitted, the other job launched per epoch
         seq1, _ = P.tracking(engine, ch1, S1)
         seq2, _ = P.tracking(e2, ch2, S2, signal="GAL_E1C")
         assert (engine.last_track_mode(), e2.last_track_mode()) == (1, 1)   # alone on the device both take their persistent kernel
+        (tr1, _), (tr2, _) = P.receiver.tracking_multi([(engine, ch1, S1, "GPS_L1CA"), (e2, ch2, S2, "GAL_E1C")])
+        modes = (engine.last_track_mode(), e2.last_track_mode())
+        assert sorted(modes) == [0, 1], modes          # one persistent kernel admitted, the other job launched per epoch
     # the first 40 epochs of every channel (later on a launch-per-epoch loop and a persistent one may cut a block one sample apart:
     # their float32 partial sums are grouped differently)
     for a, b in ((tr1, seq1), (tr2, seq2)):
