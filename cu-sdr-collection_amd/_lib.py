@@ -168,6 +168,7 @@ SYMBOLS = {
     "gc_debug_first_sample_near_edge": (C.c_longlong, [C.c_double, C.c_double, C.c_longlong, C.c_double]),
     "gc_debug_last_kernel": (C.c_int, [_P]),
     "gc_debug_last_track_mode": (C.c_int, [_P]),
+    "gc_debug_wave_transpose_sum": (C.c_int, [_P, C.c_int, _P, _P]),
     "gc_debug_tables_derivable": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "gc_debug_fft": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int]),
 }

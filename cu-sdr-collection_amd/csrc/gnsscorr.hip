@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 
 #include "corr_common.h"
 
@@ -656,6 +657,49 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
 
 extern "C" int gc_debug_last_kernel(const gc_context* ctx) { return ctx ? ctx->last_kernel : -2; }
 extern "C" int gc_debug_last_track_mode(const gc_context* ctx) { return ctx ? ctx->last_track_mode : -1; }
+
+namespace {
+template <int K>
+__global__ __launch_bounds__(64) void wts_debug_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  const int lane = (int)threadIdx.x;
+  float v[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) v[c] = in[c * 64 + lane];
+  const float r = gcorr::wave_transpose_sum<K>(v, lane);
+  const int slot = gcorr::wave_transpose_slot(lane);
+  if (slot < K) out[slot] = r;
+}
+template <int K>
+bool wts_debug_launch(int k, hipStream_t st, const float* in, float* out) {
+  if (k != K) return false;
+  hipLaunchKernelGGL(wts_debug_kernel<K>, dim3(1), dim3(64), 0, st, in, out);
+  return true;
+}
+template <int... Ks>
+bool wts_debug_any(std::integer_sequence<int, Ks...>, int k, hipStream_t st, const float* in, float* out) {
+  return (wts_debug_launch<Ks + 1>(k, st, in, out) || ...);
+}
+}  // namespace
+
+extern "C" int gc_debug_wave_transpose_sum(gc_context* ctx, int k, const float* in, float* out) {
+  if (!ctx || !in || !out || k < 1 || k > 32) {
+    gc_set_error("gc_debug_wave_transpose_sum: bad arguments");
+    return GC_E_INVALID;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  GcBuf& b = ctx->acqbuf[gc_context::ACQ_FINE_OUT];
+  if (gc_buf_reserve(b, (size_t)(k * 64 + 32) * sizeof(float), false) != hipSuccess) {
+    gc_set_error("gc_debug_wave_transpose_sum: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  float* d = (float*)b.p;
+  GC_HIP(hipMemcpyAsync(d, in, (size_t)k * 64 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  wts_debug_any(std::make_integer_sequence<int, 32>{}, k, ctx->stream, d, d + k * 64);
+  GC_HIP(hipGetLastError());
+  GC_HIP(hipMemcpyAsync(out, d + k * 64, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  return GC_OK;
+}
 
 extern "C" long long gc_debug_first_sample_near_edge(double a, double step, long long n, double eps) {
   return gc_first_sample_near_edge(a, step, n, eps);

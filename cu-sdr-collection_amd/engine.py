@@ -168,6 +168,15 @@ class Engine:
         """gc_debug_last_track_mode: 0 a launch per epoch, 1 persistent host-fed kernel, 2 device loop."""
         return int(self._lib.gc_debug_last_track_mode(self._ctx))
 
+    def debug_wave_transpose_sum(self, values: np.ndarray) -> np.ndarray:
+        """gc_debug_wave_transpose_sum: values [k, 64] float32 -> the k wave sums as the lane kernel's flush forms them."""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != 64:
+            raise ValueError("debug_wave_transpose_sum: [k, 64] values")
+        out = np.empty(v.shape[0], dtype=np.float32)
+        L.check(self._lib.gc_debug_wave_transpose_sum(self._ctx, v.shape[0], v.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def replay_prepare(self, blocks):
         self._replay_n = len(blocks)
         L.check(self._lib.gc_replay_prepare(self._ctx, len(blocks), blocks))

@@ -485,6 +485,9 @@ int gc_debug_last_kernel(const gc_context* ctx);
  * resident: next to other contexts' persistent kernels (gc_track_multi) a grid that does not fit the device together with
  * those in flight is refused and the call runs with a launch per epoch instead (same records). */
 int gc_debug_last_track_mode(const gc_context* ctx);
+/* Test hook for the lane kernel's flush (csrc/corr_common.h: wave_transpose_sum): `k` (1..32) vectors of 64 floats, in[v * 64 + lane];
+ * out[v] = the sum over the 64 lanes as the one-wave transposing reduction forms it (the tree's own order of additions). */
+int gc_debug_wave_transpose_sum(gc_context* ctx, int k, const float* in, float* out);
 
 /* Test hook: the library's four-step mixed-radix FFT on `nbatch` host sequences of n complex64
  * values (n of the form 2^a 3^b 5^c); output in natural order, unnormalised. */

@@ -374,3 +374,23 @@ print("BROADCAST_ATTACH_OK")
 """ % (ROOT,)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "BROADCAST_ATTACH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_wave_transpose_sum_adds_every_component_over_the_wave(engine):
+    """The lane kernel empties its 6 x ARMS per-lane sums through ONE transposing reduction (corr_common.h: wave_transpose_sum).
+    Integer-valued floats add exactly in any order: every component's total must be the exact sum of its 64 lanes, for the three
+    sizes the kernel instantiates (6, 12, 18) and for odd, small and full ones (1, 2, 7, 31, 32); general values within float32
+    rounding of a 64-term sum."""
+    rng = np.random.default_rng(91)
+    for k in (1, 2, 6, 7, 12, 18, 31, 32):
+        v = rng.integers(-1000, 1001, size=(k, 64)).astype(np.float32)
+        got = engine.debug_wave_transpose_sum(v)
+        assert np.array_equal(got, v.sum(axis=1, dtype=np.float64).astype(np.float32)), k
+        one = np.zeros((k, 64), np.float32)          # a single non-zero lane per component: nothing lost, nothing doubled
+        one[np.arange(k), rng.integers(0, 64, size=k)] = np.arange(1, k + 1)
+        assert np.array_equal(engine.debug_wave_transpose_sum(one), np.arange(1, k + 1, dtype=np.float32)), k
+        w = rng.standard_normal((k, 64)).astype(np.float32) * 1e3
+        ref = w.astype(np.float64).sum(axis=1)
+        assert np.max(np.abs(engine.debug_wave_transpose_sum(w) - ref)) <= 64 * 2.0 ** -24 * np.abs(w).sum(axis=1).max(), k
+    with pytest.raises(Exception):
+        engine.debug_wave_transpose_sum(np.zeros((33, 64), np.float32))
