@@ -44,24 +44,26 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH
 METRIC = "IF Msamples/s through tracking correlators; x real-time @ 12-ch GPS L1 C/A"
 
 
-def _spawn_ranks(n: int) -> int:
-    """`python bench.py --gpus N` without torch.distributed.run: start N copies of this script, one rank per GPU
-    (LOCAL_RANK selects the device; GC_BENCH_DEVICE pins every rank to one device on a 1-GPU box), rendezvous on
-    127.0.0.1.  Rank 0 prints the result line; the other ranks' stdout goes to stderr."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+def _error_line(n: int, steps: int, warmup: int, error: str, **extra) -> str:
+    """The ONE JSON line of a run that did not finish: same keys as a result line, value null, `error` says why."""
+    return json.dumps({"metric": METRIC, "value": None, "unit": "IF Msamples/s", "n_gpus": n, "steps": steps, "warmup": warmup, "ms_per_step": None,
+                       "higher_is_better": True, "error": error, **extra})
+
+
+def _spawn_ranks(n: int, steps: int, warmup: int) -> int:
+    """`python bench.py --gpus N` without torch.distributed.run: one rank per GPU through sharding.launch_ranks (LOCAL_RANK selects
+    the device; GC_BENCH_DEVICE pins every rank to one device on a 1-GPU box), rendezvous on 127.0.0.1.  Rank 0 prints the result
+    line; every rank's stderr arrives prefixed with its rank.  A rank that dies takes the others with it and the run still ends
+    with ONE JSON line (`error`, the failing rank, its stderr tail) - a first 8-GPU run cannot hang without a line."""
+    from cu_sdr_collection_amd.sharding import launch_ranks
+    out = launch_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], n,
+                       rendezvous_timeout_s=float(os.environ.get("GC_RENDEZVOUS_TIMEOUT_S", "240")),
+                       total_timeout_s=float(os.environ["GC_BENCH_TIMEOUT_S"]) if "GC_BENCH_TIMEOUT_S" in os.environ else None)
+    if out["rc"] != 0:
+        r = out["failed_rank"]
+        print(_error_line(n, steps, warmup, out["reason"], failed_rank=r, stderr_tail=out["stderr_tail"].get(r, [])[-12:],
+                          seconds=round(out["seconds"], 1)), flush=True)
+    return out["rc"]
 
 
 class Ranks:
@@ -84,7 +86,10 @@ class Ranks:
                 torch.cuda.init()
                 if not self.shared_device and os.environ.get("GC_BENCH_BACKEND", "rccl") != "gloo":
                     backend, self.rccl = "cpu:gloo,cuda:nccl", True
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            import datetime
+            # a rank that never arrives (died at gc_create, wrong device) must not hold the others for torch's default 10-30 minutes
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=float(os.environ.get("GC_RENDEZVOUS_TIMEOUT_S", "240"))))
             self.dist = dist
             self.rccl_error = None
             if self.rccl:      # one small all-reduce over RCCL before anything depends on it; every rank learns whether ALL of them got through
@@ -101,6 +106,12 @@ class Ranks:
                 if float(flag[0]) < 1.0:
                     self.rccl = False
                     self.rccl_error = self.rccl_error or "another rank's RCCL probe failed"
+
+    def probe(self):
+        """What this rank saw of the node: its device, how many devices its process can see, and how its RCCL probe went."""
+        import torch
+        return {"device": self.device, "n_devices_seen": int(torch.cuda.device_count()) if torch.cuda.is_available() else 0,
+                "rccl_probe": "ok" if self.rccl else ("not attempted (ranks share one GPU)" if self.shared_device else f"failed: {getattr(self, 'rccl_error', None)}")}
 
     @property
     def data_backend(self):
@@ -396,7 +407,7 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
         result["handover"] = handover
     if R.world > 1:
         lock = R.gather({"rank": R.rank, "channels_locked": int(locked.sum()), "prns": [s.prn for s in sats], "replay_vs_closed_loop_max_dev": replay_dev,
-                         "kernel_ms": round(kernel_ms, 4), "frac": round(achieved / HBM_PEAK_GBPS, 4)})
+                         "kernel_ms": round(kernel_ms, 4), "frac": round(achieved / HBM_PEAK_GBPS, 4), **R.probe()})
         result["ranks"] = lock
     return result, dict(eng=eng, S=S, sats=sats, scene=scene, inits=inits, fields=fields, n_epochs=n_epochs, n_samples=n_samples, job=job, record=rec_t)
 
@@ -813,7 +824,7 @@ def main() -> None:
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(_spawn_ranks(args.gpus))     # no external launcher: one process per GPU, started here
+        raise SystemExit(_spawn_ranks(args.gpus, args.steps, args.warmup))     # no external launcher: one process per GPU, started here
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -822,6 +833,16 @@ def main() -> None:
                          "they must agree (n_gpus in the result line is the number of ranks that ran)")
     # one GPU per rank; GC_BENCH_DEVICE pins every rank to one device (functional test of the N > 1 path on a 1-GPU box)
     device = int(os.environ.get("GC_BENCH_DEVICE", local_rank))
+    if rank == 0 and world > 1 and "GC_RANK_LAUNCHER" not in os.environ:       # (launch_ranks prints the error line itself)
+        # torch.distributed.run (and sharding.launch_ranks) terminate the surviving ranks when one dies: rank 0 still owes the
+        # caller ONE JSON line, and says in it that it was stopped from outside
+        import signal
+
+        def _terminated(signum, frame):
+            print(_error_line(world, args.steps, args.warmup, f"rank 0 received signal {signum} from the launcher before the result line "
+                              "(another rank failed or the launcher timed out)"), flush=True)
+            os._exit(143)
+        signal.signal(signal.SIGTERM, _terminated)
     R = Ranks(rank, world, device)
     config = args.config or ("all" if world == 1 else "l1ca")
 

@@ -687,10 +687,14 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
         sl[c].sent = now0;
         ++outstanding;
       }
-      unsigned int idle = 0;
-      auto stamp = now0;  // refreshed while idle: a descriptor's time of sending, to the precision the timeout needs
+      unsigned int idle = 0, turns = 0;
+      // a descriptor's time of sending, to the precision the timeout needs: refreshed every 256 turns of the poll loop WHETHER OR NOT
+      // records arrived (a stamp refreshed only while idle stays at now0 for a whole busy run, and the first stall after
+      // poll_timeout_ms of wall time would then read as a lost epoch), and again whenever the loop has been idle for 1024 turns
+      auto stamp = now0;
       while (outstanding > 0 && !lost.load(std::memory_order_relaxed)) {
         bool progress = false;
+        if ((++turns & 255u) == 0) stamp = std::chrono::steady_clock::now();
         for (int c = c0; c < c1; ++c) {
           if (!sl[c].waiting) continue;
           const unsigned int tag = (unsigned int)sl[c].ep + 1u;

@@ -135,3 +135,82 @@ def distribute_band_records(plan, read_record, device=None, via_host: bool = Fal
             if timings is not None:
                 timings[band] = (time.perf_counter() - t0, int(out[band].numel()) * out[band].element_size())
     return out
+
+
+def launch_ranks(argv, n: int, env_extra=None, rendezvous_timeout_s: float = 240.0, grace_s: float = 5.0, total_timeout_s: float | None = None,
+                 on_line=None) -> dict:
+    """One process per GPU without an external launcher, unable to hang: starts `argv` n times (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT set, GC_RENDEZVOUS_TIMEOUT_S = the init_process_group timeout the ranks should use), polls
+    ALL children, and on the first non-zero exit (or when `total_timeout_s` passes) terminates the rest - a rank that dies at
+    gc_create / init_process_group would otherwise leave the others inside a collective until its timeout.  Rank 0's stdout is this
+    process's stdout (the result line), every rank's stderr (and the other ranks' stdout) is relayed line by line with a
+    "[rank r] " prefix and its tail kept.
+    Returns {"rc": 0 | the failing rank's code, "failed_rank": r | None, "reason": str | None, "stderr_tail": {rank: last lines},
+    "seconds": wall time}."""
+    import collections
+    import os
+    import socket
+    import subprocess
+    import sys
+    import threading
+    import time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tails = {r: collections.deque(maxlen=30) for r in range(n)}
+    procs, pumps = [], []
+
+    def pump(r, stream):
+        for raw in iter(stream.readline, b""):
+            line = raw.decode("utf-8", "replace").rstrip("\n")
+            tails[r].append(line)
+            if on_line is not None:
+                on_line(r, line)
+            else:
+                print(f"[rank {r}] {line}", file=sys.stderr, flush=True)
+        stream.close()
+
+    t0 = time.time()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GC_RENDEZVOUS_TIMEOUT_S=str(int(rendezvous_timeout_s)), GC_RANK_LAUNCHER="launch_ranks", **(env_extra or {}))
+        p = subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        procs.append(p)
+        for stream in ([p.stderr] if r == 0 else [p.stderr, p.stdout]):
+            th = threading.Thread(target=pump, args=(r, stream), daemon=True)
+            th.start()
+            pumps.append(th)
+    failed, reason, rc = None, None, 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and failed is None:
+                failed, rc, reason = r, (code if code > 0 else 128 - code), f"rank {r} exited with code {code}"
+        if failed is None and total_timeout_s is not None and time.time() - t0 > total_timeout_s and alive:
+            failed, rc, reason = min(alive), 124, f"no result after {total_timeout_s:.0f} s"
+        if failed is not None and alive:
+            for r in alive:                                   # the survivors sit in a collective that will never complete
+                try:
+                    os.killpg(procs[r].pid, 15)               # each child is its own session: exact process group, no pattern
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t1 = time.time()
+            while any(procs[r].poll() is None for r in alive) and time.time() - t1 < grace_s:
+                time.sleep(0.05)
+            for r in alive:
+                if procs[r].poll() is None:
+                    try:
+                        os.killpg(procs[r].pid, 9)
+                    except (ProcessLookupError, PermissionError):
+                        pass
+                procs[r].wait()
+            alive.clear()
+        if alive:
+            time.sleep(0.05)
+    for th in pumps:
+        th.join(timeout=2.0)
+    return {"rc": rc, "failed_rank": failed, "reason": reason, "stderr_tail": {r: list(t) for r, t in tails.items()}, "seconds": time.time() - t0}

@@ -36,8 +36,14 @@ def _set(Sm, overrides):
     return Sm
 
 
-def gen_acq(only=None):
-    for sc in RS.ACQ_SCENES:
+def gen_acq_default(only=None):
+    """The reference's default searches (RS.DEFAULT_ACQ_SCENES: initSettings() unmodified) - minutes each, run them side by side:
+    for n in ...; do python tests/golden/make_ref_vectors.py acq_default --only $n & done"""
+    gen_acq(only, RS.DEFAULT_ACQ_SCENES)
+
+
+def gen_acq(only=None, scenes=None):
+    for sc in (RS.ACQ_SCENES if scenes is None else scenes):
         if only and only != sc.name:
             continue
         t0 = time.time()
@@ -48,7 +54,7 @@ def gen_acq(only=None):
         long_signal = (x[0::2] + 1j * x[1::2]).reshape(1, -1)          # postProcessing.m:92-96: data1 + 1i .* data2
         acq = mlab.from_matlab(I.call("acquisition", long_signal, Sm))
         out = {"record_crc32": np.array([RS.crc(rec)], dtype=np.uint32), "overrides": np.array(json.dumps(sc.overrides)), "pkg": np.array(sc.pkg),
-               "stdout": np.array("".join(I.out)[-1000:])}
+               "stdout": np.array("".join(I.out)[-1000:]), "seconds": np.array([time.time() - t0])}
         for f in vars(acq):
             v = getattr(acq, f)
             if isinstance(v, (np.ndarray, float)):

@@ -121,3 +121,65 @@ def test_gloo_band_plan_end_to_end():
     for recs in (recs0, recs1):
         for b, v in recs.items():
             assert v == expect(b)
+
+
+_RANK_SCRIPT = r'''
+import datetime, os, sys, time
+import torch
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = sys.argv[1]
+if mode == "die_before_rendezvous" and rank == 1:
+    print("rank 1: gc_create failed (simulated)", file=sys.stderr, flush=True)
+    sys.exit(7)
+dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ["GC_RENDEZVOUS_TIMEOUT_S"])))
+if mode == "die_in_collective" and rank == 1:
+    print("rank 1: out of memory (simulated)", file=sys.stderr, flush=True)
+    os._exit(9)
+x = torch.ones(1)
+if mode != "ok":
+    time.sleep(0.5)
+dist.all_reduce(x)            # rank 0 would wait here for the default timeout if nobody stopped it
+if rank == 0:
+    print('{"value": %d}' % int(x[0]), flush=True)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode", ["die_before_rendezvous", "die_in_collective"])
+def test_launcher_ends_with_the_failing_ranks_report_when_a_rank_dies(mode, tmp_path):
+    """bench.py --gpus N starts its ranks through sharding.launch_ranks: a rank that dies (before the rendezvous, or while the
+    others sit in a collective) takes the rest down within seconds, and the caller learns which rank, its exit code and the
+    tail of its stderr - instead of a hang until gloo's timeout with no result line."""
+    import time
+    sys.path.insert(0, ROOT)
+    from cu_sdr_collection_amd.sharding import launch_ranks
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    lines = []
+    t0 = time.time()
+    out = launch_ranks([sys.executable, str(script), mode], 2, rendezvous_timeout_s=120.0, on_line=lambda r, l: lines.append((r, l)))
+    took = time.time() - t0
+    assert took < 60.0, took                                     # far below the 120-s rendezvous / collective timeout
+    assert out["failed_rank"] == 1 and out["rc"] in (7, 9)
+    assert "simulated" in " ".join(out["stderr_tail"][1])
+    assert any(r == 1 and "simulated" in l for r, l in lines)     # relayed with the rank it came from
+
+
+def test_launcher_returns_zero_and_rank_zero_prints_when_all_ranks_finish(tmp_path, capfd):
+    sys.path.insert(0, ROOT)
+    from cu_sdr_collection_amd.sharding import launch_ranks
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    out = launch_ranks([sys.executable, str(script), "ok"], 2, rendezvous_timeout_s=120.0)
+    assert out["rc"] == 0 and out["failed_rank"] is None
+    assert '{"value": 2}' in capfd.readouterr().out
+
+
+def test_launcher_total_timeout_stops_ranks_that_never_finish(tmp_path):
+    sys.path.insert(0, ROOT)
+    from cu_sdr_collection_amd.sharding import launch_ranks
+    script = tmp_path / "sleep.py"
+    script.write_text("import time\ntime.sleep(600)\n")
+    out = launch_ranks([sys.executable, str(script)], 2, total_timeout_s=2.0, grace_s=1.0, on_line=lambda r, l: None)
+    assert out["rc"] == 124 and out["seconds"] < 30.0 and "no result" in out["reason"]
