@@ -460,6 +460,58 @@ def run_acquisition(P, eng, sats, R: Ranks):
             "sharding": f"PRN list round-robin over {R.world} rank(s)"}
 
 
+def run_acquisition_packages(P, device, only=None):
+    """acquisition.m of all twelve packages at the reference's DEFAULT search sizes (settings = initSettings() unmodified), each on
+    the record of its committed fixture tests/golden/ref_acq_<pkg>_default.npz (the reference's own acquisition.m executed on that
+    record by oracle/mlab, minutes per package): codePhase / carrFreq must be array_equal to the fixture - the search that is timed
+    is the search that is checked.  Per package: wall and hipEvent milliseconds of one whole call (searches + fine stage + the host
+    steps between them), the transforms it stands for (signal spectra hoisted: forward = bins x hops, one per code, one inverse
+    per PRN x arm x bin x hop), the transform length, and the algorithmic flops (5 N log2 N per transform + 10 N per inverse for
+    product, |.| and accumulation) against the f32 vector peak."""
+    import math
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_scenes as RS
+    out = {}
+    for sc in RS.DEFAULT_ACQ_SCENES:
+        name = sc.name[:-len("_default")]
+        if only and name not in only:
+            continue
+        path = os.path.join(ROOT, "tests", "golden", f"ref_acq_{sc.name}.npz")
+        if not os.path.exists(path):
+            out[name] = {"error": "no fixture"}
+            continue
+        z = np.load(path)
+        S, rec = RS.acq_inputs(P, sc)
+        if RS.crc(rec) != int(z["record_crc32"][0]):
+            out[name] = {"error": "the rebuilt record is not the fixture's"}
+            continue
+        with P.Engine(device) as eng:
+            eng.load_if(rec, fs=S.samplingFreq)
+            sc.product(P, eng, S)                      # first use: plans, twiddles, scratch, code tables
+            eng.synchronize()
+            eng.acq_stats.clear()
+            t0 = time.perf_counter()
+            eng.timer_start()
+            got = sc.product(P, eng, S)
+            ev_ms = eng.timer_stop()
+            wall = time.perf_counter() - t0
+            st = dict(eng.acq_stats)
+        same = {f: bool(np.array_equal(np.asarray(getattr(got, f), dtype=np.float64), z["f_" + f])) for f in sc.fields if f != "peakMetric"}
+        want = z["f_peakMetric"]
+        metric_dev = float(np.max(np.abs(np.asarray(got.peakMetric, dtype=np.float64) - want)) / np.max(np.abs(want)))
+        n = st.get("n_fft", 0)
+        nt = st.get("forward", 0) + st.get("code", 0) + st.get("inverse", 0)
+        flops = nt * 5.0 * n * math.log2(max(n, 2)) + st.get("inverse", 0) * 10.0 * n
+        out[name] = {"ms": round(wall * 1e3, 3), "event_ms": round(ev_ms, 3), "fft_size": n, "transforms": nt, "inverse_transforms": st.get("inverse", 0),
+                     "prns": len(list(S.acqSatelliteList)), "detected": int(np.count_nonzero(z["f_carrFreq"])),
+                     "equal_to_the_references_acquisition_m": same, "peak_metric_max_rel_dev": round(metric_dev, 7),
+                     "ms_per_prn": round(wall * 1e3 / max(1, len(list(S.acqSatelliteList))), 4),
+                     "reference_interpreter_seconds": round(float(z["seconds"][0]), 1) if "seconds" in z.files else None,
+                     "roofline": {"compute": {"bound": "valu f32", "achieved": round(flops / (ev_ms * 1e-3) / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
+                                              "frac": round(flops / (ev_ms * 1e-3) / 1e12 / 157.3, 4), "algorithmic_flops": flops}}}
+    return out
+
+
 # =======================================================================================================================
 # the other BASELINE configs: a band record, one job per package, closed loops + replay
 # =======================================================================================================================
@@ -817,6 +869,7 @@ def main() -> None:
     ap.add_argument("--numpy-epochs", type=int, default=250, help="epochs per channel of the NumPy CPU variant (~5 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-int16", action="store_true")
+    ap.add_argument("--no-acq-packages", action="store_true", help="skip acquisition.packages (the twelve default-size searches checked against their fixtures)")
     ap.add_argument("--no-handover", action="store_true", help="N > 1: every rank synthesises its own copy of the record(s) instead of receiving them from the source rank (A/B of the exchange step)")
     ap.add_argument("--spot-check", action="store_true", help="--config mix: every rank checks a few replayed blocks of each of its jobs against the float64 oracle (CPU)")
     args = ap.parse_args()
@@ -858,6 +911,8 @@ def main() -> None:
 
     result, main_ctx = run_l1ca(P, W, args, R, device)
     result["acquisition"] = run_acquisition(P, main_ctx["eng"], main_ctx["scene"], R)
+    if rank == 0 and config == "all" and not args.no_acq_packages:
+        result["acquisition"]["packages"] = run_acquisition_packages(P, device)
     extra_jobs = {}
     if config == "all" and world == 1:
         cfgs = {}

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -17,6 +18,7 @@ class Engine:
         self._ctx = C.c_void_p()
         L.check(self._lib.gc_create(C.byref(self._ctx), int(device_id)))
         self.device_id = device_id
+        self.acq_stats = {}          # transforms of the searches since the caller last cleared it (_count_transforms)
 
     # ---- lifetime ------------------------------------------------------------------------
     def close(self):
@@ -316,6 +318,9 @@ class Engine:
         codes = np.ascontiguousarray(sampled_codes, dtype=np.int8)
         nprn = codes.shape[0]
         narms = codes.shape[1] if codes.ndim == 3 else 1
+        n = int(params.block_len) if params.block_len else 2 * codes.shape[-1]
+        bins = int(params.n_bins) if params.n_bins else int(math.floor(params.search_band * 2 / params.search_step + 0.5)) + 1
+        self._count_transforms(n, forward=bins * int(params.non_coh_time), code=nprn * narms, inverse=nprn * narms * bins * int(params.non_coh_time))
         res = (L.gc_acq_result * nprn)()
         L.check(self._lib.gc_acquire_coarse_multi(self._ctx, C.byref(params), nprn, narms,
                                                   codes.ctypes.data_as(C.c_void_p), res))
@@ -368,7 +373,17 @@ class Engine:
         L.check(self._lib.gc_acq_signal_stats(self._ctx, int(first_sample), int(n), int(source), C.byref(mr), C.byref(mi), C.byref(v)))
         return complex(mr.value, mi.value), v.value
 
+    def _count_transforms(self, n: int, forward: int = 0, code: int = 0, inverse: int = 0):
+        """Bookkeeping for bench.py (acq_stats): the transforms the SEARCH needs once the signal spectra are hoisted out of the PRN
+        loop (acquisition.m:167-192 recomputes them per PRN) - n-point forward transforms of the signal, of the sampled codes,
+        and inverse transforms, since the last reset.  Counts only; nothing on the device depends on it."""
+        st = self.acq_stats
+        st["n_fft"] = max(st.get("n_fft", 0), int(n))
+        for k, v in (("forward", forward), ("code", code), ("inverse", inverse)):
+            st[k] = st.get(k, 0) + int(v)
+
     def acq_shift_prepare(self, params: L.gc_acq_shift_params):
+        self._count_transforms(int(params.n), forward=int(params.n_signals) * int(params.n_carriers))
         self._shift = params
         L.check(self._lib.gc_acq_shift_prepare(self._ctx, C.byref(params)))
 
@@ -377,6 +392,7 @@ class Engine:
         p = self._shift
         c8 = np.ascontiguousarray(codes, dtype=np.int8).reshape(-1, p.n)
         rows = p.n_carriers * p.n_signals * p.n_bins
+        self._count_transforms(int(p.n), code=c8.shape[0], inverse=c8.shape[0] * rows)
         rmax = np.empty(rows, dtype=np.float32)
         rarg = np.empty(rows, dtype=np.int32)
         w = None

@@ -147,6 +147,50 @@ def test_hip_acquisition_equals_the_references_acquisition_m(engine, sc):
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
 
 
+def _compare_acq(sc, z, got):
+    for f in sc.fields:
+        want = z["f_" + f]
+        have = np.asarray(getattr(got, f), dtype=np.float64)
+        assert have.shape == want.shape, (sc.name, f, have.shape, want.shape)
+        if f == "peakMetric":
+            assert np.max(np.abs(have - want)) <= sc.metric_rtol * np.max(np.abs(want)), (sc.name, np.max(np.abs(have - want)) / np.max(np.abs(want)))
+        else:
+            assert np.array_equal(have, want), (sc.name, f, np.flatnonzero(have != want), have[have != want], want[have != want])
+
+
+@pytest.mark.parametrize("sc", RS.DEFAULT_ACQ_SCENES, ids=[s.name for s in RS.DEFAULT_ACQ_SCENES])
+def test_hip_acquisition_at_the_references_default_search_sizes(engine, sc):
+    """settings = initSettings() UNMODIFIED - the searches the packages ship with: GPS L1 C/A 32 PRNs x 29 bins x 20 hops
+    (GPS_L1CA/initSettings.m:80-89), L5 25 hops, Galileo E5b 168 bins of 60 Hz x 15 hops x 36 PRNs, E1 94 bins x 144 000 points, BDS B3I
+    63 PRNs, B1C 62 PRNs x 201 bins x 360 000 points, L2C 401 bins x 2 sub-bin shifts x 320 000 points, B1I 53 PRNs, GLONASS K = -7..6.
+    The fixtures are the reference's own acquisition.m executed on the scene's record (oracle/mlab, minutes each, made once:
+    tests/golden/make_ref_vectors.py acq_default); codePhase and carrFreq (coarse bin + fine stage) must be IDENTICAL
+    (north_star: "acquired code-phase sample indices bit-exact"), the peak metric within the float32 transforms' 2e-3 - at the depth
+    the hop groups, slot reductions and shifted spectra actually run at."""
+    import cu_sdr_collection_amd as P
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    assert sc.overrides == {} and RS.crc(rec) == int(z["record_crc32"][0])
+    engine.load_if(rec, fs=S.samplingFreq)
+    got = sc.product(P, engine, S)
+    _compare_acq(sc, z, got)
+    assert np.count_nonzero(z["f_carrFreq"]) >= 2
+
+
+_ACQ_FUSED_DEFAULT = ("GPS_L1CA_default", "GPS_L5C_default", "GAL_E5a_default", "BDS_B2a_default", "BDS_B3I_default", "GLO_GL1_default", "GLO_GL2_default")
+
+
+@pytest.mark.parametrize("sc", [s for s in RS.DEFAULT_ACQ_SCENES if s.name in _ACQ_FUSED_DEFAULT], ids=[s.name for s in RS.DEFAULT_ACQ_SCENES if s.name in _ACQ_FUSED_DEFAULT])
+def test_fused_inverse_transform_kernel_at_the_references_default_search_sizes(engine, sc, monkeypatch):
+    """GC_ACQ_FUSED=1 (the single-launch inverse side) on the same default-size searches."""
+    import cu_sdr_collection_amd as P
+    monkeypatch.setenv("GC_ACQ_FUSED", "1")
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    engine.load_if(rec, fs=S.samplingFreq)
+    _compare_acq(sc, z, sc.product(P, engine, S))
+
+
 _ACQ_FUSED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "GAL_E5b", "BDS_B2a", "BDS_B3I", "GLO_GL1")   # searches of 36 000 / 24 000 points
 
 

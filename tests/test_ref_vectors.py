@@ -242,6 +242,27 @@ def test_oracle_acquisition_equals_the_references_acquisition_m(sc):
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
 
 
+@pytest.mark.parametrize("sc", RS.DEFAULT_ACQ_SCENES, ids=[s.name for s in RS.DEFAULT_ACQ_SCENES])
+def test_default_size_acquisition_fixtures_belong_to_their_scenes(sc):
+    """The default-search fixtures (initSettings() unmodified; minutes of the interpreter each, so the oracle is not re-run here):
+    the record the tests rebuild is the one the reference's acquisition.m was executed on, the result vectors have the package's
+    length, every satellite of the scene that the reference detected sits at a plausible place, and the search really was the
+    default one (no overrides stored)."""
+    import json
+    import cu_sdr_collection_amd as P
+    z = _load(f"ref_acq_{sc.name}.npz")
+    S, rec = RS.acq_inputs(P, sc)
+    assert RS.crc(rec) == int(z["record_crc32"][0])
+    assert json.loads(str(z["overrides"])) == {} and str(z["pkg"]) == sc.pkg
+    n = {z["f_" + f].shape[0] for f in sc.fields}
+    assert len(n) == 1
+    det = np.flatnonzero(z["f_carrFreq"])
+    assert det.shape[0] >= 2
+    assert np.all(z["f_codePhase"][det] >= 1) and np.all(z["f_codePhase"][det] == np.rint(z["f_codePhase"][det]))
+    thr = float(S.acqThreshold)
+    assert np.all(z["f_peakMetric"][det] > thr) and np.all(z["f_peakMetric"][np.setdiff1d(np.arange(n.pop()), det)] <= thr)
+
+
 @pytest.mark.parametrize("sc", RS.NAVSYNC_SCENES, ids=[s.name for s in RS.NAVSYNC_SCENES])
 def test_oracle_bit_sync_equals_the_references_navdecoding_m(sc):
     """the synchronisation block of every package's NAVdecoding.m, executed in place by oracle/mlab
