@@ -6,6 +6,7 @@ acquisition.m).  Coarse search and the per-code sums of the fine stage run on th
 gc_acquire_fine_sums); the hypothesis search over 20-100 complex numbers per bin is restated here."""
 from __future__ import annotations
 
+import functools
 import math
 from types import SimpleNamespace
 
@@ -24,30 +25,51 @@ def _round(x: float) -> int:
 
 def make_table(code: np.ndarray, settings) -> np.ndarray:
     """makeL5ITable.m / makeE5aITable.m / makeB2aDataTable.m: code(ceil(ts*(1:spc)/tc)), last index = codeLength."""
-    spc = _round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength))
-    idx = np.ceil((1.0 / settings.samplingFreq) * np.arange(1, spc + 1) / (1.0 / settings.codeFreqBasis)).astype(np.int64)
-    idx[-1] = int(settings.codeLength)
-    return code[idx - 1]
+    return code[_table_index(float(settings.samplingFreq), float(settings.codeFreqBasis), int(settings.codeLength), False)]
+
+
+@functools.lru_cache(maxsize=32)
+def _table_index(fs: float, fc: float, code_length: int, boc: bool) -> np.ndarray:
+    """codeValueIndex of the make*Table.m files (0-based), the same for every PRN and arm of a front end: kept per (fs, fc, L)."""
+    spc = _round(fs / (fc / code_length))
+    if boc:
+        idx = np.ceil((1.0 / fs) * np.arange(1, spc + 1) / (1.0 / fc / 2)).astype(np.int64)
+        idx[-1] = code_length * 2
+        idx[0] = 1
+    else:
+        idx = np.ceil((1.0 / fs) * np.arange(1, spc + 1) / (1.0 / fc)).astype(np.int64)
+        idx[-1] = code_length
+    idx -= 1
+    idx.setflags(write=False)
+    return idx
+
+
+@functools.lru_cache(maxsize=64)
+def _rolled(sec_bytes: bytes, n: int) -> np.ndarray:
+    """Row k = circshift(sec, k): the secondary code at every circular shift, built once per code."""
+    sec = np.frombuffer(sec_bytes, dtype=np.float64, count=n)
+    m = np.stack([np.roll(sec, k) for k in range(n)])
+    m.setflags(write=False)
+    return m
 
 
 def _circular_code_search(sums: np.ndarray, sec: np.ndarray) -> float:
-    """max over the len(sec) circular shifts of |sum(sumPerCode .* circshift(sec, k))| (GPS_L5C acquisition.m:243-248)."""
-    best = 0.0
-    s = sec.copy()
-    for _ in range(sec.shape[0]):
-        best = max(best, abs(np.sum(sums * s)))
-        s = np.roll(s, 1)
-    return best
+    """max over the len(sec) circular shifts of |sum(sumPerCode .* circshift(sec, k))| (GPS_L5C acquisition.m:243-248); all shifts
+    in one product with the rolled-code matrix (the loop of 100 np.roll per fine bin was 0.27 of Galileo E5a's 0.28 s per search)."""
+    sec = np.ascontiguousarray(sec, dtype=np.float64)
+    return float(np.max(np.abs(_rolled(sec.tobytes(), sec.shape[0]) @ sums)))
 
 
 def _split_code_search(sums: np.ndarray, sec: np.ndarray) -> float:
     """GAL_E1C acquisition.m:237-245 / BDS B3I acquisition.m:262-270: the secondary code aligned, then every
     circular shift k = 1..len-1 with the sum SPLIT at the possible data-bit edge: |sum(1:k)| + |sum(k+1:end)|."""
-    best = abs(np.sum(sums * sec))
-    for k in range(1, sec.shape[0]):
-        t = sums * np.roll(sec, k)
-        best = max(best, abs(np.sum(t[:k])) + abs(np.sum(t[k:])))
-    return best
+    sec = np.ascontiguousarray(sec, dtype=np.float64)
+    n = sec.shape[0]
+    cs = np.cumsum(_rolled(sec.tobytes(), n) * sums[None, :], axis=1)          # cs[k, j] = sum(t_k[:j + 1])
+    total = cs[:, -1]
+    k = np.arange(1, n)
+    head = cs[k, k - 1]
+    return float(max(abs(total[0]), np.max(np.abs(head) + np.abs(total[1:] - head))))
 
 
 def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, fine_step, combine, n_results=32,
@@ -177,11 +199,7 @@ E1C_SECONDARY = np.array([1, 1, -1, -1, -1, 1, 1, 1, 1, 1, 1, 1, -1, 1, -1, 1, -
 
 def _make_boc_table(code: np.ndarray, settings) -> np.ndarray:
     """makeE1BTable.m:43-55: half-chip code sampled at ceil(ts*(1:spc)/(tc/2)), first index forced to 1, last to 2L."""
-    spc = _round(settings.samplingFreq / (settings.codeFreqBasis / settings.codeLength))
-    idx = np.ceil((1.0 / settings.samplingFreq) * np.arange(1, spc + 1) / (1.0 / settings.codeFreqBasis / 2)).astype(np.int64)
-    idx[-1] = int(settings.codeLength) * 2
-    idx[0] = 1
-    return code[idx - 1]
+    return code[_table_index(float(settings.samplingFreq), float(settings.codeFreqBasis), int(settings.codeLength), True)]
 
 
 def acquisition_E1C(engine, settings, first_sample: int | None = None, n_long: int | None = None):

@@ -5,9 +5,28 @@ Independent bit-level implementations (integer LFSRs) of what the reference comp
 """
 from __future__ import annotations
 
+import functools
 import math
 
 import numpy as np
+
+
+def _kept(fn):
+    """The codes are constants of the signal: each (generator, arguments) is computed once per process and handed out as a fresh
+    copy (GPS L5 / Galileo E5 / BDS B2a / B3I registers cost 9-18 ms per PRN in Python, the 767 250-chip L2 CL code 285 ms - the
+    default searches of those packages spent 0.2-0.5 s generating codes around ~10 ms of GPU work)."""
+    store = {}
+
+    @functools.wraps(fn)
+    def wrapper(*args):
+        key = tuple(int(a) if isinstance(a, (int, np.integer, float)) and float(a) == int(a) else a for a in args)
+        code = store.get(key)
+        if code is None:
+            code = store[key] = fn(*args)
+            code.setflags(write=False)
+        return code.copy()
+    wrapper.__wrapped__ = fn
+    return wrapper
 
 # G2 code delays in chips for PRN 1..32 (IS-GPS-200 Table 3-Ia) followed by the SBAS delays the
 # reference also carries (generateCAcode.m:42-50).
@@ -119,16 +138,19 @@ def _boc11(bits: np.ndarray) -> np.ndarray:
     return np.stack([chips, -chips], axis=1).reshape(-1)         # sub-carrier [+1, -1] (:59-65)
 
 
+@_kept
 def generateE1Bcode(PRN: int) -> np.ndarray:
     """E1-B data code with BOC(1,1): 8184 half-chips, int8 +-1."""
     return _boc11(_e1_primary("E1b", PRN))
 
 
+@_kept
 def generateE1Ccode(PRN: int) -> np.ndarray:
     """E1-C pilot primary code with BOC(1,1): 8184 half-chips, int8 +-1."""
     return _boc11(_e1_primary("E1c", PRN))
 
 
+@_kept
 def generateE1C_BOC61(PRN: int) -> np.ndarray:
     """E1-C pilot primary code with the BOC(6,1) subcarrier of CBOC(6,1,1/11): 49104 entries (12 per chip), chip x
     [+1, -1] x 6 - same subcarrier phase convention as the BOC(1,1) table above (generateE1Bcode.m:59-65)."""
@@ -182,11 +204,13 @@ def _l5(PRN: int, adv) -> np.ndarray:
     return (1 - 2 * (_XA ^ xb).astype(np.int8)).astype(np.int8)
 
 
+@_kept
 def generateL5Icode(PRN: int) -> np.ndarray:
     """GPS L5 I5 (data) code, 10230 chips int8 +-1."""
     return _l5(PRN, _L5I_ADVANCE)
 
 
+@_kept
 def generateL5Qcode(PRN: int) -> np.ndarray:
     """GPS L5 Q5 (pilot) code, 10230 chips int8 +-1."""
     return _l5(PRN, _L5Q_ADVANCE)
@@ -195,6 +219,7 @@ def generateL5Qcode(PRN: int) -> np.ndarray:
 # ---------------------------------------------------------------------------------------------
 # GLONASS L1OF / L2OF ranging code (GLO/GLO_GL1/include/generateCAcode.m:93-104)
 # ---------------------------------------------------------------------------------------------
+@_kept
 def generateGLOcode() -> np.ndarray:
     """511-chip m-sequence x^9 + x^5 + 1, output of stage 7, all-ones start; int8 +-1 with logic 1 -> -1
     (the reference keeps the raw register value, no final negation)."""
@@ -219,6 +244,7 @@ _B1I_PHASE = ((1, 3), (1, 4), (1, 5), (1, 6), (1, 8), (1, 9), (1, 10), (1, 11), 
               (3, 4, 9))
 
 
+@_kept
 def generateCAcode53(PRN: int) -> np.ndarray:
     """BDS B1I ranging code, 2046 chips int8 +-1 (logic 1 -> +1 after the reference's final negation).
     11-stage G1 (taps 1,7,8,9,10,11) and G2 (taps 1,2,3,4,5,8,9,11), initial state 01010101010,
@@ -300,11 +326,13 @@ def _b2a(PRN: int, taps1, taps2, g2_table: str) -> np.ndarray:
     return (1 - 2 * (r1 ^ r2).astype(np.int8)).astype(np.int8)
 
 
+@_kept
 def generateB2aDataCode(PRN: int) -> np.ndarray:
     """BDS B2a data-channel code, 10230 chips int8 +-1 (logic 1 -> -1)."""
     return _b2a(PRN, (1, 5, 11, 13), (3, 5, 9, 11, 12, 13), "b2a_data_g2")
 
 
+@_kept
 def generateB2aPilotCode(PRN: int) -> np.ndarray:
     """BDS B2a pilot-channel code, 10230 chips int8 +-1."""
     return _b2a(PRN, (3, 6, 7, 13), (1, 5, 7, 8, 12, 13), "b2a_pilot_g2")
@@ -316,6 +344,7 @@ def generateB2aPilotCode(PRN: int) -> np.ndarray:
 _B3I_G1 = None
 
 
+@_kept
 def generateB3Icode(PRN: int) -> np.ndarray:
     """BDS B3I ranging code, 10230 chips int8 +-1: G1 (taps 1,3,4,13; restarts when it reaches 1111111111100,
     period 8190) times G2 (taps 1,5,6,7,9,10,12,13) pre-advanced by the PRN's table entry."""
@@ -363,11 +392,13 @@ def _e5_i(sig: str, PRN: int, flag: int) -> np.ndarray:
     return (sec[:, None] * prim[None, :]).reshape(-1)
 
 
+@_kept
 def generateE5aIcode(PRN: int, flag: int = 1) -> np.ndarray:
     """flag 1: 10230-chip primary code; flag 2: the 20-ms tiered code (primary x CS20_1 = 842E9)."""
     return _e5_i("e5ai", PRN, flag)
 
 
+@_kept
 def generateE5bIcode(PRN: int, flag: int = 1) -> np.ndarray:
     """flag 1: primary; flag 2: the 4-ms tiered code (primary x CS4_1 = E)."""
     return _e5_i("e5bi", PRN, flag)
@@ -386,19 +417,23 @@ def _e5_q(sig: str, PRN: int, flag: int) -> np.ndarray:
     return (_e5_secondary100(sig, PRN)[:, None] * prim[None, :]).reshape(-1)
 
 
+@_kept
 def generateE5aQcode(PRN: int, flag: int = 1) -> np.ndarray:
     return _e5_q("e5aq", PRN, flag)
 
 
+@_kept
 def generateE5bQcode(PRN: int, flag: int = 1) -> np.ndarray:
     return _e5_q("e5bq", PRN, flag)
 
 
+@_kept
 def generateE5aQ_secondary(PRN: int) -> np.ndarray:
     """100-chip secondary code CS100 of E5a-Q as +-1."""
     return _e5_secondary100("e5aq", PRN)
 
 
+@_kept
 def generateE5bQ_secondary(PRN: int) -> np.ndarray:
     return _e5_secondary100("e5bq", PRN)
 
@@ -432,6 +467,7 @@ def _l2c_chips(state: int, n: int) -> np.ndarray:
     return out
 
 
+@_kept
 def generateCMcode(PRN: int, codeLength: int = 10230) -> np.ndarray:
     """L2 CM code as the reference returns it: 2*codeLength entries [chip, 0, chip, 0, ...], chips +-1."""
     chips = 1 - 2 * _l2c_chips(int(_icd("l2cm_init_octal")[_l2c_index(PRN)]), codeLength).astype(np.int8)
@@ -440,6 +476,7 @@ def generateCMcode(PRN: int, codeLength: int = 10230) -> np.ndarray:
     return out
 
 
+@_kept
 def generateCLcode(PRN: int, CLCodeLength: int = 767250) -> np.ndarray:
     """L2 CL code: 2*CLCodeLength entries [0, chip, 0, chip, ...]."""
     chips = 1 - 2 * _l2c_chips(int(_icd("l2cl_init_octal")[_l2c_index(PRN)]), CLCodeLength).astype(np.int8)
@@ -470,28 +507,33 @@ def _weil(N: int, w: int, p: int, n: int) -> np.ndarray:
     return (1 - 2 * (L[k] ^ L[(k + w) % N]).astype(np.int8)).astype(np.int8)
 
 
+@_kept
 def generateB1Cprimary(PRN: int, component: str) -> np.ndarray:
     w, p = _prn_row(_icd("b1c_data_wp" if component == "data" else "b1c_pilot_wp"), PRN, "BDS B1C")
     return _weil(10243, int(w), int(p), 10230)
 
 
+@_kept
 def generateDataBOC11(PRN: int) -> np.ndarray:
     """B1C data component with the BOC(1,1) sub-carrier baked in: 20460 half-chips, chip x [-1, +1]."""
     c = generateB1Cprimary(PRN, "data")
     return (c[:, None] * np.array([-1, 1], dtype=np.int8)[None, :]).reshape(-1)
 
 
+@_kept
 def generatePilotBOC11(PRN: int) -> np.ndarray:
     c = generateB1Cprimary(PRN, "pilot")
     return (c[:, None] * np.array([-1, 1], dtype=np.int8)[None, :]).reshape(-1)
 
 
+@_kept
 def generatePilotBOC61(PRN: int) -> np.ndarray:
     """B1C pilot BOC(6,1) component: 122760 entries, chip x (-1)^ii, ii = 1..12."""
     c = generateB1Cprimary(PRN, "pilot")
     return (c[:, None] * np.tile(np.array([-1, 1], dtype=np.int8), 6)[None, :]).reshape(-1)
 
 
+@_kept
 def generatePilot2ndCodes(PRN: int) -> np.ndarray:
     """1800-chip B1C pilot secondary (overlay) code: Weil code of length 3607."""
     w, p = _prn_row(_icd("b1c_secondary_wp"), PRN, "BDS B1C")
