@@ -256,7 +256,8 @@ def time_replay(job: Job, steps: int, warmup: int, warm=None, prewarm_ms: float 
 
 
 KERNEL_NAMES = {0: "corr_epl_lane_kernel", 1: "corr_epl_fast_kernel (one-wave workgroups)", 2: "corr_epl_fast_kernel (four waves, int8-pair tables)",
-                3: "corr_epl_fast_kernel (four waves, float tables)", -1: "corr_epl_mixed_kernel"}
+                3: "corr_epl_fast_kernel (four waves, float tables)", 4: "corr_epl_multi_kernel (up to 2 / 4 transitions per 16-sample chunk)",
+                -1: "corr_epl_mixed_kernel"}
 
 
 def band_scene(P, parts, fs: float, seed: int, cn0: float = 46.0):

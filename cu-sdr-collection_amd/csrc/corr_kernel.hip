@@ -147,6 +147,35 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   long long total = (long long)nblocks * splits;
   int want_bpw = 8;
   if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
+  // Multi-transition kernel (corr_multi.hip): big periodic replay lists whose chunks of 16 samples see up to 2 or 4 table
+  // transitions - lists the single-transition kernel takes with 8-sample chunks (fast == 1) or hands to the lane kernel
+  // (fast == 0).  GC_NO_MULTI=1 keeps the old choice (A/B), GC_MULTI_MIN = epochs per CU from which it is taken.
+  {
+    const int multi_min = std::getenv("GC_MULTI_MIN") ? std::max(1, std::atoi(std::getenv("GC_MULTI_MIN"))) : 4;
+    const int mwaves = (period > 0 && max_arms <= 2) ? gc_multi_waves(ctx, max_arms, nblocks, period, ctx->scope_kt, ctx->scope_share_lane) : 0;
+    const bool multi = (fast == 0 || fast == 1) && ctx->scope_kt >= 2 && period > 0 && splits == 1 && notify_tag == 0 && !a.derived &&
+                       ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && max_arms <= 2 && mwaves > 0 &&
+                       nblocks >= multi_min * (long long)period * ctx->compute_units && !std::getenv("GC_NO_MULTI") && !ctx->force_generic;
+    if (multi) {
+      a.bpw = mwaves >= 8 ? mwaves * (nblocks / period >= 64LL * mwaves ? 2 : 1) : std::max(4, want_bpw) / 4 * 4;
+      a.stride = period;
+      a.wide = 1;
+      total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
+      a.xcd_swizzle = 0;
+      a.total_wg = 0;
+      if (total >= 64) {
+        a.xcd_swizzle = 1;
+        a.total_wg = total;
+        total = (total + 7) / 8 * 8;
+      }
+      if (total > 0x7fffffffLL) {
+        gc_set_error("too many workgroups (%lld)", total);
+        return GC_E_INVALID;
+      }
+      ctx->last_kernel = 4;
+      return gc_launch_correlator_multi(ctx, a, (unsigned int)total, max_arms, ctx->scope_kt, ctx->scope_share_lane, mwaves);
+    }
+  }
   const bool must_wide = fast > 0 && gc_fast_table_mode(ctx) == 1;  // tables too large for single-wave workgroups
   // by choice: every wave of the fast kernel parks 4-8 KB of running sums in LDS (corr_fast.hip), and
   // only four waves sharing an int8-pair table keep 16 waves per CU resident (big periodic replay lists, int8 I/Q, <= 2 arms)

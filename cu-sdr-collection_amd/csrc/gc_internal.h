@@ -122,6 +122,10 @@ struct gc_context {
   int replay_scope[3] = {0, 0, 0};
   bool scope_share_lane = false;  // every block of the scope has 2*el_spacing*R*M an exact positive integer
   bool replay_share_lane = false;
+  // multi-transition kernel (corr_multi.hip): 0 = some block or channel of the scope does not qualify, else the largest number of
+  // table transitions a 16-sample chunk of any block can see (2 or 4) - int8 tables of one ramp multiplier, no windows
+  int scope_kt = 0;
+  int replay_kt = 0;
   int replay_min_blksize = 0;
 
   // scratch for gc_correlate / gc_track
@@ -229,4 +233,7 @@ int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps);
 void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps);
 // 0 = float2 tables / single-wave workgroups, 1 = WIDE (int8 pairs, four waves), -1 = tables too large for the fast kernel
 int gc_fast_table_mode(const gc_context* ctx);
+// corr_multi.hip
+int gc_multi_table_bytes(int max_entries, int arms);
+int gc_block_multi_kt(const gc_context* ctx, const gc_block& b);  // 1, 2, 4 transitions per 16-sample chunk at most; 0 = more
 bool gc_channel_is_derived(const HostChannel& c);  // cached in HostChannel::derived_state

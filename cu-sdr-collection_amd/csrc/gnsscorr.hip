@@ -712,6 +712,13 @@ int gc_block_lowrate_level(const gc_context* ctx, const gc_block& b) {
   return (15.0 * s < 0.995) ? 2 : (7.0 * s < 0.995) ? 1 : 0;
 }
 
+int gc_block_multi_kt(const gc_context* ctx, const gc_block& b) {
+  const HostChannel& c = ctx->ch[b.channel];
+  // (16 - 1) samples advance the table index by 15*s entries: at most KT integers are crossed when that stays below KT
+  const double s = 15.0 * b.code_phase_step * c.index_scale * c.mult[0];
+  return s < 0.995 ? 1 : s < 1.995 ? 2 : s < 3.995 ? 4 : 0;
+}
+
 bool gc_block_shares_el_lane(const gc_context* ctx, const gc_block& b) {
   const HostChannel& c = ctx->ch[b.channel];
   const double v = 2.0 * b.el_spacing * c.index_scale * c.mult[0];
@@ -783,6 +790,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
   bool seen[GC_MAX_CHANNELS] = {false};
   gc_scope_reset(ctx);
   ctx->scope_share_lane = true;
+  int kt = 1;
   for (int64_t i = 0; i < n; ++i) {
     const gc_block& k = b[i];
     if (k.channel < 0 || k.channel >= GC_MAX_CHANNELS || !ctx->ch[k.channel].configured) {
@@ -835,6 +843,12 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
       }
     }
     max_arms = std::max(max_arms, c.arms);
+    if (kt > 0) {  // corr_multi.hip: whole int8 tables of one ramp multiplier, one or two arms
+      bool plain = c.arms <= 2;
+      for (int a = 0; a < c.arms; ++a) plain = plain && c.mult[a] == c.mult[0] && c.window[a] == 0 && k.table_offset[a] == 0;
+      const int need = plain ? gc_block_multi_kt(ctx, k) : 0;
+      kt = need == 0 ? 0 : std::max(kt, need);
+    }
     if (*all_lowrate >= 0) *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
     if (all_share && !gc_block_shares_el(ctx, k)) *all_share = false;
     if (ctx->scope_share_lane && !gc_block_shares_el_lane(ctx, k)) ctx->scope_share_lane = false;
@@ -842,6 +856,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
   }
   // mixed ramp multipliers: the exact per-sample kernel (-1), unless every such channel's odd arm can be derived from its
   // neighbour (BOC(6,1) from BOC(1,1)) and the record is int8 I/Q: then the lane kernel's derived-arm instantiation (0)
+  ctx->scope_kt = (kt >= 2 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && !any_derived && !any_plain_mixed) ? kt : 0;
   if (any_plain_mixed || (any_derived && (any_three_plain || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL))) {
     *all_lowrate = -1;
   } else if (any_derived) {
@@ -942,6 +957,7 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   ctx->replay_scope[1] = ctx->max_stage_len;
   ctx->replay_scope[2] = ctx->max_arms_configured;
   ctx->replay_share_lane = ctx->scope_share_lane;
+  ctx->replay_kt = ctx->scope_kt;
   ctx->replay_derived = ctx->launch_derived;
   ctx->replay_fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
@@ -957,7 +973,8 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   }
   {
     std::vector<gc_block> marked(blocks, blocks + nblocks);
-    gc_mark_tie_free(ctx, marked.data(), nblocks, ctx->replay_fast > 0 ? 8e-6 : 0.0);
+    // the band the kernel that may take the list tests in: 8e-6 samples of ramp = twice the 4e-6 of corr_fast.hip and corr_multi.hip
+    gc_mark_tie_free(ctx, marked.data(), nblocks, (ctx->replay_kt > 0 || ctx->replay_fast > 0) ? 8e-6 : 0.0);
     GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, marked.data(), sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
   }
@@ -993,6 +1010,7 @@ int gc_replay_launch(gc_context* ctx) {
   ctx->max_stage_len = ctx->replay_scope[1];
   ctx->max_arms_configured = ctx->replay_scope[2];
   ctx->scope_share_lane = ctx->replay_share_lane;
+  ctx->scope_kt = ctx->replay_kt;
   ctx->launch_derived = ctx->replay_derived;
   int splits = 1;
   if (ctx->replay_fast == 0) {

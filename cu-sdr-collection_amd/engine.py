@@ -163,7 +163,8 @@ class Engine:
         return out
 
     def last_kernel(self) -> int:
-        """gc_debug_last_kernel: 0 lane, 1 fast (one wave), 2 fast (four waves, int8 pairs), 3 fast (four waves, floats), -1 mixed."""
+        """gc_debug_last_kernel: 0 lane, 1 fast (one wave), 2 fast (four waves, int8 pairs), 3 fast (four waves, floats), 4 multi-transition
+        (corr_multi.hip), -1 mixed."""
         return int(self._lib.gc_debug_last_kernel(self._ctx))
 
     def last_track_mode(self) -> int:

@@ -11,7 +11,8 @@ import bench_workloads as W  # noqa: E402
 import cu_sdr_collection_amd as P  # noqa: E402
 
 SHAPES = {"l5": ([("GPS_L5C", 8)], 50e6), "b2a": ([("BDS_B2a", 8)], 50e6), "l5_18": ([("GPS_L5C", 8)], 18e6), "cboc": ([("GAL_E1C_CBOC", 8)], 18e6),
-          "b1c": ([("BDS_B1C_NB", 2)], 18e6), "e1": ([("GAL_E1C", 3)], 18e6), "l1ca3": ([("GPS_L1CA", 3)], 18e6), "e1x8": ([("GAL_E1C", 8)], 18e6)}
+          "b1c": ([("BDS_B1C_NB", 2)], 18e6), "e1": ([("GAL_E1C", 3)], 18e6), "l1ca3": ([("GPS_L1CA", 3)], 18e6), "e1x8": ([("GAL_E1C", 8)], 18e6),
+          "b1i": ([("BDS_B1I", 8)], 18e6), "b3i": ([("BDS_B3I", 8)], 18e6), "l2c": ([("GPS_L2C", 4)], 8e6), "glo": ([("GLO_GL1", 8)], 12e6)}
 
 
 def main():

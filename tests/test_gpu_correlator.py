@@ -312,7 +312,8 @@ def test_big_periodic_replay_with_eight_sample_chunks(engine, monkeypatch):
         engine.set_channel(k, [t])
     _, cus = engine.device_info()
     nb = 64 * 2 * cus + 2 * 11
-    for env, want in (({}, 3), ({"GC_NO_TABF": "1"}, 2)):
+    # (GC_NO_MULTI: without it such a list goes to corr_multi.hip - 16-sample chunks with two transitions, kernel 4, third pass)
+    for env, want in (({"GC_NO_MULTI": "1"}, 3), ({"GC_NO_MULTI": "1", "GC_NO_TABF": "1"}, 2), ({}, 4)):
         descs = _random_descs(rng, nb, nsamp, 2, fc=2.046e6, L=2046.0)
         for i, d in enumerate(descs):
             d["channel"] = i % 2

@@ -220,3 +220,64 @@ def test_lane_kernel_work_decompositions(engine):
     got = engine.replay_fetch()
     check(got, descs, list(range(0, 2200, 97)) + [2198, 2199])
     assert np.max(np.abs(got - engine.correlate(b))) < 0.2   # decomposition (C) of the same list: float sums only reorder
+
+
+@pytest.mark.parametrize("case", ["l5_50msps_share", "l5_50msps_three_ramps", "e1_share", "e1_three_ramps", "b1i_one_arm_qi"])
+def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine, monkeypatch, case):
+    """corr_multi.hip: periodic replay lists whose 16-sample chunks cross up to 2 (Galileo E1 / BDS B1I-type tables at 18 Msps) or
+    4 (10.23-Mcps codes at 50 Msps) table entries.  The same list through the kernel that took it before (GC_NO_MULTI=1: the lane
+    kernel or the 8-sample single-transition kernel) and, block by block, through the float64 oracle (tracking.m:247-300); blocks
+    that start on exact chip edges with the nominal rational step (the tie-dense first block of every channel) included."""
+    cfg = {"l5_50msps_share": dict(fs=50e6, L=10230, rate=10.23e6, R=1.0, arms=2, d=0.5, kt=4, layout="iq"),
+           "l5_50msps_three_ramps": dict(fs=50e6, L=10230, rate=10.23e6, R=1.0, arms=2, d=0.3, kt=4, layout="iq"),
+           "e1_share": dict(fs=18e6, L=4092, rate=1.023e6, R=2.0, arms=2, d=0.25, kt=2, layout="iq"),
+           "e1_three_ramps": dict(fs=18e6, L=4092, rate=1.023e6, R=2.0, arms=2, d=0.1, kt=2, layout="iq"),
+           "b1i_one_arm_qi": dict(fs=18e6, L=2046, rate=2.046e6, R=1.0, arms=1, d=0.5, kt=2, layout="qi")}[case]
+    from cu_sdr_collection_amd import _lib as LIB
+    fs, L, R, arms = cfg["fs"], float(cfg["L"]), cfg["R"], cfg["arms"]
+    rng = np.random.default_rng(abs(hash(case)) % 1000 + 11)
+    period, epochs = 3, 180                                   # 540 blocks >= GC_MULTI_MIN(1) x period x 256 CUs? no: see below
+    monkeypatch.setenv("GC_MULTI_MIN", "1")
+    cus = engine.device_info()[1]
+    epochs = max(epochs, (8 * cus + period - 1) // period + 4)    # lists the replay launcher does not split: >= 8 blocks per CU
+    step0 = cfg["rate"] / fs
+    nmax = int(np.ceil(L / (step0 * (1 - 3e-5)))) + 2
+    n_if = 6 * nmax
+    iq = _noise_iq(n_if, 77)
+    layout = LIB.GC_QI if cfg["layout"] == "qi" else LIB.GC_IQ
+    engine.load_if(iq, layout=layout, fs=fs)
+    tabs = {}
+    for c in range(period):
+        tabs[c] = [O.pad_code(rng.choice([-1.0, 1.0], size=int(L * R))) for _ in range(arms)]
+        engine.set_channel(c, [t.astype(np.int8) for t in tabs[c]], index_scale=R)
+    nb = period * epochs
+    b = engine.make_blocks(nb)
+    descs = []
+    for k in range(nb):
+        tie = k < period or k % 97 == 0                        # first block of every channel (and a few more): rem = 0, nominal step
+        step = step0 if tie else step0 * (1 + float(rng.uniform(-3e-5, 3e-5)))
+        rem = 0.0 if tie else float(rng.uniform(0, step))
+        n = O.blksize_for(L, rem, step)
+        dsc = dict(channel=k % period, n=n, s0=int(rng.integers(0, n_if - n)), rem=rem, step=step, d=cfg["d"],
+                   f=float(rng.uniform(-2.5e4, 2.5e4)), phi=float(rng.uniform(-3, 3)))
+        descs.append(dsc)
+        _block(b, k, **dsc)
+    engine.replay_prepare(b)
+    engine.replay_launch()
+    got = engine.replay_fetch().copy()
+    assert engine.last_kernel() == 4, engine.last_kernel()
+    monkeypatch.setenv("GC_NO_MULTI", "1")
+    engine.replay_launch()
+    other = engine.replay_fetch().copy()
+    assert engine.last_kernel() != 4
+    monkeypatch.delenv("GC_NO_MULTI")
+    raw_all = iq.astype(np.float64)
+    scale = np.array([np.sum(np.abs(raw_all[2 * d_["s0"]:2 * (d_["s0"] + d_["n"])])) for d_ in descs])
+    dev = np.max(np.abs(got - other).reshape(nb, -1), axis=1) / scale
+    assert dev.max() < 2 * TOL, (case, int(np.argmax(dev)), dev.max())
+    assert not got[:, arms:].any()
+    for k in list(range(period)) + [97, 194, nb - 1, nb // 2, nb // 3]:
+        d_ = descs[k]
+        raw = O.raw_from_if(iq, d_["s0"], d_["n"], swap_iq=cfg["layout"] == "qi")
+        ref, _, _ = O.correlate_block(raw, tabs[d_["channel"]], d_["rem"], d_["step"], d_["d"], d_["f"], d_["phi"], fs, L, r=R)
+        assert np.max(np.abs(got[k, :arms] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :arms] - ref)) / scale[k])
