@@ -166,6 +166,11 @@ struct PassArgs {
   // the next one it can, launch in gc_acquire_coarse_multi): positions wrap_len .. wrap_len + spc - 1 repeat the first spc
   // (mixed) samples, everything behind is zero
   int wrap_len;
+  // POST_ABS_ACC without hop groups, last code arm of a PRN: the workgroup's own peak candidate (PeakTrack::publish_slot) over the
+  // first peak_valid columns goes to peak_slots[2 * blockIdx.x] - the finished results are not read back by a peak kernel
+  // (94 bins x 144 000 columns = 54 MB per PRN in the Galileo E1 search: 45 us of the 190 us a PRN took)
+  unsigned long long* peak_slots;
+  int peak_valid;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -344,6 +349,76 @@ __device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, 
     for (int q = 0; q < R; ++q) dst[obase + q * ns] = oq[q];
   }
 }
+
+// The running maximum of a thread / workgroup with MATLAB's first-occurrence rule (acquisition.m:196-198), see the peak kernels below
+struct PeakTrack {
+  unsigned int m = 0, bin = 0xffffffffu, col = 0xffffffffu;
+  __device__ __forceinline__ void see(float v, unsigned int b, unsigned int c) {
+    const unsigned int u = __float_as_uint(v);
+    if (u > m) {
+      m = u;
+      bin = b;
+      col = c;
+    } else if (u == m) {
+      bin = min(bin, b);
+      col = min(col, c);
+    }
+  }
+  // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
+  // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
+  // the workgroup's candidate in thread 0: {maximum's bits, smallest bin, smallest column among the lanes that hold it}
+  __device__ __forceinline__ bool reduce(unsigned long long& ka, unsigned long long& kb) const {
+    __shared__ unsigned int sm[4], sb[4], sc[4];
+    unsigned int wm = m;
+    for (int off = 32; off > 0; off >>= 1) wm = max(wm, (unsigned int)__shfl_xor((int)wm, off, 64));
+    unsigned int b = m == wm ? bin : 0xffffffffu, c = m == wm ? col : 0xffffffffu;
+    for (int off = 32; off > 0; off >>= 1) {
+      b = min(b, (unsigned int)__shfl_xor((int)b, off, 64));
+      c = min(c, (unsigned int)__shfl_xor((int)c, off, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      sm[wave] = wm;
+      sb[wave] = b;
+      sc[wave] = c;
+    }
+    __syncthreads();
+    ka = kb = 0;
+    if (threadIdx.x != 0) return false;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) {
+      if (sm[w] > wm) {
+        wm = sm[w];
+        b = sb[w];
+        c = sc[w];
+      } else if (sm[w] == wm) {
+        b = min(b, sb[w]);
+        c = min(c, sc[w]);
+      }
+    }
+    if (b == 0xffffffffu) return true;  // nothing seen: keys stay 0
+    ka = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - b);
+    kb = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - c);
+    return true;
+  }
+  // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
+  // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
+  __device__ __forceinline__ void publish(unsigned long long* keys) const {
+    unsigned long long ka, kb;
+    if (reduce(ka, kb) && ka) {
+      if (ka > __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[0], ka);
+      if (kb > __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[1], kb);
+    }
+  }
+  // the same candidate as a plain store into this workgroup's own slot (keys_reduce_kernel picks them up)
+  __device__ __forceinline__ void publish_slot(unsigned long long* slot) const {
+    unsigned long long ka, kb;
+    if (reduce(ka, kb)) {
+      slot[0] = ka;
+      slot[1] = kb;
+    }
+  }
+};
 
 // One workgroup: `cols` vectors of length L, Stockham autosort in LDS (ping-pong), one output
 // element group (j, column) per thread per stage.
@@ -815,6 +890,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   }
   if constexpr (POST == POST_ABS_ACC) {
     const float inv_n = 1.0f / (float)N, scale = a.acc_scale != 0.0f ? a.acc_scale : 1.0f;
+    PeakTrack pk;
 #pragma unroll
     for (unsigned slot = 0; slot < SLOTS; ++slot) {
       const unsigned idx = tid + slot * kFftThreads;
@@ -830,9 +906,15 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
         a.acc_part[((long long)hg * a.acc_bins + batch) * N + pos] = accv[slot];
       } else {
         float* dstp = a.acc_out + (long long)batch * N + pos;
-        *dstp = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * scale;
+        const float v = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * scale;
+        if (a.peak_slots) {  // the finished sums of a PRN feed nothing but its peak keys
+          if ((int)pos < a.peak_valid) pk.see(v, batch, pos);
+        } else {
+          *dstp = v;
+        }
       }
     }
+    if (HG == 1 && a.peak_slots) pk.publish_slot(a.peak_slots + 2 * (size_t)blockIdx.x);
   }
 }
 
@@ -1073,75 +1155,6 @@ bool try_fused(gc_context* ctx, const Plan& pl, const FusedArgs& a, int nprn) {
 // the largest value, the smallest bin holding it and the smallest column holding it (not necessarily the same element).
 // Positive floats order like their bit patterns, so two 64-bit atomic maxima do it: (bits << 32) | ~bin and
 // (bits << 32) | ~column.
-struct PeakTrack {
-  unsigned int m = 0, bin = 0xffffffffu, col = 0xffffffffu;
-  __device__ __forceinline__ void see(float v, unsigned int b, unsigned int c) {
-    const unsigned int u = __float_as_uint(v);
-    if (u > m) {
-      m = u;
-      bin = b;
-      col = c;
-    } else if (u == m) {
-      bin = min(bin, b);
-      col = min(col, c);
-    }
-  }
-  // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
-  // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
-  // the workgroup's candidate in thread 0: {maximum's bits, smallest bin, smallest column among the lanes that hold it}
-  __device__ __forceinline__ bool reduce(unsigned long long& ka, unsigned long long& kb) const {
-    __shared__ unsigned int sm[4], sb[4], sc[4];
-    unsigned int wm = m;
-    for (int off = 32; off > 0; off >>= 1) wm = max(wm, (unsigned int)__shfl_xor((int)wm, off, 64));
-    unsigned int b = m == wm ? bin : 0xffffffffu, c = m == wm ? col : 0xffffffffu;
-    for (int off = 32; off > 0; off >>= 1) {
-      b = min(b, (unsigned int)__shfl_xor((int)b, off, 64));
-      c = min(c, (unsigned int)__shfl_xor((int)c, off, 64));
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-      sm[wave] = wm;
-      sb[wave] = b;
-      sc[wave] = c;
-    }
-    __syncthreads();
-    ka = kb = 0;
-    if (threadIdx.x != 0) return false;
-    const int nw = (blockDim.x + 63) >> 6;
-    for (int w = 1; w < nw; ++w) {
-      if (sm[w] > wm) {
-        wm = sm[w];
-        b = sb[w];
-        c = sc[w];
-      } else if (sm[w] == wm) {
-        b = min(b, sb[w]);
-        c = min(c, sc[w]);
-      }
-    }
-    if (b == 0xffffffffu) return true;  // nothing seen: keys stay 0
-    ka = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - b);
-    kb = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - c);
-    return true;
-  }
-  // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
-  // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
-  __device__ __forceinline__ void publish(unsigned long long* keys) const {
-    unsigned long long ka, kb;
-    if (reduce(ka, kb) && ka) {
-      if (ka > __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[0], ka);
-      if (kb > __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[1], kb);
-    }
-  }
-  // the same candidate as a plain store into this workgroup's own slot (keys_reduce_kernel picks them up)
-  __device__ __forceinline__ void publish_slot(unsigned long long* slot) const {
-    unsigned long long ka, kb;
-    if (reduce(ka, kb)) {
-      slot[0] = ka;
-      slot[1] = kb;
-    }
-  }
-};
-
 // The peak keys of one PRN from the per-workgroup candidates abs_combine_kernel left in `slots` (2 keys per workgroup,
 // `per_prn` workgroups per PRN): one workgroup per PRN, launched once after the last PRN.  A thousand workgroups starting
 // together and all finding the keys at zero made the two atomics of PeakTrack::publish a 2 000-deep queue on two addresses -
@@ -1511,7 +1524,17 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
    try_ct<N2, N1, true, C2, PRE_MUL_CONJ, POST_TWIDDLE, true, true, B0, B1, B2, B3>(ctx, a, nbatch_groups) ||           \
    try_ct<N1, N2, false, C1, PRE_NONE, POST_ABS_ACC, true, false, A0, A1, A2, A3>(ctx, a, nbatch_groups))
 
-int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
+// tile width C1 of the specialised columns pass for vectors of `len`, `nvec` of them per transform (the shapes of GC_CT_SHAPE below:
+// its launch has nvec / C1 workgroups per batch, whatever PassArgs::cols says); 0: no specialised pass
+int ct_columns_tile(int len, int nvec) {
+  static const int shapes[][3] = {{180, 200, 8}, {150, 160, 8}, {375, 384, 4}, {250, 288, 8}, {600, 600, 3}, {512, 625, 5}};
+  for (const auto& k : shapes)
+    if (len == k[0] && nvec == k[1]) return k[2];
+  return 0;
+}
+
+int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* used_ct = nullptr) {
+  if (used_ct) *used_ct = false;
   static const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;
   static const bool no_pairs = std::getenv("GC_ACQ_NO_XCD_PAIRS") != nullptr;
   a.no_xcd_pairs = no_pairs ? 1 : 0;
@@ -1524,6 +1547,7 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups) {
         GC_CT_SHAPE(375, 384, 4, 5, 5, 5, 3, 5, 8, 8, 6, 1) || GC_CT_SHAPE(250, 288, 8, 5, 5, 5, 2, 5, 8, 6, 6, 1) ||
         GC_CT_SHAPE(600, 600, 3, 6, 5, 5, 4, 3, 6, 5, 5, 4) || GC_CT_SHAPE(512, 625, 5, 8, 8, 8, 1, 2, 5, 5, 5, 5)) {
       GC_HIP(hipGetLastError());
+      if (used_ct) *used_ct = true;
       return GC_OK;
     }
   }
@@ -1622,8 +1646,32 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   dim3 pgrid((unsigned int)std::max(1, std::min((a.n + 1023) / 1024, 64)), (unsigned int)std::min<long long>(nbins, 65535));
   if (const char* e = std::getenv("GC_ACQ_COMBINE_GX")) pgrid.x = (unsigned int)std::max(1, std::atoi(e));
   if (hg == 1) {
-    int rc = launch_pass(ctx, a, nbins);
+    // last arm of a PRN on a specialised pass kernel: every workgroup leaves its own peak candidate (fft_pass_ct), reduced into the
+    // keys after the last PRN like the hop-grouped path's; the generic pass kernel writes the results and peak_kernel reads them
+    const int c1 = ct_columns_tile(a.len, a.nvec);
+    const bool fused_peak = keys && c1 > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL");
+    if (fused_peak) {
+      const int per = (int)((long long)(a.nvec / c1) * nbins);  // the specialised kernel's grid
+      const size_t want = (size_t)nprn * per * 2;
+      if (s->slots_cap < want) {
+        GC_HIP(hipStreamSynchronize(ctx->stream));
+        if (s->slots) (void)hipFree(s->slots);
+        s->slots = nullptr;
+        s->slots_cap = 0;
+        GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
+        GC_HIP(hipMemsetAsync(s->slots, 0, want * sizeof(unsigned long long), ctx->stream));
+        s->slots_cap = want;
+      }
+      s->slots_per_prn = per;
+      a.peak_slots = s->slots + (size_t)ip * per * 2;
+      a.peak_valid = valid;
+    }
+    bool used_ct = false;
+    int rc = launch_pass(ctx, a, nbins, &used_ct);
+    a.peak_slots = nullptr;
     if (rc || !keys) return rc;
+    if (fused_peak && used_ct) return GC_OK;
+    if (fused_peak) s->slots_per_prn = 0;  // the generic pass kernel took it after all (tuning knobs): it wrote the results, peak_kernel reads them
     hipLaunchKernelGGL(peak_kernel, pgrid, dim3(256), 0, ctx->stream, a.acc_out, (int)nbins, a.n, keys, valid);
     GC_HIP(hipGetLastError());
     return GC_OK;

@@ -516,7 +516,7 @@ def _acq_l2c_default_record(P, S):
         cm, cl = P.codes.generateCMcode(prn).astype(np.float64), P.codes.generateCLcode(prn).astype(np.float64)
         return np.roll(np.tile(cm, 75) + cl, -20460 * (segs[prn] - 1))
     sats = [P.synth.SatSpec(prn=5, doppler=3212.0, code_phase_samples=70003.4, carrier_phase=1.0, cn0_dbhz=45.0),
-            P.synth.SatSpec(prn=17, doppler=-7431.0, code_phase_samples=141234.2, carrier_phase=4.0, cn0_dbhz=43.0)]
+            P.synth.SatSpec(prn=17, doppler=-4431.0, code_phase_samples=141234.2, carrier_phase=4.0, cn0_dbhz=44.0)]
     return P.synth.generate_if(sats, int(0.25 * S.samplingFreq), S.samplingFreq, S.IF, combined, 2 * S.codeFreqBasis, 20460 * 75, seed=2491,
                                carrier_ratio=1200.0, bit_periods=1)
 
