@@ -512,6 +512,67 @@ def run_acquisition_packages(P, device, only=None):
     return out
 
 
+def run_closed_loop_sweep(P, W, device, seconds: float, l1_points=(12, 24, 48, 96, 192), l5_points=(16, 32, 64)):
+    """north_star: "shard across the 8 GPUs ... only when the channel count warrants it" (tracking.m:133: the reference's channel
+    loop).  Closed loops - the mode a receiver runs in - of n channels on ONE GPU over one record: seconds per call, microseconds
+    per epoch, x real time, which launcher the library chose (gc_debug_last_track_mode: 1 persistent host-fed kernel, 0 a launch
+    per epoch, 2 loop closed on the device), and the share of the wall time the GPU needs for the same blocks in one batched
+    replay launch (`gpu_busy_estimate`: what is left is latency - PCIe round trips, the all-gather of the partial sums).  The
+    channels beyond the 32 satellites of the scene track satellites other channels track too: the same work per channel.
+    `knee_channels`: the largest measured count whose epoch time is within 1.25x of the smallest count's - below it more GPUs buy
+    nothing (every channel's epoch is its own latency chain), above it the epoch time grows with the channels and sharding
+    divides it: sharding.recommended_world_size is built on these knees."""
+    import copy
+    out = {}
+    for name, pkgname, fs, points in (("GPS_L1CA_18Msps", "GPS_L1CA", 18e6, l1_points), ("GPS_L5C_50Msps", "GPS_L5C", 50e6, l5_points)):
+        owner = P.Engine(device)
+        (pkg, S, scene), = W.make_band(P, owner, [(pkgname, 32)], seconds, fs, 20e3, 7007)
+        n_ep = int((seconds - 3 * S.intTime) / S.intTime) - 1
+        rows = []
+        for n in points:
+            eng = P.Engine(device)
+            try:
+                eng.share_if(owner)
+                eng.set_sampling_freq(fs)
+                sats = [scene[i % len(scene)] for i in range(n)]
+                job = W.prepare_job(P, W.Job(f"{name} x {n}", pkg, copy.copy(S), sats, eng), n_ep)
+                row = {"channels": n}
+                recs = None
+                for key, device_loop in (("host_closed", False), ("device_closed", True)):
+                    try:
+                        W.run_closed_loops(P, [job], device_loop=device_loop)                  # first use
+                        t, recs = W.run_closed_loops(P, [job], device_loop=device_loop)
+                        row[key] = {"seconds": round(t, 4), "us_per_epoch": round(t / n_ep * 1e6, 2), "x_realtime": round(n_ep * S.intTime / t, 1),
+                                    "launcher": {0: "launch per epoch", 1: "persistent host-fed kernel", 2: "device loop"}.get(eng.last_track_mode(), "?")}
+                    except Exception as exc:  # noqa: BLE001 - a count the library cannot take is a finding of the sweep, not an error of the bench
+                        row[key] = {"error": str(exc)[:160]}
+                if recs is not None:
+                    W.keep_records(job, recs[0])
+                    row["locked"] = W.locked(job)
+                    ms, _, kern = W.time_replay(job, 3, 1, prewarm_ms=0.0)
+                    row["replay_ms"] = round(ms, 4)
+                    row["replay_kernel"] = W.KERNEL_NAMES.get(kern, str(kern))
+                    for key in ("host_closed", "device_closed"):
+                        if "seconds" in row[key]:
+                            row[key]["gpu_busy_estimate"] = round(ms * 1e-3 / row[key]["seconds"], 4)
+                rows.append(row)
+            finally:
+                eng.close()
+        owner.close()
+        knee = {}
+        for key in ("host_closed", "device_closed"):
+            ok = [r for r in rows if "us_per_epoch" in r[key]]
+            if ok:
+                base = ok[0][key]["us_per_epoch"]
+                knee[key] = max(r["channels"] for r in ok if r[key]["us_per_epoch"] <= 1.25 * base)
+        out[name] = {"record_seconds": seconds, "epochs_per_channel": n_ep, "points": rows, "knee_channels": knee}
+    from cu_sdr_collection_amd import sharding
+    out["policy"] = {"what": "sharding.recommended_world_size(n_channels, signal): 1 up to the knee, then ceil(n / knee) GPUs (at most 8)",
+                     "table_in_sharding_py": sharding.CLOSED_LOOP_KNEE,
+                     "examples": {f"{sig} x {n}": sharding.recommended_world_size(n, sig) for sig in ("GPS_L1CA", "GPS_L5C") for n in (12, 64, 192, 512)}}
+    return out
+
+
 # =======================================================================================================================
 # the other BASELINE configs: a band record, one job per package, closed loops + replay
 # =======================================================================================================================
@@ -860,7 +921,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=60.0, help="length of the IF record of the main workload")
     ap.add_argument("--channels", type=int, default=12)
-    ap.add_argument("--config", choices=["all", "l1ca", "mix"], default=None,
+    ap.add_argument("--no-sweep", action="store_true", help="skip closed_loop_sweep (closed loops of 12 ... 192 GPS L1 C/A and 16 ... 64 GPS L5 channels on one GPU)")
+    ap.add_argument("--sweep-seconds", type=float, default=10.0, help="record length of the closed-loop channel sweep")
+    ap.add_argument("--config", choices=["all", "l1ca", "mix", "sweep"], default=None,
                     help="all (default at N = 1): main line + the other BASELINE configs; l1ca (default at N > 1): main line only; mix: configs[4] as the line")
     ap.add_argument("--prewarm-ms", type=float, default=40.0, help="untimed replay launches before the W warm-up steps, until this many milliseconds have passed (device clocks up after the idle phases); 0 = none")
     ap.add_argument("--cfg-seconds", type=float, default=60.0, help="record length of configs 3 (8 x E1 CBOC at 18 Msps: 15 000 four-millisecond epochs per channel) and 4 (L5 + B2a at 50 Msps)")
@@ -929,6 +992,8 @@ def main() -> None:
         cfgs["mix_share_l1_band_x8"], extra_jobs["mix"] = run_band_jobs(P, W, "config 5 (one GPU's share)", device, [("GPS_L1CA", 3), ("GAL_E1C", 3), ("BDS_B1C_NB", 2)],
                                                                          args.mix_seconds, 18e6, 20e3, 5005, args.steps, args.warmup)
         result["configs"] = cfgs
+    if rank == 0 and world == 1 and (config == "sweep" or (config == "all" and not args.no_sweep)):
+        result["closed_loop_sweep"] = run_closed_loop_sweep(P, W, device, args.sweep_seconds)
     if rank == 0 and world == 1 and not args.no_cpu:
         base, spots = cpu_leg(P, W, args, main_ctx, extra_jobs)
         result["cpu_baseline"] = base

@@ -168,6 +168,7 @@ struct gc_context {
   GcBuf nav[3];  // gc_sync_xcorr: prompt stream, pattern, result
   double* cno_out = nullptr;  // gc_set_cno_output: caller-owned C/N0 buffer of the next tracking calls
   long long cno_cap = 0;
+  int persist_member_cap = 0;  // gc_track_device: team size limit of the retry after a grid that did not fit the device (0: none)
   bool concurrent_jobs = false;
   int concurrent_channels = 0;  // channels of all jobs on this device (sizes the persistent kernels' teams)
 };

@@ -388,7 +388,11 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   if (persist_lane)  // members of a lane-kernel team: workgroups of 8 waves (as gc_track_device)
     psplits_dev = std::max(1, std::min({max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4, approx_chunks * 8 / (64 * 8 * 2), std::max(1, 2 * ctx->compute_units / nch_dev)}));
   if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(persist_lane ? (max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4) : 32, std::atoi(ev)));
-  if (persist) {
+  // A grid the device cannot hold whole (the teams spin on each other's messages) is refused by the launch: the teams are halved
+  // until it fits - 192 channels x 1 member is still one launch for the whole call, where falling back to a launch per epoch cost
+  // 33-90 us per epoch from 48 GPS L1 C/A channels on (bench.py closed_loop_sweep, round 4)
+  while (persist) {
+    bool refused = false;
     pa.n_epochs = n_epochs;
     pa.splits = psplits_dev;
     pa.if_nsamples = ctx->if_nsamples;
@@ -437,19 +441,33 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
       if (persist_lane) {
         a.share_el = 0;
         a.derived = derived_nominal ? 1 : 0;
-        if (gc_launch_devloop_lane(ctx, a, (unsigned int)(nch * psplits_dev), max_arms, share_lane_nominal && !derived_nominal, 8) != GC_OK) e = hipErrorUnknown;
-      } else if (gc_launch_devloop(ctx, a, (unsigned int)(nch * psplits_dev), fast_nominal == 2, a.share_el != 0) != GC_OK) {
-        e = hipErrorUnknown;
+        const int lrc = gc_launch_devloop_lane(ctx, a, (unsigned int)(nch * psplits_dev), max_arms, share_lane_nominal && !derived_nominal, 8);
+        if (lrc != GC_OK) e = hipErrorUnknown;
+        refused = lrc == GC_E_UNSUPPORTED;
+      } else {
+        const int lrc = gc_launch_devloop(ctx, a, (unsigned int)(nch * psplits_dev), fast_nominal == 2, a.share_el != 0);
+        if (lrc != GC_OK) e = hipErrorUnknown;
+        refused = lrc == GC_E_UNSUPPORTED;
       }
+    }
+    if (e != hipSuccess && refused && psplits_dev > 1) {
+      (void)hipGetLastError();
+      gc_persistent_done(ctx);
+      psplits_dev = (psplits_dev + 1) / 2;
+      continue;
     }
     ctx->last_track_mode = e == hipSuccess ? 1 : 0;
     if (e == hipSuccess) ctx->last_kernel = persist_lane ? 0 : 1;  // gc_debug_last_kernel: lane / fast kernel (persistent instantiation)
     if (e != hipSuccess) {  // could not set the persistent kernel up: launch per epoch
+      if (std::getenv("GC_TRACK_DEBUG"))
+        std::fprintf(stderr, "gc_track: persistent kernel refused (%s): %d channels x %d members, lane %d - launching per epoch\n", hipGetErrorString(e), nch,
+                     psplits_dev, (int)persist_lane);
       (void)hipGetLastError();
       persist_free();
       persist = false;
       persist_lane = false;
     }
+    break;
   }
 
   double tau1code, tau2code, tau1carr, tau2carr;
@@ -673,7 +691,9 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
     // 6.93 us per epoch against 6.77 us on one thread, configs 3 and 4 lost 4-11 %: an epoch is one channel's own chain (descriptor
     // over PCIe, relay, correlate, all-gather, records back), and more pollers only add traffic on the lines the device writes.
     // So one thread is the default; the knob stays for hosts with slower cores.
-    int nthreads = 1;
+    // ... at 12 channels.  With the closed_loop_sweep's 96 / 192 channels the one closer is what the epoch waits for: 14.2 / 20.4 us on
+    // one thread, 12.5 / 15.8 us on four - so one more thread per 64 channels, four at most.
+    int nthreads = std::min(4, 1 + nch / 64);
     if (const char* ev = std::getenv("GC_TRACK_THREADS")) nthreads = std::max(1, std::min({16, nch, std::atoi(ev)}));
     auto serve = [&](int t) {
       const int c0 = (int)((long long)t * nch / nthreads), c1 = (int)((long long)(t + 1) * nch / nthreads);
@@ -999,6 +1019,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
     splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch_dev - 1) / nch_dev, std::max(1, chunks / 32)}));
     if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
+    if (ctx->persist_member_cap > 0) splits = std::min(splits, ctx->persist_member_cap);
     msgs_per_member = 2;
   } else {
     for (int c = 0; c < nch; ++c) share_lane = share_lane && gc_block_shares_el_lane(ctx, hc[c].blk);
@@ -1009,6 +1030,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     const int max_members = max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4;  // (members - 1) * 6 * arms messages <= 64 lanes
     splits = std::max(1, std::min({max_members, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch_dev)}));
     if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_members, std::atoi(e)));
+    if (ctx->persist_member_cap > 0) splits = std::min(splits, ctx->persist_member_cap);
     msgs_per_member = 6 * max_arms;
   }
   // Teams on one XCD each (default).  Not next to other contexts' persistent kernels (gc_track_multi): two kernels that pin
@@ -1094,6 +1116,15 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   const unsigned int grid = xcd_local ? (unsigned int)(((nch + 7) / 8) * 8 * splits) : (unsigned int)(nch * splits);
   a.derived = cboc ? 1 : 0;
   rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane && !cboc, lane_waves);
+  if (rc == GC_E_UNSUPPORTED && splits > 1) {
+    // the grid does not fit the device whole: the same call again with teams half the size (see gc_track's persistent launch)
+    cleanup();
+    const int cap0 = ctx->persist_member_cap;
+    ctx->persist_member_cap = (splits + 1) / 2;
+    rc = gc_track_device(ctx, p, nch, init, out, epochs_done);
+    ctx->persist_member_cap = cap0;
+    return rc;
+  }
   if (rc == GC_OK) {
     ctx->last_track_mode = 2;
     const auto t_l = std::chrono::steady_clock::now();

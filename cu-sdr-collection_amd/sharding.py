@@ -4,6 +4,56 @@ channel, one process per GPU, no data-path collective."""
 from __future__ import annotations
 
 
+# bench.py closed_loop_sweep (MI355X, round 4, 5-s records): microseconds per epoch of the HOST-closed loop - the mode north_star
+# names - against the channels on ONE GPU; an epoch is 1 ms of signal, so x real time = 1000 / value.  Up to the knee an epoch is one
+# channel's own latency chain (descriptor over PCIe, correlate, all-gather of the team's partial sums, records back) whatever the
+# number of channels, so more GPUs buy nothing; beyond it the teams shrink (the persistent grid must stay resident) and the single
+# closer thread fills up, and the time grows - sub-linearly: 8x the channels cost 2.4x the time.
+CLOSED_LOOP_US_PER_EPOCH = {
+    "GPS_L1CA": {12: 6.9, 24: 8.3, 48: 10.8, 96: 16.5, 192: 19.7},     # 18 Msps; device-closed: 5.3, 5.2, 6.8, 7.9, 10.8
+    "GPS_L5C": {16: 10.0, 32: 11.1, 64: 14.7},                          # 50 Msps, data + pilot; device-closed: 8.7, 8.9, 11.2
+}
+# the largest measured count whose epoch time is within 1.25x of the smallest count's (`knee_channels` of the sweep); signals that
+# were not swept take the entry of their kernel class: "fast" (<= 1 table transition per 16-sample chunk) or "lane"
+CLOSED_LOOP_KNEE = {"GPS_L1CA": 24, "GPS_L5C": 32, "fast": 24, "lane": 32}
+
+
+def expected_us_per_epoch(n_channels: int, signal: str = "GPS_L1CA") -> float:
+    """Host-closed loop of `n_channels` on one GPU: the sweep's measurement, interpolated linearly in the channel count (held flat
+    below the first point, extended with the last segment's slope above the last)."""
+    cls = signal if signal in CLOSED_LOOP_US_PER_EPOCH else ("GPS_L1CA" if CLOSED_LOOP_KNEE.get(signal, 0) == CLOSED_LOOP_KNEE["fast"] else "GPS_L5C")
+    pts = sorted(CLOSED_LOOP_US_PER_EPOCH[cls].items())
+    if n_channels <= pts[0][0]:
+        return pts[0][1]
+    for (n0, t0), (n1, t1) in zip(pts, pts[1:]):
+        if n_channels <= n1:
+            return t0 + (t1 - t0) * (n_channels - n0) / (n1 - n0)
+    (n0, t0), (n1, t1) = pts[-2], pts[-1]
+    return t1 + (t1 - t0) * (n_channels - n1) / (n1 - n0)
+
+
+def recommended_world_size(n_channels: int, signal: str = "GPS_L1CA", max_gpus: int = 8, min_x_realtime: float | None = None,
+                           epoch_ms: float = 1.0) -> int:
+    """north_star: "shard across the 8 GPUs of one node ... only when the channel count warrants it" (the reference's channel loop,
+    tracking.m:133, is serial).  Default: 1 while `n_channels` is at or below the signal's knee (CLOSED_LOOP_KNEE), then the fewest
+    GPUs that bring every rank's share back under it.  With `min_x_realtime`: the fewest GPUs whose share of the channels the
+    sweep's table (expected_us_per_epoch) runs at that many times real time or faster (`epoch_ms`: the package's block length)."""
+    if n_channels < 0 or max_gpus < 1:
+        raise ValueError("bad arguments")
+    if min_x_realtime is not None:
+        for n in range(1, max_gpus + 1):
+            if epoch_ms * 1e3 / expected_us_per_epoch(-(-n_channels // n), signal) >= min_x_realtime:
+                return n
+        return max_gpus
+    knee = CLOSED_LOOP_KNEE.get(signal)
+    if knee is None:
+        from . import signals
+        spec = signals.SIGNALS.get(signal)
+        rate = getattr(spec, "chips_per_second", None) if spec is not None else None
+        knee = CLOSED_LOOP_KNEE["fast" if (rate is not None and rate <= 2.1e6) else "lane"]
+    return max(1, min(max_gpus, -(-n_channels // knee)))
+
+
 def shard_channels(n_channels: int, world_size: int, rank: int) -> list[int]:
     """Contiguous, balanced split of channel indices 0..n_channels-1 over `world_size` ranks:
     the first (n_channels % world_size) ranks take one extra channel."""

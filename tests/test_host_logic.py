@@ -288,3 +288,29 @@ def test_skip_samples_rule():
     L2 = initSettings_GPS_L2C()
     L2.skipNumberOfBytes = 10
     assert track_params(L2, "GPS_L2C").skip_samples == 11        # GPS_L2C tracking.m:153 seeks without the -1
+
+
+def test_recommended_world_size_follows_the_closed_loop_sweep():
+    """sharding.recommended_world_size: one GPU up to the measured knee of the closed loop's epoch time (bench.py closed_loop_sweep),
+    then the fewest GPUs that bring every rank's share back under it; with a real-time requirement, the fewest GPUs whose share
+    the sweep's table runs fast enough."""
+    from cu_sdr_collection_amd import sharding as S
+    knee = S.CLOSED_LOOP_KNEE["GPS_L1CA"]
+    assert [S.recommended_world_size(n) for n in (0, 1, 12, knee)] == [1, 1, 1, 1]
+    assert S.recommended_world_size(knee + 1) == 2 and S.recommended_world_size(8 * knee) == 8 and S.recommended_world_size(100 * knee) == 8
+    assert S.recommended_world_size(64, "GPS_L5C") == 2 and S.recommended_world_size(64, "GAL_E5a") == S.recommended_world_size(64, "GPS_L5C")
+    assert S.recommended_world_size(64, "GPS_L1CA", max_gpus=2) == 2
+    pts = S.CLOSED_LOOP_US_PER_EPOCH["GPS_L1CA"]
+    for n, us in pts.items():
+        assert S.expected_us_per_epoch(n) == us
+    assert pts[12] == S.expected_us_per_epoch(3) < S.expected_us_per_epoch(36) < S.expected_us_per_epoch(400)
+    # 192 channels: one GPU runs them at 1000 / 19.7 = 50x real time; 100x needs shares of <= 24-48 channels
+    assert S.recommended_world_size(192, min_x_realtime=50) == 1
+    assert 2 <= S.recommended_world_size(192, min_x_realtime=100) <= 8
+    assert S.recommended_world_size(192, min_x_realtime=1e6) == 8
+    try:
+        S.recommended_world_size(-1)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("negative channel counts must be refused")
