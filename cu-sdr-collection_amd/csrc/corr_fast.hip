@@ -497,14 +497,33 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   }
 
   // ---- rotate into the absolute frame and reduce across the wavefront (DPP) ------------------------
+  // The lanes' sums (<= 288 samples each at 18 Msps) are float32; what they add up to is the block's float64 total in the
+  // reference (tracking.m:291-300).  A float32 tree over the 64 lanes rounds the prompt sum (tens of thousands, all lanes in phase)
+  // at 3e-3 per level - the largest error of the whole kernel - so the closed-loop instantiations, whose sums steer the next
+  // block's geometry, add the lanes in float64 (half_sum_f64: ~120 instructions per block, nothing against their latency);
+  // the batched replay keeps the float32 tree unless GC_FAST_F64_TOTALS is compiled in (measured cost: DESIGN.md 4.1).
+#ifndef GC_FAST_F64_TOTALS
+#define GC_FAST_F64_TOTALS 0
+#endif
+  constexpr bool kF64Tot = CL || DEVLOOP || GC_FAST_F64_TOTALS != 0;
   double* o = (p.splits == 1) ? p.out + lb * GC_OUT_STRIDE : p.partial + (lb * p.splits + split) * GC_OUT_STRIDE;
   float tot[ARMS * 6];
+  [[maybe_unused]] double totd[ARMS * 6];
 #pragma unroll
   for (int ar = 0; ar < ARMS; ++ar)
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
-      tot[ar * 6 + 2 * x] = wave_sum_lane63(wc * accr[ar][x] + ws * acci[ar][x]);
-      tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(wc * acci[ar][x] - ws * accr[ar][x]);
+      const float vr = wc * accr[ar][x] + ws * acci[ar][x], vi = wc * acci[ar][x] - ws * accr[ar][x];
+      if constexpr (kF64Tot) {
+        const double hr = half_sum_f64((double)vr), hi = half_sum_f64((double)vi);   // lanes 31 / 63: the halves' sums
+        totd[ar * 6 + 2 * x] = rl_f64(hr, 31) + rl_f64(hr, 63);
+        totd[ar * 6 + 2 * x + 1] = rl_f64(hi, 31) + rl_f64(hi, 63);
+        tot[ar * 6 + 2 * x] = (float)totd[ar * 6 + 2 * x];
+        tot[ar * 6 + 2 * x + 1] = (float)totd[ar * 6 + 2 * x + 1];
+      } else {
+        tot[ar * 6 + 2 * x] = wave_sum_lane63(vr);
+        tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(vi);
+      }
     }
   if constexpr (DEVLOOP) {
     // All-gather: every member posts its six partial sums as two messages {f, f, f, tag} into this epoch's half of the
@@ -588,22 +607,19 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   } else if (CL) {
     // lane v takes total v (broadcast from lane 63) and stores its 16-byte tagged record
     TaggedSlot* ts = p.tagged + (lb * p.splits + split) * GC_OUT_STRIDE;
-    float mine = 0.0f;
+    double mine = 0.0;  // (kF64Tot: every lane holds the float64 totals)
 #pragma unroll
-    for (int v = 0; v < ARMS * 6; ++v) {
-      const float t = rl_f(tot[v], 63);
-      mine = (lane == v) ? t : mine;
-    }
+    for (int v = 0; v < ARMS * 6; ++v) mine = (lane == v) ? totd[v] : mine;
     if (lane < ARMS * 6) {
       TaggedSlot rec;
-      rec.value = (lane < arms_here * 6) ? (double)mine : 0.0;
+      rec.value = (lane < arms_here * 6) ? mine : 0.0;
       rec.tag = p.notify_tag;
       rec.zero = 0u;
       *reinterpret_cast<uint4*>(ts + lane) = *reinterpret_cast<const uint4*>(&rec);
     }
   } else if (lane == 63) {
 #pragma unroll
-    for (int v = 0; v < ARMS * 6; ++v) o[v] = (v < arms_here * 6) ? (double)tot[v] : 0.0;
+    for (int v = 0; v < ARMS * 6; ++v) o[v] = (v < arms_here * 6) ? (kF64Tot ? totd[v] : (double)tot[v]) : 0.0;
     for (int v = ARMS * 6; v < GC_OUT_STRIDE; ++v) o[v] = 0.0;
   }
   }  // bpw loop
