@@ -181,3 +181,121 @@ def test_run_lines_executes_only_the_given_lines_of_a_file(tmp_path):
     with pytest.raises(mlab.MError) as e:
         I.run_lines(path, [(3, 4), (6, 6)], {"x": mlab.to_matlab(5.0)})
     assert "section.m:6" in str(e.value)
+
+
+# ---- numeric built-ins the fixtures and the oracle would otherwise share with ONE library routine -------------------------------
+# oracle/mlab's fir1 / filtfilt / fft / xcorr call SciPy / NumPy, and so does oracle/gnss_oracle.py: a wrong reading of MATLAB's
+# definition (or a library quirk) would be common to both sides of every fixture comparison.  Each is therefore checked here
+# against MATLAB's DOCUMENTED definition written out independently - closed forms and plain loops, no signal-processing library.
+def _sinc(x):
+    x = np.asarray(x, dtype=np.float64)
+    out = np.ones_like(x)
+    nz = x != 0
+    out[nz] = np.sin(np.pi * x[nz]) / (np.pi * x[nz])
+    return out
+
+
+def test_fir1_is_the_hamming_windowed_ideal_filter_scaled_at_the_passband_centre(tmp_path):
+    """fir1(n, [w1 w2]) (acquisition.m:56-58 calls fir1(700, ...)): ideal band-pass impulse response w2 sinc(w2 k) - w1 sinc(w1 k),
+    k = m - n/2, times hamming(n + 1) = 0.54 - 0.46 cos(2 pi m / n), scaled so that the magnitude response is exactly 1 at the
+    centre of the pass band (w1 + w2) / 2 (frequencies normalised to Nyquist = 1); fir1(n, w): low-pass, unit gain at DC."""
+    for order, w1, w2 in ((700, 0.2301, 0.7912), (50, 0.1, 0.35), (21, 0.4, 0.9)):
+        got = vec(run(tmp_path, f"r = fir1({order}, [{w1!r} {w2!r}]);"))
+        m = np.arange(order + 1, dtype=np.float64)
+        k = m - order / 2.0
+        h = (w2 * _sinc(w2 * k) - w1 * _sinc(w1 * k)) * (0.54 - 0.46 * np.cos(2.0 * np.pi * m / order))
+        f0 = (w1 + w2) / 2.0
+        h = h / abs(np.sum(h * np.exp(-1j * np.pi * f0 * m)))
+        assert got.shape == h.shape and np.max(np.abs(got - h)) < 1e-14, (order, np.max(np.abs(got - h)))
+    got = vec(run(tmp_path, "r = fir1(30, 0.25);"))
+    m = np.arange(31, dtype=np.float64)
+    h = 0.25 * _sinc(0.25 * (m - 15.0)) * (0.54 - 0.46 * np.cos(2.0 * np.pi * m / 30.0))
+    assert np.max(np.abs(got - h / np.sum(h))) < 1e-15
+
+
+def _filtfilt_by_hand(b, x):
+    """MATLAB's filtfilt(b, 1, x), as documented: the signal extended at both ends by nfact = 3 (nfilt - 1) samples reflected
+    about the end points (2 x(1) - x(nfact + 1 : -1 : 2) ...), filtered forwards with initial conditions that make the filter
+    start in steady state for the first extended sample, reversed, filtered again the same way, reversed and trimmed.  For an
+    FIR filter in transposed direct form II those initial conditions zi(k) = sum_{j >= k} b(j + 1), times the first sample, ARE a
+    signal that was constant at its first value before it began - which is how the loops below start."""
+    b = [float(v) for v in b]
+    nfact = 3 * (len(b) - 1)
+    ext = [2.0 * x[0] - x[i] for i in range(nfact, 0, -1)] + [float(v) for v in x] + [2.0 * x[-1] - x[-1 - i] for i in range(1, nfact + 1)]
+
+    def fir_from_steady_state(sig):
+        out = []
+        for n_ in range(len(sig)):
+            acc = 0.0
+            for k_, bk in enumerate(b):
+                acc += bk * (sig[n_ - k_] if n_ - k_ >= 0 else sig[0])
+            out.append(acc)
+        return out
+    y = fir_from_steady_state(ext)
+    y = fir_from_steady_state(y[::-1])[::-1]
+    return np.array(y[nfact:len(y) - nfact])
+
+
+def test_filtfilt_is_two_steady_state_fir_passes_over_the_odd_reflected_signal(tmp_path):
+    rng = np.random.default_rng(5)
+    for nb, nx in ((9, 120), (21, 200), (4, 40)):
+        b = rng.standard_normal(nb)
+        x = rng.standard_normal(nx) + 0.7           # a level: the start-up transient the initial conditions remove would show
+        body = "b = [" + " ".join(repr(float(v)) for v in b) + "];\nx = [" + " ".join(repr(float(v)) for v in x) + "];\nr = filtfilt(b, 1, x);"
+        got = vec(run(tmp_path, body))
+        want = _filtfilt_by_hand(b, x)
+        assert got.shape == want.shape and np.max(np.abs(got - want)) < 1e-11 * max(1.0, np.max(np.abs(want))), (nb, nx, np.max(np.abs(got - want)))
+    # a complex signal (longSignal is complex, acquisition.m:60) is filtered component by component
+    x = rng.standard_normal(64) + 1j * rng.standard_normal(64)
+    b = rng.standard_normal(7)
+    body = ("b = [" + " ".join(repr(float(v)) for v in b) + "];\nx = [" + " ".join(repr(float(v.real)) for v in x) + "] + 1i * [" +
+            " ".join(repr(float(v.imag)) for v in x) + "];\nr = filtfilt(b, 1, x);")
+    got = np.asarray(run(tmp_path, body)).reshape(-1)
+    want = _filtfilt_by_hand(b, x.real) + 1j * _filtfilt_by_hand(b, x.imag)
+    assert np.max(np.abs(got - want)) < 1e-11
+
+
+def _dft(x, sign):
+    """X[k] = sum_n x[n] exp(sign 2 pi i n k / N), term by term in float64; the angle is reduced with integer arithmetic
+    (n k mod N) so that no large argument reaches the exponential."""
+    n = x.shape[0]
+    idx = (np.arange(n)[:, None] * np.arange(n)[None, :]) % n
+    return (np.exp(sign * 2j * np.pi * idx / n) * x[None, :]).sum(axis=1)
+
+
+@pytest.mark.parametrize("n", [240, 1250, 36])
+def test_fft_and_ifft_are_the_textbook_sums_for_the_mixed_radix_sizes_the_searches_use(tmp_path, n):
+    """Y = fft(X): Y(k) = sum_j X(j) W^((j-1)(k-1)), W = exp(-2 pi i / n); X = ifft(Y): (1/n) sum_k Y(k) W^(-(j-1)(k-1)).  The
+    searches transform 36 000 = 2^5 3^2 5^3 (and 24 000, 144 000, ...) points: 240 = 2^4 3 5 and 1 250 = 2 5^4 run through the
+    same radix-2/3/5 code paths of the library the interpreter and the oracle share, against an O(n^2) sum that shares nothing."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    lit = "[" + " ".join(repr(float(v.real)) for v in x) + "] + 1i * [" + " ".join(repr(float(v.imag)) for v in x) + "]"
+    got = np.asarray(run(tmp_path, f"x = {lit};\nr = fft(x);")).reshape(-1)
+    want = _dft(x, -1.0)
+    assert np.max(np.abs(got - want)) < 1e-11 * np.max(np.abs(want))
+    got = np.asarray(run(tmp_path, f"x = {lit};\nr = ifft(x);")).reshape(-1)
+    assert np.max(np.abs(got - _dft(x, +1.0) / n)) < 1e-12
+    # zero padding: fft([c zeros(1, n)]) is what acquisition.m:160-162 transforms
+    got = np.asarray(run(tmp_path, f"x = {lit};\nr = fft([x zeros(1, {n})]);")).reshape(-1)
+    want = _dft(np.concatenate([x, np.zeros(n)]), -1.0)
+    assert np.max(np.abs(got - want)) < 1e-11 * np.max(np.abs(want))
+
+
+def test_xcorr_is_the_lag_sum_of_the_longer_length(tmp_path):
+    """c = xcorr(x, y): c(m + N) = sum_n x(n + m) conj(y(n)) for lags m = -(N - 1) .. N - 1, N = the longer length, the shorter
+    vector zero-padded (NAVdecoding.m correlates the bit stream with the preamble this way)."""
+    rng = np.random.default_rng(9)
+    x, y = rng.standard_normal(37), rng.standard_normal(11)
+    body = "x = [" + " ".join(repr(float(v)) for v in x) + "];\ny = [" + " ".join(repr(float(v)) for v in y) + "];\nr = xcorr(x, y);"
+    got = vec(run(tmp_path, body))
+    n = max(x.size, y.size)
+    xp, yp = np.concatenate([x, np.zeros(n - x.size)]), np.concatenate([y, np.zeros(n - y.size)])
+    want = []
+    for m in range(-(n - 1), n):
+        acc = 0.0
+        for k in range(n):
+            if 0 <= k + m < n:
+                acc += xp[k + m] * yp[k]
+        want.append(acc)
+    assert got.shape == (2 * n - 1,) and np.max(np.abs(got - np.array(want))) < 1e-12
