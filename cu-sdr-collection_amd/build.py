@@ -30,7 +30,10 @@ LIBDIR = os.path.join(HERE, "lib")
 INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
 
 LIBS = {
-    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip", "corr_lane.hip", "track.hip", "multi.hip", "stream.hip", "acq.hip", "navsync.hip"],
+    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip",
+                       # one source, four translation units (its 148 kernel instantiations took one compiler process 248 s): unit@MACRO=value
+                       "corr_lane.hip@GC_LANE_PART=0", "corr_lane.hip@GC_LANE_PART=1", "corr_lane.hip@GC_LANE_PART=2", "corr_lane.hip@GC_LANE_PART=3",
+                       "track.hip", "multi.hip", "stream.hip", "acq.hip", "navsync.hip"],
     "libgnsssynth.so": ["synth.hip"],
 }
 HEADERS = ["gc_internal.h", "corr_common.h", "devloop.h", os.path.join("..", "..", "include", "gnsscorr.h")]
@@ -72,15 +75,25 @@ def _sha_file(path: str) -> str:
     return h.hexdigest()
 
 
-def _tu_flags(src: str):
+def _unit(spec: str):
+    """(source file, extra -D flags, object base name) of a unit spec "file.hip" or "file.hip@MACRO=value"."""
+    src, _, macro = spec.partition("@")
+    base = os.path.splitext(src)[0]
+    if not macro:
+        return src, [], base
+    return src, ["-D" + macro], base + "_" + "".join(c if c.isalnum() else "_" for c in macro)
+
+
+def _tu_flags(spec: str):
+    src, defs, _ = _unit(spec)
     cflags = [f for f in FLAGS if f != "-shared"]
-    return cflags + (["-ffp-contract=off"] if src in NO_CONTRACT else [])
+    return cflags + (["-ffp-contract=off"] if src in NO_CONTRACT else []) + defs
 
 
 def source_hash(src: str, with_compiler: bool = True) -> str:
     """SHA-256 over a translation unit's inputs: its source, every shared header, its flags (and the compiler's version string)."""
     h = hashlib.sha256()
-    for p in [os.path.join(CSRC, src)] + [os.path.join(CSRC, x) for x in HEADERS]:
+    for p in [os.path.join(CSRC, _unit(src)[0])] + [os.path.join(CSRC, x) for x in HEADERS]:
         h.update(os.path.basename(p).encode() + b"\0" + _sha_file(p).encode() + b"\0")
     h.update(" ".join(_tu_flags(src)).encode())
     if with_compiler:
@@ -106,20 +119,20 @@ def build(force: bool = False, verbose: bool = True) -> dict:
     libs = info.setdefault("libs", {})
     t_all = time.time()
     for lib, srcs in LIBS.items():
-        missing = [s for s in srcs if not os.path.exists(os.path.join(CSRC, s))]
+        missing = [s for s in srcs if not os.path.exists(os.path.join(CSRC, _unit(s)[0]))]
         if missing:
             raise RuntimeError(f"missing sources for {lib}: {missing}")
         target = os.path.join(LIBDIR, lib)
         # one object per translation unit, compiled in parallel (the kernels are heavily templated), then linked
         jobs, rebuilt = [], False
         for s in srcs:
-            obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+            obj = os.path.join(objdir, _unit(s)[2] + ".o")
             want = source_hash(s)
             have = units.get(s, {})
             if not force and os.path.exists(obj) and have.get("inputs_sha256") == want and have.get("object_sha256") == _sha_file(obj):
                 jobs.append((s, obj, want, None, None, 0.0))
                 continue
-            cmd = [_hipcc(), *_tu_flags(s), "-c", os.path.join(CSRC, s), "-o", obj]
+            cmd = [_hipcc(), *_tu_flags(s), "-c", os.path.join(CSRC, _unit(s)[0]), "-o", obj]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             jobs.append((s, obj, want, cmd, subprocess.Popen(cmd, cwd=CSRC), time.time()))

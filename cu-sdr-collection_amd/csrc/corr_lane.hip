@@ -847,6 +847,15 @@ template __global__ void corr_epl_lane_kernel<2, I8_IQ, false, 1, true>(const KA
 template __global__ void corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>(const KArgs, const InlineBlocks);
 }  // namespace
 #else
+// The 148 instantiations (arms x record format x closed loop x table kind, + the persistent ones) took one compiler process
+// 248 s.  The build compiles this file four times instead (cu_sdr_collection_amd/build.py): GC_LANE_PART = 1, 2, 3 hold the
+// kernels of one-, two- and three-arm channels behind the gc_lane_part_* entry points below, GC_LANE_PART = 0 the dispatchers
+// (no kernel).  Without the macro everything is in one unit (scripts/variants.sh, scripts/lane_probe.sh).
+#ifndef GC_LANE_PART
+#define GC_LANE_PART (-1)
+#endif
+#define GC_LANE_HAS(part) (GC_LANE_PART == -1 || GC_LANE_PART == (part))
+
 template <typename K>
 void launch_one(gc_context* ctx, K kernel, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem) {
   if (smem > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
@@ -868,14 +877,14 @@ void launch_tab(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 gr
   }
 }
 
+int record_mode(const gc_context* ctx) {
+  if (ctx->if_dtype == GC_I8) return ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
+  return ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
+}
+
 template <int ARMS>
 int launch_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, int tabkind) {
-  int mode;
-  if (ctx->if_dtype == GC_I8)
-    mode = ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
-  else
-    mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
-  switch (mode) {
+  switch (record_mode(ctx)) {
     case I8_IQ: launch_tab<ARMS, I8_IQ>(ctx, a, ib, grid, smem, tabkind); break;
     case I8_QI: launch_tab<ARMS, I8_QI>(ctx, a, ib, grid, smem, tabkind); break;
     case I16_IQ: launch_tab<ARMS, I16_IQ>(ctx, a, ib, grid, smem, tabkind); break;
@@ -887,17 +896,92 @@ int launch_mode(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, dim3 gr
   return GC_OK;
 }
 
-template <int ARMS, int MODE>
-int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share, int waves) {
+int launch_persistent_fn(gc_context* ctx, const void* fn, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, int waves) {
   void* args[2] = {(void*)&a, (void*)&ib};
-  const void* fn = share ? (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 1, true> : (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 0, true>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   GC_PERSIST(gc_launch_persistent(ctx, fn, grid, dim3(waves * 64), args, (unsigned int)smem));
   return GC_OK;
 }
 
+template <int ARMS, int MODE>
+int launch_lane_devloop(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 grid, size_t smem, bool share, int waves) {
+  const void* fn = share ? (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 1, true> : (const void*)corr_epl_lane_kernel<ARMS, MODE, false, 0, true>;
+  return launch_persistent_fn(ctx, fn, a, ib, grid, smem, waves);
+}
+
+// the persistent instantiations of ARMS-arm channels: f32 tables for every record format, f16 tables (half) for int8 I/Q and Q/I
+template <int ARMS>
+int launch_devloop_arms(gc_context* ctx, KArgs& a, const InlineBlocks& ib, dim3 g, size_t smem, bool share_el, int waves, bool half) {
+  const bool qi = ctx->if_layout == GC_QI;
+  if (half)
+    return launch_persistent_fn(ctx, qi ? (const void*)corr_epl_lane_kernel<ARMS, I8_QI, false, 2, true> : (const void*)corr_epl_lane_kernel<ARMS, I8_IQ, false, 2, true>,
+                                a, ib, g, smem, waves);
+  switch (record_mode(ctx)) {
+    case I8_IQ: return launch_lane_devloop<ARMS, I8_IQ>(ctx, a, ib, g, smem, share_el, waves);
+    case I8_QI: return launch_lane_devloop<ARMS, I8_QI>(ctx, a, ib, g, smem, share_el, waves);
+    case I16_IQ: return launch_lane_devloop<ARMS, I16_IQ>(ctx, a, ib, g, smem, share_el, waves);
+    case I16_QI: return launch_lane_devloop<ARMS, I16_QI>(ctx, a, ib, g, smem, share_el, waves);
+    case I8_REAL: return launch_lane_devloop<ARMS, I8_REAL>(ctx, a, ib, g, smem, share_el, waves);
+    default: return launch_lane_devloop<ARMS, I16_REAL>(ctx, a, ib, g, smem, share_el, waves);
+  }
+}
+
 }  // namespace
 
+// ---- entry points of the parts (one-, two-, three-arm kernels) ----------------------------------------------------------------
+int gc_lane_part_mode1(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, int tabkind);
+int gc_lane_part_mode2(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, int tabkind);
+int gc_lane_part_mode3(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, int tabkind);
+int gc_lane_part_devloop1(gc_context* ctx, KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, bool share_el, int waves, bool half);
+int gc_lane_part_devloop2(gc_context* ctx, KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, bool share_el, int waves, bool half);
+int gc_lane_part_derived(gc_context* ctx, KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, bool half, bool devloop, int waves);
+
+#if GC_LANE_HAS(1)
+int gc_lane_part_mode1(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, int tabkind) {
+  return launch_mode<1>(ctx, a, ib, dim3(grid), smem, tabkind);
+}
+int gc_lane_part_devloop1(gc_context* ctx, KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, bool share_el, int waves, bool half) {
+  return launch_devloop_arms<1>(ctx, a, ib, dim3(grid), smem, share_el, waves, half);
+}
+#endif
+#if GC_LANE_HAS(2)
+int gc_lane_part_mode2(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, int tabkind) {
+  return launch_mode<2>(ctx, a, ib, dim3(grid), smem, tabkind);
+}
+int gc_lane_part_devloop2(gc_context* ctx, KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, bool share_el, int waves, bool half) {
+  return launch_devloop_arms<2>(ctx, a, ib, dim3(grid), smem, share_el, waves, half);
+}
+#endif
+#if GC_LANE_HAS(3)
+int gc_lane_part_mode3(gc_context* ctx, const KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, int tabkind) {
+  return launch_mode<3>(ctx, a, ib, dim3(grid), smem, tabkind);
+}
+// three arms, the third derived from the second (int8 I/Q or Q/I records): f32 or f16 (half) tables; launch per call or persistent
+int gc_lane_part_derived(gc_context* ctx, KArgs& a, const InlineBlocks& ib, unsigned int grid, size_t smem, bool half, bool devloop, int waves) {
+  const bool qi = ctx->if_layout == GC_QI;
+  if (devloop) {
+    const void* fn = half ? (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 2, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 2, true, true>)
+                          : (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 0, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>);
+    return launch_persistent_fn(ctx, fn, a, ib, dim3(grid), smem, waves);
+  }
+  const bool cl = a.tagged != nullptr, h = half;
+  if (qi) {
+    if (cl && h) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 2, false, true>, a, ib, dim3(grid), smem);
+    else if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 0, false, true>, a, ib, dim3(grid), smem);
+    else if (h) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, false, 2, false, true>, a, ib, dim3(grid), smem);
+    else launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, false, 0, false, true>, a, ib, dim3(grid), smem);
+  } else {
+    if (cl && h) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 2, false, true>, a, ib, dim3(grid), smem);
+    else if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 0, false, true>, a, ib, dim3(grid), smem);
+    else if (h) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, false, 2, false, true>, a, ib, dim3(grid), smem);
+    else launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, false, 0, false, true>, a, ib, dim3(grid), smem);
+  }
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}
+#endif
+
+#if GC_LANE_HAS(0)
 // Persistent tracker with device-side loop closure on the lane kernel: grid = channel slots x a.splits member workgroups.
 // f32 tables only (<= 96 KiB), int8 I/Q or Q/I records, one or two arms.
 int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid, int max_arms, bool share_el, int waves) {
@@ -921,48 +1005,10 @@ int gc_launch_devloop_lane(gc_context* ctx, const KArgs& a_in, unsigned int grid
   a.red_off = (int)tab_bytes;
   a.rho_off = (int)(tab_bytes + kLW * GC_OUT_STRIDE * sizeof(double) + 128 + 64 * sizeof(double));  // a multiple of 16
   const size_t smem = (size_t)a.rho_off + (size_t)kLW * kRhoPerWave * sizeof(float2);
-  const bool qi = ctx->if_layout == GC_QI;
   if (waves < 1 || waves > kLW) return GC_E_INVALID;
-  if (der) {
-    void* args[2] = {(void*)&a, (void*)&ib};
-    const void* fn = half_tables ? (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 2, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 2, true, true>)
-                                 : (qi ? (const void*)corr_epl_lane_kernel<3, I8_QI, false, 0, true, true> : (const void*)corr_epl_lane_kernel<3, I8_IQ, false, 0, true, true>);
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    GC_PERSIST(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
-    return GC_OK;
-  }
-  if (half_tables) {  // f16 tables: int8 I/Q and Q/I
-    void* args[2] = {(void*)&a, (void*)&ib};
-    const void* fn = max_arms == 1 ? (qi ? (const void*)corr_epl_lane_kernel<1, I8_QI, false, 2, true> : (const void*)corr_epl_lane_kernel<1, I8_IQ, false, 2, true>)
-                                   : (qi ? (const void*)corr_epl_lane_kernel<2, I8_QI, false, 2, true> : (const void*)corr_epl_lane_kernel<2, I8_IQ, false, 2, true>);
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    GC_PERSIST(gc_launch_persistent(ctx, fn, dim3(grid), dim3(waves * 64), args, (unsigned int)smem));
-    return GC_OK;
-  }
-  int mode;
-  if (ctx->if_dtype == GC_I8)
-    mode = ctx->if_layout == GC_IQ ? I8_IQ : ctx->if_layout == GC_QI ? I8_QI : I8_REAL;
-  else
-    mode = ctx->if_layout == GC_IQ ? I16_IQ : ctx->if_layout == GC_QI ? I16_QI : I16_REAL;
-  const dim3 g(grid);
-  if (max_arms == 1) {
-    switch (mode) {
-      case I8_IQ: return launch_lane_devloop<1, I8_IQ>(ctx, a, ib, g, smem, share_el, waves);
-      case I8_QI: return launch_lane_devloop<1, I8_QI>(ctx, a, ib, g, smem, share_el, waves);
-      case I16_IQ: return launch_lane_devloop<1, I16_IQ>(ctx, a, ib, g, smem, share_el, waves);
-      case I16_QI: return launch_lane_devloop<1, I16_QI>(ctx, a, ib, g, smem, share_el, waves);
-      case I8_REAL: return launch_lane_devloop<1, I8_REAL>(ctx, a, ib, g, smem, share_el, waves);
-      default: return launch_lane_devloop<1, I16_REAL>(ctx, a, ib, g, smem, share_el, waves);
-    }
-  }
-  switch (mode) {
-    case I8_IQ: return launch_lane_devloop<2, I8_IQ>(ctx, a, ib, g, smem, share_el, waves);
-    case I8_QI: return launch_lane_devloop<2, I8_QI>(ctx, a, ib, g, smem, share_el, waves);
-    case I16_IQ: return launch_lane_devloop<2, I16_IQ>(ctx, a, ib, g, smem, share_el, waves);
-    case I16_QI: return launch_lane_devloop<2, I16_QI>(ctx, a, ib, g, smem, share_el, waves);
-    case I8_REAL: return launch_lane_devloop<2, I8_REAL>(ctx, a, ib, g, smem, share_el, waves);
-    default: return launch_lane_devloop<2, I16_REAL>(ctx, a, ib, g, smem, share_el, waves);
-  }
+  if (der) return gc_lane_part_derived(ctx, a, ib, grid, smem, half_tables, true, waves);
+  if (max_arms == 1) return gc_lane_part_devloop1(ctx, a, ib, grid, smem, share_el, waves, half_tables);
+  return gc_lane_part_devloop2(ctx, a, ib, grid, smem, share_el, waves, half_tables);
 }
 
 // share_el: every block of the launch has 2*el_spacing*R*M an exact positive integer
@@ -1001,26 +1047,14 @@ int gc_launch_correlator_lane(gc_context* ctx, const KArgs& a_in, const InlineBl
       gc_set_error("internal: derived-arm launch with %d arms / table kind %d", max_arms, tabkind);
       return GC_E_INVALID;
     }
-    const bool cl = a.tagged != nullptr, qi = ctx->if_layout == GC_QI, h = tabkind == 2;
-    if (qi) {
-      if (cl && h) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 2, false, true>, a, ib, dim3(grid), smem);
-      else if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, true, 0, false, true>, a, ib, dim3(grid), smem);
-      else if (h) launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, false, 2, false, true>, a, ib, dim3(grid), smem);
-      else launch_one(ctx, corr_epl_lane_kernel<3, I8_QI, false, 0, false, true>, a, ib, dim3(grid), smem);
-    } else {
-      if (cl && h) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 2, false, true>, a, ib, dim3(grid), smem);
-      else if (cl) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, true, 0, false, true>, a, ib, dim3(grid), smem);
-      else if (h) launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, false, 2, false, true>, a, ib, dim3(grid), smem);
-      else launch_one(ctx, corr_epl_lane_kernel<3, I8_IQ, false, 0, false, true>, a, ib, dim3(grid), smem);
-    }
-    GC_HIP(hipGetLastError());
-    return GC_OK;
+    return gc_lane_part_derived(ctx, a, ib, grid, smem, tabkind == 2, false, 0);
   }
   switch (max_arms) {
-    case 1: return launch_mode<1>(ctx, a, ib, dim3(grid), smem, tabkind);
-    case 2: return launch_mode<2>(ctx, a, ib, dim3(grid), smem, tabkind);
-    default: return launch_mode<3>(ctx, a, ib, dim3(grid), smem, tabkind);
+    case 1: return gc_lane_part_mode1(ctx, a, ib, grid, smem, tabkind);
+    case 2: return gc_lane_part_mode2(ctx, a, ib, grid, smem, tabkind);
+    default: return gc_lane_part_mode3(ctx, a, ib, grid, smem, tabkind);
   }
 }
+#endif  // dispatchers
 
 #endif  // GC_LANE_PROBE
