@@ -53,23 +53,31 @@ def _rolled(sec_bytes: bytes, n: int) -> np.ndarray:
     return m
 
 
-def _circular_code_search(sums: np.ndarray, sec: np.ndarray) -> float:
+def _circular_code_search(sums: np.ndarray, sec: np.ndarray):
     """max over the len(sec) circular shifts of |sum(sumPerCode .* circshift(sec, k))| (GPS_L5C acquisition.m:243-248); all shifts
-    in one product with the rolled-code matrix (the loop of 100 np.roll per fine bin was 0.27 of Galileo E5a's 0.28 s per search)."""
+    in one product with the rolled-code matrix (the loop of 100 np.roll per fine bin was 0.27 of Galileo E5a's 0.28 s per search).
+    `sums`: [ncodes] -> float, or [nbins, ncodes] (every fine bin at once) -> [nbins]."""
     sec = np.ascontiguousarray(sec, dtype=np.float64)
-    return float(np.max(np.abs(_rolled(sec.tobytes(), sec.shape[0]) @ sums)))
+    m = _rolled(sec.tobytes(), sec.shape[0])
+    if sums.ndim == 2:
+        return np.max(np.abs(sums @ m.T), axis=1)
+    return float(np.max(np.abs(m @ sums)))
 
 
-def _split_code_search(sums: np.ndarray, sec: np.ndarray) -> float:
+def _split_code_search(sums: np.ndarray, sec: np.ndarray):
     """GAL_E1C acquisition.m:237-245 / BDS B3I acquisition.m:262-270: the secondary code aligned, then every
-    circular shift k = 1..len-1 with the sum SPLIT at the possible data-bit edge: |sum(1:k)| + |sum(k+1:end)|."""
+    circular shift k = 1..len-1 with the sum SPLIT at the possible data-bit edge: |sum(1:k)| + |sum(k+1:end)|.
+    `sums`: [ncodes] -> float, or [nbins, ncodes] -> [nbins]."""
     sec = np.ascontiguousarray(sec, dtype=np.float64)
     n = sec.shape[0]
-    cs = np.cumsum(_rolled(sec.tobytes(), n) * sums[None, :], axis=1)          # cs[k, j] = sum(t_k[:j + 1])
-    total = cs[:, -1]
+    one = sums.ndim == 1
+    x = sums[None, :] if one else sums
+    cs = np.cumsum(_rolled(sec.tobytes(), n)[None, :, :] * x[:, None, :], axis=2)    # cs[b, k, j] = sum(t_k[:j + 1]) of bin b
+    total = cs[:, :, -1]
     k = np.arange(1, n)
-    head = cs[k, k - 1]
-    return float(max(abs(total[0]), np.max(np.abs(head) + np.abs(total[1:] - head))))
+    head = cs[:, k, k - 1]
+    out = np.maximum(np.abs(total[:, 0]), np.max(np.abs(head) + np.abs(total[:, 1:] - head), axis=1))
+    return float(out[0]) if one else out
 
 
 def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, fine_step, combine, n_results=32,
@@ -122,7 +130,8 @@ def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, 
                                   code_len=int(fine_code_len or settings.codeLength), index_offset=index_offset,
                                   source=src)
             sums = [engine.acquire_fine_sums(fp, c) for c in fine_codes(prn)]       # each [nfine, ncodes]
-            fine = np.array([combine(prn, [s[k] for s in sums]) for k in range(nfine)])
+            fine = np.asarray(combine(prn, sums), dtype=np.float64)                  # the hypothesis search of every fine bin at once
+            assert fine.shape == (nfine,), fine.shape
             f = fp.f0 - fine_step * int(np.argmax(fine))
             acq.carrFreq[prn - 1] = f if f != 0 else 1
     if resampled:                                  # back to the record's rate and IF (GPS_L5C acquisition.m:293-305)
@@ -164,7 +173,7 @@ def acquisition_B2a(engine, settings, first_sample: int | None = None, n_long: i
     return _family_a(engine, settings, first_sample,
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)],
                      lambda prn: [codes.generateB2aDataCode(prn), codes.generateB2aPilotCode(prn)], ncodes, 25.0,
-                     lambda prn, s: float(np.sum(np.abs(s[0])) + np.sum(np.abs(s[1]))),
+                     lambda prn, s: np.sum(np.abs(s[0]), axis=-1) + np.sum(np.abs(s[1]), axis=-1),
                      n_results=int(max(settings.acqSatelliteList)),   # BDS/B2a acquisition.m:139 zeros(1, max(acqSatelliteList))
                      bandwidth=settings.codeFreqBasis * 2 + 0.5e6, n_long=n_long, band_margin=0.002)   # BW: :60, wp: :64
 
@@ -179,11 +188,12 @@ def acquisition_E5b(engine, settings, first_sample: int | None = None, n_long: i
 def _b3i_combine(prn, s):
     """BDS/B3I/include/acquisition.m:252-271: GEO satellites (PRN 1-5, 59-63; 2-ms D2 symbols) — the better of the two
     pairings of adjacent codes; MEO/IGSO (PRN 6-58) — NH20 with the split-sum search."""
-    x = s[0]
+    x = s[0]                                         # [nbins, 20] (or [20])
     if 1 <= prn <= 5 or 59 <= prn <= 63:
-        p1 = float(np.sum(np.abs(x.reshape(10, 2).sum(axis=1))))
-        p2 = float(np.sum(np.abs(x[[0, 19]])) + np.sum(np.abs(x[1:19].reshape(9, 2).sum(axis=1))))
-        return max(p1, p2)
+        lead = x.shape[:-1]
+        p1 = np.sum(np.abs(x.reshape(lead + (10, 2)).sum(axis=-1)), axis=-1)
+        p2 = np.sum(np.abs(x[..., [0, 19]]), axis=-1) + np.sum(np.abs(x[..., 1:19].reshape(lead + (9, 2)).sum(axis=-1)), axis=-1)
+        return np.maximum(p1, p2)
     return _split_code_search(x, NH20)
 
 
@@ -285,7 +295,9 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None, n_long: i
                                   first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=40, nbins=nfine, code_len=40 * spc,
                                   index_offset=0, source=src)
             sums = engine.acquire_fine_sums(fp, code40)                                                                # [nfine, 40]
-            fine = np.array([max(abs(np.sum(s[c:c + 10]) - np.sum(s[c + 10:c + 20])) for c in range(20)) for s in sums])   # :180-185
+            cs = np.concatenate([np.zeros((sums.shape[0], 1), dtype=sums.dtype), np.cumsum(sums, axis=1)], axis=1)         # cs[:, j] = sum(s[:j])
+            c = np.arange(20)
+            fine = np.max(np.abs(2.0 * cs[:, c + 10] - cs[:, c] - cs[:, c + 20]), axis=1)      # :180-185 |sum(10 codes) - sum(next 10)| at 20 alignments
             acq.carrFreq[K + 7] = float(fp.f0 - 25.0 * int(np.argmax(fine)))
             acq.codePhase[K + 7] = r.code_phase
             if acq.carrFreq[K + 7] == 0:                                                                               # :263-265

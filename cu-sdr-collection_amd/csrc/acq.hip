@@ -1601,6 +1601,15 @@ struct AcqScratch {
   float* results = nullptr;   // nbins * n
   float* partial = nullptr;   // hop-group sums of the last inverse pass (launch_pass)
   size_t partial_cap = 0;
+  // second lane of the PRN loop (gc_acquire_coarse_multi): odd PRNs run on a stream of their own with their own intermediates, so one
+  // PRN's columns pass fills the device while the next PRN's rows pass drains (and the other way round)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  float2* tmp2 = nullptr;
+  float* results2 = nullptr;
+  float* partial2 = nullptr;
+  size_t partial2_cap = 0;
+  int lane = 0;               // the lane the launches under way belong to (launch_abs_pass picks its partial buffer by it)
   int8_t* codes = nullptr;    // nprn * spc
   size_t codes_cap = 0;
   long long* sums = nullptr;  // 3 + scratch for argmax
@@ -1621,9 +1630,13 @@ struct AcqScratch {
 
 void free_scratch(AcqScratch* s) {
   if (!s) return;
-  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->rowmax, s->rowarg, s->peaks, s->slots};
+  void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->rowmax, s->rowarg, s->peaks, s->slots,
+                  s->tmp2, s->results2, s->partial2};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (s->stream2) (void)hipStreamDestroy(s->stream2);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   delete s;
 }
 
@@ -1654,12 +1667,13 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
       const int per = (int)((long long)(a.nvec / c1) * nbins);  // the specialised kernel's grid
       const size_t want = (size_t)nprn * per * 2;
       if (s->slots_cap < want) {
-        GC_HIP(hipStreamSynchronize(ctx->stream));
+        GC_HIP(hipDeviceSynchronize());  // (both lanes of the PRN loop: the buffer is theirs together)
         if (s->slots) (void)hipFree(s->slots);
         s->slots = nullptr;
         s->slots_cap = 0;
         GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
-        GC_HIP(hipMemsetAsync(s->slots, 0, want * sizeof(unsigned long long), ctx->stream));
+        GC_HIP(hipMemset(s->slots, 0, want * sizeof(unsigned long long)));
+        GC_HIP(hipDeviceSynchronize());
         s->slots_cap = want;
       }
       s->slots_per_prn = per;
@@ -1677,15 +1691,17 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
     return GC_OK;
   }
   const size_t need = (size_t)hg * (size_t)nbins * (size_t)a.n;
-  if (s->partial_cap < need) {
-    GC_HIP(hipStreamSynchronize(ctx->stream));
-    if (s->partial) (void)hipFree(s->partial);
-    s->partial = nullptr;
-    s->partial_cap = 0;
-    GC_HIP(hipMalloc((void**)&s->partial, need * sizeof(float)));
-    s->partial_cap = need;
+  float*& part = s->lane ? s->partial2 : s->partial;
+  size_t& part_cap = s->lane ? s->partial2_cap : s->partial_cap;
+  if (part_cap < need) {
+    GC_HIP(hipDeviceSynchronize());
+    if (part) (void)hipFree(part);
+    part = nullptr;
+    part_cap = 0;
+    GC_HIP(hipMalloc((void**)&part, need * sizeof(float)));
+    part_cap = need;
   }
-  a.acc_part = s->partial;
+  a.acc_part = part;
   a.acc_bins = (int)nbins;
   int rc = launch_pass(ctx, a, nbins * hg);
   if (rc) return rc;
@@ -1694,18 +1710,19 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
     const int per = (int)(pgrid.x * pgrid.y);
     const size_t want = (size_t)nprn * per * 2;
     if (s->slots_cap < want) {
-      GC_HIP(hipStreamSynchronize(ctx->stream));
+      GC_HIP(hipDeviceSynchronize());  // (both lanes of the PRN loop: the buffer is theirs together)
       if (s->slots) (void)hipFree(s->slots);
       s->slots = nullptr;
       s->slots_cap = 0;
       GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
-      GC_HIP(hipMemsetAsync(s->slots, 0, want * sizeof(unsigned long long), ctx->stream));
+      GC_HIP(hipMemset(s->slots, 0, want * sizeof(unsigned long long)));
+      GC_HIP(hipDeviceSynchronize());
       s->slots_cap = want;
     }
     s->slots_per_prn = per;
     region = s->slots + (size_t)ip * per * 2;
   }
-  hipLaunchKernelGGL(abs_combine_kernel, pgrid, dim3(256), 0, ctx->stream, s->partial, hg, (int)nbins, a.n, a.acc_out, a.acc_add,
+  hipLaunchKernelGGL(abs_combine_kernel, pgrid, dim3(256), 0, ctx->stream, part, hg, (int)nbins, a.n, a.acc_out, a.acc_add,
                      1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, region, valid);
   GC_HIP(hipGetLastError());
   return GC_OK;
@@ -1966,7 +1983,38 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       if (g >= 1 && H % g == 0) row_reps = g;
     }
   }
-  for (int ip = 0; ip < nprn && !fused; ++ip) {
+  // Two lanes: even PRNs on the context's stream, odd PRNs on a second one with intermediates of their own (GC_ACQ_LANES=1: one lane).
+  // A PRN is three dependent launches (rows pass, columns pass, combine) of a few thousand workgroups each: alone, every launch
+  // ends in a tail of half-empty CUs and starts after a gap; two independent chains fill each other's.
+  int lanes = (nprn > 1 && !fused) ? 2 : 1;
+  if (const char* e = std::getenv("GC_ACQ_LANES")) lanes = std::max(1, std::min(2, std::atoi(e)));
+  if (lanes == 2) {
+    const size_t ne = (size_t)pl.n;
+    if (!s->stream2) {
+      if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
+        lanes = 1;
+    }
+    if (lanes == 2 && !s->tmp2 &&
+        (hipMalloc((void**)&s->tmp2, (size_t)s->nbh * ne * sizeof(float2)) != hipSuccess ||
+         hipMalloc((void**)&s->results2, (size_t)s->nbins * ne * sizeof(float)) != hipSuccess)) {
+      (void)hipGetLastError();
+      if (s->tmp2) (void)hipFree(s->tmp2);
+      s->tmp2 = nullptr;
+      lanes = 1;  // no room for a second set of intermediates: one lane
+    }
+  }
+  hipStream_t const stream1 = ctx->stream;
+  if (lanes == 2) {
+    GC_HIP(hipEventRecord(s->ev_fork, stream1));  // spectra, code spectra and the cleared keys are ready
+    GC_HIP(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+  }
+  int lane_rc = GC_OK;
+  for (int ip = 0; ip < nprn && !fused && lane_rc == GC_OK; ++ip) {
+    s->lane = lanes == 2 ? (ip & 1) : 0;
+    ctx->stream = s->lane ? s->stream2 : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
+    float2* const tmp = s->lane ? s->tmp2 : s->tmp;
+    float* const results = s->lane ? s->results2 : s->results;
     for (int arm = 0; arm < narms; ++arm) {
       // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
       PassArgs a = base;
@@ -1986,12 +2034,15 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.n1 = pl.n1;
       a.n2 = pl.n2;
       a.other = s->codespec + ((size_t)ip * narms + arm) * pl.n;
-      a.out = s->tmp;
+      a.out = tmp;
       a.out_batch_stride = pl.n;
       a.out_blocked = hblock;  // the intermediate in the columns pass's tile order
       a.row_reps = row_reps;
       rc = launch_pass(ctx, a, (long long)nbins * H / row_reps);
-      if (rc) return rc;
+      if (rc) {
+        lane_rc = rc;
+        break;
+      }
       // I2: columns (length n1, stride n2), inverse, |.|/n accumulated over the hops of each bin
       a.out_blocked = 0;
       a.row_reps = 0;
@@ -2003,13 +2054,26 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.cols = choose_cols(a.len, a.estride);
       a.pre = PRE_NONE;
       a.post = POST_ABS_ACC;
-      a.in = s->tmp;
-      a.acc_out = s->results;
+      a.in = tmp;
+      a.acc_out = results;
       a.acc_add = arm > 0;
       a.acc_scale = (float)p->arm_weight[arm];  // 0: 1
       rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr, blk, ip, nprn);
-      if (rc) return rc;
+      if (rc) {
+        lane_rc = rc;
+        break;
+      }
     }
+  }
+  ctx->stream = stream1;
+  s->lane = 0;
+  if (lanes == 2) {  // the second lane joins before the keys are reduced and read back (also on an error: nothing may still run on it)
+    (void)hipEventRecord(s->ev_join, s->stream2);
+    (void)hipStreamWaitEvent(stream1, s->ev_join, 0);
+  }
+  if (lane_rc != GC_OK) {
+    (void)hipDeviceSynchronize();
+    return lane_rc;
   }
   if (!fused && s->slots_per_prn) {
     hipLaunchKernelGGL(keys_reduce_kernel, dim3((unsigned int)nprn), dim3(256), 0, ctx->stream, s->slots, s->slots_per_prn, peaks);
