@@ -636,7 +636,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
 // flips folded into the butterflies.  launch_pass picks it for the shapes listed in GC_CT_SHAPES (the FFT sizes of the
 // reference's default front ends) and falls back to the generic kernel for everything else; GC_ACQ_GENERIC=1 forces the
 // generic kernel.
-template <int R, int L, int C, int NS, bool INV>
+// LP: pitch of a tile row of dst in LDS (L, or L + 1 in the fused-I/O columns pass); SP > 0: the SOURCE rows carry one pad element after
+// every 2^SP (element i at i + (i >> SP), pitch SLP) - what a fused first stage of radix 2^SP leaves (stage_first_ct)
+template <int R, int L, int C, int NS, bool INV, int LP = L, int SP = 0, int SLP = LP>
 __device__ __forceinline__ void stage_ct(const float2* __restrict__ src, float2* __restrict__ dst, const float2* __restrict__ twl,
                                          unsigned tid) {
   constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
@@ -647,19 +649,77 @@ __device__ __forceinline__ void stage_ct(const float2* __restrict__ src, float2*
     if ((it + 1) * kFftThreads > NB && b >= NB) break;
     const unsigned c = b / LR, j = b - c * LR;
     const unsigned k = NS == 1 ? 0u : j % (unsigned)NS;
-    const float2* s = src + c * L + j;
+    const float2* s = src + c * SLP;
+    auto at = [&](unsigned i) -> float2 { return SP > 0 ? s[i + (i >> SP)] : s[i]; };
     float2 vq[R], oq[R];
-    vq[0] = s[0];
+    vq[0] = at(j);
 #pragma unroll
     for (int q = 1; q < R; ++q) {
-      float2 x = s[q * LR];
-      if constexpr (NS > 1) x = cmul(x, twl[k * (R - 1) + q - 1]);  // row k = 0 holds ones
+      float2 x = at(j + q * LR);
+      if constexpr (NS > 1) x = cmul(x, twl[(q - 1) * NS + k]);  // [q][k]: the lanes of a wave read consecutive k (k = 0 holds ones)
       vq[q] = x;
     }
     butterfly<R>(vq, sign, oq);
-    float2* d = dst + c * L + (j - k) * R + k;
+    float2* d = dst + c * LP + (j - k) * R + k;
 #pragma unroll
     for (int q = 0; q < R; ++q) d[q * NS] = oq[q];
+  }
+}
+
+// Fused-I/O passes (GC_ACQ_FUSE_IO): the FIRST stage takes its inputs straight from memory (no store of the loaded tile into LDS and
+// read back), the LAST stage hands its outputs to the pass's epilogue in registers (no store of the finished tile and read back):
+// four LDS accesses per element of a three-stage pass instead of eight.  The passes of the search were LDS-bound: 8.0 / 6.3 LDS
+// instructions per element at 2.0-2.5 bank-conflict cycles each (profiles/r03) are ~39 us of LDS time per launch against ~25 us of VALU.
+// in(c, e) -> element e of the tile's vector c.  CFAST: consecutive threads take consecutive VECTORS of one butterfly index (the
+// blocked intermediate of the columns pass is stored vector-fastest: one contiguous run per wave-load), the tile rows then sit LP = L + 1
+// apart so that the radix-R groups the threads write do not pile onto a few banks.
+// PAD: a thread's R outputs are followed by one pad element (row pitch LP = L + L / R): with R = 8 the threads' 64-byte groups
+// would otherwise start 16 banks apart - two bank groups for 64 lanes, four conflict cycles per store.
+template <int R, int L, int LP, int C, bool INV, bool CFAST, bool PAD, class F>
+__device__ __forceinline__ void stage_first_ct(F&& in, float2* __restrict__ dst, unsigned tid) {
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+  constexpr float sign = INV ? -1.0f : 1.0f;
+#pragma unroll
+  for (unsigned it = 0; it < ITERS; ++it) {
+    const unsigned b = tid + it * kFftThreads;
+    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    unsigned c, j;
+    if constexpr (CFAST) {
+      j = b / C;
+      c = b - j * C;
+    } else {
+      c = b / LR;
+      j = b - c * LR;
+    }
+    float2 vq[R], oq[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) vq[q] = in(it, q, c, j + q * LR);
+    butterfly<R>(vq, sign, oq);
+    float2* d = dst + c * LP + j * (PAD ? R + 1 : R);
+#pragma unroll
+    for (int q = 0; q < R; ++q) d[q] = oq[q];
+  }
+}
+
+// the last stage (NS = L / R: k = j): out(it, q, c, e, value) receives element e = j + q * NS of vector c
+template <int R, int L, int LP, int C, bool INV, int SP, class F>
+__device__ __forceinline__ void stage_last_ct(const float2* __restrict__ src, const float2* __restrict__ twl, unsigned tid, F&& out) {
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+  constexpr float sign = INV ? -1.0f : 1.0f;
+#pragma unroll
+  for (unsigned it = 0; it < ITERS; ++it) {
+    const unsigned b = tid + it * kFftThreads;
+    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    const unsigned c = b / LR, j = b - c * LR;
+    const float2* s = src + c * LP;
+    auto at = [&](unsigned i) -> float2 { return SP > 0 ? s[i + (i >> SP)] : s[i]; };
+    float2 vq[R], oq[R];
+    vq[0] = at(j);
+#pragma unroll
+    for (int q = 1; q < R; ++q) vq[q] = cmul(at(j + q * LR), twl[(q - 1) * LR + j]);
+    butterfly<R>(vq, sign, oq);
+#pragma unroll
+    for (int q = 0; q < R; ++q) out(it, q, c, j + q * LR, oq[q]);
   }
 }
 
@@ -667,10 +727,12 @@ __device__ __forceinline__ void stage_ct(const float2* __restrict__ src, float2*
 template <int R, int NS, int N, bool INV>
 __device__ __forceinline__ void stage_twiddles_ct(const float2* __restrict__ tw, float2* twl, unsigned tid) {
   if constexpr (R > 1 && NS > 1) {
+    // stored [q - 1][k] (not [k][q - 1]): a butterfly's lanes have consecutive k, and R - 1 = 4 values of 8 bytes per k put every
+    // fourth lane on the same banks - 2.7 / 4.0 conflict cycles per LDS instruction of the rows / columns pass (profiles/r04)
     constexpr unsigned CNT = NS * (R - 1), TWS = N / (NS * R);
     static_assert(N % (NS * R) == 0, "stage size divides the transform size");
     for (unsigned i = tid; i < CNT; i += kFftThreads) {
-      const unsigned k = i / (R - 1), q = i % (R - 1) + 1;
+      const unsigned q = i / NS + 1, k = i - (q - 1) * NS;
       float2 w = tw[k * q * TWS];
       if (INV) w.y = -w.y;
       twl[i] = w;
@@ -689,8 +751,20 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   constexpr unsigned T1 = R1 > 1 ? NS1 * (R1 - 1) : 0, T2 = R2 > 1 ? NS2 * (R2 - 1) : 0, T3 = R3 > 1 ? NS3 * (R3 - 1) : 0;
   constexpr int NST = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
   constexpr unsigned EH = ((L - 1) >> 4) + 1, TW2 = EH + 16;
-  __shared__ __attribute__((aligned(16))) float2 buf0[NEL];
-  __shared__ __attribute__((aligned(16))) float2 buf1[NEL];
+#ifndef GC_ACQ_FUSE_IO
+#define GC_ACQ_FUSE_IO 1
+#endif
+  // the two hot passes of the search - rows (product with the code spectrum -> twiddle) and columns (-> |.| summed over the hops) - with
+  // their first stage fed from memory and their last stage feeding the epilogue (stage_first_ct / stage_last_ct)
+  constexpr bool FUSE = GC_ACQ_FUSE_IO != 0 && NST >= 2 &&
+                        ((PRE == PRE_MUL_CONJ && POST == POST_TWIDDLE) || (PRE == PRE_NONE && POST == POST_ABS_ACC));
+  constexpr unsigned LP = (FUSE && !CONTIG) ? L + 1 : L;  // row pitch of the tile in LDS
+  // fused rows pass with a first stage of radix 8 (or 4): its output rows are padded (stage_first_ct PAD), read back through SP1
+  constexpr bool PAD1 = FUSE && CONTIG && (R0 == 8 || R0 == 4);
+  constexpr int SP1 = PAD1 ? (R0 == 8 ? 3 : 2) : 0;
+  constexpr unsigned LP1 = PAD1 ? L + L / R0 : LP;  // pitch of buf1's rows while they hold the first stage's output
+  __shared__ __attribute__((aligned(16))) float2 buf0[C * LP];
+  __shared__ __attribute__((aligned(16))) float2 buf1[C * LP1];
   __shared__ float2 twl[T1 + T2 + T3 + 1];
   __shared__ float2 tw2[POST == POST_TWIDDLE ? C * TW2 : 1];
   const unsigned tid = threadIdx.x;
@@ -728,6 +802,152 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   float accv[SLOTS];
 #pragma unroll
   for (unsigned k = 0; k < SLOTS; ++k) accv[k] = 0.f;
+
+  if constexpr (FUSE) {
+    constexpr int RL = R3 > 1 ? R3 : R2 > 1 ? R2 : R1;  // the last stage's radix; its inputs are L / RL apart
+    constexpr unsigned LR0 = L / R0, NB0 = LR0 * C, IT0 = (NB0 + kFftThreads - 1) / kFftThreads;
+    constexpr unsigned NBL = (L / RL) * C, ITL = (NBL + kFftThreads - 1) / kFftThreads;
+    const float2* const twl_last = R3 > 1 ? twl + T1 + T2 : R2 > 1 ? twl + T1 : twl;
+    [[maybe_unused]] float acc2[POST == POST_ABS_ACC ? ITL : 1][POST == POST_ABS_ACC ? RL : 1];
+    if constexpr (POST == POST_ABS_ACC) {
+#pragma unroll
+      for (unsigned i = 0; i < ITL; ++i)
+#pragma unroll
+        for (int q = 0; q < RL; ++q) acc2[i][q] = 0.f;
+    }
+    // rows pass that walks several hops of one bin: where each of the thread's inputs comes from and the code-spectrum value it is
+    // multiplied with do not depend on the hop
+    [[maybe_unused]] unsigned fr_src[RR ? IT0 : 1][RR ? R0 : 1];
+    [[maybe_unused]] float2 fr_oth[RR ? IT0 : 1][RR ? R0 : 1];
+    if constexpr (RR) {
+      const long long tb0 = (long long)batch * reps;
+      const unsigned sft = a.shift_q > 0 ? (unsigned)(tb0 / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
+      const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
+#pragma unroll
+      for (unsigned it = 0; it < IT0; ++it) {
+        const unsigned b = tid + it * kFftThreads;
+        if ((it + 1) * kFftThreads > NB0 && b >= NB0) break;
+        const unsigned c = b / LR0, j = b - c * LR0;
+        int k1 = (int)(v0 + c) - (int)s1;
+        const int bor = k1 < 0;
+        k1 += bor ? OTHER : 0;
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+          const unsigned e = j + q * LR0;
+          int e2 = (int)e - (int)s2 - bor;
+          e2 += e2 < 0 ? L : 0;
+          fr_src[RR ? it : 0][RR ? q : 0] = (unsigned)(k1 * L + e2);
+          fr_oth[RR ? it : 0][RR ? q : 0] = a.other[(v0 + c) * L + e];
+        }
+      }
+    }
+    for (int rep = 0; rep < reps; ++rep) {
+      const long long tb = POST == POST_ABS_ACC ? (long long)batch * a.nhops + (long long)hg * reps + rep
+                           : RR                 ? (long long)batch * reps + rep
+                                                : (long long)batch;
+      [[maybe_unused]] long long shsrc = 0;
+      [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
+      if constexpr (SHIFT) {
+        const unsigned sft = a.shift_q > 0 ? (unsigned)(tb / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
+        shsrc = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
+        sh2 = sft / OTHER;
+        sh1 = sft - sh2 * OTHER;
+      }
+      // ---- first stage, inputs from memory ---------------------------------------------------------------------------
+      if constexpr (PRE == PRE_MUL_CONJ) {
+        const float2* __restrict__ src = a.in + (SHIFT ? shsrc : tb) * a.in_batch_stride;
+        stage_first_ct<R0, L, LP1, C, INV, false, PAD1>(
+            [&](unsigned it, int q, unsigned c, unsigned e) -> float2 {
+              float2 val, o;
+              if constexpr (RR) {
+                val = src[fr_src[it][q]];
+                o = fr_oth[it][q];
+              } else {
+                const unsigned pos = (v0 + c) * L + e;
+                if constexpr (SHIFT) {
+                  int k1 = (int)(v0 + c) - (int)sh1;
+                  const int bor = k1 < 0;
+                  k1 += bor ? OTHER : 0;
+                  int e2 = (int)e - (int)sh2 - bor;
+                  e2 += e2 < 0 ? L : 0;
+                  val = src[k1 * L + e2];
+                } else {
+                  val = src[pos];
+                }
+                o = a.other[pos];
+              }
+              return make_float2(val.x * o.x + val.y * o.y, val.y * o.x - val.x * o.y);
+            },
+            buf1, tid);
+      } else {
+        const float2* __restrict__ src = a.in + tb * a.in_batch_stride;
+        const bool blocked = a.in_blocked != 0;
+        stage_first_ct<R0, L, LP1, C, INV, true, false>(
+            [&](unsigned, int, unsigned c, unsigned e) -> float2 {
+              // blocked: this tile's L x C values vector-fastest (e * C + c: consecutive threads, consecutive addresses)
+              return src[blocked ? tile * NEL + e * C + c : e * ESTR + (v0 + c) * VSTR];
+            },
+            buf1, tid);
+      }
+      __syncthreads();
+      // ---- middle stages: buf1 -> buf0 (-> buf1) ------------------------------------------------------------------------
+      if constexpr (NST >= 3) {
+        stage_ct<R1, L, C, NS1, INV, LP, SP1, LP1>(buf1, buf0, twl, tid);
+        __syncthreads();
+      }
+      if constexpr (NST >= 4) {
+        stage_ct<R2, L, C, NS2, INV, LP>(buf0, buf1, twl + T1, tid);
+        __syncthreads();
+      }
+      const float2* lsrc = (NST == 3) ? buf0 : buf1;
+      constexpr int SPL_ = NST == 2 ? SP1 : 0;            // two stages: the last one reads the first one's padded rows
+      constexpr unsigned LPL = NST == 2 ? LP1 : LP;
+      // ---- last stage, outputs to the epilogue in registers ---------------------------------------------------------------
+      if constexpr (POST == POST_TWIDDLE) {
+        float2* __restrict__ dstp = a.out + tb * a.out_batch_stride;
+        const unsigned obl = (unsigned)a.out_blocked;
+        stage_last_ct<RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned, int, unsigned c, unsigned e, float2 val) {
+          val = cmul(val, cmul(tw2[c * TW2 + (e >> 4)], tw2[c * TW2 + EH + (e & 15)]));
+          unsigned pos = (v0 + c) * L + e;
+          if (obl) {
+            const unsigned sh = obl - 1u, eb = e >> sh;
+            pos = eb * (OTHER << sh) + ((v0 + c) << sh) + (e - (eb << sh));
+          }
+          dstp[pos] = val;
+        });
+      } else {
+        stage_last_ct<RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned it, int q, unsigned, unsigned, float2 val) {
+          acc2[it][q] += sqrtf(val.x * val.x + val.y * val.y);
+        });
+      }
+      // two stages: the last one read buf1, which the next hop's first stage writes
+      if constexpr (NST == 2 || NST == 4) __syncthreads();
+    }
+    if constexpr (POST == POST_ABS_ACC) {
+      // the sums, held per (iteration, output) of the last stage, through LDS into the order of the tile in memory (once per launch)
+      float* fbuf = reinterpret_cast<float*>(buf1);
+      __syncthreads();
+      {
+        constexpr unsigned LRL = L / RL;
+#pragma unroll
+        for (unsigned it = 0; it < ITL; ++it) {
+          const unsigned b = tid + it * kFftThreads;
+          if ((it + 1) * kFftThreads > NBL && b >= NBL) break;
+          const unsigned c = b / LRL, j = b - c * LRL;
+#pragma unroll
+          for (int q = 0; q < RL; ++q) fbuf[c * L + j + q * LRL] = acc2[it][q];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (unsigned slot = 0; slot < SLOTS; ++slot) {
+        const unsigned idx = tid + slot * kFftThreads;
+        if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+        const unsigned e = idx / C, c = idx - e * C;
+        accv[slot] = fbuf[c * L + e];
+      }
+    }
+  } else {
 
   // RR: everything of the load that does not depend on the hop - where in the source spectrum each of the thread's values comes
   // from (the rotation by the bin's shift) and the code-spectrum value it is multiplied with - is worked out once
@@ -888,6 +1108,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
     // load orders this hop's reads of buf1 before the next first stage writes it)
     if constexpr ((POST == POST_ABS_ACC || RR) && !(NST & 1)) __syncthreads();
   }
+  }  // !FUSE
   if constexpr (POST == POST_ABS_ACC) {
     const float inv_n = 1.0f / (float)N, scale = a.acc_scale != 0.0f ? a.acc_scale : 1.0f;
     PeakTrack pk;
