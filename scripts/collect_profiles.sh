@@ -21,7 +21,7 @@ done
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/l1ca_pmc_sq" -- python /root/repo/bench.py --config l1ca --no-cpu --steps 4 --warmup 1 > /dev/null 2>&1
 if [ "${2:-}" != "quick" ]; then
   # the other BASELINE shapes (scripts/prof_shapes.py: one replay kernel per shape)
-  for shape in l5 cboc e1x8 b1c l1ca3; do
+  for shape in l5 b2a cboc e1x8 e1 b1c b1i l1ca3; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${shape}_stats" -- python /root/repo/scripts/prof_shapes.py $shape 5 6 > "$OUT/${shape}.txt" 2>&1
     timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${shape}_pmc_FETCH_SIZE" -- python /root/repo/scripts/prof_shapes.py $shape 5 4 > /dev/null 2>&1
     timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/${shape}_pmc_sq" -- python /root/repo/scripts/prof_shapes.py $shape 5 4 > /dev/null 2>&1
@@ -30,6 +30,9 @@ if [ "${2:-}" != "quick" ]; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/acq_stats" -- python /root/repo/scripts/acq_time.py > "$OUT/acq.txt" 2>&1
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$OUT/acq_pmc_sq" -- python /root/repo/scripts/acq_time.py > /dev/null 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/acq_pmc_FETCH_SIZE" -- python /root/repo/scripts/acq_time.py > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/acq_pmc_WRITE_SIZE" -- python /root/repo/scripts/acq_time.py > /dev/null 2>&1
+  # the twelve default-size searches (bench.py acquisition.packages) under the kernel trace
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/acqpkg_stats" -- python /root/repo/scripts/acq_packages.py > "$OUT/acq_packages.json" 2>/dev/null
 fi
 cd /root/repo
 for d in "$OUT"/*/; do

@@ -53,13 +53,14 @@ except OSError:
     lib_sha = bench.get("libgnsscorr_sha256")
 traffic, lines = [], ["# digest of " + src + " (" + build + ")", ""]
 shapes = [("l1ca", "corr_epl_fast_kernel", bench["config"]["blocks_per_step"], None)]
-for s in ("l5", "cboc", "e1x8", "b1c", "l1ca3"):
+for s in ("l5", "b2a", "cboc", "e1x8", "e1", "b1c", "b1i", "l1ca3"):
     t = os.path.join(src, s + ".txt")
     if os.path.exists(t):
         m = re.search(r"\{'shape'.*\}", open(t).read())
         if m:
             d = eval(m.group(0))
-            shapes.append((s, "corr_epl_lane_kernel" if "lane" in d["kernel"] else "corr_epl_fast_kernel", None, d))
+            kn = d["kernel"]
+            shapes.append((s, "corr_epl_multi_kernel" if "multi" in kn else "corr_epl_lane_kernel" if "lane" in kn else "corr_epl_fast_kernel", None, d))
 lines.append("| workload | replay kernel (grid) | launches | avg ms (profiler) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes / launch | VALU instr per channel-sample | LDS instr per channel-sample | VALU-active share of wave cycles | instruction-wait share of wave cycles |")
 lines.append("|---|---|---|---|---|---|---|---|---|---|---|")
 for name, want, blocks, d in shapes:
@@ -77,7 +78,7 @@ for name, want, blocks, d in shapes:
     cs = (12 * 59998 * 18000.0 * bench["config"]["blocks_per_step"] / (12 * 59998)) if name == "l1ca" else d["channel_samples_per_launch"]
     valu = sc[ks]["SQ_INSTS_VALU"][0] * 64 / cs if ks and "SQ_INSTS_VALU" in sc[ks] else None
     lds = sc[ks]["SQ_INSTS_LDS"][0] * 64 / cs if ks and "SQ_INSTS_LDS" in sc[ks] else None
-    kd = replay_kernel(st, want)
+    kd = k if k in st else replay_kernel(st, want)     # the same grid as the counter passes' row (bench.py's other legs replay other grids)
     calls, avg = (st[kd][0], st[kd][1] / 1e6) if kd else (None, None)
     wc = sc[ks].get("SQ_WAVE_CYCLES", (None,))[0] if ks else None
     act = sc[ks].get("SQ_ACTIVE_INST_VALU", (None,))[0] if ks else None
@@ -106,6 +107,8 @@ for k, (calls, avg, mn) in sorted(ad.items(), key=lambda kv: -kv[1][0] * kv[1][1
     v = c.get("SQ_INSTS_VALU", (None,))[0]
     l = c.get("SQ_INSTS_LDS", (None,))[0]
     b = c.get("SQ_LDS_BANK_CONFLICT", (None,))[0]
+    if "fft_pass" not in k[0] and "fine_multi" not in k[0] and "abs_combine" not in k[0]:
+        continue
     # elements a launch transforms: one LDS tile (2000 or 1440 elements) per workgroup; the passes of the inverse transform walk
     # several hops per workgroup, whatever their number a launch covers every (bin, hop) of the search
     per_prn_pass = ", 0, 2, true" in k[0] or ", 3, 1, true" in k[0]  # the inverse transform's two passes (columns + |.|; shifted rows, several hops per workgroup)
