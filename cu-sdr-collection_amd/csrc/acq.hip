@@ -410,7 +410,8 @@ struct PeakTrack {
       if (kb > __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[1], kb);
     }
   }
-  // the same candidate as a plain store into this workgroup's own slot (keys_reduce_kernel picks them up)
+  // the same candidate as a plain store into this workgroup's own slot (keys_reduce_kernel picks them up).  Thread 0 of EVERY
+  // workgroup stores unconditionally (zeros when it saw nothing): the slot buffer is cleared only when it is allocated
   __device__ __forceinline__ void publish_slot(unsigned long long* slot) const {
     unsigned long long ka, kb;
     if (reduce(ka, kb)) {
@@ -1819,7 +1820,8 @@ struct AcqScratch {
   float2* sig = nullptr;      // nbh * n   signal spectra, layout [k1][k2]
   float2* tmp = nullptr;      // nbh * n   scratch between passes
   float2* codespec = nullptr; // nprn * n
-  float* results = nullptr;   // nbins * n
+  float* results = nullptr;   // nbins * n: sums of a PRN's earlier code arms (what its last arm adds to).  NOT the finished results of a search:
+                              // the last arm of a PRN feeds nothing but its peak keys and is not written back (abs_combine_kernel, fft_pass_ct)
   float* partial = nullptr;   // hop-group sums of the last inverse pass (launch_pass)
   size_t partial_cap = 0;
   // second lane of the PRN loop (gc_acquire_coarse_multi): odd PRNs run on a stream of their own with their own intermediates, so one

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
     const int arms0 = chn0->arms;
     int nent[LA];
     const void* pre = kF16 ? (const void*)chn0->tabh : (const void*)chn0->tabf;
-    bool plain = pre != nullptr && (kF16 ? chn0->tabh_ap : chn0->tabf_ap) == AP;  // pre-interleaved copy usable as is
+    // pre-interleaved copy usable as is: the same pitch AND the same layout - a derived channel's f32 image is {arm 0, arm 1,
+    // arm 1 * (-1)^entry, 0}, which has the pitch of a genuine three-arm image {arm 0, arm 1, arm 2, 0}: the host routes such
+    // channels to the DER instantiation (validate_blocks), this check makes a mix-up impossible instead of silent
+    bool plain = pre != nullptr && (kF16 ? chn0->tabh_ap : chn0->tabf_ap) == AP && (kF16 || (chn0->derived != 0) == DER);
 #pragma unroll
     for (int a = 0; a < LA; ++a) {
       nent[a] = 0;
@@ -432,7 +435,9 @@ __global__ __launch_bounds__(DEVLOOP ? 8 * 64 : kLW * 64)  // device loop: at mo
         }
       const float mine = wave_transpose_sum<ARMS * 6>(turned, lane);  // the wave's total of component `slot` in this lane
       const int slot = wave_transpose_slot(lane);
-      if (slot < ARMS * 6) totw[slot] += (double)mine;
+      // lanes L and L ^ 32 hold the same slot and the same total after the transposing sum: one of them owns the float64 add
+      // (both doing it is the same read-modify-write of one address, right only while the wave runs in lock step)
+      if (slot < ARMS * 6 && lane < 32) totw[slot] += (double)mine;
     };
     // returns the entry of the last LDS arm (the one a derived arm is built from)
     auto accumulate = [&](int x, int k, float yr, float yi) __attribute__((always_inline)) -> float {

@@ -60,8 +60,12 @@ struct ResidentGrid {
 std::mutex g_ledger_mu;
 std::vector<ResidentGrid> g_ledger[64];
 
+// XCDs of the device: 8 on MI300X / MI355X (256-304 CUs); smaller parts are treated as one XCD per 32 CUs (the model only needs an upper
+// bound of the workgroups that can meet on one XCD)
+int xcds_of(int cus) { return cus >= 128 ? 8 : std::max(1, cus / 32); }
+
 bool ledger_fits(const std::vector<ResidentGrid>& set, const ResidentGrid& add, int cus) {
-  const double cu_per_xcd = std::max(1, cus / 8);
+  const double cu_per_xcd = std::max(1, cus / xcds_of(cus));
   double load = (double)add.wg_per_xcd / add.occ, rmax = 1.0 / add.occ;
   long long wgs = add.wg_per_xcd;
   for (const ResidentGrid& g : set) {
@@ -84,7 +88,8 @@ hipError_t gc_launch_persistent(gc_context* ctx, const void* fn, dim3 grid, dim3
   if (e != hipSuccess) return e;
   if (const char* ev = std::getenv("GC_PERSIST_OCC")) occ = std::min(occ, std::atoi(ev));  // tests: pretend the kernel needs more of a CU
   if (occ < 1) return hipErrorCooperativeLaunchTooLarge;
-  const ResidentGrid mine{ctx, (int)((grid.x + 7) / 8), occ};
+  const int nx = xcds_of(ctx->compute_units);
+  const ResidentGrid mine{ctx, (int)((grid.x + nx - 1) / nx), occ};
   std::lock_guard<std::mutex> lock(g_ledger_mu);
   std::vector<ResidentGrid>& set = g_ledger[ctx->device];
   set.erase(std::remove_if(set.begin(), set.end(), [&](const ResidentGrid& g) { return g.ctx == ctx; }), set.end());

@@ -297,7 +297,10 @@ typedef struct gc_track_job {
 } gc_track_job;
 
 /* Runs every job's tracking loop concurrently (one host thread per job for the loop closure, tracking.m:302-335) and
- * returns when all are done: GC_OK, or the first failure (a short read only if nothing worse happened). */
+ * returns when all are done: GC_OK, or the first failure (a short read only if nothing worse happened).
+ * The jobs' persistent kernels are admitted by a per-device ledger that knows THIS process' kernels only: other processes that
+ * run persistent kernels on the same GPU at the same time (several ranks pinned to one device) are invisible to it - serialise
+ * their tracking calls (bench.py does, with a file lock) or give every process its own GPU. */
 int gc_track_multi(int njobs, gc_track_job* jobs);
 
 /* ---- acquisition (replaces acquisition.m:151-254, resampling off) ------------------- */
@@ -482,8 +485,9 @@ int gc_debug_last_kernel(const gc_context* ctx);
 
 /* Test hook: how the last gc_track / gc_track_device call on this context ran its loop: 0 a correlator launch per epoch,
  * 1 the persistent host-fed kernel, 2 the device loop; -1 before the first call.  A persistent kernel needs all its workgroups
- * resident: next to other contexts' persistent kernels (gc_track_multi) a grid that does not fit the device together with
- * those in flight is refused and the call runs with a launch per epoch instead (same records). */
+ * resident: a grid that does not fit the device (many channels), or does not fit it together with other contexts' persistent
+ * kernels in flight (gc_track_multi), is retried with half as many workgroups per channel until it fits; only a grid that no
+ * team size brings under the limit runs with a launch per epoch instead (same records). */
 int gc_debug_last_track_mode(const gc_context* ctx);
 /* Test hook for the lane kernel's flush (csrc/corr_common.h: wave_transpose_sum): `k` (1..32) vectors of 64 floats, in[v * 64 + lane];
  * out[v] = the sum over the 64 lanes as the one-wave transposing reduction forms it (the tree's own order of additions). */

@@ -406,6 +406,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
        from what the context prepared (gc_acq_shift_dims), never from the caller's numbers: the library writes `rows` values and
        reads n * narms code samples whatever the arguments say. */
     int32_t n = 0, nrows = 0, amax = 0;
+    if (nrhs < 3) mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search: handle and codes are needed");
     if (gc_acq_shift_dims(handle(prhs[1]), &n, &nrows, &amax)) fail("gc_acq_shift_dims");
     const int narms = (int)mxGetN(prhs[2]);
     if (!mxIsInt8(prhs[2]) || (int32_t)mxGetM(prhs[2]) != n || narms < 1 || narms > amax)

