@@ -171,6 +171,8 @@ struct PassArgs {
   // (94 bins x 144 000 columns = 54 MB per PRN in the Galileo E1 search: 45 us of the 190 us a PRN took)
   unsigned long long* peak_slots;
   int peak_valid;
+  // first batch of the launch (fft_pass_ct): gc_acq_shift_row recomputes ONE row of a search whose results were not written
+  int batch0;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
   const unsigned tile = bid % TILES;
   const unsigned bb = bid / TILES;
   const unsigned HG = (POST == POST_ABS_ACC && a.hop_groups > 1) ? (unsigned)a.hop_groups : 1u;
-  const unsigned batch = bb / HG, hg = bb - batch * HG;
+  const unsigned hg = bb % HG, batch = bb / HG + (unsigned)a.batch0;
   const unsigned v0 = tile * C;
   constexpr bool RR = SHIFT && POST != POST_ABS_ACC;  // rows pass that may walk several hops of its bin (PassArgs::row_reps)
   const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : (RR && a.row_reps > 1 && a.shift_q > 0) ? a.row_reps : 1;
@@ -1136,7 +1138,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
         }
       }
     }
-    if (HG == 1 && a.peak_slots) pk.publish_slot(a.peak_slots + 2 * (size_t)blockIdx.x);
+    if (HG == 1 && a.peak_slots) pk.publish_slot(a.peak_slots + 2 * (size_t)bid);  // bid: the workgroup's (tile, batch) after the XCD pairing, not blockIdx.x
   }
 }
 
@@ -1687,6 +1689,20 @@ __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict_
 }
 
 // One workgroup per row: maximum and its first position (MATLAB's max returns the first maximum).
+// Row maxima of a circshift search from the per-workgroup candidates its last pass left (PeakTrack::publish_slot: every workgroup of
+// that pass belongs to ONE row; key = value bits << 32 | ~column, so the largest key is the row's maximum at its first column):
+// one wave per row.  Replaces writing rows x N sums and reading them back (GPS L2C: 1 GB each way per PRN).
+__global__ __launch_bounds__(64) void rowkeys_reduce_kernel(const unsigned long long* __restrict__ slots, int tiles, float* vmax, int* amax) {
+  const unsigned long long* mine = slots + (size_t)blockIdx.x * tiles * 2;
+  unsigned long long k = 0;
+  for (int i = threadIdx.x; i < tiles; i += 64) k = max(k, mine[2 * i + 1]);
+  for (int off = 32; off > 0; off >>= 1) k = max(k, (unsigned long long)__shfl_xor((long long)k, off, 64));
+  if (threadIdx.x == 0) {
+    vmax[blockIdx.x] = __uint_as_float((unsigned int)(k >> 32));
+    amax[blockIdx.x] = (int)(0xffffffffu - (unsigned int)(k & 0xffffffffu));
+  }
+}
+
 __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r, int ncols, int stride, float* vmax, int* amax) {
   __shared__ float sv[256];
   __shared__ int si[256];
@@ -1833,6 +1849,11 @@ struct AcqScratch {
   float* partial2 = nullptr;
   size_t partial2_cap = 0;
   int lane = 0;               // the lane the launches under way belong to (launch_abs_pass picks its partial buffer by it)
+  // circshift search with the row maxima taken inside the last pass (gc_acq_shift_search): `results` holds nothing then and
+  // gc_acq_shift_row transforms the row it is asked for again, with the arms and weights of the search
+  bool shift_rows_fused = false;
+  int shift_narms = 0;
+  double shift_weight[4] = {1.0, 1.0, 1.0, 1.0};
   int8_t* codes = nullptr;    // nprn * spc
   size_t codes_cap = 0;
   long long* sums = nullptr;  // 3 + scratch for argmax
@@ -1867,7 +1888,8 @@ void free_scratch(AcqScratch* s) {
 // walking all nhops hops of its bin: the hops are then split over hop groups (a divisor of nhops), whose raw sums meet in
 // abs_combine_kernel - deterministic, group order fixed.
 int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr, int valid = 0,
-                    int ip = 0, int nprn = 1) {
+                    int ip = 0, int nprn = 1, bool* rows_fused = nullptr) {
+  if (rows_fused) *rows_fused = false;
   if (valid <= 0) valid = a.n;
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   int hg = 1;
@@ -1885,6 +1907,33 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
     // last arm of a PRN on a specialised pass kernel: every workgroup leaves its own peak candidate (fft_pass_ct), reduced into the
     // keys after the last PRN like the hop-grouped path's; the generic pass kernel writes the results and peak_kernel reads them
     const int c1 = ct_columns_tile(a.len, a.nvec);
+    if (rows_fused && c1 > 0 && a.hop_groups <= 1 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_ROWMAX_KERNEL")) {
+      // circshift search, last arm: per-workgroup candidates (tiles of one row each) instead of the sums themselves
+      const int tiles_ct = a.nvec / c1;
+      const size_t want = (size_t)nbins * tiles_ct * 2;
+      if (s->slots_cap < want) {
+        GC_HIP(hipDeviceSynchronize());
+        if (s->slots) (void)hipFree(s->slots);
+        s->slots = nullptr;
+        s->slots_cap = 0;
+        GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
+        GC_HIP(hipMemset(s->slots, 0, want * sizeof(unsigned long long)));
+        GC_HIP(hipDeviceSynchronize());
+        s->slots_cap = want;
+      }
+      a.peak_slots = s->slots;
+      a.peak_valid = valid;
+      bool used_ct = false;
+      int rc = launch_pass(ctx, a, nbins, &used_ct);
+      a.peak_slots = nullptr;
+      if (rc) return rc;
+      if (used_ct) {
+        hipLaunchKernelGGL(rowkeys_reduce_kernel, dim3((unsigned int)nbins), dim3(64), 0, ctx->stream, s->slots, tiles_ct, s->rowmax, s->rowarg);
+        GC_HIP(hipGetLastError());
+        *rows_fused = true;
+      }
+      return GC_OK;  // (the generic kernel ignored the slots and wrote the sums: the caller runs rowmax_kernel)
+    }
     const bool fused_peak = keys && c1 > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL");
     if (fused_peak) {
       const int per = (int)((long long)(a.nvec / c1) * nbins);  // the specialised kernel's grid
@@ -2733,11 +2782,17 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.acc_out = s->results;
     a.acc_add = arm > 0;
     a.acc_scale = arm_weight ? (float)arm_weight[arm] : 1.0f;
-    rc = launch_abs_pass(ctx, s, a, rows);
+    bool fused_rows = false;
+    rc = launch_abs_pass(ctx, s, a, rows, nullptr, p.n, 0, 1, arm == narms - 1 ? &fused_rows : nullptr);
     if (rc) return rc;
+    s->shift_rows_fused = fused_rows;
   }
-  hipLaunchKernelGGL(rowmax_kernel, dim3(rows), dim3(256), 0, ctx->stream, s->results, p.n, pl.n, s->rowmax, s->rowarg);
-  GC_HIP(hipGetLastError());
+  s->shift_narms = narms;
+  for (int arm = 0; arm < 4; ++arm) s->shift_weight[arm] = (arm_weight && arm < narms) ? arm_weight[arm] : 1.0;
+  if (!s->shift_rows_fused) {
+    hipLaunchKernelGGL(rowmax_kernel, dim3(rows), dim3(256), 0, ctx->stream, s->results, p.n, pl.n, s->rowmax, s->rowarg);
+    GC_HIP(hipGetLastError());
+  }
   if (!s->shift_padded) {
     GC_HIP(hipMemcpyAsync(row_max, s->rowmax, sizeof(float) * rows, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipMemcpyAsync(row_argmax, s->rowarg, sizeof(int) * rows, hipMemcpyDeviceToHost, ctx->stream));
@@ -2775,7 +2830,57 @@ extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
     return GC_E_INVALID;
   }
   GC_HIP(hipSetDevice(ctx->device));
-  const size_t at = s->shift_padded ? (size_t)shift_internal_row(s->shift, row) * (size_t)s->n : (size_t)row * s->shift.n;
+  const int irow = s->shift_padded ? shift_internal_row(s->shift, row) : row;
+  const size_t at = (size_t)irow * (size_t)s->n;
+  if (s->shift_rows_fused) {
+    // the search kept only the row maxima: this row's inverse transforms again (one batch per pass; the code spectra of the search are
+    // still in place), every arm with its weight, into the row's place in `results`
+    const gc_acq_shift_params& p = s->shift;
+    const Plan& pl = s->plan;
+    PassArgs base;
+    std::memset(&base, 0, sizeof base);
+    base.spc = p.n;
+    base.nhops = 1;
+    for (int arm = 0; arm < s->shift_narms; ++arm) {
+      PassArgs a = base;
+      a.n = pl.n;
+      a.tw = s->tw;
+      a.inverse = 1;
+      fill_sub(a, pl.p2);
+      a.nvec = pl.n1;
+      a.estride = 1;
+      a.vstride = pl.n2;
+      a.cols = choose_cols(a.len, a.estride);
+      a.pre = PRE_MUL_CONJ;
+      a.post = POST_TWIDDLE;
+      a.in = s->sig;
+      a.in_batch_stride = pl.n;
+      a.other = s->codespec + (size_t)arm * pl.n;
+      a.out = s->tmp;
+      a.out_batch_stride = pl.n;
+      a.shift_bins = s->shift_padded ? 0 : p.n_bins;
+      a.n1 = pl.n1;
+      a.n2 = pl.n2;
+      a.batch0 = irow;
+      int rc = launch_pass(ctx, a, 1);
+      if (rc) return rc;
+      fill_sub(a, pl.p1);
+      a.nvec = pl.n2;
+      a.estride = pl.n2;
+      a.vstride = 1;
+      a.cols = choose_cols(a.len, a.estride);
+      a.pre = PRE_NONE;
+      a.shift_bins = 0;
+      a.post = POST_ABS_ACC;
+      a.in = s->tmp;
+      a.acc_out = s->results;
+      a.acc_add = arm > 0;
+      a.acc_scale = (float)s->shift_weight[arm];
+      a.hop_groups = 1;
+      rc = launch_pass(ctx, a, 1);
+      if (rc) return rc;
+    }
+  }
   GC_HIP(hipMemcpyAsync(out, s->results + at, sizeof(float) * s->shift.n, hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
   return GC_OK;

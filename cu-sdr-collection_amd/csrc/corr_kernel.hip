@@ -155,7 +155,10 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     const int mwaves = (period > 0 && max_arms <= 2) ? gc_multi_waves(ctx, max_arms, nblocks, period, ctx->scope_kt, ctx->scope_share_lane) : 0;
     const bool multi = (fast == 0 || fast == 1) && ctx->scope_kt >= 2 && period > 0 && splits == 1 && notify_tag == 0 && !a.derived &&
                        ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && max_arms <= 2 && mwaves > 0 &&
-                       nblocks >= multi_min * (long long)period * ctx->compute_units && !std::getenv("GC_NO_MULTI") && !ctx->force_generic;
+                       // enough work to fill the device: epochs per CU, a block counted by its length in 16 384-sample units (two BDS B1C
+                       // channels x 10 s are 2 000 blocks of 180 000 samples)
+                       nblocks * std::max<long long>(1, ctx->replay_min_blksize / 16384) >= multi_min * (long long)period * ctx->compute_units &&
+                       !std::getenv("GC_NO_MULTI") && !ctx->force_generic;
     if (multi) {
       // blocks per workgroup: a table staged once serves bpw epochs of its channel, but a short list cut into few workgroups ends in
       // a long tail (three Galileo E1 channels x 10 s: 940 workgroups of 8 blocks 0.450 ms, 1 875 of 4 blocks 0.406 ms)
