@@ -1773,8 +1773,8 @@ int ct_columns_tile(int len, int nvec) {
 
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* used_ct = nullptr) {
   if (used_ct) *used_ct = false;
-  static const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;
-  static const bool no_pairs = std::getenv("GC_ACQ_NO_XCD_PAIRS") != nullptr;
+  const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;  // (read per call: the tests switch it)
+  const bool no_pairs = std::getenv("GC_ACQ_NO_XCD_PAIRS") != nullptr;
   a.no_xcd_pairs = no_pairs ? 1 : 0;
   if (!generic) {
     // N = 36 000: 18 Msps, 1 ms codes (GPS L1 C/A, L5, Galileo E5a/E5b, BDS B2a/B3I: initSettings.m of each package);
@@ -1804,7 +1804,7 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* use
 // the specialised columns pass of this plan (GC_CT_SHAPE above) where that is a power of two; 0: natural order (generic kernel,
 // the 600 x 600 and 512 x 625 plans with tiles of 3 and 5 columns, GC_ACQ_NATURAL_ORDER=1 for A/B runs).
 int handover_block(const Plan& pl) {
-  static const bool off = std::getenv("GC_ACQ_GENERIC") != nullptr || std::getenv("GC_ACQ_NATURAL_ORDER") != nullptr;
+  const bool off = std::getenv("GC_ACQ_GENERIC") != nullptr || std::getenv("GC_ACQ_NATURAL_ORDER") != nullptr;
   if (off) return 0;
   static const struct { int n1, n2, log2b; } shapes[] = {{180, 200, 3}, {150, 160, 3}, {375, 384, 2}, {250, 288, 3}};
   for (const auto& k : shapes)

@@ -193,6 +193,30 @@ def test_fused_inverse_transform_kernel_at_the_references_default_search_sizes(e
     _compare_acq(sc, z, sc.product(P, engine, S))
 
 
+_ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": "1"}), ("GAL_E1C", {"GC_ACQ_PEAK_KERNEL": "1"}),
+              ("BDS_B1C", {"GC_ACQ_PEAK_KERNEL": "1"}), ("BDS_B1I", {"GC_ACQ_ROWMAX_KERNEL": "1"}), ("GPS_L2C", {"GC_ACQ_ROWMAX_KERNEL": "1"}),
+              ("GPS_L1CA", {"GC_ACQ_NO_HOP_GROUPS": "1"}), ("GLO_GL1", {"GC_ACQ_NATURAL_ORDER": "1"}), ("GAL_E1C", {"GC_ACQ_GENERIC": "1"}),
+              ("BDS_B1I", {"GC_ACQ_GENERIC": "1"})]
+
+
+@pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
+def test_acquisition_paths_behind_the_tuning_knobs_return_the_references_results_too(engine, monkeypatch, name, env):
+    """The round-4 additions of the search each have a switch back to what they replaced - one PRN lane instead of two streams
+    (GC_ACQ_LANES=1), the separate peak kernel over the written sums instead of the last pass's per-workgroup candidates
+    (GC_ACQ_PEAK_KERNEL=1: one-hop searches), the row-maxima kernel instead of candidates + the winning row transformed again
+    (GC_ACQ_ROWMAX_KERNEL=1: circshift family), no hop groups, the natural-order intermediate, the run-time pass kernel: every one
+    of them against the same reference-executed fixture as the default path."""
+    import cu_sdr_collection_amd as P
+    sc = next(s for s in RS.ACQ_SCENES if s.name == name)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    with P.Engine(0) as eng:                      # a context of its own: the knobs that are read once per scratch see a fresh one
+        eng.load_if(rec, fs=S.samplingFreq)
+        _compare_acq(sc, z, sc.product(P, eng, S))
+
+
 _ACQ_FUSED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "GAL_E5b", "BDS_B2a", "BDS_B3I", "GLO_GL1")   # searches of 36 000 / 24 000 points
 
 
