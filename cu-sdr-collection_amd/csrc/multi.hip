@@ -81,7 +81,15 @@ bool ledger_fits(const std::vector<ResidentGrid>& set, const ResidentGrid& add, 
 hipError_t gc_launch_persistent(gc_context* ctx, const void* fn, dim3 grid, dim3 block, void** args, unsigned int smem) {
   bool coop = !ctx->concurrent_jobs;
   if (const char* e = std::getenv("GC_PERSIST_COOP")) coop = std::atoi(e) != 0;
-  if (coop) return hipLaunchCooperativeKernel(fn, grid, block, args, smem, ctx->stream);
+  if (coop) {
+    if (std::getenv("GC_TRACK_DEBUG")) {
+      int occ = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)block.x, smem);
+      std::fprintf(stderr, "gc_launch_persistent: cooperative, grid %u x %u threads, %u B of LDS, occupancy %d workgroups per CU x %d CUs\n", grid.x, block.x, smem, occ,
+                   ctx->compute_units);
+    }
+    return hipLaunchCooperativeKernel(fn, grid, block, args, smem, ctx->stream);
+  }
   if (ctx->device < 0 || ctx->device >= 64) return hipErrorInvalidDevice;
   int occ = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)block.x, smem);

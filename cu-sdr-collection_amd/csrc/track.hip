@@ -457,6 +457,8 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
       continue;
     }
     ctx->last_track_mode = e == hipSuccess ? 1 : 0;
+    if (e == hipSuccess && std::getenv("GC_TRACK_DEBUG"))
+      std::fprintf(stderr, "gc_track: persistent kernel: %d channels x %d members (%s kernel)\n", nch, psplits_dev, persist_lane ? "lane" : "fast");
     if (e == hipSuccess) ctx->last_kernel = persist_lane ? 0 : 1;  // gc_debug_last_kernel: lane / fast kernel (persistent instantiation)
     if (e != hipSuccess) {  // could not set the persistent kernel up: launch per epoch
       if (std::getenv("GC_TRACK_DEBUG"))
