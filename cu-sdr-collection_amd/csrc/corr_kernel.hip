@@ -154,7 +154,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     const int multi_min = std::getenv("GC_MULTI_MIN") ? std::max(1, std::atoi(std::getenv("GC_MULTI_MIN"))) : 4;
     const int mwaves = (period > 0 && max_arms <= 2) ? gc_multi_waves(ctx, max_arms, nblocks, period, ctx->scope_kt, ctx->scope_share_lane) : 0;
     const bool multi = (fast == 0 || fast == 1) && ctx->scope_kt >= 2 && period > 0 && splits == 1 && notify_tag == 0 && !a.derived &&
-                       ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && max_arms <= 2 && mwaves > 0 &&
+                       ctx->if_layout != GC_REAL && max_arms <= 2 && mwaves > 0 &&
                        // enough work to fill the device: epochs per CU, a block counted by its length in 16 384-sample units (two BDS B1C
                        // channels x 10 s are 2 000 blocks of 180 000 samples)
                        nblocks * std::max<long long>(1, ctx->replay_min_blksize / 16384) >= multi_min * (long long)period * ctx->compute_units &&

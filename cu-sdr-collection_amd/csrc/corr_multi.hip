@@ -52,7 +52,7 @@ __device__ __forceinline__ float cvt_sbyte(unsigned int word) {
   return cvt_byte<B>(word);
 }
 
-// ARMS in {1, 2}; MODE in {I8_IQ, I8_QI}; KT in {2, 4}; SHARE_EL: every block has 2*earlyLateSpc*R*M == 1 (host-checked);
+// ARMS in {1, 2}; MODE in {I8_IQ, I8_QI, I16_IQ, I16_QI}; KT in {2, 4}; SHARE_EL: every block has 2*earlyLateSpc*R*M == 1 (host-checked);
 // NWV wavefronts per workgroup share the staged tables: 16 where tables + 16 x 8 KB of running sums fit the CU's 160 KB (one
 // workgroup = four waves per SIMD: the sample loop is one dependent chain of 32 multiply-adds per component, and what hides its
 // latency is other waves), 8 for the longest tables, 4 for short lists (more, smaller workgroups: less of a tail)
@@ -263,8 +263,14 @@ __global__ __launch_bounds__(NWV* kMW) void corr_epl_multi_kernel(const KArgs p)
 #pragma unroll 1
           for (int j = 0; j < SPL; ++j) {
             const int i = i0 + j;
-            const float x0 = (float)(signed char)sp8[2 * j];
-            const float x1 = (float)(signed char)sp8[2 * j + 1];
+            float x0, x1;
+            if constexpr (Fmt<MODE>::bps == 2) {
+              x0 = (float)(signed char)sp8[2 * j];
+              x1 = (float)(signed char)sp8[2 * j + 1];
+            } else {
+              x0 = (float)reinterpret_cast<const short*>(sp8)[2 * j];
+              x1 = (float)reinterpret_cast<const short*>(sp8)[2 * j + 1];
+            }
             float a = Fmt<MODE>::swap ? x1 : x0, b = Fmt<MODE>::swap ? x0 : x1;
             if ((unsigned int)i >= (unsigned int)Nq || !act) a = b = 0.0f;
             const float yr = a * cr + b * ci;
@@ -434,6 +440,18 @@ void launch_multi_mode(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem, 
 template <int NWV>
 void launch_multi_waves(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem, int max_arms, int kt, bool share) {
   const bool qi = ctx->if_layout == GC_QI;
+  if (ctx->if_dtype == GC_I16) {  // int16 I/Q records: 64 bytes per lane-chunk (instantiated for four-wave workgroups: 136-151 VGPRs, three workgroups per CU)
+    if constexpr (NWV == 4) {
+      if (max_arms <= 1) {
+        if (qi) launch_multi_mode<1, I16_QI, NWV>(ctx, a, grid, smem, kt, share);
+        else launch_multi_mode<1, I16_IQ, NWV>(ctx, a, grid, smem, kt, share);
+      } else {
+        if (qi) launch_multi_mode<2, I16_QI, NWV>(ctx, a, grid, smem, kt, share);
+        else launch_multi_mode<2, I16_IQ, NWV>(ctx, a, grid, smem, kt, share);
+      }
+    }
+    return;
+  }
   if (max_arms <= 1) {
     if (qi) launch_multi_mode<1, I8_QI, NWV>(ctx, a, grid, smem, kt, share);
     else launch_multi_mode<1, I8_IQ, NWV>(ctx, a, grid, smem, kt, share);
@@ -454,6 +472,7 @@ int gc_multi_waves(const gc_context* ctx, int max_arms, long long nblocks, int p
   const int tb = gc_multi_table_bytes(ctx->max_stage_len, max_arms);
   int forced = 0;
   if (const char* e = std::getenv("GC_MULTI_WAVES")) forced = std::atoi(e);
+  if (ctx->if_dtype == GC_I16) return tb + 4 * kMSPL * 2 * kMW * (int)sizeof(float) <= kMaxLds ? 4 : 0;  // the int16 instantiations: 4 waves
   // two transitions per chunk (short tables: Galileo E1, BDS B1I): three four-wave workgroups per CU measured 3 % ahead of one
   // sixteen-wave workgroup (e1x8: 1.40 against 1.44 ms); four transitions (GPS L5 at 50 Msps): the other way round (3.95 / 4.10 ms)
   if (forced == 0 && kt <= 2 && 3 * (tb + 4 * kMSPL * 2 * kMW * (int)sizeof(float)) <= kMaxLds) return 4;

@@ -856,7 +856,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
   }
   // mixed ramp multipliers: the exact per-sample kernel (-1), unless every such channel's odd arm can be derived from its
   // neighbour (BOC(6,1) from BOC(1,1)) and the record is int8 I/Q: then the lane kernel's derived-arm instantiation (0)
-  ctx->scope_kt = (kt >= 2 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && !any_derived && !any_plain_mixed) ? kt : 0;
+  ctx->scope_kt = (kt >= 2 && ctx->if_layout != GC_REAL && !any_derived && !any_plain_mixed) ? kt : 0;
   if (any_plain_mixed || (any_derived && (any_three_plain || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL))) {
     *all_lowrate = -1;
   } else if (any_derived) {

@@ -222,7 +222,7 @@ def test_lane_kernel_work_decompositions(engine):
     assert np.max(np.abs(got - engine.correlate(b))) < 0.2   # decomposition (C) of the same list: float sums only reorder
 
 
-@pytest.mark.parametrize("case", ["l5_50msps_share", "l5_50msps_three_ramps", "e1_share", "e1_three_ramps", "b1i_one_arm_qi"])
+@pytest.mark.parametrize("case", ["l5_50msps_share", "l5_50msps_three_ramps", "e1_share", "e1_three_ramps", "b1i_one_arm_qi", "l5_50msps_int16", "e1_int16_qi"])
 def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine, monkeypatch, case):
     """corr_multi.hip: periodic replay lists whose 16-sample chunks cross up to 2 (Galileo E1 / BDS B1I-type tables at 18 Msps) or
     4 (10.23-Mcps codes at 50 Msps) table entries.  The same list through the kernel that took it before (GC_NO_MULTI=1: the lane
@@ -232,7 +232,9 @@ def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine,
            "l5_50msps_three_ramps": dict(fs=50e6, L=10230, rate=10.23e6, R=1.0, arms=2, d=0.3, kt=4, layout="iq"),
            "e1_share": dict(fs=18e6, L=4092, rate=1.023e6, R=2.0, arms=2, d=0.25, kt=2, layout="iq"),
            "e1_three_ramps": dict(fs=18e6, L=4092, rate=1.023e6, R=2.0, arms=2, d=0.1, kt=2, layout="iq"),
-           "b1i_one_arm_qi": dict(fs=18e6, L=2046, rate=2.046e6, R=1.0, arms=1, d=0.5, kt=2, layout="qi")}[case]
+           "b1i_one_arm_qi": dict(fs=18e6, L=2046, rate=2.046e6, R=1.0, arms=1, d=0.5, kt=2, layout="qi"),
+           "l5_50msps_int16": dict(fs=50e6, L=10230, rate=10.23e6, R=1.0, arms=2, d=0.5, kt=4, layout="iq", int16=True),
+           "e1_int16_qi": dict(fs=18e6, L=4092, rate=1.023e6, R=2.0, arms=2, d=0.1, kt=2, layout="qi", int16=True)}[case]
     from cu_sdr_collection_amd import _lib as LIB
     fs, L, R, arms = cfg["fs"], float(cfg["L"]), cfg["R"], cfg["arms"]
     rng = np.random.default_rng(abs(hash(case)) % 1000 + 11)
@@ -244,6 +246,8 @@ def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine,
     nmax = int(np.ceil(L / (step0 * (1 - 3e-5)))) + 2
     n_if = 6 * nmax
     iq = _noise_iq(n_if, 77)
+    if cfg.get("int16"):
+        iq = iq.astype(np.int16) * 37               # an int16 record (settings.dataType = 'int16'): values beyond the int8 range
     layout = LIB.GC_QI if cfg["layout"] == "qi" else LIB.GC_IQ
     engine.load_if(iq, layout=layout, fs=fs)
     tabs = {}
