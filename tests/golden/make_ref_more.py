@@ -42,6 +42,60 @@ def gen_acq_default(only=None):
     gen_acq(only, RS.DEFAULT_ACQ_SCENES)
 
 
+def gen_acq_default_parts(only=None):
+    """A default search whose PRNs are independent (every package's acquisition.m loops `for PRN = settings.acqSatelliteList` and
+    writes acqResults.x(PRN) only) executed in GC_ACQ_PARTS processes side by side: part k runs the reference's acquisition.m with
+    acqSatelliteList = every GC_ACQ_PARTS-th PRN of the default list (the ONLY field changed), `--merge` adds the parts up into the
+    fixture.  BDS B1C's 62 PRNs x 201 bins x 2 x 360 000-point transforms take the interpreter 95 s per PRN: 1.7 h in one process.
+        for k in 0 1 2 3 4 5 6; do GC_ACQ_PARTS=7 GC_ACQ_PART=$k python tests/golden/make_ref_vectors.py acq_default_parts --only BDS_B1C_default & done; wait
+        GC_ACQ_PARTS=7 GC_ACQ_PART=merge python tests/golden/make_ref_vectors.py acq_default_parts --only BDS_B1C_default"""
+    nparts = int(os.environ.get("GC_ACQ_PARTS", "7"))
+    part = os.environ.get("GC_ACQ_PART", "merge")
+    tmp = os.environ.get("GC_ACQ_PARTS_DIR", "/tmp/fx/parts")
+    os.makedirs(tmp, exist_ok=True)
+    for sc in RS.DEFAULT_ACQ_SCENES:
+        if only and only != sc.name:
+            continue
+        S, rec = RS.acq_inputs(P, sc)
+        full = [int(v) for v in S.acqSatelliteList]
+        if part != "merge":
+            k = int(part)
+            t0 = time.time()
+            I = interpreter(sc.pkg)
+            Sm = _set(I.call("initSettings"), {"acqSatelliteList": [float(v) for v in full[k::nparts]]})
+            x = rec.astype(np.float64)
+            acq = mlab.from_matlab(I.call("acquisition", (x[0::2] + 1j * x[1::2]).reshape(1, -1), Sm))
+            out = {"prns": np.array(full[k::nparts]), "seconds": np.array([time.time() - t0]), "stdout": np.array("".join(I.out)[-400:])}
+            for f in vars(acq):
+                v = getattr(acq, f)
+                if isinstance(v, (np.ndarray, float)):
+                    out["f_" + f] = np.asarray(v, dtype=np.float64).reshape(-1)
+            np.savez_compressed(os.path.join(tmp, f"{sc.name}.part{k}of{nparts}.npz"), **out)
+            print(f"[acq part {k}/{nparts}] {sc.name}: PRNs {full[k::nparts]}, {time.time() - t0:.1f} s", flush=True)
+            continue
+        parts = [np.load(os.path.join(tmp, f"{sc.name}.part{k}of{nparts}.npz")) for k in range(nparts)]
+        fields = [f for f in parts[0].files if f.startswith("f_")]
+        size = max(z[f].shape[0] for z in parts for f in fields)        # acqResults are zeros(1, max(acqSatelliteList)) in some packages
+        out = {"record_crc32": np.array([RS.crc(rec)], dtype=np.uint32), "overrides": np.array(json.dumps(sc.overrides)), "pkg": np.array(sc.pkg),
+               "stdout": np.array(" | ".join(str(z["stdout"])[-120:] for z in parts)), "seconds": np.array([sum(float(z["seconds"][0]) for z in parts)]),
+               "generated_in_parts": np.array([nparts])}
+        seen = np.zeros(size, dtype=int)
+        for f in fields:
+            out[f] = np.zeros(size)
+        for z in parts:
+            idx = np.asarray(z["prns"], dtype=int) - 1
+            seen[idx] += 1
+            for f in fields:
+                v = np.zeros(size)
+                v[:z[f].shape[0]] = z[f]
+                other = np.setdiff1d(np.arange(size), idx)
+                assert not v[other].any(), (sc.name, f, "a part wrote results of PRNs it did not search")
+                out[f][idx] = v[idx]
+        assert np.array_equal(np.flatnonzero(seen) + 1, np.array(sorted(full))) and seen.max() == 1
+        np.savez_compressed(os.path.join(HERE, f"ref_acq_{sc.name}.npz"), **out)
+        print(f"[acq merge] {sc.name}: {nparts} parts, {len(full)} PRNs, detected {np.flatnonzero(out['f_carrFreq']) + 1}, interpreter seconds {float(out['seconds'][0]):.0f}", flush=True)
+
+
 def gen_acq(only=None, scenes=None):
     for sc in (RS.ACQ_SCENES if scenes is None else scenes):
         if only and only != sc.name:

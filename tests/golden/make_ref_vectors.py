@@ -114,7 +114,7 @@ def main():
                 continue
             gen_track(sc)
     import make_ref_more as MORE
-    for what in ("acq", "acq_default", "codes", "settings", "prerun", "navsync"):
+    for what in ("acq", "acq_default", "acq_default_parts", "codes", "settings", "prerun", "navsync"):
         if what in a.what:
             getattr(MORE, "gen_" + what)(a.only)
 
