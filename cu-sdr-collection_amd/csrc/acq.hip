@@ -25,6 +25,18 @@ constexpr int kMaxPassLen = 2048;  // longest vector of a pass: one tile of 2048
 constexpr int kFftThreads = 256;
 constexpr int kFftSlots = 8;  // tile elements per thread at most: L*C <= kFftSlots * kFftThreads
 
+// |z| of one output of an inverse transform (acquisition.m:187 abs(ifft(..))): v_sqrt_f32 as the hardware rounds it (1 ulp).  sqrtf()
+// expands to the instruction plus a denormal pre-scale and two correction steps - 15 VALU instructions per element, half of the
+// issue cycles of a columns pass - to move a float32 sum of squares that is itself ~1e-6 relative from the float64 reference by half
+// an ulp (GC_ACQ_IEEE_SQRT=1 at build time: the correctly rounded one).
+#ifndef GC_ACQ_IEEE_SQRT
+#define GC_ACQ_IEEE_SQRT 0
+#endif
+__device__ __forceinline__ float cabs_f(float x, float y) {
+  const float s = x * x + y * y;
+  return GC_ACQ_IEEE_SQRT ? sqrtf(s) : __builtin_amdgcn_sqrtf(s);
+}
+
 struct SubPlan {
   int len;
   int nrad;
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
       const int pos = __mul24(e, a.estride) + __mul24(v, a.vstride);
       if (a.post == POST_TWIDDLE) val = cmul(val, cmul(tw2[c * TW2 + (e >> 4)], tw2[c * TW2 + EH + (e & 15)]));
       if (a.post == POST_ABS_ACC) {
-        accv[slot] += sqrtf(val.x * val.x + val.y * val.y);
+        accv[slot] += cabs_f(val.x, val.y);
       } else {
         a.out[tb * a.out_batch_stride + pos] = val;
       }
@@ -701,6 +713,30 @@ __device__ __forceinline__ void stage_first_ct(F&& in, float2* __restrict__ dst,
     float2* d = dst + c * LP + j * (PAD ? R + 1 : R);
 #pragma unroll
     for (int q = 0; q < R; ++q) d[q] = oq[q];
+  }
+}
+
+// The inputs of a first stage into registers, in stage_first_ct's (iteration, q) order: in(it, q, c, e) -> what memory holds for
+// element e of vector c.  A pass that walks several hops fetches the NEXT hop's inputs with this right after its first stage has
+// consumed the current ones: the loads are in flight during the other stages (their barriers wait for LDS, not for memory) instead of
+// every hop starting with a full memory latency in front of its first butterfly.
+template <int R, int L, int C, bool CFAST, class F>
+__device__ __forceinline__ void first_fetch_ct(F&& in, float2 (&pre)[(L / R * C + kFftThreads - 1) / kFftThreads][R], unsigned tid) {
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+  for (unsigned it = 0; it < ITERS; ++it) {
+    const unsigned b = tid + it * kFftThreads;
+    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    unsigned c, j;
+    if constexpr (CFAST) {
+      j = b / C;
+      c = b - j * C;
+    } else {
+      c = b / LR;
+      j = b - c * LR;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) pre[it][q] = in(it, q, c, j + q * LR);
   }
 }
 
@@ -844,54 +880,73 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
         }
       }
     }
-    for (int rep = 0; rep < reps; ++rep) {
-      const long long tb = POST == POST_ABS_ACC ? (long long)batch * a.nhops + (long long)hg * reps + rep
-                           : RR                 ? (long long)batch * reps + rep
-                                                : (long long)batch;
-      [[maybe_unused]] long long shsrc = 0;
-      [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
-      if constexpr (SHIFT) {
-        const unsigned sft = a.shift_q > 0 ? (unsigned)(tb / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
-        shsrc = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
-        sh2 = sft / OTHER;
-        sh1 = sft - sh2 * OTHER;
-      }
-      // ---- first stage, inputs from memory ---------------------------------------------------------------------------
+    // ---- the first stage's inputs, one hop ahead (first_fetch_ct) ---------------------------------------------------------------
+    auto tb_of = [&](int rep) -> long long {
+      return POST == POST_ABS_ACC ? (long long)batch * a.nhops + (long long)hg * reps + rep
+             : RR                 ? (long long)batch * reps + rep
+                                  : (long long)batch;
+    };
+    float2 pre[IT0][R0];
+    [[maybe_unused]] float2 poth[(PRE == PRE_MUL_CONJ && !RR) ? IT0 : 1][(PRE == PRE_MUL_CONJ && !RR) ? R0 : 1];
+    auto fetch = [&](int rep) {
+      const long long tb = tb_of(rep);
       if constexpr (PRE == PRE_MUL_CONJ) {
+        [[maybe_unused]] long long shsrc = 0;
+        [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
+        if constexpr (SHIFT) {
+          const unsigned sft = a.shift_q > 0 ? (unsigned)(tb / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
+          shsrc = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
+          sh2 = sft / OTHER;
+          sh1 = sft - sh2 * OTHER;
+        }
         const float2* __restrict__ src = a.in + (SHIFT ? shsrc : tb) * a.in_batch_stride;
-        stage_first_ct<R0, L, LP1, C, INV, false, PAD1>(
+        first_fetch_ct<R0, L, C, false>(
             [&](unsigned it, int q, unsigned c, unsigned e) -> float2 {
-              float2 val, o;
               if constexpr (RR) {
-                val = src[fr_src[it][q]];
-                o = fr_oth[it][q];
+                return src[fr_src[it][q]];
               } else {
                 const unsigned pos = (v0 + c) * L + e;
+                poth[it][q] = a.other[pos];
                 if constexpr (SHIFT) {
                   int k1 = (int)(v0 + c) - (int)sh1;
                   const int bor = k1 < 0;
                   k1 += bor ? OTHER : 0;
                   int e2 = (int)e - (int)sh2 - bor;
                   e2 += e2 < 0 ? L : 0;
-                  val = src[k1 * L + e2];
+                  return src[k1 * L + e2];
                 } else {
-                  val = src[pos];
+                  return src[pos];
                 }
-                o = a.other[pos];
               }
+            },
+            pre, tid);
+      } else {
+        const float2* __restrict__ src = a.in + tb * a.in_batch_stride;
+        const bool blocked = a.in_blocked != 0;
+        // blocked: this tile's L x C values vector-fastest (e * C + c: consecutive threads, consecutive addresses)
+        first_fetch_ct<R0, L, C, true>(
+            [&](unsigned, int, unsigned c, unsigned e) -> float2 { return src[blocked ? tile * NEL + e * C + c : e * ESTR + (v0 + c) * VSTR]; }, pre,
+            tid);
+      }
+    };
+    fetch(0);
+    for (int rep = 0; rep < reps; ++rep) {
+      const long long tb = tb_of(rep);
+      // ---- first stage, inputs from registers -------------------------------------------------------------------------
+      if constexpr (PRE == PRE_MUL_CONJ) {
+        stage_first_ct<R0, L, LP1, C, INV, false, PAD1>(
+            [&](unsigned it, int q, unsigned, unsigned) -> float2 {
+              const float2 val = pre[it][q];
+              float2 o;
+              if constexpr (RR) o = fr_oth[it][q];
+              else o = poth[it][q];
               return make_float2(val.x * o.x + val.y * o.y, val.y * o.x - val.x * o.y);
             },
             buf1, tid);
       } else {
-        const float2* __restrict__ src = a.in + tb * a.in_batch_stride;
-        const bool blocked = a.in_blocked != 0;
-        stage_first_ct<R0, L, LP1, C, INV, true, false>(
-            [&](unsigned, int, unsigned c, unsigned e) -> float2 {
-              // blocked: this tile's L x C values vector-fastest (e * C + c: consecutive threads, consecutive addresses)
-              return src[blocked ? tile * NEL + e * C + c : e * ESTR + (v0 + c) * VSTR];
-            },
-            buf1, tid);
+        stage_first_ct<R0, L, LP1, C, INV, true, false>([&](unsigned it, int q, unsigned, unsigned) -> float2 { return pre[it][q]; }, buf1, tid);
       }
+      if (rep + 1 < reps) fetch(rep + 1);
       __syncthreads();
       // ---- middle stages: buf1 -> buf0 (-> buf1) ------------------------------------------------------------------------
       if constexpr (NST >= 3) {
@@ -920,7 +975,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
         });
       } else {
         stage_last_ct<RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned it, int q, unsigned, unsigned, float2 val) {
-          acc2[it][q] += sqrtf(val.x * val.x + val.y * val.y);
+          acc2[it][q] += cabs_f(val.x, val.y);
         });
       }
       // two stages: the last one read buf1, which the next hop's first stage writes
@@ -1102,7 +1157,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
       float2 val = res[li];
       if constexpr (POST == POST_TWIDDLE) val = cmul(val, cmul(tw2[c * TW2 + (e >> 4)], tw2[c * TW2 + EH + (e & 15)]));
       if constexpr (POST == POST_ABS_ACC) {
-        accv[slot] += sqrtf(val.x * val.x + val.y * val.y);
+        accv[slot] += cabs_f(val.x, val.y);
       } else {
         a.out[tb * a.out_batch_stride + pos] = val;
       }
@@ -1312,7 +1367,7 @@ __global__ __launch_bounds__(kFusedThreads) void acq_fused_kernel(const FusedArg
         }
         butterfly<R3>(vq, -1.0f, oq);
 #pragma unroll
-        for (int q = 0; q < R3; ++q) acc[q] = fmaf(wgt, sqrtf(oq[q].x * oq[q].x + oq[q].y * oq[q].y), acc[q]);
+        for (int q = 0; q < R3; ++q) acc[q] = fmaf(wgt, cabs_f(oq[q].x, oq[q].y), acc[q]);
       }
     }
   }
