@@ -716,12 +716,12 @@ __device__ __forceinline__ void stage_first_ct(F&& in, float2* __restrict__ dst,
   }
 }
 
-// The inputs of a first stage into registers, in stage_first_ct's (iteration, q) order: in(it, q, c, e) -> what memory holds for
-// element e of vector c.  A pass that walks several hops fetches the NEXT hop's inputs with this right after its first stage has
-// consumed the current ones: the loads are in flight during the other stages (their barriers wait for LDS, not for memory) instead of
-// every hop starting with a full memory latency in front of its first butterfly.
+// f(it, q, c, e) for every input of a first stage, in stage_first_ct's (iteration, q) order: element e of vector c.  A pass that walks
+// several hops fetches the NEXT hop's inputs into registers with this right after its first stage has consumed the current ones: the
+// loads are in flight during the other stages (their barriers wait for LDS, not for memory) instead of every hop starting with a
+// full memory latency in front of its first butterfly.
 template <int R, int L, int C, bool CFAST, class F>
-__device__ __forceinline__ void first_fetch_ct(F&& in, float2 (&pre)[(L / R * C + kFftThreads - 1) / kFftThreads][R], unsigned tid) {
+__device__ __forceinline__ void first_each_ct(unsigned tid, F&& f) {
   constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
 #pragma unroll
   for (unsigned it = 0; it < ITERS; ++it) {
@@ -736,8 +736,18 @@ __device__ __forceinline__ void first_fetch_ct(F&& in, float2 (&pre)[(L / R * C 
       j = b - c * LR;
     }
 #pragma unroll
-    for (int q = 0; q < R; ++q) pre[it][q] = in(it, q, c, j + q * LR);
+    for (int q = 0; q < R; ++q) f(it, q, c, j + q * LR);
   }
+}
+// uniform base + a 32-bit byte offset per thread, as a buffer load: the base stays in scalar registers (a descriptor built per hop)
+// and an address costs one VGPR that does not depend on the hop - with flat loads the compiler keeps a 64-bit address per input
+// and adds the hop's stride to each (16 VGPRs and 8 64-bit adds for a radix-8 first stage; the rows pass spilled at six waves per SIMD)
+__device__ __forceinline__ float2 ld_off(const float2* __restrict__ base, unsigned byte_off) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  const unsigned long long bu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu), 0, 0x7fffffff, 0x00020000);
+  // (bit_cast of the whole vector: element-wise v[0], v[1] came out of this compiler as ONE buffer_load_dword used twice)
+  return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
 }
 
 // the last stage (NS = L / R: k = j): out(it, q, c, e, value) receives element e = j + q * NS of vector c
@@ -780,7 +790,12 @@ __device__ __forceinline__ void stage_twiddles_ct(const float2* __restrict__ tw,
 }
 
 template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, bool SHIFT, int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
+#ifndef GC_ACQ_PASS_WAVES
+#define GC_ACQ_PASS_WAVES 5
+#endif
+// second bound: wavefronts per SIMD the register allocation must leave room for - the tiles of the short passes (<= 26 KB of LDS) fit
+// six workgroups per CU, and the passes are latency-bound (barriers between stages): the registers must not be what limits them
+__global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) void fft_pass_ct(const PassArgs a) {
   static_assert(R0 * R1 * R2 * R3 == L && OTHER % C == 0, "radices multiply to L; whole tiles only");
   static_assert(!SHIFT || (CONTIG && PRE == PRE_MUL_CONJ), "shifted reads belong to the rows pass of the inverse transform");
   constexpr unsigned N = L * OTHER, NEL = L * C, SLOTS = (NEL + kFftThreads - 1) / kFftThreads, TILES = OTHER / C;
@@ -875,7 +890,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
           const unsigned e = j + q * LR0;
           int e2 = (int)e - (int)s2 - bor;
           e2 += e2 < 0 ? L : 0;
-          fr_src[RR ? it : 0][RR ? q : 0] = (unsigned)(k1 * L + e2);
+          fr_src[RR ? it : 0][RR ? q : 0] = (unsigned)(k1 * L + e2) * 8u;  // byte offset (ld_off)
           fr_oth[RR ? it : 0][RR ? q : 0] = a.other[(v0 + c) * L + e];
         }
       }
@@ -888,6 +903,15 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
     };
     float2 pre[IT0][R0];
     [[maybe_unused]] float2 poth[(PRE == PRE_MUL_CONJ && !RR) ? IT0 : 1][(PRE == PRE_MUL_CONJ && !RR) ? R0 : 1];
+    // columns pass: where the thread's inputs sit in a hop's intermediate (bytes) does not depend on the hop
+    [[maybe_unused]] unsigned foff[PRE == PRE_NONE ? IT0 : 1][PRE == PRE_NONE ? R0 : 1];
+    if constexpr (PRE == PRE_NONE) {
+      const bool blocked = a.in_blocked != 0;
+      // blocked: this tile's L x C values vector-fastest (e * C + c: consecutive threads, consecutive addresses)
+      first_each_ct<R0, L, C, true>(tid, [&](unsigned it, int q, unsigned c, unsigned e) {
+        foff[it][q] = (blocked ? tile * NEL + e * C + c : e * ESTR + (v0 + c) * VSTR) * 8u;
+      });
+    }
     auto fetch = [&](int rep) {
       const long long tb = tb_of(rep);
       if constexpr (PRE == PRE_MUL_CONJ) {
@@ -900,33 +924,27 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_ct(const PassArgs a) {
           sh1 = sft - sh2 * OTHER;
         }
         const float2* __restrict__ src = a.in + (SHIFT ? shsrc : tb) * a.in_batch_stride;
-        first_fetch_ct<R0, L, C, false>(
-            [&](unsigned it, int q, unsigned c, unsigned e) -> float2 {
-              if constexpr (RR) {
-                return src[fr_src[it][q]];
-              } else {
-                const unsigned pos = (v0 + c) * L + e;
-                poth[it][q] = a.other[pos];
-                if constexpr (SHIFT) {
-                  int k1 = (int)(v0 + c) - (int)sh1;
-                  const int bor = k1 < 0;
-                  k1 += bor ? OTHER : 0;
-                  int e2 = (int)e - (int)sh2 - bor;
-                  e2 += e2 < 0 ? L : 0;
-                  return src[k1 * L + e2];
-                } else {
-                  return src[pos];
-                }
-              }
-            },
-            pre, tid);
+        first_each_ct<R0, L, C, false>(tid, [&](unsigned it, int q, unsigned c, unsigned e) {
+          if constexpr (RR) {
+            pre[it][q] = ld_off(src, fr_src[it][q]);
+          } else {
+            const unsigned pos = (v0 + c) * L + e;
+            poth[it][q] = a.other[pos];
+            if constexpr (SHIFT) {
+              int k1 = (int)(v0 + c) - (int)sh1;
+              const int bor = k1 < 0;
+              k1 += bor ? OTHER : 0;
+              int e2 = (int)e - (int)sh2 - bor;
+              e2 += e2 < 0 ? L : 0;
+              pre[it][q] = src[k1 * L + e2];
+            } else {
+              pre[it][q] = src[pos];
+            }
+          }
+        });
       } else {
         const float2* __restrict__ src = a.in + tb * a.in_batch_stride;
-        const bool blocked = a.in_blocked != 0;
-        // blocked: this tile's L x C values vector-fastest (e * C + c: consecutive threads, consecutive addresses)
-        first_fetch_ct<R0, L, C, true>(
-            [&](unsigned, int, unsigned c, unsigned e) -> float2 { return src[blocked ? tile * NEL + e * C + c : e * ESTR + (v0 + c) * VSTR]; }, pre,
-            tid);
+        first_each_ct<R0, L, C, true>(tid, [&](unsigned it, int q, unsigned, unsigned) { pre[it][q] = ld_off(src, foff[it][q]); });
       }
     };
     fetch(0);
