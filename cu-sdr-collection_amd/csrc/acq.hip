@@ -166,7 +166,7 @@ struct PassArgs {
   // shifted rows pass of the inverse transform: one workgroup walks row_reps consecutive batches (hops of ONE bin: the shift, the
   // source rows, the code-spectrum values and the twiddle tables are the same for all of them); 0 or 1: one batch per workgroup
   int row_reps;
-  int no_xcd_pairs;  // GC_ACQ_NO_XCD_PAIRS: blockIdx -> tile without the pairing of the strided passes (A/B)
+  int no_xcd_pairs;  // 0: every XCD a contiguous run of the strided passes' tiles; 1 (GC_ACQ_NO_XCD_PAIRS): blockIdx -> tile as it comes; 2 (GC_ACQ_XCD_MAP=pairs): neighbours paired (A/B)
   float* acc_part;
   // PRE_MUL_CONJ with circular spectrum shifts (the circshift search family): batch tb reads input transform
   // tb / shift_bins shifted by tb % shift_bins natural-frequency bins; n1, n2 give the [k1][k2] storage order
@@ -826,10 +826,18 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
   // tile reads the other half; consecutive workgroups go to consecutive XCDs, each with an L2 of its own, and both fetched
   // the whole line (rocprofv3 FETCH_SIZE: 328 MB per launch of the inverse columns pass for the 167 MB it reads).  Blocks b
   // and b + 8 of a group of 16 share an XCD and start together: they take neighbouring tiles.
+  // Narrower tiles (24 bytes at C = 3: the 600 x 600 plan of BDS B1C; 40 at C = 5) share a line among five: every XCD takes a
+  // contiguous run of (batch, tile) - consecutive tiles of a batch run on one XCD at about the same time and find each other's lines
+  // in its L2 (B1C columns pass: FETCH_SIZE 1.42 GB per launch for the 0.58 GB it reads with the pairs only).
   unsigned bid = blockIdx.x;
   if constexpr (!CONTIG && (C * 8) % 128 != 0) {
-    const unsigned g = bid & ~15u;
-    if (g + 16 <= gridDim.x && !a.no_xcd_pairs) bid = g + ((bid & 7u) << 1) + ((bid >> 3) & 1u);
+    if (a.no_xcd_pairs == 2) {  // GC_ACQ_XCD_MAP=pairs: the pairing only
+      const unsigned g = bid & ~15u;
+      if (g + 16 <= gridDim.x) bid = g + ((bid & 7u) << 1) + ((bid >> 3) & 1u);
+    } else if (a.no_xcd_pairs == 0) {
+      const unsigned n8 = gridDim.x & ~7u;
+      if (bid < n8) bid = (bid & 7u) * (n8 >> 3) + (bid >> 3);
+    }
   }
   const unsigned tile = bid % TILES;
   const unsigned bb = bid / TILES;
@@ -1848,7 +1856,8 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* use
   if (used_ct) *used_ct = false;
   const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;  // (read per call: the tests switch it)
   const bool no_pairs = std::getenv("GC_ACQ_NO_XCD_PAIRS") != nullptr;
-  a.no_xcd_pairs = no_pairs ? 1 : 0;
+  const char* xmap = std::getenv("GC_ACQ_XCD_MAP");
+  a.no_xcd_pairs = no_pairs ? 1 : (xmap && std::strcmp(xmap, "pairs") == 0) ? 2 : 0;
   if (!generic) {
     // N = 36 000: 18 Msps, 1 ms codes (GPS L1 C/A, L5, Galileo E5a/E5b, BDS B2a/B3I: initSettings.m of each package);
     // N = 24 000: GLONASS L1/L2 at 12 Msps
