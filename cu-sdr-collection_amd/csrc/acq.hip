@@ -1687,14 +1687,18 @@ struct FineDet {
   double f0;        // its first fine bin, Hz
 };
 constexpr int kFineBins = 24;
+constexpr int kFineParts = 8;  // at most this many workgroups per code period (fine_multi_kernel)
 
 template <bool F32>  // F32: the conditioned complex float signal instead of the int8 record
 __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict__ xv, const FineDet* __restrict__ det, int spc,
                                                           int ncodes, const int8_t* __restrict__ codes, int code_len, double ts,
                                                           double tc, double fstep, double fs, int nbins, int index_offset,
-                                                          float dcr, float dcq, double* __restrict__ out) {
+                                                          float dcr, float dcq, double* __restrict__ out, int parts, size_t part_stride) {
   constexpr int MID = kFineBins / 2;
-  const int ci = blockIdx.x, d = blockIdx.y, b0 = blockIdx.z * kFineBins;
+  // parts > 1: few detections are few workgroups (seven detections x 40 code periods on 256 CUs: 131 us of a 3.3-ms search) - a code
+  // period's samples are cut into `parts` runs, one workgroup each, summed in order by fine_parts_kernel
+  const int ci = blockIdx.x / parts, part = blockIdx.x - ci * parts, d = blockIdx.y, b0 = blockIdx.z * kFineBins;
+  const int run = ((spc + parts - 1) / parts + 255) / 256 * 256, i_lo = part * run, i_hi = min(spc, i_lo + run);
   const int nb = min(kFineBins, nbins - b0);
   const FineDet dd = det[d];
   const int8_t* code = codes + (size_t)d * code_len;
@@ -1702,7 +1706,7 @@ __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict_
   double sr[kFineBins], si[kFineBins];
 #pragma unroll
   for (int k = 0; k < kFineBins; ++k) sr[k] = si[k] = 0.0;
-  for (int i = threadIdx.x; i < spc; i += 256) {
+  for (int i = i_lo + threadIdx.x; i < i_hi; i += 256) {
     const long long n = (long long)ci * spc + i;
     // acquisition.m:215-216; tc == 0: the replica is already one entry per sample
     const double cvi = tc > 0.0 ? floor(__ddiv_rn(__dmul_rn(ts, (double)(n + index_offset)), tc)) : (double)(n + index_offset);
@@ -1765,8 +1769,16 @@ __global__ __launch_bounds__(256) void fine_multi_kernel(const void* __restrict_
   __syncthreads();
   if ((int)threadIdx.x < 2 * nb) {
     const int k = threadIdx.x >> 1, q = threadIdx.x & 1;
-    out[(((size_t)d * nbins + b0 + k) * ncodes + ci) * 2 + q] = ((red[0][k][q] + red[1][k][q]) + red[2][k][q]) + red[3][k][q];
+    out[(size_t)part * part_stride + (((size_t)d * nbins + b0 + k) * ncodes + ci) * 2 + q] = ((red[0][k][q] + red[1][k][q]) + red[2][k][q]) + red[3][k][q];
   }
+}
+
+__global__ __launch_bounds__(256) void fine_parts_kernel(const double* __restrict__ part, int parts, size_t n, double* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double sum = part[i];
+  for (int s = 1; s < parts; ++s) sum += part[(size_t)s * n + i];
+  out[i] = sum;
 }
 
 // One workgroup per row: maximum and its first position (MATLAB's max returns the first maximum).
@@ -1931,6 +1943,7 @@ struct AcqScratch {
   float* partial2 = nullptr;
   size_t partial2_cap = 0;
   int lane = 0;               // the lane the launches under way belong to (launch_abs_pass picks its partial buffer by it)
+  int nlanes = 1;             // lanes of the PRN loop under way: their launches run together, which counts when hop groups are chosen
   // circshift search with the row maxima taken inside the last pass (gc_acq_shift_search): `results` holds nothing then and
   // gc_acq_shift_row transforms the row it is asked for again, with the arms and weights of the search
   bool shift_rows_fused = false;
@@ -1976,7 +1989,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   int hg = 1;
   for (int g = 1; g <= a.nhops; ++g)
-    if (a.nhops % g == 0 && (long long)tiles * nbins * hg < 4LL * ctx->compute_units) hg = g;
+    if (a.nhops % g == 0 && (long long)tiles * nbins * hg * std::max(1, s->nlanes) < 4LL * ctx->compute_units) hg = g;  // (both lanes' launches run together)
   if (std::getenv("GC_ACQ_NO_HOP_GROUPS")) hg = 1;
   if (const char* e = std::getenv("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count
     const int g = std::atoi(e);
@@ -2366,6 +2379,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   int lane_rc = GC_OK;
   for (int ip = 0; ip < nprn && !fused && lane_rc == GC_OK; ++ip) {
     s->lane = lanes == 2 ? (ip & 1) : 0;
+    s->nlanes = lanes;
     ctx->stream = s->lane ? s->stream2 : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
     float2* const tmp = s->lane ? s->tmp2 : s->tmp;
     float* const results = s->lane ? s->results2 : s->results;
@@ -2421,6 +2435,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   }
   ctx->stream = stream1;
   s->lane = 0;
+  s->nlanes = 1;
   if (lanes == 2) {  // the second lane joins before the keys are reduced and read back (also on an error: nothing may still run on it)
     (void)hipEventRecord(s->ev_join, s->stream2);
     (void)hipStreamWaitEvent(stream1, s->ev_join, 0);
@@ -2628,23 +2643,33 @@ extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params*
   GcBuf& bout = ctx->acqbuf[gc_context::ACQ_FINE_OUT];
   if (gc_buf_reserve(bcode, (size_t)ndet * p->code_len, false) != hipSuccess ||
       gc_buf_reserve(bdet, (size_t)ndet * sizeof(FineDet), false) != hipSuccess ||
-      gc_buf_reserve(bout, nout * sizeof(double), false) != hipSuccess) {
+      gc_buf_reserve(bout, nout * sizeof(double) * (size_t)(kFineParts + 1), false) != hipSuccess) {
     gc_set_error("gc_acquire_fine_sums: device allocation failed");
     return GC_E_NOMEM;
   }
   GC_HIP(hipMemcpyAsync(bcode.p, codes, (size_t)ndet * p->code_len, hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipMemcpyAsync(bdet.p, hdet.data(), (size_t)ndet * sizeof(FineDet), hipMemcpyHostToDevice, ctx->stream));
-  const dim3 grid((unsigned int)p->ncodes, (unsigned int)ndet, (unsigned int)((p->nbins + kFineBins - 1) / kFineBins));
+  dim3 grid((unsigned int)p->ncodes, (unsigned int)ndet, (unsigned int)((p->nbins + kFineBins - 1) / kFineBins));
+  int parts = 1;  // workgroups per code period: enough of them for four per CU, runs of at least 2 048 samples
+  while (parts < kFineParts && (long long)grid.x * grid.y * grid.z * parts < 4LL * ctx->compute_units && p->spc / (2 * parts) >= 2048) parts *= 2;
+  if (std::getenv("GC_ACQ_FINE_PARTS")) parts = std::max(1, std::min(kFineParts, std::atoi(std::getenv("GC_ACQ_FINE_PARTS"))));
+  grid.x *= (unsigned int)parts;
+  double* const dout = (double*)bout.p;
+  double* const dpart = parts > 1 ? dout + nout : dout;  // [parts][nout] behind the result
   const double tc = p->code_freq > 0.0 ? 1.0 / p->code_freq : 0.0;  // 0: sampled replica, one entry per sample
   if (cond)
     hipLaunchKernelGGL(fine_multi_kernel<true>, grid, dim3(256), 0, ctx->stream, (const void*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p,
                        (const FineDet*)bdet.p, p->spc, p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq,
-                       tc, p->fstep, p->sampling_freq, p->nbins, p->index_offset, (float)p->dc_re, (float)p->dc_im, (double*)bout.p);
+                       tc, p->fstep, p->sampling_freq, p->nbins, p->index_offset, (float)p->dc_re, (float)p->dc_im, dpart, parts, nout);
   else
     hipLaunchKernelGGL(fine_multi_kernel<false>, grid, dim3(256), 0, ctx->stream, (const void*)ctx->d_if, (const FineDet*)bdet.p, p->spc,
                        p->ncodes, (const int8_t*)bcode.p, p->code_len, 1.0 / p->sampling_freq, tc, p->fstep,
-                       p->sampling_freq, p->nbins, p->index_offset, (float)p->dc_re, (float)p->dc_im, (double*)bout.p);
+                       p->sampling_freq, p->nbins, p->index_offset, (float)p->dc_re, (float)p->dc_im, dpart, parts, nout);
   GC_HIP(hipGetLastError());
+  if (parts > 1) {
+    hipLaunchKernelGGL(fine_parts_kernel, dim3((unsigned int)((nout + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)dpart, parts, nout, dout);
+    GC_HIP(hipGetLastError());
+  }
   GC_HIP(hipMemcpyAsync(out, bout.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));  // also keeps hdet / codes alive until the copies are done
   return GC_OK;
