@@ -43,6 +43,19 @@ def _second_peak(corr: np.ndarray, code_phase: int, exclude: int, period: int) -
     return float(np.max(corr[rng - 1]))
 
 
+def _first_maximum(v: np.ndarray):
+    """The reference walks the (carrier, bin) grid in order and keeps a value only if it EXCEEDS the largest so far, starting from 0
+    (BDS/B1I acquisition.m:87-122, GPS_L2C acquisition.m:46-66), skipping the last bin of every carrier but the first: the winner
+    is the first position, in that order, of the largest value - if that is above 0.  v: [carriers, bins]; returns (carrier, bin)
+    0-based or None."""
+    w = np.array(v, dtype=np.float64)
+    w[1:, -1] = -np.inf
+    i = int(np.argmax(w))                                                          # first occurrence of the maximum, row-major = scan order
+    if not w.flat[i] > 0.0:
+        return None
+    return divmod(i, w.shape[1])
+
+
 # ---------------------------------------------------------------------------------------------
 # BDS B1I
 # ---------------------------------------------------------------------------------------------
@@ -85,20 +98,14 @@ def acquisition_B1I(engine, settings, first_sample: int | None = None):
         local = np.concatenate([table, np.zeros(spb // ncodes, dtype=np.int8)])     # :86
         rmax, _ = engine.acq_shift_search(local[None, :])
         rmax = rmax.reshape(nshifts, 2, nbins)
-        prevmax, best, freq_shift, bin_idx = 0.0, None, 0, 0
-        for it in range(nshifts):                                                  # :87-122, the sequential rule
-            for b in range(nbins):
-                if b == nbins - 1 and it > 0:
-                    continue
-                p1, p2 = float(rmax[it, 0, b]), float(rmax[it, 1, b])
-                if p1 > prevmax or p2 > prevmax:
-                    if p1 > p2:
-                        prevmax, best = p1, (it, 0, b)
-                    else:
-                        prevmax, best = p2, (it, 1, b)
-                    freq_shift, bin_idx = it + 1, b + 1
-        if best is None:
+        # :87-122, the sequential rule: a (carrier, bin) is taken when one of its two blocks' maxima exceeds the largest so far, and
+        # then the first block only if it is the larger of the two
+        p1, p2 = rmax[:, 0, :], rmax[:, 1, :]
+        win = _first_maximum(np.maximum(p1, p2))
+        if win is None:
             continue
+        best = (win[0], 0 if p1[win] > p2[win] else 1, win[1])
+        freq_shift, bin_idx = win[0] + 1, win[1] + 1
         corr = engine.acq_shift_row((best[0] * 2 + best[1]) * nbins + best[2])
         code_phase = int(np.argmax(corr)) + 1                                      # :126
         max_peak = float(corr[code_phase - 1])
@@ -140,16 +147,10 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
         local = np.concatenate([table, np.zeros(spc, dtype=np.int8)])               # :44
         rmax, _ = engine.acq_shift_search(local[None, :])
         rmax = rmax.reshape(nshifts, nbins)
-        prevmax, best, freq_shift, bin_idx = 0.0, None, 0, 0
-        for it in range(nshifts):                                                  # :46-66
-            for b in range(nbins):
-                if b == nbins - 1 and it > 0:
-                    continue
-                if float(rmax[it, b]) > prevmax:
-                    prevmax, best = float(rmax[it, b]), (it, b)
-                    freq_shift, bin_idx = it + 1, b + 1
+        best = _first_maximum(rmax)                                                # :46-66
         if best is None:
             continue
+        freq_shift, bin_idx = best[0] + 1, best[1] + 1
         corr = engine.acq_shift_row(best[0] * nbins + best[1])
         code_phase = int(np.argmax(corr)) + 1                                      # :72
         max_peak = float(corr[code_phase - 1])
@@ -284,7 +285,7 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
         sel_freq = init_freq - (bin_idx - 1) * settings.acqStep                    # :194
         # [peakSize, codePhase] = max(max(results)): column maxima, first column holding the global maximum
         peak = float(rmax.max())
-        code_phase = int(min(int(rarg[r]) for r in range(nbins) if rmax[r] == rmax.max())) + 1
+        code_phase = int(rarg[rmax == rmax.max()].min()) + 1
         acq.peakMetric[prn - 1] = peak / sig_power                                 # :199
         if code_phase + spc - 1 > n_long:                                          # :232-234
             code_phase -= spc

@@ -314,3 +314,40 @@ def test_recommended_world_size_follows_the_closed_loop_sweep():
         pass
     else:
         raise AssertionError("negative channel counts must be refused")
+
+
+def test_first_maximum_is_the_references_sequential_scan():
+    """acq_shift._first_maximum against the loops of BDS/B1I acquisition.m:87-122 and GPS_L2C acquisition.m:46-66 written out: strict
+    'greater than the largest so far' from 0, last bin of every carrier but the first skipped; ties, zeros and the B1I two-block rule."""
+    from cu_sdr_collection_amd.acq_shift import _first_maximum
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        nshifts, nbins = int(rng.integers(1, 5)), int(rng.integers(1, 9))
+        levels = rng.integers(0, 4, size=(nshifts, 2, nbins)).astype(np.float32) * np.float32(0.37)     # few levels: many ties
+        if trial % 7 == 0:
+            levels[:] = 0
+        # GPS L2C: one value per (carrier, bin)
+        prevmax, best = 0.0, None
+        for it in range(nshifts):
+            for b in range(nbins):
+                if b == nbins - 1 and it > 0:
+                    continue
+                if float(levels[it, 0, b]) > prevmax:
+                    prevmax, best = float(levels[it, 0, b]), (it, b)
+        assert _first_maximum(levels[:, 0, :]) == best
+        # BDS B1I: two blocks per (carrier, bin)
+        prevmax, best = 0.0, None
+        for it in range(nshifts):
+            for b in range(nbins):
+                if b == nbins - 1 and it > 0:
+                    continue
+                p1, p2 = float(levels[it, 0, b]), float(levels[it, 1, b])
+                if p1 > prevmax or p2 > prevmax:
+                    if p1 > p2:
+                        prevmax, best = p1, (it, 0, b)
+                    else:
+                        prevmax, best = p2, (it, 1, b)
+        p1, p2 = levels[:, 0, :], levels[:, 1, :]
+        win = _first_maximum(np.maximum(p1, p2))
+        got = None if win is None else (win[0], 0 if p1[win] > p2[win] else 1, win[1])
+        assert got == best, (trial, got, best)
