@@ -19,15 +19,27 @@ def _round(x: float) -> int:
     return int(math.floor(x + 0.5))
 
 
+_INDEX_CACHE: dict = {}
+
+
 def _sampled(code: np.ndarray, n: int, ts: float, tc: float, start_at_one: bool, last: int | None, first_one: bool = False):
-    """code(ceil(ts*(k)/tc)) for k = 1..n (start_at_one) or 0..n-1, MATLAB 1-based indices into `code`."""
-    k = np.arange(1, n + 1) if start_at_one else np.arange(0, n)
-    idx = np.ceil(ts * k / tc).astype(np.int64)
-    if first_one:
-        idx[0] = 1
-    if last is not None:
-        idx[-1] = last
-    return code[idx - 1]
+    """code(ceil(ts*(k)/tc)) for k = 1..n (start_at_one) or 0..n-1, MATLAB 1-based indices into `code`.  The index vector depends on
+    the rates only, not on the PRN: kept per (n, ts, tc, ...) - the reference recomputes it in every make*Table call."""
+    key = (n, ts, tc, start_at_one, last, first_one)
+    idx = _INDEX_CACHE.get(key)
+    if idx is None:
+        k = np.arange(1, n + 1) if start_at_one else np.arange(0, n)
+        idx = np.ceil(ts * k / tc).astype(np.int64)
+        if first_one:
+            idx[0] = 1
+        if last is not None:
+            idx[-1] = last
+        idx -= 1
+        idx.setflags(write=False)
+        if len(_INDEX_CACHE) > 32:
+            _INDEX_CACHE.clear()
+        _INDEX_CACHE[key] = idx
+    return code[idx]
 
 
 def _second_peak(corr: np.ndarray, code_phase: int, exclude: int, period: int) -> float:
