@@ -166,6 +166,8 @@ struct PassArgs {
   // shifted rows pass of the inverse transform: one workgroup walks row_reps consecutive batches (hops of ONE bin: the shift, the
   // source rows, the code-spectrum values and the twiddle tables are the same for all of them); 0 or 1: one batch per workgroup
   int row_reps;
+  int bins_per_wg;   // fused columns pass without hop groups: consecutive batches (bins) one workgroup takes, the next one's inputs fetched ahead (0 / 1: one)
+  int nbatch_total;  // ... and how many batches the launch has in all
   int no_xcd_pairs;  // 0: every XCD a contiguous run of the strided passes' tiles; 1 (GC_ACQ_NO_XCD_PAIRS): blockIdx -> tile as it comes; 2 (GC_ACQ_XCD_MAP=pairs): neighbours paired (A/B)
   float* acc_part;
   // PRE_MUL_CONJ with circular spectrum shifts (the circshift search family): batch tb reads input transform
@@ -842,7 +844,11 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
   const unsigned tile = bid % TILES;
   const unsigned bb = bid / TILES;
   const unsigned HG = (POST == POST_ABS_ACC && a.hop_groups > 1) ? (unsigned)a.hop_groups : 1u;
-  const unsigned hg = bb % HG, batch = bb / HG + (unsigned)a.batch0;
+  // BQ consecutive batches per workgroup (fused columns pass of a search without hops - the circshift family, Galileo E1: a
+  // workgroup that lives for ONE tile of 1 800 values spends its life waiting for its twiddles, then for its tile)
+  const unsigned BQ = (POST == POST_ABS_ACC && HG == 1 && a.bins_per_wg > 1) ? (unsigned)a.bins_per_wg : 1u;
+  const unsigned hg = bb % HG, batch = (bb / HG) * BQ + (unsigned)a.batch0;
+  const unsigned nq = BQ == 1 ? 1u : min(BQ, (unsigned)a.nbatch_total - (bb / HG) * BQ);
   const unsigned v0 = tile * C;
   constexpr bool RR = SHIFT && POST != POST_ABS_ACC;  // rows pass that may walk several hops of its bin (PassArgs::row_reps)
   const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : (RR && a.row_reps > 1 && a.shift_q > 0) ? a.row_reps : 1;
@@ -865,18 +871,42 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
 #pragma unroll
   for (unsigned k = 0; k < SLOTS; ++k) accv[k] = 0.f;
 
+  // the sums of one batch (accv, in the tile's memory order): partial sums of a hop group, the results, or the workgroup's peak candidate
+  auto finish = [&](unsigned batch_q, unsigned slot_id) {
+    const float inv_n = 1.0f / (float)N, scale = a.acc_scale != 0.0f ? a.acc_scale : 1.0f;
+    PeakTrack pk;
+#pragma unroll
+    for (unsigned slot = 0; slot < SLOTS; ++slot) {
+      const unsigned idx = tid + slot * kFftThreads;
+      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      unsigned pos;
+      if constexpr (CONTIG) {
+        pos = v0 * L + idx;
+      } else {
+        const unsigned e = idx / C, c = idx - e * C;
+        pos = e * ESTR + (v0 + c) * VSTR;
+      }
+      if (HG > 1) {
+        a.acc_part[((long long)hg * a.acc_bins + batch_q) * N + pos] = accv[slot];
+      } else {
+        float* dstp = a.acc_out + (long long)batch_q * N + pos;
+        const float v = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * scale;
+        if (a.peak_slots) {  // the finished sums of a PRN feed nothing but its peak keys
+          if ((int)pos < a.peak_valid) pk.see(v, batch_q, pos);
+        } else {
+          *dstp = v;
+        }
+      }
+    }
+    if (HG == 1 && a.peak_slots) pk.publish_slot(a.peak_slots + 2 * (size_t)slot_id);  // slot_id: the (batch, tile) after the XCD mapping, not blockIdx.x
+  };
+
   if constexpr (FUSE) {
     constexpr int RL = R3 > 1 ? R3 : R2 > 1 ? R2 : R1;  // the last stage's radix; its inputs are L / RL apart
     constexpr unsigned LR0 = L / R0, NB0 = LR0 * C, IT0 = (NB0 + kFftThreads - 1) / kFftThreads;
     constexpr unsigned NBL = (L / RL) * C, ITL = (NBL + kFftThreads - 1) / kFftThreads;
     const float2* const twl_last = R3 > 1 ? twl + T1 + T2 : R2 > 1 ? twl + T1 : twl;
     [[maybe_unused]] float acc2[POST == POST_ABS_ACC ? ITL : 1][POST == POST_ABS_ACC ? RL : 1];
-    if constexpr (POST == POST_ABS_ACC) {
-#pragma unroll
-      for (unsigned i = 0; i < ITL; ++i)
-#pragma unroll
-        for (int q = 0; q < RL; ++q) acc2[i][q] = 0.f;
-    }
     // rows pass that walks several hops of one bin: where each of the thread's inputs comes from and the code-spectrum value it is
     // multiplied with do not depend on the hop
     [[maybe_unused]] unsigned fr_src[RR ? IT0 : 1][RR ? R0 : 1];
@@ -904,10 +934,10 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
       }
     }
     // ---- the first stage's inputs, one hop ahead (first_fetch_ct) ---------------------------------------------------------------
-    auto tb_of = [&](int rep) -> long long {
-      return POST == POST_ABS_ACC ? (long long)batch * a.nhops + (long long)hg * reps + rep
-             : RR                 ? (long long)batch * reps + rep
-                                  : (long long)batch;
+    auto tb_of = [&](unsigned bq, int rep) -> long long {
+      return POST == POST_ABS_ACC ? (long long)bq * a.nhops + (long long)hg * reps + rep
+             : RR                 ? (long long)bq * reps + rep
+                                  : (long long)bq;
     };
     float2 pre[IT0][R0];
     [[maybe_unused]] float2 poth[(PRE == PRE_MUL_CONJ && !RR) ? IT0 : 1][(PRE == PRE_MUL_CONJ && !RR) ? R0 : 1];
@@ -920,8 +950,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
         foff[it][q] = (blocked ? tile * NEL + e * C + c : e * ESTR + (v0 + c) * VSTR) * 8u;
       });
     }
-    auto fetch = [&](int rep) {
-      const long long tb = tb_of(rep);
+    auto fetch = [&](unsigned bq, int rep) {
+      const long long tb = tb_of(bq, rep);
       if constexpr (PRE == PRE_MUL_CONJ) {
         [[maybe_unused]] long long shsrc = 0;
         [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
@@ -955,9 +985,17 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
         first_each_ct<R0, L, C, true>(tid, [&](unsigned it, int q, unsigned, unsigned) { pre[it][q] = ld_off(src, foff[it][q]); });
       }
     };
-    fetch(0);
+    fetch(batch, 0);
+    for (unsigned qi = 0; qi < nq; ++qi) {  // (one batch, but for the fused columns pass of a search without hops: PassArgs::bins_per_wg)
+    const unsigned batch_q = batch + qi;
+    if constexpr (POST == POST_ABS_ACC) {
+#pragma unroll
+      for (unsigned i = 0; i < ITL; ++i)
+#pragma unroll
+        for (int q = 0; q < RL; ++q) acc2[i][q] = 0.f;
+    }
     for (int rep = 0; rep < reps; ++rep) {
-      const long long tb = tb_of(rep);
+      const long long tb = tb_of(batch_q, rep);
       // ---- first stage, inputs from registers -------------------------------------------------------------------------
       if constexpr (PRE == PRE_MUL_CONJ) {
         stage_first_ct<R0, L, LP1, C, INV, false, PAD1>(
@@ -972,7 +1010,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
       } else {
         stage_first_ct<R0, L, LP1, C, INV, true, false>([&](unsigned it, int q, unsigned, unsigned) -> float2 { return pre[it][q]; }, buf1, tid);
       }
-      if (rep + 1 < reps) fetch(rep + 1);
+      if (rep + 1 < reps) fetch(batch_q, rep + 1);
+      else if (qi + 1 < nq) fetch(batch_q + 1, 0);
       __syncthreads();
       // ---- middle stages: buf1 -> buf0 (-> buf1) ------------------------------------------------------------------------
       if constexpr (NST >= 3) {
@@ -1030,7 +1069,10 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
         const unsigned e = idx / C, c = idx - e * C;
         accv[slot] = fbuf[c * L + e];
       }
+      finish(batch_q, (bb * BQ + qi) * TILES + tile);  // (= bid when BQ == 1)
+      if (qi + 1 < nq) __syncthreads();                 // the next batch's first stage writes buf1, which held the sums
     }
+    }  // batches of the workgroup
   } else {
 
   // RR: everything of the load that does not depend on the hop - where in the source spectrum each of the thread's values comes
@@ -1192,35 +1234,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     // load orders this hop's reads of buf1 before the next first stage writes it)
     if constexpr ((POST == POST_ABS_ACC || RR) && !(NST & 1)) __syncthreads();
   }
+    if constexpr (POST == POST_ABS_ACC) finish(batch, bid);
   }  // !FUSE
-  if constexpr (POST == POST_ABS_ACC) {
-    const float inv_n = 1.0f / (float)N, scale = a.acc_scale != 0.0f ? a.acc_scale : 1.0f;
-    PeakTrack pk;
-#pragma unroll
-    for (unsigned slot = 0; slot < SLOTS; ++slot) {
-      const unsigned idx = tid + slot * kFftThreads;
-      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
-      unsigned pos;
-      if constexpr (CONTIG) {
-        pos = v0 * L + idx;
-      } else {
-        const unsigned e = idx / C, c = idx - e * C;
-        pos = e * ESTR + (v0 + c) * VSTR;
-      }
-      if (HG > 1) {
-        a.acc_part[((long long)hg * a.acc_bins + batch) * N + pos] = accv[slot];
-      } else {
-        float* dstp = a.acc_out + (long long)batch * N + pos;
-        const float v = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * scale;
-        if (a.peak_slots) {  // the finished sums of a PRN feed nothing but its peak keys
-          if ((int)pos < a.peak_valid) pk.see(v, batch, pos);
-        } else {
-          *dstp = v;
-        }
-      }
-    }
-    if (HG == 1 && a.peak_slots) pk.publish_slot(a.peak_slots + 2 * (size_t)bid);  // bid: the workgroup's (tile, batch) after the XCD pairing, not blockIdx.x
-  }
 }
 
 // ---- the whole inverse transform of a (PRN, bin) in workgroups that never touch memory in between ------------------------
@@ -1841,8 +1856,22 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
   if (CONTIG ? (a.estride != 1 || a.vstride != L) : (a.estride != OTHER || a.vstride != 1)) return false;
   for (int i = 0; i < nst; ++i)
     if (a.rad[i] != rad[i]) return false;
+  PassArgs b = a;
+  b.bins_per_wg = 1;
+  b.nbatch_total = (int)nbatch_groups;
+  constexpr bool fused = GC_ACQ_FUSE_IO != 0 && nst >= 2 && PRE == PRE_NONE && POST == POST_ABS_ACC;
+  if (fused && a.hop_groups <= 1 && !std::getenv("GC_ACQ_ONE_BIN")) {
+    // several consecutive batches per workgroup while the launch keeps a dozen workgroups per CU (BDS B1C: 200 tiles x 201 bins)
+    for (int cand : {4, 2})
+      if ((long long)(OTHER / C) * nbatch_groups / cand >= 12LL * ctx->compute_units) {
+        b.bins_per_wg = cand;
+        break;
+      }
+    if (const char* e = std::getenv("GC_ACQ_BINS_PER_WG")) b.bins_per_wg = std::max(1, std::atoi(e));
+  }
+  const long long groups = (nbatch_groups + b.bins_per_wg - 1) / b.bins_per_wg;
   hipLaunchKernelGGL((fft_pass_ct<L, OTHER, CONTIG, C, PRE, POST, INV, SHIFT, R0, R1, R2, R3>),
-                     dim3((unsigned int)((OTHER / C) * nbatch_groups)), dim3(kFftThreads), 0, ctx->stream, a);
+                     dim3((unsigned int)((OTHER / C) * groups)), dim3(kFftThreads), 0, ctx->stream, b);
   return true;
 }
 

@@ -196,7 +196,13 @@ def test_fused_inverse_transform_kernel_at_the_references_default_search_sizes(e
 _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": "1"}), ("GAL_E1C", {"GC_ACQ_PEAK_KERNEL": "1"}),
               ("BDS_B1C", {"GC_ACQ_PEAK_KERNEL": "1"}), ("BDS_B1I", {"GC_ACQ_ROWMAX_KERNEL": "1"}), ("GPS_L2C", {"GC_ACQ_ROWMAX_KERNEL": "1"}),
               ("GPS_L1CA", {"GC_ACQ_NO_HOP_GROUPS": "1"}), ("GLO_GL1", {"GC_ACQ_NATURAL_ORDER": "1"}), ("GAL_E1C", {"GC_ACQ_GENERIC": "1"}),
-              ("BDS_B1I", {"GC_ACQ_GENERIC": "1"})]
+              ("BDS_B1I", {"GC_ACQ_GENERIC": "1"}),
+              # later in round 4: several bins per workgroup of the fused columns pass (forced here: the toy searches are too small to
+              # get them by themselves; 3 and 4 leave a remainder), the pairing instead of XCD runs, the fine stage's code periods cut
+              # into runs, and the hop groups that two lanes no longer need at the default size
+              ("BDS_B1C", {"GC_ACQ_BINS_PER_WG": "3"}), ("GAL_E1C", {"GC_ACQ_BINS_PER_WG": "4"}), ("GPS_L2C", {"GC_ACQ_BINS_PER_WG": "2"}),
+              ("BDS_B1I", {"GC_ACQ_BINS_PER_WG": "4"}), ("BDS_B1C", {"GC_ACQ_XCD_MAP": "pairs"}), ("GPS_L1CA", {"GC_ACQ_FINE_PARTS": "8"}),
+              ("GPS_L1CA", {"GC_ACQ_HOP_GROUPS": "2"}), ("GAL_E5b", {"GC_ACQ_HOP_GROUPS": "3"})]
 
 
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
@@ -205,7 +211,8 @@ def test_acquisition_paths_behind_the_tuning_knobs_return_the_references_results
     (GC_ACQ_LANES=1), the separate peak kernel over the written sums instead of the last pass's per-workgroup candidates
     (GC_ACQ_PEAK_KERNEL=1: one-hop searches), the row-maxima kernel instead of candidates + the winning row transformed again
     (GC_ACQ_ROWMAX_KERNEL=1: circshift family), no hop groups, the natural-order intermediate, the run-time pass kernel: every one
-    of them against the same reference-executed fixture as the default path."""
+    of them against the same reference-executed fixture as the default path.  (GC_ACQ_ONE_BIN=1, the other switch of the bins per
+    workgroup, is what these toy sizes run by default.)"""
     import cu_sdr_collection_amd as P
     sc = next(s for s in RS.ACQ_SCENES if s.name == name)
     for k, v in env.items():
