@@ -255,6 +255,25 @@ def time_replay(job: Job, steps: int, warmup: int, warm=None, prewarm_ms: float 
     return ms, dev, eng.last_kernel()
 
 
+def time_replays_together(jobs, steps: int, warmup: int):
+    """The replays of several jobs of ONE record (one engine = one context and stream each), every pass launching all of them
+    before the next pass: milliseconds per pass of the whole band, host clock around `steps` passes between two synchronisations
+    (events of one stream do not bracket the others).  Each job's list was prepared by time_replay before."""
+    import time
+    for _ in range(max(1, warmup)):
+        for j in jobs:
+            j.engine.replay_launch()
+    for j in jobs:
+        j.engine.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for j in jobs:
+            j.engine.replay_launch()
+    for j in jobs:
+        j.engine.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
 KERNEL_NAMES = {0: "corr_epl_lane_kernel", 1: "corr_epl_fast_kernel (one-wave workgroups)", 2: "corr_epl_fast_kernel (four waves, int8-pair tables)",
                 3: "corr_epl_fast_kernel (four waves, float tables)", 4: "corr_epl_multi_kernel (up to 2 / 4 transitions per 16-sample chunk)",
                 -1: "corr_epl_mixed_kernel"}
