@@ -174,8 +174,11 @@ struct PassArgs {
   // tb / shift_bins shifted by tb % shift_bins natural-frequency bins; n1, n2 give the [k1][k2] storage order
   int shift_bins, n1, n2;
   // the same with batch tb = bin * nhops + hop (coarse search whose bin spacing is a whole number of FFT bins): reads input
-  // transform `hop` shifted by bin * shift_q
+  // transform `hop` shifted by bin * shift_q.  shift_den > 1: the spacing is shift_q / shift_den bins (Galileo E5b: 60 Hz x 2 ms = 3 / 25,
+  // Galileo E1: 150 Hz x 8 ms = 6 / 5) - bin b reads transform (b % shift_den) * nhops + hop, one of shift_den x nhops, shifted by
+  // (b / shift_den) * shift_q whole bins
   int shift_q;
+  int shift_den;
   // PRE_IF_CARRIER on a transform longer than the reference's 2*spc (sizes the radix-{2..8} plan cannot take are padded to
   // the next one it can, launch in gc_acquire_coarse_multi): positions wrap_len .. wrap_len + spc - 1 repeat the first spc
   // (mixed) samples, everything behind is zero
@@ -384,7 +387,7 @@ struct PeakTrack {
   // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
   // the workgroup's candidate in thread 0: {maximum's bits, smallest bin, smallest column among the lanes that hold it}
   __device__ __forceinline__ bool reduce(unsigned long long& ka, unsigned long long& kb) const {
-    __shared__ unsigned int sm[4], sb[4], sc[4];
+    __shared__ unsigned int sm[16], sb[16], sc[16];  // one entry per wavefront (workgroups of up to 1024 threads)
     unsigned int wm = m;
     for (int off = 32; off > 0; off >>= 1) wm = max(wm, (unsigned int)__shfl_xor((int)wm, off, 64));
     unsigned int b = m == wm ? bin : 0xffffffffu, c = m == wm ? col : 0xffffffffu;
@@ -510,8 +513,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
           if (a.pre == PRE_MUL_CONJ && (a.shift_bins > 0 || a.shift_q > 0)) {
             // circshift(X, s): Y[k] = X[(k - s) mod n] in natural frequency order; storage position of frequency
             // k = k1 + n1*k2 is k1*n2 + k2
-            const long long src = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
-            const int sft = a.shift_q > 0 ? (int)(tb / a.nhops) * a.shift_q : (int)(tb % a.shift_bins);
+            const int den = a.shift_den > 1 ? a.shift_den : 1, sbin = (int)(tb / a.nhops);
+            const long long src = a.shift_q > 0 ? (long long)(sbin % den) * a.nhops + tb % a.nhops : tb / a.shift_bins;
+            const int sft = a.shift_q > 0 ? (sbin / den) * a.shift_q : (int)(tb % a.shift_bins);
             const int k1 = (int)(pos / a.n2), k2 = (int)(pos % a.n2);
             int k = k1 + a.n1 * k2 - sft;
             if (k < 0) k += a.n;
@@ -655,15 +659,15 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
 // generic kernel.
 // LP: pitch of a tile row of dst in LDS (L, or L + 1 in the fused-I/O columns pass); SP > 0: the SOURCE rows carry one pad element after
 // every 2^SP (element i at i + (i >> SP), pitch SLP) - what a fused first stage of radix 2^SP leaves (stage_first_ct)
-template <int R, int L, int C, int NS, bool INV, int LP = L, int SP = 0, int SLP = LP>
+template <int NT, int R, int L, int C, int NS, bool INV, int LP = L, int SP = 0, int SLP = LP>
 __device__ __forceinline__ void stage_ct(const float2* __restrict__ src, float2* __restrict__ dst, const float2* __restrict__ twl,
                                          unsigned tid) {
-  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + NT - 1) / NT;
   constexpr float sign = INV ? -1.0f : 1.0f;
 #pragma unroll
   for (unsigned it = 0; it < ITERS; ++it) {
-    const unsigned b = tid + it * kFftThreads;
-    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    const unsigned b = tid + it * NT;
+    if ((it + 1) * NT > NB && b >= NB) break;
     const unsigned c = b / LR, j = b - c * LR;
     const unsigned k = NS == 1 ? 0u : j % (unsigned)NS;
     const float2* s = src + c * SLP;
@@ -692,14 +696,14 @@ __device__ __forceinline__ void stage_ct(const float2* __restrict__ src, float2*
 // apart so that the radix-R groups the threads write do not pile onto a few banks.
 // PAD: a thread's R outputs are followed by one pad element (row pitch LP = L + L / R): with R = 8 the threads' 64-byte groups
 // would otherwise start 16 banks apart - two bank groups for 64 lanes, four conflict cycles per store.
-template <int R, int L, int LP, int C, bool INV, bool CFAST, bool PAD, class F>
+template <int NT, int R, int L, int LP, int C, bool INV, bool CFAST, bool PAD, class F>
 __device__ __forceinline__ void stage_first_ct(F&& in, float2* __restrict__ dst, unsigned tid) {
-  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + NT - 1) / NT;
   constexpr float sign = INV ? -1.0f : 1.0f;
 #pragma unroll
   for (unsigned it = 0; it < ITERS; ++it) {
-    const unsigned b = tid + it * kFftThreads;
-    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    const unsigned b = tid + it * NT;
+    if ((it + 1) * NT > NB && b >= NB) break;
     unsigned c, j;
     if constexpr (CFAST) {
       j = b / C;
@@ -722,13 +726,13 @@ __device__ __forceinline__ void stage_first_ct(F&& in, float2* __restrict__ dst,
 // several hops fetches the NEXT hop's inputs into registers with this right after its first stage has consumed the current ones: the
 // loads are in flight during the other stages (their barriers wait for LDS, not for memory) instead of every hop starting with a
 // full memory latency in front of its first butterfly.
-template <int R, int L, int C, bool CFAST, class F>
+template <int NT, int R, int L, int C, bool CFAST, class F>
 __device__ __forceinline__ void first_each_ct(unsigned tid, F&& f) {
-  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + NT - 1) / NT;
 #pragma unroll
   for (unsigned it = 0; it < ITERS; ++it) {
-    const unsigned b = tid + it * kFftThreads;
-    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    const unsigned b = tid + it * NT;
+    if ((it + 1) * NT > NB && b >= NB) break;
     unsigned c, j;
     if constexpr (CFAST) {
       j = b / C;
@@ -753,14 +757,14 @@ __device__ __forceinline__ float2 ld_off(const float2* __restrict__ base, unsign
 }
 
 // the last stage (NS = L / R: k = j): out(it, q, c, e, value) receives element e = j + q * NS of vector c
-template <int R, int L, int LP, int C, bool INV, int SP, class F>
+template <int NT, int R, int L, int LP, int C, bool INV, int SP, class F>
 __device__ __forceinline__ void stage_last_ct(const float2* __restrict__ src, const float2* __restrict__ twl, unsigned tid, F&& out) {
-  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + kFftThreads - 1) / kFftThreads;
+  constexpr unsigned LR = L / R, NB = LR * C, ITERS = (NB + NT - 1) / NT;
   constexpr float sign = INV ? -1.0f : 1.0f;
 #pragma unroll
   for (unsigned it = 0; it < ITERS; ++it) {
-    const unsigned b = tid + it * kFftThreads;
-    if ((it + 1) * kFftThreads > NB && b >= NB) break;
+    const unsigned b = tid + it * NT;
+    if ((it + 1) * NT > NB && b >= NB) break;
     const unsigned c = b / LR, j = b - c * LR;
     const float2* s = src + c * LP;
     auto at = [&](unsigned i) -> float2 { return SP > 0 ? s[i + (i >> SP)] : s[i]; };
@@ -775,14 +779,14 @@ __device__ __forceinline__ void stage_last_ct(const float2* __restrict__ src, co
 }
 
 // W_{NS*R}^{k*q} (k < NS, 0 < q < R) of one stage from the global table exp(-2*pi*i*m/N)
-template <int R, int NS, int N, bool INV>
+template <int NT, int R, int NS, int N, bool INV>
 __device__ __forceinline__ void stage_twiddles_ct(const float2* __restrict__ tw, float2* twl, unsigned tid) {
   if constexpr (R > 1 && NS > 1) {
     // stored [q - 1][k] (not [k][q - 1]): a butterfly's lanes have consecutive k, and R - 1 = 4 values of 8 bytes per k put every
     // fourth lane on the same banks - 2.7 / 4.0 conflict cycles per LDS instruction of the rows / columns pass (profiles/r04)
     constexpr unsigned CNT = NS * (R - 1), TWS = N / (NS * R);
     static_assert(N % (NS * R) == 0, "stage size divides the transform size");
-    for (unsigned i = tid; i < CNT; i += kFftThreads) {
+    for (unsigned i = tid; i < CNT; i += NT) {
       const unsigned q = i / NS + 1, k = i - (q - 1) * NS;
       float2 w = tw[k * q * TWS];
       if (INV) w.y = -w.y;
@@ -791,16 +795,50 @@ __device__ __forceinline__ void stage_twiddles_ct(const float2* __restrict__ tw,
   }
 }
 
+// Threads per workgroup of a specialised pass.  A stage of radix R has (L / R) * C butterflies, one per thread and iteration; with 256
+// threads the 288 radix-5 butterflies of the 180 x 8 columns tile are two iterations for wavefront 0 (the second one for 32 lanes) and
+// one for the others, and every barrier waits for wavefront 0: the workgroup's critical path is the SUM over the stages of
+// ceil(butterflies / threads).  The passes are latency-bound, so the workgroup takes the smallest thread count up to
+// the cap that minimises that sum; wavefronts without a butterfly in a stage skip it (the issue slots spent stay the same).
+// The cap, measured per plan over the twelve default searches (-DGC_ACQ_NT_MAX=n applies one cap to every plan): 320 for the short
+// vectors of the 36 000- and 24 000-point plans (columns pass of the default L1 C/A search 4 -> 3 iterations: 3.29 -> 3.06 ms sustained,
+// L5 / E5a / E5b / B3I -5..-8 %), 512 for the 600 x 600 plan (8 -> 4: B1C 109 -> 104 ms; 320 gives 7 iterations and 137 ms), 256
+// elsewhere (375 x 384, 250 x 288, 512 x 625: within the noise or slower with more wavefronts per tile).
+template <int L>
+constexpr int ct_threads_cap() {
+#ifdef GC_ACQ_NT_MAX
+  return GC_ACQ_NT_MAX > kFftThreads ? GC_ACQ_NT_MAX : kFftThreads;
+#else
+  return L <= 200 ? 320 : L == 600 ? 512 : kFftThreads;
+#endif
+}
+template <int L, int C, int R0, int R1, int R2, int R3>
+constexpr int ct_threads() {
+  const int rad[4] = {R0, R1, R2, R3};
+  int best = kFftThreads, best_it = 1 << 30;
+  for (int nt = kFftThreads; nt <= ct_threads_cap<L>(); nt += 64) {
+    int it = 0;
+    for (int r : rad)
+      if (r > 1) it += ((L / r) * C + nt - 1) / nt;
+    if (it < best_it) {
+      best_it = it;
+      best = nt;
+    }
+  }
+  return best;
+}
+
 template <int L, int OTHER, bool CONTIG, int C, int PRE, int POST, bool INV, bool SHIFT, int R0, int R1, int R2, int R3>
 #ifndef GC_ACQ_PASS_WAVES
 #define GC_ACQ_PASS_WAVES 5
 #endif
 // second bound: wavefronts per SIMD the register allocation must leave room for - the tiles of the short passes (<= 26 KB of LDS) fit
 // six workgroups per CU, and the passes are latency-bound (barriers between stages): the registers must not be what limits them
-__global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) void fft_pass_ct(const PassArgs a) {
+__global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) void fft_pass_ct(const PassArgs a) {
+  constexpr unsigned NT = ct_threads<L, C, R0, R1, R2, R3>();
   static_assert(R0 * R1 * R2 * R3 == L && OTHER % C == 0, "radices multiply to L; whole tiles only");
   static_assert(!SHIFT || (CONTIG && PRE == PRE_MUL_CONJ), "shifted reads belong to the rows pass of the inverse transform");
-  constexpr unsigned N = L * OTHER, NEL = L * C, SLOTS = (NEL + kFftThreads - 1) / kFftThreads, TILES = OTHER / C;
+  constexpr unsigned N = L * OTHER, NEL = L * C, SLOTS = (NEL + NT - 1) / NT, TILES = OTHER / C;
   static_assert(SLOTS <= kFftSlots + 2, "tile too large");
   constexpr unsigned ESTR = CONTIG ? 1 : OTHER, VSTR = CONTIG ? L : 1;
   constexpr int NS1 = R0, NS2 = R0 * R1, NS3 = R0 * R1 * R2;
@@ -824,6 +862,7 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
   __shared__ float2 twl[T1 + T2 + T3 + 1];
   __shared__ float2 tw2[POST == POST_TWIDDLE ? C * TW2 : 1];
   const unsigned tid = threadIdx.x;
+  [[maybe_unused]] const unsigned sden = a.shift_den > 1 ? (unsigned)a.shift_den : 1u;  // (PassArgs::shift_den)
   // Strided (column) passes: a tile row is C consecutive float2 - 64 bytes at C = 8, half of a 128-byte line.  The neighbouring
   // tile reads the other half; consecutive workgroups go to consecutive XCDs, each with an L2 of its own, and both fetched
   // the whole line (rocprofv3 FETCH_SIZE: 328 MB per launch of the inverse columns pass for the 167 MB it reads).  Blocks b
@@ -853,12 +892,12 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
   constexpr bool RR = SHIFT && POST != POST_ABS_ACC;  // rows pass that may walk several hops of its bin (PassArgs::row_reps)
   const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : (RR && a.row_reps > 1 && a.shift_q > 0) ? a.row_reps : 1;
 
-  stage_twiddles_ct<R1, NS1, N, INV>(a.tw, twl, tid);
-  stage_twiddles_ct<R2, NS2, N, INV>(a.tw, twl + T1, tid);
-  stage_twiddles_ct<R3, NS3, N, INV>(a.tw, twl + T1 + T2, tid);
+  stage_twiddles_ct<NT, R1, NS1, N, INV>(a.tw, twl, tid);
+  stage_twiddles_ct<NT, R2, NS2, N, INV>(a.tw, twl + T1, tid);
+  stage_twiddles_ct<NT, R3, NS3, N, INV>(a.tw, twl + T1 + T2, tid);
   if constexpr (POST == POST_TWIDDLE) {
     // W_N^(v*e) = W_N^(v*16*(e>>4)) * W_N^(v*(e&15)): C * (EH + 16) table entries per tile
-    for (unsigned i = tid; i < C * TW2; i += kFftThreads) {
+    for (unsigned i = tid; i < C * TW2; i += NT) {
       const unsigned c = i / TW2, j = i - c * TW2;
       const unsigned v = v0 + c;
       float2 w = a.tw[j < EH ? v * (j << 4) : v * (j - EH)];  // v * e < N for every e < L
@@ -877,8 +916,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     PeakTrack pk;
 #pragma unroll
     for (unsigned slot = 0; slot < SLOTS; ++slot) {
-      const unsigned idx = tid + slot * kFftThreads;
-      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      const unsigned idx = tid + slot * NT;
+      if ((slot + 1) * NT > NEL && idx >= NEL) break;
       unsigned pos;
       if constexpr (CONTIG) {
         pos = v0 * L + idx;
@@ -903,8 +942,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
 
   if constexpr (FUSE) {
     constexpr int RL = R3 > 1 ? R3 : R2 > 1 ? R2 : R1;  // the last stage's radix; its inputs are L / RL apart
-    constexpr unsigned LR0 = L / R0, NB0 = LR0 * C, IT0 = (NB0 + kFftThreads - 1) / kFftThreads;
-    constexpr unsigned NBL = (L / RL) * C, ITL = (NBL + kFftThreads - 1) / kFftThreads;
+    constexpr unsigned LR0 = L / R0, NB0 = LR0 * C, IT0 = (NB0 + NT - 1) / NT;
+    constexpr unsigned NBL = (L / RL) * C, ITL = (NBL + NT - 1) / NT;
     const float2* const twl_last = R3 > 1 ? twl + T1 + T2 : R2 > 1 ? twl + T1 : twl;
     [[maybe_unused]] float acc2[POST == POST_ABS_ACC ? ITL : 1][POST == POST_ABS_ACC ? RL : 1];
     // rows pass that walks several hops of one bin: where each of the thread's inputs comes from and the code-spectrum value it is
@@ -913,12 +952,12 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     [[maybe_unused]] float2 fr_oth[RR ? IT0 : 1][RR ? R0 : 1];
     if constexpr (RR) {
       const long long tb0 = (long long)batch * reps;
-      const unsigned sft = a.shift_q > 0 ? (unsigned)(tb0 / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
+      const unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
       const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
 #pragma unroll
       for (unsigned it = 0; it < IT0; ++it) {
-        const unsigned b = tid + it * kFftThreads;
-        if ((it + 1) * kFftThreads > NB0 && b >= NB0) break;
+        const unsigned b = tid + it * NT;
+        if ((it + 1) * NT > NB0 && b >= NB0) break;
         const unsigned c = b / LR0, j = b - c * LR0;
         int k1 = (int)(v0 + c) - (int)s1;
         const int bor = k1 < 0;
@@ -946,7 +985,7 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     if constexpr (PRE == PRE_NONE) {
       const bool blocked = a.in_blocked != 0;
       // blocked: this tile's L x C values vector-fastest (e * C + c: consecutive threads, consecutive addresses)
-      first_each_ct<R0, L, C, true>(tid, [&](unsigned it, int q, unsigned c, unsigned e) {
+      first_each_ct<NT, R0, L, C, true>(tid, [&](unsigned it, int q, unsigned c, unsigned e) {
         foff[it][q] = (blocked ? tile * NEL + e * C + c : e * ESTR + (v0 + c) * VSTR) * 8u;
       });
     }
@@ -956,13 +995,14 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
         [[maybe_unused]] long long shsrc = 0;
         [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
         if constexpr (SHIFT) {
-          const unsigned sft = a.shift_q > 0 ? (unsigned)(tb / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
-          shsrc = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
+          const unsigned sbin = (unsigned)(tb / a.nhops);
+          const unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
+          shsrc = a.shift_q > 0 ? (long long)(sbin % sden) * a.nhops + tb % a.nhops : tb / a.shift_bins;
           sh2 = sft / OTHER;
           sh1 = sft - sh2 * OTHER;
         }
         const float2* __restrict__ src = a.in + (SHIFT ? shsrc : tb) * a.in_batch_stride;
-        first_each_ct<R0, L, C, false>(tid, [&](unsigned it, int q, unsigned c, unsigned e) {
+        first_each_ct<NT, R0, L, C, false>(tid, [&](unsigned it, int q, unsigned c, unsigned e) {
           if constexpr (RR) {
             pre[it][q] = ld_off(src, fr_src[it][q]);
           } else {
@@ -982,7 +1022,7 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
         });
       } else {
         const float2* __restrict__ src = a.in + tb * a.in_batch_stride;
-        first_each_ct<R0, L, C, true>(tid, [&](unsigned it, int q, unsigned, unsigned) { pre[it][q] = ld_off(src, foff[it][q]); });
+        first_each_ct<NT, R0, L, C, true>(tid, [&](unsigned it, int q, unsigned, unsigned) { pre[it][q] = ld_off(src, foff[it][q]); });
       }
     };
     fetch(batch, 0);
@@ -998,7 +1038,7 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
       const long long tb = tb_of(batch_q, rep);
       // ---- first stage, inputs from registers -------------------------------------------------------------------------
       if constexpr (PRE == PRE_MUL_CONJ) {
-        stage_first_ct<R0, L, LP1, C, INV, false, PAD1>(
+        stage_first_ct<NT, R0, L, LP1, C, INV, false, PAD1>(
             [&](unsigned it, int q, unsigned, unsigned) -> float2 {
               const float2 val = pre[it][q];
               float2 o;
@@ -1008,18 +1048,18 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
             },
             buf1, tid);
       } else {
-        stage_first_ct<R0, L, LP1, C, INV, true, false>([&](unsigned it, int q, unsigned, unsigned) -> float2 { return pre[it][q]; }, buf1, tid);
+        stage_first_ct<NT, R0, L, LP1, C, INV, true, false>([&](unsigned it, int q, unsigned, unsigned) -> float2 { return pre[it][q]; }, buf1, tid);
       }
       if (rep + 1 < reps) fetch(batch_q, rep + 1);
       else if (qi + 1 < nq) fetch(batch_q + 1, 0);
       __syncthreads();
       // ---- middle stages: buf1 -> buf0 (-> buf1) ------------------------------------------------------------------------
       if constexpr (NST >= 3) {
-        stage_ct<R1, L, C, NS1, INV, LP, SP1, LP1>(buf1, buf0, twl, tid);
+        stage_ct<NT, R1, L, C, NS1, INV, LP, SP1, LP1>(buf1, buf0, twl, tid);
         __syncthreads();
       }
       if constexpr (NST >= 4) {
-        stage_ct<R2, L, C, NS2, INV, LP>(buf0, buf1, twl + T1, tid);
+        stage_ct<NT, R2, L, C, NS2, INV, LP>(buf0, buf1, twl + T1, tid);
         __syncthreads();
       }
       const float2* lsrc = (NST == 3) ? buf0 : buf1;
@@ -1029,7 +1069,7 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
       if constexpr (POST == POST_TWIDDLE) {
         float2* __restrict__ dstp = a.out + tb * a.out_batch_stride;
         const unsigned obl = (unsigned)a.out_blocked;
-        stage_last_ct<RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned, int, unsigned c, unsigned e, float2 val) {
+        stage_last_ct<NT, RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned, int, unsigned c, unsigned e, float2 val) {
           val = cmul(val, cmul(tw2[c * TW2 + (e >> 4)], tw2[c * TW2 + EH + (e & 15)]));
           unsigned pos = (v0 + c) * L + e;
           if (obl) {
@@ -1039,7 +1079,7 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
           dstp[pos] = val;
         });
       } else {
-        stage_last_ct<RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned it, int q, unsigned, unsigned, float2 val) {
+        stage_last_ct<NT, RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned it, int q, unsigned, unsigned, float2 val) {
           acc2[it][q] += cabs_f(val.x, val.y);
         });
       }
@@ -1054,8 +1094,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
         constexpr unsigned LRL = L / RL;
 #pragma unroll
         for (unsigned it = 0; it < ITL; ++it) {
-          const unsigned b = tid + it * kFftThreads;
-          if ((it + 1) * kFftThreads > NBL && b >= NBL) break;
+          const unsigned b = tid + it * NT;
+          if ((it + 1) * NT > NBL && b >= NBL) break;
           const unsigned c = b / LRL, j = b - c * LRL;
 #pragma unroll
           for (int q = 0; q < RL; ++q) fbuf[c * L + j + q * LRL] = acc2[it][q];
@@ -1064,8 +1104,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
       __syncthreads();
 #pragma unroll
       for (unsigned slot = 0; slot < SLOTS; ++slot) {
-        const unsigned idx = tid + slot * kFftThreads;
-        if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+        const unsigned idx = tid + slot * NT;
+        if ((slot + 1) * NT > NEL && idx >= NEL) break;
         const unsigned e = idx / C, c = idx - e * C;
         accv[slot] = fbuf[c * L + e];
       }
@@ -1081,12 +1121,12 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
   [[maybe_unused]] float2 rr_oth[RR ? SLOTS : 1];
   if constexpr (RR) {
     const long long tb0 = (long long)batch * reps;
-    const unsigned sft = a.shift_q > 0 ? (unsigned)(tb0 / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
+    const unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
     const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
 #pragma unroll
     for (unsigned slot = 0; slot < SLOTS; ++slot) {
-      const unsigned idx = tid + slot * kFftThreads;
-      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      const unsigned idx = tid + slot * NT;
+      if ((slot + 1) * NT > NEL && idx >= NEL) break;
       const unsigned c = idx / L, e = idx - c * L;
       int k1 = (int)(v0 + c) - (int)s1;
       const int bor = k1 < 0;
@@ -1108,8 +1148,9 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     [[maybe_unused]] long long shsrc = 0;
     [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
     if constexpr (SHIFT) {
-      const unsigned sft = a.shift_q > 0 ? (unsigned)(tb / a.nhops) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
-      shsrc = a.shift_q > 0 ? tb % a.nhops : tb / a.shift_bins;
+      const unsigned sbin = (unsigned)(tb / a.nhops);
+      const unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
+      shsrc = a.shift_q > 0 ? (long long)(sbin % sden) * a.nhops + tb % a.nhops : tb / a.shift_bins;
       sh2 = sft / OTHER;
       sh1 = sft - sh2 * OTHER;
     }
@@ -1120,8 +1161,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     }
 #pragma unroll
     for (unsigned slot = 0; slot < SLOTS; ++slot) {
-      const unsigned idx = tid + slot * kFftThreads;
-      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      const unsigned idx = tid + slot * NT;
+      if ((slot + 1) * NT > NEL && idx >= NEL) break;
       unsigned pos, li;
       if constexpr (CONTIG) {
         pos = v0 * L + idx;  // the tile is C whole vectors: one contiguous run of the transform
@@ -1183,18 +1224,18 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     __syncthreads();
 
     // ---- stages: buf0 -> buf1 -> buf0 -> ... -------------------------------------------------------------
-    stage_ct<R0, L, C, 1, INV>(buf0, buf1, twl, tid);
+    stage_ct<NT, R0, L, C, 1, INV>(buf0, buf1, twl, tid);
     __syncthreads();
     if constexpr (R1 > 1) {
-      stage_ct<R1, L, C, NS1, INV>(buf1, buf0, twl, tid);
+      stage_ct<NT, R1, L, C, NS1, INV>(buf1, buf0, twl, tid);
       __syncthreads();
     }
     if constexpr (R2 > 1) {
-      stage_ct<R2, L, C, NS2, INV>(buf0, buf1, twl + T1, tid);
+      stage_ct<NT, R2, L, C, NS2, INV>(buf0, buf1, twl + T1, tid);
       __syncthreads();
     }
     if constexpr (R3 > 1) {
-      stage_ct<R3, L, C, NS3, INV>(buf1, buf0, twl + T1 + T2, tid);
+      stage_ct<NT, R3, L, C, NS3, INV>(buf1, buf0, twl + T1 + T2, tid);
       __syncthreads();
     }
     const float2* res = (NST & 1) ? buf1 : buf0;
@@ -1202,8 +1243,8 @@ __global__ __launch_bounds__(kFftThreads, (L <= 200 ? GC_ACQ_PASS_WAVES : 1)) vo
     // ---- store -------------------------------------------------------------------------------------------
 #pragma unroll
     for (unsigned slot = 0; slot < SLOTS; ++slot) {
-      const unsigned idx = tid + slot * kFftThreads;
-      if ((slot + 1) * kFftThreads > NEL && idx >= NEL) break;
+      const unsigned idx = tid + slot * NT;
+      if ((slot + 1) * NT > NEL && idx >= NEL) break;
       unsigned pos, li, e, c;
       if constexpr (CONTIG) {
         c = idx / L;
@@ -1796,6 +1837,40 @@ __global__ __launch_bounds__(256) void fine_parts_kernel(const double* __restric
   out[i] = sum;
 }
 
+// GPS L1 C/A fine stage, the part behind the per-code sums (acquisition.m:240-253): for every fine bin the largest |sum of 20 consecutive
+// per-code sums| over the 20 navigation-bit-edge hypotheses, then the first bin that holds the largest of those.  One workgroup per
+// detection, one thread per bin; every sum is added in the reference's order in float64 with separately rounded operations (what the host
+// loop this replaces did: 161 KB of sums per 12 detections came back for 100 000 dependent additions on one core - ~0.1 ms of a 3-ms search).
+__global__ __launch_bounds__(64) void fine_l1ca_pick_kernel(const double* __restrict__ sums, int nbins, int ncodes, int* __restrict__ best_bin) {
+  __shared__ double pw[64];
+  const int d = blockIdx.x, b = threadIdx.x;
+  double max_power = 0.0;
+  if (b < nbins) {
+    const double* hd = sums + ((size_t)d * nbins + b) * ncodes * 2;
+    for (int c0 = 0; c0 + 20 <= ncodes && c0 < 20; ++c0) {
+      double sr = 0.0, si = 0.0;
+      for (int c = c0; c < c0 + 20; ++c) {
+        sr = __dadd_rn(sr, hd[2 * c]);
+        si = __dadd_rn(si, hd[2 * c + 1]);
+      }
+      const double pwr = __dsqrt_rn(__dadd_rn(__dmul_rn(sr, sr), __dmul_rn(si, si)));
+      max_power = pwr > max_power ? pwr : max_power;   // max(maxPower, comPower), :247
+    }
+  }
+  pw[b] = max_power;
+  __syncthreads();
+  if (b == 0) {
+    double best = -1.0;
+    int bb = 0;
+    for (int k = 0; k < nbins; ++k)
+      if (pw[k] > best) {  // [~, maxFinBin] = max(fineResult): the first maximum, :253
+        best = pw[k];
+        bb = k;
+      }
+    best_bin[d] = bb;
+  }
+}
+
 // One workgroup per row: maximum and its first position (MATLAB's max returns the first maximum).
 // Row maxima of a circshift search from the per-workgroup candidates its last pass left (PeakTrack::publish_slot: every workgroup of
 // that pass belongs to ONE row; key = value bits << 32 | ~column, so the largest key is the row's maximum at its first column):
@@ -1871,7 +1946,7 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
   }
   const long long groups = (nbatch_groups + b.bins_per_wg - 1) / b.bins_per_wg;
   hipLaunchKernelGGL((fft_pass_ct<L, OTHER, CONTIG, C, PRE, POST, INV, SHIFT, R0, R1, R2, R3>),
-                     dim3((unsigned int)((OTHER / C) * groups)), dim3(kFftThreads), 0, ctx->stream, b);
+                     dim3((unsigned int)((OTHER / C) * groups)), dim3(ct_threads<L, C, R0, R1, R2, R3>()), 0, ctx->stream, b);
   return true;
 }
 
@@ -2317,12 +2392,26 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   // bin b is the spectrum of bin 0 moved by b*q positions: x .* exp(-1i*(f0 - b*step)*phasePoints) =
   // (x .* exp(-1i*f0*phasePoints)) .* exp(+2i*pi*b*q*n/N).  H spectra are then computed instead of nbins*H and the
   // inverse transforms read them shifted (5.8 MB that stay in cache instead of 167 MB from HBM per PRN).
+  // A spacing of q / den bins (den > 1: Galileo E5b's 60 Hz x 2 ms = 3 / 25, Galileo E1's 150 Hz x 8 ms = 6 / 5) leaves den classes of bins,
+  // b % den, each a whole-bin shift of its class's first bin: den x H spectra instead of nbins x H (E5b: 375 for 2 520, 108 MB that the
+  // rows passes of all 72 code arms find in the last-level cache instead of 725 MB from HBM each; GC_ACQ_NO_RATIONAL_SHIFT=1: whole bins only)
   const double qd = p->search_step * (double)n / p->sampling_freq;
-  const long long q = (long long)std::floor(qd + 0.5);
-  const bool shifted = !padded && q >= 1 && std::fabs(qd - (double)q) <= 1e-12 * qd && (long long)(nbins - 1) * q < n &&
-                       std::getenv("GC_ACQ_NO_SHIFT") == nullptr;
+  long long q = 0;
+  int den = 1;
+  {
+    const int den_max = std::getenv("GC_ACQ_NO_RATIONAL_SHIFT") || std::getenv("GC_ACQ_FUSED") ? 1 : std::min(64, nbins / 2);
+    for (int d = 1; d <= den_max && q == 0; ++d) {
+      const double qq = qd * d, r = std::floor(qq + 0.5);
+      if (r >= 1 && std::fabs(qq - r) <= 1e-12 * qq) {
+        q = (long long)r;
+        den = d;
+      }
+    }
+  }
+  const bool shifted = !padded && q >= 1 && (long long)((nbins - 1) / den) * q < n && std::getenv("GC_ACQ_NO_SHIFT") == nullptr;
+  if (!shifted) den = 1;
   base.wrap_len = padded ? blk : 0;
-  rc = forward(ctx, s, base, PRE_IF_CARRIER, shifted ? (long long)H : (long long)nbins * H, s->sig);
+  rc = forward(ctx, s, base, PRE_IF_CARRIER, shifted ? (long long)den * H : (long long)nbins * H, s->sig);
   if (rc) return rc;
   // code spectra (conj applied at the product)
   base.codes = s->codes;
@@ -2428,6 +2517,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.in = s->sig;
       a.in_batch_stride = pl.n;
       a.shift_q = shifted ? (int)q : 0;
+      a.shift_den = den;
       a.n1 = pl.n1;
       a.n2 = pl.n2;
       a.other = s->codespec + ((size_t)ip * narms + arm) * pl.n;
@@ -2639,9 +2729,11 @@ extern "C" int gc_acq_conditioned(gc_context* ctx, int64_t first, int64_t n, flo
 // carriers f0 - k*fstep over `ncodes` periods from first_sample; the hypothesis search over bit edges / Neuman-
 // Hofman / secondary codes / data+pilot combinations is a few hundred flops and stays with the caller.
 // `ndet` detections (code d*code_len.., first_sample[d], f0[d]) share one launch and one read-back.
-extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params* p, int ndet, const int8_t* codes,
-                                          const int64_t* first_sample, const double* f0, double* out) {
-  if (!ctx || !p || ndet <= 0 || ndet > 65535 || !codes || !first_sample || !f0 || !out || p->spc <= 0 || p->ncodes <= 0 ||
+// Queues the per-code-period sums of `ndet` detections on the context's stream and leaves them on the device (*dsums:
+// double[ndet][nbins][ncodes][2]); nothing is synchronised: hdet (filled here) and `codes` must stay alive until the caller has.
+static int fine_sums_enqueue(gc_context* ctx, const gc_fine_params* p, int ndet, const int8_t* codes, const int64_t* first_sample,
+                             const double* f0, std::vector<FineDet>& hdet, const double** dsums) {
+  if (!ctx || !p || ndet <= 0 || ndet > 65535 || !codes || !first_sample || !f0 || p->spc <= 0 || p->ncodes <= 0 ||
       p->nbins <= 0 || p->code_len <= 0) {
     gc_set_error("gc_acquire_fine_sums: bad arguments");
     return GC_E_INVALID;
@@ -2656,7 +2748,7 @@ extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params*
     return ctx->d_if ? GC_E_UNSUPPORTED : GC_E_STATE;
   }
   const uint64_t avail = cond ? (uint64_t)ctx->acq_cond_n : ctx->if_nsamples;
-  std::vector<FineDet> hdet((size_t)ndet);
+  hdet.resize((size_t)ndet);
   for (int d = 0; d < ndet; ++d) {
     if (first_sample[d] < 0 || (uint64_t)first_sample[d] + (uint64_t)p->ncodes * p->spc > avail) {
       gc_set_error("gc_acquire_fine_sums: %d code periods from sample %lld exceed the IF buffer", p->ncodes, (long long)first_sample[d]);
@@ -2699,8 +2791,31 @@ extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params*
     hipLaunchKernelGGL(fine_parts_kernel, dim3((unsigned int)((nout + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)dpart, parts, nout, dout);
     GC_HIP(hipGetLastError());
   }
-  GC_HIP(hipMemcpyAsync(out, bout.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  GC_HIP(hipStreamSynchronize(ctx->stream));  // also keeps hdet / codes alive until the copies are done
+  *dsums = dout;
+  return GC_OK;
+}
+
+extern "C" int gc_acquire_fine_sums_batch(gc_context* ctx, const gc_fine_params* p, int ndet, const int8_t* codes,
+                                          const int64_t* first_sample, const double* f0, double* out) {
+  if (!out) {
+    gc_set_error("gc_acquire_fine_sums: bad arguments");
+    return GC_E_INVALID;
+  }
+  std::vector<FineDet> hdet;
+  const double* dsums = nullptr;
+  const int rc = fine_sums_enqueue(ctx, p, ndet, codes, first_sample, f0, hdet, &dsums);
+  if (rc) {
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);  // (copies of hdet / codes may be queued)
+    return rc;
+  }
+  const size_t nout = (size_t)ndet * p->nbins * p->ncodes * 2;
+  hipError_t e = hipMemcpyAsync(out, dsums, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t e2 = hipStreamSynchronize(ctx->stream);  // also keeps hdet / codes alive until the copies are done
+  if (e == hipSuccess) e = e2;
+  if (e != hipSuccess) {
+    gc_set_error("gc_acquire_fine_sums: %s", hipGetErrorString(e));
+    return GC_E_HIP;
+  }
   return GC_OK;
 }
 
@@ -3101,6 +3216,35 @@ extern "C" int gc_acquire_fine_l1ca_batch(gc_context* ctx, const gc_acq_params* 
     }
     first[d] = p->first_sample + code_phase[d] - 1;                              // sig40cm, :221
     f0[d] = coarse_freq[d] + p->search_step / 2;                                 // fineFreqBins(1), :227-228
+  }
+  // the hypothesis search on the device (fine_l1ca_pick_kernel): one bin index per detection comes back instead of every sum
+  // (GC_ACQ_FINE_HOST=1: the sums come back and the host loop below picks, as before)
+  if (nfine <= 64 && !std::getenv("GC_ACQ_FINE_HOST")) {
+    std::vector<FineDet> hdet;
+    const double* dsums = nullptr;
+    int rc = fine_sums_enqueue(ctx, &fp, ndet, codes, first.data(), f0.data(), hdet, &dsums);
+    GcBuf& bpick = ctx->acqbuf[gc_context::ACQ_FINE_DET];  // (the detections' records were consumed by the sums kernel queued before)
+    std::vector<int> best((size_t)ndet, 0);
+    hipError_t e = hipSuccess;
+    if (rc == GC_OK) {
+      int* const dbest = reinterpret_cast<int*>(reinterpret_cast<char*>(bpick.p));
+      hipLaunchKernelGGL(fine_l1ca_pick_kernel, dim3((unsigned int)ndet), dim3(64), 0, ctx->stream, dsums, nfine, ncodes, dbest);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(best.data(), dbest, (size_t)ndet * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);  // also keeps hdet / codes alive until their copies are done
+    if (rc) return rc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) {
+      gc_set_error("gc_acquire_fine_l1ca: %s", hipGetErrorString(e));
+      return GC_E_HIP;
+    }
+    for (int d = 0; d < ndet; ++d) {
+      double f = f0[d] - fine_step * best[d];
+      if (f == 0) f = 1;  // :258-260
+      carr_freq[d] = f;
+    }
+    return GC_OK;
   }
   std::vector<double> h((size_t)ndet * nfine * ncodes * 2);
   const int rc = gc_acquire_fine_sums_batch(ctx, &fp, ndet, codes, first.data(), f0.data(), h.data());

@@ -202,7 +202,10 @@ _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": 
               # into runs, and the hop groups that two lanes no longer need at the default size
               ("BDS_B1C", {"GC_ACQ_BINS_PER_WG": "3"}), ("GAL_E1C", {"GC_ACQ_BINS_PER_WG": "4"}), ("GPS_L2C", {"GC_ACQ_BINS_PER_WG": "2"}),
               ("BDS_B1I", {"GC_ACQ_BINS_PER_WG": "4"}), ("BDS_B1C", {"GC_ACQ_XCD_MAP": "pairs"}), ("GPS_L1CA", {"GC_ACQ_FINE_PARTS": "8"}),
-              ("GPS_L1CA", {"GC_ACQ_HOP_GROUPS": "2"}), ("GAL_E5b", {"GC_ACQ_HOP_GROUPS": "3"})]
+              ("GPS_L1CA", {"GC_ACQ_HOP_GROUPS": "2"}), ("GAL_E5b", {"GC_ACQ_HOP_GROUPS": "3"}),
+              # second half of round 4: bin spacings of q / den FFT bins read den x hops spectra shifted (Galileo E5b 3 / 25, E1 6 / 5) -
+              # switched back to one spectrum per (bin, hop); the L1 C/A fine stage's hypothesis search on the host again
+              ("GAL_E5b", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GAL_E1C", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GPS_L1CA", {"GC_ACQ_FINE_HOST": "1"})]
 
 
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
