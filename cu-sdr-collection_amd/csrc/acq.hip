@@ -795,6 +795,16 @@ __device__ __forceinline__ void stage_twiddles_ct(const float2* __restrict__ tw,
   }
 }
 
+// -DGC_ACQ_STAGE_CLOCKS=1 (scripts/acq_stage_clocks.py, a tuning build): wavefront w of every workgroup of the fused columns pass adds the
+// shader-clock cycles it spent per hop in [wait for the prefetched tile + first stage | fetch issue + barrier | middle stage | barrier |
+// last stage] to g_stage_clk[w * 8 + phase] (and the hops it counted to [w * 8 + 7]); the same for the fused rows pass from slot 64 on.
+#ifdef GC_ACQ_STAGE_CLOCKS
+__device__ unsigned long long g_stage_clk[128];
+#define GC_CLK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); clk_acc[i] += t_ - clk_last; clk_last = t_; } while (0)
+#else
+#define GC_CLK(i) do { } while (0)
+#endif
+
 // Threads per workgroup of a specialised pass.  A stage of radix R has (L / R) * C butterflies, one per thread and iteration; with 256
 // threads the 288 radix-5 butterflies of the 180 x 8 columns tile are two iterations for wavefront 0 (the second one for 32 lanes) and
 // one for the others, and every barrier waits for wavefront 0: the workgroup's critical path is the SUM over the stages of
@@ -1034,8 +1044,12 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
 #pragma unroll
         for (int q = 0; q < RL; ++q) acc2[i][q] = 0.f;
     }
+#ifdef GC_ACQ_STAGE_CLOCKS
+    unsigned long long clk_acc[6] = {0, 0, 0, 0, 0, 0}, clk_last = __builtin_readcyclecounter();
+#endif
     for (int rep = 0; rep < reps; ++rep) {
       const long long tb = tb_of(batch_q, rep);
+      GC_CLK(5);
       // ---- first stage, inputs from registers -------------------------------------------------------------------------
       if constexpr (PRE == PRE_MUL_CONJ) {
         stage_first_ct<NT, R0, L, LP1, C, INV, false, PAD1>(
@@ -1050,13 +1064,17 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
       } else {
         stage_first_ct<NT, R0, L, LP1, C, INV, true, false>([&](unsigned it, int q, unsigned, unsigned) -> float2 { return pre[it][q]; }, buf1, tid);
       }
+      GC_CLK(0);
       if (rep + 1 < reps) fetch(batch_q, rep + 1);
       else if (qi + 1 < nq) fetch(batch_q + 1, 0);
       __syncthreads();
+      GC_CLK(1);
       // ---- middle stages: buf1 -> buf0 (-> buf1) ------------------------------------------------------------------------
       if constexpr (NST >= 3) {
         stage_ct<NT, R1, L, C, NS1, INV, LP, SP1, LP1>(buf1, buf0, twl, tid);
+        GC_CLK(2);
         __syncthreads();
+        GC_CLK(3);
       }
       if constexpr (NST >= 4) {
         stage_ct<NT, R2, L, C, NS2, INV, LP>(buf0, buf1, twl + T1, tid);
@@ -1083,9 +1101,17 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
           acc2[it][q] += cabs_f(val.x, val.y);
         });
       }
+      GC_CLK(4);
       // two stages: the last one read buf1, which the next hop's first stage writes
       if constexpr (NST == 2 || NST == 4) __syncthreads();
     }
+#ifdef GC_ACQ_STAGE_CLOCKS
+    if ((tid & 63u) == 0u && NST == 3) {
+      unsigned long long* g = g_stage_clk + (POST == POST_ABS_ACC ? 0 : 64) + (tid >> 6) * 8;
+      for (int i = 0; i < 6; ++i) atomicAdd(&g[i], clk_acc[i]);
+      atomicAdd(&g[7], (unsigned long long)reps);
+    }
+#endif
     if constexpr (POST == POST_ABS_ACC) {
       // the sums, held per (iteration, output) of the last stage, through LDS into the order of the tile in memory (once per launch)
       float* fbuf = reinterpret_cast<float*>(buf1);
@@ -2086,15 +2112,19 @@ void free_scratch(AcqScratch* s) {
 // Last inverse pass (POST_ABS_ACC) over `nbins` bins.  With few bins the launch would have ~2 workgroups per CU, each
 // walking all nhops hops of its bin: the hops are then split over hop groups (a divisor of nhops), whose raw sums meet in
 // abs_combine_kernel - deterministic, group order fixed.
+// bin0 / nbins_total: the launch covers bins bin0 .. bin0 + nbins - 1 of a search of nbins_total (a PRN's bins in chunks, see
+// gc_acquire_coarse_multi): no hop groups then, and the chunk's candidates go to their bins' places in the PRN's slot region.
 int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr, int valid = 0,
-                    int ip = 0, int nprn = 1, bool* rows_fused = nullptr) {
+                    int ip = 0, int nprn = 1, bool* rows_fused = nullptr, int bin0 = 0, long long nbins_total = 0) {
   if (rows_fused) *rows_fused = false;
+  const bool chunked = nbins_total > nbins;
+  if (nbins_total < nbins) nbins_total = nbins;
   if (valid <= 0) valid = a.n;
   const int tiles = (a.nvec + a.cols - 1) / a.cols;
   int hg = 1;
   for (int g = 1; g <= a.nhops; ++g)
     if (a.nhops % g == 0 && (long long)tiles * nbins * hg * std::max(1, s->nlanes) < 4LL * ctx->compute_units) hg = g;  // (both lanes' launches run together)
-  if (std::getenv("GC_ACQ_NO_HOP_GROUPS")) hg = 1;
+  if (std::getenv("GC_ACQ_NO_HOP_GROUPS") || chunked) hg = 1;
   if (const char* e = std::getenv("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count
     const int g = std::atoi(e);
     if (g >= 1 && a.nhops % g == 0) hg = g;
@@ -2134,8 +2164,12 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
       return GC_OK;  // (the generic kernel ignored the slots and wrote the sums: the caller runs rowmax_kernel)
     }
     const bool fused_peak = keys && c1 > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL");
+    if (chunked && (c1 == 0 || (keys && !fused_peak))) {
+      gc_set_error("acquisition: bins in chunks need the specialised passes and their peak candidates");
+      return GC_E_STATE;
+    }
     if (fused_peak) {
-      const int per = (int)((long long)(a.nvec / c1) * nbins);  // the specialised kernel's grid
+      const int per = (int)((long long)(a.nvec / c1) * nbins_total);  // the specialised kernel's grid (over all chunks)
       const size_t want = (size_t)nprn * per * 2;
       if (s->slots_cap < want) {
         GC_HIP(hipDeviceSynchronize());  // (both lanes of the PRN loop: the buffer is theirs together)
@@ -2148,12 +2182,14 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
         s->slots_cap = want;
       }
       s->slots_per_prn = per;
-      a.peak_slots = s->slots + (size_t)ip * per * 2;
+      a.peak_slots = s->slots + ((size_t)ip * per + (size_t)bin0 * (a.nvec / c1)) * 2;
       a.peak_valid = valid;
     }
+    a.batch0 = bin0;
     bool used_ct = false;
     int rc = launch_pass(ctx, a, nbins, &used_ct);
     a.peak_slots = nullptr;
+    a.batch0 = 0;
     if (rc || !keys) return rc;
     if (fused_peak && used_ct) return GC_OK;
     if (fused_peak) s->slots_per_prn = 0;  // the generic pass kernel took it after all (tuning knobs): it wrote the results, peak_kernel reads them
@@ -2494,12 +2530,27 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     GC_HIP(hipEventRecord(s->ev_fork, stream1));  // spectra, code spectra and the cleared keys are ready
     GC_HIP(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
   }
+  // Bins in chunks (specialised passes only): a PRN's bins are searched in `chunks` parts after one another, the lanes take (PRN, chunk)
+  // items in turn - both lanes' intermediates together are then 1 / chunks of lanes x nbins x H x N x 8 bytes: 334 MB at the default
+  // L1 C/A size, 302 MB at L5's - more than the 256 MB last-level cache in front of HBM holds; in halves they fit (L1 C/A 3.10 -> 2.99 ms,
+  // L5 6.61 -> 6.38).  Two parts when that brings the footprint under the cache's size, never more (half-size launches fill the device
+  // half as well: E5a, which fits anyway, +8 % in halves; E5b, 1.4 GB, gains nothing from 2 .. 8 parts).  GC_ACQ_BIN_CHUNKS=n overrides.
+  int chunks = 1;
+  if (hblock && !fused && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL")) {
+    const double foot = (double)lanes * nbins * H * (double)pl.n * sizeof(float2), llc = 256.0 * 1024 * 1024;
+    if (foot > llc && foot / 2 <= llc && nbins >= 16) chunks = 2;
+    if (const char* e = std::getenv("GC_ACQ_BIN_CHUNKS")) chunks = std::max(1, std::min(nbins, std::atoi(e)));
+  }
+  const int chunk_bins = (nbins + chunks - 1) / chunks;
+  chunks = (nbins + chunk_bins - 1) / chunk_bins;
   int lane_rc = GC_OK;
-  for (int ip = 0; ip < nprn && !fused && lane_rc == GC_OK; ++ip) {
-    s->lane = lanes == 2 ? (ip & 1) : 0;
+  for (int item = 0; item < nprn * chunks && !fused && lane_rc == GC_OK; ++item) {
+    const int ip = item / chunks, bin0 = (item % chunks) * chunk_bins, cb = std::min(chunk_bins, nbins - bin0);
+    s->lane = lanes == 2 ? (item & 1) : 0;
     s->nlanes = lanes;
     ctx->stream = s->lane ? s->stream2 : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
-    float2* const tmp = s->lane ? s->tmp2 : s->tmp;
+    // (a chunk's batches keep their numbers, bin0 * H on: the chunk's first batch sits at the start of the lane's intermediate)
+    float2* const tmp = (s->lane ? s->tmp2 : s->tmp) - (size_t)bin0 * H * (size_t)pl.n;
     float* const results = s->lane ? s->results2 : s->results;
     for (int arm = 0; arm < narms; ++arm) {
       // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
@@ -2525,7 +2576,9 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.out_batch_stride = pl.n;
       a.out_blocked = hblock;  // the intermediate in the columns pass's tile order
       a.row_reps = row_reps;
-      rc = launch_pass(ctx, a, (long long)nbins * H / row_reps);
+      a.batch0 = (int)((long long)bin0 * H / row_reps);
+      rc = launch_pass(ctx, a, (long long)cb * H / row_reps);
+      a.batch0 = 0;
       if (rc) {
         lane_rc = rc;
         break;
@@ -2545,7 +2598,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.acc_out = results;
       a.acc_add = arm > 0;
       a.acc_scale = (float)p->arm_weight[arm];  // 0: 1
-      rc = launch_abs_pass(ctx, s, a, nbins, arm == narms - 1 ? peaks + 2 * ip : nullptr, blk, ip, nprn);
+      rc = launch_abs_pass(ctx, s, a, cb, arm == narms - 1 ? peaks + 2 * ip : nullptr, blk, ip, nprn, nullptr, bin0, nbins);
       if (rc) {
         lane_rc = rc;
         break;
@@ -3281,3 +3334,15 @@ extern "C" int gc_acquire_fine_l1ca(gc_context* ctx, const gc_acq_params* p, con
   const int32_t cp = code_phase;
   return gc_acquire_fine_l1ca_batch(ctx, p, 1, code, &cp, &coarse_freq, carr_freq);
 }
+
+#ifdef GC_ACQ_STAGE_CLOCKS
+// tuning builds only (not declared in include/gnsscorr.h): the counters of GC_CLK, optionally cleared
+extern "C" int gc_debug_acq_stage_clocks(unsigned long long* out128, int reset) {
+  if (out128 && hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_stage_clk), sizeof(unsigned long long) * 128) != hipSuccess) return GC_E_HIP;
+  if (reset) {
+    static const unsigned long long zeros[128] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stage_clk), zeros, sizeof zeros) != hipSuccess) return GC_E_HIP;
+  }
+  return GC_OK;
+}
+#endif

@@ -193,6 +193,19 @@ def test_fused_inverse_transform_kernel_at_the_references_default_search_sizes(e
     _compare_acq(sc, z, sc.product(P, engine, S))
 
 
+@pytest.mark.parametrize("name", ["GPS_L1CA_default", "GPS_L5C_default"])
+def test_default_size_searches_in_one_chunk_of_bins(engine, monkeypatch, name):
+    """The default GPS L1 C/A and L5 searches run their bins in two chunks (both lanes' intermediates then fit the last-level cache,
+    DESIGN.md 4.4); GC_ACQ_BIN_CHUNKS=1 is the search in one piece, same results."""
+    import cu_sdr_collection_amd as P
+    sc = next(s for s in RS.DEFAULT_ACQ_SCENES if s.name == name)
+    monkeypatch.setenv("GC_ACQ_BIN_CHUNKS", "1")
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    engine.load_if(rec, fs=S.samplingFreq)
+    _compare_acq(sc, z, sc.product(P, engine, S))
+
+
 _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": "1"}), ("GAL_E1C", {"GC_ACQ_PEAK_KERNEL": "1"}),
               ("BDS_B1C", {"GC_ACQ_PEAK_KERNEL": "1"}), ("BDS_B1I", {"GC_ACQ_ROWMAX_KERNEL": "1"}), ("GPS_L2C", {"GC_ACQ_ROWMAX_KERNEL": "1"}),
               ("GPS_L1CA", {"GC_ACQ_NO_HOP_GROUPS": "1"}), ("GLO_GL1", {"GC_ACQ_NATURAL_ORDER": "1"}), ("GAL_E1C", {"GC_ACQ_GENERIC": "1"}),
@@ -205,7 +218,10 @@ _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": 
               ("GPS_L1CA", {"GC_ACQ_HOP_GROUPS": "2"}), ("GAL_E5b", {"GC_ACQ_HOP_GROUPS": "3"}),
               # second half of round 4: bin spacings of q / den FFT bins read den x hops spectra shifted (Galileo E5b 3 / 25, E1 6 / 5) -
               # switched back to one spectrum per (bin, hop); the L1 C/A fine stage's hypothesis search on the host again
-              ("GAL_E5b", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GAL_E1C", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GPS_L1CA", {"GC_ACQ_FINE_HOST": "1"})]
+              ("GAL_E5b", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GAL_E1C", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GPS_L1CA", {"GC_ACQ_FINE_HOST": "1"}),
+              # a PRN's bins in chunks dealt out to the two lanes (automatic at the default L1 C/A and L5 sizes only): forced here, with a
+              # remainder chunk, one and two code arms, and the rational spacing on top
+              ("GPS_L1CA", {"GC_ACQ_BIN_CHUNKS": "3"}), ("GPS_L5C", {"GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5b", {"GC_ACQ_BIN_CHUNKS": "4"})]
 
 
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
