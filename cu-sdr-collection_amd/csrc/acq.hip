@@ -2125,9 +2125,9 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   for (int g = 1; g <= a.nhops; ++g)
     if (a.nhops % g == 0 && (long long)tiles * nbins * hg * std::max(1, s->nlanes) < 4LL * ctx->compute_units) hg = g;  // (both lanes' launches run together)
   if (std::getenv("GC_ACQ_NO_HOP_GROUPS") || chunked) hg = 1;
-  if (const char* e = std::getenv("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count
+  if (const char* e = std::getenv("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count (a chunk of bins has none)
     const int g = std::atoi(e);
-    if (g >= 1 && a.nhops % g == 0) hg = g;
+    if (g >= 1 && a.nhops % g == 0 && !chunked) hg = g;
   }
   a.hop_groups = hg;
   dim3 pgrid((unsigned int)std::max(1, std::min((a.n + 1023) / 1024, 64)), (unsigned int)std::min<long long>(nbins, 65535));
@@ -2139,7 +2139,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
     if (rows_fused && c1 > 0 && a.hop_groups <= 1 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_ROWMAX_KERNEL")) {
       // circshift search, last arm: per-workgroup candidates (tiles of one row each) instead of the sums themselves
       const int tiles_ct = a.nvec / c1;
-      const size_t want = (size_t)nbins * tiles_ct * 2;
+      const size_t want = (size_t)nbins_total * tiles_ct * 2;
       if (s->slots_cap < want) {
         GC_HIP(hipDeviceSynchronize());
         if (s->slots) (void)hipFree(s->slots);
@@ -2150,14 +2150,17 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
         GC_HIP(hipDeviceSynchronize());
         s->slots_cap = want;
       }
-      a.peak_slots = s->slots;
+      a.peak_slots = s->slots + (size_t)bin0 * tiles_ct * 2;
       a.peak_valid = valid;
+      a.batch0 = bin0;
       bool used_ct = false;
       int rc = launch_pass(ctx, a, nbins, &used_ct);
       a.peak_slots = nullptr;
+      a.batch0 = 0;
       if (rc) return rc;
       if (used_ct) {
-        hipLaunchKernelGGL(rowkeys_reduce_kernel, dim3((unsigned int)nbins), dim3(64), 0, ctx->stream, s->slots, tiles_ct, s->rowmax, s->rowarg);
+        hipLaunchKernelGGL(rowkeys_reduce_kernel, dim3((unsigned int)nbins), dim3(64), 0, ctx->stream, s->slots + (size_t)bin0 * tiles_ct * 2, tiles_ct,
+                           s->rowmax + bin0, s->rowarg + bin0);
         GC_HIP(hipGetLastError());
         *rows_fused = true;
       }
@@ -2532,13 +2535,21 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   }
   // Bins in chunks (specialised passes only): a PRN's bins are searched in `chunks` parts after one another, the lanes take (PRN, chunk)
   // items in turn - both lanes' intermediates together are then 1 / chunks of lanes x nbins x H x N x 8 bytes: 334 MB at the default
-  // L1 C/A size, 302 MB at L5's - more than the 256 MB last-level cache in front of HBM holds; in halves they fit (L1 C/A 3.10 -> 2.99 ms,
-  // L5 6.61 -> 6.38).  Two parts when that brings the footprint under the cache's size, never more (half-size launches fill the device
-  // half as well: E5a, which fits anyway, +8 % in halves; E5b, 1.4 GB, gains nothing from 2 .. 8 parts).  GC_ACQ_BIN_CHUNKS=n overrides.
+  // L1 C/A size, 302 MB at L5's, 1.45 GB at Galileo E5b's - more than the 256 MB last-level cache in front of HBM holds; in parts that
+  // fit (with the signal spectra the rows passes read) L1 C/A 3.10 -> 2.99 ms, L5 6.61 -> 6.38, E5b 34.2 -> 28.6 ms (12 parts of 14 bins;
+  // 2 .. 8 parts, which do not fit next to its 108 MB of spectra, gain nothing; 16 parts 30.5 ms).  A search that fits anyway stays whole
+  // (smaller launches fill the device less well: E5a +8 % in halves).  GC_ACQ_BIN_CHUNKS=n overrides.
   int chunks = 1;
   if (hblock && !fused && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL")) {
-    const double foot = (double)lanes * nbins * H * (double)pl.n * sizeof(float2), llc = 256.0 * 1024 * 1024;
-    if (foot > llc && foot / 2 <= llc && nbins >= 16) chunks = 2;
+    // the fewest chunks (of at least 8 bins) that bring the lanes' intermediates + the signal spectra under ~230 MB; none if nothing does
+    const double per_bin = (double)H * (double)pl.n * sizeof(float2), spectra = (shifted ? (double)den : (double)nbins) * per_bin;
+    const double room = 232.0 * 1024 * 1024;
+    for (int c = 1; c <= nbins / 8; ++c)
+      if ((double)lanes * ((nbins + c - 1) / c) * per_bin + spectra <= room) {
+        chunks = c;
+        break;
+      }
+    if (std::getenv("GC_ACQ_HOP_GROUPS")) chunks = 1;  // (hop groups are a property of whole searches)
     if (const char* e = std::getenv("GC_ACQ_BIN_CHUNKS")) chunks = std::max(1, std::min(nbins, std::atoi(e)));
   }
   const int chunk_bins = (nbins + chunks - 1) / chunks;
@@ -3052,7 +3063,23 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
   base.codes = s->codes;
   int rc = forward(ctx, s, base, PRE_CODE, narms, s->codespec);
   if (rc) return rc;
-  for (int arm = 0; arm < narms; ++arm) {
+  // Rows in chunks (specialised passes): the rows pass writes rows x N x 8 bytes that the columns pass reads back - 579 MB per PRN and
+  // arm for BDS B1C, 2 GB for GPS L2C, through HBM both ways.  A chunk of rows whose intermediate is <= GC_ACQ_SHIFT_CHUNK_MB goes
+  // through both passes (and both arms) before the next one starts, in the same place: the columns pass finds it in the 256 MB
+  // last-level cache.  Measured: B1C (600 x 600 plan) 103.9 -> 99.3 ms at 160 MB (100.7 at 96, 113.8 at 48); L2C (512 x 625) 75.3 -> 77.8 /
+  // 82.3 / 92.9 ms - its 802 rows of 125 narrow tiles lose more to the additional launches than the cache gives back: chunks for the
+  // 600 x 600 plan only (0: all rows at once).
+  int chunk_rows = rows;
+  if (ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC")) {
+    double mb = (pl.n1 == 600 && pl.n2 == 600) ? 160.0 : 0.0;
+    if (const char* e = std::getenv("GC_ACQ_SHIFT_CHUNK_MB")) mb = std::atof(e);
+    if (mb > 0.0) chunk_rows = std::max(8, std::min(rows, (int)(mb * 1024.0 * 1024.0 / ((double)pl.n * sizeof(float2)))));
+  }
+  bool all_fused = true;
+  for (int r0 = 0; r0 < rows; r0 += chunk_rows)
+  for (int arm = 0; arm < narms; ++arm) {  // (the arms of a chunk after one another: the second one adds to sums the first one just wrote)
+    const int rc_rows = std::min(chunk_rows, rows - r0);
+    float2* const tmp = s->tmp - (size_t)r0 * (size_t)pl.n;  // (a chunk's batches keep their numbers; its first one sits at the start of the buffer)
     PassArgs a = base;
     a.n = pl.n;
     a.tw = s->tw;
@@ -3067,12 +3094,14 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.in = s->sig;
     a.in_batch_stride = pl.n;
     a.other = s->codespec + (size_t)arm * pl.n;
-    a.out = s->tmp;
+    a.out = tmp;
     a.out_batch_stride = pl.n;
     a.shift_bins = s->shift_padded ? 0 : p.n_bins;  // padded: every row is a spectrum of its own
     a.n1 = pl.n1;
     a.n2 = pl.n2;
-    rc = launch_pass(ctx, a, rows);
+    a.batch0 = r0;
+    rc = launch_pass(ctx, a, rc_rows);
+    a.batch0 = 0;
     if (rc) return rc;
     fill_sub(a, pl.p1);
     a.nvec = pl.n2;
@@ -3082,15 +3111,16 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.pre = PRE_NONE;
     a.shift_bins = 0;
     a.post = POST_ABS_ACC;
-    a.in = s->tmp;
+    a.in = tmp;
     a.acc_out = s->results;
     a.acc_add = arm > 0;
     a.acc_scale = arm_weight ? (float)arm_weight[arm] : 1.0f;
     bool fused_rows = false;
-    rc = launch_abs_pass(ctx, s, a, rows, nullptr, p.n, 0, 1, arm == narms - 1 ? &fused_rows : nullptr);
+    rc = launch_abs_pass(ctx, s, a, rc_rows, nullptr, p.n, 0, 1, arm == narms - 1 ? &fused_rows : nullptr, r0, rows);
     if (rc) return rc;
-    s->shift_rows_fused = fused_rows;
+    if (arm == narms - 1) all_fused = all_fused && fused_rows;
   }
+  s->shift_rows_fused = all_fused;
   s->shift_narms = narms;
   for (int arm = 0; arm < 4; ++arm) s->shift_weight[arm] = (arm_weight && arm < narms) ? arm_weight[arm] : 1.0;
   if (!s->shift_rows_fused) {
