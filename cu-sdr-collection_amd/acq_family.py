@@ -245,12 +245,21 @@ def _matlab_colon(a: float, d: float, b: float) -> np.ndarray:
     return out
 
 
-def glonass_sampled_code(samp_freq: float, num_samples: int) -> np.ndarray:
-    """GLO/GLO_GL1/include/generateCAcode.m:112-118 with PRN 0: the 511-chip code sampled at floor(k*511e3/fs)."""
+@functools.lru_cache(maxsize=8)
+def _glonass_sampled_code(samp_freq: float, num_samples: int) -> np.ndarray:
     code = codes.generateGLOcode()
     step = 511e3 / samp_freq
     s = np.floor(_matlab_colon(0.0, step, num_samples * step - step)).astype(np.int64)
-    return code[np.remainder(s, 511)]
+    out = code[np.remainder(s, 511)]
+    out.setflags(write=False)
+    return out
+
+
+def glonass_sampled_code(samp_freq: float, num_samples: int) -> np.ndarray:
+    """GLO/GLO_GL1/include/generateCAcode.m:112-118 with PRN 0: the 511-chip code sampled at floor(k*511e3/fs).  A constant of the
+    rate and the length: kept per (rate, length) - the 40-code replica of the fine stage is 480 000 entries through MATLAB's colon
+    rule, a millisecond and a half of every call."""
+    return _glonass_sampled_code(float(samp_freq), int(num_samples))
 
 
 def acquisition_GLO(engine, settings, first_sample: int | None = None, n_long: int | None = None):

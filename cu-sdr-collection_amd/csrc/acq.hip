@@ -14,6 +14,7 @@
 //   * the peak pick reproduces max(max(.)) first-occurrence semantics with exact float compares.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <type_traits>
 
 #include "gc_internal.h"
@@ -2067,7 +2068,8 @@ struct AcqScratch {
   // second lane of the PRN loop (gc_acquire_coarse_multi): odd PRNs run on a stream of their own with their own intermediates, so one
   // PRN's columns pass fills the device while the next PRN's rows pass drains (and the other way round)
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipStream_t lane_stream[2] = {nullptr, nullptr};  // where the lanes' launches go in the call under way
   float2* tmp2 = nullptr;
   float* results2 = nullptr;
   float* partial2 = nullptr;
@@ -2097,6 +2099,33 @@ struct AcqScratch {
   int slots_per_prn = 0;                // workgroups per region in the call under way (0: keys were published directly)
 };
 
+// The coarse search's two streams, one pair per device for the whole process (created on first use, never destroyed).  HIP deals
+// streams out to a few hardware queues; with a stream pair per context, whether a context's two PRN lanes really ran side by side
+// depended on how many streams the process had made before: of six engines in one process the second searched in 3.65 instead of
+// 2.77 ms (its lanes one after the other), bench.py's searches ran 20 - 30 % slower than the same searches alone, and streams of
+// different priority (the multi.hip remedy) moved the bad case elsewhere and made it worse (5.7 ms).  One pair made back to back and
+// used by every context behaves the same for all of them.  (Searches of two contexts on one device at the same time share the
+// pair: still correct - every call forks and joins with its own events - and no faster than one after the other.)
+struct AcqStreams {
+  hipStream_t main = nullptr, lane = nullptr;
+};
+AcqStreams* acq_streams(int device) {
+  static std::mutex mu;
+  static AcqStreams pool[64];
+  static bool made[64] = {false};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!made[device]) {
+    made[device] = true;
+    if (hipStreamCreateWithFlags(&pool[device].main, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&pool[device].lane, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      pool[device].main = pool[device].lane = nullptr;
+    }
+  }
+  return pool[device].main && pool[device].lane ? &pool[device] : nullptr;
+}
+
 void free_scratch(AcqScratch* s) {
   if (!s) return;
   void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->rowmax, s->rowarg, s->peaks, s->slots,
@@ -2106,6 +2135,7 @@ void free_scratch(AcqScratch* s) {
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
   delete s;
 }
 
@@ -2409,6 +2439,15 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   GC_HIP(hipMemcpyAsync(hs, s->sums, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
   GC_HIP(hipMemcpyAsync(s->codes, sampled_codes, (size_t)nprn * narms * cl, hipMemcpyHostToDevice, ctx->stream));
   GC_HIP(hipStreamSynchronize(ctx->stream));
+  // from here on the call runs on the device's search streams (acq_streams); the context's own is idle and comes back at every return
+  struct RestoreStream {
+    gc_context* c;
+    hipStream_t own;
+    ~RestoreStream() { c->stream = own; }
+  } restore_stream{ctx, ctx->stream};
+  const char* lane_streams_env = std::getenv("GC_ACQ_LANE_STREAMS");
+  AcqStreams* const shared = (lane_streams_env && std::strcmp(lane_streams_env, "own") == 0) ? nullptr : acq_streams(ctx->device);
+  if (shared) ctx->stream = shared->main;
   double sum3[3];
   if (cond) std::memcpy(sum3, hs, sizeof sum3);  // the float kernel wrote doubles
   else for (int k = 0; k < 3; ++k) sum3[k] = (double)hs[k];
@@ -2514,11 +2553,20 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   if (const char* e = std::getenv("GC_ACQ_LANES")) lanes = std::max(1, std::min(2, std::atoi(e)));
   if (lanes == 2) {
     const size_t ne = (size_t)pl.n;
-    if (!s->stream2) {
-      if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
-        lanes = 1;
+    // the lanes' streams: the device's pair (the first lane on the one the call runs on), or - GC_ACQ_LANE_STREAMS=own - the
+    // context's stream and a second one of its own
+    if (shared) {
+      s->lane_stream[0] = shared->main;
+      s->lane_stream[1] = shared->lane;
+    } else {
+      if (!s->stream2 && hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess) lanes = 1;
+      s->lane_stream[0] = ctx->stream;
+      s->lane_stream[1] = s->stream2;
     }
+    if (lanes == 2 && !s->ev_fork &&
+        (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) != hipSuccess))
+      lanes = 1;
     if (lanes == 2 && !s->tmp2 &&
         (hipMalloc((void**)&s->tmp2, (size_t)s->nbh * ne * sizeof(float2)) != hipSuccess ||
          hipMalloc((void**)&s->results2, (size_t)s->nbins * ne * sizeof(float)) != hipSuccess)) {
@@ -2531,7 +2579,8 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   hipStream_t const stream1 = ctx->stream;
   if (lanes == 2) {
     GC_HIP(hipEventRecord(s->ev_fork, stream1));  // spectra, code spectra and the cleared keys are ready
-    GC_HIP(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+    for (hipStream_t ls : s->lane_stream)
+      if (ls != stream1) GC_HIP(hipStreamWaitEvent(ls, s->ev_fork, 0));
   }
   // Bins in chunks (specialised passes only): a PRN's bins are searched in `chunks` parts after one another, the lanes take (PRN, chunk)
   // items in turn - both lanes' intermediates together are then 1 / chunks of lanes x nbins x H x N x 8 bytes: 334 MB at the default
@@ -2559,7 +2608,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     const int ip = item / chunks, bin0 = (item % chunks) * chunk_bins, cb = std::min(chunk_bins, nbins - bin0);
     s->lane = lanes == 2 ? (item & 1) : 0;
     s->nlanes = lanes;
-    ctx->stream = s->lane ? s->stream2 : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
+    ctx->stream = lanes == 2 ? s->lane_stream[s->lane] : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
     // (a chunk's batches keep their numbers, bin0 * H on: the chunk's first batch sits at the start of the lane's intermediate)
     float2* const tmp = (s->lane ? s->tmp2 : s->tmp) - (size_t)bin0 * H * (size_t)pl.n;
     float* const results = s->lane ? s->results2 : s->results;
@@ -2619,9 +2668,13 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   ctx->stream = stream1;
   s->lane = 0;
   s->nlanes = 1;
-  if (lanes == 2) {  // the second lane joins before the keys are reduced and read back (also on an error: nothing may still run on it)
-    (void)hipEventRecord(s->ev_join, s->stream2);
-    (void)hipStreamWaitEvent(stream1, s->ev_join, 0);
+  if (lanes == 2) {  // the lanes join before the keys are reduced and read back (also on an error: nothing may still run on them)
+    hipEvent_t const ej[2] = {s->ev_join, s->ev_join2};
+    for (int k = 0; k < 2; ++k)
+      if (s->lane_stream[k] != stream1) {
+        (void)hipEventRecord(ej[k], s->lane_stream[k]);
+        (void)hipStreamWaitEvent(stream1, ej[k], 0);
+      }
   }
   if (lane_rc != GC_OK) {
     (void)hipDeviceSynchronize();

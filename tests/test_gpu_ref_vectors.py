@@ -221,7 +221,9 @@ _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": 
               ("GAL_E5b", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GAL_E1C", {"GC_ACQ_NO_RATIONAL_SHIFT": "1"}), ("GPS_L1CA", {"GC_ACQ_FINE_HOST": "1"}),
               # a PRN's bins in chunks dealt out to the two lanes (automatic at the default L1 C/A and L5 sizes only): forced here, with a
               # remainder chunk, one and two code arms, and the rational spacing on top
-              ("GPS_L1CA", {"GC_ACQ_BIN_CHUNKS": "3"}), ("GPS_L5C", {"GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5b", {"GC_ACQ_BIN_CHUNKS": "4"})]
+              ("GPS_L1CA", {"GC_ACQ_BIN_CHUNKS": "3"}), ("GPS_L5C", {"GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5b", {"GC_ACQ_BIN_CHUNKS": "4"}),
+              # the PRN lanes on the context's own stream pair instead of the device's search streams
+              ("GPS_L1CA", {"GC_ACQ_LANE_STREAMS": "own"}), ("GAL_E5b", {"GC_ACQ_LANE_STREAMS": "own"})]
 
 
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
