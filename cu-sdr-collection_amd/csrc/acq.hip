@@ -2586,13 +2586,16 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   // items in turn - both lanes' intermediates together are then 1 / chunks of lanes x nbins x H x N x 8 bytes: 334 MB at the default
   // L1 C/A size, 302 MB at L5's, 1.45 GB at Galileo E5b's - more than the 256 MB last-level cache in front of HBM holds; in parts that
   // fit (with the signal spectra the rows passes read) L1 C/A 3.10 -> 2.99 ms, L5 6.61 -> 6.38, E5b 34.2 -> 28.6 ms (12 parts of 14 bins;
-  // 2 .. 8 parts, which do not fit next to its 108 MB of spectra, gain nothing; 16 parts 30.5 ms).  A search that fits anyway stays whole
-  // (smaller launches fill the device less well: E5a +8 % in halves).  GC_ACQ_BIN_CHUNKS=n overrides.
+  // 2 .. 8 parts, which do not fit next to its 108 MB of spectra, gain nothing; 16 parts 30.5 ms), Galileo E1 11.7 -> 11.1 ms in halves
+  // (two arms: the 54 MB of sums per lane that the pilot arm adds to count too).  A search that fits anyway stays whole (smaller
+  // launches fill the device less well: E5a +8 % in halves).  GC_ACQ_BIN_CHUNKS=n overrides.
   int chunks = 1;
   if (hblock && !fused && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL")) {
-    // the fewest chunks (of at least 8 bins) that bring the lanes' intermediates + the signal spectra under ~230 MB; none if nothing does
-    const double per_bin = (double)H * (double)pl.n * sizeof(float2), spectra = (shifted ? (double)den : (double)nbins) * per_bin;
-    const double room = 232.0 * 1024 * 1024;
+    // the fewest chunks (of at least 8 bins) that bring the lanes' intermediates (+ the sums a second code arm adds to) + the signal
+    // spectra under ~235 MB; none if nothing does
+    const double hop_bytes = (double)H * (double)pl.n * sizeof(float2);
+    const double per_bin = hop_bytes + (narms > 1 ? (double)pl.n * sizeof(float) : 0.0), spectra = (shifted ? (double)den : (double)nbins) * hop_bytes;
+    const double room = 236.0 * 1024 * 1024;
     for (int c = 1; c <= nbins / 8; ++c)
       if ((double)lanes * ((nbins + c - 1) / c) * per_bin + spectra <= room) {
         chunks = c;
