@@ -814,7 +814,9 @@ __device__ unsigned long long g_stage_clk[128];
 // The cap, measured per plan over the twelve default searches (-DGC_ACQ_NT_MAX=n applies one cap to every plan): 320 for the short
 // vectors of the 36 000- and 24 000-point plans (columns pass of the default L1 C/A search 4 -> 3 iterations: 3.29 -> 3.06 ms sustained,
 // L5 / E5a / E5b / B3I -5..-8 %), 512 for the 600 x 600 plan (8 -> 4: B1C 109 -> 104 ms; 320 gives 7 iterations and 137 ms), 256
-// elsewhere (375 x 384, 250 x 288, 512 x 625: within the noise or slower with more wavefronts per tile).
+// elsewhere (375 x 384, 250 x 288, 512 x 625: within the noise or slower with more wavefronts per tile).  With 512 threads the 600 x 600
+// plan's columns tile is 5 columns wide (3 000 values, 40-byte tile rows instead of 24: B1C 99.7 -> 90.0 ms; 4 columns 91.4, 6 113, 8 - one
+// workgroup per CU - 108; rows tiles of 2 / 4 / 5 rows instead of 3: 101.7 / 97.9 / 90.9 ms).
 template <int L>
 constexpr int ct_threads_cap() {
 #ifdef GC_ACQ_NT_MAX
@@ -1107,7 +1109,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
       if constexpr (NST == 2 || NST == 4) __syncthreads();
     }
 #ifdef GC_ACQ_STAGE_CLOCKS
-    if ((tid & 63u) == 0u && NST == 3) {
+    if ((tid & 63u) == 0u) {
       unsigned long long* g = g_stage_clk + (POST == POST_ABS_ACC ? 0 : 64) + (tid >> 6) * 8;
       for (int i = 0; i < 6; ++i) atomicAdd(&g[i], clk_acc[i]);
       atomicAdd(&g[7], (unsigned long long)reps);
@@ -1989,7 +1991,7 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
 // tile width C1 of the specialised columns pass for vectors of `len`, `nvec` of them per transform (the shapes of GC_CT_SHAPE below:
 // its launch has nvec / C1 workgroups per batch, whatever PassArgs::cols says); 0: no specialised pass
 int ct_columns_tile(int len, int nvec) {
-  static const int shapes[][3] = {{180, 200, 8}, {150, 160, 8}, {375, 384, 4}, {250, 288, 8}, {600, 600, 3}, {512, 625, 5}};
+  static const int shapes[][3] = {{180, 200, 8}, {150, 160, 8}, {375, 384, 4}, {250, 288, 8}, {600, 600, 5}, {512, 625, 5}};
   for (const auto& k : shapes)
     if (len == k[0] && nvec == k[1]) return k[2];
   return 0;
@@ -2008,7 +2010,7 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* use
     // (4-ms blocks), BDS B1C (20 ms) and GPS L2C (40 ms at 8 Msps)
     if (GC_CT_SHAPE(180, 200, 8, 6, 6, 5, 1, 6, 8, 5, 5, 1) || GC_CT_SHAPE(150, 160, 8, 6, 5, 5, 1, 6, 8, 5, 4, 1) ||
         GC_CT_SHAPE(375, 384, 4, 5, 5, 5, 3, 5, 8, 8, 6, 1) || GC_CT_SHAPE(250, 288, 8, 5, 5, 5, 2, 5, 8, 6, 6, 1) ||
-        GC_CT_SHAPE(600, 600, 3, 6, 5, 5, 4, 3, 6, 5, 5, 4) || GC_CT_SHAPE(512, 625, 5, 8, 8, 8, 1, 2, 5, 5, 5, 5)) {
+        GC_CT_SHAPE(600, 600, 5, 6, 5, 5, 4, 3, 6, 5, 5, 4) || GC_CT_SHAPE(512, 625, 5, 8, 8, 8, 1, 2, 5, 5, 5, 5)) {
       GC_HIP(hipGetLastError());
       if (used_ct) *used_ct = true;
       return GC_OK;
