@@ -117,6 +117,7 @@ def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, 
     res = engine.acquire_coarse(p, tables)
     spc = tables.shape[-1]
     nfine = _round(settings.acqSearchStep / fine_step) + 1 if fine_step else 0
+    found = []
     for prn, r in zip(prns, res):
         acq.peakMetric[prn - 1] = r.peak_metric
         if r.peak_metric > settings.acqThreshold:
@@ -124,15 +125,25 @@ def _family_a(engine, settings, first_sample, coarse_codes, fine_codes, ncodes, 
             if not fine_step:                      # GAL_E5b acquisition.m:227: the coarse bin is the answer
                 acq.carrFreq[prn - 1] = r.coarse_freq
                 continue
-            fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=fine_code_freq or settings.codeFreqBasis,
-                                  f0=r.coarse_freq + settings.acqSearchStep / 2, fstep=fine_step,
-                                  first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=ncodes, nbins=nfine,
-                                  code_len=int(fine_code_len or settings.codeLength), index_offset=index_offset,
-                                  source=src)
-            sums = [engine.acquire_fine_sums(fp, c) for c in fine_codes(prn)]       # each [nfine, ncodes]
+            found.append((prn, r))
+    if found:
+        # the per-code sums of every detection (and of both code arms where the package has two) in ONE launch and one read-back: a
+        # call per detection and arm was a launch + a synchronisation each, 0.15 - 0.3 ms of searches that take 3 - 6 ms
+        fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=fine_code_freq or settings.codeFreqBasis,
+                              f0=0.0, fstep=fine_step, first_sample=0, spc=spc, ncodes=ncodes, nbins=nfine,
+                              code_len=int(fine_code_len or settings.codeLength), index_offset=index_offset, source=src)
+        arms = [list(fine_codes(prn)) for prn, _ in found]
+        codes_all = np.stack([c for a in arms for c in a])
+        firsts = [first_sample + r.code_phase - 1 for (_, r), a in zip(found, arms) for _c in a]
+        f0s = [r.coarse_freq + settings.acqSearchStep / 2 for (_, r), a in zip(found, arms) for _c in a]
+        sums_all = engine.acquire_fine_sums_batch(fp, codes_all, firsts, f0s)        # [sum of arms, nfine, ncodes]
+        k = 0
+        for (prn, r), a in zip(found, arms):
+            sums = [sums_all[k + i] for i in range(len(a))]                          # each [nfine, ncodes]
+            k += len(a)
             fine = np.asarray(combine(prn, sums), dtype=np.float64)                  # the hypothesis search of every fine bin at once
             assert fine.shape == (nfine,), fine.shape
-            f = fp.f0 - fine_step * int(np.argmax(fine))
+            f = (r.coarse_freq + settings.acqSearchStep / 2) - fine_step * int(np.argmax(fine))
             acq.carrFreq[prn - 1] = f if f != 0 else 1
     if resampled:                                  # back to the record's rate and IF (GPS_L5C acquisition.m:293-305)
         for prn in prns:

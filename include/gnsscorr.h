@@ -376,7 +376,10 @@ int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn,
                       const int8_t* sampled_codes, gc_acq_result* out);
 
 /* Data + pilot search: `narms` sampled codes per PRN (row prn*narms + arm); the per-arm correlation
- * magnitudes are added before the non-coherent sum (GPS_L5C/include/acquisition.m:175-216). */
+ * magnitudes are added before the non-coherent sum (GPS_L5C/include/acquisition.m:175-216).
+ * The PRNs are searched on two lanes; both run on a pair of streams the library keeps per DEVICE for the whole process (forked from and
+ * joined into the context's stream inside the call - the call is synchronous as before).  Searches of two contexts on one device at
+ * the same time therefore share that pair: correct, and no faster than one after the other. */
 int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
                             const int8_t* sampled_codes, gc_acq_result* out);
 
