@@ -145,6 +145,7 @@ SYMBOLS = {
     "gc_track_multi": (C.c_int, [C.c_int, C.POINTER(gc_track_job)]),
     "gc_acquire_coarse": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, _P, C.POINTER(gc_acq_result)]),
     "gc_acquire_coarse_multi": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, C.c_int, _P, C.POINTER(gc_acq_result)]),
+    "gc_acquire_coarse_offsets": (C.c_int, [_P, C.POINTER(gc_acq_params), C.c_int, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(gc_acq_result)]),
     "gc_acquire_fine_l1ca": (C.c_int, [_P, C.POINTER(gc_acq_params), _P, C.c_int, C.c_double,
                                        C.POINTER(C.c_double)]),
     "gc_acquire_fine_sums": (C.c_int, [_P, C.POINTER(gc_fine_params), _P, C.POINTER(C.c_double)]),

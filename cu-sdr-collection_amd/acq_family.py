@@ -302,23 +302,41 @@ def acquisition_GLO(engine, settings, first_sample: int | None = None, n_long: i
     table = glonass_sampled_code(settings.samplingFreq, spc)[None, :]
     code40 = glonass_sampled_code(settings.samplingFreq, spc * 40)
     nfine = _round(settings.acqSearchStep / 25) + 1
-    for K in settings.acqSatelliteList:
+    # every frequency number in ONE coarse call where its carrier, IF - freqSpacing*K (:146-147), is a whole number of FFT bins away
+    # from IF (562.5 / 437.5 kHz on the 2-ms blocks of the default front end: 1 125 / 875 bins): the rows share the signal spectra and
+    # run on the two lanes instead of fourteen one-row calls one after the other; otherwise (GC_E_UNSUPPORTED) row by row as before
+    Ks = list(settings.acqSatelliteList)
+    coarse = None
+    if len(Ks) > 1:
+        p_all = _acq_params(settings, first_sample)
+        p_all.source = src
+        try:
+            coarse = engine.acquire_coarse(p_all, np.repeat(table, len(Ks), axis=0), freq_offset=[-settings.freqSpacing * K for K in Ks])
+        except L.GnssCorrError as e:
+            if e.status != L.GC_E_UNSUPPORTED:
+                raise
+    found = []
+    for ik, K in enumerate(Ks):
         p = _acq_params(settings, first_sample)
         p.source = src
         p.intermediate_freq = settings.IF - settings.freqSpacing * K               # :146-147
-        r = engine.acquire_coarse(p, table)[0]
+        r = coarse[ik] if coarse is not None else engine.acquire_coarse(p, table)[0]
         acq.peakMetric[K + 7] = r.peak_metric
         if r.peak_metric > settings.acqThreshold:
-            # the 40-code replica is a sequence sampled by the reference's own rule (one entry per sample: gc_fine_params.code_freq = 0);
-            # per-code sums for the 21 bins on the GPU, the 20 meander alignments of 40 complex numbers here
-            fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=0.0, f0=r.coarse_freq + settings.acqSearchStep / 2, fstep=25.0,
-                                  first_sample=first_sample + r.code_phase - 1, spc=spc, ncodes=40, nbins=nfine, code_len=40 * spc,
-                                  index_offset=0, source=src)
-            sums = engine.acquire_fine_sums(fp, code40)                                                                # [nfine, 40]
+            found.append((K, r))
+    if found:
+        # the 40-code replica is a sequence sampled by the reference's own rule (one entry per sample: gc_fine_params.code_freq = 0);
+        # per-code sums for the 21 bins of every detection in one launch on the GPU, the 20 meander alignments of 40 complex numbers here
+        fp = L.gc_fine_params(sampling_freq=settings.samplingFreq, code_freq=0.0, f0=0.0, fstep=25.0, first_sample=0, spc=spc, ncodes=40,
+                              nbins=nfine, code_len=40 * spc, index_offset=0, source=src)
+        f0s = [r.coarse_freq + settings.acqSearchStep / 2 for _, r in found]
+        sums_all = engine.acquire_fine_sums_batch(fp, np.repeat(code40[None, :], len(found), axis=0),
+                                                  [first_sample + r.code_phase - 1 for _, r in found], f0s)             # [ndet, nfine, 40]
+        for (K, r), f0, sums in zip(found, f0s, sums_all):
             cs = np.concatenate([np.zeros((sums.shape[0], 1), dtype=sums.dtype), np.cumsum(sums, axis=1)], axis=1)         # cs[:, j] = sum(s[:j])
             c = np.arange(20)
             fine = np.max(np.abs(2.0 * cs[:, c + 10] - cs[:, c] - cs[:, c + 20]), axis=1)      # :180-185 |sum(10 codes) - sum(next 10)| at 20 alignments
-            acq.carrFreq[K + 7] = float(fp.f0 - 25.0 * int(np.argmax(fine)))
+            acq.carrFreq[K + 7] = float(f0 - 25.0 * int(np.argmax(fine)))
             acq.codePhase[K + 7] = r.code_phase
             if acq.carrFreq[K + 7] == 0:                                                                               # :263-265
                 acq.carrFreq[K + 7] = 1

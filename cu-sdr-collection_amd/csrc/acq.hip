@@ -180,6 +180,7 @@ struct PassArgs {
   // (b / shift_den) * shift_q whole bins
   int shift_q;
   int shift_den;
+  int shift0;  // whole bins added to every batch's shift (a search around another centre frequency: gc_acquire_coarse_offsets), in [0, n)
   // PRE_IF_CARRIER on a transform longer than the reference's 2*spc (sizes the radix-{2..8} plan cannot take are padded to
   // the next one it can, launch in gc_acquire_coarse_multi): positions wrap_len .. wrap_len + spc - 1 repeat the first spc
   // (mixed) samples, everything behind is zero
@@ -516,7 +517,8 @@ __global__ __launch_bounds__(kFftThreads) void fft_pass_kernel(const PassArgs a)
             // k = k1 + n1*k2 is k1*n2 + k2
             const int den = a.shift_den > 1 ? a.shift_den : 1, sbin = (int)(tb / a.nhops);
             const long long src = a.shift_q > 0 ? (long long)(sbin % den) * a.nhops + tb % a.nhops : tb / a.shift_bins;
-            const int sft = a.shift_q > 0 ? (sbin / den) * a.shift_q : (int)(tb % a.shift_bins);
+            int sft = a.shift_q > 0 ? (sbin / den) * a.shift_q + a.shift0 : (int)(tb % a.shift_bins);
+            if (sft >= a.n) sft -= a.n;
             const int k1 = (int)(pos / a.n2), k2 = (int)(pos % a.n2);
             int k = k1 + a.n1 * k2 - sft;
             if (k < 0) k += a.n;
@@ -965,7 +967,8 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
     [[maybe_unused]] float2 fr_oth[RR ? IT0 : 1][RR ? R0 : 1];
     if constexpr (RR) {
       const long long tb0 = (long long)batch * reps;
-      const unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
+      unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb0 % a.shift_bins);
+      sft -= sft >= N ? N : 0u;
       const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
 #pragma unroll
       for (unsigned it = 0; it < IT0; ++it) {
@@ -1009,7 +1012,8 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
         [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
         if constexpr (SHIFT) {
           const unsigned sbin = (unsigned)(tb / a.nhops);
-          const unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
+          unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb % a.shift_bins);
+          sft -= sft >= N ? N : 0u;
           shsrc = a.shift_q > 0 ? (long long)(sbin % sden) * a.nhops + tb % a.nhops : tb / a.shift_bins;
           sh2 = sft / OTHER;
           sh1 = sft - sh2 * OTHER;
@@ -1150,7 +1154,8 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
   [[maybe_unused]] float2 rr_oth[RR ? SLOTS : 1];
   if constexpr (RR) {
     const long long tb0 = (long long)batch * reps;
-    const unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q : (unsigned)(tb0 % a.shift_bins);
+    unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb0 % a.shift_bins);
+    sft -= sft >= N ? N : 0u;
     const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
 #pragma unroll
     for (unsigned slot = 0; slot < SLOTS; ++slot) {
@@ -1178,7 +1183,8 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
     [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
     if constexpr (SHIFT) {
       const unsigned sbin = (unsigned)(tb / a.nhops);
-      const unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q : (unsigned)(tb % a.shift_bins);
+      unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb % a.shift_bins);
+      sft -= sft >= N ? N : 0u;
       shsrc = a.shift_q > 0 ? (long long)(sbin % sden) * a.nhops + tb % a.nhops : tb / a.shift_bins;
       sh2 = sft / OTHER;
       sh1 = sft - sh2 * OTHER;
@@ -2357,6 +2363,8 @@ static int forward(gc_context* ctx, AcqScratch* s, PassArgs base, int pre, long 
 
 extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
                                        const int8_t* sampled_codes, gc_acq_result* out);
+extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
+                                         const int8_t* sampled_codes, const double* freq_offset, gc_acq_result* out);
 
 extern "C" int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn, const int8_t* sampled_codes,
                                  gc_acq_result* out) {
@@ -2367,6 +2375,11 @@ extern "C" int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int np
 // the data+pilot search of GPS_L5C/include/acquisition.m:175-216 (narms = 1: acquisition.m:158-192).
 extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
                                        const int8_t* sampled_codes, gc_acq_result* out) {
+  return gc_acquire_coarse_offsets(ctx, p, nprn, narms, sampled_codes, nullptr, out);
+}
+
+extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
+                                         const int8_t* sampled_codes, const double* freq_offset, gc_acq_result* out) {
   if (!ctx || !p || nprn <= 0 || narms < 1 || narms > 4 || !sampled_codes || !out) {
     gc_set_error("gc_acquire_coarse: bad arguments");
     return GC_E_INVALID;
@@ -2490,6 +2503,21 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
   }
   const bool shifted = !padded && q >= 1 && (long long)((nbins - 1) / den) * q < n && std::getenv("GC_ACQ_NO_SHIFT") == nullptr;
   if (!shifted) den = 1;
+  // per-row centre frequencies (gc_acquire_coarse_offsets): row ip searches around IF + freq_offset[ip] - the same signal spectra moved
+  // by -freq_offset * N / fs bins, which must be whole bins (GLONASS: 562.5 kHz x 2 ms = 1 125)
+  std::vector<int> row_shift((size_t)nprn, 0);
+  if (freq_offset) {
+    for (int ip = 0; ip < nprn; ++ip) {
+      const double b = -freq_offset[ip] * (double)n / p->sampling_freq, r = std::floor(b + 0.5);
+      if (!shifted || std::fabs(b - r) > 1e-9 * std::max(1.0, std::fabs(b)) || std::getenv("GC_ACQ_FUSED")) {
+        gc_set_error("gc_acquire_coarse_offsets: a row's offset of %.3f Hz is not a whole number of the search's FFT bins (%.6f Hz), or the "
+                     "search does not run on shifted spectra", freq_offset[ip], p->sampling_freq / n);
+        return GC_E_UNSUPPORTED;
+      }
+      const long long m = (long long)r % n;
+      row_shift[(size_t)ip] = (int)(m < 0 ? m + n : m);
+    }
+  }
   base.wrap_len = padded ? blk : 0;
   rc = forward(ctx, s, base, PRE_IF_CARRIER, shifted ? (long long)den * H : (long long)nbins * H, s->sig);
   if (rc) return rc;
@@ -2634,6 +2662,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
       a.in_batch_stride = pl.n;
       a.shift_q = shifted ? (int)q : 0;
       a.shift_den = den;
+      a.shift0 = row_shift[(size_t)ip];
       a.n1 = pl.n1;
       a.n2 = pl.n2;
       a.other = s->codespec + ((size_t)ip * narms + arm) * pl.n;
@@ -2702,7 +2731,7 @@ extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, 
     out[ip].code_phase = harg[1] + 1;
     out[ip].peak = (double)peak;
     out[ip].peak_metric = (double)peak / sig_power / H;  // :200
-    out[ip].coarse_freq = p->intermediate_freq + p->search_band - p->search_step * harg[0];
+    out[ip].coarse_freq = p->intermediate_freq + (freq_offset ? freq_offset[ip] : 0.0) + p->search_band - p->search_step * harg[0];
   }
   return GC_OK;
 }

@@ -314,8 +314,10 @@ class Engine:
         return res
 
     # ---- acquisition ---------------------------------------------------------------------
-    def acquire_coarse(self, params: L.gc_acq_params, sampled_codes: np.ndarray):
-        """sampled_codes: int8 [nprn, spc], or [nprn, narms, spc] for a data+pilot search."""
+    def acquire_coarse(self, params: L.gc_acq_params, sampled_codes: np.ndarray, freq_offset=None):
+        """sampled_codes: int8 [nprn, spc], or [nprn, narms, spc] for a data+pilot search.  freq_offset: Hz per row added to
+        params.intermediate_freq (gc_acquire_coarse_offsets: GLONASS' frequency numbers in one call); raises GnssCorrError with status
+        GC_E_UNSUPPORTED when an offset is not a whole number of the search's FFT bins."""
         codes = np.ascontiguousarray(sampled_codes, dtype=np.int8)
         nprn = codes.shape[0]
         narms = codes.shape[1] if codes.ndim == 3 else 1
@@ -323,8 +325,15 @@ class Engine:
         bins = int(params.n_bins) if params.n_bins else int(math.floor(params.search_band * 2 / params.search_step + 0.5)) + 1
         self._count_transforms(n, forward=bins * int(params.non_coh_time), code=nprn * narms, inverse=nprn * narms * bins * int(params.non_coh_time))
         res = (L.gc_acq_result * nprn)()
-        L.check(self._lib.gc_acquire_coarse_multi(self._ctx, C.byref(params), nprn, narms,
-                                                  codes.ctypes.data_as(C.c_void_p), res))
+        if freq_offset is None:
+            L.check(self._lib.gc_acquire_coarse_multi(self._ctx, C.byref(params), nprn, narms,
+                                                      codes.ctypes.data_as(C.c_void_p), res))
+        else:
+            off = np.ascontiguousarray(freq_offset, dtype=np.float64)
+            if off.shape != (nprn,):
+                raise ValueError("acquire_coarse: one frequency offset per row")
+            L.check(self._lib.gc_acquire_coarse_offsets(self._ctx, C.byref(params), nprn, narms, codes.ctypes.data_as(C.c_void_p),
+                                                        off.ctypes.data_as(C.POINTER(C.c_double)), res))
         return list(res)
 
     def acquire_fine_sums(self, params: L.gc_fine_params, code: np.ndarray) -> np.ndarray:

@@ -383,6 +383,15 @@ int gc_acquire_coarse(gc_context* ctx, const gc_acq_params* p, int nprn,
 int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
                             const int8_t* sampled_codes, gc_acq_result* out);
 
+/* The same with a centre frequency per row: row ip is searched around p->intermediate_freq + freq_offset[ip] (Hz).  One code on
+ * several carriers is GLONASS' FDMA search - GLO/GLO_GL1/include/acquisition.m:146-147 runs the L1 C/A scheme once per frequency
+ * number K around IF - freqSpacing*K with the common 511-chip code - here as ONE call with the code repeated per row: the rows share
+ * the signal spectra (an offset is a whole-bin shift of them) and run on the two PRN lanes.  Every offset must be a whole number of
+ * the search's FFT bins, sampling_freq / N, and the bin spacing a whole (or q / den) number of bins - GC_E_UNSUPPORTED otherwise (the
+ * caller then searches row by row).  freq_offset == NULL: gc_acquire_coarse_multi.  out[ip].coarse_freq includes the row's offset. */
+int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
+                              const int8_t* sampled_codes, const double* freq_offset, gc_acq_result* out);
+
 /* Fine-frequency stage of GPS L1 C/A (acquisition.m:213-254) for one detected PRN:
  * `code` = 1023 chips (+-1), `code_phase` / `coarse_freq` from gc_acquire_coarse.
  * Returns the fine carrier frequency (with the "0 -> 1 Hz" rule of :258-260 applied). */

@@ -399,6 +399,42 @@ def test_glonass_fdma_acquisition_with_meander_fine_stage(engine):
     assert got.peakMetric[7] < 0.5 * min(got.peakMetric[4], got.peakMetric[12])   # K = 0: noise only (threshold 2.0 is tuned for 20 hops)
 
 
+def test_glonass_frequency_numbers_in_one_coarse_call_equal_the_calls_row_by_row(engine):
+    """gc_acquire_coarse_offsets: a centre frequency per row (GLO_GL1 acquisition.m:146-147, IF - freqSpacing*K) on shared, shifted
+    signal spectra must return the bins and code phases of one gc_acquire_coarse call per frequency number, the peaks within float32
+    rounding; an offset that is not a whole number of FFT bins is refused (the caller then goes row by row)."""
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L
+    from cu_sdr_collection_amd.receiver import _acq_params
+    from cu_sdr_collection_amd.settings import initSettings_GLO_GL1
+    S = initSettings_GLO_GL1()
+    S.acqNonCohTime = 4
+    fs = S.samplingFreq
+    rng = np.random.default_rng(77)
+    iq = np.zeros(2 * int(0.050 * fs))
+    for K in (-7, 2, 6):
+        s = P.synth.SatSpec(prn=1, doppler=float(rng.uniform(-3e3, 3e3)), code_phase_samples=float(rng.uniform(0, 12000)),
+                            carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=50.0)
+        iq += P.synth.generate_if([s], iq.shape[0] // 2, fs, S.IF - S.freqSpacing * K, lambda prn: P.codes.generateGLOcode(), S.codeFreqBasis, 511,
+                                  seed=300 + K, carrier_ratio=3135.0, noise=False, bit_periods=10)
+    iq = np.clip(np.rint(iq + 20.0 * rng.standard_normal(iq.shape[0])), -127, 127).astype(np.int8)
+    engine.load_if(iq, fs=fs)
+    Ks = list(range(-7, 7))
+    table = P.acq_family.glonass_sampled_code(fs, 12000)[None, :]
+    p = _acq_params(S, 0)
+    one = engine.acquire_coarse(p, np.repeat(table, len(Ks), axis=0), freq_offset=[-S.freqSpacing * K for K in Ks])
+    for K, r in zip(Ks, one):
+        q = _acq_params(S, 0)
+        q.intermediate_freq = S.IF - S.freqSpacing * K
+        w = engine.acquire_coarse(q, table)[0]
+        assert (r.coarse_bin, r.code_phase, r.coarse_freq) == (w.coarse_bin, w.code_phase, w.coarse_freq), K
+        assert abs(r.peak_metric - w.peak_metric) <= 2e-5 * w.peak_metric, K
+    assert sum(r.peak_metric > S.acqThreshold for r in one) >= 3
+    with pytest.raises(L.GnssCorrError) as err:
+        engine.acquire_coarse(p, np.repeat(table, 2, axis=0), freq_offset=[0.0, 562.6e3])
+    assert err.value.status == L.GC_E_UNSUPPORTED
+
+
 @pytest.mark.parametrize("fs", [16.368e6, 5.714e6])
 def test_acquisition_at_sampling_rates_the_radix_plan_cannot_factor(engine, fs):
     """2*samplesPerCode = 32 736 = 2^5*3*11*31 (16.368 Msps) and 11 428 = 2^2*2857 (5.714 Msps) have prime factors no stage
