@@ -211,7 +211,11 @@ def _traffic_entries():
     WRITE_SIZE in separate passes, gfx950 corrections of MI355X_MICROARCH.md), newest round first.  An entry counts only when it
     was measured on THIS build (its lib_sha256 = the loaded library's): a kernel change without a re-profile drops the traffic
     figure instead of carrying a stale one."""
-    for rnd in ("r03", "r02", "r01"):
+    try:
+        rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()), key=lambda d: -int(d[1:]))
+    except OSError:
+        rounds = []
+    for rnd in rounds:          # every committed round, newest first (the list used to stop at r03: round 4's passes were never read)
         path = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         try:
             tj = json.load(open(path))
