@@ -435,6 +435,45 @@ def test_glonass_frequency_numbers_in_one_coarse_call_equal_the_calls_row_by_row
     assert err.value.status == L.GC_E_UNSUPPORTED
 
 
+def test_searches_of_two_contexts_at_the_same_time_share_the_devices_search_streams():
+    """The PRN lanes of every context run on ONE pair of streams per device (include/gnsscorr.h, gc_acquire_coarse_multi): two contexts
+    searching from two host threads at the same time interleave their launches on that pair and must still return what each returns
+    alone - every call forks and joins with its own events."""
+    import threading
+    import cu_sdr_collection_amd as P
+    S = P.initSettings()
+    S.acqNonCohTime = 6
+    recs = []
+    for seed in (11, 12):
+        sats = P.synth.scene(6, seed, S.samplingFreq)
+        recs.append(P.synth.generate_if(sats, int(0.06 * S.samplingFreq), S.samplingFreq, S.IF, P.codes.generateCAcode, S.codeFreqBasis, 1023, seed=seed))
+    engs = [P.Engine(0), P.Engine(0)]
+    try:
+        for e, r in zip(engs, recs):
+            e.load_if(r, fs=S.samplingFreq)
+        alone = [P.acquisition(e, S) for e in engs]
+        assert all(np.count_nonzero(a.carrFreq) >= 4 for a in alone) and not np.array_equal(alone[0].codePhase, alone[1].codePhase)
+        got = [[], []]
+
+        def work(k):
+            for _ in range(8):
+                got[k].append(P.acquisition(engs[k], S))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for k in range(2):
+            assert len(got[k]) == 8
+            for a in got[k]:
+                assert np.array_equal(a.codePhase, alone[k].codePhase) and np.array_equal(a.carrFreq, alone[k].carrFreq)
+                assert np.array_equal(a.peakMetric, alone[k].peakMetric)
+    finally:
+        for e in engs:
+            e.close()
+
+
 @pytest.mark.parametrize("fs", [16.368e6, 5.714e6])
 def test_acquisition_at_sampling_rates_the_radix_plan_cannot_factor(engine, fs):
     """2*samplesPerCode = 32 736 = 2^5*3*11*31 (16.368 Msps) and 11 428 = 2^2*2857 (5.714 Msps) have prime factors no stage
