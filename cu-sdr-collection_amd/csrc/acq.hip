@@ -180,6 +180,10 @@ struct PassArgs {
   // (b / shift_den) * shift_q whole bins
   int shift_q;
   int shift_den;
+  // rows pass of a data + pilot search with both arms in ONE launch (gc_acquire_coarse_offsets): the launch's first arm_batches batches
+  // are arm 0's, the next ones arm 1's ...; arm k multiplies with other + k * n and writes transform (bin * narms + k) * nhops + hop of
+  // the intermediate, so that the columns pass sees narms * nhops hops per bin and adds the arms' magnitudes like hops.  0: one arm
+  int arm_batches, narms_merged;
   int shift0;  // whole bins added to every batch's shift (a search around another centre frequency: gc_acquire_coarse_offsets), in [0, n)
   // PRE_IF_CARRIER on a transform longer than the reference's 2*spc (sizes the radix-{2..8} plan cannot take are padded to
   // the next one it can, launch in gc_acquire_coarse_multi): positions wrap_len .. wrap_len + spc - 1 repeat the first spc
@@ -901,8 +905,23 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
   // BQ consecutive batches per workgroup (fused columns pass of a search without hops - the circshift family, Galileo E1: a
   // workgroup that lives for ONE tile of 1 800 values spends its life waiting for its twiddles, then for its tile)
   const unsigned BQ = (POST == POST_ABS_ACC && HG == 1 && a.bins_per_wg > 1) ? (unsigned)a.bins_per_wg : 1u;
-  const unsigned hg = bb % HG, batch = (bb / HG) * BQ + (unsigned)a.batch0;
-  const unsigned nq = BQ == 1 ? 1u : min(BQ, (unsigned)a.nbatch_total - (bb / HG) * BQ);
+  unsigned arm = 0, bbl = bb;  // (PassArgs::arm_batches)
+  if constexpr (PRE == PRE_MUL_CONJ && POST == POST_TWIDDLE) {
+    if (a.arm_batches > 0) {
+      arm = bb / (unsigned)a.arm_batches;
+      bbl = bb - arm * (unsigned)a.arm_batches;
+    }
+  }
+  [[maybe_unused]] const float2* __restrict__ const other = a.other + (size_t)arm * N;
+  // where transform tb of this launch goes in the intermediate
+  [[maybe_unused]] auto out_tb = [&](long long tb) -> long long {
+    if constexpr (PRE == PRE_MUL_CONJ && POST == POST_TWIDDLE) {
+      if (a.arm_batches > 0) return (tb / a.nhops * a.narms_merged + arm) * a.nhops + tb % a.nhops;
+    }
+    return tb;
+  };
+  const unsigned hg = bbl % HG, batch = (bbl / HG) * BQ + (unsigned)a.batch0;
+  const unsigned nq = BQ == 1 ? 1u : min(BQ, (unsigned)a.nbatch_total - (bbl / HG) * BQ);
   const unsigned v0 = tile * C;
   constexpr bool RR = SHIFT && POST != POST_ABS_ACC;  // rows pass that may walk several hops of its bin (PassArgs::row_reps)
   const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : (RR && a.row_reps > 1 && a.shift_q > 0) ? a.row_reps : 1;
@@ -984,7 +1003,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
           int e2 = (int)e - (int)s2 - bor;
           e2 += e2 < 0 ? L : 0;
           fr_src[RR ? it : 0][RR ? q : 0] = (unsigned)(k1 * L + e2) * 8u;  // byte offset (ld_off)
-          fr_oth[RR ? it : 0][RR ? q : 0] = a.other[(v0 + c) * L + e];
+          fr_oth[RR ? it : 0][RR ? q : 0] = other[(v0 + c) * L + e];
         }
       }
     }
@@ -1024,7 +1043,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
             pre[it][q] = ld_off(src, fr_src[it][q]);
           } else {
             const unsigned pos = (v0 + c) * L + e;
-            poth[it][q] = a.other[pos];
+            poth[it][q] = other[pos];
             if constexpr (SHIFT) {
               int k1 = (int)(v0 + c) - (int)sh1;
               const int bor = k1 < 0;
@@ -1092,7 +1111,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
       constexpr unsigned LPL = NST == 2 ? LP1 : LP;
       // ---- last stage, outputs to the epilogue in registers ---------------------------------------------------------------
       if constexpr (POST == POST_TWIDDLE) {
-        float2* __restrict__ dstp = a.out + tb * a.out_batch_stride;
+        float2* __restrict__ dstp = a.out + out_tb(tb) * a.out_batch_stride;
         const unsigned obl = (unsigned)a.out_blocked;
         stage_last_ct<NT, RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned, int, unsigned c, unsigned e, float2 val) {
           val = cmul(val, cmul(tw2[c * TW2 + (e >> 4)], tw2[c * TW2 + EH + (e & 15)]));
@@ -1168,7 +1187,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
       int e2 = (int)e - (int)s2 - bor;
       e2 += e2 < 0 ? L : 0;
       rr_src[RR ? slot : 0] = (unsigned)(k1 * L + e2);
-      rr_oth[RR ? slot : 0] = a.other[v0 * L + idx];
+      rr_oth[RR ? slot : 0] = other[v0 * L + idx];
     }
   }
 
@@ -1250,7 +1269,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
         if constexpr (PRE == PRE_MUL_CONJ) {
           float2 o;
           if constexpr (RR) o = rr_oth[slot];
-          else o = a.other[pos];
+          else o = other[pos];
           val = make_float2(val.x * o.x + val.y * o.y, val.y * o.x - val.x * o.y);
         }
       }
@@ -1303,7 +1322,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
       if constexpr (POST == POST_ABS_ACC) {
         accv[slot] += cabs_f(val.x, val.y);
       } else {
-        a.out[tb * a.out_batch_stride + pos] = val;
+        a.out[out_tb(tb) * a.out_batch_stride + pos] = val;
       }
     }
     // the next hop's load overwrites buf0: safe without a barrier when the result sits in buf1 (the barrier after the
@@ -2442,8 +2461,17 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
       }
     }
   }
+  // Both (all) code arms of a PRN in one rows-pass launch and one columns-pass launch when their weights are equal (the data + pilot
+  // searches add the arms' magnitudes, GPS_L5C acquisition.m:175-216): the arms' transforms sit next to each other per bin in the
+  // intermediate and the columns pass adds them like hops - half the launches, each twice the size, and no sums written by the first
+  // arm for the second to read back and add to.  It pays where a bin has few hops - Galileo E1's one: 10.9 -> 9.5 ms - and not where the
+  // columns pass already walks 15 - 25 hops per bin and the doubled intermediate needs twice the chunks (L5 6.2 -> 6.4 .. 7.2 ms, E5b 28.5 ->
+  // 30.4 .. 33, E5a / B2a +-0): merged up to 4 arm-hops per bin (GC_ACQ_ARMS_MERGE=1: always; GC_ACQ_ARMS_SEPARATE=1: never).
+  bool merge_arms = narms > 1 && !std::getenv("GC_ACQ_ARMS_SEPARATE") && !std::getenv("GC_ACQ_FUSED") && !std::getenv("GC_ACQ_GENERIC") &&
+                    ((long long)narms * H <= 4 || std::getenv("GC_ACQ_ARMS_MERGE"));
+  for (int arm = 1; arm < narms; ++arm) merge_arms = merge_arms && p->arm_weight[arm] == p->arm_weight[0];
   AcqScratch* s = nullptr;
-  int rc = ensure_scratch(ctx, n, (long long)nbins * H, nprn * narms, nbins, cl, &s);
+  int rc = ensure_scratch(ctx, n, (long long)nbins * H * (merge_arms ? narms : 1), nprn * narms, nbins, cl, &s);
   if (rc) return rc;
   s->shift.n = 0;  // the signal spectra of a circshift search, if any, are overwritten below
   const Plan& pl = s->plan;
@@ -2569,6 +2597,8 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
     }
   }
   const int hblock = base.wrap_len > 0 ? 0 : handover_block(pl);
+  merge_arms = merge_arms && hblock && shifted && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_PEAK_KERNEL");
+  const int marms = merge_arms ? narms : 1;  // arms per launch
   // shifted spectra on a specialised plan: a workgroup of the rows pass walks several hops of its bin (same rotation, same code
   // spectrum values, same twiddle tables), as long as the launch keeps ~8 workgroups per CU; GC_ACQ_ROW_REPS overrides (a divisor of H)
   int row_reps = 1;
@@ -2629,7 +2659,8 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
     // the fewest chunks (of at least 8 bins) that bring the lanes' intermediates (+ the sums a second code arm adds to) + the signal
     // spectra under ~235 MB; none if nothing does
     const double hop_bytes = (double)H * (double)pl.n * sizeof(float2);
-    const double per_bin = hop_bytes + (narms > 1 ? (double)pl.n * sizeof(float) : 0.0), spectra = (shifted ? (double)den : (double)nbins) * hop_bytes;
+    const double per_bin = marms * hop_bytes + ((narms > 1 && !merge_arms) ? (double)pl.n * sizeof(float) : 0.0),
+                 spectra = (shifted ? (double)den : (double)nbins) * hop_bytes;
     const double room = 236.0 * 1024 * 1024;
     for (int c = 1; c <= nbins / 8; ++c)
       if ((double)lanes * ((nbins + c - 1) / c) * per_bin + spectra <= room) {
@@ -2648,9 +2679,9 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
     s->nlanes = lanes;
     ctx->stream = lanes == 2 ? s->lane_stream[s->lane] : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
     // (a chunk's batches keep their numbers, bin0 * H on: the chunk's first batch sits at the start of the lane's intermediate)
-    float2* const tmp = (s->lane ? s->tmp2 : s->tmp) - (size_t)bin0 * H * (size_t)pl.n;
+    float2* const tmp = (s->lane ? s->tmp2 : s->tmp) - (size_t)bin0 * H * marms * (size_t)pl.n;
     float* const results = s->lane ? s->results2 : s->results;
-    for (int arm = 0; arm < narms; ++arm) {
+    for (int arm = 0; arm < (merge_arms ? 1 : narms); ++arm) {
       // I1: rows of the product S .* conj(Ccode) (length n2, contiguous), inverse, twiddle
       PassArgs a = base;
       a.n = pl.n;
@@ -2676,8 +2707,12 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
       a.out_blocked = hblock;  // the intermediate in the columns pass's tile order
       a.row_reps = row_reps;
       a.batch0 = (int)((long long)bin0 * H / row_reps);
-      rc = launch_pass(ctx, a, (long long)cb * H / row_reps);
+      a.arm_batches = merge_arms ? (int)((long long)cb * H / row_reps) : 0;
+      a.narms_merged = marms;
+      rc = launch_pass(ctx, a, (long long)marms * cb * H / row_reps);
       a.batch0 = 0;
+      a.arm_batches = 0;
+      a.nhops = marms * H;  // the columns pass adds the arms of a bin like hops
       if (rc) {
         lane_rc = rc;
         break;
@@ -2697,7 +2732,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
       a.acc_out = results;
       a.acc_add = arm > 0;
       a.acc_scale = (float)p->arm_weight[arm];  // 0: 1
-      rc = launch_abs_pass(ctx, s, a, cb, arm == narms - 1 ? peaks + 2 * ip : nullptr, blk, ip, nprn, nullptr, bin0, nbins);
+      rc = launch_abs_pass(ctx, s, a, cb, (merge_arms || arm == narms - 1) ? peaks + 2 * ip : nullptr, blk, ip, nprn, nullptr, bin0, nbins);
       if (rc) {
         lane_rc = rc;
         break;

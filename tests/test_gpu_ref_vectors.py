@@ -223,7 +223,12 @@ _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": 
               # remainder chunk, one and two code arms, and the rational spacing on top
               ("GPS_L1CA", {"GC_ACQ_BIN_CHUNKS": "3"}), ("GPS_L5C", {"GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5b", {"GC_ACQ_BIN_CHUNKS": "4"}),
               # the PRN lanes on the context's own stream pair instead of the device's search streams
-              ("GPS_L1CA", {"GC_ACQ_LANE_STREAMS": "own"}), ("GAL_E5b", {"GC_ACQ_LANE_STREAMS": "own"})]
+              ("GPS_L1CA", {"GC_ACQ_LANE_STREAMS": "own"}), ("GAL_E5b", {"GC_ACQ_LANE_STREAMS": "own"}),
+              # data + pilot searches arm by arm (two launches per arm, the second arm adding to the first one's sums) instead of both
+              # arms in one launch pair
+              # arms in one launch pair (automatic for Galileo E1's one hop per bin; forced for the others, with and without chunks)
+              ("GAL_E1C", {"GC_ACQ_ARMS_SEPARATE": "1"}), ("GPS_L5C", {"GC_ACQ_ARMS_MERGE": "1"}), ("GAL_E5b", {"GC_ACQ_ARMS_MERGE": "1"}),
+              ("BDS_B2a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "3"})]
 
 
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
