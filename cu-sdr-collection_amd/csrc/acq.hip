@@ -184,6 +184,10 @@ struct PassArgs {
   // are arm 0's, the next ones arm 1's ...; arm k multiplies with other + k * n and writes transform (bin * narms + k) * nhops + hop of
   // the intermediate, so that the columns pass sees narms * nhops hops per bin and adds the arms' magnitudes like hops.  0: one arm
   int arm_batches, narms_merged;
+  // the columns pass of such a search when the arms have different weights (BDS B1C: sqrt(11/40), sqrt(29/40)): hop r of a bin belongs to
+  // arm r / arm_hops and its magnitude counts arm_w[arm] times.  0: every hop counts once
+  int arm_hops;
+  float arm_w[4];
   int shift0;  // whole bins added to every batch's shift (a search around another centre frequency: gc_acquire_coarse_offsets), in [0, n)
   // PRE_IF_CARRIER on a transform longer than the reference's 2*spc (sizes the radix-{2..8} plan cannot take are padded to
   // the next one it can, launch in gc_acquire_coarse_multi): positions wrap_len .. wrap_len + spc - 1 repeat the first spc
@@ -1123,8 +1127,11 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
           dstp[pos] = val;
         });
       } else {
+        const bool weighted = a.arm_hops > 0;
+        const float wrep = weighted ? a.arm_w[min(rep / a.arm_hops, 3)] : 1.0f;
         stage_last_ct<NT, RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned it, int q, unsigned, unsigned, float2 val) {
-          acc2[it][q] += cabs_f(val.x, val.y);
+          const float m = cabs_f(val.x, val.y);
+          acc2[it][q] = weighted ? fmaf(wrep, m, acc2[it][q]) : acc2[it][q] + m;
         });
       }
       GC_CLK(4);
@@ -3232,11 +3239,17 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     if (const char* e = std::getenv("GC_ACQ_SHIFT_CHUNK_MB")) mb = std::atof(e);
     if (mb > 0.0) chunk_rows = std::max(8, std::min(rows, (int)(mb * 1024.0 * 1024.0 / ((double)pl.n * sizeof(float2)))));
   }
+  // Both arms of a chunk in one launch pair (PassArgs::arm_batches, as the coarse search does for Galileo E1): a row has ONE transform per
+  // arm, so the columns pass walks the arms like hops, weighting each (PassArgs::arm_w).  GC_ACQ_ARMS_SEPARATE=1: arm by arm.
+  const bool merge_arms = narms > 1 && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_ARMS_SEPARATE") &&
+                          !std::getenv("GC_ACQ_ROWMAX_KERNEL");
+  const int marms = merge_arms ? narms : 1;
+  if (merge_arms) chunk_rows = std::max(1, std::min(chunk_rows, rows / narms));  // (the intermediate holds `rows` transforms)
   bool all_fused = true;
   for (int r0 = 0; r0 < rows; r0 += chunk_rows)
-  for (int arm = 0; arm < narms; ++arm) {  // (the arms of a chunk after one another: the second one adds to sums the first one just wrote)
+  for (int arm = 0; arm < (merge_arms ? 1 : narms); ++arm) {  // (separate arms of a chunk after one another: the second one adds to sums the first one just wrote)
     const int rc_rows = std::min(chunk_rows, rows - r0);
-    float2* const tmp = s->tmp - (size_t)r0 * (size_t)pl.n;  // (a chunk's batches keep their numbers; its first one sits at the start of the buffer)
+    float2* const tmp = s->tmp - (size_t)r0 * marms * (size_t)pl.n;  // (a chunk's batches keep their numbers; its first one sits at the start of the buffer)
     PassArgs a = base;
     a.n = pl.n;
     a.tw = s->tw;
@@ -3257,9 +3270,17 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.n1 = pl.n1;
     a.n2 = pl.n2;
     a.batch0 = r0;
-    rc = launch_pass(ctx, a, rc_rows);
+    a.arm_batches = merge_arms ? rc_rows : 0;
+    a.narms_merged = marms;
+    rc = launch_pass(ctx, a, (long long)marms * rc_rows);
     a.batch0 = 0;
+    a.arm_batches = 0;
     if (rc) return rc;
+    if (merge_arms) {
+      a.nhops = narms;  // the columns pass adds a row's arms like hops
+      a.arm_hops = 1;
+      for (int k = 0; k < 4; ++k) a.arm_w[k] = (arm_weight && k < narms) ? (float)arm_weight[k] : 1.0f;
+    }
     fill_sub(a, pl.p1);
     a.nvec = pl.n2;
     a.estride = pl.n2;
@@ -3271,11 +3292,11 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.in = tmp;
     a.acc_out = s->results;
     a.acc_add = arm > 0;
-    a.acc_scale = arm_weight ? (float)arm_weight[arm] : 1.0f;
+    a.acc_scale = merge_arms ? 1.0f : arm_weight ? (float)arm_weight[arm] : 1.0f;
     bool fused_rows = false;
-    rc = launch_abs_pass(ctx, s, a, rc_rows, nullptr, p.n, 0, 1, arm == narms - 1 ? &fused_rows : nullptr, r0, rows);
+    rc = launch_abs_pass(ctx, s, a, rc_rows, nullptr, p.n, 0, 1, (merge_arms || arm == narms - 1) ? &fused_rows : nullptr, r0, rows);
     if (rc) return rc;
-    if (arm == narms - 1) all_fused = all_fused && fused_rows;
+    if (merge_arms || arm == narms - 1) all_fused = all_fused && fused_rows;
   }
   s->shift_rows_fused = all_fused;
   s->shift_narms = narms;

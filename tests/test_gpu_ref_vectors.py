@@ -228,7 +228,9 @@ _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": 
               # arms in one launch pair
               # arms in one launch pair (automatic for Galileo E1's one hop per bin; forced for the others, with and without chunks)
               ("GAL_E1C", {"GC_ACQ_ARMS_SEPARATE": "1"}), ("GPS_L5C", {"GC_ACQ_ARMS_MERGE": "1"}), ("GAL_E5b", {"GC_ACQ_ARMS_MERGE": "1"}),
-              ("BDS_B2a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "3"})]
+              ("BDS_B2a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "3"}),
+              # BDS B1C's weighted data + pilot arms arm by arm again, and merged in small chunks of rows
+              ("BDS_B1C", {"GC_ACQ_ARMS_SEPARATE": "1"}), ("BDS_B1C", {"GC_ACQ_SHIFT_CHUNK_MB": "40"})]
 
 
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
