@@ -351,3 +351,16 @@ def test_first_maximum_is_the_references_sequential_scan():
         win = _first_maximum(np.maximum(p1, p2))
         got = None if win is None else (win[0], 0 if p1[win] > p2[win] else 1, win[1])
         assert got == best, (trial, got, best)
+
+
+def test_bench_reads_the_traffic_passes_of_the_newest_committed_round():
+    """bench.py's roofline.traffic comes from profiles/<round>/traffic.json of the build that is loaded; the list of rounds it looked
+    through once stopped at r03, so round 4's counter passes were never read.  Every committed round counts, newest first."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rounds = [r for r, _ in bench._traffic_entries()]
+    have = sorted((d for d in os.listdir(os.path.join(bench.ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()
+                   and os.path.exists(os.path.join(bench.ROOT, "profiles", d, "traffic.json"))), key=lambda d: -int(d[1:]))
+    assert have and rounds[0] == have[0]
+    assert [r for i, r in enumerate(rounds) if i == 0 or rounds[i - 1] != r] == have
