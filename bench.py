@@ -46,8 +46,98 @@ METRIC = "IF Msamples/s through tracking correlators; x real-time @ 12-ch GPS L1
 
 def _error_line(n: int, steps: int, warmup: int, error: str, **extra) -> str:
     """The ONE JSON line of a run that did not finish: same keys as a result line, value null, `error` says why."""
+    if "stderr_tail" in extra:
+        extra["stderr_tail"] = [str(ln)[-200:] for ln in extra["stderr_tail"][-8:]]
     return json.dumps({"metric": METRIC, "value": None, "unit": "IF Msamples/s", "n_gpus": n, "steps": steps, "warmup": warmup, "ms_per_step": None,
-                       "higher_is_better": True, "error": error, **extra})
+                       "higher_is_better": True, "error": str(error)[:800], **extra})
+
+
+# =======================================================================================================================
+# The printed line.  The driver keeps a bounded tail of stdout and parses the last JSON line in it: the line is the headline, its
+# roofline and CPU baseline and a FLAT summary of the other legs (well under 4 KB); everything else goes to the detail file.
+LINE_LIMIT = 4096
+DETAIL_DEFAULT = os.path.join(ROOT, "bench_detail.json")
+
+_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+_CONFIG_KEYS = ("workload", "channels_per_gpu", "epochs", "blocks_per_step", "prewarm_ms", "parallelism")
+_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(result: dict, detail_path: str | None = None) -> str:
+    """ONE JSON line < LINE_LIMIT bytes from the full result dict of run_l1ca (+ configs, acquisition, sweep, CPU leg) or run_mix."""
+    out = {k: result[k] for k in _LINE_KEYS if k in result}
+    out["dtype"] = _short(out.get("dtype", ""), 96)
+    cfg = result.get("config", {})
+    out["config"] = {k: (_short(cfg[k], 200) if isinstance(cfg[k], str) else cfg[k]) for k in _CONFIG_KEYS if k in cfg}
+    roof = result.get("roofline")
+    if roof:
+        out["roofline"] = {k: (_short(roof[k], 100) if isinstance(roof[k], str) else roof[k]) for k in _ROOFLINE_KEYS if k in roof}
+    cpu = result.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": _short(cpu.get("sample", ""), 260),
+                               "host_cpu": (cpu.get("host_cpu") or {}).get("model"), "x_realtime": cpu.get("x_realtime")}
+    for k in ("x_realtime_replay", "corr_msps", "replay_vs_closed_loop_max_dev", "channels", "channels_locked", "channels_locked_device_loop"):
+        if k in result:
+            out[k] = result[k]
+    for k in ("closed_loop", "closed_loop_device", "closed_loop_host"):
+        if isinstance(result.get(k), dict) and "x_realtime" in result[k]:
+            out[k + "_x_realtime"] = result[k]["x_realtime"]
+    if isinstance(result.get("handover"), dict):
+        h = result["handover"]
+        out["handover"] = {k: h[k] for k in ("backend", "bytes", "seconds") if k in h}
+    if "ranks" in result:
+        out["ranks_locked"] = [r.get("channels_locked", sum(j.get("channels_locked", 0) for j in r.get("jobs", []))) for r in result["ranks"]]
+    cfgs = result.get("configs")
+    if cfgs:
+        names = {"galileo_e1c_cboc_x8": "c3", "l5_b2a_x16_50msps_int8": "c4_int8", "l5_b2a_x16_50msps_int16": "c4_int16", "mix_share_l1_band_x8": "c5_share"}
+        out["configs_frac"] = {names.get(k, k): v["replay"]["roofline"]["frac"] for k, v in cfgs.items()}
+        out["configs_if_msps"] = {names.get(k, k): v["replay"]["if_msps"] for k, v in cfgs.items()}
+    acq = result.get("acquisition")
+    if acq:
+        out["acq_l1ca_ms"] = round(acq["seconds"] * 1e3, 3)
+        out["acq_all_scene_prns_found"] = bool(acq.get("all_scene_prns_found"))
+        pk = acq.get("packages")
+        if pk:
+            out["acq_ms"] = {k: v["ms"] for k, v in pk.items()}
+            out["acq_all_equal_to_reference"] = all(all(v["equal_to_the_references_acquisition_m"].values()) for v in pk.values())
+            l1 = pk.get("GPS_L1CA", {}).get("roofline", {}).get("compute")
+            if l1:
+                out["acq_compute_frac_l1ca"] = l1["frac"]
+    spots = result.get("oracle_spot_checks_max_dev_rel_sum_abs_x")
+    if spots:
+        out["oracle_spot_checks_worst"] = max(spots.values())
+    for k in ("device", "compute_units", "libgnsscorr_sha256", "error"):
+        if k in result:
+            out[k] = result[k]
+    if detail_path:
+        out["detail"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                      # never reached with today's keys; the contract matters more than the summaries
+        for k in ("acq_ms", "configs_if_msps", "ranks_locked", "handover"):
+            out.pop(k, None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < LINE_LIMIT and "\n" not in line, len(line)
+    return line
+
+
+def emit(result: dict, detail_path: str | None) -> None:
+    """Rank 0: the long form to the detail file (its path on stderr), the short line - the LAST thing on stdout."""
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(result, f)
+                f.write("\n")
+            print(f"bench.py: full result ({len(json.dumps(result))} bytes) in {detail_path}", file=sys.stderr, flush=True)
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr, flush=True)
+            detail_path = None
+    sys.stderr.flush()
+    print(compact_line(result, detail_path), flush=True)
 
 
 def _spawn_ranks(n: int, steps: int, warmup: int) -> int:
@@ -965,6 +1055,8 @@ def main() -> None:
     ap.add_argument("--no-int16", action="store_true")
     ap.add_argument("--no-acq-packages", action="store_true", help="skip acquisition.packages (the twelve default-size searches checked against their fixtures)")
     ap.add_argument("--no-handover", action="store_true", help="N > 1: every rank synthesises its own copy of the record(s) instead of receiving them from the source rank (A/B of the exchange step)")
+    ap.add_argument("--detail", default=os.environ.get("GC_BENCH_DETAIL", DETAIL_DEFAULT),
+                    help="file that receives the full result (every leg, every rank); the printed line is its summary. '' = none")
     ap.add_argument("--spot-check", action="store_true", help="--config mix: every rank checks a few replayed blocks of each of its jobs against the float64 oracle (CPU)")
     args = ap.parse_args()
 
@@ -999,7 +1091,7 @@ def main() -> None:
     if config == "mix":
         result = run_mix(P, W, args, R, device)
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            emit(result, args.detail)
         R.close()
         return
 
@@ -1031,7 +1123,7 @@ def main() -> None:
         if spots:
             result["oracle_spot_checks_max_dev_rel_sum_abs_x"] = spots
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result, args.detail)
     main_ctx["eng"].close()
     R.close()
 

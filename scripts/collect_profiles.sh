@@ -10,10 +10,10 @@ mkdir -p "$OUT"
 cd /root/repo
 export TMPDIR=/tmp
 sha256sum cu-sdr-collection_amd/lib/libgnsscorr.so | cut -d" " -f1 > "$OUT/lib_sha256.txt"   # ties every counter pass to the build it ran on (bench.py drops traffic of another build)
-python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py --detail "$OUT/bench.json" > "$OUT/bench_line.json" 2> "$OUT/bench.err"   # the printed line (what the driver parses) and the long form
 cd /tmp
 # per-kernel durations of the same command (no CPU leg: it adds nothing on the device)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python /root/repo/bench.py --no-cpu > "$OUT/bench_under_profiler.json" 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python /root/repo/bench.py --no-cpu --detail "$OUT/bench_under_profiler.json" > /dev/null 2>&1
 # HBM traffic of the main replay kernel: separate passes (TCC slots), main line only
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/l1ca_pmc_$c" -- python /root/repo/bench.py --config l1ca --no-cpu --steps 4 --warmup 1 > /dev/null 2>&1

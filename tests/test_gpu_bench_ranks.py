@@ -16,15 +16,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args, timeout=1500):
+def _bench(*args, timeout=1500, env_extra=None, drop=()):
+    """Runs bench.py, checks the printed line (ONE line, < 4 KB, the contract's keys) and returns the long form from --detail."""
+    import tempfile
     env = dict(os.environ, GC_BENCH_DEVICE="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", *drop):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-3000:]
-    return json.loads(lines[0])
+    env.update(env_extra or {})
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--detail", detail], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0], r.stdout[-3000:]
+        line = json.loads(lines[0])
+        assert len(lines[0]) < 4096 and line["roofline"]["frac"] > 0 and line["value"] > 0 and "workload" in line["config"], lines[0]
+        full = json.load(open(detail))
+    assert full["value"] == line["value"] and full["ms_per_step"] == line["ms_per_step"] and full["roofline"]["frac"] == line["roofline"]["frac"]
+    return full
 
 
 def test_config5_sixty_four_channels_of_twelve_signals_on_eight_ranks():
@@ -69,17 +78,11 @@ def test_sharded_l1ca_line_hands_the_record_over_and_shards_acquisition_by_prn()
 def test_rccl_process_group_carries_the_hand_over_at_world_size_one():
     """The process group the driver's 8-GPU run uses - "cpu:gloo,cuda:nccl", RCCL probe, broadcast of the GPU tensor, gc_attach_if -
     with the one rank a 1-GPU box allows (GC_BENCH_FORCE_DIST): the record's hand-over runs over backend nccl."""
-    env = dict(os.environ, GC_BENCH_FORCE_DIST="1")
-    env.pop("GC_BENCH_DEVICE", None)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
-        env.pop(k, None)
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        env["MASTER_PORT"] = str(sk.getsockname()[1])
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "l1ca", "--seconds", "4", "--steps", "2", "--warmup", "1", "--no-cpu"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
-    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        port = str(sk.getsockname()[1])
+    res = _bench("--gpus", "1", "--config", "l1ca", "--seconds", "4", "--steps", "2", "--warmup", "1", "--no-cpu", timeout=900,
+                 env_extra={"GC_BENCH_FORCE_DIST": "1", "MASTER_PORT": port}, drop=("GC_BENCH_DEVICE",))
     assert res["handover"]["backend"].startswith("nccl"), res["handover"]
     assert res["closed_loop"]["channels_locked"] == 12 and res["replay_vs_closed_loop_max_dev"] < 2e-5

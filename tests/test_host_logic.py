@@ -364,3 +364,33 @@ def test_bench_reads_the_traffic_passes_of_the_newest_committed_round():
                    and os.path.exists(os.path.join(bench.ROOT, "profiles", d, "traffic.json"))), key=lambda d: -int(d[1:]))
     assert have and rounds[0] == have[0]
     assert [r for i, r in enumerate(rounds) if i == 0 or rounds[i - 1] != r] == have
+
+
+def test_bench_prints_a_line_the_driver_can_parse():
+    import os
+    """bench.py's printed line is ONE JSON line under 4 KB carrying the contract's keys, `roofline` and `cpu_baseline` (the driver keeps
+    a bounded tail of stdout: round 4's 21.7 KB line could not be parsed); the long form goes to --detail.  Run on the committed
+    long forms of rounds 3 and 4 and on an N > 1 shape with per-rank entries."""
+    import json
+    import bench
+    for rnd in ("r03", "r04"):
+        full = json.load(open(os.path.join(bench.ROOT, "profiles", rnd, "bench.json")))
+        line = bench.compact_line(full, bench.DETAIL_DEFAULT)
+        assert len(line) < 4096 and "\n" not in line
+        d = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "roofline", "cpu_baseline"):
+            assert k in d, k
+        assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"] and d["config"]["workload"] == full["config"]["workload"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert d["roofline"][k] == full["roofline"][k]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in d["cpu_baseline"]
+        assert set(d["configs_frac"]) == {"c3", "c4_int8", "c4_int16", "c5_share"}
+        assert d["detail"] == "bench_detail.json"
+    assert len(json.loads(bench.compact_line(full))["acq_ms"]) == 12 and json.loads(bench.compact_line(full))["acq_all_equal_to_reference"] is True
+    # eight ranks' worth of per-rank entries and a long error text do not grow the line
+    wide = dict(full, n_gpus=8, ranks=[{"rank": r, "channels_locked": 12, "prns": list(range(12)), "jobs": [{"x" * 50: "y" * 400}] * 6} for r in range(8)],
+                handover={"backend": "nccl", "bytes": 2 ** 31, "seconds": 0.1, "note": "z" * 3000})
+    assert len(bench.compact_line(wide)) < 4096 and json.loads(bench.compact_line(wide))["ranks_locked"] == [12] * 8
+    assert len(bench._error_line(8, 20, 5, "e" * 5000, failed_rank=3, stderr_tail=["t" * 1000] * 40)) < 4096
