@@ -276,7 +276,7 @@ def time_replays_together(jobs, steps: int, warmup: int):
 
 KERNEL_NAMES = {0: "corr_epl_lane_kernel", 1: "corr_epl_fast_kernel (one-wave workgroups)", 2: "corr_epl_fast_kernel (four waves, int8-pair tables)",
                 3: "corr_epl_fast_kernel (four waves, float tables)", 4: "corr_epl_multi_kernel (up to 2 / 4 transitions per 16-sample chunk)",
-                -1: "corr_epl_mixed_kernel"}
+                5: "corr_epl_cboc_kernel (BOC(1,1) arms by transitions, BOC(6,1) arm by a per-sample sign)", -1: "corr_epl_mixed_kernel"}
 
 
 def band_scene(P, parts, fs: float, seed: int, cn0: float = 46.0):

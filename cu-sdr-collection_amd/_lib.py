@@ -100,6 +100,13 @@ class gc_acq_shift_params(C.Structure):
                 ("n_bins", C.c_int32), ("n_arms_max", C.c_int32), ("source", C.c_int32)]
 
 
+class gc_acq_shift_pick(C.Structure):
+    _fields_ = [("row", C.c_int32), ("code_phase", C.c_int32), ("peak", C.c_float), ("second_peak", C.c_float)]
+
+
+GC_SHIFT_PICK_GLOBAL, GC_SHIFT_PICK_SEQUENTIAL, GC_SHIFT_PICK_SEQUENTIAL_PAIRS = 0, 1, 2
+
+
 class gc_acq_result(C.Structure):
     _fields_ = [("coarse_bin", C.c_int32), ("code_phase", C.c_int32), ("peak", C.c_double),
                 ("peak_metric", C.c_double), ("coarse_freq", C.c_double)]
@@ -163,6 +170,8 @@ SYMBOLS = {
     "gc_acq_shift_prepare": (C.c_int, [_P, C.POINTER(gc_acq_shift_params)]),
     "gc_acq_shift_search": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "gc_acq_shift_row": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "gc_acq_shift_search_batch": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(gc_acq_shift_pick)]),
     "gc_acq_shift_dims": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gc_preamble_xcorr": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int64, _P, C.c_int, C.POINTER(C.c_float)]),
     "gc_sync_xcorr": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int64, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -22,9 +22,9 @@ def _round(x: float) -> int:
 _INDEX_CACHE: dict = {}
 
 
-def _sampled(code: np.ndarray, n: int, ts: float, tc: float, start_at_one: bool, last: int | None, first_one: bool = False):
-    """code(ceil(ts*(k)/tc)) for k = 1..n (start_at_one) or 0..n-1, MATLAB 1-based indices into `code`.  The index vector depends on
-    the rates only, not on the PRN: kept per (n, ts, tc, ...) - the reference recomputes it in every make*Table call."""
+def _sample_index(n: int, ts: float, tc: float, start_at_one: bool, last: int | None, first_one: bool = False) -> np.ndarray:
+    """0-based ceil(ts*(k)/tc) - 1 for k = 1..n (start_at_one) or 0..n-1, with the make*Table.m end fixes.  The index vector depends
+    on the rates only, not on the PRN: kept per (n, ts, tc, ...) - the reference recomputes it in every make*Table call."""
     key = (n, ts, tc, start_at_one, last, first_one)
     idx = _INDEX_CACHE.get(key)
     if idx is None:
@@ -39,7 +39,12 @@ def _sampled(code: np.ndarray, n: int, ts: float, tc: float, start_at_one: bool,
         if len(_INDEX_CACHE) > 32:
             _INDEX_CACHE.clear()
         _INDEX_CACHE[key] = idx
-    return code[idx]
+    return idx
+
+
+def _sampled(code: np.ndarray, n: int, ts: float, tc: float, start_at_one: bool, last: int | None, first_one: bool = False):
+    """code(ceil(ts*(k)/tc)) for k = 1..n (start_at_one) or 0..n-1, MATLAB 1-based indices into `code`."""
+    return code[_sample_index(n, ts, tc, start_at_one, last, first_one)]
 
 
 def _second_peak(corr: np.ndarray, code_phase: int, exclude: int, period: int) -> float:
@@ -66,6 +71,17 @@ def _first_maximum(v: np.ndarray):
     if not w.flat[i] > 0.0:
         return None
     return divmod(i, w.shape[1])
+
+
+def _batched(engine, chips, index, weights, rule, exclude=0, period=1):
+    """The whole PRN list in one library call (gc_acq_shift_search_batch): chips int8 [nprn, narms, chips per code] and the ONE index
+    vector that samples every code (the zero padding up to the block length happens on the device).  None: GC_ACQ_SHIFT_PER_PRN=1 (the
+    PRN loop with its two read-backs per PRN, kept for A/B runs and as the path of block lengths without specialised passes) or the
+    library said so."""
+    import os
+    if os.environ.get("GC_ACQ_SHIFT_PER_PRN"):
+        return None
+    return engine.acq_shift_search_batch(chips, weights, rule, exclude, period, sample_index=index)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -104,11 +120,31 @@ def acquisition_B1I(engine, settings, first_sample: int | None = None):
     engine.acq_shift_prepare(p)
     acq = SimpleNamespace(carrFreq=np.zeros(58), codePhase=np.zeros(58), peakMetric=np.zeros(58))
     chip = _round(fs / settings.codeFreqBasis)                                     # :139
-    for prn in settings.acqSatelliteList:
+    prns = list(settings.acqSatelliteList)
+
+    def local_code(prn):
         ca = codes.generateCAcode53(prn).astype(np.int8)
         table = _sampled(np.concatenate([ca, ca]), spc2, ts, 1.0 / settings.codeFreqBasis, True, ncodes * 2046)
-        local = np.concatenate([table, np.zeros(spb // ncodes, dtype=np.int8)])     # :86
-        rmax, _ = engine.acq_shift_search(local[None, :])
+        return np.concatenate([table, np.zeros(spb // ncodes, dtype=np.int8)])     # :86
+
+    def record(prn, row, code_phase, max_peak, second):
+        carrier, rest = divmod(row, 2 * nbins)
+        freq_shift, bin_idx = carrier + 1, rest % nbins + 1
+        acq.peakMetric[prn - 1] = max_peak / second                                # :160
+        if max_peak / second > settings.acqThreshold:                              # :163
+            acq.codePhase[prn - 1] = code_phase
+            acq.carrFreq[prn - 1] = init_freq - freq_res * (bin_idx - 1) + (freq_res / nshifts) * (freq_shift - 1)  # :168
+
+    picks = _batched(engine, np.stack([np.tile(codes.generateCAcode53(prn).astype(np.int8), 2)[None, :] for prn in prns]),
+                     _sample_index(spc2, ts, 1.0 / settings.codeFreqBasis, True, ncodes * 2046), None, L.GC_SHIFT_PICK_SEQUENTIAL_PAIRS, chip, spb // nblocks)
+    if picks is not None:
+        # :87-122 (which (carrier, block, bin) wins), :126 (first maximum of that row) and :141-156 (second peak) inside the call
+        for prn, pk in zip(prns, picks):
+            if pk.row >= 0:
+                record(prn, pk.row, pk.code_phase + 1, float(pk.peak), float(pk.second_peak))
+        return acq
+    for prn in prns:
+        rmax, _ = engine.acq_shift_search(local_code(prn)[None, :])
         rmax = rmax.reshape(nshifts, 2, nbins)
         # :87-122, the sequential rule: a (carrier, bin) is taken when one of its two blocks' maxima exceeds the largest so far, and
         # then the first block only if it is the larger of the two
@@ -116,16 +152,10 @@ def acquisition_B1I(engine, settings, first_sample: int | None = None):
         win = _first_maximum(np.maximum(p1, p2))
         if win is None:
             continue
-        best = (win[0], 0 if p1[win] > p2[win] else 1, win[1])
-        freq_shift, bin_idx = win[0] + 1, win[1] + 1
-        corr = engine.acq_shift_row((best[0] * 2 + best[1]) * nbins + best[2])
+        row = (win[0] * 2 + (0 if p1[win] > p2[win] else 1)) * nbins + win[1]
+        corr = engine.acq_shift_row(row)
         code_phase = int(np.argmax(corr)) + 1                                      # :126
-        max_peak = float(corr[code_phase - 1])
-        second = _second_peak(corr, code_phase, chip, spb // nblocks)
-        acq.peakMetric[prn - 1] = max_peak / second                                # :160
-        if max_peak / second > settings.acqThreshold:                              # :163
-            acq.codePhase[prn - 1] = code_phase
-            acq.carrFreq[prn - 1] = init_freq - freq_res * (bin_idx - 1) + (freq_res / nshifts) * (freq_shift - 1)  # :168
+        record(prn, row, code_phase, float(corr[code_phase - 1]), _second_peak(corr, code_phase, chip, spb // nblocks))
     return acq
 
 
@@ -153,20 +183,33 @@ def acquisition_L2C(engine, settings, first_sample: int | None = None):
     engine.acq_shift_prepare(p)
     acq = SimpleNamespace(carrFreq=np.zeros(32), codePhase=np.zeros(32), peakMetric=np.zeros(32), CLCodePhase=np.zeros(0))
     tc = 1.0 / (settings.codeFreqBasis * 2)
-    for prn in settings.acqSatelliteList:
+    prns = list(settings.acqSatelliteList)
+
+    def local_code(prn):
         cm = codes.generateCMcode(prn, int(settings.codeLength))
         table = _sampled(cm, spc, ts, tc, False, int(settings.codeLength) * 2, first_one=True)   # makeCMTable.m
-        local = np.concatenate([table, np.zeros(spc, dtype=np.int8)])               # :44
-        rmax, _ = engine.acq_shift_search(local[None, :])
-        rmax = rmax.reshape(nshifts, nbins)
-        best = _first_maximum(rmax)                                                # :46-66
-        if best is None:
-            continue
+        return np.concatenate([table, np.zeros(spc, dtype=np.int8)])                # :44
+
+    # :46-66 (which (carrier, bin) wins), :72 (first maximum of that row) and :77-91 (second peak): inside the one call for all PRNs,
+    # or PRN by PRN with the row maxima and the winning row read back each time
+    picks = _batched(engine, np.stack([codes.generateCMcode(prn, int(settings.codeLength)).astype(np.int8)[None, :] for prn in prns]),
+                     _sample_index(spc, ts, tc, False, int(settings.codeLength) * 2, first_one=True), None, L.GC_SHIFT_PICK_SEQUENTIAL, chip, spb // nblocks)
+    for k, prn in enumerate(prns):
+        if picks is not None:
+            if picks[k].row < 0:
+                continue
+            best = divmod(int(picks[k].row), nbins)
+            code_phase, max_peak, second = int(picks[k].code_phase) + 1, float(picks[k].peak), float(picks[k].second_peak)
+        else:
+            rmax, _ = engine.acq_shift_search(local_code(prn)[None, :])
+            best = _first_maximum(rmax.reshape(nshifts, nbins))                    # :46-66
+            if best is None:
+                continue
+            corr = engine.acq_shift_row(best[0] * nbins + best[1])
+            code_phase = int(np.argmax(corr)) + 1                                  # :72
+            max_peak = float(corr[code_phase - 1])
+            second = _second_peak(corr, code_phase, chip, spb // nblocks)
         freq_shift, bin_idx = best[0] + 1, best[1] + 1
-        corr = engine.acq_shift_row(best[0] * nbins + best[1])
-        code_phase = int(np.argmax(corr)) + 1                                      # :72
-        max_peak = float(corr[code_phase - 1])
-        second = _second_peak(corr, code_phase, chip, spb // nblocks)
         acq.peakMetric[prn - 1] = max_peak / second                                # :94
         if max_peak / second > settings.acqThreshold:                              # :97
             f = init_freq - freq_res * (bin_idx - 1) - (freq_res / nshifts) * (freq_shift - 1)   # :101
@@ -284,20 +327,29 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
     engine.acq_shift_prepare(p)
     nmax = max(settings.acqSatelliteList)
     acq = SimpleNamespace(carrFreq=np.zeros(nmax), codePhase=np.zeros(nmax), peakMetric=np.zeros(nmax))
-    for prn in settings.acqSatelliteList:
-        dtab = _b1c_table(codes.generateDataBOC11(prn), settings, spc)
-        arms = [np.concatenate([dtab[:xlen], np.zeros(n - xlen, dtype=np.int8)])]   # :155-156
-        weights = None
-        if pilot:
-            ptab = _b1c_table(codes.generatePilotBOC11(prn), settings, spc)
-            arms.append(np.concatenate([ptab[:xlen], np.zeros(n - xlen, dtype=np.int8)]))
-            weights = [math.sqrt(11) / math.sqrt(40), math.sqrt(29) / math.sqrt(40)]   # :186-187
-        rmax, rarg = engine.acq_shift_search(np.stack(arms), weights)
-        bin_idx = int(np.argmax(rmax)) + 1                                         # :193 max(max(results,[],2))
+    prns = list(settings.acqSatelliteList)
+    weights = [math.sqrt(11) / math.sqrt(40), math.sqrt(29) / math.sqrt(40)] if pilot else None   # :186-187
+    table = lambda gen, prn: _b1c_table(gen(prn), settings, spc)                   # (makeDataTable.m / makePilotTable.m; sampled where it is needed)
+    pad = np.zeros(n - xlen, dtype=np.int8)
+
+    def local_codes(prn):                                                          # :155-156: [table(1:samplesXmsLen) zeros]
+        gens = [codes.generateDataBOC11, codes.generatePilotBOC11] if pilot else [codes.generateDataBOC11]
+        return np.stack([np.concatenate([table(g, prn)[:xlen], pad]) for g in gens])
+
+    index = _sample_index(spc, 1.0 / fs, 1.0 / settings.codeFreqBasis / 2, True, int(settings.codeLength) * 2, first_one=True)[:xlen]
+    picks = _batched(engine, np.stack([np.stack([codes.generateDataBOC11(prn)] + ([codes.generatePilotBOC11(prn)] if pilot else [])) for prn in prns]),
+                     index, weights, L.GC_SHIFT_PICK_GLOBAL)
+    for k, prn in enumerate(prns):
+        if picks is not None:
+            # :193 max(max(results,[],2)) and [peakSize, codePhase] = max(max(results)): the first row holding the largest row
+            # maximum, the first column holding the global maximum
+            bin_idx, peak, code_phase = int(picks[k].row) + 1, float(picks[k].peak), int(picks[k].code_phase) + 1
+        else:
+            rmax, rarg = engine.acq_shift_search(local_codes(prn), weights)
+            bin_idx = int(np.argmax(rmax)) + 1                                     # :193
+            peak = float(rmax.max())
+            code_phase = int(rarg[rmax == rmax.max()].min()) + 1
         sel_freq = init_freq - (bin_idx - 1) * settings.acqStep                    # :194
-        # [peakSize, codePhase] = max(max(results)): column maxima, first column holding the global maximum
-        peak = float(rmax.max())
-        code_phase = int(rarg[rmax == rmax.max()].min()) + 1
         acq.peakMetric[prn - 1] = peak / sig_power                                 # :199
         if code_phase + spc - 1 > n_long:                                          # :232-234
             code_phase -= spc
@@ -307,7 +359,7 @@ def acquisition_B1C(engine, settings, first_sample: int | None = None, n_long: i
             fp = L.gc_fine_params(sampling_freq=fs, code_freq=0.0, f0=sel_freq + settings.acqStep, fstep=float(fine_step),
                                   first_sample=first_sample + code_phase - 1, spc=spc, ncodes=1, nbins=nfine, code_len=spc,
                                   index_offset=0, source=src)
-            tabs = np.stack([dtab, ptab]) if pilot else dtab[None, :]
+            tabs = np.stack([table(codes.generateDataBOC11, prn)] + ([table(codes.generatePilotBOC11, prn)] if pilot else []))
             s = np.abs(engine.acquire_fine_sums_batch(fp, tabs, np.full(len(tabs), fp.first_sample), np.full(len(tabs), fp.f0))[:, :, 0])
             fine = (s[0] * 11 + s[1] * 29) / 40 if pilot else s[0]
             f = float(fp.f0 - fine_step * int(np.argmax(fine)))

@@ -30,7 +30,7 @@ LIBDIR = os.path.join(HERE, "lib")
 INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
 
 LIBS = {
-    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip",
+    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip", "corr_cboc.hip",
                        # one source, four translation units (its 148 kernel instantiations took one compiler process 248 s): unit@MACRO=value
                        "corr_lane.hip@GC_LANE_PART=0", "corr_lane.hip@GC_LANE_PART=1", "corr_lane.hip@GC_LANE_PART=2", "corr_lane.hip@GC_LANE_PART=3",
                        "track.hip", "multi.hip", "stream.hip", "acq.hip", "navsync.hip"],
@@ -44,7 +44,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wal
 # header compiled under the default -ffp-contract=fast, so the backend fuses them into v_fma_f64 (one rounding
 # instead of two: wrong table index at exact ties).  These translation units therefore forbid contraction;
 # wanted FMAs are written as fmaf() / fma().
-NO_CONTRACT = {"gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip", "corr_lane.hip", "track.hip"}
+NO_CONTRACT = {"gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip", "corr_cboc.hip", "corr_lane.hip", "track.hip"}
 
 
 def _hipcc() -> str:

@@ -2048,6 +2048,11 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* use
       return GC_OK;
     }
   }
+  if (a.batch0 != 0 || a.arm_batches > 0) {  // fft_pass_kernel numbers its batches from 0 and knows no merged arms: it would transform other rows into other places
+    gc_set_error("acquisition: rows / bins in chunks, merged arms and single-row transforms need the specialised pass kernels (length %d x %d; GC_ACQ_GENERIC set?)",
+                 a.len, a.nvec);
+    return GC_E_STATE;
+  }
   if (a.in_blocked || a.out_blocked || a.row_reps > 1) {  // handover_block() promised a specialised pair of passes for this plan
     gc_set_error("acquisition: no specialised pass kernel for a blocked hand-over (length %d x %d)", a.len, a.nvec);
     return GC_E_STATE;
@@ -2130,6 +2135,8 @@ struct AcqScratch {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   int shift_rows = 0;
+  // gc_acq_shift_search_batch: every PRN's codes, code spectra, row maxima, the winning rows and the picks of one search
+  GcBuf b_codes, b_chips, b_codespec, b_rowmax, b_rowarg, b_rows, b_pick;
   unsigned long long* peaks = nullptr;  // per-PRN peak keys of gc_acquire_coarse_multi
   int peaks_cap = 0;
   unsigned long long* slots = nullptr;  // per-workgroup peak candidates of abs_combine_kernel, one region per PRN
@@ -2175,6 +2182,7 @@ void free_scratch(AcqScratch* s) {
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
   if (s->pinned) (void)hipHostFree(s->pinned);
+  for (GcBuf* b : {&s->b_codes, &s->b_chips, &s->b_codespec, &s->b_rowmax, &s->b_rowarg, &s->b_rows, &s->b_pick}) gc_buf_free(*b);
   delete s;
 }
 
@@ -3204,29 +3212,18 @@ static int shift_read_back(gc_context* ctx, AcqScratch* s, void* dst0, const voi
   return GC_OK;
 }
 
-extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
-                                   float* row_max, int32_t* row_argmax) {
-  AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
-  if (!s || s->shift.n <= 0 || (s->shift_padded ? s->n < 2 * s->shift.n : s->shift.n != s->n)) {
-    gc_set_error("gc_acq_shift_search: call gc_acq_shift_prepare first");
-    return GC_E_STATE;
-  }
+// The inverse side of ONE PRN of a circshift search: rows pass (shifted product with the PRN's code spectra `codespec`, narms x N) and
+// columns pass for every chunk of rows, the row maxima into s->rowmax / s->rowarg (specialised passes: *all_fused, the sums
+// themselves are not written; otherwise they are in s->results and the caller runs rowmax_kernel).
+static int shift_search_passes(gc_context* ctx, AcqScratch* s, int narms, const float2* codespec, const double* arm_weight, bool* all_fused_out) {
   const gc_acq_shift_params& p = s->shift;
-  if (narms < 1 || narms > p.n_arms_max || !codes || !row_max || !row_argmax) {
-    gc_set_error("gc_acq_shift_search: bad arguments");
-    return GC_E_INVALID;
-  }
-  GC_HIP(hipSetDevice(ctx->device));
   const Plan& pl = s->plan;
   const int rows = p.n_carriers * p.n_signals * p.n_bins;
-  GC_HIP(hipMemcpyAsync(s->codes, codes, (size_t)narms * p.n, hipMemcpyHostToDevice, ctx->stream));
   PassArgs base;
   std::memset(&base, 0, sizeof base);
   base.spc = p.n;
   base.nhops = 1;
-  base.codes = s->codes;
-  int rc = forward(ctx, s, base, PRE_CODE, narms, s->codespec);
-  if (rc) return rc;
+  int rc = GC_OK;
   // Rows in chunks (specialised passes): the rows pass writes rows x N x 8 bytes that the columns pass reads back - 579 MB per PRN and
   // arm for BDS B1C, 2 GB for GPS L2C, through HBM both ways.  A chunk of rows whose intermediate is <= GC_ACQ_SHIFT_CHUNK_MB goes
   // through both passes (and both arms) before the next one starts, in the same place: the columns pass finds it in the 256 MB
@@ -3263,7 +3260,7 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     a.post = POST_TWIDDLE;
     a.in = s->sig;
     a.in_batch_stride = pl.n;
-    a.other = s->codespec + (size_t)arm * pl.n;
+    a.other = codespec + (size_t)arm * pl.n;
     a.out = tmp;
     a.out_batch_stride = pl.n;
     a.shift_bins = s->shift_padded ? 0 : p.n_bins;  // padded: every row is a spectrum of its own
@@ -3298,6 +3295,36 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
     if (rc) return rc;
     if (merge_arms || arm == narms - 1) all_fused = all_fused && fused_rows;
   }
+  *all_fused_out = all_fused;
+  return GC_OK;
+}
+
+extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
+                                   float* row_max, int32_t* row_argmax) {
+  AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
+  if (!s || s->shift.n <= 0 || (s->shift_padded ? s->n < 2 * s->shift.n : s->shift.n != s->n)) {
+    gc_set_error("gc_acq_shift_search: call gc_acq_shift_prepare first");
+    return GC_E_STATE;
+  }
+  const gc_acq_shift_params& p = s->shift;
+  if (narms < 1 || narms > p.n_arms_max || !codes || !row_max || !row_argmax) {
+    gc_set_error("gc_acq_shift_search: bad arguments");
+    return GC_E_INVALID;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  const Plan& pl = s->plan;
+  const int rows = p.n_carriers * p.n_signals * p.n_bins;
+  GC_HIP(hipMemcpyAsync(s->codes, codes, (size_t)narms * p.n, hipMemcpyHostToDevice, ctx->stream));
+  PassArgs base;
+  std::memset(&base, 0, sizeof base);
+  base.spc = p.n;
+  base.nhops = 1;
+  base.codes = s->codes;
+  int rc = forward(ctx, s, base, PRE_CODE, narms, s->codespec);
+  if (rc) return rc;
+  bool all_fused = true;
+  rc = shift_search_passes(ctx, s, narms, s->codespec, arm_weight, &all_fused);
+  if (rc) return rc;
   s->shift_rows_fused = all_fused;
   s->shift_narms = narms;
   for (int arm = 0; arm < 4; ++arm) s->shift_weight[arm] = (arm_weight && arm < narms) ? arm_weight[arm] : 1.0;
@@ -3332,6 +3359,57 @@ extern "C" int gc_acq_shift_dims(gc_context* ctx, int32_t* n, int32_t* rows, int
   return GC_OK;
 }
 
+// Row `irow` (internal order) of a circshift search transformed again: one batch per pass, every arm of `codespec` (narms x N) with its
+// weight; the row's n sums land at acc_out + irow * N (the specialised passes only: launch_pass refuses otherwise).
+static int shift_row_passes(gc_context* ctx, AcqScratch* s, int irow, int narms, const float2* codespec, const double* weight, float* acc_out) {
+  const gc_acq_shift_params& p = s->shift;
+  const Plan& pl = s->plan;
+  PassArgs base;
+  std::memset(&base, 0, sizeof base);
+  base.spc = p.n;
+  base.nhops = 1;
+  for (int arm = 0; arm < narms; ++arm) {
+    PassArgs a = base;
+    a.n = pl.n;
+    a.tw = s->tw;
+    a.inverse = 1;
+    fill_sub(a, pl.p2);
+    a.nvec = pl.n1;
+    a.estride = 1;
+    a.vstride = pl.n2;
+    a.cols = choose_cols(a.len, a.estride);
+    a.pre = PRE_MUL_CONJ;
+    a.post = POST_TWIDDLE;
+    a.in = s->sig;
+    a.in_batch_stride = pl.n;
+    a.other = codespec + (size_t)arm * pl.n;
+    a.out = s->tmp;
+    a.out_batch_stride = pl.n;
+    a.shift_bins = s->shift_padded ? 0 : p.n_bins;
+    a.n1 = pl.n1;
+    a.n2 = pl.n2;
+    a.batch0 = irow;
+    int rc = launch_pass(ctx, a, 1);
+    if (rc) return rc;
+    fill_sub(a, pl.p1);
+    a.nvec = pl.n2;
+    a.estride = pl.n2;
+    a.vstride = 1;
+    a.cols = choose_cols(a.len, a.estride);
+    a.pre = PRE_NONE;
+    a.shift_bins = 0;
+    a.post = POST_ABS_ACC;
+    a.in = s->tmp;
+    a.acc_out = acc_out;
+    a.acc_add = arm > 0;
+    a.acc_scale = (float)weight[arm];
+    a.hop_groups = 1;
+    rc = launch_pass(ctx, a, 1);
+    if (rc) return rc;
+  }
+  return GC_OK;
+}
+
 extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
   AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
   if (!s || s->shift.n <= 0 || !out || row < 0 || row >= s->shift.n_carriers * s->shift.n_signals * s->shift.n_bins) {
@@ -3342,55 +3420,257 @@ extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
   const int irow = s->shift_padded ? shift_internal_row(s->shift, row) : row;
   const size_t at = (size_t)irow * (size_t)s->n;
   if (s->shift_rows_fused) {
-    // the search kept only the row maxima: this row's inverse transforms again (one batch per pass; the code spectra of the search are
-    // still in place), every arm with its weight, into the row's place in `results`
-    const gc_acq_shift_params& p = s->shift;
-    const Plan& pl = s->plan;
+    // the search kept only the row maxima: this row's inverse transforms again (the code spectra of the search are still in place)
+    int rc = shift_row_passes(ctx, s, irow, s->shift_narms, s->codespec, s->shift_weight, s->results);
+    if (rc) return rc;
+  }
+  return shift_read_back(ctx, s, out, s->results + at, sizeof(float) * s->shift.n);
+}
+
+// ---- the whole search of a package in one call -------------------------------------------------------------------------------
+namespace {
+// One workgroup per PRN: the first maximum of the winning row (BDS/B1I acquisition.m:126, GPS_L2C :72) and the largest value of the
+// row's first `period` samples outside +-exclude samples of it - the reference's three range cases (B1I :141-156, L2C :77-91;
+// 1-based there: e1 = codePhase - exclude, e2 = codePhase + exclude; e1 < 2: e2 .. period + e1; e2 >= period: e2 - period + 1 .. e1;
+// else 1 .. e1 and e2 .. period).
+__global__ __launch_bounds__(256) void shift_pick_kernel(const float* __restrict__ rows, long long row_stride, int n, int exclude, int period,
+                                                         gc_acq_shift_pick* __restrict__ picks) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  gc_acq_shift_pick& pk = picks[blockIdx.x];
+  if (pk.row < 0) return;
+  const float* __restrict__ r = rows + (size_t)blockIdx.x * (size_t)row_stride;
+  float best = -1.0f;
+  int bi = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = r[i];
+    if (v > best) {
+      best = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const float v = sv[threadIdx.x + off];
+      const int i = si[threadIdx.x + off];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
+        sv[threadIdx.x] = v;
+        si[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  const float peak = sv[0];
+  const int cp = si[0] + 1;  // 1-based, as the reference's ranges
+  __syncthreads();
+  const int e1 = cp - exclude, e2 = cp + exclude;
+  int lo0, hi0, lo1 = 1, hi1 = 0;  // 1-based inclusive ranges
+  if (e1 < 2) {
+    lo0 = e2;
+    hi0 = period + e1;
+  } else if (e2 >= period) {
+    lo0 = e2 - period + 1;
+    hi0 = e1;
+  } else {
+    lo0 = 1;
+    hi0 = e1;
+    lo1 = e2;
+    hi1 = period;
+  }
+  float second = -1.0f;
+  for (int i = lo0 - 1 + (int)threadIdx.x; i < hi0 && i < n; i += 256)
+    if (i >= 0) second = fmaxf(second, r[i]);
+  for (int i = lo1 - 1 + (int)threadIdx.x; i < hi1 && i < n; i += 256)
+    if (i >= 0) second = fmaxf(second, r[i]);
+  sv[threadIdx.x] = second;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pk.code_phase = cp - 1;
+    pk.peak = peak;
+    pk.second_peak = sv[0];
+  }
+}
+
+// Local replicas on the device: out[c][k] = chips[c][index[k]] for k < n_index, 0 up to n - the package's make*Table.m gather
+// (code(ceil(ts * k / tc)), an index vector that depends on the rates only) and its zero padding ([table zeros], B1I :86, L2C :44,
+// B1C :155-156) without the host forming or sending n bytes per code.
+__global__ __launch_bounds__(256) void shift_expand_codes_kernel(const int8_t* __restrict__ chips, int chip_len, const int* __restrict__ index, int n_index, int n,
+                                                                 int8_t* __restrict__ out) {
+  const int8_t* __restrict__ c = chips + (size_t)blockIdx.y * chip_len;
+  int8_t* __restrict__ o = out + (size_t)blockIdx.y * n;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) o[k] = k < n_index ? c[index[k]] : (int8_t)0;
+}
+
+// The reference's sequential selection over the (carrier, bin) grid (BDS/B1I acquisition.m:87-122, GPS_L2C :46-66): a value is taken
+// only if it EXCEEDS the largest so far, starting from 0, and the last bin of every carrier but the first is not looked at - the
+// first position, in scan order, of the largest value, if that is above 0.  v(carrier, bin) = rowmax, or the larger of the two signal
+// blocks' (pairs).  Returns the public row index, or -1.
+int pick_sequential(const gc_acq_shift_params& p, const float* rmax, bool pairs) {
+  float best = 0.0f;
+  int row = -1;
+  for (int c = 0; c < p.n_carriers; ++c)
+    for (int b = 0; b < p.n_bins; ++b) {
+      if (c > 0 && b == p.n_bins - 1) continue;
+      if (!pairs) {
+        const int r = c * p.n_bins + b;
+        if (rmax[r] > best) {
+          best = rmax[r];
+          row = r;
+        }
+      } else {
+        const int r1 = (c * 2 + 0) * p.n_bins + b, r2 = (c * 2 + 1) * p.n_bins + b;
+        const float v = std::max(rmax[r1], rmax[r2]);
+        if (v > best) {
+          best = v;
+          row = rmax[r1] > rmax[r2] ? r1 : r2;
+        }
+      }
+    }
+  return row;
+}
+}  // namespace
+
+extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, const int8_t* codes, int code_len, const int32_t* sample_index,
+                                         int n_index, const double* arm_weight, int rule, int exclude, int period, gc_acq_shift_pick* out) {
+  AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
+  if (!s || s->shift.n <= 0 || (s->shift_padded ? s->n < 2 * s->shift.n : s->shift.n != s->n)) {
+    gc_set_error("gc_acq_shift_search_batch: call gc_acq_shift_prepare first");
+    return GC_E_STATE;
+  }
+  const gc_acq_shift_params& p = s->shift;
+  const bool pairs = rule == GC_SHIFT_PICK_SEQUENTIAL_PAIRS;
+  if (nprn < 1 || narms < 1 || narms > p.n_arms_max || !codes || !out || rule < GC_SHIFT_PICK_GLOBAL || rule > GC_SHIFT_PICK_SEQUENTIAL_PAIRS ||
+      (pairs && p.n_signals != 2) || (rule == GC_SHIFT_PICK_SEQUENTIAL && p.n_signals != 1) ||
+      (rule != GC_SHIFT_PICK_GLOBAL && (exclude < 0 || period < 1 || period > p.n)) ||
+      (sample_index && (code_len < 1 || n_index < 1 || n_index > p.n))) {
+    gc_set_error("gc_acq_shift_search_batch: bad arguments");
+    return GC_E_INVALID;
+  }
+  if (sample_index)
+    for (int k = 0; k < n_index; ++k)
+      if (sample_index[k] < 0 || sample_index[k] >= code_len) {
+        gc_set_error("gc_acq_shift_search_batch: sample_index[%d] = %d is outside the %d chips of a code", k, (int)sample_index[k], code_len);
+        return GC_E_INVALID;
+      }
+  if (s->shift_padded || ct_columns_tile(s->plan.p1.len, s->plan.n2) == 0 || std::getenv("GC_ACQ_GENERIC") || std::getenv("GC_ACQ_ROWMAX_KERNEL")) {
+    gc_set_error("gc_acq_shift_search_batch: this block length has no specialised pass kernels - search PRN by PRN (gc_acq_shift_search / _row)");
+    return GC_E_UNSUPPORTED;
+  }
+  GC_HIP(hipSetDevice(ctx->device));
+  const Plan& pl = s->plan;
+  const int rows = p.n_carriers * p.n_signals * p.n_bins;
+  const size_t N = (size_t)pl.n;
+  const bool second = rule != GC_SHIFT_PICK_GLOBAL;
+  if (gc_buf_reserve(s->b_codes, (size_t)nprn * narms * p.n, false) != hipSuccess ||
+      gc_buf_reserve(s->b_codespec, (size_t)nprn * narms * N * sizeof(float2), false) != hipSuccess ||
+      gc_buf_reserve(s->b_rowmax, (size_t)nprn * rows * sizeof(float), false) != hipSuccess ||
+      gc_buf_reserve(s->b_rowarg, (size_t)nprn * rows * sizeof(int), false) != hipSuccess ||
+      gc_buf_reserve(s->b_pick, (size_t)nprn * sizeof(gc_acq_shift_pick), false) != hipSuccess ||
+      (second && gc_buf_reserve(s->b_rows, (size_t)nprn * N * sizeof(float), false) != hipSuccess)) {
+    (void)hipGetLastError();
+    gc_set_error("gc_acq_shift_search_batch: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  // every PRN's codes up in one copy - sampled replicas of n entries, or chip tables and the index vector that samples them all
+  // (expanded here) -, their spectra in as few forward launches as the intermediate buffer allows
+  if (!sample_index) {
+    GC_HIP(hipMemcpyAsync(s->b_codes.p, codes, (size_t)nprn * narms * p.n, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    const size_t chips_bytes = (size_t)nprn * narms * code_len, idx_off = (chips_bytes + 15) / 16 * 16;
+    if (gc_buf_reserve(s->b_chips, idx_off + (size_t)n_index * sizeof(int), false) != hipSuccess) {
+      (void)hipGetLastError();
+      gc_set_error("gc_acq_shift_search_batch: device allocation failed");
+      return GC_E_NOMEM;
+    }
+    GC_HIP(hipMemcpyAsync(s->b_chips.p, codes, chips_bytes, hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipMemcpyAsync((char*)s->b_chips.p + idx_off, sample_index, (size_t)n_index * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(shift_expand_codes_kernel, dim3((unsigned int)std::min(64, (p.n + 255) / 256), (unsigned int)(nprn * narms)), dim3(256), 0, ctx->stream,
+                       (const int8_t*)s->b_chips.p, code_len, (const int*)((char*)s->b_chips.p + idx_off), n_index, p.n, (int8_t*)s->b_codes.p);
+    GC_HIP(hipGetLastError());
+  }
+  float2* const cspec = (float2*)s->b_codespec.p;
+  {
     PassArgs base;
     std::memset(&base, 0, sizeof base);
     base.spc = p.n;
     base.nhops = 1;
-    for (int arm = 0; arm < s->shift_narms; ++arm) {
-      PassArgs a = base;
-      a.n = pl.n;
-      a.tw = s->tw;
-      a.inverse = 1;
-      fill_sub(a, pl.p2);
-      a.nvec = pl.n1;
-      a.estride = 1;
-      a.vstride = pl.n2;
-      a.cols = choose_cols(a.len, a.estride);
-      a.pre = PRE_MUL_CONJ;
-      a.post = POST_TWIDDLE;
-      a.in = s->sig;
-      a.in_batch_stride = pl.n;
-      a.other = s->codespec + (size_t)arm * pl.n;
-      a.out = s->tmp;
-      a.out_batch_stride = pl.n;
-      a.shift_bins = s->shift_padded ? 0 : p.n_bins;
-      a.n1 = pl.n1;
-      a.n2 = pl.n2;
-      a.batch0 = irow;
-      int rc = launch_pass(ctx, a, 1);
-      if (rc) return rc;
-      fill_sub(a, pl.p1);
-      a.nvec = pl.n2;
-      a.estride = pl.n2;
-      a.vstride = 1;
-      a.cols = choose_cols(a.len, a.estride);
-      a.pre = PRE_NONE;
-      a.shift_bins = 0;
-      a.post = POST_ABS_ACC;
-      a.in = s->tmp;
-      a.acc_out = s->results;
-      a.acc_add = arm > 0;
-      a.acc_scale = (float)s->shift_weight[arm];
-      a.hop_groups = 1;
-      rc = launch_pass(ctx, a, 1);
+    const long long total = (long long)nprn * narms, step = std::max<long long>(1, s->nbh);
+    for (long long k0 = 0; k0 < total; k0 += step) {
+      base.codes = (const int8_t*)s->b_codes.p + (size_t)k0 * p.n;
+      int rc = forward(ctx, s, base, PRE_CODE, std::min(step, total - k0), cspec + (size_t)k0 * N);
       if (rc) return rc;
     }
   }
-  return shift_read_back(ctx, s, out, s->results + at, sizeof(float) * s->shift.n);
+  // phase 1: every PRN's rows and columns passes, its row maxima into its own slot - nothing comes back in between
+  float* const save_max = s->rowmax;
+  int* const save_arg = s->rowarg;
+  int rc = GC_OK;
+  bool fused = true;
+  for (int k = 0; k < nprn && rc == GC_OK && fused; ++k) {
+    s->rowmax = (float*)s->b_rowmax.p + (size_t)k * rows;
+    s->rowarg = (int*)s->b_rowarg.p + (size_t)k * rows;
+    rc = shift_search_passes(ctx, s, narms, cspec + (size_t)k * narms * N, arm_weight, &fused);
+  }
+  s->rowmax = save_max;
+  s->rowarg = save_arg;
+  if (rc) return rc;
+  if (!fused) {
+    gc_set_error("gc_acq_shift_search_batch: the passes did not run on the specialised kernels - search PRN by PRN");
+    return GC_E_UNSUPPORTED;
+  }
+  s->shift_rows_fused = true;  // gc_acq_shift_row after this call transforms a row of the LAST PRN again
+  s->shift_narms = narms;
+  for (int arm = 0; arm < 4; ++arm) s->shift_weight[arm] = (arm_weight && arm < narms) ? arm_weight[arm] : 1.0;
+  std::vector<float> hmax((size_t)nprn * rows);
+  std::vector<int> harg((size_t)nprn * rows);
+  rc = shift_read_back(ctx, s, hmax.data(), s->b_rowmax.p, sizeof(float) * hmax.size(), harg.data(), s->b_rowarg.p, sizeof(int) * harg.size());
+  if (rc) return rc;
+  // the package's selection rule on the row maxima (host: nprn x rows numbers)
+  for (int k = 0; k < nprn; ++k) {
+    const float* rm = hmax.data() + (size_t)k * rows;
+    const int* ra = harg.data() + (size_t)k * rows;
+    gc_acq_shift_pick& pk = out[k];
+    pk.row = -1;
+    pk.code_phase = 0;
+    pk.peak = 0.0f;
+    pk.second_peak = 0.0f;
+    if (rule == GC_SHIFT_PICK_GLOBAL) {
+      // BDS/B1C acquisition.m:193-197: the row of max(max(results,[],2)) (first), the first column holding the global maximum
+      int best = 0;
+      for (int r = 1; r < rows; ++r)
+        if (rm[r] > rm[best]) best = r;
+      int col = ra[best];
+      for (int r = 0; r < rows; ++r)
+        if (rm[r] == rm[best] && ra[r] < col) col = ra[r];
+      pk.row = best;
+      pk.code_phase = col;
+      pk.peak = rm[best];
+    } else {
+      pk.row = pick_sequential(p, rm, pairs);
+    }
+  }
+  if (!second) return GC_OK;
+  // phase 2: the winning rows again (their sums were never written), first maximum and second peak on the device, one read-back
+  const double ones[4] = {1.0, 1.0, 1.0, 1.0};
+  GC_HIP(hipMemcpyAsync(s->b_pick.p, out, (size_t)nprn * sizeof(gc_acq_shift_pick), hipMemcpyHostToDevice, ctx->stream));
+  for (int k = 0; k < nprn; ++k) {
+    if (out[k].row < 0) continue;
+    const int irow = out[k].row;
+    float* const dst = (float*)((char*)s->b_rows.p + ((size_t)k * N - (size_t)irow * N) * sizeof(float));  // row irow lands at b_rows + k * N
+    rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, arm_weight ? arm_weight : ones, dst);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(shift_pick_kernel, dim3((unsigned int)nprn), dim3(256), 0, ctx->stream, (const float*)s->b_rows.p, (long long)N, p.n, exclude,
+                     period, (gc_acq_shift_pick*)s->b_pick.p);
+  GC_HIP(hipGetLastError());
+  return shift_read_back(ctx, s, out, s->b_pick.p, (size_t)nprn * sizeof(gc_acq_shift_pick));
 }
 
 // Test hook: forward FFT of `nbatch` host sequences of length n (complex64) with the library's

@@ -1,0 +1,475 @@
+// corr_cboc.hip — the hybrid correlator for channels that carry a BOC(6,1) arm next to its BOC(1,1) arm: Galileo E1-C
+// CBOC(6,1,1/11) as BASELINE config 3 words it, BDS B1C wide-band (BDS/B1C/include/WB_tracking.m:285-317: tcode2 = ceil(tcode) + 1
+// for B1CData / pilotBOC11, ceil(tcode * 6) + 1 for pilotBOC61; :338-369: the 18 sums).  Three arms x three taps.
+//
+// Mapping as corr_multi.hip (lane = 16 consecutive samples, aligned to the absolute sample index; a wave walks 64 chunks at a
+// time), and the same transition / prefix-sum formulation for the two BOC(1,1) arms: at 18 Msps a half-chip table advances
+// 0.114 entries per sample, a chunk crosses at most two entries per tap (KT = 2), and a tap's sum is
+//     c[k0] P[m_0] + c[k0+1] (P[m_1] - P[m_0]) + c[k0+2] (T - P[m_1])          P = running sums of the carrier-wiped samples y
+// with nothing per sample and tap.  The BOC(6,1) arm crosses ~11 entries per chunk: for it transitions cost more than samples.
+// But its table is the BOC(1,1) table times a sign that flips every sixth of an entry (gc_channel_is_derived checks exactly that:
+// entry k6 = arm-1 entry p = (k6 + 5) / 6 times (-1)^(p + k6)), and away from ties ceil(ceil(6t) / 6) == ceil(t).  With the ramp
+// written t = p - g, 0 < g < 1, the sign is (-1)^(p + floor(6g)) - and floor(6g) is odd exactly where frac(3g) >= 1/2: bit 31 of
+// three times the ramp's 32-bit fraction word.  So per sample and tap: one integer add (the word's chain), one v_and_or (the bit
+// as +-1.0f), two multiply-adds into the running sums P6 of the SIGN-MODULATED samples - and the arm's sum is the same three-term
+// expression over P6 with the coefficients c[k0+n] (-1)^(k0+n).  No table at six times the rate, no gather, no second ramp.
+//   per sample:      2 converts + 4 (y) + 2 (P) + 3 x 4 (P6 of early / prompt / late)                       = 20 VALU, 8 LDS stores
+//   per chunk:       positions, 12 LDS reads, 27 coefficient ops, 54 tap multiply-adds, 36 Horner, ramp advance  ~ 230 VALU
+//   (lane kernel, corr_lane.hip DER: 47.4 VALU per sample for the same 18 sums)
+// The running sums of all four streams are parked in LDS with ds_write_addtid_b32 (8 floats per sample and lane: 32 KB per wave),
+// so a workgroup is NWV <= 4 waves next to the two interleaved int8 tables.
+//
+// Exactness: as corr_multi.hip for the BOC(1,1) positions (float32 positions, chunks with a position within 4e-6 samples of an
+// integer take the float64 per-sample path); for the six-fold edges an integer test on the fraction words (band kTie6 units of
+// 2^-32 sub-entry, inside the band gc_mark_tie_free searches with).  gc_block::reserved bit 0 = the host proved the block free
+// of both kinds (no test at all), bit 1 = free of six-fold near-edges (the per-sample integer test is skipped).
+#include <cstdlib>
+
+#include "corr_common.h"
+
+using namespace gcorr;
+
+namespace {
+
+constexpr float kTieTolM = 4e-6f;   // corr_multi.hip
+constexpr unsigned int kTie6 = 160u;  // 6 x (2 units of the truncated words + 16 chain steps) + the reference's float64 rounding + slack
+constexpr int kW = 64;
+constexpr int kSPL = 16;
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kGLO = 8;
+constexpr int kGHI = 8;
+constexpr int kRow = 8;                                // floats per sample and lane: P re, im; P6 early re, im; prompt; late
+constexpr int kHalf = 8;                               // rows of running sums kept at a time: samples j and j + 8 share row j
+constexpr int kWaveLds = kHalf * kRow * kW * 4;        // 16 KB
+
+template <int OFF_RE, int OFF_IM>
+__device__ __forceinline__ void park2(float tr, float ti, unsigned int lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
+               :
+               : "v"(tr), "v"(ti), "s"(lds_base), "n"(OFF_RE), "n"(OFF_IM)
+               : "memory", "m0");
+}
+
+// MODE in {I8_IQ, I8_QI}; NWV wavefronts per workgroup share the staged tables of one channel
+template <int MODE, int NWV>
+__global__ __launch_bounds__(NWV* kW) void corr_epl_cboc_kernel(const KArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SPL = kSPL;
+  constexpr int NW = SPL * Fmt<MODE>::bps / 4;
+  constexpr int kShift = 4;
+  constexpr int NS = 3;
+
+  long long wg = blockIdx.x;
+  if (p.xcd_swizzle) {
+    const long long per = (long long)gridDim.x >> 3;
+    wg = (wg & 7) * per + (wg >> 3);
+    if (wg >= p.total_wg) return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long grp = wg / p.stride;
+  const int cslot = (int)(wg - grp * p.stride);
+
+  // ---- stage arms 0 and 1 interleaved: bytes (k + kGLO) * 2 + {0, 1}, zeros in the guards -------------------------------------
+  int nmax;
+  {
+    const long long lb0 = min(grp * p.bpw * p.stride + cslot, (long long)p.nblocks - 1);
+    const gc_block blk0 = p.blocks[lb0];
+    const DevChannel* __restrict__ chn0 = p.chans + blk0.channel;
+    nmax = max(chn0->nent[0], chn0->nent[1]);
+    const int entries = nmax + kGLO + kGHI;
+    for (int e = threadIdx.x; e < entries; e += NWV * kW) {
+      const int k = e - kGLO;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        signed char v = 0;
+        if (k >= 0 && k < chn0->nent[a]) v = chn0->tab[a][k];
+        reinterpret_cast<signed char*>(smem)[e * 2 + a] = v;
+      }
+    }
+    __syncthreads();
+  }
+  auto table_word = [&](int k) -> unsigned int { return (unsigned int)reinterpret_cast<const unsigned short*>(smem)[k + kGLO]; };
+  float* pfx = reinterpret_cast<float*>(smem + p.red_off) + wave * (kWaveLds / 4);
+  const unsigned int pfx_m0 = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)pfx);
+
+  for (int bi = wave; bi < p.bpw; bi += NWV) {
+    const long long lb = (grp * p.bpw + bi) * p.stride + cslot;
+    if (lb >= p.nblocks) break;
+    const gc_block blk = p.blocks[lb];
+    const DevChannel* __restrict__ chn = p.chans + blk.channel;
+
+    // ---- per-block uniform quantities (corr_multi.hip / corr_kernel.hip have the reference line citations) --------
+    const double R = chn->index_scale;
+    const double M = chn->mult[0];
+    const double M6 = chn->mult[2];
+    const double rem = blk.rem_code_phase;
+    const double step = blk.code_phase_step;
+    const double d = blk.el_spacing;
+    const int N = blk.blksize;
+    const long long s0 = blk.first_sample;
+    const double aE = (rem - d) * R;
+    const double aL = (rem + d) * R;
+    const double aP = rem * R;
+    const double sp = step * R;
+    const double tau = blk.carr_freq * p.inv_fs;
+    const double spM = sp * M;
+    double rspM = __builtin_amdgcn_rcp(spM);
+    rspM = fma(rspM, fma(-spM, rspM, 1.0), rspM);
+    rspM = fma(rspM, fma(-spM, rspM, 1.0), rspM);
+    const float uk = (float)(rspM * 2.3283064365386963e-10);
+    const float ustep = (float)rspM;
+    const int flags = __builtin_amdgcn_readfirstlane((int)blk.reserved);
+    const bool tie_free = (flags & 1) != 0;
+    const bool tie6_free = (flags & 2) != 0;
+    // three times the per-sample advance of a ramp's fraction word, negated: the sign word's chain (spM < 1: KT <= 2)
+    const unsigned int negD3 = __builtin_amdgcn_readfirstlane(0u - 3u * (unsigned int)((spM - floor(spM)) * 4294967296.0));
+
+    float myC, myS;
+    unsigned int myJlo, myJhi;
+    int myJint;
+    {
+      const int j = (lane < SPL) ? lane : SPL * kW;
+      const double x = (double)j * tau;
+      sincospif(2.0f * (float)(x - floor(x)), &myS, &myC);
+      const double y = (double)j * spM;
+      const double yi = floor(y);
+      const unsigned long long jf = frac_to_u64(y - yi);
+      myJint = (int)yi;
+      myJlo = (unsigned int)jf;
+      myJhi = (unsigned int)(jf >> 32);
+    }
+    float C[SPL], S[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+      C[j] = rl_f(myC, j);
+      S[j] = rl_f(myS, j);
+    }
+    const float rotC = rl_f(myC, SPL), rotS = rl_f(myS, SPL);
+    const unsigned long long Df = ((unsigned long long)rl_u(myJhi, SPL) << 32) | rl_u(myJlo, SPL);
+    const int Di = __builtin_amdgcn_readlane(myJint, SPL);
+
+    const long long q0 = s0 >> kShift;
+    const long long q1 = (s0 + N - 1) >> kShift;
+    const int cend = (int)(q1 - q0 + 1);
+
+    float accr[3][3], acci[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) accr[a][x] = acci[a][x] = 0.0f;
+
+    const int iters = (cend + kW - 1) / kW;
+    const int c0 = lane;
+    float wc = 1.0f, ws = 0.0f;
+    if (iters > 0) {
+      constexpr int CB = SPL * Fmt<MODE>::bps;
+      const int i00 = (int)((q0 + c0) * SPL - s0);
+      Fx fx[NS];
+      const double isp = __dmul_rn((double)i00, sp);
+      fx[0] = to_fx(__dmul_rn(__dadd_rn(aE, isp), M));
+      fx[1] = to_fx(__dmul_rn(__dadd_rn(aP, isp), M));
+      fx[2] = to_fx(__dmul_rn(__dadd_rn(aL, isp), M));
+      const uint8_t* __restrict__ base = p.if_base;
+      unsigned int glo[NS], ghi[NS];
+      int kk[NS];
+#pragma unroll
+      for (int sx = 0; sx < NS; ++sx) {
+        glo[sx] = (unsigned int)fx[sx].G;
+        ghi[sx] = (unsigned int)(fx[sx].G >> 32);
+        kk[sx] = fx[sx].k0;
+      }
+      const unsigned int Dlo = (unsigned int)Df, Dhi = (unsigned int)(Df >> 32);
+      const uint8_t* __restrict__ bs = base + (long long)CB * q0;
+      const unsigned int voff = (unsigned int)lane * CB;
+      const unsigned int voff_last = min(voff, (unsigned int)(cend - 1 - (iters - 1) * kW) * CB);
+
+      auto load_k = [&](const int k, unsigned int (&w)[NW]) {
+        const uint8_t* __restrict__ pk = bs + (size_t)k * (size_t)(kW * CB);
+        const unsigned int off = (k == iters - 1) ? voff_last : voff;
+        load_words<MODE, SPL>(pk + off, 0, w);
+      };
+
+      auto process = [&](unsigned int (&w)[NW], const int k) {
+        const bool last = (k == iters - 1);
+        if ((k == 0) | last) {
+          int kq = k;
+          asm volatile("" : "+v"(kq));
+          const int i0 = i00 + kq * (SPL * kW);
+          if (last && c0 + kq * kW >= cend) {
+#pragma unroll
+            for (int q = 0; q < NW; ++q) w[q] = 0u;
+#pragma unroll
+            for (int sx = 0; sx < NS; ++sx) kk[sx] = 0;
+          }
+          if ((i0 < 0) | (i0 + SPL > N)) mask_words<MODE, SPL>(w, i0, N);
+        }
+
+        // BOC(1,1) transition positions u_n = (G + n) / (step*R*M), n = 0, 1, and the sign words of the six-fold arm
+        float un[NS][2];
+        unsigned int w6[NS];
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) {
+          float gh;
+          asm("v_cvt_f32_u32_e32 %0, %1" : "=v"(gh) : "v"(ghi[sx]));
+          un[sx][0] = gh * uk;
+          un[sx][1] = un[sx][0] + ustep;
+          w6[sx] = ghi[sx] + (ghi[sx] << 1);
+        }
+        bool exact = false;
+        if (!tie_free) {
+          bool suspect = false;
+#pragma unroll
+          for (int sx = 0; sx < NS; ++sx)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) suspect |= fabsf(un[sx][n] - rintf(un[sx][n])) < kTieTolM;
+          if (!tie6_free) {
+#pragma unroll
+            for (int sx = 0; sx < NS; ++sx) {
+              unsigned int wq = w6[sx];
+#pragma unroll
+              for (int j = 0; j < SPL; ++j) {
+                suspect |= ((wq << 1) + kTie6) <= 2u * kTie6;   // 6g within kTie6 units of an integer
+                wq += negD3;
+              }
+            }
+          }
+          exact = __any(suspect) != 0;
+        }
+
+        float Ur[3][3], Ui[3][3];
+        if (exact) {
+          // ---- exact path: the reference's float64 index per sample and arm (rolled loop, samples re-read from memory) ------
+#pragma unroll
+          for (int ar = 0; ar < 3; ++ar)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) Ur[ar][x] = Ui[ar][x] = 0.0f;
+          int kq = k, Nq = N;
+          asm volatile("" : "+v"(kq), "+v"(Nq));
+          const int c = c0 + kq * kW;
+          const bool act = c < cend;
+          const int i0 = i00 + kq * (SPL * kW);
+          const double nm1s = __dmul_rn((double)(Nq - 1), step);
+          const double bP = __dmul_rn(__dadd_rn(nm1s, rem), R);
+          const double bE = __dmul_rn(__dadd_rn(__dadd_rn(nm1s, rem), -d), R);
+          const double bL = __dmul_rn(__dadd_rn(__dadd_rn(nm1s, rem), d), R);
+          const uint8_t* sp8 = base + (long long)CB * (q0 + min(c, cend - 1));
+          float cr = 1.0f, ci = 0.0f;
+#pragma unroll 1
+          for (int j = 0; j < SPL; ++j) {
+            const int i = i0 + j;
+            const float x0 = (float)(signed char)sp8[2 * j];
+            const float x1 = (float)(signed char)sp8[2 * j + 1];
+            float a = Fmt<MODE>::swap ? x1 : x0, b = Fmt<MODE>::swap ? x0 : x1;
+            if ((unsigned int)i >= (unsigned int)Nq || !act) a = b = 0.0f;
+            const float yr = a * cr + b * ci;
+            const float yi = b * cr - a * ci;
+            const float ncr = cr * C[1] - ci * S[1], nci = cr * S[1] + ci * C[1];
+            cr = ncr;
+            ci = nci;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+              const double ax = (x == 0) ? aE : (x == 1) ? aP : aL;
+              const double bx = (x == 0) ? bE : (x == 1) ? bP : bL;
+              double t;
+              if (2 * i < Nq - 1)
+                t = __dadd_rn(ax, __dmul_rn((double)i, sp));
+              else if (2 * i > Nq - 1)
+                t = __dadd_rn(bx, -__dmul_rn((double)(Nq - 1 - i), sp));
+              else
+                t = __dadd_rn(ax, bx) / 2.0;
+              int kx = (int)ceil(__dmul_rn(t, M));
+              kx = max(-kGLO, min(kx, nmax + kGHI - 1));
+              const unsigned int e = table_word(kx);
+              const float cd = (float)(signed char)e, cp = (float)(signed char)(e >> 8);
+              Ur[0][x] = fmaf(cd, yr, Ur[0][x]);
+              Ui[0][x] = fmaf(cd, yi, Ui[0][x]);
+              Ur[1][x] = fmaf(cp, yr, Ur[1][x]);
+              Ui[1][x] = fmaf(cp, yi, Ui[1][x]);
+              // arm 2: entry k6 = ceil(6t) of the six-fold table = arm-1 entry (k6 + 5) / 6 times (-1)^(that + k6)
+              const int k6 = (int)fmin(fmax(ceil(__dmul_rn(t, M6)), 0.0), (double)(6 * (nmax - 2) + 1));
+              const int pidx = (int)(((float)(k6 + 5) + 0.5f) * 0.16666667f);
+              const float c1 = (float)(signed char)(table_word(pidx) >> 8);
+              const float c6 = ((pidx + k6) & 1) ? -c1 : c1;
+              Ur[2][x] = fmaf(c6, yr, Ur[2][x]);
+              Ui[2][x] = fmaf(c6, yi, Ui[2][x]);
+            }
+          }
+        } else {
+          // ---- the sample loop in two halves of eight: y, its running sums P and the three sign-modulated running sums P6, parked
+          // as they are formed; after each half every tap reads the rows its two transitions point at (row m & 7) and keeps the
+          // half's values whose m lies in it
+          float Tr = 0.f, Ti = 0.f, T6r[NS], T6i[NS];
+#pragma unroll
+          for (int sx = 0; sx < NS; ++sx) T6r[sx] = T6i[sx] = 0.f;
+          int mm[NS][2];
+#pragma unroll
+          for (int sx = 0; sx < NS; ++sx)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) mm[sx][n] = min((int)un[sx][n], SPL - 1);
+          float Q[NS][2][4];   // per tap and transition: P re, im, P6 re, im
+          auto half = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            static_for<0, kHalf>([&](auto jc) {
+              constexpr int r = decltype(jc)::value;
+              constexpr int j = h * kHalf + r;
+              if constexpr (r % 4 == 0 && r != 0) __builtin_amdgcn_sched_barrier(0);
+              float a, b;
+              sample_ab<MODE, j, NW>(w, a, b);
+              const float yr = fmaf(a, C[j], b * S[j]);
+              const float yi = fmaf(-a, S[j], b * C[j]);
+              Tr += yr;
+              Ti += yi;
+              park2<(kRow * r) * kW * 4, (kRow * r + 1) * kW * 4>(Tr, Ti, pfx_m0);
+              static_for<0, NS>([&](auto sc) {
+                constexpr int sx = decltype(sc)::value;
+                const float sg = __uint_as_float((w6[sx] & 0x80000000u) | 0x3f800000u);
+                T6r[sx] = fmaf(sg, yr, T6r[sx]);
+                T6i[sx] = fmaf(sg, yi, T6i[sx]);
+                park2<(kRow * r + 2 + 2 * sx) * kW * 4, (kRow * r + 3 + 2 * sx) * kW * 4>(T6r[sx], T6i[sx], pfx_m0);
+                w6[sx] += negD3;
+              });
+            });
+            static_for<0, NS>([&](auto sc) {
+              constexpr int sx = decltype(sc)::value;
+#pragma unroll
+              for (int n = 0; n < 2; ++n) {
+                const float* row = pfx + (kRow * (mm[sx][n] & (kHalf - 1))) * kW + lane;
+                const float v0 = row[0], v1 = row[kW], v2 = row[(2 + 2 * sx) * kW], v3 = row[(3 + 2 * sx) * kW];
+                if constexpr (h == 0) {
+                  Q[sx][n][0] = v0;
+                  Q[sx][n][1] = v1;
+                  Q[sx][n][2] = v2;
+                  Q[sx][n][3] = v3;
+                } else {
+                  const bool here = mm[sx][n] >= kHalf;
+                  Q[sx][n][0] = here ? v0 : Q[sx][n][0];
+                  Q[sx][n][1] = here ? v1 : Q[sx][n][1];
+                  Q[sx][n][2] = here ? v2 : Q[sx][n][2];
+                  Q[sx][n][3] = here ? v3 : Q[sx][n][3];
+                }
+              }
+            });
+          };
+          half(std::integral_constant<int, 0>{});
+          half(std::integral_constant<int, 1>{});
+          // ---- per tap: the three entries, the three arms ---------------------------------------------------------------------
+          static_for<0, NS>([&](auto sc) {
+            constexpr int sx = decltype(sc)::value;
+            float cd[3], cp[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+              const unsigned int e = table_word(kk[sx] + n);
+              cd[n] = cvt_byte<0>(e);
+              cp[n] = cvt_byte<1>(e);
+            }
+            // sum_n c_n (Q_n - Q_{n-1}) = (c_0 - c_1) Q_0 + (c_1 - c_2) Q_1 + c_2 T
+            const float ed0 = cd[0] - cd[1], ed1 = cd[1] - cd[2];
+            const float ep0 = cp[0] - cp[1], ep1 = cp[1] - cp[2];
+            Ur[0][sx] = fmaf(ed0, Q[sx][0][0], fmaf(ed1, Q[sx][1][0], cd[2] * Tr));
+            Ui[0][sx] = fmaf(ed0, Q[sx][0][1], fmaf(ed1, Q[sx][1][1], cd[2] * Ti));
+            Ur[1][sx] = fmaf(ep0, Q[sx][0][0], fmaf(ep1, Q[sx][1][0], cp[2] * Tr));
+            Ui[1][sx] = fmaf(ep0, Q[sx][0][1], fmaf(ep1, Q[sx][1][1], cp[2] * Ti));
+            // six-fold arm: coefficients c_n (-1)^(k0 + n): differences (-1)^k0 (c_0 + c_1), -(-1)^k0 (c_1 + c_2), last (-1)^k0 c_2
+            const float sig = __uint_as_float(((unsigned int)kk[sx] << 31) | 0x3f800000u);
+            const float e60 = sig * (cp[0] + cp[1]);
+            const float e61 = -sig * (cp[1] + cp[2]);
+            const float c62 = sig * cp[2];
+            Ur[2][sx] = fmaf(e60, Q[sx][0][2], fmaf(e61, Q[sx][1][2], c62 * T6r[sx]));
+            Ui[2][sx] = fmaf(e60, Q[sx][0][3], fmaf(e61, Q[sx][1][3], c62 * T6i[sx]));
+          });
+        }
+        // Horner step: acc = acc * conj(rho) + U
+#pragma unroll
+        for (int ar = 0; ar < 3; ++ar)
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
+            const float nr = fmaf(accr[ar][x], rotC, fmaf(-acci[ar][x], rotS, Ur[ar][x]));
+            const float ni = fmaf(accr[ar][x], rotS, fmaf(acci[ar][x], rotC, Ui[ar][x]));
+            accr[ar][x] = nr;
+            acci[ar][x] = ni;
+          }
+        // next chunk: t += 64*SPL*step*R*M, exactly
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx)
+          asm("v_sub_co_u32_e32 %0, vcc, %0, %3\n\tv_subb_co_u32_e32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32_e32 %2, vcc, %2, %5, vcc"
+              : "+v"(glo[sx]), "+v"(ghi[sx]), "+v"(kk[sx])
+              : "v"(Dlo), "v"(Dhi), "v"(Di)
+              : "vcc");
+      };
+
+      unsigned int wa[NW], wb[NW];
+      load_k(0, wa);
+      for (int k = 0;; k += 2) {
+        if (k + 1 < iters) load_k(k + 1, wb);
+        process(wa, k);
+        if (k + 1 >= iters) break;
+        if (k + 2 < iters) load_k(k + 2, wa);
+        process(wb, k + 1);
+        if (k + 2 >= iters) break;
+      }
+      const double ph = blk.rem_carr_phase * 0.15915494309189535 + (double)(i00 + (iters - 1) * (SPL * kW)) * tau;
+      sincospif(2.0f * (float)(ph - floor(ph)), &ws, &wc);
+    }
+
+    // ---- rotate into the absolute frame and reduce across the wavefront (DPP) ------------------------
+    double* o = p.out + lb * GC_OUT_STRIDE;
+    float tot[18];
+#pragma unroll
+    for (int ar = 0; ar < 3; ++ar)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        tot[ar * 6 + 2 * x] = wave_sum_lane63(wc * accr[ar][x] + ws * acci[ar][x]);
+        tot[ar * 6 + 2 * x + 1] = wave_sum_lane63(wc * acci[ar][x] - ws * accr[ar][x]);
+      }
+    if (lane == 63) {
+#pragma unroll
+      for (int v = 0; v < 18; ++v) o[v] = (double)tot[v];
+      for (int v = 18; v < GC_OUT_STRIDE; ++v) o[v] = 0.0;
+    }
+  }  // bpw loop
+}
+
+template <int MODE, int NWV>
+void launch_cboc_one(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
+  const void* fn = reinterpret_cast<const void*>(corr_epl_cboc_kernel<MODE, NWV>);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((corr_epl_cboc_kernel<MODE, NWV>), grid, dim3(NWV * kW), smem, ctx->stream, a);
+}
+
+template <int NWV>
+void launch_cboc_waves(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) {
+  if (ctx->if_layout == GC_QI) launch_cboc_one<I8_QI, NWV>(ctx, a, grid, smem);
+  else launch_cboc_one<I8_IQ, NWV>(ctx, a, grid, smem);
+}
+
+}  // namespace
+
+// Wavefronts per workgroup: the most of {4, 3, 2, 1} whose LDS (two interleaved int8 tables + 32 KB of running sums per wave)
+// fits a CU; 0 = not even one (GC_CBOC_WAVES overrides)
+int gc_cboc_waves(const gc_context* ctx) {
+  const int tb = gc_multi_table_bytes(ctx->max_stage_len, 2);
+  int forced = 0;
+  if (const char* e = std::getenv("GC_CBOC_WAVES")) forced = std::atoi(e);
+  for (int w : {8, 6, 4, 2, 1}) {
+    if (tb + w * kWaveLds > kMaxLds) continue;
+    if (forced == 0 || forced == w) return w;
+  }
+  return 0;
+}
+
+// Periodic replay lists of int8 I/Q (Q/I) records whose channels are three-arm channels with a derived six-fold arm
+// (gc_channel_is_derived), base ramp with at most two table transitions per 16-sample chunk; a.bpw = a multiple of `waves`,
+// a.stride = the list's period, a.splits == 1.
+int gc_launch_correlator_cboc(gc_context* ctx, const KArgs& a_in, unsigned int grid, int waves) {
+  KArgs a = a_in;
+  a.red_off = gc_multi_table_bytes(ctx->max_stage_len, 2);
+  const size_t smem = (size_t)a.red_off + (size_t)waves * kWaveLds;
+  if (waves == 8) launch_cboc_waves<8>(ctx, a, dim3(grid), smem);
+  else if (waves == 6) launch_cboc_waves<6>(ctx, a, dim3(grid), smem);
+  else if (waves == 4) launch_cboc_waves<4>(ctx, a, dim3(grid), smem);
+  else if (waves == 2) launch_cboc_waves<2>(ctx, a, dim3(grid), smem);
+  else launch_cboc_waves<1>(ctx, a, dim3(grid), smem);
+  GC_HIP(hipGetLastError());
+  return GC_OK;
+}

@@ -379,6 +379,9 @@ int gc_launch_correlator_lane(gc_context* ctx, const gcorr::KArgs& a, const gcor
 // corr_multi.hip
 int gc_multi_waves(const gc_context* ctx, int max_arms, long long nblocks, int period, int kt, bool share_el);
 int gc_launch_correlator_multi(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int max_arms, int kt, bool share_el, int waves);
+// corr_cboc.hip
+int gc_cboc_waves(const gc_context* ctx);
+int gc_launch_correlator_cboc(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int waves);
 // corr_fast.hip
 bool gc_fast_prefers_wide();  // compiled with the prefix-sum variant
 int gc_launch_devloop(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, bool spl16, bool share_el);

@@ -126,6 +126,10 @@ struct gc_context {
   // table transitions a 16-sample chunk of any block can see (2 or 4) - int8 tables of one ramp multiplier, no windows
   int scope_kt = 0;
   int replay_kt = 0;
+  // hybrid kernel (corr_cboc.hip): every channel of the scope has a derived six-fold arm and every block's base ramp sees at most
+  // this many (1 or 2) table transitions per 16-sample chunk; 0 = does not qualify
+  int scope_kt6 = 0;
+  int replay_kt6 = 0;
   int replay_min_blksize = 0;
 
   // scratch for gc_correlate / gc_track

@@ -623,12 +623,14 @@ int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps) 
   return x == kNone ? -1 : (int64_t)x;
 }
 
-// Marks tie-free blocks (bit 0 of `reserved`) for a launch whose kernel needs the band `eps_chips`.
+// Marks tie-free blocks for a launch whose kernel needs the band `eps_chips`: bit 0 of `reserved` = no sample of any ramp within the
+// band of a table edge (the kernels skip their near-tie tests); bit 1 (channels with a derived six-fold arm) = no sample within the
+// six-fold ramps' own narrow band of a sub-entry edge, whatever the base ramps do (corr_cboc.hip skips its per-sample integer test).
 void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps) {
-  static const bool off = std::getenv("GC_NO_TIE_MARK") != nullptr;  // debugging aid: every block takes the in-kernel test
+  const bool off = std::getenv("GC_NO_TIE_MARK") != nullptr;  // debugging aid: every block takes the in-kernel tests
   for (int64_t i = 0; i < n; ++i) {
     gc_block& k = b[i];
-    k.reserved &= ~1;
+    k.reserved &= ~3;
     if (off) continue;
     const HostChannel& c = ctx->ch[k.channel];
     if (c.mult[0] != 1.0) continue;
@@ -650,6 +652,9 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
     for (int t = 0; t < 3 && clean; ++t) clean = gc_first_sample_near_edge(starts[t], sp, k.blksize, eps) < 0;
     // the derived arm's sub-entry comes out of the base ramp's fraction times mult[2]: so does that ramp's rounding (gc_tie_window_units6)
     const double eps6 = (gcorr::gc_tie_window_units6(maxv, k.blksize / 64 + 2, m6) + 3.0 * m6) / 4294967296.0;
+    bool clean6 = m6 != 0.0;
+    for (int t = 0; t < 3 && clean6; ++t) clean6 = gc_first_sample_near_edge(starts[t] * m6, sp * m6, k.blksize, eps6) < 0;
+    if (clean6) k.reserved |= 2;
     for (int t = 0; t < 3 && clean && m6 != 0.0; ++t) clean = gc_first_sample_near_edge(starts[t] * m6, sp * m6, k.blksize, std::max(eps, eps6)) < 0;
     if (clean) k.reserved |= 1;
   }
@@ -790,7 +795,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
   bool seen[GC_MAX_CHANNELS] = {false};
   gc_scope_reset(ctx);
   ctx->scope_share_lane = true;
-  int kt = 1;
+  int kt = 1, kt6 = 1;
   for (int64_t i = 0; i < n; ++i) {
     const gc_block& k = b[i];
     if (k.channel < 0 || k.channel >= GC_MAX_CHANNELS || !ctx->ch[k.channel].configured) {
@@ -849,6 +854,12 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
       const int need = plain ? gc_block_multi_kt(ctx, k) : 0;
       kt = need == 0 ? 0 : std::max(kt, need);
     }
+    if (kt6 > 0) {  // corr_cboc.hip: whole tables, derived third arm, base ramp with at most two transitions per chunk
+      bool der = c.arms == 3 && gc_channel_is_derived(c);
+      for (int a = 0; a < c.arms; ++a) der = der && k.table_offset[a] == 0;
+      const int need = der ? gc_block_multi_kt(ctx, k) : 0;
+      kt6 = (need == 0 || need > 2) ? 0 : std::max(kt6, need);
+    }
     if (*all_lowrate >= 0) *all_lowrate = std::min(*all_lowrate, gc_block_lowrate_level(ctx, k));
     if (all_share && !gc_block_shares_el(ctx, k)) *all_share = false;
     if (ctx->scope_share_lane && !gc_block_shares_el_lane(ctx, k)) ctx->scope_share_lane = false;
@@ -857,6 +868,7 @@ static int validate_blocks(gc_context* ctx, int64_t n, const gc_block* b, int* a
   // mixed ramp multipliers: the exact per-sample kernel (-1), unless every such channel's odd arm can be derived from its
   // neighbour (BOC(6,1) from BOC(1,1)) and the record is int8 I/Q: then the lane kernel's derived-arm instantiation (0)
   ctx->scope_kt = (kt >= 2 && ctx->if_layout != GC_REAL && !any_derived && !any_plain_mixed) ? kt : 0;
+  ctx->scope_kt6 = (any_derived && !any_plain_mixed && !any_three_plain && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL) ? kt6 : 0;
   if (any_plain_mixed || (any_derived && (any_three_plain || ctx->if_dtype != GC_I8 || ctx->if_layout == GC_REAL))) {
     *all_lowrate = -1;
   } else if (any_derived) {
@@ -958,6 +970,7 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   ctx->replay_scope[2] = ctx->max_arms_configured;
   ctx->replay_share_lane = ctx->scope_share_lane;
   ctx->replay_kt = ctx->scope_kt;
+  ctx->replay_kt6 = ctx->scope_kt6;
   ctx->replay_derived = ctx->launch_derived;
   ctx->replay_fast = lowrate < 0 ? -1 : (gc_fast_lds_ok(ctx) && !ctx->force_generic) ? lowrate : 0;
   GC_HIP(hipStreamSynchronize(ctx->stream));
@@ -974,7 +987,7 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   {
     std::vector<gc_block> marked(blocks, blocks + nblocks);
     // the band the kernel that may take the list tests in: 8e-6 samples of ramp = twice the 4e-6 of corr_fast.hip and corr_multi.hip
-    gc_mark_tie_free(ctx, marked.data(), nblocks, (ctx->replay_kt > 0 || ctx->replay_fast > 0) ? 8e-6 : 0.0);
+    gc_mark_tie_free(ctx, marked.data(), nblocks, (ctx->replay_kt > 0 || ctx->replay_kt6 > 0 || ctx->replay_fast > 0) ? 8e-6 : 0.0);
     GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, marked.data(), sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
   }
@@ -1011,6 +1024,7 @@ int gc_replay_launch(gc_context* ctx) {
   ctx->max_arms_configured = ctx->replay_scope[2];
   ctx->scope_share_lane = ctx->replay_share_lane;
   ctx->scope_kt = ctx->replay_kt;
+  ctx->scope_kt6 = ctx->replay_kt6;
   ctx->launch_derived = ctx->replay_derived;
   int splits = 1;
   if (ctx->replay_fast == 0) {

@@ -412,6 +412,31 @@ class Engine:
                                               rmax.ctypes.data_as(C.POINTER(C.c_float)), rarg.ctypes.data_as(C.POINTER(C.c_int32))))
         return rmax, rarg
 
+    def acq_shift_search_batch(self, codes: np.ndarray, arm_weight, rule: int, exclude: int = 0, period: int = 1, sample_index=None):
+        """gc_acq_shift_search_batch: codes int8 [nprn, narms, n] (sampled replicas) or, with sample_index (0-based, one vector for all
+        codes), [nprn, narms, chips] -> ctypes array of gc_acq_shift_pick [nprn], or None when the library answers GC_E_UNSUPPORTED
+        (block lengths without specialised passes: the caller searches PRN by PRN)."""
+        p = self._shift
+        c8 = np.ascontiguousarray(codes, dtype=np.int8)
+        nprn, narms = c8.shape[0], c8.shape[1]
+        rows = p.n_carriers * p.n_signals * p.n_bins
+        picks = (L.gc_acq_shift_pick * nprn)()
+        w = None
+        if arm_weight is not None:
+            w = (C.c_double * narms)(*[float(v) for v in arm_weight])
+        idx, nidx = None, 0
+        if sample_index is not None:
+            i32 = np.ascontiguousarray(sample_index, dtype=np.int32)
+            idx, nidx = i32.ctypes.data_as(C.c_void_p), int(i32.shape[0])
+        rc = self._lib.gc_acq_shift_search_batch(self._ctx, nprn, narms, c8.ctypes.data_as(C.c_void_p), int(c8.shape[2]), idx, nidx, w, int(rule),
+                                                 int(exclude), int(period), picks)
+        if rc == L.GC_E_UNSUPPORTED:
+            return None
+        L.check(rc)
+        self._count_transforms(int(p.n), code=nprn * narms,
+                               inverse=nprn * narms * rows + (narms * sum(1 for k in picks if k.row >= 0) if rule != L.GC_SHIFT_PICK_GLOBAL else 0))
+        return picks
+
     def acq_shift_row(self, row: int) -> np.ndarray:
         out = np.empty(self._shift.n, dtype=np.float32)
         L.check(self._lib.gc_acq_shift_row(self._ctx, int(row), out.ctypes.data_as(C.POINTER(C.c_float))))

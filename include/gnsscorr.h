@@ -463,6 +463,31 @@ int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* p);
 int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
                         float* row_max, int32_t* row_argmax);
 int gc_acq_shift_row(gc_context* ctx, int row, float* out /* n floats */);
+/* A package's whole search in ONE call (replaces the PRN loops BDS/B1I/include/acquisition.m:76-176, GPS/GPS_L2C/include/
+ * acquisition.m:40-118, BDS/B1C/include/acquisition.m:170-235 up to the threshold test): codes int8 [nprn][narms][n] go up once, every
+ * PRN's transforms are queued back to back, the row maxima of all PRNs come back in one copy, the package's selection rule picks each
+ * PRN's row, and - rules with a second peak - the winning rows are transformed again and reduced on the device to
+ * {first maximum, second peak}: two read-backs per search instead of two per PRN, no row of n floats crosses the bus.
+ *   GC_SHIFT_PICK_GLOBAL            row of the largest row maximum, first column holding it (B1C :193-197); no second peak
+ *   GC_SHIFT_PICK_SEQUENTIAL        the sequential rule over (carrier, bin) of GPS_L2C :46-66 (n_signals == 1)
+ *   GC_SHIFT_PICK_SEQUENTIAL_PAIRS  the same over the larger of the two signal blocks' maxima, BDS/B1I :87-122 (n_signals == 2)
+ * codes: sample_index == NULL: int8 [nprn][narms][n], the local replicas sampled and zero-padded by the caller as for
+ * gc_acq_shift_search (code_len, n_index ignored).  Otherwise int8 [nprn][narms][code_len] chip tables and ONE 0-based index vector
+ * for all of them: replica(k) = chips(sample_index[k]) for k < n_index, 0 for n_index <= k < n - the make*Table.m gather
+ * (ceil(ts*k/tc) depends on the rates only: makeCaTableDMA.m, makeCMTable.m, makeDataTable.m) and the [table zeros] padding done on
+ * the device: a few KB per code cross the bus instead of n bytes.
+ * second_peak: the largest value among the row's first `period` samples at least `exclude` samples away from the peak, with the
+ * reference's three range cases (B1I :141-156, L2C :77-91).  GC_E_UNSUPPORTED when the prepared block length has no specialised pass
+ * kernels (16.368-Msps front ends, GC_ACQ_GENERIC): search PRN by PRN with gc_acq_shift_search / gc_acq_shift_row then. */
+enum { GC_SHIFT_PICK_GLOBAL = 0, GC_SHIFT_PICK_SEQUENTIAL = 1, GC_SHIFT_PICK_SEQUENTIAL_PAIRS = 2 };
+typedef struct gc_acq_shift_pick {
+  int32_t row;          /* winning row, -1: no value above 0 (the reference leaves the PRN's results at 0) */
+  int32_t code_phase;   /* 0-based position of the row's first maximum */
+  float peak;           /* its value */
+  float second_peak;    /* 0 with GC_SHIFT_PICK_GLOBAL */
+} gc_acq_shift_pick;
+int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, const int8_t* codes, int code_len, const int32_t* sample_index,
+                              int n_index, const double* arm_weight, int rule, int exclude, int period, gc_acq_shift_pick* out /* [nprn] */);
 /* What the prepared search writes: samples per row (n), rows of gc_acq_shift_search's outputs (n_carriers * n_signals *
  * n_bins) and the largest narms it takes - for callers that size their buffers (the MEX gateway); any pointer may be NULL. */
 int gc_acq_shift_dims(gc_context* ctx, int32_t* n, int32_t* rows, int32_t* n_arms_max);

@@ -285,3 +285,78 @@ def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine,
         raw = O.raw_from_if(iq, d_["s0"], d_["n"], swap_iq=cfg["layout"] == "qi")
         ref, _, _ = O.correlate_block(raw, tabs[d_["channel"]], d_["rem"], d_["step"], d_["d"], d_["f"], d_["phi"], fs, L, r=R)
         assert np.max(np.abs(got[k, :arms] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :arms] - ref)) / scale[k])
+
+
+@pytest.mark.parametrize("case", ["e1_cboc", "e1_cboc_qi", "b1c_wb"])
+def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, monkeypatch, case):
+    """corr_cboc.hip: periodic replay lists of three-arm channels whose third arm is the six-fold replica of the second (Galileo E1-C
+    CBOC as BASELINE config 3 words it; BDS/B1C/include/WB_tracking.m:285-317,338-369): the BOC(1,1) arms through the transition
+    formulation, the BOC(6,1) arm as a per-sample sign on the carrier-wiped samples.  The same list through the lane kernel's
+    derived-arm instantiation (GC_NO_CBOC=1) and, block by block, through the float64 oracle (every index from ceil(t) / ceil(6 t));
+    blocks that start on exact chip edges with the nominal rational step (tie-dense: sample 0 sits on an edge of all three tables of
+    the prompt tap) included, and the whole list once more with no block marked tie-free (GC_NO_TIE_MARK: every chunk takes the
+    in-kernel tests)."""
+    cfg = {"e1_cboc": dict(fs=18e6, L=4092, rate=1.023e6, d=0.05, layout="iq"),
+           "e1_cboc_qi": dict(fs=18e6, L=4092, rate=1.023e6, d=0.05, layout="qi"),
+           "b1c_wb": dict(fs=18e6, L=10230, rate=1.023e6, d=0.06, layout="iq")}[case]
+    from cu_sdr_collection_amd import _lib as LIB
+    fs, L, R = cfg["fs"], float(cfg["L"]), 2.0
+    rng = np.random.default_rng(abs(hash(case)) % 1000 + 23)
+    period = 3
+    cus = engine.device_info()[1]
+    epochs = (8 * cus + period - 1) // period + 5              # >= 8 blocks per CU: the replay launcher does not split the blocks
+    step0 = cfg["rate"] / fs
+    nmax = int(np.ceil(L / (step0 * (1 - 3e-5)))) + 2
+    n_if = 6 * nmax
+    iq = _noise_iq(n_if, 79)
+    layout = LIB.GC_QI if cfg["layout"] == "qi" else LIB.GC_IQ
+    engine.load_if(iq, layout=layout, fs=fs)
+    tabs = {}
+    for c in range(period):
+        data = rng.choice([-1.0, 1.0], size=int(L))
+        pilot = rng.choice([-1.0, 1.0], size=int(L))
+        boc11 = lambda x: (x[:, None] * np.array([1.0, -1.0])[None, :]).reshape(-1)
+        boc61 = (pilot[:, None] * np.tile(np.array([1.0, -1.0]), 6)[None, :]).reshape(-1)
+        tabs[c] = [O.pad_code(boc11(data)), O.pad_code(boc11(pilot)), O.pad_code(boc61)]
+        engine.set_channel(c, [t.astype(np.int8) for t in tabs[c]], index_scale=R, arm_mult=[1, 1, 6])
+    nb = period * epochs
+    b = engine.make_blocks(nb)
+    descs = []
+    for k in range(nb):
+        tie = k < period or k % 97 == 0
+        step = step0 if tie else step0 * (1 + float(rng.uniform(-3e-5, 3e-5)))
+        rem = 0.0 if tie else float(rng.uniform(0, step))
+        n = O.blksize_for(L, rem, step)
+        dsc = dict(channel=k % period, n=n, s0=int(rng.integers(0, n_if - n)), rem=rem, step=step, d=cfg["d"],
+                   f=float(rng.uniform(-2.5e4, 2.5e4)), phi=float(rng.uniform(-3, 3)))
+        descs.append(dsc)
+        _block(b, k, **dsc)
+    monkeypatch.setenv("GC_CBOC", "1")                         # opt-in: the kernel measured slower than the lane kernel (DESIGN.md 4.2c)
+    engine.replay_prepare(b)
+    engine.replay_launch()
+    got = engine.replay_fetch().copy()
+    assert engine.last_kernel() == 5, engine.last_kernel()
+    monkeypatch.delenv("GC_CBOC")
+    engine.replay_launch()
+    other = engine.replay_fetch().copy()
+    assert engine.last_kernel() == 0
+    monkeypatch.setenv("GC_CBOC", "1")
+    raw_all = iq.astype(np.float64)
+    scale = np.array([np.sum(np.abs(raw_all[2 * d_["s0"]:2 * (d_["s0"] + d_["n"])])) for d_ in descs])
+    dev = np.max(np.abs(got - other).reshape(nb, -1), axis=1) / scale
+    assert dev.max() < 2 * TOL, (case, int(np.argmax(dev)), dev.max())
+    checked = list(range(period)) + [97, 194, nb - 1, nb // 2, nb // 3]
+    for k in checked:
+        d_ = descs[k]
+        raw = O.raw_from_if(iq, d_["s0"], d_["n"], swap_iq=cfg["layout"] == "qi")
+        ref, _, _ = O.correlate_block(raw, tabs[d_["channel"]], d_["rem"], d_["step"], d_["d"], d_["f"], d_["phi"], fs, L, r=R,
+                                      arm_mult=[1.0, 1.0, 6.0])
+        assert np.max(np.abs(got[k, :3] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :3] - ref)) / scale[k])
+    # no host marks: every chunk runs the float position test and the integer test of the six-fold edges
+    monkeypatch.setenv("GC_NO_TIE_MARK", "1")
+    engine.replay_prepare(b)
+    engine.replay_launch()
+    unmarked = engine.replay_fetch().copy()
+    assert engine.last_kernel() == 5
+    dev = np.max(np.abs(got - unmarked).reshape(nb, -1), axis=1) / scale
+    assert dev.max() < 2 * TOL, (case, int(np.argmax(dev)), dev.max())
