@@ -2137,6 +2137,7 @@ struct AcqScratch {
   int shift_rows = 0;
   // gc_acq_shift_search_batch: every PRN's codes, code spectra, row maxima, the winning rows and the picks of one search
   GcBuf b_codes, b_chips, b_codespec, b_rowmax, b_rowarg, b_rows, b_pick;
+  int shift_slot_lanes = 1;   // lanes of the batch call under way: launch_abs_pass gives each its own region of row-candidate slots
   unsigned long long* peaks = nullptr;  // per-PRN peak keys of gc_acquire_coarse_multi
   int peaks_cap = 0;
   unsigned long long* slots = nullptr;  // per-workgroup peak candidates of abs_combine_kernel, one region per PRN
@@ -2216,7 +2217,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
     if (rows_fused && c1 > 0 && a.hop_groups <= 1 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_ROWMAX_KERNEL")) {
       // circshift search, last arm: per-workgroup candidates (tiles of one row each) instead of the sums themselves
       const int tiles_ct = a.nvec / c1;
-      const size_t want = (size_t)nbins_total * tiles_ct * 2;
+      const size_t want = (size_t)nbins_total * tiles_ct * 2 * (size_t)std::max(1, s->shift_slot_lanes);  // (gc_acq_shift_search_batch: a region per lane)
       if (s->slots_cap < want) {
         GC_HIP(hipDeviceSynchronize());
         if (s->slots) (void)hipFree(s->slots);
@@ -2227,7 +2228,8 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
         GC_HIP(hipDeviceSynchronize());
         s->slots_cap = want;
       }
-      a.peak_slots = s->slots + (size_t)bin0 * tiles_ct * 2;
+      unsigned long long* const region = s->slots + (size_t)s->lane * (size_t)nbins_total * tiles_ct * 2 * (s->shift_slot_lanes > 1 ? 1 : 0);
+      a.peak_slots = region + (size_t)bin0 * tiles_ct * 2;
       a.peak_valid = valid;
       a.batch0 = bin0;
       bool used_ct = false;
@@ -2236,7 +2238,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
       a.batch0 = 0;
       if (rc) return rc;
       if (used_ct) {
-        hipLaunchKernelGGL(rowkeys_reduce_kernel, dim3((unsigned int)nbins), dim3(64), 0, ctx->stream, s->slots + (size_t)bin0 * tiles_ct * 2, tiles_ct,
+        hipLaunchKernelGGL(rowkeys_reduce_kernel, dim3((unsigned int)nbins), dim3(64), 0, ctx->stream, region + (size_t)bin0 * tiles_ct * 2, tiles_ct,
                            s->rowmax + bin0, s->rowarg + bin0);
         GC_HIP(hipGetLastError());
         *rows_fused = true;
@@ -3215,7 +3217,8 @@ static int shift_read_back(gc_context* ctx, AcqScratch* s, void* dst0, const voi
 // The inverse side of ONE PRN of a circshift search: rows pass (shifted product with the PRN's code spectra `codespec`, narms x N) and
 // columns pass for every chunk of rows, the row maxima into s->rowmax / s->rowarg (specialised passes: *all_fused, the sums
 // themselves are not written; otherwise they are in s->results and the caller runs rowmax_kernel).
-static int shift_search_passes(gc_context* ctx, AcqScratch* s, int narms, const float2* codespec, const double* arm_weight, bool* all_fused_out) {
+static int shift_search_passes(gc_context* ctx, AcqScratch* s, int narms, const float2* codespec, const double* arm_weight, bool* all_fused_out,
+                               float2* tmpbuf) {
   const gc_acq_shift_params& p = s->shift;
   const Plan& pl = s->plan;
   const int rows = p.n_carriers * p.n_signals * p.n_bins;
@@ -3246,7 +3249,7 @@ static int shift_search_passes(gc_context* ctx, AcqScratch* s, int narms, const 
   for (int r0 = 0; r0 < rows; r0 += chunk_rows)
   for (int arm = 0; arm < (merge_arms ? 1 : narms); ++arm) {  // (separate arms of a chunk after one another: the second one adds to sums the first one just wrote)
     const int rc_rows = std::min(chunk_rows, rows - r0);
-    float2* const tmp = s->tmp - (size_t)r0 * marms * (size_t)pl.n;  // (a chunk's batches keep their numbers; its first one sits at the start of the buffer)
+    float2* const tmp = tmpbuf - (size_t)r0 * marms * (size_t)pl.n;  // (a chunk's batches keep their numbers; its first one sits at the start of the buffer)
     PassArgs a = base;
     a.n = pl.n;
     a.tw = s->tw;
@@ -3323,7 +3326,7 @@ extern "C" int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* cod
   int rc = forward(ctx, s, base, PRE_CODE, narms, s->codespec);
   if (rc) return rc;
   bool all_fused = true;
-  rc = shift_search_passes(ctx, s, narms, s->codespec, arm_weight, &all_fused);
+  rc = shift_search_passes(ctx, s, narms, s->codespec, arm_weight, &all_fused, s->tmp);
   if (rc) return rc;
   s->shift_rows_fused = all_fused;
   s->shift_narms = narms;
@@ -3433,16 +3436,16 @@ namespace {
 // row's first `period` samples outside +-exclude samples of it - the reference's three range cases (B1I :141-156, L2C :77-91;
 // 1-based there: e1 = codePhase - exclude, e2 = codePhase + exclude; e1 < 2: e2 .. period + e1; e2 >= period: e2 - period + 1 .. e1;
 // else 1 .. e1 and e2 .. period).
-__global__ __launch_bounds__(256) void shift_pick_kernel(const float* __restrict__ rows, long long row_stride, int n, int exclude, int period,
+__global__ __launch_bounds__(1024) void shift_pick_kernel(const float* __restrict__ rows, long long row_stride, int n, int exclude, int period,
                                                          gc_acq_shift_pick* __restrict__ picks) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
+  __shared__ float sv[1024];
+  __shared__ int si[1024];
   gc_acq_shift_pick& pk = picks[blockIdx.x];
   if (pk.row < 0) return;
   const float* __restrict__ r = rows + (size_t)blockIdx.x * (size_t)row_stride;
   float best = -1.0f;
   int bi = 0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
     const float v = r[i];
     if (v > best) {
       best = v;
@@ -3452,7 +3455,7 @@ __global__ __launch_bounds__(256) void shift_pick_kernel(const float* __restrict
   sv[threadIdx.x] = best;
   si[threadIdx.x] = bi;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 512; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) {
       const float v = sv[threadIdx.x + off];
       const int i = si[threadIdx.x + off];
@@ -3481,13 +3484,13 @@ __global__ __launch_bounds__(256) void shift_pick_kernel(const float* __restrict
     hi1 = period;
   }
   float second = -1.0f;
-  for (int i = lo0 - 1 + (int)threadIdx.x; i < hi0 && i < n; i += 256)
+  for (int i = lo0 - 1 + (int)threadIdx.x; i < hi0 && i < n; i += 1024)
     if (i >= 0) second = fmaxf(second, r[i]);
-  for (int i = lo1 - 1 + (int)threadIdx.x; i < hi1 && i < n; i += 256)
+  for (int i = lo1 - 1 + (int)threadIdx.x; i < hi1 && i < n; i += 1024)
     if (i >= 0) second = fmaxf(second, r[i]);
   sv[threadIdx.x] = second;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 512; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + off]);
     __syncthreads();
   }
@@ -3608,19 +3611,61 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
       if (rc) return rc;
     }
   }
-  // phase 1: every PRN's rows and columns passes, its row maxima into its own slot - nothing comes back in between
+  // phase 1: every PRN's rows and columns passes, its row maxima into its own slot - nothing comes back in between.  Two lanes where a
+  // PRN's intermediate is small (BDS B1I: 62 PRNs x 0.17 ms of launches that each leave a tail of half-empty CUs - 5.8 -> 5.1 ms): even
+  // PRNs on one stream of the device's search pair, odd PRNs on the other with an intermediate buffer and candidate slots of their own.
+  // With gigabyte intermediates the two lanes only share the memory system they both wait for (GPS L2C 65.0 -> 66.2 ms, BDS B1C
+  // 65.1 -> 64.1): one lane there.  GC_ACQ_SHIFT_LANES=1 / 2 overrides.
+  int lanes = (nprn > 1 && (size_t)rows * N * sizeof(float2) <= ((size_t)256 << 20)) ? 2 : 1;
+  if (const char* e = std::getenv("GC_ACQ_SHIFT_LANES")) lanes = std::max(1, std::min(2, std::atoi(e)));
+  if (nprn < 2) lanes = 1;
+  AcqStreams* const shared = lanes == 2 ? acq_streams(ctx->device) : nullptr;
+  if (!shared) lanes = 1;
+  if (lanes == 2 && !s->ev_fork &&
+      (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) != hipSuccess))
+    lanes = 1;
+  if (lanes == 2 && !s->tmp2 && hipMalloc((void**)&s->tmp2, (size_t)s->nbh * N * sizeof(float2)) != hipSuccess) {
+    (void)hipGetLastError();
+    s->tmp2 = nullptr;
+    lanes = 1;  // no room for a second intermediate
+  }
+  hipStream_t const stream1 = ctx->stream;
+  hipStream_t lane_stream[2] = {stream1, stream1};
+  if (lanes == 2) {
+    lane_stream[0] = shared->main;
+    lane_stream[1] = shared->lane;
+    GC_HIP(hipEventRecord(s->ev_fork, stream1));  // signal spectra (gc_acq_shift_prepare) and code spectra are ready
+    for (hipStream_t ls : lane_stream) GC_HIP(hipStreamWaitEvent(ls, s->ev_fork, 0));
+  }
   float* const save_max = s->rowmax;
   int* const save_arg = s->rowarg;
   int rc = GC_OK;
   bool fused = true;
+  s->shift_slot_lanes = lanes;
   for (int k = 0; k < nprn && rc == GC_OK && fused; ++k) {
+    s->lane = lanes == 2 ? (k & 1) : 0;
+    ctx->stream = lane_stream[s->lane];
     s->rowmax = (float*)s->b_rowmax.p + (size_t)k * rows;
     s->rowarg = (int*)s->b_rowarg.p + (size_t)k * rows;
-    rc = shift_search_passes(ctx, s, narms, cspec + (size_t)k * narms * N, arm_weight, &fused);
+    rc = shift_search_passes(ctx, s, narms, cspec + (size_t)k * narms * N, arm_weight, &fused, s->lane ? s->tmp2 : s->tmp);
   }
+  ctx->stream = stream1;
+  s->lane = 0;
+  s->shift_slot_lanes = 1;
   s->rowmax = save_max;
   s->rowarg = save_arg;
-  if (rc) return rc;
+  if (lanes == 2) {  // the lanes join the caller's stream (also on an error: nothing may still run on them)
+    hipEvent_t const ej[2] = {s->ev_join, s->ev_join2};
+    for (int k = 0; k < 2; ++k) {
+      (void)hipEventRecord(ej[k], lane_stream[k]);
+      (void)hipStreamWaitEvent(stream1, ej[k], 0);
+    }
+  }
+  if (rc) {
+    (void)hipDeviceSynchronize();
+    return rc;
+  }
   if (!fused) {
     gc_set_error("gc_acq_shift_search_batch: the passes did not run on the specialised kernels - search PRN by PRN");
     return GC_E_UNSUPPORTED;
@@ -3667,7 +3712,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
     rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, arm_weight ? arm_weight : ones, dst);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(shift_pick_kernel, dim3((unsigned int)nprn), dim3(256), 0, ctx->stream, (const float*)s->b_rows.p, (long long)N, p.n, exclude,
+  hipLaunchKernelGGL(shift_pick_kernel, dim3((unsigned int)nprn), dim3(1024), 0, ctx->stream, (const float*)s->b_rows.p, (long long)N, p.n, exclude,
                      period, (gc_acq_shift_pick*)s->b_pick.p);
   GC_HIP(hipGetLastError());
   return shift_read_back(ctx, s, out, s->b_pick.p, (size_t)nprn * sizeof(gc_acq_shift_pick));

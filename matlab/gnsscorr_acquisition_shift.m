@@ -4,9 +4,11 @@ function acqResults = gnsscorr_acquisition_shift(longSignal, settings, name)
 %   Same arguments and result as the package's include/acquisition.m (resampling off), so postProcessing.m:100 is called
 %   unchanged.  The GPU mixes the signal block(s) with the package's carriers and transforms them once ('acq_shift_prepare'),
 %   then forms every bin of a PRN as a shifted product with the code spectrum inside the inverse transform and returns each
-%   result row's maximum and its first position ('acq_shift_search'); the packages' selection rules (which row wins, the
-%   second-peak exclusion range, thresholds, the CL segment search, B1C's 25-Hz fine search) are a few hundred operations on
-%   those maxima and on the one winning row ('acq_shift_row') and stay here.
+%   result row's maximum.  A package's whole PRN list is ONE call ('acq_shift_search_batch': chip tables and the one index vector
+%   that samples them go up, the row selection rule, the first maximum of the winning row and the second peak come back as four
+%   numbers per PRN); thresholds, the CL segment search and B1C's 25-Hz fine search stay here.  Block lengths the transforms have
+%   no specialised passes for (and settings.gnsscorrPerPRN) search PRN by PRN: 'acq_shift_search' returns the row maxima,
+%   'acq_shift_row' the one winning row, and the selection rules run here.
 %   Written for this repository; not a copy of any reference file.
 
 [h, src, hasRecord] = gnsscorr_upload(longSignal, settings);
@@ -33,6 +35,20 @@ idx = ceil(ts * k / tc);
 if firstOne, idx(1) = 1; end
 if last > 0, idx(end) = last; end
 t = code(idx);
+end
+
+function idx = sampleIndex(k, ts, tc, last, firstOne)
+% the index vector of sampled(): it depends on the rates only, one vector serves every PRN's code
+idx = ceil(ts * k / tc);
+if firstOne, idx(1) = 1; end
+if last > 0, idx(end) = last; end
+end
+
+function picks = batched(h, chips, idx, w, rule, exclude, period, narms)
+% the whole PRN list in one call: chips (one column per PRN and arm) and the one index vector go up, the row selection, the
+% first maximum of the winning row and the second peak happen in the library; [] = search PRN by PRN (no specialised transform
+% for this block length, or settings.gnsscorrPerPRN set)
+picks = gnsscorr_mex('acq_shift_search_batch', h, int8(chips), int32(idx - 1), w, rule, exclude, period, narms);
 end
 
 function s = secondPeak(corr, codePhase, exclude, period)
@@ -102,16 +118,34 @@ q.samplesPerBlock = spb;  q.nSignals = 2;  q.nCarriers = nShifts;  q.nBins = nBi
 nRows = gnsscorr_mex('acq_shift_prepare', h, q);
 acqResults.carrFreq = zeros(1, 58);  acqResults.codePhase = zeros(1, 58);  acqResults.peakMetric = zeros(1, 58);
 chip = round(fs / settings.codeFreqBasis);                                                  % :139
-for PRN = settings.acqSatelliteList
-    ca = generateCAcode53(PRN);
-    table = sampled([ca ca], 1:spc2, ts, 1 / settings.codeFreqBasis, Ncodes * 2046, false);
-    local = [table, zeros(1, spb / Ncodes)];                                                % :86
-    rmax = double(gnsscorr_mex('acq_shift_search', h, int8(local(:)), [], nRows));
-    [best, freqShift, binIdx] = sequentialBest(rmax, nShifts, 2, nBins);
-    if isempty(best), continue; end
-    corr = double(gnsscorr_mex('acq_shift_row', h, ((best(1) - 1) * 2 + best(2) - 1) * nBins + best(3) - 1, spb));
-    [maxPeak, codePhase] = max(corr);                                                       % :126
-    second = secondPeak(corr, codePhase, chip, spb / Nblocks);
+prns = settings.acqSatelliteList;
+picks = [];
+if ~isfield(settings, 'gnsscorrPerPRN')
+    chips = zeros(2 * 2046, numel(prns));
+    for k = 1:numel(prns)
+        ca = generateCAcode53(prns(k));
+        chips(:, k) = [ca ca].';
+    end
+    picks = batched(h, chips, sampleIndex(1:spc2, ts, 1 / settings.codeFreqBasis, Ncodes * 2046, false), [], 2, chip, spb / Nblocks, 1);
+end
+for k = 1:numel(prns)
+    PRN = prns(k);
+    if ~isempty(picks)
+        % :87-122 (which (carrier, block, bin) wins), :126 and :141-156 inside the call
+        if picks(1, k) < 0, continue; end
+        row = picks(1, k);  codePhase = picks(2, k) + 1;  maxPeak = picks(3, k);  second = picks(4, k);
+        freqShift = floor(row / (2 * nBins)) + 1;  binIdx = rem(row, nBins) + 1;
+    else
+        ca = generateCAcode53(PRN);
+        table = sampled([ca ca], 1:spc2, ts, 1 / settings.codeFreqBasis, Ncodes * 2046, false);
+        local = [table, zeros(1, spb / Ncodes)];                                            % :86
+        rmax = double(gnsscorr_mex('acq_shift_search', h, int8(local(:)), [], nRows));
+        [best, freqShift, binIdx] = sequentialBest(rmax, nShifts, 2, nBins);
+        if isempty(best), continue; end
+        corr = double(gnsscorr_mex('acq_shift_row', h, ((best(1) - 1) * 2 + best(2) - 1) * nBins + best(3) - 1, spb));
+        [maxPeak, codePhase] = max(corr);                                                   % :126
+        second = secondPeak(corr, codePhase, chip, spb / Nblocks);
+    end
     acqResults.peakMetric(PRN) = maxPeak / second;                                          % :160
     if maxPeak / second > settings.acqThreshold                                             % :163
         acqResults.codePhase(PRN) = codePhase;
@@ -137,16 +171,34 @@ q.samplesPerBlock = spb;  q.nSignals = 1;  q.nCarriers = nShifts;  q.nBins = nBi
 nRows = gnsscorr_mex('acq_shift_prepare', h, q);
 acqResults.carrFreq = zeros(1, 32);  acqResults.codePhase = zeros(1, 32);  acqResults.peakMetric = zeros(1, 32);
 tc = 1 / (settings.codeFreqBasis * 2);
-for PRN = settings.acqSatelliteList
-    cm = generateCMcode(PRN, settings);
-    table = sampled(cm, 0:spc - 1, ts, tc, settings.codeLength * 2, true);                  % makeCMTable.m
-    local = [table, zeros(1, spc)];                                                         % :44
-    rmax = double(gnsscorr_mex('acq_shift_search', h, int8(local(:)), [], nRows));
-    [best, freqShift, binIdx] = sequentialBest(rmax, nShifts, 1, nBins);
-    if isempty(best), continue; end
-    corr = double(gnsscorr_mex('acq_shift_row', h, (best(1) - 1) * nBins + best(3) - 1, spb));
-    [maxPeak, codePhase] = max(corr);                                                       % :72
-    second = secondPeak(corr, codePhase, chip, spb / Nblocks);
+prns = settings.acqSatelliteList;
+picks = [];
+if ~isfield(settings, 'gnsscorrPerPRN')
+    chips = zeros(settings.codeLength * 2, numel(prns));
+    for k = 1:numel(prns)
+        cm = generateCMcode(prns(k), settings);
+        chips(:, k) = cm(:);
+    end
+    picks = batched(h, chips, sampleIndex(0:spc - 1, ts, tc, settings.codeLength * 2, true), [], 1, chip, spb / Nblocks, 1);
+end
+for k = 1:numel(prns)
+    PRN = prns(k);
+    if ~isempty(picks)
+        % :46-66 (which (carrier, bin) wins), :72 and :77-91 inside the call
+        if picks(1, k) < 0, continue; end
+        row = picks(1, k);  codePhase = picks(2, k) + 1;  maxPeak = picks(3, k);  second = picks(4, k);
+        freqShift = floor(row / nBins) + 1;  binIdx = rem(row, nBins) + 1;
+    else
+        cm = generateCMcode(PRN, settings);
+        table = sampled(cm, 0:spc - 1, ts, tc, settings.codeLength * 2, true);              % makeCMTable.m
+        local = [table, zeros(1, spc)];                                                     % :44
+        rmax = double(gnsscorr_mex('acq_shift_search', h, int8(local(:)), [], nRows));
+        [best, freqShift, binIdx] = sequentialBest(rmax, nShifts, 1, nBins);
+        if isempty(best), continue; end
+        corr = double(gnsscorr_mex('acq_shift_row', h, (best(1) - 1) * nBins + best(3) - 1, spb));
+        [maxPeak, codePhase] = max(corr);                                                   % :72
+        second = secondPeak(corr, codePhase, chip, spb / Nblocks);
+    end
     acqResults.peakMetric(PRN) = maxPeak / second;                                          % :94
     if maxPeak / second > settings.acqThreshold                                             % :97
         carr = initFreq - freqRes * (binIdx - 1) - (freqRes / nShifts) * (freqShift - 1);   % :101
@@ -257,20 +309,43 @@ nRows = gnsscorr_mex('acq_shift_prepare', h, q);
 nMax = max(settings.acqSatelliteList);
 acqResults.carrFreq = zeros(1, nMax);  acqResults.codePhase = zeros(1, nMax);  acqResults.peakMetric = zeros(1, nMax);
 tc = 1 / settings.codeFreqBasis / 2;
-for PRN = settings.acqSatelliteList
-    dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);   % makeDataTable.m
-    arms = [dtab(1:xLen), zeros(1, n - xLen)].';                                            % :155-156
-    w = [];
-    if pilot
-        ptab = sampled(generatePilotBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);
-        arms = [arms, [ptab(1:xLen), zeros(1, n - xLen)].'];
-        w = [sqrt(11) / sqrt(40), sqrt(29) / sqrt(40)];                                     % :186-187
+prns = settings.acqSatelliteList;
+w = [];
+narms = 1;
+if pilot
+    w = [sqrt(11) / sqrt(40), sqrt(29) / sqrt(40)];                                         % :186-187
+    narms = 2;
+end
+picks = [];
+if ~isfield(settings, 'gnsscorrPerPRN')
+    chips = zeros(settings.codeLength * 2, narms * numel(prns));
+    for k = 1:numel(prns)
+        d = generateDataBOC11(settings, prns(k));
+        chips(:, (k - 1) * narms + 1) = d(:);
+        if pilot
+            pl = generatePilotBOC11(settings, prns(k));
+            chips(:, (k - 1) * narms + 2) = pl(:);
+        end
     end
-    [rmax, rarg] = gnsscorr_mex('acq_shift_search', h, int8(arms), w, nRows);
-    rmax = double(rmax);  rarg = double(rarg);
-    [peak, binIdx] = max(rmax);                                                             % :193 max(max(results, [], 2))
+    idx = sampleIndex(1:spc, ts, tc, settings.codeLength * 2, true);
+    picks = batched(h, chips, idx(1:xLen), w, 0, 0, 1, narms);                              % [table(1:samplesXmsLen) zeros], :155-156
+end
+for k = 1:numel(prns)
+    PRN = prns(k);
+    dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);   % makeDataTable.m
+    if pilot, ptab = sampled(generatePilotBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true); end
+    if ~isempty(picks)
+        % :193 max(max(results, [], 2)) and [~, codePhase] = max(max(results)) inside the call
+        binIdx = picks(1, k) + 1;  peak = picks(3, k);  codePhase = picks(2, k) + 1;
+    else
+        arms = [dtab(1:xLen), zeros(1, n - xLen)].';                                        % :155-156
+        if pilot, arms = [arms, [ptab(1:xLen), zeros(1, n - xLen)].']; end
+        [rmax, rarg] = gnsscorr_mex('acq_shift_search', h, int8(arms), w, nRows);
+        rmax = double(rmax);  rarg = double(rarg);
+        [peak, binIdx] = max(rmax);                                                         % :193 max(max(results, [], 2))
+        codePhase = min(rarg(rmax == peak)) + 1;                                            % [~, codePhase] = max(max(results))
+    end
     selFreq = initFreq - (binIdx - 1) * settings.acqStep;                                   % :194
-    codePhase = min(rarg(rmax == peak)) + 1;                                                % [~, codePhase] = max(max(results))
     acqResults.peakMetric(PRN) = peak / sigPower;                                           % :199
     if codePhase + spc - 1 > nLong, codePhase = codePhase - spc; end                        % :232-234
     if acqResults.peakMetric(PRN) > settings.acqThreshold

@@ -31,6 +31,7 @@
  *   nrows = gnsscorr_mex('acq_shift_prepare', h, shift_struct)                    % circular-shift family (BDS B1I, GPS L2C, BDS B1C)
  *   [rowMax, rowArg] = gnsscorr_mex('acq_shift_search', h, int8(codes), weights, nrows)  % codes n x narms; weights [] = ones
  *   row  = gnsscorr_mex('acq_shift_row', h, row0, n)                              % one results row (single), for the 2nd-peak rule
+ *   picks = gnsscorr_mex('acq_shift_search_batch', h, int8(chips), int32(index0), weights, rule, exclude, period, narms)  % a package's whole search: 4 x nPRN
  *   x    = gnsscorr_mex('read_if', h, firstSample0, n, 'int8'|'int16', valuesPerSample)   % raw record samples back
  *   [name, cus] = gnsscorr_mex('device_info', h)
  */
@@ -426,6 +427,49 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       fail("gc_acq_shift_search");
     if (nlhs > 1) plhs[1] = arg; /* 0-based first position of each row's maximum */
     else mxDestroyArray(arg);
+  } else if (!strcmp(cmd, "acq_shift_search_batch")) {
+    /* picks = gnsscorr_mex('acq_shift_search_batch', h, int8(codes), int32(index0), weights, rule, exclude, period, narms)
+       codes: one column per (PRN, arm), the arms of a PRN next to each other.  index0 = [] : columns of samplesPerBlock sampled,
+       zero-padded replicas; otherwise columns of chips and the ONE 0-based index vector that samples them all (zero padding on the
+       device).  rule 0 | 1 | 2 = GC_SHIFT_PICK_GLOBAL | _SEQUENTIAL | _SEQUENTIAL_PAIRS.  picks: 4 x nPRN double
+       [row0; codePhase0; peak; secondPeak], row0 = -1: nothing above 0.  [] when the library answers GC_E_UNSUPPORTED (block
+       lengths without specialised transforms): search PRN by PRN with 'acq_shift_search' / 'acq_shift_row' then. */
+    int32_t n = 0, nrows = 0, amax = 0;
+    if (nrhs < 9) mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search_batch: handle, codes, index, weights, rule, exclude, period, narms");
+    if (gc_acq_shift_dims(handle(prhs[1]), &n, &nrows, &amax)) fail("gc_acq_shift_dims");
+    const int narms = (int)mxGetScalar(prhs[8]);
+    const int ncols = (int)mxGetN(prhs[2]), code_len = (int)mxGetM(prhs[2]);
+    const int have_index = !mxIsEmpty(prhs[3]);
+    if (!mxIsInt8(prhs[2]) || narms < 1 || narms > amax || ncols < narms || ncols % narms != 0 || (!have_index && code_len != n))
+      mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search_batch: codes must be int8, one column per (PRN, arm), %d rows without an index vector", (int)n);
+    if (have_index && (!mxIsInt32(prhs[3]) || (int32_t)mxGetNumberOfElements(prhs[3]) > n))
+      mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search_batch: the index vector must be int32 with at most %d entries", (int)n);
+    const double* w = NULL;
+    if (!mxIsEmpty(prhs[4])) {
+      if (!mxIsDouble(prhs[4]) || (int)mxGetNumberOfElements(prhs[4]) < narms)
+        mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search_batch: one double weight per code arm");
+      w = mxGetDoubles(prhs[4]);
+    }
+    const int nprn = ncols / narms;
+    gc_acq_shift_pick* picks = (gc_acq_shift_pick*)mxCalloc((mwSize)nprn, sizeof(gc_acq_shift_pick));
+    const int rc = gc_acq_shift_search_batch(handle(prhs[1]), nprn, narms, (const int8_t*)mxGetData(prhs[2]), code_len,
+                                             have_index ? (const int32_t*)mxGetData(prhs[3]) : NULL,
+                                             have_index ? (int)mxGetNumberOfElements(prhs[3]) : 0, w, (int)mxGetScalar(prhs[5]),
+                                             (int)mxGetScalar(prhs[6]), (int)mxGetScalar(prhs[7]), picks);
+    if (rc == GC_E_UNSUPPORTED) {
+      plhs[0] = mxCreateDoubleMatrix(0, 0, mxREAL);
+    } else {
+      if (rc) fail("gc_acq_shift_search_batch");
+      plhs[0] = mxCreateDoubleMatrix(4, (mwSize)nprn, mxREAL);
+      double* o = mxGetDoubles(plhs[0]);
+      for (int k = 0; k < nprn; ++k) {
+        o[4 * k] = picks[k].row;
+        o[4 * k + 1] = picks[k].code_phase;
+        o[4 * k + 2] = picks[k].peak;
+        o[4 * k + 3] = picks[k].second_peak;
+      }
+    }
+    mxFree(picks);
   } else if (!strcmp(cmd, "acq_shift_row")) {
     /* r = gnsscorr_mex('acq_shift_row', h, row0[, n]): one correlation row; its length is the prepared samplesPerBlock */
     int32_t n = 0;

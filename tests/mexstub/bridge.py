@@ -57,6 +57,10 @@ def install(I, gateway, P, signal: str):
         if cmd in ("acquire_coarse", "acquire_coarse_multi") or cmd in ("fine_sums", "acquire_fine_l1ca", "acq_shift_search"):
             k = 2 if cmd != "acq_shift_search" else 1
             vals[k] = np.asarray(vals[k]).astype(np.int8)
+        if cmd == "acq_shift_search_batch":     # int8(chips), int32(index0): double storage in the interpreter
+            vals[1] = np.asarray(vals[1]).astype(np.int8)
+            if np.asarray(vals[2]).size:
+                vals[2] = np.asarray(vals[2]).astype(np.int32)
         r = gateway.call(cmd, *vals, nargout=max(nargout, 1))
         if nargout <= 1:
             return _from_py(r) if nargout == 1 or r is not None else None

@@ -43,6 +43,7 @@ mxClassID mxGetClassID(const mxArray* a);
 int mxIsDouble(const mxArray* a);
 int mxIsInt8(const mxArray* a);
 int mxIsInt16(const mxArray* a);
+int mxIsInt32(const mxArray* a);
 int mxIsSingle(const mxArray* a);
 int mxIsEmpty(const mxArray* a);
 int mxIsChar(const mxArray* a);

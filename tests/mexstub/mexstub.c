@@ -149,6 +149,7 @@ mxClassID mxGetClassID(const mxArray* a) { return a->cls; }
 int mxIsDouble(const mxArray* a) { return a->cls == mxDOUBLE_CLASS; }
 int mxIsInt8(const mxArray* a) { return a->cls == mxINT8_CLASS; }
 int mxIsInt16(const mxArray* a) { return a->cls == mxINT16_CLASS; }
+int mxIsInt32(const mxArray* a) { return a->cls == mxINT32_CLASS; }
 int mxIsSingle(const mxArray* a) { return a->cls == mxSINGLE_CLASS; }
 int mxIsEmpty(const mxArray* a) { return numel(a) == 0; }
 int mxIsChar(const mxArray* a) { return a->cls == mxCHAR_CLASS; }

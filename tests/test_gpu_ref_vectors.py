@@ -206,6 +206,20 @@ def test_default_size_searches_in_one_chunk_of_bins(engine, monkeypatch, name):
     _compare_acq(sc, z, sc.product(P, engine, S))
 
 
+@pytest.mark.parametrize("name", ["BDS_B1I_default", "GPS_L2C_default", "BDS_B1C_default"])
+def test_circshift_family_at_the_default_sizes_prn_by_prn(engine, monkeypatch, name):
+    """The circshift family's default-size searches run as ONE library call per package (gc_acq_shift_search_batch, the default path of
+    test_hip_acquisition_at_the_references_default_search_sizes); GC_ACQ_SHIFT_PER_PRN=1 is the PRN loop it replaced - row maxima and
+    the winning row read back per PRN, the selection rules on the host: the same fixtures, the same results."""
+    import cu_sdr_collection_amd as P
+    sc = next(s for s in RS.DEFAULT_ACQ_SCENES if s.name == name)
+    monkeypatch.setenv("GC_ACQ_SHIFT_PER_PRN", "1")
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    engine.load_if(rec, fs=S.samplingFreq)
+    _compare_acq(sc, z, sc.product(P, engine, S))
+
+
 _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": "1"}), ("GAL_E1C", {"GC_ACQ_PEAK_KERNEL": "1"}),
               ("BDS_B1C", {"GC_ACQ_PEAK_KERNEL": "1"}), ("BDS_B1I", {"GC_ACQ_ROWMAX_KERNEL": "1"}), ("GPS_L2C", {"GC_ACQ_ROWMAX_KERNEL": "1"}),
               ("GPS_L1CA", {"GC_ACQ_NO_HOP_GROUPS": "1"}), ("GLO_GL1", {"GC_ACQ_NATURAL_ORDER": "1"}), ("GAL_E1C", {"GC_ACQ_GENERIC": "1"}),
@@ -230,7 +244,11 @@ _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": 
               ("GAL_E1C", {"GC_ACQ_ARMS_SEPARATE": "1"}), ("GPS_L5C", {"GC_ACQ_ARMS_MERGE": "1"}), ("GAL_E5b", {"GC_ACQ_ARMS_MERGE": "1"}),
               ("BDS_B2a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "2"}), ("GAL_E5a", {"GC_ACQ_ARMS_MERGE": "1", "GC_ACQ_BIN_CHUNKS": "3"}),
               # BDS B1C's weighted data + pilot arms arm by arm again, and merged in small chunks of rows
-              ("BDS_B1C", {"GC_ACQ_ARMS_SEPARATE": "1"}), ("BDS_B1C", {"GC_ACQ_SHIFT_CHUNK_MB": "40"})]
+              ("BDS_B1C", {"GC_ACQ_ARMS_SEPARATE": "1"}), ("BDS_B1C", {"GC_ACQ_SHIFT_CHUNK_MB": "40"}),
+              # round 5: the circshift family's whole PRN list in one library call (gc_acq_shift_search_batch) - back to the PRN loop
+              # with its two read-backs per PRN, and the batch with one / two PRN lanes
+              ("BDS_B1I", {"GC_ACQ_SHIFT_PER_PRN": "1"}), ("GPS_L2C", {"GC_ACQ_SHIFT_PER_PRN": "1"}), ("BDS_B1C", {"GC_ACQ_SHIFT_PER_PRN": "1"}),
+              ("BDS_B1I", {"GC_ACQ_SHIFT_LANES": "1"}), ("GPS_L2C", {"GC_ACQ_SHIFT_LANES": "2"}), ("BDS_B1C", {"GC_ACQ_SHIFT_LANES": "2"})]
 
 
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
