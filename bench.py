@@ -137,7 +137,16 @@ def emit(result: dict, detail_path: str | None) -> None:
             print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr, flush=True)
             detail_path = None
     sys.stderr.flush()
+    try:                                   # libraries that write to C stdio (RCCL's banner) hold their text in a buffer when stdout is a pipe
+        import ctypes                      # and would spill it at exit, AFTER the line: flush it out first
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(compact_line(result, detail_path), flush=True)
+    try:
+        os.dup2(2, 1)                       # whatever a library still writes at exit goes to stderr: the line stays the last on stdout
+    except OSError:
+        pass
 
 
 def _spawn_ranks(n: int, steps: int, warmup: int) -> int:
@@ -1082,6 +1091,11 @@ def main() -> None:
                               "(another rank failed or the launcher timed out)"), flush=True)
             os._exit(143)
         signal.signal(signal.SIGTERM, _terminated)
+    if rank != 0:
+        try:
+            os.dup2(2, 1)                   # stdout carries rank 0's ONE line; the other ranks' (and their libraries' C stdio) go to stderr
+        except OSError:
+            pass
     R = Ranks(rank, world, device)
     config = args.config or ("all" if world == 1 else "l1ca")
 
@@ -1090,9 +1104,9 @@ def main() -> None:
 
     if config == "mix":
         result = run_mix(P, W, args, R, device)
-        if rank == 0:
-            emit(result, args.detail)
         R.close()
+        if rank == 0:
+            emit(result, args.detail)      # the LAST thing this process writes to stdout
         return
 
     result, main_ctx = run_l1ca(P, W, args, R, device)
@@ -1122,10 +1136,10 @@ def main() -> None:
         result["cpu_baseline"] = base
         if spots:
             result["oracle_spot_checks_max_dev_rel_sum_abs_x"] = spots
-    if rank == 0:
-        emit(result, args.detail)
     main_ctx["eng"].close()
     R.close()
+    if rank == 0:
+        emit(result, args.detail)          # the LAST thing this process writes to stdout
 
 
 if __name__ == "__main__":

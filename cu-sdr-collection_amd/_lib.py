@@ -175,6 +175,7 @@ SYMBOLS = {
     "gc_acq_shift_dims": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gc_preamble_xcorr": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int64, _P, C.c_int, C.POINTER(C.c_float)]),
     "gc_sync_xcorr": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int64, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "gc_build_flags": (C.c_int, []),
     "gc_debug_first_sample_near_edge": (C.c_longlong, [C.c_double, C.c_double, C.c_longlong, C.c_double]),
     "gc_debug_last_kernel": (C.c_int, [_P]),
     "gc_debug_last_track_mode": (C.c_int, [_P]),
@@ -201,6 +202,15 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+GC_BUILD_TUNING = 1
+TUNING_LIB_PATH = os.path.join(HERE, "lib", "libgnsscorr_tuning.so")
+
+
+def is_tuning_build() -> bool:
+    """True when the loaded library is libgnsscorr_tuning.so (GC_LIB_PATH): the GC_* switches of docs/KNOBS.md are read only there."""
+    return bool(load().gc_build_flags() & GC_BUILD_TUNING)
 
 
 def check(status: int):

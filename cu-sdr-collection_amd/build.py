@@ -29,15 +29,28 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
 
+_CORR_UNITS = ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip",
+               # one source, four translation units (its 148 kernel instantiations took one compiler process 248 s): unit@MACRO=value
+               "corr_lane.hip@GC_LANE_PART=0", "corr_lane.hip@GC_LANE_PART=1", "corr_lane.hip@GC_LANE_PART=2", "corr_lane.hip@GC_LANE_PART=3",
+               "track.hip", "multi.hip", "stream.hip", "acq.hip", "navsync.hip"]
+
+
+def _tuned(spec: str) -> str:
+    return spec + ("," if "@" in spec else "@") + "GC_TUNING=1"
+
+
 LIBS = {
-    "libgnsscorr.so": ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip", "corr_cboc.hip",
-                       # one source, four translation units (its 148 kernel instantiations took one compiler process 248 s): unit@MACRO=value
-                       "corr_lane.hip@GC_LANE_PART=0", "corr_lane.hip@GC_LANE_PART=1", "corr_lane.hip@GC_LANE_PART=2", "corr_lane.hip@GC_LANE_PART=3",
-                       "track.hip", "multi.hip", "stream.hip", "acq.hip", "navsync.hip"],
+    # the product: reads no tuning variable (gc_internal.h GC_TUNE_ENV), carries no experimental kernel
+    "libgnsscorr.so": _CORR_UNITS,
+    # the same sources with -DGC_TUNING=1: every A/B switch of docs/KNOBS.md live, plus the kernels that lost their A/B
+    # (corr_cboc.hip).  Loaded through GC_LIB_PATH by the knob tests, scripts/variants.sh and the profiling scripts.
+    "libgnsscorr_tuning.so": [_tuned(u) for u in _CORR_UNITS] + [_tuned("corr_cboc.hip")],
     "libgnsssynth.so": ["synth.hip"],
 }
 HEADERS = ["gc_internal.h", "corr_common.h", "devloop.h", os.path.join("..", "..", "include", "gnsscorr.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+# --offload-compress: the gfx950 code objects inside the fat binary are zstd-compressed (10.1 -> ~1.6 MB; the HIP runtime inflates them
+# when the library is loaded: ~20 ms once per process)
+FLAGS = ["--offload-arch=gfx950", "--offload-compress", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
          "-Wno-unused-function", "-fno-slp-vectorize"]
 # The correlator's exact paths restate the reference's float64 arithmetic operation by operation
 # (fl(a + fl(i*d)), MATLAB's two-sided colon).  HIP's __dadd_rn / __dmul_rn are plain operators defined in a
@@ -76,12 +89,13 @@ def _sha_file(path: str) -> str:
 
 
 def _unit(spec: str):
-    """(source file, extra -D flags, object base name) of a unit spec "file.hip" or "file.hip@MACRO=value"."""
-    src, _, macro = spec.partition("@")
+    """(source file, extra -D flags, object base name) of a unit spec "file.hip" or "file.hip@MACRO=value[,MACRO=value...]"."""
+    src, _, macros = spec.partition("@")
     base = os.path.splitext(src)[0]
-    if not macro:
+    if not macros:
         return src, [], base
-    return src, ["-D" + macro], base + "_" + "".join(c if c.isalnum() else "_" for c in macro)
+    ms = macros.split(",")
+    return src, ["-D" + m for m in ms], base + "_" + "_".join("".join(c if c.isalnum() else "_" for c in m) for m in ms)
 
 
 def _tu_flags(spec: str):

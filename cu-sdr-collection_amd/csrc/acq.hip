@@ -62,7 +62,7 @@ constexpr int kRadixSet[] = {20, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
 
 int max_radix() {
   static const int m = [] {
-    const char* e = std::getenv("GC_ACQ_MAX_RADIX");  // tuning: largest radix a stage may take (2 .. 20)
+    const char* e = GC_TUNE_ENV("GC_ACQ_MAX_RADIX");  // tuning: largest radix a stage may take (2 .. 20)
     return std::min(GC_FFT_MAXR, e ? std::max(5, std::atoi(e)) : 20);
   }();
   return m;
@@ -93,7 +93,7 @@ bool factor(int len, SubPlan* sp) {
   sp->nrad = 0;
   if (len == 1) return true;
   int cur[kMaxRadices], best[kMaxRadices], best_n = kMaxRadices + 1, best_max = 1 << 30;
-  const bool simple = std::getenv("GC_ACQ_SIMPLE_RADIX") != nullptr;  // tuning: radices 5, 4, 3, 2 only
+  const bool simple = GC_TUNE_ENV("GC_ACQ_SIMPLE_RADIX") != nullptr;  // tuning: radices 5, 4, 3, 2 only
   if (simple) {
     int r = len;
     for (int c : {5, 4, 3, 2})
@@ -115,6 +115,16 @@ bool make_plan(int n, Plan* pl) {
   int best = 1;
   for (int d = 1; (long long)d * d <= n; ++d)
     if (n % d == 0) best = d;
+  // sizes whose most square split is not the fastest one: GPS L2C's 320 000 points as 320 x 1 000 instead of 512 x 625 - the columns pass
+  // reads 64-byte row segments (tiles of 8 columns in the same LDS) instead of 40-byte ones, 1.18 -> 1.00 ms per PRN; the rows pass has
+  // a stage more, 0.83 -> 0.97 ms; the search 65.6 -> 62.5 ms.  GC_ACQ_PLAN_N1=<n>:<n1> tries another split (run-time pass kernels)
+  static const int kSplit[][2] = {{320000, 320}};
+  for (const auto& k : kSplit)
+    if (n == k[0]) best = k[1];
+  if (const char* e = GC_TUNE_ENV("GC_ACQ_PLAN_N1")) {
+    int en = 0, e1 = 0;
+    if (std::sscanf(e, "%d:%d", &en, &e1) == 2 && en == n && e1 > 0 && n % e1 == 0) best = e1;
+  }
   pl->n = n;
   pl->n1 = best;
   pl->n2 = n / best;
@@ -1996,14 +2006,14 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
   b.bins_per_wg = 1;
   b.nbatch_total = (int)nbatch_groups;
   constexpr bool fused = GC_ACQ_FUSE_IO != 0 && nst >= 2 && PRE == PRE_NONE && POST == POST_ABS_ACC;
-  if (fused && a.hop_groups <= 1 && !std::getenv("GC_ACQ_ONE_BIN")) {
+  if (fused && a.hop_groups <= 1 && !GC_TUNE_ENV("GC_ACQ_ONE_BIN")) {
     // several consecutive batches per workgroup while the launch keeps a dozen workgroups per CU (BDS B1C: 200 tiles x 201 bins)
     for (int cand : {4, 2})
       if ((long long)(OTHER / C) * nbatch_groups / cand >= 12LL * ctx->compute_units) {
         b.bins_per_wg = cand;
         break;
       }
-    if (const char* e = std::getenv("GC_ACQ_BINS_PER_WG")) b.bins_per_wg = std::max(1, std::atoi(e));
+    if (const char* e = GC_TUNE_ENV("GC_ACQ_BINS_PER_WG")) b.bins_per_wg = std::max(1, std::atoi(e));
   }
   const long long groups = (nbatch_groups + b.bins_per_wg - 1) / b.bins_per_wg;
   hipLaunchKernelGGL((fft_pass_ct<L, OTHER, CONTIG, C, PRE, POST, INV, SHIFT, R0, R1, R2, R3>),
@@ -2023,7 +2033,7 @@ bool try_ct(gc_context* ctx, const PassArgs& a, long long nbatch_groups) {
 // tile width C1 of the specialised columns pass for vectors of `len`, `nvec` of them per transform (the shapes of GC_CT_SHAPE below:
 // its launch has nvec / C1 workgroups per batch, whatever PassArgs::cols says); 0: no specialised pass
 int ct_columns_tile(int len, int nvec) {
-  static const int shapes[][3] = {{180, 200, 8}, {150, 160, 8}, {375, 384, 4}, {250, 288, 8}, {600, 600, 5}, {512, 625, 5}};
+  static const int shapes[][3] = {{180, 200, 8}, {150, 160, 8}, {375, 384, 4}, {250, 288, 8}, {600, 600, 5}, {320, 1000, 8}};
   for (const auto& k : shapes)
     if (len == k[0] && nvec == k[1]) return k[2];
   return 0;
@@ -2031,9 +2041,9 @@ int ct_columns_tile(int len, int nvec) {
 
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* used_ct = nullptr) {
   if (used_ct) *used_ct = false;
-  const bool generic = std::getenv("GC_ACQ_GENERIC") != nullptr;  // (read per call: the tests switch it)
-  const bool no_pairs = std::getenv("GC_ACQ_NO_XCD_PAIRS") != nullptr;
-  const char* xmap = std::getenv("GC_ACQ_XCD_MAP");
+  const bool generic = GC_TUNE_ENV("GC_ACQ_GENERIC") != nullptr;  // (read per call: the tests switch it)
+  const bool no_pairs = GC_TUNE_ENV("GC_ACQ_NO_XCD_PAIRS") != nullptr;
+  const char* xmap = GC_TUNE_ENV("GC_ACQ_XCD_MAP");
   a.no_xcd_pairs = no_pairs ? 1 : (xmap && std::strcmp(xmap, "pairs") == 0) ? 2 : 0;
   if (!generic) {
     // N = 36 000: 18 Msps, 1 ms codes (GPS L1 C/A, L5, Galileo E5a/E5b, BDS B2a/B3I: initSettings.m of each package);
@@ -2042,14 +2052,14 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* use
     // (4-ms blocks), BDS B1C (20 ms) and GPS L2C (40 ms at 8 Msps)
     if (GC_CT_SHAPE(180, 200, 8, 6, 6, 5, 1, 6, 8, 5, 5, 1) || GC_CT_SHAPE(150, 160, 8, 6, 5, 5, 1, 6, 8, 5, 4, 1) ||
         GC_CT_SHAPE(375, 384, 4, 5, 5, 5, 3, 5, 8, 8, 6, 1) || GC_CT_SHAPE(250, 288, 8, 5, 5, 5, 2, 5, 8, 6, 6, 1) ||
-        GC_CT_SHAPE(600, 600, 5, 6, 5, 5, 4, 3, 6, 5, 5, 4) || GC_CT_SHAPE(512, 625, 5, 8, 8, 8, 1, 2, 5, 5, 5, 5)) {
+        GC_CT_SHAPE(600, 600, 5, 6, 5, 5, 4, 3, 6, 5, 5, 4) || GC_CT_SHAPE(320, 1000, 8, 8, 8, 5, 1, 2, 8, 5, 5, 5)) {
       GC_HIP(hipGetLastError());
       if (used_ct) *used_ct = true;
       return GC_OK;
     }
   }
   if (a.batch0 != 0 || a.arm_batches > 0) {  // fft_pass_kernel numbers its batches from 0 and knows no merged arms: it would transform other rows into other places
-    gc_set_error("acquisition: rows / bins in chunks, merged arms and single-row transforms need the specialised pass kernels (length %d x %d; GC_ACQ_GENERIC set?)",
+    gc_set_error("acquisition: rows / bins in chunks, merged arms and single-row transforms need the specialised pass kernels (length %d x %d)",
                  a.len, a.nvec);
     return GC_E_STATE;
   }
@@ -2068,7 +2078,7 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* use
 // the specialised columns pass of this plan (GC_CT_SHAPE above) where that is a power of two; 0: natural order (generic kernel,
 // the 600 x 600 and 512 x 625 plans with tiles of 3 and 5 columns, GC_ACQ_NATURAL_ORDER=1 for A/B runs).
 int handover_block(const Plan& pl) {
-  const bool off = std::getenv("GC_ACQ_GENERIC") != nullptr || std::getenv("GC_ACQ_NATURAL_ORDER") != nullptr;
+  const bool off = GC_TUNE_ENV("GC_ACQ_GENERIC") != nullptr || GC_TUNE_ENV("GC_ACQ_NATURAL_ORDER") != nullptr;
   if (off) return 0;
   static const struct { int n1, n2, log2b; } shapes[] = {{180, 200, 3}, {150, 160, 3}, {375, 384, 2}, {250, 288, 3}};
   for (const auto& k : shapes)
@@ -2085,10 +2095,10 @@ void fill_sub(PassArgs& a, const SubPlan& sp) {
 // columns per tile: keep 2*L*C*8 bytes <= 64 KiB and L*C <= 8*256 (POST_ABS_ACC register slots)
 int choose_cols(int L, int estride = 1) {
   int budget = 2048;
-  if (const char* e = std::getenv("GC_ACQ_TILE")) budget = std::max(256, std::atoi(e));  // tuning: elements per tile
+  if (const char* e = GC_TUNE_ENV("GC_ACQ_TILE")) budget = std::max(256, std::atoi(e));  // tuning: elements per tile
   int c = std::max(1, std::min(16, budget / L));
   // strided vectors (the column passes): a tile row is c consecutive float2; whole 64-byte sectors when c is a multiple of 8
-  static const int align = [] { const char* e = std::getenv("GC_ACQ_COLS_ALIGN"); return e ? std::atoi(e) : 8; }();
+  static const int align = [] { const char* e = GC_TUNE_ENV("GC_ACQ_COLS_ALIGN"); return e ? std::atoi(e) : 8; }();
   if (estride != 1 && align > 1 && c >= align) c -= c % align;
   return c;
 }
@@ -2202,19 +2212,19 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   int hg = 1;
   for (int g = 1; g <= a.nhops; ++g)
     if (a.nhops % g == 0 && (long long)tiles * nbins * hg * std::max(1, s->nlanes) < 4LL * ctx->compute_units) hg = g;  // (both lanes' launches run together)
-  if (std::getenv("GC_ACQ_NO_HOP_GROUPS") || chunked) hg = 1;
-  if (const char* e = std::getenv("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count (a chunk of bins has none)
+  if (GC_TUNE_ENV("GC_ACQ_NO_HOP_GROUPS") || chunked) hg = 1;
+  if (const char* e = GC_TUNE_ENV("GC_ACQ_HOP_GROUPS")) {  // experiments: any divisor of the hop count (a chunk of bins has none)
     const int g = std::atoi(e);
     if (g >= 1 && a.nhops % g == 0 && !chunked) hg = g;
   }
   a.hop_groups = hg;
   dim3 pgrid((unsigned int)std::max(1, std::min((a.n + 1023) / 1024, 64)), (unsigned int)std::min<long long>(nbins, 65535));
-  if (const char* e = std::getenv("GC_ACQ_COMBINE_GX")) pgrid.x = (unsigned int)std::max(1, std::atoi(e));
+  if (const char* e = GC_TUNE_ENV("GC_ACQ_COMBINE_GX")) pgrid.x = (unsigned int)std::max(1, std::atoi(e));
   if (hg == 1) {
     // last arm of a PRN on a specialised pass kernel: every workgroup leaves its own peak candidate (fft_pass_ct), reduced into the
     // keys after the last PRN like the hop-grouped path's; the generic pass kernel writes the results and peak_kernel reads them
     const int c1 = ct_columns_tile(a.len, a.nvec);
-    if (rows_fused && c1 > 0 && a.hop_groups <= 1 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_ROWMAX_KERNEL")) {
+    if (rows_fused && c1 > 0 && a.hop_groups <= 1 && !GC_TUNE_ENV("GC_ACQ_GENERIC") && !GC_TUNE_ENV("GC_ACQ_ROWMAX_KERNEL")) {
       // circshift search, last arm: per-workgroup candidates (tiles of one row each) instead of the sums themselves
       const int tiles_ct = a.nvec / c1;
       const size_t want = (size_t)nbins_total * tiles_ct * 2 * (size_t)std::max(1, s->shift_slot_lanes);  // (gc_acq_shift_search_batch: a region per lane)
@@ -2245,7 +2255,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
       }
       return GC_OK;  // (the generic kernel ignored the slots and wrote the sums: the caller runs rowmax_kernel)
     }
-    const bool fused_peak = keys && c1 > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL");
+    const bool fused_peak = keys && c1 > 0 && !GC_TUNE_ENV("GC_ACQ_GENERIC") && !GC_TUNE_ENV("GC_ACQ_PEAK_KERNEL");
     if (chunked && (c1 == 0 || (keys && !fused_peak))) {
       gc_set_error("acquisition: bins in chunks need the specialised passes and their peak candidates");
       return GC_E_STATE;
@@ -2464,7 +2474,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   bool padded = false;
   {
     Plan probe;
-    if (!make_plan(n, &probe) || std::getenv("GC_ACQ_PAD")) {
+    if (!make_plan(n, &probe) || GC_TUNE_ENV("GC_ACQ_PAD")) {
       padded = true;
       n = 0;
       for (int m = blk + cl; m < blk + cl + (1 << 20); ++m)
@@ -2484,8 +2494,8 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   // arm for the second to read back and add to.  It pays where a bin has few hops - Galileo E1's one: 10.9 -> 9.5 ms - and not where the
   // columns pass already walks 15 - 25 hops per bin and the doubled intermediate needs twice the chunks (L5 6.2 -> 6.4 .. 7.2 ms, E5b 28.5 ->
   // 30.4 .. 33, E5a / B2a +-0): merged up to 4 arm-hops per bin (GC_ACQ_ARMS_MERGE=1: always; GC_ACQ_ARMS_SEPARATE=1: never).
-  bool merge_arms = narms > 1 && !std::getenv("GC_ACQ_ARMS_SEPARATE") && !std::getenv("GC_ACQ_FUSED") && !std::getenv("GC_ACQ_GENERIC") &&
-                    ((long long)narms * H <= 4 || std::getenv("GC_ACQ_ARMS_MERGE"));
+  bool merge_arms = narms > 1 && !GC_TUNE_ENV("GC_ACQ_ARMS_SEPARATE") && !GC_TUNE_ENV("GC_ACQ_FUSED") && !GC_TUNE_ENV("GC_ACQ_GENERIC") &&
+                    ((long long)narms * H <= 4 || GC_TUNE_ENV("GC_ACQ_ARMS_MERGE"));
   for (int arm = 1; arm < narms; ++arm) merge_arms = merge_arms && p->arm_weight[arm] == p->arm_weight[0];
   AcqScratch* s = nullptr;
   int rc = ensure_scratch(ctx, n, (long long)nbins * H * (merge_arms ? narms : 1), nprn * narms, nbins, cl, &s);
@@ -2510,7 +2520,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
     hipStream_t own;
     ~RestoreStream() { c->stream = own; }
   } restore_stream{ctx, ctx->stream};
-  const char* lane_streams_env = std::getenv("GC_ACQ_LANE_STREAMS");
+  const char* lane_streams_env = GC_TUNE_ENV("GC_ACQ_LANE_STREAMS");
   AcqStreams* const shared = (lane_streams_env && std::strcmp(lane_streams_env, "own") == 0) ? nullptr : acq_streams(ctx->device);
   if (shared) ctx->stream = shared->main;
   double sum3[3];
@@ -2542,7 +2552,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   long long q = 0;
   int den = 1;
   {
-    const int den_max = std::getenv("GC_ACQ_NO_RATIONAL_SHIFT") || std::getenv("GC_ACQ_FUSED") ? 1 : std::min(64, nbins / 2);
+    const int den_max = GC_TUNE_ENV("GC_ACQ_NO_RATIONAL_SHIFT") || GC_TUNE_ENV("GC_ACQ_FUSED") ? 1 : std::min(64, nbins / 2);
     for (int d = 1; d <= den_max && q == 0; ++d) {
       const double qq = qd * d, r = std::floor(qq + 0.5);
       if (r >= 1 && std::fabs(qq - r) <= 1e-12 * qq) {
@@ -2551,7 +2561,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
       }
     }
   }
-  const bool shifted = !padded && q >= 1 && (long long)((nbins - 1) / den) * q < n && std::getenv("GC_ACQ_NO_SHIFT") == nullptr;
+  const bool shifted = !padded && q >= 1 && (long long)((nbins - 1) / den) * q < n && GC_TUNE_ENV("GC_ACQ_NO_SHIFT") == nullptr;
   if (!shifted) den = 1;
   // per-row centre frequencies (gc_acquire_coarse_offsets): row ip searches around IF + freq_offset[ip] - the same signal spectra moved
   // by -freq_offset * N / fs bins, which must be whole bins (GLONASS: 562.5 kHz x 2 ms = 1 125)
@@ -2559,7 +2569,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   if (freq_offset) {
     for (int ip = 0; ip < nprn; ++ip) {
       const double b = -freq_offset[ip] * (double)n / p->sampling_freq, r = std::floor(b + 0.5);
-      if (!shifted || std::fabs(b - r) > 1e-9 * std::max(1.0, std::fabs(b)) || std::getenv("GC_ACQ_FUSED")) {
+      if (!shifted || std::fabs(b - r) > 1e-9 * std::max(1.0, std::fabs(b)) || GC_TUNE_ENV("GC_ACQ_FUSED")) {
         gc_set_error("gc_acquire_coarse_offsets: a row's offset of %.3f Hz is not a whole number of the search's FFT bins (%.6f Hz), or the "
                      "search does not run on shifted spectra", freq_offset[ip], p->sampling_freq / n);
         return GC_E_UNSUPPORTED;
@@ -2594,7 +2604,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   // search), so the two passes stay the default.
   bool fused = false;
   {
-    const char* ev = std::getenv("GC_ACQ_FUSED");
+    const char* ev = GC_TUNE_ENV("GC_ACQ_FUSED");
     if (ev && std::atoi(ev) != 0) {
       FusedArgs fa;
       std::memset(&fa, 0, sizeof fa);
@@ -2614,7 +2624,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
     }
   }
   const int hblock = base.wrap_len > 0 ? 0 : handover_block(pl);
-  merge_arms = merge_arms && hblock && shifted && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_PEAK_KERNEL");
+  merge_arms = merge_arms && hblock && shifted && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !GC_TUNE_ENV("GC_ACQ_PEAK_KERNEL");
   const int marms = merge_arms ? narms : 1;  // arms per launch
   // shifted spectra on a specialised plan: a workgroup of the rows pass walks several hops of its bin (same rotation, same code
   // spectrum values, same twiddle tables), as long as the launch keeps ~8 workgroups per CU; GC_ACQ_ROW_REPS overrides (a divisor of H)
@@ -2623,7 +2633,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
     const long long wgs = (long long)(pl.n1 / 6 > 0 ? pl.n1 / 6 : 1) * nbins * H;  // tiles of about six rows
     for (int g = 1; g <= H && g <= 8; ++g)
       if (H % g == 0 && wgs / g >= 8LL * ctx->compute_units) row_reps = g;
-    if (const char* e = std::getenv("GC_ACQ_ROW_REPS")) {
+    if (const char* e = GC_TUNE_ENV("GC_ACQ_ROW_REPS")) {
       const int g = std::atoi(e);
       if (g >= 1 && H % g == 0) row_reps = g;
     }
@@ -2632,7 +2642,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   // A PRN is three dependent launches (rows pass, columns pass, combine) of a few thousand workgroups each: alone, every launch
   // ends in a tail of half-empty CUs and starts after a gap; two independent chains fill each other's.
   int lanes = (nprn > 1 && !fused) ? 2 : 1;
-  if (const char* e = std::getenv("GC_ACQ_LANES")) lanes = std::max(1, std::min(2, std::atoi(e)));
+  if (const char* e = GC_TUNE_ENV("GC_ACQ_LANES")) lanes = std::max(1, std::min(2, std::atoi(e)));
   if (lanes == 2) {
     const size_t ne = (size_t)pl.n;
     // the lanes' streams: the device's pair (the first lane on the one the call runs on), or - GC_ACQ_LANE_STREAMS=own - the
@@ -2672,7 +2682,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   // (two arms: the 54 MB of sums per lane that the pilot arm adds to count too).  A search that fits anyway stays whole (smaller
   // launches fill the device less well: E5a +8 % in halves).  GC_ACQ_BIN_CHUNKS=n overrides.
   int chunks = 1;
-  if (hblock && !fused && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_PEAK_KERNEL")) {
+  if (hblock && !fused && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !GC_TUNE_ENV("GC_ACQ_GENERIC") && !GC_TUNE_ENV("GC_ACQ_PEAK_KERNEL")) {
     // the fewest chunks (of at least 8 bins) that bring the lanes' intermediates (+ the sums a second code arm adds to) + the signal
     // spectra under ~235 MB; none if nothing does
     const double hop_bytes = (double)H * (double)pl.n * sizeof(float2);
@@ -2684,8 +2694,8 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
         chunks = c;
         break;
       }
-    if (std::getenv("GC_ACQ_HOP_GROUPS")) chunks = 1;  // (hop groups are a property of whole searches)
-    if (const char* e = std::getenv("GC_ACQ_BIN_CHUNKS")) chunks = std::max(1, std::min(nbins, std::atoi(e)));
+    if (GC_TUNE_ENV("GC_ACQ_HOP_GROUPS")) chunks = 1;  // (hop groups are a property of whole searches)
+    if (const char* e = GC_TUNE_ENV("GC_ACQ_BIN_CHUNKS")) chunks = std::max(1, std::min(nbins, std::atoi(e)));
   }
   const int chunk_bins = (nbins + chunks - 1) / chunks;
   chunks = (nbins + chunk_bins - 1) / chunk_bins;
@@ -2981,7 +2991,7 @@ static int fine_sums_enqueue(gc_context* ctx, const gc_fine_params* p, int ndet,
   dim3 grid((unsigned int)p->ncodes, (unsigned int)ndet, (unsigned int)((p->nbins + kFineBins - 1) / kFineBins));
   int parts = 1;  // workgroups per code period: enough of them for four per CU, runs of at least 2 048 samples
   while (parts < kFineParts && (long long)grid.x * grid.y * grid.z * parts < 4LL * ctx->compute_units && p->spc / (2 * parts) >= 2048) parts *= 2;
-  if (std::getenv("GC_ACQ_FINE_PARTS")) parts = std::max(1, std::min(kFineParts, std::atoi(std::getenv("GC_ACQ_FINE_PARTS"))));
+  if (GC_TUNE_ENV("GC_ACQ_FINE_PARTS")) parts = std::max(1, std::min(kFineParts, std::atoi(GC_TUNE_ENV("GC_ACQ_FINE_PARTS"))));
   grid.x *= (unsigned int)parts;
   double* const dout = (double*)bout.p;
   double* const dpart = parts > 1 ? dout + nout : dout;  // [parts][nout] behind the result
@@ -3119,7 +3129,7 @@ extern "C" int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* 
   bool padded = false;
   {
     Plan probe;
-    if (!make_plan(m, &probe) || std::getenv("GC_ACQ_PAD")) {
+    if (!make_plan(m, &probe) || GC_TUNE_ENV("GC_ACQ_PAD")) {
       padded = true;
       m = 0;
       for (int c = 2 * p->n; c < 2 * p->n + (1 << 20); ++c)
@@ -3189,7 +3199,7 @@ static int shift_internal_row(const gc_acq_shift_params& p, int row) {
 static int shift_read_back(gc_context* ctx, AcqScratch* s, void* dst0, const void* src0, size_t bytes0, void* dst1 = nullptr, const void* src1 = nullptr,
                            size_t bytes1 = 0) {
   const size_t total = bytes0 + bytes1;
-  if (!std::getenv("GC_ACQ_SHIFT_PAGEABLE")) {
+  if (!GC_TUNE_ENV("GC_ACQ_SHIFT_PAGEABLE")) {
     if (s->pinned_bytes < total) {
       if (s->pinned) (void)hipHostFree(s->pinned);
       s->pinned = nullptr;
@@ -3199,7 +3209,7 @@ static int shift_read_back(gc_context* ctx, AcqScratch* s, void* dst0, const voi
       else (void)hipGetLastError();
     }
   }
-  if (s->pinned_bytes >= total && !std::getenv("GC_ACQ_SHIFT_PAGEABLE")) {
+  if (s->pinned_bytes >= total && !GC_TUNE_ENV("GC_ACQ_SHIFT_PAGEABLE")) {
     char* h = static_cast<char*>(s->pinned);
     GC_HIP(hipMemcpyAsync(h, src0, bytes0, hipMemcpyDeviceToHost, ctx->stream));
     if (bytes1) GC_HIP(hipMemcpyAsync(h + bytes0, src1, bytes1, hipMemcpyDeviceToHost, ctx->stream));
@@ -3234,15 +3244,15 @@ static int shift_search_passes(gc_context* ctx, AcqScratch* s, int narms, const 
   // 82.3 / 92.9 ms - its 802 rows of 125 narrow tiles lose more to the additional launches than the cache gives back: chunks for the
   // 600 x 600 plan only (0: all rows at once).
   int chunk_rows = rows;
-  if (ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC")) {
+  if (ct_columns_tile(pl.p1.len, pl.n2) > 0 && !GC_TUNE_ENV("GC_ACQ_GENERIC")) {
     double mb = (pl.n1 == 600 && pl.n2 == 600) ? 160.0 : 0.0;
-    if (const char* e = std::getenv("GC_ACQ_SHIFT_CHUNK_MB")) mb = std::atof(e);
+    if (const char* e = GC_TUNE_ENV("GC_ACQ_SHIFT_CHUNK_MB")) mb = std::atof(e);
     if (mb > 0.0) chunk_rows = std::max(8, std::min(rows, (int)(mb * 1024.0 * 1024.0 / ((double)pl.n * sizeof(float2)))));
   }
   // Both arms of a chunk in one launch pair (PassArgs::arm_batches, as the coarse search does for Galileo E1): a row has ONE transform per
   // arm, so the columns pass walks the arms like hops, weighting each (PassArgs::arm_w).  GC_ACQ_ARMS_SEPARATE=1: arm by arm.
-  const bool merge_arms = narms > 1 && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !std::getenv("GC_ACQ_GENERIC") && !std::getenv("GC_ACQ_ARMS_SEPARATE") &&
-                          !std::getenv("GC_ACQ_ROWMAX_KERNEL");
+  const bool merge_arms = narms > 1 && ct_columns_tile(pl.p1.len, pl.n2) > 0 && !GC_TUNE_ENV("GC_ACQ_GENERIC") && !GC_TUNE_ENV("GC_ACQ_ARMS_SEPARATE") &&
+                          !GC_TUNE_ENV("GC_ACQ_ROWMAX_KERNEL");
   const int marms = merge_arms ? narms : 1;
   if (merge_arms) chunk_rows = std::max(1, std::min(chunk_rows, rows / narms));  // (the intermediate holds `rows` transforms)
   bool all_fused = true;
@@ -3562,7 +3572,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
         gc_set_error("gc_acq_shift_search_batch: sample_index[%d] = %d is outside the %d chips of a code", k, (int)sample_index[k], code_len);
         return GC_E_INVALID;
       }
-  if (s->shift_padded || ct_columns_tile(s->plan.p1.len, s->plan.n2) == 0 || std::getenv("GC_ACQ_GENERIC") || std::getenv("GC_ACQ_ROWMAX_KERNEL")) {
+  if (s->shift_padded || ct_columns_tile(s->plan.p1.len, s->plan.n2) == 0 || GC_TUNE_ENV("GC_ACQ_GENERIC") || GC_TUNE_ENV("GC_ACQ_ROWMAX_KERNEL")) {
     gc_set_error("gc_acq_shift_search_batch: this block length has no specialised pass kernels - search PRN by PRN (gc_acq_shift_search / _row)");
     return GC_E_UNSUPPORTED;
   }
@@ -3617,7 +3627,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
   // With gigabyte intermediates the two lanes only share the memory system they both wait for (GPS L2C 65.0 -> 66.2 ms, BDS B1C
   // 65.1 -> 64.1): one lane there.  GC_ACQ_SHIFT_LANES=1 / 2 overrides.
   int lanes = (nprn > 1 && (size_t)rows * N * sizeof(float2) <= ((size_t)256 << 20)) ? 2 : 1;
-  if (const char* e = std::getenv("GC_ACQ_SHIFT_LANES")) lanes = std::max(1, std::min(2, std::atoi(e)));
+  if (const char* e = GC_TUNE_ENV("GC_ACQ_SHIFT_LANES")) lanes = std::max(1, std::min(2, std::atoi(e)));
   if (nprn < 2) lanes = 1;
   AcqStreams* const shared = lanes == 2 ? acq_streams(ctx->device) : nullptr;
   if (!shared) lanes = 1;
@@ -3800,7 +3810,7 @@ extern "C" int gc_acquire_fine_l1ca_batch(gc_context* ctx, const gc_acq_params* 
   }
   // the hypothesis search on the device (fine_l1ca_pick_kernel): one bin index per detection comes back instead of every sum
   // (GC_ACQ_FINE_HOST=1: the sums come back and the host loop below picks, as before)
-  if (nfine <= 64 && !std::getenv("GC_ACQ_FINE_HOST")) {
+  if (nfine <= 64 && !GC_TUNE_ENV("GC_ACQ_FINE_HOST")) {
     std::vector<FineDet> hdet;
     const double* dsums = nullptr;
     int rc = fine_sums_enqueue(ctx, &fp, ndet, codes, first.data(), f0.data(), hdet, &dsums);

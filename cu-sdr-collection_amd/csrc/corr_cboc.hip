@@ -450,7 +450,7 @@ void launch_cboc_waves(gc_context* ctx, const KArgs& a, dim3 grid, size_t smem) 
 int gc_cboc_waves(const gc_context* ctx) {
   const int tb = gc_multi_table_bytes(ctx->max_stage_len, 2);
   int forced = 0;
-  if (const char* e = std::getenv("GC_CBOC_WAVES")) forced = std::atoi(e);
+  if (const char* e = GC_TUNE_ENV("GC_CBOC_WAVES")) forced = std::atoi(e);
   for (int w : {8, 6, 4, 2, 1}) {
     if (tb + w * kWaveLds > kMaxLds) continue;
     if (forced == 0 || forced == w) return w;

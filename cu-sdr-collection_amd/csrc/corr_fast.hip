@@ -728,7 +728,7 @@ int gc_launch_correlator_fast(gc_context* ctx, const KArgs& a, const InlineBlock
   const bool wide = spl16 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // 16-sample chunks
   // + per wave the running prefix sums of one lane-chunk ([SPL][64] float2) of the prefix-sum variant
   size_t smem = (size_t)a.red_off + 64 + (size_t)(a.wide ? 4 : 1) * (wide ? 16 : 8) * kFW * sizeof(float2);
-  if (const char* e = std::getenv("GC_FAST_EXTRA_LDS")) smem += (size_t)std::atoi(e);  // tuning: occupancy experiments
+  if (const char* e = GC_TUNE_ENV("GC_FAST_EXTRA_LDS")) smem += (size_t)std::atoi(e);  // tuning: occupancy experiments
   if (wide) {
     switch (max_arms) {
       case 1: return launch_fast_mode<1, 16>(ctx, a, ib, dim3(grid), smem);

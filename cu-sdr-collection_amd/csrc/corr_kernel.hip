@@ -146,12 +146,13 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   }
   long long total = (long long)nblocks * splits;
   int want_bpw = 8;
-  if (const char* e = std::getenv("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
+  if (const char* e = GC_TUNE_ENV("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
+#if GC_TUNING
   // Hybrid kernel for channels with a derived six-fold arm (corr_cboc.hip): periodic replay lists of int8 I/Q records, all channels
   // derived, base ramp with <= 2 transitions per 16-sample chunk.  MEASURED SLOWER than the lane kernel's derived-arm instantiation
-  // (config 3's shape over 20 s: 3.69 ms against 3.41 - DESIGN.md 4.2c has the counters), so it is opt-in: GC_CBOC=1.
+  // (config 3's shape over 20 s: 3.69 ms against 3.41 - DESIGN.md 4.2c has the counters): tuning build only, opt-in with GC_CBOC=1.
   if (fast == 0 && a.derived && ctx->scope_kt6 >= 1 && period > 0 && splits == 1 && notify_tag == 0 && max_arms == 3 &&
-      ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && !ctx->force_generic && std::getenv("GC_CBOC")) {
+      ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && !ctx->force_generic && GC_TUNE_ENV("GC_CBOC")) {
     const int cwaves = gc_cboc_waves(ctx);
     if (cwaves > 0 && nblocks >= 2LL * period * ctx->compute_units) {
       a.bpw = cwaves * (nblocks >= 64LL * cwaves * ctx->compute_units ? 2 : 1);  // a staged table serves bpw epochs of its channel
@@ -173,22 +174,23 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
       return gc_launch_correlator_cboc(ctx, a, (unsigned int)total, cwaves);
     }
   }
+#endif
   // Multi-transition kernel (corr_multi.hip): big periodic replay lists whose chunks of 16 samples see up to 2 or 4 table
   // transitions - lists the single-transition kernel takes with 8-sample chunks (fast == 1) or hands to the lane kernel
   // (fast == 0).  GC_NO_MULTI=1 keeps the old choice (A/B), GC_MULTI_MIN = epochs per CU from which it is taken.
   {
-    const int multi_min = std::getenv("GC_MULTI_MIN") ? std::max(1, std::atoi(std::getenv("GC_MULTI_MIN"))) : 4;
+    const int multi_min = GC_TUNE_ENV("GC_MULTI_MIN") ? std::max(1, std::atoi(GC_TUNE_ENV("GC_MULTI_MIN"))) : 4;
     const int mwaves = (period > 0 && max_arms <= 2) ? gc_multi_waves(ctx, max_arms, nblocks, period, ctx->scope_kt, ctx->scope_share_lane) : 0;
     const bool multi = (fast == 0 || fast == 1) && ctx->scope_kt >= 2 && period > 0 && splits == 1 && notify_tag == 0 && !a.derived &&
                        ctx->if_layout != GC_REAL && max_arms <= 2 && mwaves > 0 &&
                        // enough work to fill the device: epochs per CU, a block counted by its length in 16 384-sample units (two BDS B1C
                        // channels x 10 s are 2 000 blocks of 180 000 samples)
                        nblocks * std::max<long long>(1, ctx->replay_min_blksize / 16384) >= multi_min * (long long)period * ctx->compute_units &&
-                       !std::getenv("GC_NO_MULTI") && !ctx->force_generic;
+                       !GC_TUNE_ENV("GC_NO_MULTI") && !ctx->force_generic;
     if (multi) {
       // blocks per workgroup: a table staged once serves bpw epochs of its channel, but a short list cut into few workgroups ends in
       // a long tail (three Galileo E1 channels x 10 s: 940 workgroups of 8 blocks 0.450 ms, 1 875 of 4 blocks 0.406 ms)
-      const int bpw4 = std::getenv("GC_REPLAY_BPW") ? std::max(4, want_bpw) / 4 * 4 : (nblocks / 8 >= 6LL * ctx->compute_units ? 8 : 4);
+      const int bpw4 = GC_TUNE_ENV("GC_REPLAY_BPW") ? std::max(4, want_bpw) / 4 * 4 : (nblocks / 8 >= 6LL * ctx->compute_units ? 8 : 4);
       a.bpw = mwaves >= 8 ? mwaves * (nblocks / period >= 64LL * mwaves ? 2 : 1) : bpw4;
       a.stride = period;
       a.wide = 1;
@@ -213,7 +215,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   // only four waves sharing an int8-pair table keep 16 waves per CU resident (big periodic replay lists, int8 I/Q, <= 2 arms)
   // (measured, scripts/replay_scaling.py: the four-wave float-table kernel wins from 4 epochs per CU on - 12 channels x 2 s: 0.70 of
   // the HBM figure against 0.52 with single-wave workgroups, 3 channels x 10 s: 0.55 against 0.39; the first version waited for 64)
-  static const int wide_min = std::getenv("GC_WIDE_MIN") ? std::max(1, std::atoi(std::getenv("GC_WIDE_MIN"))) : 4;
+  static const int wide_min = GC_TUNE_ENV("GC_WIDE_MIN") ? std::max(1, std::atoi(GC_TUNE_ENV("GC_WIDE_MIN"))) : 4;
   const bool big_list0 = nblocks >= wide_min * (long long)period * ctx->compute_units;
   const bool choose_wide = fast > 0 && !must_wide && gc_fast_prefers_wide() && period > 0 && splits == 1 && big_list0 && notify_tag == 0 &&
                            ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && max_arms <= 2 && 2 * ctx->max_lds_bytes + 512 <= 40 * 1024;
@@ -225,10 +227,10 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
       // periodic list (all table offsets zero): a workgroup stages its channel's tables once and its waves
       // walk consecutive epochs of that channel
       a.bpw = (nblocks / period >= 256) ? 2 * kLaneWaves : kLaneWaves;
-      if (std::getenv("GC_REPLAY_BPW")) a.bpw = std::max(kLaneWaves, want_bpw / kLaneWaves * kLaneWaves);
+      if (GC_TUNE_ENV("GC_REPLAY_BPW")) a.bpw = std::max(kLaneWaves, want_bpw / kLaneWaves * kLaneWaves);
       a.stride = period;
       total = ((nblocks + (long long)a.bpw * period - 1) / ((long long)a.bpw * period)) * period;
-      if (total < 2LL * ctx->compute_units && nblocks > total && !std::getenv("GC_REPLAY_BPW")) {
+      if (total < 2LL * ctx->compute_units && nblocks > total && !GC_TUNE_ENV("GC_REPLAY_BPW")) {
         // few, long blocks (two BDS B1C channels, 10-ms epochs: 996 blocks would make 32 workgroups): one block per
         // workgroup, split over its 16 waves, fills the device; the table is staged per block instead of per 16-32 blocks
         a.bpw = 1;
@@ -267,7 +269,7 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
     if (!choose_wide) {
       fast = 1;
       a.share_el = 0;
-    } else if (max_arms == 1 && a.bpw > 1 && !std::getenv("GC_NO_TABF") &&
+    } else if (max_arms == 1 && a.bpw > 1 && !GC_TUNE_ENV("GC_NO_TABF") &&
                4 * (size_t)ctx->max_lds_bytes + 4 * (size_t)(fast == 2 ? 8192 : 4096) + 64 <= 40 * 1024) {
       a.wide = 2;  // small single-arm table: plain float code values, no conversions in the chunk loop; still 4 workgroups per CU
     }

@@ -471,7 +471,7 @@ int gc_multi_table_bytes(int max_entries, int arms) { return ((max_entries + kGL
 int gc_multi_waves(const gc_context* ctx, int max_arms, long long nblocks, int period, int kt, bool share_el) {
   const int tb = gc_multi_table_bytes(ctx->max_stage_len, max_arms);
   int forced = 0;
-  if (const char* e = std::getenv("GC_MULTI_WAVES")) forced = std::atoi(e);
+  if (const char* e = GC_TUNE_ENV("GC_MULTI_WAVES")) forced = std::atoi(e);
   if (ctx->if_dtype == GC_I16) return tb + 4 * kMSPL * 2 * kMW * (int)sizeof(float) <= kMaxLds ? 4 : 0;  // the int16 instantiations: 4 waves
   // two transitions per chunk (short tables: Galileo E1, BDS B1I): three four-wave workgroups per CU measured 3 % ahead of one
   // sixteen-wave workgroup (e1x8: 1.40 against 1.44 ms); four transitions (GPS L5 at 50 Msps): the other way round (3.95 / 4.10 ms)

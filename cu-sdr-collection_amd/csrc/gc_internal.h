@@ -14,6 +14,18 @@
 
 #define GC_MAX_CHANNELS 256
 
+// Tuning knobs.  Every A/B switch of the kernels' development (docs/KNOBS.md) is read through GC_TUNE_ENV: an environment variable in
+// the tuning build (libgnsscorr_tuning.so, -DGC_TUNING=1: what the knob tests, scripts/variants.sh and the profiling scripts load
+// through GC_LIB_PATH), a null pointer - and therefore no code, no string, no dependence on the process environment - in the
+// library that ships.  What libgnsscorr.so itself still reads at run time: GC_TRACK_POLL_TIMEOUT_MS (how long the host waits for a
+// record of a persistent kernel before it calls the run lost).
+#if defined(GC_TUNING) && GC_TUNING
+#define GC_TUNE_ENV(name) std::getenv(name)
+#else
+#define GC_TUNING 0
+#define GC_TUNE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 void gc_set_error(const char* fmt, ...);
 
 #define GC_HIP(call)                                                                       \
@@ -188,13 +200,16 @@ struct gc_context {
 // launch kind (experiments).  gc_persistent_done takes the context's entry out of the ledger when its kernel has ended.
 hipError_t gc_launch_persistent(gc_context* ctx, const void* fn, dim3 grid, dim3 block, void** args, unsigned int smem);
 void gc_persistent_done(gc_context* ctx);
+// internal status of the persistent launchers, never returned through the C-ABI: the grid did not fit - the ONE refusal a caller may
+// answer with smaller teams (a structural GC_E_UNSUPPORTED - tables or arms without an instantiation - no team size can fix)
+#define GC_E_NOFIT (-100)
 #define GC_PERSIST(call)                                                                                     \
   do {                                                                                                       \
     hipError_t e_ = (call);                                                                                  \
     if (e_ == hipErrorCooperativeLaunchTooLarge) {                                                           \
       (void)hipGetLastError();                                                                               \
       gc_set_error("the persistent kernel's grid does not fit the device next to the kernels in flight");    \
-      return GC_E_UNSUPPORTED;                                                                               \
+      return GC_E_NOFIT;                                                                                     \
     }                                                                                                        \
     if (e_ != hipSuccess) {                                                                                  \
       gc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);               \

@@ -60,7 +60,7 @@ int gc_create(gc_context** out, int device_id) {
   GC_HIP(hipEventCreate(&ctx->ev_stop));
   GC_HIP(hipMalloc(&ctx->d_channels, sizeof(DevChannel) * GC_MAX_CHANNELS));
   GC_HIP(hipMemset(ctx->d_channels, 0, sizeof(DevChannel) * GC_MAX_CHANNELS));
-  if (const char* e = std::getenv("GC_FORCE_GENERIC")) ctx->force_generic = std::atoi(e) != 0;  // tuning: lane kernel everywhere
+  if (const char* e = GC_TUNE_ENV("GC_FORCE_GENERIC")) ctx->force_generic = std::atoi(e) != 0;  // tuning: lane kernel everywhere
   *out = ctx;
   return GC_OK;
 }
@@ -466,7 +466,7 @@ extern "C" int gc_debug_tables_derivable(const int8_t* t1, int n1, const int8_t*
 }
 
 static bool channel_is_derived_uncached(const HostChannel& c) {
-  if (std::getenv("GC_NO_DERIVED_ARM")) return false;
+  if (GC_TUNE_ENV("GC_NO_DERIVED_ARM")) return false;
   if (c.arms != 3 || c.mult[0] != c.mult[1] || c.mult[2] != 6.0 * c.mult[1]) return false;
   for (int a = 0; a < 3; ++a)
     if (c.window[a] != 0 || (int)c.h_tab[a].size() != c.nent[a]) return false;
@@ -627,7 +627,7 @@ int64_t gc_first_sample_near_edge(double a, double step, int64_t n, double eps) 
 // band of a table edge (the kernels skip their near-tie tests); bit 1 (channels with a derived six-fold arm) = no sample within the
 // six-fold ramps' own narrow band of a sub-entry edge, whatever the base ramps do (corr_cboc.hip skips its per-sample integer test).
 void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_unit_steps) {
-  const bool off = std::getenv("GC_NO_TIE_MARK") != nullptr;  // debugging aid: every block takes the in-kernel tests
+  const bool off = GC_TUNE_ENV("GC_NO_TIE_MARK") != nullptr;  // debugging aid: every block takes the in-kernel tests
   for (int64_t i = 0; i < n; ++i) {
     gc_block& k = b[i];
     k.reserved &= ~3;
@@ -660,6 +660,7 @@ void gc_mark_tie_free(const gc_context* ctx, gc_block* b, int64_t n, double eps_
   }
 }
 
+extern "C" int gc_build_flags(void) { return GC_TUNING ? GC_BUILD_TUNING : 0; }
 extern "C" int gc_debug_last_kernel(const gc_context* ctx) { return ctx ? ctx->last_kernel : -2; }
 extern "C" int gc_debug_last_track_mode(const gc_context* ctx) { return ctx ? ctx->last_track_mode : -1; }
 

@@ -80,9 +80,9 @@ bool ledger_fits(const std::vector<ResidentGrid>& set, const ResidentGrid& add, 
 
 hipError_t gc_launch_persistent(gc_context* ctx, const void* fn, dim3 grid, dim3 block, void** args, unsigned int smem) {
   bool coop = !ctx->concurrent_jobs;
-  if (const char* e = std::getenv("GC_PERSIST_COOP")) coop = std::atoi(e) != 0;
+  if (const char* e = GC_TUNE_ENV("GC_PERSIST_COOP")) coop = std::atoi(e) != 0;
   if (coop) {
-    if (std::getenv("GC_TRACK_DEBUG")) {
+    if (GC_TUNE_ENV("GC_TRACK_DEBUG")) {
       int occ = 0;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)block.x, smem);
       std::fprintf(stderr, "gc_launch_persistent: cooperative, grid %u x %u threads, %u B of LDS, occupancy %d workgroups per CU x %d CUs\n", grid.x, block.x, smem, occ,
@@ -94,7 +94,7 @@ hipError_t gc_launch_persistent(gc_context* ctx, const void* fn, dim3 grid, dim3
   int occ = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)block.x, smem);
   if (e != hipSuccess) return e;
-  if (const char* ev = std::getenv("GC_PERSIST_OCC")) occ = std::min(occ, std::atoi(ev));  // tests: pretend the kernel needs more of a CU
+  if (const char* ev = GC_TUNE_ENV("GC_PERSIST_OCC")) occ = std::min(occ, std::atoi(ev));  // tests: pretend the kernel needs more of a CU
   if (occ < 1) return hipErrorCooperativeLaunchTooLarge;
   const int nx = xcds_of(ctx->compute_units);
   const ResidentGrid mine{ctx, (int)((grid.x + nx - 1) / nx), occ};
@@ -134,7 +134,7 @@ MultiStreams* multi_streams(int device) {
   MultiStreams& m = pool[device];
   if (!made[device]) {
     made[device] = true;
-    if (std::getenv("GC_MULTI_OWN_STREAMS") == nullptr && hipSetDevice(device) == hipSuccess) {
+    if (GC_TUNE_ENV("GC_MULTI_OWN_STREAMS") == nullptr && hipSetDevice(device) == hipSuccess) {
       int least = 0, greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       const int prio[3] = {0, greatest, least};
@@ -231,7 +231,7 @@ extern "C" int gc_track_multi(int njobs, gc_track_job* jobs) {
   }
   std::vector<std::thread> workers;
   workers.reserve((size_t)njobs);
-  const bool timing = std::getenv("GC_TRACK_TIMING") != nullptr;
+  const bool timing = GC_TUNE_ENV("GC_TRACK_TIMING") != nullptr;
   const auto t_call = std::chrono::steady_clock::now();
   for (int i = 0; i < njobs; ++i)
     workers.emplace_back([&jobs, i, timing, t_call]() {

@@ -277,7 +277,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
     splits = gc_lane_splits(ctx, nch, approx_chunks * 8, 32);  // lane kernel: one wave per item, 16 items per workgroup
     if (splits == 1) splits = 16;  // the closed loop always goes through per-item records
   }
-  if (const char* e = std::getenv("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));
+  if (const char* e = GC_TUNE_ENV("GC_TRACK_SPLITS")) splits = std::max(1, std::min(32, std::atoi(e)));
 
   // pinned, device-visible descriptor and result buffers
   if (ctx->pinned_cap_blocks < nch * 32) {
@@ -292,7 +292,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   }
   // Results of the fast kernel arrive as host-mapped tagged 16-byte records (corr_common.h TaggedSlot): a
   // stream synchronise costs ~15-20 us of wake-up latency per epoch, polling the tags does not.
-  const bool poll = std::getenv("GC_TRACK_NO_POLL") == nullptr;
+  const bool poll = GC_TUNE_ENV("GC_TRACK_NO_POLL") == nullptr;
   int poll_timeout_ms = 2000;  // per epoch; GC_TRACK_POLL_TIMEOUT_MS overrides
   if (const char* ev = std::getenv("GC_TRACK_POLL_TIMEOUT_MS")) poll_timeout_ms = std::max(1, std::atoi(ev));
   const int64_t need_slots = (int64_t)nch * 32 * GC_OUT_STRIDE;
@@ -322,7 +322,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   ctx->last_track_mode = 0;
   bool persist = poll && !any_mixed && max_arms == 1 && fast_nominal > 0 && gc_fast_table_mode(ctx) == 0 && p->pilot_combine == 0 &&
                  p->table_phase_count == 0 && n_epochs > 0 &&
-                 !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
+                 !(GC_TUNE_ENV("GC_TRACK_PERSIST") && std::atoi(GC_TUNE_ENV("GC_TRACK_PERSIST")) == 0);
   const bool i8c_rec = ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL;  // int8 I/Q or Q/I (the derived-arm instantiation's only format)
   for (int c = 0; c < nch && persist; ++c) {
     const HostChannel& hcn = ctx->ch[init[c].channel];
@@ -333,7 +333,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   // gathers the team's sums, hands them to the host and relays the host's next descriptor
   const bool derived_nominal = any_mixed && all_mixed_derived && !any_three_plain;  // three arms, the third derived (E1-C CBOC)
   bool persist_lane = !persist && poll && ((!any_mixed && max_arms <= 2) || (derived_nominal && i8c_rec)) && n_epochs > 0 &&
-                      !(std::getenv("GC_TRACK_PERSIST") && std::atoi(std::getenv("GC_TRACK_PERSIST")) == 0);
+                      !(GC_TUNE_ENV("GC_TRACK_PERSIST") && std::atoi(GC_TUNE_ENV("GC_TRACK_PERSIST")) == 0);
   bool share_lane_nominal = true;
   for (int c = 0; c < nch && persist_lane; ++c) {
     gc_block probe;
@@ -387,7 +387,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   int psplits_dev = std::max(1, std::min({32, (4 * ctx->compute_units + nch_dev - 1) / nch_dev, std::max(1, approx_chunks * 8 / (fast_nominal == 2 ? 16 : 8) / 48)}));
   if (persist_lane)  // members of a lane-kernel team: workgroups of 8 waves (as gc_track_device)
     psplits_dev = std::max(1, std::min({max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4, approx_chunks * 8 / (64 * 8 * 2), std::max(1, 2 * ctx->compute_units / nch_dev)}));
-  if (const char* ev = std::getenv("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(persist_lane ? (max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4) : 32, std::atoi(ev)));
+  if (const char* ev = GC_TUNE_ENV("GC_TRACK_SPLITS")) psplits_dev = std::max(1, std::min(persist_lane ? (max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4) : 32, std::atoi(ev)));
   // A grid the device cannot hold whole (the teams spin on each other's messages) is refused by the launch: the teams are halved
   // until it fits - 192 channels x 1 member is still one launch for the whole call, where falling back to a launch per epoch cost
   // 33-90 us per epoch from 48 GPS L1 C/A channels on (bench.py closed_loop_sweep, round 4)
@@ -443,11 +443,11 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
         a.derived = derived_nominal ? 1 : 0;
         const int lrc = gc_launch_devloop_lane(ctx, a, (unsigned int)(nch * psplits_dev), max_arms, share_lane_nominal && !derived_nominal, 8);
         if (lrc != GC_OK) e = hipErrorUnknown;
-        refused = lrc == GC_E_UNSUPPORTED;
+        refused = lrc == GC_E_NOFIT;   // (only a grid that did not fit is retried with smaller teams)
       } else {
         const int lrc = gc_launch_devloop(ctx, a, (unsigned int)(nch * psplits_dev), fast_nominal == 2, a.share_el != 0);
         if (lrc != GC_OK) e = hipErrorUnknown;
-        refused = lrc == GC_E_UNSUPPORTED;
+        refused = lrc == GC_E_NOFIT;
       }
     }
     if (e != hipSuccess && refused && psplits_dev > 1) {
@@ -457,11 +457,11 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
       continue;
     }
     ctx->last_track_mode = e == hipSuccess ? 1 : 0;
-    if (e == hipSuccess && std::getenv("GC_TRACK_DEBUG"))
+    if (e == hipSuccess && GC_TUNE_ENV("GC_TRACK_DEBUG"))
       std::fprintf(stderr, "gc_track: persistent kernel: %d channels x %d members (%s kernel)\n", nch, psplits_dev, persist_lane ? "lane" : "fast");
     if (e == hipSuccess) ctx->last_kernel = persist_lane ? 0 : 1;  // gc_debug_last_kernel: lane / fast kernel (persistent instantiation)
     if (e != hipSuccess) {  // could not set the persistent kernel up: launch per epoch
-      if (std::getenv("GC_TRACK_DEBUG"))
+      if (GC_TUNE_ENV("GC_TRACK_DEBUG"))
         std::fprintf(stderr, "gc_track: persistent kernel refused (%s): %d channels x %d members, lane %d - launching per epoch\n", hipGetErrorString(e), nch,
                      psplits_dev, (int)persist_lane);
       (void)hipGetLastError();
@@ -676,7 +676,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
   // are still correlating or their records are on the way.  Lock step (the loop below) cost an epoch the sum of the PCIe round
   // trip, the team's work and the twelve closures; this way the round trip of one channel hides behind the others' work.
   // (Not under pause_at_end: a window of a streamed record must end all channels at the same epoch.)
-  const bool async = persist && poll && !(r && r->pause_at_end) && std::getenv("GC_TRACK_LOCKSTEP") == nullptr;
+  const bool async = persist && poll && !(r && r->pause_at_end) && GC_TUNE_ENV("GC_TRACK_LOCKSTEP") == nullptr;
   if (async) {
     const int arms6 = max_arms * 6;
     struct alignas(64) Slot {  // a channel's loop state on cache lines of its own: neighbouring channels may belong to other threads
@@ -696,7 +696,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
     // ... at 12 channels.  With the closed_loop_sweep's 96 / 192 channels the one closer is what the epoch waits for: 14.2 / 20.4 us on
     // one thread, 12.5 / 15.8 us on four - so one more thread per 64 channels, four at most.
     int nthreads = std::min(4, 1 + nch / 64);
-    if (const char* ev = std::getenv("GC_TRACK_THREADS")) nthreads = std::max(1, std::min({16, nch, std::atoi(ev)}));
+    if (const char* ev = GC_TUNE_ENV("GC_TRACK_THREADS")) nthreads = std::max(1, std::min({16, nch, std::atoi(ev)}));
     auto serve = [&](int t) {
       const int c0 = (int)((long long)t * nch / nthreads), c1 = (int)((long long)(t + 1) * nch / nthreads);
       int outstanding = 0;
@@ -840,7 +840,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
     t_launch += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
     t_wait += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
     if (!signalled) {
-      if (persist && std::getenv("GC_TRACK_TIMING")) {
+      if (persist && GC_TUNE_ENV("GC_TRACK_TIMING")) {
         const hipError_t q = hipStreamQuery(ctx->stream);
         std::fprintf(stderr, "gc_track persistent: epoch %d records missing; stream: %s; first tags:", e, hipGetErrorString(q));
         for (int k = 0; k < std::min(nb, 16); ++k) std::fprintf(stderr, " %u", tagged[(size_t)slot[k] * GC_OUT_STRIDE].tag);
@@ -912,7 +912,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
     (void)hipStreamSynchronize(ctx->stream);
     persist_free();
   }
-  if (std::getenv("GC_TRACK_TIMING") && n_epochs > 0)
+  if (GC_TUNE_ENV("GC_TRACK_TIMING") && n_epochs > 0)
     std::fprintf(stderr, "gc_track: per epoch %.2f us in the launch call / descriptor writes, %.2f us until the records arrived, %.2f us total (%s, %d workgroups per block)\n",
                  t_launch / n_epochs, t_wait / n_epochs,
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count() / n_epochs,
@@ -1020,7 +1020,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     // team size: just under one lane-chunk per lane and member — the epoch is a latency chain
     const int chunks = (int)(p->code_length / (p->code_freq_basis / p->sampling_freq) / spl) + 1;
     splits = std::max(1, std::min({32, (4 * ctx->compute_units + nch_dev - 1) / nch_dev, std::max(1, chunks / 32)}));
-    if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
+    if (const char* e = GC_TUNE_ENV("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(32, std::atoi(e)));  // closer polls <= 62 messages
     if (ctx->persist_member_cap > 0) splits = std::min(splits, ctx->persist_member_cap);
     msgs_per_member = 2;
   } else {
@@ -1028,17 +1028,17 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     // member workgroups per channel: about four 64-sample steps per lane; the closer polls (members - 1) * 6 * arms <= 64 messages
     const int nsamp = hc[0].blk.blksize;
     lane_waves = 8;  // measured best for both the 1-ms and the 4-ms packages (scripts/devloop_lane_sweep.py)
-    if (const char* e = std::getenv("GC_DEVLOOP_WAVES")) lane_waves = std::max(1, std::min(8, std::atoi(e)));  // the device-loop instantiations are bounded to 8 waves
+    if (const char* e = GC_TUNE_ENV("GC_DEVLOOP_WAVES")) lane_waves = std::max(1, std::min(8, std::atoi(e)));  // the device-loop instantiations are bounded to 8 waves
     const int max_members = max_arms == 1 ? 8 : max_arms == 2 ? 6 : 4;  // (members - 1) * 6 * arms messages <= 64 lanes
     splits = std::max(1, std::min({max_members, nsamp / (64 * lane_waves * 2), std::max(1, 2 * ctx->compute_units / nch_dev)}));
-    if (const char* e = std::getenv("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_members, std::atoi(e)));
+    if (const char* e = GC_TUNE_ENV("GC_DEVLOOP_MEMBERS")) splits = std::max(1, std::min(max_members, std::atoi(e)));
     if (ctx->persist_member_cap > 0) splits = std::min(splits, ctx->persist_member_cap);
     msgs_per_member = 6 * max_arms;
   }
   // Teams on one XCD each (default).  Not next to other contexts' persistent kernels (gc_track_multi): two kernels that pin
   // their teams to the same XCDs were measured to run one after the other (E1 lane kernel 32 ms = its own 11 ms + the L1 C/A
   // kernel's 21 ms beside it), spread over the device they overlap completely and lose nothing alone (88.7 vs 89.7 ms).
-  const bool xcd_local = std::getenv("GC_DEVLOOP_SPREAD") == nullptr && !ctx->concurrent_jobs;
+  const bool xcd_local = GC_TUNE_ENV("GC_DEVLOOP_SPREAD") == nullptr && !ctx->concurrent_jobs;
 
   gcorr::DevLoopArgs ha;
   std::memset(&ha, 0, sizeof ha);
@@ -1053,8 +1053,8 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   ha.n_epochs = n_epochs;
   ha.splits = splits;
   ha.code_index_scale_is_one = 1;
-  if (const char* e = std::getenv("GC_DEVLOOP_SCOPE")) ha.reserved = std::atoi(e);  // message scope (devloop.h): 0 system (default), 2 agent
-  ha.timing = std::getenv("GC_DEVLOOP_TIMING") ? std::atoi(std::getenv("GC_DEVLOOP_TIMING")) : 0;  // 1: host + in-kernel phase clocks, 2: host only
+  if (const char* e = GC_TUNE_ENV("GC_DEVLOOP_SCOPE")) ha.reserved = std::atoi(e);  // message scope (devloop.h): 0 system (default), 2 agent
+  ha.timing = GC_TUNE_ENV("GC_DEVLOOP_TIMING") ? std::atoi(GC_TUNE_ENV("GC_DEVLOOP_TIMING")) : 0;  // 1: host + in-kernel phase clocks, 2: host only
   gcorr::DevLoopArgs* d_args = nullptr;
   const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
   const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * msgs_per_member * (use_fast ? 2 : 1),  // fast kernel: two alternating halves
@@ -1072,7 +1072,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     gc_set_error("gc_track_device: %s", hipGetErrorString(e));
     return GC_E_NOMEM;
   }
-  ha.one_writer = std::getenv("GC_DEVLOOP_ONE_WRITER") != nullptr;
+  ha.one_writer = GC_TUNE_ENV("GC_DEVLOOP_ONE_WRITER") != nullptr;
   if (want_cno) {
     ha.cno = (double*)ctx->trk[gc_context::TRK_CNO].p;
     ha.cno_nk = cno_nk;
@@ -1118,8 +1118,9 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   const unsigned int grid = xcd_local ? (unsigned int)(((nch + 7) / 8) * 8 * splits) : (unsigned int)(nch * splits);
   a.derived = cboc ? 1 : 0;
   rc = use_fast ? gc_launch_devloop(ctx, a, grid, lowrate == 2, share) : gc_launch_devloop_lane(ctx, a, grid, max_arms, share_lane && !cboc, lane_waves);
-  if (rc == GC_E_UNSUPPORTED && splits > 1) {
-    // the grid does not fit the device whole: the same call again with teams half the size (see gc_track's persistent launch)
+  if (rc == GC_E_NOFIT && splits > 1) {
+    // the grid does not fit the device whole: the same call again with teams half the size (see gc_track's persistent launch);
+    // a structural refusal (no instantiation for these tables / arms) is not retried
     cleanup();
     const int cap0 = ctx->persist_member_cap;
     ctx->persist_member_cap = (splits + 1) / 2;
@@ -1127,6 +1128,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
     ctx->persist_member_cap = cap0;
     return rc;
   }
+  if (rc == GC_E_NOFIT) rc = GC_E_UNSUPPORTED;  // one member per channel and still no room: the caller falls back to gc_track
   if (rc == GC_OK) {
     ctx->last_track_mode = 2;
     const auto t_l = std::chrono::steady_clock::now();

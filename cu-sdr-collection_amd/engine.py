@@ -321,9 +321,6 @@ class Engine:
         codes = np.ascontiguousarray(sampled_codes, dtype=np.int8)
         nprn = codes.shape[0]
         narms = codes.shape[1] if codes.ndim == 3 else 1
-        n = int(params.block_len) if params.block_len else 2 * codes.shape[-1]
-        bins = int(params.n_bins) if params.n_bins else int(math.floor(params.search_band * 2 / params.search_step + 0.5)) + 1
-        self._count_transforms(n, forward=bins * int(params.non_coh_time), code=nprn * narms, inverse=nprn * narms * bins * int(params.non_coh_time))
         res = (L.gc_acq_result * nprn)()
         if freq_offset is None:
             L.check(self._lib.gc_acquire_coarse_multi(self._ctx, C.byref(params), nprn, narms,
@@ -334,6 +331,10 @@ class Engine:
                 raise ValueError("acquire_coarse: one frequency offset per row")
             L.check(self._lib.gc_acquire_coarse_offsets(self._ctx, C.byref(params), nprn, narms, codes.ctypes.data_as(C.c_void_p),
                                                         off.ctypes.data_as(C.POINTER(C.c_double)), res))
+        # bench bookkeeping, after the library has accepted the parameters (it must never change the call's error behaviour)
+        n = int(params.block_len) if params.block_len else 2 * codes.shape[-1]
+        bins = int(params.n_bins) if params.n_bins else int(math.floor(params.search_band * 2 / params.search_step + 0.5)) + 1
+        self._count_transforms(n, forward=bins * int(params.non_coh_time), code=nprn * narms, inverse=nprn * narms * bins * int(params.non_coh_time))
         return list(res)
 
     def acquire_fine_sums(self, params: L.gc_fine_params, code: np.ndarray) -> np.ndarray:

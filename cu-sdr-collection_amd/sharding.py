@@ -1,6 +1,7 @@
-"""Channel sharding for multi-GPU runs: tracking channels are independent
-(tracking.m:133 loop body shares nothing but the read-only IF record), so the partition is by
-channel, one process per GPU, no data-path collective."""
+"""Channel sharding for multi-GPU runs: tracking channels are independent (tracking.m:133 loop body shares nothing
+but the read-only IF record), so the partition is by channel, one process per GPU.  The ONE exchange step of the data path is the
+hand-over of a band's raw record from the rank that read it to the other ranks that track channels of that band (broadcast_record /
+distribute_band_records: RCCL broadcast of the GPU tensor, one sub-group per band); nothing is exchanged per epoch."""
 from __future__ import annotations
 
 
@@ -16,12 +17,17 @@ CLOSED_LOOP_US_PER_EPOCH = {
 # the largest measured count whose epoch time is within 1.25x of the smallest count's (`knee_channels` of the sweep); signals that
 # were not swept take the entry of their kernel class: "fast" (<= 1 table transition per 16-sample chunk) or "lane"
 CLOSED_LOOP_KNEE = {"GPS_L1CA": 24, "GPS_L5C": 32, "fast": 24, "lane": 32}
-
+# kernel class of the closed loop per package (gc_block_lowrate_level at the package's default front end): table entries per sample
+# step * R - at most one table transition per 8-sample chunk (7 * step * R < 1) runs the fast kernel: the 0.511 / 1.023 / 2.046-Mcps
+# codes at 12 - 18 Msps, BOC(1,1) half-chip tables included; the 10.23-Mcps codes and the three-arm channels with a derived BOC(6,1)
+# arm run the lane kernel
+SIGNAL_CLASS = {"GPS_L1CA": "fast", "GLO_GL1": "fast", "GLO_GL2": "fast", "GPS_L2C": "fast", "BDS_B1I": "fast", "GAL_E1C": "fast", "BDS_B1C_NB": "fast",
+                "GAL_E1C_CBOC": "lane", "BDS_B1C_WB": "lane", "GPS_L5C": "lane", "GAL_E5a": "lane", "GAL_E5b": "lane", "BDS_B2a": "lane", "BDS_B3I": "lane"}
 
 def expected_us_per_epoch(n_channels: int, signal: str = "GPS_L1CA") -> float:
     """Host-closed loop of `n_channels` on one GPU: the sweep's measurement, interpolated linearly in the channel count (held flat
     below the first point, extended with the last segment's slope above the last)."""
-    cls = signal if signal in CLOSED_LOOP_US_PER_EPOCH else ("GPS_L1CA" if CLOSED_LOOP_KNEE.get(signal, 0) == CLOSED_LOOP_KNEE["fast"] else "GPS_L5C")
+    cls = signal if signal in CLOSED_LOOP_US_PER_EPOCH else ("GPS_L1CA" if SIGNAL_CLASS.get(signal, "lane") == "fast" else "GPS_L5C")
     pts = sorted(CLOSED_LOOP_US_PER_EPOCH[cls].items())
     if n_channels <= pts[0][0]:
         return pts[0][1]
@@ -47,10 +53,7 @@ def recommended_world_size(n_channels: int, signal: str = "GPS_L1CA", max_gpus: 
         return max_gpus
     knee = CLOSED_LOOP_KNEE.get(signal)
     if knee is None:
-        from . import signals
-        spec = signals.SIGNALS.get(signal)
-        rate = getattr(spec, "chips_per_second", None) if spec is not None else None
-        knee = CLOSED_LOOP_KNEE["fast" if (rate is not None and rate <= 2.1e6) else "lane"]
+        knee = CLOSED_LOOP_KNEE[SIGNAL_CLASS.get(signal, "lane")]
     return max(1, min(max_gpus, -(-n_channels // knee)))
 
 

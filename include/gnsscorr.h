@@ -56,6 +56,10 @@ enum gc_layout { GC_REAL = 0, GC_IQ = 1, GC_QI = 2 };
 int gc_create(gc_context** ctx, int device_id);
 int gc_destroy(gc_context* ctx);
 const char* gc_last_error(void);
+/* What this library was built as.  GC_BUILD_TUNING: libgnsscorr_tuning.so (-DGC_TUNING=1) - the kernels' A/B switches of
+ * docs/KNOBS.md are live environment variables and the experimental kernels are linked in; the library that ships reads none. */
+enum { GC_BUILD_TUNING = 1 };
+int gc_build_flags(void);
 int gc_api_version(void);
 /* Device name / CU count of the context's device (for bench reporting). */
 int gc_device_info(gc_context* ctx, char* name, int name_len, int* compute_units);

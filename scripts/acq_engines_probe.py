@@ -1,6 +1,8 @@
 """Does the default GPS L1 C/A search take the same time in every engine of a process?  Six engines made one after the other, each timed
 while the earlier ones are alive, with two PRN lanes and with one (GC_ACQ_LANE_STREAMS=own: a stream pair per context - the second engine
 searched in 3.65 instead of 2.77 ms; default: the device's search streams)."""
+import os as _os
+_os.environ.setdefault("GC_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "cu-sdr-collection_amd", "lib", "libgnsscorr_tuning.so"))  # the GC_* switches used below exist in the tuning build only (docs/KNOBS.md)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,7 @@
 """Does the intermediate's footprint matter?  The default GPS L1 C/A search with fewer frequency bins (the intermediate of one PRN is
 bins x 20 hops x 288 KB; two PRN lanes hold two): microseconds per inverse transform, one and two lanes.  The last-level cache holds 256 MB."""
+import os as _os
+_os.environ.setdefault("GC_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "cu-sdr-collection_amd", "lib", "libgnsscorr_tuning.so"))  # the GC_* switches used below exist in the tuning build only (docs/KNOBS.md)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

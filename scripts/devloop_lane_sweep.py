@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("GC_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "cu-sdr-collection_amd", "lib", "libgnsscorr_tuning.so"))  # the GC_* switches used below exist in the tuning build only (docs/KNOBS.md)
 import os, sys, subprocess, json
 for waves in (2, 4, 8, 16):
     for members in (1, 2, 4, 6):

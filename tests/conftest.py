@@ -10,6 +10,25 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "tuning: switches kernels through GC_* tuning variables, which only libgnsscorr_tuning.so reads "
+                                       "(GC_LIB_PATH; tests/test_gpu_tuning_build.py runs these in a process that loads it)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Knob tests need the tuning build: with the library that ships the GC_* switches are compiled out (gc_internal.h GC_TUNE_ENV) and
+    setting them changes nothing.  They run in the child process of tests/test_gpu_tuning_build.py; here they are skipped."""
+    tuned = [it for it in items if it.get_closest_marker("tuning")]
+    if not tuned:
+        return
+    try:
+        from cu_sdr_collection_amd import _lib as L
+        is_tuning = L.is_tuning_build()
+    except Exception:
+        return                                    # no library / no GPU: the tests fail on their own, loudly
+    if not is_tuning:
+        skip = pytest.mark.skip(reason="needs libgnsscorr_tuning.so (run by tests/test_gpu_tuning_build.py with GC_LIB_PATH set)")
+        for it in tuned:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -273,7 +273,10 @@ def test_big_periodic_replay_lists_take_the_four_wave_kernels_and_match_the_orac
         engine.set_channel(k, [t])
     _, cus = engine.device_info()
     nb = 64 * 2 * cus + 2 * 37                      # just over the launcher's big-list threshold, not a multiple of 8 epochs
+    from cu_sdr_collection_amd import _lib as L
     for spacing, env, want in ((0.5, {}, 3), (0.5, {"GC_NO_TABF": "1"}, 2), (0.3, {}, 3)):
+        if env and not L.is_tuning_build():          # the switch back to the int8-pair tables exists in libgnsscorr_tuning.so only
+            continue
         descs = _random_descs(rng, nb, nsamp, 2)
         for i, d in enumerate(descs):
             d["channel"] = i % 2
@@ -313,7 +316,10 @@ def test_big_periodic_replay_with_eight_sample_chunks(engine, monkeypatch):
     _, cus = engine.device_info()
     nb = 64 * 2 * cus + 2 * 11
     # (GC_NO_MULTI: without it such a list goes to corr_multi.hip - 16-sample chunks with two transitions, kernel 4, third pass)
+    from cu_sdr_collection_amd import _lib as L
     for env, want in (({"GC_NO_MULTI": "1"}, 3), ({"GC_NO_MULTI": "1", "GC_NO_TABF": "1"}, 2), ({}, 4)):
+        if env and not L.is_tuning_build():          # the 8-sample kernels behind their switches: libgnsscorr_tuning.so only
+            continue
         descs = _random_descs(rng, nb, nsamp, 2, fc=2.046e6, L=2046.0)
         for i, d in enumerate(descs):
             d["channel"] = i % 2

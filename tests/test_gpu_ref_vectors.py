@@ -182,6 +182,7 @@ def test_hip_acquisition_at_the_references_default_search_sizes(engine, sc):
 _ACQ_FUSED_DEFAULT = ("GPS_L1CA_default", "GPS_L5C_default", "GAL_E5a_default", "BDS_B2a_default", "BDS_B3I_default", "GLO_GL1_default", "GLO_GL2_default")
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("sc", [s for s in RS.DEFAULT_ACQ_SCENES if s.name in _ACQ_FUSED_DEFAULT], ids=[s.name for s in RS.DEFAULT_ACQ_SCENES if s.name in _ACQ_FUSED_DEFAULT])
 def test_fused_inverse_transform_kernel_at_the_references_default_search_sizes(engine, sc, monkeypatch):
     """GC_ACQ_FUSED=1 (the single-launch inverse side) on the same default-size searches."""
@@ -193,6 +194,7 @@ def test_fused_inverse_transform_kernel_at_the_references_default_search_sizes(e
     _compare_acq(sc, z, sc.product(P, engine, S))
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("name", ["GPS_L1CA_default", "GPS_L5C_default"])
 def test_default_size_searches_in_one_chunk_of_bins(engine, monkeypatch, name):
     """The default GPS L1 C/A and L5 searches run their bins in two chunks (both lanes' intermediates then fit the last-level cache,
@@ -206,6 +208,7 @@ def test_default_size_searches_in_one_chunk_of_bins(engine, monkeypatch, name):
     _compare_acq(sc, z, sc.product(P, engine, S))
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("name", ["BDS_B1I_default", "GPS_L2C_default", "BDS_B1C_default"])
 def test_circshift_family_at_the_default_sizes_prn_by_prn(engine, monkeypatch, name):
     """The circshift family's default-size searches run as ONE library call per package (gc_acq_shift_search_batch, the default path of
@@ -251,6 +254,7 @@ _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": 
               ("BDS_B1I", {"GC_ACQ_SHIFT_LANES": "1"}), ("GPS_L2C", {"GC_ACQ_SHIFT_LANES": "2"}), ("BDS_B1C", {"GC_ACQ_SHIFT_LANES": "2"})]
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("name,env", _ACQ_KNOBS, ids=[f"{n}-{'+'.join(e)}" for n, e in _ACQ_KNOBS])
 def test_acquisition_paths_behind_the_tuning_knobs_return_the_references_results_too(engine, monkeypatch, name, env):
     """The round-4 additions of the search each have a switch back to what they replaced - one PRN lane instead of two streams
@@ -273,6 +277,7 @@ def test_acquisition_paths_behind_the_tuning_knobs_return_the_references_results
 _ACQ_FUSED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "GAL_E5b", "BDS_B2a", "BDS_B3I", "GLO_GL1")   # searches of 36 000 / 24 000 points
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("sc", [s for s in RS.ACQ_SCENES if s.name in _ACQ_FUSED], ids=[s.name for s in RS.ACQ_SCENES if s.name in _ACQ_FUSED])
 def test_fused_inverse_transform_kernel_equals_the_references_acquisition_m(engine, sc, monkeypatch):
     """GC_ACQ_FUSED=1: the inverse side of the search in one launch (acq_fused_kernel: radix-4 decimation-in-frequency step, four

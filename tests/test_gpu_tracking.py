@@ -611,8 +611,11 @@ def test_galileo_e1c_cboc_pilot_tracking_matches_oracle(engine):
         for f in ("I_P", "Q_P", "Pilot_I_E", "Pilot_I_P", "Pilot_Q_P", "Pilot_I_L"):
             assert np.max(np.abs(getattr(dev[k], f) - getattr(ref[k], f))) < 1e-5 * 2.0 * 72000 * 28.0, f
         assert np.max(np.abs(dev[k].carrFreq - ref[k].carrFreq)) < 1e-3
-    # the same through the exact per-sample kernel
+    # the same through the exact per-sample kernel (its switch exists in libgnsscorr_tuning.so only)
     import os
+    from cu_sdr_collection_amd import _lib as L
+    if not L.is_tuning_build():
+        return
     os.environ["GC_NO_DERIVED_ARM"] = "1"
     try:
         tr2, _ = P.tracking(engine, ch, S, signal="GAL_E1C_CBOC")
@@ -645,6 +648,7 @@ def test_config4_l5_and_b2a_at_50_msps(engine):
                 "a", 1150.0, (20, 44), 53)
 
 
+@pytest.mark.tuning
 def test_persistent_and_launch_per_epoch_host_loops_agree(engine, l1ca_scene, monkeypatch):
     """gc_track closes the loop on the host either way; the correlator runs as one persistent, host-fed kernel (default where
     the configuration allows it) or as one launch per epoch (GC_TRACK_PERSIST=0).  Same block geometry, sums within the
@@ -669,6 +673,7 @@ def test_persistent_and_launch_per_epoch_host_loops_agree(engine, l1ca_scene, mo
         assert np.max(np.abs(a[k].carrFreq - b[k].carrFreq)) < 1e-4
 
 
+@pytest.mark.tuning
 def test_host_loops_dealt_out_to_several_host_threads_give_the_same_records(engine, l1ca_scene, monkeypatch):
     """GC_TRACK_THREADS: the persistent kernel's channels served by three host threads (measured, not faster, so one
     thread is the default).  A channel's loop never depends on which thread closes it: bit-identical records, and the lock-step

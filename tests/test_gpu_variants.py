@@ -222,6 +222,7 @@ def test_lane_kernel_work_decompositions(engine):
     assert np.max(np.abs(got - engine.correlate(b))) < 0.2   # decomposition (C) of the same list: float sums only reorder
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("case", ["l5_50msps_share", "l5_50msps_three_ramps", "e1_share", "e1_three_ramps", "b1i_one_arm_qi", "l5_50msps_int16", "e1_int16_qi"])
 def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine, monkeypatch, case):
     """corr_multi.hip: periodic replay lists whose 16-sample chunks cross up to 2 (Galileo E1 / BDS B1I-type tables at 18 Msps) or
@@ -287,6 +288,7 @@ def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine,
         assert np.max(np.abs(got[k, :arms] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :arms] - ref)) / scale[k])
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("case", ["e1_cboc", "e1_cboc_qi", "b1c_wb"])
 def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, monkeypatch, case):
     """corr_cboc.hip: periodic replay lists of three-arm channels whose third arm is the six-fold replica of the second (Galileo E1-C

@@ -300,6 +300,14 @@ def test_recommended_world_size_follows_the_closed_loop_sweep():
     assert S.recommended_world_size(knee + 1) == 2 and S.recommended_world_size(8 * knee) == 8 and S.recommended_world_size(100 * knee) == 8
     assert S.recommended_world_size(64, "GPS_L5C") == 2 and S.recommended_world_size(64, "GAL_E5a") == S.recommended_world_size(64, "GPS_L5C")
     assert S.recommended_world_size(64, "GPS_L1CA", max_gpus=2) == 2
+    # packages that were not swept take the knee of their closed loop's kernel class (the class came from an attribute
+    # SignalSpec does not have, so every unlisted signal was "lane"): GLONASS and BDS B1I run the fast kernel, BDS B3I the lane kernel
+    from cu_sdr_collection_amd import signals
+    assert set(S.SIGNAL_CLASS) == set(signals.SIGNALS)
+    assert S.recommended_world_size(48, "GLO_GL1") == S.recommended_world_size(48, "BDS_B1I") == S.recommended_world_size(48, "GPS_L1CA") == 2
+    assert S.recommended_world_size(33, "BDS_B3I") == 2 and S.recommended_world_size(32, "BDS_B3I") == 1
+    assert S.expected_us_per_epoch(24, "GLO_GL1") == S.expected_us_per_epoch(24, "GPS_L1CA")
+    assert S.expected_us_per_epoch(32, "BDS_B3I") == S.expected_us_per_epoch(32, "GPS_L5C")
     pts = S.CLOSED_LOOP_US_PER_EPOCH["GPS_L1CA"]
     for n, us in pts.items():
         assert S.expected_us_per_epoch(n) == us
