@@ -636,3 +636,60 @@ def test_block_and_replica_lengths_of_the_coarse_search_are_checked(engine, acq_
     with pytest.raises(P.GnssCorrError) as e:
         engine.acquire_coarse(p, table)
     assert e.value.status == L.GC_E_RANGE
+
+
+def test_shift_search_batch_equals_the_search_prn_by_prn_and_checks_its_arguments(engine):
+    """gc_acq_shift_search_batch (BDS/B1I acquisition.m:76-176 as one call): the picks of the whole PRN list - winning row by the
+    package's sequential rule, first maximum of that row, second peak - against the same search PRN by PRN (gc_acq_shift_search's row
+    maxima, gc_acq_shift_row's winning row, the rules of acq_shift.py on the host); the codes once as sampled, zero-padded replicas and
+    once as chip tables + the one index vector (the padding done on the device): identical picks.  Then the argument checks."""
+    import ctypes as C
+    import cu_sdr_collection_amd as P
+    from cu_sdr_collection_amd import _lib as L, acq_shift as A
+    from cu_sdr_collection_amd.settings import initSettings_BDS_B1I
+    S = initSettings_BDS_B1I()
+    fs = S.samplingFreq
+    rng = np.random.default_rng(91)
+    sats = [P.synth.SatSpec(prn=p, doppler=d, code_phase_samples=float(rng.uniform(0, 18000)), carrier_phase=float(rng.uniform(0, 6.28)), cn0_dbhz=c)
+            for p, d, c in ((9, 1310.0, 49.0), (21, -2890.0, 48.0))]
+    iq = P.synth.generate_if(sats, int(0.010 * fs), fs, S.IF, P.codes.generateCAcode53, S.codeFreqBasis, 2046, seed=92, carrier_ratio=763.0 * 2, bit_periods=20)
+    engine.load_if(iq, fs=fs)
+    spb, nbins, nshifts, chip = 72000, 41, 2, 9
+    p = L.gc_acq_shift_params(sampling_freq=fs, carrier_f0=S.IF + 5000.0, carrier_step=62.5, first_sample=0, n=spb, n_signals=2, n_carriers=nshifts,
+                              n_bins=nbins, n_arms_max=1, source=0)
+    engine.acq_shift_prepare(p)
+    prns = [9, 14, 21]                                        # 14 is absent: its winner is a noise row, still the same row both ways
+    index = A._sample_index(36000, 1.0 / fs, 1.0 / S.codeFreqBasis, True, 2 * 2046)
+    chips = np.stack([np.tile(P.codes.generateCAcode53(q).astype(np.int8), 2)[None, :] for q in prns])
+    sampled = np.stack([np.concatenate([c[0][index], np.zeros(spb // 2, dtype=np.int8)])[None, :] for c in chips])
+    picks_idx = engine.acq_shift_search_batch(chips, None, L.GC_SHIFT_PICK_SEQUENTIAL_PAIRS, chip, spb // 4, sample_index=index)
+    picks_smp = engine.acq_shift_search_batch(sampled, None, L.GC_SHIFT_PICK_SEQUENTIAL_PAIRS, chip, spb // 4)
+    for k, q in enumerate(prns):
+        rmax, _ = engine.acq_shift_search(sampled[k])
+        r3 = rmax.reshape(nshifts, 2, nbins)
+        win = A._first_maximum(np.maximum(r3[:, 0, :], r3[:, 1, :]))
+        row = (win[0] * 2 + (0 if r3[win[0], 0, win[1]] > r3[win[0], 1, win[1]] else 1)) * nbins + win[1]
+        corr = engine.acq_shift_row(row)
+        cp = int(np.argmax(corr))
+        for pk in (picks_idx[k], picks_smp[k]):
+            assert (pk.row, pk.code_phase) == (row, cp), (q, pk.row, row, pk.code_phase, cp)
+            assert pk.peak == corr[cp] and pk.second_peak == np.float32(A._second_peak(corr, cp + 1, chip, spb // 4))
+    # a present satellite's peak stands out of its second peak; the absent one's does not
+    assert picks_idx[0].peak / picks_idx[0].second_peak > S.acqThreshold > picks_idx[1].peak / picks_idx[1].second_peak
+    # ---- arguments ----------------------------------------------------------------------------------------------------------------
+    lib, ctx = engine._lib, engine._ctx
+    out = (L.gc_acq_shift_pick * 3)()
+    c8 = np.ascontiguousarray(chips)
+    i32 = np.ascontiguousarray(index, dtype=np.int32)
+
+    def call(nprn=3, narms=1, codes=c8, code_len=4092, idx=i32, nidx=36000, rule=L.GC_SHIFT_PICK_SEQUENTIAL_PAIRS, excl=chip, period=spb // 4):
+        return lib.gc_acq_shift_search_batch(ctx, nprn, narms, codes.ctypes.data_as(C.c_void_p), code_len, None if idx is None else idx.ctypes.data_as(C.c_void_p),
+                                             nidx, None, rule, excl, period, out)
+    assert call() == L.GC_OK
+    assert call(nprn=0) == L.GC_E_INVALID and call(narms=2) == L.GC_E_INVALID and call(rule=7) == L.GC_E_INVALID
+    assert call(rule=L.GC_SHIFT_PICK_SEQUENTIAL) == L.GC_E_INVALID            # two signal blocks were prepared: the pairs rule only
+    assert call(period=spb + 1) == L.GC_E_INVALID and call(excl=-1) == L.GC_E_INVALID and call(nidx=spb + 1) == L.GC_E_INVALID
+    bad = i32.copy()
+    bad[17] = 4092                                                             # one past the last chip
+    assert call(idx=bad) == L.GC_E_INVALID and b"sample_index[17]" in lib.gc_last_error()
+    assert call(rule=L.GC_SHIFT_PICK_GLOBAL, excl=0, period=1) == L.GC_OK and out[0].second_peak == 0.0 and out[0].row >= 0
