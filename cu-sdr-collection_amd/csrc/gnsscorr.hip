@@ -988,7 +988,10 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
   {
     std::vector<gc_block> marked(blocks, blocks + nblocks);
     // the band the kernel that may take the list tests in: 8e-6 samples of ramp = twice the 4e-6 of corr_fast.hip and corr_multi.hip
-    gc_mark_tie_free(ctx, marked.data(), nblocks, (ctx->replay_kt > 0 || ctx->replay_kt6 > 0 || ctx->replay_fast > 0) ? 8e-6 : 0.0);
+    // (a list of derived-arm channels needs the wide band only where corr_cboc.hip may take it: the tuning build with GC_CBOC set -
+    // with it on every such list the lane kernel lost its tie-free marks on ~40 % of config 3's blocks, 0.26 -> 0.22)
+    const bool cboc_list = GC_TUNING && GC_TUNE_ENV("GC_CBOC") != nullptr && ctx->replay_kt6 > 0;
+    gc_mark_tie_free(ctx, marked.data(), nblocks, (ctx->replay_kt > 0 || cboc_list || ctx->replay_fast > 0) ? 8e-6 : 0.0);
     GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, marked.data(), sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
   }

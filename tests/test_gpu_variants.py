@@ -294,7 +294,7 @@ def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, monkey
     """corr_cboc.hip: periodic replay lists of three-arm channels whose third arm is the six-fold replica of the second (Galileo E1-C
     CBOC as BASELINE config 3 words it; BDS/B1C/include/WB_tracking.m:285-317,338-369): the BOC(1,1) arms through the transition
     formulation, the BOC(6,1) arm as a per-sample sign on the carrier-wiped samples.  The same list through the lane kernel's
-    derived-arm instantiation (GC_NO_CBOC=1) and, block by block, through the float64 oracle (every index from ceil(t) / ceil(6 t));
+    derived-arm instantiation (without GC_CBOC) and, block by block, through the float64 oracle (every index from ceil(t) / ceil(6 t));
     blocks that start on exact chip edges with the nominal rational step (tie-dense: sample 0 sits on an edge of all three tables of
     the prompt tap) included, and the whole list once more with no block marked tie-free (GC_NO_TIE_MARK: every chunk takes the
     in-kernel tests)."""
