@@ -700,7 +700,7 @@ def run_closed_loop_sweep(P, W, device, seconds: float, l1_points=(12, 24, 48, 9
 # =======================================================================================================================
 # the other BASELINE configs: a band record, one job per package, closed loops + replay
 # =======================================================================================================================
-def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, seed, steps, warmup, dtype=np.int8):
+def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, seed, steps, warmup, dtype=np.int8, side_by_side=True):
     """parts = [(package, channels)] tracked from ONE record.  Returns (summary dict, jobs)."""
     engines = [P.Engine(device) for _ in parts]
     t0 = time.time()
@@ -743,7 +743,7 @@ def run_band_jobs(P, W, name, device, parts, seconds, fs, intermediate_freq, see
     nch = sum(len(j.sats) for j in jobs)
     signal_s = min(j.params.n_epochs * j.S.intTime for j in jobs)
     together = None
-    if len(jobs) > 1:   # a band's packages replayed side by side (their own streams), as gc_track_multi runs their closed loops
+    if len(jobs) > 1 and side_by_side:   # a band's packages replayed side by side (their own streams), as gc_track_multi runs their closed loops
         ms_all = W.time_replays_together(jobs, max(steps, 10), warmup)
         together = {"ms_per_pass": round(ms_all, 4), "frac": round(total_bytes / ms_all / 1e6 / HBM_PEAK_GBPS, 4), "clock": "host, around all streams",
                     "note": "all jobs of the band launched per pass, each on its context's stream; kernel_ms_sum above is the jobs one after the other"}
@@ -1063,6 +1063,8 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-int16", action="store_true")
     ap.add_argument("--no-acq-packages", action="store_true", help="skip acquisition.packages (the twelve default-size searches checked against their fixtures)")
+    ap.add_argument("--no-side-by-side", action="store_true", help="skip replay.side_by_side (a band's packages replayed together on their streams): under the "
+                    "kernel-trace profiler the rows of a kernel then hold the one-after-the-other launches only")
     ap.add_argument("--no-handover", action="store_true", help="N > 1: every rank synthesises its own copy of the record(s) instead of receiving them from the source rank (A/B of the exchange step)")
     ap.add_argument("--detail", default=os.environ.get("GC_BENCH_DETAIL", DETAIL_DEFAULT),
                     help="file that receives the full result (every leg, every rank); the printed line is its summary. '' = none")
@@ -1118,16 +1120,16 @@ def main() -> None:
         cfgs = {}
         # configs[2]: Galileo E1-C CBOC(6,1,1/11) x 8 (the replica as BASELINE words it; the reference's package tracks BOC(1,1))
         cfgs["galileo_e1c_cboc_x8"], extra_jobs["cboc"] = run_band_jobs(P, W, "config 3", device, [("GAL_E1C_CBOC", 8)], args.cfg_seconds, 18e6, 20e3, 3003,
-                                                                          args.steps, args.warmup)
+                                                                          args.steps, args.warmup, side_by_side=not args.no_side_by_side)
         # configs[3]: GPS L5 + BDS B2a, pilot + data arms, 16 channels, 50 Msps - two packages on ONE record
         cfgs["l5_b2a_x16_50msps_int8"], extra_jobs["l5b2a"] = run_band_jobs(P, W, "config 4", device, [("GPS_L5C", 8), ("BDS_B2a", 8)], args.cfg_seconds, 50e6, 20e3,
-                                                                             4004, args.steps, args.warmup)
+                                                                             4004, args.steps, args.warmup, side_by_side=not args.no_side_by_side)
         if not args.no_int16:
             cfgs["l5_b2a_x16_50msps_int16"], extra_jobs["l5b2a_int16"] = run_band_jobs(P, W, "config 4 (int16 record)", device, [("GPS_L5C", 8), ("BDS_B2a", 8)],
-                                                                                       args.cfg_seconds, 50e6, 20e3, 4004, max(2, args.steps // 4), 1, dtype=np.int16)
+                                                                                       args.cfg_seconds, 50e6, 20e3, 4004, max(2, args.steps // 4), 1, dtype=np.int16, side_by_side=not args.no_side_by_side)
         # configs[4], one GPU's share: 8 channels of three packages on the L1-band record
         cfgs["mix_share_l1_band_x8"], extra_jobs["mix"] = run_band_jobs(P, W, "config 5 (one GPU's share)", device, [("GPS_L1CA", 3), ("GAL_E1C", 3), ("BDS_B1C_NB", 2)],
-                                                                         args.mix_seconds, 18e6, 20e3, 5005, args.steps, args.warmup)
+                                                                         args.mix_seconds, 18e6, 20e3, 5005, args.steps, args.warmup, side_by_side=not args.no_side_by_side)
         result["configs"] = cfgs
     if rank == 0 and world == 1 and (config == "sweep" or (config == "all" and not args.no_sweep)):
         result["closed_loop_sweep"] = run_closed_loop_sweep(P, W, device, args.sweep_seconds)

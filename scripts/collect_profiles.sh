@@ -13,7 +13,7 @@ sha256sum cu-sdr-collection_amd/lib/libgnsscorr.so | cut -d" " -f1 > "$OUT/lib_s
 python bench.py --detail "$OUT/bench.json" > "$OUT/bench_line.json" 2> "$OUT/bench.err"   # the printed line (what the driver parses) and the long form
 cd /tmp
 # per-kernel durations of the same command (no CPU leg: it adds nothing on the device)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python /root/repo/bench.py --no-cpu --detail "$OUT/bench_under_profiler.json" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python /root/repo/bench.py --no-cpu --no-side-by-side --no-sweep --detail "$OUT/bench_under_profiler.json" > /dev/null 2>&1
 # HBM traffic of the main replay kernel: separate passes (TCC slots), main line only
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/l1ca_pmc_$c" -- python /root/repo/bench.py --config l1ca --no-cpu --steps 4 --warmup 1 > /dev/null 2>&1
@@ -33,6 +33,9 @@ if [ "${2:-}" != "quick" ]; then
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/acq_pmc_WRITE_SIZE" -- python /root/repo/scripts/acq_time.py > /dev/null 2>&1
   # the twelve default-size searches (bench.py acquisition.packages) under the kernel trace
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/acqpkg_stats" -- python /root/repo/scripts/acq_packages.py > "$OUT/acq_packages.json" 2>/dev/null
+  # counter passes (FETCH / WRITE / SQ / LDS) of the default L1 C/A search and of the two plans whose searches take 60 ms (GPS L2C 320 x 1000,
+  # BDS B1C 600 x 600)
+  for pkg in GPS_L1CA GPS_L2C BDS_B1C; do bash /root/repo/scripts/prof_acq_pmc.sh "$TAG" $pkg; done
 fi
 cd /root/repo
 for d in "$OUT"/*/; do
