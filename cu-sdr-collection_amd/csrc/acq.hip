@@ -131,6 +131,22 @@ bool make_plan(int n, Plan* pl) {
   return factor(pl->n1, &pl->p1) && factor(pl->n2, &pl->p2) && pl->n2 <= kMaxPassLen;
 }
 
+// Division of a small wave-uniform number by a run-time constant of the launch (hops per bin, bins per spectrum, hop groups ...) as one
+// multiply-high: q = (x * mul) >> 32 with mul = floor(2^32 / d) + 1 is floor(x / d) whenever x * d < 2^32 (launch_pass checks the
+// launch's largest batch number against that).  The pass kernels did these as 64-bit divisions - the compiler's float-reciprocal
+// sequences, ~10 of them per fetch: a fifth of the vector instructions of a rows pass that is VALU-bound (BDS B1C, DESIGN.md 4.4 xxv).
+struct FDiv {
+  unsigned mul, d;
+};
+inline FDiv make_fdiv(long long d) {
+  FDiv f;
+  f.d = d > 0 ? (unsigned)d : 0u;
+  f.mul = d > 1 ? (unsigned)((1ull << 32) / (unsigned long long)d) + 1u : 0u;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, FDiv f) { return f.d <= 1u ? x : __umulhi(x, f.mul); }
+__device__ __forceinline__ unsigned fmodu(unsigned x, FDiv f) { return x - fdiv(x, f) * f.d; }
+
 enum PreOp { PRE_NONE = 0, PRE_IF_CARRIER, PRE_CODE, PRE_MUL_CONJ };
 enum PostOp { POST_STORE = 0, POST_TWIDDLE, POST_ABS_ACC };
 
@@ -197,6 +213,8 @@ struct PassArgs {
   // the columns pass of such a search when the arms have different weights (BDS B1C: sqrt(11/40), sqrt(29/40)): hop r of a bin belongs to
   // arm r / arm_hops and its magnitude counts arm_w[arm] times.  0: every hop counts once
   int arm_hops;
+  // the launch's run-time divisors as multiply-high constants (filled by launch_pass)
+  FDiv fd_nhops, fd_shift_bins, fd_sden, fd_hg, fd_arm_batches, fd_arm_hops;
   float arm_w[4];
   int shift0;  // whole bins added to every batch's shift (a search around another centre frequency: gc_acquire_coarse_offsets), in [0, n)
   // PRE_IF_CARRIER on a transform longer than the reference's 2*spc (sizes the radix-{2..8} plan cannot take are padded to
@@ -922,7 +940,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
   unsigned arm = 0, bbl = bb;  // (PassArgs::arm_batches)
   if constexpr (PRE == PRE_MUL_CONJ && POST == POST_TWIDDLE) {
     if (a.arm_batches > 0) {
-      arm = bb / (unsigned)a.arm_batches;
+      arm = fdiv(bb, a.fd_arm_batches);
       bbl = bb - arm * (unsigned)a.arm_batches;
     }
   }
@@ -930,15 +948,19 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
   // where transform tb of this launch goes in the intermediate
   [[maybe_unused]] auto out_tb = [&](long long tb) -> long long {
     if constexpr (PRE == PRE_MUL_CONJ && POST == POST_TWIDDLE) {
-      if (a.arm_batches > 0) return (tb / a.nhops * a.narms_merged + arm) * a.nhops + tb % a.nhops;
+      if (a.arm_batches > 0) {
+        const unsigned t = (unsigned)tb, q = fdiv(t, a.fd_nhops);
+        return (long long)(q * (unsigned)a.narms_merged + arm) * a.nhops + (t - q * (unsigned)a.nhops);
+      }
     }
     return tb;
   };
-  const unsigned hg = bbl % HG, batch = (bbl / HG) * BQ + (unsigned)a.batch0;
-  const unsigned nq = BQ == 1 ? 1u : min(BQ, (unsigned)a.nbatch_total - (bbl / HG) * BQ);
+  const unsigned bgrp = HG == 1u ? bbl : fdiv(bbl, a.fd_hg);
+  const unsigned hg = bbl - bgrp * HG, batch = bgrp * BQ + (unsigned)a.batch0;
+  const unsigned nq = BQ == 1 ? 1u : min(BQ, (unsigned)a.nbatch_total - bgrp * BQ);
   const unsigned v0 = tile * C;
   constexpr bool RR = SHIFT && POST != POST_ABS_ACC;  // rows pass that may walk several hops of its bin (PassArgs::row_reps)
-  const int reps = POST == POST_ABS_ACC ? a.nhops / (int)HG : (RR && a.row_reps > 1 && a.shift_q > 0) ? a.row_reps : 1;
+  const int reps = POST == POST_ABS_ACC ? (HG == 1u ? a.nhops : (int)fdiv((unsigned)a.nhops, a.fd_hg)) : (RR && a.row_reps > 1 && a.shift_q > 0) ? a.row_reps : 1;
 
   stage_twiddles_ct<NT, R1, NS1, N, INV>(a.tw, twl, tid);
   stage_twiddles_ct<NT, R2, NS2, N, INV>(a.tw, twl + T1, tid);
@@ -1000,7 +1022,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
     [[maybe_unused]] float2 fr_oth[RR ? IT0 : 1][RR ? R0 : 1];
     if constexpr (RR) {
       const long long tb0 = (long long)batch * reps;
-      unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb0 % a.shift_bins);
+      unsigned sft = a.shift_q > 0 ? fdiv(fdiv((unsigned)tb0, a.fd_nhops), a.fd_sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : fmodu((unsigned)tb0, a.fd_shift_bins);
       sft -= sft >= N ? N : 0u;
       const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
 #pragma unroll
@@ -1044,10 +1066,11 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
         [[maybe_unused]] long long shsrc = 0;
         [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
         if constexpr (SHIFT) {
-          const unsigned sbin = (unsigned)(tb / a.nhops);
-          unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb % a.shift_bins);
+          const unsigned tbu = (unsigned)tb, sbin = fdiv(tbu, a.fd_nhops);
+          const unsigned sbq = fdiv(sbin, a.fd_sden);
+          unsigned sft = a.shift_q > 0 ? sbq * (unsigned)a.shift_q + (unsigned)a.shift0 : fmodu(tbu, a.fd_shift_bins);
           sft -= sft >= N ? N : 0u;
-          shsrc = a.shift_q > 0 ? (long long)(sbin % sden) * a.nhops + tb % a.nhops : tb / a.shift_bins;
+          shsrc = a.shift_q > 0 ? (long long)(sbin - sbq * sden) * a.nhops + (tbu - sbin * (unsigned)a.nhops) : (long long)fdiv(tbu, a.fd_shift_bins);
           sh2 = sft / OTHER;
           sh1 = sft - sh2 * OTHER;
         }
@@ -1138,7 +1161,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
         });
       } else {
         const bool weighted = a.arm_hops > 0;
-        const float wrep = weighted ? a.arm_w[min(rep / a.arm_hops, 3)] : 1.0f;
+        const float wrep = weighted ? a.arm_w[min((int)fdiv((unsigned)rep, a.fd_arm_hops), 3)] : 1.0f;
         stage_last_ct<NT, RL, L, LPL, C, INV, SPL_>(lsrc, twl_last, tid, [&](unsigned it, int q, unsigned, unsigned, float2 val) {
           const float m = cabs_f(val.x, val.y);
           acc2[it][q] = weighted ? fmaf(wrep, m, acc2[it][q]) : acc2[it][q] + m;
@@ -1190,7 +1213,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
   [[maybe_unused]] float2 rr_oth[RR ? SLOTS : 1];
   if constexpr (RR) {
     const long long tb0 = (long long)batch * reps;
-    unsigned sft = a.shift_q > 0 ? ((unsigned)(tb0 / a.nhops) / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb0 % a.shift_bins);
+    unsigned sft = a.shift_q > 0 ? fdiv(fdiv((unsigned)tb0, a.fd_nhops), a.fd_sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : fmodu((unsigned)tb0, a.fd_shift_bins);
     sft -= sft >= N ? N : 0u;
     const unsigned s2 = sft / OTHER, s1 = sft - s2 * OTHER;
 #pragma unroll
@@ -1218,16 +1241,17 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
     [[maybe_unused]] long long shsrc = 0;
     [[maybe_unused]] unsigned sh1 = 0, sh2 = 0;
     if constexpr (SHIFT) {
-      const unsigned sbin = (unsigned)(tb / a.nhops);
-      unsigned sft = a.shift_q > 0 ? (sbin / sden) * (unsigned)a.shift_q + (unsigned)a.shift0 : (unsigned)(tb % a.shift_bins);
+      const unsigned tbu = (unsigned)tb, sbin = fdiv(tbu, a.fd_nhops);
+      const unsigned sbq = fdiv(sbin, a.fd_sden);
+          unsigned sft = a.shift_q > 0 ? sbq * (unsigned)a.shift_q + (unsigned)a.shift0 : fmodu(tbu, a.fd_shift_bins);
       sft -= sft >= N ? N : 0u;
-      shsrc = a.shift_q > 0 ? (long long)(sbin % sden) * a.nhops + tb % a.nhops : tb / a.shift_bins;
+      shsrc = a.shift_q > 0 ? (long long)(sbin - sbq * sden) * a.nhops + (tbu - sbin * (unsigned)a.nhops) : (long long)fdiv(tbu, a.fd_shift_bins);
       sh2 = sft / OTHER;
       sh1 = sft - sh2 * OTHER;
     }
     if constexpr (PRE == PRE_IF_CARRIER) {
-      cb = (int)(tb / a.nhops);
-      ch = (int)(tb % a.nhops);
+      cb = (int)fdiv((unsigned)tb, a.fd_nhops);
+      ch = (int)((unsigned)tb - (unsigned)cb * (unsigned)a.nhops);
       fcyc = (a.f0 - a.fstep * cb) / a.fs;  // cycles per sample of bin cb (acquisition.m:169-181)
     }
 #pragma unroll
@@ -2041,6 +2065,22 @@ int ct_columns_tile(int len, int nvec) {
 
 int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* used_ct = nullptr) {
   if (used_ct) *used_ct = false;
+  {
+    const long long sden = a.shift_den > 1 ? a.shift_den : 1, hgr = a.hop_groups > 1 ? a.hop_groups : 1;
+    a.fd_nhops = make_fdiv(a.nhops);
+    a.fd_shift_bins = make_fdiv(a.shift_bins);
+    a.fd_sden = make_fdiv(sden);
+    a.fd_hg = make_fdiv(hgr);
+    a.fd_arm_batches = make_fdiv(a.arm_batches);
+    a.fd_arm_hops = make_fdiv(a.arm_hops);
+    // the largest number any of them divides: a transform index of the launch (batches x hops, plus the first batch's number)
+    const long long xmax = (nbatch_groups + a.batch0 + 1) * std::max(1, a.nhops) * std::max<long long>(1, a.row_reps);
+    const long long dmax = std::max({(long long)a.nhops, (long long)a.shift_bins, sden, hgr, (long long)a.arm_batches, (long long)a.arm_hops, 1LL});
+    if (xmax * dmax >= (1LL << 32)) {
+      gc_set_error("acquisition: %lld transforms per launch (divisor %lld) are more than the pass kernels' index arithmetic takes", xmax, dmax);
+      return GC_E_UNSUPPORTED;
+    }
+  }
   const bool generic = GC_TUNE_ENV("GC_ACQ_GENERIC") != nullptr;  // (read per call: the tests switch it)
   const bool no_pairs = GC_TUNE_ENV("GC_ACQ_NO_XCD_PAIRS") != nullptr;
   const char* xmap = GC_TUNE_ENV("GC_ACQ_XCD_MAP");
