@@ -3469,6 +3469,10 @@ extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
     gc_set_error("gc_acq_shift_row: bad arguments or nothing searched yet");
     return GC_E_INVALID;
   }
+  if (s->shift_rows_fused && s->shift_narms < 1) {
+    gc_set_error("gc_acq_shift_row: the last search was gc_acq_shift_search_batch (it returns each PRN's pick itself); search one PRN with gc_acq_shift_search first");
+    return GC_E_STATE;
+  }
   GC_HIP(hipSetDevice(ctx->device));
   const int irow = s->shift_padded ? shift_internal_row(s->shift, row) : row;
   const size_t at = (size_t)irow * (size_t)s->n;
@@ -3720,9 +3724,10 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
     gc_set_error("gc_acq_shift_search_batch: the passes did not run on the specialised kernels - search PRN by PRN");
     return GC_E_UNSUPPORTED;
   }
-  s->shift_rows_fused = true;  // gc_acq_shift_row after this call transforms a row of the LAST PRN again
-  s->shift_narms = narms;
-  for (int arm = 0; arm < 4; ++arm) s->shift_weight[arm] = (arm_weight && arm < narms) ? arm_weight[arm] : 1.0;
+  // no single PRN's search is "the last one" after this call: gc_acq_shift_row has nothing to take a row from until the next
+  // gc_acq_shift_search (its code spectra are not the ones in place)
+  s->shift_rows_fused = true;
+  s->shift_narms = 0;
   std::vector<float> hmax((size_t)nprn * rows);
   std::vector<int> harg((size_t)nprn * rows);
   rc = shift_read_back(ctx, s, hmax.data(), s->b_rowmax.p, sizeof(float) * hmax.size(), harg.data(), s->b_rowarg.p, sizeof(int) * harg.size());

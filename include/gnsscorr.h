@@ -466,7 +466,7 @@ int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* p);
  * Returns each row's maximum and its 0-based first position; the rows stay on the device for gc_acq_shift_row. */
 int gc_acq_shift_search(gc_context* ctx, int narms, const int8_t* codes, const double* arm_weight,
                         float* row_max, int32_t* row_argmax);
-int gc_acq_shift_row(gc_context* ctx, int row, float* out /* n floats */);
+int gc_acq_shift_row(gc_context* ctx, int row, float* out /* n floats */);  /* a row of the last gc_acq_shift_search (GC_E_STATE after a batch call) */
 /* A package's whole search in ONE call (replaces the PRN loops BDS/B1I/include/acquisition.m:76-176, GPS/GPS_L2C/include/
  * acquisition.m:40-118, BDS/B1C/include/acquisition.m:170-235 up to the threshold test): codes int8 [nprn][narms][n] go up once, every
  * PRN's transforms are queued back to back, the row maxima of all PRNs come back in one copy, the package's selection rule picks each

@@ -693,3 +693,9 @@ def test_shift_search_batch_equals_the_search_prn_by_prn_and_checks_its_argument
     bad[17] = 4092                                                             # one past the last chip
     assert call(idx=bad) == L.GC_E_INVALID and b"sample_index[17]" in lib.gc_last_error()
     assert call(rule=L.GC_SHIFT_PICK_GLOBAL, excl=0, period=1) == L.GC_OK and out[0].second_peak == 0.0 and out[0].row >= 0
+    # a row belongs to ONE PRN's search: after a batch call there is none to take it from
+    with pytest.raises(L.GnssCorrError) as e:
+        engine.acq_shift_row(0)
+    assert e.value.status == L.GC_E_STATE
+    engine.acq_shift_search(sampled[0])
+    assert engine.acq_shift_row(3).shape == (spb,)
