@@ -149,6 +149,32 @@ def emit(result: dict, detail_path: str | None) -> None:
         pass
 
 
+TEARDOWN_LIMIT_S = 30.0
+
+
+def _finish(result: dict, args, rank: int, closers) -> None:
+    """The line first, the tear-down after it.  gc_destroy / destroy_process_group can raise or hang when ranks leave out of step
+    (ADVICE r5): a run that finished measuring must still print its line, so rank 0 emits BEFORE anything is closed (emit points
+    fd 1 at stderr afterwards: the line stays the last thing on stdout whatever the closers write), every closer's exception is
+    reported on stderr instead of raised, and a watchdog ends the process with status 0 if the tear-down does not return."""
+    import threading
+    if rank == 0:
+        emit(result, args.detail)          # the LAST thing this process writes to stdout
+    done = threading.Event()
+
+    def _watchdog():
+        if not done.wait(TEARDOWN_LIMIT_S):
+            print(f"bench.py: tear-down still running after {TEARDOWN_LIMIT_S:.0f} s; the result line is out, leaving", file=sys.stderr, flush=True)
+            os._exit(0)
+    threading.Thread(target=_watchdog, daemon=True).start()
+    for close in closers:
+        try:
+            close()
+        except Exception as e:            # noqa: BLE001 - the measurement is already reported
+            print(f"bench.py: {getattr(close, '__qualname__', close)} raised after the result line: {e!r}", file=sys.stderr, flush=True)
+    done.set()
+
+
 def _spawn_ranks(n: int, steps: int, warmup: int) -> int:
     """`python bench.py --gpus N` without torch.distributed.run: one rank per GPU through sharding.launch_ranks (LOCAL_RANK selects
     the device; GC_BENCH_DEVICE pins every rank to one device on a 1-GPU box), rendezvous on 127.0.0.1.  Rank 0 prints the result
@@ -1106,9 +1132,7 @@ def main() -> None:
 
     if config == "mix":
         result = run_mix(P, W, args, R, device)
-        R.close()
-        if rank == 0:
-            emit(result, args.detail)      # the LAST thing this process writes to stdout
+        _finish(result, args, rank, [R.close])
         return
 
     result, main_ctx = run_l1ca(P, W, args, R, device)
@@ -1138,10 +1162,7 @@ def main() -> None:
         result["cpu_baseline"] = base
         if spots:
             result["oracle_spot_checks_max_dev_rel_sum_abs_x"] = spots
-    main_ctx["eng"].close()
-    R.close()
-    if rank == 0:
-        emit(result, args.detail)          # the LAST thing this process writes to stdout
+    _finish(result, args, rank, [main_ctx["eng"].close, R.close])
 
 
 if __name__ == "__main__":

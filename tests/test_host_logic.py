@@ -402,3 +402,29 @@ def test_bench_prints_a_line_the_driver_can_parse():
                 handover={"backend": "nccl", "bytes": 2 ** 31, "seconds": 0.1, "note": "z" * 3000})
     assert len(bench.compact_line(wide)) < 4096 and json.loads(bench.compact_line(wide))["ranks_locked"] == [12] * 8
     assert len(bench._error_line(8, 20, 5, "e" * 5000, failed_rank=3, stderr_tail=["t" * 1000] * 40)) < 4096
+
+
+def test_bench_line_is_out_before_the_tear_down_and_survives_it():
+    """the result line is printed BEFORE eng.close() / destroy_process_group, a closer that raises is reported on stderr
+    and a closer that hangs is cut off by the watchdog - the line is still the one JSON line on stdout, the status is 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = os.path.join(root, "profiles", "r05", "bench.json")
+    prog = (
+        "import json, sys, time, types\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import bench\n"
+        "bench.TEARDOWN_LIMIT_S = 1.0\n"
+        f"full = json.load(open({full!r}))\n"
+        "def boom():\n    print('closing', flush=True)\n    raise RuntimeError('destroy_process_group failed')\n"
+        "def hang():\n    time.sleep(60)\n"
+        "bench._finish(full, types.SimpleNamespace(detail=''), 0, [boom, hang])\n"
+        "print('not reached')\n")
+    t0 = __import__("time").perf_counter()
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # what the closers print goes to stderr: fd 1 was re-pointed after the line
+    assert json.loads(lines[0])["value"] == json.load(open(full))["value"]
+    assert "destroy_process_group failed" in r.stderr and "tear-down still running" in r.stderr and "closing" in r.stderr
+    assert __import__("time").perf_counter() - t0 < 40
