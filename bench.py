@@ -108,6 +108,10 @@ def compact_line(result: dict, detail_path: str | None = None) -> str:
             l1 = pk.get("GPS_L1CA", {}).get("roofline", {}).get("compute")
             if l1:
                 out["acq_compute_frac_l1ca"] = l1["frac"]
+        if acq.get("cpu_baseline"):
+            out["acq_cpu_baseline"] = {k: {"ms": v["ms"], "cores": v["cores"], "kind": v["kind"], "gpu_ms": v["gpu_ms"],
+                                           "sample": v.get("sample_short", "")}
+                                       for k, v in acq["cpu_baseline"].items()}
     spots = result.get("oracle_spot_checks_max_dev_rel_sum_abs_x")
     if spots:
         out["oracle_spot_checks_worst"] = max(spots.values())
@@ -1070,6 +1074,50 @@ def cpu_leg(P, W, args, main, extra_jobs):
     return base, spots
 
 
+def acq_cpu_leg(P, packages, per_kind=3):
+    """The acquisition half's CPU baseline (the reference times its own searches: BDS/B1I/include/acquisition.m:77,195
+    `timeVec`, GPS_L1CA/include/postProcessing.m:100).  The float64 restatement of acquisition.m (oracle/gnss_oracle.py, NumPy /
+    pocketfft, ONE core) on the SAME record as the package's timed GPU search (tests/golden/ref_acq_<pkg>_default.npz's scene), for a
+    bounded sample of the PRN list - `per_kind` PRNs the reference detects and `per_kind` it does not, each timed on its own (a
+    detected PRN also runs the fine stage) - and scaled to the whole list by the two kinds' means.  Every sampled PRN's codePhase /
+    carrFreq must equal the fixture's: the search that is timed is a search that is right."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_scenes as RS
+    from oracle import gnss_oracle as O
+
+    def l1ca(rec, S):
+        x = rec.astype(np.float64)
+        return O.acquisition_l1ca(x[0::2] + 1j * x[1::2], S)
+    legs = {"GPS_L1CA": ("acquisition_l1ca (GPS_L1CA/include/acquisition.m:113-260: per PRN 29 bins x 20 hops x (fft + ifft) of 36 000 points, fine stage)", l1ca),
+            "BDS_B1I": ("acquisition_b1i (BDS/B1I/include/acquisition.m:34-176: circshift search, 2 carrier shifts x 2 blocks x bins of 72 000 points)", O.acquisition_b1i)}
+    out = {}
+    for name, (what, fn) in legs.items():
+        sc = next(s for s in RS.DEFAULT_ACQ_SCENES if s.name == name + "_default")
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"ref_acq_{sc.name}.npz"))
+        S, rec = RS.acq_inputs(P, sc)
+        full = [int(p) for p in S.acqSatelliteList]
+        det = [p for p in full if z["f_carrFreq"][p - 1] != 0]
+        und = [p for p in full if z["f_carrFreq"][p - 1] == 0]
+        times, equal = {True: [], False: []}, True
+        for p in det[:per_kind] + und[:per_kind]:
+            S.acqSatelliteList = [p]
+            t0 = time.perf_counter()
+            a = fn(rec, S)
+            times[p in det].append(time.perf_counter() - t0)
+            equal = equal and a.codePhase[p - 1] == z["f_codePhase"][p - 1] and a.carrFreq[p - 1] == z["f_carrFreq"][p - 1]
+        mean = {k: (sum(v) / len(v) if v else 0.0) for k, v in times.items()}
+        cpu_ms = 1e3 * (mean[True] * len(det) + mean[False] * len(und))
+        gpu_ms = (packages or {}).get(name, {}).get("ms")
+        out[name] = {"ms": round(cpu_ms, 1), "cores": 1, "kind": "port", "unit": "ms per default-size search (whole PRN list)",
+                     "ms_per_prn_detected": round(mean[True] * 1e3, 1), "ms_per_prn_not_detected": round(mean[False] * 1e3, 1),
+                     "sample": f"oracle/gnss_oracle.py {what}, NumPy float64 on one core: {len(times[True])} detected + {len(times[False])} other PRNs of {len(full)} "
+                               f"timed one by one ({sum(times[True]) + sum(times[False]):.1f} s of CPU) on the fixture's record, scaled to {len(det)} + {len(und)} PRNs",
+                     "sample_short": f"oracle (NumPy f64) on {len(times[True]) + len(times[False])} of {len(full)} PRNs of the same record, scaled",
+                     "sampled_prns_equal_to_the_references_acquisition_m": bool(equal), "gpu_ms": gpu_ms,
+                     "gpu_over_cpu": round(cpu_ms / gpu_ms, 1) if gpu_ms else None}
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1162,6 +1210,8 @@ def main() -> None:
         result["cpu_baseline"] = base
         if spots:
             result["oracle_spot_checks_max_dev_rel_sum_abs_x"] = spots
+        if config == "all" and not args.no_acq_packages:
+            result["acquisition"]["cpu_baseline"] = acq_cpu_leg(P, result["acquisition"].get("packages"))
     _finish(result, args, rank, [main_ctx["eng"].close, R.close])
 
 

@@ -8,9 +8,9 @@ synth.py (synthetic IF records).  Nothing here imports `oracle/`; there is no CP
 """
 from . import _lib, acq_family, acq_shift, codes, nav_sync, settings, signals, synth  # noqa: F401
 from ._lib import GnssCorrError  # noqa: F401
-from .engine import Engine  # noqa: F401
+from .engine import Engine, device_count  # noqa: F401
 from .receiver import CNoVSM, acquisition, preRun, tracking, tracking_file, tracking_multi  # noqa: F401
 from .settings import initSettings  # noqa: F401
 
-__all__ = ["Engine", "GnssCorrError", "acquisition", "preRun", "tracking", "tracking_file", "tracking_multi", "CNoVSM", "initSettings",
+__all__ = ["Engine", "device_count", "GnssCorrError", "acquisition", "preRun", "tracking", "tracking_file", "tracking_multi", "CNoVSM", "initSettings",
            "codes", "settings", "synth"]

@@ -120,6 +120,7 @@ SYMBOLS = {
     "gc_last_error": (C.c_char_p, []),
     "gc_api_version": (C.c_int, []),
     "gc_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    "gc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gc_synchronize": (C.c_int, [_P]),
     "gc_load_if": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int]),
     "gc_load_if_packed2": (C.c_int, [_P, _P, C.c_uint64]),

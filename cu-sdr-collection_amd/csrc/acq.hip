@@ -228,6 +228,9 @@ struct PassArgs {
   int peak_valid;
   // first batch of the launch (fft_pass_ct): gc_acq_shift_row recomputes ONE row of a search whose results were not written
   int batch0;
+  // POST_ABS_ACC (fft_pass_ct): batch q's sums land at acc_out + (q - acc_row0) * N - the batch search writes PRN k's winning row
+  // (batch irow) to slot k of its row buffer with acc_out = slot k, acc_row0 = irow (no pointer formed outside the allocation)
+  int acc_row0;
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
       if (HG > 1) {
         a.acc_part[((long long)hg * a.acc_bins + batch_q) * N + pos] = accv[slot];
       } else {
-        float* dstp = a.acc_out + (long long)batch_q * N + pos;
+        float* dstp = a.acc_out + (long long)(batch_q - a.acc_row0) * N + pos;
         const float v = (a.acc_add ? *dstp : 0.0f) + accv[slot] * inv_n * scale;
         if (a.peak_slots) {  // the finished sums of a PRN feed nothing but its peak keys
           if ((int)pos < a.peak_valid) pk.see(v, batch_q, pos);
@@ -2098,7 +2101,7 @@ int launch_pass(gc_context* ctx, PassArgs& a, long long nbatch_groups, bool* use
       return GC_OK;
     }
   }
-  if (a.batch0 != 0 || a.arm_batches > 0) {  // fft_pass_kernel numbers its batches from 0 and knows no merged arms: it would transform other rows into other places
+  if (a.batch0 != 0 || a.arm_batches > 0 || a.acc_row0 != 0) {  // fft_pass_kernel numbers its batches from 0 and knows no merged arms: it would transform other rows into other places
     gc_set_error("acquisition: rows / bins in chunks, merged arms and single-row transforms need the specialised pass kernels (length %d x %d)",
                  a.len, a.nvec);
     return GC_E_STATE;
@@ -2220,6 +2223,26 @@ AcqStreams* acq_streams(int device) {
     }
   }
   return pool[device].main && pool[device].lane ? &pool[device] : nullptr;
+}
+
+// The two-lane searches' fork / join events, created as a unit: all three exist or none does (a half-made set would leave later calls
+// recording and waiting on null events with the lanes never joined into the caller's stream - ADVICE r5).
+bool lane_events(AcqScratch* s) {
+  if (s->ev_fork && s->ev_join && s->ev_join2) return true;
+  hipEvent_t* const evs[3] = {&s->ev_fork, &s->ev_join, &s->ev_join2};
+  bool ok = true;
+  for (hipEvent_t* e : evs)
+    if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
+      *e = nullptr;
+      ok = false;
+    }
+  if (ok) return true;
+  (void)hipGetLastError();
+  for (hipEvent_t* e : evs) {
+    if (*e) (void)hipEventDestroy(*e);
+    *e = nullptr;
+  }
+  return false;
 }
 
 void free_scratch(AcqScratch* s) {
@@ -2695,10 +2718,7 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
       s->lane_stream[0] = ctx->stream;
       s->lane_stream[1] = s->stream2;
     }
-    if (lanes == 2 && !s->ev_fork &&
-        (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
-         hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) != hipSuccess))
-      lanes = 1;
+    if (lanes == 2 && !lane_events(s)) lanes = 1;
     if (lanes == 2 && !s->tmp2 &&
         (hipMalloc((void**)&s->tmp2, (size_t)s->nbh * ne * sizeof(float2)) != hipSuccess ||
          hipMalloc((void**)&s->results2, (size_t)s->nbins * ne * sizeof(float)) != hipSuccess)) {
@@ -3413,8 +3433,10 @@ extern "C" int gc_acq_shift_dims(gc_context* ctx, int32_t* n, int32_t* rows, int
 }
 
 // Row `irow` (internal order) of a circshift search transformed again: one batch per pass, every arm of `codespec` (narms x N) with its
-// weight; the row's n sums land at acc_out + irow * N (the specialised passes only: launch_pass refuses otherwise).
-static int shift_row_passes(gc_context* ctx, AcqScratch* s, int irow, int narms, const float2* codespec, const double* weight, float* acc_out) {
+// weight; the row's n sums land at acc_out + irow * N, or with to_slot at acc_out itself (the specialised passes only: launch_pass
+// refuses otherwise).
+static int shift_row_passes(gc_context* ctx, AcqScratch* s, int irow, int narms, const float2* codespec, const double* weight, float* acc_out,
+                            bool to_slot = false) {
   const gc_acq_shift_params& p = s->shift;
   const Plan& pl = s->plan;
   PassArgs base;
@@ -3454,6 +3476,7 @@ static int shift_row_passes(gc_context* ctx, AcqScratch* s, int irow, int narms,
     a.post = POST_ABS_ACC;
     a.in = s->tmp;
     a.acc_out = acc_out;
+    a.acc_row0 = to_slot ? irow : 0;
     a.acc_add = arm > 0;
     a.acc_scale = (float)weight[arm];
     a.hop_groups = 1;
@@ -3675,10 +3698,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
   if (nprn < 2) lanes = 1;
   AcqStreams* const shared = lanes == 2 ? acq_streams(ctx->device) : nullptr;
   if (!shared) lanes = 1;
-  if (lanes == 2 && !s->ev_fork &&
-      (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) != hipSuccess))
-    lanes = 1;
+  if (lanes == 2 && !lane_events(s)) lanes = 1;
   if (lanes == 2 && !s->tmp2 && hipMalloc((void**)&s->tmp2, (size_t)s->nbh * N * sizeof(float2)) != hipSuccess) {
     (void)hipGetLastError();
     s->tmp2 = nullptr;
@@ -3763,8 +3783,8 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
   for (int k = 0; k < nprn; ++k) {
     if (out[k].row < 0) continue;
     const int irow = out[k].row;
-    float* const dst = (float*)((char*)s->b_rows.p + ((size_t)k * N - (size_t)irow * N) * sizeof(float));  // row irow lands at b_rows + k * N
-    rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, arm_weight ? arm_weight : ones, dst);
+    rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, arm_weight ? arm_weight : ones, (float*)s->b_rows.p + (size_t)k * N,
+                          /*to_slot=*/true);  // row irow lands at b_rows + k * N
     if (rc) return rc;
   }
   hipLaunchKernelGGL(shift_pick_kernel, dim3((unsigned int)nprn), dim3(1024), 0, ctx->stream, (const float*)s->b_rows.p, (long long)N, p.n, exclude,

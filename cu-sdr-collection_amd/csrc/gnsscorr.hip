@@ -116,6 +116,18 @@ int gc_device_info(gc_context* ctx, char* name, int name_len, int* compute_units
   return GC_OK;
 }
 
+int gc_device_count(int* count) {
+  if (!count) return GC_E_INVALID;
+  *count = 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return GC_OK;  // no driver / no device: zero devices, not an error of the call
+  }
+  *count = n;
+  return GC_OK;
+}
+
 int gc_synchronize(gc_context* ctx) {
   if (!ctx) return GC_E_INVALID;
   GC_HIP(hipSetDevice(ctx->device));

@@ -10,6 +10,13 @@ import numpy as np
 from . import _lib as L
 
 
+def device_count() -> int:
+    """gc_device_count: the HIP devices this process sees (valid Engine(device_id) are 0 .. n - 1); 0 without a GPU.  No context."""
+    n = C.c_int(0)
+    L.check(L.load().gc_device_count(C.byref(n)))
+    return int(n.value)
+
+
 class Engine:
     """Owns a gc_context on `device_id`.  Raises GnssCorrError when no MI355X is visible."""
 
@@ -416,7 +423,7 @@ class Engine:
     def acq_shift_search_batch(self, codes: np.ndarray, arm_weight, rule: int, exclude: int = 0, period: int = 1, sample_index=None):
         """gc_acq_shift_search_batch: codes int8 [nprn, narms, n] (sampled replicas) or, with sample_index (0-based, one vector for all
         codes), [nprn, narms, chips] -> ctypes array of gc_acq_shift_pick [nprn], or None when the library answers GC_E_UNSUPPORTED
-        (block lengths without specialised passes: the caller searches PRN by PRN)."""
+        (block lengths without specialised passes) or GC_E_NOMEM (the batch's buffers do not fit): the caller searches PRN by PRN."""
         p = self._shift
         c8 = np.ascontiguousarray(codes, dtype=np.int8)
         nprn, narms = c8.shape[0], c8.shape[1]
@@ -431,7 +438,9 @@ class Engine:
             idx, nidx = i32.ctypes.data_as(C.c_void_p), int(i32.shape[0])
         rc = self._lib.gc_acq_shift_search_batch(self._ctx, nprn, narms, c8.ctypes.data_as(C.c_void_p), int(c8.shape[2]), idx, nidx, w, int(rule),
                                                  int(exclude), int(period), picks)
-        if rc == L.GC_E_UNSUPPORTED:
+        if rc in (L.GC_E_UNSUPPORTED, L.GC_E_NOMEM):
+            # GC_E_NOMEM: the batch holds every PRN's code spectra (nprn x narms x N x 8 bytes) and winning rows at once; the PRN-by-PRN
+            # path needs one PRN's and still fits on a device that is short of memory (next to gc_track_multi contexts)
             return None
         L.check(rc)
         self._count_transforms(int(p.n), code=nprn * narms,

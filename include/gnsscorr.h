@@ -63,6 +63,11 @@ int gc_build_flags(void);
 int gc_api_version(void);
 /* Device name / CU count of the context's device (for bench reporting). */
 int gc_device_info(gc_context* ctx, char* name, int name_len, int* compute_units);
+/* How many HIP devices this process sees (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES applied): the valid device_id of gc_create are
+ * 0 .. *count - 1 (gc_create refuses an ordinal that is not gfx950).  0 without a driver or a device; needs no context.  The caller that shards channels over the GPUs of a node (tracking.m:133: channels are independent) makes
+ * ONE context per device - gc_create(&ctx[i], i), i < *count - instead of SURVEY 8b's gc_create(ctx**, device_ids, ndev): a context
+ * is bound to one device, one stream and one host thread ("deviations from SURVEY 8b"). */
+int gc_device_count(int* count);
 int gc_synchronize(gc_context* ctx);
 
 /* ---- IF samples -> HBM (replaces fread + conversion, tracking.m:226-236) ------------ */

@@ -332,12 +332,13 @@ if ~isfield(settings, 'gnsscorrPerPRN')
 end
 for k = 1:numel(prns)
     PRN = prns(k);
-    dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);   % makeDataTable.m
-    if pilot, ptab = sampled(generatePilotBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true); end
+    dtab = [];  ptab = [];                   % the spc-long sampled tables: only the per-PRN search and the fine stage of a detection need them
     if ~isempty(picks)
         % :193 max(max(results, [], 2)) and [~, codePhase] = max(max(results)) inside the call
         binIdx = picks(1, k) + 1;  peak = picks(3, k);  codePhase = picks(2, k) + 1;
     else
+        dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);   % makeDataTable.m
+        if pilot, ptab = sampled(generatePilotBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true); end
         arms = [dtab(1:xLen), zeros(1, n - xLen)].';                                        % :155-156
         if pilot, arms = [arms, [ptab(1:xLen), zeros(1, n - xLen)].']; end
         [rmax, rarg] = gnsscorr_mex('acq_shift_search', h, int8(arms), w, nRows);
@@ -351,6 +352,10 @@ for k = 1:numel(prns)
     if acqResults.peakMetric(PRN) > settings.acqThreshold
         % one code period against the sampled BOC tables at nFine carriers (:242-250): the tables go to the GPU as replicas of one
         % entry per sample (codeFreq = 0), data and pilot in one call
+        if isempty(dtab)
+            dtab = sampled(generateDataBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true);   % makeDataTable.m
+            if pilot, ptab = sampled(generatePilotBOC11(settings, PRN), 1:spc, ts, tc, settings.codeLength * 2, true); end
+        end
         tabs = dtab(:);
         if pilot, tabs = [dtab(:), ptab(:)]; end
         q3 = struct('samplingFreq', fs, 'codeFreq', 0, 'f0', selFreq + settings.acqStep, 'fstep', fineStep, 'firstSample', codePhase - 1, ...

@@ -34,6 +34,7 @@
  *   picks = gnsscorr_mex('acq_shift_search_batch', h, int8(chips), int32(index0), weights, rule, exclude, period, narms)  % a package's whole search: 4 x nPRN
  *   x    = gnsscorr_mex('read_if', h, firstSample0, n, 'int8'|'int16', valuesPerSample)   % raw record samples back
  *   [name, cus] = gnsscorr_mex('device_info', h)
+ *   n    = gnsscorr_mex('device_count')                                              % HIP devices visible: one context per device
  */
 #include <string.h>
 
@@ -433,7 +434,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
        zero-padded replicas; otherwise columns of chips and the ONE 0-based index vector that samples them all (zero padding on the
        device).  rule 0 | 1 | 2 = GC_SHIFT_PICK_GLOBAL | _SEQUENTIAL | _SEQUENTIAL_PAIRS.  picks: 4 x nPRN double
        [row0; codePhase0; peak; secondPeak], row0 = -1: nothing above 0.  [] when the library answers GC_E_UNSUPPORTED (block
-       lengths without specialised transforms): search PRN by PRN with 'acq_shift_search' / 'acq_shift_row' then. */
+       lengths without specialised transforms) or GC_E_NOMEM (the whole list's buffers do not fit): search PRN by PRN with 'acq_shift_search' / 'acq_shift_row' then. */
     int32_t n = 0, nrows = 0, amax = 0;
     if (nrhs < 9) mexErrMsgIdAndTxt("gnsscorr:args", "acq_shift_search_batch: handle, codes, index, weights, rule, exclude, period, narms");
     if (gc_acq_shift_dims(handle(prhs[1]), &n, &nrows, &amax)) fail("gc_acq_shift_dims");
@@ -456,7 +457,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                              have_index ? (const int32_t*)mxGetData(prhs[3]) : NULL,
                                              have_index ? (int)mxGetNumberOfElements(prhs[3]) : 0, w, (int)mxGetScalar(prhs[5]),
                                              (int)mxGetScalar(prhs[6]), (int)mxGetScalar(prhs[7]), picks);
-    if (rc == GC_E_UNSUPPORTED) {
+    if (rc == GC_E_UNSUPPORTED || rc == GC_E_NOMEM) { /* NOMEM: all PRNs' spectra at once do not fit; one PRN's still may */
       plhs[0] = mxCreateDoubleMatrix(0, 0, mxREAL);
     } else {
       if (rc) fail("gc_acq_shift_search_batch");
@@ -508,6 +509,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       mxGetDoubles(plhs[0])[1] = (double)dt;
       mxGetDoubles(plhs[0])[2] = (double)lay;
     }
+  } else if (!strcmp(cmd, "device_count")) {
+    int n = 0;
+    if (gc_device_count(&n)) fail("gc_device_count");
+    plhs[0] = mxCreateDoubleScalar(n);
   } else if (!strcmp(cmd, "device_info")) {
     char name[128] = "";
     int cus = 0;
