@@ -105,6 +105,10 @@ def compact_line(result: dict, detail_path: str | None = None) -> str:
         if pk:
             out["acq_ms"] = {k: v["ms"] for k, v in pk.items()}
             out["acq_all_equal_to_reference"] = all(all(v["equal_to_the_references_acquisition_m"].values()) for v in pk.values())
+            devs = [v["float64_guard"]["max_dev"] for v in pk.values() if v.get("float64_guard")]
+            if devs:                       # float32 search values against the float64 re-evaluation of the same cells, worst package
+                out["acq_f32_vs_f64_peak_max_rel"] = float("%.3g" % max(devs))
+                out["acq_guard_ties"] = sum(v["float64_guard"]["ties"] for v in pk.values() if v.get("float64_guard"))
             l1 = pk.get("GPS_L1CA", {}).get("roofline", {}).get("compute")
             if l1:
                 out["acq_compute_frac_l1ca"] = l1["frac"]
@@ -650,6 +654,10 @@ def run_acquisition_packages(P, device, only=None):
             runs.sort()
             wall, ev_ms = runs[1]
             st = dict(eng.acq_stats)
+            try:
+                guard = eng.acq_guard_stats()       # the float64 guard of the LAST search call of the package's acquisition (csrc/acq_guard.h)
+            except Exception:                      # noqa: BLE001
+                guard = None
         same = {f: bool(np.array_equal(np.asarray(getattr(got, f), dtype=np.float64), z["f_" + f])) for f in sc.fields if f != "peakMetric"}
         want = z["f_peakMetric"]
         metric_dev = float(np.max(np.abs(np.asarray(got.peakMetric, dtype=np.float64) - want)) / np.max(np.abs(want)))
@@ -661,6 +669,7 @@ def run_acquisition_packages(P, device, only=None):
                      "equal_to_the_references_acquisition_m": same, "peak_metric_max_rel_dev": round(metric_dev, 7),
                      "ms_per_prn": round(wall * 1e3 / max(1, len(list(S.acqSatelliteList))), 4),
                      "reference_interpreter_seconds": round(float(z["seconds"][0]), 1) if "seconds" in z.files else None,
+                     "float64_guard": guard,
                      "roofline": {"compute": {"bound": "valu f32", "achieved": round(flops / (ev_ms * 1e-3) / 1e12, 3), "peak": 157.3, "unit": "TFLOP/s",
                                               "frac": round(flops / (ev_ms * 1e-3) / 1e12 / 157.3, 4), "algorithmic_flops": flops}}}
     return out

@@ -183,6 +183,7 @@ SYMBOLS = {
     "gc_debug_wave_transpose_sum": (C.c_int, [_P, C.c_int, _P, _P]),
     "gc_debug_tables_derivable": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "gc_debug_fft": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int]),
+    "gc_acq_guard_stats": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

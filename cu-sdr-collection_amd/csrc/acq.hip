@@ -17,10 +17,12 @@
 #include <mutex>
 #include <type_traits>
 
+#include "acq_guard.h"
 #include "gc_internal.h"
 
 namespace {
 
+constexpr int kGuardListCap = 4096;  // cells within gc_acq_tie_eps of a PRN's winner that the guard's slow path re-evaluates at most
 constexpr int kMaxRadices = 12;
 constexpr int kMaxPassLen = 2048;  // longest vector of a pass: one tile of 2048 complex values (choose_cols), i.e. transforms of up to 2048 x 2048 points
 constexpr int kFftThreads = 256;
@@ -226,6 +228,8 @@ struct PassArgs {
   // (94 bins x 144 000 columns = 54 MB per PRN in the Galileo E1 search: 45 us of the 190 us a PRN took)
   unsigned long long* peak_slots;
   int peak_valid;
+  // ... and, next to each slot, the workgroup's runner-up value (float bits; PeakTrack::m2) for the float64 guard; nullptr: not wanted
+  unsigned int* peak_second;
   // first batch of the launch (fft_pass_ct): gc_acq_shift_row recomputes ONE row of a search whose results were not written
   int batch0;
   // POST_ABS_ACC (fft_pass_ct): batch q's sums land at acc_out + (q - acc_row0) * N - the batch search writes PRN k's winning row
@@ -413,34 +417,46 @@ __device__ __forceinline__ void fft_stage(const float2* __restrict__ tw, int n, 
 // The running maximum of a thread / workgroup with MATLAB's first-occurrence rule (acquisition.m:196-198), see the peak kernels below
 struct PeakTrack {
   unsigned int m = 0, bin = 0xffffffffu, col = 0xffffffffu;
+  // the largest value among all OTHER cells seen (== m when another cell holds the same value): how far the runner-up is from the
+  // winner decides whether the float32 ordering can be trusted or the cells go to the float64 guard (acq_guard.h)
+  unsigned int m2 = 0;
   __device__ __forceinline__ void see(float v, unsigned int b, unsigned int c) {
     const unsigned int u = __float_as_uint(v);
     if (u > m) {
+      m2 = m;
       m = u;
       bin = b;
       col = c;
-    } else if (u == m) {
-      bin = min(bin, b);
-      col = min(col, c);
+    } else {
+      m2 = max(m2, u);
+      if (u == m) {
+        bin = min(bin, b);
+        col = min(col, c);
+      }
     }
   }
   // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
   // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
   // the workgroup's candidate in thread 0: {maximum's bits, smallest bin, smallest column among the lanes that hold it}
-  __device__ __forceinline__ bool reduce(unsigned long long& ka, unsigned long long& kb) const {
-    __shared__ unsigned int sm[16], sb[16], sc[16];  // one entry per wavefront (workgroups of up to 1024 threads)
+  __device__ __forceinline__ bool reduce(unsigned long long& ka, unsigned long long& kb, unsigned int* second = nullptr) const {
+    __shared__ unsigned int sm[16], sb[16], sc[16], s2[16];  // one entry per wavefront (workgroups of up to 1024 threads)
     unsigned int wm = m;
     for (int off = 32; off > 0; off >>= 1) wm = max(wm, (unsigned int)__shfl_xor((int)wm, off, 64));
     unsigned int b = m == wm ? bin : 0xffffffffu, c = m == wm ? col : 0xffffffffu;
+    // the wave's runner-up: every lane's second, every lane's maximum except ONE holder of the wave's (two holders: a tie)
+    const unsigned long long holders = __ballot(m == wm);
+    unsigned int w2 = (m == wm && __popcll(holders) == 1) ? m2 : (m == wm ? m : max(m, m2));
     for (int off = 32; off > 0; off >>= 1) {
       b = min(b, (unsigned int)__shfl_xor((int)b, off, 64));
       c = min(c, (unsigned int)__shfl_xor((int)c, off, 64));
+      w2 = max(w2, (unsigned int)__shfl_xor((int)w2, off, 64));
     }
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
       sm[wave] = wm;
       sb[wave] = b;
       sc[wave] = c;
+      s2[wave] = w2;
     }
     __syncthreads();
     ka = kb = 0;
@@ -448,14 +464,19 @@ struct PeakTrack {
     const int nw = (blockDim.x + 63) >> 6;
     for (int w = 1; w < nw; ++w) {
       if (sm[w] > wm) {
+        w2 = max(max(w2, wm), s2[w]);  // the old maximum is now a runner-up
         wm = sm[w];
         b = sb[w];
         c = sc[w];
-      } else if (sm[w] == wm) {
-        b = min(b, sb[w]);
-        c = min(c, sc[w]);
+      } else {
+        w2 = max(max(w2, sm[w]), s2[w]);  // (sm[w] == wm: a second holder, w2 becomes wm)
+        if (sm[w] == wm) {
+          b = min(b, sb[w]);
+          c = min(c, sc[w]);
+        }
       }
     }
+    if (second) *second = w2;
     if (b == 0xffffffffu) return true;  // nothing seen: keys stay 0
     ka = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - b);
     kb = ((unsigned long long)wm << 32) | (unsigned long long)(0xffffffffu - c);
@@ -463,20 +484,34 @@ struct PeakTrack {
   }
   // one pair of atomics per workgroup at most, and none when the workgroup's maximum is below what is already there
   // (every wave of a 4 000-workgroup launch hitting the same two addresses cost 0.37 ms per PRN)
-  __device__ __forceinline__ void publish(unsigned long long* keys) const {
+  // second != nullptr: the PRN's runner-up value (float bits) by the same scheme - whichever of {this workgroup's maximum, the key it
+  // displaces} loses goes to *second together with the workgroup's own second
+  __device__ __forceinline__ void publish(unsigned long long* keys, unsigned int* second = nullptr) const {
     unsigned long long ka, kb;
-    if (reduce(ka, kb) && ka) {
-      if (ka > __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[0], ka);
+    unsigned int w2 = 0;
+    if (reduce(ka, kb, &w2) && ka) {
+      unsigned int loser = (unsigned int)(ka >> 32);
+      if (ka > __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const unsigned long long old = atomicMax(&keys[0], ka);
+        if (ka > old) loser = (unsigned int)(old >> 32);
+      }
       if (kb > __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&keys[1], kb);
+      if (second) {
+        w2 = max(w2, loser);
+        if (w2 > __hip_atomic_load(second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(second, w2);
+      }
     }
   }
   // the same candidate as a plain store into this workgroup's own slot (keys_reduce_kernel picks them up).  Thread 0 of EVERY
   // workgroup stores unconditionally (zeros when it saw nothing): the slot buffer is cleared only when it is allocated
-  __device__ __forceinline__ void publish_slot(unsigned long long* slot) const {
+  // second_slot != nullptr: the workgroup's runner-up value (float bits) next to its candidate (keys_reduce_kernel)
+  __device__ __forceinline__ void publish_slot(unsigned long long* slot, unsigned int* second_slot = nullptr) const {
     unsigned long long ka, kb;
-    if (reduce(ka, kb)) {
+    unsigned int w2 = 0;
+    if (reduce(ka, kb, &w2)) {
       slot[0] = ka;
       slot[1] = kb;
+      if (second_slot) *second_slot = w2;
     }
   }
 };
@@ -1010,7 +1045,7 @@ __global__ __launch_bounds__((ct_threads<L, C, R0, R1, R2, R3>()), (L <= 200 ? G
         }
       }
     }
-    if (HG == 1 && a.peak_slots) pk.publish_slot(a.peak_slots + 2 * (size_t)slot_id);  // slot_id: the (batch, tile) after the XCD mapping, not blockIdx.x
+    if (HG == 1 && a.peak_slots) pk.publish_slot(a.peak_slots + 2 * (size_t)slot_id, a.peak_second ? a.peak_second + slot_id : nullptr);  // slot_id: the (batch, tile) after the XCD mapping, not blockIdx.x
   };
 
   if constexpr (FUSE) {
@@ -1619,8 +1654,10 @@ bool try_fused(gc_context* ctx, const Plan& pl, const FusedArgs& a, int nprn) {
 // together and all finding the keys at zero made the two atomics of PeakTrack::publish a 2 000-deep queue on two addresses -
 // a third of that kernel's time; plain stores and this one small launch replace them.
 __global__ __launch_bounds__(256) void keys_reduce_kernel(const unsigned long long* __restrict__ slots, int per_prn,
-                                                          unsigned long long* __restrict__ keys) {
+                                                          unsigned long long* __restrict__ keys, const unsigned int* __restrict__ sec_slots = nullptr,
+                                                          unsigned int* __restrict__ sec_out = nullptr) {
   __shared__ unsigned long long sa[4], sb[4];
+  __shared__ unsigned int s2[4], sh[4], top;
   const unsigned long long* mine = slots + (size_t)blockIdx.x * per_prn * 2;
   unsigned long long ka = 0, kb = 0;
   for (int i = threadIdx.x; i < per_prn; i += blockDim.x) {
@@ -1643,6 +1680,36 @@ __global__ __launch_bounds__(256) void keys_reduce_kernel(const unsigned long lo
     }
     keys[2 * blockIdx.x] = max(keys[2 * blockIdx.x], ka);
     keys[2 * blockIdx.x + 1] = max(keys[2 * blockIdx.x + 1], kb);
+    top = (unsigned int)(ka >> 32);
+  }
+  if (!sec_slots) return;
+  // the PRN's runner-up (float bits): every workgroup's own second, every workgroup's maximum except ONE holder of the PRN's
+  __syncthreads();
+  const unsigned int* sec = sec_slots + (size_t)blockIdx.x * per_prn;
+  const unsigned int m1 = top;
+  unsigned int w2 = 0, holders = 0;
+  for (int i = threadIdx.x; i < per_prn; i += blockDim.x) {
+    const unsigned int mi = (unsigned int)(mine[2 * i] >> 32);
+    w2 = max(w2, sec[i]);
+    if (mi == m1) ++holders;
+    else w2 = max(w2, mi);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    w2 = max(w2, (unsigned int)__shfl_xor((int)w2, off, 64));
+    holders += (unsigned int)__shfl_xor((int)holders, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s2[threadIdx.x >> 6] = w2;
+    sh[threadIdx.x >> 6] = holders;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      w2 = max(w2, s2[w]);
+      holders += sh[w];
+    }
+    if (holders > 1) w2 = m1;
+    sec_out[blockIdx.x] = max(sec_out[blockIdx.x], w2);
   }
 }
 
@@ -1650,7 +1717,7 @@ __global__ __launch_bounds__(256) void keys_reduce_kernel(const unsigned long lo
 // `keys` != nullptr: also the peak pick of the finished results (last code arm of a PRN) over their first `valid` columns
 __global__ __launch_bounds__(256) void abs_combine_kernel(const float* __restrict__ part, int groups, int nbins, int n,
                                                           float* __restrict__ out, int add, float inv_n, float scale,
-                                                          unsigned long long* keys, int valid) {
+                                                          unsigned long long* keys, int valid, unsigned int* seconds = nullptr) {
   // keys: this launch's slot region (2 keys per workgroup), nullptr: no peak pick
   PeakTrack pk;
   const long long total = (long long)nbins * n;
@@ -1691,16 +1758,17 @@ __global__ __launch_bounds__(256) void abs_combine_kernel(const float* __restric
         if (c < valid) pk.see(v, (unsigned int)bin, (unsigned int)c);
       }
   }
-  if (keys) pk.publish_slot(keys + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+  if (keys) pk.publish_slot(keys + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x), seconds ? seconds + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr);
 }
 
 // the peak pick alone (results written by the pass kernel itself: no hop groups)
-__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ r, int nbins, int n, unsigned long long* keys, int valid) {
+__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ r, int nbins, int n, unsigned long long* keys, int valid,
+                                                   unsigned int* second = nullptr) {
   PeakTrack pk;
   for (int bin = blockIdx.y; bin < nbins; bin += gridDim.y)
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < valid; c += gridDim.x * blockDim.x)
       pk.see(r[(long long)bin * n + c], (unsigned int)bin, (unsigned int)c);
-  pk.publish(keys);
+  pk.publish(keys, second);
 }
 
 // ---- sigPower inputs: exact integer sums of the first spc samples (acquisition.m:151) -------------------
@@ -2195,6 +2263,11 @@ struct AcqScratch {
   int peaks_cap = 0;
   unsigned long long* slots = nullptr;  // per-workgroup peak candidates of abs_combine_kernel, one region per PRN
   size_t slots_cap = 0;
+  unsigned int* sec_slots = nullptr;    // per-workgroup runner-up values (float bits), slots_cap / 2 of them (ensure_slots)
+  // the float64 guard (acq_guard.h): per-PRN runner-up, cells, their per-hop values, the slow path's candidate list + count
+  GcBuf b_second, b_cells, b_exact, b_list, b_off;
+  int guard_ties = 0;          // PRNs of the last search whose runner-up was within gc_acq_tie_eps of the winner (resolved in float64)
+  double guard_max_dev = 0.0;  // largest |float32 peak - float64 peak| / float64 peak over the last search's PRNs
   int slots_per_prn = 0;                // workgroups per region in the call under way (0: keys were published directly)
 };
 
@@ -2248,7 +2321,7 @@ bool lane_events(AcqScratch* s) {
 void free_scratch(AcqScratch* s) {
   if (!s) return;
   void* ptrs[] = {s->tw, s->sig, s->tmp, s->codespec, s->results, s->partial, s->codes, s->sums, s->rowmax, s->rowarg, s->peaks, s->slots,
-                  s->tmp2, s->results2, s->partial2};
+                  s->tmp2, s->results2, s->partial2, s->sec_slots};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -2256,8 +2329,29 @@ void free_scratch(AcqScratch* s) {
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
   if (s->pinned) (void)hipHostFree(s->pinned);
-  for (GcBuf* b : {&s->b_codes, &s->b_chips, &s->b_codespec, &s->b_rowmax, &s->b_rowarg, &s->b_rows, &s->b_pick}) gc_buf_free(*b);
+  for (GcBuf* b : {&s->b_codes, &s->b_chips, &s->b_codespec, &s->b_rowmax, &s->b_rowarg, &s->b_rows, &s->b_pick, &s->b_second, &s->b_cells, &s->b_exact,
+                   &s->b_list, &s->b_off})
+    gc_buf_free(*b);
   delete s;
+}
+
+// Room for `want` slot keys (two per workgroup) and, next to them, one runner-up value per workgroup (sec_slots).  Both are cleared
+// only when they are (re)allocated: every workgroup of a launch stores into its own slot unconditionally.
+int ensure_slots(AcqScratch* s, size_t want) {
+  if (s->slots_cap >= want) return GC_OK;
+  GC_HIP(hipDeviceSynchronize());  // (both lanes of the PRN loop: the buffers are theirs together)
+  if (s->slots) (void)hipFree(s->slots);
+  if (s->sec_slots) (void)hipFree(s->sec_slots);
+  s->slots = nullptr;
+  s->sec_slots = nullptr;
+  s->slots_cap = 0;
+  GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
+  GC_HIP(hipMalloc((void**)&s->sec_slots, (want / 2 + 1) * sizeof(unsigned int)));
+  GC_HIP(hipMemset(s->slots, 0, want * sizeof(unsigned long long)));
+  GC_HIP(hipMemset(s->sec_slots, 0, (want / 2 + 1) * sizeof(unsigned int)));
+  GC_HIP(hipDeviceSynchronize());
+  s->slots_cap = want;
+  return GC_OK;
 }
 
 // Last inverse pass (POST_ABS_ACC) over `nbins` bins.  With few bins the launch would have ~2 workgroups per CU, each
@@ -2291,16 +2385,7 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
       // circshift search, last arm: per-workgroup candidates (tiles of one row each) instead of the sums themselves
       const int tiles_ct = a.nvec / c1;
       const size_t want = (size_t)nbins_total * tiles_ct * 2 * (size_t)std::max(1, s->shift_slot_lanes);  // (gc_acq_shift_search_batch: a region per lane)
-      if (s->slots_cap < want) {
-        GC_HIP(hipDeviceSynchronize());
-        if (s->slots) (void)hipFree(s->slots);
-        s->slots = nullptr;
-        s->slots_cap = 0;
-        GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
-        GC_HIP(hipMemset(s->slots, 0, want * sizeof(unsigned long long)));
-        GC_HIP(hipDeviceSynchronize());
-        s->slots_cap = want;
-      }
+      if (int rc = ensure_slots(s, want)) return rc;
       unsigned long long* const region = s->slots + (size_t)s->lane * (size_t)nbins_total * tiles_ct * 2 * (s->shift_slot_lanes > 1 ? 1 : 0);
       a.peak_slots = region + (size_t)bin0 * tiles_ct * 2;
       a.peak_valid = valid;
@@ -2326,29 +2411,23 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
     if (fused_peak) {
       const int per = (int)((long long)(a.nvec / c1) * nbins_total);  // the specialised kernel's grid (over all chunks)
       const size_t want = (size_t)nprn * per * 2;
-      if (s->slots_cap < want) {
-        GC_HIP(hipDeviceSynchronize());  // (both lanes of the PRN loop: the buffer is theirs together)
-        if (s->slots) (void)hipFree(s->slots);
-        s->slots = nullptr;
-        s->slots_cap = 0;
-        GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
-        GC_HIP(hipMemset(s->slots, 0, want * sizeof(unsigned long long)));
-        GC_HIP(hipDeviceSynchronize());
-        s->slots_cap = want;
-      }
+      if (int rc = ensure_slots(s, want)) return rc;
       s->slots_per_prn = per;
       a.peak_slots = s->slots + ((size_t)ip * per + (size_t)bin0 * (a.nvec / c1)) * 2;
+      a.peak_second = s->sec_slots + ((size_t)ip * per + (size_t)bin0 * (a.nvec / c1));
       a.peak_valid = valid;
     }
     a.batch0 = bin0;
     bool used_ct = false;
     int rc = launch_pass(ctx, a, nbins, &used_ct);
     a.peak_slots = nullptr;
+    a.peak_second = nullptr;
     a.batch0 = 0;
     if (rc || !keys) return rc;
     if (fused_peak && used_ct) return GC_OK;
     if (fused_peak) s->slots_per_prn = 0;  // the generic pass kernel took it after all (tuning knobs): it wrote the results, peak_kernel reads them
-    hipLaunchKernelGGL(peak_kernel, pgrid, dim3(256), 0, ctx->stream, a.acc_out, (int)nbins, a.n, keys, valid);
+    hipLaunchKernelGGL(peak_kernel, pgrid, dim3(256), 0, ctx->stream, a.acc_out, (int)nbins, a.n, keys, valid,
+                       s->b_second.p ? (unsigned int*)s->b_second.p + ip : nullptr);
     GC_HIP(hipGetLastError());
     return GC_OK;
   }
@@ -2371,21 +2450,12 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
   if (keys) {  // PRN ip of nprn: its own region of candidate slots, reduced into the keys after the last PRN (finish_keys)
     const int per = (int)(pgrid.x * pgrid.y);
     const size_t want = (size_t)nprn * per * 2;
-    if (s->slots_cap < want) {
-      GC_HIP(hipDeviceSynchronize());  // (both lanes of the PRN loop: the buffer is theirs together)
-      if (s->slots) (void)hipFree(s->slots);
-      s->slots = nullptr;
-      s->slots_cap = 0;
-      GC_HIP(hipMalloc((void**)&s->slots, want * sizeof(unsigned long long)));
-      GC_HIP(hipMemset(s->slots, 0, want * sizeof(unsigned long long)));
-      GC_HIP(hipDeviceSynchronize());
-      s->slots_cap = want;
-    }
+    if (int rc = ensure_slots(s, want)) return rc;
     s->slots_per_prn = per;
     region = s->slots + (size_t)ip * per * 2;
   }
   hipLaunchKernelGGL(abs_combine_kernel, pgrid, dim3(256), 0, ctx->stream, part, hg, (int)nbins, a.n, a.acc_out, a.acc_add,
-                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, region, valid);
+                     1.0f / (float)a.n, a.acc_scale != 0.0f ? a.acc_scale : 1.0f, region, valid, region ? s->sec_slots + (size_t)ip * (pgrid.x * pgrid.y) : nullptr);
   GC_HIP(hipGetLastError());
   return GC_OK;
 }
@@ -2473,6 +2543,63 @@ static int forward(gc_context* ctx, AcqScratch* s, PassArgs base, int pre, long 
   a.out = dst;
   a.out_batch_stride = pl.n;
   return launch_pass(ctx, a, nbatch);
+}
+
+// The guard's slow path for ONE PRN whose runner-up is within eps of its winner: `rerun(ip)` searches the PRN again with the sums of all
+// its bins written (s->results, [nbins][n]); every cell at or above `thr` within the first `valid` columns is re-evaluated in float64
+// and the reference's rule picks: the largest value, the smallest bin and the smallest column holding it (acquisition.m:196-198).
+// More than kGuardListCap such cells (a plateau: a record of zeros, a saturated block - inputs on which the float32 sums are exact
+// anyway): the float32 decision stands.
+template <class Rerun>
+int guard_resolve(gc_context* ctx, AcqScratch* s, const GcExactSetup& ex, int ip, int nbins, int n, int valid, int H, float thr, double f0_row, double fstep,
+                  long long first, Rerun rerun, int* bin, int* col, double* val) {
+  int rc = rerun(ip);
+  if (rc) return rc;
+  int* const d_count = (int*)s->b_list.p;
+  int2* const d_list = (int2*)((char*)s->b_list.p + 64);
+  GC_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+  rc = gc_collect_cells(ctx->stream, s->results, nbins, (long long)n, valid, thr, d_count, d_list, kGuardListCap);
+  if (rc) return rc;
+  int count = 0;
+  GC_HIP(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  if (count <= 0 || count > kGuardListCap) return GC_OK;
+  std::vector<int2> list((size_t)count);
+  GC_HIP(hipMemcpy(list.data(), d_list, list.size() * sizeof(int2), hipMemcpyDeviceToHost));
+  std::vector<GcExactCell> cells((size_t)count);
+  for (int k = 0; k < count; ++k) {
+    GcExactCell& c = cells[(size_t)k];
+    c.code = ip;
+    c.col = list[(size_t)k].y;
+    c.shift = 0;
+    c.bin = list[(size_t)k].x;
+    c.freq = f0_row - fstep * (double)c.bin;
+    c.first = first;
+  }
+  GC_HIP(hipMemcpyAsync(s->b_cells.p, cells.data(), cells.size() * sizeof(GcExactCell), hipMemcpyHostToDevice, ctx->stream));
+  rc = gc_exact_cells(ctx->stream, ex, (const GcExactCell*)s->b_cells.p, count, (double*)s->b_exact.p);
+  if (rc) return rc;
+  std::vector<double> part((size_t)count * H);
+  GC_HIP(hipMemcpyAsync(part.data(), s->b_exact.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
+  double best = -1.0;
+  int bb = 0, bc = 0;
+  for (int k = 0; k < count; ++k) {
+    double v = 0.0;
+    for (int h = 0; h < H; ++h) v += part[(size_t)k * H + h];
+    if (v > best) {
+      best = v;
+      bb = cells[(size_t)k].bin;
+      bc = cells[(size_t)k].col;
+    } else if (v == best) {
+      bb = std::min(bb, cells[(size_t)k].bin);
+      bc = std::min(bc, cells[(size_t)k].col);
+    }
+  }
+  *bin = bb;
+  *col = bc;
+  *val = best;
+  return GC_OK;
 }
 
 extern "C" int gc_acquire_coarse_multi(gc_context* ctx, const gc_acq_params* p, int nprn, int narms,
@@ -2660,6 +2787,18 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   unsigned long long* const peaks = s->peaks;
   GC_HIP(hipMemsetAsync(peaks, 0, (size_t)nprn * 2 * sizeof(unsigned long long), ctx->stream));
   s->slots_per_prn = 0;
+  // the float64 guard's buffers: per-PRN runner-up (cleared like the keys), winner cells, their per-hop values, per-row offsets
+  if (gc_buf_reserve(s->b_second, (size_t)nprn * sizeof(unsigned int), false) != hipSuccess ||
+      gc_buf_reserve(s->b_cells, (size_t)std::max(nprn, kGuardListCap) * sizeof(GcExactCell), false) != hipSuccess ||
+      gc_buf_reserve(s->b_exact, (size_t)std::max(nprn, kGuardListCap) * H * sizeof(double), false) != hipSuccess ||
+      gc_buf_reserve(s->b_list, (size_t)kGuardListCap * sizeof(int2) + 64, false) != hipSuccess ||
+      gc_buf_reserve(s->b_off, (size_t)nprn * sizeof(double), false) != hipSuccess) {
+    (void)hipGetLastError();
+    gc_set_error("acquisition: no memory for the guard's buffers");
+    return GC_E_NOMEM;
+  }
+  GC_HIP(hipMemsetAsync(s->b_second.p, 0, (size_t)nprn * sizeof(unsigned int), ctx->stream));
+  if (freq_offset) GC_HIP(hipMemcpyAsync(s->b_off.p, freq_offset, (size_t)nprn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 
   // GC_ACQ_FUSED=1: the whole inverse side in one launch where a fused kernel exists for the plan (acq_fused_kernel: N = 36 000 -
   // GPS L1 C/A, L5, Galileo E5a / E5b, BDS B2a / B3I at 18 Msps - and N = 24 000, GLONASS at 12 Msps).  Same results (the parity
@@ -2760,11 +2899,10 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   const int chunk_bins = (nbins + chunks - 1) / chunks;
   chunks = (nbins + chunk_bins - 1) / chunk_bins;
   int lane_rc = GC_OK;
-  for (int item = 0; item < nprn * chunks && !fused && lane_rc == GC_OK; ++item) {
-    const int ip = item / chunks, bin0 = (item % chunks) * chunk_bins, cb = std::min(chunk_bins, nbins - bin0);
-    s->lane = lanes == 2 ? (item & 1) : 0;
-    s->nlanes = lanes;
-    ctx->stream = lanes == 2 ? s->lane_stream[s->lane] : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
+  // One (PRN, chunk of bins) item on the lane and stream that s->lane / ctx->stream name.  with_keys: the item's peak candidates go to
+  // the PRN's keys (and its runner-up to s->b_second); without, the sums of ALL the item's bins are written to the lane's `results`
+  // (the float64 guard's slow path collects its candidate cells from them).
+  auto run_item = [&](int ip, int bin0, int cb, bool with_keys) -> int {
     // (a chunk's batches keep their numbers, bin0 * H on: the chunk's first batch sits at the start of the lane's intermediate)
     float2* const tmp = (s->lane ? s->tmp2 : s->tmp) - (size_t)bin0 * H * marms * (size_t)pl.n;
     float* const results = s->lane ? s->results2 : s->results;
@@ -2796,14 +2934,11 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
       a.batch0 = (int)((long long)bin0 * H / row_reps);
       a.arm_batches = merge_arms ? (int)((long long)cb * H / row_reps) : 0;
       a.narms_merged = marms;
-      rc = launch_pass(ctx, a, (long long)marms * cb * H / row_reps);
+      int rc = launch_pass(ctx, a, (long long)marms * cb * H / row_reps);
       a.batch0 = 0;
       a.arm_batches = 0;
       a.nhops = marms * H;  // the columns pass adds the arms of a bin like hops
-      if (rc) {
-        lane_rc = rc;
-        break;
-      }
+      if (rc) return rc;
       // I2: columns (length n1, stride n2), inverse, |.|/n accumulated over the hops of each bin
       a.out_blocked = 0;
       a.row_reps = 0;
@@ -2819,12 +2954,17 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
       a.acc_out = results;
       a.acc_add = arm > 0;
       a.acc_scale = (float)p->arm_weight[arm];  // 0: 1
-      rc = launch_abs_pass(ctx, s, a, cb, (merge_arms || arm == narms - 1) ? peaks + 2 * ip : nullptr, blk, ip, nprn, nullptr, bin0, nbins);
-      if (rc) {
-        lane_rc = rc;
-        break;
-      }
+      rc = launch_abs_pass(ctx, s, a, cb, (with_keys && (merge_arms || arm == narms - 1)) ? peaks + 2 * ip : nullptr, blk, ip, nprn, nullptr, bin0, nbins);
+      if (rc) return rc;
     }
+    return GC_OK;
+  };
+  for (int item = 0; item < nprn * chunks && !fused && lane_rc == GC_OK; ++item) {
+    const int ip = item / chunks, bin0 = (item % chunks) * chunk_bins, cb = std::min(chunk_bins, nbins - bin0);
+    s->lane = lanes == 2 ? (item & 1) : 0;
+    s->nlanes = lanes;
+    ctx->stream = lanes == 2 ? s->lane_stream[s->lane] : stream1;  // launch_pass / launch_abs_pass launch on the context's stream
+    lane_rc = run_item(ip, bin0, cb, true);
   }
   ctx->stream = stream1;
   s->lane = 0;
@@ -2841,23 +2981,79 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
     (void)hipDeviceSynchronize();
     return lane_rc;
   }
+  unsigned int* const seconds = (unsigned int*)s->b_second.p;
   if (!fused && s->slots_per_prn) {
-    hipLaunchKernelGGL(keys_reduce_kernel, dim3((unsigned int)nprn), dim3(256), 0, ctx->stream, s->slots, s->slots_per_prn, peaks);
+    hipLaunchKernelGGL(keys_reduce_kernel, dim3((unsigned int)nprn), dim3(256), 0, ctx->stream, s->slots, s->slots_per_prn, peaks, s->sec_slots, seconds);
     GC_HIP(hipGetLastError());
   }
+  // ---- the float64 guard (acq_guard.h; GC_ACQ_NO_GUARD=1 in the tuning build: the float32 values as before) ----------------------
+  // Always: the winner's cell of every PRN again in float64, so that peak / peakMetric - the numbers the caller thresholds
+  // (acquisition.m:200-206) - carry no float32 transform error.  The cells are decoded from the keys on the device: one read-back.
+  const bool guard = !fused && GC_TUNE_ENV("GC_ACQ_NO_GUARD") == nullptr;
+  GcExactSetup ex;
+  ex.if_i8 = cond ? nullptr : (const int8_t*)ctx->d_if;
+  ex.if_f32 = cond_sig;
+  ex.blk = blk;
+  ex.cl = cl;
+  ex.hop_stride = base.spc;
+  ex.nhops = H;
+  ex.narms = narms;
+  for (int arm = 0; arm < narms; ++arm) ex.w[arm] = p->arm_weight[arm] != 0.0 ? p->arm_weight[arm] : 1.0;
+  ex.codes = s->codes;
+  ex.code_stride = cl;
+  ex.fs = p->sampling_freq;
+  GcExactCell* const d_cells = (GcExactCell*)s->b_cells.p;
+  double* const d_exact = (double*)s->b_exact.p;
+  if (guard) {
+    rc = gc_exact_cells_from_keys(ctx->stream, peaks, nprn, base.f0, base.fstep, freq_offset ? (const double*)s->b_off.p : nullptr, p->first_sample, d_cells);
+    if (!rc) rc = gc_exact_cells(ctx->stream, ex, d_cells, nprn, d_exact);
+    if (rc) return rc;
+  }
   std::vector<unsigned long long> hpeaks((size_t)nprn * 2);
+  std::vector<unsigned int> hsec((size_t)nprn, 0u);
+  std::vector<double> hexact((size_t)nprn * H, 0.0);
   GC_HIP(hipMemcpyAsync(hpeaks.data(), peaks, hpeaks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  if (guard) {
+    GC_HIP(hipMemcpyAsync(hsec.data(), seconds, hsec.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipMemcpyAsync(hexact.data(), d_exact, hexact.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
   GC_HIP(hipStreamSynchronize(ctx->stream));
+  const double eps = gc_acq_tie_eps(pl.n);
+  s->guard_ties = 0;
+  s->guard_max_dev = 0.0;
   for (int ip = 0; ip < nprn; ++ip) {
-    const int harg[2] = {(int)(0xffffffffu - (unsigned int)(hpeaks[2 * ip] & 0xffffffffu)),
-                         (int)(0xffffffffu - (unsigned int)(hpeaks[2 * ip + 1] & 0xffffffffu))};
+    int harg[2] = {(int)(0xffffffffu - (unsigned int)(hpeaks[2 * ip] & 0xffffffffu)),
+                   (int)(0xffffffffu - (unsigned int)(hpeaks[2 * ip + 1] & 0xffffffffu))};
     const unsigned int bits = (unsigned int)(hpeaks[2 * ip] >> 32);
-    float peak;
-    std::memcpy(&peak, &bits, sizeof peak);
+    float peak32;
+    std::memcpy(&peak32, &bits, sizeof peak32);
+    double peak = (double)peak32;
+    if (guard && hpeaks[2 * ip] != 0) {
+      float second32;
+      std::memcpy(&second32, &hsec[(size_t)ip], sizeof second32);
+      double exact = 0.0;
+      for (int h = 0; h < H; ++h) exact += hexact[(size_t)ip * H + h];  // hop order, acquisition.m:186-190
+      if (exact > 0.0) s->guard_max_dev = std::max(s->guard_max_dev, std::fabs((double)peak32 - exact) / exact);
+      // Near-tie: another cell within eps of the winner.  Which of them is the larger - and so codePhase, the coarse bin, everything
+      // the fine stage is then run on - is decided on float64 values of ALL the cells that close, by the reference's rule: the largest
+      // value, the first bin and the first column that hold it (acquisition.m:196-198).
+      if (peak32 > 0.0f && (double)second32 >= (double)peak32 * (1.0 - eps)) {
+        ++s->guard_ties;
+        int gbin = harg[0], gcol = harg[1];
+        double gval = exact;
+        rc = guard_resolve(ctx, s, ex, ip, nbins, pl.n, blk, H, (float)((double)peak32 * (1.0 - eps)), base.f0 + (freq_offset ? freq_offset[ip] : 0.0), base.fstep,
+                           p->first_sample, [&](int q) { s->lane = 0; s->nlanes = 1; return run_item(q, 0, nbins, false); }, &gbin, &gcol, &gval);
+        if (rc) return rc;
+        harg[0] = gbin;
+        harg[1] = gcol;
+        exact = gval;
+      }
+      peak = exact;
+    }
     out[ip].coarse_bin = harg[0] + 1;   // 1-based like MATLAB
     out[ip].code_phase = harg[1] + 1;
-    out[ip].peak = (double)peak;
-    out[ip].peak_metric = (double)peak / sig_power / H;  // :200
+    out[ip].peak = peak;
+    out[ip].peak_metric = peak / sig_power / H;  // :200
     out[ip].coarse_freq = p->intermediate_freq + (freq_offset ? freq_offset[ip] : 0.0) + p->search_band - p->search_step * harg[0];
   }
   return GC_OK;
@@ -3795,6 +3991,18 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
 
 // Test hook: forward FFT of `nbatch` host sequences of length n (complex64) with the library's
 // transform; output in natural frequency order.
+extern "C" int gc_acq_guard_stats(gc_context* ctx, int32_t* ties, double* max_dev, double* eps) {
+  AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
+  if (!s) {
+    gc_set_error("gc_acq_guard_stats: nothing searched yet");
+    return GC_E_STATE;
+  }
+  if (ties) *ties = s->guard_ties;
+  if (max_dev) *max_dev = s->guard_max_dev;
+  if (eps) *eps = gc_acq_tie_eps(s->plan.n);
+  return GC_OK;
+}
+
 extern "C" int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in, float* out_natural, int inverse) {
   if (!ctx || n <= 1 || nbatch <= 0 || !in || !out_natural) return GC_E_INVALID;
   GC_HIP(hipSetDevice(ctx->device));

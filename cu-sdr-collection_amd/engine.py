@@ -51,6 +51,12 @@ class Engine:
         L.check(self._lib.gc_device_info(self._ctx, name, 128, C.byref(cus)))
         return name.value.decode(), cus.value
 
+    def acq_guard_stats(self):
+        """gc_acq_guard_stats of the last search: {ties, max_dev, eps} (include/gnsscorr.h)."""
+        t, d, e = C.c_int32(), C.c_double(), C.c_double()
+        L.check(self._lib.gc_acq_guard_stats(self._ctx, C.byref(t), C.byref(d), C.byref(e)))
+        return {"ties": int(t.value), "max_dev": float(d.value), "eps": float(e.value)}
+
     def synchronize(self):
         L.check(self._lib.gc_synchronize(self._ctx))
 

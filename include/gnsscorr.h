@@ -543,6 +543,14 @@ int gc_debug_wave_transpose_sum(gc_context* ctx, int k, const float* in, float* 
  * values (n of the form 2^a 3^b 5^c); output in natural order, unnormalised. */
 int gc_debug_fft(gc_context* ctx, int n, int nbatch, const float* in, float* out, int inverse);
 
+/* The float64 guard of the last search of this context (gc_acquire_coarse*, gc_acq_shift_search_batch): the searches transform in
+ * float32, the reference decides in float64 (acquisition.m:196-206 max(max(results)), peakMetric > acqThreshold; BDS/B1I acquisition.m:
+ * 141-166 max_peak / second).  Every PRN's winning cell is evaluated again in float64 as a circular correlation at one lag, so peak
+ * and peak_metric leave the library without the transforms' rounding; a PRN whose runner-up lies within *eps (relative) of its winner
+ * has every cell that close re-evaluated and the reference's first-occurrence rule applied to the float64 values.
+ * ties: PRNs of the last search resolved that way; max_dev: largest |float32 peak - float64 peak| / float64 peak over its PRNs. */
+int gc_acq_guard_stats(gc_context* ctx, int32_t* ties, double* max_dev, double* eps);
+
 #ifdef __cplusplus
 }
 #endif

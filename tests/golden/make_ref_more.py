@@ -97,7 +97,7 @@ def gen_acq_default_parts(only=None):
 
 
 def gen_acq(only=None, scenes=None):
-    for sc in (RS.ACQ_SCENES if scenes is None else scenes):
+    for sc in (RS.ACQ_SCENES + RS.GUARD_ACQ_SCENES if scenes is None else scenes):
         if only and only != sc.name:
             continue
         t0 = time.time()

@@ -472,6 +472,66 @@ ACQ_SCENES = [
 ]
 
 
+# ---- constructed near-ties and near-threshold metrics (the float64 guard of csrc/acq_guard.h) ----------------------------------------
+# The HIP searches transform in float32; the reference picks `[peakSize, codePhase] = max(max(results))` and gates on `peakMetric >
+# acqThreshold` in float64 (GPS_L1CA/include/acquisition.m:196-206).  These records put two cells of `results`, or the metric and the
+# threshold, a few 1e-7 apart (relative): far above anything float64 transforms could confuse (~1e-13), below what float32 ones resolve.
+_TIE_PRN, _TIE_TAU0 = 7, 4321
+
+
+def _sampled_ca(P, S, prn):
+    return np.asarray(P.codes.makeCaTable(prn, S), dtype=np.float64)          # one code period at the sampling rate (makeCaTable.m)
+
+
+def _acq_tie_cols_record(P, S):
+    """IF = 0, no noise, Q = 0: PRN 7 twice, one sample apart, at exactly 0 Hz (bin 15 of 29) - columns tau0 and tau0 + 1 of that bin hold
+    the same integer sum per hop; ONE sample raised by 1 where the replica's neighbours differ makes the LATER column larger by 2 in
+    one hop (3.6e-7 of the sum over the hops): first-occurrence on float32-equal values would answer tau0."""
+    t = _sampled_ca(P, S, _TIE_PRN)
+    spc, n = t.shape[0], 44 * t.shape[0]
+    idx = np.arange(n)
+    xi = 40.0 * (t[(idx - _TIE_TAU0) % spc] + t[(idx - _TIE_TAU0 - 1) % spc])
+    k = next(k for k in range(100, spc - 1) if t[k] == 1.0 and t[k + 1] == -1.0)    # column tau0 + 1 sees t[k] = +1 there, column tau0 t[k + 1] = -1
+    xi[_TIE_TAU0 + 1 + k] += 1.0
+    rec = np.zeros(2 * n, dtype=np.int8)
+    rec[0::2] = xi.astype(np.int8)
+    return rec
+
+
+def _acq_tie_bins_record(P, S):
+    """IF = 0, no noise: PRN 7 on a REAL carrier cos(2 pi 500 t), Q = 0 - the bins at +500 and -500 Hz (14 and 16 of 29) are complex
+    conjugates of each other, equal in magnitude whatever the int8 rounding did; ONE sample of Q set to 1 tilts them by ~5e-7
+    towards the LATER bin."""
+    t = _sampled_ca(P, S, _TIE_PRN)
+    spc, n = t.shape[0], 44 * t.shape[0]
+    idx = np.arange(n)
+    xi = np.rint(100.0 * t[(idx - _TIE_TAU0) % spc] * np.cos(2.0 * np.pi * 500.0 * idx / S.samplingFreq))
+    rec = np.zeros(2 * n, dtype=np.int8)
+    rec[0::2] = xi.astype(np.int8)
+    rec[2 * (_TIE_TAU0 + 777) + 1] = _TIE_BINS_Q
+    return rec
+
+
+_TIE_BINS_Q = 1          # the sign that makes bin 16 (-500 Hz) the larger one (checked by test_ref_vectors against the fixture's carrFreq)
+_THR_METRIC_PRN22 = 4.690999243563728       # peakMetric(22) of the GPS_L1CA scene's record: oracle and reference fixture agree to the last bit
+
+GUARD_ACQ_SCENES = [
+    AcqScene("GPS_L1CA_tie_cols", "GPS/GPS_L1CA", "initSettings", dict(IF=0.0, acqNonCohTime=4, acqSatelliteList=[_TIE_PRN]), _acq_tie_cols_record,
+             product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0),
+             oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=1e-9),
+    AcqScene("GPS_L1CA_tie_bins", "GPS/GPS_L1CA", "initSettings", dict(IF=0.0, acqNonCohTime=4, acqSatelliteList=[_TIE_PRN]), _acq_tie_bins_record,
+             product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0),
+             oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=1e-9),
+    # the GPS_L1CA scene's record with the threshold 2.5e-7 (relative) below / above PRN 22's metric: detected / not detected
+    AcqScene("GPS_L1CA_thr_below", "GPS/GPS_L1CA", "initSettings", dict(acqNonCohTime=4, acqSatelliteList=[22, 3], acqThreshold=_THR_METRIC_PRN22 * (1.0 - 2.5e-7)),
+             _acq_l1ca_record, product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0),
+             oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=1e-9),
+    AcqScene("GPS_L1CA_thr_above", "GPS/GPS_L1CA", "initSettings", dict(acqNonCohTime=4, acqSatelliteList=[22, 3], acqThreshold=_THR_METRIC_PRN22 * (1.0 + 2.5e-7)),
+             _acq_l1ca_record, product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0),
+             oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=1e-9),
+]
+
+
 # ---- the reference's DEFAULT searches: settings = initSettings() unmodified (only the record is ours) -----------------------------
 # GPS L1 C/A 32 PRNs x 29 bins x 20 hops (GPS_L1CA/initSettings.m:80-89), GPS L5 25 hops (GPS_L5C/initSettings.m:74-83), Galileo E5b
 # 168 bins of 60 Hz x 15 hops x 36 PRNs (GAL_E5b/initSettings.m:83-92), Galileo E1 94 bins x 144 000 points (GAL_E1C/initSettings.m:81-89),

@@ -147,6 +147,33 @@ def test_hip_acquisition_equals_the_references_acquisition_m(engine, sc):
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
 
 
+@pytest.mark.parametrize("sc", RS.GUARD_ACQ_SCENES, ids=[s.name for s in RS.GUARD_ACQ_SCENES])
+def test_hip_acquisition_on_constructed_near_ties_and_near_threshold_metrics(engine, sc):
+    """The float64 guard (csrc/acq_guard.h).  The searches transform in float32; the reference decides `max(max(results))` and
+    `peakMetric > acqThreshold` in float64 (GPS_L1CA/include/acquisition.m:196-206).  Records with two cells of `results` 2e-7 apart
+    (two columns: the same satellite twice, one sample apart; two bins: a real carrier, whose +-500 Hz bins are conjugates) and a
+    threshold 2.5e-7 below / above a satellite's metric: codePhase, carrFreq AND the detected set identical to the reference's own
+    acquisition.m, the metric to 1e-9 - the winner's cell is re-evaluated in float64 for every PRN, all cells within eps of a
+    near-tied winner are, and the reference's first-occurrence rule runs on those values."""
+    import cu_sdr_collection_amd as P
+    z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
+    S, rec = RS.acq_inputs(P, sc)
+    assert RS.crc(rec) == int(z["record_crc32"][0])
+    engine.load_if(rec, fs=S.samplingFreq)
+    got = sc.product(P, engine, S)
+    st = engine.acq_guard_stats()
+    for f in sc.fields:
+        want, have = z["f_" + f], np.asarray(getattr(got, f), dtype=np.float64)
+        if f == "peakMetric":
+            assert np.max(np.abs(have - want)) <= 1e-9 * np.max(np.abs(want)), (sc.name, np.max(np.abs(have - want)) / np.max(np.abs(want)))
+        else:
+            assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want], st)
+    assert np.array_equal(np.asarray(got.carrFreq) != 0, z["f_carrFreq"] != 0)          # the detected set
+    assert 2e-5 < st["eps"] < 2e-4 and st["max_dev"] < st["eps"] / 8, st                 # float32 stayed well inside the band the guard assumes
+    if "tie" in sc.name:
+        assert st["ties"] == 1, st                                                       # the slow path did run for the constructed tie
+
+
 def _compare_acq(sc, z, got):
     for f in sc.fields:
         want = z["f_" + f]

@@ -242,6 +242,37 @@ def test_oracle_acquisition_equals_the_references_acquisition_m(sc):
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
 
 
+@pytest.mark.parametrize("sc", RS.GUARD_ACQ_SCENES, ids=[s.name for s in RS.GUARD_ACQ_SCENES])
+def test_oracle_on_the_constructed_near_ties_and_near_threshold_metrics(sc):
+    """The guard scenes (tests/ref_scenes.py GUARD_ACQ_SCENES): two cells of `results`, or the metric and the threshold, 2e-7 apart
+    (relative).  The float64 oracle and the reference's acquisition.m (executed by oracle/mlab) agree on which wins - and the records
+    really are that close: the winner's margin over the runner-up cell is between 1e-9 and 1e-6."""
+    import cu_sdr_collection_amd as P
+    z = _load(f"ref_acq_{sc.name}.npz")
+    S, rec = RS.acq_inputs(P, sc)
+    assert RS.crc(rec) == int(z["record_crc32"][0])
+    x = rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64)
+    got, res = O.acquisition_l1ca(x, S, want_results=True)
+    for f in sc.fields:
+        want, have = z["f_" + f], np.asarray(getattr(got, f), dtype=np.float64)
+        if f == "peakMetric":
+            assert np.max(np.abs(have - want)) <= 1e-12 * np.max(np.abs(want)), (sc.name, f)
+        else:
+            assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
+    if "tie" in sc.name:
+        r = res[RS._TIE_PRN]
+        top = np.sort(r.ravel())[::-1]
+        assert 1e-9 < (top[0] - top[1]) / top[0] < 1e-6
+        b, c = np.unravel_index(int(np.argmax(r)), r.shape)
+        # the winner is NOT the first of the near-tied cells in MATLAB's order: a first-occurrence pick over float32-equal values would miss it
+        near = np.argwhere(r >= top[0] * (1.0 - 1e-6))
+        assert (near[:, 1].min() < c) if "cols" in sc.name else (near[:, 0].min() < b)
+        assert got.carrFreq[RS._TIE_PRN - 1] == (1.0 if "cols" in sc.name else -500.0)     # (0 Hz is reported as 1, acquisition.m:258-260)
+    else:
+        m = got.peakMetric[21]
+        assert abs(m / S.acqThreshold - 1.0) < 3e-7 and (got.carrFreq[21] != 0) == (m > S.acqThreshold) == ("below" in sc.name)
+
+
 @pytest.mark.parametrize("sc", RS.DEFAULT_ACQ_SCENES, ids=[s.name for s in RS.DEFAULT_ACQ_SCENES])
 def test_default_size_acquisition_fixtures_belong_to_their_scenes(sc):
     """The default-search fixtures (initSettings() unmodified; minutes of the interpreter each, so the oracle is not re-run here):
