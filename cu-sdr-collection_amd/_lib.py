@@ -101,7 +101,7 @@ class gc_acq_shift_params(C.Structure):
 
 
 class gc_acq_shift_pick(C.Structure):
-    _fields_ = [("row", C.c_int32), ("code_phase", C.c_int32), ("peak", C.c_float), ("second_peak", C.c_float)]
+    _fields_ = [("row", C.c_int32), ("code_phase", C.c_int32), ("peak", C.c_double), ("second_peak", C.c_double)]
 
 
 GC_SHIFT_PICK_GLOBAL, GC_SHIFT_PICK_SEQUENTIAL, GC_SHIFT_PICK_SEQUENTIAL_PAIRS = 0, 1, 2

@@ -3705,15 +3705,27 @@ extern "C" int gc_acq_shift_row(gc_context* ctx, int row, float* out) {
 
 // ---- the whole search of a package in one call -------------------------------------------------------------------------------
 namespace {
+// What shift_pick_kernel leaves per PRN (device-internal; the public gc_acq_shift_pick is filled from it and from the float64 guard)
+struct ShiftPickDev {
+  int row;          // in: the winning row (-1: none)
+  int code_phase;   // 0-based first maximum of the row
+  int second_col;   // 0-based first position of the second peak (-1: no second peak asked for or range empty)
+  int near_peak;    // cells of the row at or above peak * (1 - eps), the maximum itself included
+  int near_second;  // cells of the second-peak range at or above second * (1 - eps)
+  float peak, second;
+  int pad_;
+};
+
 // One workgroup per PRN: the first maximum of the winning row (BDS/B1I acquisition.m:126, GPS_L2C :72) and the largest value of the
 // row's first `period` samples outside +-exclude samples of it - the reference's three range cases (B1I :141-156, L2C :77-91;
 // 1-based there: e1 = codePhase - exclude, e2 = codePhase + exclude; e1 < 2: e2 .. period + e1; e2 >= period: e2 - period + 1 .. e1;
-// else 1 .. e1 and e2 .. period).
-__global__ __launch_bounds__(1024) void shift_pick_kernel(const float* __restrict__ rows, long long row_stride, int n, int exclude, int period,
-                                                         gc_acq_shift_pick* __restrict__ picks) {
+// else 1 .. e1 and e2 .. period).  period <= 0: no second peak (GC_SHIFT_PICK_GLOBAL).  For the float64 guard: how many cells lie
+// within eps (relative) of either value - more than one means the float32 ordering decided something it cannot.
+__global__ __launch_bounds__(1024) void shift_pick_kernel(const float* __restrict__ rows, long long row_stride, int n, int exclude, int period, float eps,
+                                                         ShiftPickDev* __restrict__ picks) {
   __shared__ float sv[1024];
   __shared__ int si[1024];
-  gc_acq_shift_pick& pk = picks[blockIdx.x];
+  ShiftPickDev& pk = picks[blockIdx.x];
   if (pk.row < 0) return;
   const float* __restrict__ r = rows + (size_t)blockIdx.x * (size_t)row_stride;
   float best = -1.0f;
@@ -3743,34 +3755,82 @@ __global__ __launch_bounds__(1024) void shift_pick_kernel(const float* __restric
   const int cp = si[0] + 1;  // 1-based, as the reference's ranges
   __syncthreads();
   const int e1 = cp - exclude, e2 = cp + exclude;
-  int lo0, hi0, lo1 = 1, hi1 = 0;  // 1-based inclusive ranges
-  if (e1 < 2) {
-    lo0 = e2;
-    hi0 = period + e1;
-  } else if (e2 >= period) {
-    lo0 = e2 - period + 1;
-    hi0 = e1;
-  } else {
-    lo0 = 1;
-    hi0 = e1;
-    lo1 = e2;
-    hi1 = period;
+  int lo0 = 1, hi0 = 0, lo1 = 1, hi1 = 0;  // 1-based inclusive ranges
+  if (period > 0) {
+    if (e1 < 2) {
+      lo0 = e2;
+      hi0 = period + e1;
+    } else if (e2 >= period) {
+      lo0 = e2 - period + 1;
+      hi0 = e1;
+    } else {
+      lo0 = 1;
+      hi0 = e1;
+      lo1 = e2;
+      hi1 = period;
+    }
   }
   float second = -1.0f;
+  int sc = 0x7fffffff;
+  auto see = [&](int i) {
+    const float v = r[i];
+    if (v > second || (v == second && i < sc)) {
+      second = v;
+      sc = i;
+    }
+  };
   for (int i = lo0 - 1 + (int)threadIdx.x; i < hi0 && i < n; i += 1024)
-    if (i >= 0) second = fmaxf(second, r[i]);
+    if (i >= 0) see(i);
   for (int i = lo1 - 1 + (int)threadIdx.x; i < hi1 && i < n; i += 1024)
-    if (i >= 0) second = fmaxf(second, r[i]);
+    if (i >= 0) see(i);
   sv[threadIdx.x] = second;
+  si[threadIdx.x] = sc;
   __syncthreads();
   for (int off = 512; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + off]);
+    if ((int)threadIdx.x < off) {
+      const float v = sv[threadIdx.x + off];
+      const int i = si[threadIdx.x + off];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
+        sv[threadIdx.x] = v;
+        si[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  const float sec = sv[0];
+  const int sec_col = si[0];
+  __syncthreads();
+  // the guard's counts
+  const float tp = peak * (1.0f - eps), ts2 = sec * (1.0f - eps);
+  int np = 0, ns = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) np += r[i] >= tp ? 1 : 0;
+  if (sec >= 0.0f) {
+    for (int i = lo0 - 1 + (int)threadIdx.x; i < hi0 && i < n; i += 1024)
+      if (i >= 0) ns += r[i] >= ts2 ? 1 : 0;
+    for (int i = lo1 - 1 + (int)threadIdx.x; i < hi1 && i < n; i += 1024)
+      if (i >= 0) ns += r[i] >= ts2 ? 1 : 0;
+  }
+  si[threadIdx.x] = np;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) si[threadIdx.x] += si[threadIdx.x + off];
+    __syncthreads();
+  }
+  np = si[0];
+  __syncthreads();
+  si[threadIdx.x] = ns;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) si[threadIdx.x] += si[threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     pk.code_phase = cp - 1;
     pk.peak = peak;
-    pk.second_peak = sv[0];
+    pk.second = sec >= 0.0f ? sec : 0.0f;
+    pk.second_col = sec >= 0.0f ? sec_col : -1;
+    pk.near_peak = np;
+    pk.near_second = si[0];
   }
 }
 
@@ -3788,8 +3848,9 @@ __global__ __launch_bounds__(256) void shift_expand_codes_kernel(const int8_t* _
 // only if it EXCEEDS the largest so far, starting from 0, and the last bin of every carrier but the first is not looked at - the
 // first position, in scan order, of the largest value, if that is above 0.  v(carrier, bin) = rowmax, or the larger of the two signal
 // blocks' (pairs).  Returns the public row index, or -1.
-int pick_sequential(const gc_acq_shift_params& p, const float* rmax, bool pairs) {
-  float best = 0.0f;
+template <class T>
+int pick_sequential(const gc_acq_shift_params& p, const T* rmax, bool pairs) {
+  T best = 0;
   int row = -1;
   for (int c = 0; c < p.n_carriers; ++c)
     for (int b = 0; b < p.n_bins; ++b) {
@@ -3802,7 +3863,7 @@ int pick_sequential(const gc_acq_shift_params& p, const float* rmax, bool pairs)
         }
       } else {
         const int r1 = (c * 2 + 0) * p.n_bins + b, r2 = (c * 2 + 1) * p.n_bins + b;
-        const float v = std::max(rmax[r1], rmax[r2]);
+        const T v = std::max(rmax[r1], rmax[r2]);
         if (v > best) {
           best = v;
           row = rmax[r1] > rmax[r2] ? r1 : r2;
@@ -3848,8 +3909,8 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
       gc_buf_reserve(s->b_codespec, (size_t)nprn * narms * N * sizeof(float2), false) != hipSuccess ||
       gc_buf_reserve(s->b_rowmax, (size_t)nprn * rows * sizeof(float), false) != hipSuccess ||
       gc_buf_reserve(s->b_rowarg, (size_t)nprn * rows * sizeof(int), false) != hipSuccess ||
-      gc_buf_reserve(s->b_pick, (size_t)nprn * sizeof(gc_acq_shift_pick), false) != hipSuccess ||
-      (second && gc_buf_reserve(s->b_rows, (size_t)nprn * N * sizeof(float), false) != hipSuccess)) {
+      gc_buf_reserve(s->b_pick, (size_t)nprn * sizeof(ShiftPickDev), false) != hipSuccess ||
+      gc_buf_reserve(s->b_rows, (size_t)nprn * N * sizeof(float), false) != hipSuccess) {
     (void)hipGetLastError();
     gc_set_error("gc_acq_shift_search_batch: device allocation failed");
     return GC_E_NOMEM;
@@ -3948,45 +4009,253 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
   std::vector<int> harg((size_t)nprn * rows);
   rc = shift_read_back(ctx, s, hmax.data(), s->b_rowmax.p, sizeof(float) * hmax.size(), harg.data(), s->b_rowarg.p, sizeof(int) * harg.size());
   if (rc) return rc;
+  // ---- the float64 guard (acq_guard.h) --------------------------------------------------------------------------------------------
+  // Row maxima, first maxima and second peaks come out of float32 transforms; the reference's sequential `>` tests (B1I :98-119,
+  // L2C :46-66), `[~, codePhase] = max(corr)` and `max_peak / second > threshold` (B1I :126-166) are float64.  Wherever two candidates
+  // are closer than eps the cells that close are evaluated again as float64 correlations at one lag, and peak / second_peak of every
+  // PRN always are (the two numbers the caller divides and thresholds).
+  const bool guard = GC_TUNE_ENV("GC_ACQ_NO_GUARD") == nullptr;
+  const double eps = gc_acq_tie_eps(pl.n);
+  const double ones[4] = {1.0, 1.0, 1.0, 1.0};
+  const double* const wts = arm_weight ? arm_weight : ones;
+  GcExactSetup ex;
+  ex.if_i8 = p.source == GC_ACQ_SOURCE_CONDITIONED ? nullptr : (const int8_t*)ctx->d_if;
+  ex.if_f32 = p.source == GC_ACQ_SOURCE_CONDITIONED ? (const float2*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p : nullptr;
+  ex.blk = p.n;
+  ex.cl = sample_index ? n_index : p.n;  // (replica entries beyond the index vector are the zero padding)
+  ex.hop_stride = 0;
+  ex.nhops = 1;
+  ex.narms = narms;
+  for (int arm = 0; arm < narms; ++arm) ex.w[arm] = wts[arm];
+  ex.codes = (const int8_t*)s->b_codes.p;
+  ex.code_stride = p.n;
+  ex.fs = p.sampling_freq;
+  auto cell_of = [&](int k, int row, int col) {
+    GcExactCell c;
+    const int carrier = row / (p.n_signals * p.n_bins), sig = (row / p.n_bins) % p.n_signals, bin = row % p.n_bins;
+    c.code = k;
+    c.col = col;
+    c.shift = bin;                                            // circshift(IQfreqDom, bin): the signal times exp(+2i*pi*bin*m/n)
+    c.bin = row;
+    c.freq = p.carrier_f0 + p.carrier_step * (double)carrier;
+    c.first = p.first_sample + (long long)sig * p.n;
+    return c;
+  };
+  s->guard_ties = 0;
+  s->guard_max_dev = 0.0;
+  const size_t cells_cap = (size_t)std::max(2 * nprn, kGuardListCap);
+  if (guard && (gc_buf_reserve(s->b_cells, cells_cap * sizeof(GcExactCell), false) != hipSuccess ||
+                gc_buf_reserve(s->b_exact, cells_cap * sizeof(double), false) != hipSuccess ||
+                gc_buf_reserve(s->b_list, (size_t)kGuardListCap * sizeof(int2) + 64, false) != hipSuccess ||
+                gc_buf_reserve(s->b_rows, (size_t)nprn * N * sizeof(float), false) != hipSuccess)) {
+    (void)hipGetLastError();
+    gc_set_error("gc_acq_shift_search_batch: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  // float64 values of cells {row, col} of PRN k's results
+  auto exact_values = [&](int k, const std::vector<int2>& rc_list, std::vector<double>& vals) -> int {
+    std::vector<GcExactCell> cells(rc_list.size());
+    for (size_t i = 0; i < rc_list.size(); ++i) cells[i] = cell_of(k, rc_list[i].x, rc_list[i].y);
+    GC_HIP(hipMemcpyAsync(s->b_cells.p, cells.data(), cells.size() * sizeof(GcExactCell), hipMemcpyHostToDevice, ctx->stream));
+    int rc2 = gc_exact_cells(ctx->stream, ex, (const GcExactCell*)s->b_cells.p, (int)cells.size(), (double*)s->b_exact.p);
+    if (rc2) return rc2;
+    vals.resize(cells.size());
+    GC_HIP(hipMemcpyAsync(vals.data(), s->b_exact.p, vals.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+  };
+  // Row `row` of PRN k transformed again into the PRN's slot of b_rows; its cells at or above thr collected (<= kGuardListCap, else
+  // *overflow) as {row, col}
+  auto row_cells = [&](int k, int row, float thr, std::vector<int2>& list, bool* overflow) -> int {
+    int rc2 = shift_row_passes(ctx, s, row, narms, cspec + (size_t)k * narms * N, wts, (float*)s->b_rows.p + (size_t)k * N, /*to_slot=*/true);
+    if (rc2) return rc2;
+    int* const d_count = (int*)s->b_list.p;
+    int2* const d_list = (int2*)((char*)s->b_list.p + 64);
+    GC_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    rc2 = gc_collect_cells(ctx->stream, (const float*)s->b_rows.p + (size_t)k * N, 1, (long long)N, p.n, thr, d_count, d_list, kGuardListCap);
+    if (rc2) return rc2;
+    int count = 0;
+    GC_HIP(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    *overflow = count > kGuardListCap;
+    list.assign((size_t)std::max(0, std::min(count, kGuardListCap)), make_int2(0, 0));
+    if (!list.empty()) GC_HIP(hipMemcpy(list.data(), d_list, list.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    for (int2& c : list) c.x = row;  // (the collector numbered the one row it saw 0)
+    return GC_OK;
+  };
+
   // the package's selection rule on the row maxima (host: nprn x rows numbers)
+  std::vector<double> rmd((size_t)rows);
+  std::vector<int> rad((size_t)rows);
   for (int k = 0; k < nprn; ++k) {
     const float* rm = hmax.data() + (size_t)k * rows;
     const int* ra = harg.data() + (size_t)k * rows;
     gc_acq_shift_pick& pk = out[k];
     pk.row = -1;
     pk.code_phase = 0;
-    pk.peak = 0.0f;
-    pk.second_peak = 0.0f;
-    if (rule == GC_SHIFT_PICK_GLOBAL) {
-      // BDS/B1C acquisition.m:193-197: the row of max(max(results,[],2)) (first), the first column holding the global maximum
-      int best = 0;
-      for (int r = 1; r < rows; ++r)
-        if (rm[r] > rm[best]) best = r;
-      int col = ra[best];
-      for (int r = 0; r < rows; ++r)
-        if (rm[r] == rm[best] && ra[r] < col) col = ra[r];
-      pk.row = best;
-      pk.code_phase = col;
-      pk.peak = rm[best];
-    } else {
-      pk.row = pick_sequential(p, rm, pairs);
+    pk.peak = 0.0;
+    pk.second_peak = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      rmd[(size_t)r] = (double)rm[r];
+      rad[(size_t)r] = ra[r];
+    }
+    auto apply_rule = [&]() {
+      if (rule == GC_SHIFT_PICK_GLOBAL) {
+        // BDS/B1C acquisition.m:193-197: the row of max(max(results,[],2)) (first), the first column holding the global maximum
+        int best = 0;
+        for (int r = 1; r < rows; ++r)
+          if (rmd[(size_t)r] > rmd[(size_t)best]) best = r;
+        int col = rad[(size_t)best];
+        for (int r = 0; r < rows; ++r)
+          if (rmd[(size_t)r] == rmd[(size_t)best] && rad[(size_t)r] < col) col = rad[(size_t)r];
+        pk.row = best;
+        pk.code_phase = col;
+        pk.peak = rmd[(size_t)best];
+      } else {
+        pk.row = pick_sequential(p, rmd.data(), pairs);
+      }
+    };
+    apply_rule();
+    if (!guard || pk.row < 0) continue;
+    // rows whose maximum is within eps of the chosen one: which of them the rule takes is decided on their float64 maxima
+    const double near = rmd[(size_t)pk.row] * (1.0 - eps);
+    std::vector<int> tied;
+    for (int r = 0; r < rows; ++r)
+      if (rmd[(size_t)r] >= near && rmd[(size_t)r] > 0.0) tied.push_back(r);
+    if (tied.size() > 1 && tied.size() <= 64) {
+      ++s->guard_ties;
+      for (int r : tied) {
+        std::vector<int2> list;
+        bool overflow = false;
+        rc = row_cells(k, r, (float)((double)rm[r] * (1.0 - eps)), list, &overflow);
+        if (rc) return rc;
+        if (overflow || list.empty()) continue;  // a plateau: the float32 maximum stands for this row
+        std::vector<double> vals;
+        rc = exact_values(k, list, vals);
+        if (rc) return rc;
+        double best = -1.0;
+        int bc = 0;
+        for (size_t i = 0; i < list.size(); ++i)
+          if (vals[i] > best || (vals[i] == best && list[i].y < bc)) {
+            best = vals[i];
+            bc = list[i].y;
+          }
+        rmd[(size_t)r] = best;
+        rad[(size_t)r] = bc;
+      }
+      apply_rule();
     }
   }
-  if (!second) return GC_OK;
   // phase 2: the winning rows again (their sums were never written), first maximum and second peak on the device, one read-back
-  const double ones[4] = {1.0, 1.0, 1.0, 1.0};
-  GC_HIP(hipMemcpyAsync(s->b_pick.p, out, (size_t)nprn * sizeof(gc_acq_shift_pick), hipMemcpyHostToDevice, ctx->stream));
+  std::vector<ShiftPickDev> dev((size_t)nprn);
+  for (int k = 0; k < nprn; ++k) {
+    std::memset(&dev[(size_t)k], 0, sizeof(ShiftPickDev));
+    dev[(size_t)k].row = out[k].row;
+    dev[(size_t)k].second_col = -1;
+  }
+  if (!second && !guard) return GC_OK;
+  if (gc_buf_reserve(s->b_pick, (size_t)nprn * sizeof(ShiftPickDev), false) != hipSuccess) {
+    (void)hipGetLastError();
+    return GC_E_NOMEM;
+  }
+  GC_HIP(hipMemcpyAsync(s->b_pick.p, dev.data(), (size_t)nprn * sizeof(ShiftPickDev), hipMemcpyHostToDevice, ctx->stream));
   for (int k = 0; k < nprn; ++k) {
     if (out[k].row < 0) continue;
     const int irow = out[k].row;
-    rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, arm_weight ? arm_weight : ones, (float*)s->b_rows.p + (size_t)k * N,
+    rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, wts, (float*)s->b_rows.p + (size_t)k * N,
                           /*to_slot=*/true);  // row irow lands at b_rows + k * N
     if (rc) return rc;
   }
   hipLaunchKernelGGL(shift_pick_kernel, dim3((unsigned int)nprn), dim3(1024), 0, ctx->stream, (const float*)s->b_rows.p, (long long)N, p.n, exclude,
-                     period, (gc_acq_shift_pick*)s->b_pick.p);
+                     second ? period : 0, (float)eps, (ShiftPickDev*)s->b_pick.p);
   GC_HIP(hipGetLastError());
-  return shift_read_back(ctx, s, out, s->b_pick.p, (size_t)nprn * sizeof(gc_acq_shift_pick));
+  rc = shift_read_back(ctx, s, dev.data(), s->b_pick.p, (size_t)nprn * sizeof(ShiftPickDev));
+  if (rc) return rc;
+  for (int k = 0; k < nprn; ++k) {
+    if (out[k].row < 0) continue;
+    const ShiftPickDev& d = dev[(size_t)k];
+    if (second || !guard) out[k].code_phase = d.code_phase;  // (GC_SHIFT_PICK_GLOBAL took its column from the row maxima; the guard may move it below)
+    out[k].peak = (double)d.peak;
+    out[k].second_peak = second ? (double)d.second : 0.0;
+  }
+  if (!guard) return GC_OK;
+  // every PRN's peak and second-peak cells in float64 (one launch), then the PRNs whose row holds another cell within eps of either
+  {
+    std::vector<GcExactCell> cells;
+    std::vector<int> owner;
+    for (int k = 0; k < nprn; ++k) {
+      if (out[k].row < 0) continue;
+      cells.push_back(cell_of(k, out[k].row, second ? dev[(size_t)k].code_phase : out[k].code_phase));
+      owner.push_back(2 * k);
+      if (second && dev[(size_t)k].second_col >= 0) {
+        cells.push_back(cell_of(k, out[k].row, dev[(size_t)k].second_col));
+        owner.push_back(2 * k + 1);
+      }
+    }
+    if (!cells.empty()) {
+      GC_HIP(hipMemcpyAsync(s->b_cells.p, cells.data(), cells.size() * sizeof(GcExactCell), hipMemcpyHostToDevice, ctx->stream));
+      rc = gc_exact_cells(ctx->stream, ex, (const GcExactCell*)s->b_cells.p, (int)cells.size(), (double*)s->b_exact.p);
+      if (rc) return rc;
+      std::vector<double> vals(cells.size());
+      GC_HIP(hipMemcpyAsync(vals.data(), s->b_exact.p, vals.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      GC_HIP(hipStreamSynchronize(ctx->stream));
+      for (size_t i = 0; i < cells.size(); ++i) {
+        const int k = owner[i] / 2;
+        double& dst = (owner[i] & 1) ? out[k].second_peak : out[k].peak;
+        if (vals[i] > 0.0) s->guard_max_dev = std::max(s->guard_max_dev, std::fabs(dst - vals[i]) / vals[i]);
+        dst = vals[i];
+      }
+    }
+  }
+  for (int k = 0; k < nprn; ++k) {
+    const ShiftPickDev& d = dev[(size_t)k];
+    if (out[k].row < 0 || (d.near_peak <= 1 && d.near_second <= 1)) continue;
+    ++s->guard_ties;
+    // every cell of the winning row that could be the first maximum or the second peak: all those at or above the smaller of the two
+    // float32 values less eps (the peak's lobe is among them).  Then the reference's rules on the float64 values.
+    const float low = second && d.second_col >= 0 ? std::min(d.peak, d.second) : d.peak;
+    std::vector<int2> list;
+    bool overflow = false;
+    rc = row_cells(k, out[k].row, (float)((double)low * (1.0 - eps)), list, &overflow);
+    if (rc) return rc;
+    if (overflow || list.empty()) continue;
+    std::vector<double> vals;
+    rc = exact_values(k, list, vals);
+    if (rc) return rc;
+    double best = -1.0;
+    int bc = 0;
+    for (size_t i = 0; i < list.size(); ++i)
+      if (vals[i] > best || (vals[i] == best && list[i].y < bc)) {
+        best = vals[i];
+        bc = list[i].y;
+      }
+    out[k].code_phase = bc;
+    out[k].peak = best;
+    if (second) {
+      // the reference's three range cases around the (float64) first maximum, 1-based (B1I :141-156, L2C :77-91)
+      const int cp = bc + 1, e1 = cp - exclude, e2 = cp + exclude;
+      int lo0, hi0, lo1 = 1, hi1 = 0;
+      if (e1 < 2) {
+        lo0 = e2;
+        hi0 = period + e1;
+      } else if (e2 >= period) {
+        lo0 = e2 - period + 1;
+        hi0 = e1;
+      } else {
+        lo0 = 1;
+        hi0 = e1;
+        lo1 = e2;
+        hi1 = period;
+      }
+      double sec = -1.0;
+      for (size_t i = 0; i < list.size(); ++i) {
+        const int c1 = list[i].y + 1;
+        if ((c1 >= lo0 && c1 <= hi0) || (c1 >= lo1 && c1 <= hi1)) sec = std::max(sec, vals[i]);
+      }
+      if (sec >= 0.0) out[k].second_peak = sec;
+    }
+  }
+  return GC_OK;
 }
 
 // Test hook: forward FFT of `nbatch` host sequences of length n (complex64) with the library's

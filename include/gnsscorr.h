@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GC_API_VERSION 3
+#define GC_API_VERSION 4 /* 4: gc_acq_shift_pick.peak / second_peak are doubles (float64 guard); gc_device_count, gc_acq_guard_stats */
 
 typedef struct gc_context gc_context;
 
@@ -492,8 +492,8 @@ enum { GC_SHIFT_PICK_GLOBAL = 0, GC_SHIFT_PICK_SEQUENTIAL = 1, GC_SHIFT_PICK_SEQ
 typedef struct gc_acq_shift_pick {
   int32_t row;          /* winning row, -1: no value above 0 (the reference leaves the PRN's results at 0) */
   int32_t code_phase;   /* 0-based position of the row's first maximum */
-  float peak;           /* its value */
-  float second_peak;    /* 0 with GC_SHIFT_PICK_GLOBAL */
+  double peak;          /* its value - float64: the winning cell evaluated again as a float64 correlation (gc_acq_guard_stats) */
+  double second_peak;   /* likewise; 0 with GC_SHIFT_PICK_GLOBAL */
 } gc_acq_shift_pick;
 int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, const int8_t* codes, int code_len, const int32_t* sample_index,
                               int n_index, const double* arm_weight, int rule, int exclude, int period, gc_acq_shift_pick* out /* [nprn] */);

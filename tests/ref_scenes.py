@@ -512,7 +512,33 @@ def _acq_tie_bins_record(P, S):
     return rec
 
 
+def _acq_b1i_tie_record(P, S):
+    """BDS B1I (circshift search: 2 carriers x 2 blocks of 4 ms x 41 bins, a 2-ms replica), IF = 0, no noise, Q = 0: PRN 7 on a REAL
+    carrier cos(2 pi 1000 t).  The rows at +1000 and -1000 Hz are conjugates, the two 4-ms blocks are identical, and the four code periods
+    of a block give four equal columns: sixteen cells of `results` tie exactly.  Three single samples raised by 1 make ONE of them the
+    largest by a few 1e-7 (relative) - the row at -1000 Hz (scanned AFTER the one at +1000 Hz: the reference's `>` keeps the first of
+    equal values, BDS/B1I/include/acquisition.m:98-119), first block, first period - and leave the others 1e-7 .. 1e-6 apart."""
+    fs, tau0 = S.samplingFreq, 5000
+    t = np.asarray(P.codes.generateCAcode53(_TIE_PRN), dtype=np.float64)
+    spc = 18000
+    idx = np.ceil(np.arange(1, spc + 1) / fs * S.codeFreqBasis).astype(np.int64)
+    idx[-1] = 2046
+    t = t[idx - 1]
+    n = int(0.012 * fs)
+    k = np.arange(n)
+    xi = np.rint(100.0 * t[(k - tau0) % spc] * np.cos(2.0 * np.pi * 1000.0 * k / fs))
+    rec = np.zeros(2 * n, dtype=np.int8)
+    rec[0::2] = xi.astype(np.int8)
+    # I + sign(replica): one sample in the first period after tau0 (seen by the windows at tau0 and tau0 + 3 periods), one in the second
+    # (windows at tau0 and tau0 + 1 period): the column at tau0 gains 2, its periodic copies 1, 1 and 0
+    for off in (1234, spc + 4321):
+        rec[2 * (tau0 + off)] += np.int8(1 if xi[tau0 + off] >= 0 else -1)
+    rec[2 * (tau0 + 777) + 1] = 1          # Q: tilts the conjugate rows towards -1000 Hz
+    return rec
+
+
 _TIE_BINS_Q = 1          # the sign that makes bin 16 (-500 Hz) the larger one (checked by test_ref_vectors against the fixture's carrFreq)
+_THR_METRIC_B1I_PRN23 = 3.1654201090103307  # max_peak / second of PRN 23 on the BDS_B1I scene's record, likewise
 _THR_METRIC_PRN22 = 4.690999243563728       # peakMetric(22) of the GPS_L1CA scene's record: oracle and reference fixture agree to the last bit
 
 GUARD_ACQ_SCENES = [
@@ -529,6 +555,15 @@ GUARD_ACQ_SCENES = [
     AcqScene("GPS_L1CA_thr_above", "GPS/GPS_L1CA", "initSettings", dict(acqNonCohTime=4, acqSatelliteList=[22, 3], acqThreshold=_THR_METRIC_PRN22 * (1.0 + 2.5e-7)),
              _acq_l1ca_record, product=lambda P, eng, S: P.acquisition(eng, S, first_sample=0),
              oracle=lambda O, P, rec, S: O.acquisition_l1ca(rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64), S), metric_rtol=1e-9),
+    # the circshift family: sixteen near-tied cells over four rows (which row the sequential rule keeps decides carrFreq), a second peak on a
+    # plateau of equal side lobes
+    AcqScene("BDS_B1I_tie_rows", "BDS/B1I", "initSettings_BDS_B1I", dict(IF=0.0, acqSatelliteList=[_TIE_PRN]), _acq_b1i_tie_record,
+             product=lambda P, eng, S: P.acq_shift.acquisition_B1I(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_b1i(rec, S, 0), metric_rtol=1e-9),
+    # the BDS_B1I scene's record with the threshold 2.5e-7 (relative) below / above max_peak / second of PRN 23 (:157-166)
+    AcqScene("BDS_B1I_thr_below", "BDS/B1I", "initSettings_BDS_B1I", dict(acqSatelliteList=[23, 12], acqThreshold=_THR_METRIC_B1I_PRN23 * (1.0 - 2.5e-7)), _acq_b1i_record,
+             product=lambda P, eng, S: P.acq_shift.acquisition_B1I(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_b1i(rec, S, 0), metric_rtol=1e-9),
+    AcqScene("BDS_B1I_thr_above", "BDS/B1I", "initSettings_BDS_B1I", dict(acqSatelliteList=[23, 12], acqThreshold=_THR_METRIC_B1I_PRN23 * (1.0 + 2.5e-7)), _acq_b1i_record,
+             product=lambda P, eng, S: P.acq_shift.acquisition_B1I(eng, S, first_sample=0), oracle=lambda O, P, rec, S: O.acquisition_b1i(rec, S, 0), metric_rtol=1e-9),
 ]
 
 

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"libgnsscorr.so does not export {n}"
         assert n in L.SYMBOLS, f"_lib.py has no binding for {n}"
-    assert lib.gc_api_version() == 3
+    assert lib.gc_api_version() == 4
 
 
 def test_struct_layouts_match_the_c_compiler():

@@ -171,7 +171,7 @@ def test_hip_acquisition_on_constructed_near_ties_and_near_threshold_metrics(eng
     assert np.array_equal(np.asarray(got.carrFreq) != 0, z["f_carrFreq"] != 0)          # the detected set
     assert 2e-5 < st["eps"] < 2e-4 and st["max_dev"] < st["eps"] / 8, st                 # float32 stayed well inside the band the guard assumes
     if "tie" in sc.name:
-        assert st["ties"] == 1, st                                                       # the slow path did run for the constructed tie
+        assert st["ties"] >= 1, st                                                       # the slow path did run for the constructed tie
 
 
 def _compare_acq(sc, z, got):

@@ -242,35 +242,65 @@ def test_oracle_acquisition_equals_the_references_acquisition_m(sc):
     assert np.count_nonzero(z["f_carrFreq"]) >= 1
 
 
+def _b1i_rows(O, rec, S, prn, wanted):
+    """|ifft(circshift(fft(carrier .* block), bin - 1) .* conj(fft(local code)))| of the (carrier, block, bin) rows in `wanted`
+    (BDS/B1I/include/acquisition.m:76-119 restated with NumPy, as oracle.acquisition_b1i forms them)."""
+    import math
+    fs = S.samplingFreq
+    ts, tc = 1.0 / fs, 1.0 / S.codeFreqBasis
+    spb = int(O.matlab_round(fs / (S.codeFreqBasis / (4 * S.codeLength))))
+    spc2 = int(O.matlab_round(fs / (S.codeFreqBasis / (2 * S.codeLength))))
+    ca = O.generate_b1i_code(prn)
+    idx = np.ceil(ts * np.arange(1, spc2 + 1) / tc).astype(np.int64)
+    idx[-1] = 2 * 2046
+    code_fd = np.conj(np.fft.fft(np.concatenate([np.concatenate([ca, ca])[idx - 1], np.zeros(spb // 2)])))
+    freq_res, init = fs / spb, S.IF + (S.acqSearchBand / 2) * 1000
+    out = {}
+    for it, blk, b in wanted:
+        f = init + it * (freq_res / 2)
+        x = O._if_complex(rec, blk * spb, spb) * np.exp(-1j * f * (np.arange(spb) * 2 * math.pi * ts))
+        out[(it, blk, b)] = np.abs(np.fft.ifft(np.roll(np.fft.fft(x), b - 1) * code_fd))
+    return out
+
+
 @pytest.mark.parametrize("sc", RS.GUARD_ACQ_SCENES, ids=[s.name for s in RS.GUARD_ACQ_SCENES])
 def test_oracle_on_the_constructed_near_ties_and_near_threshold_metrics(sc):
-    """The guard scenes (tests/ref_scenes.py GUARD_ACQ_SCENES): two cells of `results`, or the metric and the threshold, 2e-7 apart
-    (relative).  The float64 oracle and the reference's acquisition.m (executed by oracle/mlab) agree on which wins - and the records
-    really are that close: the winner's margin over the runner-up cell is between 1e-9 and 1e-6."""
+    """The guard scenes (tests/ref_scenes.py GUARD_ACQ_SCENES): two cells of `results`, or the metric and the threshold, a few 1e-7
+    apart (relative).  The float64 oracle and the reference's acquisition.m (executed by oracle/mlab) agree on which wins - and the
+    records really are that close: the winner's margin over the runner-up cell is between 1e-9 and 2e-6, and the winner is NOT the
+    first of the near-tied cells in the reference's scan order (a first-occurrence pick over float32-equal values would miss it)."""
     import cu_sdr_collection_amd as P
     z = _load(f"ref_acq_{sc.name}.npz")
     S, rec = RS.acq_inputs(P, sc)
     assert RS.crc(rec) == int(z["record_crc32"][0])
-    x = rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64)
-    got, res = O.acquisition_l1ca(x, S, want_results=True)
+    got = sc.oracle(O, P, rec, S)
     for f in sc.fields:
         want, have = z["f_" + f], np.asarray(getattr(got, f), dtype=np.float64)
         if f == "peakMetric":
             assert np.max(np.abs(have - want)) <= 1e-12 * np.max(np.abs(want)), (sc.name, f)
         else:
             assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
-    if "tie" in sc.name:
-        r = res[RS._TIE_PRN]
+    if sc.name.startswith("GPS_L1CA_tie"):
+        x = rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64)
+        r = O.acquisition_coarse_results(x, RS._TIE_PRN, S)
         top = np.sort(r.ravel())[::-1]
-        assert 1e-9 < (top[0] - top[1]) / top[0] < 1e-6
+        assert 1e-9 < (top[0] - top[1]) / top[0] < 2e-6
         b, c = np.unravel_index(int(np.argmax(r)), r.shape)
-        # the winner is NOT the first of the near-tied cells in MATLAB's order: a first-occurrence pick over float32-equal values would miss it
-        near = np.argwhere(r >= top[0] * (1.0 - 1e-6))
+        near = np.argwhere(r >= top[0] * (1.0 - 2e-6))
         assert (near[:, 1].min() < c) if "cols" in sc.name else (near[:, 0].min() < b)
         assert got.carrFreq[RS._TIE_PRN - 1] == (1.0 if "cols" in sc.name else -500.0)     # (0 Hz is reported as 1, acquisition.m:258-260)
+    elif sc.name == "BDS_B1I_tie_rows":
+        # bins 17 / 25 of carrier 0 are +1000 / -1000 Hz; both blocks; the four periodic copies of the peak in each
+        rows = _b1i_rows(O, rec, S, RS._TIE_PRN, [(0, blk, b) for b in (17, 25) for blk in (0, 1)])
+        cells = sorted(((float(r[5000 + 18000 * j]), key, j) for key, r in rows.items() for j in range(4)), reverse=True)
+        assert cells[0][1:] == ((0, 0, 25), 0)                                              # -1000 Hz, first block, first period
+        assert 1e-9 < (cells[0][0] - cells[1][0]) / cells[0][0] < 2e-6 and (cells[0][0] - cells[15][0]) / cells[0][0] < 5e-6
+        assert max(float(r.max()) for r in rows.values()) == cells[0][0]
+        assert got.carrFreq[RS._TIE_PRN - 1] == -1000.0 and got.codePhase[RS._TIE_PRN - 1] == 5001.0
     else:
-        m = got.peakMetric[21]
-        assert abs(m / S.acqThreshold - 1.0) < 3e-7 and (got.carrFreq[21] != 0) == (m > S.acqThreshold) == ("below" in sc.name)
+        prn = 22 if sc.name.startswith("GPS") else 23
+        m = got.peakMetric[prn - 1]
+        assert abs(m / S.acqThreshold - 1.0) < 3e-7 and (got.carrFreq[prn - 1] != 0) == (m > S.acqThreshold) == ("below" in sc.name)
 
 
 @pytest.mark.parametrize("sc", RS.DEFAULT_ACQ_SCENES, ids=[s.name for s in RS.DEFAULT_ACQ_SCENES])
