@@ -60,7 +60,7 @@ DETAIL_DEFAULT = os.path.join(ROOT, "bench_detail.json")
 
 _LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _CONFIG_KEYS = ("workload", "channels_per_gpu", "epochs", "blocks_per_step", "prewarm_ms", "parallelism")
-_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")
+_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")
 
 
 def _short(s, n):
@@ -90,6 +90,8 @@ def compact_line(result: dict, detail_path: str | None = None) -> str:
     if isinstance(result.get("handover"), dict):
         h = result["handover"]
         out["handover"] = {k: h[k] for k in ("backend", "bytes", "seconds") if k in h}
+    if "rank_diag" in result:      # per rank: device, devices its process saw, how the RCCL probe went
+        out["rank_diag"] = [{"r": d.get("rank"), "dev": d.get("device"), "seen": d.get("n_devices_seen"), "rccl": _short(d.get("rccl_probe"), 48)} for d in result["rank_diag"]]
     if "ranks" in result:
         out["ranks_locked"] = [r.get("channels_locked", sum(j.get("channels_locked", 0) for j in r.get("jobs", []))) for r in result["ranks"]]
     cfgs = result.get("configs")
@@ -97,6 +99,8 @@ def compact_line(result: dict, detail_path: str | None = None) -> str:
         names = {"galileo_e1c_cboc_x8": "c3", "l5_b2a_x16_50msps_int8": "c4_int8", "l5_b2a_x16_50msps_int16": "c4_int16", "mix_share_l1_band_x8": "c5_share"}
         out["configs_frac"] = {names.get(k, k): v["replay"]["roofline"]["frac"] for k, v in cfgs.items()}
         out["configs_if_msps"] = {names.get(k, k): v["replay"]["if_msps"] for k, v in cfgs.items()}
+        if "galileo_e1c_cboc_x8" in cfgs:
+            out["c3_parity"] = "oracle-only (the CBOC(6,1,1/11) replica is not in the reference: GAL_E1C tracks BOC(1,1); modelled on BDS/B1C WB_tracking.m)"
     acq = result.get("acquisition")
     if acq:
         out["acq_l1ca_ms"] = round(acq["seconds"] * 1e3, 3)
@@ -126,7 +130,7 @@ def compact_line(result: dict, detail_path: str | None = None) -> str:
         out["detail"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
     line = json.dumps(out, separators=(",", ":"))
     if len(line) >= LINE_LIMIT:                      # never reached with today's keys; the contract matters more than the summaries
-        for k in ("acq_ms", "configs_if_msps", "ranks_locked", "handover"):
+        for k in ("acq_ms", "configs_if_msps", "ranks_locked", "handover", "rank_diag", "acq_cpu_baseline"):
             out.pop(k, None)
         line = json.dumps(out, separators=(",", ":"))
     assert len(line) < LINE_LIMIT and "\n" not in line, len(line)
@@ -241,7 +245,11 @@ class Ranks:
                     self.rccl_error = self.rccl_error or "another rank's RCCL probe failed"
 
     def probe(self):
-        """What this rank saw of the node: its device, how many devices its process can see, and how its RCCL probe went."""
+        """What this rank saw of the node: its device, how many devices its process can see, and how its RCCL probe went.  At world
+        size 1 (no process group, torch not imported) the device count is the library's own (gc_device_count)."""
+        if self.dist is None:
+            from cu_sdr_collection_amd import device_count
+            return {"device": self.device, "n_devices_seen": device_count(), "rccl_probe": "not attempted (world size 1)"}
         import torch
         return {"device": self.device, "n_devices_seen": int(torch.cuda.device_count()) if torch.cuda.is_available() else 0,
                 "rccl_probe": "ok" if self.rccl else ("not attempted (ranks share one GPU)" if self.shared_device else f"failed: {getattr(self, 'rccl_error', None)}")}
@@ -546,6 +554,9 @@ def run_l1ca(P, W, args, R: Ranks, device: int):
         lock = R.gather({"rank": R.rank, "channels_locked": int(locked.sum()), "prns": [s.prn for s in sats], "replay_vs_closed_loop_max_dev": replay_dev,
                          "kernel_ms": round(kernel_ms, 4), "frac": round(achieved / HBM_PEAK_GBPS, 4), **R.probe()})
         result["ranks"] = lock
+        result["rank_diag"] = [{k: r.get(k) for k in ("rank", "device", "n_devices_seen", "rccl_probe")} for r in lock]
+    else:       # the same self-diagnosis at N = 1: what the one rank saw of the node (the driver's first 8-GPU run reads the same keys per rank)
+        result["rank_diag"] = [{"rank": 0, **R.probe()}]
     return result, dict(eng=eng, S=S, sats=sats, scene=scene, inits=inits, fields=fields, n_epochs=n_epochs, n_samples=n_samples, job=job, record=rec_t)
 
 
@@ -1156,6 +1167,22 @@ def main() -> None:
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    # More ranks than devices (a 1-GPU box asked for --gpus 8): said at once, as the ONE JSON line, before anything is launched or
+    # imported - the library's own device count needs neither torch nor a context.  GC_BENCH_DEVICE pins every rank to one device
+    # on purpose (functional tests of the N > 1 path on one GPU).
+    if args.gpus > 1 and "GC_BENCH_DEVICE" not in os.environ:
+        try:
+            from cu_sdr_collection_amd import device_count
+            seen = device_count()
+        except Exception as e:                      # noqa: BLE001 - no library, no driver: the ranks will say so themselves
+            seen = None
+            print(f"bench.py: device count unavailable ({e!r})", file=sys.stderr, flush=True)
+        if seen is not None and seen < args.gpus:
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(_error_line(args.gpus, args.steps, args.warmup, f"--gpus {args.gpus} but this process sees {seen} device(s) (gc_device_count); "
+                                  "one rank per GPU needs that many (GC_BENCH_DEVICE=<d> pins every rank to one device for functional tests)",
+                                  n_devices_seen=seen), flush=True)
+            raise SystemExit(2)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_spawn_ranks(args.gpus, args.steps, args.warmup))     # no external launcher: one process per GPU, started here
     rank = int(os.environ.get("RANK", "0"))

@@ -68,16 +68,48 @@ def shard_channels(n_channels: int, world_size: int, rank: int) -> list[int]:
 
 
 def shard_bands(band_channels: dict, world_size: int) -> list:
-    """BASELINE config 4 (all-constellation mix, 64 channels on 8 GPUs): channels of several IF
-    records (bands) placed so that every rank holds the same number of channels (+-1) while each band's record lives on as
-    few GPUs as possible -- a rank needs the record of every band it tracks, and a band shared by k ranks costs k - 1
-    peer copies (`broadcast_record`) and k x its size in HBM.  `band_channels`: {band: number of channels}.
-    Returns plan[rank] = [(band, channel index within the band), ...].  Bands are laid out largest first (ties by name) and
-    cut only at rank boundaries, so a band of n channels touches at most ceil(n / per_rank) + 1 ranks."""
+    """BASELINE config 5 (all-constellation mix, 64 channels on 8 GPUs): channels of several IF
+    records (bands) placed so that every rank holds the same number of channels (+-1: the shares of `shard_channels`) while each
+    band's record lives on as few GPUs as possible -- a rank needs the record of every band it tracks, and a band shared by k
+    ranks costs k - 1 peer copies (`broadcast_record`) and k x its size in HBM.  `band_channels`: {band: number of channels}.
+    Returns plan[rank] = [(band, channel index within the band), ...].
+
+    Bands are placed largest first (ties by name).  A band takes whole EMPTY ranks for as many full shares as it has, and its
+    remainder goes to the rank with the least free room that still holds it (best fit); only when no rank does is it cut, over the
+    ranks with the most room.  A band of n channels therefore sits on ceil(n / share) ranks whenever the ranks' room allows it
+    (config 5: the 18-channel L1 band on 3 GPUs, the 16-channel L5 band on 2, four of the six 5-channel bands on 1)."""
     if world_size < 1 or any(n < 0 for n in band_channels.values()):
         raise ValueError("bad sharding arguments")
-    flat = [(b, i) for b, n in sorted(band_channels.items(), key=lambda kv: (-kv[1], kv[0])) for i in range(n)]
-    return [[flat[i] for i in shard_channels(len(flat), world_size, r)] for r in range(world_size)]
+    total = sum(band_channels.values())
+    free = [len(shard_channels(total, world_size, r)) for r in range(world_size)]
+    cap = list(free)
+    plan = [[] for _ in range(world_size)]
+
+    def put(band, first, count, rank):
+        plan[rank].extend((band, first + i) for i in range(count))
+        free[rank] -= count
+
+    for band, n in sorted(band_channels.items(), key=lambda kv: (-kv[1], kv[0])):
+        at = 0
+        for r in range(world_size):                       # full shares on ranks that are still empty
+            if n - at >= cap[r] > 0 and free[r] == cap[r]:
+                put(band, at, cap[r], r)
+                at += cap[r]
+        while at < n:
+            rest = n - at
+            fits = [r for r in range(world_size) if free[r] >= rest]
+            if fits:                                      # best fit: the least room that still holds the remainder
+                r = min(fits, key=lambda q: (free[q], q))
+                put(band, at, rest, r)
+                at = n
+            else:                                         # no rank holds it: the most room first
+                r = max(range(world_size), key=lambda q: (free[q], -q))
+                if free[r] == 0:
+                    raise AssertionError("shard_bands: the shares do not add up")
+                take = free[r]
+                put(band, at, take, r)
+                at += take
+    return plan
 
 
 def band_ranks(plan) -> dict:

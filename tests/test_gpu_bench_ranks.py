@@ -86,3 +86,27 @@ def test_rccl_process_group_carries_the_hand_over_at_world_size_one():
                  env_extra={"GC_BENCH_FORCE_DIST": "1", "MASTER_PORT": port}, drop=("GC_BENCH_DEVICE",))
     assert res["handover"]["backend"].startswith("nccl"), res["handover"]
     assert res["closed_loop"]["channels_locked"] == 12 and res["replay_vs_closed_loop_max_dev"] < 2e-5
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_devices_fails_fast_with_the_error_line():
+    """VERDICT r5 #8a: `bench.py --gpus 8` on a box with fewer GPUs ends in seconds with the ONE JSON line (`error`, value null) and a
+    non-zero status - without an external launcher and as rank 0 of one (torch.distributed.run sets RANK / WORLD_SIZE), before torch
+    is imported or a rank is started."""
+    import json, subprocess, sys, time
+    import cu_sdr_collection_amd as P
+    seen = P.device_count()
+    assert seen >= 1
+    n = seen + 7
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("GC_BENCH_DEVICE", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    for extra in ({}, {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"}):
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"], env={**env, **extra},
+                           capture_output=True, text=True, timeout=120)
+        dt = time.perf_counter() - t0
+        assert r.returncode != 0 and dt < 10.0, (r.returncode, dt, r.stderr[-500:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["value"] is None and d["n_gpus"] == n and d["n_devices_seen"] == seen and "device" in d["error"]
