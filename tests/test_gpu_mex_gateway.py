@@ -329,6 +329,8 @@ def test_matlab_drop_in_takes_longsignal_as_the_reference_does(gateway, sc, scal
         want, got = z["f_" + f], np.asarray(getattr(acq, f), dtype=np.float64).reshape(-1)
         assert got.shape == want.shape, (sc.name, f, got.shape, want.shape)
         if f == "peakMetric":
-            assert np.max(np.abs(got - want)) <= sc.metric_rtol * np.max(np.abs(want)), sc.name
+            # samples times 0.37 go up in single precision: the signal itself is rounded at 6e-8 (the guard's float64 cannot undo that)
+            rtol = sc.metric_rtol if scale == round(scale) else max(sc.metric_rtol, 5e-7)
+            assert np.max(np.abs(got - want)) <= rtol * np.max(np.abs(want)), (sc.name, np.max(np.abs(got - want)) / np.max(np.abs(want)))
         else:
             assert np.array_equal(got, want), (sc.name, f, got[got != want], want[got != want])

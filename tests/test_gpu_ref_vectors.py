@@ -7,7 +7,7 @@ Tolerances (north_star: correlator I/Q within a stated float tolerance, acquired
   block geometry (absoluteSample), acquisition codePhase / carrFreq / CLCodePhase       identical
   correlator sums                                                                      1e-5 of full scale 2*N*28 (f32 accumulate)
   loop state: carrFreq, codeFreq 1e-3 Hz; remCodePhase 1e-7 chip; discriminators 1e-5   (they integrate the f32 sums)
-  C/N0 records 1e-3 dB; peakMetric 2e-3 relative (f32 FFTs)
+  C/N0 records 1e-3 dB; peakMetric 1e-9 relative (float32 FFTs find the cell, the float64 guard evaluates it: csrc/acq_guard.h; 2e-7 on a float32 conditioned signal)
   which entries are Inf / 0 (epochs and channels never processed)                       identical"""
 import os
 
@@ -174,13 +174,16 @@ def test_hip_acquisition_on_constructed_near_ties_and_near_threshold_metrics(eng
         assert st["ties"] >= 1, st                                                       # the slow path did run for the constructed tie
 
 
-def _compare_acq(sc, z, got):
+def _compare_acq(sc, z, got, float32_metric=False):
+    """float32_metric: a path without the float64 guard (the fused kernel of the tuning build, the circshift family PRN by PRN) - its
+    peakMetric carries the float32 transforms' rounding, 2e-3 as before round 6."""
     for f in sc.fields:
         want = z["f_" + f]
         have = np.asarray(getattr(got, f), dtype=np.float64)
         assert have.shape == want.shape, (sc.name, f, have.shape, want.shape)
         if f == "peakMetric":
-            assert np.max(np.abs(have - want)) <= sc.metric_rtol * np.max(np.abs(want)), (sc.name, np.max(np.abs(have - want)) / np.max(np.abs(want)))
+            rtol = 2e-3 if float32_metric else sc.metric_rtol
+            assert np.max(np.abs(have - want)) <= rtol * np.max(np.abs(want)), (sc.name, np.max(np.abs(have - want)) / np.max(np.abs(want)))
         else:
             assert np.array_equal(have, want), (sc.name, f, np.flatnonzero(have != want), have[have != want], want[have != want])
 
@@ -192,7 +195,7 @@ def test_hip_acquisition_at_the_references_default_search_sizes(engine, sc):
     63 PRNs, B1C 62 PRNs x 201 bins x 360 000 points, L2C 401 bins x 2 sub-bin shifts x 320 000 points, B1I 53 PRNs, GLONASS K = -7..6.
     The fixtures are the reference's own acquisition.m executed on the scene's record (oracle/mlab, minutes each, made once:
     tests/golden/make_ref_vectors.py acq_default); codePhase and carrFreq (coarse bin + fine stage) must be IDENTICAL
-    (north_star: "acquired code-phase sample indices bit-exact"), the peak metric within the float32 transforms' 2e-3 - at the depth
+    (north_star: "acquired code-phase sample indices bit-exact"), the peak metric to 1e-9 (the winning cell re-evaluated in float64) - at the depth
     the hop groups, slot reductions and shifted spectra actually run at."""
     import cu_sdr_collection_amd as P
     if not os.path.exists(os.path.join(GOLD, f"ref_acq_{sc.name}.npz")):
@@ -218,7 +221,7 @@ def test_fused_inverse_transform_kernel_at_the_references_default_search_sizes(e
     z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
     S, rec = RS.acq_inputs(P, sc)
     engine.load_if(rec, fs=S.samplingFreq)
-    _compare_acq(sc, z, sc.product(P, engine, S))
+    _compare_acq(sc, z, sc.product(P, engine, S), float32_metric=True)
 
 
 @pytest.mark.tuning
@@ -247,7 +250,7 @@ def test_circshift_family_at_the_default_sizes_prn_by_prn(engine, monkeypatch, n
     z = np.load(os.path.join(GOLD, f"ref_acq_{sc.name}.npz"))
     S, rec = RS.acq_inputs(P, sc)
     engine.load_if(rec, fs=S.samplingFreq)
-    _compare_acq(sc, z, sc.product(P, engine, S))
+    _compare_acq(sc, z, sc.product(P, engine, S), float32_metric=True)      # (float32 rows on the host: the guard lives in the batch call)
 
 
 _ACQ_KNOBS = [("GPS_L1CA", {"GC_ACQ_LANES": "1"}), ("GPS_L5C", {"GC_ACQ_LANES": "1"}), ("GAL_E1C", {"GC_ACQ_PEAK_KERNEL": "1"}),
@@ -298,7 +301,8 @@ def test_acquisition_paths_behind_the_tuning_knobs_return_the_references_results
     S, rec = RS.acq_inputs(P, sc)
     with P.Engine(0) as eng:                      # a context of its own: the knobs that are read once per scratch see a fresh one
         eng.load_if(rec, fs=S.samplingFreq)
-        _compare_acq(sc, z, sc.product(P, eng, S))
+        # the circshift family without its specialised passes searches PRN by PRN: float32 rows, no guard
+        _compare_acq(sc, z, sc.product(P, eng, S), float32_metric=name in ("BDS_B1I", "GPS_L2C", "BDS_B1C") and any(k in env for k in ("GC_ACQ_ROWMAX_KERNEL", "GC_ACQ_GENERIC", "GC_ACQ_SHIFT_PER_PRN")))
 
 
 _ACQ_FUSED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "GAL_E5b", "BDS_B2a", "BDS_B3I", "GLO_GL1")   # searches of 36 000 / 24 000 points
@@ -321,7 +325,7 @@ def test_fused_inverse_transform_kernel_equals_the_references_acquisition_m(engi
         want = z["f_" + f]
         have = np.asarray(getattr(got, f), dtype=np.float64)
         if f == "peakMetric":
-            assert np.max(np.abs(have - want)) <= sc.metric_rtol * np.max(np.abs(want)), (sc.name, f)
+            assert np.max(np.abs(have - want)) <= 2e-3 * np.max(np.abs(want)), (sc.name, f)     # (no float64 guard on the fused kernel's path)
         else:
             assert np.array_equal(have, want), (sc.name, f, have[have != want], want[have != want])
 
