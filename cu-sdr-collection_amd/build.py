@@ -32,7 +32,9 @@ INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
 _CORR_UNITS = ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip",
                # one source, four translation units (its 148 kernel instantiations took one compiler process 248 s): unit@MACRO=value
                "corr_lane.hip@GC_LANE_PART=0", "corr_lane.hip@GC_LANE_PART=1", "corr_lane.hip@GC_LANE_PART=2", "corr_lane.hip@GC_LANE_PART=3",
-               "track.hip", "multi.hip", "stream.hip", "acq.hip", "acq_guard.hip", "navsync.hip"]
+               "track.hip", "multi.hip", "stream.hip",
+               # the acquisition, one translation unit per part of the search (acq_internal.h is what they share)
+               "acq_fft.hip", "acq_coarse.hip", "acq_shift.hip", "acq_fine.hip", "acq_cond.hip", "acq_guard.hip", "navsync.hip"]
 
 
 def _tuned(spec: str) -> str:
@@ -47,7 +49,7 @@ LIBS = {
     "libgnsscorr_tuning.so": [_tuned(u) for u in _CORR_UNITS] + [_tuned("corr_cboc.hip")],
     "libgnsssynth.so": ["synth.hip"],
 }
-HEADERS = ["gc_internal.h", "corr_common.h", "devloop.h", "acq_guard.h", os.path.join("..", "..", "include", "gnsscorr.h")]
+HEADERS = ["gc_internal.h", "corr_common.h", "devloop.h", "acq_guard.h", "acq_internal.h", os.path.join("..", "..", "include", "gnsscorr.h")]
 # --offload-compress: the gfx950 code objects inside the fat binary are zstd-compressed (10.1 -> ~1.6 MB; the HIP runtime inflates them
 # when the library is loaded: ~20 ms once per process)
 FLAGS = ["--offload-arch=gfx950", "--offload-compress", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",

@@ -1,6 +1,6 @@
 // acq_guard.h - float64 re-evaluation of single cells of an acquisition search (csrc/acq_guard.hip).
 //
-// The searches of acq.hip transform in float32.  The reference decides in float64: `[peakSize, codePhase] = max(max(results))`,
+// The searches (acq_coarse.hip, acq_shift.hip) transform in float32.  The reference decides in float64: `[peakSize, codePhase] = max(max(results))`,
 // `peakMetric > acqThreshold` (GPS/GPS_L1CA/include/acquisition.m:196-206), `max_peak / second` (BDS/B1I/include/acquisition.m:
 // 141-166, GPS/GPS_L2C/include/acquisition.m:89-112).  Two cells of `results` that lie closer together than the float32 transforms'
 // rounding, or a metric that close to the threshold, would be decided by that rounding.  The guard closes the gap without a float64
@@ -56,9 +56,10 @@ int gc_exact_cells(hipStream_t stream, const GcExactSetup& s, const GcExactCell*
 int gc_collect_cells(hipStream_t stream, const float* r, int rows, long long row_stride, int valid, float thr, int* d_count, int2* d_list, int cap);
 
 // Relative distance under which two float32 results count as tied (and a collected cell as a candidate): 64 * log2(N) * 2^-24 -
-// the float32 forward + inverse transforms, product, magnitude and hop sums of a cell stay within ~(2 log2 N + 4) * 2^-24 of the
-// float64 value relative to the peak (measured: <= 2e-6 over all default searches, bench.py acq_guard), so this is > 10x margin on
-// both cells of a comparison.  ~6e-5 at N = 36 000, 7e-5 at N = 360 000.
+// the float32 forward + inverse transforms, product, magnitude and hop sums of a cell stay within ~(2 log2 N + 4) * 2^-24 ~ 2e-6 of the
+// float64 value relative to the peak (measured: <= 2.8e-7 over the twelve default-size searches and every fixture scene,
+// scripts/acq_guard_report.py; bench.py prints the run's own figure), so this is > 10x margin on both cells of a comparison even at
+// the bound and > 200x at what is measured.  ~6e-5 at N = 36 000, 7e-5 at N = 360 000.
 inline double gc_acq_tie_eps(int n) {
   double l2 = 1.0;
   for (long long m = 2; m < n; m *= 2) l2 += 1.0;

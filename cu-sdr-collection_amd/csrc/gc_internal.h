@@ -171,7 +171,7 @@ struct gc_context {
   int last_kernel = -2;  // gc_debug_last_kernel
   int last_track_mode = -1;  // gc_debug_last_track_mode: 0 launch per epoch, 1 persistent host-fed kernel, 2 device loop
 
-  // acquisition scratch (acq.hip)
+  // acquisition scratch (acq_coarse.hip: AcqScratch)
   void* acq_scratch = nullptr;
   enum { ACQ_FINE_CODE = 0, ACQ_FINE_DET, ACQ_FINE_OUT, ACQ_COND_SIG, ACQ_COND_A, ACQ_COND_B, ACQ_COND_TAPS, ACQ_NBUF };
   GcBuf acqbuf[ACQ_NBUF];  // fine-frequency stage: codes, detections, per-code sums; conditioned signal of gc_acq_condition + its scratch
@@ -232,7 +232,7 @@ int gc_track_window(gc_context* ctx, const gc_track_params* p, int nch, const gc
 void gc_fill_cno_host(gc_context* ctx, const gc_track_params* p, int nch, const double* out, const int32_t* epochs_done);
 
 int gc_bytes_per_sample(int dtype, int layout);
-void gc_acq_free(gc_context* ctx);  // acq.hip
+void gc_acq_free(gc_context* ctx);  // acq_coarse.hip
 int gc_sync_channels(gc_context* ctx);
 void gc_scope_reset(gc_context* ctx);
 void gc_scope_add(gc_context* ctx, int channel);

@@ -159,3 +159,55 @@ def test_unpack_cplx_rule_against_the_references_tables():
         table = np.array([int(x) for x in re.findall(r"-?\d+", body)])
         assert table.shape == (256,)
         assert np.array_equal(out[:, col], table), name
+
+
+def test_one_cell_of_results_is_a_circular_correlation_at_one_lag():
+    """The identity the float64 guard of the HIP searches rests on (csrc/acq_guard.h): a cell of the reference's `results` is, term by
+    term, a time-domain sum -
+        abs(ifft(fft(carrier .* x) .* conj(fft([code zeros]))))(tau) = | sum_{n < cl} z[(n + tau) mod N] * code[n] |   (acquisition.m:167-191)
+        circshift(fft(z), s)                                          = fft(z .* exp(+2i*pi*s*m/N))                        (BDS/B1I :98-119)
+    checked against the oracle's FFT-based rows (GPS L1 C/A: bins x hops summed; BDS B1I: carrier shift, block, circshift bin) to a few
+    1e-16 - the guard evaluates exactly this sum in float64 for the handful of cells a float32 search cannot order."""
+    import math
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cu_sdr_collection_amd as P
+    import ref_scenes as RS
+
+    def cell(x, code, f, ts, blk, cl, tau, shift=0):
+        n = np.arange(cl)
+        m = (n + tau) % blk
+        ph = np.exp(-1j * f * (((m * 2.0) * math.pi) * ts)) * np.exp(2j * math.pi * ((shift * m) % blk) / blk)
+        return abs(np.sum(x[m] * ph * code[:cl]))
+
+    sc = next(s for s in RS.ACQ_SCENES if s.name == "GPS_L1CA")
+    S, rec = RS.acq_inputs(P, sc)
+    x = rec[0::2].astype(np.float64) + 1j * rec[1::2].astype(np.float64)
+    prn = int(list(S.acqSatelliteList)[1])
+    res = O.acquisition_coarse_results(x, prn, S)
+    spc, ts, tab = O.samples_per_code(S), 1.0 / S.samplingFreq, O.make_ca_table(prn, S)
+    peak = np.unravel_index(int(np.argmax(res)), res.shape)
+    for b, tau in (peak, (3, 100), (10, 2 * spc - 5), (0, spc + 7)):           # the peak, a noise cell, lags that wrap around the block
+        f = S.IF + S.acqSearchBand - S.acqSearchStep * b
+        v = sum(cell(x[h * spc:(h + 2) * spc], tab, f, ts, 2 * spc, spc, tau) for h in range(int(S.acqNonCohTime)))
+        assert abs(v - res[b, tau]) <= 4e-15 * res[b, tau], (b, tau, v, res[b, tau])
+
+    sc = next(s for s in RS.ACQ_SCENES if s.name == "BDS_B1I")
+    S, rec = RS.acq_inputs(P, sc)
+    fs = S.samplingFreq
+    ts, tc = 1.0 / fs, 1.0 / S.codeFreqBasis
+    spb = int(O.matlab_round(fs / (S.codeFreqBasis / (4 * S.codeLength))))
+    spc2 = int(O.matlab_round(fs / (S.codeFreqBasis / (2 * S.codeLength))))
+    ca = O.generate_b1i_code(int(list(S.acqSatelliteList)[0]))
+    idx = np.ceil(ts * np.arange(1, spc2 + 1) / tc).astype(np.int64)
+    idx[-1] = 2 * 2046
+    local = np.concatenate([np.concatenate([ca, ca])[idx - 1], np.zeros(spb // 2)])
+    code_fd = np.conj(np.fft.fft(local))
+    freq_res, init = fs / spb, S.IF + (S.acqSearchBand / 2) * 1000
+    for it, blk, b, tau in ((0, 0, 1, 5), (1, 1, 7, 30000), (0, 1, 12, spb - 3), (1, 0, 3, 40000)):
+        f = init + it * (freq_res / 2)
+        sig = O._if_complex(rec, blk * spb, spb)
+        row = np.abs(np.fft.ifft(np.roll(np.fft.fft(np.exp(-1j * f * (np.arange(spb) * 2 * math.pi * ts)) * sig), b - 1) * code_fd))
+        v = cell(sig, local, f, ts, spb, spc2, tau, shift=b - 1)
+        assert abs(v - row[tau]) <= 4e-15 * row[tau], (it, blk, b, tau, v, row[tau])
