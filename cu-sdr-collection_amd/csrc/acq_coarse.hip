@@ -174,7 +174,8 @@ __global__ __launch_bounds__(1024) void sigpower_f32_kernel(const float2* __rest
 // Row maxima of a circshift search from the per-workgroup candidates its last pass left (PeakTrack::publish_slot: every workgroup of
 // that pass belongs to ONE row; key = value bits << 32 | ~column, so the largest key is the row's maximum at its first column):
 // one wave per row.  Replaces writing rows x N sums and reading them back (GPS L2C: 1 GB each way per PRN).
-__global__ __launch_bounds__(64) void rowkeys_reduce_kernel(const unsigned long long* __restrict__ slots, int tiles, float* vmax, int* amax) {
+__global__ __launch_bounds__(64) void rowkeys_reduce_kernel(const unsigned long long* __restrict__ slots, int tiles, float* vmax, int* amax,
+                                                            const unsigned int* __restrict__ sec_slots = nullptr, float* vsecond = nullptr) {
   const unsigned long long* mine = slots + (size_t)blockIdx.x * tiles * 2;
   unsigned long long k = 0;
   for (int i = threadIdx.x; i < tiles; i += 64) k = max(k, mine[2 * i + 1]);
@@ -183,6 +184,22 @@ __global__ __launch_bounds__(64) void rowkeys_reduce_kernel(const unsigned long 
     vmax[blockIdx.x] = __uint_as_float((unsigned int)(k >> 32));
     amax[blockIdx.x] = (int)(0xffffffffu - (unsigned int)(k & 0xffffffffu));
   }
+  if (!sec_slots || !vsecond) return;
+  // the row's runner-up for the float64 guard: every tile's own second, every tile's maximum except ONE holder of the row's
+  const unsigned int m1 = (unsigned int)(k >> 32);
+  const unsigned int* sec = sec_slots + (size_t)blockIdx.x * tiles;
+  unsigned int w2 = 0, holders = 0;
+  for (int i = threadIdx.x; i < tiles; i += 64) {
+    const unsigned int mi = (unsigned int)(mine[2 * i + 1] >> 32);
+    w2 = max(w2, sec[i]);
+    if (mi == m1) ++holders;
+    else w2 = max(w2, mi);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    w2 = max(w2, (unsigned int)__shfl_xor((int)w2, off, 64));
+    holders += (unsigned int)__shfl_xor((int)holders, off, 64);
+  }
+  if (threadIdx.x == 0) vsecond[blockIdx.x] = __uint_as_float(holders > 1 ? m1 : w2);
 }
 }  // namespace
 namespace gcacq {
@@ -235,7 +252,7 @@ void free_scratch(AcqScratch* s) {
   if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
   if (s->pinned) (void)hipHostFree(s->pinned);
   for (GcBuf* b : {&s->b_codes, &s->b_chips, &s->b_codespec, &s->b_rowmax, &s->b_rowarg, &s->b_rows, &s->b_pick, &s->b_second, &s->b_cells, &s->b_exact,
-                   &s->b_list, &s->b_off})
+                   &s->b_list, &s->b_off, &s->b_rowsec})
     gc_buf_free(*b);
   delete s;
 }
@@ -256,6 +273,39 @@ int ensure_slots(AcqScratch* s, size_t want) {
   GC_HIP(hipMemset(s->sec_slots, 0, (want / 2 + 1) * sizeof(unsigned int)));
   GC_HIP(hipDeviceSynchronize());
   s->slots_cap = want;
+  return GC_OK;
+}
+
+int acq_read_back(gc_context* ctx, AcqScratch* s, const AcqBack* parts, int nparts) {
+  size_t total = 0;
+  for (int i = 0; i < nparts; ++i) total += (parts[i].bytes + 15) / 16 * 16;
+  const bool pageable = GC_TUNE_ENV("GC_ACQ_SHIFT_PAGEABLE") != nullptr;
+  if (!pageable && s->pinned_bytes < total) {
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    s->pinned = nullptr;
+    s->pinned_bytes = 0;
+    const size_t want = std::max(total, (size_t)1 << 21);
+    if (hipHostMalloc(&s->pinned, want, hipHostMallocDefault) == hipSuccess) s->pinned_bytes = want;
+    else (void)hipGetLastError();
+  }
+  if (!pageable && s->pinned_bytes >= total) {
+    char* h = static_cast<char*>(s->pinned);
+    size_t at = 0;
+    for (int i = 0; i < nparts; ++i) {
+      if (parts[i].bytes) GC_HIP(hipMemcpyAsync(h + at, parts[i].src, parts[i].bytes, hipMemcpyDeviceToHost, ctx->stream));
+      at += (parts[i].bytes + 15) / 16 * 16;
+    }
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    at = 0;
+    for (int i = 0; i < nparts; ++i) {
+      if (parts[i].bytes) std::memcpy(parts[i].dst, h + at, parts[i].bytes);
+      at += (parts[i].bytes + 15) / 16 * 16;
+    }
+    return GC_OK;
+  }
+  for (int i = 0; i < nparts; ++i)
+    if (parts[i].bytes) GC_HIP(hipMemcpyAsync(parts[i].dst, parts[i].src, parts[i].bytes, hipMemcpyDeviceToHost, ctx->stream));
+  GC_HIP(hipStreamSynchronize(ctx->stream));
   return GC_OK;
 }
 
@@ -291,18 +341,23 @@ int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins
       const int tiles_ct = a.nvec / c1;
       const size_t want = (size_t)nbins_total * tiles_ct * 2 * (size_t)std::max(1, s->shift_slot_lanes);  // (gc_acq_shift_search_batch: a region per lane)
       if (int rc = ensure_slots(s, want)) return rc;
-      unsigned long long* const region = s->slots + (size_t)s->lane * (size_t)nbins_total * tiles_ct * 2 * (s->shift_slot_lanes > 1 ? 1 : 0);
+      const size_t lane_off = (size_t)s->lane * (size_t)nbins_total * tiles_ct * (s->shift_slot_lanes > 1 ? 1 : 0);
+      unsigned long long* const region = s->slots + lane_off * 2;
+      unsigned int* const sec_region = s->sec_slots + lane_off;
       a.peak_slots = region + (size_t)bin0 * tiles_ct * 2;
+      a.peak_second = s->rowsecond ? sec_region + (size_t)bin0 * tiles_ct : nullptr;
       a.peak_valid = valid;
       a.batch0 = bin0;
       bool used_ct = false;
       int rc = launch_pass(ctx, a, nbins, &used_ct);
       a.peak_slots = nullptr;
+      a.peak_second = nullptr;
       a.batch0 = 0;
       if (rc) return rc;
       if (used_ct) {
         hipLaunchKernelGGL(rowkeys_reduce_kernel, dim3((unsigned int)nbins), dim3(64), 0, ctx->stream, region + (size_t)bin0 * tiles_ct * 2, tiles_ct,
-                           s->rowmax + bin0, s->rowarg + bin0);
+                           s->rowmax + bin0, s->rowarg + bin0, s->rowsecond ? sec_region + (size_t)bin0 * tiles_ct : nullptr,
+                           s->rowsecond ? s->rowsecond + bin0 : nullptr);
         GC_HIP(hipGetLastError());
         *rows_fused = true;
       }
@@ -883,12 +938,13 @@ extern "C" int gc_acquire_coarse_offsets(gc_context* ctx, const gc_acq_params* p
   std::vector<unsigned long long> hpeaks((size_t)nprn * 2);
   std::vector<unsigned int> hsec((size_t)nprn, 0u);
   std::vector<double> hexact((size_t)nprn * H, 0.0);
-  GC_HIP(hipMemcpyAsync(hpeaks.data(), peaks, hpeaks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-  if (guard) {
-    GC_HIP(hipMemcpyAsync(hsec.data(), seconds, hsec.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    GC_HIP(hipMemcpyAsync(hexact.data(), d_exact, hexact.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  {
+    const AcqBack back[3] = {{hpeaks.data(), peaks, hpeaks.size() * sizeof(unsigned long long)},
+                             {hsec.data(), seconds, guard ? hsec.size() * sizeof(unsigned int) : 0},
+                             {hexact.data(), d_exact, guard ? hexact.size() * sizeof(double) : 0}};
+    rc = acq_read_back(ctx, s, back, 3);  // keys, runner-ups and the winners' float64 values: one pinned staging buffer, one synchronisation
+    if (rc) return rc;
   }
-  GC_HIP(hipStreamSynchronize(ctx->stream));
   const double eps = gc_acq_tie_eps(pl.n);
   s->guard_ties = 0;
   s->guard_max_dev = 0.0;

@@ -55,13 +55,15 @@ int gc_exact_cells(hipStream_t stream, const GcExactSetup& s, const GcExactCell*
 // there are (the list holds the first `cap` in no particular order; *count > cap: it overflowed).  *count must be zero before.
 int gc_collect_cells(hipStream_t stream, const float* r, int rows, long long row_stride, int valid, float thr, int* d_count, int2* d_list, int cap);
 
-// Relative distance under which two float32 results count as tied (and a collected cell as a candidate): 64 * log2(N) * 2^-24 -
-// the float32 forward + inverse transforms, product, magnitude and hop sums of a cell stay within ~(2 log2 N + 4) * 2^-24 ~ 2e-6 of the
-// float64 value relative to the peak (measured: <= 2.8e-7 over the twelve default-size searches and every fixture scene,
-// scripts/acq_guard_report.py; bench.py prints the run's own figure), so this is > 10x margin on both cells of a comparison even at
-// the bound and > 200x at what is measured.  ~6e-5 at N = 36 000, 7e-5 at N = 360 000.
+// Relative distance under which two float32 results count as tied (and a collected cell as a candidate): 8 * log2(N) * 2^-24.
+// The float32 forward + inverse transforms, product, magnitude and hop sums of a cell stay within ~(2 log2 N + 4) * 2^-24 ~ 2e-6 of the
+// float64 value relative to the peak in the worst case and measure <= 2.8e-7 (the twelve default-size searches and every fixture
+// scene: scripts/acq_guard_report.py; bench.py prints the run's own figure, acq_f32_vs_f64_peak_max_rel): two cells of a comparison
+// stay inside the band even at the bound, with 27x margin on what is measured.  7.6e-6 at N = 36 000, 9e-6 at N = 360 000.  (A wider band
+// only costs time: every noise-only PRN whose two largest cells happen to lie that close takes the slow path - 64 * log2 N had one
+// such PRN in the default GPS L1 C/A search, +0.25 ms.)
 inline double gc_acq_tie_eps(int n) {
   double l2 = 1.0;
   for (long long m = 2; m < n; m *= 2) l2 += 1.0;
-  return 64.0 * l2 / 16777216.0;
+  return 8.0 * l2 / 16777216.0;
 }

@@ -278,13 +278,14 @@ struct AcqScratch {
   bool shift_padded = false;  // the block length is no size for the plan: every row has its own carrier, transforms of s->n >= 2*shift.n points
   float* rowmax = nullptr;
   int* rowarg = nullptr;
+  float* rowsecond = nullptr;  // per row the largest value of any OTHER cell of the row (== rowmax: a second cell holds the maximum); nullptr: not tracked
   // pinned staging for the circshift family's read-backs (row maxima per search, the winning row's n sums per PRN): a copy into the
   // caller's pageable array goes through the runtime's own staging in pieces - 0.15 - 0.3 ms for the 1.4 MB row of a B1C search
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   int shift_rows = 0;
   // gc_acq_shift_search_batch: every PRN's codes, code spectra, row maxima, the winning rows and the picks of one search
-  GcBuf b_codes, b_chips, b_codespec, b_rowmax, b_rowarg, b_rows, b_pick;
+  GcBuf b_codes, b_chips, b_codespec, b_rowmax, b_rowarg, b_rows, b_pick, b_rowsec;
   int shift_slot_lanes = 1;   // lanes of the batch call under way: launch_abs_pass gives each its own region of row-candidate slots
   unsigned long long* peaks = nullptr;  // per-PRN peak keys of gc_acquire_coarse_multi
   int peaks_cap = 0;
@@ -339,6 +340,14 @@ bool lane_events(AcqScratch* s);
 void free_scratch(AcqScratch* s);
 int ensure_slots(AcqScratch* s, size_t want);
 int ensure_scratch(gc_context* ctx, int n, long long nbh, int nprn, int nbins, int spc, AcqScratch** out);
+// up to four device regions back to host arrays through ONE pinned staging buffer and one synchronisation of the context's stream (a copy
+// into pageable memory goes through the runtime's own staging in pieces and blocks: 20 - 30 us each)
+struct AcqBack {
+  void* dst;
+  const void* src;
+  size_t bytes;
+};
+int acq_read_back(gc_context* ctx, AcqScratch* s, const AcqBack* parts, int nparts);
 int launch_abs_pass(gc_context* ctx, AcqScratch* s, PassArgs& a, long long nbins, unsigned long long* keys = nullptr, int valid = 0,
                     int ip = 0, int nprn = 1, bool* rows_fused = nullptr, int bin0 = 0, long long nbins_total = 0);
 

@@ -95,6 +95,7 @@ extern "C" int gc_acq_shift_prepare(gc_context* ctx, const gc_acq_shift_params* 
   AcqScratch* s = nullptr;
   int rc = ensure_scratch(ctx, m, rows, p->n_arms_max, rows, p->n, &s);
   if (rc) return rc;
+  s->rowsecond = nullptr;  // (only the batch search tracks the rows' runner-ups)
   if (s->shift_rows < rows) {
     if (s->rowmax) (void)hipFree(s->rowmax);
     if (s->rowarg) (void)hipFree(s->rowarg);
@@ -146,31 +147,9 @@ static int shift_internal_row(const gc_acq_shift_params& p, int row) {
 // device -> caller through the scratch's pinned buffer (grown on demand); GC_ACQ_SHIFT_PAGEABLE=1 or no pinned memory: straight into the
 // caller's array.  Synchronises the stream.
 static int shift_read_back(gc_context* ctx, AcqScratch* s, void* dst0, const void* src0, size_t bytes0, void* dst1 = nullptr, const void* src1 = nullptr,
-                           size_t bytes1 = 0) {
-  const size_t total = bytes0 + bytes1;
-  if (!GC_TUNE_ENV("GC_ACQ_SHIFT_PAGEABLE")) {
-    if (s->pinned_bytes < total) {
-      if (s->pinned) (void)hipHostFree(s->pinned);
-      s->pinned = nullptr;
-      s->pinned_bytes = 0;
-      const size_t want = std::max(total, (size_t)1 << 21);
-      if (hipHostMalloc(&s->pinned, want, hipHostMallocDefault) == hipSuccess) s->pinned_bytes = want;
-      else (void)hipGetLastError();
-    }
-  }
-  if (s->pinned_bytes >= total && !GC_TUNE_ENV("GC_ACQ_SHIFT_PAGEABLE")) {
-    char* h = static_cast<char*>(s->pinned);
-    GC_HIP(hipMemcpyAsync(h, src0, bytes0, hipMemcpyDeviceToHost, ctx->stream));
-    if (bytes1) GC_HIP(hipMemcpyAsync(h + bytes0, src1, bytes1, hipMemcpyDeviceToHost, ctx->stream));
-    GC_HIP(hipStreamSynchronize(ctx->stream));
-    std::memcpy(dst0, h, bytes0);
-    if (bytes1) std::memcpy(dst1, h + bytes0, bytes1);
-    return GC_OK;
-  }
-  GC_HIP(hipMemcpyAsync(dst0, src0, bytes0, hipMemcpyDeviceToHost, ctx->stream));
-  if (bytes1) GC_HIP(hipMemcpyAsync(dst1, src1, bytes1, hipMemcpyDeviceToHost, ctx->stream));
-  GC_HIP(hipStreamSynchronize(ctx->stream));
-  return GC_OK;
+                           size_t bytes1 = 0, void* dst2 = nullptr, const void* src2 = nullptr, size_t bytes2 = 0) {
+  const AcqBack back[3] = {{dst0, src0, bytes0}, {dst1, src1, bytes1}, {dst2, src2, bytes2}};
+  return acq_read_back(ctx, s, back, 3);
 }
 
 // The inverse side of ONE PRN of a circshift search: rows pass (shifted product with the PRN's code spectra `codespec`, narms x N) and
@@ -602,6 +581,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
       gc_buf_reserve(s->b_codespec, (size_t)nprn * narms * N * sizeof(float2), false) != hipSuccess ||
       gc_buf_reserve(s->b_rowmax, (size_t)nprn * rows * sizeof(float), false) != hipSuccess ||
       gc_buf_reserve(s->b_rowarg, (size_t)nprn * rows * sizeof(int), false) != hipSuccess ||
+      gc_buf_reserve(s->b_rowsec, (size_t)nprn * rows * sizeof(float), false) != hipSuccess ||
       gc_buf_reserve(s->b_pick, (size_t)nprn * sizeof(ShiftPickDev), false) != hipSuccess ||
       gc_buf_reserve(s->b_rows, (size_t)nprn * N * sizeof(float), false) != hipSuccess) {
     (void)hipGetLastError();
@@ -672,6 +652,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
     ctx->stream = lane_stream[s->lane];
     s->rowmax = (float*)s->b_rowmax.p + (size_t)k * rows;
     s->rowarg = (int*)s->b_rowarg.p + (size_t)k * rows;
+    s->rowsecond = (float*)s->b_rowsec.p + (size_t)k * rows;
     rc = shift_search_passes(ctx, s, narms, cspec + (size_t)k * narms * N, arm_weight, &fused, s->lane ? s->tmp2 : s->tmp);
   }
   ctx->stream = stream1;
@@ -679,6 +660,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
   s->shift_slot_lanes = 1;
   s->rowmax = save_max;
   s->rowarg = save_arg;
+  s->rowsecond = nullptr;
   if (lanes == 2) {  // the lanes join the caller's stream (also on an error: nothing may still run on them)
     hipEvent_t const ej[2] = {s->ev_join, s->ev_join2};
     for (int k = 0; k < 2; ++k) {
@@ -698,9 +680,10 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
   // gc_acq_shift_search (its code spectra are not the ones in place)
   s->shift_rows_fused = true;
   s->shift_narms = 0;
-  std::vector<float> hmax((size_t)nprn * rows);
+  std::vector<float> hmax((size_t)nprn * rows), hsecond((size_t)nprn * rows);
   std::vector<int> harg((size_t)nprn * rows);
-  rc = shift_read_back(ctx, s, hmax.data(), s->b_rowmax.p, sizeof(float) * hmax.size(), harg.data(), s->b_rowarg.p, sizeof(int) * harg.size());
+  rc = shift_read_back(ctx, s, hmax.data(), s->b_rowmax.p, sizeof(float) * hmax.size(), harg.data(), s->b_rowarg.p, sizeof(int) * harg.size(),
+                       hsecond.data(), s->b_rowsec.p, sizeof(float) * hsecond.size());
   if (rc) return rc;
   // ---- the float64 guard (acq_guard.h) --------------------------------------------------------------------------------------------
   // Row maxima, first maxima and second peaks come out of float32 transforms; the reference's sequential `>` tests (B1I :98-119,
@@ -847,29 +830,40 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
     dev[(size_t)k].second_col = -1;
   }
   if (!second && !guard) return GC_OK;
-  if (gc_buf_reserve(s->b_pick, (size_t)nprn * sizeof(ShiftPickDev), false) != hipSuccess) {
-    (void)hipGetLastError();
-    return GC_E_NOMEM;
-  }
-  GC_HIP(hipMemcpyAsync(s->b_pick.p, dev.data(), (size_t)nprn * sizeof(ShiftPickDev), hipMemcpyHostToDevice, ctx->stream));
-  for (int k = 0; k < nprn; ++k) {
-    if (out[k].row < 0) continue;
-    const int irow = out[k].row;
-    rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, wts, (float*)s->b_rows.p + (size_t)k * N,
-                          /*to_slot=*/true);  // row irow lands at b_rows + k * N
+  if (second) {
+    GC_HIP(hipMemcpyAsync(s->b_pick.p, dev.data(), (size_t)nprn * sizeof(ShiftPickDev), hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 0; k < nprn; ++k) {
+      if (out[k].row < 0) continue;
+      const int irow = out[k].row;
+      rc = shift_row_passes(ctx, s, irow, narms, cspec + (size_t)k * narms * N, wts, (float*)s->b_rows.p + (size_t)k * N,
+                            /*to_slot=*/true);  // row irow lands at b_rows + k * N
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(shift_pick_kernel, dim3((unsigned int)nprn), dim3(1024), 0, ctx->stream, (const float*)s->b_rows.p, (long long)N, p.n, exclude, period,
+                       (float)eps, (ShiftPickDev*)s->b_pick.p);
+    GC_HIP(hipGetLastError());
+    rc = shift_read_back(ctx, s, dev.data(), s->b_pick.p, (size_t)nprn * sizeof(ShiftPickDev));
     if (rc) return rc;
-  }
-  hipLaunchKernelGGL(shift_pick_kernel, dim3((unsigned int)nprn), dim3(1024), 0, ctx->stream, (const float*)s->b_rows.p, (long long)N, p.n, exclude,
-                     second ? period : 0, (float)eps, (ShiftPickDev*)s->b_pick.p);
-  GC_HIP(hipGetLastError());
-  rc = shift_read_back(ctx, s, dev.data(), s->b_pick.p, (size_t)nprn * sizeof(ShiftPickDev));
-  if (rc) return rc;
-  for (int k = 0; k < nprn; ++k) {
-    if (out[k].row < 0) continue;
-    const ShiftPickDev& d = dev[(size_t)k];
-    if (second || !guard) out[k].code_phase = d.code_phase;  // (GC_SHIFT_PICK_GLOBAL took its column from the row maxima; the guard may move it below)
-    out[k].peak = (double)d.peak;
-    out[k].second_peak = second ? (double)d.second : 0.0;
+    for (int k = 0; k < nprn; ++k) {
+      if (out[k].row < 0) continue;
+      const ShiftPickDev& d = dev[(size_t)k];
+      out[k].code_phase = d.code_phase;
+      out[k].peak = (double)d.peak;
+      out[k].second_peak = (double)d.second;
+    }
+  } else {
+    // GC_SHIFT_PICK_GLOBAL has no second peak and took its column from the row maxima: the winning row is not transformed again -
+    // whether another of its cells lies within eps of the maximum is known from the row's runner-up (PeakTrack::m2 through the
+    // per-tile slots, rowkeys_reduce_kernel)
+    for (int k = 0; k < nprn; ++k) {
+      if (out[k].row < 0) continue;
+      ShiftPickDev& d = dev[(size_t)k];
+      const size_t at = (size_t)k * rows + (size_t)out[k].row;
+      d.code_phase = out[k].code_phase;
+      d.peak = (float)out[k].peak;
+      d.near_peak = (double)hsecond[at] >= (double)hmax[at] * (1.0 - eps) ? 2 : 1;
+      d.near_second = 0;
+    }
   }
   if (!guard) return GC_OK;
   // every PRN's peak and second-peak cells in float64 (one launch), then the PRNs whose row holds another cell within eps of either
