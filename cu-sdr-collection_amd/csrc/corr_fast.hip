@@ -167,12 +167,26 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   unsigned int pfx_m0 = __builtin_amdgcn_readfirstlane((unsigned int)(size_t)pfx);  // its LDS byte address (low half of the flat address)
   if (wave_items && wq >= p.nblocks) return;
 
-  const int nloop = DEVLOOP ? p.devloop->n_epochs : p.bpw;
+  // DEVLOOP: the launch's constants (loop-filter coefficients, thresholds, buffer addresses: ~60 words) in registers for the whole
+  // run.  Read through the pointer, every one of them was a vector load + s_waitcnt vmcnt(0) inside the closure - the compiler cannot
+  // know that nothing writes the struct - : some twenty dependent cache round trips per epoch, and a wait that also drains the next
+  // epoch's sample fetch (pf_w below).
+  [[maybe_unused]] DevLoopArgs dl_loc;
+  if constexpr (DEVLOOP) dl_loc = *p.devloop;
+  const int nloop = DEVLOOP ? dl_loc.n_epochs : p.bpw;
   gc_block dl_next;  // DEVLOOP: the descriptor this member computed for the next epoch
   (void)dl_next;
   DevLoopChan dl_st;  // DEVLOOP: the channel's loop state, in registers across the epochs (every member keeps its own copy)
   if constexpr (DEVLOOP) dl_st = p.devloop->chan[min(wq, (long long)p.nblocks - 1)];
   (void)dl_st;
+  // DEVLOOP: the next epoch's samples, fetched while this epoch's loop is being closed.  The next block starts exactly where this one
+  // ends (tracking.m:219-222, 249: absoluteSample advances by blksize) - only its LENGTH waits for the closure -, so the 16-byte
+  // chunk every lane will read first is known before the discriminators are: the load goes out right after the team's partial
+  // sums have arrived and its ~1.5 us of memory latency pass under the closure instead of in front of the next correlation.
+  // pf_off: byte offset the words were read from (per lane), -1: nothing fetched; the next epoch checks it against its own.
+  constexpr int kPfWords = SPL * Fmt<MODE>::bps / 4;
+  [[maybe_unused]] unsigned int pf_w[kPfWords];
+  [[maybe_unused]] long long pf_off = -1;
   for (int bi = (WIDE != 0 && !wave_items) ? wave : 0; bi < nloop; bi += (WIDE != 0 && !wave_items) ? 4 : 1) {
   const long long lb = DEVLOOP ? wq : (grp * p.bpw + bi) * p.stride + cslot;
   if (lb >= p.nblocks) break;
@@ -180,10 +194,10 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
   if constexpr (DEVLOOP) {
     // every member closes the loop itself (all-gather of the partial sums, see below), so from the second epoch on the
     // descriptor is the one it computed; the first one comes from the host
-    if (p.devloop->host_loop) {
+    if (dl_loc.host_loop) {
       // host-fed: member 0 polls the ten descriptor messages in host memory (one PCIe read per lane and round) and relays
       // them to the team; the others poll the relay.  Bounded: a lost host must not hang the device.
-      const DevLoopArgs* dl = p.devloop;
+      const DevLoopArgs* dl = &dl_loc;
       const msg_t* dm = (split == 0 ? dl->host_desc : dl->desc_msg) + lb * kDescWords;
       msg_t m = {0u, 0u, 0u, 0u};
       unsigned int spins = 0;
@@ -482,7 +496,18 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
 
     // two word buffers, alternating: the next chunk's loads are in flight while this one is processed, no copies
     unsigned int wa[NW], wb[NW];
-    load_k(0, wa);
+    bool fetched = false;
+    if constexpr (DEVLOOP) {
+      // the words fetched during the last closure are this epoch's first chunk if they came from the same place in every lane
+      const long long want = (long long)CB * (q0 + cbeg) + (long long)((0 == iters - 1) ? voff_last : voff);
+      fetched = __all(pf_off == want) != 0;
+      if (fetched) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) wa[q] = pf_w[q];
+      }
+      pf_off = -1;
+    }
+    if (!fetched) load_k(0, wa);
     for (int k = 0;; k += 2) {
       if (k + 1 < iters) load_k(k + 1, wb);
       process(wa, k);
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     // the whole team's messages — lane 32h + k takes message h of member k — adds them in double in a fixed order (DPP),
     // and closes the loop itself: identical inputs, identical instructions, identical next descriptor in every member, so
     // there is ONE message hop per epoch and no descriptor broadcast.  Member 0 alone writes records and host-visible state.
-    const DevLoopArgs* dl = p.devloop;
+    const DevLoopArgs* dl = &dl_loc;
     const unsigned int tag = (unsigned int)bi + 1u;
     msg_t* pm = dl->part_msg + ((lb * 2 + (bi & 1)) * dl->splits) * 2;
     if (lane == 63) {
@@ -557,6 +582,23 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
       break;
     }
     const unsigned long long dl_t2 = __builtin_amdgcn_s_memrealtime();
+    if (!dl->host_loop && dl->prefetch) {
+      // next epoch's first chunk (see pf_w above): the block of blksize N' (N' = N or a sample either side) from s0 + N on, cut into
+      // the members' shares as the loop's head does; a member whose share moves with N' finds the mismatch there and reloads
+      constexpr int CBn = SPL * Fmt<MODE>::bps;
+      const long long s0n = blk.first_sample + blk.blksize;
+      const long long q0n = s0n >> kShift, q1n = (s0n + blk.blksize - 1) >> kShift;
+      const int nchn = (int)(q1n - q0n + 1);
+      const int cpsn = (nchn + p.splits - 1) / p.splits;
+      const int cbegn = split * cpsn, cendn = min(nchn, cbegn + cpsn);
+      const int itersn = (cendn - cbegn + kFW - 1) / kFW;
+      if (itersn > 0 && (unsigned long long)(s0n + blk.blksize + 2 * SPL) <= dl->if_nsamples) {
+        const unsigned int voffn = (unsigned int)lane * CBn;
+        const unsigned int vlastn = min(voffn, (unsigned int)(cendn - 1 - cbegn - (itersn - 1) * kFW) * CBn);
+        pf_off = (long long)CBn * (q0n + cbegn) + (long long)((0 == itersn - 1) ? vlastn : voffn);
+        load_words<MODE, SPL>(p.if_base + pf_off, 0, pf_w);
+      }
+    }
     double part[3] = {mine ? (double)__uint_as_float(m.x) : 0.0, mine ? (double)__uint_as_float(m.y) : 0.0,
                       mine ? (double)__uint_as_float(m.z) : 0.0};
 #pragma unroll

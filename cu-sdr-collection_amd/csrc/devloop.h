@@ -55,6 +55,8 @@ struct DevLoopArgs {
   int code_index_scale_is_one;  // R == 1 (the only case wired up)
   int reserved;                 // message scope (msg_load / msg_store): 0 = system
   int timing;                   // GC_DEVLOOP_TIMING: the closer accumulates its phase clocks in DevLoopChan::pad (costs ~1 us per epoch)
+  int prefetch;                 // fast kernel: fetch the next epoch's first chunk during the closure (corr_fast.hip; GC_DEVLOOP_NO_PREFETCH=1 in the tuning build: 0)
+  int pad_prefetch;
   // Host-fed variant (gc_track's persistent mode): the HOST closes the loop (tracking.m:302-335 stay where the reference has
   // them) but nothing is launched per epoch: member 0 of a team polls the channel's descriptor messages in host-mapped
   // memory (tag = epoch + 1), relays them to its team through desc_msg, and every member writes its six partial sums as

@@ -1055,6 +1055,7 @@ extern "C" int gc_track_device(gc_context* ctx, const gc_track_params* p, int nc
   ha.code_index_scale_is_one = 1;
   if (const char* e = GC_TUNE_ENV("GC_DEVLOOP_SCOPE")) ha.reserved = std::atoi(e);  // message scope (devloop.h): 0 system (default), 2 agent
   ha.timing = GC_TUNE_ENV("GC_DEVLOOP_TIMING") ? std::atoi(GC_TUNE_ENV("GC_DEVLOOP_TIMING")) : 0;  // 1: host + in-kernel phase clocks, 2: host only
+  ha.prefetch = GC_TUNE_ENV("GC_DEVLOOP_NO_PREFETCH") ? 0 : 1;  // the next epoch's first chunk fetched during the closure (corr_fast.hip)
   gcorr::DevLoopArgs* d_args = nullptr;
   const size_t rec_bytes = sizeof(double) * (size_t)nch * GC_TRK_NFIELDS * n_epochs;
   const size_t part_bytes = sizeof(gcorr::msg_t) * (size_t)nch * splits * msgs_per_member * (use_fast ? 2 : 1),  // fast kernel: two alternating halves

@@ -11,8 +11,8 @@ from __future__ import annotations
 # number of channels, so more GPUs buy nothing; beyond it the teams shrink (the persistent grid must stay resident) and the single
 # closer thread fills up, and the time grows - sub-linearly: 8x the channels cost 2.4x the time.
 CLOSED_LOOP_US_PER_EPOCH = {
-    "GPS_L1CA": {12: 6.9, 24: 8.3, 48: 10.8, 96: 16.5, 192: 19.7},     # 18 Msps; device-closed: 5.3, 5.2, 6.8, 7.9, 10.8
-    "GPS_L5C": {16: 10.0, 32: 11.1, 64: 14.7},                          # 50 Msps, data + pilot; device-closed: 8.7, 8.9, 11.2
+    "GPS_L1CA": {12: 6.7, 24: 7.6, 48: 8.6, 96: 13.1, 192: 16.3},      # 18 Msps, host-closed (round 6: gpurun_out/r06*/bench.json); device-closed: 5.0, 7.0, 6.3, 7.5, 9.9
+    "GPS_L5C": {16: 9.7, 32: 10.1, 64: 13.1},                           # 50 Msps, data + pilot; device-closed: 8.7, 8.7, 11.1
 }
 # the largest measured count whose epoch time is within 1.25x of the smallest count's (`knee_channels` of the sweep); signals that
 # were not swept take the entry of their kernel class: "fast" (<= 1 table transition per 16-sample chunk) or "lane"
