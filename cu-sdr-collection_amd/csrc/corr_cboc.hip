@@ -38,9 +38,8 @@ constexpr int kSPL = 16;
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kGLO = 8;
 constexpr int kGHI = 8;
-constexpr int kRow = 8;                                // floats per sample and lane: P re, im; P6 early re, im; prompt; late
-constexpr int kHalf = 8;                               // rows of running sums kept at a time: samples j and j + 8 share row j
-constexpr int kWaveLds = kHalf * kRow * kW * 4;        // 16 KB
+constexpr int kRow = 2;                                // floats per sample and lane: one stream's running sum, re and im
+constexpr int kWaveLds = kSPL * kRow * kW * 4;         // 8 KB: the rows of ONE stream, used by P, then by the P6 of each tap in turn
 
 template <int OFF_RE, int OFF_IM>
 __device__ __forceinline__ void park2(float tr, float ti, unsigned int lds_base) {
@@ -48,6 +47,22 @@ __device__ __forceinline__ void park2(float tr, float ti, unsigned int lds_base)
                :
                : "v"(tr), "v"(ti), "s"(lds_base), "n"(OFF_RE), "n"(OFF_IM)
                : "memory", "m0");
+}
+
+// four samples' running sums (re, im of rows J .. J + 3) in one go: ONE m0 set-up for eight stores
+template <int J>
+__device__ __forceinline__ void park8(const float (&tr)[4], const float (&ti)[4], unsigned int lds_base) {
+  asm volatile(
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+      "ds_write_addtid_b32 %0 offset:%9\n\tds_write_addtid_b32 %1 offset:%10\n\t"
+      "ds_write_addtid_b32 %2 offset:%11\n\tds_write_addtid_b32 %3 offset:%12\n\t"
+      "ds_write_addtid_b32 %4 offset:%13\n\tds_write_addtid_b32 %5 offset:%14\n\t"
+      "ds_write_addtid_b32 %6 offset:%15\n\tds_write_addtid_b32 %7 offset:%16"
+      :
+      : "v"(tr[0]), "v"(ti[0]), "v"(tr[1]), "v"(ti[1]), "v"(tr[2]), "v"(ti[2]), "v"(tr[3]), "v"(ti[3]), "s"(lds_base),
+        "n"((kRow * J) * kW * 4), "n"((kRow * J + 1) * kW * 4), "n"((kRow * (J + 1)) * kW * 4), "n"((kRow * (J + 1) + 1) * kW * 4),
+        "n"((kRow * (J + 2)) * kW * 4), "n"((kRow * (J + 2) + 1) * kW * 4), "n"((kRow * (J + 3)) * kW * 4), "n"((kRow * (J + 3) + 1) * kW * 4)
+      : "memory", "m0");
 }
 
 // MODE in {I8_IQ, I8_QI}; NWV wavefronts per workgroup share the staged tables of one channel
@@ -237,8 +252,15 @@ __global__ __launch_bounds__(NWV* kW) void corr_epl_cboc_kernel(const KArgs p) {
           exact = __any(suspect) != 0;
         }
 
-        float Ur[3][3], Ui[3][3];
+        // Horner step of one sum: acc = acc * conj(rho) + U, rho = delta^(SPL*64) = rotC - i rotS
+        auto horner = [&](int ar, int x, float ur, float ui) __attribute__((always_inline)) {
+          const float nr = fmaf(accr[ar][x], rotC, fmaf(-acci[ar][x], rotS, ur));
+          const float ni = fmaf(accr[ar][x], rotS, fmaf(acci[ar][x], rotC, ui));
+          accr[ar][x] = nr;
+          acci[ar][x] = ni;
+        };
         if (exact) {
+          float Ur[3][3], Ui[3][3];
           // ---- exact path: the reference's float64 index per sample and arm (rolled loop, samples re-read from memory) ------
 #pragma unroll
           for (int ar = 0; ar < 3; ++ar)
@@ -295,66 +317,49 @@ __global__ __launch_bounds__(NWV* kW) void corr_epl_cboc_kernel(const KArgs p) {
               Ui[2][x] = fmaf(c6, yi, Ui[2][x]);
             }
           }
-        } else {
-          // ---- the sample loop in two halves of eight: y, its running sums P and the three sign-modulated running sums P6, parked
-          // as they are formed; after each half every tap reads the rows its two transitions point at (row m & 7) and keeps the
-          // half's values whose m lies in it
-          float Tr = 0.f, Ti = 0.f, T6r[NS], T6i[NS];
 #pragma unroll
-          for (int sx = 0; sx < NS; ++sx) T6r[sx] = T6i[sx] = 0.f;
-          int mm[NS][2];
+          for (int ar = 0; ar < 3; ++ar)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) horner(ar, x, Ur[ar][x], Ui[ar][x]);
+        } else {
+          // ---- phase A: the carrier-wiped samples y - KEPT IN REGISTERS for the three sign phases below - and their running sums
+          // P, parked as they are formed (row j = sample j: {re, im} x 64 lanes)
+          float yr[SPL], yi[SPL];
+          float Tr = 0.f, Ti = 0.f;
+          static_for<0, SPL / 4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g != 0) __builtin_amdgcn_sched_barrier(0);
+            float pr[4], pi[4];
+            static_for<0, 4>([&](auto rc) {
+              constexpr int r = decltype(rc)::value, j = 4 * g + r;
+              float a, b;
+              sample_ab<MODE, j, NW>(w, a, b);
+              yr[j] = fmaf(a, C[j], b * S[j]);
+              yi[j] = fmaf(-a, S[j], b * C[j]);
+              Tr += yr[j];
+              Ti += yi[j];
+              pr[r] = Tr;
+              pi[r] = Ti;
+            });
+            park8<4 * g>(pr, pi, pfx_m0);
+          });
+          // every tap's two transition rows of P, read BEFORE the rows are reused (a wave's LDS operations complete in issue order)
+          const float* prow[NS][2];
+          float Q[NS][2][2];
 #pragma unroll
           for (int sx = 0; sx < NS; ++sx)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) mm[sx][n] = min((int)un[sx][n], SPL - 1);
-          float Q[NS][2][4];   // per tap and transition: P re, im, P6 re, im
-          auto half = [&](auto hc) {
-            constexpr int h = decltype(hc)::value;
-            static_for<0, kHalf>([&](auto jc) {
-              constexpr int r = decltype(jc)::value;
-              constexpr int j = h * kHalf + r;
-              if constexpr (r % 4 == 0 && r != 0) __builtin_amdgcn_sched_barrier(0);
-              float a, b;
-              sample_ab<MODE, j, NW>(w, a, b);
-              const float yr = fmaf(a, C[j], b * S[j]);
-              const float yi = fmaf(-a, S[j], b * C[j]);
-              Tr += yr;
-              Ti += yi;
-              park2<(kRow * r) * kW * 4, (kRow * r + 1) * kW * 4>(Tr, Ti, pfx_m0);
-              static_for<0, NS>([&](auto sc) {
-                constexpr int sx = decltype(sc)::value;
-                const float sg = __uint_as_float((w6[sx] & 0x80000000u) | 0x3f800000u);
-                T6r[sx] = fmaf(sg, yr, T6r[sx]);
-                T6i[sx] = fmaf(sg, yi, T6i[sx]);
-                park2<(kRow * r + 2 + 2 * sx) * kW * 4, (kRow * r + 3 + 2 * sx) * kW * 4>(T6r[sx], T6i[sx], pfx_m0);
-                w6[sx] += negD3;
-              });
-            });
-            static_for<0, NS>([&](auto sc) {
-              constexpr int sx = decltype(sc)::value;
-#pragma unroll
-              for (int n = 0; n < 2; ++n) {
-                const float* row = pfx + (kRow * (mm[sx][n] & (kHalf - 1))) * kW + lane;
-                const float v0 = row[0], v1 = row[kW], v2 = row[(2 + 2 * sx) * kW], v3 = row[(3 + 2 * sx) * kW];
-                if constexpr (h == 0) {
-                  Q[sx][n][0] = v0;
-                  Q[sx][n][1] = v1;
-                  Q[sx][n][2] = v2;
-                  Q[sx][n][3] = v3;
-                } else {
-                  const bool here = mm[sx][n] >= kHalf;
-                  Q[sx][n][0] = here ? v0 : Q[sx][n][0];
-                  Q[sx][n][1] = here ? v1 : Q[sx][n][1];
-                  Q[sx][n][2] = here ? v2 : Q[sx][n][2];
-                  Q[sx][n][3] = here ? v3 : Q[sx][n][3];
-                }
-              }
-            });
-          };
-          half(std::integral_constant<int, 0>{});
-          half(std::integral_constant<int, 1>{});
-          // ---- per tap: the three entries, the three arms ---------------------------------------------------------------------
-          static_for<0, NS>([&](auto sc) {
+            for (int n = 0; n < 2; ++n) {
+              prow[sx][n] = pfx + (kRow * min((int)un[sx][n], SPL - 1)) * kW + lane;
+              Q[sx][n][0] = prow[sx][n][0];
+              Q[sx][n][1] = prow[sx][n][kW];
+            }
+          // ---- phases E, P, L: one tap's sign-modulated running sums P6 at a time through the SAME rows (8 KB per wave instead of
+          // the 32 KB all four streams took side by side: twelve to sixteen waves per CU instead of four).  A tap's two rows of P6 are
+          // read as soon as its phase has parked them and USED one phase later (the next tap's sample loop runs while the reads are
+          // on their way: a wave's LDS operations complete in issue order, so the next phase's stores cannot overtake them)
+          float q6[NS][2][2], t6r[NS], t6i[NS];
+          auto tap_sums = [&](auto sc) {
             constexpr int sx = decltype(sc)::value;
             float cd[3], cp[3];
 #pragma unroll
@@ -366,29 +371,44 @@ __global__ __launch_bounds__(NWV* kW) void corr_epl_cboc_kernel(const KArgs p) {
             // sum_n c_n (Q_n - Q_{n-1}) = (c_0 - c_1) Q_0 + (c_1 - c_2) Q_1 + c_2 T
             const float ed0 = cd[0] - cd[1], ed1 = cd[1] - cd[2];
             const float ep0 = cp[0] - cp[1], ep1 = cp[1] - cp[2];
-            Ur[0][sx] = fmaf(ed0, Q[sx][0][0], fmaf(ed1, Q[sx][1][0], cd[2] * Tr));
-            Ui[0][sx] = fmaf(ed0, Q[sx][0][1], fmaf(ed1, Q[sx][1][1], cd[2] * Ti));
-            Ur[1][sx] = fmaf(ep0, Q[sx][0][0], fmaf(ep1, Q[sx][1][0], cp[2] * Tr));
-            Ui[1][sx] = fmaf(ep0, Q[sx][0][1], fmaf(ep1, Q[sx][1][1], cp[2] * Ti));
+            horner(0, sx, fmaf(ed0, Q[sx][0][0], fmaf(ed1, Q[sx][1][0], cd[2] * Tr)), fmaf(ed0, Q[sx][0][1], fmaf(ed1, Q[sx][1][1], cd[2] * Ti)));
+            horner(1, sx, fmaf(ep0, Q[sx][0][0], fmaf(ep1, Q[sx][1][0], cp[2] * Tr)), fmaf(ep0, Q[sx][0][1], fmaf(ep1, Q[sx][1][1], cp[2] * Ti)));
             // six-fold arm: coefficients c_n (-1)^(k0 + n): differences (-1)^k0 (c_0 + c_1), -(-1)^k0 (c_1 + c_2), last (-1)^k0 c_2
             const float sig = __uint_as_float(((unsigned int)kk[sx] << 31) | 0x3f800000u);
             const float e60 = sig * (cp[0] + cp[1]);
             const float e61 = -sig * (cp[1] + cp[2]);
             const float c62 = sig * cp[2];
-            Ur[2][sx] = fmaf(e60, Q[sx][0][2], fmaf(e61, Q[sx][1][2], c62 * T6r[sx]));
-            Ui[2][sx] = fmaf(e60, Q[sx][0][3], fmaf(e61, Q[sx][1][3], c62 * T6i[sx]));
+            horner(2, sx, fmaf(e60, q6[sx][0][0], fmaf(e61, q6[sx][1][0], c62 * t6r[sx])), fmaf(e60, q6[sx][0][1], fmaf(e61, q6[sx][1][1], c62 * t6i[sx])));
+          };
+          static_for<0, NS>([&](auto sc) {
+            constexpr int sx = decltype(sc)::value;
+            float ar = 0.f, ai = 0.f;
+            unsigned int wq = w6[sx];
+            static_for<0, SPL / 4>([&](auto gc) {
+              constexpr int g = decltype(gc)::value;
+              float pr[4], pi[4];
+              static_for<0, 4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value, j = 4 * g + r;
+                const float sg = __uint_as_float((wq & 0x80000000u) | 0x3f800000u);
+                ar = fmaf(sg, yr[j], ar);
+                ai = fmaf(sg, yi[j], ai);
+                pr[r] = ar;
+                pi[r] = ai;
+                wq += negD3;
+              });
+              park8<4 * g>(pr, pi, pfx_m0);
+            });
+            t6r[sx] = ar;
+            t6i[sx] = ai;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              q6[sx][n][0] = prow[sx][n][0];
+              q6[sx][n][1] = prow[sx][n][kW];
+            }
+            if constexpr (sx > 0) tap_sums(std::integral_constant<int, sx - 1>{});
           });
+          tap_sums(std::integral_constant<int, NS - 1>{});
         }
-        // Horner step: acc = acc * conj(rho) + U
-#pragma unroll
-        for (int ar = 0; ar < 3; ++ar)
-#pragma unroll
-          for (int x = 0; x < 3; ++x) {
-            const float nr = fmaf(accr[ar][x], rotC, fmaf(-acci[ar][x], rotS, Ur[ar][x]));
-            const float ni = fmaf(accr[ar][x], rotS, fmaf(acci[ar][x], rotC, Ui[ar][x]));
-            accr[ar][x] = nr;
-            acci[ar][x] = ni;
-          }
         // next chunk: t += 64*SPL*step*R*M, exactly
 #pragma unroll
         for (int sx = 0; sx < NS; ++sx)
@@ -451,7 +471,7 @@ int gc_cboc_waves(const gc_context* ctx) {
   const int tb = gc_multi_table_bytes(ctx->max_stage_len, 2);
   int forced = 0;
   if (const char* e = GC_TUNE_ENV("GC_CBOC_WAVES")) forced = std::atoi(e);
-  for (int w : {8, 6, 4, 2, 1}) {
+  for (int w : {16, 12, 8, 6, 4, 2, 1}) {
     if (tb + w * kWaveLds > kMaxLds) continue;
     if (forced == 0 || forced == w) return w;
   }
@@ -465,7 +485,9 @@ int gc_launch_correlator_cboc(gc_context* ctx, const KArgs& a_in, unsigned int g
   KArgs a = a_in;
   a.red_off = gc_multi_table_bytes(ctx->max_stage_len, 2);
   const size_t smem = (size_t)a.red_off + (size_t)waves * kWaveLds;
-  if (waves == 8) launch_cboc_waves<8>(ctx, a, dim3(grid), smem);
+  if (waves == 16) launch_cboc_waves<16>(ctx, a, dim3(grid), smem);
+  else if (waves == 8) launch_cboc_waves<8>(ctx, a, dim3(grid), smem);
+  else if (waves == 12) launch_cboc_waves<12>(ctx, a, dim3(grid), smem);
   else if (waves == 6) launch_cboc_waves<6>(ctx, a, dim3(grid), smem);
   else if (waves == 4) launch_cboc_waves<4>(ctx, a, dim3(grid), smem);
   else if (waves == 2) launch_cboc_waves<2>(ctx, a, dim3(grid), smem);
