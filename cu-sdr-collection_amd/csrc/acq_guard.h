@@ -62,8 +62,4 @@ int gc_collect_cells(hipStream_t stream, const float* r, int rows, long long row
 // stay inside the band even at the bound, with 27x margin on what is measured.  7.6e-6 at N = 36 000, 9e-6 at N = 360 000.  (A wider band
 // only costs time: every noise-only PRN whose two largest cells happen to lie that close takes the slow path - 64 * log2 N had one
 // such PRN in the default GPS L1 C/A search, +0.25 ms.)
-inline double gc_acq_tie_eps(int n) {
-  double l2 = 1.0;
-  for (long long m = 2; m < n; m *= 2) l2 += 1.0;
-  return 8.0 * l2 / 16777216.0;
-}
+double gc_acq_tie_eps(int n);  // (acq_guard.hip; GC_ACQ_GUARD_EPS=<value> in the tuning build: that band instead - the tests widen it to send every search through the slow path)

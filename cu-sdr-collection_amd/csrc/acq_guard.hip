@@ -115,6 +115,16 @@ __global__ __launch_bounds__(256) void collect_cells_kernel(const float* __restr
 
 }  // namespace
 
+double gc_acq_tie_eps(int n) {
+  if (const char* e = GC_TUNE_ENV("GC_ACQ_GUARD_EPS")) {
+    const double v = std::atof(e);
+    if (v > 0.0 && v < 0.5) return v;
+  }
+  double l2 = 1.0;
+  for (long long m = 2; m < n; m *= 2) l2 += 1.0;
+  return 8.0 * l2 / 16777216.0;
+}
+
 int gc_exact_cells_from_keys(hipStream_t stream, const unsigned long long* keys, int nprn, double f0, double fstep, const double* d_off,
                              long long first, GcExactCell* d_cells) {
   if (nprn <= 0) return GC_OK;

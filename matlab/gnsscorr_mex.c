@@ -34,6 +34,7 @@
  *   picks = gnsscorr_mex('acq_shift_search_batch', h, int8(chips), int32(index0), weights, rule, exclude, period, narms)  % a package's whole search: 4 x nPRN
  *   x    = gnsscorr_mex('read_if', h, firstSample0, n, 'int8'|'int16', valuesPerSample)   % raw record samples back
  *   [name, cus] = gnsscorr_mex('device_info', h)
+ *   [ties, maxDev, eps] = gnsscorr_mex('acq_guard_stats', h)                         % float64 guard of the last search (gc_acq_guard_stats)
  *   n    = gnsscorr_mex('device_count')                                              % HIP devices visible: one context per device
  */
 #include <string.h>
@@ -509,6 +510,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       mxGetDoubles(plhs[0])[1] = (double)dt;
       mxGetDoubles(plhs[0])[2] = (double)lay;
     }
+  } else if (!strcmp(cmd, "acq_guard_stats")) {
+    /* [ties, maxDev, eps] = gnsscorr_mex('acq_guard_stats', h): the float64 guard of the context's last search (gc_acq_guard_stats) */
+    int32_t ties = 0;
+    double dev = 0.0, eps = 0.0;
+    if (gc_acq_guard_stats(handle(prhs[1]), &ties, &dev, &eps)) fail("gc_acq_guard_stats");
+    plhs[0] = mxCreateDoubleScalar(ties);
+    if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(dev);
+    if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(eps);
   } else if (!strcmp(cmd, "device_count")) {
     int n = 0;
     if (gc_device_count(&n)) fail("gc_device_count");

@@ -305,6 +305,35 @@ def test_acquisition_paths_behind_the_tuning_knobs_return_the_references_results
         _compare_acq(sc, z, sc.product(P, eng, S), float32_metric=name in ("BDS_B1I", "GPS_L2C", "BDS_B1C") and any(k in env for k in ("GC_ACQ_ROWMAX_KERNEL", "GC_ACQ_GENERIC", "GC_ACQ_SHIFT_PER_PRN")))
 
 
+_WIDE_BAND = [s for s in RS.ACQ_SCENES + RS.GUARD_ACQ_SCENES] + [s for s in RS.DEFAULT_ACQ_SCENES if s.name in ("GPS_L1CA_default", "GPS_L5C_default", "GLO_GL1_default", "BDS_B1I_default")]
+
+
+@pytest.mark.tuning
+@pytest.mark.parametrize("sc", _WIDE_BAND, ids=[s.name for s in _WIDE_BAND])
+def test_guards_slow_path_on_every_search_returns_the_references_results(sc, monkeypatch):
+    """GC_ACQ_GUARD_EPS=0.02 (tuning build): every PRN whose runner-up lies within 2 % of its winner - most noise-only PRNs, many rows of
+    the circshift searches - goes through the float64 guard's SLOW path: the PRN searched again with its sums written, the cells within
+    the band collected and re-evaluated as float64 correlations, the reference's first-occurrence rule on those values.  Data + pilot
+    arms with weights, GLONASS' per-row centre frequencies, merged arms, bins in chunks, conditioned (float32) signals, padded
+    transforms, the circshift family's row ties and second peaks: codePhase / carrFreq identical to the reference's acquisition.m,
+    peakMetric to the scene's (float64) tolerance, as on the fast path."""
+    import cu_sdr_collection_amd as P
+    path = os.path.join(GOLD, f"ref_acq_{sc.name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    monkeypatch.setenv("GC_ACQ_GUARD_EPS", "0.02")
+    z = np.load(path)
+    S, rec = RS.acq_inputs(P, sc)
+    with P.Engine(0) as eng:
+        eng.load_if(rec, fs=S.samplingFreq)
+        got = sc.product(P, eng, S)
+        st = eng.acq_guard_stats()
+    _compare_acq(sc, z, got)
+    assert st["eps"] == 0.02
+    if sc.name in ("GPS_L1CA_default", "GPS_L5C_default", "BDS_B1I_default", "GPS_L1CA", "BDS_B1I_tie_rows"):
+        assert st["ties"] >= 1, st          # (the default lists' noise-only PRNs: among 25 - 50 of them some have their two largest cells within 2 %)
+
+
 _ACQ_FUSED = ("GPS_L1CA", "GPS_L5C", "GAL_E5a", "GAL_E5b", "BDS_B2a", "BDS_B3I", "GLO_GL1")   # searches of 36 000 / 24 000 points
 
 
