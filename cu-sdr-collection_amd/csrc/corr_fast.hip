@@ -556,7 +556,11 @@ __global__ __launch_bounds__(WIDE != 0 ? 256 : kFW) void corr_epl_fast_kernel(co
     // the whole team's messages — lane 32h + k takes message h of member k — adds them in double in a fixed order (DPP),
     // and closes the loop itself: identical inputs, identical instructions, identical next descriptor in every member, so
     // there is ONE message hop per epoch and no descriptor broadcast.  Member 0 alone writes records and host-visible state.
+#if defined(GC_DEVLOOP_ARGS_BY_POINTER) && GC_DEVLOOP_ARGS_BY_POINTER
+    const DevLoopArgs* dl = p.devloop;  // A/B (scripts/variants.sh): the closure reads the constants through the pointer, as before round 6
+#else
     const DevLoopArgs* dl = &dl_loc;
+#endif
     const unsigned int tag = (unsigned int)bi + 1u;
     msg_t* pm = dl->part_msg + ((lb * 2 + (bi & 1)) * dl->splits) * 2;
     if (lane == 63) {

@@ -8,7 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["GC_LIB_PATH"] = os.path.join(ROOT, "cu-sdr-collection_amd", "lib", "libgnsscorr_tuning.so")
+os.environ.setdefault("GC_LIB_PATH", os.path.join(ROOT, "cu-sdr-collection_amd", "lib", "libgnsscorr_tuning.so"))
 import numpy as np  # noqa: E402
 import cu_sdr_collection_amd as P  # noqa: E402
 from cu_sdr_collection_amd import _lib as L  # noqa: E402
