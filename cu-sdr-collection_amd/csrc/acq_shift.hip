@@ -8,7 +8,7 @@ using namespace gcacq;
 
 namespace {
 
-__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r, int ncols, int stride, float* vmax, int* amax) {
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r, int ncols, int stride, float* vmax, int* amax, float* vsecond = nullptr) {
   __shared__ float sv[256];
   __shared__ int si[256];
   const float* row = r + (long long)blockIdx.x * stride;
@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ r
     vmax[blockIdx.x] = sv[0];
     amax[blockIdx.x] = si[0];
   }
+  if (!vsecond) return;
+  // the row's runner-up for the float64 guard: the largest value at any OTHER column (== the maximum when a second column holds it)
+  const float m1 = sv[0];
+  const int a1 = si[0];
+  __syncthreads();
+  float sec = -1.0f;
+  for (int i = threadIdx.x; i < ncols; i += 256)
+    if (i != a1) sec = fmaxf(sec, row[i]);
+  sv[threadIdx.x] = sec;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sv[threadIdx.x] = fmaxf(sv[threadIdx.x], sv[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) vsecond[blockIdx.x] = fminf(sv[0], m1);
 }
 }  // namespace
 
@@ -546,6 +561,228 @@ int pick_sequential(const gc_acq_shift_params& p, const T* rmax, bool pairs) {
 }
 }  // namespace
 
+// gc_acq_shift_search_batch where the passes WRITE the rows (no per-tile candidates): PRN by PRN inside the call - rows and columns
+// passes, row maxima with their runner-ups (rowmax_kernel), the package's rule on the host, rows within eps of the chosen one and the
+// cells within eps of the first maximum / second peak re-evaluated in float64 (acq_guard.h) from the rows as they lie in s->results.
+// b_codes (replicas, [nprn * narms][p.n]) and cspec (their spectra) are in place.
+static int shift_batch_written(gc_context* ctx, AcqScratch* s, int nprn, int narms, const float2* cspec, const double* arm_weight, int rule, int exclude,
+                               int period, int code_samples, gc_acq_shift_pick* out) {
+  const gc_acq_shift_params& p = s->shift;
+  const Plan& pl = s->plan;
+  const int rows = p.n_carriers * p.n_signals * p.n_bins;
+  const size_t N = (size_t)pl.n;
+  const bool pairs = rule == GC_SHIFT_PICK_SEQUENTIAL_PAIRS, second = rule != GC_SHIFT_PICK_GLOBAL;
+  const bool guard = GC_TUNE_ENV("GC_ACQ_NO_GUARD") == nullptr;
+  const double eps = gc_acq_tie_eps(pl.n);
+  const double ones[4] = {1.0, 1.0, 1.0, 1.0};
+  const double* const wts = arm_weight ? arm_weight : ones;
+  GcExactSetup ex;
+  ex.if_i8 = p.source == GC_ACQ_SOURCE_CONDITIONED ? nullptr : (const int8_t*)ctx->d_if;
+  ex.if_f32 = p.source == GC_ACQ_SOURCE_CONDITIONED ? (const float2*)ctx->acqbuf[gc_context::ACQ_COND_SIG].p : nullptr;
+  ex.blk = p.n;
+  ex.cl = code_samples;
+  ex.hop_stride = 0;
+  ex.nhops = 1;
+  ex.narms = narms;
+  for (int arm = 0; arm < narms; ++arm) ex.w[arm] = wts[arm];
+  ex.codes = (const int8_t*)s->b_codes.p;
+  ex.code_stride = p.n;
+  ex.fs = p.sampling_freq;
+  if (gc_buf_reserve(s->b_cells, (size_t)kGuardListCap * sizeof(GcExactCell), false) != hipSuccess ||
+      gc_buf_reserve(s->b_exact, (size_t)kGuardListCap * sizeof(double), false) != hipSuccess ||
+      gc_buf_reserve(s->b_list, (size_t)kGuardListCap * sizeof(int2) + 64, false) != hipSuccess ||
+      gc_buf_reserve(s->b_rowsec, (size_t)rows * sizeof(float), false) != hipSuccess ||
+      gc_buf_reserve(s->b_pick, sizeof(ShiftPickDev), false) != hipSuccess) {
+    (void)hipGetLastError();
+    gc_set_error("gc_acq_shift_search_batch: device allocation failed");
+    return GC_E_NOMEM;
+  }
+  s->guard_ties = 0;
+  s->guard_max_dev = 0.0;
+  s->rowsecond = nullptr;
+  auto irow_of = [&](int row) { return s->shift_padded ? shift_internal_row(p, row) : row; };
+  auto exact_values = [&](int k, const std::vector<int2>& rc_list, std::vector<double>& vals) -> int {
+    std::vector<GcExactCell> cells(rc_list.size());
+    for (size_t i = 0; i < rc_list.size(); ++i) {
+      GcExactCell& c = cells[i];
+      const int row = rc_list[i].x;
+      c.code = k;
+      c.col = rc_list[i].y;
+      c.shift = row % p.n_bins;
+      c.bin = row;
+      c.freq = p.carrier_f0 + p.carrier_step * (double)(row / (p.n_signals * p.n_bins));
+      c.first = p.first_sample + (long long)((row / p.n_bins) % p.n_signals) * p.n;
+    }
+    GC_HIP(hipMemcpyAsync(s->b_cells.p, cells.data(), cells.size() * sizeof(GcExactCell), hipMemcpyHostToDevice, ctx->stream));
+    int rc2 = gc_exact_cells(ctx->stream, ex, (const GcExactCell*)s->b_cells.p, (int)cells.size(), (double*)s->b_exact.p);
+    if (rc2) return rc2;
+    vals.resize(cells.size());
+    GC_HIP(hipMemcpyAsync(vals.data(), s->b_exact.p, vals.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+  };
+  // cells of public row `row` (as it lies in s->results) at or above thr
+  auto row_cells = [&](int row, float thr, std::vector<int2>& list, bool* overflow) -> int {
+    int* const d_count = (int*)s->b_list.p;
+    int2* const d_list = (int2*)((char*)s->b_list.p + 64);
+    GC_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    int rc2 = gc_collect_cells(ctx->stream, s->results + (size_t)irow_of(row) * N, 1, (long long)N, p.n, thr, d_count, d_list, kGuardListCap);
+    if (rc2) return rc2;
+    int count = 0;
+    GC_HIP(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    *overflow = count > kGuardListCap;
+    list.assign((size_t)std::max(0, std::min(count, kGuardListCap)), make_int2(0, 0));
+    if (!list.empty()) GC_HIP(hipMemcpy(list.data(), d_list, list.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    for (int2& c : list) c.x = row;
+    return GC_OK;
+  };
+  std::vector<float> hm((size_t)rows), hs((size_t)rows);
+  std::vector<int> ha((size_t)rows);
+  std::vector<double> rmd((size_t)rows);
+  std::vector<int> rad((size_t)rows);
+  for (int k = 0; k < nprn; ++k) {
+    gc_acq_shift_pick& pk = out[k];
+    pk.row = -1;
+    pk.code_phase = 0;
+    pk.peak = 0.0;
+    pk.second_peak = 0.0;
+    bool all_fused = false;
+    int rc = shift_search_passes(ctx, s, narms, cspec + (size_t)k * narms * N, arm_weight, &all_fused, s->tmp);
+    if (rc) return rc;
+    if (all_fused) {
+      gc_set_error("gc_acq_shift_search_batch: internal - the written-rows path met fused row candidates");
+      return GC_E_STATE;
+    }
+    hipLaunchKernelGGL(rowmax_kernel, dim3(rows), dim3(256), 0, ctx->stream, s->results, p.n, pl.n, s->rowmax, s->rowarg, (float*)s->b_rowsec.p);
+    GC_HIP(hipGetLastError());
+    rc = shift_read_back(ctx, s, hm.data(), s->rowmax, sizeof(float) * rows, ha.data(), s->rowarg, sizeof(int) * rows, hs.data(), s->b_rowsec.p, sizeof(float) * rows);
+    if (rc) return rc;
+    for (int r = 0; r < rows; ++r) {  // public order
+      rmd[(size_t)r] = (double)hm[(size_t)irow_of(r)];
+      rad[(size_t)r] = ha[(size_t)irow_of(r)];
+    }
+    auto apply_rule = [&]() {
+      if (rule == GC_SHIFT_PICK_GLOBAL) {
+        int best = 0;
+        for (int r = 1; r < rows; ++r)
+          if (rmd[(size_t)r] > rmd[(size_t)best]) best = r;
+        int col = rad[(size_t)best];
+        for (int r = 0; r < rows; ++r)
+          if (rmd[(size_t)r] == rmd[(size_t)best] && rad[(size_t)r] < col) col = rad[(size_t)r];
+        pk.row = best;
+        pk.code_phase = col;
+        pk.peak = rmd[(size_t)best];
+      } else {
+        pk.row = pick_sequential(p, rmd.data(), pairs);
+      }
+    };
+    apply_rule();
+    if (pk.row < 0) continue;
+    if (guard) {
+      const double near = rmd[(size_t)pk.row] * (1.0 - eps);
+      std::vector<int> tied;
+      for (int r = 0; r < rows; ++r)
+        if (rmd[(size_t)r] >= near && rmd[(size_t)r] > 0.0) tied.push_back(r);
+      if (tied.size() > 1 && tied.size() <= 64) {
+        ++s->guard_ties;
+        for (int r : tied) {
+          std::vector<int2> list;
+          bool overflow = false;
+          rc = row_cells(r, (float)(rmd[(size_t)r] * (1.0 - eps)), list, &overflow);
+          if (rc) return rc;
+          if (overflow || list.empty()) continue;
+          std::vector<double> vals;
+          rc = exact_values(k, list, vals);
+          if (rc) return rc;
+          double best = -1.0;
+          int bc = 0;
+          for (size_t i = 0; i < list.size(); ++i)
+            if (vals[i] > best || (vals[i] == best && list[i].y < bc)) {
+              best = vals[i];
+              bc = list[i].y;
+            }
+          rmd[(size_t)r] = best;
+          rad[(size_t)r] = bc;
+        }
+        apply_rule();
+      }
+    }
+    // first maximum and second peak of the chosen row, from the row in memory
+    ShiftPickDev d;
+    std::memset(&d, 0, sizeof d);
+    d.row = pk.row;
+    d.second_col = -1;
+    GC_HIP(hipMemcpyAsync(s->b_pick.p, &d, sizeof d, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(shift_pick_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->results + (size_t)irow_of(pk.row) * N, (long long)N, p.n, exclude,
+                       second ? period : 0, (float)eps, (ShiftPickDev*)s->b_pick.p);
+    GC_HIP(hipGetLastError());
+    rc = shift_read_back(ctx, s, &d, s->b_pick.p, sizeof d);
+    if (rc) return rc;
+    if (second) pk.code_phase = d.code_phase;
+    pk.peak = (double)d.peak;
+    pk.second_peak = second ? (double)d.second : 0.0;
+    if (!guard) continue;
+    {
+      std::vector<int2> two;
+      two.push_back(make_int2(pk.row, pk.code_phase));
+      if (second && d.second_col >= 0) two.push_back(make_int2(pk.row, d.second_col));
+      std::vector<double> vals;
+      rc = exact_values(k, two, vals);
+      if (rc) return rc;
+      if (vals[0] > 0.0) s->guard_max_dev = std::max(s->guard_max_dev, std::fabs(pk.peak - vals[0]) / vals[0]);
+      pk.peak = vals[0];
+      if (two.size() > 1) pk.second_peak = vals[1];
+    }
+    if (d.near_peak <= 1 && d.near_second <= 1) continue;
+    ++s->guard_ties;
+    const float low = second && d.second_col >= 0 ? std::min(d.peak, d.second) : d.peak;
+    std::vector<int2> list;
+    bool overflow = false;
+    rc = row_cells(pk.row, (float)((double)low * (1.0 - eps)), list, &overflow);
+    if (rc) return rc;
+    if (overflow || list.empty()) continue;
+    std::vector<double> vals;
+    rc = exact_values(k, list, vals);
+    if (rc) return rc;
+    double best = -1.0;
+    int bc = 0;
+    for (size_t i = 0; i < list.size(); ++i)
+      if (vals[i] > best || (vals[i] == best && list[i].y < bc)) {
+        best = vals[i];
+        bc = list[i].y;
+      }
+    pk.code_phase = bc;
+    pk.peak = best;
+    if (second) {
+      const int cp = bc + 1, e1 = cp - exclude, e2 = cp + exclude;
+      int lo0, hi0, lo1 = 1, hi1 = 0;
+      if (e1 < 2) {
+        lo0 = e2;
+        hi0 = period + e1;
+      } else if (e2 >= period) {
+        lo0 = e2 - period + 1;
+        hi0 = e1;
+      } else {
+        lo0 = 1;
+        hi0 = e1;
+        lo1 = e2;
+        hi1 = period;
+      }
+      double sec = -1.0;
+      for (size_t i = 0; i < list.size(); ++i) {
+        const int c1 = list[i].y + 1;
+        if ((c1 >= lo0 && c1 <= hi0) || (c1 >= lo1 && c1 <= hi1)) sec = std::max(sec, vals[i]);
+      }
+      if (sec >= 0.0) pk.second_peak = sec;
+    }
+  }
+  // no single PRN's search is "the last one" for gc_acq_shift_row after this call
+  s->shift_rows_fused = true;
+  s->shift_narms = 0;
+  return GC_OK;
+}
+
 extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, const int8_t* codes, int code_len, const int32_t* sample_index,
                                          int n_index, const double* arm_weight, int rule, int exclude, int period, gc_acq_shift_pick* out) {
   AcqScratch* s = ctx ? (AcqScratch*)ctx->acq_scratch : nullptr;
@@ -568,10 +805,11 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
         gc_set_error("gc_acq_shift_search_batch: sample_index[%d] = %d is outside the %d chips of a code", k, (int)sample_index[k], code_len);
         return GC_E_INVALID;
       }
-  if (s->shift_padded || ct_columns_tile(s->plan.p1.len, s->plan.n2) == 0 || GC_TUNE_ENV("GC_ACQ_GENERIC") || GC_TUNE_ENV("GC_ACQ_ROWMAX_KERNEL")) {
-    gc_set_error("gc_acq_shift_search_batch: this block length has no specialised pass kernels - search PRN by PRN (gc_acq_shift_search / _row)");
-    return GC_E_UNSUPPORTED;
-  }
+  // Block lengths without specialised pass kernels (16.368-Msps front ends: padded transforms; GC_ACQ_GENERIC / GC_ACQ_ROWMAX_KERNEL in the
+  // tuning build): the passes write every row's sums, so the PRNs are searched one after the other and each one's rows are picked, and
+  // guarded, straight from s->results before the next PRN overwrites them (round 5 answered GC_E_UNSUPPORTED here and left the rules to
+  // the caller, on float32 rows)
+  const bool written_rows = s->shift_padded || ct_columns_tile(s->plan.p1.len, s->plan.n2) == 0 || GC_TUNE_ENV("GC_ACQ_GENERIC") || GC_TUNE_ENV("GC_ACQ_ROWMAX_KERNEL");
   GC_HIP(hipSetDevice(ctx->device));
   const Plan& pl = s->plan;
   const int rows = p.n_carriers * p.n_signals * p.n_bins;
@@ -618,6 +856,7 @@ extern "C" int gc_acq_shift_search_batch(gc_context* ctx, int nprn, int narms, c
       if (rc) return rc;
     }
   }
+  if (written_rows) return shift_batch_written(ctx, s, nprn, narms, cspec, arm_weight, rule, exclude, period, sample_index ? n_index : p.n, out);
   // phase 1: every PRN's rows and columns passes, its row maxima into its own slot - nothing comes back in between.  Two lanes where a
   // PRN's intermediate is small (BDS B1I: 62 PRNs x 0.17 ms of launches that each leave a tail of half-empty CUs - 5.8 -> 5.1 ms): even
   // PRNs on one stream of the device's search pair, odd PRNs on the other with an intermediate buffer and candidate slots of their own.

@@ -428,8 +428,8 @@ class Engine:
 
     def acq_shift_search_batch(self, codes: np.ndarray, arm_weight, rule: int, exclude: int = 0, period: int = 1, sample_index=None):
         """gc_acq_shift_search_batch: codes int8 [nprn, narms, n] (sampled replicas) or, with sample_index (0-based, one vector for all
-        codes), [nprn, narms, chips] -> ctypes array of gc_acq_shift_pick [nprn], or None when the library answers GC_E_UNSUPPORTED
-        (block lengths without specialised passes) or GC_E_NOMEM (the batch's buffers do not fit): the caller searches PRN by PRN."""
+        codes), [nprn, narms, chips] -> ctypes array of gc_acq_shift_pick [nprn], or None when the library answers GC_E_NOMEM (the batch's buffers
+        do not fit; GC_E_UNSUPPORTED is kept for older libraries): the caller searches PRN by PRN."""
         p = self._shift
         c8 = np.ascontiguousarray(codes, dtype=np.int8)
         nprn, narms = c8.shape[0], c8.shape[1]

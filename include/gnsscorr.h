@@ -486,8 +486,10 @@ int gc_acq_shift_row(gc_context* ctx, int row, float* out /* n floats */);  /* a
  * (ceil(ts*k/tc) depends on the rates only: makeCaTableDMA.m, makeCMTable.m, makeDataTable.m) and the [table zeros] padding done on
  * the device: a few KB per code cross the bus instead of n bytes.
  * second_peak: the largest value among the row's first `period` samples at least `exclude` samples away from the peak, with the
- * reference's three range cases (B1I :141-156, L2C :77-91).  GC_E_UNSUPPORTED when the prepared block length has no specialised pass
- * kernels (16.368-Msps front ends, GC_ACQ_GENERIC): search PRN by PRN with gc_acq_shift_search / gc_acq_shift_row then. */
+ * reference's three range cases (B1I :141-156, L2C :77-91).  Block lengths without specialised pass kernels (16.368-Msps front ends:
+ * padded transforms) run PRN after PRN inside the call, every PRN's rows picked - and guarded in float64, gc_acq_guard_stats - from the
+ * written sums (API version 4; version 3 answered GC_E_UNSUPPORTED there).  GC_E_NOMEM: the whole list's buffers do not fit - search
+ * PRN by PRN with gc_acq_shift_search / gc_acq_shift_row (float32 rows, the rules and no guard on the caller's side). */
 enum { GC_SHIFT_PICK_GLOBAL = 0, GC_SHIFT_PICK_SEQUENTIAL = 1, GC_SHIFT_PICK_SEQUENTIAL_PAIRS = 2 };
 typedef struct gc_acq_shift_pick {
   int32_t row;          /* winning row, -1: no value above 0 (the reference leaves the PRN's results at 0) */

@@ -301,8 +301,9 @@ def test_acquisition_paths_behind_the_tuning_knobs_return_the_references_results
     S, rec = RS.acq_inputs(P, sc)
     with P.Engine(0) as eng:                      # a context of its own: the knobs that are read once per scratch see a fresh one
         eng.load_if(rec, fs=S.samplingFreq)
-        # the circshift family without its specialised passes searches PRN by PRN: float32 rows, no guard
-        _compare_acq(sc, z, sc.product(P, eng, S), float32_metric=name in ("BDS_B1I", "GPS_L2C", "BDS_B1C") and any(k in env for k in ("GC_ACQ_ROWMAX_KERNEL", "GC_ACQ_GENERIC", "GC_ACQ_SHIFT_PER_PRN")))
+        # (GC_ACQ_SHIFT_PER_PRN: the circshift family PRN by PRN from the caller's side - float32 rows, no guard; without specialised passes the
+        # batch call itself runs PRN after PRN on written rows, guarded)
+        _compare_acq(sc, z, sc.product(P, eng, S), float32_metric=name in ("BDS_B1I", "GPS_L2C", "BDS_B1C") and "GC_ACQ_SHIFT_PER_PRN" in env)
 
 
 _WIDE_BAND = [s for s in RS.ACQ_SCENES + RS.GUARD_ACQ_SCENES] + [s for s in RS.DEFAULT_ACQ_SCENES if s.name in ("GPS_L1CA_default", "GPS_L5C_default", "GLO_GL1_default", "BDS_B1I_default")]
