@@ -389,7 +389,7 @@ def test_bench_prints_a_line_the_driver_can_parse():
     long forms of rounds 3 and 4 and on an N > 1 shape with per-rank entries."""
     import json
     import bench
-    for rnd in ("r03", "r04", "r05"):
+    for rnd in ("r03", "r04", "r05", "r06"):
         full = json.load(open(os.path.join(bench.ROOT, "profiles", rnd, "bench.json")))
         line = bench.compact_line(full, bench.DETAIL_DEFAULT)
         assert len(line) < 4096 and "\n" not in line
