@@ -31,6 +31,7 @@ INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
 
 _CORR_UNITS = ["gnsscorr.hip", "corr_kernel.hip", "corr_fast.hip", "corr_multi.hip",
                # one source, four translation units (its 148 kernel instantiations took one compiler process 248 s): unit@MACRO=value
+               "corr_cboc.hip",   # (round 6: the hybrid for channels with a derived BOC(6,1) arm ships - it beats the lane kernel on config 3's lists)
                "corr_lane.hip@GC_LANE_PART=0", "corr_lane.hip@GC_LANE_PART=1", "corr_lane.hip@GC_LANE_PART=2", "corr_lane.hip@GC_LANE_PART=3",
                "track.hip", "multi.hip", "stream.hip",
                # the acquisition, one translation unit per part of the search (acq_internal.h is what they share)
@@ -44,9 +45,8 @@ def _tuned(spec: str) -> str:
 LIBS = {
     # the product: reads no tuning variable (gc_internal.h GC_TUNE_ENV), carries no experimental kernel
     "libgnsscorr.so": _CORR_UNITS,
-    # the same sources with -DGC_TUNING=1: every A/B switch of docs/KNOBS.md live, plus the kernels that lost their A/B
-    # (corr_cboc.hip).  Loaded through GC_LIB_PATH by the knob tests, scripts/variants.sh and the profiling scripts.
-    "libgnsscorr_tuning.so": [_tuned(u) for u in _CORR_UNITS] + [_tuned("corr_cboc.hip")],
+    # the same sources with -DGC_TUNING=1: every A/B switch of docs/KNOBS.md live.  Loaded through GC_LIB_PATH by the knob tests, scripts/variants.sh and the profiling scripts.
+    "libgnsscorr_tuning.so": [_tuned(u) for u in _CORR_UNITS],
     "libgnsssynth.so": ["synth.hip"],
 }
 HEADERS = ["gc_internal.h", "corr_common.h", "devloop.h", "acq_guard.h", "acq_internal.h", os.path.join("..", "..", "include", "gnsscorr.h")]

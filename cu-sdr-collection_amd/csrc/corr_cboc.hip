@@ -65,6 +65,12 @@ __device__ __forceinline__ void park8(const float (&tr)[4], const float (&ti)[4]
       : "memory", "m0");
 }
 
+// a block-uniform float64 into scalar registers (the compiler computes the block's constants with vector instructions and keeps them in
+// VGPRs - two dozen registers of a kernel that has 128 at four waves per SIMD)
+__device__ __forceinline__ double uni64(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
 // MODE in {I8_IQ, I8_QI}; NWV wavefronts per workgroup share the staged tables of one channel
 template <int MODE, int NWV>
 __global__ __launch_bounds__(NWV* kW) void corr_epl_cboc_kernel(const KArgs p) {
@@ -115,20 +121,20 @@ __global__ __launch_bounds__(NWV* kW) void corr_epl_cboc_kernel(const KArgs p) {
     const DevChannel* __restrict__ chn = p.chans + blk.channel;
 
     // ---- per-block uniform quantities (corr_multi.hip / corr_kernel.hip have the reference line citations) --------
-    const double R = chn->index_scale;
-    const double M = chn->mult[0];
-    const double M6 = chn->mult[2];
-    const double rem = blk.rem_code_phase;
-    const double step = blk.code_phase_step;
-    const double d = blk.el_spacing;
-    const int N = blk.blksize;
+    const double R = uni64(chn->index_scale);
+    const double M = uni64(chn->mult[0]);
+    const double M6 = uni64(chn->mult[2]);
+    const double rem = uni64(blk.rem_code_phase);
+    const double step = uni64(blk.code_phase_step);
+    const double d = uni64(blk.el_spacing);
+    const int N = __builtin_amdgcn_readfirstlane(blk.blksize);
     const long long s0 = blk.first_sample;
-    const double aE = (rem - d) * R;
-    const double aL = (rem + d) * R;
-    const double aP = rem * R;
-    const double sp = step * R;
-    const double tau = blk.carr_freq * p.inv_fs;
-    const double spM = sp * M;
+    const double aE = uni64((rem - d) * R);
+    const double aL = uni64((rem + d) * R);
+    const double aP = uni64(rem * R);
+    const double sp = uni64(step * R);
+    const double tau = uni64(blk.carr_freq * p.inv_fs);
+    const double spM = uni64(sp * M);
     double rspM = __builtin_amdgcn_rcp(spM);
     rspM = fma(rspM, fma(-spM, rspM, 1.0), rspM);
     rspM = fma(rspM, fma(-spM, rspM, 1.0), rspM);
@@ -476,6 +482,11 @@ int gc_cboc_waves(const gc_context* ctx) {
     if (forced == 0 || forced == w) return w;
   }
   return 0;
+}
+
+bool gc_cboc_takes(const gc_context* ctx, long long nblocks, int period) {
+  return ctx->scope_kt6 >= 1 && period > 0 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && gc_cboc_waves(ctx) > 0 &&
+         nblocks >= 2LL * period * ctx->compute_units;
 }
 
 // Periodic replay lists of int8 I/Q (Q/I) records whose channels are three-arm channels with a derived six-fold arm

@@ -147,14 +147,15 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
   long long total = (long long)nblocks * splits;
   int want_bpw = 8;
   if (const char* e = GC_TUNE_ENV("GC_REPLAY_BPW")) want_bpw = std::max(1, std::atoi(e));
-#if GC_TUNING
   // Hybrid kernel for channels with a derived six-fold arm (corr_cboc.hip): periodic replay lists of int8 I/Q records, all channels
-  // derived, base ramp with <= 2 transitions per 16-sample chunk.  MEASURED SLOWER than the lane kernel's derived-arm instantiation
-  // (config 3's shape over 20 s: 3.69 ms against 3.41 - DESIGN.md 4.2c has the counters): tuning build only, opt-in with GC_CBOC=1.
-  if (fast == 0 && a.derived && ctx->scope_kt6 >= 1 && period > 0 && splits == 1 && notify_tag == 0 && max_arms == 3 &&
-      ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && !ctx->force_generic && GC_TUNE_ENV("GC_CBOC")) {
+  // derived, base ramp with <= 2 transitions per 16-sample chunk.  Round 5's version (all four running-sum streams parked side by side:
+  // 4 - 8 waves per CU) measured slower than the lane kernel's derived-arm instantiation; round 6's phased parking at sixteen waves per CU
+  // is ahead of it (config 3's shape over 20 s: 2.76 ms against 2.91 - DESIGN.md 4.2c), so it takes these lists.  GC_NO_CBOC=1 (tuning
+  // build): the lane kernel as before.
+  if (fast == 0 && a.derived && gc_cboc_takes(ctx, nblocks, period) && splits == 1 && notify_tag == 0 && max_arms == 3 && !ctx->force_generic &&
+      !GC_TUNE_ENV("GC_NO_CBOC")) {
     const int cwaves = gc_cboc_waves(ctx);
-    if (cwaves > 0 && nblocks >= 2LL * period * ctx->compute_units) {
+    {
       a.bpw = cwaves * (nblocks >= 64LL * cwaves * ctx->compute_units ? 2 : 1);  // a staged table serves bpw epochs of its channel
       a.stride = period;
       a.wide = 1;
@@ -174,7 +175,6 @@ int gc_launch_correlator(gc_context* ctx, const gc_block* d_blocks, int64_t nblo
       return gc_launch_correlator_cboc(ctx, a, (unsigned int)total, cwaves);
     }
   }
-#endif
   // Multi-transition kernel (corr_multi.hip): big periodic replay lists whose chunks of 16 samples see up to 2 or 4 table
   // transitions - lists the single-transition kernel takes with 8-sample chunks (fast == 1) or hands to the lane kernel
   // (fast == 0).  GC_NO_MULTI=1 keeps the old choice (A/B), GC_MULTI_MIN = epochs per CU from which it is taken.

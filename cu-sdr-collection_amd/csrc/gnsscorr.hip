@@ -997,16 +997,6 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
     gc_set_error("gc_replay_prepare: device allocation failed");
     return GC_E_NOMEM;
   }
-  {
-    std::vector<gc_block> marked(blocks, blocks + nblocks);
-    // the band the kernel that may take the list tests in: 8e-6 samples of ramp = twice the 4e-6 of corr_fast.hip and corr_multi.hip
-    // (a list of derived-arm channels needs the wide band only where corr_cboc.hip may take it: the tuning build with GC_CBOC set -
-    // with it on every such list the lane kernel lost its tie-free marks on ~40 % of config 3's blocks, 0.26 -> 0.22)
-    const bool cboc_list = GC_TUNING && GC_TUNE_ENV("GC_CBOC") != nullptr && ctx->replay_kt6 > 0;
-    gc_mark_tie_free(ctx, marked.data(), nblocks, (ctx->replay_kt > 0 || cboc_list || ctx->replay_fast > 0) ? 8e-6 : 0.0);
-    GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, marked.data(), sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
-    GC_HIP(hipStreamSynchronize(ctx->stream));
-  }
   ctx->replay_nblocks = nblocks;
   ctx->replay_max_arms = max_arms;
   ctx->replay_min_blksize = 1 << 30;
@@ -1025,6 +1015,16 @@ int gc_replay_prepare(gc_context* ctx, int64_t nblocks, const gc_block* blocks) 
         period = 0;
         break;
       }
+  {
+    std::vector<gc_block> marked(blocks, blocks + nblocks);
+    // the band the kernel that may take the list tests in: 8e-6 samples of ramp = twice the 4e-6 of corr_fast.hip and corr_multi.hip
+    // (a list of derived-arm channels needs the wide band only where corr_cboc.hip takes it - gc_cboc_takes, the launcher's own
+    // predicate: with it on every such list the lane kernel lost its tie-free marks on ~40 % of config 3's blocks, 0.26 -> 0.22)
+    const bool cboc_list = ctx->replay_kt6 > 0 && !GC_TUNE_ENV("GC_NO_CBOC") && gc_cboc_takes(ctx, nblocks, period);
+    gc_mark_tie_free(ctx, marked.data(), nblocks, (ctx->replay_kt > 0 || cboc_list || ctx->replay_fast > 0) ? 8e-6 : 0.0);
+    GC_HIP(hipMemcpyAsync(ctx->d_replay_blocks, marked.data(), sizeof(gc_block) * (size_t)nblocks, hipMemcpyHostToDevice, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+  }
   ctx->replay_period = period;
   return GC_OK;
 }

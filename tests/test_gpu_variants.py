@@ -288,16 +288,8 @@ def test_multi_transition_kernel_equals_the_other_kernels_and_the_oracle(engine,
         assert np.max(np.abs(got[k, :arms] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :arms] - ref)) / scale[k])
 
 
-@pytest.mark.tuning
-@pytest.mark.parametrize("case", ["e1_cboc", "e1_cboc_qi", "b1c_wb"])
-def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, monkeypatch, case):
-    """corr_cboc.hip: periodic replay lists of three-arm channels whose third arm is the six-fold replica of the second (Galileo E1-C
-    CBOC as BASELINE config 3 words it; BDS/B1C/include/WB_tracking.m:285-317,338-369): the BOC(1,1) arms through the transition
-    formulation, the BOC(6,1) arm as a per-sample sign on the carrier-wiped samples.  The same list through the lane kernel's
-    derived-arm instantiation (without GC_CBOC) and, block by block, through the float64 oracle (every index from ceil(t) / ceil(6 t));
-    blocks that start on exact chip edges with the nominal rational step (tie-dense: sample 0 sits on an edge of all three tables of
-    the prompt tap) included, and the whole list once more with no block marked tie-free (GC_NO_TIE_MARK: every chunk takes the
-    in-kernel tests)."""
+def _hybrid_list(engine, case):
+    """A periodic replay list of three channels with a derived six-fold arm, prepared on `engine`: (blocks, descriptors, tables, record, cfg)."""
     cfg = {"e1_cboc": dict(fs=18e6, L=4092, rate=1.023e6, d=0.05, layout="iq"),
            "e1_cboc_qi": dict(fs=18e6, L=4092, rate=1.023e6, d=0.05, layout="qi"),
            "b1c_wb": dict(fs=18e6, L=10230, rate=1.023e6, d=0.06, layout="iq")}[case]
@@ -333,16 +325,30 @@ def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, monkey
                    f=float(rng.uniform(-2.5e4, 2.5e4)), phi=float(rng.uniform(-3, 3)))
         descs.append(dsc)
         _block(b, k, **dsc)
-    monkeypatch.setenv("GC_CBOC", "1")                         # opt-in: the kernel measured slower than the lane kernel
+    return b, descs, tabs, iq, cfg
+
+
+@pytest.mark.parametrize("case", ["e1_cboc", "e1_cboc_qi", "b1c_wb"])
+def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, case):
+    """corr_cboc.hip: periodic replay lists of three-arm channels whose third arm is the six-fold replica of the second (Galileo E1-C
+    CBOC as BASELINE config 3 words it; BDS/B1C/include/WB_tracking.m:285-317,338-369): the BOC(1,1) arms through the transition
+    formulation, the BOC(6,1) arm as a per-sample sign on the carrier-wiped samples.  The kernel takes such lists from two epochs per
+    CU on (gc_cboc_takes).  The same list through the lane kernel's derived-arm instantiation (gc_force_generic_kernel) and, block by
+    block, through the float64 oracle (every index from ceil(t) / ceil(6 t)); blocks that start on exact chip edges with the nominal
+    rational step (tie-dense: sample 0 sits on an edge of all three tables of the prompt tap) included."""
+    b, descs, tabs, iq, cfg = _hybrid_list(engine, case)
+    fs, L, R, period, nb = cfg["fs"], float(cfg["L"]), 2.0, 3, len(descs)
     engine.replay_prepare(b)
     engine.replay_launch()
     got = engine.replay_fetch().copy()
     assert engine.last_kernel() == 5, engine.last_kernel()
-    monkeypatch.delenv("GC_CBOC")
-    engine.replay_launch()
-    other = engine.replay_fetch().copy()
-    assert engine.last_kernel() == 0
-    monkeypatch.setenv("GC_CBOC", "1")
+    engine.force_generic_kernel(True)
+    try:
+        engine.replay_launch()
+        other = engine.replay_fetch().copy()
+        assert engine.last_kernel() == 0
+    finally:
+        engine.force_generic_kernel(False)
     raw_all = iq.astype(np.float64)
     scale = np.array([np.sum(np.abs(raw_all[2 * d_["s0"]:2 * (d_["s0"] + d_["n"])])) for d_ in descs])
     dev = np.max(np.abs(got - other).reshape(nb, -1), axis=1) / scale
@@ -354,11 +360,42 @@ def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, monkey
         ref, _, _ = O.correlate_block(raw, tabs[d_["channel"]], d_["rem"], d_["step"], d_["d"], d_["f"], d_["phi"], fs, L, r=R,
                                       arm_mult=[1.0, 1.0, 6.0])
         assert np.max(np.abs(got[k, :3] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :3] - ref)) / scale[k])
-    # no host marks: every chunk runs the float position test and the integer test of the six-fold edges
+    # a list too short for the kernel (under two epochs per CU) stays on the lane kernel
+    few = engine.make_blocks(2 * period)
+    for k in range(2 * period):
+        _block(few, k, **descs[k])
+    engine.replay_prepare(few)
+    engine.replay_launch()
+    short = engine.replay_fetch().copy()
+    assert engine.last_kernel() == 0
+    assert np.max(np.abs(short - got[:2 * period]).reshape(2 * period, -1), axis=1).max() < 2 * TOL * scale[:2 * period].max()
+
+
+@pytest.mark.tuning
+@pytest.mark.parametrize("case", ["e1_cboc", "b1c_wb"])
+def test_hybrid_cboc_kernel_without_the_host_tie_marks_and_switched_off(engine, monkeypatch, case):
+    """The whole list once more with no block marked tie-free (GC_NO_TIE_MARK: every chunk takes the in-kernel float position test
+    and the integer test of the six-fold edges), and with GC_NO_CBOC=1: the lane kernel, prepared with its own narrow tie band."""
+    b, descs, tabs, iq, cfg = _hybrid_list(engine, case)
+    nb = len(descs)
+    engine.replay_prepare(b)
+    engine.replay_launch()
+    got = engine.replay_fetch().copy()
+    assert engine.last_kernel() == 5
+    raw_all = iq.astype(np.float64)
+    scale = np.array([np.sum(np.abs(raw_all[2 * d_["s0"]:2 * (d_["s0"] + d_["n"])])) for d_ in descs])
     monkeypatch.setenv("GC_NO_TIE_MARK", "1")
     engine.replay_prepare(b)
     engine.replay_launch()
     unmarked = engine.replay_fetch().copy()
     assert engine.last_kernel() == 5
     dev = np.max(np.abs(got - unmarked).reshape(nb, -1), axis=1) / scale
+    assert dev.max() < 2 * TOL, (case, int(np.argmax(dev)), dev.max())
+    monkeypatch.delenv("GC_NO_TIE_MARK")
+    monkeypatch.setenv("GC_NO_CBOC", "1")
+    engine.replay_prepare(b)
+    engine.replay_launch()
+    lane = engine.replay_fetch().copy()
+    assert engine.last_kernel() == 0
+    dev = np.max(np.abs(got - lane).reshape(nb, -1), axis=1) / scale
     assert dev.max() < 2 * TOL, (case, int(np.argmax(dev)), dev.max())
