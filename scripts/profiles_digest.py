@@ -60,7 +60,7 @@ for s in ("l5", "b2a", "cboc", "e1x8", "e1", "b1c", "b1i", "l1ca3"):
         if m:
             d = eval(m.group(0))
             kn = d["kernel"]
-            shapes.append((s, "corr_epl_multi_kernel" if "multi" in kn else "corr_epl_lane_kernel" if "lane" in kn else "corr_epl_fast_kernel", None, d))
+            shapes.append((s, "corr_epl_cboc_kernel" if "cboc" in kn else "corr_epl_multi_kernel" if "multi" in kn else "corr_epl_lane_kernel" if "lane" in kn else "corr_epl_fast_kernel", None, d))
 lines.append("| workload | replay kernel (grid) | launches | avg ms (profiler) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes / launch | VALU instr per channel-sample | LDS instr per channel-sample | VALU-active share of wave cycles | instruction-wait share of wave cycles |")
 lines.append("|---|---|---|---|---|---|---|---|---|---|---|")
 for name, want, blocks, d in shapes:
