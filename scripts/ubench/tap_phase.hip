@@ -6,6 +6,7 @@
 //   D  B + six ds_read2st64_b32 and their s_waitcnt at the end of the phase (the transition rows)
 //   F / G  A + 16 writes, in two bursts of eight / two after every second sample;  H / I  32 writes, two after every sample (m0 set
 //      each time / once): does spreading the writes let the VALU keep its rate?
+//   J  the 32 dwords as 16 ds_write2st64_b32 (one address register, the same rows);  K  as 16 ds_write_b64 (rows of [lane][re, im])
 //   E  A with the and_or / add of each sample replaced by fma (all 64 at the double rate: the issue ceiling)
 // at 1, 2, 3, 4 waves per SIMD.  Answers whether the kernel's 4.4 cycles per VALU instruction at four waves per SIMD is the LDS
 // instructions' doing.   Build: hipcc --offload-arch=gfx950 -O3 tap_phase.hip -o tap_phase ; run on the GPU box.
@@ -21,6 +22,8 @@
 #define W2 "s_mov_b32 m0, %10\n s_nop 0\n ds_write_addtid_b32 %0 offset:0\n ds_write_addtid_b32 %1 offset:0x100\n"
 #define W2N "ds_write_addtid_b32 %0 offset:0x200\n ds_write_addtid_b32 %1 offset:0x300\n"
 #define S2(n0, n1) "v_and_or_b32 %4, %2, %3, 1.0\n v_add_u32 %2, %2, %5\n v_fma_f32 %0, %4, %" #n0 ", %0\n v_fma_f32 %1, %4, %" #n1 ", %1\n"
+#define X2(o0, o1) "ds_write2st64_b32 %11, %0, %1 offset0:" #o0 " offset1:" #o1 "\n"
+#define X64(o) "ds_write_b64 %11, %13 offset:" #o "\n"
 #define W128 "ds_write_b128 %11, %12 offset:0\n ds_write_b128 %11, %12 offset:0x400\n"
 #define R6 "ds_read2st64_b32 %13, %11 offset1:1\n ds_read2st64_b32 %14, %11 offset0:2 offset1:3\n ds_read2st64_b32 %15, %11 offset0:4 offset1:5\n ds_read2st64_b32 %13, %11 offset0:6 offset1:7\n ds_read2st64_b32 %14, %11 offset0:8 offset1:9\n ds_read2st64_b32 %15, %11 offset0:10 offset1:11\n s_waitcnt lgkmcnt(0)\n"
 #define OPS : "+v"(sr), "+v"(si), "+v"(w), "+s"(mask), "+v"(sg), "+v"(step), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+s"(m0v), "+v"(addr), "+v"(q), "+v"(r0), "+v"(r1), "+v"(r2)::"memory"
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
   extern __shared__ float lds[];
   float sr = seed, si = seed + 1, sg = 1.f, y0 = seed + threadIdx.x, y1 = y0 + 1, y2 = y0 + 2, y3 = y0 + 3;
   unsigned int w = threadIdx.x * 2654435761u, step = 0x4e5e0a73u, mask = 0x80000000u;
-  unsigned int m0v = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 8192u), addr = (threadIdx.x & 63) * 16u + (threadIdx.x >> 6) * 8192u;
+  unsigned int m0v = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 8192u), addr = (threadIdx.x & 63) * (V == 9 ? 4u : V == 10 ? 8u : 16u) + (threadIdx.x >> 6) * 8192u;
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   f4 q = {y0, y1, y2, y3};
@@ -46,6 +49,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     if (V == 6) asm volatile(S4(6, 7, 8, 9) W2 S4(7, 8, 9, 6) W2 S4(8, 9, 6, 7) W2 S4(9, 6, 7, 8) W2 S4(6, 7, 8, 9) W2 S4(7, 8, 9, 6) W2 S4(8, 9, 6, 7) W2 S4(9, 6, 7, 8) W2 OPS);
     if (V == 7) asm volatile(S2(6, 7) W2 S2(8, 9) W2 S2(7, 8) W2 S2(9, 6) W2 S2(8, 9) W2 S2(6, 7) W2 S2(9, 6) W2 S2(7, 8) W2 S2(6, 7) W2 S2(8, 9) W2 S2(7, 8) W2 S2(9, 6) W2 S2(8, 9) W2 S2(6, 7) W2 S2(9, 6) W2 S2(7, 8) W2 OPS);
     if (V == 8) asm volatile("s_mov_b32 m0, %10\n s_nop 0\n" S2(6, 7) W2N S2(8, 9) W2N S2(7, 8) W2N S2(9, 6) W2N S2(8, 9) W2N S2(6, 7) W2N S2(9, 6) W2N S2(7, 8) W2N S2(6, 7) W2N S2(8, 9) W2N S2(7, 8) W2N S2(9, 6) W2N S2(8, 9) W2N S2(6, 7) W2N S2(9, 6) W2N S2(7, 8) W2N OPS);
+    if (V == 9) asm volatile(S2(6, 7) X2(0, 1) S2(8, 9) X2(2, 3) S2(7, 8) X2(4, 5) S2(9, 6) X2(6, 7) S2(8, 9) X2(8, 9) S2(6, 7) X2(10, 11) S2(9, 6) X2(12, 13) S2(7, 8) X2(14, 15) S2(6, 7) X2(16, 17) S2(8, 9) X2(18, 19) S2(7, 8) X2(20, 21) S2(9, 6) X2(22, 23) S2(8, 9) X2(24, 25) S2(6, 7) X2(26, 27) S2(9, 6) X2(28, 29) S2(7, 8) X2(30, 31) OPS);
+    if (V == 10) asm volatile(S2(6, 7) X64(0) S2(8, 9) X64(512) S2(7, 8) X64(1024) S2(9, 6) X64(1536) S2(8, 9) X64(2048) S2(6, 7) X64(2560) S2(9, 6) X64(3072) S2(7, 8) X64(3584) S2(6, 7) X64(4096) S2(8, 9) X64(4608) S2(7, 8) X64(5120) S2(9, 6) X64(5632) S2(8, 9) X64(6144) S2(6, 7) X64(6656) S2(9, 6) X64(7168) S2(7, 8) X64(7680) OPS);
     if (V == 4) asm volatile(F4(6, 7, 8, 9) F4(7, 8, 9, 6) F4(8, 9, 6, 7) F4(9, 6, 7, 8) F4(6, 7, 8, 9) F4(7, 8, 9, 6) F4(8, 9, 6, 7) F4(9, 6, 7, 8) OPS);
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = sr + si + sg + (float)w + r0.x + r1.x + r2.x + lds[(threadIdx.x * 7) & 255];
@@ -83,6 +88,8 @@ int main() {
     run<5>("F A + 16 ds_write_addtid_b32 (2 x 8)", d, b);
     run<6>("G A + 16 ds_write_addtid_b32 (8 x 2)", d, b);
     run<7>("H A + 32 ds_write_addtid_b32 (16 x 2)", d, b);
+    run<9>("J A + 16 ds_write2st64_b32 (same rows)", d, b);
+    run<10>("K A + 16 ds_write_b64 ([lane][re, im] rows)", d, b);
     run<8>("I A + 32 ds_write_addtid_b32 (16 x 2, one m0)", d, b);
   }
   return 0;
