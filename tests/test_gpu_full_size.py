@@ -149,6 +149,20 @@ def test_config_3_eight_galileo_e1_channels_with_the_cboc_pilot_over_sixty_secon
     try:
         assert jobs[0].params.n_epochs >= 14990
         _check_jobs(P, W, jobs, 8)
+        # the whole 120 000-block list through both kernels that take it: the hybrid kernel (corr_cboc.hip, what _check_jobs replayed)
+        # and the lane kernel's derived-arm instantiation
+        j = jobs[0]
+        out = _replayed(j)
+        assert j.engine.last_kernel() == 5, j.engine.last_kernel()
+        j.engine.force_generic_kernel(True)
+        try:
+            j.engine.replay_launch()
+            lane = j.engine.replay_fetch()
+            assert j.engine.last_kernel() == 0
+        finally:
+            j.engine.force_generic_kernel(False)
+        scale = 2.0 * float(j.blks.mean()) * 28.0
+        assert np.max(np.abs(out - lane)) / scale < TOL_REPLAY, np.max(np.abs(out - lane)) / scale
     finally:
         for e in engines:
             e.close()
