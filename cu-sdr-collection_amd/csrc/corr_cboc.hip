@@ -485,8 +485,18 @@ int gc_cboc_waves(const gc_context* ctx) {
 }
 
 bool gc_cboc_takes(const gc_context* ctx, long long nblocks, int period) {
-  return ctx->scope_kt6 >= 1 && period > 0 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL && gc_cboc_waves(ctx) > 0 &&
-         nblocks >= 2LL * period * ctx->compute_units;
+  if (!(ctx->scope_kt6 >= 1 && period > 0 && ctx->if_dtype == GC_I8 && ctx->if_layout != GC_REAL)) return false;
+  const long long waves = gc_cboc_waves(ctx);
+  if (waves <= 0) return false;
+  // A wave takes one epoch and a workgroup fills a CU, so the launch runs in rounds of waves x CUs epochs and a part-filled last round
+  // costs a whole one; a single round is as long as its slowest wave (a channel's first block sits on exact chip edges and takes the
+  // float64 path chunk after chunk: ~0.2 ms more).  Measured on config 3's shape (eight channels, 1 - 10 s: lane kernel 97 ns per block;
+  // the hybrid 0.47 ms for one round, 0.255 ms per round from two on): ahead from two rounds at least two thirds full on (3 s: 0.52
+  // against 0.57 ms), up to 58 % behind below (1.5 s = 0.72 rounds: 0.47 / 0.30; 2.1 s = 1.02 rounds: 0.51 / 0.41).
+  const long long cus = ctx->compute_units;
+  const long long wgs = ((nblocks / period + waves - 1) / waves) * period;
+  const long long rounds = (wgs + cus - 1) / cus;
+  return rounds >= 2 && 3 * nblocks >= 2 * rounds * cus * waves;
 }
 
 // Periodic replay lists of int8 I/Q (Q/I) records whose channels are three-arm channels with a derived six-fold arm

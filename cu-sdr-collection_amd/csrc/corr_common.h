@@ -383,7 +383,8 @@ int gc_launch_correlator_multi(gc_context* ctx, const gcorr::KArgs& a, unsigned 
 int gc_cboc_waves(const gc_context* ctx);
 // the hybrid kernel takes a periodic replay list of `nblocks` blocks (channel pattern period `period`) of the scope just validated:
 // every channel a three-arm channel with a derived six-fold arm, base ramp with <= 2 transitions per 16-sample chunk (scope_kt6), int8
-// I/Q or Q/I record, tables + 8 KB of running sums per wave fit a CU, at least two epochs per CU
+// I/Q or Q/I record, tables + 8 KB of running sums per wave fit a CU, and the launch at least two rounds (of waves x CUs epochs), at
+// least two thirds full
 bool gc_cboc_takes(const gc_context* ctx, long long nblocks, int period);
 int gc_launch_correlator_cboc(gc_context* ctx, const gcorr::KArgs& a, unsigned int grid, int waves);
 // corr_fast.hip

@@ -298,7 +298,7 @@ def _hybrid_list(engine, case):
     rng = np.random.default_rng(abs(hash(case)) % 1000 + 23)
     period = 3
     cus = engine.device_info()[1]
-    epochs = (8 * cus + period - 1) // period + 5              # >= 8 blocks per CU: the replay launcher does not split the blocks
+    epochs = 16 * cus                                          # full rounds at 16 and 8 waves per CU, 0.8 at 12: the hybrid kernel's case (gc_cboc_takes)
     step0 = cfg["rate"] / fs
     nmax = int(np.ceil(L / (step0 * (1 - 3e-5)))) + 2
     n_if = 6 * nmax
@@ -332,8 +332,8 @@ def _hybrid_list(engine, case):
 def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, case):
     """corr_cboc.hip: periodic replay lists of three-arm channels whose third arm is the six-fold replica of the second (Galileo E1-C
     CBOC as BASELINE config 3 words it; BDS/B1C/include/WB_tracking.m:285-317,338-369): the BOC(1,1) arms through the transition
-    formulation, the BOC(6,1) arm as a per-sample sign on the carrier-wiped samples.  The kernel takes such lists from two epochs per
-    CU on (gc_cboc_takes).  The same list through the lane kernel's derived-arm instantiation (gc_force_generic_kernel) and, block by
+    formulation, the BOC(6,1) arm as a per-sample sign on the carrier-wiped samples.  The kernel takes such lists from two rounds of
+    sixteen epochs per CU, two thirds full, on (gc_cboc_takes).  The same list through the lane kernel's derived-arm instantiation (gc_force_generic_kernel) and, block by
     block, through the float64 oracle (every index from ceil(t) / ceil(6 t)); blocks that start on exact chip edges with the nominal
     rational step (tie-dense: sample 0 sits on an edge of all three tables of the prompt tap) included."""
     b, descs, tabs, iq, cfg = _hybrid_list(engine, case)
@@ -360,7 +360,7 @@ def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, case):
         ref, _, _ = O.correlate_block(raw, tabs[d_["channel"]], d_["rem"], d_["step"], d_["d"], d_["f"], d_["phi"], fs, L, r=R,
                                       arm_mult=[1.0, 1.0, 6.0])
         assert np.max(np.abs(got[k, :3] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :3] - ref)) / scale[k])
-    # a list too short for the kernel (under two epochs per CU) stays on the lane kernel
+    # a list too short for the kernel (a few blocks: its one round nearly empty) stays on the lane kernel
     few = engine.make_blocks(2 * period)
     for k in range(2 * period):
         _block(few, k, **descs[k])
