@@ -360,6 +360,14 @@ def test_hybrid_cboc_kernel_equals_the_lane_kernel_and_the_oracle(engine, case):
         ref, _, _ = O.correlate_block(raw, tabs[d_["channel"]], d_["rem"], d_["step"], d_["d"], d_["f"], d_["phi"], fs, L, r=R,
                                       arm_mult=[1.0, 1.0, 6.0])
         assert np.max(np.abs(got[k, :3] - ref)) < TOL * scale[k], (case, k, np.max(np.abs(got[k, :3] - ref)) / scale[k])
+    # 15 epochs per CU: one round at 16 waves per CU (as long as its slowest wave), 1.25 rounds at 12 (under two thirds full) - lane kernel
+    one = engine.make_blocks(period * 5 * (cus := engine.device_info()[1]))
+    for k in range(period * 5 * cus):
+        _block(one, k, **descs[k])
+    engine.replay_prepare(one)
+    engine.replay_launch()
+    engine.replay_fetch()
+    assert engine.last_kernel() == 0
     # a list too short for the kernel (a few blocks: its one round nearly empty) stays on the lane kernel
     few = engine.make_blocks(2 * period)
     for k in range(2 * period):
